@@ -1,0 +1,165 @@
+/*
+ * saccot.h — C ABI of libsaccot.so: the SAC-COT compatibility-triangle sample-consensus hot path
+ * on AMD Instinct MI355X (gfx950).
+ *
+ * What this replaces in the reference
+ * -----------------------------------
+ * The upstream tree (ytuhzq/SAC-COT) is a single file, /root/reference/README.md:1-2, which names the
+ * algorithm ("SAC-COT: Sample Consensus by Sampling Compatibility Triangles in Graphs for 3-D Point Cloud
+ * Registration") and ships no code, no FFI and no tests.  There is therefore no reference interface to
+ * cite beyond README.md:2; the boundary below is the one fixed by BASELINE.json `north_star`
+ * ("correspondence-in / (R,t,inlier-mask)-out", "thin C-ABI layer") and SURVEY.md §8(b).
+ * Every entry point says which SURVEY §8(a) row it implements.
+ *
+ * Conventions
+ * -----------
+ *  - plain C types only; no C++ exception crosses this boundary; every function returns an int status
+ *    (0 = SC_OK, negative = error) unless stated otherwise;
+ *  - "host" entry points take host pointers and do the H2D/D2H copies themselves; "_device" entry points
+ *    take device pointers (hipMalloc / torch CUDA tensors) and enqueue on the context's stream;
+ *  - a context (`sc_ctx`) is bound to ONE GPU and ONE stream (one process per GPU).  Calls on one context
+ *    must be serialised by the caller; distinct contexts are independent; there is no global mutable state;
+ *  - device workspace is owned by the context, grows on demand, is never shrunk, and is freed by
+ *    sc_destroy();  the library never keeps a caller pointer past the return of the call;
+ *  - there is NO CPU fallback in this library: without a usable HIP device sc_create() fails with SC_EHIP.
+ */
+#ifndef SACCOT_H
+#define SACCOT_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SC_VERSION_MAJOR 0
+#define SC_VERSION_MINOR 1
+
+/* status codes */
+#define SC_OK        0
+#define SC_EINVAL   -1   /* bad argument: n < 3, null pointer, non-finite input, bad params.size ...        */
+#define SC_ENOMEM   -2   /* device or host allocation failed / workspace cap exceeded                       */
+#define SC_EHIP     -3   /* HIP runtime error (sc_last_error() has the string)                              */
+#define SC_ERCCL    -4   /* reserved: collective error (the all-reduce lives in the host layer, see below)  */
+#define SC_ENOHYP   -5   /* no compatibility triangle / every inlier count is 0: R = I, t = 0, mask = 0     */
+#define SC_ETOOMANY -6   /* the graph has more triangles than the workspace cap can rank (see max_workspace)*/
+
+/* point layouts for `src` / `tgt` */
+#define SC_AOS 0   /* N x 3 row-major: x0 y0 z0 x1 y1 z1 ...                                   */
+#define SC_SOA 1   /* 3 planes of N: x[0..N) y[0..N) z[0..N)  (a MATLAB N x 3 column-major array) */
+
+/* triangle ranking */
+#define SC_RANK_WEIGHT 0   /* w = (s_ij + s_ik) + s_jk, fp32, descending                     */
+#define SC_RANK_DEGREE 1   /* deg_i + deg_j + deg_k, u32, descending                         */
+
+/* flags */
+#define SC_FLAG_TIMING  1u  /* record a HIP event pair around every stage and fill sc_stats.us_*      */
+
+typedef struct sc_ctx sc_ctx;
+
+/* All tunables of the path (SURVEY §8a `sc_params`).  POD; `size` must be sizeof(sc_params). */
+typedef struct sc_params {
+  uint32_t size;            /* = sizeof(sc_params); versioning                                          */
+  float    sigma;           /* rigidity scale: s_ij = exp(-d^2 / (2 sigma^2)), d = | |pi-pj| - |qi-qj| | */
+  float    t_cmp;           /* edge iff s_ij >= t_cmp  <=>  d <= sigma*sqrt(-2 ln t_cmp); in (0,1)       */
+  float    tau;             /* inlier distance: |R p + t - q| < tau                                     */
+  float    min_len;         /* edge additionally needs |pi-pj| >= min_len and |qi-qj| >= min_len        */
+  uint32_t max_triangles;   /* T: hypotheses scored = top-T ranked compatibility triangles              */
+  int32_t  rank_mode;       /* SC_RANK_WEIGHT / SC_RANK_DEGREE                                          */
+  int32_t  layout;          /* SC_AOS / SC_SOA                                                          */
+  int32_t  shard_rank;      /* this GPU's rank in [0, shard_world)                                      */
+  int32_t  shard_world;     /* number of GPUs sharing the T hypotheses (1 = no sharding)                */
+  uint32_t shard_block;     /* ranked triangles are dealt round-robin in blocks of this many (0 -> 1024) */
+  uint32_t flags;           /* SC_FLAG_*                                                                */
+  uint64_t max_workspace;   /* cap in bytes on the device workspace (0 -> 64 GiB)                       */
+} sc_params;
+
+/* Per-call statistics (all optional: pass NULL).  Times are device times from HIP events on the
+ * context's stream and are only filled when SC_FLAG_TIMING is set. */
+typedef struct sc_stats {
+  uint32_t size;            /* = sizeof(sc_stats)                                                       */
+  uint32_t n;               /* correspondences                                                          */
+  uint64_t edges;           /* undirected edges of the compatibility graph                              */
+  uint64_t tri_total;       /* 3-cliques in the graph                                                   */
+  uint32_t tri_kept;        /* T_eff = min(T, tri_total)                                                */
+  uint32_t tri_scored;      /* hypotheses scored by THIS rank                                           */
+  uint32_t best_rank;       /* rank index (0-based) of the winning triangle in the ranked list          */
+  uint32_t best_count;      /* its inlier count                                                         */
+  float    us_compat;       /* stage A                                                                  */
+  float    us_triangles;    /* stage B                                                                  */
+  float    us_kabsch;       /* stage C1                                                                 */
+  float    us_score;        /* stage C2 (incl. the partial-count reduction and arg-max)                 */
+  float    us_mask;         /* stage C3                                                                 */
+  float    us_total;        /* first kernel -> last kernel of the call                                  */
+  uint64_t workspace_bytes; /* device bytes currently held by the context                               */
+} sc_stats;
+
+/* ---- library ---------------------------------------------------------------------------------- */
+int         sc_version(void);                 /* (major << 16) | minor                               */
+const char* sc_strerror(int status);          /* static string, never NULL                           */
+void        sc_default_params(sc_params* p);  /* size set, sigma = tau = min_len = 0.1, t_cmp = 0.9,
+                                                 T = 50000, weight ranking, AOS, no sharding          */
+
+/* ---- context ---------------------------------------------------------------------------------- */
+int         sc_create(int device, sc_ctx** out);      /* binds `device`, creates a private stream    */
+void        sc_destroy(sc_ctx* ctx);                   /* frees the workspace; NULL is a no-op        */
+int         sc_set_stream(sc_ctx* ctx, void* hip_stream); /* enqueue on a caller stream (e.g. torch's
+                                                 current stream) instead of the private one; NULL
+                                                 restores the private stream                          */
+const char* sc_last_error(const sc_ctx* ctx);          /* last HIP error text seen by this context    */
+
+/* ---- the drop-in entry point: correspondences in, (R, t, inlier mask) out ------------------------
+ * north_star: "keeping the reference's correspondence-in / (R,t,inlier-mask)-out function signature".
+ * Runs A (compat graph) -> B (ranked triangles) -> C1 (Kabsch) -> C2 (score, arg-max) -> C3 (mask) on the
+ * GPU.  src/tgt: n points each, fp32, `params->layout`; row m of src corresponds to row m of tgt.
+ * R: 3x3 row-major, t: 3, mask: n bytes (0/1), all caller-allocated HOST memory.  q ~ R p + t.
+ * Requires shard_world == 1 (multi-GPU callers use the two-phase form below). */
+int sc_register(sc_ctx* ctx, const float* src, const float* tgt, int64_t n, const sc_params* params,
+                float R[9], float t[3], uint8_t* mask, sc_stats* stats);
+
+/* Same, with every buffer already resident in HBM (d_Rt: 12 floats = R row-major then t). */
+int sc_register_device(sc_ctx* ctx, const float* d_src, const float* d_tgt, int64_t n,
+                       const sc_params* params, float* d_Rt, uint8_t* d_mask, sc_stats* stats);
+
+/* ---- two-phase form for one-process-per-GPU sharding --------------------------------
+ * Phase 1: A and B replicated, C1+C2 on this rank's blocks of the ranked list; writes this rank's best
+ * key  K = (count << 32) | (0xFFFFFFFF - global_rank_index)  to *d_key (device, 8 bytes; 0 = no
+ * hypothesis).  The caller max-reduces the key over ranks (RCCL all-reduce through torch.distributed
+ * in this repo's host layer; any transport works — it is 8 bytes).
+ * Phase 2: every rank decodes the same winner from the reduced key, re-solves its (R,t) from its own
+ * replicated ranked list and builds the mask.  Returns SC_ENOHYP when the key is 0. */
+int sc_hypothesize_device(sc_ctx* ctx, const float* d_src, const float* d_tgt, int64_t n,
+                          const sc_params* params, uint64_t* d_key, sc_stats* stats);
+int sc_finalize_device(sc_ctx* ctx, const uint64_t* d_key, float* d_Rt, uint8_t* d_mask, sc_stats* stats);
+
+/* ---- stage-level hooks (host pointers in and out) so every kernel is parity-testable alone --------
+ * All take SoA or AoS input per params->layout and run ONLY the named stage(s) on the GPU. */
+
+/* row A: S n x n fp32 row-major, bits n x ceil(n/64) u64 (bit j%64 of word j/64 of row i), deg n u32.
+ * Any output pointer may be NULL. */
+int sc_compat_host(sc_ctx* ctx, const float* src, const float* tgt, int64_t n, const sc_params* params,
+                   float* S, uint64_t* bits, uint32_t* deg);
+
+/* rows A+B: ranked top-T triangles.  tri: T x 3 u32 (i<j<k, rank order), key: T u32 (fp32 bits of w for
+ * SC_RANK_WEIGHT, the degree sum for SC_RANK_DEGREE), *t_eff = min(T, tri_total). */
+int sc_triangles_host(sc_ctx* ctx, const float* src, const float* tgt, int64_t n, const sc_params* params,
+                      uint32_t* tri, uint32_t* key, uint32_t* t_eff, uint64_t* tri_total, uint64_t* edges);
+
+/* row C1: Rt: T x 12 fp32 (R row-major, then t) for the given triangles. */
+int sc_kabsch_host(sc_ctx* ctx, const float* src, const float* tgt, int64_t n, const sc_params* params,
+                   const uint32_t* tri, uint32_t n_tri, float* Rt);
+
+/* row C2: inlier count of every hypothesis over all n correspondences, plus the arg-max key
+ * (rank index = position in Rt).  cnt may be NULL. */
+int sc_score_host(sc_ctx* ctx, const float* src, const float* tgt, int64_t n, const sc_params* params,
+                  const float* Rt, uint32_t n_hyp, uint32_t* cnt, uint64_t* key);
+
+/* row C3: mask of one hypothesis. */
+int sc_mask_host(sc_ctx* ctx, const float* src, const float* tgt, int64_t n, const sc_params* params,
+                 const float Rt[12], uint8_t* mask);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SACCOT_H */

@@ -1,0 +1,226 @@
+"""Host-side mirror of the C ABI in include/saccot.h (ctypes over libsaccot.so).
+
+The reference has no operator/plugin interface to mirror (/root/reference/README.md:1-2 is the whole tree), so the
+names follow SURVEY.md §8(b): `register()` is the drop-in entry point — correspondences in, (R, t, inlier mask)
+out — and the `compat` / `triangles` / `kabsch` / `score` / `mask` methods are the per-stage hooks the parity
+tests drive.  Everything computes on the GPU through libsaccot.so; if the library or a HIP device is missing
+this module raises — there is no CPU fallback (the CPU restatement lives in oracle/ and is test-only).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libsaccot.so")
+
+SC_OK, SC_EINVAL, SC_ENOMEM, SC_EHIP, SC_ERCCL, SC_ENOHYP, SC_ETOOMANY = 0, -1, -2, -3, -4, -5, -6
+SC_AOS, SC_SOA = 0, 1
+SC_RANK_WEIGHT, SC_RANK_DEGREE = 0, 1
+SC_FLAG_TIMING = 1
+
+EXPORTS = ["sc_version", "sc_strerror", "sc_default_params", "sc_create", "sc_destroy", "sc_set_stream",
+           "sc_last_error", "sc_register", "sc_register_device", "sc_hypothesize_device", "sc_finalize_device",
+           "sc_compat_host", "sc_triangles_host", "sc_kabsch_host", "sc_score_host", "sc_mask_host"]
+
+
+class ScParams(C.Structure):
+    _fields_ = [("size", C.c_uint32), ("sigma", C.c_float), ("t_cmp", C.c_float), ("tau", C.c_float),
+                ("min_len", C.c_float), ("max_triangles", C.c_uint32), ("rank_mode", C.c_int32),
+                ("layout", C.c_int32), ("shard_rank", C.c_int32), ("shard_world", C.c_int32),
+                ("shard_block", C.c_uint32), ("flags", C.c_uint32), ("max_workspace", C.c_uint64)]
+
+
+class ScStats(C.Structure):
+    _fields_ = [("size", C.c_uint32), ("n", C.c_uint32), ("edges", C.c_uint64), ("tri_total", C.c_uint64),
+                ("tri_kept", C.c_uint32), ("tri_scored", C.c_uint32), ("best_rank", C.c_uint32),
+                ("best_count", C.c_uint32), ("us_compat", C.c_float), ("us_triangles", C.c_float),
+                ("us_kabsch", C.c_float), ("us_score", C.c_float), ("us_mask", C.c_float), ("us_total", C.c_float),
+                ("workspace_bytes", C.c_uint64)]
+
+    def as_dict(self) -> dict:
+        return {k: getattr(self, k) for k, _ in self._fields_ if k != "size"}
+
+
+class SacCotError(RuntimeError):
+    def __init__(self, status: int, msg: str):
+        super().__init__(f"libsaccot status {status}: {msg}")
+        self.status = status
+
+
+_LIB = None
+
+
+def load_library() -> C.CDLL:
+    """dlopen libsaccot.so and declare every prototype.  Raises if it was not built (run __graft_entry__.build())."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    # One HIP runtime per process: torch bundles its own libamdhip64.so.7 (same SONAME as /opt/rocm's), and the
+    # copy that is loaded first serves every later DT_NEEDED.  torch cannot run on the system copy ("No HIP GPUs
+    # are available"), libsaccot.so runs on either — so when torch is present, let it load first.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
+    if not os.path.exists(LIB_PATH):
+        raise FileNotFoundError(f"{LIB_PATH} is missing: build it with `python __graft_entry__.py` "
+                                "(hipcc --offload-arch=gfx950); there is no CPU fallback")
+    L = C.CDLL(LIB_PATH)
+    vp, f32p, u8p, u32p, u64p = C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_uint8), C.POINTER(C.c_uint32), C.POINTER(C.c_uint64)
+    pp, sp = C.POINTER(ScParams), C.POINTER(ScStats)
+    L.sc_version.restype = C.c_int
+    L.sc_strerror.argtypes = [C.c_int]; L.sc_strerror.restype = C.c_char_p
+    L.sc_default_params.argtypes = [pp]; L.sc_default_params.restype = None
+    L.sc_create.argtypes = [C.c_int, C.POINTER(vp)]
+    L.sc_destroy.argtypes = [vp]; L.sc_destroy.restype = None
+    L.sc_set_stream.argtypes = [vp, vp]
+    L.sc_last_error.argtypes = [vp]; L.sc_last_error.restype = C.c_char_p
+    L.sc_register.argtypes = [vp, f32p, f32p, C.c_int64, pp, f32p, f32p, u8p, sp]
+    L.sc_register_device.argtypes = [vp, vp, vp, C.c_int64, pp, vp, vp, sp]
+    L.sc_hypothesize_device.argtypes = [vp, vp, vp, C.c_int64, pp, vp, sp]
+    L.sc_finalize_device.argtypes = [vp, vp, vp, vp, sp]
+    L.sc_compat_host.argtypes = [vp, f32p, f32p, C.c_int64, pp, f32p, u64p, u32p]
+    L.sc_triangles_host.argtypes = [vp, f32p, f32p, C.c_int64, pp, u32p, u32p, u32p, u64p, u64p]
+    L.sc_kabsch_host.argtypes = [vp, f32p, f32p, C.c_int64, pp, u32p, C.c_uint32, f32p]
+    L.sc_score_host.argtypes = [vp, f32p, f32p, C.c_int64, pp, f32p, C.c_uint32, u32p, u64p]
+    L.sc_mask_host.argtypes = [vp, f32p, f32p, C.c_int64, pp, f32p, u8p]
+    _LIB = L
+    return L
+
+
+def make_params(sigma=0.1, t_cmp=0.9, tau=0.1, min_len=0.1, max_triangles=50000, rank_mode=SC_RANK_WEIGHT,
+                layout=SC_AOS, shard_rank=0, shard_world=1, shard_block=1024, flags=0, max_workspace=0) -> ScParams:
+    return ScParams(C.sizeof(ScParams), sigma, t_cmp, tau, min_len, max_triangles, rank_mode, layout, shard_rank,
+                    shard_world, shard_block, flags, max_workspace)
+
+
+def _p(a, t):
+    return None if a is None else a.ctypes.data_as(C.POINTER(t))
+
+
+def _f32c(a) -> np.ndarray:
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+class Registrar:
+    """One GPU context (`sc_ctx`): one process, one GPU, one stream."""
+
+    def __init__(self, device: int = 0):
+        self._lib = load_library()
+        h = C.c_void_p()
+        rc = self._lib.sc_create(device, C.byref(h))
+        if rc != SC_OK:
+            raise SacCotError(rc, "sc_create failed (no usable HIP device? this library has no CPU fallback): "
+                              + self._lib.sc_strerror(rc).decode())
+        self._h = h
+        self.device = device
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.sc_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc: int, allow=()):
+        if rc != SC_OK and rc not in allow:
+            raise SacCotError(rc, self._lib.sc_strerror(rc).decode() + " — " + self._lib.sc_last_error(self._h).decode())
+        return rc
+
+    def set_stream(self, stream_ptr: int | None):
+        self._check(self._lib.sc_set_stream(self._h, C.c_void_p(stream_ptr or 0)))
+
+    # ---- drop-in entry point ----------------------------------------------------------------------------
+    def register(self, src, tgt, params: ScParams | None = None, **kw):
+        """(n,3) src/tgt correspondences -> dict(status, R (3,3), t (3,), mask (n,) uint8, stats)."""
+        p = params or make_params(**kw)
+        src, tgt = _f32c(src), _f32c(tgt)
+        n = src.shape[0] if p.layout == SC_AOS else src.shape[1]
+        R = np.zeros(9, np.float32); t = np.zeros(3, np.float32); mask = np.zeros(n, np.uint8)
+        st = ScStats(C.sizeof(ScStats))
+        rc = self._check(self._lib.sc_register(self._h, _p(src, C.c_float), _p(tgt, C.c_float), n, C.byref(p),
+                                               _p(R, C.c_float), _p(t, C.c_float), _p(mask, C.c_uint8), C.byref(st)),
+                         allow=(SC_ENOHYP,))
+        return dict(status=rc, R=R.reshape(3, 3), t=t, mask=mask, stats=st.as_dict())
+
+    # ---- device-resident forms (pointers are ints: torch .data_ptr()) -------------------------------------
+    def register_device(self, d_src: int, d_tgt: int, n: int, params: ScParams, d_Rt: int, d_mask: int):
+        st = ScStats(C.sizeof(ScStats))
+        rc = self._check(self._lib.sc_register_device(self._h, d_src, d_tgt, n, C.byref(params), d_Rt, d_mask,
+                                                      C.byref(st)), allow=(SC_ENOHYP,))
+        return rc, st.as_dict()
+
+    def hypothesize_device(self, d_src: int, d_tgt: int, n: int, params: ScParams, d_key: int):
+        st = ScStats(C.sizeof(ScStats))
+        self._check(self._lib.sc_hypothesize_device(self._h, d_src, d_tgt, n, C.byref(params), d_key, C.byref(st)))
+        return st.as_dict()
+
+    def finalize_device(self, d_key: int, d_Rt: int, d_mask: int):
+        st = ScStats(C.sizeof(ScStats))
+        rc = self._check(self._lib.sc_finalize_device(self._h, d_key, d_Rt, d_mask, C.byref(st)), allow=(SC_ENOHYP,))
+        return rc, st.as_dict()
+
+    # ---- stage hooks -----------------------------------------------------------------------------------------
+    def compat(self, src, tgt, params: ScParams, want_S=True):
+        src, tgt = _f32c(src), _f32c(tgt)
+        n = src.shape[0] if params.layout == SC_AOS else src.shape[1]
+        W = (n + 63) // 64
+        S = np.empty((n, n), np.float32) if want_S else None
+        bits = np.zeros((n, W), np.uint64); deg = np.zeros(n, np.uint32)
+        self._check(self._lib.sc_compat_host(self._h, _p(src, C.c_float), _p(tgt, C.c_float), n, C.byref(params),
+                                             _p(S, C.c_float), _p(bits, C.c_uint64), _p(deg, C.c_uint32)))
+        return S, bits, deg
+
+    def triangles(self, src, tgt, params: ScParams):
+        src, tgt = _f32c(src), _f32c(tgt)
+        n = src.shape[0] if params.layout == SC_AOS else src.shape[1]
+        T = params.max_triangles
+        tri = np.zeros((T, 3), np.uint32); key = np.zeros(T, np.uint32)
+        t_eff = C.c_uint32(0); total = C.c_uint64(0); edges = C.c_uint64(0)
+        self._check(self._lib.sc_triangles_host(self._h, _p(src, C.c_float), _p(tgt, C.c_float), n, C.byref(params),
+                                                _p(tri, C.c_uint32), _p(key, C.c_uint32), C.byref(t_eff),
+                                                C.byref(total), C.byref(edges)))
+        return tri[: t_eff.value].copy(), key[: t_eff.value].copy(), int(total.value), int(edges.value)
+
+    def kabsch(self, src, tgt, params: ScParams, tri):
+        src, tgt = _f32c(src), _f32c(tgt)
+        n = src.shape[0] if params.layout == SC_AOS else src.shape[1]
+        tri = np.ascontiguousarray(tri, dtype=np.uint32)
+        Rt = np.zeros((tri.shape[0], 12), np.float32)
+        self._check(self._lib.sc_kabsch_host(self._h, _p(src, C.c_float), _p(tgt, C.c_float), n, C.byref(params),
+                                             _p(tri, C.c_uint32), tri.shape[0], _p(Rt, C.c_float)))
+        return Rt
+
+    def score(self, src, tgt, params: ScParams, Rt):
+        src, tgt = _f32c(src), _f32c(tgt)
+        n = src.shape[0] if params.layout == SC_AOS else src.shape[1]
+        Rt = _f32c(Rt)
+        cnt = np.zeros(Rt.shape[0], np.uint32); key = C.c_uint64(0)
+        self._check(self._lib.sc_score_host(self._h, _p(src, C.c_float), _p(tgt, C.c_float), n, C.byref(params),
+                                            _p(Rt, C.c_float), Rt.shape[0], _p(cnt, C.c_uint32), C.byref(key)))
+        return cnt, int(key.value)
+
+    def mask(self, src, tgt, params: ScParams, Rt12):
+        src, tgt = _f32c(src), _f32c(tgt)
+        n = src.shape[0] if params.layout == SC_AOS else src.shape[1]
+        Rt12 = _f32c(Rt12).reshape(12)
+        m = np.zeros(n, np.uint8)
+        self._check(self._lib.sc_mask_host(self._h, _p(src, C.c_float), _p(tgt, C.c_float), n, C.byref(params),
+                                           _p(Rt12, C.c_float), _p(m, C.c_uint8)))
+        return m
+
+
+def register(src, tgt, device: int = 0, **kw):
+    """One-shot convenience: create a context, run the whole path, destroy the context."""
+    r = Registrar(device)
+    try:
+        return r.register(src, tgt, **kw)
+    finally:
+        r.close()

@@ -1,0 +1,570 @@
+// sc_capi.hip — the C ABI of include/saccot.h: context, grow-only device workspace, stage sequencing.
+//
+// There is no reference interface to mirror (the reference tree is /root/reference/README.md:1-2); the
+// boundary is SURVEY.md §8(b).  Everything that computes runs on the GPU: this file only validates,
+// allocates, enqueues kernels (sc_kernels.hpp) and copies.  Two small read-backs (edge count, triangle
+// count) size the data-dependent buffers; there is no CPU fallback of any stage.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+
+#include "../../include/saccot.h"
+#include "sc_kernels.hpp"
+
+using namespace sc;
+
+namespace {
+
+struct Buf {
+  void* p = nullptr;
+  size_t cap = 0;
+  template <class T> T* as() const { return static_cast<T*>(p); }
+};
+
+constexpr int N_EVENTS = 8;
+
+}  // namespace
+
+struct sc_ctx {
+  int device = 0;
+  hipStream_t own_stream = nullptr;
+  hipStream_t stream = nullptr;
+  std::string last_error;
+  size_t held = 0;
+  uint64_t cap_bytes = 64ull << 30;
+  hipEvent_t ev[N_EVENTS] = {};
+  uint64_t* pinned = nullptr;  // 8 x u64 host-pinned read-back area
+
+  // workspace
+  Buf in_src, in_tgt, planes, S, bits, deg, degp, edge_off, scan_tmp, ei, ej, es, tcnt, toff, wkey, sel, blk_gt,
+      blk_eq, off_gt, off_eq, sel_ord, sortkey, sorted, sort_tmp, tri, trikey, rt, rt_aos, partial, cnt, key, rt12,
+      mask, flag;
+
+  // state of the last hypothesize call (consumed by finalize)
+  int n = 0, ld = 0;
+  uint64_t E = 0, M = 0;
+  uint32_t T_eff = 0;
+  Derived dv{};
+  Shard sh{};
+  bool have_hyp = false;
+  bool timing = false;
+};
+
+namespace {
+
+int fail_hip(sc_ctx* c, hipError_t e, const char* what) {
+  char buf[256];
+  snprintf(buf, sizeof buf, "%s: %s", what, hipGetErrorString(e));
+  if (c) c->last_error = buf;
+  return SC_EHIP;
+}
+
+#define HIPCHK(c, expr)                                        \
+  do {                                                         \
+    hipError_t _e = (expr);                                    \
+    if (_e != hipSuccess) return fail_hip((c), _e, #expr);     \
+  } while (0)
+
+int ensure(sc_ctx* c, Buf& b, size_t bytes) {
+  if (bytes <= b.cap) return SC_OK;
+  size_t want = bytes + bytes / 8 + 256;
+  if (c->held - b.cap + want > c->cap_bytes) {
+    want = bytes;
+    if (c->held - b.cap + want > c->cap_bytes) { c->last_error = "workspace cap exceeded"; return SC_ENOMEM; }
+  }
+  if (b.p) {
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipFree(b.p));
+    c->held -= b.cap;
+    b.p = nullptr; b.cap = 0;
+  }
+  hipError_t e = hipMalloc(&b.p, want);
+  if (e != hipSuccess) { b.p = nullptr; (void)hipGetLastError(); c->last_error = "hipMalloc failed"; return SC_ENOMEM; }
+  b.cap = want;
+  c->held += want;
+  return SC_OK;
+}
+
+#define ENSURE(c, buf, bytes)                      \
+  do {                                             \
+    int _rc = ensure((c), (buf), (bytes));         \
+    if (_rc != SC_OK) return _rc;                  \
+  } while (0)
+
+int check_params(const sc_params* p) {
+  if (!p || p->size != sizeof(sc_params)) return SC_EINVAL;
+  if (!(p->sigma > 0.f) || !(p->t_cmp > 0.f) || !(p->t_cmp < 1.f) || !(p->tau > 0.f) || !(p->min_len >= 0.f))
+    return SC_EINVAL;
+  if (!std::isfinite(p->sigma) || !std::isfinite(p->tau) || !std::isfinite(p->min_len)) return SC_EINVAL;
+  if (p->max_triangles == 0) return SC_EINVAL;
+  if (p->rank_mode != SC_RANK_WEIGHT && p->rank_mode != SC_RANK_DEGREE) return SC_EINVAL;
+  if (p->layout != SC_AOS && p->layout != SC_SOA) return SC_EINVAL;
+  if (p->shard_world < 1 || p->shard_rank < 0 || p->shard_rank >= p->shard_world) return SC_EINVAL;
+  return SC_OK;
+}
+
+// thresholds precomputed on the host in fp64, rounded once to fp32
+Derived derive(const sc_params* p) {
+  Derived d;
+  d.d_thr = (float)((double)p->sigma * std::sqrt(-2.0 * std::log((double)p->t_cmp)));
+  d.neg_inv2sig2 = (float)(-1.0 / (2.0 * (double)p->sigma * (double)p->sigma));
+  d.tau2 = (float)((double)p->tau * (double)p->tau);
+  d.min_len = p->min_len;
+  return d;
+}
+
+inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
+
+Points points_of(const sc_ctx* c) { return Points{c->planes.as<float>(), c->n, c->ld}; }
+Graph graph_of(const sc_ctx* c) {
+  return Graph{c->bits.as<uint64_t>(), c->S.as<float>(), c->deg.as<uint32_t>(), c->n, c->ld, c->ld >> 6};
+}
+
+int rec(sc_ctx* c, int i) {
+  if (c->timing) HIPCHK(c, hipEventRecord(c->ev[i], c->stream));
+  return SC_OK;
+}
+
+// user points (device) -> padded planes; zero the "non-finite" flag first
+int stage_inputs(sc_ctx* c, const float* d_src, const float* d_tgt, int64_t n, const sc_params* p) {
+  if (n < 3 || n > (1 << 24)) return SC_EINVAL;
+  c->n = (int)n;
+  c->ld = round_up((int)n, 64);
+  ENSURE(c, c->planes, (size_t)6 * c->ld * sizeof(float));
+  ENSURE(c, c->flag, 64);
+  HIPCHK(c, hipMemsetAsync(c->flag.p, 0, 64, c->stream));
+  launch_stage_points(d_src, d_tgt, c->n, c->ld, p->layout, c->planes.as<float>(), c->flag.as<uint32_t>(), c->stream);
+  return SC_OK;
+}
+
+int run_compat(sc_ctx* c) {
+  const size_t n = c->n, ld = c->ld, W = ld >> 6;
+  ENSURE(c, c->S, n * ld * sizeof(float));
+  ENSURE(c, c->bits, n * W * sizeof(uint64_t));
+  ENSURE(c, c->deg, n * sizeof(uint32_t));
+  ENSURE(c, c->degp, n * sizeof(uint32_t));
+  launch_compat(points_of(c), c->dv, c->S.as<float>(), c->bits.as<uint64_t>(), c->deg.as<uint32_t>(),
+                c->degp.as<uint32_t>(), c->stream);
+  return SC_OK;
+}
+
+// stage B; on return c->E, c->M, c->T_eff are set and tri/trikey hold the ranked list
+int run_triangles(sc_ctx* c, const sc_params* p) {
+  const size_t n = c->n;
+  hipStream_t st = c->stream;
+  ENSURE(c, c->edge_off, (n + 1) * sizeof(uint64_t));
+  ENSURE(c, c->scan_tmp, scan_temp_bytes(n));
+  launch_scan_u32(c->degp.as<uint32_t>(), n, c->edge_off.as<uint64_t>(), c->scan_tmp.p, st);
+  // read-back #1: edge count + the non-finite flag
+  HIPCHK(c, hipMemcpyAsync(&c->pinned[0], c->edge_off.as<uint64_t>() + n, 8, hipMemcpyDeviceToHost, st));
+  HIPCHK(c, hipMemcpyAsync(&c->pinned[1], c->flag.p, 4, hipMemcpyDeviceToHost, st));
+  HIPCHK(c, hipStreamSynchronize(st));
+  if ((uint32_t)c->pinned[1] != 0) { c->last_error = "non-finite input coordinate"; return SC_EINVAL; }
+  const uint64_t E = c->E = c->pinned[0];
+  c->M = 0; c->T_eff = 0;
+  if (E == 0) return SC_OK;
+  ENSURE(c, c->ei, E * 4);
+  ENSURE(c, c->ej, E * 4);
+  ENSURE(c, c->es, E * 4);
+  ENSURE(c, c->tcnt, E * 4);
+  ENSURE(c, c->toff, (E + 1) * 8);
+  ENSURE(c, c->scan_tmp, scan_temp_bytes(E));
+  const Graph g = graph_of(c);
+  launch_edge_fill(g, c->edge_off.as<uint64_t>(), c->ei.as<uint32_t>(), c->ej.as<uint32_t>(), c->es.as<float>(), st);
+  launch_tri_count(g, c->ei.as<uint32_t>(), c->ej.as<uint32_t>(), E, c->tcnt.as<uint32_t>(), st);
+  launch_scan_u32(c->tcnt.as<uint32_t>(), E, c->toff.as<uint64_t>(), c->scan_tmp.p, st);
+  // read-back #2: triangle count
+  HIPCHK(c, hipMemcpyAsync(&c->pinned[2], c->toff.as<uint64_t>() + E, 8, hipMemcpyDeviceToHost, st));
+  HIPCHK(c, hipStreamSynchronize(st));
+  const uint64_t M = c->M = c->pinned[2];
+  if (M == 0) return SC_OK;
+  const uint32_t T_eff = c->T_eff = (uint32_t)(M < p->max_triangles ? M : p->max_triangles);
+  if (M * 4 > c->cap_bytes) { c->last_error = "triangle keys exceed the workspace cap"; return SC_ETOOMANY; }
+  const size_t nb = compact_blocks(M);
+  ENSURE(c, c->wkey, M * 4);
+  ENSURE(c, c->sel, sizeof(SelectState));
+  ENSURE(c, c->blk_gt, nb * 4);
+  ENSURE(c, c->blk_eq, nb * 4);
+  ENSURE(c, c->off_gt, (nb + 1) * 8);
+  ENSURE(c, c->off_eq, (nb + 1) * 8);
+  ENSURE(c, c->scan_tmp, scan_temp_bytes(nb));
+  ENSURE(c, c->sel_ord, (size_t)T_eff * 8);
+  ENSURE(c, c->sortkey, (size_t)T_eff * 8);
+  ENSURE(c, c->sorted, (size_t)T_eff * 8);
+  const size_t sort_bytes = sort_temp_bytes(T_eff);
+  ENSURE(c, c->sort_tmp, sort_bytes + 16);
+  ENSURE(c, c->tri, (size_t)T_eff * 12);
+  ENSURE(c, c->trikey, (size_t)T_eff * 4);
+  SelectState* sel = c->sel.as<SelectState>();
+  launch_select_init(sel, T_eff, st);
+  launch_tri_keys(g, c->edge_off.as<uint64_t>(), c->ei.as<uint32_t>(), c->ej.as<uint32_t>(), c->es.as<float>(),
+                  c->toff.as<uint64_t>(), E, p->rank_mode, c->wkey.as<uint32_t>(), sel, st);
+  launch_select_rounds(c->wkey.as<uint32_t>(), M, sel, st);
+  launch_compact_count(c->wkey.as<uint32_t>(), M, sel, c->blk_gt.as<uint32_t>(), c->blk_eq.as<uint32_t>(), st);
+  launch_scan_u32(c->blk_gt.as<uint32_t>(), nb, c->off_gt.as<uint64_t>(), c->scan_tmp.p, st);
+  launch_scan_u32(c->blk_eq.as<uint32_t>(), nb, c->off_eq.as<uint64_t>(), c->scan_tmp.p, st);
+  launch_compact_write(c->wkey.as<uint32_t>(), M, sel, c->off_gt.as<uint64_t>(), c->off_eq.as<uint64_t>(),
+                       c->sel_ord.as<uint64_t>(), c->sortkey.as<uint64_t>(), st);
+  launch_sort_u64(c->sortkey.as<uint64_t>(), c->sorted.as<uint64_t>(), T_eff, c->sort_tmp.p, sort_bytes, st);
+  launch_tri_decode(g, c->ei.as<uint32_t>(), c->ej.as<uint32_t>(), c->toff.as<uint64_t>(), E,
+                    c->sorted.as<uint64_t>(), c->sel_ord.as<uint64_t>(), T_eff, c->tri.as<uint32_t>(),
+                    c->trikey.as<uint32_t>(), st);
+  return SC_OK;
+}
+
+void fill_stats(const sc_ctx* c, sc_stats* s) {
+  if (!s) return;
+  const uint32_t sz = s->size;
+  if (sz != sizeof(sc_stats)) return;
+  s->n = (uint32_t)c->n;
+  s->edges = c->E;
+  s->tri_total = c->M;
+  s->tri_kept = c->T_eff;
+  s->tri_scored = c->sh.n_local;
+  s->workspace_bytes = c->held;
+}
+
+float ev_us(sc_ctx* c, int a, int b) {
+  float ms = 0.f;
+  if (hipEventElapsedTime(&ms, c->ev[a], c->ev[b]) != hipSuccess) { (void)hipGetLastError(); return 0.f; }
+  return ms * 1000.f;
+}
+
+int host_to_planes(sc_ctx* c, const float* src, const float* tgt, int64_t n, const sc_params* p) {
+  if (!src || !tgt || n < 3 || n > (1 << 24)) return SC_EINVAL;
+  ENSURE(c, c->in_src, (size_t)n * 12);
+  ENSURE(c, c->in_tgt, (size_t)n * 12);
+  HIPCHK(c, hipMemcpyAsync(c->in_src.p, src, (size_t)n * 12, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(c->in_tgt.p, tgt, (size_t)n * 12, hipMemcpyHostToDevice, c->stream));
+  return stage_inputs(c, c->in_src.as<float>(), c->in_tgt.as<float>(), n, p);
+}
+
+int check_flag(sc_ctx* c) {
+  HIPCHK(c, hipMemcpyAsync(&c->pinned[1], c->flag.p, 4, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  if ((uint32_t)c->pinned[1] != 0) { c->last_error = "non-finite input coordinate"; return SC_EINVAL; }
+  return SC_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int sc_version(void) { return (SC_VERSION_MAJOR << 16) | SC_VERSION_MINOR; }
+
+const char* sc_strerror(int status) {
+  switch (status) {
+    case SC_OK: return "ok";
+    case SC_EINVAL: return "invalid argument";
+    case SC_ENOMEM: return "out of memory or workspace cap exceeded";
+    case SC_EHIP: return "HIP runtime error";
+    case SC_ERCCL: return "collective error";
+    case SC_ENOHYP: return "no hypothesis: the compatibility graph has no triangle with an inlier";
+    case SC_ETOOMANY: return "too many triangles for the workspace cap";
+    default: return "unknown status";
+  }
+}
+
+void sc_default_params(sc_params* p) {
+  if (!p) return;
+  memset(p, 0, sizeof *p);
+  p->size = sizeof(sc_params);
+  p->sigma = 0.1f; p->t_cmp = 0.9f; p->tau = 0.1f; p->min_len = 0.1f;
+  p->max_triangles = 50000;
+  p->rank_mode = SC_RANK_WEIGHT;
+  p->layout = SC_AOS;
+  p->shard_rank = 0; p->shard_world = 1; p->shard_block = 1024;
+  p->flags = 0; p->max_workspace = 0;
+}
+
+int sc_create(int device, sc_ctx** out) {
+  if (!out) return SC_EINVAL;
+  *out = nullptr;
+  int count = 0;
+  hipError_t e = hipGetDeviceCount(&count);
+  if (e != hipSuccess || count <= 0) { (void)hipGetLastError(); return SC_EHIP; }  // no GPU: fail loudly
+  if (device < 0 || device >= count) return SC_EINVAL;
+  sc_ctx* c = new (std::nothrow) sc_ctx();
+  if (!c) return SC_ENOMEM;
+  c->device = device;
+  if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess) {
+    delete c;
+    return SC_EHIP;
+  }
+  c->stream = c->own_stream;
+  for (int i = 0; i < N_EVENTS; i++)
+    if (hipEventCreate(&c->ev[i]) != hipSuccess) { sc_destroy(c); return SC_EHIP; }
+  if (hipHostMalloc((void**)&c->pinned, 8 * sizeof(uint64_t), hipHostMallocDefault) != hipSuccess) {
+    sc_destroy(c);
+    return SC_EHIP;
+  }
+  *out = c;
+  return SC_OK;
+}
+
+void sc_destroy(sc_ctx* c) {
+  if (!c) return;
+  (void)hipSetDevice(c->device);
+  if (c->stream) (void)hipStreamSynchronize(c->stream);
+  Buf* bufs[] = {&c->in_src, &c->in_tgt, &c->planes, &c->S, &c->bits, &c->deg, &c->degp, &c->edge_off, &c->scan_tmp,
+                 &c->ei, &c->ej, &c->es, &c->tcnt, &c->toff, &c->wkey, &c->sel, &c->blk_gt, &c->blk_eq, &c->off_gt,
+                 &c->off_eq, &c->sel_ord, &c->sortkey, &c->sorted, &c->sort_tmp, &c->tri, &c->trikey, &c->rt,
+                 &c->rt_aos, &c->partial, &c->cnt, &c->key, &c->rt12, &c->mask, &c->flag};
+  for (Buf* b : bufs) if (b->p) (void)hipFree(b->p);
+  for (int i = 0; i < N_EVENTS; i++) if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
+  if (c->pinned) (void)hipHostFree(c->pinned);
+  if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
+  delete c;
+}
+
+int sc_set_stream(sc_ctx* c, void* hip_stream) {
+  if (!c) return SC_EINVAL;
+  (void)hipSetDevice(c->device);
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  c->stream = hip_stream ? static_cast<hipStream_t>(hip_stream) : c->own_stream;
+  return SC_OK;
+}
+
+const char* sc_last_error(const sc_ctx* c) { return c ? c->last_error.c_str() : "null context"; }
+
+int sc_hypothesize_device(sc_ctx* c, const float* d_src, const float* d_tgt, int64_t n, const sc_params* p,
+                          uint64_t* d_key, sc_stats* stats) {
+  if (!c || !d_src || !d_tgt || !d_key) return SC_EINVAL;
+  int rc = check_params(p);
+  if (rc) return rc;
+  HIPCHK(c, hipSetDevice(c->device));
+  c->have_hyp = false;
+  c->timing = (p->flags & SC_FLAG_TIMING) != 0;
+  c->cap_bytes = p->max_workspace ? p->max_workspace : (64ull << 30);
+  c->dv = derive(p);
+  if ((rc = rec(c, 0))) return rc;
+  if ((rc = stage_inputs(c, d_src, d_tgt, n, p))) return rc;
+  if ((rc = run_compat(c))) return rc;
+  if ((rc = rec(c, 1))) return rc;
+  if ((rc = run_triangles(c, p))) return rc;
+  if ((rc = rec(c, 2))) return rc;
+  // stage C on this rank's share of the ranked list
+  Shard sh;
+  sh.T_eff = c->T_eff;
+  sh.block = p->shard_block ? p->shard_block : 1024u;
+  sh.rank = (uint32_t)p->shard_rank;
+  sh.world = (uint32_t)p->shard_world;
+  sh.n_local = shard_local_count(sh.T_eff, sh.block, sh.rank, sh.world);
+  sh.ld_local = (uint32_t)round_up((int)sh.n_local, 256);
+  c->sh = sh;
+  if (sh.n_local) {
+    ENSURE(c, c->rt, (size_t)12 * sh.ld_local * 4);
+    ENSURE(c, c->partial, (size_t)score_chunks(c->n) * sh.ld_local * 4);
+    launch_kabsch(points_of(c), c->tri.as<uint32_t>(), sh, c->rt.as<float>(), c->stream);
+  }
+  if ((rc = rec(c, 3))) return rc;
+  launch_score(points_of(c), c->rt.as<float>(), sh, c->dv.tau2, c->partial.as<uint32_t>(), nullptr, d_key, c->stream);
+  if ((rc = rec(c, 4))) return rc;
+  HIPCHK(c, hipGetLastError());
+  c->have_hyp = true;
+  if (stats && stats->size == sizeof(sc_stats)) {
+    fill_stats(c, stats);
+    if (c->timing) {
+      HIPCHK(c, hipStreamSynchronize(c->stream));
+      // A's interval includes input staging; B's includes its two read-backs
+      stats->us_compat = ev_us(c, 0, 1);
+      stats->us_triangles = ev_us(c, 1, 2);
+      stats->us_kabsch = ev_us(c, 2, 3);
+      stats->us_score = ev_us(c, 3, 4);
+      stats->us_total = ev_us(c, 0, 4);
+    }
+  }
+  return SC_OK;
+}
+
+int sc_finalize_device(sc_ctx* c, const uint64_t* d_key, float* d_Rt, uint8_t* d_mask, sc_stats* stats) {
+  if (!c || !d_key || !d_Rt || !d_mask) return SC_EINVAL;
+  if (!c->have_hyp) { c->last_error = "sc_finalize_device without a preceding sc_hypothesize_device"; return SC_EINVAL; }
+  HIPCHK(c, hipSetDevice(c->device));
+  int rc;
+  if ((rc = rec(c, 5))) return rc;
+  launch_finalize(points_of(c), c->tri.as<uint32_t>(), d_key, c->dv.tau2, d_Rt, d_mask, c->stream);
+  if ((rc = rec(c, 6))) return rc;
+  HIPCHK(c, hipMemcpyAsync(&c->pinned[3], d_key, 8, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  HIPCHK(c, hipGetLastError());
+  const uint64_t key = c->pinned[3];
+  if (stats && stats->size == sizeof(sc_stats)) {
+    fill_stats(c, stats);
+    stats->best_count = (uint32_t)(key >> 32);
+    stats->best_rank = key ? 0xFFFFFFFFu - (uint32_t)(key & 0xFFFFFFFFull) : 0u;
+    if (c->timing) {
+      stats->us_mask = ev_us(c, 5, 6);
+      stats->us_total += stats->us_mask;
+    }
+  }
+  return key ? SC_OK : SC_ENOHYP;
+}
+
+int sc_register_device(sc_ctx* c, const float* d_src, const float* d_tgt, int64_t n, const sc_params* p,
+                       float* d_Rt, uint8_t* d_mask, sc_stats* stats) {
+  if (!c || !d_Rt || !d_mask) return SC_EINVAL;
+  if (p && p->size == sizeof(sc_params) && p->shard_world != 1) return SC_EINVAL;
+  ENSURE(c, c->key, 64);
+  int rc = sc_hypothesize_device(c, d_src, d_tgt, n, p, c->key.as<uint64_t>(), stats);
+  if (rc) return rc;
+  return sc_finalize_device(c, c->key.as<uint64_t>(), d_Rt, d_mask, stats);
+}
+
+int sc_register(sc_ctx* c, const float* src, const float* tgt, int64_t n, const sc_params* p, float R[9],
+                float t[3], uint8_t* mask, sc_stats* stats) {
+  if (!c || !src || !tgt || !R || !t || !mask || n < 3 || n > (1 << 24)) return SC_EINVAL;
+  int rc = check_params(p);
+  if (rc) return rc;
+  if (p->shard_world != 1) return SC_EINVAL;
+  HIPCHK(c, hipSetDevice(c->device));
+  c->cap_bytes = p->max_workspace ? p->max_workspace : (64ull << 30);
+  ENSURE(c, c->in_src, (size_t)n * 12);
+  ENSURE(c, c->in_tgt, (size_t)n * 12);
+  ENSURE(c, c->rt12, 64);
+  ENSURE(c, c->mask, (size_t)n);
+  HIPCHK(c, hipMemcpyAsync(c->in_src.p, src, (size_t)n * 12, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(c->in_tgt.p, tgt, (size_t)n * 12, hipMemcpyHostToDevice, c->stream));
+  rc = sc_register_device(c, c->in_src.as<float>(), c->in_tgt.as<float>(), n, p, c->rt12.as<float>(),
+                          c->mask.as<uint8_t>(), stats);
+  if (rc != SC_OK && rc != SC_ENOHYP) return rc;
+  float Rt[12];
+  HIPCHK(c, hipMemcpyAsync(Rt, c->rt12.p, 48, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipMemcpyAsync(mask, c->mask.p, (size_t)n, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  memcpy(R, Rt, 36);
+  memcpy(t, Rt + 9, 12);
+  return rc;
+}
+
+// ---- stage hooks ------------------------------------------------------------------------------------
+
+int sc_compat_host(sc_ctx* c, const float* src, const float* tgt, int64_t n, const sc_params* p, float* S,
+                   uint64_t* bits, uint32_t* deg) {
+  if (!c) return SC_EINVAL;
+  int rc = check_params(p);
+  if (rc) return rc;
+  HIPCHK(c, hipSetDevice(c->device));
+  c->have_hyp = false;
+  c->timing = false;
+  c->cap_bytes = p->max_workspace ? p->max_workspace : (64ull << 30);
+  c->dv = derive(p);
+  if ((rc = host_to_planes(c, src, tgt, n, p))) return rc;
+  if ((rc = run_compat(c))) return rc;
+  if ((rc = check_flag(c))) return rc;
+  const size_t W = (size_t)c->ld >> 6;
+  if (S)
+    HIPCHK(c, hipMemcpy2DAsync(S, (size_t)n * 4, c->S.p, (size_t)c->ld * 4, (size_t)n * 4, (size_t)n,
+                               hipMemcpyDeviceToHost, c->stream));
+  if (bits) HIPCHK(c, hipMemcpyAsync(bits, c->bits.p, (size_t)n * W * 8, hipMemcpyDeviceToHost, c->stream));
+  if (deg) HIPCHK(c, hipMemcpyAsync(deg, c->deg.p, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  HIPCHK(c, hipGetLastError());
+  return SC_OK;
+}
+
+int sc_triangles_host(sc_ctx* c, const float* src, const float* tgt, int64_t n, const sc_params* p, uint32_t* tri,
+                      uint32_t* key, uint32_t* t_eff, uint64_t* tri_total, uint64_t* edges) {
+  if (!c || !tri || !t_eff) return SC_EINVAL;
+  int rc = check_params(p);
+  if (rc) return rc;
+  HIPCHK(c, hipSetDevice(c->device));
+  c->have_hyp = false;
+  c->timing = false;
+  c->cap_bytes = p->max_workspace ? p->max_workspace : (64ull << 30);
+  c->dv = derive(p);
+  if ((rc = host_to_planes(c, src, tgt, n, p))) return rc;
+  if ((rc = run_compat(c))) return rc;
+  if ((rc = run_triangles(c, p))) return rc;
+  *t_eff = c->T_eff;
+  if (tri_total) *tri_total = c->M;
+  if (edges) *edges = c->E;
+  if (c->T_eff) {
+    HIPCHK(c, hipMemcpyAsync(tri, c->tri.p, (size_t)c->T_eff * 12, hipMemcpyDeviceToHost, c->stream));
+    if (key) HIPCHK(c, hipMemcpyAsync(key, c->trikey.p, (size_t)c->T_eff * 4, hipMemcpyDeviceToHost, c->stream));
+  }
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  HIPCHK(c, hipGetLastError());
+  return SC_OK;
+}
+
+int sc_kabsch_host(sc_ctx* c, const float* src, const float* tgt, int64_t n, const sc_params* p,
+                   const uint32_t* tri, uint32_t n_tri, float* Rt) {
+  if (!c || !tri || !Rt) return SC_EINVAL;
+  int rc = check_params(p);
+  if (rc) return rc;
+  for (size_t k = 0; k < (size_t)n_tri * 3; k++) if ((int64_t)tri[k] >= n) return SC_EINVAL;
+  HIPCHK(c, hipSetDevice(c->device));
+  c->have_hyp = false;
+  c->cap_bytes = p->max_workspace ? p->max_workspace : (64ull << 30);
+  if ((rc = host_to_planes(c, src, tgt, n, p))) return rc;
+  if (n_tri == 0) return check_flag(c);
+  ENSURE(c, c->tri, (size_t)n_tri * 12);
+  ENSURE(c, c->rt_aos, (size_t)n_tri * 48);
+  HIPCHK(c, hipMemcpyAsync(c->tri.p, tri, (size_t)n_tri * 12, hipMemcpyHostToDevice, c->stream));
+  launch_kabsch_aos(points_of(c), c->tri.as<uint32_t>(), n_tri, c->rt_aos.as<float>(), c->stream);
+  if ((rc = check_flag(c))) return rc;
+  HIPCHK(c, hipMemcpyAsync(Rt, c->rt_aos.p, (size_t)n_tri * 48, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  HIPCHK(c, hipGetLastError());
+  return SC_OK;
+}
+
+int sc_score_host(sc_ctx* c, const float* src, const float* tgt, int64_t n, const sc_params* p, const float* Rt,
+                  uint32_t n_hyp, uint32_t* cnt, uint64_t* key) {
+  if (!c || !Rt || !key) return SC_EINVAL;
+  int rc = check_params(p);
+  if (rc) return rc;
+  HIPCHK(c, hipSetDevice(c->device));
+  c->have_hyp = false;
+  c->cap_bytes = p->max_workspace ? p->max_workspace : (64ull << 30);
+  c->dv = derive(p);
+  if ((rc = host_to_planes(c, src, tgt, n, p))) return rc;
+  Shard sh;
+  sh.T_eff = n_hyp; sh.block = 0x40000000u; sh.rank = 0; sh.world = 1; sh.n_local = n_hyp;
+  sh.ld_local = (uint32_t)round_up((int)n_hyp, 256);
+  ENSURE(c, c->key, 64);
+  if (n_hyp) {
+    ENSURE(c, c->rt_aos, (size_t)n_hyp * 48);
+    ENSURE(c, c->rt, (size_t)12 * sh.ld_local * 4);
+    ENSURE(c, c->partial, (size_t)score_chunks(c->n) * sh.ld_local * 4);
+    ENSURE(c, c->cnt, (size_t)n_hyp * 4);
+    HIPCHK(c, hipMemcpyAsync(c->rt_aos.p, Rt, (size_t)n_hyp * 48, hipMemcpyHostToDevice, c->stream));
+    launch_rt_to_soa(c->rt_aos.as<float>(), n_hyp, sh.ld_local, c->rt.as<float>(), c->stream);
+  }
+  launch_score(points_of(c), c->rt.as<float>(), sh, c->dv.tau2, c->partial.as<uint32_t>(), c->cnt.as<uint32_t>(),
+               c->key.as<uint64_t>(), c->stream);
+  if ((rc = check_flag(c))) return rc;
+  if (cnt && n_hyp) HIPCHK(c, hipMemcpyAsync(cnt, c->cnt.p, (size_t)n_hyp * 4, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipMemcpyAsync(key, c->key.p, 8, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  HIPCHK(c, hipGetLastError());
+  return SC_OK;
+}
+
+int sc_mask_host(sc_ctx* c, const float* src, const float* tgt, int64_t n, const sc_params* p, const float Rt[12],
+                 uint8_t* mask) {
+  if (!c || !Rt || !mask) return SC_EINVAL;
+  int rc = check_params(p);
+  if (rc) return rc;
+  HIPCHK(c, hipSetDevice(c->device));
+  c->have_hyp = false;
+  c->cap_bytes = p->max_workspace ? p->max_workspace : (64ull << 30);
+  c->dv = derive(p);
+  if ((rc = host_to_planes(c, src, tgt, n, p))) return rc;
+  ENSURE(c, c->rt12, 64);
+  ENSURE(c, c->mask, (size_t)n);
+  HIPCHK(c, hipMemcpyAsync(c->rt12.p, Rt, 48, hipMemcpyHostToDevice, c->stream));
+  launch_mask(points_of(c), c->rt12.as<float>(), c->dv.tau2, c->mask.as<uint8_t>(), c->stream);
+  if ((rc = check_flag(c))) return rc;
+  HIPCHK(c, hipMemcpyAsync(mask, c->mask.p, (size_t)n, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  HIPCHK(c, hipGetLastError());
+  return SC_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,110 @@
+// sc_kernels.hpp — launchers of the hand-written gfx950 kernels (one per SURVEY.md §8(a) row).
+// Every launcher only enqueues on `st`; none allocates, frees or synchronises (capture-safe).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace sc {
+
+// Derived fp32 constants, computed once per call on the host in fp64.
+struct Derived {
+  float d_thr;         // sigma * sqrt(-2 ln t_cmp)
+  float neg_inv2sig2;  // -1 / (2 sigma^2)
+  float tau2;          // tau^2
+  float min_len;
+};
+
+// Device view of the padded SoA point planes: px py pz qx qy qz, each `ld` floats (ld = roundup(n,64)),
+// zero-filled beyond n.
+struct Points {
+  const float* planes;  // 6 * ld
+  int n;
+  int ld;
+};
+
+// ---- input staging -----------------------------------------------------------------------------
+// user layout (AoS n x 3 or SoA 3 x n) -> padded planes; sets *bad_flag != 0 when a value is not finite.
+void launch_stage_points(const float* d_src, const float* d_tgt, int n, int ld, int layout, float* planes,
+                         uint32_t* bad_flag, hipStream_t st);
+
+// ---- stage A: compat_graph -----------------------------------------------------------------------
+// S: n x ld fp32 (row-major, symmetric, zero diagonal / pad columns); bits: n x (ld/64) u64;
+// deg[i] = edges of i; degp[i] = edges (i,j) with j > i.
+void launch_compat(const Points& pts, const Derived& dv, float* S, uint64_t* bits, uint32_t* deg,
+                   uint32_t* degp, hipStream_t st);
+
+// ---- exclusive scan u32 -> u64 (out has n+1 entries; out[n] = total) -----------------------------
+size_t scan_temp_bytes(size_t n);
+void launch_scan_u32(const uint32_t* in, size_t n, uint64_t* out, void* temp, hipStream_t st);
+
+// ---- stage B: triangles_topT ---------------------------------------------------------------------
+struct Graph {
+  const uint64_t* bits;  // n x W
+  const float* S;        // n x ld
+  const uint32_t* deg;
+  int n, ld, W;
+};
+// CSR edge list of the upper triangle, rows ascending, columns ascending: ei/ej/es (es = S[i][j]).
+void launch_edge_fill(const Graph& g, const uint64_t* edge_off, uint32_t* ei, uint32_t* ej, float* es,
+                      hipStream_t st);
+// tcnt[e] = #k > j adjacent to both ends of edge e = (i,j).
+void launch_tri_count(const Graph& g, const uint32_t* ei, const uint32_t* ej, uint64_t E, uint32_t* tcnt,
+                      hipStream_t st);
+
+// Radix-select state, lives in device memory; zeroed by launch_select_init.
+struct SelectState {
+  uint32_t kmin, kmax;   // key range, filled by tri_keys
+  uint32_t lo, wbits;    // current window [lo, lo + 2^wbits); wbits = 0xFFFFFFFF before the first round
+  uint32_t done, kstar;  // kstar valid when done
+  uint64_t want;         // number of keys to keep
+  uint64_t above;        // keys strictly above the current window
+  uint64_t need_eq;      // how many keys == kstar to keep (lowest ordinals first)
+  uint32_t hist[2048];
+};
+void launch_select_init(SelectState* s, uint64_t want, hipStream_t st);
+// key of every triangle, in ordinal (lexicographic i,j,k) order: wkey[toff[e] + r].
+void launch_tri_keys(const Graph& g, const uint64_t* edge_off, const uint32_t* ei, const uint32_t* ej,
+                     const float* es, const uint64_t* toff, uint64_t E, int rank_mode, uint32_t* wkey,
+                     SelectState* s, hipStream_t st);
+// up to three (hist, pick) rounds find the exact threshold key
+void launch_select_rounds(const uint32_t* wkey, uint64_t M, SelectState* s, hipStream_t st);
+// compaction of the selected keys in ordinal order
+size_t compact_blocks(uint64_t M);
+void launch_compact_count(const uint32_t* wkey, uint64_t M, const SelectState* s, uint32_t* blk_gt,
+                          uint32_t* blk_eq, hipStream_t st);
+void launch_compact_write(const uint32_t* wkey, uint64_t M, const SelectState* s, const uint64_t* off_gt,
+                          const uint64_t* off_eq, uint64_t* sel_ord, uint64_t* sortkey, hipStream_t st);
+// ranked order: sortkey ascending = (key desc, ordinal asc).  Implemented with rocPRIM (sc_sort.hip).
+size_t sort_temp_bytes(size_t n);
+void launch_sort_u64(const uint64_t* in, uint64_t* out, size_t n, void* temp, size_t temp_bytes, hipStream_t st);
+// ordinal -> (i,j,k) in ranked order
+void launch_tri_decode(const Graph& g, const uint32_t* ei, const uint32_t* ej, const uint64_t* toff, uint64_t E,
+                       const uint64_t* sorted, const uint64_t* sel_ord, uint32_t T, uint32_t* tri,
+                       uint32_t* key, hipStream_t st);
+
+// ---- stage C ---------------------------------------------------------------------------------------
+struct Shard {
+  uint32_t T_eff;   // ranked triangles in total
+  uint32_t block;   // dealing granularity
+  uint32_t rank, world;
+  uint32_t n_local; // hypotheses of this rank
+  uint32_t ld_local;// roundup(n_local, 256): plane stride of RtSoA / partial counts
+};
+uint32_t shard_local_count(uint32_t T_eff, uint32_t block, uint32_t rank, uint32_t world);
+// C1: RtSoA[c * ld_local + l], c = 0..11, for the local hypotheses of the shard (global rank index derived).
+void launch_kabsch(const Points& pts, const uint32_t* tri, const Shard& sh, float* RtSoA, hipStream_t st);
+// C1 on an explicit triangle list to AoS T x 12 (stage hook)
+void launch_kabsch_aos(const Points& pts, const uint32_t* tri, uint32_t T, float* Rt, hipStream_t st);
+// AoS T x 12 -> SoA planes (stage hook for sc_score_host)
+void launch_rt_to_soa(const float* Rt, uint32_t T, uint32_t ld_local, float* RtSoA, hipStream_t st);
+// C2: inlier counts + arg-max key.  partial: n_chunks * ld_local u32 scratch.  cnt (may be null): n_local.
+uint32_t score_chunks(int n);
+void launch_score(const Points& pts, const float* RtSoA, const Shard& sh, float tau2, uint32_t* partial,
+                  uint32_t* cnt, uint64_t* key, hipStream_t st);
+// C3: winner decode + re-solve + mask.  Rt12 receives R (row-major) and t; identity / zero mask when key == 0.
+void launch_finalize(const Points& pts, const uint32_t* tri, const uint64_t* key, float tau2, float* Rt12,
+                     uint8_t* mask, hipStream_t st);
+// mask of an explicit hypothesis (stage hook)
+void launch_mask(const Points& pts, const float* Rt12, float tau2, uint8_t* mask, hipStream_t st);
+
+}  // namespace sc

@@ -1,0 +1,237 @@
+// sc_score.hip — stage C: per-triangle rigid transform (C1), hypothesis x correspondence inlier counting
+// (C2) and the winner's mask (C3).  SURVEY.md §8a rows C1, C2, C3.
+//
+// C2 is the arithmetic-heavy kernel of the path (T*N tests, 27 flop each) and moves almost no HBM bytes
+// (48 B per hypothesis in, 4 B out), so it is bounded by the fp32 vector rate, not by HBM.  Mapping:
+//   lane          = one hypothesis: its 12 coefficients live in VGPRs for the whole kernel, its inlier
+//                   count is a private register — no cross-lane reduction, no atomics on the hot loop;
+//   workgroup     = 256 hypotheses x one chunk of <= 1024 correspondences staged once into LDS;
+//   inner loop    = every lane reads the SAME point (one ds_read_b128 + one ds_read_b64, LDS broadcast,
+//                   conflict-free), then 12 FMA-class ops for the residual, 3 for its square norm, one
+//                   compare and one add-with-carry: 17 VALU instructions per test;
+//   grid          = ceil(T/256) x chunks, so a 50k x 5k problem is ~1000 workgroups (~4 waves per SIMD);
+//   partial counts are stored coalesced ([chunk][hypothesis]) and summed by the arg-max kernel.
+#include "sc_arith.hpp"
+#include "sc_block.hpp"
+#include "sc_kernels.hpp"
+
+namespace sc {
+
+// ------------------------------------------------------------------------------------------------
+// sharding of the ranked list: blocks of `block` triangles dealt round-robin to ranks
+// ------------------------------------------------------------------------------------------------
+__host__ __device__ __forceinline__ uint32_t shard_global_index(uint32_t l, uint32_t block, uint32_t rank,
+                                                                uint32_t world) {
+  return ((l / block) * world + rank) * block + (l % block);
+}
+
+uint32_t shard_local_count(uint32_t T_eff, uint32_t block, uint32_t rank, uint32_t world) {
+  uint64_t n = 0;
+  for (uint64_t gb = rank; gb * block < T_eff; gb += world) {
+    const uint64_t lo = gb * block, hi = (gb + 1) * (uint64_t)block;
+    n += (hi < T_eff ? hi : T_eff) - lo;
+  }
+  return (uint32_t)n;
+}
+
+// ------------------------------------------------------------------------------------------------
+// C1
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void load_triangle(const float* __restrict__ planes, int ld, const uint32_t* tri3,
+                                              float P[9], float Q[9]) {
+#pragma unroll
+  for (int m = 0; m < 3; m++) {
+    const uint32_t v = tri3[m];
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+      P[3 * m + c] = planes[(size_t)c * ld + v];
+      Q[3 * m + c] = planes[(size_t)(3 + c) * ld + v];
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void kabsch_shard_kernel(const float* __restrict__ planes, int ld,
+                                                           const uint32_t* __restrict__ tri, Shard sh,
+                                                           float* __restrict__ RtSoA) {
+  const uint32_t l = blockIdx.x * 256 + threadIdx.x;
+  if (l >= sh.ld_local) return;
+  float Rt[12];
+  if (l < sh.n_local) {
+    const uint32_t g = shard_global_index(l, sh.block, sh.rank, sh.world);
+    float P[9], Q[9];
+    load_triangle(planes, ld, tri + 3 * (size_t)g, P, Q);
+    kabsch3(P, Q, Rt);
+  } else {
+#pragma unroll
+    for (int c = 0; c < 12; c++) Rt[c] = 0.0f;
+  }
+#pragma unroll
+  for (int c = 0; c < 12; c++) RtSoA[(size_t)c * sh.ld_local + l] = Rt[c];
+}
+
+void launch_kabsch(const Points& pts, const uint32_t* tri, const Shard& sh, float* RtSoA, hipStream_t st) {
+  if (sh.ld_local == 0) return;
+  hipLaunchKernelGGL(kabsch_shard_kernel, dim3(sh.ld_local / 256), dim3(256), 0, st, pts.planes, pts.ld, tri, sh,
+                     RtSoA);
+}
+
+__global__ __launch_bounds__(256) void kabsch_aos_kernel(const float* __restrict__ planes, int ld,
+                                                         const uint32_t* __restrict__ tri, uint32_t T,
+                                                         float* __restrict__ Rt_out) {
+  const uint32_t h = blockIdx.x * 256 + threadIdx.x;
+  if (h >= T) return;
+  float P[9], Q[9], Rt[12];
+  load_triangle(planes, ld, tri + 3 * (size_t)h, P, Q);
+  kabsch3(P, Q, Rt);
+#pragma unroll
+  for (int c = 0; c < 12; c++) Rt_out[12 * (size_t)h + c] = Rt[c];
+}
+
+void launch_kabsch_aos(const Points& pts, const uint32_t* tri, uint32_t T, float* Rt, hipStream_t st) {
+  if (T == 0) return;
+  hipLaunchKernelGGL(kabsch_aos_kernel, dim3((T + 255) / 256), dim3(256), 0, st, pts.planes, pts.ld, tri, T, Rt);
+}
+
+__global__ __launch_bounds__(256) void rt_to_soa_kernel(const float* __restrict__ Rt, uint32_t T, uint32_t ld_local,
+                                                        float* __restrict__ RtSoA) {
+  const uint32_t l = blockIdx.x * 256 + threadIdx.x;
+  if (l >= ld_local) return;
+#pragma unroll
+  for (int c = 0; c < 12; c++) RtSoA[(size_t)c * ld_local + l] = (l < T) ? Rt[12 * (size_t)l + c] : 0.0f;
+}
+
+void launch_rt_to_soa(const float* Rt, uint32_t T, uint32_t ld_local, float* RtSoA, hipStream_t st) {
+  if (ld_local == 0) return;
+  hipLaunchKernelGGL(rt_to_soa_kernel, dim3(ld_local / 256), dim3(256), 0, st, Rt, T, ld_local, RtSoA);
+}
+
+// ------------------------------------------------------------------------------------------------
+// C2
+// ------------------------------------------------------------------------------------------------
+constexpr int SCORE_THREADS = 256;
+constexpr int SCORE_PC = 1024;  // correspondences per chunk (LDS: 24 KiB)
+
+uint32_t score_chunks(int n) { return (uint32_t)((n + SCORE_PC - 1) / SCORE_PC); }
+static inline int score_chunk_points(int n) {  // equalised chunk length, multiple of 4
+  const int c = (int)score_chunks(n);
+  const int per = (n + c - 1) / c;
+  return (per + 3) & ~3;
+}
+
+__global__ __launch_bounds__(SCORE_THREADS) void score_kernel(const float* __restrict__ planes, int n, int ld,
+                                                              const float* __restrict__ RtSoA, uint32_t ld_local,
+                                                              float tau2, int chunk_pts,
+                                                              uint32_t* __restrict__ partial) {
+  __shared__ float4 pA[SCORE_PC];  // px py pz qx
+  __shared__ float2 pB[SCORE_PC];  // qy qz
+  const int m0 = blockIdx.y * chunk_pts;
+  const int cnt_pts = min(chunk_pts, n - m0);
+  for (int t = threadIdx.x; t < cnt_pts; t += SCORE_THREADS) {
+    const int m = m0 + t;
+    pA[t] = make_float4(planes[m], planes[(size_t)ld + m], planes[2 * (size_t)ld + m], planes[3 * (size_t)ld + m]);
+    pB[t] = make_float2(planes[4 * (size_t)ld + m], planes[5 * (size_t)ld + m]);
+  }
+  const uint32_t l = blockIdx.x * SCORE_THREADS + threadIdx.x;
+  float M[12];
+#pragma unroll
+  for (int c = 0; c < 12; c++) M[c] = RtSoA[(size_t)c * ld_local + l];
+  const bool ok = finite12(M);
+  __syncthreads();
+  uint32_t cnt = 0;
+  int t = 0;
+#pragma unroll 4
+  for (; t < cnt_pts; t++) {
+    const float4 a = pA[t];
+    const float2 b = pB[t];
+    const float d2 = resid2(M, a.x, a.y, a.z, a.w, b.x, b.y);
+    cnt += (d2 < tau2) ? 1u : 0u;
+  }
+  partial[(size_t)blockIdx.y * ld_local + l] = ok ? cnt : 0u;
+}
+
+__global__ __launch_bounds__(256) void score_argmax_kernel(const uint32_t* __restrict__ partial, uint32_t n_chunks,
+                                                           Shard sh, uint32_t* __restrict__ cnt_out,
+                                                           unsigned long long* __restrict__ key) {
+  __shared__ unsigned long long lds[4];
+  const uint32_t l = blockIdx.x * 256 + threadIdx.x;
+  unsigned long long k = 0;
+  if (l < sh.n_local) {
+    uint32_t c = 0;
+    for (uint32_t ch = 0; ch < n_chunks; ch++) c += partial[(size_t)ch * sh.ld_local + l];
+    if (cnt_out) cnt_out[l] = c;
+    const uint32_t g = shard_global_index(l, sh.block, sh.rank, sh.world);
+    if (c) k = ((unsigned long long)c << 32) | (unsigned long long)(0xFFFFFFFFu - g);
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const unsigned long long other = __shfl_xor(k, o);
+    k = other > k ? other : k;
+  }
+  if ((threadIdx.x & 63) == 0) lds[threadIdx.x >> 6] = k;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    unsigned long long b = lds[0];
+    for (int w = 1; w < 4; w++) b = lds[w] > b ? lds[w] : b;
+    if (b) atomicMax(key, b);  // max is order-independent: deterministic
+  }
+}
+
+void launch_score(const Points& pts, const float* RtSoA, const Shard& sh, float tau2, uint32_t* partial,
+                  uint32_t* cnt, uint64_t* key, hipStream_t st) {
+  (void)hipMemsetAsync(key, 0, sizeof(uint64_t), st);
+  if (sh.n_local == 0) return;
+  const uint32_t chunks = score_chunks(pts.n);
+  const int chunk_pts = score_chunk_points(pts.n);
+  hipLaunchKernelGGL(score_kernel, dim3(sh.ld_local / SCORE_THREADS, chunks), dim3(SCORE_THREADS), 0, st,
+                     pts.planes, pts.n, pts.ld, RtSoA, sh.ld_local, tau2, chunk_pts, partial);
+  hipLaunchKernelGGL(score_argmax_kernel, dim3(sh.ld_local / 256), dim3(256), 0, st, partial, chunks, sh, cnt,
+                     reinterpret_cast<unsigned long long*>(key));
+}
+
+// ------------------------------------------------------------------------------------------------
+// C3
+// ------------------------------------------------------------------------------------------------
+__global__ void winner_kernel(const float* __restrict__ planes, int ld, const uint32_t* __restrict__ tri,
+                              const unsigned long long* __restrict__ key, float* __restrict__ Rt12) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  const unsigned long long k = *key;
+  float Rt[12] = {1.f, 0.f, 0.f, 0.f, 1.f, 0.f, 0.f, 0.f, 1.f, 0.f, 0.f, 0.f};
+  if (k != 0) {
+    const uint32_t g = 0xFFFFFFFFu - (uint32_t)(k & 0xFFFFFFFFull);
+    float P[9], Q[9];
+    load_triangle(planes, ld, tri + 3 * (size_t)g, P, Q);
+    kabsch3(P, Q, Rt);
+  }
+#pragma unroll
+  for (int c = 0; c < 12; c++) Rt12[c] = Rt[c];
+}
+
+__global__ __launch_bounds__(256) void mask_kernel(const float* __restrict__ planes, int n, int ld,
+                                                   const float* __restrict__ Rt12,
+                                                   const unsigned long long* __restrict__ key, float tau2,
+                                                   uint8_t* __restrict__ mask) {
+  const int m = blockIdx.x * 256 + threadIdx.x;
+  if (m >= n) return;
+  float M[12];
+#pragma unroll
+  for (int c = 0; c < 12; c++) M[c] = Rt12[c];
+  const bool live = (key == nullptr || *key != 0ull) && finite12(M);
+  const float d2 = resid2(M, planes[m], planes[(size_t)ld + m], planes[2 * (size_t)ld + m],
+                          planes[3 * (size_t)ld + m], planes[4 * (size_t)ld + m], planes[5 * (size_t)ld + m]);
+  mask[m] = (live && d2 < tau2) ? 1 : 0;
+}
+
+void launch_finalize(const Points& pts, const uint32_t* tri, const uint64_t* key, float tau2, float* Rt12,
+                     uint8_t* mask, hipStream_t st) {
+  hipLaunchKernelGGL(winner_kernel, dim3(1), dim3(64), 0, st, pts.planes, pts.ld, tri,
+                     reinterpret_cast<const unsigned long long*>(key), Rt12);
+  hipLaunchKernelGGL(mask_kernel, dim3((pts.n + 255) / 256), dim3(256), 0, st, pts.planes, pts.n, pts.ld, Rt12,
+                     reinterpret_cast<const unsigned long long*>(key), tau2, mask);
+}
+
+void launch_mask(const Points& pts, const float* Rt12, float tau2, uint8_t* mask, hipStream_t st) {
+  hipLaunchKernelGGL(mask_kernel, dim3((pts.n + 255) / 256), dim3(256), 0, st, pts.planes, pts.n, pts.ld, Rt12,
+                     (const unsigned long long*)nullptr, tau2, mask);
+}
+
+}  // namespace sc

@@ -1,0 +1,48 @@
+"""Multi-GPU layer: one process per GPU, hypotheses sharded, one 8-byte max all-reduce.
+
+Stages A and B are replicated (deterministic, so every rank holds the identical ranked list); stage C scores this
+rank's blocks of the ranked list (blocks of `shard_block` triangles dealt round-robin, so every rank sees the same
+mix of high- and low-ranked triangles).  The winner key K = (count << 32) | (0xFFFFFFFF - rank_index) embeds the
+global rank index, so after `all_reduce(MAX)` every rank decodes the same winner and re-solves it locally — no
+broadcast.  The collective is torch.distributed's: backend "nccl" is RCCL over xGMI on ROCm, "gloo" on CPU tests.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+
+def global_index(l: np.ndarray | int, block: int, rank: int, world: int):
+    """Global rank index of local hypothesis l (mirror of shard_global_index in csrc/sc_score.hip)."""
+    l = np.asarray(l, dtype=np.int64)
+    return ((l // block) * world + rank) * block + (l % block)
+
+
+def local_count(t_eff: int, block: int, rank: int, world: int) -> int:
+    n, gb = 0, rank
+    while gb * block < t_eff:
+        n += min((gb + 1) * block, t_eff) - gb * block
+        gb += world
+    return n
+
+
+def local_indices(t_eff: int, block: int, rank: int, world: int) -> np.ndarray:
+    """Global rank indices scored by `rank`, in local order."""
+    return global_index(np.arange(local_count(t_eff, block, rank, world)), block, rank, world)
+
+
+def encode_key(count: int, rank_index: int) -> int:
+    return 0 if count == 0 else (int(count) << 32) | (0xFFFFFFFF - int(rank_index))
+
+
+def decode_key(key: int) -> tuple[int, int]:
+    """-> (count, rank_index)"""
+    return int(key) >> 32, 0xFFFFFFFF - (int(key) & 0xFFFFFFFF)
+
+
+def allreduce_best(key_tensor):
+    """In-place MAX all-reduce of the int64 key tensor (1 element) over the default process group.
+    Keys are < 2^63 (count < 2^31), so the signed int64 view orders like the unsigned key."""
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        dist.all_reduce(key_tensor, op=dist.ReduceOp.MAX)
+    return key_tensor

@@ -1,0 +1,240 @@
+"""GPU parity: every stage of the HIP path, called through the C ABI (libsaccot.so), must equal the CPU
+restatement (oracle/saccot_oracle.c) BIT FOR BIT on the same seeded inputs — adjacency bits, degrees, weights,
+the ranked triangle list (order included), every (R,t), every inlier count, the winner and the mask.
+
+PARITY UNPINNED: the reference (/root/reference/README.md:1-2) has no implementation or vectors; the oracle is this
+repo's restatement of SURVEY.md §8(a), itself cross-checked against an fp64 numpy restatement in the CPU suite.
+"""
+import numpy as np
+import pytest
+
+from conftest import nan_equal_bits
+
+pytestmark = pytest.mark.gpu
+
+
+def _scene(pkg, n, rho=0.3, L=1.0, tau=0.05, seed=7):
+    return pkg.synth.make_scene(n, rho, L, tau, seed)
+
+
+def _params(pkg, tau, T, **kw):
+    d = dict(sigma=tau, t_cmp=0.9, tau=tau, min_len=tau, max_triangles=T, rank_mode=0)
+    d.update(kw)
+    return d
+
+
+# ---------------------------------------------------------------------------------------------------------
+# stage A
+# ---------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("n,seed", [(3, 1), (64, 2), (65, 3), (500, 1000), (777, 4), (1024, 5), (2000, 1001)])
+def test_compat_bit_exact(pkg, O, reg, n, seed):
+    sc = _scene(pkg, n, seed=seed)
+    kw = _params(pkg, 0.05, 10)
+    S, bits, deg = reg.compat(sc.src, sc.tgt, pkg.make_params(**kw))
+    S0, bits0, deg0 = O.compat(sc.src, sc.tgt, kw["sigma"], kw["t_cmp"], kw["min_len"], kw["tau"])
+    assert np.array_equal(bits, bits0)
+    assert np.array_equal(deg, deg0)
+    assert np.array_equal(S.view(np.uint32), S0.view(np.uint32))
+    assert np.array_equal(S, S.T) and not S.diagonal().any()
+
+
+def test_compat_soa_layout_and_min_len_zero(pkg, O, reg):
+    sc = _scene(pkg, 300, seed=11)
+    kw = _params(pkg, 0.05, 10, min_len=0.0)
+    p = pkg.make_params(layout=pkg.SC_SOA, **kw)
+    S, bits, deg = reg.compat(np.ascontiguousarray(sc.src.T), np.ascontiguousarray(sc.tgt.T), p)
+    S0, bits0, deg0 = O.compat(sc.src, sc.tgt, kw["sigma"], kw["t_cmp"], 0.0, kw["tau"])
+    assert np.array_equal(bits, bits0) and np.array_equal(deg, deg0)
+    assert np.array_equal(S.view(np.uint32), S0.view(np.uint32))
+
+
+# ---------------------------------------------------------------------------------------------------------
+# stage B
+# ---------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("n,T,rank_mode,seed", [(64, 50, 0, 2), (500, 200, 0, 1000), (500, 200, 1, 1000),
+                                                (777, 5000, 0, 4), (2000, 10000, 0, 1001), (2000, 10000, 1, 1001),
+                                                (500, 10_000_000, 0, 1000)])
+def test_triangles_ranked_list_bit_exact(pkg, O, reg, n, T, rank_mode, seed):
+    tau = 0.05 if n != 2000 else 0.02
+    rho = 0.3 if n != 2000 else 0.2
+    sc = _scene(pkg, n, rho=rho, tau=tau, seed=seed)
+    kw = _params(pkg, tau, T, rank_mode=rank_mode)
+    tri, key, total, edges = reg.triangles(sc.src, sc.tgt, pkg.make_params(**kw))
+    S0, bits0, deg0 = O.compat(sc.src, sc.tgt, kw["sigma"], kw["t_cmp"], kw["min_len"], kw["tau"])
+    tri0, key0, total0 = O.triangles(S0, bits0, deg0, T, rank_mode)
+    assert total == total0 and edges == int(deg0.sum()) // 2
+    assert tri.shape == tri0.shape == (min(T, total0), 3)
+    assert np.array_equal(key, key0)
+    assert np.array_equal(tri, tri0)
+
+
+def test_triangles_massive_ties(pkg, O, reg):
+    """Noise-free all-inlier scene: every weight is (nearly) the same float, so the top-T is decided almost
+    entirely by the lexicographic tie-break — the path the ordinal-indexed select exists for."""
+    sc = pkg.synth.make_scene(150, 1.0, 1.0, 1e-7, 21)
+    kw = _params(pkg, 0.05, 3000)
+    tri, key, total, _ = reg.triangles(sc.src, sc.tgt, pkg.make_params(**kw))
+    S0, bits0, deg0 = O.compat(sc.src, sc.tgt, kw["sigma"], kw["t_cmp"], kw["min_len"], kw["tau"])
+    tri0, key0, total0 = O.triangles(S0, bits0, deg0, 3000, 0)
+    assert total == total0 and total0 > 100_000
+    assert len(np.unique(key0)) < 50
+    assert np.array_equal(key, key0) and np.array_equal(tri, tri0)
+
+
+def test_triangles_none(pkg, reg):
+    """A scene with no compatible pair at all: zero edges, zero triangles, and the path reports SC_ENOHYP."""
+    rng = np.random.default_rng(5)
+    src = rng.uniform(-1, 1, (40, 3)).astype(np.float32)
+    tgt = (src * 37.0).astype(np.float32)  # every distance scaled: no rigid pair
+    kw = _params(pkg, 0.001, 100)
+    tri, key, total, edges = reg.triangles(src, tgt, pkg.make_params(**kw))
+    assert total == 0 and edges == 0 and tri.shape[0] == 0
+    out = reg.register(src, tgt, **kw)
+    assert out["status"] == pkg.SC_ENOHYP
+    assert np.array_equal(out["R"], np.eye(3, dtype=np.float32)) and not out["t"].any() and not out["mask"].any()
+
+
+# ---------------------------------------------------------------------------------------------------------
+# stage C1
+# ---------------------------------------------------------------------------------------------------------
+def test_kabsch_bit_exact_random_and_degenerate(pkg, O, reg):
+    sc = _scene(pkg, 400, seed=31)
+    rng = np.random.default_rng(3)
+    tri = np.sort(rng.integers(0, 400, (5000, 3)), axis=1).astype(np.uint32)
+    tri[:50, 1] = tri[:50, 0]                       # duplicate vertex: rank-1 H
+    src = sc.src.copy(); tgt = sc.tgt.copy()
+    src[:3] = np.array([[0, 0, 0], [1, 1, 1], [2, 2, 2]], np.float32)  # collinear triangle (0,1,2)
+    tri[50] = (0, 1, 2)
+    tgt[3:6] = tgt[3]                               # coincident target points: H = 0
+    tri[51] = (3, 4, 5)
+    p = pkg.make_params(**_params(pkg, 0.05, 10))
+    Rt = reg.kabsch(src, tgt, p, tri)
+    Rt0 = O.kabsch3(src, tgt, tri)
+    assert nan_equal_bits(Rt, Rt0)
+    good = np.isfinite(Rt0).all(axis=1)
+    assert good.sum() > 4000
+    R = Rt0[good, :9].reshape(-1, 3, 3).astype(np.float64)
+    assert np.abs(np.linalg.det(R) - 1).max() < 1e-4  # proper rotations
+
+
+# ---------------------------------------------------------------------------------------------------------
+# stage C2 / C3
+# ---------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("n,T", [(500, 200), (1000, 257), (2000, 10000), (1025, 3000)])
+def test_score_counts_bit_exact(pkg, O, reg, n, T):
+    sc = _scene(pkg, n, seed=n)
+    rng = np.random.default_rng(n)
+    tri = np.sort(np.stack([rng.choice(n, 3, replace=False) for _ in range(T)]), axis=1).astype(np.uint32)
+    inl = np.nonzero(sc.inlier)[0]
+    tri[: T // 2] = np.sort(np.stack([rng.choice(inl, 3, replace=False) for _ in range(T // 2)]), axis=1)
+    Rt0 = O.kabsch3(sc.src, sc.tgt, tri)
+    Rt0[7, 4] = np.nan                                # non-finite hypothesis scores 0
+    kw = _params(pkg, 0.05, T)
+    cnt, key = reg.score(sc.src, sc.tgt, pkg.make_params(**kw), Rt0)
+    cnt0 = O.score(sc.src, sc.tgt, Rt0, kw["tau"])
+    assert cnt0.max() > 20 and cnt0[7] == 0
+    assert np.array_equal(cnt, cnt0)
+    assert key == O.best_key(cnt0)
+    best = 0xFFFFFFFF - (key & 0xFFFFFFFF)
+    m = reg.mask(sc.src, sc.tgt, pkg.make_params(**kw), Rt0[best])
+    assert np.array_equal(m, O.mask(sc.src, sc.tgt, Rt0[best], kw["tau"])) and m.sum() == cnt0[best]
+
+
+# ---------------------------------------------------------------------------------------------------------
+# whole path
+# ---------------------------------------------------------------------------------------------------------
+def _check_register(pkg, O, reg, scene, kw, threads=8):
+    got = reg.register(scene.src, scene.tgt, **kw)
+    ref = O.register(scene.src, scene.tgt, threads=threads, **kw)
+    assert got["status"] == ref["rc"]
+    st = got["stats"]
+    assert (st["edges"], st["tri_total"], st["tri_kept"]) == (ref["edges"], ref["tri_total"], ref["t_eff"])
+    assert (st["best_rank"], st["best_count"]) == (ref["best_rank"], ref["best_count"])
+    assert np.array_equal(got["mask"], ref["mask"])                      # bit-exact mask   [north_star]
+    assert nan_equal_bits(got["R"], ref["R"]) and nan_equal_bits(got["t"], ref["t"])  # stronger than 1e-5
+    return got, ref
+
+
+@pytest.mark.parametrize("name", ["C0", "C1", "C2"])
+def test_register_matches_oracle(pkg, O, reg, name):
+    cfg, scene = pkg.synth.make_config_scene(name)
+    got, _ = _check_register(pkg, O, reg, scene, cfg.params())
+    # known-answer: synthetic ground truth (3-point hypotheses are coarse; bounds are loose on purpose)
+    assert pkg.synth.rotation_error_deg(got["R"], scene.R_gt) < 3.0
+    assert np.linalg.norm(got["t"] - scene.t_gt) < 2 * cfg.tau + 0.05 * cfg.L
+    m = got["mask"].astype(bool)
+    assert (m & scene.inlier).sum() >= 0.9 * scene.inlier.sum()
+
+
+def test_register_degree_ranking_and_small_T(pkg, O, reg):
+    cfg, scene = pkg.synth.make_config_scene("C0")
+    kw = cfg.params(); kw["rank_mode"] = 1; kw["max_triangles"] = 37
+    _check_register(pkg, O, reg, scene, kw)
+
+
+def test_register_deterministic_and_context_reuse(pkg, reg):
+    """Same context, interleaved problem sizes (workspace grows, never shrinks): byte-identical repeats."""
+    cfg1, s1 = pkg.synth.make_config_scene("C1")
+    cfg0, s0 = pkg.synth.make_config_scene("C0")
+    a = reg.register(s1.src, s1.tgt, **cfg1.params())
+    reg.register(s0.src, s0.tgt, **cfg0.params())
+    b = reg.register(s1.src, s1.tgt, **cfg1.params())
+    assert np.array_equal(a["mask"], b["mask"]) and a["R"].tobytes() == b["R"].tobytes() and a["t"].tobytes() == b["t"].tobytes()
+    assert a["stats"]["best_rank"] == b["stats"]["best_rank"]
+
+
+def test_register_sharded_equals_unsharded(pkg, reg):
+    """SURVEY §8e on one GPU: run the two-phase API once per (rank, world) with the same context, max-reduce the
+    keys on the host, finalize — the winner, (R,t) and mask must equal the unsharded run for every world size."""
+    import torch
+    cfg, scene = pkg.synth.make_config_scene("C1")
+    base = reg.register(scene.src, scene.tgt, **cfg.params())
+    dev = torch.device("cuda:0")
+    d_src = torch.from_numpy(scene.src).to(dev); d_tgt = torch.from_numpy(scene.tgt).to(dev)
+    d_key = torch.zeros(1, dtype=torch.int64, device=dev)
+    d_Rt = torch.zeros(12, dtype=torch.float32, device=dev); d_mask = torch.zeros(cfg.n, dtype=torch.uint8, device=dev)
+    torch.cuda.synchronize()
+    for world in (1, 2, 3, 8):
+        keys, scored = [], 0
+        for rank in range(world):
+            p = pkg.make_params(shard_rank=rank, shard_world=world, shard_block=256, **cfg.params())
+            st = reg.hypothesize_device(d_src.data_ptr(), d_tgt.data_ptr(), cfg.n, p, d_key.data_ptr())
+            torch.cuda.synchronize()
+            keys.append(int(d_key.item())); scored += st["tri_scored"]
+        assert scored == base["stats"]["tri_kept"]
+        d_key.fill_(max(keys)); torch.cuda.synchronize()
+        rc, st = reg.finalize_device(d_key.data_ptr(), d_Rt.data_ptr(), d_mask.data_ptr())
+        torch.cuda.synchronize()
+        assert rc == 0 and st["best_rank"] == base["stats"]["best_rank"] and st["best_count"] == base["stats"]["best_count"]
+        assert np.array_equal(d_mask.cpu().numpy(), base["mask"])
+        assert d_Rt.cpu().numpy().tobytes() == np.concatenate([base["R"].ravel(), base["t"]]).tobytes()
+
+
+def test_errors(pkg, reg):
+    cfg, scene = pkg.synth.make_config_scene("C0")
+    with pytest.raises(pkg.SacCotError) as e:
+        reg.register(scene.src[:2], scene.tgt[:2], **cfg.params())          # n < 3
+    assert e.value.status == pkg.SC_EINVAL
+    bad = scene.src.copy(); bad[17, 1] = np.nan
+    with pytest.raises(pkg.SacCotError) as e:
+        reg.register(bad, scene.tgt, **cfg.params())                          # non-finite input
+    assert e.value.status == pkg.SC_EINVAL
+    with pytest.raises(pkg.SacCotError) as e:
+        reg.register(scene.src, scene.tgt, **dict(cfg.params(), t_cmp=1.5))   # bad parameter
+    assert e.value.status == pkg.SC_EINVAL
+    out = reg.register(scene.src, scene.tgt, **cfg.params())                   # context still usable
+    assert out["status"] == 0
+
+
+def test_rigid_motion_invariance_of_graph(pkg, reg):
+    """Property: moving the target cloud rigidly leaves the edge set unchanged away from the thresholds."""
+    cfg, scene = pkg.synth.make_config_scene("C0")
+    p = pkg.make_params(**cfg.params())
+    _, bits, _ = reg.compat(scene.src, scene.tgt, p, want_S=False)
+    th = 0.7
+    Rz = np.array([[np.cos(th), -np.sin(th), 0], [np.sin(th), np.cos(th), 0], [0, 0, 1]])
+    tgt2 = (scene.tgt.astype(np.float64) @ Rz.T + np.array([0.3, -0.2, 0.1])).astype(np.float32)
+    _, bits2, _ = reg.compat(scene.src, tgt2, p, want_S=False)
+    diff = sum(bin(int(x)).count("1") for x in (bits ^ bits2).ravel())
+    total = sum(bin(int(x)).count("1") for x in bits.ravel())
+    assert diff <= 0.002 * total + 4   # only threshold-edge pairs may flip under fp32 re-rounding
