@@ -86,12 +86,14 @@ typedef struct sc_stats {
   uint32_t tri_scored;      /* hypotheses scored by THIS rank                                           */
   uint32_t best_rank;       /* rank index (0-based) of the winning triangle in the ranked list          */
   uint32_t best_count;      /* its inlier count                                                         */
-  float    us_compat;       /* stage A                                                                  */
-  float    us_triangles;    /* stage B                                                                  */
+  float    us_stage;        /* input staging (layout -> padded planes, finiteness check)                */
+  float    us_compat;       /* stage A: the compat_rows kernel alone                                    */
+  float    us_triangles;    /* stage B: every kernel of it plus its two 8-byte read-backs               */
   float    us_kabsch;       /* stage C1                                                                 */
-  float    us_score;        /* stage C2 (incl. the partial-count reduction and arg-max)                 */
-  float    us_mask;         /* stage C3                                                                 */
-  float    us_total;        /* first kernel -> last kernel of the call                                  */
+  float    us_score;        /* stage C2: the score kernel alone                                         */
+  float    us_argmax;       /* stage C2: partial-count reduction + arg-max key                          */
+  float    us_mask;         /* stage C3: winner re-solve + mask                                         */
+  float    us_total;        /* sum of the above                                                         */
   uint64_t workspace_bytes; /* device bytes currently held by the context                               */
 } sc_stats;
 

@@ -25,7 +25,7 @@ struct Buf {
   template <class T> T* as() const { return static_cast<T*>(p); }
 };
 
-constexpr int N_EVENTS = 8;
+constexpr int N_EVENTS = 10;
 
 }  // namespace
 
@@ -41,7 +41,7 @@ struct sc_ctx {
 
   // workspace
   Buf in_src, in_tgt, planes, S, bits, deg, degp, edge_off, scan_tmp, ei, ej, es, tcnt, toff, wkey, sel, blk_gt,
-      blk_eq, off_gt, off_eq, sel_ord, sortkey, sorted, sort_tmp, tri, trikey, rt, rt_aos, partial, cnt, key, rt12,
+      blk_eq, blk_minmax, off_gt, off_eq, sel_ord, sortkey, sorted, sort_tmp, tri, trikey, rt, rt_aos, partial, cnt, key, rt12,
       mask, flag;
 
   // state of the last hypothesize call (consumed by finalize)
@@ -187,6 +187,7 @@ int run_triangles(sc_ctx* c, const sc_params* p) {
   const size_t nb = compact_blocks(M);
   ENSURE(c, c->wkey, M * 4);
   ENSURE(c, c->sel, sizeof(SelectState));
+  ENSURE(c, c->blk_minmax, 2 * 8192 * 4);
   ENSURE(c, c->blk_gt, nb * 4);
   ENSURE(c, c->blk_eq, nb * 4);
   ENSURE(c, c->off_gt, (nb + 1) * 8);
@@ -202,12 +203,14 @@ int run_triangles(sc_ctx* c, const sc_params* p) {
   SelectState* sel = c->sel.as<SelectState>();
   launch_select_init(sel, T_eff, st);
   launch_tri_keys(g, c->edge_off.as<uint64_t>(), c->ei.as<uint32_t>(), c->ej.as<uint32_t>(), c->es.as<float>(),
-                  c->toff.as<uint64_t>(), E, p->rank_mode, c->wkey.as<uint32_t>(), sel, st);
+                  c->toff.as<uint64_t>(), E, p->rank_mode, c->wkey.as<uint32_t>(), c->blk_minmax.as<uint32_t>(), sel,
+                  st);
   launch_select_rounds(c->wkey.as<uint32_t>(), M, sel, st);
   launch_compact_count(c->wkey.as<uint32_t>(), M, sel, c->blk_gt.as<uint32_t>(), c->blk_eq.as<uint32_t>(), st);
   launch_scan_u32(c->blk_gt.as<uint32_t>(), nb, c->off_gt.as<uint64_t>(), c->scan_tmp.p, st);
   launch_scan_u32(c->blk_eq.as<uint32_t>(), nb, c->off_eq.as<uint64_t>(), c->scan_tmp.p, st);
-  launch_compact_write(c->wkey.as<uint32_t>(), M, sel, c->off_gt.as<uint64_t>(), c->off_eq.as<uint64_t>(),
+  launch_compact_write(c->wkey.as<uint32_t>(), M, sel, c->blk_gt.as<uint32_t>(), c->blk_eq.as<uint32_t>(),
+                       c->off_gt.as<uint64_t>(), c->off_eq.as<uint64_t>(),
                        c->sel_ord.as<uint64_t>(), c->sortkey.as<uint64_t>(), st);
   launch_sort_u64(c->sortkey.as<uint64_t>(), c->sorted.as<uint64_t>(), T_eff, c->sort_tmp.p, sort_bytes, st);
   launch_tri_decode(g, c->ei.as<uint32_t>(), c->ej.as<uint32_t>(), c->toff.as<uint64_t>(), E,
@@ -311,7 +314,7 @@ void sc_destroy(sc_ctx* c) {
   (void)hipSetDevice(c->device);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   Buf* bufs[] = {&c->in_src, &c->in_tgt, &c->planes, &c->S, &c->bits, &c->deg, &c->degp, &c->edge_off, &c->scan_tmp,
-                 &c->ei, &c->ej, &c->es, &c->tcnt, &c->toff, &c->wkey, &c->sel, &c->blk_gt, &c->blk_eq, &c->off_gt,
+                 &c->ei, &c->ej, &c->es, &c->tcnt, &c->toff, &c->wkey, &c->sel, &c->blk_gt, &c->blk_eq, &c->blk_minmax, &c->off_gt,
                  &c->off_eq, &c->sel_ord, &c->sortkey, &c->sorted, &c->sort_tmp, &c->tri, &c->trikey, &c->rt,
                  &c->rt_aos, &c->partial, &c->cnt, &c->key, &c->rt12, &c->mask, &c->flag};
   for (Buf* b : bufs) if (b->p) (void)hipFree(b->p);
@@ -343,10 +346,11 @@ int sc_hypothesize_device(sc_ctx* c, const float* d_src, const float* d_tgt, int
   c->dv = derive(p);
   if ((rc = rec(c, 0))) return rc;
   if ((rc = stage_inputs(c, d_src, d_tgt, n, p))) return rc;
-  if ((rc = run_compat(c))) return rc;
   if ((rc = rec(c, 1))) return rc;
-  if ((rc = run_triangles(c, p))) return rc;
+  if ((rc = run_compat(c))) return rc;
   if ((rc = rec(c, 2))) return rc;
+  if ((rc = run_triangles(c, p))) return rc;
+  if ((rc = rec(c, 3))) return rc;
   // stage C on this rank's share of the ranked list
   Shard sh;
   sh.T_eff = c->T_eff;
@@ -361,21 +365,26 @@ int sc_hypothesize_device(sc_ctx* c, const float* d_src, const float* d_tgt, int
     ENSURE(c, c->partial, (size_t)score_chunks(c->n) * sh.ld_local * 4);
     launch_kabsch(points_of(c), c->tri.as<uint32_t>(), sh, c->rt.as<float>(), c->stream);
   }
-  if ((rc = rec(c, 3))) return rc;
-  launch_score(points_of(c), c->rt.as<float>(), sh, c->dv.tau2, c->partial.as<uint32_t>(), nullptr, d_key, c->stream);
   if ((rc = rec(c, 4))) return rc;
+  launch_score(points_of(c), c->rt.as<float>(), sh, c->dv.tau2, c->partial.as<uint32_t>(), c->stream);
+  if ((rc = rec(c, 5))) return rc;
+  launch_argmax(points_of(c), sh, c->partial.as<uint32_t>(), nullptr, d_key, c->stream);
+  if ((rc = rec(c, 6))) return rc;
   HIPCHK(c, hipGetLastError());
   c->have_hyp = true;
   if (stats && stats->size == sizeof(sc_stats)) {
     fill_stats(c, stats);
     if (c->timing) {
       HIPCHK(c, hipStreamSynchronize(c->stream));
-      // A's interval includes input staging; B's includes its two read-backs
-      stats->us_compat = ev_us(c, 0, 1);
-      stats->us_triangles = ev_us(c, 1, 2);
-      stats->us_kabsch = ev_us(c, 2, 3);
-      stats->us_score = ev_us(c, 3, 4);
-      stats->us_total = ev_us(c, 0, 4);
+      stats->us_stage = ev_us(c, 0, 1);
+      stats->us_compat = ev_us(c, 1, 2);
+      stats->us_triangles = ev_us(c, 2, 3);  // includes its two 8-byte read-backs
+      stats->us_kabsch = ev_us(c, 3, 4);
+      stats->us_score = ev_us(c, 4, 5);
+      stats->us_argmax = ev_us(c, 5, 6);
+      stats->us_mask = 0.f;
+      stats->us_total = stats->us_stage + stats->us_compat + stats->us_triangles + stats->us_kabsch +
+                        stats->us_score + stats->us_argmax;
     }
   }
   return SC_OK;
@@ -386,9 +395,9 @@ int sc_finalize_device(sc_ctx* c, const uint64_t* d_key, float* d_Rt, uint8_t* d
   if (!c->have_hyp) { c->last_error = "sc_finalize_device without a preceding sc_hypothesize_device"; return SC_EINVAL; }
   HIPCHK(c, hipSetDevice(c->device));
   int rc;
-  if ((rc = rec(c, 5))) return rc;
+  if ((rc = rec(c, 7))) return rc;
   launch_finalize(points_of(c), c->tri.as<uint32_t>(), d_key, c->dv.tau2, d_Rt, d_mask, c->stream);
-  if ((rc = rec(c, 6))) return rc;
+  if ((rc = rec(c, 8))) return rc;
   HIPCHK(c, hipMemcpyAsync(&c->pinned[3], d_key, 8, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   HIPCHK(c, hipGetLastError());
@@ -398,7 +407,7 @@ int sc_finalize_device(sc_ctx* c, const uint64_t* d_key, float* d_Rt, uint8_t* d
     stats->best_count = (uint32_t)(key >> 32);
     stats->best_rank = key ? 0xFFFFFFFFu - (uint32_t)(key & 0xFFFFFFFFull) : 0u;
     if (c->timing) {
-      stats->us_mask = ev_us(c, 5, 6);
+      stats->us_mask = ev_us(c, 7, 8);
       stats->us_total += stats->us_mask;
     }
   }
@@ -536,8 +545,8 @@ int sc_score_host(sc_ctx* c, const float* src, const float* tgt, int64_t n, cons
     HIPCHK(c, hipMemcpyAsync(c->rt_aos.p, Rt, (size_t)n_hyp * 48, hipMemcpyHostToDevice, c->stream));
     launch_rt_to_soa(c->rt_aos.as<float>(), n_hyp, sh.ld_local, c->rt.as<float>(), c->stream);
   }
-  launch_score(points_of(c), c->rt.as<float>(), sh, c->dv.tau2, c->partial.as<uint32_t>(), c->cnt.as<uint32_t>(),
-               c->key.as<uint64_t>(), c->stream);
+  launch_score(points_of(c), c->rt.as<float>(), sh, c->dv.tau2, c->partial.as<uint32_t>(), c->stream);
+  launch_argmax(points_of(c), sh, c->partial.as<uint32_t>(), c->cnt.as<uint32_t>(), c->key.as<uint64_t>(), c->stream);
   if ((rc = check_flag(c))) return rc;
   if (cnt && n_hyp) HIPCHK(c, hipMemcpyAsync(cnt, c->cnt.p, (size_t)n_hyp * 4, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipMemcpyAsync(key, c->key.p, 8, hipMemcpyDeviceToHost, c->stream));

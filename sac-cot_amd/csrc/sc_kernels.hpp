@@ -63,17 +63,19 @@ struct SelectState {
 };
 void launch_select_init(SelectState* s, uint64_t want, hipStream_t st);
 // key of every triangle, in ordinal (lexicographic i,j,k) order: wkey[toff[e] + r].
+// blk_minmax: 2 * 8192 u32 scratch (per-block key min / max, reduced into s->kmin / s->kmax).
 void launch_tri_keys(const Graph& g, const uint64_t* edge_off, const uint32_t* ei, const uint32_t* ej,
                      const float* es, const uint64_t* toff, uint64_t E, int rank_mode, uint32_t* wkey,
-                     SelectState* s, hipStream_t st);
+                     uint32_t* blk_minmax, SelectState* s, hipStream_t st);
 // up to three (hist, pick) rounds find the exact threshold key
 void launch_select_rounds(const uint32_t* wkey, uint64_t M, SelectState* s, hipStream_t st);
 // compaction of the selected keys in ordinal order
 size_t compact_blocks(uint64_t M);
 void launch_compact_count(const uint32_t* wkey, uint64_t M, const SelectState* s, uint32_t* blk_gt,
                           uint32_t* blk_eq, hipStream_t st);
-void launch_compact_write(const uint32_t* wkey, uint64_t M, const SelectState* s, const uint64_t* off_gt,
-                          const uint64_t* off_eq, uint64_t* sel_ord, uint64_t* sortkey, hipStream_t st);
+void launch_compact_write(const uint32_t* wkey, uint64_t M, const SelectState* s, const uint32_t* blk_gt,
+                          const uint32_t* blk_eq, const uint64_t* off_gt, const uint64_t* off_eq,
+                          uint64_t* sel_ord, uint64_t* sortkey, hipStream_t st);
 // ranked order: sortkey ascending = (key desc, ordinal asc).  Implemented with rocPRIM (sc_sort.hip).
 size_t sort_temp_bytes(size_t n);
 void launch_sort_u64(const uint64_t* in, uint64_t* out, size_t n, void* temp, size_t temp_bytes, hipStream_t st);
@@ -100,7 +102,9 @@ void launch_rt_to_soa(const float* Rt, uint32_t T, uint32_t ld_local, float* RtS
 // C2: inlier counts + arg-max key.  partial: n_chunks * ld_local u32 scratch.  cnt (may be null): n_local.
 uint32_t score_chunks(int n);
 void launch_score(const Points& pts, const float* RtSoA, const Shard& sh, float tau2, uint32_t* partial,
-                  uint32_t* cnt, uint64_t* key, hipStream_t st);
+                  hipStream_t st);
+void launch_argmax(const Points& pts, const Shard& sh, const uint32_t* partial, uint32_t* cnt, uint64_t* key,
+                   hipStream_t st);
 // C3: winner decode + re-solve + mask.  Rt12 receives R (row-major) and t; identity / zero mask when key == 0.
 void launch_finalize(const Points& pts, const uint32_t* tri, const uint64_t* key, float tau2, float* Rt12,
                      uint8_t* mask, hipStream_t st);

@@ -177,15 +177,20 @@ __global__ __launch_bounds__(256) void score_argmax_kernel(const uint32_t* __res
 }
 
 void launch_score(const Points& pts, const float* RtSoA, const Shard& sh, float tau2, uint32_t* partial,
-                  uint32_t* cnt, uint64_t* key, hipStream_t st) {
-  (void)hipMemsetAsync(key, 0, sizeof(uint64_t), st);
+                  hipStream_t st) {
   if (sh.n_local == 0) return;
   const uint32_t chunks = score_chunks(pts.n);
   const int chunk_pts = score_chunk_points(pts.n);
   hipLaunchKernelGGL(score_kernel, dim3(sh.ld_local / SCORE_THREADS, chunks), dim3(SCORE_THREADS), 0, st,
                      pts.planes, pts.n, pts.ld, RtSoA, sh.ld_local, tau2, chunk_pts, partial);
-  hipLaunchKernelGGL(score_argmax_kernel, dim3(sh.ld_local / 256), dim3(256), 0, st, partial, chunks, sh, cnt,
-                     reinterpret_cast<unsigned long long*>(key));
+}
+
+void launch_argmax(const Points& pts, const Shard& sh, const uint32_t* partial, uint32_t* cnt, uint64_t* key,
+                   hipStream_t st) {
+  (void)hipMemsetAsync(key, 0, sizeof(uint64_t), st);
+  if (sh.n_local == 0) return;
+  hipLaunchKernelGGL(score_argmax_kernel, dim3(sh.ld_local / 256), dim3(256), 0, st, partial, score_chunks(pts.n),
+                     sh, cnt, reinterpret_cast<unsigned long long*>(key));
 }
 
 // ------------------------------------------------------------------------------------------------

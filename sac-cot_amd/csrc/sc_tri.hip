@@ -129,6 +129,8 @@ void launch_select_init(SelectState* s, uint64_t want, hipStream_t st) {
   hipLaunchKernelGGL(select_init_kernel, dim3(1), dim3(256), 0, st, s, want);
 }
 
+constexpr int TK_MAX_BLOCKS = 8192;  // bounds the per-block min/max arrays
+
 __global__ __launch_bounds__(256) void tri_keys_kernel(const uint64_t* __restrict__ bits, int W,
                                                        const uint32_t* __restrict__ deg,
                                                        const uint64_t* __restrict__ edge_off,
@@ -137,73 +139,103 @@ __global__ __launch_bounds__(256) void tri_keys_kernel(const uint64_t* __restric
                                                        const float* __restrict__ es,
                                                        const uint64_t* __restrict__ toff, uint64_t E,
                                                        int rank_mode, uint32_t* __restrict__ wkey,
-                                                       SelectState* __restrict__ sel) {
+                                                       uint32_t* __restrict__ blk_min,
+                                                       uint32_t* __restrict__ blk_max) {
+  __shared__ uint32_t lmin[4], lmax[4];
   const int gl = threadIdx.x & (TG - 1);
-  const uint64_t e = (uint64_t)blockIdx.x * (256 / TG) + (threadIdx.x / TG);
-  const bool live = e < E;
-  const uint64_t ec = live ? e : 0;
-  const uint32_t i = ei[ec], j = ej[ec];
-  const uint64_t* ri = bits + (size_t)i * W;
-  const uint64_t* rj = bits + (size_t)j * W;
-  const int w0 = j >> 6;
-  const float s_ij = es[ec];
-  const uint32_t dsum_ij = deg[i] + deg[j];
-  const uint64_t out0 = toff[ec];
-  const uint64_t eik0 = ec + 1;          // edge index of (i, first neighbour of i above j)
-  const uint64_t ejk0 = edge_off[j];     // edge index of (j, first neighbour of j above j)
-  uint32_t base_m = 0, base_i = 0, base_j = 0;
   uint32_t kmin = 0xFFFFFFFFu, kmax = 0;
-  // every lane of the group runs the same number of rounds so the group scans stay converged
-  const int rounds = live ? (W - w0 + TG - 1) / TG : 0;
-  for (int it = 0; it < rounds; it++) {
-    const int w = w0 + it * TG + gl;
-    uint64_t ai = 0, aj = 0;
-    if (w < W) {
-      ai = ri[w]; aj = rj[w];
-      if (w == w0) { const uint64_t mk = mask_above(j & 63); ai &= mk; aj &= mk; }
-    }
-    uint64_t m = ai & aj;
-    uint32_t tm, ti, tj;
-    uint32_t pm = base_m + group_exscan<TG>((uint32_t)__popcll(m), &tm);
-    uint32_t pi = base_i + group_exscan<TG>((uint32_t)__popcll(ai), &ti);
-    uint32_t pj = base_j + group_exscan<TG>((uint32_t)__popcll(aj), &tj);
-    base_m += tm; base_i += ti; base_j += tj;
-    while (m) {
-      const int b = __builtin_ctzll(m);
-      const uint64_t below = (1ull << b) - 1ull;
-      m &= m - 1;
-      uint32_t key;
-      if (rank_mode == 0) {
-        const float s_ik = es[eik0 + pi + (uint32_t)__popcll(ai & below)];
-        const float s_jk = es[ejk0 + pj + (uint32_t)__popcll(aj & below)];
-        key = __float_as_uint((s_ij + s_ik) + s_jk);
-      } else {
-        key = dsum_ij + deg[w * 64 + b];
+  const uint64_t groups = (uint64_t)gridDim.x * (256 / TG);
+  // every group of TG lanes walks edges e, e + groups, ...; all lanes of a group share the trip counts
+  for (uint64_t e = (uint64_t)blockIdx.x * (256 / TG) + (threadIdx.x / TG); e < E; e += groups) {
+    const uint32_t i = ei[e], j = ej[e];
+    const uint64_t* ri = bits + (size_t)i * W;
+    const uint64_t* rj = bits + (size_t)j * W;
+    const int w0 = j >> 6;
+    const float s_ij = es[e];
+    const uint32_t dsum_ij = deg[i] + deg[j];
+    const uint64_t out0 = toff[e];
+    const uint64_t eik0 = e + 1;           // edge index of (i, first neighbour of i above j)
+    const uint64_t ejk0 = edge_off[j];     // edge index of (j, first neighbour of j above j)
+    uint32_t base_m = 0, base_i = 0, base_j = 0;
+    const int rounds = (W - w0 + TG - 1) / TG;
+    for (int it = 0; it < rounds; it++) {
+      const int w = w0 + it * TG + gl;
+      uint64_t ai = 0, aj = 0;
+      if (w < W) {
+        ai = ri[w]; aj = rj[w];
+        if (w == w0) { const uint64_t mk = mask_above(j & 63); ai &= mk; aj &= mk; }
       }
-      wkey[out0 + pm++] = key;
-      kmin = min(kmin, key);
-      kmax = max(kmax, key);
+      uint64_t m = ai & aj;
+      uint32_t tm, ti, tj;
+      uint32_t pm = base_m + group_exscan<TG>((uint32_t)__popcll(m), &tm);
+      const uint32_t pi = base_i + group_exscan<TG>((uint32_t)__popcll(ai), &ti);
+      const uint32_t pj = base_j + group_exscan<TG>((uint32_t)__popcll(aj), &tj);
+      base_m += tm; base_i += ti; base_j += tj;
+      while (m) {
+        const int b = __builtin_ctzll(m);
+        const uint64_t below = (1ull << b) - 1ull;
+        m &= m - 1;
+        uint32_t key;
+        if (rank_mode == 0) {
+          const float s_ik = es[eik0 + pi + (uint32_t)__popcll(ai & below)];
+          const float s_jk = es[ejk0 + pj + (uint32_t)__popcll(aj & below)];
+          key = __float_as_uint((s_ij + s_ik) + s_jk);
+        } else {
+          key = dsum_ij + deg[w * 64 + b];
+        }
+        wkey[out0 + pm++] = key;
+        kmin = min(kmin, key);
+        kmax = max(kmax, key);
+      }
     }
   }
-  // wave-level min/max, one atomic pair per wave
+  // block min/max -> one plain store per block (no same-address atomics: they serialise at ~12 ns each)
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) {
     kmin = min(kmin, (uint32_t)__shfl_xor(kmin, o));
     kmax = max(kmax, (uint32_t)__shfl_xor(kmax, o));
   }
-  if ((threadIdx.x & 63) == 0 && kmin <= kmax) {
-    atomicMin(&sel->kmin, kmin);
-    atomicMax(&sel->kmax, kmax);
+  if ((threadIdx.x & 63) == 0) { lmin[threadIdx.x >> 6] = kmin; lmax[threadIdx.x >> 6] = kmax; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    blk_min[blockIdx.x] = min(min(lmin[0], lmin[1]), min(lmin[2], lmin[3]));
+    blk_max[blockIdx.x] = max(max(lmax[0], lmax[1]), max(lmax[2], lmax[3]));
   }
+}
+
+__global__ __launch_bounds__(1024) void key_range_kernel(const uint32_t* __restrict__ blk_min,
+                                                         const uint32_t* __restrict__ blk_max, int nb,
+                                                         SelectState* __restrict__ sel) {
+  __shared__ uint32_t lmin[16], lmax[16];
+  uint32_t kmin = 0xFFFFFFFFu, kmax = 0;
+  for (int b = threadIdx.x; b < nb; b += 1024) { kmin = min(kmin, blk_min[b]); kmax = max(kmax, blk_max[b]); }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    kmin = min(kmin, (uint32_t)__shfl_xor(kmin, o));
+    kmax = max(kmax, (uint32_t)__shfl_xor(kmax, o));
+  }
+  if ((threadIdx.x & 63) == 0) { lmin[threadIdx.x >> 6] = kmin; lmax[threadIdx.x >> 6] = kmax; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int w = 1; w < 16; w++) { kmin = min(kmin, lmin[w]); kmax = max(kmax, lmax[w]); }
+    sel->kmin = kmin; sel->kmax = kmax;
+  }
+}
+
+size_t tri_keys_blocks(uint64_t E) {
+  const uint64_t per = 256 / TG;
+  const uint64_t nb = (E + per - 1) / per;
+  return (size_t)(nb < (uint64_t)TK_MAX_BLOCKS ? nb : (uint64_t)TK_MAX_BLOCKS);
 }
 
 void launch_tri_keys(const Graph& g, const uint64_t* edge_off, const uint32_t* ei, const uint32_t* ej,
                      const float* es, const uint64_t* toff, uint64_t E, int rank_mode, uint32_t* wkey,
-                     SelectState* s, hipStream_t st) {
+                     uint32_t* blk_minmax, SelectState* s, hipStream_t st) {
   if (E == 0) return;
-  const uint64_t per = 256 / TG;
-  hipLaunchKernelGGL(tri_keys_kernel, dim3((unsigned)((E + per - 1) / per)), dim3(256), 0, st, g.bits, g.W, g.deg,
-                     edge_off, ei, ej, es, toff, E, rank_mode, wkey, s);
+  const int nb = (int)tri_keys_blocks(E);
+  hipLaunchKernelGGL(tri_keys_kernel, dim3(nb), dim3(256), 0, st, g.bits, g.W, g.deg, edge_off, ei, ej, es, toff, E,
+                     rank_mode, wkey, blk_minmax, blk_minmax + TK_MAX_BLOCKS);
+  hipLaunchKernelGGL(key_range_kernel, dim3(1), dim3(1024), 0, st, blk_minmax, blk_minmax + TK_MAX_BLOCKS, nb, s);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -229,6 +261,20 @@ __device__ __forceinline__ SelWindow select_window(const SelectState* sel) {
   return w;
 }
 
+__device__ __forceinline__ void hist_add(uint32_t* lh, bool in, uint32_t bin) {
+  // wave-uniform fast path: heavy ties put a whole wave in one bin (one LDS atomic instead of a 64-way conflict)
+  const uint32_t b = in ? bin : 0xFFFFFFFFu;
+  const uint32_t b0 = __builtin_amdgcn_readfirstlane(b);
+  const uint64_t same = __ballot(b == b0);
+  const uint64_t active = __ballot(true);
+  if (same == active) {
+    if (b0 != 0xFFFFFFFFu && (threadIdx.x & 63) == (unsigned)__builtin_ctzll(active))
+      atomicAdd(&lh[b0], (uint32_t)__popcll(active));
+  } else if (in) {
+    atomicAdd(&lh[b], 1u);
+  }
+}
+
 __global__ __launch_bounds__(SEL_THREADS) void select_hist_kernel(const uint32_t* __restrict__ wkey, uint64_t M,
                                                                   SelectState* __restrict__ sel) {
   __shared__ uint32_t lh[SEL_BINS];
@@ -237,22 +283,22 @@ __global__ __launch_bounds__(SEL_THREADS) void select_hist_kernel(const uint32_t
   __syncthreads();
   const SelWindow win = select_window(sel);
   const uint64_t width = 1ull << win.wbits;
+  const uint64_t M4 = M >> 2;  // whole uint4 groups (wkey comes from hipMalloc: 16-byte aligned)
+  const uint4* __restrict__ wkey4 = reinterpret_cast<const uint4*>(wkey);
   const uint64_t stride = (uint64_t)gridDim.x * SEL_THREADS;
-  for (uint64_t idx = (uint64_t)blockIdx.x * SEL_THREADS + threadIdx.x; idx < M; idx += stride) {
-    const uint32_t key = wkey[idx];
-    const uint64_t rel = (uint64_t)key - (uint64_t)win.lo;  // wraps huge when key < lo
-    const bool in = (key >= win.lo) && (rel < width);
-    // wave-uniform fast path: heavy ties put a whole wave in one bin
-    const uint32_t b = in ? (uint32_t)(rel >> win.shift) : 0xFFFFFFFFu;
-    const uint32_t b0 = __builtin_amdgcn_readfirstlane(b);
-    const uint64_t same = __ballot(b == b0);
-    const uint64_t active = __ballot(true);
-    if (same == active) {
-      if (b0 != 0xFFFFFFFFu && (threadIdx.x & 63) == (unsigned)__builtin_ctzll(active))
-        atomicAdd(&lh[b0], (uint32_t)__popcll(active));
-    } else if (in) {
-      atomicAdd(&lh[b], 1u);
+  for (uint64_t q = (uint64_t)blockIdx.x * SEL_THREADS + threadIdx.x; q < M4; q += stride) {
+    const uint4 k4 = wkey4[q];
+    const uint32_t ks[4] = {k4.x, k4.y, k4.z, k4.w};
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+      const uint64_t rel = (uint64_t)ks[c] - (uint64_t)win.lo;  // wraps huge when key < lo
+      hist_add(lh, (ks[c] >= win.lo) && (rel < width), (uint32_t)(rel >> win.shift));
     }
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (M & 3)) {  // tail
+    const uint32_t key = wkey[(M4 << 2) + threadIdx.x];
+    const uint64_t rel = (uint64_t)key - (uint64_t)win.lo;
+    if ((key >= win.lo) && (rel < width)) atomicAdd(&lh[(uint32_t)(rel >> win.shift)], 1u);
   }
   __syncthreads();
   for (int b = threadIdx.x; b < SEL_BINS; b += SEL_THREADS) {
@@ -301,6 +347,7 @@ void launch_select_rounds(const uint32_t* wkey, uint64_t M, SelectState* s, hipS
   if (M == 0) return;
   uint64_t blocks = (M + (uint64_t)SEL_THREADS * SEL_ITEMS - 1) / ((uint64_t)SEL_THREADS * SEL_ITEMS);
   if (blocks > 2048) blocks = 2048;
+  if (blocks == 0) blocks = 1;
   for (int round = 0; round < 3; round++) {
     hipLaunchKernelGGL(select_hist_kernel, dim3((unsigned)blocks), dim3(SEL_THREADS), 0, st, wkey, M, s);
     hipLaunchKernelGGL(select_pick_kernel, dim3(1), dim3(256), 0, st, s);
@@ -311,10 +358,23 @@ void launch_select_rounds(const uint32_t* wkey, uint64_t M, SelectState* s, hipS
 // 5. compaction in ordinal order
 // ------------------------------------------------------------------------------------------------
 constexpr int CP_THREADS = 256;
-constexpr int CP_ITEMS = 16;
+constexpr int CP_ITEMS = 4;  // one 16-byte load per thread: every wave reads 1 KiB contiguous
 constexpr int CP_TILE = CP_THREADS * CP_ITEMS;
 
 size_t compact_blocks(uint64_t M) { return (size_t)((M + CP_TILE - 1) / CP_TILE); }
+
+__device__ __forceinline__ void load_tile_keys(const uint32_t* __restrict__ wkey, uint64_t M, uint64_t base,
+                                               uint32_t keys[CP_ITEMS], int& valid) {
+  if (base + CP_ITEMS <= M) {
+    const uint4 k4 = *reinterpret_cast<const uint4*>(wkey + base);
+    keys[0] = k4.x; keys[1] = k4.y; keys[2] = k4.z; keys[3] = k4.w;
+    valid = CP_ITEMS;
+  } else {
+    valid = base < M ? (int)(M - base) : 0;
+#pragma unroll
+    for (int k = 0; k < CP_ITEMS; k++) keys[k] = (k < valid) ? wkey[base + k] : 0u;
+  }
+}
 
 __global__ __launch_bounds__(CP_THREADS) void compact_count_kernel(const uint32_t* __restrict__ wkey, uint64_t M,
                                                                    const SelectState* __restrict__ sel,
@@ -323,11 +383,13 @@ __global__ __launch_bounds__(CP_THREADS) void compact_count_kernel(const uint32_
   __shared__ uint32_t lds[2][4];
   const uint32_t kstar = sel->kstar;
   const uint64_t base = (uint64_t)blockIdx.x * CP_TILE + (uint64_t)threadIdx.x * CP_ITEMS;
+  uint32_t keys[CP_ITEMS];
+  int valid;
+  load_tile_keys(wkey, M, base, keys, valid);
   uint32_t g = 0, q = 0;
 #pragma unroll
-  for (int k = 0; k < CP_ITEMS; k++) {
-    if (base + k < M) { const uint32_t key = wkey[base + k]; g += key > kstar; q += key == kstar; }
-  }
+  for (int k = 0; k < CP_ITEMS; k++)
+    if (k < valid) { g += keys[k] > kstar; q += keys[k] == kstar; }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) { g += __shfl_xor(g, o); q += __shfl_xor(q, o); }
   if ((threadIdx.x & 63) == 0) { lds[0][threadIdx.x >> 6] = g; lds[1][threadIdx.x >> 6] = q; }
@@ -347,6 +409,8 @@ void launch_compact_count(const uint32_t* wkey, uint64_t M, const SelectState* s
 
 __global__ __launch_bounds__(CP_THREADS) void compact_write_kernel(const uint32_t* __restrict__ wkey, uint64_t M,
                                                                    const SelectState* __restrict__ sel,
+                                                                   const uint32_t* __restrict__ blk_gt,
+                                                                   const uint32_t* __restrict__ blk_eq,
                                                                    const uint64_t* __restrict__ off_gt,
                                                                    const uint64_t* __restrict__ off_eq,
                                                                    uint64_t* __restrict__ sel_ord,
@@ -354,22 +418,25 @@ __global__ __launch_bounds__(CP_THREADS) void compact_write_kernel(const uint32_
   __shared__ uint64_t lds[8];
   const uint32_t kstar = sel->kstar;
   const uint64_t need_eq = sel->need_eq;
+  // most tiles hold nothing to emit (T << M): skip them on the block counts alone, without touching the keys
+  const uint64_t eq0 = off_eq[blockIdx.x];
+  if (blk_gt[blockIdx.x] == 0 && (blk_eq[blockIdx.x] == 0 || eq0 >= need_eq)) return;
   const uint64_t base = (uint64_t)blockIdx.x * CP_TILE + (uint64_t)threadIdx.x * CP_ITEMS;
   uint32_t keys[CP_ITEMS];
+  int valid;
+  load_tile_keys(wkey, M, base, keys, valid);
   uint32_t g = 0, q = 0;
 #pragma unroll
-  for (int k = 0; k < CP_ITEMS; k++) {
-    keys[k] = (base + k < M) ? wkey[base + k] : 0u;
-    if (base + k < M) { g += keys[k] > kstar; q += keys[k] == kstar; }
-  }
+  for (int k = 0; k < CP_ITEMS; k++)
+    if (k < valid) { g += keys[k] > kstar; q += keys[k] == kstar; }
   uint64_t tot;
-  // pack both counts in one u64 scan: gt in the high half, eq in the low half (each < 2^32 per block)
-  uint64_t ex = block_exscan_u64(((uint64_t)g << 32) | q, lds, &tot);
+  // both counts ride one u64 scan: gt in the high half, eq in the low half (each <= 1024 per tile)
+  const uint64_t ex = block_exscan_u64(((uint64_t)g << 32) | q, lds, &tot);
   uint64_t gt_before = off_gt[blockIdx.x] + (ex >> 32);
-  uint64_t eq_before = off_eq[blockIdx.x] + (ex & 0xFFFFFFFFull);
+  uint64_t eq_before = eq0 + (ex & 0xFFFFFFFFull);
 #pragma unroll
   for (int k = 0; k < CP_ITEMS; k++) {
-    if (base + k < M) {
+    if (k < valid) {
       const uint32_t key = keys[k];
       const bool isg = key > kstar, isq = key == kstar;
       if (isg || (isq && eq_before < need_eq)) {
@@ -383,11 +450,12 @@ __global__ __launch_bounds__(CP_THREADS) void compact_write_kernel(const uint32_
   }
 }
 
-void launch_compact_write(const uint32_t* wkey, uint64_t M, const SelectState* s, const uint64_t* off_gt,
-                          const uint64_t* off_eq, uint64_t* sel_ord, uint64_t* sortkey, hipStream_t st) {
+void launch_compact_write(const uint32_t* wkey, uint64_t M, const SelectState* s, const uint32_t* blk_gt,
+                          const uint32_t* blk_eq, const uint64_t* off_gt, const uint64_t* off_eq,
+                          uint64_t* sel_ord, uint64_t* sortkey, hipStream_t st) {
   if (M == 0) return;
   hipLaunchKernelGGL(compact_write_kernel, dim3((unsigned)compact_blocks(M)), dim3(CP_THREADS), 0, st, wkey, M, s,
-                     off_gt, off_eq, sel_ord, sortkey);
+                     blk_gt, blk_eq, off_gt, off_eq, sel_ord, sortkey);
 }
 
 // ------------------------------------------------------------------------------------------------
