@@ -1,0 +1,81 @@
+"""CPU suite, part 2: the C-ABI library builds, loads and exports exactly what include/saccot.h declares —
+no compute call is made (there is no GPU here), and without a GPU the library must fail loudly."""
+import ctypes as C
+import os
+import re
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared():
+    text = open(os.path.join(ROOT, "include", "saccot.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(sc_[a-z_]+)\s*\(", text)))
+
+
+def test_header_exports_present(pkg):
+    names = _declared()
+    assert len(names) >= 16 and "sc_register" in names and "sc_hypothesize_device" in names
+    L = pkg.load_library()
+    for n in names:
+        assert hasattr(L, n), f"libsaccot.so does not export {n}"
+    assert sorted(pkg.api.EXPORTS) == names
+
+
+def test_header_is_plain_c():
+    src = '#include "saccot.h"\nint main(void){ sc_params p; sc_default_params(&p); return (int)p.size; }\n'
+    r = subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", "-fsyntax-only", "-I", os.path.join(ROOT, "include"),
+                        "-x", "c", "-"], input=src.encode(), capture_output=True)
+    assert r.returncode == 0, r.stderr.decode()
+
+
+def test_struct_layouts_match(pkg):
+    L = pkg.load_library()
+    p = pkg.ScParams()
+    L.sc_default_params(C.byref(p))
+    assert p.size == C.sizeof(pkg.ScParams) == 56
+    assert (p.t_cmp, p.max_triangles, p.shard_world, p.shard_block) == (pytest.approx(0.9), 50000, 1, 1024)
+    # sc_stats: compile a probe against the header and compare sizeof
+    exe = os.path.join(ROOT, "tests", ".abi_probe")
+    src = '#include <stdio.h>\n#include "saccot.h"\nint main(void){printf("%zu %zu", sizeof(sc_params), sizeof(sc_stats));return 0;}\n'
+    subprocess.run(["gcc", "-I", os.path.join(ROOT, "include"), "-x", "c", "-", "-o", exe], input=src.encode(), check=True)
+    try:
+        a, b = subprocess.check_output([exe]).decode().split()
+    finally:
+        os.remove(exe)
+    assert int(a) == C.sizeof(pkg.ScParams) and int(b) == C.sizeof(pkg.ScStats)
+
+
+def test_version_and_strerror(pkg):
+    L = pkg.load_library()
+    assert L.sc_version() >> 16 == 0
+    assert L.sc_strerror(0) == b"ok" and b"hypothesis" in L.sc_strerror(-5) and L.sc_strerror(-99) == b"unknown status"
+
+
+def test_no_gpu_means_loud_failure(pkg):
+    """The product has no CPU fallback: without a HIP device sc_create must fail (SC_EHIP) and the Python
+    layer must raise.  (Skipped on a GPU box, where the GPU suite exercises the real path.)"""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    with pytest.raises(pkg.SacCotError) as e:
+        pkg.Registrar(0)
+    assert e.value.status == -3
+
+
+def test_product_never_touches_the_oracle():
+    """The oracle is test infrastructure: nothing under sac-cot_amd/ may import, load or link it."""
+    pk = os.path.join(ROOT, "sac-cot_amd")
+    for d, _, files in os.walk(pk):
+        for f in files:
+            if f.endswith((".py", ".hip", ".hpp", ".h", ".cpp")):
+                text = open(os.path.join(d, f)).read()
+                code = "\n".join(line for line in text.splitlines()
+                                 if not line.lstrip().startswith(("//", "#", "*", "/*", '"""')))
+                assert "libsaccot_oracle" not in code and "saccot_oracle" not in code, f
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", text, flags=re.M), f
+    out = subprocess.check_output(["readelf", "-d", os.path.join(pk, "libsaccot.so")]).decode()
+    assert "oracle" not in out

@@ -1,0 +1,86 @@
+"""CPU suite, part 3: the multi-GPU layer without GPUs.
+
+Host logic (round-robin block dealing, key encode/decode) is checked directly; the N > 1 path — every rank scores its
+share of the replicated ranked list, one MAX all-reduce of the 8-byte key, every rank decodes the same winner — runs
+as two real processes over torch.distributed's gloo backend, with the CPU restatement standing in for the kernels
+(tests may call the oracle; the product never does)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+
+
+@pytest.mark.parametrize("t_eff,block,world", [(0, 1024, 1), (1, 1024, 4), (1023, 256, 3), (50000, 1000, 8),
+                                               (400000, 1000, 8), (777, 64, 5), (4096, 1024, 4)])
+def test_block_dealing_partitions_the_ranked_list(pkg, t_eff, block, world):
+    sh = pkg.shard
+    seen = []
+    for r in range(world):
+        idx = sh.local_indices(t_eff, block, r, world)
+        assert len(idx) == sh.local_count(t_eff, block, r, world)
+        assert np.all(idx < t_eff) and np.all(np.diff(idx) > 0)
+        seen.append(idx)
+    allidx = np.sort(np.concatenate(seen)) if seen else np.zeros(0)
+    assert np.array_equal(allidx, np.arange(t_eff))                   # every hypothesis scored exactly once
+    if t_eff >= block * world:
+        first = [s[0] // block for s in seen]
+        assert first == list(range(world))                              # every rank starts at the top of the list
+
+
+def test_key_encoding_orders_like_the_spec(pkg):
+    sh = pkg.shard
+    assert sh.encode_key(0, 5) == 0
+    assert sh.decode_key(sh.encode_key(734, 22370)) == (734, 22370)
+    assert sh.encode_key(10, 99) > sh.encode_key(9, 0)                  # count dominates
+    assert sh.encode_key(10, 3) > sh.encode_key(10, 4)                  # ties -> better (lower) rank index
+    assert sh.encode_key(2**31 - 1, 0) < 2**63                          # fits torch int64
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, block, out_dir):
+    import sys
+    import torch
+    import torch.distributed as dist
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import __graft_entry__ as ge
+    pkg = ge.load_package(); O = ge.load_oracle()
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    cfg, sc = pkg.synth.make_config_scene("C0")
+    kw = cfg.params()
+    # stages A + B replicated on every rank (deterministic -> identical ranked lists)
+    S, bits, deg = O.compat(sc.src, sc.tgt, kw["sigma"], kw["t_cmp"], kw["min_len"], kw["tau"])
+    tri, _, _ = O.triangles(S, bits, deg, kw["max_triangles"], 0)
+    mine = pkg.shard.local_indices(len(tri), block, rank, world)
+    Rt = O.kabsch3(sc.src, sc.tgt, tri[mine])
+    cnt = O.score(sc.src, sc.tgt, Rt, kw["tau"])
+    key = torch.tensor([O.best_key(cnt, mine.astype(np.uint32))], dtype=torch.int64)
+    pkg.shard.allreduce_best(key)                                       # the one collective of the path
+    count, widx = pkg.shard.decode_key(int(key.item()))
+    Rt_w = O.kabsch3(sc.src, sc.tgt, tri[widx:widx + 1])[0]            # every rank re-solves the winner locally
+    mask = O.mask(sc.src, sc.tgt, Rt_w, kw["tau"])
+    np.savez(os.path.join(out_dir, f"rank{rank}.npz"), key=int(key.item()), Rt=Rt_w, mask=mask, scored=len(mine))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,block", [(2, 32), (2, 1024)])
+def test_two_ranks_gloo_agree_with_single_rank(pkg, O, tmp_path, world, block):
+    import torch.multiprocessing as mp
+    port = _free_port()
+    mp.spawn(_worker, args=(world, port, block, str(tmp_path)), nprocs=world, join=True)
+    cfg, sc = pkg.synth.make_config_scene("C0")
+    ref = O.register(sc.src, sc.tgt, threads=1, **cfg.params())
+    outs = [np.load(tmp_path / f"rank{r}.npz") for r in range(world)]
+    assert sum(int(o["scored"]) for o in outs) == ref["t_eff"]
+    for o in outs:
+        assert pkg.shard.decode_key(int(o["key"])) == (ref["best_count"], ref["best_rank"])
+        assert o["Rt"].tobytes() == np.concatenate([ref["R"].ravel(), ref["t"]]).astype(np.float32).tobytes()
+        assert np.array_equal(o["mask"], ref["mask"])
