@@ -89,6 +89,7 @@ typedef struct sc_stats {
   float    us_stage;        /* input staging (layout -> padded planes, finiteness check)                */
   float    us_compat;       /* stage A: the compat_rows kernel alone                                    */
   float    us_triangles;    /* stage B: every kernel of it plus its two 8-byte read-backs               */
+  float    us_trikeys;      /* stage B: the tri_keys kernel alone (part of us_triangles)                */
   float    us_kabsch;       /* stage C1                                                                 */
   float    us_score;        /* stage C2: the score kernel alone                                         */
   float    us_argmax;       /* stage C2: partial-count reduction + arg-max key                          */

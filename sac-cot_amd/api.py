@@ -37,6 +37,7 @@ class ScStats(C.Structure):
     _fields_ = [("size", C.c_uint32), ("n", C.c_uint32), ("edges", C.c_uint64), ("tri_total", C.c_uint64),
                 ("tri_kept", C.c_uint32), ("tri_scored", C.c_uint32), ("best_rank", C.c_uint32),
                 ("best_count", C.c_uint32), ("us_stage", C.c_float), ("us_compat", C.c_float), ("us_triangles", C.c_float),
+                ("us_trikeys", C.c_float),
                 ("us_kabsch", C.c_float), ("us_score", C.c_float), ("us_argmax", C.c_float), ("us_mask", C.c_float),
                 ("us_total", C.c_float),
                 ("workspace_bytes", C.c_uint64)]

@@ -25,7 +25,7 @@ struct Buf {
   template <class T> T* as() const { return static_cast<T*>(p); }
 };
 
-constexpr int N_EVENTS = 10;
+constexpr int N_EVENTS = 12;
 
 }  // namespace
 
@@ -52,6 +52,7 @@ struct sc_ctx {
   Shard sh{};
   bool have_hyp = false;
   bool timing = false;
+  bool timed_trikeys = false;
 };
 
 namespace {
@@ -202,9 +203,12 @@ int run_triangles(sc_ctx* c, const sc_params* p) {
   ENSURE(c, c->trikey, (size_t)T_eff * 4);
   SelectState* sel = c->sel.as<SelectState>();
   launch_select_init(sel, T_eff, st);
+  if (c->timing) HIPCHK(c, hipEventRecord(c->ev[9], st));
   launch_tri_keys(g, c->edge_off.as<uint64_t>(), c->ei.as<uint32_t>(), c->ej.as<uint32_t>(), c->es.as<float>(),
                   c->toff.as<uint64_t>(), E, p->rank_mode, c->wkey.as<uint32_t>(), c->blk_minmax.as<uint32_t>(), sel,
                   st);
+  if (c->timing) HIPCHK(c, hipEventRecord(c->ev[10], st));
+  c->timed_trikeys = c->timing;
   launch_select_rounds(c->wkey.as<uint32_t>(), M, sel, st);
   launch_compact_count(c->wkey.as<uint32_t>(), M, sel, c->blk_gt.as<uint32_t>(), c->blk_eq.as<uint32_t>(), st);
   launch_scan_u32(c->blk_gt.as<uint32_t>(), nb, c->off_gt.as<uint64_t>(), c->scan_tmp.p, st);
@@ -341,6 +345,7 @@ int sc_hypothesize_device(sc_ctx* c, const float* d_src, const float* d_tgt, int
   if (rc) return rc;
   HIPCHK(c, hipSetDevice(c->device));
   c->have_hyp = false;
+  c->timed_trikeys = false;
   c->timing = (p->flags & SC_FLAG_TIMING) != 0;
   c->cap_bytes = p->max_workspace ? p->max_workspace : (64ull << 30);
   c->dv = derive(p);
@@ -379,6 +384,7 @@ int sc_hypothesize_device(sc_ctx* c, const float* d_src, const float* d_tgt, int
       stats->us_stage = ev_us(c, 0, 1);
       stats->us_compat = ev_us(c, 1, 2);
       stats->us_triangles = ev_us(c, 2, 3);  // includes its two 8-byte read-backs
+      stats->us_trikeys = c->timed_trikeys ? ev_us(c, 9, 10) : 0.f;
       stats->us_kabsch = ev_us(c, 3, 4);
       stats->us_score = ev_us(c, 4, 5);
       stats->us_argmax = ev_us(c, 5, 6);

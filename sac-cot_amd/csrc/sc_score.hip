@@ -109,27 +109,41 @@ void launch_rt_to_soa(const float* Rt, uint32_t T, uint32_t ld_local, float* RtS
 // C2
 // ------------------------------------------------------------------------------------------------
 constexpr int SCORE_THREADS = 256;
-constexpr int SCORE_PC = 1024;  // correspondences per chunk (LDS: 24 KiB)
+constexpr int SCORE_PC = 512;  // correspondences per chunk (LDS: 12 KiB per workgroup, 8 workgroups per CU)
 
 uint32_t score_chunks(int n) { return (uint32_t)((n + SCORE_PC - 1) / SCORE_PC); }
-static inline int score_chunk_points(int n) {  // equalised chunk length, multiple of 4
+static inline int score_chunk_points(int n) {  // equalised chunk length, multiple of 4, <= SCORE_PC
   const int c = (int)score_chunks(n);
   const int per = (n + c - 1) / c;
   return (per + 3) & ~3;
 }
 
-__global__ __launch_bounds__(SCORE_THREADS) void score_kernel(const float* __restrict__ planes, int n, int ld,
-                                                              const float* __restrict__ RtSoA, uint32_t ld_local,
-                                                              float tau2, int chunk_pts,
-                                                              uint32_t* __restrict__ partial) {
+// One inlier test, written so that hipcc keeps 17 single-issue VALU ops (build.py passes -fno-slp-vectorize:
+// SLP packing turns the chain into v_pk_* plus ~5 v_mov per test, which is slower on gfx950).
+__device__ __forceinline__ uint32_t inlier_bit(const float (&M)[12], const float4 a, const float2 b, float tau2) {
+  return resid2(M, a.x, a.y, a.z, a.w, b.x, b.y) < tau2 ? 1u : 0u;
+}
+
+// __launch_bounds__(256, 8): 8 waves per SIMD (<= 64 VGPRs) — plain v_fma_f32 needs that occupancy to reach its
+// issue rate on gfx950 (measured: 45 / 80 / 99 / 117 TFLOP/s at 1 / 2 / 4 / 8 waves per SIMD, tools/ubench_valu.hip)
+__global__ __launch_bounds__(SCORE_THREADS, 8) void score_kernel(const float* __restrict__ planes, int n, int ld,
+                                                                 const float* __restrict__ RtSoA, uint32_t ld_local,
+                                                                 float tau2, int chunk_pts,
+                                                                 uint32_t* __restrict__ partial) {
   __shared__ float4 pA[SCORE_PC];  // px py pz qx
   __shared__ float2 pB[SCORE_PC];  // qy qz
   const int m0 = blockIdx.y * chunk_pts;
   const int cnt_pts = min(chunk_pts, n - m0);
-  for (int t = threadIdx.x; t < cnt_pts; t += SCORE_THREADS) {
+  const int padded = (cnt_pts + 3) & ~3;  // <= chunk_pts <= SCORE_PC (chunk_pts is a multiple of 4)
+  for (int t = threadIdx.x; t < padded; t += SCORE_THREADS) {
     const int m = m0 + t;
-    pA[t] = make_float4(planes[m], planes[(size_t)ld + m], planes[2 * (size_t)ld + m], planes[3 * (size_t)ld + m]);
-    pB[t] = make_float2(planes[4 * (size_t)ld + m], planes[5 * (size_t)ld + m]);
+    if (t < cnt_pts) {
+      pA[t] = make_float4(planes[m], planes[(size_t)ld + m], planes[2 * (size_t)ld + m], planes[3 * (size_t)ld + m]);
+      pB[t] = make_float2(planes[4 * (size_t)ld + m], planes[5 * (size_t)ld + m]);
+    } else {  // sentinel: p = 0, q = 1e30 -> residual ~1e30, squared = +inf, never < tau2, never NaN
+      pA[t] = make_float4(0.f, 0.f, 0.f, 1e30f);
+      pB[t] = make_float2(1e30f, 1e30f);
+    }
   }
   const uint32_t l = blockIdx.x * SCORE_THREADS + threadIdx.x;
   float M[12];
@@ -137,16 +151,17 @@ __global__ __launch_bounds__(SCORE_THREADS) void score_kernel(const float* __res
   for (int c = 0; c < 12; c++) M[c] = RtSoA[(size_t)c * ld_local + l];
   const bool ok = finite12(M);
   __syncthreads();
-  uint32_t cnt = 0;
-  int t = 0;
-#pragma unroll 4
-  for (; t < cnt_pts; t++) {
-    const float4 a = pA[t];
-    const float2 b = pB[t];
-    const float d2 = resid2(M, a.x, a.y, a.z, a.w, b.x, b.y);
-    cnt += (d2 < tau2) ? 1u : 0u;
+  uint32_t c0 = 0, c1 = 0, c2 = 0, c3 = 0;
+#pragma clang loop vectorize(disable) interleave(disable) unroll(disable)
+  for (int t = 0; t < padded; t += 4) {
+    const float4 a0 = pA[t], a1 = pA[t + 1], a2 = pA[t + 2], a3 = pA[t + 3];
+    const float2 b0 = pB[t], b1 = pB[t + 1], b2 = pB[t + 2], b3 = pB[t + 3];
+    c0 += inlier_bit(M, a0, b0, tau2);
+    c1 += inlier_bit(M, a1, b1, tau2);
+    c2 += inlier_bit(M, a2, b2, tau2);
+    c3 += inlier_bit(M, a3, b3, tau2);
   }
-  partial[(size_t)blockIdx.y * ld_local + l] = ok ? cnt : 0u;
+  partial[(size_t)blockIdx.y * ld_local + l] = ok ? (c0 + c1) + (c2 + c3) : 0u;
 }
 
 __global__ __launch_bounds__(256) void score_argmax_kernel(const uint32_t* __restrict__ partial, uint32_t n_chunks,
