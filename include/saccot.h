@@ -54,7 +54,10 @@ extern "C" {
 #define SC_RANK_DEGREE 1   /* deg_i + deg_j + deg_k, u32, descending                         */
 
 /* flags */
-#define SC_FLAG_TIMING  1u  /* record a HIP event pair around every stage and fill sc_stats.us_*      */
+#define SC_FLAG_TIMING       1u /* record a HIP event pair around every stage and fill sc_stats.us_*          */
+#define SC_FLAG_EXACT_TOTAL  2u /* sc_stats.tri_total = 3-cliques of the WHOLE graph (one extra counting pass);  */
+                                /* default: 3-cliques of the pruned graph the top-T search actually enumerated   */
+#define SC_FLAG_NO_PRUNE     4u /* disable the certified pruning of stage B (results are identical either way)    */
 
 typedef struct sc_ctx sc_ctx;
 
@@ -81,7 +84,7 @@ typedef struct sc_stats {
   uint32_t size;            /* = sizeof(sc_stats)                                                       */
   uint32_t n;               /* correspondences                                                          */
   uint64_t edges;           /* undirected edges of the compatibility graph                              */
-  uint64_t tri_total;       /* 3-cliques in the graph                                                   */
+  uint64_t tri_total;       /* 3-cliques enumerated (whole graph with SC_FLAG_EXACT_TOTAL / NO_PRUNE)   */
   uint32_t tri_kept;        /* T_eff = min(T, tri_total)                                                */
   uint32_t tri_scored;      /* hypotheses scored by THIS rank                                           */
   uint32_t best_rank;       /* rank index (0-based) of the winning triangle in the ranked list          */

@@ -40,19 +40,22 @@ struct sc_ctx {
   uint64_t* pinned = nullptr;  // 8 x u64 host-pinned read-back area
 
   // workspace
-  Buf in_src, in_tgt, planes, S, bits, deg, degp, edge_off, scan_tmp, ei, ej, es, tcnt, toff, wkey, sel, blk_gt,
-      blk_eq, blk_minmax, off_gt, off_eq, sel_ord, sortkey, sorted, sort_tmp, tri, trikey, rt, rt_aos, partial, cnt, key, rt12,
+  Buf in_src, in_tgt, planes, S, bits, deg, degp, wpre, ebase, edge_off, scan_tmp, ei, ej, es, tcnt, toff, wkey, sel, blk_gt,
+      blk_eq, blk_minmax, bits2, prune_hist, smin, off_gt, off_eq, sel_ord, sortkey, sorted, sort_tmp, tri, trikey, rt, rt_aos, partial, cnt, key, rt12,
       mask, flag;
 
   // state of the last hypothesize call (consumed by finalize)
   int n = 0, ld = 0;
-  uint64_t E = 0, M = 0;
+  uint64_t E = 0, M = 0, M_total = 0;
+  bool pruned = false;
   uint32_t T_eff = 0;
   Derived dv{};
   Shard sh{};
   bool have_hyp = false;
   bool timing = false;
   bool timed_trikeys = false;
+  const uint64_t* mbits = nullptr;
+  const float* smin_ptr = nullptr;
 };
 
 namespace {
@@ -122,7 +125,8 @@ inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
 
 Points points_of(const sc_ctx* c) { return Points{c->planes.as<float>(), c->n, c->ld}; }
 Graph graph_of(const sc_ctx* c) {
-  return Graph{c->bits.as<uint64_t>(), c->S.as<float>(), c->deg.as<uint32_t>(), c->n, c->ld, c->ld >> 6};
+  return Graph{c->bits.as<uint64_t>(), c->S.as<float>(), c->deg.as<uint32_t>(), c->degp.as<uint32_t>(),
+               c->wpre.as<uint32_t>(), c->n, c->ld, c->ld >> 6};
 }
 
 int rec(sc_ctx* c, int i) {
@@ -148,8 +152,9 @@ int run_compat(sc_ctx* c) {
   ENSURE(c, c->bits, n * W * sizeof(uint64_t));
   ENSURE(c, c->deg, n * sizeof(uint32_t));
   ENSURE(c, c->degp, n * sizeof(uint32_t));
+  ENSURE(c, c->wpre, n * W * sizeof(uint32_t));
   launch_compat(points_of(c), c->dv, c->S.as<float>(), c->bits.as<uint64_t>(), c->deg.as<uint32_t>(),
-                c->degp.as<uint32_t>(), c->stream);
+                c->degp.as<uint32_t>(), c->wpre.as<uint32_t>(), c->stream);
   return SC_OK;
 }
 
@@ -166,21 +171,51 @@ int run_triangles(sc_ctx* c, const sc_params* p) {
   HIPCHK(c, hipStreamSynchronize(st));
   if ((uint32_t)c->pinned[1] != 0) { c->last_error = "non-finite input coordinate"; return SC_EINVAL; }
   const uint64_t E = c->E = c->pinned[0];
-  c->M = 0; c->T_eff = 0;
+  c->M = 0; c->M_total = 0; c->T_eff = 0; c->pruned = false;
   if (E == 0) return SC_OK;
   ENSURE(c, c->ei, E * 4);
   ENSURE(c, c->ej, E * 4);
-  ENSURE(c, c->es, E * 4);
+  ENSURE(c, c->es, (E + 2) * 4);  // +1: the 4-way unrolled gathers of idle slots may touch index E
   ENSURE(c, c->tcnt, E * 4);
+  ENSURE(c, c->ebase, n * 4);
   ENSURE(c, c->toff, (E + 1) * 8);
   ENSURE(c, c->scan_tmp, scan_temp_bytes(E));
   const Graph g = graph_of(c);
-  launch_edge_fill(g, c->edge_off.as<uint64_t>(), c->ei.as<uint32_t>(), c->ej.as<uint32_t>(), c->es.as<float>(), st);
-  launch_tri_count(g, c->ei.as<uint32_t>(), c->ej.as<uint32_t>(), E, c->tcnt.as<uint32_t>(), st);
+  launch_edge_fill(g, c->edge_off.as<uint64_t>(), c->ei.as<uint32_t>(), c->ej.as<uint32_t>(), c->es.as<float>(),
+                   c->ebase.as<uint32_t>(), st);
+  // certified pruning (sc_tri.hip §3b): weight ranking only; pointless on tiny graphs
+  const bool prune = (p->rank_mode == SC_RANK_WEIGHT) && !(p->flags & SC_FLAG_NO_PRUNE) && E >= 4096;
+  c->pruned = prune;
+  const uint64_t* mbits = g.bits;
+  const float* smin = nullptr;
+  bool have_total = false;
+  if (prune) {
+    ENSURE(c, c->bits2, (size_t)c->n * g.W * sizeof(uint64_t));
+    ENSURE(c, c->prune_hist, 256 * 4);
+    ENSURE(c, c->smin, 64);
+    if (p->flags & SC_FLAG_EXACT_TOTAL) {  // statistics only: 3-cliques of the whole graph
+      launch_tri_count(g, g.bits, c->es.as<float>(), nullptr, c->ei.as<uint32_t>(), c->ej.as<uint32_t>(), E,
+                       c->tcnt.as<uint32_t>(), st);
+      launch_scan_u32(c->tcnt.as<uint32_t>(), E, c->toff.as<uint64_t>(), c->scan_tmp.p, st);
+      HIPCHK(c, hipMemcpyAsync(&c->pinned[4], c->toff.as<uint64_t>() + E, 8, hipMemcpyDeviceToHost, st));
+      have_total = true;
+    }
+    // the smallest possible weight is ~3 t_cmp (every edge has s >= t_cmp up to rounding); 0.1 % slack
+    launch_prune(g, c->ebase.as<uint32_t>(), c->ei.as<uint32_t>(), c->ej.as<uint32_t>(), c->es.as<float>(), E,
+                 p->max_triangles, 3.0f * p->t_cmp * 0.999f, c->prune_hist.as<uint32_t>(), c->bits2.as<uint64_t>(),
+                 c->smin.as<float>(), st);
+    mbits = c->bits2.as<uint64_t>();
+    smin = c->smin.as<float>();
+  }
+  c->mbits = mbits;
+  c->smin_ptr = smin;
+  launch_tri_count(g, mbits, c->es.as<float>(), smin, c->ei.as<uint32_t>(), c->ej.as<uint32_t>(), E,
+                   c->tcnt.as<uint32_t>(), st);
   launch_scan_u32(c->tcnt.as<uint32_t>(), E, c->toff.as<uint64_t>(), c->scan_tmp.p, st);
-  // read-back #2: triangle count
+  // read-back #2: triangle count (of the pruned graph when pruning)
   HIPCHK(c, hipMemcpyAsync(&c->pinned[2], c->toff.as<uint64_t>() + E, 8, hipMemcpyDeviceToHost, st));
   HIPCHK(c, hipStreamSynchronize(st));
+  c->M_total = have_total ? c->pinned[4] : c->pinned[2];
   const uint64_t M = c->M = c->pinned[2];
   if (M == 0) return SC_OK;
   const uint32_t T_eff = c->T_eff = (uint32_t)(M < p->max_triangles ? M : p->max_triangles);
@@ -204,20 +239,20 @@ int run_triangles(sc_ctx* c, const sc_params* p) {
   SelectState* sel = c->sel.as<SelectState>();
   launch_select_init(sel, T_eff, st);
   if (c->timing) HIPCHK(c, hipEventRecord(c->ev[9], st));
-  launch_tri_keys(g, c->edge_off.as<uint64_t>(), c->ei.as<uint32_t>(), c->ej.as<uint32_t>(), c->es.as<float>(),
-                  c->toff.as<uint64_t>(), E, p->rank_mode, c->wkey.as<uint32_t>(), c->blk_minmax.as<uint32_t>(), sel,
+  launch_tri_keys(g, mbits, smin, c->ebase.as<uint32_t>(), c->ei.as<uint32_t>(), c->ej.as<uint32_t>(),
+                  c->es.as<float>(), c->toff.as<uint64_t>(), E, p->rank_mode, c->wkey.as<uint32_t>(), c->blk_minmax.as<uint32_t>(), sel,
                   st);
   if (c->timing) HIPCHK(c, hipEventRecord(c->ev[10], st));
   c->timed_trikeys = c->timing;
   launch_select_rounds(c->wkey.as<uint32_t>(), M, sel, st);
   launch_compact_count(c->wkey.as<uint32_t>(), M, sel, c->blk_gt.as<uint32_t>(), c->blk_eq.as<uint32_t>(), st);
-  launch_scan_u32(c->blk_gt.as<uint32_t>(), nb, c->off_gt.as<uint64_t>(), c->scan_tmp.p, st);
-  launch_scan_u32(c->blk_eq.as<uint32_t>(), nb, c->off_eq.as<uint64_t>(), c->scan_tmp.p, st);
+  launch_scan_u32_pair(c->blk_gt.as<uint32_t>(), c->off_gt.as<uint64_t>(), c->blk_eq.as<uint32_t>(),
+                       c->off_eq.as<uint64_t>(), nb, c->scan_tmp.p, st);
   launch_compact_write(c->wkey.as<uint32_t>(), M, sel, c->blk_gt.as<uint32_t>(), c->blk_eq.as<uint32_t>(),
                        c->off_gt.as<uint64_t>(), c->off_eq.as<uint64_t>(),
                        c->sel_ord.as<uint64_t>(), c->sortkey.as<uint64_t>(), st);
   launch_sort_u64(c->sortkey.as<uint64_t>(), c->sorted.as<uint64_t>(), T_eff, c->sort_tmp.p, sort_bytes, st);
-  launch_tri_decode(g, c->ei.as<uint32_t>(), c->ej.as<uint32_t>(), c->toff.as<uint64_t>(), E,
+  launch_tri_decode(g, mbits, c->ei.as<uint32_t>(), c->ej.as<uint32_t>(), c->toff.as<uint64_t>(), E,
                     c->sorted.as<uint64_t>(), c->sel_ord.as<uint64_t>(), T_eff, c->tri.as<uint32_t>(),
                     c->trikey.as<uint32_t>(), st);
   return SC_OK;
@@ -229,7 +264,7 @@ void fill_stats(const sc_ctx* c, sc_stats* s) {
   if (sz != sizeof(sc_stats)) return;
   s->n = (uint32_t)c->n;
   s->edges = c->E;
-  s->tri_total = c->M;
+  s->tri_total = c->M_total;
   s->tri_kept = c->T_eff;
   s->tri_scored = c->sh.n_local;
   s->workspace_bytes = c->held;
@@ -317,8 +352,8 @@ void sc_destroy(sc_ctx* c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
-  Buf* bufs[] = {&c->in_src, &c->in_tgt, &c->planes, &c->S, &c->bits, &c->deg, &c->degp, &c->edge_off, &c->scan_tmp,
-                 &c->ei, &c->ej, &c->es, &c->tcnt, &c->toff, &c->wkey, &c->sel, &c->blk_gt, &c->blk_eq, &c->blk_minmax, &c->off_gt,
+  Buf* bufs[] = {&c->in_src, &c->in_tgt, &c->planes, &c->S, &c->bits, &c->deg, &c->degp, &c->wpre, &c->ebase, &c->edge_off, &c->scan_tmp,
+                 &c->ei, &c->ej, &c->es, &c->tcnt, &c->toff, &c->wkey, &c->sel, &c->blk_gt, &c->blk_eq, &c->blk_minmax, &c->bits2, &c->prune_hist, &c->smin, &c->off_gt,
                  &c->off_eq, &c->sel_ord, &c->sortkey, &c->sorted, &c->sort_tmp, &c->tri, &c->trikey, &c->rt,
                  &c->rt_aos, &c->partial, &c->cnt, &c->key, &c->rt12, &c->mask, &c->flag};
   for (Buf* b : bufs) if (b->p) (void)hipFree(b->p);
@@ -494,9 +529,11 @@ int sc_triangles_host(sc_ctx* c, const float* src, const float* tgt, int64_t n, 
   c->dv = derive(p);
   if ((rc = host_to_planes(c, src, tgt, n, p))) return rc;
   if ((rc = run_compat(c))) return rc;
-  if ((rc = run_triangles(c, p))) return rc;
+  sc_params pe = *p;
+  pe.flags |= SC_FLAG_EXACT_TOTAL;  // the hook reports the 3-clique count of the whole graph
+  if ((rc = run_triangles(c, &pe))) return rc;
   *t_eff = c->T_eff;
-  if (tri_total) *tri_total = c->M;
+  if (tri_total) *tri_total = c->M_total;
   if (edges) *edges = c->E;
   if (c->T_eff) {
     HIPCHK(c, hipMemcpyAsync(tri, c->tri.p, (size_t)c->T_eff * 12, hipMemcpyDeviceToHost, c->stream));

@@ -57,7 +57,8 @@ __global__ __launch_bounds__(COMPAT_THREADS) void compat_rows_kernel(const float
                                                                      float nis, float* __restrict__ S,
                                                                      uint64_t* __restrict__ bits,
                                                                      uint32_t* __restrict__ deg,
-                                                                     uint32_t* __restrict__ degp) {
+                                                                     uint32_t* __restrict__ degp,
+                                                                     uint32_t* __restrict__ wpre) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   uint64_t* lbits = reinterpret_cast<uint64_t*>(smem);  // COMPAT_ROWS x W
   const int W = ld >> 6;
@@ -102,35 +103,48 @@ __global__ __launch_bounds__(COMPAT_THREADS) void compat_rows_kernel(const float
     }
   }
   __syncthreads();
-  // epilogue: wave r owns row i0 + r — write its bit row coalesced, reduce deg and deg+ (bits above i)
+  // epilogue: wave r owns row i0 + r — write its bit row coalesced, reduce deg and deg+ (bits above i), and emit
+  // the word-prefix popcounts wpre[i][w] = #set bits of row i in words [0, w): they turn "index of edge (i,k) in
+  // the CSR arrays" into an O(1) lookup for stage B.
   {
     const int r = wave, i = i0 + r;
     if (i < n) {
       uint32_t d_all = 0, d_up = 0;
-      for (int w = lane; w < W; w += 64) {
-        const uint64_t v = lbits[r * W + w];
-        bits[(size_t)i * W + w] = v;
-        d_all += __popcll(v);
-        uint64_t up = v;
-        if (w < (i >> 6)) up = 0;
-        else if (w == (i >> 6)) up &= ((i & 63) == 63) ? 0ull : (~0ull << ((i & 63) + 1));
-        d_up += __popcll(up);
+      for (int wb = 0; wb < W; wb += 64) {
+        const int w = wb + lane;
+        const uint64_t v = w < W ? lbits[r * W + w] : 0ull;
+        const uint32_t pc = (uint32_t)__popcll(v);
+        uint32_t inc = pc;  // inclusive wave scan of the word popcounts
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+          const uint32_t t = __shfl_up(inc, o);
+          if (lane >= o) inc += t;
+        }
+        if (w < W) {
+          bits[(size_t)i * W + w] = v;
+          wpre[(size_t)i * W + w] = d_all + inc - pc;
+          uint64_t up = v;
+          if (w < (i >> 6)) up = 0;
+          else if (w == (i >> 6)) up &= ((i & 63) == 63) ? 0ull : (~0ull << ((i & 63) + 1));
+          d_up += __popcll(up);
+        }
+        d_all += __shfl(inc, 63);
       }
 #pragma unroll
-      for (int o = 32; o > 0; o >>= 1) { d_all += __shfl_xor(d_all, o); d_up += __shfl_xor(d_up, o); }
+      for (int o = 32; o > 0; o >>= 1) d_up += __shfl_xor(d_up, o);
       if (lane == 0) { deg[i] = d_all; degp[i] = d_up; }
     }
   }
 }
 
 void launch_compat(const Points& pts, const Derived& dv, float* S, uint64_t* bits, uint32_t* deg,
-                   uint32_t* degp, hipStream_t st) {
+                   uint32_t* degp, uint32_t* wpre, hipStream_t st) {
   static_assert(COMPAT_ROWS * 64 == COMPAT_THREADS, "epilogue maps wave r to row r");
   const int W = pts.ld >> 6;
   const int grid = (pts.n + COMPAT_ROWS - 1) / COMPAT_ROWS;
   const size_t lds = (size_t)COMPAT_ROWS * W * sizeof(uint64_t);
   hipLaunchKernelGGL(compat_rows_kernel, dim3(grid), dim3(COMPAT_THREADS), lds, st, pts.planes, pts.n, pts.ld,
-                     dv.d_thr, dv.min_len, dv.neg_inv2sig2, S, bits, deg, degp);
+                     dv.d_thr, dv.min_len, dv.neg_inv2sig2, S, bits, deg, degp, wpre);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -184,9 +198,48 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_downsweep_kernel(const uint
   }
 }
 
+// small inputs: ONE block scans up to two arrays in one launch (three launches of the tiled scan are pure latency there)
+__global__ __launch_bounds__(1024) void scan_small_kernel(const uint32_t* __restrict__ in0, uint64_t* __restrict__ out0,
+                                                          const uint32_t* __restrict__ in1, uint64_t* __restrict__ out1,
+                                                          size_t n) {
+  __shared__ uint64_t lds[16];
+  const int arrays = in1 ? 2 : 1;
+  for (int a = 0; a < arrays; a++) {
+    const uint32_t* in = a ? in1 : in0;
+    uint64_t* out = a ? out1 : out0;
+    uint64_t carry = 0;
+    for (size_t b0 = 0; b0 < n; b0 += 1024) {
+      const size_t b = b0 + threadIdx.x;
+      const uint64_t v = b < n ? in[b] : 0;
+      uint64_t tot;
+      const uint64_t ex = block_exscan_u64(v, lds, &tot);
+      if (b < n) out[b] = carry + ex;
+      carry += tot;
+    }
+    if (threadIdx.x == 0) out[n] = carry;
+  }
+}
+
+constexpr size_t SCAN_SMALL_MAX = 32768;
+
+void launch_scan_u32_pair(const uint32_t* in0, uint64_t* out0, const uint32_t* in1, uint64_t* out1, size_t n,
+                          void* temp, hipStream_t st) {
+  if (n <= SCAN_SMALL_MAX) {
+    hipLaunchKernelGGL(scan_small_kernel, dim3(1), dim3(1024), 0, st, in0, out0, in1, out1, n);
+  } else {
+    launch_scan_u32(in0, n, out0, temp, st);
+    if (in1) launch_scan_u32(in1, n, out1, temp, st);
+  }
+}
+
 size_t scan_temp_bytes(size_t n) { return ((n + SCAN_TILE - 1) / SCAN_TILE + 1) * sizeof(uint64_t); }
 
 void launch_scan_u32(const uint32_t* in, size_t n, uint64_t* out, void* temp, hipStream_t st) {
+  if (n <= SCAN_SMALL_MAX) {
+    hipLaunchKernelGGL(scan_small_kernel, dim3(1), dim3(1024), 0, st, in, out, (const uint32_t*)nullptr,
+                       (uint64_t*)nullptr, n);
+    return;
+  }
   uint64_t* bsum = static_cast<uint64_t*>(temp);
   const size_t nb = (n + SCAN_TILE - 1) / SCAN_TILE;
   if (nb == 0) { (void)hipMemsetAsync(out, 0, sizeof(uint64_t), st); return; }

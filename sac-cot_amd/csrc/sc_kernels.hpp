@@ -29,27 +29,40 @@ void launch_stage_points(const float* d_src, const float* d_tgt, int n, int ld, 
 
 // ---- stage A: compat_graph -----------------------------------------------------------------------
 // S: n x ld fp32 (row-major, symmetric, zero diagonal / pad columns); bits: n x (ld/64) u64;
-// deg[i] = edges of i; degp[i] = edges (i,j) with j > i.
+// deg[i] = edges of i; degp[i] = edges (i,j) with j > i; wpre: n x (ld/64) u32, set bits of row i in words [0,w).
 void launch_compat(const Points& pts, const Derived& dv, float* S, uint64_t* bits, uint32_t* deg,
-                   uint32_t* degp, hipStream_t st);
+                   uint32_t* degp, uint32_t* wpre, hipStream_t st);
 
 // ---- exclusive scan u32 -> u64 (out has n+1 entries; out[n] = total) -----------------------------
 size_t scan_temp_bytes(size_t n);
 void launch_scan_u32(const uint32_t* in, size_t n, uint64_t* out, void* temp, hipStream_t st);
+// two arrays of the same length in one go (one launch when n is small); in1/out1 may be null
+void launch_scan_u32_pair(const uint32_t* in0, uint64_t* out0, const uint32_t* in1, uint64_t* out1, size_t n,
+                          void* temp, hipStream_t st);
 
 // ---- stage B: triangles_topT ---------------------------------------------------------------------
 struct Graph {
   const uint64_t* bits;  // n x W
   const float* S;        // n x ld
   const uint32_t* deg;
+  const uint32_t* degp;  // edges to higher indices
+  const uint32_t* wpre;  // n x W word-prefix popcounts of `bits`
   int n, ld, W;
 };
 // CSR edge list of the upper triangle, rows ascending, columns ascending: ei/ej/es (es = S[i][j]).
+// ebase[i] (u32, modular): CSR index of edge (i,k), k > i, is ebase[i] + wpre[i][k/64] + popc(bits[i][k/64] below k).
 void launch_edge_fill(const Graph& g, const uint64_t* edge_off, uint32_t* ei, uint32_t* ej, float* es,
-                      hipStream_t st);
-// tcnt[e] = #k > j adjacent to both ends of edge e = (i,j).
-void launch_tri_count(const Graph& g, const uint32_t* ei, const uint32_t* ej, uint64_t E, uint32_t* tcnt,
-                      hipStream_t st);
+                      uint32_t* ebase, hipStream_t st);
+// tcnt[e] = #k > j adjacent (in `mbits`) to both ends of edge e = (i,j); edges with es[e] < *smin count 0
+// (smin == nullptr: no pruning, mbits = g.bits).
+void launch_tri_count(const Graph& g, const uint64_t* mbits, const float* es, const float* smin, const uint32_t* ei,
+                      const uint32_t* ej, uint64_t E, uint32_t* tcnt, hipStream_t st);
+// Certified pruning (weight ranking): samples every R-th edge's triangles into `hist` (2048 u32), derives the
+// strong-edge threshold *smin (device float; -1 = nothing certified) and builds the strong upper-triangle bit
+// matrix `mbits` (n x W, zeroed here).  key_floor: a value at or below the smallest possible triangle weight.
+void launch_prune(const Graph& g, const uint32_t* ebase, const uint32_t* ei, const uint32_t* ej, const float* es,
+                  uint64_t E, uint64_t want, float key_floor, uint32_t* hist, uint64_t* mbits, float* smin,
+                  hipStream_t st);
 
 // Radix-select state, lives in device memory; zeroed by launch_select_init.
 struct SelectState {
@@ -64,9 +77,9 @@ struct SelectState {
 void launch_select_init(SelectState* s, uint64_t want, hipStream_t st);
 // key of every triangle, in ordinal (lexicographic i,j,k) order: wkey[toff[e] + r].
 // blk_minmax: 2 * 8192 u32 scratch (per-block key min / max, reduced into s->kmin / s->kmax).
-void launch_tri_keys(const Graph& g, const uint64_t* edge_off, const uint32_t* ei, const uint32_t* ej,
-                     const float* es, const uint64_t* toff, uint64_t E, int rank_mode, uint32_t* wkey,
-                     uint32_t* blk_minmax, SelectState* s, hipStream_t st);
+void launch_tri_keys(const Graph& g, const uint64_t* mbits, const float* smin, const uint32_t* ebase,
+                     const uint32_t* ei, const uint32_t* ej, const float* es, const uint64_t* toff, uint64_t E,
+                     int rank_mode, uint32_t* wkey, uint32_t* blk_minmax, SelectState* s, hipStream_t st);
 // up to three (hist, pick) rounds find the exact threshold key
 void launch_select_rounds(const uint32_t* wkey, uint64_t M, SelectState* s, hipStream_t st);
 // compaction of the selected keys in ordinal order
@@ -80,9 +93,9 @@ void launch_compact_write(const uint32_t* wkey, uint64_t M, const SelectState* s
 size_t sort_temp_bytes(size_t n);
 void launch_sort_u64(const uint64_t* in, uint64_t* out, size_t n, void* temp, size_t temp_bytes, hipStream_t st);
 // ordinal -> (i,j,k) in ranked order
-void launch_tri_decode(const Graph& g, const uint32_t* ei, const uint32_t* ej, const uint64_t* toff, uint64_t E,
-                       const uint64_t* sorted, const uint64_t* sel_ord, uint32_t T, uint32_t* tri,
-                       uint32_t* key, hipStream_t st);
+void launch_tri_decode(const Graph& g, const uint64_t* mbits, const uint32_t* ei, const uint32_t* ej,
+                       const uint64_t* toff, uint64_t E, const uint64_t* sorted, const uint64_t* sel_ord, uint32_t T,
+                       uint32_t* tri, uint32_t* key, hipStream_t st);
 
 // ---- stage C ---------------------------------------------------------------------------------------
 struct Shard {

@@ -12,6 +12,9 @@
 //   6. sort (rocPRIM)  by (~key, position)    7. tri_decode  ordinal -> (i,j,k)
 // Everything is integer / bit work except the two fp32 adds of the key; results do not depend on grid size
 // or on the order atomics land in (atomics are only used for commutative integer sums, min and max).
+#include <cstdlib>
+#include <cstring>
+
 #include "sc_arith.hpp"
 #include "sc_block.hpp"
 #include "sc_kernels.hpp"
@@ -36,6 +39,22 @@ __device__ __forceinline__ uint32_t group_exscan(uint32_t v, uint32_t* total) {
   return inc - v;
 }
 
+
+// Pop up to four set bits of m (lowest first).  nb = how many were popped; b[] are their positions (0 for unused
+// slots, so derived indices stay in range).  Lets a lane issue the gathers of four triangles before it consumes the
+// first: a lane's triangles would otherwise cost one dependent L2 round trip each.
+__device__ __forceinline__ int pop4(uint64_t& m, int b[4]) {
+  int nb = 0;
+#pragma unroll
+  for (int q = 0; q < 4; q++) {
+    const bool has = m != 0;
+    b[q] = has ? __builtin_ctzll(m) : 0;
+    m = has ? (m & (m - 1)) : 0;
+    nb += has ? 1 : 0;
+  }
+  return nb;
+}
+
 // ------------------------------------------------------------------------------------------------
 // 1. edge_fill: one wave per row
 // ------------------------------------------------------------------------------------------------
@@ -43,11 +62,16 @@ __global__ __launch_bounds__(256) void edge_fill_kernel(const uint64_t* __restri
                                                         const float* __restrict__ S, int n, int ld, int W,
                                                         const uint64_t* __restrict__ edge_off,
                                                         uint32_t* __restrict__ ei, uint32_t* __restrict__ ej,
-                                                        float* __restrict__ es) {
+                                                        float* __restrict__ es,
+                                                        const uint32_t* __restrict__ deg,
+                                                        const uint32_t* __restrict__ degp,
+                                                        uint32_t* __restrict__ ebase) {
   const int lane = threadIdx.x & 63;
   const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (i >= n) return;
   uint64_t base = edge_off[i];
+  // (# bits of row i at or below i) = deg - deg+; modular u32 arithmetic (edge indices are < 2^32)
+  if (lane == 0) ebase[i] = (uint32_t)base - (deg[i] - degp[i]);
   const int w0 = i >> 6;
   for (int wb = w0; wb < W; wb += 64) {
     const int w = wb + lane;
@@ -72,47 +96,96 @@ __global__ __launch_bounds__(256) void edge_fill_kernel(const uint64_t* __restri
 }
 
 void launch_edge_fill(const Graph& g, const uint64_t* edge_off, uint32_t* ei, uint32_t* ej, float* es,
-                      hipStream_t st) {
+                      uint32_t* ebase, hipStream_t st) {
   hipLaunchKernelGGL(edge_fill_kernel, dim3((g.n + 3) / 4), dim3(256), 0, st, g.bits, g.S, g.n, g.ld, g.W,
-                     edge_off, ei, ej, es);
+                     edge_off, ei, ej, es, g.deg, g.degp, ebase);
 }
 
 // ------------------------------------------------------------------------------------------------
 // 2. tri_count: 16 lanes per edge
 // ------------------------------------------------------------------------------------------------
-constexpr int TG = 16;  // lanes per edge
-
-__global__ __launch_bounds__(256) void tri_count_kernel(const uint64_t* __restrict__ bits, int W,
-                                                        const uint32_t* __restrict__ ei,
-                                                        const uint32_t* __restrict__ ej, uint64_t E,
-                                                        uint32_t* __restrict__ tcnt) {
-  const int gl = threadIdx.x & (TG - 1);
-  const uint64_t e = (uint64_t)blockIdx.x * (256 / TG) + (threadIdx.x / TG);
-  const bool live = e < E;
-  const uint64_t ec = live ? e : 0;
-  const uint32_t i = ei[ec], j = ej[ec];
-  const uint64_t* ri = bits + (size_t)i * W;
-  const uint64_t* rj = bits + (size_t)j * W;
-  const int w0 = j >> 6;
-  uint32_t c = 0;
-  if (live) {
-    for (int w = w0 + gl; w < W; w += TG) {
-      uint64_t m = ri[w] & rj[w];
-      if (w == w0) m &= mask_above(j & 63);
-      c += __popcll(m);
-    }
-  }
-#pragma unroll
-  for (int o = TG / 2; o > 0; o >>= 1) c += __shfl_xor(c, o, TG);
-  if (live && gl == 0) tcnt[e] = c;
+// lanes-per-edge tuning knob (SC_TG_COUNT / SC_TG_KEYS / SC_TG_SAMPLE = 4|8|16|32|64); 8 measured best on C2
+static int tune_tg(const char* name, int dflt) {
+  const char* v = getenv(name);
+  if (!v) return dflt;
+  const int t = atoi(v);
+  return (t == 4 || t == 8 || t == 16 || t == 32 || t == 64) ? t : dflt;
 }
 
-void launch_tri_count(const Graph& g, const uint32_t* ei, const uint32_t* ej, uint64_t E, uint32_t* tcnt,
-                      hipStream_t st) {
+constexpr int TG_DEFAULT = 16;  // lanes per edge (template parameter TG of the edge kernels)
+
+// mbits: the bit matrix that decides MEMBERSHIP (the full adjacency, or the pruned "strong" upper-triangle matrix);
+// smin != nullptr: edges with es[e] < *smin are outside the pruned graph and count 0 without touching any row.
+// EB edges per group are processed together: every dependent memory level (edge record -> rows -> ...) is then paid
+// once per batch instead of once per edge.  These kernels are latency-bound (PMC: > 60 % of wave cycles waiting), so
+// the batch is worth ~EB in time until the L2 request queues fill.
+constexpr int EB = 4;
+
+template <int TG>
+__global__ __launch_bounds__(256) void tri_count_kernel(const uint64_t* __restrict__ mbits, int W,
+                                                        const uint32_t* __restrict__ ei,
+                                                        const uint32_t* __restrict__ ej,
+                                                        const float* __restrict__ es,
+                                                        const float* __restrict__ smin, uint64_t E,
+                                                        uint32_t* __restrict__ tcnt) {
+  const int gl = threadIdx.x & (TG - 1);
+  const float s_floor = smin ? *smin : -1.0f;
+  const uint64_t groups = (uint64_t)gridDim.x * (256 / TG);
+  const uint64_t g0 = (uint64_t)blockIdx.x * (256 / TG) + (threadIdx.x / TG);
+  for (uint64_t e0 = g0 * EB; e0 < E; e0 += groups * EB) {  // a group owns EB consecutive edges per trip
+    uint32_t rowi[EB], rowj[EB], c[EB];
+    int w0[EB], jb[EB];
+    bool on[EB];
+#pragma unroll
+    for (int q = 0; q < EB; q++) {  // level 1: the edge records of the whole batch
+      const uint64_t e = e0 + q;
+      on[q] = e < E;
+      const uint64_t ec = on[q] ? e : 0;
+      const float s = es[ec];
+      const uint32_t i = ei[ec], j = ej[ec];
+      on[q] = on[q] && (s >= s_floor);
+      rowi[q] = i * (uint32_t)W; rowj[q] = j * (uint32_t)W;
+      w0[q] = (int)(j >> 6); jb[q] = (int)(j & 63);
+      c[q] = 0;
+    }
+    int wmin = W;
+#pragma unroll
+    for (int q = 0; q < EB; q++) wmin = on[q] ? min(wmin, w0[q]) : wmin;
+    for (int wb = wmin; wb < W; wb += TG) {  // level 2..: one round of words for all EB edges at a time
+      const int w = wb + gl;
+      uint64_t a[EB], bq[EB];
+#pragma unroll
+      for (int q = 0; q < EB; q++) {
+        const bool live = on[q] && w >= w0[q] && w < W;
+        a[q] = live ? mbits[rowi[q] + w] : 0ull;
+        bq[q] = live ? mbits[rowj[q] + w] : 0ull;
+      }
+#pragma unroll
+      for (int q = 0; q < EB; q++) {
+        uint64_t m = a[q] & bq[q];
+        if (w == w0[q]) m &= mask_above(jb[q]);
+        c[q] += (uint32_t)__popcll(m);
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < EB; q++) {
+#pragma unroll
+      for (int o = TG / 2; o > 0; o >>= 1) c[q] += __shfl_xor(c[q], o, TG);
+      if (gl == 0 && e0 + q < E) tcnt[e0 + q] = c[q];
+    }
+  }
+}
+
+void launch_tri_count(const Graph& g, const uint64_t* mbits, const float* es, const float* smin, const uint32_t* ei,
+                      const uint32_t* ej, uint64_t E, uint32_t* tcnt, hipStream_t st) {
   if (E == 0) return;
-  const uint64_t per = 256 / TG;
-  hipLaunchKernelGGL(tri_count_kernel, dim3((unsigned)((E + per - 1) / per)), dim3(256), 0, st, g.bits, g.W, ei, ej,
-                     E, tcnt);
+  const int tg = tune_tg("SC_TG_COUNT", 8);
+  const uint64_t per = (uint64_t)(256 / tg) * EB;
+  uint64_t nb = (E + per - 1) / per;
+  if (nb > 4096) nb = 4096;
+#define SC_LAUNCH_COUNT(TGV) hipLaunchKernelGGL(tri_count_kernel<TGV>, dim3((unsigned)nb), dim3(256), 0, st, mbits, g.W, ei, ej, es, smin, E, tcnt)
+  if (tg == 4) SC_LAUNCH_COUNT(4); else if (tg == 8) SC_LAUNCH_COUNT(8); else if (tg == 32) SC_LAUNCH_COUNT(32); else SC_LAUNCH_COUNT(16);
+#undef SC_LAUNCH_COUNT
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -129,11 +202,20 @@ void launch_select_init(SelectState* s, uint64_t want, hipStream_t st) {
   hipLaunchKernelGGL(select_init_kernel, dim3(1), dim3(256), 0, st, s, want);
 }
 
-constexpr int TK_MAX_BLOCKS = 8192;  // bounds the per-block min/max arrays
+constexpr int TK_MAX_BLOCKS = 4096;  // bounds the per-block min/max arrays
 
-__global__ __launch_bounds__(256) void tri_keys_kernel(const uint64_t* __restrict__ bits, int W,
+// bits / wpre / ebase: full adjacency + its word-prefix popcounts + per-row CSR bases: the index of edge (v,k) in the
+// edge arrays is ebase[v] + wpre[v][k/64] + popc(bits[v][k/64] & below k) — an O(1) lookup, no running prefix.
+// mbits: membership matrix (== bits when nothing is pruned); smin: strong-edge threshold or nullptr.
+// Per round only the member words are ANDed; the one remaining group scan (triangle rank inside the edge, for the
+// ordinal) is skipped when the whole group found nothing — the common case in the pruned graph.
+template <int TG>
+__global__ __launch_bounds__(256) void tri_keys_kernel(const uint64_t* __restrict__ bits,
+                                                       const uint64_t* __restrict__ mbits,
+                                                       const float* __restrict__ smin, int W,
                                                        const uint32_t* __restrict__ deg,
-                                                       const uint64_t* __restrict__ edge_off,
+                                                       const uint32_t* __restrict__ wpre,
+                                                       const uint32_t* __restrict__ ebase,
                                                        const uint32_t* __restrict__ ei,
                                                        const uint32_t* __restrict__ ej,
                                                        const float* __restrict__ es,
@@ -143,49 +225,69 @@ __global__ __launch_bounds__(256) void tri_keys_kernel(const uint64_t* __restric
                                                        uint32_t* __restrict__ blk_max) {
   __shared__ uint32_t lmin[4], lmax[4];
   const int gl = threadIdx.x & (TG - 1);
+  const uint64_t gmask = (TG == 64) ? ~0ull : (((1ull << TG) - 1ull) << ((threadIdx.x & 63) & ~(TG - 1)));
   uint32_t kmin = 0xFFFFFFFFu, kmax = 0;
   const uint64_t groups = (uint64_t)gridDim.x * (256 / TG);
-  // every group of TG lanes walks edges e, e + groups, ...; all lanes of a group share the trip counts
+  const bool pruned = (mbits != bits);
+  const float s_floor = smin ? *smin : -1.0f;
   for (uint64_t e = (uint64_t)blockIdx.x * (256 / TG) + (threadIdx.x / TG); e < E; e += groups) {
-    const uint32_t i = ei[e], j = ej[e];
-    const uint64_t* ri = bits + (size_t)i * W;
-    const uint64_t* rj = bits + (size_t)j * W;
-    const int w0 = j >> 6;
     const float s_ij = es[e];
-    const uint32_t dsum_ij = deg[i] + deg[j];
+    if (s_ij < s_floor) continue;  // group-uniform: the edge is outside the pruned graph
+    const uint32_t i = ei[e], j = ej[e];
+    const uint32_t rowi = i * (uint32_t)W, rowj = j * (uint32_t)W;  // word offsets: n * W < 2^32
+    const int w0 = j >> 6;
+    const uint32_t dsum_ij = (rank_mode == 0) ? 0u : deg[i] + deg[j];
+    const uint32_t ebi = ebase[i], ebj = ebase[j];
+    uint32_t out = (uint32_t)0;  // triangle rank inside the edge
     const uint64_t out0 = toff[e];
-    const uint64_t eik0 = e + 1;           // edge index of (i, first neighbour of i above j)
-    const uint64_t ejk0 = edge_off[j];     // edge index of (j, first neighbour of j above j)
-    uint32_t base_m = 0, base_i = 0, base_j = 0;
     const int rounds = (W - w0 + TG - 1) / TG;
     for (int it = 0; it < rounds; it++) {
       const int w = w0 + it * TG + gl;
-      uint64_t ai = 0, aj = 0;
+      uint64_t m = 0;
       if (w < W) {
-        ai = ri[w]; aj = rj[w];
-        if (w == w0) { const uint64_t mk = mask_above(j & 63); ai &= mk; aj &= mk; }
+        m = mbits[rowi + w] & mbits[rowj + w];
+        if (w == w0) m &= mask_above(j & 63);
       }
-      uint64_t m = ai & aj;
-      uint32_t tm, ti, tj;
-      uint32_t pm = base_m + group_exscan<TG>((uint32_t)__popcll(m), &tm);
-      const uint32_t pi = base_i + group_exscan<TG>((uint32_t)__popcll(ai), &ti);
-      const uint32_t pj = base_j + group_exscan<TG>((uint32_t)__popcll(aj), &tj);
-      base_m += tm; base_i += ti; base_j += tj;
-      while (m) {
-        const int b = __builtin_ctzll(m);
-        const uint64_t below = (1ull << b) - 1ull;
-        m &= m - 1;
-        uint32_t key;
-        if (rank_mode == 0) {
-          const float s_ik = es[eik0 + pi + (uint32_t)__popcll(ai & below)];
-          const float s_jk = es[ejk0 + pj + (uint32_t)__popcll(aj & below)];
-          key = __float_as_uint((s_ij + s_ik) + s_jk);
-        } else {
-          key = dsum_ij + deg[w * 64 + b];
+      const uint64_t any = __ballot(m != 0) & gmask;
+      if (any == 0) continue;  // group-uniform
+      uint32_t tm;
+      uint32_t pm = out + group_exscan<TG>((uint32_t)__popcll(m), &tm);
+      out += tm;
+      if (m) {
+        // full-row words and prefixes only where a triangle was found
+        const uint64_t ai = pruned ? bits[rowi + w] : 0ull, aj = pruned ? bits[rowj + w] : 0ull;
+        const uint64_t fi = pruned ? ai : mbits[rowi + w], fj = pruned ? aj : mbits[rowj + w];
+        const uint32_t pi = ebi + wpre[rowi + w], pj = ebj + wpre[rowj + w];
+        while (m) {
+          int b[4];
+          const int nbits = pop4(m, b);
+          uint32_t key[4];
+          if (rank_mode == 0) {
+            float s_ik[4], s_jk[4];
+#pragma unroll
+            for (int q = 0; q < 4; q++) {  // all eight gathers are issued before the first use
+              const uint64_t below = (1ull << b[q]) - 1ull;
+              const bool live = q < nbits;  // idle slots read es[0]: their modular index may be out of range
+              const uint32_t xi = live ? pi + (uint32_t)__popcll(fi & below) : 0u;
+              const uint32_t xj = live ? pj + (uint32_t)__popcll(fj & below) : 0u;
+              s_ik[q] = es[xi];
+              s_jk[q] = es[xj];
+            }
+#pragma unroll
+            for (int q = 0; q < 4; q++) key[q] = __float_as_uint((s_ij + s_ik[q]) + s_jk[q]);
+          } else {
+#pragma unroll
+            for (int q = 0; q < 4; q++) key[q] = dsum_ij + deg[w * 64 + b[q]];
+          }
+#pragma unroll
+          for (int q = 0; q < 4; q++) {
+            if (q < nbits) {
+              wkey[out0 + pm++] = key[q];
+              kmin = min(kmin, key[q]);
+              kmax = max(kmax, key[q]);
+            }
+          }
         }
-        wkey[out0 + pm++] = key;
-        kmin = min(kmin, key);
-        kmax = max(kmax, key);
       }
     }
   }
@@ -222,20 +324,163 @@ __global__ __launch_bounds__(1024) void key_range_kernel(const uint32_t* __restr
   }
 }
 
-size_t tri_keys_blocks(uint64_t E) {
-  const uint64_t per = 256 / TG;
+size_t tri_keys_blocks(uint64_t E, int tg) {
+  const uint64_t per = 256 / tg;
   const uint64_t nb = (E + per - 1) / per;
   return (size_t)(nb < (uint64_t)TK_MAX_BLOCKS ? nb : (uint64_t)TK_MAX_BLOCKS);
 }
 
-void launch_tri_keys(const Graph& g, const uint64_t* edge_off, const uint32_t* ei, const uint32_t* ej,
-                     const float* es, const uint64_t* toff, uint64_t E, int rank_mode, uint32_t* wkey,
-                     uint32_t* blk_minmax, SelectState* s, hipStream_t st) {
+void launch_tri_keys(const Graph& g, const uint64_t* mbits, const float* smin, const uint32_t* ebase,
+                     const uint32_t* ei, const uint32_t* ej, const float* es, const uint64_t* toff, uint64_t E,
+                     int rank_mode, uint32_t* wkey, uint32_t* blk_minmax, SelectState* s, hipStream_t st) {
   if (E == 0) return;
-  const int nb = (int)tri_keys_blocks(E);
-  hipLaunchKernelGGL(tri_keys_kernel, dim3(nb), dim3(256), 0, st, g.bits, g.W, g.deg, edge_off, ei, ej, es, toff, E,
-                     rank_mode, wkey, blk_minmax, blk_minmax + TK_MAX_BLOCKS);
+  const int tg = tune_tg("SC_TG_KEYS", 8);
+  const int nb = (int)tri_keys_blocks(E, tg);
+#define SC_LAUNCH_KEYS(TGV) hipLaunchKernelGGL(tri_keys_kernel<TGV>, dim3(nb), dim3(256), 0, st, g.bits, mbits, smin, g.W, g.deg, g.wpre, ebase, ei, ej, es, toff, E, rank_mode, wkey, blk_minmax, blk_minmax + TK_MAX_BLOCKS)
+  if (tg == 4) SC_LAUNCH_KEYS(4); else if (tg == 8) SC_LAUNCH_KEYS(8); else if (tg == 32) SC_LAUNCH_KEYS(32); else if (tg == 64) SC_LAUNCH_KEYS(64); else SC_LAUNCH_KEYS(16);
+#undef SC_LAUNCH_KEYS
   hipLaunchKernelGGL(key_range_kernel, dim3(1), dim3(1024), 0, st, blk_minmax, blk_minmax + TK_MAX_BLOCKS, nb, s);
+}
+
+// ------------------------------------------------------------------------------------------------
+// 3b. certified pruning (weight ranking only)
+//
+// Claim: let LB be any value such that at least T triangles have key >= LB.  Then the top-T list of the full graph
+// equals the top-T list of the subgraph of "strong" edges, s >= smin := LB - 2 - 1e-6.
+// Proof: w = fl(fl(a+b)+c) with a,b,c in (0,1] satisfies w <= a+b+c + 5*2^-24, so a triangle with w >= LB has every
+// edge >= LB - 2 - 3e-7 > smin: all triangles with key >= LB live in the strong subgraph, there are >= T of them, and
+// every triangle outside it has key < LB, i.e. strictly below at least T others — it cannot enter the top-T, ties
+// included.  Ordinals keep their relative order (same CSR edge order, same ascending k), so the tie-break is unchanged.
+// LB comes from a SAMPLE: the triangles of every R-th edge are enumerated once, their keys go into a 2048-bin
+// histogram over [klo, khi]; walking it from the top to the first bin where the count reaches T gives a bin whose
+// lower edge is a valid LB (>= T genuine triangles lie at or above it).  Bin 0 collects everything below klo, so a
+// crossing in bin 0 certifies nothing and disables the pruning (smin = -1).
+// ------------------------------------------------------------------------------------------------
+constexpr int PR_BINS = 256;   // coarse is enough: LB only needs to be a valid, reasonably tight lower bound
+constexpr int PR_COPIES = 16;  // one private copy per lane-in-group: same-bin hits land on different LDS words
+
+__device__ __forceinline__ uint32_t prune_bin(uint32_t key, uint32_t klo, uint32_t shift) {
+  if (key <= klo) return 0u;
+  const uint32_t b = (key - klo) >> shift;
+  return b < (uint32_t)PR_BINS ? b : (uint32_t)(PR_BINS - 1);
+}
+
+template <int TG>
+__global__ __launch_bounds__(256) void tri_sample_hist_kernel(const uint64_t* __restrict__ bits, int W,
+                                                              const uint32_t* __restrict__ wpre,
+                                                              const uint32_t* __restrict__ ebase,
+                                                              const uint32_t* __restrict__ ei,
+                                                              const uint32_t* __restrict__ ej,
+                                                              const float* __restrict__ es, uint64_t E,
+                                                              uint32_t stride, uint32_t klo, uint32_t shift,
+                                                              uint32_t* __restrict__ hist) {
+  __shared__ uint32_t lh[PR_BINS * PR_COPIES];  // [bin][copy]
+  for (int b = threadIdx.x; b < PR_BINS * PR_COPIES; b += 256) lh[b] = 0;
+  __syncthreads();
+  const int gl = threadIdx.x & (TG - 1);
+  const uint64_t n_s = (E + stride - 1) / stride;  // sampled edges: e = g * stride
+  const uint64_t groups = (uint64_t)gridDim.x * (256 / TG);
+  for (uint64_t g = (uint64_t)blockIdx.x * (256 / TG) + (threadIdx.x / TG); g < n_s; g += groups) {
+    const uint64_t e = g * stride;
+    const uint32_t i = ei[e], j = ej[e];
+    const uint32_t rowi = i * (uint32_t)W, rowj = j * (uint32_t)W;
+    const int w0 = j >> 6;
+    const float s_ij = es[e];
+    const uint32_t ebi = ebase[i], ebj = ebase[j];
+    for (int w = w0 + gl; w < W; w += TG) {  // no cross-lane step at all: every lane owns its words
+      const uint64_t ai = bits[rowi + w], aj = bits[rowj + w];
+      uint64_t m = ai & aj;
+      if (w == w0) m &= mask_above(j & 63);
+      if (m) {
+        const uint32_t pi = ebi + wpre[rowi + w], pj = ebj + wpre[rowj + w];
+        while (m) {
+          int b[4];
+          const int nbits = pop4(m, b);
+          float s_ik[4], s_jk[4];
+#pragma unroll
+          for (int q = 0; q < 4; q++) {
+            const uint64_t below = (1ull << b[q]) - 1ull;
+            const bool live = q < nbits;
+            s_ik[q] = es[live ? pi + (uint32_t)__popcll(ai & below) : 0u];
+            s_jk[q] = es[live ? pj + (uint32_t)__popcll(aj & below) : 0u];
+          }
+#pragma unroll
+          for (int q = 0; q < 4; q++)
+            if (q < nbits)
+              atomicAdd(&lh[prune_bin(__float_as_uint((s_ij + s_ik[q]) + s_jk[q]), klo, shift) * PR_COPIES +
+                            (threadIdx.x & (PR_COPIES - 1))], 1u);
+        }
+      }
+    }
+  }
+  __syncthreads();
+  for (int b = threadIdx.x; b < PR_BINS; b += 256) {
+    uint32_t v = 0;
+#pragma unroll
+    for (int c = 0; c < PR_COPIES; c++) v += lh[b * PR_COPIES + ((c + threadIdx.x) & (PR_COPIES - 1))];
+    if (v) atomicAdd(&hist[b], v);
+  }
+}
+
+// every block derives smin from the histogram (2048 bins: cheap) and sets the strong bits of its edges in `mbits`
+// (zeroed beforehand; only upper-triangle entries are needed: bit j of row i for i < j).  Block 0 publishes smin.
+__global__ __launch_bounds__(256) void prune_bits_kernel(const uint32_t* __restrict__ hist, uint64_t want,
+                                                         uint32_t klo, uint32_t shift,
+                                                         const uint32_t* __restrict__ ei,
+                                                         const uint32_t* __restrict__ ej,
+                                                         const float* __restrict__ es, uint64_t E, int W,
+                                                         unsigned long long* __restrict__ mbits,
+                                                         float* __restrict__ smin_out) {
+  __shared__ uint64_t lds[8];
+  __shared__ float s_smin;
+  static_assert(PR_BINS == 256, "one bin per thread, walked from the top");
+  const uint32_t bin = PR_BINS - 1 - threadIdx.x;
+  const uint64_t mine = hist[bin];
+  if (threadIdx.x == 0) s_smin = -1.0f;  // default: no certified bound -> every edge is strong
+  uint64_t tot;
+  const uint64_t before = block_exscan_u64(mine, lds, &tot);
+  if (before < want && want <= before + mine && bin > 0) {
+    const float lb = __uint_as_float(klo + (bin << shift));  // lower edge of the crossing bin
+    s_smin = (lb - 2.0f) - 1e-6f;
+  }
+  __syncthreads();
+  const float smin = s_smin;
+  if (blockIdx.x == 0 && threadIdx.x == 0) *smin_out = smin;
+  const uint64_t e = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  if (e < E && es[e] >= smin) {
+    const uint32_t i = ei[e], j = ej[e];
+    atomicOr(&mbits[(size_t)i * W + (j >> 6)], 1ull << (j & 63));
+  }
+}
+
+void launch_prune(const Graph& g, const uint32_t* ebase, const uint32_t* ei, const uint32_t* ej, const float* es,
+                  uint64_t E, uint64_t want, float key_floor, uint32_t* hist, uint64_t* mbits, float* smin,
+                  hipStream_t st) {
+  // histogram window in key space: [bits(key_floor), bits(3.0f)], monotone in the value
+  const uint32_t khi = 0x40400000u;  // 3.0f
+  uint32_t klo;
+  memcpy(&klo, &key_floor, 4);
+  if (!(key_floor > 0.f) || klo >= khi) klo = 0x3F800000u;  // 1.0f
+  const uint32_t range = khi - klo;
+  const int bitsn = 32 - __builtin_clz(range);
+  const uint32_t shift = bitsn > 8 ? (uint32_t)(bitsn - 8) : 0u;  // (khi - klo) >> shift < 256
+  // every R-th edge: about 32k sampled edges whatever E is
+  uint64_t stride = E / 32768;
+  if (stride < 1) stride = 1;
+  if (stride > 64) stride = 64;
+  (void)hipMemsetAsync(hist, 0, PR_BINS * sizeof(uint32_t), st);
+  (void)hipMemsetAsync(mbits, 0, (size_t)g.n * g.W * sizeof(uint64_t), st);
+  const uint64_t n_s = (E + stride - 1) / stride;
+  const int tg = tune_tg("SC_TG_SAMPLE", 8);
+  uint64_t nb = (n_s + (256 / tg) - 1) / (256 / tg);
+  // about one sampled edge per group: the kernel's time is the dependent-load chain of its heaviest edges, so
+  // stacking several edges per group only adds to it (measured: 256 blocks 70 us, 1024+ blocks 35 us on C2)
+  if (nb > 4096) nb = 4096;
+#define SC_LAUNCH_SAMPLE(TGV) hipLaunchKernelGGL(tri_sample_hist_kernel<TGV>, dim3((unsigned)nb), dim3(256), 0, st, g.bits, g.W, g.wpre, ebase, ei, ej, es, E, (uint32_t)stride, klo, shift, hist)
+  if (tg == 4) SC_LAUNCH_SAMPLE(4); else if (tg == 8) SC_LAUNCH_SAMPLE(8); else if (tg == 32) SC_LAUNCH_SAMPLE(32); else if (tg == 64) SC_LAUNCH_SAMPLE(64); else SC_LAUNCH_SAMPLE(16);
+#undef SC_LAUNCH_SAMPLE
+  hipLaunchKernelGGL(prune_bits_kernel, dim3((unsigned)((E + 255) / 256)), dim3(256), 0, st, hist, want, klo, shift, ei,
+                     ej, es, E, g.W, reinterpret_cast<unsigned long long*>(mbits), smin);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -502,11 +747,11 @@ __global__ __launch_bounds__(256) void tri_decode_kernel(const uint64_t* __restr
   key[t] = ~(uint32_t)(sk >> 32);
 }
 
-void launch_tri_decode(const Graph& g, const uint32_t* ei, const uint32_t* ej, const uint64_t* toff, uint64_t E,
-                       const uint64_t* sorted, const uint64_t* sel_ord, uint32_t T, uint32_t* tri,
-                       uint32_t* key, hipStream_t st) {
+void launch_tri_decode(const Graph& g, const uint64_t* mbits, const uint32_t* ei, const uint32_t* ej,
+                       const uint64_t* toff, uint64_t E, const uint64_t* sorted, const uint64_t* sel_ord, uint32_t T,
+                       uint32_t* tri, uint32_t* key, hipStream_t st) {
   if (T == 0) return;
-  hipLaunchKernelGGL(tri_decode_kernel, dim3((T + 255) / 256), dim3(256), 0, st, g.bits, g.W, ei, ej, toff, E,
+  hipLaunchKernelGGL(tri_decode_kernel, dim3((T + 255) / 256), dim3(256), 0, st, mbits, g.W, ei, ej, toff, E,
                      sorted, sel_ord, T, tri, key);
 }
 

@@ -144,7 +144,7 @@ def test_score_counts_bit_exact(pkg, O, reg, n, T):
 # whole path
 # ---------------------------------------------------------------------------------------------------------
 def _check_register(pkg, O, reg, scene, kw, threads=8):
-    got = reg.register(scene.src, scene.tgt, **kw)
+    got = reg.register(scene.src, scene.tgt, flags=pkg.SC_FLAG_EXACT_TOTAL, **kw)
     ref = O.register(scene.src, scene.tgt, threads=threads, **kw)
     assert got["status"] == ref["rc"]
     st = got["stats"]
@@ -164,6 +164,26 @@ def test_register_matches_oracle(pkg, O, reg, name):
     assert np.linalg.norm(got["t"] - scene.t_gt) < 2 * cfg.tau + 0.05 * cfg.L
     m = got["mask"].astype(bool)
     assert (m & scene.inlier).sum() >= 0.9 * scene.inlier.sum()
+
+
+@pytest.mark.parametrize("name", ["C0", "C1", "C2"])
+def test_certified_pruning_changes_nothing_but_the_work(pkg, reg, name):
+    """Stage B enumerates only the certified 'strong' subgraph by default (sc_tri.hip 3b).  The ranked list — keys,
+    triangles, order — and the whole result must be identical with the pruning switched off, while the number of
+    enumerated 3-cliques must drop."""
+    cfg, scene = pkg.synth.make_config_scene(name)
+    kw = cfg.params()
+    tri_a, key_a, total_a, edges_a = reg.triangles(scene.src, scene.tgt, pkg.make_params(**kw))
+    tri_b, key_b, total_b, edges_b = reg.triangles(scene.src, scene.tgt, pkg.make_params(flags=pkg.SC_FLAG_NO_PRUNE, **kw))
+    assert (total_a, edges_a) == (total_b, edges_b)           # the hook always reports the whole graph
+    assert np.array_equal(key_a, key_b) and np.array_equal(tri_a, tri_b)
+    a = reg.register(scene.src, scene.tgt, **kw)
+    b = reg.register(scene.src, scene.tgt, flags=pkg.SC_FLAG_NO_PRUNE, **kw)
+    assert np.array_equal(a["mask"], b["mask"]) and a["R"].tobytes() == b["R"].tobytes() and a["t"].tobytes() == b["t"].tobytes()
+    assert a["stats"]["best_rank"] == b["stats"]["best_rank"] and a["stats"]["tri_kept"] == b["stats"]["tri_kept"]
+    assert kw["max_triangles"] <= a["stats"]["tri_total"] < b["stats"]["tri_total"]   # pruned < whole graph
+    if name == "C2":
+        assert a["stats"]["tri_total"] < b["stats"]["tri_total"] // 5
 
 
 def test_register_degree_ranking_and_small_T(pkg, O, reg):
