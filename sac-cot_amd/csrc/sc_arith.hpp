@@ -20,6 +20,21 @@ __device__ __forceinline__ float fma_(float a, float b, float c) { return __buil
 __device__ __forceinline__ float sqrt_rn(float x) { return __builtin_sqrtf(x); }
 __device__ __forceinline__ float div_rn(float a, float b) { return a / b; }
 
+// Correctly rounded sqrt with fewer instructions, for the O(N^2) stage: the same algorithm LLVM emits for sqrtf
+// (v_sqrt_f32 is within 1 ulp; the exact fma residuals of its two neighbours pick the correctly rounded value) minus
+// the 2^32 pre-scaling that only inputs below 2^-96 need.  Such inputs (two points closer than ~3.6e-15) take the
+// full sqrtf through a wave-uniform branch, so the result is identical to sqrt_rn for every input, including 0
+// (NaN residual compares false, result 0) and +inf.
+__device__ __forceinline__ float sqrt_rn_fast(float x) {
+  if (__builtin_expect(__ballot(x < 0x1p-96f && x > 0.0f) != 0, 0)) return __builtin_sqrtf(x);
+  const float s = __builtin_amdgcn_sqrtf(x);
+  const float sd = __int_as_float(__float_as_int(s) - 1), su = __int_as_float(__float_as_int(s) + 1);
+  const float rd = fma_(-sd, s, x), ru = fma_(-su, s, x);
+  float r = (rd <= 0.0f) ? sd : s;
+  r = (ru > 0.0f) ? su : r;
+  return r;
+}
+
 // exp(x), x <= 0 (clamped at -87): k = rint(x log2e) via the 1.5*2^23 trick, two-term ln2 reduction,
 // degree-6 Horner, scale through the exponent field.
 __device__ __forceinline__ float sc_expf(float x) {
@@ -45,6 +60,10 @@ __device__ __forceinline__ float sc_expf(float x) {
 __device__ __forceinline__ float dist3(float ax, float ay, float az, float bx, float by, float bz) {
   float dx = ax - bx, dy = ay - by, dz = az - bz;
   return sqrt_rn(fma_(dz, dz, fma_(dy, dy, dx * dx)));
+}
+__device__ __forceinline__ float dist3_fast(float ax, float ay, float az, float bx, float by, float bz) {
+  float dx = ax - bx, dy = ay - by, dz = az - bz;
+  return sqrt_rn_fast(fma_(dz, dz, fma_(dy, dy, dx * dx)));
 }
 
 // Stage A pair test.  Returns the weight (0 when not an edge); `edge` gets the decision.

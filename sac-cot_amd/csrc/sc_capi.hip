@@ -153,9 +153,14 @@ int run_compat(sc_ctx* c) {
   ENSURE(c, c->deg, n * sizeof(uint32_t));
   ENSURE(c, c->degp, n * sizeof(uint32_t));
   ENSURE(c, c->wpre, n * W * sizeof(uint32_t));
-  launch_compat(points_of(c), c->dv, c->S.as<float>(), c->bits.as<uint64_t>(), c->deg.as<uint32_t>(),
-                c->degp.as<uint32_t>(), c->wpre.as<uint32_t>(), c->stream);
+  launch_compat(points_of(c), c->dv, c->S.as<float>(), c->bits.as<uint64_t>(), c->stream);
   return SC_OK;
+}
+
+// deg / deg+ / word-prefix popcounts from the bit rows (first kernel of stage B's timing bracket)
+void run_row_stats(sc_ctx* c) {
+  launch_row_stats(points_of(c), c->bits.as<uint64_t>(), c->deg.as<uint32_t>(), c->degp.as<uint32_t>(),
+                   c->wpre.as<uint32_t>(), c->stream);
 }
 
 // stage B; on return c->E, c->M, c->T_eff are set and tri/trikey hold the ranked list
@@ -389,6 +394,7 @@ int sc_hypothesize_device(sc_ctx* c, const float* d_src, const float* d_tgt, int
   if ((rc = rec(c, 1))) return rc;
   if ((rc = run_compat(c))) return rc;
   if ((rc = rec(c, 2))) return rc;
+  run_row_stats(c);
   if ((rc = run_triangles(c, p))) return rc;
   if ((rc = rec(c, 3))) return rc;
   // stage C on this rank's share of the ranked list
@@ -505,6 +511,7 @@ int sc_compat_host(sc_ctx* c, const float* src, const float* tgt, int64_t n, con
   c->dv = derive(p);
   if ((rc = host_to_planes(c, src, tgt, n, p))) return rc;
   if ((rc = run_compat(c))) return rc;
+  run_row_stats(c);
   if ((rc = check_flag(c))) return rc;
   const size_t W = (size_t)c->ld >> 6;
   if (S)
@@ -529,6 +536,7 @@ int sc_triangles_host(sc_ctx* c, const float* src, const float* tgt, int64_t n, 
   c->dv = derive(p);
   if ((rc = host_to_planes(c, src, tgt, n, p))) return rc;
   if ((rc = run_compat(c))) return rc;
+  run_row_stats(c);
   sc_params pe = *p;
   pe.flags |= SC_FLAG_EXACT_TOTAL;  // the hook reports the 3-clique count of the whole graph
   if ((rc = run_triangles(c, &pe))) return rc;

@@ -1,13 +1,10 @@
 // sc_compat.hip — input staging, stage A (compat_graph) and the exclusive scan.
 //
-// Stage A is HBM-write bound: 4 N^2 bytes of weights + N^2/8 bytes of adjacency bits (103 MB at N = 5000).
-// Layout: one workgroup owns COMPAT_ROWS full rows of the matrix.  Lane l of wave w owns column
-// c0 + 64 w + l of each 256-column step, so
-//   * the six coordinates of column j are loaded once (coalesced) and reused for COMPAT_ROWS rows,
-//   * the row operands are wave-uniform (scalar loads),
-//   * every store instruction of a wave writes 256 contiguous bytes of one row of S,
-//   * __ballot() of the edge predicate IS the 64-bit adjacency word of that row — no shuffles,
-//   * the bit rows are assembled in LDS and written once, coalesced; deg / deg+ fall out of them.
+// Stage A's output is 4 N^2 bytes of weights + N^2/8 bytes of adjacency bits (103 MB at N = 5000): the HBM write
+// roofline is its bound; see the stage-A section below for the tiling that gets the arithmetic out of the way.
+#include <cstdlib>
+#include <type_traits>
+
 #include "sc_arith.hpp"
 #include "sc_block.hpp"
 #include "sc_kernels.hpp"
@@ -48,103 +45,168 @@ void launch_stage_points(const float* d_src, const float* d_tgt, int n, int ld, 
 
 // ------------------------------------------------------------------------------------------------
 // stage A
+//
+// The matrix is symmetric and the pair arithmetic is bit-symmetric (dist3(a,b) == dist3(b,a)), so only tiles on or
+// above the diagonal are evaluated: one wave = one tile of TILE_R rows x 64 columns (lane = column).
+//   * direct half:   S[i][j] is stored row by row (256 B contiguous per wave store); __ballot of the edge predicate
+//                    IS the adjacency word of row i for this column block — lane r keeps the word of row r;
+//   * mirrored half: the tile goes through an LDS transpose and S[j][i0..i0+31] is stored as 128-B row segments; the
+//                    mirrored adjacency half-word of row j accumulates in lane j (bit r = edge with row i0 + r);
+//   * tiles crossing the diagonal evaluate their full rectangle and write the direct half only.
+// PMC on the previous one-sided kernel: WRITE_SIZE == algorithmic bytes, VALU-bound (74 VALU per pair); evaluating
+// each pair once halves that work, which is what moves the kernel toward the HBM write roofline.
+// deg / deg+ / word-prefix popcounts come from the bit rows in a second, tiny kernel.
 // ------------------------------------------------------------------------------------------------
-constexpr int COMPAT_ROWS = 4;     // rows per workgroup (= waves per workgroup, used by the epilogue)
-constexpr int COMPAT_THREADS = 256;
+// value of `v` in lane `src` (wave-uniform src) as a scalar: v_readlane_b32 works on the bit pattern
+__device__ __forceinline__ float bcast(float v, int src) {
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), src));
+}
 
-__global__ __launch_bounds__(COMPAT_THREADS) void compat_rows_kernel(const float* __restrict__ planes, int n,
-                                                                     int ld, float d_thr, float min_len,
-                                                                     float nis, float* __restrict__ S,
-                                                                     uint64_t* __restrict__ bits,
-                                                                     uint32_t* __restrict__ deg,
-                                                                     uint32_t* __restrict__ degp,
-                                                                     uint32_t* __restrict__ wpre) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  uint64_t* lbits = reinterpret_cast<uint64_t*>(smem);  // COMPAT_ROWS x W
-  const int W = ld >> 6;
+constexpr int COMPAT_WAVES = 4;  // tiles per workgroup
+
+// TILE_R rows per tile (16 or 32): 64 / TILE_R tiles stack into one 64-row block
+template <int TILE_R>
+__global__ __launch_bounds__(64 * COMPAT_WAVES) void compat_tiles_kernel(const float* __restrict__ planes, int n,
+                                                                         int ld, float d_thr, float min_len,
+                                                                         float nis, float* __restrict__ S,
+                                                                         uint64_t* __restrict__ bits, int n_tiles) {
+  constexpr int TILE_PAD = TILE_R + 1;  // LDS row stride of the transposed tile: conflict-free both ways
+  constexpr int SUB = 64 / TILE_R;      // tiles per 64-row block
+  __shared__ float tileT[COMPAT_WAVES][64 * TILE_PAD];  // [column][row] per wave
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int i0 = blockIdx.x * COMPAT_ROWS;
+  const int t = blockIdx.x * COMPAT_WAVES + wave;
+  if (t >= n_tiles) return;  // whole wave; no block-level barrier is used below
+  const int W = ld >> 6;
+  // tile t -> (column block J, row sub-block h):  t = SUB J (J + 1) / 2 + h,  0 <= h < SUB (J + 1)
+  int J = (int)((__builtin_sqrtf(8.0f * (float)(t / SUB) + 1.0f) - 1.0f) * 0.5f);
+  while (SUB * (J + 1) * (J + 2) / 2 <= t) J++;
+  while (SUB * J * (J + 1) / 2 > t) J--;
+  const int h = t - SUB * J * (J + 1) / 2;
+  const int i0 = h * TILE_R;
+  const int j = J * 64 + lane;
+  const bool diag = (h / SUB) == J;
   const float* px = planes;
   const float* py = planes + ld;
   const float* pz = planes + 2 * (size_t)ld;
   const float* qx = planes + 3 * (size_t)ld;
   const float* qy = planes + 4 * (size_t)ld;
   const float* qz = planes + 5 * (size_t)ld;
-
-  // wave-uniform row operands (i0 + r < ld always: ld >= n rounded up to 64 and COMPAT_ROWS divides 64)
-  float rpx[COMPAT_ROWS], rpy[COMPAT_ROWS], rpz[COMPAT_ROWS], rqx[COMPAT_ROWS], rqy[COMPAT_ROWS], rqz[COMPAT_ROWS];
-#pragma unroll
-  for (int r = 0; r < COMPAT_ROWS; r++) {
-    const int i = i0 + r;
-    rpx[r] = px[i]; rpy[r] = py[i]; rpz[r] = pz[i];
-    rqx[r] = qx[i]; rqy[r] = qy[i]; rqz[r] = qz[i];
-  }
-
-  for (int c0 = 0; c0 < ld; c0 += COMPAT_THREADS) {
-    const int j = c0 + threadIdx.x;
-    if (c0 + wave * 64 < ld) {  // wave-uniform: ld is a multiple of 64
-      const float jpx = px[j], jpy = py[j], jpz = pz[j], jqx = qx[j], jqy = qy[j], jqz = qz[j];
-#pragma unroll
-      for (int r = 0; r < COMPAT_ROWS; r++) {
-        const int i = i0 + r;
-        const float dp = dist3(rpx[r], rpy[r], rpz[r], jpx, jpy, jpz);
-        const float dq = dist3(rqx[r], rqy[r], rqz[r], jqx, jqy, jqz);
-        const float d = fabsf(dp - dq);
-        const bool e = (d <= d_thr) && (dp >= min_len) && (dq >= min_len) && (j != i) && (j < n) && (i < n);
-        const uint64_t word = __ballot(e);
-        float s = 0.0f;
-        if (word != 0) {  // wave-uniform: skip the polynomial when no lane holds an edge
-          const float v = sc_expf((d * d) * nis);
-          s = e ? v : 0.0f;
-        }
-        if (i < n) S[(size_t)i * ld + j] = s;
-        if (lane == 0) lbits[r * W + (c0 >> 6) + wave] = word;
-      }
+  const float jpx = px[j], jpy = py[j], jpz = pz[j], jqx = qx[j], jqy = qy[j], jqz = qz[j];
+  const int i0s = __builtin_amdgcn_readfirstlane(i0);  // provably wave-uniform row base
+  float* myT = tileT[wave];
+  uint64_t rowword = 0;      // lane r: adjacency word of row i0 + r over this column block
+  uint32_t colword = 0;      // lane c: bit r = edge (row i0 + r, column j)
+  // Interior tiles (every row and column real, not on the diagonal) are ~97 % of the work: they skip the bounds and
+  // i != j predicates.  Two rows per trip; ONE wave-uniform branch around the exponential polynomial.
+  const bool interior = !diag && (i0 + TILE_R <= n) && (J * 64 + 64 <= n);
+  auto row_pair = [&](int r, auto guarded) {
+    constexpr bool G = decltype(guarded)::value;
+    float dpa, dqa, dpb, dqb;
+    {  // row operands: wave-uniform addresses -> scalar loads, no VALU work
+      const float ipx = px[i0s + r], ipy = py[i0s + r], ipz = pz[i0s + r], iqx = qx[i0s + r], iqy = qy[i0s + r],
+                  iqz = qz[i0s + r];
+      dpa = dist3_fast(ipx, ipy, ipz, jpx, jpy, jpz);
+      dqa = dist3_fast(iqx, iqy, iqz, jqx, jqy, jqz);
     }
+    {
+      const float ipx = px[i0s + r + 1], ipy = py[i0s + r + 1], ipz = pz[i0s + r + 1], iqx = qx[i0s + r + 1],
+                  iqy = qy[i0s + r + 1], iqz = qz[i0s + r + 1];
+      dpb = dist3_fast(ipx, ipy, ipz, jpx, jpy, jpz);
+      dqb = dist3_fast(iqx, iqy, iqz, jqx, jqy, jqz);
+    }
+    const int ia = i0 + r, ib = ia + 1;
+    const float da = fabsf(dpa - dqa), db = fabsf(dpb - dqb);
+    bool ea = (da <= d_thr) && (dpa >= min_len) && (dqa >= min_len);
+    bool eb = (db <= d_thr) && (dpb >= min_len) && (dqb >= min_len);
+    if (G) {
+      ea = ea && (j != ia) && (j < n) && (ia < n);
+      eb = eb && (j != ib) && (j < n) && (ib < n);
+    }
+    const uint64_t worda = __ballot(ea), wordb = __ballot(eb);
+    float sa = 0.0f, sb = 0.0f;
+    if ((worda | wordb) != 0) {
+      const float va = sc_expf((da * da) * nis), vb = sc_expf((db * db) * nis);
+      sa = ea ? va : 0.0f;
+      sb = eb ? vb : 0.0f;
+    }
+    if (!G || ia < n) S[(size_t)ia * ld + j] = sa;
+    if (!G || ib < n) S[(size_t)ib * ld + j] = sb;
+    if (lane == r) rowword = worda;
+    if (lane == r + 1) rowword = wordb;
+    colword |= (ea ? (1u << r) : 0u) | (eb ? (2u << r) : 0u);
+    if (!diag) { myT[lane * TILE_PAD + r] = sa; myT[lane * TILE_PAD + r + 1] = sb; }
+  };
+  if (interior) {
+#pragma unroll 2
+    for (int r = 0; r < TILE_R; r += 2) row_pair(r, std::false_type{});
+  } else {
+#pragma unroll 2
+    for (int r = 0; r < TILE_R; r += 2) row_pair(r, std::true_type{});
   }
-  __syncthreads();
-  // epilogue: wave r owns row i0 + r — write its bit row coalesced, reduce deg and deg+ (bits above i), and emit
-  // the word-prefix popcounts wpre[i][w] = #set bits of row i in words [0, w): they turn "index of edge (i,k) in
-  // the CSR arrays" into an O(1) lookup for stage B.
-  {
-    const int r = wave, i = i0 + r;
-    if (i < n) {
-      uint32_t d_all = 0, d_up = 0;
-      for (int wb = 0; wb < W; wb += 64) {
-        const int w = wb + lane;
-        const uint64_t v = w < W ? lbits[r * W + w] : 0ull;
-        const uint32_t pc = (uint32_t)__popcll(v);
-        uint32_t inc = pc;  // inclusive wave scan of the word popcounts
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-          const uint32_t t = __shfl_up(inc, o);
-          if (lane >= o) inc += t;
-        }
-        if (w < W) {
-          bits[(size_t)i * W + w] = v;
-          wpre[(size_t)i * W + w] = d_all + inc - pc;
-          uint64_t up = v;
-          if (w < (i >> 6)) up = 0;
-          else if (w == (i >> 6)) up &= ((i & 63) == 63) ? 0ull : (~0ull << ((i & 63) + 1));
-          d_up += __popcll(up);
-        }
-        d_all += __shfl(inc, 63);
-      }
-#pragma unroll
-      for (int o = 32; o > 0; o >>= 1) d_up += __shfl_xor(d_up, o);
-      if (lane == 0) { deg[i] = d_all; degp[i] = d_up; }
+  if (lane < TILE_R && i0 + lane < n) bits[(size_t)(i0 + lane) * W + J] = rowword;
+  if (!diag) {
+    // mirrored half: row j of S, columns i0 .. i0 + TILE_R - 1; SUB output rows per instruction
+    const int r = lane & (TILE_R - 1), hi = lane / TILE_R;
+#pragma unroll 4
+    for (int c = 0; c < 64; c += SUB) {
+      const int cc = c + hi;
+      const float v = myT[cc * TILE_PAD + r];
+      const int jj = J * 64 + cc;
+      if (jj < n) S[(size_t)jj * ld + i0 + r] = v;
+    }
+    // mirrored adjacency: row j, piece (h % SUB) of word (i0 / 64)
+    if (j < n) {
+      if (TILE_R == 32) reinterpret_cast<uint32_t*>(bits)[((size_t)j * W + (i0 >> 6)) * 2 + (h % SUB)] = colword;
+      else reinterpret_cast<uint16_t*>(bits)[((size_t)j * W + (i0 >> 6)) * 4 + (h % SUB)] = (uint16_t)colword;
     }
   }
 }
 
-void launch_compat(const Points& pts, const Derived& dv, float* S, uint64_t* bits, uint32_t* deg,
-                   uint32_t* degp, uint32_t* wpre, hipStream_t st) {
-  static_assert(COMPAT_ROWS * 64 == COMPAT_THREADS, "epilogue maps wave r to row r");
+// deg[i], degp[i] (bits above i) and wpre[i][w] = #set bits of row i in words [0, w): one wave per row.
+__global__ __launch_bounds__(256) void row_stats_kernel(const uint64_t* __restrict__ bits, int n, int W,
+                                                        uint32_t* __restrict__ deg, uint32_t* __restrict__ degp,
+                                                        uint32_t* __restrict__ wpre) {
+  const int lane = threadIdx.x & 63;
+  const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (i >= n) return;
+  uint32_t d_all = 0, d_up = 0;
+  for (int wb = 0; wb < W; wb += 64) {
+    const int w = wb + lane;
+    const uint64_t v = w < W ? bits[(size_t)i * W + w] : 0ull;
+    const uint32_t pc = (uint32_t)__popcll(v);
+    uint32_t inc = pc;  // inclusive wave scan of the word popcounts
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const uint32_t t = __shfl_up(inc, o);
+      if (lane >= o) inc += t;
+    }
+    if (w < W) {
+      wpre[(size_t)i * W + w] = d_all + inc - pc;
+      uint64_t up = v;
+      if (w < (i >> 6)) up = 0;
+      else if (w == (i >> 6)) up &= ((i & 63) == 63) ? 0ull : (~0ull << ((i & 63) + 1));
+      d_up += __popcll(up);
+    }
+    d_all += __shfl(inc, 63);
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) d_up += __shfl_xor(d_up, o);
+  if (lane == 0) { deg[i] = d_all; degp[i] = d_up; }
+}
+
+void launch_compat(const Points& pts, const Derived& dv, float* S, uint64_t* bits, hipStream_t st) {
   const int W = pts.ld >> 6;
-  const int grid = (pts.n + COMPAT_ROWS - 1) / COMPAT_ROWS;
-  const size_t lds = (size_t)COMPAT_ROWS * W * sizeof(uint64_t);
-  hipLaunchKernelGGL(compat_rows_kernel, dim3(grid), dim3(COMPAT_THREADS), lds, st, pts.planes, pts.n, pts.ld,
-                     dv.d_thr, dv.min_len, dv.neg_inv2sig2, S, bits, deg, degp, wpre);
+  // 16-row tiles: 4.3 KiB of LDS per wave -> 8 waves per SIMD (32-row tiles measured 37 us vs 30 us on C2)
+  constexpr int TR = 16;
+  const int n_tiles = (64 / TR) * W * (W + 1) / 2;
+  hipLaunchKernelGGL(compat_tiles_kernel<TR>, dim3((n_tiles + COMPAT_WAVES - 1) / COMPAT_WAVES), dim3(64 * COMPAT_WAVES),
+                     0, st, pts.planes, pts.n, pts.ld, dv.d_thr, dv.min_len, dv.neg_inv2sig2, S, bits, n_tiles);
+}
+
+void launch_row_stats(const Points& pts, const uint64_t* bits, uint32_t* deg, uint32_t* degp, uint32_t* wpre,
+                      hipStream_t st) {
+  hipLaunchKernelGGL(row_stats_kernel, dim3((pts.n + 3) / 4), dim3(256), 0, st, bits, pts.n, pts.ld >> 6, deg, degp,
+                     wpre);
 }
 
 // ------------------------------------------------------------------------------------------------

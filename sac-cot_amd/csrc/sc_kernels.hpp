@@ -29,9 +29,10 @@ void launch_stage_points(const float* d_src, const float* d_tgt, int n, int ld, 
 
 // ---- stage A: compat_graph -----------------------------------------------------------------------
 // S: n x ld fp32 (row-major, symmetric, zero diagonal / pad columns); bits: n x (ld/64) u64;
+void launch_compat(const Points& pts, const Derived& dv, float* S, uint64_t* bits, hipStream_t st);
 // deg[i] = edges of i; degp[i] = edges (i,j) with j > i; wpre: n x (ld/64) u32, set bits of row i in words [0,w).
-void launch_compat(const Points& pts, const Derived& dv, float* S, uint64_t* bits, uint32_t* deg,
-                   uint32_t* degp, uint32_t* wpre, hipStream_t st);
+void launch_row_stats(const Points& pts, const uint64_t* bits, uint32_t* deg, uint32_t* degp, uint32_t* wpre,
+                      hipStream_t st);
 
 // ---- exclusive scan u32 -> u64 (out has n+1 entries; out[n] = total) -----------------------------
 size_t scan_temp_bytes(size_t n);
