@@ -40,9 +40,9 @@ struct sc_ctx {
   uint64_t* pinned = nullptr;  // 8 x u64 host-pinned read-back area
 
   // workspace
-  Buf in_src, in_tgt, planes, S, bits, deg, degp, wpre, ebase, edge_off, scan_tmp, ei, ej, es, tcnt, toff, wkey, sel, blk_gt,
-      blk_eq, blk_minmax, bits2, prune_hist, smin, off_gt, off_eq, sel_ord, sortkey, sorted, sort_tmp, tri, trikey, rt, rt_aos, partial, cnt, key, rt12,
-      mask, flag;
+  Buf in_src, in_tgt, planes, S, bits, deg, degp, wpre, ebase, edge_off, scan_tmp, ei, ej, es, tcnt, toff, wkey, ctl, blk_gt,
+      blk_eq, blk_minmax, bits2, off_gt, off_eq, sel_ord, sortkey, sorted, sort_tmp, tri, trikey, rt, rt_aos, partial, cnt, key, rt12,
+      mask;
 
   // state of the last hypothesize call (consumed by finalize)
   int n = 0, ld = 0;
@@ -140,9 +140,12 @@ int stage_inputs(sc_ctx* c, const float* d_src, const float* d_tgt, int64_t n, c
   c->n = (int)n;
   c->ld = round_up((int)n, 64);
   ENSURE(c, c->planes, (size_t)6 * c->ld * sizeof(float));
-  ENSURE(c, c->flag, 64);
-  HIPCHK(c, hipMemsetAsync(c->flag.p, 0, 64, c->stream));
-  launch_stage_points(d_src, d_tgt, c->n, c->ld, p->layout, c->planes.as<float>(), c->flag.as<uint32_t>(), c->stream);
+  // per-call control block: ONE memset instead of one per flag / histogram / key
+  ENSURE(c, c->ctl, sizeof(ControlBlock));
+  HIPCHK(c, hipMemsetAsync(c->ctl.p, 0, sizeof(ControlBlock), c->stream));
+  c->pinned[1] = 0;  // "non-finite input" flag lives in host-pinned memory: the kernel only touches it on bad data
+  launch_stage_points(d_src, d_tgt, c->n, c->ld, p->layout, c->planes.as<float>(),
+                      reinterpret_cast<uint32_t*>(&c->pinned[1]), c->stream);
   return SC_OK;
 }
 
@@ -158,10 +161,18 @@ int run_compat(sc_ctx* c) {
 }
 
 // deg / deg+ / word-prefix popcounts from the bit rows (first kernel of stage B's timing bracket)
-void run_row_stats(sc_ctx* c) {
+int run_row_stats(sc_ctx* c, bool will_prune) {
+  uint64_t* zero_rows = nullptr;
+  if (will_prune) {  // the pruned bit matrix is cleared on the way (no separate memset)
+    ENSURE(c, c->bits2, (size_t)c->n * (c->ld >> 6) * sizeof(uint64_t));
+    zero_rows = c->bits2.as<uint64_t>();
+  }
   launch_row_stats(points_of(c), c->bits.as<uint64_t>(), c->deg.as<uint32_t>(), c->degp.as<uint32_t>(),
-                   c->wpre.as<uint32_t>(), c->stream);
+                   c->wpre.as<uint32_t>(), zero_rows, c->stream);
+  return SC_OK;
 }
+
+bool may_prune(const sc_params* p) { return p->rank_mode == SC_RANK_WEIGHT && !(p->flags & SC_FLAG_NO_PRUNE); }
 
 // stage B; on return c->E, c->M, c->T_eff are set and tri/trikey hold the ranked list
 int run_triangles(sc_ctx* c, const sc_params* p) {
@@ -169,10 +180,8 @@ int run_triangles(sc_ctx* c, const sc_params* p) {
   hipStream_t st = c->stream;
   ENSURE(c, c->edge_off, (n + 1) * sizeof(uint64_t));
   ENSURE(c, c->scan_tmp, scan_temp_bytes(n));
-  launch_scan_u32(c->degp.as<uint32_t>(), n, c->edge_off.as<uint64_t>(), c->scan_tmp.p, st);
-  // read-back #1: edge count + the non-finite flag
-  HIPCHK(c, hipMemcpyAsync(&c->pinned[0], c->edge_off.as<uint64_t>() + n, 8, hipMemcpyDeviceToHost, st));
-  HIPCHK(c, hipMemcpyAsync(&c->pinned[1], c->flag.p, 4, hipMemcpyDeviceToHost, st));
+  // read-back #1: the scan kernel itself writes the edge count to host-pinned memory (no copy kernel)
+  launch_scan_u32(c->degp.as<uint32_t>(), n, c->edge_off.as<uint64_t>(), c->scan_tmp.p, st, &c->pinned[0]);
   HIPCHK(c, hipStreamSynchronize(st));
   if ((uint32_t)c->pinned[1] != 0) { c->last_error = "non-finite input coordinate"; return SC_EINVAL; }
   const uint64_t E = c->E = c->pinned[0];
@@ -189,36 +198,31 @@ int run_triangles(sc_ctx* c, const sc_params* p) {
   launch_edge_fill(g, c->edge_off.as<uint64_t>(), c->ei.as<uint32_t>(), c->ej.as<uint32_t>(), c->es.as<float>(),
                    c->ebase.as<uint32_t>(), st);
   // certified pruning (sc_tri.hip §3b): weight ranking only; pointless on tiny graphs
-  const bool prune = (p->rank_mode == SC_RANK_WEIGHT) && !(p->flags & SC_FLAG_NO_PRUNE) && E >= 4096;
+  const bool prune = may_prune(p) && E >= 4096;
   c->pruned = prune;
   const uint64_t* mbits = g.bits;
   const float* smin = nullptr;
   bool have_total = false;
   if (prune) {
-    ENSURE(c, c->bits2, (size_t)c->n * g.W * sizeof(uint64_t));
-    ENSURE(c, c->prune_hist, 256 * 4);
-    ENSURE(c, c->smin, 64);
+    ControlBlock* ctl = c->ctl.as<ControlBlock>();
     if (p->flags & SC_FLAG_EXACT_TOTAL) {  // statistics only: 3-cliques of the whole graph
       launch_tri_count(g, g.bits, c->es.as<float>(), nullptr, c->ei.as<uint32_t>(), c->ej.as<uint32_t>(), E,
                        c->tcnt.as<uint32_t>(), st);
-      launch_scan_u32(c->tcnt.as<uint32_t>(), E, c->toff.as<uint64_t>(), c->scan_tmp.p, st);
-      HIPCHK(c, hipMemcpyAsync(&c->pinned[4], c->toff.as<uint64_t>() + E, 8, hipMemcpyDeviceToHost, st));
+      launch_scan_u32(c->tcnt.as<uint32_t>(), E, c->toff.as<uint64_t>(), c->scan_tmp.p, st, &c->pinned[4]);
       have_total = true;
     }
     // the smallest possible weight is ~3 t_cmp (every edge has s >= t_cmp up to rounding); 0.1 % slack
     launch_prune(g, c->ebase.as<uint32_t>(), c->ei.as<uint32_t>(), c->ej.as<uint32_t>(), c->es.as<float>(), E,
-                 p->max_triangles, 3.0f * p->t_cmp * 0.999f, c->prune_hist.as<uint32_t>(), c->bits2.as<uint64_t>(),
-                 c->smin.as<float>(), st);
+                 p->max_triangles, 3.0f * p->t_cmp * 0.999f, ctl->prune_hist, c->bits2.as<uint64_t>(), &ctl->smin, st);
     mbits = c->bits2.as<uint64_t>();
-    smin = c->smin.as<float>();
+    smin = &ctl->smin;
   }
   c->mbits = mbits;
   c->smin_ptr = smin;
   launch_tri_count(g, mbits, c->es.as<float>(), smin, c->ei.as<uint32_t>(), c->ej.as<uint32_t>(), E,
                    c->tcnt.as<uint32_t>(), st);
-  launch_scan_u32(c->tcnt.as<uint32_t>(), E, c->toff.as<uint64_t>(), c->scan_tmp.p, st);
-  // read-back #2: triangle count (of the pruned graph when pruning)
-  HIPCHK(c, hipMemcpyAsync(&c->pinned[2], c->toff.as<uint64_t>() + E, 8, hipMemcpyDeviceToHost, st));
+  // read-back #2: triangle count (of the pruned graph when pruning), written to pinned memory by the scan
+  launch_scan_u32(c->tcnt.as<uint32_t>(), E, c->toff.as<uint64_t>(), c->scan_tmp.p, st, &c->pinned[2]);
   HIPCHK(c, hipStreamSynchronize(st));
   c->M_total = have_total ? c->pinned[4] : c->pinned[2];
   const uint64_t M = c->M = c->pinned[2];
@@ -227,7 +231,6 @@ int run_triangles(sc_ctx* c, const sc_params* p) {
   if (M * 4 > c->cap_bytes) { c->last_error = "triangle keys exceed the workspace cap"; return SC_ETOOMANY; }
   const size_t nb = compact_blocks(M);
   ENSURE(c, c->wkey, M * 4);
-  ENSURE(c, c->sel, sizeof(SelectState));
   ENSURE(c, c->blk_minmax, 2 * 8192 * 4);
   ENSURE(c, c->blk_gt, nb * 4);
   ENSURE(c, c->blk_eq, nb * 4);
@@ -241,12 +244,11 @@ int run_triangles(sc_ctx* c, const sc_params* p) {
   ENSURE(c, c->sort_tmp, sort_bytes + 16);
   ENSURE(c, c->tri, (size_t)T_eff * 12);
   ENSURE(c, c->trikey, (size_t)T_eff * 4);
-  SelectState* sel = c->sel.as<SelectState>();
-  launch_select_init(sel, T_eff, st);
+  SelectState* sel = &c->ctl.as<ControlBlock>()->sel;
   if (c->timing) HIPCHK(c, hipEventRecord(c->ev[9], st));
   launch_tri_keys(g, mbits, smin, c->ebase.as<uint32_t>(), c->ei.as<uint32_t>(), c->ej.as<uint32_t>(),
                   c->es.as<float>(), c->toff.as<uint64_t>(), E, p->rank_mode, c->wkey.as<uint32_t>(), c->blk_minmax.as<uint32_t>(), sel,
-                  st);
+                  T_eff, st);
   if (c->timing) HIPCHK(c, hipEventRecord(c->ev[10], st));
   c->timed_trikeys = c->timing;
   launch_select_rounds(c->wkey.as<uint32_t>(), M, sel, st);
@@ -291,7 +293,6 @@ int host_to_planes(sc_ctx* c, const float* src, const float* tgt, int64_t n, con
 }
 
 int check_flag(sc_ctx* c) {
-  HIPCHK(c, hipMemcpyAsync(&c->pinned[1], c->flag.p, 4, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   if ((uint32_t)c->pinned[1] != 0) { c->last_error = "non-finite input coordinate"; return SC_EINVAL; }
   return SC_OK;
@@ -358,9 +359,9 @@ void sc_destroy(sc_ctx* c) {
   (void)hipSetDevice(c->device);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   Buf* bufs[] = {&c->in_src, &c->in_tgt, &c->planes, &c->S, &c->bits, &c->deg, &c->degp, &c->wpre, &c->ebase, &c->edge_off, &c->scan_tmp,
-                 &c->ei, &c->ej, &c->es, &c->tcnt, &c->toff, &c->wkey, &c->sel, &c->blk_gt, &c->blk_eq, &c->blk_minmax, &c->bits2, &c->prune_hist, &c->smin, &c->off_gt,
+                 &c->ei, &c->ej, &c->es, &c->tcnt, &c->toff, &c->wkey, &c->ctl, &c->blk_gt, &c->blk_eq, &c->blk_minmax, &c->bits2, &c->off_gt,
                  &c->off_eq, &c->sel_ord, &c->sortkey, &c->sorted, &c->sort_tmp, &c->tri, &c->trikey, &c->rt,
-                 &c->rt_aos, &c->partial, &c->cnt, &c->key, &c->rt12, &c->mask, &c->flag};
+                 &c->rt_aos, &c->partial, &c->cnt, &c->key, &c->rt12, &c->mask};
   for (Buf* b : bufs) if (b->p) (void)hipFree(b->p);
   for (int i = 0; i < N_EVENTS; i++) if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
   if (c->pinned) (void)hipHostFree(c->pinned);
@@ -394,7 +395,7 @@ int sc_hypothesize_device(sc_ctx* c, const float* d_src, const float* d_tgt, int
   if ((rc = rec(c, 1))) return rc;
   if ((rc = run_compat(c))) return rc;
   if ((rc = rec(c, 2))) return rc;
-  run_row_stats(c);
+  if ((rc = run_row_stats(c, may_prune(p)))) return rc;
   if ((rc = run_triangles(c, p))) return rc;
   if ((rc = rec(c, 3))) return rc;
   // stage C on this rank's share of the ranked list
@@ -511,7 +512,7 @@ int sc_compat_host(sc_ctx* c, const float* src, const float* tgt, int64_t n, con
   c->dv = derive(p);
   if ((rc = host_to_planes(c, src, tgt, n, p))) return rc;
   if ((rc = run_compat(c))) return rc;
-  run_row_stats(c);
+  if ((rc = run_row_stats(c, false))) return rc;
   if ((rc = check_flag(c))) return rc;
   const size_t W = (size_t)c->ld >> 6;
   if (S)
@@ -536,7 +537,7 @@ int sc_triangles_host(sc_ctx* c, const float* src, const float* tgt, int64_t n, 
   c->dv = derive(p);
   if ((rc = host_to_planes(c, src, tgt, n, p))) return rc;
   if ((rc = run_compat(c))) return rc;
-  run_row_stats(c);
+  if ((rc = run_row_stats(c, may_prune(p)))) return rc;
   sc_params pe = *p;
   pe.flags |= SC_FLAG_EXACT_TOTAL;  // the hook reports the 3-clique count of the whole graph
   if ((rc = run_triangles(c, &pe))) return rc;

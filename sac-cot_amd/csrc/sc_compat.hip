@@ -165,10 +165,13 @@ __global__ __launch_bounds__(64 * COMPAT_WAVES) void compat_tiles_kernel(const f
 // deg[i], degp[i] (bits above i) and wpre[i][w] = #set bits of row i in words [0, w): one wave per row.
 __global__ __launch_bounds__(256) void row_stats_kernel(const uint64_t* __restrict__ bits, int n, int W,
                                                         uint32_t* __restrict__ deg, uint32_t* __restrict__ degp,
-                                                        uint32_t* __restrict__ wpre) {
+                                                        uint32_t* __restrict__ wpre,
+                                                        uint64_t* __restrict__ zero_rows) {
   const int lane = threadIdx.x & 63;
   const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (i >= n) return;
+  if (zero_rows)
+    for (int w = lane; w < W; w += 64) zero_rows[(size_t)i * W + w] = 0ull;
   uint32_t d_all = 0, d_up = 0;
   for (int wb = 0; wb < W; wb += 64) {
     const int w = wb + lane;
@@ -204,9 +207,9 @@ void launch_compat(const Points& pts, const Derived& dv, float* S, uint64_t* bit
 }
 
 void launch_row_stats(const Points& pts, const uint64_t* bits, uint32_t* deg, uint32_t* degp, uint32_t* wpre,
-                      hipStream_t st) {
+                      uint64_t* zero_rows, hipStream_t st) {
   hipLaunchKernelGGL(row_stats_kernel, dim3((pts.n + 3) / 4), dim3(256), 0, st, bits, pts.n, pts.ld >> 6, deg, degp,
-                     wpre);
+                     wpre, zero_rows);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -228,7 +231,8 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_block_sums_kernel(const uin
 }
 
 __global__ __launch_bounds__(1024) void scan_of_sums_kernel(uint64_t* __restrict__ bsum, size_t nb,
-                                                            uint64_t* __restrict__ total_out) {
+                                                            uint64_t* __restrict__ total_out,
+                                                            uint64_t* __restrict__ host_total) {
   __shared__ uint64_t lds[16];
   uint64_t carry = 0;
   for (size_t b0 = 0; b0 < nb; b0 += 1024) {
@@ -239,7 +243,10 @@ __global__ __launch_bounds__(1024) void scan_of_sums_kernel(uint64_t* __restrict
     if (b < nb) bsum[b] = carry + ex;
     carry += tot;
   }
-  if (threadIdx.x == 0) *total_out = carry;
+  if (threadIdx.x == 0) {
+    *total_out = carry;
+    if (host_total) *host_total = carry;
+  }
 }
 
 __global__ __launch_bounds__(SCAN_THREADS) void scan_downsweep_kernel(const uint32_t* __restrict__ in, size_t n,
@@ -263,7 +270,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_downsweep_kernel(const uint
 // small inputs: ONE block scans up to two arrays in one launch (three launches of the tiled scan are pure latency there)
 __global__ __launch_bounds__(1024) void scan_small_kernel(const uint32_t* __restrict__ in0, uint64_t* __restrict__ out0,
                                                           const uint32_t* __restrict__ in1, uint64_t* __restrict__ out1,
-                                                          size_t n) {
+                                                          size_t n, uint64_t* __restrict__ host_total) {
   __shared__ uint64_t lds[16];
   const int arrays = in1 ? 2 : 1;
   for (int a = 0; a < arrays; a++) {
@@ -278,7 +285,10 @@ __global__ __launch_bounds__(1024) void scan_small_kernel(const uint32_t* __rest
       if (b < n) out[b] = carry + ex;
       carry += tot;
     }
-    if (threadIdx.x == 0) out[n] = carry;
+    if (threadIdx.x == 0) {
+      out[n] = carry;
+      if (a == 0 && host_total) *host_total = carry;
+    }
   }
 }
 
@@ -287,7 +297,7 @@ constexpr size_t SCAN_SMALL_MAX = 32768;
 void launch_scan_u32_pair(const uint32_t* in0, uint64_t* out0, const uint32_t* in1, uint64_t* out1, size_t n,
                           void* temp, hipStream_t st) {
   if (n <= SCAN_SMALL_MAX) {
-    hipLaunchKernelGGL(scan_small_kernel, dim3(1), dim3(1024), 0, st, in0, out0, in1, out1, n);
+    hipLaunchKernelGGL(scan_small_kernel, dim3(1), dim3(1024), 0, st, in0, out0, in1, out1, n, (uint64_t*)nullptr);
   } else {
     launch_scan_u32(in0, n, out0, temp, st);
     if (in1) launch_scan_u32(in1, n, out1, temp, st);
@@ -296,17 +306,17 @@ void launch_scan_u32_pair(const uint32_t* in0, uint64_t* out0, const uint32_t* i
 
 size_t scan_temp_bytes(size_t n) { return ((n + SCAN_TILE - 1) / SCAN_TILE + 1) * sizeof(uint64_t); }
 
-void launch_scan_u32(const uint32_t* in, size_t n, uint64_t* out, void* temp, hipStream_t st) {
+void launch_scan_u32(const uint32_t* in, size_t n, uint64_t* out, void* temp, hipStream_t st, uint64_t* host_total) {
   if (n <= SCAN_SMALL_MAX) {
     hipLaunchKernelGGL(scan_small_kernel, dim3(1), dim3(1024), 0, st, in, out, (const uint32_t*)nullptr,
-                       (uint64_t*)nullptr, n);
+                       (uint64_t*)nullptr, n, host_total);
     return;
   }
   uint64_t* bsum = static_cast<uint64_t*>(temp);
   const size_t nb = (n + SCAN_TILE - 1) / SCAN_TILE;
-  if (nb == 0) { (void)hipMemsetAsync(out, 0, sizeof(uint64_t), st); return; }
+  if (nb == 0) return;  // n == 0 is handled by the small path above
   hipLaunchKernelGGL(scan_block_sums_kernel, dim3((unsigned)nb), dim3(SCAN_THREADS), 0, st, in, n, bsum);
-  hipLaunchKernelGGL(scan_of_sums_kernel, dim3(1), dim3(1024), 0, st, bsum, nb, out + n);
+  hipLaunchKernelGGL(scan_of_sums_kernel, dim3(1), dim3(1024), 0, st, bsum, nb, out + n, host_total);
   hipLaunchKernelGGL(scan_downsweep_kernel, dim3((unsigned)nb), dim3(SCAN_THREADS), 0, st, in, n, bsum, out);
 }
 

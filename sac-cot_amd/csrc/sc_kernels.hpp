@@ -24,6 +24,7 @@ struct Points {
 
 // ---- input staging -----------------------------------------------------------------------------
 // user layout (AoS n x 3 or SoA 3 x n) -> padded planes; sets *bad_flag != 0 when a value is not finite.
+// bad_flag may be host-pinned memory: it is only touched (atomicOr) when a non-finite value is found.
 void launch_stage_points(const float* d_src, const float* d_tgt, int n, int ld, int layout, float* planes,
                          uint32_t* bad_flag, hipStream_t st);
 
@@ -31,12 +32,16 @@ void launch_stage_points(const float* d_src, const float* d_tgt, int n, int ld, 
 // S: n x ld fp32 (row-major, symmetric, zero diagonal / pad columns); bits: n x (ld/64) u64;
 void launch_compat(const Points& pts, const Derived& dv, float* S, uint64_t* bits, hipStream_t st);
 // deg[i] = edges of i; degp[i] = edges (i,j) with j > i; wpre: n x (ld/64) u32, set bits of row i in words [0,w).
+// zero_rows (optional): an n x W u64 matrix cleared on the way (the pruned bit matrix of stage B).
 void launch_row_stats(const Points& pts, const uint64_t* bits, uint32_t* deg, uint32_t* degp, uint32_t* wpre,
-                      hipStream_t st);
+                      uint64_t* zero_rows, hipStream_t st);
 
 // ---- exclusive scan u32 -> u64 (out has n+1 entries; out[n] = total) -----------------------------
+// host_total (optional): host-pinned u64 that also receives the total, written by the kernel itself — the host
+// reads it after its next stream synchronise, with no copy kernel in between.
 size_t scan_temp_bytes(size_t n);
-void launch_scan_u32(const uint32_t* in, size_t n, uint64_t* out, void* temp, hipStream_t st);
+void launch_scan_u32(const uint32_t* in, size_t n, uint64_t* out, void* temp, hipStream_t st,
+                     uint64_t* host_total = nullptr);
 // two arrays of the same length in one go (one launch when n is small); in1/out1 may be null
 void launch_scan_u32_pair(const uint32_t* in0, uint64_t* out0, const uint32_t* in1, uint64_t* out1, size_t n,
                           void* temp, hipStream_t st);
@@ -63,25 +68,38 @@ void launch_tri_count(const Graph& g, const uint64_t* mbits, const float* es, co
 // matrix `mbits` (n x W, zeroed here).  key_floor: a value at or below the smallest possible triangle weight.
 void launch_prune(const Graph& g, const uint32_t* ebase, const uint32_t* ei, const uint32_t* ej, const float* es,
                   uint64_t E, uint64_t want, float key_floor, uint32_t* hist, uint64_t* mbits, float* smin,
-                  hipStream_t st);
+                  hipStream_t st);  // hist and mbits must already be zero
 
-// Radix-select state, lives in device memory; zeroed by launch_select_init.
+// Radix-select state.  Lives in the context's control block, which ONE memset zeroes per call; key_range_kernel
+// (end of launch_tri_keys) fills kmin / kmax / want.
 struct SelectState {
-  uint32_t kmin, kmax;   // key range, filled by tri_keys
-  uint32_t lo, wbits;    // current window [lo, lo + 2^wbits); wbits = 0xFFFFFFFF before the first round
-  uint32_t done, kstar;  // kstar valid when done
-  uint64_t want;         // number of keys to keep
-  uint64_t above;        // keys strictly above the current window
-  uint64_t need_eq;      // how many keys == kstar to keep (lowest ordinals first)
+  uint32_t kmin, kmax;     // key range
+  uint32_t lo, wbits;      // current window [lo, lo + 2^wbits), valid once started != 0
+  uint32_t started, done;  // kstar / need_eq valid when done
+  uint32_t kstar, ticket;  // ticket: blocks-finished counter of the running round
+  uint64_t want;           // number of keys to keep
+  uint64_t above;          // keys strictly above the current window
+  uint64_t need_eq;        // how many keys == kstar to keep (lowest ordinals first)
   uint32_t hist[2048];
 };
-void launch_select_init(SelectState* s, uint64_t want, hipStream_t st);
+
+// Per-call control block (device memory, zeroed by one hipMemsetAsync at the start of every call).
+struct ControlBlock {
+  uint32_t prune_hist[256];  // sampled key histogram of the certified pruning
+  float smin;                // strong-edge threshold (written by prune_bits_kernel)
+  uint32_t pad0[15];
+  uint64_t key2[2];          // internal winner key pair (sc_register_device)
+  uint64_t pad1[6];
+  SelectState sel;
+};
+
 // key of every triangle, in ordinal (lexicographic i,j,k) order: wkey[toff[e] + r].
-// blk_minmax: 2 * 8192 u32 scratch (per-block key min / max, reduced into s->kmin / s->kmax).
+// blk_minmax: 2 * 8192 u32 scratch (per-block key min / max, reduced into s->kmin / s->kmax; s->want = want).
 void launch_tri_keys(const Graph& g, const uint64_t* mbits, const float* smin, const uint32_t* ebase,
                      const uint32_t* ei, const uint32_t* ej, const float* es, const uint64_t* toff, uint64_t E,
-                     int rank_mode, uint32_t* wkey, uint32_t* blk_minmax, SelectState* s, hipStream_t st);
-// up to three (hist, pick) rounds find the exact threshold key
+                     int rank_mode, uint32_t* wkey, uint32_t* blk_minmax, SelectState* s, uint64_t want,
+                     hipStream_t st);
+// up to three rounds (histogram + pick by the last block to finish) find the exact threshold key
 void launch_select_rounds(const uint32_t* wkey, uint64_t M, SelectState* s, hipStream_t st);
 // compaction of the selected keys in ordinal order
 size_t compact_blocks(uint64_t M);

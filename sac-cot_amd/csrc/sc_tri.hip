@@ -191,17 +191,6 @@ void launch_tri_count(const Graph& g, const uint64_t* mbits, const float* es, co
 // ------------------------------------------------------------------------------------------------
 // 3. tri_keys
 // ------------------------------------------------------------------------------------------------
-__global__ void select_init_kernel(SelectState* s, uint64_t want) {
-  for (int b = threadIdx.x; b < 2048; b += blockDim.x) s->hist[b] = 0;
-  if (threadIdx.x == 0) {
-    s->kmin = 0xFFFFFFFFu; s->kmax = 0; s->lo = 0; s->wbits = 0xFFFFFFFFu; s->done = 0; s->kstar = 0;
-    s->want = want; s->above = 0; s->need_eq = 0;
-  }
-}
-void launch_select_init(SelectState* s, uint64_t want, hipStream_t st) {
-  hipLaunchKernelGGL(select_init_kernel, dim3(1), dim3(256), 0, st, s, want);
-}
-
 constexpr int TK_MAX_BLOCKS = 4096;  // bounds the per-block min/max arrays
 
 // bits / wpre / ebase: full adjacency + its word-prefix popcounts + per-row CSR bases: the index of edge (v,k) in the
@@ -307,7 +296,7 @@ __global__ __launch_bounds__(256) void tri_keys_kernel(const uint64_t* __restric
 
 __global__ __launch_bounds__(1024) void key_range_kernel(const uint32_t* __restrict__ blk_min,
                                                          const uint32_t* __restrict__ blk_max, int nb,
-                                                         SelectState* __restrict__ sel) {
+                                                         SelectState* __restrict__ sel, uint64_t want) {
   __shared__ uint32_t lmin[16], lmax[16];
   uint32_t kmin = 0xFFFFFFFFu, kmax = 0;
   for (int b = threadIdx.x; b < nb; b += 1024) { kmin = min(kmin, blk_min[b]); kmax = max(kmax, blk_max[b]); }
@@ -320,7 +309,7 @@ __global__ __launch_bounds__(1024) void key_range_kernel(const uint32_t* __restr
   __syncthreads();
   if (threadIdx.x == 0) {
     for (int w = 1; w < 16; w++) { kmin = min(kmin, lmin[w]); kmax = max(kmax, lmax[w]); }
-    sel->kmin = kmin; sel->kmax = kmax;
+    sel->kmin = kmin; sel->kmax = kmax; sel->want = want;
   }
 }
 
@@ -332,14 +321,15 @@ size_t tri_keys_blocks(uint64_t E, int tg) {
 
 void launch_tri_keys(const Graph& g, const uint64_t* mbits, const float* smin, const uint32_t* ebase,
                      const uint32_t* ei, const uint32_t* ej, const float* es, const uint64_t* toff, uint64_t E,
-                     int rank_mode, uint32_t* wkey, uint32_t* blk_minmax, SelectState* s, hipStream_t st) {
+                     int rank_mode, uint32_t* wkey, uint32_t* blk_minmax, SelectState* s, uint64_t want,
+                     hipStream_t st) {
   if (E == 0) return;
   const int tg = tune_tg("SC_TG_KEYS", 8);
   const int nb = (int)tri_keys_blocks(E, tg);
 #define SC_LAUNCH_KEYS(TGV) hipLaunchKernelGGL(tri_keys_kernel<TGV>, dim3(nb), dim3(256), 0, st, g.bits, mbits, smin, g.W, g.deg, g.wpre, ebase, ei, ej, es, toff, E, rank_mode, wkey, blk_minmax, blk_minmax + TK_MAX_BLOCKS)
   if (tg == 4) SC_LAUNCH_KEYS(4); else if (tg == 8) SC_LAUNCH_KEYS(8); else if (tg == 32) SC_LAUNCH_KEYS(32); else if (tg == 64) SC_LAUNCH_KEYS(64); else SC_LAUNCH_KEYS(16);
 #undef SC_LAUNCH_KEYS
-  hipLaunchKernelGGL(key_range_kernel, dim3(1), dim3(1024), 0, st, blk_minmax, blk_minmax + TK_MAX_BLOCKS, nb, s);
+  hipLaunchKernelGGL(key_range_kernel, dim3(1), dim3(1024), 0, st, blk_minmax, blk_minmax + TK_MAX_BLOCKS, nb, s, want);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -468,8 +458,6 @@ void launch_prune(const Graph& g, const uint32_t* ebase, const uint32_t* ei, con
   uint64_t stride = E / 32768;
   if (stride < 1) stride = 1;
   if (stride > 64) stride = 64;
-  (void)hipMemsetAsync(hist, 0, PR_BINS * sizeof(uint32_t), st);
-  (void)hipMemsetAsync(mbits, 0, (size_t)g.n * g.W * sizeof(uint64_t), st);
   const uint64_t n_s = (E + stride - 1) / stride;
   const int tg = tune_tg("SC_TG_SAMPLE", 8);
   uint64_t nb = (n_s + (256 / tg) - 1) / (256 / tg);
@@ -494,7 +482,7 @@ constexpr int SEL_ITEMS = 16;
 struct SelWindow { uint32_t lo, wbits, shift; };
 __device__ __forceinline__ SelWindow select_window(const SelectState* sel) {
   SelWindow w;
-  if (sel->wbits == 0xFFFFFFFFu) {  // first round: the window is the key range [kmin, kmax]
+  if (!sel->started) {  // first round: the window is the key range [kmin, kmax]
     w.lo = sel->kmin;
     const uint32_t range_m1 = sel->kmax - sel->kmin;
     w.wbits = range_m1 == 0 ? 0u : (uint32_t)(32 - __builtin_clz(range_m1));
@@ -520,13 +508,22 @@ __device__ __forceinline__ void hist_add(uint32_t* lh, bool in, uint32_t bin) {
   }
 }
 
-__global__ __launch_bounds__(SEL_THREADS) void select_hist_kernel(const uint32_t* __restrict__ wkey, uint64_t M,
-                                                                  SelectState* __restrict__ sel) {
+// One select round: every block histograms its share of the keys into the window's bins; the LAST block to finish
+// (device-scope ticket) walks the bins from the top, picks the bin holding the want-th key and narrows the window —
+// one launch per round instead of a histogram launch plus a pick launch.  Hand-off per cdna guide §6 G16, counter
+// form: hist adds are device-scope atomics; each block fences (release) before its ticket; the last block fences
+// (acquire) and reads the bins with device-scope atomic loads.
+__global__ __launch_bounds__(SEL_THREADS) void select_round_kernel(const uint32_t* __restrict__ wkey, uint64_t M,
+                                                                   SelectState* __restrict__ sel) {
   __shared__ uint32_t lh[SEL_BINS];
-  if (sel->done) return;
+  __shared__ uint64_t lds[8];
+  __shared__ uint32_t s_bin, s_last;
+  __shared__ uint64_t s_above;
+  if (sel->done) return;  // set by an earlier launch: uniform over the grid
   for (int b = threadIdx.x; b < SEL_BINS; b += SEL_THREADS) lh[b] = 0;
   __syncthreads();
   const SelWindow win = select_window(sel);
+  const uint64_t want = sel->want, above0 = sel->above;
   const uint64_t width = 1ull << win.wbits;
   const uint64_t M4 = M >> 2;  // whole uint4 groups (wkey comes from hipMalloc: 16-byte aligned)
   const uint4* __restrict__ wkey4 = reinterpret_cast<const uint4*>(wkey);
@@ -550,21 +547,31 @@ __global__ __launch_bounds__(SEL_THREADS) void select_hist_kernel(const uint32_t
     const uint32_t v = lh[b];
     if (v) atomicAdd(&sel->hist[b], v);
   }
-}
-
-// one block: walk the bins from the top, pick the bin holding the want-th key, narrow the window
-__global__ __launch_bounds__(256) void select_pick_kernel(SelectState* __restrict__ sel) {
-  __shared__ uint64_t lds[8];
-  __shared__ uint32_t s_bin;
-  __shared__ uint64_t s_above;
-  if (sel->done) return;
-  const SelWindow win = select_window(sel);
-  const uint64_t want = sel->want, above0 = sel->above;
+  // ---- arrive; the last block picks.  The bin adds are device-scope atomics (performed at L2 / memory side); every
+  // wave drains them, the block meets, then ONE lane releases at agent scope and takes a ticket (a __threadfence()
+  // by all 256 threads costs ~10 us per block here; this form ~2 us, and only the last block acquires).
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const uint32_t t = __hip_atomic_fetch_add(&sel->ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    s_last = (t == gridDim.x - 1) ? 1u : 0u;
+    if (s_last) {
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+  }
+  __syncthreads();
+  if (!s_last) return;
   // thread t owns bins [8t, 8t+8) counted from the TOP: bin index = 2047 - (8t + k)
   uint32_t h[8];
   uint64_t mine = 0;
 #pragma unroll
-  for (int k = 0; k < 8; k++) { h[k] = sel->hist[SEL_BINS - 1 - (threadIdx.x * 8 + k)]; mine += h[k]; }
+  for (int k = 0; k < 8; k++) {
+    h[k] = __hip_atomic_load(&sel->hist[SEL_BINS - 1 - (threadIdx.x * 8 + k)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    mine += h[k];
+  }
   if (threadIdx.x == 0) { s_bin = 0; s_above = above0; }
   uint64_t tot;
   const uint64_t before = above0 + block_exscan_u64(mine, lds, &tot);
@@ -578,12 +585,14 @@ __global__ __launch_bounds__(256) void select_pick_kernel(SelectState* __restric
     }
   }
   __syncthreads();
-  for (int b = threadIdx.x; b < SEL_BINS; b += 256) sel->hist[b] = 0;
+  for (int b = threadIdx.x; b < SEL_BINS; b += SEL_THREADS) sel->hist[b] = 0;  // ready for the next round (next launch)
   if (threadIdx.x == 0) {
     const uint32_t nlo = win.lo + (s_bin << win.shift);
     sel->above = s_above;
     sel->lo = nlo;
     sel->wbits = win.shift;  // the chosen bin is the next window
+    sel->started = 1;
+    sel->ticket = 0;
     if (win.shift == 0) { sel->done = 1; sel->kstar = nlo; sel->need_eq = want - s_above; }
   }
 }
@@ -593,10 +602,8 @@ void launch_select_rounds(const uint32_t* wkey, uint64_t M, SelectState* s, hipS
   uint64_t blocks = (M + (uint64_t)SEL_THREADS * SEL_ITEMS - 1) / ((uint64_t)SEL_THREADS * SEL_ITEMS);
   if (blocks > 2048) blocks = 2048;
   if (blocks == 0) blocks = 1;
-  for (int round = 0; round < 3; round++) {
-    hipLaunchKernelGGL(select_hist_kernel, dim3((unsigned)blocks), dim3(SEL_THREADS), 0, st, wkey, M, s);
-    hipLaunchKernelGGL(select_pick_kernel, dim3(1), dim3(256), 0, st, s);
-  }
+  for (int round = 0; round < 3; round++)
+    hipLaunchKernelGGL(select_round_kernel, dim3((unsigned)blocks), dim3(SEL_THREADS), 0, st, wkey, M, s);
 }
 
 // ------------------------------------------------------------------------------------------------
