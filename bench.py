@@ -5,8 +5,8 @@
     (N > 1: launched by the driver as  python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...)
 
 A *step* is one full pass of the hot path over one synthetic correspondence set already resident in HBM:
-stage A (compat graph) -> B (ranked top-T triangles) -> C1 (Kabsch) -> C2 (score + arg-max) -> 8-byte MAX
-all-reduce of the winner key (RCCL, only when N > 1) -> C3 (winner re-solve + inlier mask).
+stage A (compat graph) -> B (top-T triangles) -> C1 (Kabsch) -> C2 (score + arg-max) -> two 8-byte MAX
+all-reduces of the winner key pair (RCCL, only when N > 1) -> C3 (winner re-solve + inlier mask).
 Workload at N = 1: BASELINE.json configs[2] ("3DMatch indoor pair, N~5k correspondences, 50k triangles,
 1xMI355X") — the configuration BASELINE.json's `metric` is quoted on ("N=5k corrs"), as a synthetic scene of that
 shape (the reference ships no data).  For N > 1 every GPU scores 50k ranked triangles of the SAME scene
@@ -73,7 +73,7 @@ def main() -> int:
     reg.set_stream(torch.cuda.current_stream().cuda_stream)  # same stream as torch, so the all-reduce is ordered
     d_src = torch.from_numpy(scene.src).to(dev)
     d_tgt = torch.from_numpy(scene.tgt).to(dev)
-    d_key = torch.zeros(1, dtype=torch.int64, device=dev)
+    d_key = torch.zeros(2, dtype=torch.int64, device=dev)  # winner key pair (include/saccot.h)
     d_Rt = torch.zeros(12, dtype=torch.float32, device=dev)
     d_mask = torch.zeros(cfg.n, dtype=torch.uint8, device=dev)
     torch.cuda.synchronize()

@@ -129,12 +129,18 @@ int sc_register_device(sc_ctx* ctx, const float* d_src, const float* d_tgt, int6
                        const sc_params* params, float* d_Rt, uint8_t* d_mask, sc_stats* stats);
 
 /* ---- two-phase form for one-process-per-GPU sharding --------------------------------
- * Phase 1: A and B replicated, C1+C2 on this rank's blocks of the ranked list; writes this rank's best
- * key  K = (count << 32) | (0xFFFFFFFF - global_rank_index)  to *d_key (device, 8 bytes; 0 = no
- * hypothesis).  The caller max-reduces the key over ranks (RCCL all-reduce through torch.distributed
- * in this repo's host layer; any transport works — it is 8 bytes).
- * Phase 2: every rank decodes the same winner from the reduced key, re-solves its (R,t) from its own
- * replicated ranked list and builds the mask.  Returns SC_ENOHYP when the key is 0. */
+ * Phase 1: A and B replicated, C1+C2 on this rank's blocks of the top-T list; writes this rank's winner key
+ * PAIR to d_key (device, 2 x u64 = 16 bytes):
+ *     d_key[0] = (inlier_count << 32) | ranking_key_of_the_triangle      (0 = no hypothesis with an inlier)
+ *     d_key[1] = 0xFFFFFFFF - position of that triangle in the replicated top-T list, taking the LOWEST
+ *                position among this rank's hypotheses that attain d_key[0]
+ * The caller reduces over ranks in two steps (both 8-byte MAX all-reduces; RCCL through torch.distributed in
+ * this repo's host layer, see sac-cot_amd/shard.py — any transport works):
+ *     K0 = max_r d_key_r[0];   every rank whose own d_key[0] != K0 sets its d_key[1] = 0;   K1 = max_r d_key_r[1]
+ * and stores (K0, K1) back into d_key.  The winner is thus: most inliers, then best ranking key, then lowest
+ * (i,j,k) — "ties -> best-ranked triangle" of SURVEY §8a, decided without sorting the T hypotheses.
+ * Phase 2: every rank decodes the same winner from the reduced pair, re-solves its (R,t) from its own
+ * replicated list and builds the mask.  Returns SC_ENOHYP when d_key[0] is 0. */
 int sc_hypothesize_device(sc_ctx* ctx, const float* d_src, const float* d_tgt, int64_t n,
                           const sc_params* params, uint64_t* d_key, sc_stats* stats);
 int sc_finalize_device(sc_ctx* ctx, const uint64_t* d_key, float* d_Rt, uint8_t* d_mask, sc_stats* stats);

@@ -26,6 +26,7 @@ struct Buf {
 };
 
 constexpr int N_EVENTS = 12;
+constexpr int N_PINNED = 16;
 
 }  // namespace
 
@@ -37,11 +38,11 @@ struct sc_ctx {
   size_t held = 0;
   uint64_t cap_bytes = 64ull << 30;
   hipEvent_t ev[N_EVENTS] = {};
-  uint64_t* pinned = nullptr;  // 8 x u64 host-pinned read-back area
+  uint64_t* pinned = nullptr;  // N_PINNED x u64 host-pinned area the kernels write results into
 
   // workspace
   Buf in_src, in_tgt, planes, S, bits, deg, degp, wpre, ebase, edge_off, scan_tmp, ei, ej, es, tcnt, toff, wkey, ctl, blk_gt,
-      blk_eq, blk_minmax, bits2, off_gt, off_eq, sel_ord, sortkey, sorted, sort_tmp, tri, trikey, rt, rt_aos, partial, cnt, key, rt12,
+      blk_eq, blk_minmax, bits2, off_gt, off_eq, sel_ord, sel_key, sortkey, sorted, sort_tmp, tri, tri_rk, key_rk, rt, rt_aos, partial, cnt, key, rt12,
       mask;
 
   // state of the last hypothesize call (consumed by finalize)
@@ -238,17 +239,13 @@ int run_triangles(sc_ctx* c, const sc_params* p) {
   ENSURE(c, c->off_eq, (nb + 1) * 8);
   ENSURE(c, c->scan_tmp, scan_temp_bytes(nb));
   ENSURE(c, c->sel_ord, (size_t)T_eff * 8);
-  ENSURE(c, c->sortkey, (size_t)T_eff * 8);
-  ENSURE(c, c->sorted, (size_t)T_eff * 8);
-  const size_t sort_bytes = sort_temp_bytes(T_eff);
-  ENSURE(c, c->sort_tmp, sort_bytes + 16);
+  ENSURE(c, c->sel_key, (size_t)T_eff * 4);
   ENSURE(c, c->tri, (size_t)T_eff * 12);
-  ENSURE(c, c->trikey, (size_t)T_eff * 4);
   SelectState* sel = &c->ctl.as<ControlBlock>()->sel;
   if (c->timing) HIPCHK(c, hipEventRecord(c->ev[9], st));
   launch_tri_keys(g, mbits, smin, c->ebase.as<uint32_t>(), c->ei.as<uint32_t>(), c->ej.as<uint32_t>(),
-                  c->es.as<float>(), c->toff.as<uint64_t>(), E, p->rank_mode, c->wkey.as<uint32_t>(), c->blk_minmax.as<uint32_t>(), sel,
-                  T_eff, st);
+                  c->es.as<float>(), c->toff.as<uint64_t>(), E, p->rank_mode, c->wkey.as<uint32_t>(),
+                  c->blk_minmax.as<uint32_t>(), sel, T_eff, st);
   if (c->timing) HIPCHK(c, hipEventRecord(c->ev[10], st));
   c->timed_trikeys = c->timing;
   launch_select_rounds(c->wkey.as<uint32_t>(), M, sel, st);
@@ -256,12 +253,11 @@ int run_triangles(sc_ctx* c, const sc_params* p) {
   launch_scan_u32_pair(c->blk_gt.as<uint32_t>(), c->off_gt.as<uint64_t>(), c->blk_eq.as<uint32_t>(),
                        c->off_eq.as<uint64_t>(), nb, c->scan_tmp.p, st);
   launch_compact_write(c->wkey.as<uint32_t>(), M, sel, c->blk_gt.as<uint32_t>(), c->blk_eq.as<uint32_t>(),
-                       c->off_gt.as<uint64_t>(), c->off_eq.as<uint64_t>(),
-                       c->sel_ord.as<uint64_t>(), c->sortkey.as<uint64_t>(), st);
-  launch_sort_u64(c->sortkey.as<uint64_t>(), c->sorted.as<uint64_t>(), T_eff, c->sort_tmp.p, sort_bytes, st);
+                       c->off_gt.as<uint64_t>(), c->off_eq.as<uint64_t>(), c->sel_ord.as<uint64_t>(),
+                       c->sel_key.as<uint32_t>(), st);
+  // the list stays in ordinal order: no sort on the hot path (the winner is found by (count, key, position))
   launch_tri_decode(g, mbits, c->ei.as<uint32_t>(), c->ej.as<uint32_t>(), c->toff.as<uint64_t>(), E,
-                    c->sorted.as<uint64_t>(), c->sel_ord.as<uint64_t>(), T_eff, c->tri.as<uint32_t>(),
-                    c->trikey.as<uint32_t>(), st);
+                    c->sel_ord.as<uint64_t>(), T_eff, c->tri.as<uint32_t>(), st);
   return SC_OK;
 }
 
@@ -346,7 +342,7 @@ int sc_create(int device, sc_ctx** out) {
   c->stream = c->own_stream;
   for (int i = 0; i < N_EVENTS; i++)
     if (hipEventCreate(&c->ev[i]) != hipSuccess) { sc_destroy(c); return SC_EHIP; }
-  if (hipHostMalloc((void**)&c->pinned, 8 * sizeof(uint64_t), hipHostMallocDefault) != hipSuccess) {
+  if (hipHostMalloc((void**)&c->pinned, N_PINNED * sizeof(uint64_t), hipHostMallocDefault) != hipSuccess) {
     sc_destroy(c);
     return SC_EHIP;
   }
@@ -360,7 +356,7 @@ void sc_destroy(sc_ctx* c) {
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   Buf* bufs[] = {&c->in_src, &c->in_tgt, &c->planes, &c->S, &c->bits, &c->deg, &c->degp, &c->wpre, &c->ebase, &c->edge_off, &c->scan_tmp,
                  &c->ei, &c->ej, &c->es, &c->tcnt, &c->toff, &c->wkey, &c->ctl, &c->blk_gt, &c->blk_eq, &c->blk_minmax, &c->bits2, &c->off_gt,
-                 &c->off_eq, &c->sel_ord, &c->sortkey, &c->sorted, &c->sort_tmp, &c->tri, &c->trikey, &c->rt,
+                 &c->off_eq, &c->sel_ord, &c->sel_key, &c->sortkey, &c->sorted, &c->sort_tmp, &c->tri, &c->tri_rk, &c->key_rk, &c->rt,
                  &c->rt_aos, &c->partial, &c->cnt, &c->key, &c->rt12, &c->mask};
   for (Buf* b : bufs) if (b->p) (void)hipFree(b->p);
   for (int i = 0; i < N_EVENTS; i++) if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
@@ -410,12 +406,14 @@ int sc_hypothesize_device(sc_ctx* c, const float* d_src, const float* d_tgt, int
   if (sh.n_local) {
     ENSURE(c, c->rt, (size_t)12 * sh.ld_local * 4);
     ENSURE(c, c->partial, (size_t)score_chunks(c->n) * sh.ld_local * 4);
+    ENSURE(c, c->cnt, (size_t)sh.ld_local * 4);
     launch_kabsch(points_of(c), c->tri.as<uint32_t>(), sh, c->rt.as<float>(), c->stream);
   }
   if ((rc = rec(c, 4))) return rc;
   launch_score(points_of(c), c->rt.as<float>(), sh, c->dv.tau2, c->partial.as<uint32_t>(), c->stream);
   if ((rc = rec(c, 5))) return rc;
-  launch_argmax(points_of(c), sh, c->partial.as<uint32_t>(), nullptr, d_key, c->stream);
+  launch_argmax(points_of(c), sh, c->partial.as<uint32_t>(), c->T_eff ? c->sel_key.as<uint32_t>() : nullptr,
+                c->cnt.as<uint32_t>(), d_key, c->stream);
   if ((rc = rec(c, 6))) return rc;
   HIPCHK(c, hipGetLastError());
   c->have_hyp = true;
@@ -444,16 +442,16 @@ int sc_finalize_device(sc_ctx* c, const uint64_t* d_key, float* d_Rt, uint8_t* d
   HIPCHK(c, hipSetDevice(c->device));
   int rc;
   if ((rc = rec(c, 7))) return rc;
-  launch_finalize(points_of(c), c->tri.as<uint32_t>(), d_key, c->dv.tau2, d_Rt, d_mask, c->stream);
+  launch_finalize(points_of(c), c->tri.as<uint32_t>(), c->T_eff ? c->sel_key.as<uint32_t>() : nullptr, c->T_eff, d_key,
+                  c->dv.tau2, d_Rt, d_mask, &c->pinned[8], c->stream);
   if ((rc = rec(c, 8))) return rc;
-  HIPCHK(c, hipMemcpyAsync(&c->pinned[3], d_key, 8, hipMemcpyDeviceToHost, c->stream));
-  HIPCHK(c, hipStreamSynchronize(c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));  // the winner kernel wrote key / position / rank to pinned memory
   HIPCHK(c, hipGetLastError());
-  const uint64_t key = c->pinned[3];
+  const uint64_t key = c->pinned[8];
   if (stats && stats->size == sizeof(sc_stats)) {
     fill_stats(c, stats);
     stats->best_count = (uint32_t)(key >> 32);
-    stats->best_rank = key ? 0xFFFFFFFFu - (uint32_t)(key & 0xFFFFFFFFull) : 0u;
+    stats->best_rank = key ? (uint32_t)c->pinned[10] : 0u;
     if (c->timing) {
       stats->us_mask = ev_us(c, 7, 8);
       stats->us_total += stats->us_mask;
@@ -545,8 +543,18 @@ int sc_triangles_host(sc_ctx* c, const float* src, const float* tgt, int64_t n, 
   if (tri_total) *tri_total = c->M_total;
   if (edges) *edges = c->E;
   if (c->T_eff) {
-    HIPCHK(c, hipMemcpyAsync(tri, c->tri.p, (size_t)c->T_eff * 12, hipMemcpyDeviceToHost, c->stream));
-    if (key) HIPCHK(c, hipMemcpyAsync(key, c->trikey.p, (size_t)c->T_eff * 4, hipMemcpyDeviceToHost, c->stream));
+    // the hook returns the RANKED list; the hot path itself never sorts
+    const size_t T = c->T_eff, sort_bytes = sort_temp_bytes(T);
+    ENSURE(c, c->sortkey, T * 8);
+    ENSURE(c, c->sorted, T * 8);
+    ENSURE(c, c->sort_tmp, sort_bytes + 16);
+    ENSURE(c, c->tri_rk, T * 12);
+    ENSURE(c, c->key_rk, T * 4);
+    launch_rank_order(c->tri.as<uint32_t>(), c->sel_key.as<uint32_t>(), c->T_eff, c->sortkey.as<uint64_t>(),
+                      c->sorted.as<uint64_t>(), c->sort_tmp.p, sort_bytes, c->tri_rk.as<uint32_t>(),
+                      c->key_rk.as<uint32_t>(), c->stream);
+    HIPCHK(c, hipMemcpyAsync(tri, c->tri_rk.p, T * 12, hipMemcpyDeviceToHost, c->stream));
+    if (key) HIPCHK(c, hipMemcpyAsync(key, c->key_rk.p, T * 4, hipMemcpyDeviceToHost, c->stream));
   }
   HIPCHK(c, hipStreamSynchronize(c->stream));
   HIPCHK(c, hipGetLastError());
@@ -593,12 +601,13 @@ int sc_score_host(sc_ctx* c, const float* src, const float* tgt, int64_t n, cons
     ENSURE(c, c->rt_aos, (size_t)n_hyp * 48);
     ENSURE(c, c->rt, (size_t)12 * sh.ld_local * 4);
     ENSURE(c, c->partial, (size_t)score_chunks(c->n) * sh.ld_local * 4);
-    ENSURE(c, c->cnt, (size_t)n_hyp * 4);
     HIPCHK(c, hipMemcpyAsync(c->rt_aos.p, Rt, (size_t)n_hyp * 48, hipMemcpyHostToDevice, c->stream));
     launch_rt_to_soa(c->rt_aos.as<float>(), n_hyp, sh.ld_local, c->rt.as<float>(), c->stream);
   }
   launch_score(points_of(c), c->rt.as<float>(), sh, c->dv.tau2, c->partial.as<uint32_t>(), c->stream);
-  launch_argmax(points_of(c), sh, c->partial.as<uint32_t>(), c->cnt.as<uint32_t>(), c->key.as<uint64_t>(), c->stream);
+  ENSURE(c, c->cnt, (size_t)(sh.ld_local ? sh.ld_local : 256) * 4);
+  launch_argmax(points_of(c), sh, c->partial.as<uint32_t>(), nullptr, c->cnt.as<uint32_t>(), c->key.as<uint64_t>(),
+                c->stream);  // positions in Rt ARE the rank indices here: single-stage key
   if ((rc = check_flag(c))) return rc;
   if (cnt && n_hyp) HIPCHK(c, hipMemcpyAsync(cnt, c->cnt.p, (size_t)n_hyp * 4, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipMemcpyAsync(key, c->key.p, 8, hipMemcpyDeviceToHost, c->stream));

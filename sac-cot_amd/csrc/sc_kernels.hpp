@@ -107,14 +107,17 @@ void launch_compact_count(const uint32_t* wkey, uint64_t M, const SelectState* s
                           uint32_t* blk_eq, hipStream_t st);
 void launch_compact_write(const uint32_t* wkey, uint64_t M, const SelectState* s, const uint32_t* blk_gt,
                           const uint32_t* blk_eq, const uint64_t* off_gt, const uint64_t* off_eq,
-                          uint64_t* sel_ord, uint64_t* sortkey, hipStream_t st);
+                          uint64_t* sel_ord, uint32_t* sel_key, hipStream_t st);
 // ranked order: sortkey ascending = (key desc, ordinal asc).  Implemented with rocPRIM (sc_sort.hip).
 size_t sort_temp_bytes(size_t n);
 void launch_sort_u64(const uint64_t* in, uint64_t* out, size_t n, void* temp, size_t temp_bytes, hipStream_t st);
-// ordinal -> (i,j,k) in ranked order
+// selected position -> (i,j,k); the list stays in ordinal ((i,j,k) ascending) order
 void launch_tri_decode(const Graph& g, const uint64_t* mbits, const uint32_t* ei, const uint32_t* ej,
-                       const uint64_t* toff, uint64_t E, const uint64_t* sorted, const uint64_t* sel_ord, uint32_t T,
-                       uint32_t* tri, uint32_t* key, hipStream_t st);
+                       const uint64_t* toff, uint64_t E, const uint64_t* sel_ord, uint32_t T, uint32_t* tri,
+                       hipStream_t st);
+// ranked order (key desc, ordinal asc) of the ordinal-ordered list: only the stage hook needs it
+void launch_rank_order(const uint32_t* tri, const uint32_t* sel_key, uint32_t T, uint64_t* sortkey, uint64_t* sorted,
+                       void* sort_tmp, size_t sort_bytes, uint32_t* tri_ranked, uint32_t* key_ranked, hipStream_t st);
 
 // ---- stage C ---------------------------------------------------------------------------------------
 struct Shard {
@@ -131,15 +134,25 @@ void launch_kabsch(const Points& pts, const uint32_t* tri, const Shard& sh, floa
 void launch_kabsch_aos(const Points& pts, const uint32_t* tri, uint32_t T, float* Rt, hipStream_t st);
 // AoS T x 12 -> SoA planes (stage hook for sc_score_host)
 void launch_rt_to_soa(const float* Rt, uint32_t T, uint32_t ld_local, float* RtSoA, hipStream_t st);
-// C2: inlier counts + arg-max key.  partial: n_chunks * ld_local u32 scratch.  cnt (may be null): n_local.
+// C2: inlier counts.  partial: n_chunks * ld_local u32 scratch.
 uint32_t score_chunks(int n);
 void launch_score(const Points& pts, const float* RtSoA, const Shard& sh, float tau2, uint32_t* partial,
                   hipStream_t st);
-void launch_argmax(const Points& pts, const Shard& sh, const uint32_t* partial, uint32_t* cnt, uint64_t* key,
-                   hipStream_t st);
-// C3: winner decode + re-solve + mask.  Rt12 receives R (row-major) and t; identity / zero mask when key == 0.
-void launch_finalize(const Points& pts, const uint32_t* tri, const uint64_t* key, float tau2, float* Rt12,
-                     uint8_t* mask, hipStream_t st);
+// Winner key pair key2[0..1] (zeroed here):
+//   key2[0] = max over hypotheses with count > 0 of  (count << 32) | second,   second = sel_key[g] (the triangle's
+//             ranking key) or, when sel_key == nullptr, 0xFFFFFFFF - g;
+//   key2[1] = max of (0xFFFFFFFF - g) over the hypotheses attaining key2[0]  (only when sel_key != nullptr).
+// With g the position in the ordinal-ordered list this picks: most inliers, then best ranking key, then lowest
+// (i,j,k) — exactly "ties -> best-ranked triangle" of SURVEY §8a, without ever sorting the list.
+// cnt (n_local u32) is scratch for the second pass and the per-hypothesis counts of the stage hook.
+void launch_argmax(const Points& pts, const Shard& sh, const uint32_t* partial, const uint32_t* sel_key,
+                   uint32_t* cnt, uint64_t* key2, hipStream_t st);
+// C3: winner decode + re-solve + mask.  Rt12 receives R (row-major) and t; identity / zero mask when key2[0] == 0.
+// sel_key / T: the ordinal-ordered ranking keys (for the winner's rank index); host_out (pinned, 3 x u64) receives
+// key2[0], the winner's position and its rank index.
+void launch_finalize(const Points& pts, const uint32_t* tri, const uint32_t* sel_key, uint32_t T,
+                     const uint64_t* key2, float tau2, float* Rt12, uint8_t* mask, uint64_t* host_out,
+                     hipStream_t st);
 // mask of an explicit hypothesis (stage hook)
 void launch_mask(const Points& pts, const float* Rt12, float tau2, uint8_t* mask, hipStream_t st);
 

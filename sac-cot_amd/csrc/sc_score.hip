@@ -164,19 +164,7 @@ __global__ __launch_bounds__(SCORE_THREADS, 8) void score_kernel(const float* __
   partial[(size_t)blockIdx.y * ld_local + l] = ok ? (c0 + c1) + (c2 + c3) : 0u;
 }
 
-__global__ __launch_bounds__(256) void score_argmax_kernel(const uint32_t* __restrict__ partial, uint32_t n_chunks,
-                                                           Shard sh, uint32_t* __restrict__ cnt_out,
-                                                           unsigned long long* __restrict__ key) {
-  __shared__ unsigned long long lds[4];
-  const uint32_t l = blockIdx.x * 256 + threadIdx.x;
-  unsigned long long k = 0;
-  if (l < sh.n_local) {
-    uint32_t c = 0;
-    for (uint32_t ch = 0; ch < n_chunks; ch++) c += partial[(size_t)ch * sh.ld_local + l];
-    if (cnt_out) cnt_out[l] = c;
-    const uint32_t g = shard_global_index(l, sh.block, sh.rank, sh.world);
-    if (c) k = ((unsigned long long)c << 32) | (unsigned long long)(0xFFFFFFFFu - g);
-  }
+__device__ __forceinline__ unsigned long long block_max_u64(unsigned long long k, unsigned long long* lds) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) {
     const unsigned long long other = __shfl_xor(k, o);
@@ -184,11 +172,46 @@ __global__ __launch_bounds__(256) void score_argmax_kernel(const uint32_t* __res
   }
   if ((threadIdx.x & 63) == 0) lds[threadIdx.x >> 6] = k;
   __syncthreads();
-  if (threadIdx.x == 0) {
-    unsigned long long b = lds[0];
-    for (int w = 1; w < 4; w++) b = lds[w] > b ? lds[w] : b;
-    if (b) atomicMax(key, b);  // max is order-independent: deterministic
+  unsigned long long b = lds[0];
+  for (int w = 1; w < 4; w++) b = lds[w] > b ? lds[w] : b;
+  return b;
+}
+
+// pass 1: per-hypothesis count (sum of the chunk partials) and key2[0] = max (count << 32 | second)
+__global__ __launch_bounds__(256) void score_argmax_kernel(const uint32_t* __restrict__ partial, uint32_t n_chunks,
+                                                           Shard sh, const uint32_t* __restrict__ sel_key,
+                                                           uint32_t* __restrict__ cnt_out,
+                                                           unsigned long long* __restrict__ key2) {
+  __shared__ unsigned long long lds[4];
+  const uint32_t l = blockIdx.x * 256 + threadIdx.x;
+  unsigned long long k = 0;
+  if (l < sh.n_local) {
+    uint32_t c = 0;
+    for (uint32_t ch = 0; ch < n_chunks; ch++) c += partial[(size_t)ch * sh.ld_local + l];
+    cnt_out[l] = c;
+    const uint32_t g = shard_global_index(l, sh.block, sh.rank, sh.world);
+    const uint32_t second = sel_key ? sel_key[g] : 0xFFFFFFFFu - g;
+    if (c) k = ((unsigned long long)c << 32) | (unsigned long long)second;
   }
+  const unsigned long long b = block_max_u64(k, lds);
+  if (threadIdx.x == 0 && b) atomicMax(&key2[0], b);  // max is order-independent: deterministic
+}
+
+// pass 2: among the hypotheses attaining key2[0], the lowest position (stored as max of 0xFFFFFFFF - g)
+__global__ __launch_bounds__(256) void score_argpos_kernel(const uint32_t* __restrict__ cnt, Shard sh,
+                                                           const uint32_t* __restrict__ sel_key,
+                                                           unsigned long long* __restrict__ key2) {
+  __shared__ unsigned long long lds[4];
+  const unsigned long long best = key2[0];
+  const uint32_t l = blockIdx.x * 256 + threadIdx.x;
+  unsigned long long k = 0;
+  if (best != 0 && l < sh.n_local) {
+    const uint32_t g = shard_global_index(l, sh.block, sh.rank, sh.world);
+    const unsigned long long mine = ((unsigned long long)cnt[l] << 32) | (unsigned long long)sel_key[g];
+    if (mine == best) k = (unsigned long long)(0xFFFFFFFFu - g);
+  }
+  const unsigned long long b = block_max_u64(k, lds);
+  if (threadIdx.x == 0 && b) atomicMax(&key2[1], b);
 }
 
 void launch_score(const Points& pts, const float* RtSoA, const Shard& sh, float tau2, uint32_t* partial,
@@ -200,30 +223,64 @@ void launch_score(const Points& pts, const float* RtSoA, const Shard& sh, float 
                      pts.planes, pts.n, pts.ld, RtSoA, sh.ld_local, tau2, chunk_pts, partial);
 }
 
-void launch_argmax(const Points& pts, const Shard& sh, const uint32_t* partial, uint32_t* cnt, uint64_t* key,
-                   hipStream_t st) {
-  (void)hipMemsetAsync(key, 0, sizeof(uint64_t), st);
+void launch_argmax(const Points& pts, const Shard& sh, const uint32_t* partial, const uint32_t* sel_key,
+                   uint32_t* cnt, uint64_t* key2, hipStream_t st) {
+  (void)hipMemsetAsync(key2, 0, 2 * sizeof(uint64_t), st);
   if (sh.n_local == 0) return;
   hipLaunchKernelGGL(score_argmax_kernel, dim3(sh.ld_local / 256), dim3(256), 0, st, partial, score_chunks(pts.n),
-                     sh, cnt, reinterpret_cast<unsigned long long*>(key));
+                     sh, sel_key, cnt, reinterpret_cast<unsigned long long*>(key2));
+  if (sel_key)
+    hipLaunchKernelGGL(score_argpos_kernel, dim3(sh.ld_local / 256), dim3(256), 0, st, cnt, sh, sel_key,
+                       reinterpret_cast<unsigned long long*>(key2));
 }
 
 // ------------------------------------------------------------------------------------------------
 // C3
 // ------------------------------------------------------------------------------------------------
-__global__ void winner_kernel(const float* __restrict__ planes, int ld, const uint32_t* __restrict__ tri,
-                              const unsigned long long* __restrict__ key, float* __restrict__ Rt12) {
-  if (threadIdx.x != 0 || blockIdx.x != 0) return;
-  const unsigned long long k = *key;
-  float Rt[12] = {1.f, 0.f, 0.f, 0.f, 1.f, 0.f, 0.f, 0.f, 1.f, 0.f, 0.f, 0.f};
-  if (k != 0) {
-    const uint32_t g = 0xFFFFFFFFu - (uint32_t)(k & 0xFFFFFFFFull);
-    float P[9], Q[9];
-    load_triangle(planes, ld, tri + 3 * (size_t)g, P, Q);
-    kabsch3(P, Q, Rt);
-  }
+// One block: thread 0 re-solves the winner while everybody counts its rank index
+// (#keys above the winner's + #equal keys at lower positions) — the number the ranked list would have given it.
+__global__ __launch_bounds__(1024) void winner_kernel(const float* __restrict__ planes, int ld,
+                                                     const uint32_t* __restrict__ tri,
+                                                     const uint32_t* __restrict__ sel_key, uint32_t T,
+                                                     const unsigned long long* __restrict__ key2,
+                                                     float* __restrict__ Rt12,
+                                                     unsigned long long* __restrict__ host_out) {
+  __shared__ uint64_t lds[16];
+  const unsigned long long k0 = key2[0];
+  const bool two_stage = sel_key != nullptr;
+  uint32_t g = 0;
+  if (k0 != 0) g = 0xFFFFFFFFu - (uint32_t)((two_stage ? key2[1] : k0) & 0xFFFFFFFFull);
+  if (threadIdx.x == 0) {
+    float Rt[12] = {1.f, 0.f, 0.f, 0.f, 1.f, 0.f, 0.f, 0.f, 1.f, 0.f, 0.f, 0.f};
+    if (k0 != 0) {
+      float P[9], Q[9];
+      load_triangle(planes, ld, tri + 3 * (size_t)g, P, Q);
+      kabsch3(P, Q, Rt);
+    }
 #pragma unroll
-  for (int c = 0; c < 12; c++) Rt12[c] = Rt[c];
+    for (int c = 0; c < 12; c++) Rt12[c] = Rt[c];
+  }
+  uint64_t rank = g;
+  if (two_stage && k0 != 0) {
+    const uint32_t wk = sel_key[g];
+    uint32_t r = 0;
+    const uint32_t T4 = T >> 2;  // 16-byte loads, all independent: the loop is a handful of trips
+    const uint4* __restrict__ k4 = reinterpret_cast<const uint4*>(sel_key);
+    for (uint32_t q = threadIdx.x; q < T4; q += 1024) {
+      const uint4 v = k4[q];
+      const uint32_t t = q << 2;
+      r += (v.x > wk) || (v.x == wk && t < g);
+      r += (v.y > wk) || (v.y == wk && t + 1 < g);
+      r += (v.z > wk) || (v.z == wk && t + 2 < g);
+      r += (v.w > wk) || (v.w == wk && t + 3 < g);
+    }
+    for (uint32_t t = (T4 << 2) + threadIdx.x; t < T; t += 1024) {
+      const uint32_t kt = sel_key[t];
+      r += (kt > wk) || (kt == wk && t < g);
+    }
+    rank = block_reduce_u64(r, lds);
+  }
+  if (threadIdx.x == 0 && host_out) { host_out[0] = k0; host_out[1] = g; host_out[2] = k0 ? rank : 0; }
 }
 
 __global__ __launch_bounds__(256) void mask_kernel(const float* __restrict__ planes, int n, int ld,
@@ -241,12 +298,14 @@ __global__ __launch_bounds__(256) void mask_kernel(const float* __restrict__ pla
   mask[m] = (live && d2 < tau2) ? 1 : 0;
 }
 
-void launch_finalize(const Points& pts, const uint32_t* tri, const uint64_t* key, float tau2, float* Rt12,
-                     uint8_t* mask, hipStream_t st) {
-  hipLaunchKernelGGL(winner_kernel, dim3(1), dim3(64), 0, st, pts.planes, pts.ld, tri,
-                     reinterpret_cast<const unsigned long long*>(key), Rt12);
+void launch_finalize(const Points& pts, const uint32_t* tri, const uint32_t* sel_key, uint32_t T,
+                     const uint64_t* key2, float tau2, float* Rt12, uint8_t* mask, uint64_t* host_out,
+                     hipStream_t st) {
+  hipLaunchKernelGGL(winner_kernel, dim3(1), dim3(1024), 0, st, pts.planes, pts.ld, tri, sel_key, T,
+                     reinterpret_cast<const unsigned long long*>(key2), Rt12,
+                     reinterpret_cast<unsigned long long*>(host_out));
   hipLaunchKernelGGL(mask_kernel, dim3((pts.n + 255) / 256), dim3(256), 0, st, pts.planes, pts.n, pts.ld, Rt12,
-                     reinterpret_cast<const unsigned long long*>(key), tau2, mask);
+                     reinterpret_cast<const unsigned long long*>(key2), tau2, mask);
 }
 
 void launch_mask(const Points& pts, const float* Rt12, float tau2, uint8_t* mask, hipStream_t st) {

@@ -666,7 +666,7 @@ __global__ __launch_bounds__(CP_THREADS) void compact_write_kernel(const uint32_
                                                                    const uint64_t* __restrict__ off_gt,
                                                                    const uint64_t* __restrict__ off_eq,
                                                                    uint64_t* __restrict__ sel_ord,
-                                                                   uint64_t* __restrict__ sortkey) {
+                                                                   uint32_t* __restrict__ sel_key) {
   __shared__ uint64_t lds[8];
   const uint32_t kstar = sel->kstar;
   const uint64_t need_eq = sel->need_eq;
@@ -694,7 +694,7 @@ __global__ __launch_bounds__(CP_THREADS) void compact_write_kernel(const uint32_
       if (isg || (isq && eq_before < need_eq)) {
         const uint64_t pos = gt_before + (eq_before < need_eq ? eq_before : need_eq);
         sel_ord[pos] = base + k;
-        sortkey[pos] = ((uint64_t)(~key) << 32) | (uint64_t)(uint32_t)pos;
+        sel_key[pos] = key;
       }
       gt_before += isg;
       eq_before += isq;
@@ -704,27 +704,26 @@ __global__ __launch_bounds__(CP_THREADS) void compact_write_kernel(const uint32_
 
 void launch_compact_write(const uint32_t* wkey, uint64_t M, const SelectState* s, const uint32_t* blk_gt,
                           const uint32_t* blk_eq, const uint64_t* off_gt, const uint64_t* off_eq,
-                          uint64_t* sel_ord, uint64_t* sortkey, hipStream_t st) {
+                          uint64_t* sel_ord, uint32_t* sel_key, hipStream_t st) {
   if (M == 0) return;
   hipLaunchKernelGGL(compact_write_kernel, dim3((unsigned)compact_blocks(M)), dim3(CP_THREADS), 0, st, wkey, M, s,
-                     blk_gt, blk_eq, off_gt, off_eq, sel_ord, sortkey);
+                     blk_gt, blk_eq, off_gt, off_eq, sel_ord, sel_key);
 }
 
 // ------------------------------------------------------------------------------------------------
-// 7. decode: ranked position -> ordinal -> edge (binary search in toff) -> r-th common neighbour above j
+// 7. decode: selected position -> ordinal -> edge (binary search in toff) -> r-th common neighbour above j.
+//    The list stays in ORDINAL order ((i,j,k) ascending): neighbouring threads hit neighbouring edges, and the hot
+//    path never needs the ranked order (see score_argmax_kernel).  launch_rank_order produces it for the stage hook.
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void tri_decode_kernel(const uint64_t* __restrict__ bits, int W,
                                                          const uint32_t* __restrict__ ei,
                                                          const uint32_t* __restrict__ ej,
                                                          const uint64_t* __restrict__ toff, uint64_t E,
-                                                         const uint64_t* __restrict__ sorted,
                                                          const uint64_t* __restrict__ sel_ord, uint32_t T,
-                                                         uint32_t* __restrict__ tri, uint32_t* __restrict__ key) {
+                                                         uint32_t* __restrict__ tri) {
   const uint32_t t = blockIdx.x * 256 + threadIdx.x;
   if (t >= T) return;
-  const uint64_t sk = sorted[t];
-  const uint32_t pos = (uint32_t)(sk & 0xFFFFFFFFull);
-  const uint64_t ord = sel_ord[pos];
+  const uint64_t ord = sel_ord[t];
   // largest e with toff[e] <= ord  (toff has E+1 entries, toff[E] = M > ord)
   uint64_t lo = 0, hi = E;
   while (hi - lo > 1) {
@@ -751,15 +750,44 @@ __global__ __launch_bounds__(256) void tri_decode_kernel(const uint64_t* __restr
   tri[3 * (size_t)t] = i;
   tri[3 * (size_t)t + 1] = j;
   tri[3 * (size_t)t + 2] = k;
-  key[t] = ~(uint32_t)(sk >> 32);
 }
 
 void launch_tri_decode(const Graph& g, const uint64_t* mbits, const uint32_t* ei, const uint32_t* ej,
-                       const uint64_t* toff, uint64_t E, const uint64_t* sorted, const uint64_t* sel_ord, uint32_t T,
-                       uint32_t* tri, uint32_t* key, hipStream_t st) {
+                       const uint64_t* toff, uint64_t E, const uint64_t* sel_ord, uint32_t T, uint32_t* tri,
+                       hipStream_t st) {
   if (T == 0) return;
-  hipLaunchKernelGGL(tri_decode_kernel, dim3((T + 255) / 256), dim3(256), 0, st, mbits, g.W, ei, ej, toff, E,
-                     sorted, sel_ord, T, tri, key);
+  hipLaunchKernelGGL(tri_decode_kernel, dim3((T + 255) / 256), dim3(256), 0, st, mbits, g.W, ei, ej, toff, E, sel_ord,
+                     T, tri);
+}
+
+// ---- ranked order for the stage hook: sort (~key, position), then gather
+__global__ __launch_bounds__(256) void sortkey_kernel(const uint32_t* __restrict__ sel_key, uint32_t T,
+                                                      uint64_t* __restrict__ sortkey) {
+  const uint32_t t = blockIdx.x * 256 + threadIdx.x;
+  if (t < T) sortkey[t] = ((uint64_t)(~sel_key[t]) << 32) | (uint64_t)t;
+}
+__global__ __launch_bounds__(256) void gather_ranked_kernel(const uint64_t* __restrict__ sorted,
+                                                            const uint32_t* __restrict__ tri,
+                                                            const uint32_t* __restrict__ sel_key, uint32_t T,
+                                                            uint32_t* __restrict__ tri_ranked,
+                                                            uint32_t* __restrict__ key_ranked) {
+  const uint32_t t = blockIdx.x * 256 + threadIdx.x;
+  if (t >= T) return;
+  const uint32_t src = (uint32_t)(sorted[t] & 0xFFFFFFFFull);
+  tri_ranked[3 * (size_t)t] = tri[3 * (size_t)src];
+  tri_ranked[3 * (size_t)t + 1] = tri[3 * (size_t)src + 1];
+  tri_ranked[3 * (size_t)t + 2] = tri[3 * (size_t)src + 2];
+  key_ranked[t] = sel_key[src];
+}
+
+void launch_rank_order(const uint32_t* tri, const uint32_t* sel_key, uint32_t T, uint64_t* sortkey, uint64_t* sorted,
+                       void* sort_tmp, size_t sort_bytes, uint32_t* tri_ranked, uint32_t* key_ranked,
+                       hipStream_t st) {
+  if (T == 0) return;
+  hipLaunchKernelGGL(sortkey_kernel, dim3((T + 255) / 256), dim3(256), 0, st, sel_key, T, sortkey);
+  launch_sort_u64(sortkey, sorted, T, sort_tmp, sort_bytes, st);
+  hipLaunchKernelGGL(gather_ranked_kernel, dim3((T + 255) / 256), dim3(256), 0, st, sorted, tri, sel_key, T,
+                     tri_ranked, key_ranked);
 }
 
 }  // namespace sc

@@ -31,6 +31,7 @@ def local_indices(t_eff: int, block: int, rank: int, world: int) -> np.ndarray:
 
 
 def encode_key(count: int, rank_index: int) -> int:
+    """Single-stage key of a RANKED list (stage hook sc_score_host, oracle so_best_key)."""
     return 0 if count == 0 else (int(count) << 32) | (0xFFFFFFFF - int(rank_index))
 
 
@@ -39,10 +40,33 @@ def decode_key(key: int) -> tuple[int, int]:
     return int(key) >> 32, 0xFFFFFFFF - (int(key) & 0xFFFFFFFF)
 
 
-def allreduce_best(key_tensor):
-    """In-place MAX all-reduce of the int64 key tensor (1 element) over the default process group.
-    Keys are < 2^63 (count < 2^31), so the signed int64 view orders like the unsigned key."""
+def encode_pair(count: int, ranking_key: int, position: int) -> tuple[int, int]:
+    """Two-stage winner key of the hot path (include/saccot.h, sc_hypothesize_device)."""
+    if count == 0:
+        return 0, 0
+    return (int(count) << 32) | (int(ranking_key) & 0xFFFFFFFF), 0xFFFFFFFF - int(position)
+
+
+def decode_pair(k0: int, k1: int) -> tuple[int, int, int]:
+    """-> (count, ranking_key, position)"""
+    return int(k0) >> 32, int(k0) & 0xFFFFFFFF, 0xFFFFFFFF - (int(k1) & 0xFFFFFFFF)
+
+
+def reduce_pairs(pairs) -> tuple[int, int]:
+    """Host-side reference of the two-step reduction over ranks: max K0, then max K1 among the ranks attaining it."""
+    k0 = max(int(p[0]) for p in pairs)
+    k1 = max((int(p[1]) for p in pairs if int(p[0]) == k0), default=0)
+    return k0, (k1 if k0 else 0)
+
+
+def allreduce_best(key2):
+    """In-place two-step MAX all-reduce of the int64 key-pair tensor (2 elements) over the default process group.
+    Values are < 2^63 (count < 2^31), so the signed int64 view orders like the unsigned keys.  No host sync."""
+    import torch
     import torch.distributed as dist
     if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-        dist.all_reduce(key_tensor, op=dist.ReduceOp.MAX)
-    return key_tensor
+        mine = key2[0:1].clone()
+        dist.all_reduce(key2[0:1], op=dist.ReduceOp.MAX)
+        key2[1:2] = torch.where(mine == key2[0:1], key2[1:2], torch.zeros_like(key2[1:2]))
+        dist.all_reduce(key2[1:2], op=dist.ReduceOp.MAX)
+    return key2

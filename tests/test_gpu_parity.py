@@ -211,7 +211,7 @@ def test_register_sharded_equals_unsharded(pkg, reg):
     base = reg.register(scene.src, scene.tgt, **cfg.params())
     dev = torch.device("cuda:0")
     d_src = torch.from_numpy(scene.src).to(dev); d_tgt = torch.from_numpy(scene.tgt).to(dev)
-    d_key = torch.zeros(1, dtype=torch.int64, device=dev)
+    d_key = torch.zeros(2, dtype=torch.int64, device=dev)
     d_Rt = torch.zeros(12, dtype=torch.float32, device=dev); d_mask = torch.zeros(cfg.n, dtype=torch.uint8, device=dev)
     torch.cuda.synchronize()
     for world in (1, 2, 3, 8):
@@ -220,9 +220,10 @@ def test_register_sharded_equals_unsharded(pkg, reg):
             p = pkg.make_params(shard_rank=rank, shard_world=world, shard_block=256, **cfg.params())
             st = reg.hypothesize_device(d_src.data_ptr(), d_tgt.data_ptr(), cfg.n, p, d_key.data_ptr())
             torch.cuda.synchronize()
-            keys.append(int(d_key.item())); scored += st["tri_scored"]
+            keys.append(tuple(int(x) for x in d_key.cpu())); scored += st["tri_scored"]
         assert scored == base["stats"]["tri_kept"]
-        d_key.fill_(max(keys)); torch.cuda.synchronize()
+        k0, k1 = pkg.shard.reduce_pairs(keys)               # what the two all-reduces compute
+        d_key.copy_(torch.tensor([k0, k1], dtype=torch.int64)); torch.cuda.synchronize()
         rc, st = reg.finalize_device(d_key.data_ptr(), d_Rt.data_ptr(), d_mask.data_ptr())
         torch.cuda.synchronize()
         assert rc == 0 and st["best_rank"] == base["stats"]["best_rank"] and st["best_count"] == base["stats"]["best_count"]

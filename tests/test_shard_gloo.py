@@ -28,6 +28,15 @@ def test_block_dealing_partitions_the_ranked_list(pkg, t_eff, block, world):
         assert first == list(range(world))                              # every rank starts at the top of the list
 
 
+def test_pair_reduction_picks_the_best_ranked_winner(pkg):
+    sh = pkg.shard
+    # rank 0: 9 inliers, key 70, position 5;  rank 1: 9 inliers, key 90, position 17;  rank 2: 9 / 90 / 11
+    pairs = [sh.encode_pair(9, 70, 5), sh.encode_pair(9, 90, 17), sh.encode_pair(9, 90, 11), sh.encode_pair(0, 99, 0)]
+    assert sh.decode_pair(*sh.reduce_pairs(pairs)) == (9, 90, 11)   # most inliers, best key, lowest position
+    assert sh.reduce_pairs([(0, 0), (0, 0)]) == (0, 0)
+    assert sh.decode_pair(*sh.reduce_pairs([sh.encode_pair(3, 1, 0), sh.encode_pair(4, 0, 99)])) == (4, 0, 99)
+
+
 def test_key_encoding_orders_like_the_spec(pkg):
     sh = pkg.shard
     assert sh.encode_key(0, 5) == 0
@@ -57,16 +66,22 @@ def _worker(rank, world, port, block, out_dir):
     kw = cfg.params()
     # stages A + B replicated on every rank (deterministic -> identical ranked lists)
     S, bits, deg = O.compat(sc.src, sc.tgt, kw["sigma"], kw["t_cmp"], kw["min_len"], kw["tau"])
-    tri, _, _ = O.triangles(S, bits, deg, kw["max_triangles"], 0)
+    tri, wkey, _ = O.triangles(S, bits, deg, kw["max_triangles"], 0)
     mine = pkg.shard.local_indices(len(tri), block, rank, world)
     Rt = O.kabsch3(sc.src, sc.tgt, tri[mine])
     cnt = O.score(sc.src, sc.tgt, Rt, kw["tau"])
-    key = torch.tensor([O.best_key(cnt, mine.astype(np.uint32))], dtype=torch.int64)
-    pkg.shard.allreduce_best(key)                                       # the one collective of the path
-    count, widx = pkg.shard.decode_key(int(key.item()))
+    # this rank's winner pair: most inliers, then best ranking key, then lowest position (include/saccot.h)
+    best = (0, 0)
+    for c, g in zip(cnt, mine):
+        cand = pkg.shard.encode_pair(int(c), int(wkey[g]), int(g))
+        if cand > best:
+            best = cand
+    key = torch.tensor(best, dtype=torch.int64)
+    pkg.shard.allreduce_best(key)                                       # the two 8-byte collectives of the path
+    count, _, widx = pkg.shard.decode_pair(int(key[0]), int(key[1]))
     Rt_w = O.kabsch3(sc.src, sc.tgt, tri[widx:widx + 1])[0]            # every rank re-solves the winner locally
     mask = O.mask(sc.src, sc.tgt, Rt_w, kw["tau"])
-    np.savez(os.path.join(out_dir, f"rank{rank}.npz"), key=int(key.item()), Rt=Rt_w, mask=mask, scored=len(mine))
+    np.savez(os.path.join(out_dir, f"rank{rank}.npz"), count=count, widx=widx, Rt=Rt_w, mask=mask, scored=len(mine))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -81,6 +96,6 @@ def test_two_ranks_gloo_agree_with_single_rank(pkg, O, tmp_path, world, block):
     outs = [np.load(tmp_path / f"rank{r}.npz") for r in range(world)]
     assert sum(int(o["scored"]) for o in outs) == ref["t_eff"]
     for o in outs:
-        assert pkg.shard.decode_key(int(o["key"])) == (ref["best_count"], ref["best_rank"])
+        assert (int(o["count"]), int(o["widx"])) == (ref["best_count"], ref["best_rank"])
         assert o["Rt"].tobytes() == np.concatenate([ref["R"].ravel(), ref["t"]]).astype(np.float32).tobytes()
         assert np.array_equal(o["mask"], ref["mask"])
