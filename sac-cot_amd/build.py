@@ -11,8 +11,9 @@ LIB = os.path.join(HERE, "libsaccot.so")
 SOURCES = ["sc_compat.hip", "sc_tri.hip", "sc_score.hip", "sc_sort.hip", "sc_capi.hip"]
 HEADERS = ["sc_arith.hpp", "sc_block.hpp", "sc_kernels.hpp", os.path.join("..", "..", "include", "saccot.h")]
 # -ffp-contract=off: the canonical arithmetic (sc_arith.hpp) fuses only where it says fmaf.
+# -amdgpu-mfma-vgpr-form: MFMA results land in VGPRs (unified register file on gfx950), no v_accvgpr_read copies.
 # -fno-slp-vectorize / -fno-vectorize: the vectorizers pack the fp32 chains into v_pk_* + v_mov shuffles, slower than plain VALU on gfx950.
-FLAGS = ["-O3", "--offload-arch=gfx950", "-ffp-contract=off", "-fhip-fp32-correctly-rounded-divide-sqrt", "-fno-slp-vectorize", "-fno-vectorize", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-result"]
+FLAGS = ["-O3", "--offload-arch=gfx950", "-ffp-contract=off", "-fhip-fp32-correctly-rounded-divide-sqrt", "-fno-slp-vectorize", "-fno-vectorize", "-mllvm", "-amdgpu-mfma-vgpr-form=1", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-result"]
 
 
 def _stale(target: str, deps: list[str]) -> bool:

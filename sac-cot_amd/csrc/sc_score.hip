@@ -11,6 +11,8 @@
 //                   compare and one add-with-carry: 17 VALU instructions per test;
 //   grid          = ceil(T/256) x chunks, so a 50k x 5k problem is ~1000 workgroups (~4 waves per SIMD);
 //   partial counts are stored coalesced ([chunk][hypothesis]) and summed by the arg-max kernel.
+#include <cstdlib>
+
 #include "sc_arith.hpp"
 #include "sc_block.hpp"
 #include "sc_kernels.hpp"
@@ -124,15 +126,14 @@ __device__ __forceinline__ uint32_t inlier_bit(const float (&M)[12], const float
   return resid2(M, a.x, a.y, a.z, a.w, b.x, b.y) < tau2 ? 1u : 0u;
 }
 
-// __launch_bounds__(256, 8): 8 waves per SIMD (<= 64 VGPRs) — plain v_fma_f32 needs that occupancy to reach its
-// issue rate on gfx950 (measured: 45 / 80 / 99 / 117 TFLOP/s at 1 / 2 / 4 / 8 waves per SIMD, tools/ubench_valu.hip)
-__global__ __launch_bounds__(SCORE_THREADS, 8) void score_kernel(const float* __restrict__ planes, int n, int ld,
-                                                                 const float* __restrict__ RtSoA, uint32_t ld_local,
-                                                                 float tau2, int chunk_pts,
-                                                                 uint32_t* __restrict__ partial) {
-  __shared__ float4 pA[SCORE_PC];  // px py pz qx
-  __shared__ float2 pB[SCORE_PC];  // qy qz
-  const int m0 = blockIdx.y * chunk_pts;
+// VALU body: lane = hypothesis.  bx = workgroup index along the hypotheses (256 per workgroup), hyp_base = first one.
+__device__ __forceinline__ void score_valu_body(float4* __restrict__ smem, uint32_t hyp_base, int chunk,
+                                                const float* __restrict__ planes, int n, int ld,
+                                                const float* __restrict__ RtSoA, uint32_t ld_local, float tau2,
+                                                int chunk_pts, uint32_t* __restrict__ partial) {
+  float4* pA = smem;                                          // px py pz qx
+  float2* pB = reinterpret_cast<float2*>(smem + SCORE_PC);    // qy qz
+  const int m0 = chunk * chunk_pts;
   const int cnt_pts = min(chunk_pts, n - m0);
   const int padded = (cnt_pts + 3) & ~3;  // <= chunk_pts <= SCORE_PC (chunk_pts is a multiple of 4)
   for (int t = threadIdx.x; t < padded; t += SCORE_THREADS) {
@@ -145,7 +146,7 @@ __global__ __launch_bounds__(SCORE_THREADS, 8) void score_kernel(const float* __
       pB[t] = make_float2(1e30f, 1e30f);
     }
   }
-  const uint32_t l = blockIdx.x * SCORE_THREADS + threadIdx.x;
+  const uint32_t l = hyp_base + threadIdx.x;
   float M[12];
 #pragma unroll
   for (int c = 0; c < 12; c++) M[c] = RtSoA[(size_t)c * ld_local + l];
@@ -161,7 +162,113 @@ __global__ __launch_bounds__(SCORE_THREADS, 8) void score_kernel(const float* __
     c2 += inlier_bit(M, a2, b2, tau2);
     c3 += inlier_bit(M, a3, b3, tau2);
   }
-  partial[(size_t)blockIdx.y * ld_local + l] = ok ? (c0 + c1) + (c2 + c3) : 0u;
+  partial[(size_t)chunk * ld_local + l] = ok ? (c0 + c1) + (c2 + c3) : 0u;
+}
+
+// ------------------------------------------------------------------------------------------------
+// C2 on the matrix pipe.  v_mfma_f32_16x16x4_f32 computes D = A(16x4) B(4x16) + C as a k-ordered fp32 fma chain
+// (one rounding per product, bit-for-bit fmaf: cdna guide §3 "FP32-input MFMA"), which is exactly the canonical
+// residual  e_c = fma(t_c,1, fma(r_c2,pz, fma(r_c1,py, fma(r_c0,px, -q_c))))  when
+//   A[row = 4 hq + c][k] = (r_c0, r_c1, r_c2, t_c)[k]      4 hypotheses hq x 3 components c (row 4hq+3 is zero)
+//   B[k][col]            = (px, py, pz, 1)[k] of point col   16 correspondences
+//   C[row][col]          = -q_c of point col
+// so one instruction yields the residuals of 4 x 16 tests.  Lane l receives D rows 4 (l>>4) + {0,1,2} of column
+// l & 15: the three components of ONE test, so the squared norm, the compare and the count stay lane-local (5 VALU
+// instructions per 64 tests instead of 17.5), and 4 shuffles per hypothesis at the very end sum the 16 columns.
+// ------------------------------------------------------------------------------------------------
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+constexpr int MF_QUADS = 8;                 // hypothesis quads per wave: 32 hypotheses
+constexpr int MF_HYPS_PER_BLOCK = 4 * 4 * MF_QUADS;  // 4 waves
+
+// MFMA body: hyp_base = first hypothesis of the workgroup (MF_HYPS_PER_BLOCK per workgroup).
+__device__ __forceinline__ void score_mfma_body(float4* __restrict__ smem, uint32_t hyp_base, int chunk,
+                                                const float* __restrict__ planes, int n, int ld,
+                                                const float* __restrict__ RtSoA, uint32_t ld_local, float tau2,
+                                                int chunk_pts, uint32_t* __restrict__ partial) {
+  float4* P4 = smem;             // px py pz 1
+  float4* Qn = smem + SCORE_PC;  // -qx -qy -qz 0
+  const int m0 = chunk * chunk_pts;
+  const int cnt_pts = min(chunk_pts, n - m0);
+  const int padded = (cnt_pts + 15) & ~15;  // whole 16-point groups; chunk_pts <= SCORE_PC and SCORE_PC % 16 == 0
+  for (int t = threadIdx.x; t < padded; t += 256) {
+    const int m = m0 + t;
+    if (t < cnt_pts) {
+      P4[t] = make_float4(planes[m], planes[(size_t)ld + m], planes[2 * (size_t)ld + m], 1.0f);
+      Qn[t] = make_float4(-planes[3 * (size_t)ld + m], -planes[4 * (size_t)ld + m], -planes[5 * (size_t)ld + m], 0.f);
+    } else {  // sentinel: residual ~ -1e30, squared = +inf, never < tau2, never NaN
+      P4[t] = make_float4(0.f, 0.f, 0.f, 1.0f);
+      Qn[t] = make_float4(-1e30f, -1e30f, -1e30f, 0.f);
+    }
+  }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const uint32_t hyp0 = hyp_base + wave * (4 * MF_QUADS);  // first hypothesis of this wave
+  // A operands: lane l feeds row (l & 15) = 4 hq + c, k = l >> 4
+  const int a_hq = (lane & 15) >> 2, a_c = lane & 3, a_k = lane >> 4;
+  float a[MF_QUADS];
+  uint64_t badmask[MF_QUADS];
+#pragma unroll
+  for (int q = 0; q < MF_QUADS; q++) {
+    const uint32_t h = hyp0 + 4 * q + a_hq;  // < ld_local: ld_local is a multiple of 256 >= MF_HYPS_PER_BLOCK blocks
+    float v = 0.0f;
+    if (a_c < 3) v = RtSoA[(size_t)(a_k < 3 ? 3 * a_c + a_k : 9 + a_c) * ld_local + h];
+    a[q] = v;
+    badmask[q] = __ballot(!(fabsf(v) < __builtin_inff()));  // lanes holding a non-finite coefficient
+  }
+  __syncthreads();
+  uint32_t cnt[MF_QUADS];
+#pragma unroll
+  for (int q = 0; q < MF_QUADS; q++) cnt[q] = 0;
+  const float* P4f = reinterpret_cast<const float*>(P4);
+  const int col = lane & 15, kb = lane >> 4;
+  for (int g = 0; g < padded; g += 16) {
+    const float b = P4f[(g + col) * 4 + kb];
+    const float4 cq = Qn[g + col];
+    const f32x4 c = {cq.x, cq.y, cq.z, cq.w};
+    // all MF_QUADS products first, into distinct result tiles (independent: they pipeline at the 32-cycle issue rate),
+    // then the lane-local epilogues — a single reused tile would serialise on the 40-cycle result latency
+    f32x4 d[MF_QUADS];
+#pragma unroll
+    for (int q = 0; q < MF_QUADS; q++) d[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[q], b, c, 0, 0, 0);
+#pragma unroll
+    for (int q = 0; q < MF_QUADS; q++) {
+      const float d2 = fma_(d[q][2], d[q][2], fma_(d[q][1], d[q][1], d[q][0] * d[q][0]));
+      cnt[q] += (d2 < tau2) ? 1u : 0u;
+    }
+  }
+  // lane l counted hypothesis (quad q, member l >> 4) over the columns l & 15: sum the 16 columns
+#pragma unroll
+  for (int q = 0; q < MF_QUADS; q++) {
+    uint32_t c = cnt[q];
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) c += __shfl_xor(c, o, 16);
+    // coefficient lanes of member hq' = l >> 4 are {16 k + 4 hq' + c}: any non-finite one zeroes the hypothesis
+    const uint64_t mine = 0x000F000F000F000Full << (4 * (lane >> 4));
+    if (badmask[q] & mine) c = 0;
+    const uint32_t h = hyp0 + 4 * q + (lane >> 4);
+    if (col == 0) partial[(size_t)chunk * ld_local + h] = c;
+  }
+}
+
+// One launch, two kinds of workgroup.  Hypotheses [0, hv) go to VALU workgroups (256 each), [hv, ld_local) to MFMA
+// workgroups (128 each); the two kinds are interleaved along blockIdx.x so that every CU holds both and its vector
+// and matrix pipes work at the same time (cdna guide: "MFMA and VALU pipes are separate").
+// __launch_bounds__(256, 8): <= 64 VGPRs, 8 waves per SIMD — plain v_fma_f32 needs that occupancy on gfx950
+// (measured 45 / 80 / 99 / 117 TFLOP/s at 1 / 2 / 4 / 8 waves per SIMD, tools/ubench_valu.hip).
+__global__ __launch_bounds__(SCORE_THREADS, 8) void score_kernel(const float* __restrict__ planes, int n, int ld,
+                                                                 const float* __restrict__ RtSoA, uint32_t ld_local,
+                                                                 float tau2, int chunk_pts,
+                                                                 uint32_t* __restrict__ partial, uint32_t nv,
+                                                                 uint32_t nm) {
+  __shared__ float4 smem[2 * SCORE_PC];  // 16 KiB: both bodies carve their point images out of it
+  const uint32_t bx = blockIdx.x, tot = nv + nm;
+  // Bresenham spread of the nm MFMA workgroups among the nv VALU ones
+  const uint32_t m_before = (uint32_t)(((uint64_t)bx * nm) / tot), m_after = (uint32_t)(((uint64_t)(bx + 1) * nm) / tot);
+  if (m_after != m_before)
+    score_mfma_body(smem, nv * SCORE_THREADS + m_before * MF_HYPS_PER_BLOCK, blockIdx.y, planes, n, ld, RtSoA, ld_local,
+                    tau2, chunk_pts, partial);
+  else
+    score_valu_body(smem, (bx - m_before) * SCORE_THREADS, blockIdx.y, planes, n, ld, RtSoA, ld_local, tau2, chunk_pts,
+                    partial);
 }
 
 __device__ __forceinline__ unsigned long long block_max_u64(unsigned long long k, unsigned long long* lds) {
@@ -214,13 +321,23 @@ __global__ __launch_bounds__(256) void score_argpos_kernel(const uint32_t* __res
   if (threadIdx.x == 0 && b) atomicMax(&key2[1], b);
 }
 
+// share of the hypotheses (in 256ths) scored on the matrix pipe; SC_SCORE_SPLIT=0..256 overrides (experiments)
+static uint32_t score_mfma_share() {
+  const char* v = getenv("SC_SCORE_SPLIT");
+  if (v) { const int t = atoi(v); if (t >= 0 && t <= 256) return (uint32_t)t; }
+  return 0;
+}
+
 void launch_score(const Points& pts, const float* RtSoA, const Shard& sh, float tau2, uint32_t* partial,
                   hipStream_t st) {
   if (sh.n_local == 0) return;
   const uint32_t chunks = score_chunks(pts.n);
   const int chunk_pts = score_chunk_points(pts.n);
-  hipLaunchKernelGGL(score_kernel, dim3(sh.ld_local / SCORE_THREADS, chunks), dim3(SCORE_THREADS), 0, st,
-                     pts.planes, pts.n, pts.ld, RtSoA, sh.ld_local, tau2, chunk_pts, partial);
+  const uint32_t groups = sh.ld_local / SCORE_THREADS;            // 256-hypothesis groups
+  const uint32_t gm = (uint32_t)(((uint64_t)groups * score_mfma_share() + 128) / 256);  // groups on the matrix pipe
+  const uint32_t nv = groups - gm, nm = gm * (SCORE_THREADS / MF_HYPS_PER_BLOCK);
+  hipLaunchKernelGGL(score_kernel, dim3(nv + nm, chunks), dim3(SCORE_THREADS), 0, st, pts.planes, pts.n, pts.ld,
+                     RtSoA, sh.ld_local, tau2, chunk_pts, partial, nv, nm);
 }
 
 void launch_argmax(const Points& pts, const Shard& sh, const uint32_t* partial, const uint32_t* sel_key,
