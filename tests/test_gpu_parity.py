@@ -259,3 +259,45 @@ def test_rigid_motion_invariance_of_graph(pkg, reg):
     diff = sum(bin(int(x)).count("1") for x in (bits ^ bits2).ravel())
     total = sum(bin(int(x)).count("1") for x in bits.ravel())
     assert diff <= 0.002 * total + 4   # only threshold-edge pairs may flip under fp32 re-rounding
+
+
+# ---------------------------------------------------------------------------------------------------------
+# the matrix-pipe variant of C2 and the big configs
+# ---------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("split", ["256", "96"])
+def test_score_mfma_variant_bit_exact(pkg, O, reg, split, monkeypatch):
+    """the f32-MFMA scoring body (v_mfma_f32_16x16x4_f32, C = -q) must count exactly like the VALU
+    body.  SC_SCORE_SPLIT (read at every launch) sends that share (of 256) of the hypotheses to MFMA workgroups."""
+    monkeypatch.setenv("SC_SCORE_SPLIT", split)
+    n, T = 1300, 5000
+    sc = _scene(pkg, n, seed=91)
+    rng = np.random.default_rng(91)
+    inl = np.nonzero(sc.inlier)[0]
+    tri = np.sort(np.stack([rng.choice(inl if h % 2 else n, 3, replace=False) for h in range(T)]), axis=1).astype(np.uint32)
+    Rt0 = O.kabsch3(sc.src, sc.tgt, tri)
+    Rt0[11, 2] = np.inf; Rt0[4000, 9] = np.nan
+    kw = _params(pkg, 0.05, T)
+    cnt, key = reg.score(sc.src, sc.tgt, pkg.make_params(**kw), Rt0)
+    cnt0 = O.score(sc.src, sc.tgt, Rt0, kw["tau"])
+    assert cnt0.max() > 50 and cnt0[11] == 0 and cnt0[4000] == 0
+    assert np.array_equal(cnt, cnt0) and key == O.best_key(cnt0)
+    cfg, scene = pkg.synth.make_config_scene("C1")
+    _check_register(pkg, O, reg, scene, cfg.params())
+
+
+def test_register_C4_half_a_million_hypotheses(pkg, O, reg):
+    """BASELINE.json configs[4]: N = 5000 with 90 % outliers, 500k ranked triangles (one GPU scores them all here)."""
+    cfg, scene = pkg.synth.make_config_scene("C4")
+    got, ref = _check_register(pkg, O, reg, scene, cfg.params())
+    assert got["stats"]["tri_kept"] == 500_000 and got["stats"]["tri_scored"] == 500_000
+    assert pkg.synth.rotation_error_deg(got["R"], scene.R_gt) < 1.0
+
+
+def test_register_C3_twenty_thousand_correspondences(pkg, O, reg):
+    """BASELINE.json configs[3]: N = 20000 (1.6 GB weight matrix, ~4e8 triangles in the graph), 200k hypotheses."""
+    cfg, scene = pkg.synth.make_config_scene("C3")
+    got, ref = _check_register(pkg, O, reg, scene, cfg.params(), threads=64)
+    assert got["stats"]["tri_kept"] == 200_000
+    assert pkg.synth.rotation_error_deg(got["R"], scene.R_gt) < 1.0
+    m = got["mask"].astype(bool)
+    assert (m & scene.inlier).sum() >= 0.95 * scene.inlier.sum()
