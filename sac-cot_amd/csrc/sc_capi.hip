@@ -8,6 +8,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -41,13 +42,14 @@ struct sc_ctx {
   uint64_t* pinned = nullptr;  // N_PINNED x u64 host-pinned area the kernels write results into
 
   // workspace
-  Buf in_src, in_tgt, planes, S, bits, deg, degp, wpre, ebase, edge_off, scan_tmp, ei, ej, es, tcnt, toff, wkey, ctl, blk_gt,
+  Buf in_src, in_tgt, planes, S, bits, deg, degp, wpre, ebase, edge_off, scan_tmp, ei, ej, es, ebi, ebj, tcnt, toff, wkey, ctl, events, blk_gt,
       blk_eq, blk_minmax, bits2, off_gt, off_eq, sel_ord, sel_key, sortkey, sorted, sort_tmp, tri, tri_rk, key_rk, rt, rt_aos, partial, cnt, key, rt12,
       mask;
 
   // state of the last hypothesize call (consumed by finalize)
   int n = 0, ld = 0;
   uint64_t E = 0, M = 0, M_total = 0;
+  uint64_t ev_capacity = 1ull << 21;  // event records (32 B each); doubled after an overflow
   bool pruned = false;
   uint32_t T_eff = 0;
   Derived dv{};
@@ -192,12 +194,14 @@ int run_triangles(sc_ctx* c, const sc_params* p) {
   ENSURE(c, c->ej, E * 4);
   ENSURE(c, c->es, (E + 2) * 4);  // +1: the 4-way unrolled gathers of idle slots may touch index E
   ENSURE(c, c->tcnt, E * 4);
+  ENSURE(c, c->ebi, E * 4);
+  ENSURE(c, c->ebj, E * 4);
   ENSURE(c, c->ebase, n * 4);
   ENSURE(c, c->toff, (E + 1) * 8);
   ENSURE(c, c->scan_tmp, scan_temp_bytes(E));
   const Graph g = graph_of(c);
   launch_edge_fill(g, c->edge_off.as<uint64_t>(), c->ei.as<uint32_t>(), c->ej.as<uint32_t>(), c->es.as<float>(),
-                   c->ebase.as<uint32_t>(), st);
+                   c->ebase.as<uint32_t>(), c->ebi.as<uint32_t>(), c->ebj.as<uint32_t>(), st);
   // certified pruning (sc_tri.hip §3b): weight ranking only; pointless on tiny graphs
   const bool prune = may_prune(p) && E >= 4096;
   c->pruned = prune;
@@ -220,8 +224,21 @@ int run_triangles(sc_ctx* c, const sc_params* p) {
   }
   c->mbits = mbits;
   c->smin_ptr = smin;
-  launch_tri_count(g, mbits, c->es.as<float>(), smin, c->ei.as<uint32_t>(), c->ej.as<uint32_t>(), E,
-                   c->tcnt.as<uint32_t>(), st);
+  // counting pass + event list (sc_tri.hip 2b); SC_NO_EVENTS=1 keeps the row-walking pair for comparison
+  // (only for a pruned graph with moderately wide rows: see the kernel's header for why)
+  const bool use_events = prune && g.W <= 128 && getenv("SC_NO_EVENTS") == nullptr;
+  EventList ev{};
+  if (use_events) {
+    ENSURE(c, c->events, event_bytes(c->ev_capacity));
+    c->pinned[5] = 0;
+    ev = event_list(c->events.p, c->ev_capacity, g.W, reinterpret_cast<uint32_t*>(&c->pinned[5]));
+    launch_tri_count_events(g, mbits, smin, c->ebi.as<uint32_t>(), c->ebj.as<uint32_t>(), c->ei.as<uint32_t>(),
+                            c->ej.as<uint32_t>(),
+                            c->es.as<float>(), E, p->rank_mode, c->tcnt.as<uint32_t>(), ev, st);
+  } else {
+    launch_tri_count(g, mbits, c->es.as<float>(), smin, c->ei.as<uint32_t>(), c->ej.as<uint32_t>(), E,
+                     c->tcnt.as<uint32_t>(), st);
+  }
   // read-back #2: triangle count (of the pruned graph when pruning), written to pinned memory by the scan
   launch_scan_u32(c->tcnt.as<uint32_t>(), E, c->toff.as<uint64_t>(), c->scan_tmp.p, st, &c->pinned[2]);
   HIPCHK(c, hipStreamSynchronize(st));
@@ -243,9 +260,21 @@ int run_triangles(sc_ctx* c, const sc_params* p) {
   ENSURE(c, c->tri, (size_t)T_eff * 12);
   SelectState* sel = &c->ctl.as<ControlBlock>()->sel;
   if (c->timing) HIPCHK(c, hipEventRecord(c->ev[9], st));
-  launch_tri_keys(g, mbits, smin, c->ebase.as<uint32_t>(), c->ei.as<uint32_t>(), c->ej.as<uint32_t>(),
-                  c->es.as<float>(), c->toff.as<uint64_t>(), E, p->rank_mode, c->wkey.as<uint32_t>(),
-                  c->blk_minmax.as<uint32_t>(), sel, T_eff, st);
+  bool events_ok = use_events;
+  if (use_events && (uint32_t)c->pinned[5] != 0) {  // a region overflowed: this call walks the rows again
+    events_ok = false;
+    uint64_t want_cap = c->ev_capacity * 2;          // every event holds >= 1 triangle, so M bounds the need
+    if (want_cap < M + M / 4) want_cap = M + M / 4;
+    if (want_cap > (1ull << 28)) want_cap = 1ull << 28;
+    c->ev_capacity = want_cap;
+  }
+  if (events_ok)
+    launch_tri_keys_events(g, c->es.as<float>(), c->toff.as<uint64_t>(), p->rank_mode, ev, c->wkey.as<uint32_t>(),
+                           c->blk_minmax.as<uint32_t>(), sel, T_eff, st);
+  else
+    launch_tri_keys(g, mbits, smin, c->ebase.as<uint32_t>(), c->ei.as<uint32_t>(), c->ej.as<uint32_t>(),
+                    c->es.as<float>(), c->toff.as<uint64_t>(), E, p->rank_mode, c->wkey.as<uint32_t>(),
+                    c->blk_minmax.as<uint32_t>(), sel, T_eff, st);
   if (c->timing) HIPCHK(c, hipEventRecord(c->ev[10], st));
   c->timed_trikeys = c->timing;
   launch_select_rounds(c->wkey.as<uint32_t>(), M, sel, st);
@@ -355,7 +384,7 @@ void sc_destroy(sc_ctx* c) {
   (void)hipSetDevice(c->device);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   Buf* bufs[] = {&c->in_src, &c->in_tgt, &c->planes, &c->S, &c->bits, &c->deg, &c->degp, &c->wpre, &c->ebase, &c->edge_off, &c->scan_tmp,
-                 &c->ei, &c->ej, &c->es, &c->tcnt, &c->toff, &c->wkey, &c->ctl, &c->blk_gt, &c->blk_eq, &c->blk_minmax, &c->bits2, &c->off_gt,
+                 &c->ei, &c->ej, &c->es, &c->ebi, &c->ebj, &c->tcnt, &c->toff, &c->wkey, &c->ctl, &c->events, &c->blk_gt, &c->blk_eq, &c->blk_minmax, &c->bits2, &c->off_gt,
                  &c->off_eq, &c->sel_ord, &c->sel_key, &c->sortkey, &c->sorted, &c->sort_tmp, &c->tri, &c->tri_rk, &c->key_rk, &c->rt,
                  &c->rt_aos, &c->partial, &c->cnt, &c->key, &c->rt12, &c->mask};
   for (Buf* b : bufs) if (b->p) (void)hipFree(b->p);
@@ -405,7 +434,7 @@ int sc_hypothesize_device(sc_ctx* c, const float* d_src, const float* d_tgt, int
   c->sh = sh;
   if (sh.n_local) {
     ENSURE(c, c->rt, (size_t)12 * sh.ld_local * 4);
-    ENSURE(c, c->partial, (size_t)score_chunks(c->n) * sh.ld_local * 4);
+    ENSURE(c, c->partial, (size_t)score_chunks(c->n, sh.ld_local) * sh.ld_local * 4);
     ENSURE(c, c->cnt, (size_t)sh.ld_local * 4);
     launch_kabsch(points_of(c), c->tri.as<uint32_t>(), sh, c->rt.as<float>(), c->stream);
   }
@@ -600,7 +629,7 @@ int sc_score_host(sc_ctx* c, const float* src, const float* tgt, int64_t n, cons
   if (n_hyp) {
     ENSURE(c, c->rt_aos, (size_t)n_hyp * 48);
     ENSURE(c, c->rt, (size_t)12 * sh.ld_local * 4);
-    ENSURE(c, c->partial, (size_t)score_chunks(c->n) * sh.ld_local * 4);
+    ENSURE(c, c->partial, (size_t)score_chunks(c->n, sh.ld_local) * sh.ld_local * 4);
     HIPCHK(c, hipMemcpyAsync(c->rt_aos.p, Rt, (size_t)n_hyp * 48, hipMemcpyHostToDevice, c->stream));
     launch_rt_to_soa(c->rt_aos.as<float>(), n_hyp, sh.ld_local, c->rt.as<float>(), c->stream);
   }

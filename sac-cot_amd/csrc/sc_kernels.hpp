@@ -57,8 +57,9 @@ struct Graph {
 };
 // CSR edge list of the upper triangle, rows ascending, columns ascending: ei/ej/es (es = S[i][j]).
 // ebase[i] (u32, modular): CSR index of edge (i,k), k > i, is ebase[i] + wpre[i][k/64] + popc(bits[i][k/64] below k).
+// ebi[e] / ebj[e]: the bases of both ends of edge e (so an edge is fetched in one memory level).
 void launch_edge_fill(const Graph& g, const uint64_t* edge_off, uint32_t* ei, uint32_t* ej, float* es,
-                      uint32_t* ebase, hipStream_t st);
+                      uint32_t* ebase, uint32_t* ebi, uint32_t* ebj, hipStream_t st);
 // tcnt[e] = #k > j adjacent (in `mbits`) to both ends of edge e = (i,j); edges with es[e] < *smin count 0
 // (smin == nullptr: no pruning, mbits = g.bits).
 void launch_tri_count(const Graph& g, const uint64_t* mbits, const float* es, const float* smin, const uint32_t* ei,
@@ -69,6 +70,28 @@ void launch_tri_count(const Graph& g, const uint64_t* mbits, const float* es, co
 void launch_prune(const Graph& g, const uint32_t* ebase, const uint32_t* ei, const uint32_t* ej, const float* es,
                   uint64_t E, uint64_t want, float key_floor, uint32_t* hist, uint64_t* mbits, float* smin,
                   hipStream_t st);  // hist and mbits must already be zero
+
+// Event list of stage B (sc_tri.hip 2b): one record per non-zero member word of a strong edge, SoA, split into
+// EV_SHARDS regions of shard_cap records; fill[shard] = records appended to that region.
+struct EventList {
+  uint64_t* m;       // member word (bits = common neighbours k of the edge inside this 64-column word)
+  uint32_t* wi;      // word offset of row i: i * W + w   (into bits / wpre)
+  uint32_t* wj;      // word offset of row j
+  uint32_t* a;       // weight ranking: ebase[i];  degree ranking: deg[i] + deg[j]
+  uint32_t* b;       // weight ranking: ebase[j]
+  uint32_t* e;       // edge index
+  uint32_t* rb;      // rank of the word's first triangle inside its edge
+  uint32_t* fill;    // EV_SHARDS counters
+  uint64_t shard_cap;
+  uint32_t* overflow;  // host-pinned flag, set when a region is full
+  int W;
+};
+size_t event_bytes(uint64_t capacity);
+EventList event_list(void* buf, uint64_t capacity, int W, uint32_t* overflow_host);
+// counting pass that also emits the events (replaces launch_tri_count when an event buffer is available)
+void launch_tri_count_events(const Graph& g, const uint64_t* mbits, const float* smin, const uint32_t* ebi,
+                             const uint32_t* ebj, const uint32_t* ei, const uint32_t* ej, const float* es, uint64_t E, int rank_mode,
+                             uint32_t* tcnt, const EventList& ev, hipStream_t st);
 
 // Radix-select state.  Lives in the context's control block, which ONE memset zeroes per call; key_range_kernel
 // (end of launch_tri_keys) fills kmin / kmax / want.
@@ -99,6 +122,10 @@ void launch_tri_keys(const Graph& g, const uint64_t* mbits, const float* smin, c
                      const uint32_t* ei, const uint32_t* ej, const float* es, const uint64_t* toff, uint64_t E,
                      int rank_mode, uint32_t* wkey, uint32_t* blk_minmax, SelectState* s, uint64_t want,
                      hipStream_t st);
+// keys from the event list (replaces launch_tri_keys when no region overflowed)
+void launch_tri_keys_events(const Graph& g, const float* es, const uint64_t* toff, int rank_mode,
+                            const EventList& ev, uint32_t* wkey, uint32_t* blk_minmax, SelectState* s,
+                            uint64_t want, hipStream_t st);
 // up to three rounds (histogram + pick by the last block to finish) find the exact threshold key
 void launch_select_rounds(const uint32_t* wkey, uint64_t M, SelectState* s, hipStream_t st);
 // compaction of the selected keys in ordinal order
@@ -135,7 +162,7 @@ void launch_kabsch_aos(const Points& pts, const uint32_t* tri, uint32_t T, float
 // AoS T x 12 -> SoA planes (stage hook for sc_score_host)
 void launch_rt_to_soa(const float* Rt, uint32_t T, uint32_t ld_local, float* RtSoA, hipStream_t st);
 // C2: inlier counts.  partial: n_chunks * ld_local u32 scratch.
-uint32_t score_chunks(int n);
+uint32_t score_chunks(int n, uint32_t ld_local);  // point chunks the scoring launch will use
 void launch_score(const Points& pts, const float* RtSoA, const Shard& sh, float tau2, uint32_t* partial,
                   hipStream_t st);
 // Winner key pair key2[0..1] (zeroed here):

@@ -113,11 +113,26 @@ void launch_rt_to_soa(const float* Rt, uint32_t T, uint32_t ld_local, float* RtS
 constexpr int SCORE_THREADS = 256;
 constexpr int SCORE_PC = 512;  // correspondences per chunk (LDS: 12 KiB per workgroup, 8 workgroups per CU)
 
-uint32_t score_chunks(int n) { return (uint32_t)((n + SCORE_PC - 1) / SCORE_PC); }
-static inline int score_chunk_points(int n) {  // equalised chunk length, multiple of 4, <= SCORE_PC
-  const int c = (int)score_chunks(n);
-  const int per = (n + c - 1) / c;
-  return (per + 3) & ~3;
+// Point chunking of C2: workgroups = (hypothesis groups of 256) x chunks.  Chunks are as long as LDS allows (512) for
+// big problems, shorter for small ones so that the launch still has ~2048 workgroups (8 per CU) to fill the chip.
+void score_plan(int n, uint32_t ld_local, uint32_t* chunks, int* chunk_pts) {
+  const uint32_t groups = ld_local / SCORE_THREADS ? ld_local / SCORE_THREADS : 1u;
+  uint32_t want = 2048 / groups;                                      // at most one resident generation (8 per CU)
+  const uint32_t min_chunks = (uint32_t)((n + SCORE_PC - 1) / SCORE_PC);  // LDS capacity
+  const uint32_t max_chunks = (uint32_t)((n + 63) / 64);                  // at least 64 points per chunk
+  if (want < min_chunks) want = min_chunks;
+  if (want > max_chunks) want = max_chunks;
+  if (want < 1) want = 1;
+  int per = (int)((n + want - 1) / want);
+  per = (per + 3) & ~3;                                               // multiple of 4, <= SCORE_PC
+  if (per > SCORE_PC) per = SCORE_PC;
+  *chunk_pts = per;
+  *chunks = (uint32_t)((n + per - 1) / per);
+}
+uint32_t score_chunks(int n, uint32_t ld_local) {
+  uint32_t c; int p;
+  score_plan(n, ld_local, &c, &p);
+  return c;
 }
 
 // One inlier test, written so that hipcc keeps 17 single-issue VALU ops (build.py passes -fno-slp-vectorize:
@@ -331,8 +346,9 @@ static uint32_t score_mfma_share() {
 void launch_score(const Points& pts, const float* RtSoA, const Shard& sh, float tau2, uint32_t* partial,
                   hipStream_t st) {
   if (sh.n_local == 0) return;
-  const uint32_t chunks = score_chunks(pts.n);
-  const int chunk_pts = score_chunk_points(pts.n);
+  uint32_t chunks;
+  int chunk_pts;
+  score_plan(pts.n, sh.ld_local, &chunks, &chunk_pts);
   const uint32_t groups = sh.ld_local / SCORE_THREADS;            // 256-hypothesis groups
   const uint32_t gm = (uint32_t)(((uint64_t)groups * score_mfma_share() + 128) / 256);  // groups on the matrix pipe
   const uint32_t nv = groups - gm, nm = gm * (SCORE_THREADS / MF_HYPS_PER_BLOCK);
@@ -344,7 +360,8 @@ void launch_argmax(const Points& pts, const Shard& sh, const uint32_t* partial, 
                    uint32_t* cnt, uint64_t* key2, hipStream_t st) {
   (void)hipMemsetAsync(key2, 0, 2 * sizeof(uint64_t), st);
   if (sh.n_local == 0) return;
-  hipLaunchKernelGGL(score_argmax_kernel, dim3(sh.ld_local / 256), dim3(256), 0, st, partial, score_chunks(pts.n),
+  hipLaunchKernelGGL(score_argmax_kernel, dim3(sh.ld_local / 256), dim3(256), 0, st, partial,
+                     score_chunks(pts.n, sh.ld_local),
                      sh, sel_key, cnt, reinterpret_cast<unsigned long long*>(key2));
   if (sel_key)
     hipLaunchKernelGGL(score_argpos_kernel, dim3(sh.ld_local / 256), dim3(256), 0, st, cnt, sh, sel_key,

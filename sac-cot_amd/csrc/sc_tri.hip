@@ -65,13 +65,15 @@ __global__ __launch_bounds__(256) void edge_fill_kernel(const uint64_t* __restri
                                                         float* __restrict__ es,
                                                         const uint32_t* __restrict__ deg,
                                                         const uint32_t* __restrict__ degp,
-                                                        uint32_t* __restrict__ ebase) {
+                                                        uint32_t* __restrict__ ebase, uint32_t* __restrict__ ebi,
+                                                        uint32_t* __restrict__ ebj) {
   const int lane = threadIdx.x & 63;
   const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (i >= n) return;
   uint64_t base = edge_off[i];
   // (# bits of row i at or below i) = deg - deg+; modular u32 arithmetic (edge indices are < 2^32)
-  if (lane == 0) ebase[i] = (uint32_t)base - (deg[i] - degp[i]);
+  const uint32_t my_base = (uint32_t)base - (deg[i] - degp[i]);
+  if (lane == 0) ebase[i] = my_base;
   const int w0 = i >> 6;
   for (int wb = w0; wb < W; wb += 64) {
     const int w = wb + lane;
@@ -90,15 +92,18 @@ __global__ __launch_bounds__(256) void edge_fill_kernel(const uint64_t* __restri
       ei[e] = (uint32_t)i;
       ej[e] = j;
       es[e] = S[(size_t)i * ld + j];
+      // both CSR bases travel with the edge, so stage B fetches an edge in ONE memory level
+      ebi[e] = my_base;
+      ebj[e] = (uint32_t)edge_off[j] - (deg[j] - degp[j]);
     }
     base += tot;
   }
 }
 
 void launch_edge_fill(const Graph& g, const uint64_t* edge_off, uint32_t* ei, uint32_t* ej, float* es,
-                      uint32_t* ebase, hipStream_t st) {
+                      uint32_t* ebase, uint32_t* ebi, uint32_t* ebj, hipStream_t st) {
   hipLaunchKernelGGL(edge_fill_kernel, dim3((g.n + 3) / 4), dim3(256), 0, st, g.bits, g.S, g.n, g.ld, g.W,
-                     edge_off, ei, ej, es, g.deg, g.degp, ebase);
+                     edge_off, ei, ej, es, g.deg, g.degp, ebase, ebi, ebj);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -112,6 +117,7 @@ static int tune_tg(const char* name, int dflt) {
   return (t == 4 || t == 8 || t == 16 || t == 32 || t == 64) ? t : dflt;
 }
 
+constexpr int TK_MAX_BLOCKS = 4096;  // bounds the per-block min/max arrays
 constexpr int TG_DEFAULT = 16;  // lanes per edge (template parameter TG of the edge kernels)
 
 // mbits: the bit matrix that decides MEMBERSHIP (the full adjacency, or the pruned "strong" upper-triangle matrix);
@@ -191,7 +197,6 @@ void launch_tri_count(const Graph& g, const uint64_t* mbits, const float* es, co
 // ------------------------------------------------------------------------------------------------
 // 3. tri_keys
 // ------------------------------------------------------------------------------------------------
-constexpr int TK_MAX_BLOCKS = 4096;  // bounds the per-block min/max arrays
 
 // bits / wpre / ebase: full adjacency + its word-prefix popcounts + per-row CSR bases: the index of edge (v,k) in the
 // edge arrays is ebase[v] + wpre[v][k/64] + popc(bits[v][k/64] & below k) — an O(1) lookup, no running prefix.
@@ -329,6 +334,247 @@ void launch_tri_keys(const Graph& g, const uint64_t* mbits, const float* smin, c
 #define SC_LAUNCH_KEYS(TGV) hipLaunchKernelGGL(tri_keys_kernel<TGV>, dim3(nb), dim3(256), 0, st, g.bits, mbits, smin, g.W, g.deg, g.wpre, ebase, ei, ej, es, toff, E, rank_mode, wkey, blk_minmax, blk_minmax + TK_MAX_BLOCKS)
   if (tg == 4) SC_LAUNCH_KEYS(4); else if (tg == 8) SC_LAUNCH_KEYS(8); else if (tg == 32) SC_LAUNCH_KEYS(32); else if (tg == 64) SC_LAUNCH_KEYS(64); else SC_LAUNCH_KEYS(16);
 #undef SC_LAUNCH_KEYS
+  hipLaunchKernelGGL(key_range_kernel, dim3(1), dim3(1024), 0, st, blk_minmax, blk_minmax + TK_MAX_BLOCKS, nb, s, want);
+}
+
+// ------------------------------------------------------------------------------------------------
+// 2b/3'. event list: count and keys without enumerating twice
+//
+// tri_count and tri_keys used to AND the same pairs of bit rows, and tri_keys paid three dependent memory levels per
+// wave-round (rows -> prefix words -> edge weights).  Now the counting pass also records every non-zero member word
+// as an EVENT {member word m, word offsets of both rows, CSR bases of both ends, edge, rank of its first triangle
+// inside the edge}.  Events are staged per workgroup in LDS and appended to one of EV_SHARDS global regions with a
+// single atomic per flush (one counter per region: same-address atomics serialise at ~11 ns each).  After the scan
+// of the per-edge counts, tri_keys_events_kernel runs one lane per event: all its gathers are independent, and a
+// triangle's key lands at its ordinal toff[e] + rank.  Event order is arbitrary; the result is not.
+// If a region overflows, a flag reaches the host with the triangle count and the call falls back to the row-walking
+// tri_keys_kernel (and doubles the event capacity for the next call).
+// ------------------------------------------------------------------------------------------------
+constexpr int EV_SHARDS = 256;
+
+// Staging is per workgroup (EVB records in LDS, slots handed out by an LDS counter); a flush happens at a
+// workgroup-uniform point between trips.  Used only for moderately wide rows (W <= 128) of a pruned graph: with very
+// wide or dense rows a trip can overflow the staging buffer into per-event global atomics (C3, W = 313: 4.7 ms), so the
+// host then keeps the row-walking tri_count / tri_keys pair.  Other shapes measured on C2 and rejected: per-wave
+// staging with a global-atomic overflow path (235 us), per-group staging with group-uniform flushes (118 us), and a
+// wave-uniform one-round-per-iteration state machine with ballot compaction and software prefetch (98 us); this one
+// takes 50 us.
+constexpr int EVB = 512;  // events staged per workgroup (16 KiB of LDS: still 8 workgroups per CU)
+
+template <int TG>
+__global__ __launch_bounds__(256) void tri_count_events_kernel(const uint64_t* __restrict__ mbits, int W,
+                                                               const uint32_t* __restrict__ deg,
+                                                               const uint32_t* __restrict__ ebi,
+                                                               const uint32_t* __restrict__ ebj,
+                                                               const uint32_t* __restrict__ ei,
+                                                               const uint32_t* __restrict__ ej,
+                                                               const float* __restrict__ es,
+                                                               const float* __restrict__ smin, uint64_t E,
+                                                               int rank_mode, uint32_t* __restrict__ tcnt,
+                                                               EventList ev) {
+  __shared__ uint64_t l_m[EVB];
+  __shared__ uint32_t l_wi[EVB], l_wj[EVB], l_a[EVB], l_b[EVB], l_e[EVB], l_rb[EVB];
+  __shared__ uint32_t l_cnt, l_base;
+  const int gl = threadIdx.x & (TG - 1);
+  const uint64_t gmask = (TG == 64) ? ~0ull : (((1ull << TG) - 1ull) << ((threadIdx.x & 63) & ~(TG - 1)));
+  const float s_floor = smin ? *smin : -1.0f;
+  const uint64_t groups = (uint64_t)gridDim.x * (256 / TG);
+  const uint64_t g0 = (uint64_t)blockIdx.x * (256 / TG) + (threadIdx.x / TG);
+  const uint32_t shard = blockIdx.x & (EV_SHARDS - 1);
+  const uint64_t trips = (E + groups - 1) / groups;  // the same for every thread: the loop holds workgroup barriers
+  if (threadIdx.x == 0) l_cnt = 0;
+  __syncthreads();
+  auto flush = [&]() {  // workgroup-uniform
+    const uint32_t n = min(l_cnt, (uint32_t)EVB);
+    if (threadIdx.x == 0 && n) l_base = atomicAdd(&ev.fill[shard], n);
+    __syncthreads();
+    const uint32_t base = l_base;
+    for (uint32_t k = threadIdx.x; k < n; k += 256) {
+      const uint64_t pos = (uint64_t)base + k;
+      if (pos < ev.shard_cap) {
+        const uint64_t o = (uint64_t)shard * ev.shard_cap + pos;
+        ev.m[o] = l_m[k]; ev.wi[o] = l_wi[k]; ev.wj[o] = l_wj[k]; ev.a[o] = l_a[k]; ev.b[o] = l_b[k];
+        ev.e[o] = l_e[k]; ev.rb[o] = l_rb[k];
+      } else {
+        *ev.overflow = 1u;
+      }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) l_cnt = 0;
+    __syncthreads();
+  };
+  for (uint64_t trip = 0; trip < trips; trip++) {
+    const uint64_t e = g0 + trip * groups;
+    uint32_t c = 0;
+    if (e < E && es[e] >= s_floor) {  // group-uniform
+      const uint32_t i = ei[e], j = ej[e];
+      const uint32_t rowi = i * (uint32_t)W, rowj = j * (uint32_t)W;
+      const uint32_t fa = (rank_mode == 0) ? ebi[e] : deg[i] + deg[j];  // weight mode: CSR bases; degree mode: deg sum
+      const uint32_t fb = (rank_mode == 0) ? ebj[e] : 0u;
+      const int w0 = j >> 6;
+      const int rounds = (W - w0 + TG - 1) / TG;
+      for (int it = 0; it < rounds; it++) {
+        const int w = w0 + it * TG + gl;
+        uint64_t m = 0;
+        if (w < W) {
+          m = mbits[rowi + w] & mbits[rowj + w];
+          if (w == w0) m &= mask_above(j & 63);
+        }
+        const uint64_t any = __ballot(m != 0) & gmask;
+        if (any == 0) continue;  // group-uniform
+        uint32_t tm;
+        const uint32_t rb = c + group_exscan<TG>((uint32_t)__popcll(m), &tm);
+        c += tm;
+        if (m) {
+          const uint32_t slot = atomicAdd(&l_cnt, 1u);
+          if (slot < (uint32_t)EVB) {
+            l_m[slot] = m; l_wi[slot] = rowi + w; l_wj[slot] = rowj + w; l_a[slot] = fa; l_b[slot] = fb;
+            l_e[slot] = (uint32_t)e; l_rb[slot] = rb;
+          } else {  // staging full inside one trip (very dense rows): straight to the global region
+            const uint64_t pos = atomicAdd(&ev.fill[shard], 1u);
+            if (pos < ev.shard_cap) {
+              const uint64_t o = (uint64_t)shard * ev.shard_cap + pos;
+              ev.m[o] = m; ev.wi[o] = rowi + w; ev.wj[o] = rowj + w; ev.a[o] = fa; ev.b[o] = fb;
+              ev.e[o] = (uint32_t)e; ev.rb[o] = rb;
+            } else {
+              *ev.overflow = 1u;
+            }
+          }
+        }
+      }
+    }
+    if (gl == 0 && e < E) tcnt[e] = c;
+    __syncthreads();
+    const uint32_t staged = l_cnt;  // read between two barriers: nobody appends here, so every thread sees one value
+    __syncthreads();
+    if (staged > (uint32_t)(EVB / 2)) flush();
+  }
+  __syncthreads();
+  flush();
+}
+
+// one lane per event
+__global__ __launch_bounds__(256) void tri_keys_events_kernel(const uint64_t* __restrict__ bits,
+                                                              const uint32_t* __restrict__ wpre,
+                                                              const uint32_t* __restrict__ deg,
+                                                              const float* __restrict__ es,
+                                                              const uint64_t* __restrict__ toff, int rank_mode,
+                                                              EventList ev, uint32_t* __restrict__ wkey,
+                                                              uint32_t* __restrict__ blk_min,
+                                                              uint32_t* __restrict__ blk_max) {
+  __shared__ uint32_t lmin[4], lmax[4];
+  __shared__ uint64_t pre[EV_SHARDS + 1];  // exclusive prefix of the region fills: one flat index space over all events
+  {
+    static_assert(EV_SHARDS == 256, "one region per thread");
+    __shared__ uint64_t plds[8];
+    const uint64_t mine = min((uint64_t)ev.fill[threadIdx.x], ev.shard_cap);
+    uint64_t tot;
+    pre[threadIdx.x] = block_exscan_u64(mine, plds, &tot);
+    if (threadIdx.x == 0) pre[EV_SHARDS] = tot;
+    __syncthreads();
+  }
+  uint32_t kmin = 0xFFFFFFFFu, kmax = 0;
+  const uint64_t nthreads = (uint64_t)gridDim.x * 256, total = pre[EV_SHARDS];
+  {
+    for (uint64_t x = (uint64_t)blockIdx.x * 256 + threadIdx.x; x < total; x += nthreads) {
+      int sh = 0;  // largest sh with pre[sh] <= x
+#pragma unroll
+      for (int step = EV_SHARDS / 2; step > 0; step >>= 1) sh += (pre[sh + step] <= x) ? step : 0;
+      const uint64_t o = (uint64_t)sh * ev.shard_cap + (x - pre[sh]);
+      uint64_t m = ev.m[o];
+      const uint32_t wi = ev.wi[o], wj = ev.wj[o], fa = ev.a[o], e = ev.e[o];
+      uint64_t out = toff[e] + ev.rb[o];
+      if (rank_mode == 0) {
+        const uint32_t fb = ev.b[o];
+        const uint64_t fi = bits[wi], fj = bits[wj];  // full-graph words: ranks in the CSR edge arrays
+        const uint32_t pi = fa + wpre[wi], pj = fb + wpre[wj];
+        const float s_ij = es[e];
+        while (m) {
+          int b[4];
+          const int nbits = pop4(m, b);
+          float s_ik[4], s_jk[4];
+#pragma unroll
+          for (int q = 0; q < 4; q++) {
+            const uint64_t below = (1ull << b[q]) - 1ull;
+            const bool live = q < nbits;  // idle slots read es[0]
+            s_ik[q] = es[live ? pi + (uint32_t)__popcll(fi & below) : 0u];
+            s_jk[q] = es[live ? pj + (uint32_t)__popcll(fj & below) : 0u];
+          }
+#pragma unroll
+          for (int q = 0; q < 4; q++) {
+            if (q < nbits) {
+              const uint32_t key = __float_as_uint((s_ij + s_ik[q]) + s_jk[q]);
+              wkey[out++] = key;
+              kmin = min(kmin, key);
+              kmax = max(kmax, key);
+            }
+          }
+        }
+      } else {
+        const uint32_t kbase = (uint32_t)(wi % (uint32_t)ev.W) * 64u;  // column index of bit 0 of this word
+        while (m) {
+          const int b = __builtin_ctzll(m);
+          m &= m - 1;
+          const uint32_t key = fa + deg[kbase + b];
+          wkey[out++] = key;
+          kmin = min(kmin, key);
+          kmax = max(kmax, key);
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    kmin = min(kmin, (uint32_t)__shfl_xor(kmin, o));
+    kmax = max(kmax, (uint32_t)__shfl_xor(kmax, o));
+  }
+  if ((threadIdx.x & 63) == 0) { lmin[threadIdx.x >> 6] = kmin; lmax[threadIdx.x >> 6] = kmax; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    blk_min[blockIdx.x] = min(min(lmin[0], lmin[1]), min(lmin[2], lmin[3]));
+    blk_max[blockIdx.x] = max(max(lmax[0], lmax[1]), max(lmax[2], lmax[3]));
+  }
+}
+
+size_t event_bytes(uint64_t capacity) { return (size_t)capacity * 32 + EV_SHARDS * 4 + 64; }
+
+EventList event_list(void* buf, uint64_t capacity, int W, uint32_t* overflow_host) {
+  EventList ev;
+  const uint64_t cap = capacity / EV_SHARDS * EV_SHARDS;
+  unsigned char* p = static_cast<unsigned char*>(buf);
+  ev.m = reinterpret_cast<uint64_t*>(p); p += cap * 8;
+  ev.wi = reinterpret_cast<uint32_t*>(p); p += cap * 4;
+  ev.wj = reinterpret_cast<uint32_t*>(p); p += cap * 4;
+  ev.a = reinterpret_cast<uint32_t*>(p); p += cap * 4;
+  ev.b = reinterpret_cast<uint32_t*>(p); p += cap * 4;
+  ev.e = reinterpret_cast<uint32_t*>(p); p += cap * 4;
+  ev.rb = reinterpret_cast<uint32_t*>(p); p += cap * 4;
+  ev.fill = reinterpret_cast<uint32_t*>(p);
+  ev.shard_cap = cap / EV_SHARDS;
+  ev.overflow = overflow_host;
+  ev.W = W;
+  return ev;
+}
+
+void launch_tri_count_events(const Graph& g, const uint64_t* mbits, const float* smin, const uint32_t* ebi,
+                             const uint32_t* ebj, const uint32_t* ei, const uint32_t* ej, const float* es, uint64_t E, int rank_mode,
+                             uint32_t* tcnt, const EventList& ev, hipStream_t st) {
+  if (E == 0) return;
+  (void)hipMemsetAsync(ev.fill, 0, EV_SHARDS * sizeof(uint32_t), st);
+  constexpr int TGV = 8;
+  const uint64_t per = 256 / TGV;
+  uint64_t nb = (E + per - 1) / per;
+  if (nb > 4096) nb = 4096;
+  hipLaunchKernelGGL(tri_count_events_kernel<TGV>, dim3((unsigned)nb), dim3(256), 0, st, mbits, g.W, g.deg, ebi, ebj, ei,
+                     ej, es, smin, E, rank_mode, tcnt, ev);
+}
+
+void launch_tri_keys_events(const Graph& g, const float* es, const uint64_t* toff, int rank_mode,
+                            const EventList& ev, uint32_t* wkey, uint32_t* blk_minmax, SelectState* s,
+                            uint64_t want, hipStream_t st) {
+  const int nb = 2048;
+  hipLaunchKernelGGL(tri_keys_events_kernel, dim3(nb), dim3(256), 0, st, g.bits, g.wpre, g.deg, es, toff, rank_mode,
+                     ev, wkey, blk_minmax, blk_minmax + TK_MAX_BLOCKS);
   hipLaunchKernelGGL(key_range_kernel, dim3(1), dim3(1024), 0, st, blk_minmax, blk_minmax + TK_MAX_BLOCKS, nb, s, want);
 }
 
