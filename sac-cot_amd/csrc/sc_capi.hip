@@ -42,7 +42,7 @@ struct sc_ctx {
   uint64_t* pinned = nullptr;  // N_PINNED x u64 host-pinned area the kernels write results into
 
   // workspace
-  Buf in_src, in_tgt, planes, S, bits, deg, degp, wpre, ebase, edge_off, scan_tmp, ei, ej, es, ebi, ebj, tcnt, toff, wkey, ctl, events, blk_gt,
+  Buf in_src, in_tgt, planes, S, bits, deg, degp, wpre, ebase, edge_off, scan_tmp, ei, ej, es, ebi, ebj, tcnt, toff, wkey, kcol, ctl, events, blk_gt,
       blk_eq, blk_minmax, bits2, off_gt, off_eq, sel_ord, sel_key, sortkey, sorted, sort_tmp, tri, tri_rk, key_rk, rt, rt_aos, partial, cnt, key, rt12,
       mask;
 
@@ -143,12 +143,13 @@ int stage_inputs(sc_ctx* c, const float* d_src, const float* d_tgt, int64_t n, c
   c->n = (int)n;
   c->ld = round_up((int)n, 64);
   ENSURE(c, c->planes, (size_t)6 * c->ld * sizeof(float));
-  // per-call control block: ONE memset instead of one per flag / histogram / key
+  // per-call control block (flags, histograms, counters, select state): cleared by the staging kernel itself
   ENSURE(c, c->ctl, sizeof(ControlBlock));
-  HIPCHK(c, hipMemsetAsync(c->ctl.p, 0, sizeof(ControlBlock), c->stream));
+  static_assert(sizeof(ControlBlock) % 4 == 0, "cleared word-wise");
   c->pinned[1] = 0;  // "non-finite input" flag lives in host-pinned memory: the kernel only touches it on bad data
   launch_stage_points(d_src, d_tgt, c->n, c->ld, p->layout, c->planes.as<float>(),
-                      reinterpret_cast<uint32_t*>(&c->pinned[1]), c->stream);
+                      reinterpret_cast<uint32_t*>(&c->pinned[1]), c->ctl.as<uint32_t>(),
+                      (uint32_t)(sizeof(ControlBlock) / 4), c->stream);
   return SC_OK;
 }
 
@@ -231,7 +232,8 @@ int run_triangles(sc_ctx* c, const sc_params* p) {
   if (use_events) {
     ENSURE(c, c->events, event_bytes(c->ev_capacity));
     c->pinned[5] = 0;
-    ev = event_list(c->events.p, c->ev_capacity, g.W, reinterpret_cast<uint32_t*>(&c->pinned[5]));
+    ev = event_list(c->events.p, c->ev_capacity, g.W, c->ctl.as<ControlBlock>()->ev_fill,
+                    reinterpret_cast<uint32_t*>(&c->pinned[5]));
     launch_tri_count_events(g, mbits, smin, c->ebi.as<uint32_t>(), c->ebj.as<uint32_t>(), c->ei.as<uint32_t>(),
                             c->ej.as<uint32_t>(),
                             c->es.as<float>(), E, p->rank_mode, c->tcnt.as<uint32_t>(), ev, st);
@@ -246,9 +248,10 @@ int run_triangles(sc_ctx* c, const sc_params* p) {
   const uint64_t M = c->M = c->pinned[2];
   if (M == 0) return SC_OK;
   const uint32_t T_eff = c->T_eff = (uint32_t)(M < p->max_triangles ? M : p->max_triangles);
-  if (M * 4 > c->cap_bytes) { c->last_error = "triangle keys exceed the workspace cap"; return SC_ETOOMANY; }
+  if (M * 8 > c->cap_bytes) { c->last_error = "triangle keys exceed the workspace cap"; return SC_ETOOMANY; }
   const size_t nb = compact_blocks(M);
   ENSURE(c, c->wkey, M * 4);
+  ENSURE(c, c->kcol, M * 4);
   ENSURE(c, c->blk_minmax, 2 * 8192 * 4);
   ENSURE(c, c->blk_gt, nb * 4);
   ENSURE(c, c->blk_eq, nb * 4);
@@ -270,11 +273,11 @@ int run_triangles(sc_ctx* c, const sc_params* p) {
   }
   if (events_ok)
     launch_tri_keys_events(g, c->es.as<float>(), c->toff.as<uint64_t>(), p->rank_mode, ev, c->wkey.as<uint32_t>(),
-                           c->blk_minmax.as<uint32_t>(), sel, T_eff, st);
+                           c->kcol.as<uint32_t>(), c->blk_minmax.as<uint32_t>(), sel, T_eff, st);
   else
     launch_tri_keys(g, mbits, smin, c->ebase.as<uint32_t>(), c->ei.as<uint32_t>(), c->ej.as<uint32_t>(),
                     c->es.as<float>(), c->toff.as<uint64_t>(), E, p->rank_mode, c->wkey.as<uint32_t>(),
-                    c->blk_minmax.as<uint32_t>(), sel, T_eff, st);
+                    c->kcol.as<uint32_t>(), c->blk_minmax.as<uint32_t>(), sel, T_eff, st);
   if (c->timing) HIPCHK(c, hipEventRecord(c->ev[10], st));
   c->timed_trikeys = c->timing;
   launch_select_rounds(c->wkey.as<uint32_t>(), M, sel, st);
@@ -285,7 +288,7 @@ int run_triangles(sc_ctx* c, const sc_params* p) {
                        c->off_gt.as<uint64_t>(), c->off_eq.as<uint64_t>(), c->sel_ord.as<uint64_t>(),
                        c->sel_key.as<uint32_t>(), st);
   // the list stays in ordinal order: no sort on the hot path (the winner is found by (count, key, position))
-  launch_tri_decode(g, mbits, c->ei.as<uint32_t>(), c->ej.as<uint32_t>(), c->toff.as<uint64_t>(), E,
+  launch_tri_decode(c->ei.as<uint32_t>(), c->ej.as<uint32_t>(), c->kcol.as<uint32_t>(), c->toff.as<uint64_t>(), E,
                     c->sel_ord.as<uint64_t>(), T_eff, c->tri.as<uint32_t>(), st);
   return SC_OK;
 }
@@ -384,7 +387,7 @@ void sc_destroy(sc_ctx* c) {
   (void)hipSetDevice(c->device);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   Buf* bufs[] = {&c->in_src, &c->in_tgt, &c->planes, &c->S, &c->bits, &c->deg, &c->degp, &c->wpre, &c->ebase, &c->edge_off, &c->scan_tmp,
-                 &c->ei, &c->ej, &c->es, &c->ebi, &c->ebj, &c->tcnt, &c->toff, &c->wkey, &c->ctl, &c->events, &c->blk_gt, &c->blk_eq, &c->blk_minmax, &c->bits2, &c->off_gt,
+                 &c->ei, &c->ej, &c->es, &c->ebi, &c->ebj, &c->tcnt, &c->toff, &c->wkey, &c->kcol, &c->ctl, &c->events, &c->blk_gt, &c->blk_eq, &c->blk_minmax, &c->bits2, &c->off_gt,
                  &c->off_eq, &c->sel_ord, &c->sel_key, &c->sortkey, &c->sorted, &c->sort_tmp, &c->tri, &c->tri_rk, &c->key_rk, &c->rt,
                  &c->rt_aos, &c->partial, &c->cnt, &c->key, &c->rt12, &c->mask};
   for (Buf* b : bufs) if (b->p) (void)hipFree(b->p);

@@ -17,8 +17,10 @@ namespace sc {
 __global__ __launch_bounds__(256) void stage_points_kernel(const float* __restrict__ src,
                                                            const float* __restrict__ tgt, int n, int ld,
                                                            int layout, float* __restrict__ planes,
-                                                           uint32_t* __restrict__ bad_flag) {
+                                                           uint32_t* __restrict__ bad_flag,
+                                                           uint32_t* __restrict__ zero, uint32_t zero_words) {
   int m = blockIdx.x * 256 + threadIdx.x;
+  for (uint32_t z = (uint32_t)m; z < zero_words; z += gridDim.x * 256) zero[z] = 0u;  // the per-call control block
   if (m >= ld) return;
   float v[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   if (m < n) {
@@ -38,9 +40,9 @@ __global__ __launch_bounds__(256) void stage_points_kernel(const float* __restri
 }
 
 void launch_stage_points(const float* d_src, const float* d_tgt, int n, int ld, int layout, float* planes,
-                         uint32_t* bad_flag, hipStream_t st) {
+                         uint32_t* bad_flag, uint32_t* zero, uint32_t zero_words, hipStream_t st) {
   hipLaunchKernelGGL(stage_points_kernel, dim3((ld + 255) / 256), dim3(256), 0, st, d_src, d_tgt, n, ld, layout,
-                     planes, bad_flag);
+                     planes, bad_flag, zero, zero_words);
 }
 
 // ------------------------------------------------------------------------------------------------

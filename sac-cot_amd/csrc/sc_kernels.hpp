@@ -25,8 +25,9 @@ struct Points {
 // ---- input staging -----------------------------------------------------------------------------
 // user layout (AoS n x 3 or SoA 3 x n) -> padded planes; sets *bad_flag != 0 when a value is not finite.
 // bad_flag may be host-pinned memory: it is only touched (atomicOr) when a non-finite value is found.
+// zero / zero_words: a buffer (the per-call control block) the kernel clears on the way — saves a memset launch.
 void launch_stage_points(const float* d_src, const float* d_tgt, int n, int ld, int layout, float* planes,
-                         uint32_t* bad_flag, hipStream_t st);
+                         uint32_t* bad_flag, uint32_t* zero, uint32_t zero_words, hipStream_t st);
 
 // ---- stage A: compat_graph -----------------------------------------------------------------------
 // S: n x ld fp32 (row-major, symmetric, zero diagonal / pad columns); bits: n x (ld/64) u64;
@@ -87,7 +88,7 @@ struct EventList {
   int W;
 };
 size_t event_bytes(uint64_t capacity);
-EventList event_list(void* buf, uint64_t capacity, int W, uint32_t* overflow_host);
+EventList event_list(void* buf, uint64_t capacity, int W, uint32_t* fill, uint32_t* overflow_host);
 // counting pass that also emits the events (replaces launch_tri_count when an event buffer is available)
 void launch_tri_count_events(const Graph& g, const uint64_t* mbits, const float* smin, const uint32_t* ebi,
                              const uint32_t* ebj, const uint32_t* ei, const uint32_t* ej, const float* es, uint64_t E, int rank_mode,
@@ -108,6 +109,7 @@ struct SelectState {
 
 // Per-call control block (device memory, zeroed by one hipMemsetAsync at the start of every call).
 struct ControlBlock {
+  uint32_t ev_fill[256];     // event-list region fill counters (EV_SHARDS)
   uint32_t prune_hist[256];  // sampled key histogram of the certified pruning
   float smin;                // strong-edge threshold (written by prune_bits_kernel)
   uint32_t pad0[15];
@@ -120,12 +122,12 @@ struct ControlBlock {
 // blk_minmax: 2 * 8192 u32 scratch (per-block key min / max, reduced into s->kmin / s->kmax; s->want = want).
 void launch_tri_keys(const Graph& g, const uint64_t* mbits, const float* smin, const uint32_t* ebase,
                      const uint32_t* ei, const uint32_t* ej, const float* es, const uint64_t* toff, uint64_t E,
-                     int rank_mode, uint32_t* wkey, uint32_t* blk_minmax, SelectState* s, uint64_t want,
-                     hipStream_t st);
+                     int rank_mode, uint32_t* wkey, uint32_t* kcol, uint32_t* blk_minmax, SelectState* s,
+                     uint64_t want, hipStream_t st);  // kcol[ordinal] = the triangle's third vertex
 // keys from the event list (replaces launch_tri_keys when no region overflowed)
 void launch_tri_keys_events(const Graph& g, const float* es, const uint64_t* toff, int rank_mode,
-                            const EventList& ev, uint32_t* wkey, uint32_t* blk_minmax, SelectState* s,
-                            uint64_t want, hipStream_t st);
+                            const EventList& ev, uint32_t* wkey, uint32_t* kcol, uint32_t* blk_minmax,
+                            SelectState* s, uint64_t want, hipStream_t st);
 // up to three rounds (histogram + pick by the last block to finish) find the exact threshold key
 void launch_select_rounds(const uint32_t* wkey, uint64_t M, SelectState* s, hipStream_t st);
 // compaction of the selected keys in ordinal order
@@ -139,9 +141,8 @@ void launch_compact_write(const uint32_t* wkey, uint64_t M, const SelectState* s
 size_t sort_temp_bytes(size_t n);
 void launch_sort_u64(const uint64_t* in, uint64_t* out, size_t n, void* temp, size_t temp_bytes, hipStream_t st);
 // selected position -> (i,j,k); the list stays in ordinal ((i,j,k) ascending) order
-void launch_tri_decode(const Graph& g, const uint64_t* mbits, const uint32_t* ei, const uint32_t* ej,
-                       const uint64_t* toff, uint64_t E, const uint64_t* sel_ord, uint32_t T, uint32_t* tri,
-                       hipStream_t st);
+void launch_tri_decode(const uint32_t* ei, const uint32_t* ej, const uint32_t* kcol, const uint64_t* toff, uint64_t E,
+                       const uint64_t* sel_ord, uint32_t T, uint32_t* tri, hipStream_t st);
 // ranked order (key desc, ordinal asc) of the ordinal-ordered list: only the stage hook needs it
 void launch_rank_order(const uint32_t* tri, const uint32_t* sel_key, uint32_t T, uint64_t* sortkey, uint64_t* sorted,
                        void* sort_tmp, size_t sort_bytes, uint32_t* tri_ranked, uint32_t* key_ranked, hipStream_t st);

@@ -215,6 +215,7 @@ __global__ __launch_bounds__(256) void tri_keys_kernel(const uint64_t* __restric
                                                        const float* __restrict__ es,
                                                        const uint64_t* __restrict__ toff, uint64_t E,
                                                        int rank_mode, uint32_t* __restrict__ wkey,
+                                                       uint32_t* __restrict__ kcol,
                                                        uint32_t* __restrict__ blk_min,
                                                        uint32_t* __restrict__ blk_max) {
   __shared__ uint32_t lmin[4], lmax[4];
@@ -276,6 +277,7 @@ __global__ __launch_bounds__(256) void tri_keys_kernel(const uint64_t* __restric
 #pragma unroll
           for (int q = 0; q < 4; q++) {
             if (q < nbits) {
+              kcol[out0 + pm] = (uint32_t)(w * 64 + b[q]);  // third vertex, looked up by tri_decode
               wkey[out0 + pm++] = key[q];
               kmin = min(kmin, key[q]);
               kmax = max(kmax, key[q]);
@@ -326,12 +328,12 @@ size_t tri_keys_blocks(uint64_t E, int tg) {
 
 void launch_tri_keys(const Graph& g, const uint64_t* mbits, const float* smin, const uint32_t* ebase,
                      const uint32_t* ei, const uint32_t* ej, const float* es, const uint64_t* toff, uint64_t E,
-                     int rank_mode, uint32_t* wkey, uint32_t* blk_minmax, SelectState* s, uint64_t want,
-                     hipStream_t st) {
+                     int rank_mode, uint32_t* wkey, uint32_t* kcol, uint32_t* blk_minmax, SelectState* s,
+                     uint64_t want, hipStream_t st) {
   if (E == 0) return;
   const int tg = tune_tg("SC_TG_KEYS", 8);
   const int nb = (int)tri_keys_blocks(E, tg);
-#define SC_LAUNCH_KEYS(TGV) hipLaunchKernelGGL(tri_keys_kernel<TGV>, dim3(nb), dim3(256), 0, st, g.bits, mbits, smin, g.W, g.deg, g.wpre, ebase, ei, ej, es, toff, E, rank_mode, wkey, blk_minmax, blk_minmax + TK_MAX_BLOCKS)
+#define SC_LAUNCH_KEYS(TGV) hipLaunchKernelGGL(tri_keys_kernel<TGV>, dim3(nb), dim3(256), 0, st, g.bits, mbits, smin, g.W, g.deg, g.wpre, ebase, ei, ej, es, toff, E, rank_mode, wkey, kcol, blk_minmax, blk_minmax + TK_MAX_BLOCKS)
   if (tg == 4) SC_LAUNCH_KEYS(4); else if (tg == 8) SC_LAUNCH_KEYS(8); else if (tg == 32) SC_LAUNCH_KEYS(32); else if (tg == 64) SC_LAUNCH_KEYS(64); else SC_LAUNCH_KEYS(16);
 #undef SC_LAUNCH_KEYS
   hipLaunchKernelGGL(key_range_kernel, dim3(1), dim3(1024), 0, st, blk_minmax, blk_minmax + TK_MAX_BLOCKS, nb, s, want);
@@ -460,6 +462,7 @@ __global__ __launch_bounds__(256) void tri_keys_events_kernel(const uint64_t* __
                                                               const float* __restrict__ es,
                                                               const uint64_t* __restrict__ toff, int rank_mode,
                                                               EventList ev, uint32_t* __restrict__ wkey,
+                                                              uint32_t* __restrict__ kcol,
                                                               uint32_t* __restrict__ blk_min,
                                                               uint32_t* __restrict__ blk_max) {
   __shared__ uint32_t lmin[4], lmax[4];
@@ -484,6 +487,7 @@ __global__ __launch_bounds__(256) void tri_keys_events_kernel(const uint64_t* __
       uint64_t m = ev.m[o];
       const uint32_t wi = ev.wi[o], wj = ev.wj[o], fa = ev.a[o], e = ev.e[o];
       uint64_t out = toff[e] + ev.rb[o];
+      const uint32_t kbase = (uint32_t)(wi % (uint32_t)ev.W) * 64u;  // column index of bit 0 of this word
       if (rank_mode == 0) {
         const uint32_t fb = ev.b[o];
         const uint64_t fi = bits[wi], fj = bits[wj];  // full-graph words: ranks in the CSR edge arrays
@@ -504,6 +508,7 @@ __global__ __launch_bounds__(256) void tri_keys_events_kernel(const uint64_t* __
           for (int q = 0; q < 4; q++) {
             if (q < nbits) {
               const uint32_t key = __float_as_uint((s_ij + s_ik[q]) + s_jk[q]);
+              kcol[out] = kbase + (uint32_t)b[q];
               wkey[out++] = key;
               kmin = min(kmin, key);
               kmax = max(kmax, key);
@@ -511,11 +516,11 @@ __global__ __launch_bounds__(256) void tri_keys_events_kernel(const uint64_t* __
           }
         }
       } else {
-        const uint32_t kbase = (uint32_t)(wi % (uint32_t)ev.W) * 64u;  // column index of bit 0 of this word
         while (m) {
           const int b = __builtin_ctzll(m);
           m &= m - 1;
           const uint32_t key = fa + deg[kbase + b];
+          kcol[out] = kbase + (uint32_t)b;
           wkey[out++] = key;
           kmin = min(kmin, key);
           kmax = max(kmax, key);
@@ -538,7 +543,7 @@ __global__ __launch_bounds__(256) void tri_keys_events_kernel(const uint64_t* __
 
 size_t event_bytes(uint64_t capacity) { return (size_t)capacity * 32 + EV_SHARDS * 4 + 64; }
 
-EventList event_list(void* buf, uint64_t capacity, int W, uint32_t* overflow_host) {
+EventList event_list(void* buf, uint64_t capacity, int W, uint32_t* fill, uint32_t* overflow_host) {
   EventList ev;
   const uint64_t cap = capacity / EV_SHARDS * EV_SHARDS;
   unsigned char* p = static_cast<unsigned char*>(buf);
@@ -549,7 +554,7 @@ EventList event_list(void* buf, uint64_t capacity, int W, uint32_t* overflow_hos
   ev.b = reinterpret_cast<uint32_t*>(p); p += cap * 4;
   ev.e = reinterpret_cast<uint32_t*>(p); p += cap * 4;
   ev.rb = reinterpret_cast<uint32_t*>(p); p += cap * 4;
-  ev.fill = reinterpret_cast<uint32_t*>(p);
+  ev.fill = fill;  // EV_SHARDS zeroed counters (control block)
   ev.shard_cap = cap / EV_SHARDS;
   ev.overflow = overflow_host;
   ev.W = W;
@@ -560,7 +565,6 @@ void launch_tri_count_events(const Graph& g, const uint64_t* mbits, const float*
                              const uint32_t* ebj, const uint32_t* ei, const uint32_t* ej, const float* es, uint64_t E, int rank_mode,
                              uint32_t* tcnt, const EventList& ev, hipStream_t st) {
   if (E == 0) return;
-  (void)hipMemsetAsync(ev.fill, 0, EV_SHARDS * sizeof(uint32_t), st);
   constexpr int TGV = 8;
   const uint64_t per = 256 / TGV;
   uint64_t nb = (E + per - 1) / per;
@@ -570,11 +574,11 @@ void launch_tri_count_events(const Graph& g, const uint64_t* mbits, const float*
 }
 
 void launch_tri_keys_events(const Graph& g, const float* es, const uint64_t* toff, int rank_mode,
-                            const EventList& ev, uint32_t* wkey, uint32_t* blk_minmax, SelectState* s,
-                            uint64_t want, hipStream_t st) {
+                            const EventList& ev, uint32_t* wkey, uint32_t* kcol, uint32_t* blk_minmax,
+                            SelectState* s, uint64_t want, hipStream_t st) {
   const int nb = 2048;
   hipLaunchKernelGGL(tri_keys_events_kernel, dim3(nb), dim3(256), 0, st, g.bits, g.wpre, g.deg, es, toff, rank_mode,
-                     ev, wkey, blk_minmax, blk_minmax + TK_MAX_BLOCKS);
+                     ev, wkey, kcol, blk_minmax, blk_minmax + TK_MAX_BLOCKS);
   hipLaunchKernelGGL(key_range_kernel, dim3(1), dim3(1024), 0, st, blk_minmax, blk_minmax + TK_MAX_BLOCKS, nb, s, want);
 }
 
@@ -966,48 +970,47 @@ void launch_compact_write(const uint32_t* wkey, uint64_t M, const SelectState* s
 //    The list stays in ORDINAL order ((i,j,k) ascending): neighbouring threads hit neighbouring edges, and the hot
 //    path never needs the ranked order (see score_argmax_kernel).  launch_rank_order produces it for the stage hook.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void tri_decode_kernel(const uint64_t* __restrict__ bits, int W,
-                                                         const uint32_t* __restrict__ ei,
+constexpr int DEC_COARSE = 4096;  // coarse index entries staged in LDS (32 KiB)
+
+// cshift: the coarse index holds toff[k << cshift], k = 0 .. nc-1 (nc <= DEC_COARSE): the binary search for the edge
+// of an ordinal runs ~12 steps in LDS and only cshift steps in global memory.
+__global__ __launch_bounds__(256) void tri_decode_kernel(const uint32_t* __restrict__ ei,
                                                          const uint32_t* __restrict__ ej,
-                                                         const uint64_t* __restrict__ toff, uint64_t E,
+                                                         const uint32_t* __restrict__ kcol,
+                                                         const uint64_t* __restrict__ toff, uint64_t E, int cshift,
                                                          const uint64_t* __restrict__ sel_ord, uint32_t T,
                                                          uint32_t* __restrict__ tri) {
+  __shared__ uint64_t coarse[DEC_COARSE];
+  const uint32_t nc = (uint32_t)(((E + 1) + ((1ull << cshift) - 1)) >> cshift);  // entries k with (k << cshift) <= E
+  for (uint32_t k = threadIdx.x; k < nc; k += 256) coarse[k] = toff[(uint64_t)k << cshift];
+  __syncthreads();
   const uint32_t t = blockIdx.x * 256 + threadIdx.x;
   if (t >= T) return;
   const uint64_t ord = sel_ord[t];
-  // largest e with toff[e] <= ord  (toff has E+1 entries, toff[E] = M > ord)
-  uint64_t lo = 0, hi = E;
+  const uint32_t k3 = kcol[ord];  // the third vertex was stored at the ordinal by the key kernel: no row walk here
+  // largest k with coarse[k] <= ord
+  uint32_t klo = 0, khi = nc;
+  while (khi - klo > 1) {
+    const uint32_t mid = (klo + khi) >> 1;
+    if (coarse[mid] <= ord) klo = mid; else khi = mid;
+  }
+  // largest e in [klo << cshift, ...) with toff[e] <= ord  (toff has E+1 entries, toff[E] = M > ord)
+  uint64_t lo = (uint64_t)klo << cshift, hi = min(((uint64_t)klo + 1) << cshift, E);
   while (hi - lo > 1) {
     const uint64_t mid = (lo + hi) >> 1;
     if (toff[mid] <= ord) lo = mid; else hi = mid;
   }
-  const uint64_t e = lo;
-  uint32_t r = (uint32_t)(ord - toff[e]);
-  const uint32_t i = ei[e], j = ej[e];
-  const uint64_t* ri = bits + (size_t)i * W;
-  const uint64_t* rj = bits + (size_t)j * W;
-  uint32_t k = 0xFFFFFFFFu;
-  for (int w = j >> 6; w < W; w++) {
-    uint64_t m = ri[w] & rj[w];
-    if (w == (int)(j >> 6)) m &= mask_above(j & 63);
-    const uint32_t c = (uint32_t)__popcll(m);
-    if (r < c) {
-      for (uint32_t q = 0; q < r; q++) m &= m - 1;
-      k = (uint32_t)(w * 64 + __builtin_ctzll(m));
-      break;
-    }
-    r -= c;
-  }
-  tri[3 * (size_t)t] = i;
-  tri[3 * (size_t)t + 1] = j;
-  tri[3 * (size_t)t + 2] = k;
+  tri[3 * (size_t)t] = ei[lo];
+  tri[3 * (size_t)t + 1] = ej[lo];
+  tri[3 * (size_t)t + 2] = k3;
 }
 
-void launch_tri_decode(const Graph& g, const uint64_t* mbits, const uint32_t* ei, const uint32_t* ej,
-                       const uint64_t* toff, uint64_t E, const uint64_t* sel_ord, uint32_t T, uint32_t* tri,
-                       hipStream_t st) {
+void launch_tri_decode(const uint32_t* ei, const uint32_t* ej, const uint32_t* kcol, const uint64_t* toff, uint64_t E,
+                       const uint64_t* sel_ord, uint32_t T, uint32_t* tri, hipStream_t st) {
   if (T == 0) return;
-  hipLaunchKernelGGL(tri_decode_kernel, dim3((T + 255) / 256), dim3(256), 0, st, mbits, g.W, ei, ej, toff, E, sel_ord,
+  int cshift = 0;
+  while ((((E + 1) + ((1ull << cshift) - 1)) >> cshift) > (uint64_t)DEC_COARSE) cshift++;
+  hipLaunchKernelGGL(tri_decode_kernel, dim3((T + 255) / 256), dim3(256), 0, st, ei, ej, kcol, toff, E, cshift, sel_ord,
                      T, tri);
 }
 
