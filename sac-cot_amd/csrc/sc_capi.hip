@@ -230,6 +230,10 @@ int run_triangles(sc_ctx* c, const sc_params* p) {
   const bool use_events = prune && g.W <= 128 && getenv("SC_NO_EVENTS") == nullptr;
   EventList ev{};
   if (use_events) {
+    if (const char* capenv = getenv("SC_EVENT_CAP")) {  // test knob: force a (too) small event buffer
+      const uint64_t forced = (uint64_t)atoll(capenv);
+      if (forced >= 256) c->ev_capacity = forced;
+    }
     ENSURE(c, c->events, event_bytes(c->ev_capacity));
     c->pinned[5] = 0;
     ev = event_list(c->events.p, c->ev_capacity, g.W, c->ctl.as<ControlBlock>()->ev_fill,

@@ -301,3 +301,25 @@ def test_register_C3_twenty_thousand_correspondences(pkg, O, reg):
     assert pkg.synth.rotation_error_deg(got["R"], scene.R_gt) < 1.0
     m = got["mask"].astype(bool)
     assert (m & scene.inlier).sum() >= 0.95 * scene.inlier.sum()
+
+
+def test_event_buffer_overflow_falls_back_to_row_walk(pkg, O, monkeypatch):
+    """Stage B's event list has a fixed capacity per call; when a region overflows, the call must fall back to the
+    row-walking key kernel (and grow the buffer for next time) with identical results.  SC_EVENT_CAP forces a buffer
+    far too small for C1/C2; SC_NO_EVENTS=1 disables the event path altogether."""
+    cfg, scene = pkg.synth.make_config_scene("C2")
+    ref = O.register(scene.src, scene.tgt, threads=8, **cfg.params())
+    for env in ({"SC_EVENT_CAP": "4096"}, {"SC_NO_EVENTS": "1"}):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        r = pkg.Registrar(0)   # fresh context: default capacities
+        try:
+            for _ in range(2):  # second call runs with the capacity the first one asked for (knob still forces it small)
+                got = r.register(scene.src, scene.tgt, flags=pkg.SC_FLAG_EXACT_TOTAL, **cfg.params())
+                assert got["status"] == 0 and got["stats"]["best_rank"] == ref["best_rank"]
+                assert np.array_equal(got["mask"], ref["mask"]) and nan_equal_bits(got["R"], ref["R"]) and nan_equal_bits(got["t"], ref["t"])
+                assert got["stats"]["tri_total"] == ref["tri_total"]
+        finally:
+            r.close()
+        for k in env:
+            monkeypatch.delenv(k)
