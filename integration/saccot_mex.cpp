@@ -1,0 +1,48 @@
+// saccot_mex.cpp — MATLAB mex gateway for libsaccot.so.
+//
+// UNTESTED: MATLAB / Octave / mex are not installed in the build image, and the upstream repository ships no MATLAB
+// code to plug it into (/root/reference/README.md:1-2 is the whole tree).  It is the binding BASELINE.json's north star
+// describes ("MATLAB/C++ mex calling HIP through a thin C-ABI layer").
+//   build:  mex saccot_mex.cpp -I../include -L../sac-cot_amd -lsaccot
+//   use:    [R, t, inl] = saccot_mex(single(src), single(tgt), struct('sigma',0.1,'t_cmp',0.9,'tau',0.1,'min_len',0.1,'T',50000));
+//           src, tgt: N x 3 single (column-major = SC_SOA); R 3x3, t 3x1, inl N x 1 logical;  q ~ R p + t
+#include <cstring>
+
+#include "mex.h"
+#include "saccot.h"
+static sc_ctx* g_ctx = nullptr;
+static void at_exit() { sc_destroy(g_ctx); g_ctx = nullptr; }
+
+static float fieldf(const mxArray* s, const char* name, float dflt) {
+  const mxArray* f = mxGetField(s, 0, name);
+  return f ? (float)mxGetScalar(f) : dflt;
+}
+
+void mexFunction(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
+  if (nrhs < 2 || !mxIsSingle(prhs[0]) || !mxIsSingle(prhs[1]) || mxGetN(prhs[0]) != 3 || mxGetN(prhs[1]) != 3 ||
+      mxGetM(prhs[0]) != mxGetM(prhs[1]))
+    mexErrMsgIdAndTxt("saccot:args", "src and tgt must be N x 3 single");
+  if (!g_ctx) {
+    if (sc_create(0, &g_ctx) != SC_OK) mexErrMsgIdAndTxt("saccot:gpu", "no usable HIP device");
+    mexAtExit(at_exit);
+  }
+  sc_params p; sc_default_params(&p);
+  p.layout = SC_SOA;                                   // MATLAB N x 3 is three planes of N
+  if (nrhs > 2) {
+    p.sigma = fieldf(prhs[2], "sigma", p.sigma);   p.t_cmp = fieldf(prhs[2], "t_cmp", p.t_cmp);
+    p.tau = fieldf(prhs[2], "tau", p.tau);         p.min_len = fieldf(prhs[2], "min_len", p.min_len);
+    p.max_triangles = (uint32_t)fieldf(prhs[2], "T", (float)p.max_triangles);
+  }
+  const int64_t n = (int64_t)mxGetM(prhs[0]);
+  float R[9], t[3];
+  plhs[2 < nlhs ? 2 : 0] = nullptr;
+  mxArray* inl = mxCreateLogicalMatrix(n, 1);          // mxLogical is 1 byte: written in place
+  int rc = sc_register(g_ctx, (const float*)mxGetData(prhs[0]), (const float*)mxGetData(prhs[1]), n, &p, R, t,
+                       (uint8_t*)mxGetLogicals(inl), nullptr);
+  if (rc != SC_OK && rc != SC_ENOHYP) mexErrMsgIdAndTxt("saccot:run", "%s: %s", sc_strerror(rc), sc_last_error(g_ctx));
+  plhs[0] = mxCreateNumericMatrix(3, 3, mxSINGLE_CLASS, mxREAL);
+  float* Rm = (float*)mxGetData(plhs[0]);
+  for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) Rm[c * 3 + r] = R[r * 3 + c];   // row-major -> column-major
+  if (nlhs > 1) { plhs[1] = mxCreateNumericMatrix(3, 1, mxSINGLE_CLASS, mxREAL); memcpy(mxGetData(plhs[1]), t, 12); }
+  if (nlhs > 2) plhs[2] = inl; else mxDestroyArray(inl);
+}
