@@ -57,6 +57,8 @@ extern "C" {
 #define SC_FLAG_TIMING       1u /* record a HIP event pair around every stage and fill sc_stats.us_*          */
 #define SC_FLAG_EXACT_TOTAL  2u /* sc_stats.tri_total = 3-cliques of the WHOLE graph (one extra counting pass);  */
                                 /* default: 3-cliques of the pruned graph the top-T search actually enumerated   */
+#define SC_FLAG_REFINE       8u /* after C3, replace (R,t) by the fp64 least-squares refit over the winner's inlier  */
+                                /* mask; the mask itself stays the fp32 winner's                   */
 #define SC_FLAG_NO_PRUNE     4u /* disable the certified pruning of stage B (results are identical either way)    */
 
 typedef struct sc_ctx sc_ctx;

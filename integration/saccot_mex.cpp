@@ -35,7 +35,6 @@ void mexFunction(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
   }
   const int64_t n = (int64_t)mxGetM(prhs[0]);
   float R[9], t[3];
-  plhs[2 < nlhs ? 2 : 0] = nullptr;
   mxArray* inl = mxCreateLogicalMatrix(n, 1);          // mxLogical is 1 byte: written in place
   int rc = sc_register(g_ctx, (const float*)mxGetData(prhs[0]), (const float*)mxGetData(prhs[1]), n, &p, R, t,
                        (uint8_t*)mxGetLogicals(inl), nullptr);

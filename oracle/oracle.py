@@ -45,6 +45,7 @@ def lib() -> C.CDLL:
         L.so_mask.restype = None
         L.so_register.argtypes = [f32p, f32p, C.c_int64, C.c_float, C.c_float, C.c_float, C.c_float, C.c_uint32,
                                   C.c_int, C.c_int, f32p, f32p, u8p, u64p, f64p]
+        L.so_refine.argtypes = [f32p, f32p, C.c_int64, u8p, f32p]
         L.so_max_threads.restype = C.c_int
         _LIB = L
     return _LIB
@@ -157,3 +158,13 @@ def register(src: np.ndarray, tgt: np.ndarray, sigma: float, t_cmp: float, tau: 
                            _p(st, C.c_uint64), _p(ss, C.c_double))
     return dict(rc=rc, R=R.reshape(3, 3), t=t, mask=m, edges=int(st[0]), tri_total=int(st[1]), t_eff=int(st[2]),
                 best_rank=int(st[3]), best_count=int(st[4]), stage_s=ss)
+
+
+def refine(src: np.ndarray, tgt: np.ndarray, mask_: np.ndarray, Rt12: np.ndarray):
+    """fp64 least-squares refit over the inlier mask.  Returns (done, Rt12 float32)."""
+    n = src.shape[0]
+    Rt = np.ascontiguousarray(Rt12, dtype=np.float32).reshape(12).copy()
+    mk = np.ascontiguousarray(mask_, dtype=np.uint8)
+    ps, qs = soa(src), soa(tgt)
+    done = lib().so_refine(_p(ps, C.c_float), _p(qs, C.c_float), n, _p(mk, C.c_uint8), _p(Rt, C.c_float))
+    return bool(done), Rt

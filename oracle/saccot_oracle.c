@@ -357,6 +357,94 @@ void so_mask(const float* src, const float* tgt, int64_t n, const float* Rt, flo
 }
 
 /* ------------------------------------------------------------------------------------------------
+ * Winner refinement (optional): least-squares rigid refit over the inlier mask, in fp64.
+ * Canonical order (so that the GPU reproduces it bit for bit): points are visited in chunks of 64 consecutive
+ * indices; a chunk's masked sums are accumulated sequentially in index order; chunk sums are then added
+ * sequentially in chunk order.  Pass 1: count, sum p, sum q -> centroids (division).  Pass 2:
+ * H[r][c] = sum fma(a_r, b_c, H[r][c]) with a = p - pc, b = q - qc.  Then the same two-dominant-pairs +
+ * cross-product construction as so_kabsch3_one, on H, in double, 10 Jacobi sweeps.  Fewer than 3 inliers or a
+ * non-finite result leaves Rt untouched (returns 0); otherwise Rt is overwritten with the fp32-rounded refit.
+ * ---------------------------------------------------------------------------------------------- */
+#define SO_REFINE_SWEEPS 10
+static inline double ddot3(const double* a, const double* b) { return fma(a[2], b[2], fma(a[1], b[1], a[0] * b[0])); }
+static inline void dcross3(const double* a, const double* b, double* c) {
+  c[0] = fma(a[1], b[2], -(a[2] * b[1]));
+  c[1] = fma(a[2], b[0], -(a[0] * b[2]));
+  c[2] = fma(a[0], b[1], -(a[1] * b[0]));
+}
+
+int so_refine(const float* src, const float* tgt, int64_t n, const uint8_t* mask, float* Rt) {
+  const int64_t nch = (n + 63) / 64;
+  double S[7] = {0, 0, 0, 0, 0, 0, 0}; /* count, sum p (3), sum q (3) */
+  for (int64_t ch = 0; ch < nch; ch++) {
+    double c[7] = {0, 0, 0, 0, 0, 0, 0};
+    for (int64_t m = ch * 64; m < n && m < ch * 64 + 64; m++) {
+      if (!mask[m]) continue;
+      c[0] += 1.0;
+      for (int k = 0; k < 3; k++) { c[1 + k] += (double)src[k * n + m]; c[4 + k] += (double)tgt[k * n + m]; }
+    }
+    for (int k = 0; k < 7; k++) S[k] += c[k];
+  }
+  if (S[0] < 3.0) return 0;
+  double pc[3], qc[3];
+  for (int k = 0; k < 3; k++) { pc[k] = S[1 + k] / S[0]; qc[k] = S[4 + k] / S[0]; }
+  double H[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
+  for (int64_t ch = 0; ch < nch; ch++) {
+    double h[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
+    for (int64_t m = ch * 64; m < n && m < ch * 64 + 64; m++) {
+      if (!mask[m]) continue;
+      double a[3], b[3];
+      for (int k = 0; k < 3; k++) { a[k] = (double)src[k * n + m] - pc[k]; b[k] = (double)tgt[k * n + m] - qc[k]; }
+      for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) h[r][c] = fma(a[r], b[c], h[r][c]);
+    }
+    for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) H[r][c] += h[r][c];
+  }
+  /* columns of H: B[col][row] */
+  double B[3][3], V[3][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}};
+  for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) B[c][r] = H[r][c];
+  static const int PAIRS[3][2] = {{0, 1}, {0, 2}, {1, 2}};
+  for (int sweep = 0; sweep < SO_REFINE_SWEEPS; sweep++) {
+    for (int pr = 0; pr < 3; pr++) {
+      double *bp = B[PAIRS[pr][0]], *bq = B[PAIRS[pr][1]], *vp = V[PAIRS[pr][0]], *vq = V[PAIRS[pr][1]];
+      double alpha = ddot3(bp, bp), beta = ddot3(bq, bq), gamma = ddot3(bp, bq);
+      if (gamma == 0.0) continue;
+      double zeta = (beta - alpha) / (gamma + gamma);
+      double tt = 1.0 / (fabs(zeta) + sqrt(fma(zeta, zeta, 1.0)));
+      if (zeta < 0.0) tt = -tt;
+      double cs = 1.0 / sqrt(fma(tt, tt, 1.0));
+      double sn = cs * tt;
+      for (int r = 0; r < 3; r++) {
+        double x = bp[r], y = bq[r];
+        bp[r] = fma(-sn, y, cs * x); bq[r] = fma(sn, x, cs * y);
+        x = vp[r]; y = vq[r];
+        vp[r] = fma(-sn, y, cs * x); vq[r] = fma(sn, x, cs * y);
+      }
+    }
+  }
+  double nrm[3] = {ddot3(B[0], B[0]), ddot3(B[1], B[1]), ddot3(B[2], B[2])};
+  int i1 = 0;
+  if (nrm[1] > nrm[i1]) i1 = 1;
+  if (nrm[2] > nrm[i1]) i1 = 2;
+  int i2 = (i1 == 0) ? 1 : 0;
+  { const int c = 3 - i1 - i2; if (nrm[c] > nrm[i2]) i2 = c; }
+  double s1 = sqrt(nrm[i1]), s2 = sqrt(nrm[i2]);
+  double u1[3], u2[3], u3[3], v3[3];
+  for (int r = 0; r < 3; r++) { u1[r] = B[i1][r] / s1; u2[r] = B[i2][r] / s2; }
+  const double *v1 = V[i1], *v2 = V[i2];
+  dcross3(u1, u2, u3);
+  dcross3(v1, v2, v3);
+  double R[9], t[3];
+  for (int r = 0; r < 3; r++)
+    for (int c = 0; c < 3; c++) R[3 * r + c] = fma(v3[r], u3[c], fma(v2[r], u2[c], v1[r] * u1[c]));
+  for (int r = 0; r < 3; r++) t[r] = qc[r] - fma(R[3 * r + 2], pc[2], fma(R[3 * r + 1], pc[1], R[3 * r] * pc[0]));
+  for (int k = 0; k < 9; k++) if (!isfinite(R[k])) return 0;
+  for (int k = 0; k < 3; k++) if (!isfinite(t[k])) return 0;
+  for (int k = 0; k < 9; k++) Rt[k] = (float)R[k];
+  for (int k = 0; k < 3; k++) Rt[9 + k] = (float)t[k];
+  return 1;
+}
+
+/* ------------------------------------------------------------------------------------------------
  * Whole path (SoA input).  stats[0]=edges stats[1]=tri_total stats[2]=t_eff stats[3]=best_rank
  * stats[4]=best_count.  stage_s (may be NULL): seconds for A, B, C1, C2, C3.
  * ---------------------------------------------------------------------------------------------- */

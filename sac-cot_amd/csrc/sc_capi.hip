@@ -44,7 +44,7 @@ struct sc_ctx {
   // workspace
   Buf in_src, in_tgt, planes, S, bits, deg, degp, wpre, ebase, edge_off, scan_tmp, ei, ej, es, ebi, ebj, tcnt, toff, wkey, kcol, ctl, events, blk_gt,
       blk_eq, blk_minmax, bits2, off_gt, off_eq, sel_ord, sel_key, sortkey, sorted, sort_tmp, tri, tri_rk, key_rk, rt, rt_aos, partial, cnt, key, rt12,
-      mask;
+      mask, refine_tmp;
 
   // state of the last hypothesize call (consumed by finalize)
   int n = 0, ld = 0;
@@ -57,6 +57,7 @@ struct sc_ctx {
   bool have_hyp = false;
   bool timing = false;
   bool timed_trikeys = false;
+  bool refine = false;
   const uint64_t* mbits = nullptr;
   const float* smin_ptr = nullptr;
 };
@@ -393,7 +394,7 @@ void sc_destroy(sc_ctx* c) {
   Buf* bufs[] = {&c->in_src, &c->in_tgt, &c->planes, &c->S, &c->bits, &c->deg, &c->degp, &c->wpre, &c->ebase, &c->edge_off, &c->scan_tmp,
                  &c->ei, &c->ej, &c->es, &c->ebi, &c->ebj, &c->tcnt, &c->toff, &c->wkey, &c->kcol, &c->ctl, &c->events, &c->blk_gt, &c->blk_eq, &c->blk_minmax, &c->bits2, &c->off_gt,
                  &c->off_eq, &c->sel_ord, &c->sel_key, &c->sortkey, &c->sorted, &c->sort_tmp, &c->tri, &c->tri_rk, &c->key_rk, &c->rt,
-                 &c->rt_aos, &c->partial, &c->cnt, &c->key, &c->rt12, &c->mask};
+                 &c->rt_aos, &c->partial, &c->cnt, &c->key, &c->rt12, &c->mask, &c->refine_tmp};
   for (Buf* b : bufs) if (b->p) (void)hipFree(b->p);
   for (int i = 0; i < N_EVENTS; i++) if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
   if (c->pinned) (void)hipHostFree(c->pinned);
@@ -420,6 +421,7 @@ int sc_hypothesize_device(sc_ctx* c, const float* d_src, const float* d_tgt, int
   c->have_hyp = false;
   c->timed_trikeys = false;
   c->timing = (p->flags & SC_FLAG_TIMING) != 0;
+  c->refine = (p->flags & SC_FLAG_REFINE) != 0;
   c->cap_bytes = p->max_workspace ? p->max_workspace : (64ull << 30);
   c->dv = derive(p);
   if ((rc = rec(c, 0))) return rc;
@@ -480,6 +482,10 @@ int sc_finalize_device(sc_ctx* c, const uint64_t* d_key, float* d_Rt, uint8_t* d
   if ((rc = rec(c, 7))) return rc;
   launch_finalize(points_of(c), c->tri.as<uint32_t>(), c->T_eff ? c->sel_key.as<uint32_t>() : nullptr, c->T_eff, d_key,
                   c->dv.tau2, d_Rt, d_mask, &c->pinned[8], c->stream);
+  if (c->refine) {  // fp64 least-squares refit over the winner's inliers (mask unchanged)
+    ENSURE(c, c->refine_tmp, refine_scratch_bytes(c->n));
+    launch_refine(points_of(c), d_mask, d_key, c->refine_tmp.as<double>(), d_Rt, c->stream);
+  }
   if ((rc = rec(c, 8))) return rc;
   HIPCHK(c, hipStreamSynchronize(c->stream));  // the winner kernel wrote key / position / rank to pinned memory
   HIPCHK(c, hipGetLastError());

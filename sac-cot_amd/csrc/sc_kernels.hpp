@@ -181,6 +181,11 @@ void launch_argmax(const Points& pts, const Shard& sh, const uint32_t* partial, 
 void launch_finalize(const Points& pts, const uint32_t* tri, const uint32_t* sel_key, uint32_t T,
                      const uint64_t* key2, float tau2, float* Rt12, uint8_t* mask, uint64_t* host_out,
                      hipStream_t st);
+// SURVEY §8f-2 (SC_FLAG_REFINE): fp64 least-squares refit of Rt12 over the inlier mask; no-op when key2[0] == 0 or
+// fewer than 3 inliers.  scratch: refine_scratch_bytes(n).
+size_t refine_scratch_bytes(int n);
+void launch_refine(const Points& pts, const uint8_t* mask, const uint64_t* key2, double* scratch, float* Rt12,
+                   hipStream_t st);
 // mask of an explicit hypothesis (stage hook)
 void launch_mask(const Points& pts, const float* Rt12, float tau2, uint8_t* mask, hipStream_t st);
 

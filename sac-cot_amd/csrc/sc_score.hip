@@ -442,6 +442,164 @@ void launch_finalize(const Points& pts, const uint32_t* tri, const uint32_t* sel
                      reinterpret_cast<const unsigned long long*>(key2), tau2, mask);
 }
 
+// ------------------------------------------------------------------------------------------------
+// Winner refinement (optional — SC_FLAG_REFINE): fp64 least-squares rigid refit over the inlier mask.
+// Canonical order shared with oracle/saccot_oracle.c::so_refine: chunks of 64 consecutive points are summed
+// sequentially in index order (one thread per chunk), chunk sums are added sequentially in chunk order (thread 0);
+// pass 1 gives count and centroids, pass 2 H = sum (p - pc)(q - qc)^T by fma, then the two-dominant-pairs +
+// cross-product construction of kabsch3 in double with 10 Jacobi sweeps.  One workgroup: N is a few thousand.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ double ddot3(const double* a, const double* b) {
+  return __builtin_fma(a[2], b[2], __builtin_fma(a[1], b[1], a[0] * b[0]));
+}
+__device__ __forceinline__ void dcross3(const double* a, const double* b, double* c) {
+  c[0] = __builtin_fma(a[1], b[2], -(a[2] * b[1]));
+  c[1] = __builtin_fma(a[2], b[0], -(a[0] * b[2]));
+  c[2] = __builtin_fma(a[0], b[1], -(a[1] * b[0]));
+}
+
+__global__ __launch_bounds__(1024) void refine_kernel(const float* __restrict__ planes, int n, int ld,
+                                                      const uint8_t* __restrict__ mask,
+                                                      const unsigned long long* __restrict__ key2,
+                                                      double* __restrict__ scratch, float* __restrict__ Rt12) {
+  __shared__ double cen[8];
+  if (key2[0] == 0ull) return;  // no hypothesis: nothing to refine (uniform)
+  const int nch = (n + 63) / 64;
+  // pass 1: per-chunk count / sum p / sum q
+  for (int ch = threadIdx.x; ch < nch; ch += 1024) {
+    double c[7] = {0, 0, 0, 0, 0, 0, 0};
+    const int m1 = min(n, ch * 64 + 64);
+    for (int m = ch * 64; m < m1; m++) {
+      if (!mask[m]) continue;
+      c[0] += 1.0;
+#pragma unroll
+      for (int k = 0; k < 3; k++) { c[1 + k] += (double)planes[(size_t)k * ld + m]; c[4 + k] += (double)planes[(size_t)(3 + k) * ld + m]; }
+    }
+#pragma unroll
+    for (int k = 0; k < 7; k++) scratch[(size_t)ch * 16 + k] = c[k];
+  }
+  __threadfence_block();
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double S[7] = {0, 0, 0, 0, 0, 0, 0};
+    for (int ch = 0; ch < nch; ch++)
+#pragma unroll
+      for (int k = 0; k < 7; k++) S[k] += scratch[(size_t)ch * 16 + k];
+    cen[0] = S[0];
+#pragma unroll
+    for (int k = 0; k < 3; k++) { cen[1 + k] = S[1 + k] / S[0]; cen[4 + k] = S[4 + k] / S[0]; }
+  }
+  __syncthreads();
+  if (cen[0] < 3.0) return;  // uniform
+  const double pc[3] = {cen[1], cen[2], cen[3]}, qc[3] = {cen[4], cen[5], cen[6]};
+  // pass 2: per-chunk covariance
+  for (int ch = threadIdx.x; ch < nch; ch += 1024) {
+    double h[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    const int m1 = min(n, ch * 64 + 64);
+    for (int m = ch * 64; m < m1; m++) {
+      if (!mask[m]) continue;
+      double a[3], b[3];
+#pragma unroll
+      for (int k = 0; k < 3; k++) {
+        a[k] = (double)planes[(size_t)k * ld + m] - pc[k];
+        b[k] = (double)planes[(size_t)(3 + k) * ld + m] - qc[k];
+      }
+#pragma unroll
+      for (int r = 0; r < 3; r++)
+#pragma unroll
+        for (int c = 0; c < 3; c++) h[3 * r + c] = __builtin_fma(a[r], b[c], h[3 * r + c]);
+    }
+#pragma unroll
+    for (int k = 0; k < 9; k++) scratch[(size_t)ch * 16 + k] = h[k];
+  }
+  __threadfence_block();
+  __syncthreads();
+  if (threadIdx.x != 0) return;
+  double H[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+  for (int ch = 0; ch < nch; ch++)
+#pragma unroll
+    for (int k = 0; k < 9; k++) H[k] += scratch[(size_t)ch * 16 + k];
+  double B[3][3], V[3][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}};
+#pragma unroll
+  for (int r = 0; r < 3; r++)
+#pragma unroll
+    for (int c = 0; c < 3; c++) B[c][r] = H[3 * r + c];
+#pragma unroll 1
+  for (int sweep = 0; sweep < 10; sweep++) {
+#pragma unroll
+    for (int pr = 0; pr < 3; pr++) {
+      const int ip = (pr == 2) ? 1 : 0, iq = (pr == 0) ? 1 : 2;
+      const double alpha = ddot3(B[ip], B[ip]), beta = ddot3(B[iq], B[iq]), gamma = ddot3(B[ip], B[iq]);
+      if (gamma != 0.0) {
+        const double zeta = (beta - alpha) / (gamma + gamma);
+        double tt = 1.0 / (__builtin_fabs(zeta) + __builtin_sqrt(__builtin_fma(zeta, zeta, 1.0)));
+        if (zeta < 0.0) tt = -tt;
+        const double cs = 1.0 / __builtin_sqrt(__builtin_fma(tt, tt, 1.0));
+        const double sn = cs * tt;
+#pragma unroll
+        for (int r = 0; r < 3; r++) {
+          double x = B[ip][r], y = B[iq][r];
+          B[ip][r] = __builtin_fma(-sn, y, cs * x);
+          B[iq][r] = __builtin_fma(sn, x, cs * y);
+          x = V[ip][r]; y = V[iq][r];
+          V[ip][r] = __builtin_fma(-sn, y, cs * x);
+          V[iq][r] = __builtin_fma(sn, x, cs * y);
+        }
+      }
+    }
+  }
+  const double n0 = ddot3(B[0], B[0]), n1 = ddot3(B[1], B[1]), n2 = ddot3(B[2], B[2]);
+  int i1 = 0; double m1 = n0;
+  if (n1 > m1) { i1 = 1; m1 = n1; }
+  if (n2 > m1) { i1 = 2; m1 = n2; }
+  int i2 = (i1 == 0) ? 1 : 0;
+  {
+    const int c = 3 - i1 - i2;
+    const double nc = (c == 0) ? n0 : (c == 1 ? n1 : n2), ni2 = (i2 == 0) ? n0 : (i2 == 1 ? n1 : n2);
+    if (nc > ni2) i2 = c;
+  }
+  double b1[3], b2[3], v1[3], v2[3];
+#pragma unroll
+  for (int r = 0; r < 3; r++) {
+    b1[r] = (i1 == 0) ? B[0][r] : (i1 == 1 ? B[1][r] : B[2][r]);
+    b2[r] = (i2 == 0) ? B[0][r] : (i2 == 1 ? B[1][r] : B[2][r]);
+    v1[r] = (i1 == 0) ? V[0][r] : (i1 == 1 ? V[1][r] : V[2][r]);
+    v2[r] = (i2 == 0) ? V[0][r] : (i2 == 1 ? V[1][r] : V[2][r]);
+  }
+  const double s1 = __builtin_sqrt(ddot3(b1, b1)), s2 = __builtin_sqrt(ddot3(b2, b2));
+  double u1[3], u2[3], u3[3], v3[3];
+#pragma unroll
+  for (int r = 0; r < 3; r++) { u1[r] = b1[r] / s1; u2[r] = b2[r] / s2; }
+  dcross3(u1, u2, u3);
+  dcross3(v1, v2, v3);
+  double R[9], t[3];
+#pragma unroll
+  for (int r = 0; r < 3; r++)
+#pragma unroll
+    for (int c = 0; c < 3; c++) R[3 * r + c] = __builtin_fma(v3[r], u3[c], __builtin_fma(v2[r], u2[c], v1[r] * u1[c]));
+#pragma unroll
+  for (int r = 0; r < 3; r++)
+    t[r] = qc[r] - __builtin_fma(R[3 * r + 2], pc[2], __builtin_fma(R[3 * r + 1], pc[1], R[3 * r] * pc[0]));
+  bool ok = true;
+#pragma unroll
+  for (int k = 0; k < 9; k++) ok = ok && (__builtin_fabs(R[k]) < __builtin_inf());
+#pragma unroll
+  for (int k = 0; k < 3; k++) ok = ok && (__builtin_fabs(t[k]) < __builtin_inf());
+  if (!ok) return;
+#pragma unroll
+  for (int k = 0; k < 9; k++) Rt12[k] = (float)R[k];
+#pragma unroll
+  for (int k = 0; k < 3; k++) Rt12[9 + k] = (float)t[k];
+}
+
+size_t refine_scratch_bytes(int n) { return (size_t)((n + 63) / 64) * 16 * sizeof(double); }
+
+void launch_refine(const Points& pts, const uint8_t* mask, const uint64_t* key2, double* scratch, float* Rt12,
+                   hipStream_t st) {
+  hipLaunchKernelGGL(refine_kernel, dim3(1), dim3(1024), 0, st, pts.planes, pts.n, pts.ld, mask,
+                     reinterpret_cast<const unsigned long long*>(key2), scratch, Rt12);
+}
+
 void launch_mask(const Points& pts, const float* Rt12, float tau2, uint8_t* mask, hipStream_t st) {
   hipLaunchKernelGGL(mask_kernel, dim3((pts.n + 255) / 256), dim3(256), 0, st, pts.planes, pts.n, pts.ld, Rt12,
                      (const unsigned long long*)nullptr, tau2, mask);

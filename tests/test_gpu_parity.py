@@ -323,3 +323,20 @@ def test_event_buffer_overflow_falls_back_to_row_walk(pkg, O, monkeypatch):
             r.close()
         for k in env:
             monkeypatch.delenv(k)
+
+
+@pytest.mark.parametrize("name", ["C0", "C1", "C2"])
+def test_refine_matches_oracle_and_improves(pkg, O, reg, name):
+    """SURVEY §8f-2 (SC_FLAG_REFINE): the fp64 least-squares refit over the winner's inliers must equal the oracle's
+    (same chunked summation order) bit for bit after rounding to fp32, leave the mask alone, and not be worse than the
+    3-point hypothesis against the synthetic ground truth."""
+    cfg, scene = pkg.synth.make_config_scene(name)
+    base = reg.register(scene.src, scene.tgt, **cfg.params())
+    got = reg.register(scene.src, scene.tgt, flags=pkg.SC_FLAG_REFINE, **cfg.params())
+    assert np.array_equal(got["mask"], base["mask"]) and got["stats"]["best_rank"] == base["stats"]["best_rank"]
+    done, Rt0 = O.refine(scene.src, scene.tgt, base["mask"], np.concatenate([base["R"].ravel(), base["t"]]))
+    assert done
+    assert np.concatenate([got["R"].ravel(), got["t"]]).astype(np.float32).tobytes() == Rt0.tobytes()
+    e0 = pkg.synth.rotation_error_deg(base["R"], scene.R_gt); e1 = pkg.synth.rotation_error_deg(got["R"], scene.R_gt)
+    assert e1 <= e0 + 1e-3 and e1 < 0.5
+    assert np.linalg.norm(got["t"] - scene.t_gt) <= np.linalg.norm(base["t"] - scene.t_gt) + 1e-4

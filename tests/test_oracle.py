@@ -178,3 +178,17 @@ def test_errors_and_degenerate_inputs(pkg, O):
     assert r["rc"] == -5 and np.array_equal(r["R"], np.eye(3)) and not r["mask"].any()  # no triangle
     r = O.register(sc.src, sc.tgt, **dict(cfg.params(), max_triangles=10_000_000))
     assert r["rc"] == 0 and r["t_eff"] == r["tri_total"]                               # T > triangles -> T_eff
+
+
+def test_refine_against_lapack(pkg, O):
+    """so_refine (fp64 least-squares refit over the inlier mask) against numpy's SVD Kabsch."""
+    from oracle import saccot_fp64 as F
+    cfg, sc = pkg.synth.make_config_scene("C1")
+    r = O.register(sc.src, sc.tgt, threads=4, **cfg.params())
+    done, Rt = O.refine(sc.src, sc.tgt, r["mask"], np.concatenate([r["R"].ravel(), r["t"]]))
+    m = r["mask"].astype(bool)
+    R64, t64, _ = F.kabsch(sc.src[m], sc.tgt[m])
+    assert done and np.abs(Rt[:9].reshape(3, 3) - R64).max() < 2e-7 and np.abs(Rt[9:] - t64).max() < 2e-7
+    assert pkg.synth.rotation_error_deg(Rt[:9].reshape(3, 3), sc.R_gt) < pkg.synth.rotation_error_deg(r["R"], sc.R_gt)
+    none, Rt_same = O.refine(sc.src, sc.tgt, np.zeros(cfg.n, np.uint8), np.arange(12, dtype=np.float32))
+    assert not none and np.array_equal(Rt_same, np.arange(12, dtype=np.float32))     # < 3 inliers: untouched
