@@ -19,7 +19,12 @@ def pytest_configure(config):
 
 @pytest.fixture(scope="session")
 def pkg():
-    return ge.load_package()
+    """The product package.  The shared library is git-ignored, so a fresh checkout builds it first (hipcc
+    cross-compiles for gfx950 without a GPU; on the GPU box the prebuilt .so travels with the snapshot)."""
+    p = ge.load_package()
+    if not os.path.exists(p.api.LIB_PATH):
+        ge.build()
+    return p
 
 
 @pytest.fixture(scope="session")
