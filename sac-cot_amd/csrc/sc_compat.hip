@@ -274,17 +274,25 @@ __global__ __launch_bounds__(1024) void scan_small_kernel(const uint32_t* __rest
                                                           const uint32_t* __restrict__ in1, uint64_t* __restrict__ out1,
                                                           size_t n, uint64_t* __restrict__ host_total) {
   __shared__ uint64_t lds[16];
+  constexpr int PER = 8;  // consecutive elements per thread and pass: 8192 per pass, so a few passes at most
   const int arrays = in1 ? 2 : 1;
   for (int a = 0; a < arrays; a++) {
     const uint32_t* in = a ? in1 : in0;
     uint64_t* out = a ? out1 : out0;
     uint64_t carry = 0;
-    for (size_t b0 = 0; b0 < n; b0 += 1024) {
-      const size_t b = b0 + threadIdx.x;
-      const uint64_t v = b < n ? in[b] : 0;
+    for (size_t b0 = 0; b0 < n; b0 += 1024 * PER) {
+      const size_t base = b0 + (size_t)threadIdx.x * PER;
+      uint32_t v[PER];
+      uint64_t sum = 0;
+#pragma unroll
+      for (int k = 0; k < PER; k++) { v[k] = (base + k < n) ? in[base + k] : 0u; sum += v[k]; }
       uint64_t tot;
-      const uint64_t ex = block_exscan_u64(v, lds, &tot);
-      if (b < n) out[b] = carry + ex;
+      uint64_t run = carry + block_exscan_u64(sum, lds, &tot);
+#pragma unroll
+      for (int k = 0; k < PER; k++) {
+        if (base + k < n) out[base + k] = run;
+        run += v[k];
+      }
       carry += tot;
     }
     if (threadIdx.x == 0) {
