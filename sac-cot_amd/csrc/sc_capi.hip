@@ -202,7 +202,7 @@ int run_triangles(sc_ctx* c, const sc_params* p) {
   ENSURE(c, c->toff, (E + 1) * 8);
   ENSURE(c, c->scan_tmp, scan_temp_bytes(E));
   const Graph g = graph_of(c);
-  launch_edge_fill(g, c->edge_off.as<uint64_t>(), c->ei.as<uint32_t>(), c->ej.as<uint32_t>(), c->es.as<float>(),
+  launch_edge_fill(g, points_of(c), c->dv, c->edge_off.as<uint64_t>(), c->ei.as<uint32_t>(), c->ej.as<uint32_t>(), c->es.as<float>(),
                    c->ebase.as<uint32_t>(), c->ebi.as<uint32_t>(), c->ebj.as<uint32_t>(), st);
   // certified pruning (sc_tri.hip §3b): weight ranking only; pointless on tiny graphs
   const bool prune = may_prune(p) && E >= 4096;
@@ -227,8 +227,8 @@ int run_triangles(sc_ctx* c, const sc_params* p) {
   c->mbits = mbits;
   c->smin_ptr = smin;
   // counting pass + event list (sc_tri.hip 2b); SC_NO_EVENTS=1 keeps the row-walking pair for comparison
-  // (only for a pruned graph with moderately wide rows: see the kernel's header for why)
-  const bool use_events = prune && g.W <= 128 && getenv("SC_NO_EVENTS") == nullptr;
+  // (only for a pruned graph: the unpruned one has too many events to be worth recording)
+  const bool use_events = prune && getenv("SC_NO_EVENTS") == nullptr;
   EventList ev{};
   if (use_events) {
     if (const char* capenv = getenv("SC_EVENT_CAP")) {  // test knob: force a (too) small event buffer

@@ -58,8 +58,13 @@ __device__ __forceinline__ int pop4(uint64_t& m, int b[4]) {
 // ------------------------------------------------------------------------------------------------
 // 1. edge_fill: one wave per row
 // ------------------------------------------------------------------------------------------------
+// The edge weight is RECOMPUTED from the two correspondences with stage A's own chain (pair_weight over dist3: the
+// same correctly rounded operations on the same operands give the same bits; the squares make the argument order
+// irrelevant) instead of being gathered from S: a gather moves a 64-byte sector of the n x n matrix for 4 useful
+// bytes (C3: 215 us), the recomputation is ~80 VALU operations on points that sit in L2.
 __global__ __launch_bounds__(256) void edge_fill_kernel(const uint64_t* __restrict__ bits,
-                                                        const float* __restrict__ S, int n, int ld, int W,
+                                                        const float* __restrict__ planes, Derived dv,
+                                                        int n, int ld, int W,
                                                         const uint64_t* __restrict__ edge_off,
                                                         uint32_t* __restrict__ ei, uint32_t* __restrict__ ej,
                                                         float* __restrict__ es,
@@ -67,14 +72,18 @@ __global__ __launch_bounds__(256) void edge_fill_kernel(const uint64_t* __restri
                                                         const uint32_t* __restrict__ degp,
                                                         uint32_t* __restrict__ ebase, uint32_t* __restrict__ ebi,
                                                         uint32_t* __restrict__ ebj) {
-  const int lane = threadIdx.x & 63;
-  const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (i >= n) return;
+  constexpr int CH = 512;  // column indices staged per wave and chunk
+  __shared__ uint32_t l_j[4][CH];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int i = blockIdx.x * 4 + wave;
+  if (i >= n) return;  // whole waves leave: there is no workgroup barrier below
   uint64_t base = edge_off[i];
   // (# bits of row i at or below i) = deg - deg+; modular u32 arithmetic (edge indices are < 2^32)
   const uint32_t my_base = (uint32_t)base - (deg[i] - degp[i]);
   if (lane == 0) ebase[i] = my_base;
   const int w0 = i >> 6;
+  const float pix = planes[i], piy = planes[ld + i], piz = planes[2 * ld + i];  // wave-uniform: scalar loads
+  const float qix = planes[3 * ld + i], qiy = planes[4 * ld + i], qiz = planes[5 * ld + i];
   for (int wb = w0; wb < W; wb += 64) {
     const int w = wb + lane;
     uint64_t v = 0;
@@ -83,26 +92,43 @@ __global__ __launch_bounds__(256) void edge_fill_kernel(const uint64_t* __restri
       if (w == w0) v &= mask_above(i & 63);
     }
     uint32_t tot;
-    uint32_t r = group_exscan<64>((uint32_t)__popcll(v), &tot);
-    while (v) {
-      const int b = __builtin_ctzll(v);
-      v &= v - 1;
-      const uint32_t j = (uint32_t)(w * 64 + b);
-      const uint64_t e = base + r++;
-      ei[e] = (uint32_t)i;
-      ej[e] = j;
-      es[e] = S[(size_t)i * ld + j];
-      // both CSR bases travel with the edge, so stage B fetches an edge in ONE memory level
-      ebi[e] = my_base;
-      ebj[e] = (uint32_t)edge_off[j] - (deg[j] - degp[j]);
+    const uint32_t r = group_exscan<64>((uint32_t)__popcll(v), &tot);
+    for (uint32_t c0 = 0; c0 < tot; c0 += CH) {  // wave-uniform; one chunk unless the row is very dense
+      // (1) divergent part, LDS only: the columns of this chunk in ascending order
+      uint64_t vv = v;
+      uint32_t rr = r - c0;  // modular: positions outside [0, CH) are skipped
+      while (vv) {
+        const int b = __builtin_ctzll(vv);
+        vv &= vv - 1;
+        if (rr < (uint32_t)CH) l_j[wave][rr] = (uint32_t)(w * 64 + b);
+        rr++;
+      }
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // LDS is in-order within a wave
+      // (2) flat part, one lane per edge: gathers, weight, coalesced stores
+      const uint32_t cnt = min((uint32_t)CH, tot - c0);
+      for (uint32_t t = lane; t < cnt; t += 64) {
+        const uint32_t j = l_j[wave][t];
+        const uint64_t e = base + c0 + t;
+        const float dp = dist3(pix, piy, piz, planes[j], planes[ld + j], planes[2 * ld + j]);
+        const float dq = dist3(qix, qiy, qiz, planes[3 * ld + j], planes[4 * ld + j], planes[5 * ld + j]);
+        bool edge;
+        const float sw = pair_weight(dp, dq, dv.d_thr, dv.min_len, dv.neg_inv2sig2, edge);
+        ei[e] = (uint32_t)i;
+        ej[e] = j;
+        es[e] = sw;
+        // both CSR bases travel with the edge, so stage B fetches an edge in ONE memory level
+        ebi[e] = my_base;
+        ebj[e] = (uint32_t)edge_off[j] - (deg[j] - degp[j]);
+      }
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     }
     base += tot;
   }
 }
 
-void launch_edge_fill(const Graph& g, const uint64_t* edge_off, uint32_t* ei, uint32_t* ej, float* es,
-                      uint32_t* ebase, uint32_t* ebi, uint32_t* ebj, hipStream_t st) {
-  hipLaunchKernelGGL(edge_fill_kernel, dim3((g.n + 3) / 4), dim3(256), 0, st, g.bits, g.S, g.n, g.ld, g.W,
+void launch_edge_fill(const Graph& g, const Points& pts, const Derived& dv, const uint64_t* edge_off, uint32_t* ei,
+                      uint32_t* ej, float* es, uint32_t* ebase, uint32_t* ebi, uint32_t* ebj, hipStream_t st) {
+  hipLaunchKernelGGL(edge_fill_kernel, dim3((g.n + 3) / 4), dim3(256), 0, st, g.bits, pts.planes, dv, g.n, g.ld, g.W,
                      edge_off, ei, ej, es, g.deg, g.degp, ebase, ebi, ebj);
 }
 
@@ -354,15 +380,14 @@ void launch_tri_keys(const Graph& g, const uint64_t* mbits, const float* smin, c
 // ------------------------------------------------------------------------------------------------
 constexpr int EV_SHARDS = 256;
 
-// Staging is per workgroup (EVB records in LDS, slots handed out by an LDS counter); a flush happens at a
-// workgroup-uniform point between trips.  Used only for moderately wide rows (W <= 128) of a pruned graph: with very
-// wide or dense rows a trip can overflow the staging buffer into per-event global atomics (C3, W = 313: 4.7 ms), so the
-// host then keeps the row-walking tri_count / tri_keys pair.  Other shapes measured on C2 and rejected: per-wave
-// staging with a global-atomic overflow path (235 us), per-group staging with group-uniform flushes (118 us), and a
-// wave-uniform one-round-per-iteration state machine with ballot compaction and software prefetch (98 us); this one
-// takes 50 us.
-constexpr int EVB = 512;  // events staged per workgroup (16 KiB of LDS: still 8 workgroups per CU)
-
+// Staging is per WAVE (EVW records of LDS each).  The rounds loop is wave-uniform: it runs to the largest round count
+// among the wave's groups and idle groups contribute empty words, so (a) events are appended with __ballot / mbcnt —
+// no atomics, (b) the flush decision is taken by the whole wave after any round — a round adds at most 64 records, so
+// the segment can never overflow, whatever the row width, and (c) no workgroup barrier is needed.  One global atomic
+// per flush, on one of EV_SHARDS counters.
+// Shapes measured and rejected (C2 unless noted): workgroup staging with two barriers per trip (48 us, and it overflows
+// into per-event global atomics at W = 313: 4.7 ms on C3), per-wave staging with a global-atomic overflow path
+// (235 us), per-group staging (118 us), a one-round-per-iteration state machine with software prefetch (98 us).
 template <int TG>
 __global__ __launch_bounds__(256) void tri_count_events_kernel(const uint64_t* __restrict__ mbits, int W,
                                                                const uint32_t* __restrict__ deg,
@@ -374,85 +399,75 @@ __global__ __launch_bounds__(256) void tri_count_events_kernel(const uint64_t* _
                                                                const float* __restrict__ smin, uint64_t E,
                                                                int rank_mode, uint32_t* __restrict__ tcnt,
                                                                EventList ev) {
-  __shared__ uint64_t l_m[EVB];
-  __shared__ uint32_t l_wi[EVB], l_wj[EVB], l_a[EVB], l_b[EVB], l_e[EVB], l_rb[EVB];
-  __shared__ uint32_t l_cnt, l_base;
+  constexpr int EVW = 192;  // records per wave segment: flush above 128, a round adds <= 64
+  __shared__ uint64_t l_m[4 * EVW];
+  __shared__ uint32_t l_wi[4 * EVW], l_wj[4 * EVW], l_a[4 * EVW], l_b[4 * EVW], l_e[4 * EVW], l_rb[4 * EVW];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int gl = threadIdx.x & (TG - 1);
-  const uint64_t gmask = (TG == 64) ? ~0ull : (((1ull << TG) - 1ull) << ((threadIdx.x & 63) & ~(TG - 1)));
   const float s_floor = smin ? *smin : -1.0f;
   const uint64_t groups = (uint64_t)gridDim.x * (256 / TG);
   const uint64_t g0 = (uint64_t)blockIdx.x * (256 / TG) + (threadIdx.x / TG);
-  const uint32_t shard = blockIdx.x & (EV_SHARDS - 1);
-  const uint64_t trips = (E + groups - 1) / groups;  // the same for every thread: the loop holds workgroup barriers
-  if (threadIdx.x == 0) l_cnt = 0;
-  __syncthreads();
-  auto flush = [&]() {  // workgroup-uniform
-    const uint32_t n = min(l_cnt, (uint32_t)EVB);
-    if (threadIdx.x == 0 && n) l_base = atomicAdd(&ev.fill[shard], n);
-    __syncthreads();
-    const uint32_t base = l_base;
-    for (uint32_t k = threadIdx.x; k < n; k += 256) {
+  const uint32_t shard = (blockIdx.x * 4 + wave) & (EV_SHARDS - 1);
+  const uint64_t trips = (E + groups - 1) / groups;  // the same for every lane of the wave
+  const int wbase = wave * EVW;
+  uint32_t scnt = 0;  // records staged by this wave (wave-uniform)
+  auto flush = [&]() {  // wave-uniform
+    uint32_t base = 0;
+    if (lane == 0) base = atomicAdd(&ev.fill[shard], scnt);
+    base = __builtin_amdgcn_readfirstlane(base);
+    for (uint32_t k = lane; k < scnt; k += 64) {
       const uint64_t pos = (uint64_t)base + k;
       if (pos < ev.shard_cap) {
         const uint64_t o = (uint64_t)shard * ev.shard_cap + pos;
-        ev.m[o] = l_m[k]; ev.wi[o] = l_wi[k]; ev.wj[o] = l_wj[k]; ev.a[o] = l_a[k]; ev.b[o] = l_b[k];
-        ev.e[o] = l_e[k]; ev.rb[o] = l_rb[k];
+        const int q = wbase + (int)k;
+        ev.m[o] = l_m[q]; ev.wi[o] = l_wi[q]; ev.wj[o] = l_wj[q]; ev.a[o] = l_a[q]; ev.b[o] = l_b[q];
+        ev.e[o] = l_e[q]; ev.rb[o] = l_rb[q];
       } else {
         *ev.overflow = 1u;
       }
     }
-    __syncthreads();
-    if (threadIdx.x == 0) l_cnt = 0;
-    __syncthreads();
+    scnt = 0;
   };
   for (uint64_t trip = 0; trip < trips; trip++) {
     const uint64_t e = g0 + trip * groups;
-    uint32_t c = 0;
-    if (e < E && es[e] >= s_floor) {  // group-uniform
+    const bool on = e < E && es[e < E ? e : 0] >= s_floor;  // group-uniform
+    uint32_t rowi = 0, rowj = 0, fa = 0, fb = 0, c = 0;
+    int w0 = 0, jbit = 0, rounds = 0;
+    if (on) {
       const uint32_t i = ei[e], j = ej[e];
-      const uint32_t rowi = i * (uint32_t)W, rowj = j * (uint32_t)W;
-      const uint32_t fa = (rank_mode == 0) ? ebi[e] : deg[i] + deg[j];  // weight mode: CSR bases; degree mode: deg sum
-      const uint32_t fb = (rank_mode == 0) ? ebj[e] : 0u;
-      const int w0 = j >> 6;
-      const int rounds = (W - w0 + TG - 1) / TG;
-      for (int it = 0; it < rounds; it++) {
-        const int w = w0 + it * TG + gl;
-        uint64_t m = 0;
-        if (w < W) {
-          m = mbits[rowi + w] & mbits[rowj + w];
-          if (w == w0) m &= mask_above(j & 63);
-        }
-        const uint64_t any = __ballot(m != 0) & gmask;
-        if (any == 0) continue;  // group-uniform
+      rowi = i * (uint32_t)W; rowj = j * (uint32_t)W;
+      fa = (rank_mode == 0) ? ebi[e] : deg[i] + deg[j];  // weight mode: CSR bases; degree mode: the degree sum
+      fb = (rank_mode == 0) ? ebj[e] : 0u;
+      w0 = (int)(j >> 6); jbit = (int)(j & 63);
+      rounds = (W - w0 + TG - 1) / TG;
+    }
+    int wave_rounds = rounds;  // max over the wave: the loop below is wave-uniform
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) wave_rounds = max(wave_rounds, __shfl_xor(wave_rounds, o));
+    for (int it = 0; it < wave_rounds; it++) {
+      const int w = w0 + it * TG + gl;
+      uint64_t m = 0;
+      if (it < rounds && w < W) {
+        m = mbits[rowi + w] & mbits[rowj + w];
+        if (w == w0) m &= mask_above(jbit);
+      }
+      const uint64_t bal = __ballot(m != 0);
+      if (bal != 0) {  // wave-uniform
         uint32_t tm;
         const uint32_t rb = c + group_exscan<TG>((uint32_t)__popcll(m), &tm);
         c += tm;
         if (m) {
-          const uint32_t slot = atomicAdd(&l_cnt, 1u);
-          if (slot < (uint32_t)EVB) {
-            l_m[slot] = m; l_wi[slot] = rowi + w; l_wj[slot] = rowj + w; l_a[slot] = fa; l_b[slot] = fb;
-            l_e[slot] = (uint32_t)e; l_rb[slot] = rb;
-          } else {  // staging full inside one trip (very dense rows): straight to the global region
-            const uint64_t pos = atomicAdd(&ev.fill[shard], 1u);
-            if (pos < ev.shard_cap) {
-              const uint64_t o = (uint64_t)shard * ev.shard_cap + pos;
-              ev.m[o] = m; ev.wi[o] = rowi + w; ev.wj[o] = rowj + w; ev.a[o] = fa; ev.b[o] = fb;
-              ev.e[o] = (uint32_t)e; ev.rb[o] = rb;
-            } else {
-              *ev.overflow = 1u;
-            }
-          }
+          const int q = wbase + (int)scnt + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32),
+                                                   __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
+          l_m[q] = m; l_wi[q] = rowi + w; l_wj[q] = rowj + w; l_a[q] = fa; l_b[q] = fb; l_e[q] = (uint32_t)e; l_rb[q] = rb;
         }
+        scnt += (uint32_t)__popcll(bal);
+        if (scnt > (uint32_t)(EVW - 64)) flush();
       }
     }
     if (gl == 0 && e < E) tcnt[e] = c;
-    __syncthreads();
-    const uint32_t staged = l_cnt;  // read between two barriers: nobody appends here, so every thread sees one value
-    __syncthreads();
-    if (staged > (uint32_t)(EVB / 2)) flush();
   }
-  __syncthreads();
-  flush();
+  if (scnt) flush();
 }
 
 // one lane per event
