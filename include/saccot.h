@@ -54,7 +54,9 @@ extern "C" {
 #define SC_RANK_DEGREE 1   /* deg_i + deg_j + deg_k, u32, descending                         */
 
 /* flags */
-#define SC_FLAG_TIMING       1u /* record a HIP event pair around every stage and fill sc_stats.us_*          */
+#define SC_FLAG_TIMING       1u /* record a HIP event pair around every stage and fill sc_stats.us_* (each record  */
+                                /* costs ~5 us of stream time: diagnostics, not for the timed loop)               */
+#define SC_FLAG_TIMING_HOT  16u /* only the two roofline kernels: us_compat and us_score (4 records per call)      */
 #define SC_FLAG_EXACT_TOTAL  2u /* sc_stats.tri_total = 3-cliques of the WHOLE graph (one extra counting pass);  */
                                 /* default: 3-cliques of the pruned graph the top-T search actually enumerated   */
 #define SC_FLAG_REFINE       8u /* after C3, replace (R,t) by the fp64 least-squares refit over the winner's inlier  */
@@ -81,7 +83,9 @@ typedef struct sc_params {
 } sc_params;
 
 /* Per-call statistics (all optional: pass NULL).  Times are device times from HIP events on the
- * context's stream and are only filled when SC_FLAG_TIMING is set. */
+ * context's stream, only filled when SC_FLAG_TIMING / SC_FLAG_TIMING_HOT is set, and delivered by the call
+ * that ends the path (sc_register, sc_register_device, sc_finalize_device): sc_hypothesize_device never waits
+ * for the GPU at its end, so the us_* fields of ITS stats stay 0. */
 typedef struct sc_stats {
   uint32_t size;            /* = sizeof(sc_stats)                                                       */
   uint32_t n;               /* correspondences                                                          */

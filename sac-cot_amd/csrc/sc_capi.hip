@@ -44,7 +44,7 @@ struct sc_ctx {
   // workspace
   Buf in_src, in_tgt, planes, S, bits, deg, degp, wpre, ebase, edge_off, scan_tmp, ei, ej, es, ebi, ebj, tcnt, toff, wkey, kcol, ctl, events, blk_gt,
       blk_eq, blk_minmax, bits2, off_gt, off_eq, sel_ord, sel_key, sortkey, sorted, sort_tmp, tri, tri_rk, key_rk, rt, rt_aos, partial, cnt, key, rt12,
-      mask, refine_tmp;
+      mask, refine_tmp, amx_pairs;
 
   // state of the last hypothesize call (consumed by finalize)
   int n = 0, ld = 0;
@@ -55,7 +55,7 @@ struct sc_ctx {
   Derived dv{};
   Shard sh{};
   bool have_hyp = false;
-  bool timing = false;
+  bool timing = false, timing_hot = false;
   bool timed_trikeys = false;
   bool refine = false;
   const uint64_t* mbits = nullptr;
@@ -133,8 +133,10 @@ Graph graph_of(const sc_ctx* c) {
                c->wpre.as<uint32_t>(), c->n, c->ld, c->ld >> 6};
 }
 
+// event i of the per-stage timing; SC_FLAG_TIMING_HOT keeps only the brackets of the two roofline kernels
 int rec(sc_ctx* c, int i) {
-  if (c->timing) HIPCHK(c, hipEventRecord(c->ev[i], c->stream));
+  const bool hot = i == 1 || i == 2 || i == 4 || i == 5;
+  if (c->timing || (c->timing_hot && hot)) HIPCHK(c, hipEventRecord(c->ev[i], c->stream));
   return SC_OK;
 }
 
@@ -287,11 +289,14 @@ int run_triangles(sc_ctx* c, const sc_params* p) {
   c->timed_trikeys = c->timing;
   launch_select_rounds(c->wkey.as<uint32_t>(), M, sel, st);
   launch_compact_count(c->wkey.as<uint32_t>(), M, sel, c->blk_gt.as<uint32_t>(), c->blk_eq.as<uint32_t>(), st);
-  launch_scan_u32_pair(c->blk_gt.as<uint32_t>(), c->off_gt.as<uint64_t>(), c->blk_eq.as<uint32_t>(),
-                       c->off_eq.as<uint64_t>(), nb, c->scan_tmp.p, st);
+  // few tiles (and M < 2^32): compact_write adds up the tile counts itself, no scan launch in between
+  const bool self_off = nb <= 4096 && M < (1ull << 32);
+  if (!self_off)
+    launch_scan_u32_pair(c->blk_gt.as<uint32_t>(), c->off_gt.as<uint64_t>(), c->blk_eq.as<uint32_t>(),
+                         c->off_eq.as<uint64_t>(), nb, c->scan_tmp.p, st);
   launch_compact_write(c->wkey.as<uint32_t>(), M, sel, c->blk_gt.as<uint32_t>(), c->blk_eq.as<uint32_t>(),
-                       c->off_gt.as<uint64_t>(), c->off_eq.as<uint64_t>(), c->sel_ord.as<uint64_t>(),
-                       c->sel_key.as<uint32_t>(), st);
+                       self_off ? nullptr : c->off_gt.as<uint64_t>(), self_off ? nullptr : c->off_eq.as<uint64_t>(),
+                       c->sel_ord.as<uint64_t>(), c->sel_key.as<uint32_t>(), st);
   // the list stays in ordinal order: no sort on the hot path (the winner is found by (count, key, position))
   launch_tri_decode(c->ei.as<uint32_t>(), c->ej.as<uint32_t>(), c->kcol.as<uint32_t>(), c->toff.as<uint64_t>(), E,
                     c->sel_ord.as<uint64_t>(), T_eff, c->tri.as<uint32_t>(), st);
@@ -394,7 +399,7 @@ void sc_destroy(sc_ctx* c) {
   Buf* bufs[] = {&c->in_src, &c->in_tgt, &c->planes, &c->S, &c->bits, &c->deg, &c->degp, &c->wpre, &c->ebase, &c->edge_off, &c->scan_tmp,
                  &c->ei, &c->ej, &c->es, &c->ebi, &c->ebj, &c->tcnt, &c->toff, &c->wkey, &c->kcol, &c->ctl, &c->events, &c->blk_gt, &c->blk_eq, &c->blk_minmax, &c->bits2, &c->off_gt,
                  &c->off_eq, &c->sel_ord, &c->sel_key, &c->sortkey, &c->sorted, &c->sort_tmp, &c->tri, &c->tri_rk, &c->key_rk, &c->rt,
-                 &c->rt_aos, &c->partial, &c->cnt, &c->key, &c->rt12, &c->mask, &c->refine_tmp};
+                 &c->rt_aos, &c->partial, &c->cnt, &c->key, &c->rt12, &c->mask, &c->refine_tmp, &c->amx_pairs};
   for (Buf* b : bufs) if (b->p) (void)hipFree(b->p);
   for (int i = 0; i < N_EVENTS; i++) if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
   if (c->pinned) (void)hipHostFree(c->pinned);
@@ -421,6 +426,7 @@ int sc_hypothesize_device(sc_ctx* c, const float* d_src, const float* d_tgt, int
   c->have_hyp = false;
   c->timed_trikeys = false;
   c->timing = (p->flags & SC_FLAG_TIMING) != 0;
+  c->timing_hot = !c->timing && (p->flags & SC_FLAG_TIMING_HOT) != 0;
   c->refine = (p->flags & SC_FLAG_REFINE) != 0;
   c->cap_bytes = p->max_workspace ? p->max_workspace : (64ull << 30);
   c->dv = derive(p);
@@ -450,27 +456,14 @@ int sc_hypothesize_device(sc_ctx* c, const float* d_src, const float* d_tgt, int
   if ((rc = rec(c, 4))) return rc;
   launch_score(points_of(c), c->rt.as<float>(), sh, c->dv.tau2, c->partial.as<uint32_t>(), c->stream);
   if ((rc = rec(c, 5))) return rc;
+  ENSURE(c, c->amx_pairs, argmax_scratch_bytes(sh.ld_local));
   launch_argmax(points_of(c), sh, c->partial.as<uint32_t>(), c->T_eff ? c->sel_key.as<uint32_t>() : nullptr,
-                c->cnt.as<uint32_t>(), d_key, c->stream);
+                c->cnt.as<uint32_t>(), c->amx_pairs.as<uint64_t>(), &c->ctl.as<ControlBlock>()->amx_ticket, d_key,
+                c->stream);
   if ((rc = rec(c, 6))) return rc;
   HIPCHK(c, hipGetLastError());
   c->have_hyp = true;
-  if (stats && stats->size == sizeof(sc_stats)) {
-    fill_stats(c, stats);
-    if (c->timing) {
-      HIPCHK(c, hipStreamSynchronize(c->stream));
-      stats->us_stage = ev_us(c, 0, 1);
-      stats->us_compat = ev_us(c, 1, 2);
-      stats->us_triangles = ev_us(c, 2, 3);  // includes its two 8-byte read-backs
-      stats->us_trikeys = c->timed_trikeys ? ev_us(c, 9, 10) : 0.f;
-      stats->us_kabsch = ev_us(c, 3, 4);
-      stats->us_score = ev_us(c, 4, 5);
-      stats->us_argmax = ev_us(c, 5, 6);
-      stats->us_mask = 0.f;
-      stats->us_total = stats->us_stage + stats->us_compat + stats->us_triangles + stats->us_kabsch +
-                        stats->us_score + stats->us_argmax;
-    }
-  }
+  fill_stats(c, stats);  // counts only: the event times are read by sc_finalize_device, after ITS synchronisation
   return SC_OK;
 }
 
@@ -495,8 +488,19 @@ int sc_finalize_device(sc_ctx* c, const uint64_t* d_key, float* d_Rt, uint8_t* d
     stats->best_count = (uint32_t)(key >> 32);
     stats->best_rank = key ? (uint32_t)c->pinned[10] : 0u;
     if (c->timing) {
+      stats->us_stage = ev_us(c, 0, 1);
+      stats->us_compat = ev_us(c, 1, 2);
+      stats->us_triangles = ev_us(c, 2, 3);  // includes its two 8-byte read-backs
+      stats->us_trikeys = c->timed_trikeys ? ev_us(c, 9, 10) : 0.f;
+      stats->us_kabsch = ev_us(c, 3, 4);
+      stats->us_score = ev_us(c, 4, 5);
+      stats->us_argmax = ev_us(c, 5, 6);
       stats->us_mask = ev_us(c, 7, 8);
-      stats->us_total += stats->us_mask;
+      stats->us_total = stats->us_stage + stats->us_compat + stats->us_triangles + stats->us_kabsch +
+                        stats->us_score + stats->us_argmax + stats->us_mask;
+    } else if (c->timing_hot) {
+      stats->us_compat = ev_us(c, 1, 2);
+      stats->us_score = ev_us(c, 4, 5);
     }
   }
   return key ? SC_OK : SC_ENOHYP;
@@ -547,7 +551,7 @@ int sc_compat_host(sc_ctx* c, const float* src, const float* tgt, int64_t n, con
   if (rc) return rc;
   HIPCHK(c, hipSetDevice(c->device));
   c->have_hyp = false;
-  c->timing = false;
+  c->timing = c->timing_hot = false;
   c->cap_bytes = p->max_workspace ? p->max_workspace : (64ull << 30);
   c->dv = derive(p);
   if ((rc = host_to_planes(c, src, tgt, n, p))) return rc;
@@ -572,7 +576,7 @@ int sc_triangles_host(sc_ctx* c, const float* src, const float* tgt, int64_t n, 
   if (rc) return rc;
   HIPCHK(c, hipSetDevice(c->device));
   c->have_hyp = false;
-  c->timing = false;
+  c->timing = c->timing_hot = false;
   c->cap_bytes = p->max_workspace ? p->max_workspace : (64ull << 30);
   c->dv = derive(p);
   if ((rc = host_to_planes(c, src, tgt, n, p))) return rc;
@@ -648,7 +652,9 @@ int sc_score_host(sc_ctx* c, const float* src, const float* tgt, int64_t n, cons
   }
   launch_score(points_of(c), c->rt.as<float>(), sh, c->dv.tau2, c->partial.as<uint32_t>(), c->stream);
   ENSURE(c, c->cnt, (size_t)(sh.ld_local ? sh.ld_local : 256) * 4);
-  launch_argmax(points_of(c), sh, c->partial.as<uint32_t>(), nullptr, c->cnt.as<uint32_t>(), c->key.as<uint64_t>(),
+  ENSURE(c, c->amx_pairs, argmax_scratch_bytes(sh.ld_local));
+  launch_argmax(points_of(c), sh, c->partial.as<uint32_t>(), nullptr, c->cnt.as<uint32_t>(), c->amx_pairs.as<uint64_t>(),
+                &c->ctl.as<ControlBlock>()->amx_ticket, c->key.as<uint64_t>(),
                 c->stream);  // positions in Rt ARE the rank indices here: single-stage key
   if ((rc = check_flag(c))) return rc;
   if (cnt && n_hyp) HIPCHK(c, hipMemcpyAsync(cnt, c->cnt.p, (size_t)n_hyp * 4, hipMemcpyDeviceToHost, c->stream));

@@ -215,7 +215,8 @@ void launch_row_stats(const Points& pts, const uint64_t* bits, uint32_t* deg, ui
 }
 
 // ------------------------------------------------------------------------------------------------
-// exclusive scan u32 -> u64, three launches: block sums, scan of block sums (one block), down-sweep
+// exclusive scan u32 -> u64: block sums, then a down-sweep whose blocks add up the sums before them (two launches);
+// beyond SCAN_SELF_MAX tiles a one-block scan of the sums runs in between
 // ------------------------------------------------------------------------------------------------
 constexpr int SCAN_THREADS = 256;
 constexpr int SCAN_ITEMS = 16;
@@ -251,21 +252,37 @@ __global__ __launch_bounds__(1024) void scan_of_sums_kernel(uint64_t* __restrict
   }
 }
 
+// SELF: every block sums the raw block sums before it by itself (<= SCAN_SELF_MAX of them, from L2) and the last one
+// writes the total — the single-block scan-of-sums launch (a ~4.6 us floor) disappears.
+template <bool SELF>
 __global__ __launch_bounds__(SCAN_THREADS) void scan_downsweep_kernel(const uint32_t* __restrict__ in, size_t n,
                                                                       const uint64_t* __restrict__ bsum,
-                                                                      uint64_t* __restrict__ out) {
+                                                                      uint64_t* __restrict__ out,
+                                                                      uint64_t* __restrict__ host_total) {
   __shared__ uint64_t lds[8];
   const size_t base = (size_t)blockIdx.x * SCAN_TILE + (size_t)threadIdx.x * SCAN_ITEMS;
   uint32_t v[SCAN_ITEMS];
   uint64_t s = 0;
 #pragma unroll
   for (int k = 0; k < SCAN_ITEMS; k++) { v[k] = (base + k < n) ? in[base + k] : 0u; s += v[k]; }
+  uint64_t pre;
+  if (SELF) {
+    uint64_t a = 0;
+    for (uint32_t b = threadIdx.x; b < blockIdx.x; b += SCAN_THREADS) a += bsum[b];
+    pre = block_reduce_u64(a, lds);
+  } else {
+    pre = bsum[blockIdx.x];
+  }
   uint64_t tot;
-  uint64_t run = bsum[blockIdx.x] + block_exscan_u64(s, lds, &tot);
+  uint64_t run = pre + block_exscan_u64(s, lds, &tot);
 #pragma unroll
   for (int k = 0; k < SCAN_ITEMS; k++) {
     if (base + k < n) out[base + k] = run;
     run += v[k];
+  }
+  if (SELF && blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) {
+    out[n] = pre + tot;
+    if (host_total) *host_total = pre + tot;
   }
 }
 
@@ -303,6 +320,7 @@ __global__ __launch_bounds__(1024) void scan_small_kernel(const uint32_t* __rest
 }
 
 constexpr size_t SCAN_SMALL_MAX = 32768;
+constexpr size_t SCAN_SELF_MAX = 4096;  // tiles (16.7 M elements): beyond it the scan of sums is its own launch
 
 void launch_scan_u32_pair(const uint32_t* in0, uint64_t* out0, const uint32_t* in1, uint64_t* out1, size_t n,
                           void* temp, hipStream_t st) {
@@ -326,8 +344,14 @@ void launch_scan_u32(const uint32_t* in, size_t n, uint64_t* out, void* temp, hi
   const size_t nb = (n + SCAN_TILE - 1) / SCAN_TILE;
   if (nb == 0) return;  // n == 0 is handled by the small path above
   hipLaunchKernelGGL(scan_block_sums_kernel, dim3((unsigned)nb), dim3(SCAN_THREADS), 0, st, in, n, bsum);
-  hipLaunchKernelGGL(scan_of_sums_kernel, dim3(1), dim3(1024), 0, st, bsum, nb, out + n, host_total);
-  hipLaunchKernelGGL(scan_downsweep_kernel, dim3((unsigned)nb), dim3(SCAN_THREADS), 0, st, in, n, bsum, out);
+  if (nb <= SCAN_SELF_MAX) {
+    hipLaunchKernelGGL(scan_downsweep_kernel<true>, dim3((unsigned)nb), dim3(SCAN_THREADS), 0, st, in, n, bsum, out,
+                       host_total);
+  } else {
+    hipLaunchKernelGGL(scan_of_sums_kernel, dim3(1), dim3(1024), 0, st, bsum, nb, out + n, host_total);
+    hipLaunchKernelGGL(scan_downsweep_kernel<false>, dim3((unsigned)nb), dim3(SCAN_THREADS), 0, st, in, n, bsum, out,
+                       (uint64_t*)nullptr);
+  }
 }
 
 }  // namespace sc

@@ -112,7 +112,8 @@ struct ControlBlock {
   uint32_t ev_fill[256];     // event-list region fill counters (EV_SHARDS)
   uint32_t prune_hist[256];  // sampled key histogram of the certified pruning
   float smin;                // strong-edge threshold (written by prune_bits_kernel)
-  uint32_t pad0[15];
+  uint32_t amx_ticket;       // blocks-finished counter of score_argmax_kernel
+  uint32_t pad0[14];
   uint64_t key2[2];          // internal winner key pair (sc_register_device)
   uint64_t pad1[6];
   SelectState sel;
@@ -166,15 +167,17 @@ void launch_rt_to_soa(const float* Rt, uint32_t T, uint32_t ld_local, float* RtS
 uint32_t score_chunks(int n, uint32_t ld_local);  // point chunks the scoring launch will use
 void launch_score(const Points& pts, const float* RtSoA, const Shard& sh, float tau2, uint32_t* partial,
                   hipStream_t st);
-// Winner key pair key2[0..1] (zeroed here):
+// Winner key pair key2[0..1] (written, not accumulated: no zeroing needed):
 //   key2[0] = max over hypotheses with count > 0 of  (count << 32) | second,   second = sel_key[g] (the triangle's
 //             ranking key) or, when sel_key == nullptr, 0xFFFFFFFF - g;
 //   key2[1] = max of (0xFFFFFFFF - g) over the hypotheses attaining key2[0]  (only when sel_key != nullptr).
 // With g the position in the ordinal-ordered list this picks: most inliers, then best ranking key, then lowest
 // (i,j,k) — exactly "ties -> best-ranked triangle" of SURVEY §8a, without ever sorting the list.
-// cnt (n_local u32) is scratch for the second pass and the per-hypothesis counts of the stage hook.
+// cnt (n_local u32): the per-hypothesis counts (the stage hook returns them).  pairs: argmax_scratch_bytes() of
+// per-block (key, position) pairs; ticket: a zeroed u32 in the control block (left zero).
+size_t argmax_scratch_bytes(uint32_t ld_local);
 void launch_argmax(const Points& pts, const Shard& sh, const uint32_t* partial, const uint32_t* sel_key,
-                   uint32_t* cnt, uint64_t* key2, hipStream_t st);
+                   uint32_t* cnt, uint64_t* pairs, uint32_t* ticket, uint64_t* key2, hipStream_t st);
 // C3: winner decode + re-solve + mask.  Rt12 receives R (row-major) and t; identity / zero mask when key2[0] == 0.
 // sel_key / T: the ordinal-ordered ranking keys (for the winner's rank index); host_out (pinned, 3 x u64) receives
 // key2[0], the winner's position and its rank index.

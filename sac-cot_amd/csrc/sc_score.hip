@@ -299,41 +299,55 @@ __device__ __forceinline__ unsigned long long block_max_u64(unsigned long long k
   return b;
 }
 
-// pass 1: per-hypothesis count (sum of the chunk partials) and key2[0] = max (count << 32 | second)
+// Per-hypothesis count (sum of the chunk partials) and the winner key pair, in ONE launch and without atomics on
+// the keys: every block reduces its hypotheses to (best key, lowest position attaining it) and stores the pair; the
+// block that takes the last ticket reduces the pairs and writes key2[0..1] (so key2 needs no zeroing).
+//   key = (count << 32) | second, second = sel_key[g] or, without sel_key, 0xFFFFFFFF - g;  position = 0xFFFFFFFF - g.
 __global__ __launch_bounds__(256) void score_argmax_kernel(const uint32_t* __restrict__ partial, uint32_t n_chunks,
                                                            Shard sh, const uint32_t* __restrict__ sel_key,
                                                            uint32_t* __restrict__ cnt_out,
+                                                           unsigned long long* __restrict__ pairs,
+                                                           uint32_t* __restrict__ ticket,
                                                            unsigned long long* __restrict__ key2) {
   __shared__ unsigned long long lds[4];
+  __shared__ uint32_t s_last;
   const uint32_t l = blockIdx.x * 256 + threadIdx.x;
-  unsigned long long k = 0;
+  unsigned long long k = 0, pos = 0;
   if (l < sh.n_local) {
     uint32_t c = 0;
     for (uint32_t ch = 0; ch < n_chunks; ch++) c += partial[(size_t)ch * sh.ld_local + l];
     cnt_out[l] = c;
     const uint32_t g = shard_global_index(l, sh.block, sh.rank, sh.world);
     const uint32_t second = sel_key ? sel_key[g] : 0xFFFFFFFFu - g;
-    if (c) k = ((unsigned long long)c << 32) | (unsigned long long)second;
+    if (c) { k = ((unsigned long long)c << 32) | (unsigned long long)second; pos = (unsigned long long)(0xFFFFFFFFu - g); }
   }
-  const unsigned long long b = block_max_u64(k, lds);
-  if (threadIdx.x == 0 && b) atomicMax(&key2[0], b);  // max is order-independent: deterministic
-}
-
-// pass 2: among the hypotheses attaining key2[0], the lowest position (stored as max of 0xFFFFFFFF - g)
-__global__ __launch_bounds__(256) void score_argpos_kernel(const uint32_t* __restrict__ cnt, Shard sh,
-                                                           const uint32_t* __restrict__ sel_key,
-                                                           unsigned long long* __restrict__ key2) {
-  __shared__ unsigned long long lds[4];
-  const unsigned long long best = key2[0];
-  const uint32_t l = blockIdx.x * 256 + threadIdx.x;
-  unsigned long long k = 0;
-  if (best != 0 && l < sh.n_local) {
-    const uint32_t g = shard_global_index(l, sh.block, sh.rank, sh.world);
-    const unsigned long long mine = ((unsigned long long)cnt[l] << 32) | (unsigned long long)sel_key[g];
-    if (mine == best) k = (unsigned long long)(0xFFFFFFFFu - g);
+  const unsigned long long bk = block_max_u64(k, lds);
+  __syncthreads();
+  const unsigned long long bp = block_max_u64((k == bk) ? pos : 0ull, lds);
+  if (threadIdx.x == 0) {
+    __hip_atomic_store(&pairs[2 * blockIdx.x], bk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(&pairs[2 * blockIdx.x + 1], bp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    const uint32_t t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    s_last = (t == gridDim.x - 1) ? 1u : 0u;
+    if (s_last) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
   }
-  const unsigned long long b = block_max_u64(k, lds);
-  if (threadIdx.x == 0 && b) atomicMax(&key2[1], b);
+  __syncthreads();
+  if (!s_last) return;
+  unsigned long long gk = 0, gp = 0;
+  for (uint32_t b = threadIdx.x; b < gridDim.x; b += 256) {
+    const unsigned long long a = __hip_atomic_load(&pairs[2 * b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned long long q = __hip_atomic_load(&pairs[2 * b + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (a > gk || (a == gk && q > gp)) { gk = a; gp = q; }
+  }
+  const unsigned long long K = block_max_u64(gk, lds);
+  __syncthreads();
+  const unsigned long long P = block_max_u64((gk == K) ? gp : 0ull, lds);
+  if (threadIdx.x == 0) {
+    key2[0] = K;
+    key2[1] = (K != 0 && sel_key) ? P : 0ull;
+    __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // ready for the next launch
+  }
 }
 
 // share of the hypotheses (in 256ths) scored on the matrix pipe; SC_SCORE_SPLIT=0..256 overrides (experiments)
@@ -356,16 +370,17 @@ void launch_score(const Points& pts, const float* RtSoA, const Shard& sh, float 
                      RtSoA, sh.ld_local, tau2, chunk_pts, partial, nv, nm);
 }
 
+size_t argmax_scratch_bytes(uint32_t ld_local) { return (size_t)(ld_local / 256 + 1) * 2 * sizeof(uint64_t); }
+
 void launch_argmax(const Points& pts, const Shard& sh, const uint32_t* partial, const uint32_t* sel_key,
-                   uint32_t* cnt, uint64_t* key2, hipStream_t st) {
-  (void)hipMemsetAsync(key2, 0, 2 * sizeof(uint64_t), st);
-  if (sh.n_local == 0) return;
+                   uint32_t* cnt, uint64_t* pairs, uint32_t* ticket, uint64_t* key2, hipStream_t st) {
+  if (sh.n_local == 0) {  // nothing scored: the pair is (0, 0)
+    (void)hipMemsetAsync(key2, 0, 2 * sizeof(uint64_t), st);
+    return;
+  }
   hipLaunchKernelGGL(score_argmax_kernel, dim3(sh.ld_local / 256), dim3(256), 0, st, partial,
-                     score_chunks(pts.n, sh.ld_local),
-                     sh, sel_key, cnt, reinterpret_cast<unsigned long long*>(key2));
-  if (sel_key)
-    hipLaunchKernelGGL(score_argpos_kernel, dim3(sh.ld_local / 256), dim3(256), 0, st, cnt, sh, sel_key,
-                       reinterpret_cast<unsigned long long*>(key2));
+                     score_chunks(pts.n, sh.ld_local), sh, sel_key, cnt,
+                     reinterpret_cast<unsigned long long*>(pairs), ticket, reinterpret_cast<unsigned long long*>(key2));
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -144,7 +144,6 @@ static int tune_tg(const char* name, int dflt) {
 }
 
 constexpr int TK_MAX_BLOCKS = 4096;  // bounds the per-block min/max arrays
-constexpr int TG_DEFAULT = 16;  // lanes per edge (template parameter TG of the edge kernels)
 
 // mbits: the bit matrix that decides MEMBERSHIP (the full adjacency, or the pruned "strong" upper-triangle matrix);
 // smin != nullptr: edges with es[e] < *smin are outside the pruned graph and count 0 without touching any row.
@@ -940,8 +939,18 @@ __global__ __launch_bounds__(CP_THREADS) void compact_write_kernel(const uint32_
   __shared__ uint64_t lds[8];
   const uint32_t kstar = sel->kstar;
   const uint64_t need_eq = sel->need_eq;
+  // off_gt == nullptr: this block adds up the tile counts before it by itself (a few thousand u32 from L2) — saves
+  // the scan launch in between; both sums ride one u64 (gt high, eq low: each below 2^32 since M < 2^32 here)
+  uint64_t gt0, eq0;
+  if (off_gt == nullptr) {
+    uint64_t a = 0;
+    for (uint32_t b = threadIdx.x; b < blockIdx.x; b += CP_THREADS) a += ((uint64_t)blk_gt[b] << 32) | blk_eq[b];
+    a = block_reduce_u64(a, lds);
+    gt0 = a >> 32; eq0 = a & 0xFFFFFFFFull;
+  } else {
+    gt0 = off_gt[blockIdx.x]; eq0 = off_eq[blockIdx.x];
+  }
   // most tiles hold nothing to emit (T << M): skip them on the block counts alone, without touching the keys
-  const uint64_t eq0 = off_eq[blockIdx.x];
   if (blk_gt[blockIdx.x] == 0 && (blk_eq[blockIdx.x] == 0 || eq0 >= need_eq)) return;
   const uint64_t base = (uint64_t)blockIdx.x * CP_TILE + (uint64_t)threadIdx.x * CP_ITEMS;
   uint32_t keys[CP_ITEMS];
@@ -954,7 +963,7 @@ __global__ __launch_bounds__(CP_THREADS) void compact_write_kernel(const uint32_
   uint64_t tot;
   // both counts ride one u64 scan: gt in the high half, eq in the low half (each <= 1024 per tile)
   const uint64_t ex = block_exscan_u64(((uint64_t)g << 32) | q, lds, &tot);
-  uint64_t gt_before = off_gt[blockIdx.x] + (ex >> 32);
+  uint64_t gt_before = gt0 + (ex >> 32);
   uint64_t eq_before = eq0 + (ex & 0xFFFFFFFFull);
 #pragma unroll
   for (int k = 0; k < CP_ITEMS; k++) {

@@ -15,11 +15,11 @@ d_key = torch.zeros(2, dtype=torch.int64, device=dev)
 d_Rt = torch.zeros(12, dtype=torch.float32, device=dev); d_mask = torch.zeros(cfg.n, dtype=torch.uint8, device=dev)
 for world in (1, 2, 4, 8):
     kw = cfg.params(); kw["max_triangles"] = cfg.T * world
-    p = pkg.make_params(shard_rank=0, shard_world=world, shard_block=1000, flags=pkg.SC_FLAG_TIMING, **kw)
+    p = pkg.make_params(shard_rank=0, shard_world=world, shard_block=1000, flags=pkg.SC_FLAG_TIMING_HOT, **kw)
     for _ in range(3):
         reg.hypothesize_device(d_src.data_ptr(), d_tgt.data_ptr(), cfg.n, p, d_key.data_ptr()); reg.finalize_device(d_key.data_ptr(), d_Rt.data_ptr(), d_mask.data_ptr())
     torch.cuda.synchronize(); t0 = time.perf_counter(); K = 30
     for _ in range(K):
-        st = reg.hypothesize_device(d_src.data_ptr(), d_tgt.data_ptr(), cfg.n, p, d_key.data_ptr()); reg.finalize_device(d_key.data_ptr(), d_Rt.data_ptr(), d_mask.data_ptr())
+        reg.hypothesize_device(d_src.data_ptr(), d_tgt.data_ptr(), cfg.n, p, d_key.data_ptr()); _, st = reg.finalize_device(d_key.data_ptr(), d_Rt.data_ptr(), d_mask.data_ptr())
     torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / K
-    print(f"world={world} T_total={cfg.T*world} per-rank step {dt*1e3:.3f} ms -> job {cfg.T*world/dt/1e6:.1f} M hyp/s (efficiency vs linear {cfg.T*world/dt/ (world*104.2e6)*100:.0f}%)  tri_enum={st['tri_total']} B={st['us_triangles']:.0f}us score={st['us_score']:.0f}us scored={st['tri_scored']}")
+    print(f"world={world} T_total={cfg.T*world} per-rank step {dt*1e3:.3f} ms -> job {cfg.T*world/dt/1e6:.1f} M hyp/s (efficiency vs linear {cfg.T*world/dt/ (world*104.2e6)*100:.0f}%)  tri_enum={st['tri_total']} compat={st['us_compat']:.0f}us score={st['us_score']:.0f}us scored={st['tri_scored']}")

@@ -17,7 +17,8 @@ cd /tmp && export TMPDIR=/tmp && timeout -k 10 300 rocprofv3 --kernel-trace --st
 python - <<PY
 import csv,glob
 f=sorted(glob.glob("$R/gpurun_out/prof_$TAG/*/*_kernel_stats.csv"))[-1]
-rows=list(csv.DictReader(open(f))); n=34.0; tot=0
+rows=list(csv.DictReader(open(f))); tot=0
+n=float([r["Calls"] for r in rows if "stage_points" in r["Name"]][0])  # calls of the path in the profiled run
 for r in rows:
     per=float(r["TotalDurationNs"])/1e3/n; tot+=per
     if per>=2.0: print(f"{r['Name'][:58]:58s} n/step={int(r['Calls'])/n:4.1f} avg={float(r['AverageNs'])/1e3:7.2f} us/step={per:7.2f}")
