@@ -5,6 +5,11 @@
 
 namespace sc {
 
+// A result the HOST polls for in pinned memory (sc_capi.hip wait_word): one system-scope release store.
+__device__ __forceinline__ void publish_host(uint64_t* p, uint64_t v) {
+  __hip_atomic_store(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 // sum over the block; lds: >= blockDim.x/64 entries.  Every thread gets the total.
 __device__ __forceinline__ uint64_t block_reduce_u64(uint64_t v, uint64_t* lds) {
 #pragma unroll

@@ -5,6 +5,8 @@
 // allocates, enqueues kernels (sc_kernels.hpp) and copies.  Two small read-backs (edge count, triangle
 // count) size the data-dependent buffers; there is no CPU fallback of any stage.
 #include <hip/hip_runtime.h>
+#include <atomic>
+#include <chrono>
 
 #include <cmath>
 #include <cstdio>
@@ -179,6 +181,32 @@ int run_row_stats(sc_ctx* c, bool will_prune) {
   return SC_OK;
 }
 
+// Read-backs: the producing kernel stores its 8-byte result into host-pinned memory (publish_host) and the host
+// polls that word instead of blocking in hipStreamSynchronize (whose wake-up alone costs ~10 us, twice per call).
+// After ~200 us of polling it falls back to the blocking wait (long-running stages, or a failed launch).
+constexpr uint64_t PIN_PENDING = ~0ull;
+inline void cpu_relax() {
+#if defined(__x86_64__) && !defined(__HIP_DEVICE_COMPILE__)
+  __builtin_ia32_pause();
+#endif
+}
+void arm_word(sc_ctx* c, int idx) { c->pinned[idx] = PIN_PENDING; }
+int wait_word(sc_ctx* c, int idx) {
+  volatile uint64_t* w = &c->pinned[idx];
+  const auto t0 = std::chrono::steady_clock::now();
+  uint32_t spins = 0;
+  while (*w == PIN_PENDING) {
+    cpu_relax();
+    if ((++spins & 255u) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(200)) {
+      HIPCHK(c, hipStreamSynchronize(c->stream));
+      break;
+    }
+  }
+  std::atomic_thread_fence(std::memory_order_acquire);
+  if (*w == PIN_PENDING) { c->last_error = "a kernel did not deliver its result"; return SC_EHIP; }
+  return SC_OK;
+}
+
 bool may_prune(const sc_params* p) { return p->rank_mode == SC_RANK_WEIGHT && !(p->flags & SC_FLAG_NO_PRUNE); }
 
 // stage B; on return c->E, c->M, c->T_eff are set and tri/trikey hold the ranked list
@@ -188,8 +216,9 @@ int run_triangles(sc_ctx* c, const sc_params* p) {
   ENSURE(c, c->edge_off, (n + 1) * sizeof(uint64_t));
   ENSURE(c, c->scan_tmp, scan_temp_bytes(n));
   // read-back #1: the scan kernel itself writes the edge count to host-pinned memory (no copy kernel)
+  arm_word(c, 0);
   launch_scan_u32(c->degp.as<uint32_t>(), n, c->edge_off.as<uint64_t>(), c->scan_tmp.p, st, &c->pinned[0]);
-  HIPCHK(c, hipStreamSynchronize(st));
+  { const int wrc = wait_word(c, 0); if (wrc) return wrc; }
   if ((uint32_t)c->pinned[1] != 0) { c->last_error = "non-finite input coordinate"; return SC_EINVAL; }
   const uint64_t E = c->E = c->pinned[0];
   c->M = 0; c->M_total = 0; c->T_eff = 0; c->pruned = false;
@@ -222,7 +251,8 @@ int run_triangles(sc_ctx* c, const sc_params* p) {
     }
     // the smallest possible weight is ~3 t_cmp (every edge has s >= t_cmp up to rounding); 0.1 % slack
     launch_prune(g, c->ebase.as<uint32_t>(), c->ei.as<uint32_t>(), c->ej.as<uint32_t>(), c->es.as<float>(), E,
-                 p->max_triangles, 3.0f * p->t_cmp * 0.999f, ctl->prune_hist, c->bits2.as<uint64_t>(), &ctl->smin, st);
+                 p->max_triangles, 3.0f * p->t_cmp * 0.999f, ctl->prune_hist, c->bits2.as<uint64_t>(), &ctl->smin, &ctl->klb,
+                 st);
     mbits = c->bits2.as<uint64_t>();
     smin = &ctl->smin;
   }
@@ -249,8 +279,9 @@ int run_triangles(sc_ctx* c, const sc_params* p) {
                      c->tcnt.as<uint32_t>(), st);
   }
   // read-back #2: triangle count (of the pruned graph when pruning), written to pinned memory by the scan
+  arm_word(c, 2);
   launch_scan_u32(c->tcnt.as<uint32_t>(), E, c->toff.as<uint64_t>(), c->scan_tmp.p, st, &c->pinned[2]);
-  HIPCHK(c, hipStreamSynchronize(st));
+  { const int wrc = wait_word(c, 2); if (wrc) return wrc; }
   c->M_total = have_total ? c->pinned[4] : c->pinned[2];
   const uint64_t M = c->M = c->pinned[2];
   if (M == 0) return SC_OK;
@@ -278,16 +309,19 @@ int run_triangles(sc_ctx* c, const sc_params* p) {
     if (want_cap > (1ull << 28)) want_cap = 1ull << 28;
     c->ev_capacity = want_cap;
   }
+  // weight keys of a graph whose edges all weigh >= 2/3 (0.1 % slack) lie in [2.0, 3.0]: window known a priori
+  const bool fast_window = events_ok && p->rank_mode == SC_RANK_WEIGHT && 3.0f * p->t_cmp * 0.999f >= 2.0f;
   if (events_ok)
     launch_tri_keys_events(g, c->es.as<float>(), c->toff.as<uint64_t>(), p->rank_mode, ev, c->wkey.as<uint32_t>(),
-                           c->kcol.as<uint32_t>(), c->blk_minmax.as<uint32_t>(), sel, T_eff, st);
+                           c->kcol.as<uint32_t>(), c->blk_minmax.as<uint32_t>(), sel, T_eff,
+                           fast_window ? &c->ctl.as<ControlBlock>()->klb : nullptr, st);
   else
     launch_tri_keys(g, mbits, smin, c->ebase.as<uint32_t>(), c->ei.as<uint32_t>(), c->ej.as<uint32_t>(),
                     c->es.as<float>(), c->toff.as<uint64_t>(), E, p->rank_mode, c->wkey.as<uint32_t>(),
                     c->kcol.as<uint32_t>(), c->blk_minmax.as<uint32_t>(), sel, T_eff, st);
   if (c->timing) HIPCHK(c, hipEventRecord(c->ev[10], st));
   c->timed_trikeys = c->timing;
-  launch_select_rounds(c->wkey.as<uint32_t>(), M, sel, st);
+  launch_select_rounds(c->wkey.as<uint32_t>(), M, sel, fast_window ? 2 : 3, st);
   launch_compact_count(c->wkey.as<uint32_t>(), M, sel, c->blk_gt.as<uint32_t>(), c->blk_eq.as<uint32_t>(), st);
   // few tiles (and M < 2^32): compact_write adds up the tile counts itself, no scan launch in between
   const bool self_off = nb <= 4096 && M < (1ull << 32);
@@ -473,6 +507,7 @@ int sc_finalize_device(sc_ctx* c, const uint64_t* d_key, float* d_Rt, uint8_t* d
   HIPCHK(c, hipSetDevice(c->device));
   int rc;
   if ((rc = rec(c, 7))) return rc;
+  arm_word(c, 8);
   launch_finalize(points_of(c), c->tri.as<uint32_t>(), c->T_eff ? c->sel_key.as<uint32_t>() : nullptr, c->T_eff, d_key,
                   c->dv.tau2, d_Rt, d_mask, &c->pinned[8], c->stream);
   if (c->refine) {  // fp64 least-squares refit over the winner's inliers (mask unchanged)
@@ -480,7 +515,10 @@ int sc_finalize_device(sc_ctx* c, const uint64_t* d_key, float* d_Rt, uint8_t* d
     launch_refine(points_of(c), d_mask, d_key, c->refine_tmp.as<double>(), d_Rt, c->stream);
   }
   if ((rc = rec(c, 8))) return rc;
-  HIPCHK(c, hipStreamSynchronize(c->stream));  // the winner kernel wrote key / position / rank to pinned memory
+  // the winner kernel publishes key / position / rank; d_Rt and d_mask complete in stream order (a full wait only
+  // when the per-stage events are read below)
+  if (c->timing) HIPCHK(c, hipStreamSynchronize(c->stream));
+  if ((rc = wait_word(c, 8))) return rc;
   HIPCHK(c, hipGetLastError());
   const uint64_t key = c->pinned[8];
   if (stats && stats->size == sizeof(sc_stats)) {

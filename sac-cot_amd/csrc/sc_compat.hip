@@ -248,7 +248,7 @@ __global__ __launch_bounds__(1024) void scan_of_sums_kernel(uint64_t* __restrict
   }
   if (threadIdx.x == 0) {
     *total_out = carry;
-    if (host_total) *host_total = carry;
+    if (host_total) publish_host(host_total, carry);
   }
 }
 
@@ -282,7 +282,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_downsweep_kernel(const uint
   }
   if (SELF && blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) {
     out[n] = pre + tot;
-    if (host_total) *host_total = pre + tot;
+    if (host_total) publish_host(host_total, pre + tot);
   }
 }
 
@@ -314,7 +314,7 @@ __global__ __launch_bounds__(1024) void scan_small_kernel(const uint32_t* __rest
     }
     if (threadIdx.x == 0) {
       out[n] = carry;
-      if (a == 0 && host_total) *host_total = carry;
+      if (a == 0 && host_total) publish_host(host_total, carry);
     }
   }
 }

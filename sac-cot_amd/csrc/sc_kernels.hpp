@@ -1,6 +1,7 @@
 // sc_kernels.hpp — launchers of the hand-written gfx950 kernels (one per SURVEY.md §8(a) row).
 // Every launcher only enqueues on `st`; none allocates, frees or synchronises (capture-safe).
 #pragma once
+#include <cstddef>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -70,7 +71,7 @@ void launch_tri_count(const Graph& g, const uint64_t* mbits, const float* es, co
 // matrix `mbits` (n x W, zeroed here).  key_floor: a value at or below the smallest possible triangle weight.
 void launch_prune(const Graph& g, const uint32_t* ebase, const uint32_t* ei, const uint32_t* ej, const float* es,
                   uint64_t E, uint64_t want, float key_floor, uint32_t* hist, uint64_t* mbits, float* smin,
-                  hipStream_t st);  // hist and mbits must already be zero
+                  uint32_t* klb, hipStream_t st);  // hist and mbits must already be zero; *klb = key of the bound or 0
 
 // Event list of stage B (sc_tri.hip 2b): one record per non-zero member word of a strong edge, SoA, split into
 // EV_SHARDS regions of shard_cap records; fill[shard] = records appended to that region.
@@ -104,8 +105,10 @@ struct SelectState {
   uint64_t want;           // number of keys to keep
   uint64_t above;          // keys strictly above the current window
   uint64_t need_eq;        // how many keys == kstar to keep (lowest ordinals first)
-  uint32_t hist[2048];
+  uint64_t pad;            // keeps hist 16-byte aligned (it is read and cleared with 16-byte accesses)
+  uint32_t hist[4096];
 };
+static_assert(offsetof(SelectState, hist) % 16 == 0, "SelectState::hist must be 16-byte aligned");
 
 // Per-call control block (device memory, zeroed by one hipMemsetAsync at the start of every call).
 struct ControlBlock {
@@ -113,11 +116,13 @@ struct ControlBlock {
   uint32_t prune_hist[256];  // sampled key histogram of the certified pruning
   float smin;                // strong-edge threshold (written by prune_bits_kernel)
   uint32_t amx_ticket;       // blocks-finished counter of score_argmax_kernel
-  uint32_t pad0[14];
+  uint32_t klb;              // key of the certified lower bound of the pruning (0: none)
+  uint32_t pad0[13];
   uint64_t key2[2];          // internal winner key pair (sc_register_device)
   uint64_t pad1[6];
   SelectState sel;
 };
+static_assert(offsetof(ControlBlock, sel) % 16 == 0, "ControlBlock::sel must be 16-byte aligned");
 
 // key of every triangle, in ordinal (lexicographic i,j,k) order: wkey[toff[e] + r].
 // blk_minmax: 2 * 8192 u32 scratch (per-block key min / max, reduced into s->kmin / s->kmax; s->want = want).
@@ -128,9 +133,11 @@ void launch_tri_keys(const Graph& g, const uint64_t* mbits, const float* smin, c
 // keys from the event list (replaces launch_tri_keys when no region overflowed)
 void launch_tri_keys_events(const Graph& g, const float* es, const uint64_t* toff, int rank_mode,
                             const EventList& ev, uint32_t* wkey, uint32_t* kcol, uint32_t* blk_minmax,
-                            SelectState* s, uint64_t want, hipStream_t st);
-// up to three rounds (histogram + pick by the last block to finish) find the exact threshold key
-void launch_select_rounds(const uint32_t* wkey, uint64_t M, SelectState* s, hipStream_t st);
+                            SelectState* s, uint64_t want, const uint32_t* klb, hipStream_t st);
+// klb != nullptr (weight ranking, every edge weight >= 2/3): the kernel presets the select window to
+// [*klb or 2.0, 3.0] and no key-range pass runs; two select rounds then always suffice.
+// `rounds` launches (histogram + pick by the last block to finish; 12 key bits each) find the exact threshold key
+void launch_select_rounds(const uint32_t* wkey, uint64_t M, SelectState* s, int rounds, hipStream_t st);
 // compaction of the selected keys in ordinal order
 size_t compact_blocks(uint64_t M);
 void launch_compact_count(const uint32_t* wkey, uint64_t M, const SelectState* s, uint32_t* blk_gt,

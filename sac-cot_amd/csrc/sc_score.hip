@@ -429,7 +429,11 @@ __global__ __launch_bounds__(1024) void winner_kernel(const float* __restrict__ 
     }
     rank = block_reduce_u64(r, lds);
   }
-  if (threadIdx.x == 0 && host_out) { host_out[0] = k0; host_out[1] = g; host_out[2] = k0 ? rank : 0; }
+  if (threadIdx.x == 0 && host_out) {  // [0] last: the host polls it (release orders the other two before it)
+    host_out[1] = g;
+    host_out[2] = k0 ? rank : 0;
+    publish_host(reinterpret_cast<uint64_t*>(host_out), k0);
+  }
 }
 
 __global__ __launch_bounds__(256) void mask_kernel(const float* __restrict__ planes, int n, int ld,

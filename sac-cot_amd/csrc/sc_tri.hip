@@ -478,9 +478,22 @@ __global__ __launch_bounds__(256) void tri_keys_events_kernel(const uint64_t* __
                                                               EventList ev, uint32_t* __restrict__ wkey,
                                                               uint32_t* __restrict__ kcol,
                                                               uint32_t* __restrict__ blk_min,
-                                                              uint32_t* __restrict__ blk_max) {
+                                                              uint32_t* __restrict__ blk_max,
+                                                              SelectState* __restrict__ preset,
+                                                              const uint32_t* __restrict__ klb, uint64_t want) {
   __shared__ uint32_t lmin[4], lmax[4];
-  __shared__ uint64_t pre[EV_SHARDS + 1];  // exclusive prefix of the region fills: one flat index space over all events
+  __shared__ uint64_t pre[EV_SHARDS + 1];
+  // Weight keys of a graph whose edges all weigh >= 2/3 live in one binade, [2.0, 3.0]: the select window is known
+  // before a single key exists — [certified bound (or 2.0), 3.0] — so no key-range pass, and two 12-bit rounds
+  // always resolve it.  (Keys below a certified bound cannot be among the `want` largest: sc_tri.hip 3b.)
+  if (preset && blockIdx.x == 0 && threadIdx.x == 0) {
+    const uint32_t lo = *klb ? *klb : 0x40000000u, hi = 0x40400000u;  // 2.0f, 3.0f
+    const uint32_t range_m1 = hi - lo;
+    preset->lo = lo;
+    preset->wbits = range_m1 == 0 ? 0u : (uint32_t)(32 - __builtin_clz(range_m1));
+    preset->kmin = lo; preset->kmax = hi;
+    preset->started = 1; preset->done = 0; preset->above = 0; preset->want = want;
+  }  // exclusive prefix of the region fills: one flat index space over all events
   {
     static_assert(EV_SHARDS == 256, "one region per thread");
     __shared__ uint64_t plds[8];
@@ -589,11 +602,12 @@ void launch_tri_count_events(const Graph& g, const uint64_t* mbits, const float*
 
 void launch_tri_keys_events(const Graph& g, const float* es, const uint64_t* toff, int rank_mode,
                             const EventList& ev, uint32_t* wkey, uint32_t* kcol, uint32_t* blk_minmax,
-                            SelectState* s, uint64_t want, hipStream_t st) {
+                            SelectState* s, uint64_t want, const uint32_t* klb, hipStream_t st) {
   const int nb = 2048;
   hipLaunchKernelGGL(tri_keys_events_kernel, dim3(nb), dim3(256), 0, st, g.bits, g.wpre, g.deg, es, toff, rank_mode,
-                     ev, wkey, kcol, blk_minmax, blk_minmax + TK_MAX_BLOCKS);
-  hipLaunchKernelGGL(key_range_kernel, dim3(1), dim3(1024), 0, st, blk_minmax, blk_minmax + TK_MAX_BLOCKS, nb, s, want);
+                     ev, wkey, kcol, blk_minmax, blk_minmax + TK_MAX_BLOCKS, klb ? s : (SelectState*)nullptr, klb, want);
+  if (!klb)  // no a-priori window: the key range comes from the per-block extremes
+    hipLaunchKernelGGL(key_range_kernel, dim3(1), dim3(1024), 0, st, blk_minmax, blk_minmax + TK_MAX_BLOCKS, nb, s, want);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -684,22 +698,25 @@ __global__ __launch_bounds__(256) void prune_bits_kernel(const uint32_t* __restr
                                                          const uint32_t* __restrict__ ej,
                                                          const float* __restrict__ es, uint64_t E, int W,
                                                          unsigned long long* __restrict__ mbits,
-                                                         float* __restrict__ smin_out) {
+                                                         float* __restrict__ smin_out,
+                                                         uint32_t* __restrict__ klb_out) {
   __shared__ uint64_t lds[8];
   __shared__ float s_smin;
+  __shared__ uint32_t s_klb;
   static_assert(PR_BINS == 256, "one bin per thread, walked from the top");
   const uint32_t bin = PR_BINS - 1 - threadIdx.x;
   const uint64_t mine = hist[bin];
-  if (threadIdx.x == 0) s_smin = -1.0f;  // default: no certified bound -> every edge is strong
+  if (threadIdx.x == 0) { s_smin = -1.0f; s_klb = 0u; }  // default: no certified bound -> every edge is strong
   uint64_t tot;
   const uint64_t before = block_exscan_u64(mine, lds, &tot);
   if (before < want && want <= before + mine && bin > 0) {
     const float lb = __uint_as_float(klo + (bin << shift));  // lower edge of the crossing bin
     s_smin = (lb - 2.0f) - 1e-6f;
+    s_klb = klo + (bin << shift);  // >= want triangles have a key >= this one: the select may ignore anything below
   }
   __syncthreads();
   const float smin = s_smin;
-  if (blockIdx.x == 0 && threadIdx.x == 0) *smin_out = smin;
+  if (blockIdx.x == 0 && threadIdx.x == 0) { *smin_out = smin; *klb_out = s_klb; }
   const uint64_t e = (uint64_t)blockIdx.x * 256 + threadIdx.x;
   if (e < E && es[e] >= smin) {
     const uint32_t i = ei[e], j = ej[e];
@@ -709,7 +726,7 @@ __global__ __launch_bounds__(256) void prune_bits_kernel(const uint32_t* __restr
 
 void launch_prune(const Graph& g, const uint32_t* ebase, const uint32_t* ei, const uint32_t* ej, const float* es,
                   uint64_t E, uint64_t want, float key_floor, uint32_t* hist, uint64_t* mbits, float* smin,
-                  hipStream_t st) {
+                  uint32_t* klb, hipStream_t st) {
   // histogram window in key space: [bits(key_floor), bits(3.0f)], monotone in the value
   const uint32_t khi = 0x40400000u;  // 3.0f
   uint32_t klo;
@@ -737,17 +754,19 @@ void launch_prune(const Graph& g, const uint32_t* ebase, const uint32_t* ei, con
   if (tg == 4) SC_LAUNCH_SAMPLE(4); else if (tg == 8) SC_LAUNCH_SAMPLE(8); else if (tg == 32) SC_LAUNCH_SAMPLE(32); else if (tg == 64) SC_LAUNCH_SAMPLE(64); else SC_LAUNCH_SAMPLE(16);
 #undef SC_LAUNCH_SAMPLE
   hipLaunchKernelGGL(prune_bits_kernel, dim3((unsigned)((E + 255) / 256)), dim3(256), 0, st, hist, want, klo, shift, ei,
-                     ej, es, E, g.W, reinterpret_cast<unsigned long long*>(mbits), smin);
+                     ej, es, E, g.W, reinterpret_cast<unsigned long long*>(mbits), smin, klb);
 }
 
 // ------------------------------------------------------------------------------------------------
-// 4. radix select: window [lo, lo + 2048 << shift), <= 3 rounds down to shift 0
+// 4. radix select: window [lo, lo + SEL_BINS << shift), <= 3 rounds of SEL_BITS bits down to shift 0
 // ------------------------------------------------------------------------------------------------
-constexpr int SEL_BINS = 2048;
+constexpr int SEL_BITS = 12;  // key bits resolved per round
+constexpr int SEL_BINS = 1 << SEL_BITS;
+constexpr int SEL_PER = SEL_BINS / 256;  // bins per thread of the picking block
 constexpr int SEL_THREADS = 256;
 constexpr int SEL_ITEMS = 16;
 
-// current window of the select: keys in [lo, lo + 2^wbits), binned by (key - lo) >> shift into <= 2048 bins
+// current window of the select: keys in [lo, lo + 2^wbits), binned by (key - lo) >> shift into <= SEL_BINS bins
 struct SelWindow { uint32_t lo, wbits, shift; };
 __device__ __forceinline__ SelWindow select_window(const SelectState* sel) {
   SelWindow w;
@@ -759,7 +778,7 @@ __device__ __forceinline__ SelWindow select_window(const SelectState* sel) {
     w.lo = sel->lo;
     w.wbits = sel->wbits;
   }
-  w.shift = w.wbits > 11 ? w.wbits - 11 : 0u;
+  w.shift = w.wbits > (uint32_t)SEL_BITS ? w.wbits - (uint32_t)SEL_BITS : 0u;
   return w;
 }
 
@@ -833,13 +852,23 @@ __global__ __launch_bounds__(SEL_THREADS) void select_round_kernel(const uint32_
   }
   __syncthreads();
   if (!s_last) return;
-  // thread t owns bins [8t, 8t+8) counted from the TOP: bin index = 2047 - (8t + k)
-  uint32_t h[8];
+  // thread t owns bins [PER t, PER t + PER) counted from the TOP: bin index = SEL_BINS - 1 - (PER t + k)
+  static_assert(SEL_THREADS == 256, "SEL_PER assumes 256 picking threads");
+  // The bins were only ever touched by L2-side atomics; after an acquire by every wave of this block plain 16-byte
+  // loads see them (16 agent-scope atomic loads per thread serialise: ~0.8 us each, measured).
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  uint32_t h[SEL_PER];
   uint64_t mine = 0;
+  {
+    const uint4* __restrict__ h4 = reinterpret_cast<const uint4*>(&sel->hist[SEL_BINS - SEL_PER * (threadIdx.x + 1)]);
 #pragma unroll
-  for (int k = 0; k < 8; k++) {
-    h[k] = __hip_atomic_load(&sel->hist[SEL_BINS - 1 - (threadIdx.x * 8 + k)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    mine += h[k];
+    for (int q = 0; q < SEL_PER / 4; q++) {  // ascending in memory = descending from the top: reverse while unpacking
+      const uint4 v = h4[q];
+      const int k0 = SEL_PER - 4 * (q + 1);
+      h[k0 + 3] = v.x; h[k0 + 2] = v.y; h[k0 + 1] = v.z; h[k0] = v.w;
+    }
+#pragma unroll
+    for (int k = 0; k < SEL_PER; k++) mine += h[k];
   }
   if (threadIdx.x == 0) { s_bin = 0; s_above = above0; }
   uint64_t tot;
@@ -848,13 +877,16 @@ __global__ __launch_bounds__(SEL_THREADS) void select_round_kernel(const uint32_
   if (before < want && want <= before + mine) {
     uint64_t run = before;
 #pragma unroll
-    for (int k = 0; k < 8; k++) {
-      if (run < want && want <= run + h[k]) { s_bin = SEL_BINS - 1 - (threadIdx.x * 8 + k); s_above = run; }
+    for (int k = 0; k < SEL_PER; k++) {
+      if (run < want && want <= run + h[k]) { s_bin = SEL_BINS - 1 - (threadIdx.x * SEL_PER + k); s_above = run; }
       run += h[k];
     }
   }
   __syncthreads();
-  for (int b = threadIdx.x; b < SEL_BINS; b += SEL_THREADS) sel->hist[b] = 0;  // ready for the next round (next launch)
+  {  // ready for the next round (next launch)
+    uint4* __restrict__ z4 = reinterpret_cast<uint4*>(sel->hist);
+    for (int b = threadIdx.x; b < SEL_BINS / 4; b += SEL_THREADS) z4[b] = make_uint4(0u, 0u, 0u, 0u);
+  }
   if (threadIdx.x == 0) {
     const uint32_t nlo = win.lo + (s_bin << win.shift);
     sel->above = s_above;
@@ -866,12 +898,14 @@ __global__ __launch_bounds__(SEL_THREADS) void select_round_kernel(const uint32_
   }
 }
 
-void launch_select_rounds(const uint32_t* wkey, uint64_t M, SelectState* s, hipStream_t st) {
+void launch_select_rounds(const uint32_t* wkey, uint64_t M, SelectState* s, int rounds, hipStream_t st) {
   if (M == 0) return;
   uint64_t blocks = (M + (uint64_t)SEL_THREADS * SEL_ITEMS - 1) / ((uint64_t)SEL_THREADS * SEL_ITEMS);
-  if (blocks > 2048) blocks = 2048;
+  // 256 blocks measured best on C2 (1.5 M keys): every block pays an agent-scope release for its ticket
+  if (blocks > 256) blocks = 256;
+  if (const char* v = getenv("SC_SEL_BLOCKS")) { const uint64_t cap = (uint64_t)atoll(v); if (cap >= 1 && blocks > cap) blocks = cap; }
   if (blocks == 0) blocks = 1;
-  for (int round = 0; round < 3; round++)
+  for (int round = 0; round < rounds; round++)
     hipLaunchKernelGGL(select_round_kernel, dim3((unsigned)blocks), dim3(SEL_THREADS), 0, st, wkey, M, s);
 }
 

@@ -192,6 +192,19 @@ def test_register_degree_ranking_and_small_T(pkg, O, reg):
     _check_register(pkg, O, reg, scene, kw)
 
 
+@pytest.mark.parametrize("t_cmp", [0.5, 0.66, 0.67, 0.97])
+def test_register_select_window_both_forms(pkg, O, reg, t_cmp):
+    """Stage B's select takes its key window a priori ([certified bound or 2.0, 3.0], two rounds) when every edge
+    weight is provably >= 2/3, and from the measured key range (three rounds) otherwise: t_cmp on both sides of the
+    switch, against the CPU restatement; also the triangle list itself, pruned, against the unpruned one."""
+    cfg, scene = pkg.synth.make_config_scene("C1")
+    kw = cfg.params(); kw["t_cmp"] = t_cmp; kw["max_triangles"] = 4000
+    _check_register(pkg, O, reg, scene, kw)
+    tri_a, key_a, _, _ = reg.triangles(scene.src, scene.tgt, pkg.make_params(**kw))
+    tri_b, key_b, _, _ = reg.triangles(scene.src, scene.tgt, pkg.make_params(flags=pkg.SC_FLAG_NO_PRUNE, **kw))
+    assert np.array_equal(key_a, key_b) and np.array_equal(tri_a, tri_b)
+
+
 def test_register_deterministic_and_context_reuse(pkg, reg):
     """Same context, interleaved problem sizes (workspace grows, never shrinks): byte-identical repeats."""
     cfg1, s1 = pkg.synth.make_config_scene("C1")
