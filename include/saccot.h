@@ -56,7 +56,7 @@ extern "C" {
 /* flags */
 #define SC_FLAG_TIMING       1u /* record a HIP event pair around every stage and fill sc_stats.us_* (each record  */
                                 /* costs ~5 us of stream time: diagnostics, not for the timed loop)               */
-#define SC_FLAG_TIMING_HOT  16u /* only the two roofline kernels: us_compat and us_score (4 records per call)      */
+#define SC_FLAG_TIMING_HOT  16u /* only the dominant kernel: us_score (2 records per call)                          */
 #define SC_FLAG_EXACT_TOTAL  2u /* sc_stats.tri_total = 3-cliques of the WHOLE graph (one extra counting pass);  */
                                 /* default: 3-cliques of the pruned graph the top-T search actually enumerated   */
 #define SC_FLAG_REFINE       8u /* after C3, replace (R,t) by the fp64 least-squares refit over the winner's inlier  */

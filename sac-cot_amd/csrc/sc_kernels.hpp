@@ -61,7 +61,8 @@ struct Graph {
 // ebase[i] (u32, modular): CSR index of edge (i,k), k > i, is ebase[i] + wpre[i][k/64] + popc(bits[i][k/64] below k).
 // ebi[e] / ebj[e]: the bases of both ends of edge e (so an edge is fetched in one memory level).
 void launch_edge_fill(const Graph& g, const Points& pts, const Derived& dv, const uint64_t* edge_off, uint32_t* ei,
-                      uint32_t* ej, float* es, uint32_t* ebase, uint32_t* ebi, uint32_t* ebj, hipStream_t st);
+                      uint32_t* ej, float* es, uint32_t* ebase, uint32_t* ebi, uint32_t* ebj, uint64_t cap,
+                      hipStream_t st);
 // tcnt[e] = #k > j adjacent (in `mbits`) to both ends of edge e = (i,j); edges with es[e] < *smin count 0
 // (smin == nullptr: no pruning, mbits = g.bits).
 void launch_tri_count(const Graph& g, const uint64_t* mbits, const float* es, const float* smin, const uint32_t* ei,

@@ -71,7 +71,9 @@ __global__ __launch_bounds__(256) void edge_fill_kernel(const uint64_t* __restri
                                                         const uint32_t* __restrict__ deg,
                                                         const uint32_t* __restrict__ degp,
                                                         uint32_t* __restrict__ ebase, uint32_t* __restrict__ ebi,
-                                                        uint32_t* __restrict__ ebj) {
+                                                        uint32_t* __restrict__ ebj, uint64_t cap) {
+  // cap: entries the edge arrays hold.  The host may launch this kernel BEFORE it knows the edge count (into the
+  // arrays of the previous call, while it polls for the count); writes beyond cap are dropped and the host re-runs.
   constexpr int CH = 512;  // column indices staged per wave and chunk
   __shared__ uint32_t l_j[4][CH];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -109,6 +111,7 @@ __global__ __launch_bounds__(256) void edge_fill_kernel(const uint64_t* __restri
       for (uint32_t t = lane; t < cnt; t += 64) {
         const uint32_t j = l_j[wave][t];
         const uint64_t e = base + c0 + t;
+        if (e >= cap) continue;
         const float dp = dist3(pix, piy, piz, planes[j], planes[ld + j], planes[2 * ld + j]);
         const float dq = dist3(qix, qiy, qiz, planes[3 * ld + j], planes[4 * ld + j], planes[5 * ld + j]);
         bool edge;
@@ -127,9 +130,10 @@ __global__ __launch_bounds__(256) void edge_fill_kernel(const uint64_t* __restri
 }
 
 void launch_edge_fill(const Graph& g, const Points& pts, const Derived& dv, const uint64_t* edge_off, uint32_t* ei,
-                      uint32_t* ej, float* es, uint32_t* ebase, uint32_t* ebi, uint32_t* ebj, hipStream_t st) {
+                      uint32_t* ej, float* es, uint32_t* ebase, uint32_t* ebi, uint32_t* ebj, uint64_t cap,
+                      hipStream_t st) {
   hipLaunchKernelGGL(edge_fill_kernel, dim3((g.n + 3) / 4), dim3(256), 0, st, g.bits, pts.planes, dv, g.n, g.ld, g.W,
-                     edge_off, ei, ej, es, g.deg, g.degp, ebase, ebi, ebj);
+                     edge_off, ei, ej, es, g.deg, g.degp, ebase, ebi, ebj, cap);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -22,4 +22,4 @@ for world in (1, 2, 4, 8):
     for _ in range(K):
         reg.hypothesize_device(d_src.data_ptr(), d_tgt.data_ptr(), cfg.n, p, d_key.data_ptr()); _, st = reg.finalize_device(d_key.data_ptr(), d_Rt.data_ptr(), d_mask.data_ptr())
     torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / K
-    print(f"world={world} T_total={cfg.T*world} per-rank step {dt*1e3:.3f} ms -> job {cfg.T*world/dt/1e6:.1f} M hyp/s (efficiency vs linear {cfg.T*world/dt/ (world*104.2e6)*100:.0f}%)  tri_enum={st['tri_total']} compat={st['us_compat']:.0f}us score={st['us_score']:.0f}us scored={st['tri_scored']}")
+    print(f"world={world} T_total={cfg.T*world} per-rank step {dt*1e3:.3f} ms -> job {cfg.T*world/dt/1e6:.1f} M hyp/s (efficiency vs linear {cfg.T*world/dt/ (world*104.2e6)*100:.0f}%)  tri_enum={st['tri_total']} score={st['us_score']:.0f}us scored={st['tri_scored']}")
