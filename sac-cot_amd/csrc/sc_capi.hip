@@ -46,7 +46,7 @@ struct sc_ctx {
   // workspace
   Buf in_src, in_tgt, planes, S, bits, deg, degp, wpre, ebase, edge_off, scan_tmp, ei, ej, es, ebi, ebj, tcnt, toff, wkey, kcol, ctl, events, blk_gt,
       blk_eq, blk_minmax, bits2, off_gt, off_eq, sel_ord, sel_key, sortkey, sorted, sort_tmp, tri, tri_rk, key_rk, rt, rt_aos, partial, cnt, key, rt12,
-      mask, refine_tmp, amx_pairs;
+      mask, refine_tmp, amx_pairs, strong;
 
   // state of the last hypothesize call (consumed by finalize)
   int n = 0, ld = 0;
@@ -247,6 +247,9 @@ int run_triangles(sc_ctx* c, const sc_params* p) {
   // certified pruning (sc_tri.hip §3b): weight ranking only; pointless on tiny graphs
   const bool prune = may_prune(p) && E >= 4096;
   c->pruned = prune;
+  // counting pass + event list (sc_tri.hip 2b) on the pruned graph; SC_NO_EVENTS=1 keeps the row-walking pair
+  const bool use_events = prune && getenv("SC_NO_EVENTS") == nullptr;
+  StrongList sl{nullptr, nullptr, 0};
   const uint64_t* mbits = g.bits;
   const float* smin = nullptr;
   bool have_total = false;
@@ -259,17 +262,18 @@ int run_triangles(sc_ctx* c, const sc_params* p) {
       have_total = true;
     }
     // the smallest possible weight is ~3 t_cmp (every edge has s >= t_cmp up to rounding); 0.1 % slack
+    if (use_events) {  // the pruning kernel also compacts the strong edges for the counting pass
+      ENSURE(c, c->strong, strong_list_bytes(E));
+      sl = StrongList{c->strong.as<uint32_t>(), ctl->st_fill, strong_list_cap(E)};
+    }
     launch_prune(g, c->ebase.as<uint32_t>(), c->ei.as<uint32_t>(), c->ej.as<uint32_t>(), c->es.as<float>(), E,
                  p->max_triangles, 3.0f * p->t_cmp * 0.999f, ctl->prune_hist, c->bits2.as<uint64_t>(), &ctl->smin, &ctl->klb,
-                 st);
+                 sl, c->tcnt.as<uint32_t>(), st);
     mbits = c->bits2.as<uint64_t>();
     smin = &ctl->smin;
   }
   c->mbits = mbits;
   c->smin_ptr = smin;
-  // counting pass + event list (sc_tri.hip 2b); SC_NO_EVENTS=1 keeps the row-walking pair for comparison
-  // (only for a pruned graph: the unpruned one has too many events to be worth recording)
-  const bool use_events = prune && getenv("SC_NO_EVENTS") == nullptr;
   EventList ev{};
   if (use_events) {
     if (const char* capenv = getenv("SC_EVENT_CAP")) {  // test knob: force a (too) small event buffer
@@ -280,9 +284,8 @@ int run_triangles(sc_ctx* c, const sc_params* p) {
     c->pinned[5] = 0;
     ev = event_list(c->events.p, c->ev_capacity, g.W, c->ctl.as<ControlBlock>()->ev_fill,
                     reinterpret_cast<uint32_t*>(&c->pinned[5]));
-    launch_tri_count_events(g, mbits, smin, c->ebi.as<uint32_t>(), c->ebj.as<uint32_t>(), c->ei.as<uint32_t>(),
-                            c->ej.as<uint32_t>(),
-                            c->es.as<float>(), E, p->rank_mode, c->tcnt.as<uint32_t>(), ev, st);
+    launch_tri_count_events(g, mbits, sl, c->ebi.as<uint32_t>(), c->ebj.as<uint32_t>(), c->ei.as<uint32_t>(),
+                            c->ej.as<uint32_t>(), E, p->rank_mode, c->tcnt.as<uint32_t>(), ev, st);
   } else {
     launch_tri_count(g, mbits, c->es.as<float>(), smin, c->ei.as<uint32_t>(), c->ej.as<uint32_t>(), E,
                      c->tcnt.as<uint32_t>(), st);
@@ -442,7 +445,7 @@ void sc_destroy(sc_ctx* c) {
   Buf* bufs[] = {&c->in_src, &c->in_tgt, &c->planes, &c->S, &c->bits, &c->deg, &c->degp, &c->wpre, &c->ebase, &c->edge_off, &c->scan_tmp,
                  &c->ei, &c->ej, &c->es, &c->ebi, &c->ebj, &c->tcnt, &c->toff, &c->wkey, &c->kcol, &c->ctl, &c->events, &c->blk_gt, &c->blk_eq, &c->blk_minmax, &c->bits2, &c->off_gt,
                  &c->off_eq, &c->sel_ord, &c->sel_key, &c->sortkey, &c->sorted, &c->sort_tmp, &c->tri, &c->tri_rk, &c->key_rk, &c->rt,
-                 &c->rt_aos, &c->partial, &c->cnt, &c->key, &c->rt12, &c->mask, &c->refine_tmp, &c->amx_pairs};
+                 &c->rt_aos, &c->partial, &c->cnt, &c->key, &c->rt12, &c->mask, &c->refine_tmp, &c->amx_pairs, &c->strong};
   for (Buf* b : bufs) if (b->p) (void)hipFree(b->p);
   for (int i = 0; i < N_EVENTS; i++) if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
   if (c->pinned) (void)hipHostFree(c->pinned);

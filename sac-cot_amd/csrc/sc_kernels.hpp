@@ -67,12 +67,25 @@ void launch_edge_fill(const Graph& g, const Points& pts, const Derived& dv, cons
 // (smin == nullptr: no pruning, mbits = g.bits).
 void launch_tri_count(const Graph& g, const uint64_t* mbits, const float* es, const float* smin, const uint32_t* ei,
                       const uint32_t* ej, uint64_t E, uint32_t* tcnt, hipStream_t st);
+// Compact list of the strong edges (those of the pruned graph), written by the pruning kernel in ST_SHARDS regions of
+// `cap` entries (fill[r] = entries of region r; ST_SHARDS zeroed counters of the control block).  list == nullptr: off.
+constexpr int ST_SHARDS = 256;
+struct StrongList {
+  uint32_t* list;
+  uint32_t* fill;
+  uint32_t cap;
+};
+uint32_t strong_list_cap(uint64_t E);
+size_t strong_list_bytes(uint64_t E);
+
 // Certified pruning (weight ranking): samples every R-th edge's triangles into `hist` (2048 u32), derives the
 // strong-edge threshold *smin (device float; -1 = nothing certified) and builds the strong upper-triangle bit
 // matrix `mbits` (n x W, zeroed here).  key_floor: a value at or below the smallest possible triangle weight.
 void launch_prune(const Graph& g, const uint32_t* ebase, const uint32_t* ei, const uint32_t* ej, const float* es,
                   uint64_t E, uint64_t want, float key_floor, uint32_t* hist, uint64_t* mbits, float* smin,
-                  uint32_t* klb, hipStream_t st);  // hist and mbits must already be zero; *klb = key of the bound or 0
+                  uint32_t* klb, const StrongList& sl, uint32_t* tcnt,
+                  hipStream_t st);  // hist and mbits must already be zero; *klb = key of the bound or 0; with
+                                    // sl.list set it also compacts the strong edges and zeroes tcnt of the weak ones
 
 // Event list of stage B (sc_tri.hip 2b): one record per non-zero member word of a strong edge, SoA, split into
 // EV_SHARDS regions of shard_cap records; fill[shard] = records appended to that region.
@@ -92,8 +105,8 @@ struct EventList {
 size_t event_bytes(uint64_t capacity);
 EventList event_list(void* buf, uint64_t capacity, int W, uint32_t* fill, uint32_t* overflow_host);
 // counting pass that also emits the events (replaces launch_tri_count when an event buffer is available)
-void launch_tri_count_events(const Graph& g, const uint64_t* mbits, const float* smin, const uint32_t* ebi,
-                             const uint32_t* ebj, const uint32_t* ei, const uint32_t* ej, const float* es, uint64_t E, int rank_mode,
+void launch_tri_count_events(const Graph& g, const uint64_t* mbits, const StrongList& sl, const uint32_t* ebi,
+                             const uint32_t* ebj, const uint32_t* ei, const uint32_t* ej, uint64_t E, int rank_mode,
                              uint32_t* tcnt, const EventList& ev, hipStream_t st);
 
 // Radix-select state.  Lives in the context's control block, which ONE memset zeroes per call; key_range_kernel
@@ -115,6 +128,7 @@ static_assert(offsetof(SelectState, hist) % 16 == 0, "SelectState::hist must be 
 struct ControlBlock {
   uint32_t ev_fill[256];     // event-list region fill counters (EV_SHARDS)
   uint32_t prune_hist[256];  // sampled key histogram of the certified pruning
+  uint32_t st_fill[256];     // strong-edge list region fill counters (ST_SHARDS)
   float smin;                // strong-edge threshold (written by prune_bits_kernel)
   uint32_t amx_ticket;       // blocks-finished counter of score_argmax_kernel
   uint32_t klb;              // key of the certified lower bound of the pruning (0: none)

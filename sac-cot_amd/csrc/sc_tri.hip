@@ -398,20 +398,28 @@ __global__ __launch_bounds__(256) void tri_count_events_kernel(const uint64_t* _
                                                                const uint32_t* __restrict__ ebj,
                                                                const uint32_t* __restrict__ ei,
                                                                const uint32_t* __restrict__ ej,
-                                                               const float* __restrict__ es,
-                                                               const float* __restrict__ smin, uint64_t E,
-                                                               int rank_mode, uint32_t* __restrict__ tcnt,
-                                                               EventList ev) {
+                                                               StrongList sl, int rank_mode,
+                                                               uint32_t* __restrict__ tcnt, EventList ev) {
   constexpr int EVW = 192;  // records per wave segment: flush above 128, a round adds <= 64
   __shared__ uint64_t l_m[4 * EVW];
   __shared__ uint32_t l_wi[4 * EVW], l_wj[4 * EVW], l_a[4 * EVW], l_b[4 * EVW], l_e[4 * EVW], l_rb[4 * EVW];
+  __shared__ uint32_t l_pre[ST_SHARDS + 1];  // exclusive prefix of the strong-list region fills
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int gl = threadIdx.x & (TG - 1);
-  const float s_floor = smin ? *smin : -1.0f;
+  static_assert(ST_SHARDS == 256, "one region per thread");
+  {
+    __shared__ uint64_t plds[8];
+    const uint64_t v = sl.fill[threadIdx.x];
+    uint64_t tot;
+    l_pre[threadIdx.x] = (uint32_t)block_exscan_u64(v, plds, &tot);
+    if (threadIdx.x == 0) l_pre[ST_SHARDS] = (uint32_t)tot;
+  }
+  __syncthreads();
+  const uint64_t S = l_pre[ST_SHARDS];  // strong edges (only they can carry a triangle of the pruned graph)
   const uint64_t groups = (uint64_t)gridDim.x * (256 / TG);
   const uint64_t g0 = (uint64_t)blockIdx.x * (256 / TG) + (threadIdx.x / TG);
   const uint32_t shard = (blockIdx.x * 4 + wave) & (EV_SHARDS - 1);
-  const uint64_t trips = (E + groups - 1) / groups;  // the same for every lane of the wave
+  const uint64_t trips = (S + groups - 1) / groups;  // the same for every lane of the wave
   const int wbase = wave * EVW;
   uint32_t scnt = 0;  // records staged by this wave (wave-uniform)
   auto flush = [&]() {  // wave-uniform
@@ -432,11 +440,15 @@ __global__ __launch_bounds__(256) void tri_count_events_kernel(const uint64_t* _
     scnt = 0;
   };
   for (uint64_t trip = 0; trip < trips; trip++) {
-    const uint64_t e = g0 + trip * groups;
-    const bool on = e < E && es[e < E ? e : 0] >= s_floor;  // group-uniform
-    uint32_t rowi = 0, rowj = 0, fa = 0, fb = 0, c = 0;
+    const uint64_t x = g0 + trip * groups;  // position in the flat strong list
+    const bool on = x < S;                  // group-uniform
+    uint32_t e = 0, rowi = 0, rowj = 0, fa = 0, fb = 0, c = 0;
     int w0 = 0, jbit = 0, rounds = 0;
     if (on) {
+      int r = 0;  // region of x: the largest r with l_pre[r] <= x
+#pragma unroll
+      for (int step = ST_SHARDS / 2; step > 0; step >>= 1) r += (l_pre[r + step] <= (uint32_t)x) ? step : 0;
+      e = sl.list[(uint64_t)r * sl.cap + ((uint32_t)x - l_pre[r])];
       const uint32_t i = ei[e], j = ej[e];
       rowi = i * (uint32_t)W; rowj = j * (uint32_t)W;
       fa = (rank_mode == 0) ? ebi[e] : deg[i] + deg[j];  // weight mode: CSR bases; degree mode: the degree sum
@@ -462,13 +474,13 @@ __global__ __launch_bounds__(256) void tri_count_events_kernel(const uint64_t* _
         if (m) {
           const int q = wbase + (int)scnt + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32),
                                                    __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
-          l_m[q] = m; l_wi[q] = rowi + w; l_wj[q] = rowj + w; l_a[q] = fa; l_b[q] = fb; l_e[q] = (uint32_t)e; l_rb[q] = rb;
+          l_m[q] = m; l_wi[q] = rowi + w; l_wj[q] = rowj + w; l_a[q] = fa; l_b[q] = fb; l_e[q] = e; l_rb[q] = rb;
         }
         scnt += (uint32_t)__popcll(bal);
         if (scnt > (uint32_t)(EVW - 64)) flush();
       }
     }
-    if (gl == 0 && e < E) tcnt[e] = c;
+    if (gl == 0 && on) tcnt[e] = c;  // weak edges were zeroed by prune_bits_kernel
   }
   if (scnt) flush();
 }
@@ -592,16 +604,19 @@ EventList event_list(void* buf, uint64_t capacity, int W, uint32_t* fill, uint32
   return ev;
 }
 
-void launch_tri_count_events(const Graph& g, const uint64_t* mbits, const float* smin, const uint32_t* ebi,
-                             const uint32_t* ebj, const uint32_t* ei, const uint32_t* ej, const float* es, uint64_t E, int rank_mode,
+void launch_tri_count_events(const Graph& g, const uint64_t* mbits, const StrongList& sl, const uint32_t* ebi,
+                             const uint32_t* ebj, const uint32_t* ei, const uint32_t* ej, uint64_t E, int rank_mode,
                              uint32_t* tcnt, const EventList& ev, hipStream_t st) {
   if (E == 0) return;
   constexpr int TGV = 8;
   const uint64_t per = 256 / TGV;
-  uint64_t nb = (E + per - 1) / per;
+  // the strong edges are a fraction of E that only the device knows (20 - 45 % on C1 .. C4): size the grid for ~E/3
+  uint64_t nb = (E / 3 + per - 1) / per;
+  if (nb < 256) nb = 256;
   if (nb > 4096) nb = 4096;
+  if (const char* v = getenv("SC_CNT_BLOCKS")) { const uint64_t t = (uint64_t)atoll(v); if (t >= 1 && t <= 65535) nb = t; }
   hipLaunchKernelGGL(tri_count_events_kernel<TGV>, dim3((unsigned)nb), dim3(256), 0, st, mbits, g.W, g.deg, ebi, ebj, ei,
-                     ej, es, smin, E, rank_mode, tcnt, ev);
+                     ej, sl, rank_mode, tcnt, ev);
 }
 
 void launch_tri_keys_events(const Graph& g, const float* es, const uint64_t* toff, int rank_mode,
@@ -703,10 +718,11 @@ __global__ __launch_bounds__(256) void prune_bits_kernel(const uint32_t* __restr
                                                          const float* __restrict__ es, uint64_t E, int W,
                                                          unsigned long long* __restrict__ mbits,
                                                          float* __restrict__ smin_out,
-                                                         uint32_t* __restrict__ klb_out) {
+                                                         uint32_t* __restrict__ klb_out, StrongList sl,
+                                                         uint32_t* __restrict__ tcnt) {
   __shared__ uint64_t lds[8];
   __shared__ float s_smin;
-  __shared__ uint32_t s_klb;
+  __shared__ uint32_t s_klb, s_base, s_wcnt[4];
   static_assert(PR_BINS == 256, "one bin per thread, walked from the top");
   const uint32_t bin = PR_BINS - 1 - threadIdx.x;
   const uint64_t mine = hist[bin];
@@ -722,15 +738,43 @@ __global__ __launch_bounds__(256) void prune_bits_kernel(const uint32_t* __restr
   const float smin = s_smin;
   if (blockIdx.x == 0 && threadIdx.x == 0) { *smin_out = smin; *klb_out = s_klb; }
   const uint64_t e = (uint64_t)blockIdx.x * 256 + threadIdx.x;
-  if (e < E && es[e] >= smin) {
+  const bool strong = e < E && es[e] >= smin;
+  if (strong) {
     const uint32_t i = ei[e], j = ej[e];
     atomicOr(&mbits[(size_t)i * W + (j >> 6)], 1ull << (j & 63));
   }
+  if (sl.list) {
+    // the strong edges, compacted (any order: everything downstream is indexed by the edge id): one atomic per block
+    // on one of ST_SHARDS counters; region r receives the blocks with blockIdx % ST_SHARDS == r, so sl.cap =
+    // ceil(blocks / ST_SHARDS) * 256 entries can never overflow.  Weak edges carry no triangle: count 0.
+    if (e < E && !strong) tcnt[e] = 0u;
+    const uint64_t bal = __ballot(strong);
+    const int wave = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) s_wcnt[wave] = (uint32_t)__popcll(bal);
+    __syncthreads();
+    if (threadIdx.x == 0) {  // ONE atomic per block (returning atomics on a shared address cost ~170 ns each here)
+      const uint32_t tot = s_wcnt[0] + s_wcnt[1] + s_wcnt[2] + s_wcnt[3];
+      s_base = tot ? atomicAdd(&sl.fill[blockIdx.x & (ST_SHARDS - 1)], tot) : 0u;
+    }
+    __syncthreads();
+    if (strong) {
+      uint32_t pos = s_base + __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
+      for (int w = 0; w < wave; w++) pos += s_wcnt[w];
+      sl.list[(uint64_t)(blockIdx.x & (ST_SHARDS - 1)) * sl.cap + pos] = (uint32_t)e;
+    }
+  }
 }
+
+uint32_t strong_list_cap(uint64_t E) {
+  const uint64_t blocks = (E + 255) / 256;
+  return (uint32_t)(((blocks + ST_SHARDS - 1) / ST_SHARDS) * 256);
+}
+size_t strong_list_bytes(uint64_t E) { return (size_t)strong_list_cap(E) * ST_SHARDS * sizeof(uint32_t); }
+
 
 void launch_prune(const Graph& g, const uint32_t* ebase, const uint32_t* ei, const uint32_t* ej, const float* es,
                   uint64_t E, uint64_t want, float key_floor, uint32_t* hist, uint64_t* mbits, float* smin,
-                  uint32_t* klb, hipStream_t st) {
+                  uint32_t* klb, const StrongList& sl, uint32_t* tcnt, hipStream_t st) {
   // histogram window in key space: [bits(key_floor), bits(3.0f)], monotone in the value
   const uint32_t khi = 0x40400000u;  // 3.0f
   uint32_t klo;
@@ -758,7 +802,7 @@ void launch_prune(const Graph& g, const uint32_t* ebase, const uint32_t* ei, con
   if (tg == 4) SC_LAUNCH_SAMPLE(4); else if (tg == 8) SC_LAUNCH_SAMPLE(8); else if (tg == 32) SC_LAUNCH_SAMPLE(32); else if (tg == 64) SC_LAUNCH_SAMPLE(64); else SC_LAUNCH_SAMPLE(16);
 #undef SC_LAUNCH_SAMPLE
   hipLaunchKernelGGL(prune_bits_kernel, dim3((unsigned)((E + 255) / 256)), dim3(256), 0, st, hist, want, klo, shift, ei,
-                     ej, es, E, g.W, reinterpret_cast<unsigned long long*>(mbits), smin, klb);
+                     ej, es, E, g.W, reinterpret_cast<unsigned long long*>(mbits), smin, klb, sl, tcnt);
 }
 
 // ------------------------------------------------------------------------------------------------
