@@ -126,7 +126,7 @@ static_assert(offsetof(SelectState, hist) % 16 == 0, "SelectState::hist must be 
 
 // Per-call control block (device memory, zeroed by one hipMemsetAsync at the start of every call).
 struct ControlBlock {
-  uint32_t ev_fill[256];     // event-list region fill counters (EV_SHARDS)
+  uint32_t ev_fill[1024];    // event-list region fill counters (EV_SHARDS)
   uint32_t prune_hist[256];  // sampled key histogram of the certified pruning
   uint32_t st_fill[256];     // strong-edge list region fill counters (ST_SHARDS)
   float smin;                // strong-edge threshold (written by prune_bits_kernel)
