@@ -266,7 +266,8 @@ int run_triangles(sc_ctx* c, const sc_params* p) {
       ENSURE(c, c->strong, strong_list_bytes(E));
       sl = StrongList{c->strong.as<uint32_t>(), ctl->st_fill, strong_list_cap(E)};
     }
-    launch_prune(g, c->ebase.as<uint32_t>(), c->ei.as<uint32_t>(), c->ej.as<uint32_t>(), c->es.as<float>(), E,
+    launch_prune(g, c->ebi.as<uint32_t>(), c->ebj.as<uint32_t>(), c->ei.as<uint32_t>(), c->ej.as<uint32_t>(),
+                 c->es.as<float>(), E,
                  p->max_triangles, 3.0f * p->t_cmp * 0.999f, ctl->prune_hist, c->bits2.as<uint64_t>(), &ctl->smin, &ctl->klb,
                  sl, c->tcnt.as<uint32_t>(), st);
     mbits = c->bits2.as<uint64_t>();

@@ -81,7 +81,8 @@ size_t strong_list_bytes(uint64_t E);
 // Certified pruning (weight ranking): samples every R-th edge's triangles into `hist` (2048 u32), derives the
 // strong-edge threshold *smin (device float; -1 = nothing certified) and builds the strong upper-triangle bit
 // matrix `mbits` (n x W, zeroed here).  key_floor: a value at or below the smallest possible triangle weight.
-void launch_prune(const Graph& g, const uint32_t* ebase, const uint32_t* ei, const uint32_t* ej, const float* es,
+void launch_prune(const Graph& g, const uint32_t* ebi, const uint32_t* ebj, const uint32_t* ei, const uint32_t* ej,
+                  const float* es,
                   uint64_t E, uint64_t want, float key_floor, uint32_t* hist, uint64_t* mbits, float* smin,
                   uint32_t* klb, const StrongList& sl, uint32_t* tcnt,
                   hipStream_t st);  // hist and mbits must already be zero; *klb = key of the bound or 0; with

@@ -659,7 +659,8 @@ __device__ __forceinline__ uint32_t prune_bin(uint32_t key, uint32_t klo, uint32
 template <int TG>
 __global__ __launch_bounds__(256) void tri_sample_hist_kernel(const uint64_t* __restrict__ bits, int W,
                                                               const uint32_t* __restrict__ wpre,
-                                                              const uint32_t* __restrict__ ebase,
+                                                              const uint32_t* __restrict__ ebi,
+                                                              const uint32_t* __restrict__ ebj,
                                                               const uint32_t* __restrict__ ei,
                                                               const uint32_t* __restrict__ ej,
                                                               const float* __restrict__ es, uint64_t E,
@@ -677,23 +678,43 @@ __global__ __launch_bounds__(256) void tri_sample_hist_kernel(const uint64_t* __
     const uint32_t rowi = i * (uint32_t)W, rowj = j * (uint32_t)W;
     const int w0 = j >> 6;
     const float s_ij = es[e];
-    const uint32_t ebi = ebase[i], ebj = ebase[j];
-    for (int w = w0 + gl; w < W; w += TG) {  // no cross-lane step at all: every lane owns its words
-      const uint64_t ai = bits[rowi + w], aj = bits[rowj + w];
-      uint64_t m = ai & aj;
-      if (w == w0) m &= mask_above(j & 63);
-      if (m) {
-        const uint32_t pi = ebi + wpre[rowi + w], pj = ebj + wpre[rowj + w];
-        while (m) {
+    const uint32_t bi = ebi[e], bj = ebj[e];  // the CSR bases travel with the edge: same memory level as ei / ej
+    // No cross-lane step: every lane owns its words.  The loads of RB rounds are issued together, level by level (row
+    // words -> prefix words -> weights).  Measured on C2: 33 us either way — the time is not the per-round latency chain
+    // but gather / LDS-atomic throughput: most sampled edges join two inliers (the inlier clique holds ~60 % of all
+    // edges) with ~250 common neighbours above j each, i.e. ~8 M key evaluations per call.
+    constexpr int RB = 4;
+    for (int wb = w0 + gl; wb < W; wb += TG * RB) {
+      uint64_t ai[RB], aj[RB], m[RB];
+#pragma unroll
+      for (int r = 0; r < RB; r++) {  // level 1: row words
+        const int w = wb + r * TG;
+        const bool live = w < W;
+        ai[r] = bits[rowi + (live ? w : w0)];
+        aj[r] = bits[rowj + (live ? w : w0)];
+        m[r] = live ? (ai[r] & aj[r]) : 0ull;
+        if (w == w0) m[r] &= mask_above(j & 63);
+      }
+      uint32_t pi[RB], pj[RB];
+#pragma unroll
+      for (int r = 0; r < RB; r++) {  // level 2: prefix words (idle slots re-read the row's first one)
+        const int w = wb + r * TG;
+        pi[r] = bi + wpre[rowi + (m[r] ? w : w0)];
+        pj[r] = bj + wpre[rowj + (m[r] ? w : w0)];
+      }
+#pragma unroll
+      for (int r = 0; r < RB; r++) {  // level 3: weights of the common neighbours, four at a time
+        uint64_t mr = m[r];
+        while (mr) {
           int b[4];
-          const int nbits = pop4(m, b);
+          const int nbits = pop4(mr, b);
           float s_ik[4], s_jk[4];
 #pragma unroll
           for (int q = 0; q < 4; q++) {
             const uint64_t below = (1ull << b[q]) - 1ull;
             const bool live = q < nbits;
-            s_ik[q] = es[live ? pi + (uint32_t)__popcll(ai & below) : 0u];
-            s_jk[q] = es[live ? pj + (uint32_t)__popcll(aj & below) : 0u];
+            s_ik[q] = es[live ? pi[r] + (uint32_t)__popcll(ai[r] & below) : 0u];
+            s_jk[q] = es[live ? pj[r] + (uint32_t)__popcll(aj[r] & below) : 0u];
           }
 #pragma unroll
           for (int q = 0; q < 4; q++)
@@ -776,7 +797,8 @@ uint32_t strong_list_cap(uint64_t E) {
 size_t strong_list_bytes(uint64_t E) { return (size_t)strong_list_cap(E) * ST_SHARDS * sizeof(uint32_t); }
 
 
-void launch_prune(const Graph& g, const uint32_t* ebase, const uint32_t* ei, const uint32_t* ej, const float* es,
+void launch_prune(const Graph& g, const uint32_t* ebi, const uint32_t* ebj, const uint32_t* ei, const uint32_t* ej,
+                  const float* es,
                   uint64_t E, uint64_t want, float key_floor, uint32_t* hist, uint64_t* mbits, float* smin,
                   uint32_t* klb, const StrongList& sl, uint32_t* tcnt, hipStream_t st) {
   // histogram window in key space: [bits(key_floor), bits(3.0f)], monotone in the value
@@ -802,7 +824,7 @@ void launch_prune(const Graph& g, const uint32_t* ebase, const uint32_t* ei, con
   // about one sampled edge per group: the kernel's time is the dependent-load chain of its heaviest edges, so
   // stacking several edges per group only adds to it (measured: 256 blocks 70 us, 1024+ blocks 35 us on C2)
   if (nb > 4096) nb = 4096;
-#define SC_LAUNCH_SAMPLE(TGV) hipLaunchKernelGGL(tri_sample_hist_kernel<TGV>, dim3((unsigned)nb), dim3(256), 0, st, g.bits, g.W, g.wpre, ebase, ei, ej, es, E, (uint32_t)stride, klo, shift, hist)
+#define SC_LAUNCH_SAMPLE(TGV) hipLaunchKernelGGL(tri_sample_hist_kernel<TGV>, dim3((unsigned)nb), dim3(256), 0, st, g.bits, g.W, g.wpre, ebi, ebj, ei, ej, es, E, (uint32_t)stride, klo, shift, hist)
   if (tg == 4) SC_LAUNCH_SAMPLE(4); else if (tg == 8) SC_LAUNCH_SAMPLE(8); else if (tg == 32) SC_LAUNCH_SAMPLE(32); else if (tg == 64) SC_LAUNCH_SAMPLE(64); else SC_LAUNCH_SAMPLE(16);
 #undef SC_LAUNCH_SAMPLE
   hipLaunchKernelGGL(prune_bits_kernel, dim3((unsigned)((E + 255) / 256)), dim3(256), 0, st, hist, want, klo, shift, ei,
