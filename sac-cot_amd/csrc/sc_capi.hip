@@ -522,7 +522,8 @@ int sc_finalize_device(sc_ctx* c, const uint64_t* d_key, float* d_Rt, uint8_t* d
   if ((rc = rec(c, 7))) return rc;
   arm_word(c, 8);
   launch_finalize(points_of(c), c->tri.as<uint32_t>(), c->T_eff ? c->sel_key.as<uint32_t>() : nullptr, c->T_eff, d_key,
-                  c->dv.tau2, d_Rt, d_mask, &c->pinned[8], c->stream);
+                  c->dv.tau2, d_Rt, d_mask, &c->ctl.as<ControlBlock>()->fin_rank, &c->ctl.as<ControlBlock>()->fin_ticket,
+                  &c->pinned[8], c->stream);
   if (c->refine) {  // fp64 least-squares refit over the winner's inliers (mask unchanged)
     ENSURE(c, c->refine_tmp, refine_scratch_bytes(c->n));
     launch_refine(points_of(c), d_mask, d_key, c->refine_tmp.as<double>(), d_Rt, c->stream);

@@ -133,7 +133,8 @@ struct ControlBlock {
   float smin;                // strong-edge threshold (written by prune_bits_kernel)
   uint32_t amx_ticket;       // blocks-finished counter of score_argmax_kernel
   uint32_t klb;              // key of the certified lower bound of the pruning (0: none)
-  uint32_t pad0[13];
+  uint32_t fin_rank, fin_ticket;  // finalize_kernel: rank-count accumulator, blocks-finished counter (left zero)
+  uint32_t pad0[11];
   uint64_t key2[2];          // internal winner key pair (sc_register_device)
   uint64_t pad1[6];
   SelectState sel;
@@ -205,8 +206,8 @@ void launch_argmax(const Points& pts, const Shard& sh, const uint32_t* partial, 
 // sel_key / T: the ordinal-ordered ranking keys (for the winner's rank index); host_out (pinned, 3 x u64) receives
 // key2[0], the winner's position and its rank index.
 void launch_finalize(const Points& pts, const uint32_t* tri, const uint32_t* sel_key, uint32_t T,
-                     const uint64_t* key2, float tau2, float* Rt12, uint8_t* mask, uint64_t* host_out,
-                     hipStream_t st);
+                     const uint64_t* key2, float tau2, float* Rt12, uint8_t* mask, uint32_t* rank_acc,
+                     uint32_t* ticket, uint64_t* host_out, hipStream_t st);
 // SURVEY §8f-2 (SC_FLAG_REFINE): fp64 least-squares refit of Rt12 over the inlier mask; no-op when key2[0] == 0 or
 // fewer than 3 inliers.  scratch: refine_scratch_bytes(n).
 size_t refine_scratch_bytes(int n);

@@ -386,15 +386,21 @@ void launch_argmax(const Points& pts, const Shard& sh, const uint32_t* partial, 
 // ------------------------------------------------------------------------------------------------
 // C3
 // ------------------------------------------------------------------------------------------------
-// One block: thread 0 re-solves the winner while everybody counts its rank index
-// (#keys above the winner's + #equal keys at lower positions) — the number the ranked list would have given it.
-__global__ __launch_bounds__(1024) void winner_kernel(const float* __restrict__ planes, int ld,
-                                                     const uint32_t* __restrict__ tri,
-                                                     const uint32_t* __restrict__ sel_key, uint32_t T,
-                                                     const unsigned long long* __restrict__ key2,
-                                                     float* __restrict__ Rt12,
-                                                     unsigned long long* __restrict__ host_out) {
-  __shared__ uint64_t lds[16];
+// C3 in ONE launch: every block re-solves the winner (thread 0; deterministic, so all blocks hold the same R,t) while
+// its other threads count their slice of the winner's rank index (#keys above the winner's + #equal keys at lower
+// positions — the number the ranked list would have given it), then masks its 256 correspondences.  The slice counts
+// meet in a control-block counter; the block that takes the last ticket publishes (key, position, rank) to the host.
+// (A single-block rank count cost 42 us at T = 400 k; a separate mask launch another ~4.5 us floor.)
+__global__ __launch_bounds__(256) void finalize_kernel(const float* __restrict__ planes, int n, int ld,
+                                                       const uint32_t* __restrict__ tri,
+                                                       const uint32_t* __restrict__ sel_key, uint32_t T,
+                                                       const unsigned long long* __restrict__ key2, float tau2,
+                                                       float* __restrict__ Rt12, uint8_t* __restrict__ mask,
+                                                       uint32_t* __restrict__ rank_acc, uint32_t* __restrict__ ticket,
+                                                       unsigned long long* __restrict__ host_out) {
+  __shared__ uint64_t lds[8];
+  __shared__ float sRt[12];
+  __shared__ uint32_t s_last;
   const unsigned long long k0 = key2[0];
   const bool two_stage = sel_key != nullptr;
   uint32_t g = 0;
@@ -407,15 +413,18 @@ __global__ __launch_bounds__(1024) void winner_kernel(const float* __restrict__ 
       kabsch3(P, Q, Rt);
     }
 #pragma unroll
-    for (int c = 0; c < 12; c++) Rt12[c] = Rt[c];
+    for (int c = 0; c < 12; c++) sRt[c] = Rt[c];
+    if (blockIdx.x == 0) {
+#pragma unroll
+      for (int c = 0; c < 12; c++) Rt12[c] = Rt[c];
+    }
   }
-  uint64_t rank = g;
+  uint32_t r = 0;
   if (two_stage && k0 != 0) {
     const uint32_t wk = sel_key[g];
-    uint32_t r = 0;
-    const uint32_t T4 = T >> 2;  // 16-byte loads, all independent: the loop is a handful of trips
+    const uint32_t T4 = T >> 2;  // 16-byte loads, grid-strided
     const uint4* __restrict__ k4 = reinterpret_cast<const uint4*>(sel_key);
-    for (uint32_t q = threadIdx.x; q < T4; q += 1024) {
+    for (uint32_t q = blockIdx.x * 256 + threadIdx.x; q < T4; q += gridDim.x * 256) {
       const uint4 v = k4[q];
       const uint32_t t = q << 2;
       r += (v.x > wk) || (v.x == wk && t < g);
@@ -423,16 +432,38 @@ __global__ __launch_bounds__(1024) void winner_kernel(const float* __restrict__ 
       r += (v.z > wk) || (v.z == wk && t + 2 < g);
       r += (v.w > wk) || (v.w == wk && t + 3 < g);
     }
-    for (uint32_t t = (T4 << 2) + threadIdx.x; t < T; t += 1024) {
-      const uint32_t kt = sel_key[t];
-      r += (kt > wk) || (kt == wk && t < g);
+    if (blockIdx.x == 0) {
+      const uint32_t t = (T4 << 2) + threadIdx.x;  // the last T % 4 keys
+      if (t < T) { const uint32_t kt = sel_key[t]; r += (kt > wk) || (kt == wk && t < g); }
     }
-    rank = block_reduce_u64(r, lds);
   }
-  if (threadIdx.x == 0 && host_out) {  // [0] last: the host polls it (release orders the other two before it)
-    host_out[1] = g;
-    host_out[2] = k0 ? rank : 0;
-    publish_host(reinterpret_cast<uint64_t*>(host_out), k0);
+  const uint64_t rb = block_reduce_u64(r, lds);  // also the barrier that publishes sRt to the block
+  const int m = blockIdx.x * 256 + threadIdx.x;
+  if (m < n) {
+    float M[12];
+#pragma unroll
+    for (int c = 0; c < 12; c++) M[c] = sRt[c];
+    const bool live = k0 != 0ull && finite12(M);
+    const float d2 = resid2(M, planes[m], planes[(size_t)ld + m], planes[2 * (size_t)ld + m],
+                            planes[3 * (size_t)ld + m], planes[4 * (size_t)ld + m], planes[5 * (size_t)ld + m]);
+    mask[m] = (live && d2 < tau2) ? 1 : 0;
+  }
+  if (threadIdx.x == 0) {
+    if (rb) __hip_atomic_fetch_add(rank_acc, (uint32_t)rb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    const uint32_t t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    s_last = (t == gridDim.x - 1) ? 1u : 0u;
+    if (s_last) {
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      const uint32_t rank = __hip_atomic_load(rank_acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(rank_acc, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // ready for the next call
+      __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (host_out) {  // [0] last: the host polls it (release orders the other two before it)
+        host_out[1] = g;
+        host_out[2] = k0 ? (two_stage ? (unsigned long long)rank : (unsigned long long)g) : 0ull;
+        publish_host(reinterpret_cast<uint64_t*>(host_out), k0);
+      }
+    }
   }
 }
 
@@ -452,13 +483,14 @@ __global__ __launch_bounds__(256) void mask_kernel(const float* __restrict__ pla
 }
 
 void launch_finalize(const Points& pts, const uint32_t* tri, const uint32_t* sel_key, uint32_t T,
-                     const uint64_t* key2, float tau2, float* Rt12, uint8_t* mask, uint64_t* host_out,
-                     hipStream_t st) {
-  hipLaunchKernelGGL(winner_kernel, dim3(1), dim3(1024), 0, st, pts.planes, pts.ld, tri, sel_key, T,
-                     reinterpret_cast<const unsigned long long*>(key2), Rt12,
+                     const uint64_t* key2, float tau2, float* Rt12, uint8_t* mask, uint32_t* rank_acc,
+                     uint32_t* ticket, uint64_t* host_out, hipStream_t st) {
+  uint32_t blocks = (uint32_t)((pts.n + 255) / 256);  // the mask needs these; more only if the key list is long
+  const uint32_t for_keys = (T / 4 + 1023) / 1024;    // >= 4 uint4 per thread before another block pays off
+  if (for_keys > blocks) blocks = for_keys < 1024u ? for_keys : 1024u;
+  hipLaunchKernelGGL(finalize_kernel, dim3(blocks), dim3(256), 0, st, pts.planes, pts.n, pts.ld, tri, sel_key, T,
+                     reinterpret_cast<const unsigned long long*>(key2), tau2, Rt12, mask, rank_acc, ticket,
                      reinterpret_cast<unsigned long long*>(host_out));
-  hipLaunchKernelGGL(mask_kernel, dim3((pts.n + 255) / 256), dim3(256), 0, st, pts.planes, pts.n, pts.ld, Rt12,
-                     reinterpret_cast<const unsigned long long*>(key2), tau2, mask);
 }
 
 // ------------------------------------------------------------------------------------------------

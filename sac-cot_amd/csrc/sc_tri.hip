@@ -1106,6 +1106,7 @@ constexpr int DEC_COARSE = 4096;  // coarse index entries staged in LDS (32 KiB)
 
 // cshift: the coarse index holds toff[k << cshift], k = 0 .. nc-1 (nc <= DEC_COARSE): the binary search for the edge
 // of an ordinal runs ~12 steps in LDS and only cshift steps in global memory.
+template <int ITEMS>
 __global__ __launch_bounds__(256) void tri_decode_kernel(const uint32_t* __restrict__ ei,
                                                          const uint32_t* __restrict__ ej,
                                                          const uint32_t* __restrict__ kcol,
@@ -1116,25 +1117,28 @@ __global__ __launch_bounds__(256) void tri_decode_kernel(const uint32_t* __restr
   const uint32_t nc = (uint32_t)(((E + 1) + ((1ull << cshift) - 1)) >> cshift);  // entries k with (k << cshift) <= E
   for (uint32_t k = threadIdx.x; k < nc; k += 256) coarse[k] = toff[(uint64_t)k << cshift];
   __syncthreads();
-  const uint32_t t = blockIdx.x * 256 + threadIdx.x;
-  if (t >= T) return;
-  const uint64_t ord = sel_ord[t];
-  const uint32_t k3 = kcol[ord];  // the third vertex was stored at the ordinal by the key kernel: no row walk here
-  // largest k with coarse[k] <= ord
-  uint32_t klo = 0, khi = nc;
-  while (khi - klo > 1) {
-    const uint32_t mid = (klo + khi) >> 1;
-    if (coarse[mid] <= ord) klo = mid; else khi = mid;
+#pragma unroll
+  for (int it = 0; it < ITEMS; it++) {  // ITEMS positions per thread share one coarse-index build
+    const uint32_t t = (blockIdx.x * ITEMS + it) * 256 + threadIdx.x;
+    if (t >= T) continue;
+    const uint64_t ord = sel_ord[t];
+    const uint32_t k3 = kcol[ord];  // the third vertex was stored at the ordinal by the key kernel: no row walk here
+    // largest k with coarse[k] <= ord
+    uint32_t klo = 0, khi = nc;
+    while (khi - klo > 1) {
+      const uint32_t mid = (klo + khi) >> 1;
+      if (coarse[mid] <= ord) klo = mid; else khi = mid;
+    }
+    // largest e in [klo << cshift, ...) with toff[e] <= ord  (toff has E+1 entries, toff[E] = M > ord)
+    uint64_t lo = (uint64_t)klo << cshift, hi = min(((uint64_t)klo + 1) << cshift, E);
+    while (hi - lo > 1) {
+      const uint64_t mid = (lo + hi) >> 1;
+      if (toff[mid] <= ord) lo = mid; else hi = mid;
+    }
+    tri[3 * (size_t)t] = ei[lo];
+    tri[3 * (size_t)t + 1] = ej[lo];
+    tri[3 * (size_t)t + 2] = k3;
   }
-  // largest e in [klo << cshift, ...) with toff[e] <= ord  (toff has E+1 entries, toff[E] = M > ord)
-  uint64_t lo = (uint64_t)klo << cshift, hi = min(((uint64_t)klo + 1) << cshift, E);
-  while (hi - lo > 1) {
-    const uint64_t mid = (lo + hi) >> 1;
-    if (toff[mid] <= ord) lo = mid; else hi = mid;
-  }
-  tri[3 * (size_t)t] = ei[lo];
-  tri[3 * (size_t)t + 1] = ej[lo];
-  tri[3 * (size_t)t + 2] = k3;
 }
 
 void launch_tri_decode(const uint32_t* ei, const uint32_t* ej, const uint32_t* kcol, const uint64_t* toff, uint64_t E,
@@ -1142,8 +1146,14 @@ void launch_tri_decode(const uint32_t* ei, const uint32_t* ej, const uint32_t* k
   if (T == 0) return;
   int cshift = 0;
   while ((((E + 1) + ((1ull << cshift) - 1)) >> cshift) > (uint64_t)DEC_COARSE) cshift++;
-  hipLaunchKernelGGL(tri_decode_kernel, dim3((T + 255) / 256), dim3(256), 0, st, ei, ej, kcol, toff, E, cshift, sel_ord,
-                     T, tri);
+  // long lists: four positions per thread, so the 32 KiB coarse index is built a quarter as often (400 k positions:
+  // 28 -> see DESIGN.md); short ones keep one per thread (more workgroups than CUs matters more there)
+  if (T > 131072u)
+    hipLaunchKernelGGL(tri_decode_kernel<4>, dim3((T + 1023) / 1024), dim3(256), 0, st, ei, ej, kcol, toff, E, cshift,
+                       sel_ord, T, tri);
+  else
+    hipLaunchKernelGGL(tri_decode_kernel<1>, dim3((T + 255) / 256), dim3(256), 0, st, ei, ej, kcol, toff, E, cshift,
+                       sel_ord, T, tri);
 }
 
 // ---- ranked order for the stage hook: sort (~key, position), then gather
