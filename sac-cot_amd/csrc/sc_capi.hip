@@ -299,10 +299,10 @@ int run_triangles(sc_ctx* c, const sc_params* p) {
   const uint64_t M = c->M = c->pinned[2];
   if (M == 0) return SC_OK;
   const uint32_t T_eff = c->T_eff = (uint32_t)(M < p->max_triangles ? M : p->max_triangles);
-  if (M * 8 > c->cap_bytes) { c->last_error = "triangle keys exceed the workspace cap"; return SC_ETOOMANY; }
+  if (M * 12 > c->cap_bytes) { c->last_error = "triangle keys exceed the workspace cap"; return SC_ETOOMANY; }
   const size_t nb = compact_blocks(M);
   ENSURE(c, c->wkey, M * 4);
-  ENSURE(c, c->kcol, M * 4);
+  ENSURE(c, c->kcol, M * 8);
   ENSURE(c, c->blk_minmax, 2 * 8192 * 4);
   ENSURE(c, c->blk_gt, nb * 4);
   ENSURE(c, c->blk_eq, nb * 4);
@@ -326,12 +326,12 @@ int run_triangles(sc_ctx* c, const sc_params* p) {
   const bool fast_window = events_ok && p->rank_mode == SC_RANK_WEIGHT && 3.0f * p->t_cmp * 0.999f >= 2.0f;
   if (events_ok)
     launch_tri_keys_events(g, c->es.as<float>(), c->toff.as<uint64_t>(), p->rank_mode, ev, c->wkey.as<uint32_t>(),
-                           c->kcol.as<uint32_t>(), c->blk_minmax.as<uint32_t>(), sel, T_eff,
+                           c->kcol.as<uint2>(), c->blk_minmax.as<uint32_t>(), sel, T_eff,
                            fast_window ? &c->ctl.as<ControlBlock>()->klb : nullptr, st);
   else
     launch_tri_keys(g, mbits, smin, c->ebase.as<uint32_t>(), c->ei.as<uint32_t>(), c->ej.as<uint32_t>(),
                     c->es.as<float>(), c->toff.as<uint64_t>(), E, p->rank_mode, c->wkey.as<uint32_t>(),
-                    c->kcol.as<uint32_t>(), c->blk_minmax.as<uint32_t>(), sel, T_eff, st);
+                    c->kcol.as<uint2>(), c->blk_minmax.as<uint32_t>(), sel, T_eff, st);
   if (c->timing) HIPCHK(c, hipEventRecord(c->ev[10], st));
   c->timed_trikeys = c->timing;
   launch_select_rounds(c->wkey.as<uint32_t>(), M, sel, fast_window ? 2 : 3, st);
@@ -345,8 +345,8 @@ int run_triangles(sc_ctx* c, const sc_params* p) {
                        self_off ? nullptr : c->off_gt.as<uint64_t>(), self_off ? nullptr : c->off_eq.as<uint64_t>(),
                        c->sel_ord.as<uint64_t>(), c->sel_key.as<uint32_t>(), st);
   // the list stays in ordinal order: no sort on the hot path (the winner is found by (count, key, position))
-  launch_tri_decode(c->ei.as<uint32_t>(), c->ej.as<uint32_t>(), c->kcol.as<uint32_t>(), c->toff.as<uint64_t>(), E,
-                    c->sel_ord.as<uint64_t>(), T_eff, c->tri.as<uint32_t>(), st);
+  launch_tri_decode(c->ei.as<uint32_t>(), c->ej.as<uint32_t>(), c->kcol.as<uint2>(), c->sel_ord.as<uint64_t>(), T_eff,
+                    c->tri.as<uint32_t>(), st);
   return SC_OK;
 }
 

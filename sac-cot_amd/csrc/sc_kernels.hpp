@@ -145,11 +145,11 @@ static_assert(offsetof(ControlBlock, sel) % 16 == 0, "ControlBlock::sel must be 
 // blk_minmax: 2 * 8192 u32 scratch (per-block key min / max, reduced into s->kmin / s->kmax; s->want = want).
 void launch_tri_keys(const Graph& g, const uint64_t* mbits, const float* smin, const uint32_t* ebase,
                      const uint32_t* ei, const uint32_t* ej, const float* es, const uint64_t* toff, uint64_t E,
-                     int rank_mode, uint32_t* wkey, uint32_t* kcol, uint32_t* blk_minmax, SelectState* s,
-                     uint64_t want, hipStream_t st);  // kcol[ordinal] = the triangle's third vertex
+                     int rank_mode, uint32_t* wkey, uint2* kcol, uint32_t* blk_minmax, SelectState* s,
+                     uint64_t want, hipStream_t st);  // kcol[ordinal] = {the triangle's third vertex, its edge id}
 // keys from the event list (replaces launch_tri_keys when no region overflowed)
 void launch_tri_keys_events(const Graph& g, const float* es, const uint64_t* toff, int rank_mode,
-                            const EventList& ev, uint32_t* wkey, uint32_t* kcol, uint32_t* blk_minmax,
+                            const EventList& ev, uint32_t* wkey, uint2* kcol, uint32_t* blk_minmax,
                             SelectState* s, uint64_t want, const uint32_t* klb, hipStream_t st);
 // klb != nullptr (weight ranking, every edge weight >= 2/3): the kernel presets the select window to
 // [*klb or 2.0, 3.0] and no key-range pass runs; two select rounds then always suffice.
@@ -166,8 +166,8 @@ void launch_compact_write(const uint32_t* wkey, uint64_t M, const SelectState* s
 size_t sort_temp_bytes(size_t n);
 void launch_sort_u64(const uint64_t* in, uint64_t* out, size_t n, void* temp, size_t temp_bytes, hipStream_t st);
 // selected position -> (i,j,k); the list stays in ordinal ((i,j,k) ascending) order
-void launch_tri_decode(const uint32_t* ei, const uint32_t* ej, const uint32_t* kcol, const uint64_t* toff, uint64_t E,
-                       const uint64_t* sel_ord, uint32_t T, uint32_t* tri, hipStream_t st);
+void launch_tri_decode(const uint32_t* ei, const uint32_t* ej, const uint2* kcol, const uint64_t* sel_ord, uint32_t T,
+                       uint32_t* tri, hipStream_t st);
 // ranked order (key desc, ordinal asc) of the ordinal-ordered list: only the stage hook needs it
 void launch_rank_order(const uint32_t* tri, const uint32_t* sel_key, uint32_t T, uint64_t* sortkey, uint64_t* sorted,
                        void* sort_tmp, size_t sort_bytes, uint32_t* tri_ranked, uint32_t* key_ranked, hipStream_t st);

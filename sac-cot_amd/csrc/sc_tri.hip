@@ -244,7 +244,7 @@ __global__ __launch_bounds__(256) void tri_keys_kernel(const uint64_t* __restric
                                                        const float* __restrict__ es,
                                                        const uint64_t* __restrict__ toff, uint64_t E,
                                                        int rank_mode, uint32_t* __restrict__ wkey,
-                                                       uint32_t* __restrict__ kcol,
+                                                       uint2* __restrict__ kcol,
                                                        uint32_t* __restrict__ blk_min,
                                                        uint32_t* __restrict__ blk_max) {
   __shared__ uint32_t lmin[4], lmax[4];
@@ -306,7 +306,7 @@ __global__ __launch_bounds__(256) void tri_keys_kernel(const uint64_t* __restric
 #pragma unroll
           for (int q = 0; q < 4; q++) {
             if (q < nbits) {
-              kcol[out0 + pm] = (uint32_t)(w * 64 + b[q]);  // third vertex, looked up by tri_decode
+              kcol[out0 + pm] = make_uint2((uint32_t)(w * 64 + b[q]), (uint32_t)e);  // third vertex + edge: tri_decode
               wkey[out0 + pm++] = key[q];
               kmin = min(kmin, key[q]);
               kmax = max(kmax, key[q]);
@@ -357,7 +357,7 @@ size_t tri_keys_blocks(uint64_t E, int tg) {
 
 void launch_tri_keys(const Graph& g, const uint64_t* mbits, const float* smin, const uint32_t* ebase,
                      const uint32_t* ei, const uint32_t* ej, const float* es, const uint64_t* toff, uint64_t E,
-                     int rank_mode, uint32_t* wkey, uint32_t* kcol, uint32_t* blk_minmax, SelectState* s,
+                     int rank_mode, uint32_t* wkey, uint2* kcol, uint32_t* blk_minmax, SelectState* s,
                      uint64_t want, hipStream_t st) {
   if (E == 0) return;
   const int tg = tune_tg("SC_TG_KEYS", 8);
@@ -492,7 +492,7 @@ __global__ __launch_bounds__(256) void tri_keys_events_kernel(const uint64_t* __
                                                               const float* __restrict__ es,
                                                               const uint64_t* __restrict__ toff, int rank_mode,
                                                               EventList ev, uint32_t* __restrict__ wkey,
-                                                              uint32_t* __restrict__ kcol,
+                                                              uint2* __restrict__ kcol,
                                                               uint32_t* __restrict__ blk_min,
                                                               uint32_t* __restrict__ blk_max,
                                                               SelectState* __restrict__ preset,
@@ -555,7 +555,7 @@ __global__ __launch_bounds__(256) void tri_keys_events_kernel(const uint64_t* __
           for (int q = 0; q < 4; q++) {
             if (q < nbits) {
               const uint32_t key = __float_as_uint((s_ij + s_ik[q]) + s_jk[q]);
-              kcol[out] = kbase + (uint32_t)b[q];
+              kcol[out] = make_uint2(kbase + (uint32_t)b[q], e);
               wkey[out++] = key;
               kmin = min(kmin, key);
               kmax = max(kmax, key);
@@ -567,7 +567,7 @@ __global__ __launch_bounds__(256) void tri_keys_events_kernel(const uint64_t* __
           const int b = __builtin_ctzll(m);
           m &= m - 1;
           const uint32_t key = fa + deg[kbase + b];
-          kcol[out] = kbase + (uint32_t)b;
+          kcol[out] = make_uint2(kbase + (uint32_t)b, e);
           wkey[out++] = key;
           kmin = min(kmin, key);
           kmax = max(kmax, key);
@@ -624,7 +624,7 @@ void launch_tri_count_events(const Graph& g, const uint64_t* mbits, const Strong
 }
 
 void launch_tri_keys_events(const Graph& g, const float* es, const uint64_t* toff, int rank_mode,
-                            const EventList& ev, uint32_t* wkey, uint32_t* kcol, uint32_t* blk_minmax,
+                            const EventList& ev, uint32_t* wkey, uint2* kcol, uint32_t* blk_minmax,
                             SelectState* s, uint64_t want, const uint32_t* klb, hipStream_t st) {
   const int nb = 2048;
   hipLaunchKernelGGL(tri_keys_events_kernel, dim3(nb), dim3(256), 0, st, g.bits, g.wpre, g.deg, es, toff, rank_mode,
@@ -1102,58 +1102,25 @@ void launch_compact_write(const uint32_t* wkey, uint64_t M, const SelectState* s
 //    The list stays in ORDINAL order ((i,j,k) ascending): neighbouring threads hit neighbouring edges, and the hot
 //    path never needs the ranked order (see score_argmax_kernel).  launch_rank_order produces it for the stage hook.
 // ------------------------------------------------------------------------------------------------
-constexpr int DEC_COARSE = 4096;  // coarse index entries staged in LDS (32 KiB)
-
-// cshift: the coarse index holds toff[k << cshift], k = 0 .. nc-1 (nc <= DEC_COARSE): the binary search for the edge
-// of an ordinal runs ~12 steps in LDS and only cshift steps in global memory.
-template <int ITEMS>
+// kcol[ordinal] = {third vertex, edge id}, stored by the key kernels: decode is two lookups, no search (the earlier
+// form searched toff for the edge: 12 LDS + 7 global steps per position, 10 us at T = 50 k and 28 us at 400 k).
 __global__ __launch_bounds__(256) void tri_decode_kernel(const uint32_t* __restrict__ ei,
                                                          const uint32_t* __restrict__ ej,
-                                                         const uint32_t* __restrict__ kcol,
-                                                         const uint64_t* __restrict__ toff, uint64_t E, int cshift,
+                                                         const uint2* __restrict__ kcol,
                                                          const uint64_t* __restrict__ sel_ord, uint32_t T,
                                                          uint32_t* __restrict__ tri) {
-  __shared__ uint64_t coarse[DEC_COARSE];
-  const uint32_t nc = (uint32_t)(((E + 1) + ((1ull << cshift) - 1)) >> cshift);  // entries k with (k << cshift) <= E
-  for (uint32_t k = threadIdx.x; k < nc; k += 256) coarse[k] = toff[(uint64_t)k << cshift];
-  __syncthreads();
-#pragma unroll
-  for (int it = 0; it < ITEMS; it++) {  // ITEMS positions per thread share one coarse-index build
-    const uint32_t t = (blockIdx.x * ITEMS + it) * 256 + threadIdx.x;
-    if (t >= T) continue;
-    const uint64_t ord = sel_ord[t];
-    const uint32_t k3 = kcol[ord];  // the third vertex was stored at the ordinal by the key kernel: no row walk here
-    // largest k with coarse[k] <= ord
-    uint32_t klo = 0, khi = nc;
-    while (khi - klo > 1) {
-      const uint32_t mid = (klo + khi) >> 1;
-      if (coarse[mid] <= ord) klo = mid; else khi = mid;
-    }
-    // largest e in [klo << cshift, ...) with toff[e] <= ord  (toff has E+1 entries, toff[E] = M > ord)
-    uint64_t lo = (uint64_t)klo << cshift, hi = min(((uint64_t)klo + 1) << cshift, E);
-    while (hi - lo > 1) {
-      const uint64_t mid = (lo + hi) >> 1;
-      if (toff[mid] <= ord) lo = mid; else hi = mid;
-    }
-    tri[3 * (size_t)t] = ei[lo];
-    tri[3 * (size_t)t + 1] = ej[lo];
-    tri[3 * (size_t)t + 2] = k3;
-  }
+  const uint32_t t = blockIdx.x * 256 + threadIdx.x;
+  if (t >= T) return;
+  const uint2 ke = kcol[sel_ord[t]];
+  tri[3 * (size_t)t] = ei[ke.y];
+  tri[3 * (size_t)t + 1] = ej[ke.y];
+  tri[3 * (size_t)t + 2] = ke.x;
 }
 
-void launch_tri_decode(const uint32_t* ei, const uint32_t* ej, const uint32_t* kcol, const uint64_t* toff, uint64_t E,
-                       const uint64_t* sel_ord, uint32_t T, uint32_t* tri, hipStream_t st) {
+void launch_tri_decode(const uint32_t* ei, const uint32_t* ej, const uint2* kcol, const uint64_t* sel_ord, uint32_t T,
+                       uint32_t* tri, hipStream_t st) {
   if (T == 0) return;
-  int cshift = 0;
-  while ((((E + 1) + ((1ull << cshift) - 1)) >> cshift) > (uint64_t)DEC_COARSE) cshift++;
-  // long lists: four positions per thread, so the 32 KiB coarse index is built a quarter as often (400 k positions:
-  // 28 -> see DESIGN.md); short ones keep one per thread (more workgroups than CUs matters more there)
-  if (T > 131072u)
-    hipLaunchKernelGGL(tri_decode_kernel<4>, dim3((T + 1023) / 1024), dim3(256), 0, st, ei, ej, kcol, toff, E, cshift,
-                       sel_ord, T, tri);
-  else
-    hipLaunchKernelGGL(tri_decode_kernel<1>, dim3((T + 255) / 256), dim3(256), 0, st, ei, ej, kcol, toff, E, cshift,
-                       sel_ord, T, tri);
+  hipLaunchKernelGGL(tri_decode_kernel, dim3((T + 255) / 256), dim3(256), 0, st, ei, ej, kcol, sel_ord, T, tri);
 }
 
 // ---- ranked order for the stage hook: sort (~key, position), then gather
