@@ -136,6 +136,10 @@ Graph graph_of(const sc_ctx* c) {
 }
 
 // event i of the per-stage timing; SC_FLAG_TIMING_HOT keeps only the bracket of the dominant (score) kernel
+TriSource tri_source_of(const sc_ctx* c) {
+  return TriSource{c->sel_ord.as<uint64_t>(), c->kcol.as<uint2>(), c->ei.as<uint32_t>(), c->ej.as<uint32_t>()};
+}
+
 int rec(sc_ctx* c, int i) {
   const bool hot = i == 4 || i == 5;
   if (c->timing || (c->timing_hot && hot)) HIPCHK(c, hipEventRecord(c->ev[i], c->stream));
@@ -210,7 +214,8 @@ int wait_word(sc_ctx* c, int idx) {
 bool may_prune(const sc_params* p) { return p->rank_mode == SC_RANK_WEIGHT && !(p->flags & SC_FLAG_NO_PRUNE); }
 
 // stage B; on return c->E, c->M, c->T_eff are set and tri/trikey hold the ranked list
-int run_triangles(sc_ctx* c, const sc_params* p) {
+// want_list: also materialise the T x 3 triangle list (stage hook; the hot path reads triangles through TriSource)
+int run_triangles(sc_ctx* c, const sc_params* p, bool want_list) {
   const size_t n = c->n;
   hipStream_t st = c->stream;
   ENSURE(c, c->edge_off, (n + 1) * sizeof(uint64_t));
@@ -311,7 +316,7 @@ int run_triangles(sc_ctx* c, const sc_params* p) {
   ENSURE(c, c->scan_tmp, scan_temp_bytes(nb));
   ENSURE(c, c->sel_ord, (size_t)T_eff * 8);
   ENSURE(c, c->sel_key, (size_t)T_eff * 4);
-  ENSURE(c, c->tri, (size_t)T_eff * 12);
+  if (want_list) ENSURE(c, c->tri, (size_t)T_eff * 12);
   SelectState* sel = &c->ctl.as<ControlBlock>()->sel;
   if (c->timing) HIPCHK(c, hipEventRecord(c->ev[9], st));
   bool events_ok = use_events;
@@ -345,8 +350,9 @@ int run_triangles(sc_ctx* c, const sc_params* p) {
                        self_off ? nullptr : c->off_gt.as<uint64_t>(), self_off ? nullptr : c->off_eq.as<uint64_t>(),
                        c->sel_ord.as<uint64_t>(), c->sel_key.as<uint32_t>(), st);
   // the list stays in ordinal order: no sort on the hot path (the winner is found by (count, key, position))
-  launch_tri_decode(c->ei.as<uint32_t>(), c->ej.as<uint32_t>(), c->kcol.as<uint2>(), c->sel_ord.as<uint64_t>(), T_eff,
-                    c->tri.as<uint32_t>(), st);
+  if (want_list)
+    launch_tri_decode(c->ei.as<uint32_t>(), c->ej.as<uint32_t>(), c->kcol.as<uint2>(), c->sel_ord.as<uint64_t>(), T_eff,
+                      c->tri.as<uint32_t>(), st);
   return SC_OK;
 }
 
@@ -483,7 +489,7 @@ int sc_hypothesize_device(sc_ctx* c, const float* d_src, const float* d_tgt, int
   if ((rc = run_compat(c))) return rc;
   if ((rc = rec(c, 2))) return rc;
   if ((rc = run_row_stats(c, may_prune(p)))) return rc;
-  if ((rc = run_triangles(c, p))) return rc;
+  if ((rc = run_triangles(c, p, false))) return rc;
   if ((rc = rec(c, 3))) return rc;
   // stage C on this rank's share of the ranked list
   Shard sh;
@@ -498,7 +504,7 @@ int sc_hypothesize_device(sc_ctx* c, const float* d_src, const float* d_tgt, int
     ENSURE(c, c->rt, (size_t)12 * sh.ld_local * 4);
     ENSURE(c, c->partial, (size_t)score_chunks(c->n, sh.ld_local) * sh.ld_local * 4);
     ENSURE(c, c->cnt, (size_t)sh.ld_local * 4);
-    launch_kabsch(points_of(c), c->tri.as<uint32_t>(), sh, c->rt.as<float>(), c->stream);
+    launch_kabsch(points_of(c), tri_source_of(c), sh, c->rt.as<float>(), c->stream);
   }
   if ((rc = rec(c, 4))) return rc;
   launch_score(points_of(c), c->rt.as<float>(), sh, c->dv.tau2, c->partial.as<uint32_t>(), c->stream);
@@ -521,7 +527,7 @@ int sc_finalize_device(sc_ctx* c, const uint64_t* d_key, float* d_Rt, uint8_t* d
   int rc;
   if ((rc = rec(c, 7))) return rc;
   arm_word(c, 8);
-  launch_finalize(points_of(c), c->tri.as<uint32_t>(), c->T_eff ? c->sel_key.as<uint32_t>() : nullptr, c->T_eff, d_key,
+  launch_finalize(points_of(c), tri_source_of(c), c->T_eff ? c->sel_key.as<uint32_t>() : nullptr, c->T_eff, d_key,
                   c->dv.tau2, d_Rt, d_mask, &c->ctl.as<ControlBlock>()->fin_rank, &c->ctl.as<ControlBlock>()->fin_ticket,
                   &c->pinned[8], c->stream);
   if (c->refine) {  // fp64 least-squares refit over the winner's inliers (mask unchanged)
@@ -635,7 +641,7 @@ int sc_triangles_host(sc_ctx* c, const float* src, const float* tgt, int64_t n, 
   if ((rc = run_row_stats(c, may_prune(p)))) return rc;
   sc_params pe = *p;
   pe.flags |= SC_FLAG_EXACT_TOTAL;  // the hook reports the 3-clique count of the whole graph
-  if ((rc = run_triangles(c, &pe))) return rc;
+  if ((rc = run_triangles(c, &pe, true))) return rc;
   *t_eff = c->T_eff;
   if (tri_total) *tri_total = c->M_total;
   if (edges) *edges = c->E;

@@ -181,8 +181,16 @@ struct Shard {
   uint32_t ld_local;// roundup(n_local, 256): plane stride of RtSoA / partial counts
 };
 uint32_t shard_local_count(uint32_t T_eff, uint32_t block, uint32_t rank, uint32_t world);
+// Where stage C finds triangle g of the selected list: the selection itself (position -> ordinal -> {third vertex,
+// edge} -> edge ends) — the hot path never materialises the T x 3 list (only the stage hook does, launch_tri_decode).
+struct TriSource {
+  const uint64_t* sel_ord;
+  const uint2* kcol;
+  const uint32_t* ei;
+  const uint32_t* ej;
+};
 // C1: RtSoA[c * ld_local + l], c = 0..11, for the local hypotheses of the shard (global rank index derived).
-void launch_kabsch(const Points& pts, const uint32_t* tri, const Shard& sh, float* RtSoA, hipStream_t st);
+void launch_kabsch(const Points& pts, const TriSource& ts, const Shard& sh, float* RtSoA, hipStream_t st);
 // C1 on an explicit triangle list to AoS T x 12 (stage hook)
 void launch_kabsch_aos(const Points& pts, const uint32_t* tri, uint32_t T, float* Rt, hipStream_t st);
 // AoS T x 12 -> SoA planes (stage hook for sc_score_host)
@@ -205,7 +213,7 @@ void launch_argmax(const Points& pts, const Shard& sh, const uint32_t* partial, 
 // C3: winner decode + re-solve + mask.  Rt12 receives R (row-major) and t; identity / zero mask when key2[0] == 0.
 // sel_key / T: the ordinal-ordered ranking keys (for the winner's rank index); host_out (pinned, 3 x u64) receives
 // key2[0], the winner's position and its rank index.
-void launch_finalize(const Points& pts, const uint32_t* tri, const uint32_t* sel_key, uint32_t T,
+void launch_finalize(const Points& pts, const TriSource& ts, const uint32_t* sel_key, uint32_t T,
                      const uint64_t* key2, float tau2, float* Rt12, uint8_t* mask, uint32_t* rank_acc,
                      uint32_t* ticket, uint64_t* host_out, hipStream_t st);
 // SURVEY §8f-2 (SC_FLAG_REFINE): fp64 least-squares refit of Rt12 over the inlier mask; no-op when key2[0] == 0 or

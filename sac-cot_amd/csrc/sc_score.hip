@@ -52,16 +52,25 @@ __device__ __forceinline__ void load_triangle(const float* __restrict__ planes, 
   }
 }
 
-__global__ __launch_bounds__(256) void kabsch_shard_kernel(const float* __restrict__ planes, int ld,
-                                                           const uint32_t* __restrict__ tri, Shard sh,
-                                                           float* __restrict__ RtSoA) {
+// triangle g of the selected list, straight from the selection (two dependent lookups, no materialised list)
+__device__ __forceinline__ void tri_lookup(const TriSource& ts, uint32_t g, uint32_t v[3]) {
+  const uint2 ke = ts.kcol[ts.sel_ord[g]];
+  v[0] = ts.ei[ke.y];
+  v[1] = ts.ej[ke.y];
+  v[2] = ke.x;
+}
+
+__global__ __launch_bounds__(256) void kabsch_shard_kernel(const float* __restrict__ planes, int ld, TriSource ts,
+                                                           Shard sh, float* __restrict__ RtSoA) {
   const uint32_t l = blockIdx.x * 256 + threadIdx.x;
   if (l >= sh.ld_local) return;
   float Rt[12];
   if (l < sh.n_local) {
     const uint32_t g = shard_global_index(l, sh.block, sh.rank, sh.world);
+    uint32_t v[3];
+    tri_lookup(ts, g, v);
     float P[9], Q[9];
-    load_triangle(planes, ld, tri + 3 * (size_t)g, P, Q);
+    load_triangle(planes, ld, v, P, Q);
     kabsch3(P, Q, Rt);
   } else {
 #pragma unroll
@@ -71,9 +80,9 @@ __global__ __launch_bounds__(256) void kabsch_shard_kernel(const float* __restri
   for (int c = 0; c < 12; c++) RtSoA[(size_t)c * sh.ld_local + l] = Rt[c];
 }
 
-void launch_kabsch(const Points& pts, const uint32_t* tri, const Shard& sh, float* RtSoA, hipStream_t st) {
+void launch_kabsch(const Points& pts, const TriSource& ts, const Shard& sh, float* RtSoA, hipStream_t st) {
   if (sh.ld_local == 0) return;
-  hipLaunchKernelGGL(kabsch_shard_kernel, dim3(sh.ld_local / 256), dim3(256), 0, st, pts.planes, pts.ld, tri, sh,
+  hipLaunchKernelGGL(kabsch_shard_kernel, dim3(sh.ld_local / 256), dim3(256), 0, st, pts.planes, pts.ld, ts, sh,
                      RtSoA);
 }
 
@@ -392,7 +401,7 @@ void launch_argmax(const Points& pts, const Shard& sh, const uint32_t* partial, 
 // meet in a control-block counter; the block that takes the last ticket publishes (key, position, rank) to the host.
 // (A single-block rank count cost 42 us at T = 400 k; a separate mask launch another ~4.5 us floor.)
 __global__ __launch_bounds__(256) void finalize_kernel(const float* __restrict__ planes, int n, int ld,
-                                                       const uint32_t* __restrict__ tri,
+                                                       TriSource ts,
                                                        const uint32_t* __restrict__ sel_key, uint32_t T,
                                                        const unsigned long long* __restrict__ key2, float tau2,
                                                        float* __restrict__ Rt12, uint8_t* __restrict__ mask,
@@ -408,8 +417,10 @@ __global__ __launch_bounds__(256) void finalize_kernel(const float* __restrict__
   if (threadIdx.x == 0) {
     float Rt[12] = {1.f, 0.f, 0.f, 0.f, 1.f, 0.f, 0.f, 0.f, 1.f, 0.f, 0.f, 0.f};
     if (k0 != 0) {
+      uint32_t v[3];
+      tri_lookup(ts, g, v);
       float P[9], Q[9];
-      load_triangle(planes, ld, tri + 3 * (size_t)g, P, Q);
+      load_triangle(planes, ld, v, P, Q);
       kabsch3(P, Q, Rt);
     }
 #pragma unroll
@@ -482,13 +493,13 @@ __global__ __launch_bounds__(256) void mask_kernel(const float* __restrict__ pla
   mask[m] = (live && d2 < tau2) ? 1 : 0;
 }
 
-void launch_finalize(const Points& pts, const uint32_t* tri, const uint32_t* sel_key, uint32_t T,
+void launch_finalize(const Points& pts, const TriSource& ts, const uint32_t* sel_key, uint32_t T,
                      const uint64_t* key2, float tau2, float* Rt12, uint8_t* mask, uint32_t* rank_acc,
                      uint32_t* ticket, uint64_t* host_out, hipStream_t st) {
   uint32_t blocks = (uint32_t)((pts.n + 255) / 256);  // the mask needs these; more only if the key list is long
   const uint32_t for_keys = (T / 4 + 1023) / 1024;    // >= 4 uint4 per thread before another block pays off
   if (for_keys > blocks) blocks = for_keys < 1024u ? for_keys : 1024u;
-  hipLaunchKernelGGL(finalize_kernel, dim3(blocks), dim3(256), 0, st, pts.planes, pts.n, pts.ld, tri, sel_key, T,
+  hipLaunchKernelGGL(finalize_kernel, dim3(blocks), dim3(256), 0, st, pts.planes, pts.n, pts.ld, ts, sel_key, T,
                      reinterpret_cast<const unsigned long long*>(key2), tau2, Rt12, mask, rank_acc, ticket,
                      reinterpret_cast<unsigned long long*>(host_out));
 }
