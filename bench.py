@@ -148,7 +148,7 @@ def main() -> int:
                 pmc_all = {}
         # stage B's key kernel: one u32 key + one u32 third vertex per enumerated 3-clique, in ordinal order
         M, E = st["tri_total"], st["edges"]
-        tk_bytes = 8 * M + 32 * M / 1.2 + 12 * E                  # keys + third vertices written, ~M/1.2 event records read
+        tk_bytes = 12 * M + 32 * M / 1.37 + 12 * E                # keys + {third vertex, edge} written, ~M/1.37 event records read
         tk_gbs = tk_bytes / (max(avg["us_trikeys"], 1e-3) * 1e-6) / 1e9
         roof_tk = {"kernel": "tri_keys_events_kernel", "bound": "hbm", "achieved": round(tk_gbs, 1), "peak": HBM_PEAK_GBS,
                    "unit": "GB/s", "frac": round(tk_gbs / HBM_PEAK_GBS, 4), "traffic": None,

@@ -130,7 +130,8 @@ const char* sc_last_error(const sc_ctx* ctx);          /* last HIP error text se
 int sc_register(sc_ctx* ctx, const float* src, const float* tgt, int64_t n, const sc_params* params,
                 float R[9], float t[3], uint8_t* mask, sc_stats* stats);
 
-/* Same, with every buffer already resident in HBM (d_Rt: 12 floats = R row-major then t). */
+/* Same, with every buffer already resident in HBM (d_Rt: 12 floats = R row-major then t).  Output visibility as
+ * for sc_finalize_device below: complete on return with the private stream, stream-ordered with a caller stream. */
 int sc_register_device(sc_ctx* ctx, const float* d_src, const float* d_tgt, int64_t n,
                        const sc_params* params, float* d_Rt, uint8_t* d_mask, sc_stats* stats);
 
@@ -146,7 +147,11 @@ int sc_register_device(sc_ctx* ctx, const float* d_src, const float* d_tgt, int6
  * and stores (K0, K1) back into d_key.  The winner is thus: most inliers, then best ranking key, then lowest
  * (i,j,k) — "ties -> best-ranked triangle" of SURVEY §8a, decided without sorting the T hypotheses.
  * Phase 2: every rank decodes the same winner from the reduced pair, re-solves its (R,t) from its own
- * replicated list and builds the mask.  Returns SC_ENOHYP when d_key[0] is 0. */
+ * replicated list and builds the mask.  Returns SC_ENOHYP when d_key[0] is 0.
+ * Synchronisation: sc_hypothesize_device returns with its last kernels still queued (d_key is valid in stream order:
+ * enqueue the reduction on the same stream, or synchronise it).  sc_finalize_device returns once the winner is known
+ * to the host (status, stats); on the context's private stream it also waits for d_Rt / d_mask, on a stream given
+ * with sc_set_stream they are complete in THAT stream's order, like any other work the caller enqueues there. */
 int sc_hypothesize_device(sc_ctx* ctx, const float* d_src, const float* d_tgt, int64_t n,
                           const sc_params* params, uint64_t* d_key, sc_stats* stats);
 int sc_finalize_device(sc_ctx* ctx, const uint64_t* d_key, float* d_Rt, uint8_t* d_mask, sc_stats* stats);

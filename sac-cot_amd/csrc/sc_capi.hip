@@ -535,9 +535,10 @@ int sc_finalize_device(sc_ctx* c, const uint64_t* d_key, float* d_Rt, uint8_t* d
     launch_refine(points_of(c), d_mask, d_key, c->refine_tmp.as<double>(), d_Rt, c->stream);
   }
   if ((rc = rec(c, 8))) return rc;
-  // the winner kernel publishes key / position / rank; d_Rt and d_mask complete in stream order (a full wait only
-  // when the per-stage events are read below)
-  if (c->timing) HIPCHK(c, hipStreamSynchronize(c->stream));
+  // The finalize kernel publishes key / position / rank.  On a caller-provided stream (sc_set_stream) d_Rt and d_mask
+  // are complete in stream order, like any other work the caller enqueues there; on the context's private stream —
+  // which the caller cannot order against — and when the per-stage events are read below, wait for everything.
+  if (c->timing || c->stream == c->own_stream) HIPCHK(c, hipStreamSynchronize(c->stream));
   if ((rc = wait_word(c, 8))) return rc;
   HIPCHK(c, hipGetLastError());
   const uint64_t key = c->pinned[8];
