@@ -151,7 +151,7 @@ int stage_inputs(sc_ctx* c, const float* d_src, const float* d_tgt, int64_t n, c
   if (n < 3 || n > (1 << 24)) return SC_EINVAL;
   c->n = (int)n;
   c->ld = round_up((int)n, 64);
-  ENSURE(c, c->planes, (size_t)6 * c->ld * sizeof(float));
+  ENSURE(c, c->planes, (size_t)(6 + 8) * c->ld * sizeof(float));  // 6 SoA planes + the AoS copy (8 floats each)
   // per-call control block (flags, histograms, counters, select state): cleared by the staging kernel itself
   ENSURE(c, c->ctl, sizeof(ControlBlock));
   static_assert(sizeof(ControlBlock) % 4 == 0, "cleared word-wise");

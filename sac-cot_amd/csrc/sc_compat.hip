@@ -37,6 +37,11 @@ __global__ __launch_bounds__(256) void stage_points_kernel(const float* __restri
   }
 #pragma unroll
   for (int c = 0; c < 6; c++) planes[(size_t)c * ld + m] = v[c];
+  // AoS copy behind the planes (8 floats per correspondence, 32-byte aligned): stage A fetches a ROW operand with one
+  // s_load_dwordx8 instead of six scalar loads and their address arithmetic
+  float4* aos = reinterpret_cast<float4*>(planes + 6 * (size_t)ld);
+  aos[2 * (size_t)m] = make_float4(v[0], v[1], v[2], v[3]);
+  aos[2 * (size_t)m + 1] = make_float4(v[4], v[5], 0.0f, 0.0f);
 }
 
 void launch_stage_points(const float* d_src, const float* d_tgt, int n, int ld, int layout, float* planes,
@@ -59,6 +64,8 @@ void launch_stage_points(const float* d_src, const float* d_tgt, int n, int ld, 
 // each pair once halves that work, which is what moves the kernel toward the HBM write roofline.
 // deg / deg+ / word-prefix popcounts come from the bit rows in a second, tiny kernel.
 // ------------------------------------------------------------------------------------------------
+struct alignas(32) RowPt { float px, py, pz, qx, qy, qz, pad0, pad1; };  // the AoS copy written by stage_points_kernel
+
 // value of `v` in lane `src` (wave-uniform src) as a scalar: v_readlane_b32 works on the bit pattern
 __device__ __forceinline__ float bcast(float v, int src) {
   return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), src));
@@ -71,7 +78,8 @@ template <int TILE_R>
 __global__ __launch_bounds__(64 * COMPAT_WAVES) void compat_tiles_kernel(const float* __restrict__ planes, int n,
                                                                          int ld, float d_thr, float min_len,
                                                                          float nis, float* __restrict__ S,
-                                                                         uint64_t* __restrict__ bits, int n_tiles) {
+                                                                         uint64_t* __restrict__ bits, int n_tiles,
+                                                                         int two_phase) {
   constexpr int TILE_PAD = TILE_R + 1;  // LDS row stride of the transposed tile: conflict-free both ways
   constexpr int SUB = 64 / TILE_R;      // tiles per 64-row block
   __shared__ float tileT[COMPAT_WAVES][64 * TILE_PAD];  // [column][row] per wave
@@ -98,9 +106,114 @@ __global__ __launch_bounds__(64 * COMPAT_WAVES) void compat_tiles_kernel(const f
   float* myT = tileT[wave];
   uint64_t rowword = 0;      // lane r: adjacency word of row i0 + r over this column block
   uint32_t colword = 0;      // lane c: bit r = edge (row i0 + r, column j)
-  // Interior tiles (every row and column real, not on the diagonal) are ~97 % of the work: they skip the bounds and
-  // i != j predicates.  Two rows per trip; ONE wave-uniform branch around the exponential polynomial.
+  // Interior tiles (every row and column real, not on the diagonal) are ~97 % of the work.
   const bool interior = !diag && (i0 + TILE_R <= n) && (J * 64 + 64 <= n);
+  if (interior && two_phase) {
+    // ---- two-phase form ----------------------------------------------------------------------------------
+    // Only ~4 % of the pairs are edges, yet the exact chain (two correctly rounded square roots, the exponential)
+    // is ~60 of the ~83 VALU instructions a pair used to cost, and the kernel was VALU-issue-bound.  Phase 1 computes
+    // the two squared lengths (the same fp32 values the exact chain starts from) and a CONSERVATIVE candidate test in
+    // squared quantities — no sqrt, no exp; phase 2 runs the exact chain on the queued candidates only and scatters
+    // weights and adjacency bits into the LDS image of the tile, which is then written out as before.
+    // Candidate test (theta = d_thr, L = min_len, A = sqrt(n2p), B = sqrt(n2q) as reals):
+    //   an edge has |dp - dq| <= theta (1 + 2^-24) with dp = A (1 + e1), dq = B (1 + e2), |e| <= 2^-24, hence
+    //   A^2 + B^2 - theta^2 - sigma <= 2 A B  with  sigma = (theta^2 + A^2 + B^2) 2^-21  (generous).
+    //   a = fma(RN(n2p + n2q), 1 - 2^-20, -theta^2 (1 + 2^-20)) is <= that left side; so an edge has a <= 0 or
+    //   a^2 <= 4 n2p n2q (1 + 2^-18).  Products so small that they could round to zero count as candidates.
+    //   dp >= L needs n2p >= L^2 (1 - 2^-23); the test uses L^2 (1 - 2^-20), rounded down.
+    // False positives cost a queue slot; a false negative is impossible, so the output is bit-identical.
+    // Measured (r01): C2 29.4 -> 26.6 us, C3 ~400 -> ~385 us.  Ablation on C3 (N = 20 000, 1.65 GB of S): arithmetic
+    // and LDS work alone 187 us, the stores alone 334 us (4.9 TB/s: 256-byte row pieces + 64-byte mirrored pieces; a
+    // plain fill of the same bytes runs at 6.8 TB/s), both 383 us — the store PATTERN is the limiter now, not VALU.
+    // A one-sided row kernel (1 KiB zero-fill stores per instruction + 4-byte patches of the edges, both triangles
+    // evaluated) was built and was bit-exact but no faster: 234 us of arithmetic + ~190 us of stores that did not
+    // overlap (423 us).  Next step: 64-row tiles (256-byte mirrored pieces) with a compact LDS image.
+    constexpr int QCAP = 320;  // candidate queue per wave (a row adds <= 64; drained above QCAP - 64)
+    __shared__ uint16_t queue[COMPAT_WAVES][QCAP];
+    __shared__ unsigned long long rowbits[COMPAT_WAVES][TILE_R];
+    __shared__ uint32_t colbits[COMPAT_WAVES][64];
+    uint16_t* myQ = queue[wave];
+    unsigned long long* myRB = rowbits[wave];
+    uint32_t* myCB = colbits[wave];
+    for (int k = lane; k < 64 * TILE_PAD; k += 64) myT[k] = 0.0f;
+    if (lane < TILE_R) myRB[lane] = 0ull;
+    myCB[lane] = 0u;
+    const RowPt* __restrict__ aos = reinterpret_cast<const RowPt*>(planes + 6 * (size_t)ld);
+    // lane r (< TILE_R) keeps row point i0 + r in registers: phase 2 fetches both points of a candidate with
+    // ds_bpermute (no memory latency in the drain — with ~1.5 tiles per wave slot the kernel's time is a wave's latency)
+    const RowPt mine = aos[i0 + (lane & (TILE_R - 1))];
+    const float theta2 = d_thr * d_thr;
+    const float c1 = 1.0f - 0x1p-20f;
+    const float c2 = theta2 * (1.0f + 0x1p-20f) * (1.0f + 0x1p-22f);  // rounded up a little: never below theta^2 (1 + 2^-20)
+    const float k4 = 4.0f + 0x1p-16f;                                   // 4 (1 + 2^-18), exact
+    const float Lc = (min_len * min_len) * (1.0f - 0x1p-20f) * (1.0f - 0x1p-22f);
+    uint32_t cnt = 0;  // queued candidates (wave-uniform)
+    auto drain = [&]() {
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // LDS is in-order within a wave
+      for (uint32_t q0 = 0; q0 < cnt; q0 += 64) {  // wave-uniform trips: ds_bpermute reads 0 from inactive lanes
+        const bool valid = q0 + lane < cnt;
+        const uint32_t code = valid ? myQ[q0 + lane] : 0u;
+        const int r = (int)(code >> 6), c = (int)(code & 63);
+        const float dp = dist3_fast(__shfl(mine.px, r), __shfl(mine.py, r), __shfl(mine.pz, r), __shfl(jpx, c),
+                                    __shfl(jpy, c), __shfl(jpz, c));
+        const float dq = dist3_fast(__shfl(mine.qx, r), __shfl(mine.qy, r), __shfl(mine.qz, r), __shfl(jqx, c),
+                                    __shfl(jqy, c), __shfl(jqz, c));
+        bool edge;
+        const float s = pair_weight(dp, dq, d_thr, min_len, nis, edge);
+        if (valid && edge) {
+          myT[c * TILE_PAD + r] = s;
+          atomicOr(&myRB[r], 1ull << c);
+          atomicOr(&myCB[c], 1u << r);
+        }
+      }
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      cnt = 0;
+    };
+    // The scalar unit (one per CU) was the limiter of the first two-phase form (666 SALU + 101 SMEM per wave): one
+    // 32-byte scalar load per row, and the test folded into VALU selects so that ONE compare produces a lane mask.
+    const float INF = __builtin_inff(), QNAN = __builtin_nanf("");
+    RowPt nxt = aos[i0s];  // wave-uniform address: scalar load, issued one row ahead of its use
+#pragma unroll 4
+    for (int r = 0; r < TILE_R; r++) {
+      const RowPt rp = nxt;
+      nxt = aos[i0s + ((r + 1) & (TILE_R - 1))];
+      const float dxp = rp.px - jpx, dyp = rp.py - jpy, dzp = rp.pz - jpz;
+      const float dxq = rp.qx - jqx, dyq = rp.qy - jqy, dzq = rp.qz - jqz;
+      const float n2p = fma_(dzp, dzp, fma_(dyp, dyp, dxp * dxp));  // exactly dist3's radicand
+      const float n2q = fma_(dzq, dzq, fma_(dyq, dyq, dxq * dxq));
+      const float m = fmaxf(fma_(n2p + n2q, c1, -c2), 0.0f);        // a <= 0 or a^2 <= R  <=>  max(a,0)^2 <= R
+      const float t = n2p * n2q;
+      const float R = (t < 0x1p-100f) ? INF : t * k4;               // vanishing products: candidate
+      const float lhs = (fminf(n2p, n2q) >= Lc) ? m * m : QNAN;     // too short: NaN never compares true
+      const bool cand = lhs <= R;
+      const uint64_t bal = __ballot(cand);
+      if (bal != 0) {  // wave-uniform
+        if (cand)
+          myQ[cnt + __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u))] =
+              (uint16_t)((r << 6) | lane);
+        cnt += (uint32_t)__popcll(bal);
+        if (cnt > (uint32_t)(QCAP - 64)) drain();
+      }
+    }
+    if (cnt) drain();
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    // direct half: row i0 + r, one 256-byte store per row from the tile image ([column][row], stride TILE_PAD)
+#pragma unroll 4
+    for (int r = 0; r < TILE_R; r++) S[(size_t)(i0 + r) * ld + j] = myT[lane * TILE_PAD + r];
+    if (lane < TILE_R) bits[(size_t)(i0 + lane) * W + J] = myRB[lane];
+    colword = myCB[lane];
+    {
+      const int r = lane & (TILE_R - 1), hi = lane / TILE_R;
+#pragma unroll 4
+      for (int c = 0; c < 64; c += SUB) {
+        const int cc = c + hi;
+        S[(size_t)(J * 64 + cc) * ld + i0 + r] = myT[cc * TILE_PAD + r];
+      }
+      if (TILE_R == 32) reinterpret_cast<uint32_t*>(bits)[((size_t)j * W + (i0 >> 6)) * 2 + (h % SUB)] = colword;
+      else reinterpret_cast<uint16_t*>(bits)[((size_t)j * W + (i0 >> 6)) * 4 + (h % SUB)] = (uint16_t)colword;
+    }
+    return;
+  }
   auto row_pair = [&](int r, auto guarded) {
     constexpr bool G = decltype(guarded)::value;
     float dpa, dqa, dpb, dqb;
@@ -205,7 +318,8 @@ void launch_compat(const Points& pts, const Derived& dv, float* S, uint64_t* bit
   constexpr int TR = 16;
   const int n_tiles = (64 / TR) * W * (W + 1) / 2;
   hipLaunchKernelGGL(compat_tiles_kernel<TR>, dim3((n_tiles + COMPAT_WAVES - 1) / COMPAT_WAVES), dim3(64 * COMPAT_WAVES),
-                     0, st, pts.planes, pts.n, pts.ld, dv.d_thr, dv.min_len, dv.neg_inv2sig2, S, bits, n_tiles);
+                     0, st, pts.planes, pts.n, pts.ld, dv.d_thr, dv.min_len, dv.neg_inv2sig2, S, bits, n_tiles,
+                     getenv("SC_COMPAT_ONE_PHASE") ? 0 : 1);  // the one-phase form of the interior tiles stays for A/B and parity
 }
 
 void launch_row_stats(const Points& pts, const uint64_t* bits, uint32_t* deg, uint32_t* degp, uint32_t* wpre,

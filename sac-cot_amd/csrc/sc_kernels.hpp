@@ -16,9 +16,10 @@ struct Derived {
 };
 
 // Device view of the padded SoA point planes: px py pz qx qy qz, each `ld` floats (ld = roundup(n,64)),
-// zero-filled beyond n.
+// zero-filled beyond n — followed, at planes + 6 * ld, by an AoS copy of 8 floats per correspondence
+// (px py pz qx qy qz 0 0; 32-byte aligned) for the consumers that fetch one whole correspondence at a time.
 struct Points {
-  const float* planes;  // 6 * ld
+  const float* planes;  // (6 + 8) * ld
   int n;
   int ld;
 };

@@ -38,6 +38,29 @@ def test_compat_bit_exact(pkg, O, reg, n, seed):
     assert np.array_equal(S, S.T) and not S.diagonal().any()
 
 
+@pytest.mark.parametrize("one_phase", [False, True])
+@pytest.mark.parametrize("min_len_scale", [0.0, 1.0])
+def test_compat_both_interior_forms_bit_exact(pkg, O, one_phase, min_len_scale, monkeypatch):
+    """Interior tiles of stage A run a conservative candidate test on squared lengths and the exact chain only on the
+    candidates (default), or the exact chain on every pair (SC_COMPAT_ONE_PHASE=1): both against the CPU restatement,
+    with min_len = 0 (coincident-point candidates) and on a scene with exact duplicates and near-threshold pairs."""
+    if one_phase:
+        monkeypatch.setenv("SC_COMPAT_ONE_PHASE", "1")
+    sc = pkg.synth.make_scene(1500, 0.3, 1.0, 0.05, seed=77)
+    src, tgt = sc.src.copy(), sc.tgt.copy()
+    src[100:164] = src[36:100]; tgt[100:164] = tgt[36:100]        # exact duplicates: zero lengths, ties
+    tgt[200:400] = src[200:400] * np.float32(1.0) + np.float32(0.25)  # a pure translation block: d == 0 exactly
+    kw = dict(sigma=0.05, t_cmp=0.9, tau=0.05, min_len=0.05 * min_len_scale)
+    r = pkg.Registrar(0)
+    try:
+        S1, b1, d1 = r.compat(src, tgt, pkg.make_params(**kw))
+    finally:
+        r.close()
+    S0, b0, d0 = O.compat(src, tgt, kw["sigma"], kw["t_cmp"], kw["min_len"], kw["tau"])
+    assert np.array_equal(b1, b0) and np.array_equal(d1, d0)
+    assert np.array_equal(S1.view(np.uint32), S0.view(np.uint32))
+
+
 def test_compat_soa_layout_and_min_len_zero(pkg, O, reg):
     sc = _scene(pkg, 300, seed=11)
     kw = _params(pkg, 0.05, 10, min_len=0.0)
