@@ -71,10 +71,9 @@ __device__ __forceinline__ float bcast(float v, int src) {
   return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), src));
 }
 
-constexpr int COMPAT_WAVES = 4;  // tiles per workgroup
 
 // TILE_R rows per tile (16 or 32): 64 / TILE_R tiles stack into one 64-row block
-template <int TILE_R>
+template <int TILE_R, int COMPAT_WAVES>
 __global__ __launch_bounds__(64 * COMPAT_WAVES) void compat_tiles_kernel(const float* __restrict__ planes, int n,
                                                                          int ld, float d_thr, float min_len,
                                                                          float nis, float* __restrict__ S,
@@ -105,7 +104,7 @@ __global__ __launch_bounds__(64 * COMPAT_WAVES) void compat_tiles_kernel(const f
   const int i0s = __builtin_amdgcn_readfirstlane(i0);  // provably wave-uniform row base
   float* myT = tileT[wave];
   uint64_t rowword = 0;      // lane r: adjacency word of row i0 + r over this column block
-  uint32_t colword = 0;      // lane c: bit r = edge (row i0 + r, column j)
+  uint64_t colword = 0;      // lane c: bit r = edge (row i0 + r, column j)
   // Interior tiles (every row and column real, not on the diagonal) are ~97 % of the work.
   const bool interior = !diag && (i0 + TILE_R <= n) && (J * 64 + 64 <= n);
   if (interior && two_phase) {
@@ -127,17 +126,17 @@ __global__ __launch_bounds__(64 * COMPAT_WAVES) void compat_tiles_kernel(const f
     // plain fill of the same bytes runs at 6.8 TB/s), both 383 us — the store PATTERN is the limiter now, not VALU.
     // A one-sided row kernel (1 KiB zero-fill stores per instruction + 4-byte patches of the edges, both triangles
     // evaluated) was built and was bit-exact but no faster: 234 us of arithmetic + ~190 us of stores that did not
-    // overlap (423 us).  Next step: 64-row tiles (256-byte mirrored pieces) with a compact LDS image.
+    // overlap (423 us); 64-row tiles (256-byte mirrored pieces, SC_COMPAT_ROWS=64) change nothing on C3 either.
     constexpr int QCAP = 320;  // candidate queue per wave (a row adds <= 64; drained above QCAP - 64)
     __shared__ uint16_t queue[COMPAT_WAVES][QCAP];
     __shared__ unsigned long long rowbits[COMPAT_WAVES][TILE_R];
-    __shared__ uint32_t colbits[COMPAT_WAVES][64];
+    __shared__ unsigned long long colbits[COMPAT_WAVES][64];
     uint16_t* myQ = queue[wave];
     unsigned long long* myRB = rowbits[wave];
-    uint32_t* myCB = colbits[wave];
+    unsigned long long* myCB = colbits[wave];
     for (int k = lane; k < 64 * TILE_PAD; k += 64) myT[k] = 0.0f;
     if (lane < TILE_R) myRB[lane] = 0ull;
-    myCB[lane] = 0u;
+    myCB[lane] = 0ull;
     const RowPt* __restrict__ aos = reinterpret_cast<const RowPt*>(planes + 6 * (size_t)ld);
     // lane r (< TILE_R) keeps row point i0 + r in registers: phase 2 fetches both points of a candidate with
     // ds_bpermute (no memory latency in the drain — with ~1.5 tiles per wave slot the kernel's time is a wave's latency)
@@ -163,7 +162,7 @@ __global__ __launch_bounds__(64 * COMPAT_WAVES) void compat_tiles_kernel(const f
         if (valid && edge) {
           myT[c * TILE_PAD + r] = s;
           atomicOr(&myRB[r], 1ull << c);
-          atomicOr(&myCB[c], 1u << r);
+          atomicOr(&myCB[c], 1ull << r);
         }
       }
       __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -209,7 +208,8 @@ __global__ __launch_bounds__(64 * COMPAT_WAVES) void compat_tiles_kernel(const f
         const int cc = c + hi;
         S[(size_t)(J * 64 + cc) * ld + i0 + r] = myT[cc * TILE_PAD + r];
       }
-      if (TILE_R == 32) reinterpret_cast<uint32_t*>(bits)[((size_t)j * W + (i0 >> 6)) * 2 + (h % SUB)] = colword;
+      if (TILE_R == 64) bits[(size_t)j * W + (i0 >> 6)] = colword;
+      else if (TILE_R == 32) reinterpret_cast<uint32_t*>(bits)[((size_t)j * W + (i0 >> 6)) * 2 + (h % SUB)] = (uint32_t)colword;
       else reinterpret_cast<uint16_t*>(bits)[((size_t)j * W + (i0 >> 6)) * 4 + (h % SUB)] = (uint16_t)colword;
     }
     return;
@@ -248,7 +248,7 @@ __global__ __launch_bounds__(64 * COMPAT_WAVES) void compat_tiles_kernel(const f
     if (!G || ib < n) S[(size_t)ib * ld + j] = sb;
     if (lane == r) rowword = worda;
     if (lane == r + 1) rowword = wordb;
-    colword |= (ea ? (1u << r) : 0u) | (eb ? (2u << r) : 0u);
+    colword |= (ea ? (1ull << r) : 0ull) | (eb ? (2ull << r) : 0ull);
     if (!diag) { myT[lane * TILE_PAD + r] = sa; myT[lane * TILE_PAD + r + 1] = sb; }
   };
   if (interior) {
@@ -271,7 +271,8 @@ __global__ __launch_bounds__(64 * COMPAT_WAVES) void compat_tiles_kernel(const f
     }
     // mirrored adjacency: row j, piece (h % SUB) of word (i0 / 64)
     if (j < n) {
-      if (TILE_R == 32) reinterpret_cast<uint32_t*>(bits)[((size_t)j * W + (i0 >> 6)) * 2 + (h % SUB)] = colword;
+      if (TILE_R == 64) bits[(size_t)j * W + (i0 >> 6)] = colword;
+      else if (TILE_R == 32) reinterpret_cast<uint32_t*>(bits)[((size_t)j * W + (i0 >> 6)) * 2 + (h % SUB)] = (uint32_t)colword;
       else reinterpret_cast<uint16_t*>(bits)[((size_t)j * W + (i0 >> 6)) * 4 + (h % SUB)] = (uint16_t)colword;
     }
   }
@@ -314,12 +315,21 @@ __global__ __launch_bounds__(256) void row_stats_kernel(const uint64_t* __restri
 
 void launch_compat(const Points& pts, const Derived& dv, float* S, uint64_t* bits, hipStream_t st) {
   const int W = pts.ld >> 6;
-  // 16-row tiles: 4.3 KiB of LDS per wave -> 8 waves per SIMD (32-row tiles measured 37 us vs 30 us on C2)
-  constexpr int TR = 16;
-  const int n_tiles = (64 / TR) * W * (W + 1) / 2;
-  hipLaunchKernelGGL(compat_tiles_kernel<TR>, dim3((n_tiles + COMPAT_WAVES - 1) / COMPAT_WAVES), dim3(64 * COMPAT_WAVES),
-                     0, st, pts.planes, pts.n, pts.ld, dv.d_thr, dv.min_len, dv.neg_inv2sig2, S, bits, n_tiles,
-                     getenv("SC_COMPAT_ONE_PHASE") ? 0 : 1);  // the one-phase form of the interior tiles stays for A/B and parity
+  const int two_phase = getenv("SC_COMPAT_ONE_PHASE") ? 0 : 1;  // the one-phase interior form stays for A/B and parity
+  // tile height: 16 rows (4.3 KiB LDS image per wave, 4 waves per workgroup; default) or 64 rows (16.6 KiB, one wave
+  // per workgroup; the mirrored half is then written as full 256-byte segments).  Measured: C2 28 vs 49 us, C3 432 vs
+  // 435 us — bigger mirrored pieces do not pay for the lost occupancy.  SC_COMPAT_ROWS=64 selects it (experiments).
+  int tr = 16;
+  if (const char* v = getenv("SC_COMPAT_ROWS")) tr = atoi(v) == 64 ? 64 : 16;
+  if (tr == 64) {
+    const int n_tiles = W * (W + 1) / 2;
+    hipLaunchKernelGGL((compat_tiles_kernel<64, 1>), dim3(n_tiles), dim3(64), 0, st, pts.planes, pts.n, pts.ld, dv.d_thr,
+                       dv.min_len, dv.neg_inv2sig2, S, bits, n_tiles, two_phase);
+  } else {
+    const int n_tiles = 4 * W * (W + 1) / 2;
+    hipLaunchKernelGGL((compat_tiles_kernel<16, 4>), dim3((n_tiles + 3) / 4), dim3(256), 0, st, pts.planes, pts.n, pts.ld,
+                       dv.d_thr, dv.min_len, dv.neg_inv2sig2, S, bits, n_tiles, two_phase);
+  }
 }
 
 void launch_row_stats(const Points& pts, const uint64_t* bits, uint32_t* deg, uint32_t* degp, uint32_t* wpre,

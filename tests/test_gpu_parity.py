@@ -38,14 +38,15 @@ def test_compat_bit_exact(pkg, O, reg, n, seed):
     assert np.array_equal(S, S.T) and not S.diagonal().any()
 
 
-@pytest.mark.parametrize("one_phase", [False, True])
+@pytest.mark.parametrize("one_phase,rows", [(False, "16"), (True, "16"), (False, "64")])
 @pytest.mark.parametrize("min_len_scale", [0.0, 1.0])
-def test_compat_both_interior_forms_bit_exact(pkg, O, one_phase, min_len_scale, monkeypatch):
+def test_compat_both_interior_forms_bit_exact(pkg, O, one_phase, rows, min_len_scale, monkeypatch):
     """Interior tiles of stage A run a conservative candidate test on squared lengths and the exact chain only on the
     candidates (default), or the exact chain on every pair (SC_COMPAT_ONE_PHASE=1): both against the CPU restatement,
     with min_len = 0 (coincident-point candidates) and on a scene with exact duplicates and near-threshold pairs."""
     if one_phase:
         monkeypatch.setenv("SC_COMPAT_ONE_PHASE", "1")
+    monkeypatch.setenv("SC_COMPAT_ROWS", rows)  # 64-row tiles: the experimental variant of launch_compat
     sc = pkg.synth.make_scene(1500, 0.3, 1.0, 0.05, seed=77)
     src, tgt = sc.src.copy(), sc.tgt.copy()
     src[100:164] = src[36:100]; tgt[100:164] = tgt[36:100]        # exact duplicates: zero lengths, ties
