@@ -41,6 +41,8 @@ def main() -> int:
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--config", default="C2", help="synthetic scene template (default: the headline config C2)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--split-sample", choices=("auto", "on", "off"), default="auto",
+                    help="shard stage B's pruning sample over the ranks (one extra 1 KiB all-reduce); auto: world >= 4")
     args = ap.parse_args()
 
     import torch
@@ -55,11 +57,19 @@ def main() -> int:
         if rank == 0:
             print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch one rank per GPU", file=sys.stderr)
         return 2
+    # SC_BENCH_REHEARSAL=1: every rank on cuda:0 over gloo — runs the whole N > 1 code path (sharded sample, histogram
+    # all-reduce, key all-gather, gathered finalize) on a one-GPU box; its timings mean nothing (RCCL is not in it)
+    rehearsal = os.environ.get("SC_BENCH_REHEARSAL") == "1"
+    if rehearsal:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)  # "nccl" is RCCL on ROCm
+        if rehearsal:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)  # "nccl" is RCCL on ROCm
 
     cfg, scene = pkg.synth.make_config_scene(args.config)
     T_per_gpu = cfg.T
@@ -81,10 +91,24 @@ def main() -> int:
     d_mask = torch.zeros(cfg.n, dtype=torch.uint8, device=dev)
     torch.cuda.synchronize()
 
+    # Stage B's certificate samples ~5 T_total / 8 edges; replicated, that is 126 us at T_total = 400k (33 us at 50k).
+    # From 4 ranks on, every rank samples its share and the 256-bin histograms are summed by one 1 KiB all-reduce
+    # (sc_hypothesize_begin_device / _end_device); below that the extra collective costs more than it saves.
+    split = args.split_sample == "on" or (args.split_sample == "auto" and world >= 4)
+    d_hist = torch.zeros(pkg.SC_HIST_WORDS, dtype=torch.int32, device=dev)
+    d_all = torch.zeros(2 * world, dtype=torch.int64, device=dev)  # every rank's key pair (one all-gather)
+
     def step(prm=params):
-        reg.hypothesize_device(d_src.data_ptr(), d_tgt.data_ptr(), cfg.n, prm, d_key.data_ptr())  # no host wait at its end
-        pkg.shard.allreduce_best(d_key)
-        return reg.finalize_device(d_key.data_ptr(), d_Rt.data_ptr(), d_mask.data_ptr())  # (rc, stats incl. event times)
+        if split:
+            reg.hypothesize_begin_device(d_src.data_ptr(), d_tgt.data_ptr(), cfg.n, prm, d_hist.data_ptr())
+            pkg.shard.allreduce_hist(d_hist)
+            reg.hypothesize_end_device(d_hist.data_ptr(), d_key.data_ptr())
+        else:
+            reg.hypothesize_device(d_src.data_ptr(), d_tgt.data_ptr(), cfg.n, prm, d_key.data_ptr())  # no host wait at its end
+        if world == 1:
+            return reg.finalize_device(d_key.data_ptr(), d_Rt.data_ptr(), d_mask.data_ptr())  # (rc, stats incl. event times)
+        pkg.shard.allgather_best(d_key, d_all)  # ONE collective (16 bytes per rank); the reduction runs in the kernel
+        return reg.finalize_gathered_device(d_all.data_ptr(), world, d_Rt.data_ptr(), d_mask.data_ptr())
 
     def fence():
         torch.cuda.synchronize()
@@ -165,11 +189,12 @@ def main() -> int:
             "metric": "triangle-hypotheses scored/sec (end-to-end: compat graph + ranked triangles + SVD + scoring + mask)",
             "value": value, "unit": "hypotheses/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "ms_to_best_Rt": ms_per_step, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic" + (" (REHEARSAL: all ranks on one GPU over gloo)" if rehearsal else ""),
             "config": {"workload": f"{cfg.name}: N={n} synthetic correspondences ({cfg.rho:.0%} inliers, L={cfg.L}, "
                                    f"tau={cfg.tau}), T={T_per_gpu} ranked triangles scored per GPU (T_total={T_total})",
                        "n_corr": n, "triangles_per_gpu": T_per_gpu, "triangles_total": T_total,
-                       "edges": st["edges"], "triangles_in_graph": st["tri_total"], "parallelism": f"shard{world}"},
+                       "edges": st["edges"], "triangles_in_graph": st["tri_total"], "parallelism": f"shard{world}",
+                       "pruning_sample": "sharded + 1 KiB all-reduce" if split else "replicated"},
             "score_stage_hyp_per_s": n_local * world / ((avg["us_kabsch"] + avg["us_score"] + avg["us_argmax"]) * 1e-6),
             "stage_us": {k[3:]: round(v, 2) for k, v in avg.items()},  # untimed diagnostic pass (all stages bracketed)
             "winner": {"rank": st["best_rank"], "inliers": st["best_count"], "status": rc},

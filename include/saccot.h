@@ -117,8 +117,14 @@ void        sc_default_params(sc_params* p);  /* size set, sigma = tau = min_len
 int         sc_create(int device, sc_ctx** out);      /* binds `device`, creates a private stream    */
 void        sc_destroy(sc_ctx* ctx);                   /* frees the workspace; NULL is a no-op        */
 int         sc_set_stream(sc_ctx* ctx, void* hip_stream); /* enqueue on a caller stream (e.g. torch's
-                                                 current stream) instead of the private one; NULL
-                                                 restores the private stream                          */
+                                                 current stream) instead of the private one, so that the
+                                                 caller's own work on that stream (an all-reduce of d_key,
+                                                 a copy of d_mask) is ordered with the kernels.  NULL
+                                                 restores the private stream, which is NON-blocking: nothing
+                                                 orders it against other streams.  The device's default
+                                                 (null) stream has no handle of its own: pass
+                                                 SC_STREAM_DEFAULT for it (torch reports it as 0)        */
+#define SC_STREAM_DEFAULT ((void*)1)
 const char* sc_last_error(const sc_ctx* ctx);          /* last HIP error text seen by this context    */
 
 /* ---- the drop-in entry point: correspondences in, (R, t, inlier mask) out ------------------------
@@ -155,6 +161,24 @@ int sc_register_device(sc_ctx* ctx, const float* d_src, const float* d_tgt, int6
 int sc_hypothesize_device(sc_ctx* ctx, const float* d_src, const float* d_tgt, int64_t n,
                           const sc_params* params, uint64_t* d_key, sc_stats* stats);
 int sc_finalize_device(sc_ctx* ctx, const uint64_t* d_key, float* d_Rt, uint8_t* d_mask, sc_stats* stats);
+
+/* Phase 2 on the all-GATHERED key pairs: d_keys holds n_pairs pairs (rank r's pair at d_keys[2r], d_keys[2r+1]), e.g. the
+ * output of ONE all-gather of the 16-byte pairs; the reduction described above (a lexicographic max) runs inside the
+ * finalize kernel.  One collective per call instead of two dependent ones; sc_finalize_device is the n_pairs = 1 case. */
+int sc_finalize_gathered_device(sc_ctx* ctx, const uint64_t* d_keys, int n_pairs, float* d_Rt, uint8_t* d_mask,
+                                sc_stats* stats);
+
+/* Phase 1 in two halves, for large T_total over several GPUs: stage B's certificate (sc_tri.hip 3b) samples ~5T/8
+ * edges, which every rank would otherwise repeat (126 us at T_total = 400 k against 33 us at 50 k).  `begin` runs A,
+ * the edge list and THIS rank's share of the sample (every shard_world-th sampled edge) into d_hist (device,
+ * SC_HIST_WORDS x u32, zeroed here); the caller SUMS d_hist over the ranks (one 1 KiB all-reduce; any order: integer
+ * sums) and passes the result to `end`, which prunes, enumerates, selects and scores exactly like
+ * sc_hypothesize_device — the summed histogram counts distinct genuine triangles, so the bound it certifies is valid
+ * and identical on every rank, and results equal the unsharded run's.  With shard_world == 1 the sum is the identity. */
+#define SC_HIST_WORDS 256
+int sc_hypothesize_begin_device(sc_ctx* ctx, const float* d_src, const float* d_tgt, int64_t n,
+                                const sc_params* params, uint32_t* d_hist, sc_stats* stats);
+int sc_hypothesize_end_device(sc_ctx* ctx, const uint32_t* d_hist, uint64_t* d_key, sc_stats* stats);
 
 /* ---- stage-level hooks (host pointers in and out) so every kernel is parity-testable alone --------
  * All take SoA or AoS input per params->layout and run ONLY the named stage(s) on the GPU. */

@@ -20,9 +20,11 @@ SC_OK, SC_EINVAL, SC_ENOMEM, SC_EHIP, SC_ERCCL, SC_ENOHYP, SC_ETOOMANY = 0, -1, 
 SC_AOS, SC_SOA = 0, 1
 SC_RANK_WEIGHT, SC_RANK_DEGREE = 0, 1
 SC_FLAG_TIMING, SC_FLAG_EXACT_TOTAL, SC_FLAG_NO_PRUNE, SC_FLAG_REFINE, SC_FLAG_TIMING_HOT = 1, 2, 4, 8, 16
+SC_HIST_WORDS = 256  # u32 words of the pruning-sample histogram (sc_hypothesize_begin_device)
 
 EXPORTS = ["sc_version", "sc_strerror", "sc_default_params", "sc_create", "sc_destroy", "sc_set_stream",
            "sc_last_error", "sc_register", "sc_register_device", "sc_hypothesize_device", "sc_finalize_device",
+           "sc_hypothesize_begin_device", "sc_hypothesize_end_device", "sc_finalize_gathered_device",
            "sc_compat_host", "sc_triangles_host", "sc_kabsch_host", "sc_score_host", "sc_mask_host"]
 
 
@@ -84,6 +86,9 @@ def load_library() -> C.CDLL:
     L.sc_register_device.argtypes = [vp, vp, vp, C.c_int64, pp, vp, vp, sp]
     L.sc_hypothesize_device.argtypes = [vp, vp, vp, C.c_int64, pp, vp, sp]
     L.sc_finalize_device.argtypes = [vp, vp, vp, vp, sp]
+    L.sc_hypothesize_begin_device.argtypes = [vp, vp, vp, C.c_int64, pp, vp, sp]
+    L.sc_hypothesize_end_device.argtypes = [vp, vp, vp, sp]
+    L.sc_finalize_gathered_device.argtypes = [vp, vp, C.c_int, vp, vp, sp]
     L.sc_compat_host.argtypes = [vp, f32p, f32p, C.c_int64, pp, f32p, u64p, u32p]
     L.sc_triangles_host.argtypes = [vp, f32p, f32p, C.c_int64, pp, u32p, u32p, u32p, u64p, u64p]
     L.sc_kabsch_host.argtypes = [vp, f32p, f32p, C.c_int64, pp, u32p, C.c_uint32, f32p]
@@ -137,7 +142,16 @@ class Registrar:
         return rc
 
     def set_stream(self, stream_ptr: int | None):
-        self._check(self._lib.sc_set_stream(self._h, C.c_void_p(stream_ptr or 0)))
+        """Enqueue on a caller stream: pass `torch.cuda.current_stream().cuda_stream` (0 = the default stream, mapped
+        to SC_STREAM_DEFAULT here).  None restores the context's private, NON-blocking stream — nothing the caller
+        enqueues elsewhere (an all-reduce of the key, a copy of the mask) is ordered against it."""
+        if stream_ptr is None:
+            ptr = 0
+        elif stream_ptr == 0:
+            ptr = 1  # SC_STREAM_DEFAULT
+        else:
+            ptr = stream_ptr
+        self._check(self._lib.sc_set_stream(self._h, C.c_void_p(ptr)))
 
     # ---- drop-in entry point ----------------------------------------------------------------------------
     def register(self, src, tgt, params: ScParams | None = None, **kw):
@@ -164,9 +178,29 @@ class Registrar:
         self._check(self._lib.sc_hypothesize_device(self._h, d_src, d_tgt, n, C.byref(params), d_key, C.byref(st)))
         return st.as_dict()
 
+    def hypothesize_begin_device(self, d_src: int, d_tgt: int, n: int, params: ScParams, d_hist: int):
+        """Phase 1, first half (include/saccot.h): A, edges, and this rank's share of the pruning sample into
+        d_hist (SC_HIST_WORDS u32 on the device, zeroed by the call).  Sum d_hist over the ranks
+        (shard.allreduce_hist), then call hypothesize_end_device."""
+        st = ScStats(C.sizeof(ScStats))
+        self._check(self._lib.sc_hypothesize_begin_device(self._h, d_src, d_tgt, n, C.byref(params), d_hist, C.byref(st)))
+        return st.as_dict()
+
+    def hypothesize_end_device(self, d_hist: int, d_key: int):
+        st = ScStats(C.sizeof(ScStats))
+        self._check(self._lib.sc_hypothesize_end_device(self._h, d_hist, d_key, C.byref(st)))
+        return st.as_dict()
+
     def finalize_device(self, d_key: int, d_Rt: int, d_mask: int):
         st = ScStats(C.sizeof(ScStats))
         rc = self._check(self._lib.sc_finalize_device(self._h, d_key, d_Rt, d_mask, C.byref(st)), allow=(SC_ENOHYP,))
+        return rc, st.as_dict()
+
+    def finalize_gathered_device(self, d_keys: int, n_pairs: int, d_Rt: int, d_mask: int):
+        """Phase 2 on n_pairs all-gathered key pairs (shard.allgather_best): the reduction runs in the kernel."""
+        st = ScStats(C.sizeof(ScStats))
+        rc = self._check(self._lib.sc_finalize_gathered_device(self._h, d_keys, n_pairs, d_Rt, d_mask, C.byref(st)),
+                         allow=(SC_ENOHYP,))
         return rc, st.as_dict()
 
     # ---- stage hooks -----------------------------------------------------------------------------------------

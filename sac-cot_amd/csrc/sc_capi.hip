@@ -52,11 +52,12 @@ struct sc_ctx {
   int n = 0, ld = 0;
   uint64_t E = 0, M = 0, M_total = 0;
   uint64_t ev_capacity = 1ull << 21;  // event records (32 B each); doubled after an overflow
-  bool pruned = false;
+  bool pruned = false, use_events = false, have_total = false;
   uint32_t T_eff = 0;
   Derived dv{};
   Shard sh{};
-  bool have_hyp = false;
+  bool have_hyp = false, begun = false;
+  sc_params params{};  // the parameters of the running call (begin -> end)
   bool timing = false, timing_hot = false;
   bool timed_trikeys = false;
   bool refine = false;
@@ -214,8 +215,10 @@ int wait_word(sc_ctx* c, int idx) {
 bool may_prune(const sc_params* p) { return p->rank_mode == SC_RANK_WEIGHT && !(p->flags & SC_FLAG_NO_PRUNE); }
 
 // stage B; on return c->E, c->M, c->T_eff are set and tri/trikey hold the ranked list
-// want_list: also materialise the T x 3 triangle list (stage hook; the hot path reads triangles through TriSource)
-int run_triangles(sc_ctx* c, const sc_params* p, bool want_list) {
+// Stage B, first half: CSR edge list and this process's share (`part` of `parts`) of the pruning sample, accumulated
+// into `hist` (256 u32 on the device, already zero; nullptr = the control block's own histogram).  Sets c->E and the
+// decisions the second half needs.
+int run_edges(sc_ctx* c, const sc_params* p, uint32_t* hist, uint32_t part, uint32_t parts) {
   const size_t n = c->n;
   hipStream_t st = c->stream;
   ENSURE(c, c->edge_off, (n + 1) * sizeof(uint64_t));
@@ -238,7 +241,7 @@ int run_triangles(sc_ctx* c, const sc_params* p, bool want_list) {
   { const int wrc = wait_word(c, 0); if (wrc) return wrc; }
   if ((uint32_t)c->pinned[1] != 0) { c->last_error = "non-finite input coordinate"; return SC_EINVAL; }
   const uint64_t E = c->E = c->pinned[0];
-  c->M = 0; c->M_total = 0; c->T_eff = 0; c->pruned = false;
+  c->M = 0; c->M_total = 0; c->T_eff = 0; c->pruned = false; c->use_events = false; c->have_total = false;
   if (E == 0) return SC_OK;
   ENSURE(c, c->ei, E * 4);
   ENSURE(c, c->ej, E * 4);
@@ -249,32 +252,47 @@ int run_triangles(sc_ctx* c, const sc_params* p, bool want_list) {
   ENSURE(c, c->toff, (E + 1) * 8);
   ENSURE(c, c->scan_tmp, scan_temp_bytes(E));
   if (E > spec_cap) fill_edges(E);  // first call, or the graph outgrew the arrays (just re-allocated above)
-  // certified pruning (sc_tri.hip §3b): weight ranking only; pointless on tiny graphs
-  const bool prune = may_prune(p) && E >= 4096;
-  c->pruned = prune;
+  // certified pruning (sc_tri.hip 3b): weight ranking only; pointless on tiny graphs
+  c->pruned = may_prune(p) && E >= 4096;
   // counting pass + event list (sc_tri.hip 2b) on the pruned graph; SC_NO_EVENTS=1 keeps the row-walking pair
-  const bool use_events = prune && getenv("SC_NO_EVENTS") == nullptr;
-  StrongList sl{nullptr, nullptr, 0};
-  const uint64_t* mbits = g.bits;
-  const float* smin = nullptr;
-  bool have_total = false;
-  if (prune) {
+  c->use_events = c->pruned && getenv("SC_NO_EVENTS") == nullptr;
+  if (c->pruned) {
     ControlBlock* ctl = c->ctl.as<ControlBlock>();
     if (p->flags & SC_FLAG_EXACT_TOTAL) {  // statistics only: 3-cliques of the whole graph
       launch_tri_count(g, g.bits, c->es.as<float>(), nullptr, c->ei.as<uint32_t>(), c->ej.as<uint32_t>(), E,
                        c->tcnt.as<uint32_t>(), st);
       launch_scan_u32(c->tcnt.as<uint32_t>(), E, c->toff.as<uint64_t>(), c->scan_tmp.p, st, &c->pinned[4]);
-      have_total = true;
+      c->have_total = true;
     }
     // the smallest possible weight is ~3 t_cmp (every edge has s >= t_cmp up to rounding); 0.1 % slack
+    launch_sample_hist(g, c->ebi.as<uint32_t>(), c->ebj.as<uint32_t>(), c->ei.as<uint32_t>(), c->ej.as<uint32_t>(),
+                       c->es.as<float>(), E, p->max_triangles, 3.0f * p->t_cmp * 0.999f, part, parts,
+                       hist ? hist : ctl->prune_hist, st);
+  }
+  return SC_OK;
+}
+
+// Stage B, second half: prune with the (summed) sample histogram, enumerate, select.  On return c->M, c->T_eff are set
+// and sel_ord / sel_key hold the selection.  want_list: also materialise the T x 3 triangle list (stage hook; the hot
+// path reads triangles through TriSource).  hist == nullptr: the control block's own histogram.
+int run_select(sc_ctx* c, const sc_params* p, const uint32_t* hist, bool want_list) {
+  hipStream_t st = c->stream;
+  const uint64_t E = c->E;
+  if (E == 0) return SC_OK;
+  const Graph g = graph_of(c);
+  const bool use_events = c->use_events, have_total = c->have_total;
+  StrongList sl{nullptr, nullptr, 0};
+  const uint64_t* mbits = g.bits;
+  const float* smin = nullptr;
+  if (c->pruned) {
+    ControlBlock* ctl = c->ctl.as<ControlBlock>();
     if (use_events) {  // the pruning kernel also compacts the strong edges for the counting pass
       ENSURE(c, c->strong, strong_list_bytes(E));
       sl = StrongList{c->strong.as<uint32_t>(), ctl->st_fill, strong_list_cap(E)};
     }
-    launch_prune(g, c->ebi.as<uint32_t>(), c->ebj.as<uint32_t>(), c->ei.as<uint32_t>(), c->ej.as<uint32_t>(),
-                 c->es.as<float>(), E,
-                 p->max_triangles, 3.0f * p->t_cmp * 0.999f, ctl->prune_hist, c->bits2.as<uint64_t>(), &ctl->smin, &ctl->klb,
-                 sl, c->tcnt.as<uint32_t>(), st);
+    launch_prune_bits(g, hist ? hist : ctl->prune_hist, c->ei.as<uint32_t>(), c->ej.as<uint32_t>(), c->es.as<float>(), E,
+                      p->max_triangles, 3.0f * p->t_cmp * 0.999f, c->bits2.as<uint64_t>(), &ctl->smin, &ctl->klb, sl,
+                      c->tcnt.as<uint32_t>(), st);
     mbits = c->bits2.as<uint64_t>();
     smin = &ctl->smin;
   }
@@ -354,6 +372,11 @@ int run_triangles(sc_ctx* c, const sc_params* p, bool want_list) {
     launch_tri_decode(c->ei.as<uint32_t>(), c->ej.as<uint32_t>(), c->kcol.as<uint2>(), c->sel_ord.as<uint64_t>(), T_eff,
                       c->tri.as<uint32_t>(), st);
   return SC_OK;
+}
+
+int run_triangles(sc_ctx* c, const sc_params* p, bool want_list) {
+  const int rc = run_edges(c, p, nullptr, 0, 1);
+  return rc ? rc : run_select(c, p, nullptr, want_list);
 }
 
 void fill_stats(const sc_ctx* c, sc_stats* s) {
@@ -448,7 +471,7 @@ int sc_create(int device, sc_ctx** out) {
 void sc_destroy(sc_ctx* c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
-  if (c->stream) (void)hipStreamSynchronize(c->stream);
+  (void)hipStreamSynchronize(c->stream);  // nullptr = the default stream
   Buf* bufs[] = {&c->in_src, &c->in_tgt, &c->planes, &c->S, &c->bits, &c->deg, &c->degp, &c->wpre, &c->ebase, &c->edge_off, &c->scan_tmp,
                  &c->ei, &c->ej, &c->es, &c->ebi, &c->ebj, &c->tcnt, &c->toff, &c->wkey, &c->kcol, &c->ctl, &c->events, &c->blk_gt, &c->blk_eq, &c->blk_minmax, &c->bits2, &c->off_gt,
                  &c->off_eq, &c->sel_ord, &c->sel_key, &c->sortkey, &c->sorted, &c->sort_tmp, &c->tri, &c->tri_rk, &c->key_rk, &c->rt,
@@ -464,34 +487,50 @@ int sc_set_stream(sc_ctx* c, void* hip_stream) {
   if (!c) return SC_EINVAL;
   (void)hipSetDevice(c->device);
   HIPCHK(c, hipStreamSynchronize(c->stream));
-  c->stream = hip_stream ? static_cast<hipStream_t>(hip_stream) : c->own_stream;
+  if (hip_stream == SC_STREAM_DEFAULT) c->stream = nullptr;  // the null stream
+  else c->stream = hip_stream ? static_cast<hipStream_t>(hip_stream) : c->own_stream;
   return SC_OK;
 }
 
 const char* sc_last_error(const sc_ctx* c) { return c ? c->last_error.c_str() : "null context"; }
 
-int sc_hypothesize_device(sc_ctx* c, const float* d_src, const float* d_tgt, int64_t n, const sc_params* p,
-                          uint64_t* d_key, sc_stats* stats) {
-  if (!c || !d_src || !d_tgt || !d_key) return SC_EINVAL;
+}  // extern "C" (the two halves below are internal)
+
+namespace {
+
+// phase 1, first half: staging, stage A, the edge list and this process's share of the pruning sample
+int hyp_begin(sc_ctx* c, const float* d_src, const float* d_tgt, int64_t n, const sc_params* p, uint32_t* d_hist,
+              uint32_t part, uint32_t parts) {
   int rc = check_params(p);
   if (rc) return rc;
   HIPCHK(c, hipSetDevice(c->device));
   c->have_hyp = false;
+  c->begun = false;
   c->timed_trikeys = false;
   c->timing = (p->flags & SC_FLAG_TIMING) != 0;
   c->timing_hot = !c->timing && (p->flags & SC_FLAG_TIMING_HOT) != 0;
   c->refine = (p->flags & SC_FLAG_REFINE) != 0;
   c->cap_bytes = p->max_workspace ? p->max_workspace : (64ull << 30);
   c->dv = derive(p);
+  c->params = *p;
   if ((rc = rec(c, 0))) return rc;
   if ((rc = stage_inputs(c, d_src, d_tgt, n, p))) return rc;
   if ((rc = rec(c, 1))) return rc;
   if ((rc = run_compat(c))) return rc;
   if ((rc = rec(c, 2))) return rc;
   if ((rc = run_row_stats(c, may_prune(p)))) return rc;
-  if ((rc = run_triangles(c, p, false))) return rc;
+  if ((rc = run_edges(c, p, d_hist, part, parts))) return rc;
+  c->begun = true;
+  return SC_OK;
+}
+
+// phase 1, second half: prune with the (summed) histogram, enumerate, select, then stage C on this rank's share
+int hyp_end(sc_ctx* c, const uint32_t* d_hist, uint64_t* d_key, sc_stats* stats) {
+  const sc_params* p = &c->params;
+  int rc;
+  c->begun = false;
+  if ((rc = run_select(c, p, d_hist, false))) return rc;
   if ((rc = rec(c, 3))) return rc;
-  // stage C on this rank's share of the ranked list
   Shard sh;
   sh.T_eff = c->T_eff;
   sh.block = p->shard_block ? p->shard_block : 1024u;
@@ -520,19 +559,53 @@ int sc_hypothesize_device(sc_ctx* c, const float* d_src, const float* d_tgt, int
   return SC_OK;
 }
 
+}  // namespace
+
+extern "C" {
+
+int sc_hypothesize_device(sc_ctx* c, const float* d_src, const float* d_tgt, int64_t n, const sc_params* p,
+                          uint64_t* d_key, sc_stats* stats) {
+  if (!c || !d_src || !d_tgt || !d_key) return SC_EINVAL;
+  const int rc = hyp_begin(c, d_src, d_tgt, n, p, nullptr, 0, 1);  // the whole sample, into the context's histogram
+  return rc ? rc : hyp_end(c, nullptr, d_key, stats);
+}
+
+int sc_hypothesize_begin_device(sc_ctx* c, const float* d_src, const float* d_tgt, int64_t n, const sc_params* p,
+                                uint32_t* d_hist, sc_stats* stats) {
+  if (!c || !d_src || !d_tgt || !d_hist) return SC_EINVAL;
+  if (!p || p->size != sizeof(sc_params)) return SC_EINVAL;
+  HIPCHK(c, hipSetDevice(c->device));
+  HIPCHK(c, hipMemsetAsync(d_hist, 0, SC_HIST_WORDS * sizeof(uint32_t), c->stream));
+  const int rc = hyp_begin(c, d_src, d_tgt, n, p, d_hist, (uint32_t)p->shard_rank, (uint32_t)p->shard_world);
+  if (rc == SC_OK) fill_stats(c, stats);
+  return rc;
+}
+
+int sc_hypothesize_end_device(sc_ctx* c, const uint32_t* d_hist, uint64_t* d_key, sc_stats* stats) {
+  if (!c || !d_hist || !d_key) return SC_EINVAL;
+  if (!c->begun) { c->last_error = "sc_hypothesize_end_device without a preceding sc_hypothesize_begin_device"; return SC_EINVAL; }
+  HIPCHK(c, hipSetDevice(c->device));
+  return hyp_end(c, d_hist, d_key, stats);
+}
+
 int sc_finalize_device(sc_ctx* c, const uint64_t* d_key, float* d_Rt, uint8_t* d_mask, sc_stats* stats) {
-  if (!c || !d_key || !d_Rt || !d_mask) return SC_EINVAL;
+  return sc_finalize_gathered_device(c, d_key, 1, d_Rt, d_mask, stats);
+}
+
+int sc_finalize_gathered_device(sc_ctx* c, const uint64_t* d_keys, int n_pairs, float* d_Rt, uint8_t* d_mask,
+                                sc_stats* stats) {
+  if (!c || !d_keys || !d_Rt || !d_mask || n_pairs < 1 || n_pairs > 4096) return SC_EINVAL;
   if (!c->have_hyp) { c->last_error = "sc_finalize_device without a preceding sc_hypothesize_device"; return SC_EINVAL; }
   HIPCHK(c, hipSetDevice(c->device));
   int rc;
   if ((rc = rec(c, 7))) return rc;
   arm_word(c, 8);
-  launch_finalize(points_of(c), tri_source_of(c), c->T_eff ? c->sel_key.as<uint32_t>() : nullptr, c->T_eff, d_key,
-                  c->dv.tau2, d_Rt, d_mask, &c->ctl.as<ControlBlock>()->fin_rank, &c->ctl.as<ControlBlock>()->fin_ticket,
-                  &c->pinned[8], c->stream);
+  ControlBlock* ctl = c->ctl.as<ControlBlock>();
+  launch_finalize(points_of(c), tri_source_of(c), c->T_eff ? c->sel_key.as<uint32_t>() : nullptr, c->T_eff, d_keys, n_pairs,
+                  ctl->key2, c->dv.tau2, d_Rt, d_mask, &ctl->fin_rank, &ctl->fin_ticket, &c->pinned[8], c->stream);
   if (c->refine) {  // fp64 least-squares refit over the winner's inliers (mask unchanged)
     ENSURE(c, c->refine_tmp, refine_scratch_bytes(c->n));
-    launch_refine(points_of(c), d_mask, d_key, c->refine_tmp.as<double>(), d_Rt, c->stream);
+    launch_refine(points_of(c), d_mask, ctl->key2, c->refine_tmp.as<double>(), d_Rt, c->stream);
   }
   if ((rc = rec(c, 8))) return rc;
   // The finalize kernel publishes key / position / rank.  On a caller-provided stream (sc_set_stream) d_Rt and d_mask

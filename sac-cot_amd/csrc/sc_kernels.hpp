@@ -79,15 +79,20 @@ struct StrongList {
 uint32_t strong_list_cap(uint64_t E);
 size_t strong_list_bytes(uint64_t E);
 
-// Certified pruning (weight ranking): samples every R-th edge's triangles into `hist` (2048 u32), derives the
-// strong-edge threshold *smin (device float; -1 = nothing certified) and builds the strong upper-triangle bit
-// matrix `mbits` (n x W, zeroed here).  key_floor: a value at or below the smallest possible triangle weight.
-void launch_prune(const Graph& g, const uint32_t* ebi, const uint32_t* ebj, const uint32_t* ei, const uint32_t* ej,
-                  const float* es,
-                  uint64_t E, uint64_t want, float key_floor, uint32_t* hist, uint64_t* mbits, float* smin,
-                  uint32_t* klb, const StrongList& sl, uint32_t* tcnt,
-                  hipStream_t st);  // hist and mbits must already be zero; *klb = key of the bound or 0; with
-                                    // sl.list set it also compacts the strong edges and zeroes tcnt of the weak ones
+// Certified pruning (weight ranking), two launches:
+//  launch_sample_hist: the triangles of every R-th edge go into `hist` (256 u32, zeroed by the caller); `part` of
+//    `parts`: this launch takes every parts-th SAMPLED edge starting at `part` (one process per GPU: the histograms of
+//    all parts are summed before launch_prune_bits sees them).  key_floor: a value at or below the smallest possible
+//    triangle weight.
+//  launch_prune_bits: derives the strong-edge threshold *smin (device float; -1 = nothing certified) and *klb (key of
+//    the bound or 0) from the histogram, builds the strong upper-triangle bit matrix `mbits` (n x W, already zero), and
+//    with sl.list set also compacts the strong edges and zeroes tcnt of the weak ones.
+void launch_sample_hist(const Graph& g, const uint32_t* ebi, const uint32_t* ebj, const uint32_t* ei,
+                        const uint32_t* ej, const float* es, uint64_t E, uint64_t want, float key_floor, uint32_t part,
+                        uint32_t parts, uint32_t* hist, hipStream_t st);
+void launch_prune_bits(const Graph& g, const uint32_t* hist, const uint32_t* ei, const uint32_t* ej, const float* es,
+                       uint64_t E, uint64_t want, float key_floor, uint64_t* mbits, float* smin, uint32_t* klb,
+                       const StrongList& sl, uint32_t* tcnt, hipStream_t st);
 
 // Event list of stage B (sc_tri.hip 2b): one record per non-zero member word of a strong edge, SoA, split into
 // EV_SHARDS regions of shard_cap records; fill[shard] = records appended to that region.
@@ -214,9 +219,11 @@ void launch_argmax(const Points& pts, const Shard& sh, const uint32_t* partial, 
 // C3: winner decode + re-solve + mask.  Rt12 receives R (row-major) and t; identity / zero mask when key2[0] == 0.
 // sel_key / T: the ordinal-ordered ranking keys (for the winner's rank index); host_out (pinned, 3 x u64) receives
 // key2[0], the winner's position and its rank index.
+// key2: npairs key pairs (all-gathered, one per rank; 1 = already reduced); key_out (2 x u64, optional) receives the
+// reduced pair.
 void launch_finalize(const Points& pts, const TriSource& ts, const uint32_t* sel_key, uint32_t T,
-                     const uint64_t* key2, float tau2, float* Rt12, uint8_t* mask, uint32_t* rank_acc,
-                     uint32_t* ticket, uint64_t* host_out, hipStream_t st);
+                     const uint64_t* key2, int npairs, uint64_t* key_out, float tau2, float* Rt12, uint8_t* mask,
+                     uint32_t* rank_acc, uint32_t* ticket, uint64_t* host_out, hipStream_t st);
 // SURVEY §8f-2 (SC_FLAG_REFINE): fp64 least-squares refit of Rt12 over the inlier mask; no-op when key2[0] == 0 or
 // fewer than 3 inliers.  scratch: refine_scratch_bytes(n).
 size_t refine_scratch_bytes(int n);

@@ -403,17 +403,25 @@ void launch_argmax(const Points& pts, const Shard& sh, const uint32_t* partial, 
 __global__ __launch_bounds__(256) void finalize_kernel(const float* __restrict__ planes, int n, int ld,
                                                        TriSource ts,
                                                        const uint32_t* __restrict__ sel_key, uint32_t T,
-                                                       const unsigned long long* __restrict__ key2, float tau2,
+                                                       const unsigned long long* __restrict__ key2, int npairs,
+                                                       unsigned long long* __restrict__ key_out, float tau2,
                                                        float* __restrict__ Rt12, uint8_t* __restrict__ mask,
                                                        uint32_t* __restrict__ rank_acc, uint32_t* __restrict__ ticket,
                                                        unsigned long long* __restrict__ host_out) {
   __shared__ uint64_t lds[8];
   __shared__ float sRt[12];
   __shared__ uint32_t s_last;
-  const unsigned long long k0 = key2[0];
+  // key2: npairs winner key pairs (one per rank, all-gathered; npairs = 1: an already reduced pair).  The reduction of
+  // include/saccot.h — K0 = max pair[0], K1 = max pair[1] among the pairs attaining K0 — is a lexicographic max.
+  unsigned long long k0 = 0, k1 = 0;
+  for (int w = 0; w < npairs; w++) {  // wave-uniform addresses: scalar loads
+    const unsigned long long a = key2[2 * w], b = key2[2 * w + 1];
+    if (a > k0 || (a == k0 && b > k1)) { k0 = a; k1 = b; }
+  }
+  if (key_out && blockIdx.x == 0 && threadIdx.x == 0) { key_out[0] = k0; key_out[1] = k0 ? k1 : 0ull; }
   const bool two_stage = sel_key != nullptr;
   uint32_t g = 0;
-  if (k0 != 0) g = 0xFFFFFFFFu - (uint32_t)((two_stage ? key2[1] : k0) & 0xFFFFFFFFull);
+  if (k0 != 0) g = 0xFFFFFFFFu - (uint32_t)((two_stage ? k1 : k0) & 0xFFFFFFFFull);
   if (threadIdx.x == 0) {
     float Rt[12] = {1.f, 0.f, 0.f, 0.f, 1.f, 0.f, 0.f, 0.f, 1.f, 0.f, 0.f, 0.f};
     if (k0 != 0) {
@@ -494,13 +502,14 @@ __global__ __launch_bounds__(256) void mask_kernel(const float* __restrict__ pla
 }
 
 void launch_finalize(const Points& pts, const TriSource& ts, const uint32_t* sel_key, uint32_t T,
-                     const uint64_t* key2, float tau2, float* Rt12, uint8_t* mask, uint32_t* rank_acc,
-                     uint32_t* ticket, uint64_t* host_out, hipStream_t st) {
+                     const uint64_t* key2, int npairs, uint64_t* key_out, float tau2, float* Rt12, uint8_t* mask,
+                     uint32_t* rank_acc, uint32_t* ticket, uint64_t* host_out, hipStream_t st) {
   uint32_t blocks = (uint32_t)((pts.n + 255) / 256);  // the mask needs these; more only if the key list is long
   const uint32_t for_keys = (T / 4 + 1023) / 1024;    // >= 4 uint4 per thread before another block pays off
   if (for_keys > blocks) blocks = for_keys < 1024u ? for_keys : 1024u;
   hipLaunchKernelGGL(finalize_kernel, dim3(blocks), dim3(256), 0, st, pts.planes, pts.n, pts.ld, ts, sel_key, T,
-                     reinterpret_cast<const unsigned long long*>(key2), tau2, Rt12, mask, rank_acc, ticket,
+                     reinterpret_cast<const unsigned long long*>(key2), npairs,
+                     reinterpret_cast<unsigned long long*>(key_out), tau2, Rt12, mask, rank_acc, ticket,
                      reinterpret_cast<unsigned long long*>(host_out));
 }
 

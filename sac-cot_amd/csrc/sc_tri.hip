@@ -664,16 +664,20 @@ __global__ __launch_bounds__(256) void tri_sample_hist_kernel(const uint64_t* __
                                                               const uint32_t* __restrict__ ei,
                                                               const uint32_t* __restrict__ ej,
                                                               const float* __restrict__ es, uint64_t E,
-                                                              uint32_t stride, uint32_t klo, uint32_t shift,
+                                                              uint32_t stride, uint32_t part, uint32_t parts,
+                                                              uint32_t klo, uint32_t shift,
                                                               uint32_t* __restrict__ hist) {
   __shared__ uint32_t lh[PR_BINS * PR_COPIES];  // [bin][copy]
   for (int b = threadIdx.x; b < PR_BINS * PR_COPIES; b += 256) lh[b] = 0;
   __syncthreads();
   const int gl = threadIdx.x & (TG - 1);
-  const uint64_t n_s = (E + stride - 1) / stride;  // sampled edges: e = g * stride
+  const uint64_t n_s = (E + stride - 1) / stride;  // sampled edges: e = g * stride, g = 0 .. n_s - 1
+  // this launch takes the sampled edges g = part, part + parts, ... (one process per GPU: every rank samples its share
+  // and the histograms are summed by an all-reduce — distinct edges give distinct triangles, so the sum certifies)
+  const uint64_t n_loc = n_s > part ? (n_s - part + parts - 1) / parts : 0;
   const uint64_t groups = (uint64_t)gridDim.x * (256 / TG);
-  for (uint64_t g = (uint64_t)blockIdx.x * (256 / TG) + (threadIdx.x / TG); g < n_s; g += groups) {
-    const uint64_t e = g * stride;
+  for (uint64_t q = (uint64_t)blockIdx.x * (256 / TG) + (threadIdx.x / TG); q < n_loc; q += groups) {
+    const uint64_t e = (q * parts + part) * stride;
     const uint32_t i = ei[e], j = ej[e];
     const uint32_t rowi = i * (uint32_t)W, rowj = j * (uint32_t)W;
     const int w0 = j >> 6;
@@ -797,21 +801,26 @@ uint32_t strong_list_cap(uint64_t E) {
 size_t strong_list_bytes(uint64_t E) { return (size_t)strong_list_cap(E) * ST_SHARDS * sizeof(uint32_t); }
 
 
-void launch_prune(const Graph& g, const uint32_t* ebi, const uint32_t* ebj, const uint32_t* ei, const uint32_t* ej,
-                  const float* es,
-                  uint64_t E, uint64_t want, float key_floor, uint32_t* hist, uint64_t* mbits, float* smin,
-                  uint32_t* klb, const StrongList& sl, uint32_t* tcnt, hipStream_t st) {
-  // histogram window in key space: [bits(key_floor), bits(3.0f)], monotone in the value
+// histogram window in key space: [bits(key_floor), bits(3.0f)], monotone in the value; (khi - klo) >> shift < 256
+static void prune_window(float key_floor, uint32_t* klo_out, uint32_t* shift_out) {
   const uint32_t khi = 0x40400000u;  // 3.0f
   uint32_t klo;
   memcpy(&klo, &key_floor, 4);
   if (!(key_floor > 0.f) || klo >= khi) klo = 0x3F800000u;  // 1.0f
   const uint32_t range = khi - klo;
   const int bitsn = 32 - __builtin_clz(range);
-  const uint32_t shift = bitsn > 8 ? (uint32_t)(bitsn - 8) : 0u;  // (khi - klo) >> shift < 256
+  *klo_out = klo;
+  *shift_out = bitsn > 8 ? (uint32_t)(bitsn - 8) : 0u;
+}
+
+void launch_sample_hist(const Graph& g, const uint32_t* ebi, const uint32_t* ebj, const uint32_t* ei,
+                        const uint32_t* ej, const float* es, uint64_t E, uint64_t want, float key_floor, uint32_t part,
+                        uint32_t parts, uint32_t* hist, hipStream_t st) {
+  uint32_t klo, shift;
+  prune_window(key_floor, &klo, &shift);
   // every R-th edge.  The sample must grow with T: the bound is the T-th largest SAMPLED key, so a small sample of a
-  // large T certifies little.  ~5T/8 sampled edges (>= 32k) was the sweet spot on C2 for T = 50k ... 400k
-  // (0.51 / 0.61 ms per step against 0.52 / 0.77 ms with a fixed 32k); SC_SAMPLE_EDGES overrides (tuning knob).
+  // large T certifies little.  ~5T/8 sampled edges (>= 32k) is the sweet spot on C2 for T = 50k ... 400k (swept again
+  // at the end of round 1); SC_SAMPLE_EDGES overrides (tuning knob).
   uint64_t target = want * 5 / 8;
   if (target < 32768) target = 32768;
   if (getenv("SC_SAMPLE_EDGES")) target = (uint64_t)atoll(getenv("SC_SAMPLE_EDGES"));
@@ -819,14 +828,22 @@ void launch_prune(const Graph& g, const uint32_t* ebi, const uint32_t* ebj, cons
   if (stride < 1) stride = 1;
   if (stride > 64) stride = 64;
   const uint64_t n_s = (E + stride - 1) / stride;
+  const uint64_t n_loc = n_s > part ? (n_s - part + parts - 1) / parts : 0;
+  if (n_loc == 0) return;
   const int tg = tune_tg("SC_TG_SAMPLE", 8);
-  uint64_t nb = (n_s + (256 / tg) - 1) / (256 / tg);
-  // about one sampled edge per group: the kernel's time is the dependent-load chain of its heaviest edges, so
-  // stacking several edges per group only adds to it (measured: 256 blocks 70 us, 1024+ blocks 35 us on C2)
+  uint64_t nb = (n_loc + (256 / tg) - 1) / (256 / tg);
+  // about one sampled edge per group (measured: 256 blocks 70 us, 1024+ blocks 35 us on C2)
   if (nb > 4096) nb = 4096;
-#define SC_LAUNCH_SAMPLE(TGV) hipLaunchKernelGGL(tri_sample_hist_kernel<TGV>, dim3((unsigned)nb), dim3(256), 0, st, g.bits, g.W, g.wpre, ebi, ebj, ei, ej, es, E, (uint32_t)stride, klo, shift, hist)
+#define SC_LAUNCH_SAMPLE(TGV) hipLaunchKernelGGL(tri_sample_hist_kernel<TGV>, dim3((unsigned)nb), dim3(256), 0, st, g.bits, g.W, g.wpre, ebi, ebj, ei, ej, es, E, (uint32_t)stride, part, parts, klo, shift, hist)
   if (tg == 4) SC_LAUNCH_SAMPLE(4); else if (tg == 8) SC_LAUNCH_SAMPLE(8); else if (tg == 32) SC_LAUNCH_SAMPLE(32); else if (tg == 64) SC_LAUNCH_SAMPLE(64); else SC_LAUNCH_SAMPLE(16);
 #undef SC_LAUNCH_SAMPLE
+}
+
+void launch_prune_bits(const Graph& g, const uint32_t* hist, const uint32_t* ei, const uint32_t* ej, const float* es,
+                       uint64_t E, uint64_t want, float key_floor, uint64_t* mbits, float* smin, uint32_t* klb,
+                       const StrongList& sl, uint32_t* tcnt, hipStream_t st) {
+  uint32_t klo, shift;
+  prune_window(key_floor, &klo, &shift);
   hipLaunchKernelGGL(prune_bits_kernel, dim3((unsigned)((E + 255) / 256)), dim3(256), 0, st, hist, want, klo, shift, ei,
                      ej, es, E, g.W, reinterpret_cast<unsigned long long*>(mbits), smin, klb, sl, tcnt);
 }

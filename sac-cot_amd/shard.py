@@ -70,3 +70,29 @@ def allreduce_best(key2):
         key2[1:2] = torch.where(mine == key2[0:1], key2[1:2], torch.zeros_like(key2[1:2]))
         dist.all_reduce(key2[1:2], op=dist.ReduceOp.MAX)
     return key2
+
+
+def allreduce_hist(d_hist) -> None:
+    """Sum the pruning-sample histograms of all ranks in place (include/saccot.h, sc_hypothesize_begin_device).
+    d_hist: int32 tensor of SC_HIST_WORDS entries (the counts are < 2^31: at most 5T/8 * 64 * 64 sampled triangles
+    would be needed to overflow — the bins are u32 on the device and the int32 view adds the same bit patterns).
+    One 1 KiB SUM all-reduce; no-op without an initialised process group or with world size 1."""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return
+    dist.all_reduce(d_hist, op=dist.ReduceOp.SUM)
+
+
+def allgather_best(key2, out):
+    """ONE all-gather of every rank's 16-byte winner key pair into `out` (int64 tensor of 2 * world entries, rank r's
+    pair at out[2r : 2r + 2]) for Registrar.finalize_gathered_device, instead of the two dependent MAX all-reduces of
+    allreduce_best.  Without a process group (or world 1) the pair is copied to out[0:2].  No host sync."""
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        try:
+            dist.all_gather_into_tensor(out, key2)
+        except (RuntimeError, NotImplementedError):  # a backend without the flat form
+            dist.all_gather(list(out.view(-1, 2).unbind(0)), key2)
+    else:
+        out[0:2].copy_(key2)
+    return out

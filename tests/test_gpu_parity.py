@@ -259,13 +259,100 @@ def test_register_sharded_equals_unsharded(pkg, reg):
             torch.cuda.synchronize()
             keys.append(tuple(int(x) for x in d_key.cpu())); scored += st["tri_scored"]
         assert scored == base["stats"]["tri_kept"]
-        k0, k1 = pkg.shard.reduce_pairs(keys)               # what the two all-reduces compute
+        if world % 2:
+            k0, k1 = pkg.shard.reduce_pairs(keys)           # what the two all-reduces compute
+            d_key.copy_(torch.tensor([k0, k1], dtype=torch.int64)); torch.cuda.synchronize()
+            rc, st = reg.finalize_device(d_key.data_ptr(), d_Rt.data_ptr(), d_mask.data_ptr())
+        else:                                               # what ONE all-gather delivers: the reduction runs in the kernel
+            d_all = torch.tensor([x for k in keys for x in k], dtype=torch.int64).to(dev); torch.cuda.synchronize()
+            rc, st = reg.finalize_gathered_device(d_all.data_ptr(), world, d_Rt.data_ptr(), d_mask.data_ptr())
+        torch.cuda.synchronize()
+        assert rc == 0 and st["best_rank"] == base["stats"]["best_rank"] and st["best_count"] == base["stats"]["best_count"]
+        assert np.array_equal(d_mask.cpu().numpy(), base["mask"])
+        assert d_Rt.cpu().numpy().tobytes() == np.concatenate([base["R"].ravel(), base["t"]]).tobytes()
+
+
+def test_split_phase1_sharded_sample_equals_unsharded(pkg, reg):
+    """sc_hypothesize_begin_device / _end_device (include/saccot.h): every rank samples its share of the pruning
+    certificate, the histograms are summed (the 1 KiB all-reduce, done on the host here), and the rest runs as usual.
+    The summed histogram must equal the one a single rank builds, and winner, (R,t) and mask the unsharded run's."""
+    import torch
+    cfg, scene = pkg.synth.make_config_scene("C1")
+    kw = cfg.params()
+    base = reg.register(scene.src, scene.tgt, **kw)
+    dev = torch.device("cuda:0")
+    d_src = torch.from_numpy(scene.src).to(dev); d_tgt = torch.from_numpy(scene.tgt).to(dev)
+    d_key = torch.zeros(2, dtype=torch.int64, device=dev)
+    d_hist = torch.zeros(pkg.SC_HIST_WORDS, dtype=torch.int32, device=dev)
+    d_Rt = torch.zeros(12, dtype=torch.float32, device=dev); d_mask = torch.zeros(cfg.n, dtype=torch.uint8, device=dev)
+    torch.cuda.synchronize()
+    full = None
+    for world in (1, 2, 5):
+        parts = []
+        for rank in range(world):
+            p = pkg.make_params(shard_rank=rank, shard_world=world, shard_block=256, **kw)
+            reg.hypothesize_begin_device(d_src.data_ptr(), d_tgt.data_ptr(), cfg.n, p, d_hist.data_ptr())
+            torch.cuda.synchronize()
+            parts.append(d_hist.cpu().numpy().view(np.uint32).astype(np.uint64))
+        total = sum(parts)
+        assert total.sum() > 0 and all(q.sum() > 0 for q in parts)     # every rank really sampled something
+        if full is None:
+            full = total                                                # world 1: the whole sample
+        assert np.array_equal(total, full)                              # shares partition the sample exactly
+        summed = torch.from_numpy((total & np.uint64(0xFFFFFFFF)).astype(np.uint32).view(np.int32)).to(dev)
+        keys, scored = [], 0
+        for rank in range(world):
+            p = pkg.make_params(shard_rank=rank, shard_world=world, shard_block=256, **kw)
+            reg.hypothesize_begin_device(d_src.data_ptr(), d_tgt.data_ptr(), cfg.n, p, d_hist.data_ptr())
+            d_hist.copy_(summed)                                        # what shard.allreduce_hist leaves on every rank
+            torch.cuda.synchronize()
+            st = reg.hypothesize_end_device(d_hist.data_ptr(), d_key.data_ptr())
+            torch.cuda.synchronize()
+            keys.append(tuple(int(x) for x in d_key.cpu())); scored += st["tri_scored"]
+        assert scored == base["stats"]["tri_kept"]
+        k0, k1 = pkg.shard.reduce_pairs(keys)
         d_key.copy_(torch.tensor([k0, k1], dtype=torch.int64)); torch.cuda.synchronize()
         rc, st = reg.finalize_device(d_key.data_ptr(), d_Rt.data_ptr(), d_mask.data_ptr())
         torch.cuda.synchronize()
         assert rc == 0 and st["best_rank"] == base["stats"]["best_rank"] and st["best_count"] == base["stats"]["best_count"]
         assert np.array_equal(d_mask.cpu().numpy(), base["mask"])
         assert d_Rt.cpu().numpy().tobytes() == np.concatenate([base["R"].ravel(), base["t"]]).tobytes()
+    with pytest.raises(pkg.SacCotError):                                # end without begin
+        reg.hypothesize_end_device(d_hist.data_ptr(), d_key.data_ptr())
+
+
+def test_caller_stream_orders_torch_work_with_the_kernels(pkg):
+    """sc_set_stream: on torch's current stream (the default stream, which torch reports as 0 and api.py maps to
+    SC_STREAM_DEFAULT, and a side stream) torch's own work on that stream is ordered with the library's kernels: the
+    key pair read back by torch right after hypothesize_device — no explicit synchronisation — is the final one."""
+    import torch
+    cfg, scene = pkg.synth.make_config_scene("C1")
+    dev = torch.device("cuda:0")
+    r = pkg.Registrar(0)
+    try:
+        base = r.register(scene.src, scene.tgt, **cfg.params())
+        d_src = torch.from_numpy(scene.src).to(dev); d_tgt = torch.from_numpy(scene.tgt).to(dev)
+        p = pkg.make_params(**cfg.params())
+        side = torch.cuda.Stream(device=dev)
+        torch.cuda.synchronize()
+        for stream in (torch.cuda.current_stream(dev), side):
+            with torch.cuda.stream(stream):
+                r.set_stream(stream.cuda_stream)
+                d_key = torch.zeros(2, dtype=torch.int64, device=dev)
+                d_Rt = torch.zeros(12, dtype=torch.float32, device=dev)
+                d_mask = torch.zeros(cfg.n, dtype=torch.uint8, device=dev)
+                for _ in range(3):
+                    d_key.zero_()
+                    r.hypothesize_device(d_src.data_ptr(), d_tgt.data_ptr(), cfg.n, p, d_key.data_ptr())
+                    k = d_key.clone()                          # torch work on the same stream: ordered after the arg-max
+                    rc, st = r.finalize_device(d_key.data_ptr(), d_Rt.data_ptr(), d_mask.data_ptr())
+                    m = d_mask.clone()
+                    k0 = int(k.cpu()[0])
+                    assert (k0 >> 32) == base["stats"]["best_count"] and rc == 0
+                    assert np.array_equal(m.cpu().numpy(), base["mask"])
+        r.set_stream(None)
+    finally:
+        r.close()
 
 
 def test_errors(pkg, reg):

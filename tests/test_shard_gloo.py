@@ -52,6 +52,14 @@ def _free_port():
         return s.getsockname()[1]
 
 
+def _fake_hist(rank, words):
+    """A rank's share of the sample histogram (any int32 content will do: the reduction is a plain sum; one bin is
+    chosen so that the u32 sum passes 2^31 and must wrap like the device's counters)."""
+    h = ((np.arange(words, dtype=np.int64) * (rank + 3) + 7 * rank) % 1000).astype(np.int32)
+    h[5] = np.int32(0x7FFFFFF0 if rank == 0 else 0x40)
+    return h
+
+
 def _worker(rank, world, port, block, out_dir):
     import sys
     import torch
@@ -77,11 +85,19 @@ def _worker(rank, world, port, block, out_dir):
         if cand > best:
             best = cand
     key = torch.tensor(best, dtype=torch.int64)
+    gathered = torch.zeros(2 * world, dtype=torch.int64)
+    pkg.shard.allgather_best(key, gathered)                             # the one-collective form (16 bytes per rank)
     pkg.shard.allreduce_best(key)                                       # the two 8-byte collectives of the path
+    assert pkg.shard.reduce_pairs([tuple(int(x) for x in gathered[2 * r:2 * r + 2]) for r in range(world)]) == \
+        (int(key[0]), int(key[1]))                                      # both forms agree on every rank
     count, _, widx = pkg.shard.decode_pair(int(key[0]), int(key[1]))
     Rt_w = O.kabsch3(sc.src, sc.tgt, tri[widx:widx + 1])[0]            # every rank re-solves the winner locally
     mask = O.mask(sc.src, sc.tgt, Rt_w, kw["tau"])
-    np.savez(os.path.join(out_dir, f"rank{rank}.npz"), count=count, widx=widx, Rt=Rt_w, mask=mask, scored=len(mine))
+    # the split phase 1 (sc_hypothesize_begin_device / _end_device): per-rank sample histograms are summed in place
+    hist = torch.from_numpy(_fake_hist(rank, pkg.SC_HIST_WORDS))
+    pkg.shard.allreduce_hist(hist)
+    np.savez(os.path.join(out_dir, f"rank{rank}.npz"), count=count, widx=widx, Rt=Rt_w, mask=mask, scored=len(mine),
+             hist=hist.numpy())
     dist.barrier()
     dist.destroy_process_group()
 
@@ -99,3 +115,6 @@ def test_two_ranks_gloo_agree_with_single_rank(pkg, O, tmp_path, world, block):
         assert (int(o["count"]), int(o["widx"])) == (ref["best_count"], ref["best_rank"])
         assert o["Rt"].tobytes() == np.concatenate([ref["R"].ravel(), ref["t"]]).astype(np.float32).tobytes()
         assert np.array_equal(o["mask"], ref["mask"])
+    want = sum(_fake_hist(r, pkg.SC_HIST_WORDS).view(np.uint32).astype(np.uint64) for r in range(world))
+    for o in outs:                                                     # summed histogram, identical on every rank
+        assert np.array_equal(o["hist"].view(np.uint32).astype(np.uint64), want & np.uint64(0xFFFFFFFF))
