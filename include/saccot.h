@@ -83,7 +83,7 @@ typedef struct sc_params {
 } sc_params;
 
 /* Per-call statistics (all optional: pass NULL).  Times are device times from HIP events on the
- * context's stream, only filled when SC_FLAG_TIMING / SC_FLAG_TIMING_HOT is set, and delivered by the call
+ * context's stream (each bracket minus the cost of one event record, calibrated once per context and stream), only filled when SC_FLAG_TIMING / SC_FLAG_TIMING_HOT is set, and delivered by the call
  * that ends the path (sc_register, sc_register_device, sc_finalize_device): sc_hypothesize_device never waits
  * for the GPU at its end, so the us_* fields of ITS stats stay 0. */
 typedef struct sc_stats {
