@@ -318,6 +318,21 @@ int run_select(sc_ctx* c, const sc_params* p, const uint32_t* hist, bool want_li
   // read-back #2: triangle count (of the pruned graph when pruning), written to pinned memory by the scan
   arm_word(c, 2);
   launch_scan_u32(c->tcnt.as<uint32_t>(), E, c->toff.as<uint64_t>(), c->scan_tmp.p, st, &c->pinned[2]);
+  // While the host polls for the count, the key kernel already runs into the key arrays this context holds from earlier
+  // calls (it takes everything else from device memory).  Only in the common form — events, a-priori select window —
+  // and not when every stage is bracketed by events; re-run below if the count outgrew the arrays or a region overflowed.
+  SelectState* sel = &c->ctl.as<ControlBlock>()->sel;
+  const bool window_known = p->rank_mode == SC_RANK_WEIGHT && 3.0f * p->t_cmp * 0.999f >= 2.0f;
+  uint64_t spec_cap = 0;
+  if (use_events && window_known && !c->timing) {
+    spec_cap = c->wkey.cap / 4 < c->kcol.cap / 8 ? c->wkey.cap / 4 : c->kcol.cap / 8;
+    if (spec_cap) {
+      ENSURE(c, c->blk_minmax, 2 * 8192 * 4);
+      launch_tri_keys_events(g, c->es.as<float>(), c->toff.as<uint64_t>(), p->rank_mode, ev, c->wkey.as<uint32_t>(),
+                             c->kcol.as<uint2>(), c->blk_minmax.as<uint32_t>(), sel, p->max_triangles,
+                             &c->ctl.as<ControlBlock>()->klb, E, spec_cap, st);
+    }
+  }
   { const int wrc = wait_word(c, 2); if (wrc) return wrc; }
   c->M_total = have_total ? c->pinned[4] : c->pinned[2];
   const uint64_t M = c->M = c->pinned[2];
@@ -336,7 +351,6 @@ int run_select(sc_ctx* c, const sc_params* p, const uint32_t* hist, bool want_li
   ENSURE(c, c->sel_ord, (size_t)T_eff * 8);
   ENSURE(c, c->sel_key, (size_t)T_eff * 4);
   if (want_list) ENSURE(c, c->tri, (size_t)T_eff * 12);
-  SelectState* sel = &c->ctl.as<ControlBlock>()->sel;
   if (c->timing) HIPCHK(c, hipEventRecord(c->ev[9], st));
   bool events_ok = use_events;
   if (use_events && (uint32_t)c->pinned[5] != 0) {  // a region overflowed: this call walks the rows again
@@ -347,15 +361,19 @@ int run_select(sc_ctx* c, const sc_params* p, const uint32_t* hist, bool want_li
     c->ev_capacity = want_cap;
   }
   // weight keys of a graph whose edges all weigh >= 2/3 (0.1 % slack) lie in [2.0, 3.0]: window known a priori
-  const bool fast_window = events_ok && p->rank_mode == SC_RANK_WEIGHT && 3.0f * p->t_cmp * 0.999f >= 2.0f;
-  if (events_ok)
+  const bool fast_window = events_ok && window_known;
+  const bool keys_done = spec_cap != 0 && events_ok && M <= spec_cap;  // the speculative pass wrote every key
+  if (keys_done) {
+    // nothing to do
+  } else if (events_ok) {
     launch_tri_keys_events(g, c->es.as<float>(), c->toff.as<uint64_t>(), p->rank_mode, ev, c->wkey.as<uint32_t>(),
                            c->kcol.as<uint2>(), c->blk_minmax.as<uint32_t>(), sel, T_eff,
-                           fast_window ? &c->ctl.as<ControlBlock>()->klb : nullptr, st);
-  else
+                           fast_window ? &c->ctl.as<ControlBlock>()->klb : nullptr, E, M, st);
+  } else {
     launch_tri_keys(g, mbits, smin, c->ebase.as<uint32_t>(), c->ei.as<uint32_t>(), c->ej.as<uint32_t>(),
                     c->es.as<float>(), c->toff.as<uint64_t>(), E, p->rank_mode, c->wkey.as<uint32_t>(),
                     c->kcol.as<uint2>(), c->blk_minmax.as<uint32_t>(), sel, T_eff, st);
+  }
   if (c->timing) HIPCHK(c, hipEventRecord(c->ev[10], st));
   c->timed_trikeys = c->timing;
   launch_select_rounds(c->wkey.as<uint32_t>(), M, sel, fast_window ? 2 : 3, st);

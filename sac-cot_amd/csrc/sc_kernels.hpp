@@ -156,7 +156,8 @@ void launch_tri_keys(const Graph& g, const uint64_t* mbits, const float* smin, c
 // keys from the event list (replaces launch_tri_keys when no region overflowed)
 void launch_tri_keys_events(const Graph& g, const float* es, const uint64_t* toff, int rank_mode,
                             const EventList& ev, uint32_t* wkey, uint2* kcol, uint32_t* blk_minmax,
-                            SelectState* s, uint64_t want, const uint32_t* klb, hipStream_t st);
+                            SelectState* s, uint64_t want, const uint32_t* klb, uint64_t E, uint64_t cap,
+                            hipStream_t st);  // cap: entries of wkey / kcol (writes beyond are dropped); want is clipped to toff[E]
 // klb != nullptr (weight ranking, every edge weight >= 2/3): the kernel presets the select window to
 // [*klb or 2.0, 3.0] and no key-range pass runs; two select rounds then always suffice.
 // `rounds` launches (histogram + pick by the last block to finish; 12 key bits each) find the exact threshold key

@@ -346,6 +346,7 @@ __global__ __launch_bounds__(1024) void key_range_kernel(const uint32_t* __restr
   if (threadIdx.x == 0) {
     for (int w = 1; w < 16; w++) { kmin = min(kmin, lmin[w]); kmax = max(kmax, lmax[w]); }
     sel->kmin = kmin; sel->kmax = kmax; sel->want = want;
+    sel->started = 0; sel->done = 0; sel->above = 0;  // (a speculative key pass may have preset a window)
   }
 }
 
@@ -496,7 +497,11 @@ __global__ __launch_bounds__(256) void tri_keys_events_kernel(const uint64_t* __
                                                               uint32_t* __restrict__ blk_min,
                                                               uint32_t* __restrict__ blk_max,
                                                               SelectState* __restrict__ preset,
-                                                              const uint32_t* __restrict__ klb, uint64_t want) {
+                                                              const uint32_t* __restrict__ klb, uint64_t want,
+                                                              uint64_t E, uint64_t cap) {
+  // cap: entries wkey / kcol hold.  The host may launch this kernel BEFORE it knows the triangle count (into the
+  // arrays of the previous call, while it polls for the count): writes beyond cap are dropped and the host re-runs.
+  // For the same reason `want` is clipped here to the count the scan left in toff[E].
   __shared__ uint32_t lmin[4], lmax[4];
   __shared__ uint64_t pre[EV_SHARDS + 1];
   // Weight keys of a graph whose edges all weigh >= 2/3 live in one binade, [2.0, 3.0]: the select window is known
@@ -508,7 +513,7 @@ __global__ __launch_bounds__(256) void tri_keys_events_kernel(const uint64_t* __
     preset->lo = lo;
     preset->wbits = range_m1 == 0 ? 0u : (uint32_t)(32 - __builtin_clz(range_m1));
     preset->kmin = lo; preset->kmax = hi;
-    preset->started = 1; preset->done = 0; preset->above = 0; preset->want = want;
+    preset->started = 1; preset->done = 0; preset->above = 0; preset->want = min(want, (uint64_t)toff[E]);
   }  // exclusive prefix of the region fills: one flat index space over all events
   {
     constexpr int PT = EV_SHARDS / 256;  // regions per thread
@@ -555,8 +560,8 @@ __global__ __launch_bounds__(256) void tri_keys_events_kernel(const uint64_t* __
           for (int q = 0; q < 4; q++) {
             if (q < nbits) {
               const uint32_t key = __float_as_uint((s_ij + s_ik[q]) + s_jk[q]);
-              kcol[out] = make_uint2(kbase + (uint32_t)b[q], e);
-              wkey[out++] = key;
+              if (out < cap) { kcol[out] = make_uint2(kbase + (uint32_t)b[q], e); wkey[out] = key; }
+              out++;
               kmin = min(kmin, key);
               kmax = max(kmax, key);
             }
@@ -567,8 +572,8 @@ __global__ __launch_bounds__(256) void tri_keys_events_kernel(const uint64_t* __
           const int b = __builtin_ctzll(m);
           m &= m - 1;
           const uint32_t key = fa + deg[kbase + b];
-          kcol[out] = make_uint2(kbase + (uint32_t)b, e);
-          wkey[out++] = key;
+          if (out < cap) { kcol[out] = make_uint2(kbase + (uint32_t)b, e); wkey[out] = key; }
+          out++;
           kmin = min(kmin, key);
           kmax = max(kmax, key);
         }
@@ -625,10 +630,11 @@ void launch_tri_count_events(const Graph& g, const uint64_t* mbits, const Strong
 
 void launch_tri_keys_events(const Graph& g, const float* es, const uint64_t* toff, int rank_mode,
                             const EventList& ev, uint32_t* wkey, uint2* kcol, uint32_t* blk_minmax,
-                            SelectState* s, uint64_t want, const uint32_t* klb, hipStream_t st) {
+                            SelectState* s, uint64_t want, const uint32_t* klb, uint64_t E, uint64_t cap,
+                            hipStream_t st) {
   const int nb = 2048;
   hipLaunchKernelGGL(tri_keys_events_kernel, dim3(nb), dim3(256), 0, st, g.bits, g.wpre, g.deg, es, toff, rank_mode,
-                     ev, wkey, kcol, blk_minmax, blk_minmax + TK_MAX_BLOCKS, klb ? s : (SelectState*)nullptr, klb, want);
+                     ev, wkey, kcol, blk_minmax, blk_minmax + TK_MAX_BLOCKS, klb ? s : (SelectState*)nullptr, klb, want, E, cap);
   if (!klb)  // no a-priori window: the key range comes from the per-block extremes
     hipLaunchKernelGGL(key_range_kernel, dim3(1), dim3(1024), 0, st, blk_minmax, blk_minmax + TK_MAX_BLOCKS, nb, s, want);
 }

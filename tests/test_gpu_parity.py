@@ -321,6 +321,43 @@ def test_split_phase1_sharded_sample_equals_unsharded(pkg, reg):
         reg.hypothesize_end_device(d_hist.data_ptr(), d_key.data_ptr())
 
 
+@pytest.mark.parametrize("name,extra", [("C0", {}), ("C1", {"rank_mode": 1}), ("C1", {"flags": 4})])
+def test_split_phase1_without_pruning_and_gathered_finalize(pkg, reg, name, extra):
+    """begin/end where the certificate does not run (a graph below 4096 edges, degree ranking, SC_FLAG_NO_PRUNE): the
+    histogram stays zero and is ignored; the gathered finalize (two ranks' pairs, one of them 'no hypothesis') must
+    give the unsharded result, and an all-zero gather must report SC_ENOHYP with identity / zero mask."""
+    import torch
+    cfg, scene = pkg.synth.make_config_scene(name)
+    kw = dict(cfg.params(), **{k: v for k, v in extra.items() if k != "flags"})
+    flags = extra.get("flags", 0)
+    base = reg.register(scene.src, scene.tgt, flags=flags, **kw)
+    dev = torch.device("cuda:0")
+    d_src = torch.from_numpy(scene.src).to(dev); d_tgt = torch.from_numpy(scene.tgt).to(dev)
+    d_key = torch.zeros(2, dtype=torch.int64, device=dev)
+    d_hist = torch.ones(pkg.SC_HIST_WORDS, dtype=torch.int32, device=dev)        # begin must zero it
+    d_Rt = torch.zeros(12, dtype=torch.float32, device=dev); d_mask = torch.zeros(cfg.n, dtype=torch.uint8, device=dev)
+    torch.cuda.synchronize()
+    p = pkg.make_params(flags=flags, **kw)
+    reg.hypothesize_begin_device(d_src.data_ptr(), d_tgt.data_ptr(), cfg.n, p, d_hist.data_ptr())
+    torch.cuda.synchronize()
+    pruned = kw.get("rank_mode", 0) == 0 and not (flags & 4) and base["stats"]["edges"] >= 4096
+    assert (int(d_hist.abs().sum()) > 0) == pruned
+    reg.hypothesize_end_device(d_hist.data_ptr(), d_key.data_ptr())
+    torch.cuda.synchronize()
+    mine = [int(x) for x in d_key.cpu()]
+    d_all = torch.tensor([0, 0] + mine, dtype=torch.int64).to(dev); torch.cuda.synchronize()   # rank 0: nothing, rank 1: ours
+    rc, st = reg.finalize_gathered_device(d_all.data_ptr(), 2, d_Rt.data_ptr(), d_mask.data_ptr())
+    torch.cuda.synchronize()
+    assert rc == 0 and (st["best_rank"], st["best_count"]) == (base["stats"]["best_rank"], base["stats"]["best_count"])
+    assert np.array_equal(d_mask.cpu().numpy(), base["mask"])
+    assert d_Rt.cpu().numpy().tobytes() == np.concatenate([base["R"].ravel(), base["t"]]).tobytes()
+    d_all.zero_(); torch.cuda.synchronize()
+    rc, st = reg.finalize_gathered_device(d_all.data_ptr(), 2, d_Rt.data_ptr(), d_mask.data_ptr())
+    torch.cuda.synchronize()
+    assert rc == pkg.SC_ENOHYP and int(d_mask.sum()) == 0
+    assert np.array_equal(d_Rt.cpu().numpy(), np.array([1, 0, 0, 0, 1, 0, 0, 0, 1, 0, 0, 0], np.float32))
+
+
 def test_caller_stream_orders_torch_work_with_the_kernels(pkg):
     """sc_set_stream: on torch's current stream (the default stream, which torch reports as 0 and api.py maps to
     SC_STREAM_DEFAULT, and a side stream) torch's own work on that stream is ordered with the library's kernels: the
