@@ -34,7 +34,7 @@ extern "C" {
 #endif
 
 #define SC_VERSION_MAJOR 0
-#define SC_VERSION_MINOR 1
+#define SC_VERSION_MINOR 2   /* 0.2: SC_FLAG_TIMING_HOT, SC_STREAM_DEFAULT, sc_hypothesize_begin/end_device, sc_finalize_gathered_device */
 
 /* status codes */
 #define SC_OK        0
