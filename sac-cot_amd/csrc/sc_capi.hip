@@ -189,7 +189,7 @@ int run_row_stats(sc_ctx* c, bool will_prune) {
 
 // Read-backs: the producing kernel stores its 8-byte result into host-pinned memory (publish_host) and the host
 // polls that word instead of blocking in hipStreamSynchronize (whose wake-up alone costs ~10 us, twice per call).
-// After ~200 us of polling it falls back to the blocking wait (long-running stages, or a failed launch).
+// After ~1 ms of polling it falls back to the blocking wait (very long stages, or a failed launch).
 constexpr uint64_t PIN_PENDING = ~0ull;
 inline void cpu_relax() {
 #if defined(__x86_64__) && !defined(__HIP_DEVICE_COMPILE__)
@@ -203,7 +203,7 @@ int wait_word(sc_ctx* c, int idx) {
   uint32_t spins = 0;
   while (*w == PIN_PENDING) {
     cpu_relax();
-    if ((++spins & 255u) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(200)) {
+    if ((++spins & 255u) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(1000)) {
       HIPCHK(c, hipStreamSynchronize(c->stream));
       break;
     }
