@@ -3,9 +3,9 @@
 The directory is named `sac-cot_amd` (not importable by name); load it with `__graft_entry__.load_package()`,
 which registers it as the module `saccot_amd`.
 """
-from . import api, shard, synth  # noqa: F401
+from . import api, corrio, shard, synth  # noqa: F401
 from .api import (Registrar, SacCotError, ScParams, ScStats, load_library, make_params, register,  # noqa: F401
                   SC_AOS, SC_SOA, SC_RANK_WEIGHT, SC_RANK_DEGREE, SC_FLAG_TIMING, SC_FLAG_EXACT_TOTAL, SC_FLAG_NO_PRUNE, SC_FLAG_REFINE, SC_FLAG_TIMING_HOT, SC_HIST_WORDS, SC_OK, SC_ENOHYP, SC_EINVAL)
 
-__all__ = ["api", "shard", "synth", "Registrar", "SacCotError", "ScParams", "ScStats", "load_library", "make_params",
+__all__ = ["api", "corrio", "shard", "synth", "Registrar", "SacCotError", "ScParams", "ScStats", "load_library", "make_params",
            "register"]
