@@ -229,6 +229,30 @@ def test_register_select_window_both_forms(pkg, O, reg, t_cmp):
     assert np.array_equal(key_a, key_b) and np.array_equal(tri_a, tri_b)
 
 
+@pytest.mark.parametrize("seed", list(range(16)))
+def test_register_random_configurations(pkg, O, reg, seed):
+    """Randomised sweep of the whole path against the CPU restatement: ragged N, random inlier ratio and scale, random
+    sigma / t_cmp / tau / min_len / T, both ranking modes, and one context reused across all of them (so the
+    speculative launches run into buffers of other sizes)."""
+    rng = np.random.default_rng(1234 + seed)
+    n = int(rng.integers(40, 1800))
+    rho = float(rng.uniform(0.05, 0.6))
+    L = float(10.0 ** rng.uniform(-1, 2))
+    tau = L * float(rng.uniform(0.01, 0.06))
+    scene = pkg.synth.make_scene(n, rho, L, tau, seed=500 + seed)
+    kw = dict(sigma=tau * float(rng.uniform(0.5, 2.0)), t_cmp=float(rng.uniform(0.45, 0.98)), tau=tau,
+              min_len=tau * float(rng.choice([0.0, 0.5, 1.0, 3.0])), max_triangles=int(rng.integers(1, 30000)),
+              rank_mode=int(rng.integers(0, 2)))
+    ref = O.register(scene.src, scene.tgt, threads=1, **kw)
+    got = reg.register(scene.src, scene.tgt, flags=pkg.SC_FLAG_EXACT_TOTAL, **kw)
+    assert got["status"] == ref["rc"], (kw, n)
+    st = got["stats"]
+    assert (st["edges"], st["tri_total"], st["tri_kept"]) == (ref["edges"], ref["tri_total"], ref["t_eff"]), (kw, n)
+    assert (st["best_rank"], st["best_count"]) == (ref["best_rank"], ref["best_count"]), (kw, n)
+    assert np.array_equal(got["mask"], ref["mask"])
+    assert nan_equal_bits(got["R"], ref["R"]) and nan_equal_bits(got["t"], ref["t"])
+
+
 def test_register_deterministic_and_context_reuse(pkg, reg):
     """Same context, interleaved problem sizes (workspace grows, never shrinks): byte-identical repeats."""
     cfg1, s1 = pkg.synth.make_config_scene("C1")
