@@ -131,7 +131,7 @@ struct SelectState {
 };
 static_assert(offsetof(SelectState, hist) % 16 == 0, "SelectState::hist must be 16-byte aligned");
 
-// Per-call control block (device memory, zeroed by one hipMemsetAsync at the start of every call).
+// Per-call control block (device memory, zeroed by the staging kernel at the start of every call).
 struct ControlBlock {
   uint32_t ev_fill[1024];    // event-list region fill counters (EV_SHARDS)
   uint32_t prune_hist[256];  // sampled key histogram of the certified pruning

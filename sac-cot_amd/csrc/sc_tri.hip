@@ -375,8 +375,8 @@ void launch_tri_keys(const Graph& g, const uint64_t* mbits, const float* smin, c
 // tri_count and tri_keys used to AND the same pairs of bit rows, and tri_keys paid three dependent memory levels per
 // wave-round (rows -> prefix words -> edge weights).  Now the counting pass also records every non-zero member word
 // as an EVENT {member word m, word offsets of both rows, CSR bases of both ends, edge, rank of its first triangle
-// inside the edge}.  Events are staged per workgroup in LDS and appended to one of EV_SHARDS global regions with a
-// single atomic per flush (one counter per region: same-address atomics serialise at ~11 ns each).  After the scan
+// inside the edge}.  Events are staged per WAVE in LDS and appended to one of EV_SHARDS global regions with a single
+// atomic per flush (one counter per region: same-address RETURNING atomics serialise at ~170 ns each).  After the scan
 // of the per-edge counts, tri_keys_events_kernel runs one lane per event: all its gathers are independent, and a
 // triangle's key lands at its ordinal toff[e] + rank.  Event order is arbitrary; the result is not.
 // If a region overflows, a flag reaches the host with the triangle count and the call falls back to the row-walking
@@ -648,7 +648,7 @@ void launch_tri_keys_events(const Graph& g, const float* es, const uint64_t* tof
 // edge >= LB - 2 - 3e-7 > smin: all triangles with key >= LB live in the strong subgraph, there are >= T of them, and
 // every triangle outside it has key < LB, i.e. strictly below at least T others — it cannot enter the top-T, ties
 // included.  Ordinals keep their relative order (same CSR edge order, same ascending k), so the tie-break is unchanged.
-// LB comes from a SAMPLE: the triangles of every R-th edge are enumerated once, their keys go into a 2048-bin
+// LB comes from a SAMPLE: the triangles of every R-th edge are enumerated once, their keys go into a 256-bin
 // histogram over [klo, khi]; walking it from the top to the first bin where the count reaches T gives a bin whose
 // lower edge is a valid LB (>= T genuine triangles lie at or above it).  Bin 0 collects everything below klo, so a
 // crossing in bin 0 certifies nothing and disables the pruning (smin = -1).
@@ -744,7 +744,7 @@ __global__ __launch_bounds__(256) void tri_sample_hist_kernel(const uint64_t* __
   }
 }
 
-// every block derives smin from the histogram (2048 bins: cheap) and sets the strong bits of its edges in `mbits`
+// every block derives smin from the histogram (256 bins: cheap) and sets the strong bits of its edges in `mbits`
 // (zeroed beforehand; only upper-triangle entries are needed: bit j of row i for i < j).  Block 0 publishes smin.
 __global__ __launch_bounds__(256) void prune_bits_kernel(const uint32_t* __restrict__ hist, uint64_t want,
                                                          uint32_t klo, uint32_t shift,
