@@ -62,6 +62,31 @@ def test_compat_both_interior_forms_bit_exact(pkg, O, one_phase, rows, min_len_s
     assert np.array_equal(S1.view(np.uint32), S0.view(np.uint32))
 
 
+@pytest.mark.parametrize("one_phase", [False, True])
+@pytest.mark.parametrize("eps,scale", [(0.03, 1.0), (0.002, 40.0), (0.25, 0.01)])
+def test_compat_threshold_sweep_on_a_scaled_scene(pkg, O, eps, scale, one_phase, monkeypatch):
+    """q = (1 + eps) p: the rigidity residual d = eps * |p_i - p_j| sweeps continuously through d_thr, so of the ~1.1 M
+    pairs many sit within a few ulps of the threshold (and of min_len) — where the candidate test of the two-phase
+    interior tiles has to err on the safe side.  Bit-exact S, bit rows and degrees against the CPU restatement."""
+    if one_phase:
+        monkeypatch.setenv("SC_COMPAT_ONE_PHASE", "1")
+    rng = np.random.default_rng(7)
+    src = (rng.random((1500, 3), dtype=np.float32) - np.float32(0.5)) * np.float32(scale)
+    tgt = (src * np.float32(1.0 + eps)).astype(np.float32)
+    typical = 0.66 * scale                       # mean distance of two uniform points in a cube of this edge
+    sigma = eps * typical / 0.459                # d_thr = 0.459 sigma at t_cmp = 0.9  ->  threshold mid-range
+    kw = dict(sigma=sigma, t_cmp=0.9, tau=sigma, min_len=0.3 * scale)
+    r = pkg.Registrar(0)
+    try:
+        S1, b1, d1 = r.compat(src, tgt, pkg.make_params(**kw))
+    finally:
+        r.close()
+    S0, b0, d0 = O.compat(src, tgt, kw["sigma"], kw["t_cmp"], kw["min_len"], kw["tau"])
+    assert 0.05 < d0.mean() / 1500 < 0.9          # the threshold really cuts through the distribution
+    assert np.array_equal(b1, b0) and np.array_equal(d1, d0)
+    assert np.array_equal(S1.view(np.uint32), S0.view(np.uint32))
+
+
 def test_compat_soa_layout_and_min_len_zero(pkg, O, reg):
     sc = _scene(pkg, 300, seed=11)
     kw = _params(pkg, 0.05, 10, min_len=0.0)
