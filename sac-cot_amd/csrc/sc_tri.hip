@@ -86,6 +86,7 @@ __global__ __launch_bounds__(256) void edge_fill_kernel(const uint64_t* __restri
   const int w0 = i >> 6;
   const float pix = planes[i], piy = planes[ld + i], piz = planes[2 * ld + i];  // wave-uniform: scalar loads
   const float qix = planes[3 * ld + i], qiy = planes[4 * ld + i], qiz = planes[5 * ld + i];
+  const float4* __restrict__ aos4 = reinterpret_cast<const float4*>(planes + 6 * (size_t)ld);
   for (int wb = w0; wb < W; wb += 64) {
     const int w = wb + lane;
     uint64_t v = 0;
@@ -112,8 +113,10 @@ __global__ __launch_bounds__(256) void edge_fill_kernel(const uint64_t* __restri
         const uint32_t j = l_j[wave][t];
         const uint64_t e = base + c0 + t;
         if (e >= cap) continue;
-        const float dp = dist3(pix, piy, piz, planes[j], planes[ld + j], planes[2 * ld + j]);
-        const float dq = dist3(qix, qiy, qiz, planes[3 * ld + j], planes[4 * ld + j], planes[5 * ld + j]);
+        // the other end from the AoS copy behind the planes (8 floats per correspondence): two 16-byte loads
+        const float4 a4 = aos4[2 * (size_t)j], b4 = aos4[2 * (size_t)j + 1];
+        const float dp = dist3(pix, piy, piz, a4.x, a4.y, a4.z);
+        const float dq = dist3(qix, qiy, qiz, a4.w, b4.x, b4.y);
         bool edge;
         const float sw = pair_weight(dp, dq, dv.d_thr, dv.min_len, dv.neg_inv2sig2, edge);
         ei[e] = (uint32_t)i;
