@@ -39,16 +39,17 @@ uint32_t shard_local_count(uint32_t T_eff, uint32_t block, uint32_t rank, uint32
 // ------------------------------------------------------------------------------------------------
 // C1
 // ------------------------------------------------------------------------------------------------
+// the three correspondences of a triangle, from the AoS copy behind the planes (8 floats each: two 16-byte loads per
+// vertex instead of six scattered 4-byte gathers)
 __device__ __forceinline__ void load_triangle(const float* __restrict__ planes, int ld, const uint32_t* tri3,
                                               float P[9], float Q[9]) {
+  const float4* __restrict__ aos4 = reinterpret_cast<const float4*>(planes + 6 * (size_t)ld);
 #pragma unroll
   for (int m = 0; m < 3; m++) {
     const uint32_t v = tri3[m];
-#pragma unroll
-    for (int c = 0; c < 3; c++) {
-      P[3 * m + c] = planes[(size_t)c * ld + v];
-      Q[3 * m + c] = planes[(size_t)(3 + c) * ld + v];
-    }
+    const float4 a = aos4[2 * (size_t)v], b = aos4[2 * (size_t)v + 1];
+    P[3 * m] = a.x; P[3 * m + 1] = a.y; P[3 * m + 2] = a.z;
+    Q[3 * m] = a.w; Q[3 * m + 1] = b.x; Q[3 * m + 2] = b.y;
   }
 }
 
