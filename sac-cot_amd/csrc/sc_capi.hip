@@ -645,7 +645,8 @@ int sc_finalize_gathered_device(sc_ctx* c, const uint64_t* d_keys, int n_pairs, 
   if ((rc = rec(c, 7))) return rc;
   arm_word(c, 8);
   ControlBlock* ctl = c->ctl.as<ControlBlock>();
-  launch_finalize(points_of(c), tri_source_of(c), c->T_eff ? c->sel_key.as<uint32_t>() : nullptr, c->T_eff, d_keys, n_pairs,
+  launch_finalize(points_of(c), tri_source_of(c), c->sh, c->sh.n_local ? c->rt.as<float>() : nullptr,
+                  c->T_eff ? c->sel_key.as<uint32_t>() : nullptr, c->T_eff, d_keys, n_pairs,
                   ctl->key2, c->dv.tau2, d_Rt, d_mask, &ctl->fin_rank, &ctl->fin_ticket, &c->pinned[8], c->stream);
   if (c->refine) {  // fp64 least-squares refit over the winner's inliers (mask unchanged)
     ENSURE(c, c->refine_tmp, refine_scratch_bytes(c->n));

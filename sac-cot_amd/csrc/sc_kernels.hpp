@@ -222,8 +222,9 @@ void launch_argmax(const Points& pts, const Shard& sh, const uint32_t* partial, 
 // key2[0], the winner's position and its rank index.
 // key2: npairs key pairs (all-gathered, one per rank; 1 = already reduced); key_out (2 x u64, optional) receives the
 // reduced pair.
-void launch_finalize(const Points& pts, const TriSource& ts, const uint32_t* sel_key, uint32_t T,
-                     const uint64_t* key2, int npairs, uint64_t* key_out, float tau2, float* Rt12, uint8_t* mask,
+// sh / RtSoA: this rank's shard and the (R,t) planes phase 1 produced — a locally scored winner is looked up there.
+void launch_finalize(const Points& pts, const TriSource& ts, const Shard& sh, const float* RtSoA,
+                     const uint32_t* sel_key, uint32_t T, const uint64_t* key2, int npairs, uint64_t* key_out, float tau2, float* Rt12, uint8_t* mask,
                      uint32_t* rank_acc, uint32_t* ticket, uint64_t* host_out, hipStream_t st);
 // SURVEY §8f-2 (SC_FLAG_REFINE): fp64 least-squares refit of Rt12 over the inlier mask; no-op when key2[0] == 0 or
 // fewer than 3 inliers.  scratch: refine_scratch_bytes(n).

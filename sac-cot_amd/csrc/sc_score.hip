@@ -402,7 +402,7 @@ void launch_argmax(const Points& pts, const Shard& sh, const uint32_t* partial, 
 // meet in a control-block counter; the block that takes the last ticket publishes (key, position, rank) to the host.
 // (A single-block rank count cost 42 us at T = 400 k; a separate mask launch another ~4.5 us floor.)
 __global__ __launch_bounds__(256) void finalize_kernel(const float* __restrict__ planes, int n, int ld,
-                                                       TriSource ts,
+                                                       TriSource ts, Shard sh, const float* __restrict__ RtSoA,
                                                        const uint32_t* __restrict__ sel_key, uint32_t T,
                                                        const unsigned long long* __restrict__ key2, int npairs,
                                                        unsigned long long* __restrict__ key_out, float tau2,
@@ -423,7 +423,18 @@ __global__ __launch_bounds__(256) void finalize_kernel(const float* __restrict__
   const bool two_stage = sel_key != nullptr;
   uint32_t g = 0;
   if (k0 != 0) g = 0xFFFFFFFFu - (uint32_t)((two_stage ? k1 : k0) & 0xFFFFFFFFull);
-  if (threadIdx.x == 0) {
+  // The winner's (R,t): if THIS rank scored it, phase 1 left it in RtSoA (kabsch3 is deterministic, so these are the
+  // very bits a re-solve gives) — 12 parallel loads; otherwise thread 0 re-solves it from the replicated selection.
+  const uint32_t gb = sh.block ? g / sh.block : 0u;
+  const bool local = RtSoA != nullptr && k0 != 0 && g < sh.T_eff && (gb % sh.world) == sh.rank;
+  if (local) {
+    const uint32_t l = (gb / sh.world) * sh.block + (g % sh.block);
+    if (threadIdx.x < 12) {
+      const float v = RtSoA[(size_t)threadIdx.x * sh.ld_local + l];
+      sRt[threadIdx.x] = v;
+      if (blockIdx.x == 0) Rt12[threadIdx.x] = v;
+    }
+  } else if (threadIdx.x == 0) {
     float Rt[12] = {1.f, 0.f, 0.f, 0.f, 1.f, 0.f, 0.f, 0.f, 1.f, 0.f, 0.f, 0.f};
     if (k0 != 0) {
       uint32_t v[3];
@@ -502,13 +513,13 @@ __global__ __launch_bounds__(256) void mask_kernel(const float* __restrict__ pla
   mask[m] = (live && d2 < tau2) ? 1 : 0;
 }
 
-void launch_finalize(const Points& pts, const TriSource& ts, const uint32_t* sel_key, uint32_t T,
-                     const uint64_t* key2, int npairs, uint64_t* key_out, float tau2, float* Rt12, uint8_t* mask,
+void launch_finalize(const Points& pts, const TriSource& ts, const Shard& sh, const float* RtSoA,
+                     const uint32_t* sel_key, uint32_t T, const uint64_t* key2, int npairs, uint64_t* key_out, float tau2, float* Rt12, uint8_t* mask,
                      uint32_t* rank_acc, uint32_t* ticket, uint64_t* host_out, hipStream_t st) {
   uint32_t blocks = (uint32_t)((pts.n + 255) / 256);  // the mask needs these; more only if the key list is long
   const uint32_t for_keys = (T / 4 + 1023) / 1024;    // >= 4 uint4 per thread before another block pays off
   if (for_keys > blocks) blocks = for_keys < 1024u ? for_keys : 1024u;
-  hipLaunchKernelGGL(finalize_kernel, dim3(blocks), dim3(256), 0, st, pts.planes, pts.n, pts.ld, ts, sel_key, T,
+  hipLaunchKernelGGL(finalize_kernel, dim3(blocks), dim3(256), 0, st, pts.planes, pts.n, pts.ld, ts, sh, RtSoA, sel_key, T,
                      reinterpret_cast<const unsigned long long*>(key2), npairs,
                      reinterpret_cast<unsigned long long*>(key_out), tau2, Rt12, mask, rank_acc, ticket,
                      reinterpret_cast<unsigned long long*>(host_out));
