@@ -867,8 +867,11 @@ constexpr int SEL_THREADS = 256;
 constexpr int SEL_ITEMS = 16;
 
 // current window of the select: keys in [lo, lo + 2^wbits), binned by (key - lo) >> shift into <= SEL_BINS bins
-struct SelWindow { uint32_t lo, wbits, shift; };
-__device__ __forceinline__ SelWindow select_window(const SelectState* sel) {
+// rounds_left: launches still to come INCLUDING this one.  The window's bits are split evenly over them (at most
+// SEL_BITS per round): a 16-bit window resolved in two rounds uses 256 bins per round, not 4096 — every block flushes its
+// non-zero bins with global atomics, and all per-bin loops scale with the bin count.
+struct SelWindow { uint32_t lo, wbits, shift, nbins; };
+__device__ __forceinline__ SelWindow select_window(const SelectState* sel, int rounds_left) {
   SelWindow w;
   if (!sel->started) {  // first round: the window is the key range [kmin, kmax]
     w.lo = sel->kmin;
@@ -878,7 +881,12 @@ __device__ __forceinline__ SelWindow select_window(const SelectState* sel) {
     w.lo = sel->lo;
     w.wbits = sel->wbits;
   }
-  w.shift = w.wbits > (uint32_t)SEL_BITS ? w.wbits - (uint32_t)SEL_BITS : 0u;
+  const uint32_t rl = rounds_left > 0 ? (uint32_t)rounds_left : 1u;
+  uint32_t br = (w.wbits + rl - 1u) / rl;                    // this round's share of the bits
+  if (br > (uint32_t)SEL_BITS) br = (uint32_t)SEL_BITS;
+  if (w.wbits > br + (uint32_t)SEL_BITS * (rl - 1u)) br = (uint32_t)SEL_BITS;  // (cannot happen for wbits <= SEL_BITS * rl)
+  w.shift = w.wbits > br ? w.wbits - br : 0u;
+  w.nbins = 1u << (w.wbits - w.shift);                      // bins (key - lo) >> shift can reach
   return w;
 }
 
@@ -905,15 +913,16 @@ __device__ __forceinline__ void hist_add(uint32_t* lh, bool in, uint32_t bin) {
 // form: hist adds are device-scope atomics; each block fences (release) before its ticket; the last block fences
 // (acquire) and reads the bins with device-scope atomic loads.
 __global__ __launch_bounds__(SEL_THREADS) void select_round_kernel(const uint32_t* __restrict__ wkey, uint64_t M,
-                                                                   SelectState* __restrict__ sel) {
+                                                                   SelectState* __restrict__ sel, int rounds_left) {
   __shared__ uint32_t lh[SEL_BINS];
   __shared__ uint64_t lds[8];
   __shared__ uint32_t s_bin, s_last;
   __shared__ uint64_t s_above;
   if (sel->done) return;  // set by an earlier launch: uniform over the grid
-  for (int b = threadIdx.x; b < SEL_BINS; b += SEL_THREADS) lh[b] = 0;
+  const SelWindow win = select_window(sel, rounds_left);
+  const int nbins = (int)win.nbins;
+  for (int b = threadIdx.x; b < nbins; b += SEL_THREADS) lh[b] = 0;
   __syncthreads();
-  const SelWindow win = select_window(sel);
   const uint64_t want = sel->want, above0 = sel->above;
   const uint64_t width = 1ull << win.wbits;
   const uint64_t M4 = M >> 2;  // whole uint4 groups (wkey comes from hipMalloc: 16-byte aligned)
@@ -934,7 +943,7 @@ __global__ __launch_bounds__(SEL_THREADS) void select_round_kernel(const uint32_
     if ((key >= win.lo) && (rel < width)) atomicAdd(&lh[(uint32_t)(rel >> win.shift)], 1u);
   }
   __syncthreads();
-  for (int b = threadIdx.x; b < SEL_BINS; b += SEL_THREADS) {
+  for (int b = threadIdx.x; b < nbins; b += SEL_THREADS) {
     const uint32_t v = lh[b];
     if (v) atomicAdd(&sel->hist[b], v);
   }
@@ -955,23 +964,19 @@ __global__ __launch_bounds__(SEL_THREADS) void select_round_kernel(const uint32_
   }
   __syncthreads();
   if (!s_last) return;
-  // thread t owns bins [PER t, PER t + PER) counted from the TOP: bin index = SEL_BINS - 1 - (PER t + k)
-  static_assert(SEL_THREADS == 256, "SEL_PER assumes 256 picking threads");
-  // The bins were only ever touched by L2-side atomics; after an acquire by every wave of this block plain 16-byte
-  // loads see them (16 agent-scope atomic loads per thread serialise: ~0.8 us each, measured).
+  // thread t owns `per` bins counted from the TOP: bins nbins - 1 - (per t + k), k = 0 .. per - 1 (threads beyond the
+  // last bin own nothing).  The bins were only ever touched by L2-side atomics; after an acquire by every wave of this
+  // block plain loads see them (agent-scope atomic loads serialise: ~0.8 us each, measured).
+  static_assert(SEL_THREADS == 256 && SEL_PER == 16, "the picking block: 256 threads, at most 16 bins each");
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  const int per = nbins >= SEL_THREADS ? nbins / SEL_THREADS : 1;
+  const bool owner = (int)threadIdx.x * per < nbins;
   uint32_t h[SEL_PER];
   uint64_t mine = 0;
-  {
-    const uint4* __restrict__ h4 = reinterpret_cast<const uint4*>(&sel->hist[SEL_BINS - SEL_PER * (threadIdx.x + 1)]);
 #pragma unroll
-    for (int q = 0; q < SEL_PER / 4; q++) {  // ascending in memory = descending from the top: reverse while unpacking
-      const uint4 v = h4[q];
-      const int k0 = SEL_PER - 4 * (q + 1);
-      h[k0 + 3] = v.x; h[k0 + 2] = v.y; h[k0 + 1] = v.z; h[k0] = v.w;
-    }
-#pragma unroll
-    for (int k = 0; k < SEL_PER; k++) mine += h[k];
+  for (int k = 0; k < SEL_PER; k++) {
+    h[k] = (owner && k < per) ? sel->hist[nbins - 1 - ((int)threadIdx.x * per + k)] : 0u;
+    mine += h[k];
   }
   if (threadIdx.x == 0) { s_bin = 0; s_above = above0; }
   uint64_t tot;
@@ -981,15 +986,12 @@ __global__ __launch_bounds__(SEL_THREADS) void select_round_kernel(const uint32_
     uint64_t run = before;
 #pragma unroll
     for (int k = 0; k < SEL_PER; k++) {
-      if (run < want && want <= run + h[k]) { s_bin = SEL_BINS - 1 - (threadIdx.x * SEL_PER + k); s_above = run; }
+      if (k < per && run < want && want <= run + h[k]) { s_bin = (uint32_t)(nbins - 1 - ((int)threadIdx.x * per + k)); s_above = run; }
       run += h[k];
     }
   }
   __syncthreads();
-  {  // ready for the next round (next launch)
-    uint4* __restrict__ z4 = reinterpret_cast<uint4*>(sel->hist);
-    for (int b = threadIdx.x; b < SEL_BINS / 4; b += SEL_THREADS) z4[b] = make_uint4(0u, 0u, 0u, 0u);
-  }
+  for (int b2 = threadIdx.x; b2 < nbins; b2 += SEL_THREADS) sel->hist[b2] = 0u;  // ready for the next round (next launch)
   if (threadIdx.x == 0) {
     const uint32_t nlo = win.lo + (s_bin << win.shift);
     sel->above = s_above;
@@ -1009,7 +1011,7 @@ void launch_select_rounds(const uint32_t* wkey, uint64_t M, SelectState* s, int 
   if (const char* v = getenv("SC_SEL_BLOCKS")) { const uint64_t cap = (uint64_t)atoll(v); if (cap >= 1 && blocks > cap) blocks = cap; }
   if (blocks == 0) blocks = 1;
   for (int round = 0; round < rounds; round++)
-    hipLaunchKernelGGL(select_round_kernel, dim3((unsigned)blocks), dim3(SEL_THREADS), 0, st, wkey, M, s);
+    hipLaunchKernelGGL(select_round_kernel, dim3((unsigned)blocks), dim3(SEL_THREADS), 0, st, wkey, M, s, rounds - round);
 }
 
 // ------------------------------------------------------------------------------------------------
