@@ -635,7 +635,8 @@ void launch_tri_keys_events(const Graph& g, const float* es, const uint64_t* tof
                             const EventList& ev, uint32_t* wkey, uint2* kcol, uint32_t* blk_minmax,
                             SelectState* s, uint64_t want, const uint32_t* klb, uint64_t E, uint64_t cap,
                             hipStream_t st) {
-  const int nb = 2048;
+  int nb = 2048;
+  if (const char* v = getenv("SC_KEYS_BLOCKS")) { const int t = atoi(v); if (t >= 1 && t <= TK_MAX_BLOCKS) nb = t; }
   hipLaunchKernelGGL(tri_keys_events_kernel, dim3(nb), dim3(256), 0, st, g.bits, g.wpre, g.deg, es, toff, rank_mode,
                      ev, wkey, kcol, blk_minmax, blk_minmax + TK_MAX_BLOCKS, klb ? s : (SelectState*)nullptr, klb, want, E, cap);
   if (!klb)  // no a-priori window: the key range comes from the per-block extremes
@@ -1007,8 +1008,9 @@ void launch_select_rounds(const uint32_t* wkey, uint64_t M, SelectState* s, int 
   if (M == 0) return;
   uint64_t blocks = (M + (uint64_t)SEL_THREADS * SEL_ITEMS - 1) / ((uint64_t)SEL_THREADS * SEL_ITEMS);
   // 256 blocks measured best on C2 (1.5 M keys): every block pays an agent-scope release for its ticket
-  if (blocks > 256) blocks = 256;
-  if (const char* v = getenv("SC_SEL_BLOCKS")) { const uint64_t cap = (uint64_t)atoll(v); if (cap >= 1 && blocks > cap) blocks = cap; }
+  uint64_t cap = 256;
+  if (const char* v = getenv("SC_SEL_BLOCKS")) { const uint64_t t = (uint64_t)atoll(v); if (t >= 1) cap = t; }
+  if (blocks > cap) blocks = cap;
   if (blocks == 0) blocks = 1;
   for (int round = 0; round < rounds; round++)
     hipLaunchKernelGGL(select_round_kernel, dim3((unsigned)blocks), dim3(SEL_THREADS), 0, st, wkey, M, s, rounds - round);
