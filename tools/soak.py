@@ -1,0 +1,53 @@
+#!/usr/bin/env python3
+"""Soak: one context, thousands of calls over alternating problem sizes and both phase-1 forms; every result must be
+byte-identical to the first one of its configuration (tickets, polled read-backs and speculative launches are exercised
+on buffers left over from other sizes).   python tools/soak.py [seconds]"""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+import __graft_entry__ as ge
+
+pkg = ge.load_package()
+budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
+dev = torch.device("cuda", 0)
+reg = pkg.Registrar(0)
+stream = torch.cuda.Stream(device=dev)
+cases = []
+for name, T in (("C0", 200), ("C1", 10000), ("C2", 50000), ("C1", 3000), ("C2", 200000)):
+    cfg, sc = pkg.synth.make_config_scene(name)
+    kw = cfg.params(); kw["max_triangles"] = T
+    cases.append((f"{name}/T={T}", cfg.n, kw, torch.from_numpy(sc.src).to(dev), torch.from_numpy(sc.tgt).to(dev)))
+first = {}
+calls = mism = 0
+t0 = time.time()
+rng = np.random.default_rng(0)
+with torch.cuda.stream(stream):
+    reg.set_stream(stream.cuda_stream)
+    d_key = torch.zeros(2, dtype=torch.int64, device=dev)
+    d_hist = torch.zeros(pkg.SC_HIST_WORDS, dtype=torch.int32, device=dev)
+    d_Rt = torch.zeros(12, dtype=torch.float32, device=dev)
+    while time.time() - t0 < budget:
+        name, n, kw, s, t = cases[int(rng.integers(len(cases)))]
+        split = bool(rng.integers(2))
+        p = pkg.make_params(**kw)
+        d_mask = torch.zeros(n, dtype=torch.uint8, device=dev)
+        if split:
+            reg.hypothesize_begin_device(s.data_ptr(), t.data_ptr(), n, p, d_hist.data_ptr())
+            reg.hypothesize_end_device(d_hist.data_ptr(), d_key.data_ptr())
+        else:
+            reg.hypothesize_device(s.data_ptr(), t.data_ptr(), n, p, d_key.data_ptr())
+        rc, st = reg.finalize_device(d_key.data_ptr(), d_Rt.data_ptr(), d_mask.data_ptr())
+        stream.synchronize()
+        sig = (rc, st["edges"], st["tri_total"], st["tri_kept"], st["best_rank"], st["best_count"],
+               d_Rt.cpu().numpy().tobytes(), d_mask.cpu().numpy().tobytes(), tuple(int(x) for x in d_key.cpu()))
+        if name not in first:
+            first[name] = sig
+        elif first[name] != sig:
+            mism += 1
+            print("MISMATCH", name, "split" if split else "plain", sig[:6], "vs", first[name][:6], flush=True)
+        calls += 1
+        if calls % 2000 == 0:
+            print(f"{calls} calls, {mism} mismatches, {time.time() - t0:.0f} s", flush=True)
+print(f"soak: {calls} calls over {len(first)} configurations in {time.time() - t0:.0f} s, {mism} mismatches")
+sys.exit(1 if mism else 0)
