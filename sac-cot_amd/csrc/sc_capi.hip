@@ -379,7 +379,9 @@ int run_select(sc_ctx* c, const sc_params* p, const uint32_t* hist, bool want_li
   launch_select_rounds(c->wkey.as<uint32_t>(), M, sel, fast_window ? 2 : 3, st);
   launch_compact_count(c->wkey.as<uint32_t>(), M, sel, c->blk_gt.as<uint32_t>(), c->blk_eq.as<uint32_t>(), st);
   // few tiles (and M < 2^32): compact_write adds up the tile counts itself, no scan launch in between
-  const bool self_off = nb <= 4096 && M < (1ull << 32);
+  size_t self_tiles = 4096;
+  if (const char* v = getenv("SC_COMPACT_SELF_MAX")) self_tiles = (size_t)atoll(v);  // test knob: force the scanned offsets
+  const bool self_off = nb <= self_tiles && M < (1ull << 32);
   if (!self_off)
     launch_scan_u32_pair(c->blk_gt.as<uint32_t>(), c->off_gt.as<uint64_t>(), c->blk_eq.as<uint32_t>(),
                          c->off_eq.as<uint64_t>(), nb, c->scan_tmp.p, st);

@@ -468,7 +468,9 @@ void launch_scan_u32(const uint32_t* in, size_t n, uint64_t* out, void* temp, hi
   const size_t nb = (n + SCAN_TILE - 1) / SCAN_TILE;
   if (nb == 0) return;  // n == 0 is handled by the small path above
   hipLaunchKernelGGL(scan_block_sums_kernel, dim3((unsigned)nb), dim3(SCAN_THREADS), 0, st, in, n, bsum);
-  if (nb <= SCAN_SELF_MAX) {
+  size_t self_max = SCAN_SELF_MAX;
+  if (const char* v = getenv("SC_SCAN_SELF_MAX")) self_max = (size_t)atoll(v);  // test knob: force the three-kernel form
+  if (nb <= self_max) {
     hipLaunchKernelGGL(scan_downsweep_kernel<true>, dim3((unsigned)nb), dim3(SCAN_THREADS), 0, st, in, n, bsum, out,
                        host_total);
   } else {

@@ -235,6 +235,20 @@ def test_certified_pruning_changes_nothing_but_the_work(pkg, reg, name):
         assert a["stats"]["tri_total"] < b["stats"]["tri_total"] // 5
 
 
+def test_large_input_fallbacks_forced_on_a_small_one(pkg, O, monkeypatch):
+    """Two paths only very large inputs reach — the three-kernel scan (beyond 16.7 M elements) and the scanned
+    compaction offsets (beyond 4096 key tiles) — forced by their test knobs on C1 / C2 and checked like any other run."""
+    monkeypatch.setenv("SC_SCAN_SELF_MAX", "0")
+    monkeypatch.setenv("SC_COMPACT_SELF_MAX", "0")
+    r = pkg.Registrar(0)
+    try:
+        for name in ("C1", "C2"):
+            cfg, scene = pkg.synth.make_config_scene(name)
+            _check_register(pkg, O, r, scene, cfg.params())
+    finally:
+        r.close()
+
+
 def test_register_degree_ranking_and_small_T(pkg, O, reg):
     cfg, scene = pkg.synth.make_config_scene("C0")
     kw = cfg.params(); kw["rank_mode"] = 1; kw["max_triangles"] = 37
