@@ -235,6 +235,30 @@ def test_certified_pruning_changes_nothing_but_the_work(pkg, reg, name):
         assert a["stats"]["tri_total"] < b["stats"]["tri_total"] // 5
 
 
+@pytest.mark.parametrize("knobs", [dict(SC_CNT_BLOCKS="37", SC_KEYS_BLOCKS="53", SC_SEL_BLOCKS="7", SC_SAMPLE_EDGES="5000"),
+                                   dict(SC_CNT_BLOCKS="4096", SC_KEYS_BLOCKS="1", SC_SEL_BLOCKS="1", SC_SAMPLE_EDGES="1000000",
+                                        SC_TG_SAMPLE="32")])
+def test_results_do_not_depend_on_grid_or_sample_size(pkg, O, monkeypatch, knobs):
+    """Stage B's launch geometry and the size of the pruning sample only change the amount of work (a looser or tighter
+    certified bound, more or fewer workgroups) — never the result: odd values for every scheduling knob on C1 and C2."""
+    for k, v in knobs.items():
+        monkeypatch.setenv(k, v)
+    r = pkg.Registrar(0)
+    try:
+        for name in ("C1", "C2"):
+            cfg, scene = pkg.synth.make_config_scene(name)
+            kw = cfg.params()
+            ref = O.register(scene.src, scene.tgt, threads=1, **kw)
+            got = r.register(scene.src, scene.tgt, **kw)         # tri_total depends on the bound: not compared here
+            assert got["status"] == ref["rc"] == 0
+            assert (got["stats"]["edges"], got["stats"]["tri_kept"]) == (ref["edges"], ref["t_eff"])
+            assert (got["stats"]["best_rank"], got["stats"]["best_count"]) == (ref["best_rank"], ref["best_count"])
+            assert np.array_equal(got["mask"], ref["mask"])
+            assert nan_equal_bits(got["R"], ref["R"]) and nan_equal_bits(got["t"], ref["t"])
+    finally:
+        r.close()
+
+
 def test_large_input_fallbacks_forced_on_a_small_one(pkg, O, monkeypatch):
     """Two paths only very large inputs reach — the three-kernel scan (beyond 16.7 M elements) and the scanned
     compaction offsets (beyond 4096 key tiles) — forced by their test knobs on C1 / C2 and checked like any other run."""
