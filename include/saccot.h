@@ -34,7 +34,8 @@ extern "C" {
 #endif
 
 #define SC_VERSION_MAJOR 0
-#define SC_VERSION_MINOR 2   /* 0.2: SC_FLAG_TIMING_HOT, SC_STREAM_DEFAULT, sc_hypothesize_begin/end_device, sc_finalize_gathered_device */
+#define SC_VERSION_MINOR 3   /* 0.3: sc_set_debug (no environment variables), SC_FLAG_NO_DENSE_S; 0.2: SC_FLAG_TIMING_HOT,
+                                SC_STREAM_DEFAULT, sc_hypothesize_begin/end_device, sc_finalize_gathered_device */
 
 /* status codes */
 #define SC_OK        0
@@ -43,7 +44,11 @@ extern "C" {
 #define SC_EHIP     -3   /* HIP runtime error (sc_last_error() has the string)                              */
 #define SC_ERCCL    -4   /* reserved: collective error (the all-reduce lives in the host layer, see below)  */
 #define SC_ENOHYP   -5   /* no compatibility triangle / every inlier count is 0: R = I, t = 0, mask = 0     */
-#define SC_ETOOMANY -6   /* the graph has more triangles than the workspace cap can rank (see max_workspace)*/
+#define SC_ETOOMANY -6   /* the graph has more triangles than the workspace cap can rank (see max_workspace),  */
+                         /* or 2^32 or more edges (edge ids are 32-bit)                                      */
+
+/* Limits: 3 <= n <= 2^24; max_triangles <= 2^32 - 256; the compatibility graph must have fewer than 2^32 edges
+ * (SC_ETOOMANY otherwise; with the default 64 GiB workspace cap a dense graph runs out of workspace long before). */
 
 /* point layouts for `src` / `tgt` */
 #define SC_AOS 0   /* N x 3 row-major: x0 y0 z0 x1 y1 z1 ...                                   */
@@ -62,6 +67,9 @@ extern "C" {
 #define SC_FLAG_REFINE       8u /* after C3, replace (R,t) by the fp64 least-squares refit over the winner's inlier  */
                                 /* mask; the mask itself stays the fp32 winner's                   */
 #define SC_FLAG_NO_PRUNE     4u /* disable the certified pruning of stage B (results are identical either way)    */
+#define SC_FLAG_NO_DENSE_S  32u /* stage A writes only the adjacency bit rows, not the dense n x n weight matrix S:   */
+                                /* nothing after stage A reads S (edge weights are recomputed from the points), so    */
+                                /* every result is identical; sc_compat_host returns S only without this flag         */
 
 typedef struct sc_ctx sc_ctx;
 
@@ -126,6 +134,26 @@ int         sc_set_stream(sc_ctx* ctx, void* hip_stream); /* enqueue on a caller
                                                  SC_STREAM_DEFAULT for it (torch reports it as 0)        */
 #define SC_STREAM_DEFAULT ((void*)1)
 const char* sc_last_error(const sc_ctx* ctx);          /* last HIP error text seen by this context    */
+
+/* Test / tuning hook, NOT part of the drop-in surface.  The library reads no environment variable; the scheduling
+ * knobs and forced fallbacks the parity tests and the sweeps drive live in this per-context struct.  None of them can
+ * change a result — only launch geometry, or which of two bit-identical code paths runs.  0 = default everywhere
+ * (-1 for the two *_self_max fields).  sc_set_debug(ctx, NULL) restores the defaults. */
+typedef struct sc_debug {
+  uint32_t size;              /* = sizeof(sc_debug)                                                          */
+  uint32_t no_events;         /* 1: stage B walks the bit rows twice instead of recording an event list       */
+  uint64_t event_cap;         /* event records per call (>= 256): forces the overflow fallback when too small  */
+  int64_t  compact_self_max;  /* key tiles up to which the compaction sums the tile counts itself (-1: 4096)  */
+  int64_t  scan_self_max;     /* scan tiles up to which the down-sweep sums the block sums itself (-1: 4096)  */
+  uint32_t cnt_blocks, keys_blocks, sel_blocks;   /* grid sizes of the counting / key / select kernels        */
+  uint32_t tg_count, tg_keys, tg_sample;          /* lanes per edge: 4, 8 (default), 16, 32 (64: keys, sample)*/
+  uint64_t sample_edges;      /* edges in stage B's pruning sample (default ~5T/8, at least 32768)            */
+  uint32_t score_split;       /* share (of 256) of the hypotheses scored by the f32-MFMA body of C2 */
+  uint32_t compat_one_phase;  /* 1: stage A runs the exact chain on every pair of an interior tile            */
+  uint32_t compat_rows;       /* stage A tile height: 16 (default) or 64                                      */
+  uint32_t reserved;
+} sc_debug;
+int         sc_set_debug(sc_ctx* ctx, const sc_debug* dbg);
 
 /* ---- the drop-in entry point: correspondences in, (R, t, inlier mask) out ------------------------
  * north_star: "keeping the reference's correspondence-in / (R,t,inlier-mask)-out function signature".

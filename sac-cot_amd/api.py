@@ -19,11 +19,11 @@ LIB_PATH = os.path.join(_HERE, "libsaccot.so")
 SC_OK, SC_EINVAL, SC_ENOMEM, SC_EHIP, SC_ERCCL, SC_ENOHYP, SC_ETOOMANY = 0, -1, -2, -3, -4, -5, -6
 SC_AOS, SC_SOA = 0, 1
 SC_RANK_WEIGHT, SC_RANK_DEGREE = 0, 1
-SC_FLAG_TIMING, SC_FLAG_EXACT_TOTAL, SC_FLAG_NO_PRUNE, SC_FLAG_REFINE, SC_FLAG_TIMING_HOT = 1, 2, 4, 8, 16
+SC_FLAG_TIMING, SC_FLAG_EXACT_TOTAL, SC_FLAG_NO_PRUNE, SC_FLAG_REFINE, SC_FLAG_TIMING_HOT, SC_FLAG_NO_DENSE_S = 1, 2, 4, 8, 16, 32
 SC_HIST_WORDS = 256  # u32 words of the pruning-sample histogram (sc_hypothesize_begin_device)
 
 EXPORTS = ["sc_version", "sc_strerror", "sc_default_params", "sc_create", "sc_destroy", "sc_set_stream",
-           "sc_last_error", "sc_register", "sc_register_device", "sc_hypothesize_device", "sc_finalize_device",
+           "sc_last_error", "sc_set_debug", "sc_register", "sc_register_device", "sc_hypothesize_device", "sc_finalize_device",
            "sc_hypothesize_begin_device", "sc_hypothesize_end_device", "sc_finalize_gathered_device",
            "sc_compat_host", "sc_triangles_host", "sc_kabsch_host", "sc_score_host", "sc_mask_host"]
 
@@ -46,6 +46,16 @@ class ScStats(C.Structure):
 
     def as_dict(self) -> dict:
         return {k: getattr(self, k) for k, _ in self._fields_ if k != "size"}
+
+
+class ScDebug(C.Structure):
+    """Mirror of `sc_debug` (include/saccot.h): test / tuning hook, 0 = default (-1 for the *_self_max fields)."""
+    _fields_ = [("size", C.c_uint32), ("no_events", C.c_uint32), ("event_cap", C.c_uint64),
+                ("compact_self_max", C.c_int64), ("scan_self_max", C.c_int64),
+                ("cnt_blocks", C.c_uint32), ("keys_blocks", C.c_uint32), ("sel_blocks", C.c_uint32),
+                ("tg_count", C.c_uint32), ("tg_keys", C.c_uint32), ("tg_sample", C.c_uint32),
+                ("sample_edges", C.c_uint64), ("score_split", C.c_uint32), ("compat_one_phase", C.c_uint32),
+                ("compat_rows", C.c_uint32), ("reserved", C.c_uint32)]
 
 
 class SacCotError(RuntimeError):
@@ -82,6 +92,7 @@ def load_library() -> C.CDLL:
     L.sc_destroy.argtypes = [vp]; L.sc_destroy.restype = None
     L.sc_set_stream.argtypes = [vp, vp]
     L.sc_last_error.argtypes = [vp]; L.sc_last_error.restype = C.c_char_p
+    L.sc_set_debug.argtypes = [vp, C.POINTER(ScDebug)]
     L.sc_register.argtypes = [vp, f32p, f32p, C.c_int64, pp, f32p, f32p, u8p, sp]
     L.sc_register_device.argtypes = [vp, vp, vp, C.c_int64, pp, vp, vp, sp]
     L.sc_hypothesize_device.argtypes = [vp, vp, vp, C.c_int64, pp, vp, sp]
@@ -152,6 +163,19 @@ class Registrar:
         else:
             ptr = stream_ptr
         self._check(self._lib.sc_set_stream(self._h, C.c_void_p(ptr)))
+
+    def set_debug(self, **knobs):
+        """sc_set_debug: scheduling knobs / forced fallbacks for tests and sweeps (field names of `sc_debug`); no
+        arguments restores the defaults.  The library itself reads no environment variable."""
+        if not knobs:
+            self._check(self._lib.sc_set_debug(self._h, None))
+            return
+        d = ScDebug(size=C.sizeof(ScDebug), compact_self_max=-1, scan_self_max=-1)
+        for k, v in knobs.items():
+            if k not in dict(ScDebug._fields_) or k in ("size", "reserved"):
+                raise KeyError(f"sc_debug has no field {k!r}")
+            setattr(d, k, int(v))
+        self._check(self._lib.sc_set_debug(self._h, C.byref(d)))
 
     # ---- drop-in entry point ----------------------------------------------------------------------------
     def register(self, src, tgt, params: ScParams | None = None, **kw):

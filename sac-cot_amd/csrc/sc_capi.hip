@@ -64,6 +64,7 @@ struct sc_ctx {
   bool refine = false;
   const uint64_t* mbits = nullptr;
   const float* smin_ptr = nullptr;
+  Tuning tn;  // defaults unless sc_set_debug() changed them; the library reads no environment variable
 };
 
 namespace {
@@ -112,7 +113,7 @@ int check_params(const sc_params* p) {
   if (!(p->sigma > 0.f) || !(p->t_cmp > 0.f) || !(p->t_cmp < 1.f) || !(p->tau > 0.f) || !(p->min_len >= 0.f))
     return SC_EINVAL;
   if (!std::isfinite(p->sigma) || !std::isfinite(p->tau) || !std::isfinite(p->min_len)) return SC_EINVAL;
-  if (p->max_triangles == 0) return SC_EINVAL;
+  if (p->max_triangles == 0 || p->max_triangles > 0xFFFFFF00u) return SC_EINVAL;  // padded to 256 in u32
   if (p->rank_mode != SC_RANK_WEIGHT && p->rank_mode != SC_RANK_DEGREE) return SC_EINVAL;
   if (p->layout != SC_AOS && p->layout != SC_SOA) return SC_EINVAL;
   if (p->shard_world < 1 || p->shard_rank < 0 || p->shard_rank >= p->shard_world) return SC_EINVAL;
@@ -171,7 +172,7 @@ int run_compat(sc_ctx* c) {
   ENSURE(c, c->deg, n * sizeof(uint32_t));
   ENSURE(c, c->degp, n * sizeof(uint32_t));
   ENSURE(c, c->wpre, n * W * sizeof(uint32_t));
-  launch_compat(points_of(c), c->dv, c->S.as<float>(), c->bits.as<uint64_t>(), c->stream);
+  launch_compat(points_of(c), c->dv, c->S.as<float>(), c->bits.as<uint64_t>(), c->tn, c->stream);
   return SC_OK;
 }
 
@@ -226,7 +227,7 @@ int run_edges(sc_ctx* c, const sc_params* p, uint32_t* hist, uint32_t part, uint
   ENSURE(c, c->scan_tmp, scan_temp_bytes(n));
   // read-back #1: the scan kernel itself writes the edge count to host-pinned memory (no copy kernel)
   arm_word(c, 0);
-  launch_scan_u32(c->degp.as<uint32_t>(), n, c->edge_off.as<uint64_t>(), c->scan_tmp.p, st, &c->pinned[0]);
+  launch_scan_u32(c->degp.as<uint32_t>(), n, c->edge_off.as<uint64_t>(), c->scan_tmp.p, c->tn, st, &c->pinned[0]);
   // While the host polls for the edge count, edge_fill already runs into the edge arrays this context holds from
   // earlier calls (it needs no host-side count: one wave per row, offsets from the scan).  Writes beyond their
   // capacity are dropped by the kernel; in that case, or on a first call, it runs (again) after the read-back.
@@ -244,6 +245,8 @@ int run_edges(sc_ctx* c, const sc_params* p, uint32_t* hist, uint32_t part, uint
   const uint64_t E = c->E = c->pinned[0];
   c->M = 0; c->M_total = 0; c->T_eff = 0; c->pruned = false; c->use_events = false; c->have_total = false;
   if (E == 0) return SC_OK;
+  // edge ids, CSR bases and the strong list are u32 (include/saccot.h, limits): a graph beyond that is refused, not wrapped
+  if (E >= (1ull << 32)) { c->last_error = "the compatibility graph has 2^32 or more edges"; return SC_ETOOMANY; }
   ENSURE(c, c->ei, E * 4);
   ENSURE(c, c->ej, E * 4);
   ENSURE(c, c->es, (E + 2) * 4);  // +1: the 4-way unrolled gathers of idle slots may touch index E
@@ -255,20 +258,20 @@ int run_edges(sc_ctx* c, const sc_params* p, uint32_t* hist, uint32_t part, uint
   if (E > spec_cap) fill_edges(E);  // first call, or the graph outgrew the arrays (just re-allocated above)
   // certified pruning (sc_tri.hip 3b): weight ranking only; pointless on tiny graphs
   c->pruned = may_prune(p) && E >= 4096;
-  // counting pass + event list (sc_tri.hip 2b) on the pruned graph; SC_NO_EVENTS=1 keeps the row-walking pair
-  c->use_events = c->pruned && getenv("SC_NO_EVENTS") == nullptr;
+  // counting pass + event list (sc_tri.hip 2b) on the pruned graph; Tuning::no_events keeps the row-walking pair
+  c->use_events = c->pruned && !c->tn.no_events;
   if (c->pruned) {
     ControlBlock* ctl = c->ctl.as<ControlBlock>();
     if (p->flags & SC_FLAG_EXACT_TOTAL) {  // statistics only: 3-cliques of the whole graph
       launch_tri_count(g, g.bits, c->es.as<float>(), nullptr, c->ei.as<uint32_t>(), c->ej.as<uint32_t>(), E,
-                       c->tcnt.as<uint32_t>(), st);
-      launch_scan_u32(c->tcnt.as<uint32_t>(), E, c->toff.as<uint64_t>(), c->scan_tmp.p, st, &c->pinned[4]);
+                       c->tcnt.as<uint32_t>(), c->tn, st);
+      launch_scan_u32(c->tcnt.as<uint32_t>(), E, c->toff.as<uint64_t>(), c->scan_tmp.p, c->tn, st, &c->pinned[4]);
       c->have_total = true;
     }
     // the smallest possible weight is ~3 t_cmp (every edge has s >= t_cmp up to rounding); 0.1 % slack
     launch_sample_hist(g, c->ebi.as<uint32_t>(), c->ebj.as<uint32_t>(), c->ei.as<uint32_t>(), c->ej.as<uint32_t>(),
                        c->es.as<float>(), E, p->max_triangles, 3.0f * p->t_cmp * 0.999f, part, parts,
-                       hist ? hist : ctl->prune_hist, st);
+                       hist ? hist : ctl->prune_hist, c->tn, st);
   }
   return SC_OK;
 }
@@ -301,23 +304,22 @@ int run_select(sc_ctx* c, const sc_params* p, const uint32_t* hist, bool want_li
   c->smin_ptr = smin;
   EventList ev{};
   if (use_events) {
-    if (const char* capenv = getenv("SC_EVENT_CAP")) {  // test knob: force a (too) small event buffer
-      const uint64_t forced = (uint64_t)atoll(capenv);
-      if (forced >= 256) c->ev_capacity = forced;
-    }
-    ENSURE(c, c->events, event_bytes(c->ev_capacity));
+    // Tuning::event_cap (test hook) forces a (too) small buffer for THIS call without touching the context's own
+    // capacity, which only grows (after an overflow)
+    const uint64_t ev_cap = c->tn.event_cap >= 256 ? c->tn.event_cap : c->ev_capacity;
+    ENSURE(c, c->events, event_bytes(ev_cap));
     c->pinned[5] = 0;
-    ev = event_list(c->events.p, c->ev_capacity, g.W, c->ctl.as<ControlBlock>()->ev_fill,
+    ev = event_list(c->events.p, ev_cap, g.W, c->ctl.as<ControlBlock>()->ev_fill,
                     reinterpret_cast<uint32_t*>(&c->pinned[5]));
     launch_tri_count_events(g, mbits, sl, c->ebi.as<uint32_t>(), c->ebj.as<uint32_t>(), c->ei.as<uint32_t>(),
-                            c->ej.as<uint32_t>(), E, p->rank_mode, c->tcnt.as<uint32_t>(), ev, st);
+                            c->ej.as<uint32_t>(), E, p->rank_mode, c->tcnt.as<uint32_t>(), ev, c->tn, st);
   } else {
     launch_tri_count(g, mbits, c->es.as<float>(), smin, c->ei.as<uint32_t>(), c->ej.as<uint32_t>(), E,
-                     c->tcnt.as<uint32_t>(), st);
+                     c->tcnt.as<uint32_t>(), c->tn, st);
   }
   // read-back #2: triangle count (of the pruned graph when pruning), written to pinned memory by the scan
   arm_word(c, 2);
-  launch_scan_u32(c->tcnt.as<uint32_t>(), E, c->toff.as<uint64_t>(), c->scan_tmp.p, st, &c->pinned[2]);
+  launch_scan_u32(c->tcnt.as<uint32_t>(), E, c->toff.as<uint64_t>(), c->scan_tmp.p, c->tn, st, &c->pinned[2]);
   // While the host polls for the count, the key kernel already runs into the key arrays this context holds from earlier
   // calls (it takes everything else from device memory).  Only in the common form — events, a-priori select window —
   // and not when every stage is bracketed by events; re-run below if the count outgrew the arrays or a region overflowed.
@@ -330,7 +332,7 @@ int run_select(sc_ctx* c, const sc_params* p, const uint32_t* hist, bool want_li
       ENSURE(c, c->blk_minmax, 2 * 8192 * 4);
       launch_tri_keys_events(g, c->es.as<float>(), c->toff.as<uint64_t>(), p->rank_mode, ev, c->wkey.as<uint32_t>(),
                              c->kcol.as<uint2>(), c->blk_minmax.as<uint32_t>(), sel, p->max_triangles,
-                             &c->ctl.as<ControlBlock>()->klb, E, spec_cap, st);
+                             &c->ctl.as<ControlBlock>()->klb, E, spec_cap, c->tn, st);
     }
   }
   { const int wrc = wait_word(c, 2); if (wrc) return wrc; }
@@ -368,23 +370,21 @@ int run_select(sc_ctx* c, const sc_params* p, const uint32_t* hist, bool want_li
   } else if (events_ok) {
     launch_tri_keys_events(g, c->es.as<float>(), c->toff.as<uint64_t>(), p->rank_mode, ev, c->wkey.as<uint32_t>(),
                            c->kcol.as<uint2>(), c->blk_minmax.as<uint32_t>(), sel, T_eff,
-                           fast_window ? &c->ctl.as<ControlBlock>()->klb : nullptr, E, M, st);
+                           fast_window ? &c->ctl.as<ControlBlock>()->klb : nullptr, E, M, c->tn, st);
   } else {
     launch_tri_keys(g, mbits, smin, c->ebase.as<uint32_t>(), c->ei.as<uint32_t>(), c->ej.as<uint32_t>(),
                     c->es.as<float>(), c->toff.as<uint64_t>(), E, p->rank_mode, c->wkey.as<uint32_t>(),
-                    c->kcol.as<uint2>(), c->blk_minmax.as<uint32_t>(), sel, T_eff, st);
+                    c->kcol.as<uint2>(), c->blk_minmax.as<uint32_t>(), sel, T_eff, c->tn, st);
   }
   if (c->timing) HIPCHK(c, hipEventRecord(c->ev[10], st));
   c->timed_trikeys = c->timing;
-  launch_select_rounds(c->wkey.as<uint32_t>(), M, sel, fast_window ? 2 : 3, st);
+  launch_select_rounds(c->wkey.as<uint32_t>(), M, sel, fast_window ? 2 : 3, c->tn, st);
   launch_compact_count(c->wkey.as<uint32_t>(), M, sel, c->blk_gt.as<uint32_t>(), c->blk_eq.as<uint32_t>(), st);
   // few tiles (and M < 2^32): compact_write adds up the tile counts itself, no scan launch in between
-  size_t self_tiles = 4096;
-  if (const char* v = getenv("SC_COMPACT_SELF_MAX")) self_tiles = (size_t)atoll(v);  // test knob: force the scanned offsets
-  const bool self_off = nb <= self_tiles && M < (1ull << 32);
+  const bool self_off = nb <= c->tn.compact_self_max && M < (1ull << 32);  // (a test sets 0: the scanned offsets)
   if (!self_off)
     launch_scan_u32_pair(c->blk_gt.as<uint32_t>(), c->off_gt.as<uint64_t>(), c->blk_eq.as<uint32_t>(),
-                         c->off_eq.as<uint64_t>(), nb, c->scan_tmp.p, st);
+                         c->off_eq.as<uint64_t>(), nb, c->scan_tmp.p, c->tn, st);
   launch_compact_write(c->wkey.as<uint32_t>(), M, sel, c->blk_gt.as<uint32_t>(), c->blk_eq.as<uint32_t>(),
                        self_off ? nullptr : c->off_gt.as<uint64_t>(), self_off ? nullptr : c->off_eq.as<uint64_t>(),
                        c->sel_ord.as<uint64_t>(), c->sel_key.as<uint32_t>(), st);
@@ -539,6 +539,32 @@ int sc_set_stream(sc_ctx* c, void* hip_stream) {
 
 const char* sc_last_error(const sc_ctx* c) { return c ? c->last_error.c_str() : "null context"; }
 
+int sc_set_debug(sc_ctx* c, const sc_debug* d) {
+  if (!c) return SC_EINVAL;
+  if (!d) { c->tn = Tuning(); return SC_OK; }
+  if (d->size != sizeof(sc_debug)) return SC_EINVAL;
+  auto tg_ok = [](uint32_t t) { return t == 0 || t == 4 || t == 8 || t == 16 || t == 32 || t == 64; };
+  if (!tg_ok(d->tg_count) || !tg_ok(d->tg_keys) || !tg_ok(d->tg_sample)) return SC_EINVAL;
+  if (d->tg_count == 64) return SC_EINVAL;  // the plain counting kernel has no 64-lane form
+  if (d->score_split > 256 || (d->compat_rows != 0 && d->compat_rows != 16 && d->compat_rows != 64)) return SC_EINVAL;
+  if (d->event_cap != 0 && d->event_cap < 256) return SC_EINVAL;
+  Tuning t;
+  t.no_events = d->no_events != 0;
+  t.event_cap = d->event_cap;
+  if (d->compact_self_max >= 0) t.compact_self_max = (size_t)d->compact_self_max;
+  if (d->scan_self_max >= 0) t.scan_self_max = (size_t)d->scan_self_max;
+  t.cnt_blocks = d->cnt_blocks; t.keys_blocks = d->keys_blocks; t.sel_blocks = d->sel_blocks;
+  if (d->tg_count) t.tg_count = (int)d->tg_count;
+  if (d->tg_keys) t.tg_keys = (int)d->tg_keys;
+  if (d->tg_sample) t.tg_sample = (int)d->tg_sample;
+  t.sample_edges = d->sample_edges;
+  t.score_split = d->score_split;
+  t.compat_one_phase = d->compat_one_phase != 0;
+  t.compat_rows = d->compat_rows == 64 ? 64 : 16;
+  c->tn = t;
+  return SC_OK;
+}
+
 }  // extern "C" (the two halves below are internal)
 
 namespace {
@@ -583,7 +609,7 @@ int hyp_end(sc_ctx* c, const uint32_t* d_hist, uint64_t* d_key, sc_stats* stats)
   sh.rank = (uint32_t)p->shard_rank;
   sh.world = (uint32_t)p->shard_world;
   sh.n_local = shard_local_count(sh.T_eff, sh.block, sh.rank, sh.world);
-  sh.ld_local = (uint32_t)round_up((int)sh.n_local, 256);
+  sh.ld_local = (uint32_t)(((uint64_t)sh.n_local + 255u) / 256u * 256u);  // T <= 2^32 - 256 (check_params)
   c->sh = sh;
   if (sh.n_local) {
     ENSURE(c, c->rt, (size_t)12 * sh.ld_local * 4);
@@ -592,7 +618,7 @@ int hyp_end(sc_ctx* c, const uint32_t* d_hist, uint64_t* d_key, sc_stats* stats)
     launch_kabsch(points_of(c), tri_source_of(c), sh, c->rt.as<float>(), c->stream);
   }
   if ((rc = rec(c, 4))) return rc;
-  launch_score(points_of(c), c->rt.as<float>(), sh, c->dv.tau2, c->partial.as<uint32_t>(), c->stream);
+  launch_score(points_of(c), c->rt.as<float>(), sh, c->dv.tau2, c->partial.as<uint32_t>(), c->tn, c->stream);
   if ((rc = rec(c, 5))) return rc;
   ENSURE(c, c->amx_pairs, argmax_scratch_bytes(sh.ld_local));
   launch_argmax(points_of(c), sh, c->partial.as<uint32_t>(), c->T_eff ? c->sel_key.as<uint32_t>() : nullptr,
@@ -661,6 +687,10 @@ int sc_finalize_gathered_device(sc_ctx* c, const uint64_t* d_keys, int n_pairs, 
   if (c->timing || c->stream == c->own_stream) HIPCHK(c, hipStreamSynchronize(c->stream));
   if ((rc = wait_word(c, 8))) return rc;
   HIPCHK(c, hipGetLastError());
+  if (c->pinned[11] != 0) {  // finalize_kernel: a pair decodes to a position outside the selection (outputs: identity, zero mask)
+    c->last_error = "a winner key pair points outside the selected list (stale / uninitialised pair, or ranks that disagree on T or the parameters)";
+    return SC_EINVAL;
+  }
   const uint64_t key = c->pinned[8];
   if (stats && stats->size == sizeof(sc_stats)) {
     fill_stats(c, stats);
@@ -819,7 +849,7 @@ int sc_score_host(sc_ctx* c, const float* src, const float* tgt, int64_t n, cons
   if ((rc = host_to_planes(c, src, tgt, n, p))) return rc;
   Shard sh;
   sh.T_eff = n_hyp; sh.block = 0x40000000u; sh.rank = 0; sh.world = 1; sh.n_local = n_hyp;
-  sh.ld_local = (uint32_t)round_up((int)n_hyp, 256);
+  sh.ld_local = (uint32_t)(((uint64_t)n_hyp + 255u) / 256u * 256u);
   ENSURE(c, c->key, 64);
   if (n_hyp) {
     ENSURE(c, c->rt_aos, (size_t)n_hyp * 48);
@@ -828,7 +858,7 @@ int sc_score_host(sc_ctx* c, const float* src, const float* tgt, int64_t n, cons
     HIPCHK(c, hipMemcpyAsync(c->rt_aos.p, Rt, (size_t)n_hyp * 48, hipMemcpyHostToDevice, c->stream));
     launch_rt_to_soa(c->rt_aos.as<float>(), n_hyp, sh.ld_local, c->rt.as<float>(), c->stream);
   }
-  launch_score(points_of(c), c->rt.as<float>(), sh, c->dv.tau2, c->partial.as<uint32_t>(), c->stream);
+  launch_score(points_of(c), c->rt.as<float>(), sh, c->dv.tau2, c->partial.as<uint32_t>(), c->tn, c->stream);
   ENSURE(c, c->cnt, (size_t)(sh.ld_local ? sh.ld_local : 256) * 4);
   ENSURE(c, c->amx_pairs, argmax_scratch_bytes(sh.ld_local));
   launch_argmax(points_of(c), sh, c->partial.as<uint32_t>(), nullptr, c->cnt.as<uint32_t>(), c->amx_pairs.as<uint64_t>(),

@@ -2,7 +2,6 @@
 //
 // Stage A's output is 4 N^2 bytes of weights + N^2/8 bytes of adjacency bits (103 MB at N = 5000): the HBM write
 // roofline is its bound; see the stage-A section below for the tiling that gets the arithmetic out of the way.
-#include <cstdlib>
 #include <type_traits>
 
 #include "sc_arith.hpp"
@@ -313,14 +312,13 @@ __global__ __launch_bounds__(256) void row_stats_kernel(const uint64_t* __restri
   if (lane == 0) { deg[i] = d_all; degp[i] = d_up; }
 }
 
-void launch_compat(const Points& pts, const Derived& dv, float* S, uint64_t* bits, hipStream_t st) {
+void launch_compat(const Points& pts, const Derived& dv, float* S, uint64_t* bits, const Tuning& tn, hipStream_t st) {
   const int W = pts.ld >> 6;
-  const int two_phase = getenv("SC_COMPAT_ONE_PHASE") ? 0 : 1;  // the one-phase interior form stays for A/B and parity
+  const int two_phase = tn.compat_one_phase ? 0 : 1;  // the one-phase interior form stays for A/B and parity
   // tile height: 16 rows (4.3 KiB LDS image per wave, 4 waves per workgroup; default) or 64 rows (16.6 KiB, one wave
   // per workgroup; the mirrored half is then written as full 256-byte segments).  Measured: C2 28 vs 49 us, C3 432 vs
-  // 435 us — bigger mirrored pieces do not pay for the lost occupancy.  SC_COMPAT_ROWS=64 selects it (experiments).
-  int tr = 16;
-  if (const char* v = getenv("SC_COMPAT_ROWS")) tr = atoi(v) == 64 ? 64 : 16;
+  // 435 us — bigger mirrored pieces do not pay for the lost occupancy.  Tuning::compat_rows = 64 selects it (experiments).
+  const int tr = tn.compat_rows == 64 ? 64 : 16;
   if (tr == 64) {
     const int n_tiles = W * (W + 1) / 2;
     hipLaunchKernelGGL((compat_tiles_kernel<64, 1>), dim3(n_tiles), dim3(64), 0, st, pts.planes, pts.n, pts.ld, dv.d_thr,
@@ -444,21 +442,22 @@ __global__ __launch_bounds__(1024) void scan_small_kernel(const uint32_t* __rest
 }
 
 constexpr size_t SCAN_SMALL_MAX = 32768;
-constexpr size_t SCAN_SELF_MAX = 4096;  // tiles (16.7 M elements): beyond it the scan of sums is its own launch
+// Tuning::scan_self_max (4096 tiles = 16.7 M elements): beyond it the scan of sums is its own launch
 
 void launch_scan_u32_pair(const uint32_t* in0, uint64_t* out0, const uint32_t* in1, uint64_t* out1, size_t n,
-                          void* temp, hipStream_t st) {
+                          void* temp, const Tuning& tn, hipStream_t st) {
   if (n <= SCAN_SMALL_MAX) {
     hipLaunchKernelGGL(scan_small_kernel, dim3(1), dim3(1024), 0, st, in0, out0, in1, out1, n, (uint64_t*)nullptr);
   } else {
-    launch_scan_u32(in0, n, out0, temp, st);
-    if (in1) launch_scan_u32(in1, n, out1, temp, st);
+    launch_scan_u32(in0, n, out0, temp, tn, st);
+    if (in1) launch_scan_u32(in1, n, out1, temp, tn, st);
   }
 }
 
 size_t scan_temp_bytes(size_t n) { return ((n + SCAN_TILE - 1) / SCAN_TILE + 1) * sizeof(uint64_t); }
 
-void launch_scan_u32(const uint32_t* in, size_t n, uint64_t* out, void* temp, hipStream_t st, uint64_t* host_total) {
+void launch_scan_u32(const uint32_t* in, size_t n, uint64_t* out, void* temp, const Tuning& tn, hipStream_t st,
+                     uint64_t* host_total) {
   if (n <= SCAN_SMALL_MAX) {
     hipLaunchKernelGGL(scan_small_kernel, dim3(1), dim3(1024), 0, st, in, out, (const uint32_t*)nullptr,
                        (uint64_t*)nullptr, n, host_total);
@@ -468,9 +467,7 @@ void launch_scan_u32(const uint32_t* in, size_t n, uint64_t* out, void* temp, hi
   const size_t nb = (n + SCAN_TILE - 1) / SCAN_TILE;
   if (nb == 0) return;  // n == 0 is handled by the small path above
   hipLaunchKernelGGL(scan_block_sums_kernel, dim3((unsigned)nb), dim3(SCAN_THREADS), 0, st, in, n, bsum);
-  size_t self_max = SCAN_SELF_MAX;
-  if (const char* v = getenv("SC_SCAN_SELF_MAX")) self_max = (size_t)atoll(v);  // test knob: force the three-kernel form
-  if (nb <= self_max) {
+  if (nb <= tn.scan_self_max) {  // (a test sets scan_self_max = 0 to force the three-kernel form)
     hipLaunchKernelGGL(scan_downsweep_kernel<true>, dim3((unsigned)nb), dim3(SCAN_THREADS), 0, st, in, n, bsum, out,
                        host_total);
   } else {

@@ -15,6 +15,22 @@ struct Derived {
   float min_len;
 };
 
+// Scheduling / fallback knobs of the kernels.  The shipped library reads NO environment variable: these defaults are
+// what runs, and only sc_set_debug() (include/saccot.h, test and tuning hook) changes them, per context.  None of them
+// can change a result — only the launch geometry or which of two bit-identical code paths runs.
+struct Tuning {
+  bool no_events = false;          // row-walking count / key kernels instead of the event list
+  uint64_t event_cap = 0;          // forced event capacity (0: the context's own, grown after an overflow)
+  size_t compact_self_max = 4096;  // tiles up to which compact_write adds up the tile counts by itself
+  size_t scan_self_max = 4096;     // tiles up to which the scan's down-sweep adds up the block sums by itself
+  uint32_t cnt_blocks = 0, keys_blocks = 0, sel_blocks = 0;  // grid sizes (0: automatic)
+  int tg_count = 8, tg_keys = 8, tg_sample = 8;              // lanes per edge
+  uint64_t sample_edges = 0;       // edges of the pruning sample (0: automatic, ~5T/8)
+  uint32_t score_split = 0;        // share (of 256) of the hypotheses scored on the matrix pipe
+  bool compat_one_phase = false;   // exact chain on every pair of an interior tile
+  int compat_rows = 16;            // tile height of stage A: 16 or 64
+};
+
 // Device view of the padded SoA point planes: px py pz qx qy qz, each `ld` floats (ld = roundup(n,64)),
 // zero-filled beyond n — followed, at planes + 6 * ld, by an AoS copy of 8 floats per correspondence
 // (px py pz qx qy qz 0 0; 32-byte aligned) for the consumers that fetch one whole correspondence at a time.
@@ -33,7 +49,7 @@ void launch_stage_points(const float* d_src, const float* d_tgt, int n, int ld, 
 
 // ---- stage A: compat_graph -----------------------------------------------------------------------
 // S: n x ld fp32 (row-major, symmetric, zero diagonal / pad columns); bits: n x (ld/64) u64;
-void launch_compat(const Points& pts, const Derived& dv, float* S, uint64_t* bits, hipStream_t st);
+void launch_compat(const Points& pts, const Derived& dv, float* S, uint64_t* bits, const Tuning& tn, hipStream_t st);
 // deg[i] = edges of i; degp[i] = edges (i,j) with j > i; wpre: n x (ld/64) u32, set bits of row i in words [0,w).
 // zero_rows (optional): an n x W u64 matrix cleared on the way (the pruned bit matrix of stage B).
 void launch_row_stats(const Points& pts, const uint64_t* bits, uint32_t* deg, uint32_t* degp, uint32_t* wpre,
@@ -43,11 +59,11 @@ void launch_row_stats(const Points& pts, const uint64_t* bits, uint32_t* deg, ui
 // host_total (optional): host-pinned u64 that also receives the total, written by the kernel itself — the host
 // reads it after its next stream synchronise, with no copy kernel in between.
 size_t scan_temp_bytes(size_t n);
-void launch_scan_u32(const uint32_t* in, size_t n, uint64_t* out, void* temp, hipStream_t st,
+void launch_scan_u32(const uint32_t* in, size_t n, uint64_t* out, void* temp, const Tuning& tn, hipStream_t st,
                      uint64_t* host_total = nullptr);
 // two arrays of the same length in one go (one launch when n is small); in1/out1 may be null
 void launch_scan_u32_pair(const uint32_t* in0, uint64_t* out0, const uint32_t* in1, uint64_t* out1, size_t n,
-                          void* temp, hipStream_t st);
+                          void* temp, const Tuning& tn, hipStream_t st);
 
 // ---- stage B: triangles_topT ---------------------------------------------------------------------
 struct Graph {
@@ -67,7 +83,7 @@ void launch_edge_fill(const Graph& g, const Points& pts, const Derived& dv, cons
 // tcnt[e] = #k > j adjacent (in `mbits`) to both ends of edge e = (i,j); edges with es[e] < *smin count 0
 // (smin == nullptr: no pruning, mbits = g.bits).
 void launch_tri_count(const Graph& g, const uint64_t* mbits, const float* es, const float* smin, const uint32_t* ei,
-                      const uint32_t* ej, uint64_t E, uint32_t* tcnt, hipStream_t st);
+                      const uint32_t* ej, uint64_t E, uint32_t* tcnt, const Tuning& tn, hipStream_t st);
 // Compact list of the strong edges (those of the pruned graph), written by the pruning kernel in ST_SHARDS regions of
 // `cap` entries (fill[r] = entries of region r; ST_SHARDS zeroed counters of the control block).  list == nullptr: off.
 constexpr int ST_SHARDS = 256;
@@ -89,7 +105,7 @@ size_t strong_list_bytes(uint64_t E);
 //    with sl.list set also compacts the strong edges and zeroes tcnt of the weak ones.
 void launch_sample_hist(const Graph& g, const uint32_t* ebi, const uint32_t* ebj, const uint32_t* ei,
                         const uint32_t* ej, const float* es, uint64_t E, uint64_t want, float key_floor, uint32_t part,
-                        uint32_t parts, uint32_t* hist, hipStream_t st);
+                        uint32_t parts, uint32_t* hist, const Tuning& tn, hipStream_t st);
 void launch_prune_bits(const Graph& g, const uint32_t* hist, const uint32_t* ei, const uint32_t* ej, const float* es,
                        uint64_t E, uint64_t want, float key_floor, uint64_t* mbits, float* smin, uint32_t* klb,
                        const StrongList& sl, uint32_t* tcnt, hipStream_t st);
@@ -114,7 +130,7 @@ EventList event_list(void* buf, uint64_t capacity, int W, uint32_t* fill, uint32
 // counting pass that also emits the events (replaces launch_tri_count when an event buffer is available)
 void launch_tri_count_events(const Graph& g, const uint64_t* mbits, const StrongList& sl, const uint32_t* ebi,
                              const uint32_t* ebj, const uint32_t* ei, const uint32_t* ej, uint64_t E, int rank_mode,
-                             uint32_t* tcnt, const EventList& ev, hipStream_t st);
+                             uint32_t* tcnt, const EventList& ev, const Tuning& tn, hipStream_t st);
 
 // Radix-select state.  Lives in the context's control block, which ONE memset zeroes per call; key_range_kernel
 // (end of launch_tri_keys) fills kmin / kmax / want.
@@ -152,16 +168,16 @@ static_assert(offsetof(ControlBlock, sel) % 16 == 0, "ControlBlock::sel must be 
 void launch_tri_keys(const Graph& g, const uint64_t* mbits, const float* smin, const uint32_t* ebase,
                      const uint32_t* ei, const uint32_t* ej, const float* es, const uint64_t* toff, uint64_t E,
                      int rank_mode, uint32_t* wkey, uint2* kcol, uint32_t* blk_minmax, SelectState* s,
-                     uint64_t want, hipStream_t st);  // kcol[ordinal] = {the triangle's third vertex, its edge id}
+                     uint64_t want, const Tuning& tn, hipStream_t st);  // kcol[ordinal] = {the triangle's third vertex, its edge id}
 // keys from the event list (replaces launch_tri_keys when no region overflowed)
 void launch_tri_keys_events(const Graph& g, const float* es, const uint64_t* toff, int rank_mode,
                             const EventList& ev, uint32_t* wkey, uint2* kcol, uint32_t* blk_minmax,
                             SelectState* s, uint64_t want, const uint32_t* klb, uint64_t E, uint64_t cap,
-                            hipStream_t st);  // cap: entries of wkey / kcol (writes beyond are dropped); want is clipped to toff[E]
+                            const Tuning& tn, hipStream_t st);  // cap: entries of wkey / kcol (writes beyond are dropped); want is clipped to toff[E]
 // klb != nullptr (weight ranking, every edge weight >= 2/3): the kernel presets the select window to
 // [*klb or 2.0, 3.0] and no key-range pass runs; two select rounds then always suffice.
 // `rounds` launches (histogram + pick by the last block to finish; 12 key bits each) find the exact threshold key
-void launch_select_rounds(const uint32_t* wkey, uint64_t M, SelectState* s, int rounds, hipStream_t st);
+void launch_select_rounds(const uint32_t* wkey, uint64_t M, SelectState* s, int rounds, const Tuning& tn, hipStream_t st);
 // compaction of the selected keys in ordinal order
 size_t compact_blocks(uint64_t M);
 void launch_compact_count(const uint32_t* wkey, uint64_t M, const SelectState* s, uint32_t* blk_gt,
@@ -205,7 +221,7 @@ void launch_rt_to_soa(const float* Rt, uint32_t T, uint32_t ld_local, float* RtS
 // C2: inlier counts.  partial: n_chunks * ld_local u32 scratch.
 uint32_t score_chunks(int n, uint32_t ld_local);  // point chunks the scoring launch will use
 void launch_score(const Points& pts, const float* RtSoA, const Shard& sh, float tau2, uint32_t* partial,
-                  hipStream_t st);
+                  const Tuning& tn, hipStream_t st);
 // Winner key pair key2[0..1] (written, not accumulated: no zeroing needed):
 //   key2[0] = max over hypotheses with count > 0 of  (count << 32) | second,   second = sel_key[g] (the triangle's
 //             ranking key) or, when sel_key == nullptr, 0xFFFFFFFF - g;

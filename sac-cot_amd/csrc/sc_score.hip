@@ -11,8 +11,6 @@
 //                   compare and one add-with-carry: 17 VALU instructions per test;
 //   grid          = ceil(T/256) x chunks, so a 50k x 5k problem is ~1000 workgroups (~4 waves per SIMD);
 //   partial counts are stored coalesced ([chunk][hypothesis]) and summed by the arg-max kernel.
-#include <cstdlib>
-
 #include "sc_arith.hpp"
 #include "sc_block.hpp"
 #include "sc_kernels.hpp"
@@ -360,21 +358,15 @@ __global__ __launch_bounds__(256) void score_argmax_kernel(const uint32_t* __res
   }
 }
 
-// share of the hypotheses (in 256ths) scored on the matrix pipe; SC_SCORE_SPLIT=0..256 overrides (experiments)
-static uint32_t score_mfma_share() {
-  const char* v = getenv("SC_SCORE_SPLIT");
-  if (v) { const int t = atoi(v); if (t >= 0 && t <= 256) return (uint32_t)t; }
-  return 0;
-}
-
+// Tuning::score_split: share of the hypotheses (in 256ths) scored on the matrix pipe (default 0; experiments)
 void launch_score(const Points& pts, const float* RtSoA, const Shard& sh, float tau2, uint32_t* partial,
-                  hipStream_t st) {
+                  const Tuning& tn, hipStream_t st) {
   if (sh.n_local == 0) return;
   uint32_t chunks;
   int chunk_pts;
   score_plan(pts.n, sh.ld_local, &chunks, &chunk_pts);
   const uint32_t groups = sh.ld_local / SCORE_THREADS;            // 256-hypothesis groups
-  const uint32_t gm = (uint32_t)(((uint64_t)groups * score_mfma_share() + 128) / 256);  // groups on the matrix pipe
+  const uint32_t gm = (uint32_t)(((uint64_t)groups * (tn.score_split <= 256 ? tn.score_split : 256u) + 128) / 256);  // groups on the matrix pipe
   const uint32_t nv = groups - gm, nm = gm * (SCORE_THREADS / MF_HYPS_PER_BLOCK);
   hipLaunchKernelGGL(score_kernel, dim3(nv + nm, chunks), dim3(SCORE_THREADS), 0, st, pts.planes, pts.n, pts.ld,
                      RtSoA, sh.ld_local, tau2, chunk_pts, partial, nv, nm);
@@ -419,10 +411,15 @@ __global__ __launch_bounds__(256) void finalize_kernel(const float* __restrict__
     const unsigned long long a = key2[2 * w], b = key2[2 * w + 1];
     if (a > k0 || (a == k0 && b > k1)) { k0 = a; k1 = b; }
   }
-  if (key_out && blockIdx.x == 0 && threadIdx.x == 0) { key_out[0] = k0; key_out[1] = k0 ? k1 : 0ull; }
   const bool two_stage = sel_key != nullptr;
   uint32_t g = 0;
   if (k0 != 0) g = 0xFFFFFFFFu - (uint32_t)((two_stage ? k1 : k0) & 0xFFFFFFFFull);
+  // The pairs come from the caller (an all-gather): a position outside the selection — a stale or uninitialised pair,
+  // ranks that disagree on T or the parameters — must not index sel_key / the triangle lookup.  It is treated as "no
+  // hypothesis" (identity, zero mask) and reported: host_out[3] = 1 makes the host return SC_EINVAL.
+  const bool bad_pair = k0 != 0 && g >= T;
+  if (bad_pair) { k0 = 0; k1 = 0; g = 0; }
+  if (key_out && blockIdx.x == 0 && threadIdx.x == 0) { key_out[0] = k0; key_out[1] = k0 ? k1 : 0ull; }
   // The winner's (R,t): if THIS rank scored it, phase 1 left it in RtSoA (kabsch3 is deterministic, so these are the
   // very bits a re-solve gives) — 12 parallel loads; otherwise thread 0 re-solves it from the replicated selection.
   const uint32_t gb = sh.block ? g / sh.block : 0u;
@@ -489,7 +486,8 @@ __global__ __launch_bounds__(256) void finalize_kernel(const float* __restrict__
       const uint32_t rank = __hip_atomic_load(rank_acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       __hip_atomic_store(rank_acc, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // ready for the next call
       __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if (host_out) {  // [0] last: the host polls it (release orders the other two before it)
+      if (host_out) {  // [0] last: the host polls it (release orders the others before it)
+        host_out[3] = bad_pair ? 1ull : 0ull;
         host_out[1] = g;
         host_out[2] = k0 ? (two_stage ? (unsigned long long)rank : (unsigned long long)g) : 0ull;
         publish_host(reinterpret_cast<uint64_t*>(host_out), k0);

@@ -12,7 +12,6 @@
 //   6. sort (rocPRIM)  by (~key, position)    7. tri_decode  ordinal -> (i,j,k)
 // Everything is integer / bit work except the two fp32 adds of the key; results do not depend on grid size
 // or on the order atomics land in (atomics are only used for commutative integer sums, min and max).
-#include <cstdlib>
 #include <cstring>
 
 #include "sc_arith.hpp"
@@ -142,13 +141,7 @@ void launch_edge_fill(const Graph& g, const Points& pts, const Derived& dv, cons
 // ------------------------------------------------------------------------------------------------
 // 2. tri_count: 16 lanes per edge
 // ------------------------------------------------------------------------------------------------
-// lanes-per-edge tuning knob (SC_TG_COUNT / SC_TG_KEYS / SC_TG_SAMPLE = 4|8|16|32|64); 8 measured best on C2
-static int tune_tg(const char* name, int dflt) {
-  const char* v = getenv(name);
-  if (!v) return dflt;
-  const int t = atoi(v);
-  return (t == 4 || t == 8 || t == 16 || t == 32 || t == 64) ? t : dflt;
-}
+// lanes per edge: Tuning::tg_count / tg_keys / tg_sample (4|8|16|32|64); 8 measured best on C2
 
 constexpr int TK_MAX_BLOCKS = 4096;  // bounds the per-block min/max arrays
 
@@ -215,9 +208,9 @@ __global__ __launch_bounds__(256) void tri_count_kernel(const uint64_t* __restri
 }
 
 void launch_tri_count(const Graph& g, const uint64_t* mbits, const float* es, const float* smin, const uint32_t* ei,
-                      const uint32_t* ej, uint64_t E, uint32_t* tcnt, hipStream_t st) {
+                      const uint32_t* ej, uint64_t E, uint32_t* tcnt, const Tuning& tn, hipStream_t st) {
   if (E == 0) return;
-  const int tg = tune_tg("SC_TG_COUNT", 8);
+  const int tg = tn.tg_count;
   const uint64_t per = (uint64_t)(256 / tg) * EB;
   uint64_t nb = (E + per - 1) / per;
   if (nb > 4096) nb = 4096;
@@ -362,9 +355,9 @@ size_t tri_keys_blocks(uint64_t E, int tg) {
 void launch_tri_keys(const Graph& g, const uint64_t* mbits, const float* smin, const uint32_t* ebase,
                      const uint32_t* ei, const uint32_t* ej, const float* es, const uint64_t* toff, uint64_t E,
                      int rank_mode, uint32_t* wkey, uint2* kcol, uint32_t* blk_minmax, SelectState* s,
-                     uint64_t want, hipStream_t st) {
+                     uint64_t want, const Tuning& tn, hipStream_t st) {
   if (E == 0) return;
-  const int tg = tune_tg("SC_TG_KEYS", 8);
+  const int tg = tn.tg_keys;
   const int nb = (int)tri_keys_blocks(E, tg);
 #define SC_LAUNCH_KEYS(TGV) hipLaunchKernelGGL(tri_keys_kernel<TGV>, dim3(nb), dim3(256), 0, st, g.bits, mbits, smin, g.W, g.deg, g.wpre, ebase, ei, ej, es, toff, E, rank_mode, wkey, kcol, blk_minmax, blk_minmax + TK_MAX_BLOCKS)
   if (tg == 4) SC_LAUNCH_KEYS(4); else if (tg == 8) SC_LAUNCH_KEYS(8); else if (tg == 32) SC_LAUNCH_KEYS(32); else if (tg == 64) SC_LAUNCH_KEYS(64); else SC_LAUNCH_KEYS(16);
@@ -618,7 +611,7 @@ EventList event_list(void* buf, uint64_t capacity, int W, uint32_t* fill, uint32
 
 void launch_tri_count_events(const Graph& g, const uint64_t* mbits, const StrongList& sl, const uint32_t* ebi,
                              const uint32_t* ebj, const uint32_t* ei, const uint32_t* ej, uint64_t E, int rank_mode,
-                             uint32_t* tcnt, const EventList& ev, hipStream_t st) {
+                             uint32_t* tcnt, const EventList& ev, const Tuning& tn, hipStream_t st) {
   if (E == 0) return;
   constexpr int TGV = 8;
   const uint64_t per = 256 / TGV;
@@ -626,7 +619,7 @@ void launch_tri_count_events(const Graph& g, const uint64_t* mbits, const Strong
   uint64_t nb = (E / 3 + per - 1) / per;
   if (nb < 256) nb = 256;
   if (nb > 4096) nb = 4096;
-  if (const char* v = getenv("SC_CNT_BLOCKS")) { const uint64_t t = (uint64_t)atoll(v); if (t >= 1 && t <= 65535) nb = t; }
+  if (tn.cnt_blocks >= 1 && tn.cnt_blocks <= 65535) nb = tn.cnt_blocks;
   hipLaunchKernelGGL(tri_count_events_kernel<TGV>, dim3((unsigned)nb), dim3(256), 0, st, mbits, g.W, g.deg, ebi, ebj, ei,
                      ej, sl, rank_mode, tcnt, ev);
 }
@@ -634,9 +627,9 @@ void launch_tri_count_events(const Graph& g, const uint64_t* mbits, const Strong
 void launch_tri_keys_events(const Graph& g, const float* es, const uint64_t* toff, int rank_mode,
                             const EventList& ev, uint32_t* wkey, uint2* kcol, uint32_t* blk_minmax,
                             SelectState* s, uint64_t want, const uint32_t* klb, uint64_t E, uint64_t cap,
-                            hipStream_t st) {
+                            const Tuning& tn, hipStream_t st) {
   int nb = 2048;
-  if (const char* v = getenv("SC_KEYS_BLOCKS")) { const int t = atoi(v); if (t >= 1 && t <= TK_MAX_BLOCKS) nb = t; }
+  if (tn.keys_blocks >= 1 && tn.keys_blocks <= (uint32_t)TK_MAX_BLOCKS) nb = (int)tn.keys_blocks;
   hipLaunchKernelGGL(tri_keys_events_kernel, dim3(nb), dim3(256), 0, st, g.bits, g.wpre, g.deg, es, toff, rank_mode,
                      ev, wkey, kcol, blk_minmax, blk_minmax + TK_MAX_BLOCKS, klb ? s : (SelectState*)nullptr, klb, want, E, cap);
   if (!klb)  // no a-priori window: the key range comes from the per-block extremes
@@ -825,22 +818,22 @@ static void prune_window(float key_floor, uint32_t* klo_out, uint32_t* shift_out
 
 void launch_sample_hist(const Graph& g, const uint32_t* ebi, const uint32_t* ebj, const uint32_t* ei,
                         const uint32_t* ej, const float* es, uint64_t E, uint64_t want, float key_floor, uint32_t part,
-                        uint32_t parts, uint32_t* hist, hipStream_t st) {
+                        uint32_t parts, uint32_t* hist, const Tuning& tn, hipStream_t st) {
   uint32_t klo, shift;
   prune_window(key_floor, &klo, &shift);
   // every R-th edge.  The sample must grow with T: the bound is the T-th largest SAMPLED key, so a small sample of a
   // large T certifies little.  ~5T/8 sampled edges (>= 32k) is the sweet spot on C2 for T = 50k ... 400k (swept again
-  // at the end of round 1); SC_SAMPLE_EDGES overrides (tuning knob).
+  // at the end of round 1); Tuning::sample_edges overrides.
   uint64_t target = want * 5 / 8;
   if (target < 32768) target = 32768;
-  if (getenv("SC_SAMPLE_EDGES")) target = (uint64_t)atoll(getenv("SC_SAMPLE_EDGES"));
+  if (tn.sample_edges) target = tn.sample_edges;
   uint64_t stride = E / (target ? target : 1);
   if (stride < 1) stride = 1;
   if (stride > 64) stride = 64;
   const uint64_t n_s = (E + stride - 1) / stride;
   const uint64_t n_loc = n_s > part ? (n_s - part + parts - 1) / parts : 0;
   if (n_loc == 0) return;
-  const int tg = tune_tg("SC_TG_SAMPLE", 8);
+  const int tg = tn.tg_sample;
   uint64_t nb = (n_loc + (256 / tg) - 1) / (256 / tg);
   // about one sampled edge per group (measured: 256 blocks 70 us, 1024+ blocks 35 us on C2)
   if (nb > 4096) nb = 4096;
@@ -1004,12 +997,12 @@ __global__ __launch_bounds__(SEL_THREADS) void select_round_kernel(const uint32_
   }
 }
 
-void launch_select_rounds(const uint32_t* wkey, uint64_t M, SelectState* s, int rounds, hipStream_t st) {
+void launch_select_rounds(const uint32_t* wkey, uint64_t M, SelectState* s, int rounds, const Tuning& tn, hipStream_t st) {
   if (M == 0) return;
   uint64_t blocks = (M + (uint64_t)SEL_THREADS * SEL_ITEMS - 1) / ((uint64_t)SEL_THREADS * SEL_ITEMS);
   // 256 blocks measured best on C2 (1.5 M keys): every block pays an agent-scope release for its ticket
   uint64_t cap = 256;
-  if (const char* v = getenv("SC_SEL_BLOCKS")) { const uint64_t t = (uint64_t)atoll(v); if (t >= 1) cap = t; }
+  if (tn.sel_blocks >= 1) cap = tn.sel_blocks;
   if (blocks > cap) blocks = cap;
   if (blocks == 0) blocks = 1;
   for (int round = 0; round < rounds; round++)

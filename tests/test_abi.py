@@ -49,6 +49,26 @@ def test_struct_layouts_match(pkg):
     assert int(a) == C.sizeof(pkg.ScParams) and int(b) == C.sizeof(pkg.ScStats)
 
 
+def test_product_reads_no_environment(pkg):
+    """SURVEY §5 "config / flags: one POD sc_params; no env vars": no getenv in the product sources, none imported by
+    the shared library; the knobs the tests drive go through sc_set_debug, whose struct layout is checked here."""
+    pk = os.path.join(ROOT, "sac-cot_amd", "csrc")
+    for f in os.listdir(pk):
+        if f.endswith((".hip", ".hpp", ".cpp", ".h")):
+            assert "getenv" not in open(os.path.join(pk, f)).read(), f
+    und = subprocess.check_output(["nm", "-D", "--undefined-only", pkg.api.LIB_PATH]).decode()
+    assert "getenv" not in und
+    exe = os.path.join(ROOT, "tests", ".abi_probe_dbg")
+    src = '#include <stdio.h>\n#include <stddef.h>\n#include "saccot.h"\nint main(void){printf("%zu %zu %zu", sizeof(sc_debug), offsetof(sc_debug, sample_edges), offsetof(sc_debug, compat_rows));return 0;}\n'
+    subprocess.run(["gcc", "-I", os.path.join(ROOT, "include"), "-x", "c", "-", "-o", exe], input=src.encode(), check=True)
+    try:
+        a, b, c = (int(x) for x in subprocess.check_output([exe]).decode().split())
+    finally:
+        os.remove(exe)
+    D = pkg.api.ScDebug
+    assert (a, b, c) == (C.sizeof(D), D.sample_edges.offset, D.compat_rows.offset)
+
+
 def test_version_and_strerror(pkg):
     L = pkg.load_library()
     assert L.sc_version() >> 16 == 0

@@ -40,13 +40,10 @@ def test_compat_bit_exact(pkg, O, reg, n, seed):
 
 @pytest.mark.parametrize("one_phase,rows", [(False, "16"), (True, "16"), (False, "64")])
 @pytest.mark.parametrize("min_len_scale", [0.0, 1.0])
-def test_compat_both_interior_forms_bit_exact(pkg, O, one_phase, rows, min_len_scale, monkeypatch):
+def test_compat_both_interior_forms_bit_exact(pkg, O, one_phase, rows, min_len_scale):
     """Interior tiles of stage A run a conservative candidate test on squared lengths and the exact chain only on the
-    candidates (default), or the exact chain on every pair (SC_COMPAT_ONE_PHASE=1): both against the CPU restatement,
+    candidates (default), or the exact chain on every pair (sc_debug.compat_one_phase): both against the CPU restatement,
     with min_len = 0 (coincident-point candidates) and on a scene with exact duplicates and near-threshold pairs."""
-    if one_phase:
-        monkeypatch.setenv("SC_COMPAT_ONE_PHASE", "1")
-    monkeypatch.setenv("SC_COMPAT_ROWS", rows)  # 64-row tiles: the experimental variant of launch_compat
     sc = pkg.synth.make_scene(1500, 0.3, 1.0, 0.05, seed=77)
     src, tgt = sc.src.copy(), sc.tgt.copy()
     src[100:164] = src[36:100]; tgt[100:164] = tgt[36:100]        # exact duplicates: zero lengths, ties
@@ -54,6 +51,7 @@ def test_compat_both_interior_forms_bit_exact(pkg, O, one_phase, rows, min_len_s
     kw = dict(sigma=0.05, t_cmp=0.9, tau=0.05, min_len=0.05 * min_len_scale)
     r = pkg.Registrar(0)
     try:
+        r.set_debug(compat_one_phase=int(one_phase), compat_rows=int(rows))  # 64-row tiles: the experimental variant
         S1, b1, d1 = r.compat(src, tgt, pkg.make_params(**kw))
     finally:
         r.close()
@@ -64,12 +62,10 @@ def test_compat_both_interior_forms_bit_exact(pkg, O, one_phase, rows, min_len_s
 
 @pytest.mark.parametrize("one_phase", [False, True])
 @pytest.mark.parametrize("eps,scale", [(0.03, 1.0), (0.002, 40.0), (0.25, 0.01)])
-def test_compat_threshold_sweep_on_a_scaled_scene(pkg, O, eps, scale, one_phase, monkeypatch):
+def test_compat_threshold_sweep_on_a_scaled_scene(pkg, O, eps, scale, one_phase):
     """q = (1 + eps) p: the rigidity residual d = eps * |p_i - p_j| sweeps continuously through d_thr, so of the ~1.1 M
     pairs many sit within a few ulps of the threshold (and of min_len) — where the candidate test of the two-phase
     interior tiles has to err on the safe side.  Bit-exact S, bit rows and degrees against the CPU restatement."""
-    if one_phase:
-        monkeypatch.setenv("SC_COMPAT_ONE_PHASE", "1")
     rng = np.random.default_rng(7)
     src = (rng.random((1500, 3), dtype=np.float32) - np.float32(0.5)) * np.float32(scale)
     tgt = (src * np.float32(1.0 + eps)).astype(np.float32)
@@ -78,6 +74,7 @@ def test_compat_threshold_sweep_on_a_scaled_scene(pkg, O, eps, scale, one_phase,
     kw = dict(sigma=sigma, t_cmp=0.9, tau=sigma, min_len=0.3 * scale)
     r = pkg.Registrar(0)
     try:
+        r.set_debug(compat_one_phase=int(one_phase))
         S1, b1, d1 = r.compat(src, tgt, pkg.make_params(**kw))
     finally:
         r.close()
@@ -235,16 +232,16 @@ def test_certified_pruning_changes_nothing_but_the_work(pkg, reg, name):
         assert a["stats"]["tri_total"] < b["stats"]["tri_total"] // 5
 
 
-@pytest.mark.parametrize("knobs", [dict(SC_CNT_BLOCKS="37", SC_KEYS_BLOCKS="53", SC_SEL_BLOCKS="7", SC_SAMPLE_EDGES="5000"),
-                                   dict(SC_CNT_BLOCKS="4096", SC_KEYS_BLOCKS="1", SC_SEL_BLOCKS="1", SC_SAMPLE_EDGES="1000000",
-                                        SC_TG_SAMPLE="32")])
-def test_results_do_not_depend_on_grid_or_sample_size(pkg, O, monkeypatch, knobs):
+@pytest.mark.parametrize("knobs", [dict(cnt_blocks=37, keys_blocks=53, sel_blocks=7, sample_edges=5000),
+                                   dict(cnt_blocks=4096, keys_blocks=1, sel_blocks=1, sample_edges=1000000, tg_sample=32),
+                                   dict(no_events=1, tg_count=4, tg_keys=64, sel_blocks=3)])
+def test_results_do_not_depend_on_grid_or_sample_size(pkg, O, knobs):
     """Stage B's launch geometry and the size of the pruning sample only change the amount of work (a looser or tighter
-    certified bound, more or fewer workgroups) — never the result: odd values for every scheduling knob on C1 and C2."""
-    for k, v in knobs.items():
-        monkeypatch.setenv(k, v)
+    certified bound, more or fewer workgroups) — never the result: odd values for every scheduling knob on C1 and C2,
+    set through sc_set_debug (the library reads no environment variable)."""
     r = pkg.Registrar(0)
     try:
+        r.set_debug(**knobs)
         for name in ("C1", "C2"):
             cfg, scene = pkg.synth.make_config_scene(name)
             kw = cfg.params()
@@ -259,13 +256,12 @@ def test_results_do_not_depend_on_grid_or_sample_size(pkg, O, monkeypatch, knobs
         r.close()
 
 
-def test_large_input_fallbacks_forced_on_a_small_one(pkg, O, monkeypatch):
+def test_large_input_fallbacks_forced_on_a_small_one(pkg, O):
     """Two paths only very large inputs reach — the three-kernel scan (beyond 16.7 M elements) and the scanned
-    compaction offsets (beyond 4096 key tiles) — forced by their test knobs on C1 / C2 and checked like any other run."""
-    monkeypatch.setenv("SC_SCAN_SELF_MAX", "0")
-    monkeypatch.setenv("SC_COMPACT_SELF_MAX", "0")
+    compaction offsets (beyond 4096 key tiles) — forced by their sc_debug knobs on C1 / C2 and checked like any other run."""
     r = pkg.Registrar(0)
     try:
+        r.set_debug(scan_self_max=0, compact_self_max=0)
         for name in ("C1", "C2"):
             cfg, scene = pkg.synth.make_config_scene(name)
             _check_register(pkg, O, r, scene, cfg.params())
@@ -445,6 +441,39 @@ def test_split_phase1_without_pruning_and_gathered_finalize(pkg, reg, name, extr
     assert np.array_equal(d_Rt.cpu().numpy(), np.array([1, 0, 0, 0, 1, 0, 0, 0, 1, 0, 0, 0], np.float32))
 
 
+def test_finalize_rejects_a_pair_outside_the_selection(pkg, reg):
+    """The key pairs of phase 2 come from the caller (an all-gather).  A pair whose position lies outside the selected
+    list — a stale or uninitialised buffer, ranks that disagree on T — must not be used as an index on the device: the
+    call returns SC_EINVAL with identity / zero mask, and the context stays usable."""
+    import torch
+    cfg, scene = pkg.synth.make_config_scene("C0")
+    kw = cfg.params()
+    base = reg.register(scene.src, scene.tgt, **kw)
+    dev = torch.device("cuda:0")
+    d_src = torch.from_numpy(scene.src).to(dev); d_tgt = torch.from_numpy(scene.tgt).to(dev)
+    d_key = torch.zeros(2, dtype=torch.int64, device=dev)
+    d_Rt = torch.zeros(12, dtype=torch.float32, device=dev); d_mask = torch.ones(cfg.n, dtype=torch.uint8, device=dev)
+    torch.cuda.synchronize()
+    p = pkg.make_params(**kw)
+    reg.hypothesize_device(d_src.data_ptr(), d_tgt.data_ptr(), cfg.n, p, d_key.data_ptr())
+    torch.cuda.synchronize()
+    good = [int(x) for x in d_key.cpu()]
+    T_eff = base["stats"]["tri_kept"]
+    for pos in (T_eff, T_eff + 12345, 0xFFFFFFFF):                      # first position outside, far outside, maximal
+        bad = [good[0] + (1 << 40), 0xFFFFFFFF - pos]                   # more inliers than anyone: it wins the reduction
+        d_all = torch.tensor(good + bad, dtype=torch.int64).to(dev); torch.cuda.synchronize()
+        with pytest.raises(pkg.SacCotError) as e:
+            reg.finalize_gathered_device(d_all.data_ptr(), 2, d_Rt.data_ptr(), d_mask.data_ptr())
+        assert e.value.status == pkg.SC_EINVAL
+        torch.cuda.synchronize()
+        assert int(d_mask.sum()) == 0
+        assert np.array_equal(d_Rt.cpu().numpy(), np.array([1, 0, 0, 0, 1, 0, 0, 0, 1, 0, 0, 0], np.float32))
+    d_all = torch.tensor(good + [0, 0], dtype=torch.int64).to(dev); torch.cuda.synchronize()
+    rc, st = reg.finalize_gathered_device(d_all.data_ptr(), 2, d_Rt.data_ptr(), d_mask.data_ptr())
+    torch.cuda.synchronize()
+    assert rc == 0 and np.array_equal(d_mask.cpu().numpy(), base["mask"])
+
+
 def test_caller_stream_orders_torch_work_with_the_kernels(pkg):
     """sc_set_stream: on torch's current stream (the default stream, which torch reports as 0 and api.py maps to
     SC_STREAM_DEFAULT, and a side stream) torch's own work on that stream is ordered with the library's kernels: the
@@ -513,10 +542,11 @@ def test_rigid_motion_invariance_of_graph(pkg, reg):
 # the matrix-pipe variant of C2 and the big configs
 # ---------------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("split", ["256", "96"])
-def test_score_mfma_variant_bit_exact(pkg, O, reg, split, monkeypatch):
+def test_score_mfma_variant_bit_exact(pkg, O, split):
     """the f32-MFMA scoring body (v_mfma_f32_16x16x4_f32, C = -q) must count exactly like the VALU
-    body.  SC_SCORE_SPLIT (read at every launch) sends that share (of 256) of the hypotheses to MFMA workgroups."""
-    monkeypatch.setenv("SC_SCORE_SPLIT", split)
+    body.  sc_debug.score_split sends that share (of 256) of the hypotheses to MFMA workgroups."""
+    reg = pkg.Registrar(0)
+    reg.set_debug(score_split=int(split))
     n, T = 1300, 5000
     sc = _scene(pkg, n, seed=91)
     rng = np.random.default_rng(91)
@@ -531,6 +561,7 @@ def test_score_mfma_variant_bit_exact(pkg, O, reg, split, monkeypatch):
     assert np.array_equal(cnt, cnt0) and key == O.best_key(cnt0)
     cfg, scene = pkg.synth.make_config_scene("C1")
     _check_register(pkg, O, reg, scene, cfg.params())
+    reg.close()
 
 
 def test_register_C4_half_a_million_hypotheses(pkg, O, reg):
@@ -551,17 +582,16 @@ def test_register_C3_twenty_thousand_correspondences(pkg, O, reg):
     assert (m & scene.inlier).sum() >= 0.95 * scene.inlier.sum()
 
 
-def test_event_buffer_overflow_falls_back_to_row_walk(pkg, O, monkeypatch):
+def test_event_buffer_overflow_falls_back_to_row_walk(pkg, O):
     """Stage B's event list has a fixed capacity per call; when a region overflows, the call must fall back to the
-    row-walking key kernel (and grow the buffer for next time) with identical results.  SC_EVENT_CAP forces a buffer
-    far too small for C1/C2; SC_NO_EVENTS=1 disables the event path altogether."""
+    row-walking key kernel (and grow the buffer for next time) with identical results.  sc_debug.event_cap forces a
+    buffer far too small for C1/C2; sc_debug.no_events disables the event path altogether."""
     cfg, scene = pkg.synth.make_config_scene("C2")
     ref = O.register(scene.src, scene.tgt, threads=8, **cfg.params())
-    for env in ({"SC_EVENT_CAP": "4096"}, {"SC_NO_EVENTS": "1"}):
-        for k, v in env.items():
-            monkeypatch.setenv(k, v)
+    for knobs in (dict(event_cap=4096), dict(no_events=1)):
         r = pkg.Registrar(0)   # fresh context: default capacities
         try:
+            r.set_debug(**knobs)
             for _ in range(2):  # second call runs with the capacity the first one asked for (knob still forces it small)
                 got = r.register(scene.src, scene.tgt, flags=pkg.SC_FLAG_EXACT_TOTAL, **cfg.params())
                 assert got["status"] == 0 and got["stats"]["best_rank"] == ref["best_rank"]
@@ -569,8 +599,6 @@ def test_event_buffer_overflow_falls_back_to_row_walk(pkg, O, monkeypatch):
                 assert got["stats"]["tri_total"] == ref["tri_total"]
         finally:
             r.close()
-        for k in env:
-            monkeypatch.delenv(k)
 
 
 @pytest.mark.parametrize("name", ["C0", "C1", "C2"])
