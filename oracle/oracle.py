@@ -34,7 +34,7 @@ def lib() -> C.CDLL:
         L.so_expf.argtypes = [C.c_float]
         L.so_expf.restype = C.c_float
         L.so_compat.argtypes = [f32p, f32p, C.c_int64, C.c_float, C.c_float, C.c_float, f32p, u64p, u32p, C.c_int]
-        L.so_triangles.argtypes = [f32p, u64p, u32p, C.c_int64, C.c_int, C.c_uint32, u32p, u32p, u32p, u64p]
+        L.so_triangles.argtypes = [f32p, u64p, u32p, C.c_int64, C.c_int, C.c_uint32, u32p, u32p, u32p, u64p, C.c_int]
         L.so_kabsch3.argtypes = [f32p, f32p, C.c_int64, u32p, C.c_uint32, f32p, C.c_int]
         L.so_kabsch3.restype = None
         L.so_score.argtypes = [f32p, f32p, C.c_int64, f32p, C.c_uint32, C.c_float, u32p, C.c_int]
@@ -92,7 +92,7 @@ def compat(src: np.ndarray, tgt: np.ndarray, sigma: float, t_cmp: float, min_len
     return S, bits, deg
 
 
-def triangles(S: np.ndarray | None, bits: np.ndarray, deg: np.ndarray, T: int, rank_mode: int = 0):
+def triangles(S: np.ndarray | None, bits: np.ndarray, deg: np.ndarray, T: int, rank_mode: int = 0, threads: int = 1):
     """Stage B.  Returns tri (t_eff,3) u32, key (t_eff,) u32, tri_total."""
     n = bits.shape[0]
     tri = np.zeros((max(T, 1), 3), dtype=np.uint32)
@@ -100,7 +100,7 @@ def triangles(S: np.ndarray | None, bits: np.ndarray, deg: np.ndarray, T: int, r
     t_eff = C.c_uint32(0)
     total = C.c_uint64(0)
     rc = lib().so_triangles(_p(S, C.c_float), _p(bits, C.c_uint64), _p(deg, C.c_uint32), n, rank_mode, T,
-                            _p(tri, C.c_uint32), _p(key, C.c_uint32), C.byref(t_eff), C.byref(total))
+                            _p(tri, C.c_uint32), _p(key, C.c_uint32), C.byref(t_eff), C.byref(total), threads)
     if rc != 0:
         raise RuntimeError(f"so_triangles rc={rc}")
     return tri[: t_eff.value].copy(), key[: t_eff.value].copy(), int(total.value)

@@ -111,9 +111,10 @@ int so_compat(const float* src, const float* tgt, int64_t n, float d_thr, float 
  * Enumerates every i<j<k with the three edges present, key = fp32 bits of w = (s_ij + s_ik) + s_jk
  * (rank_mode 0; w > 0 so the bit pattern orders like the value) or deg_i + deg_j + deg_k (rank_mode 1),
  * and returns the top-T under the total order (key desc, then i asc, j asc, k asc).
- * Selection is done by value (two-level counting select on the key), then one ordered re-enumeration,
- * then a sort of the T survivors with the full comparator — deliberately a different mechanism from
- * the GPU's ordinal-indexed radix select.
+ * Selection is done by value (two-level counting select on the key), then per-row survivor counts and one
+ * re-enumeration that writes every row's survivors at its prefix, then a sort of the T survivors with the full
+ * comparator — deliberately a different mechanism from the GPU's ordinal-indexed radix select.  Every
+ * enumeration pass runs over the rows in parallel (OpenMP); results do not depend on the thread count.
  * ---------------------------------------------------------------------------------------------- */
 typedef struct { uint32_t key, i, j, k; } so_tri;
 
@@ -133,82 +134,150 @@ static inline uint32_t tri_key(const float* S, const uint32_t* deg, int64_t n, i
   return as_u32(w);
 }
 
-/* calls f(ctx, key, i, j, k) for every triangle in lexicographic (i,j,k) order */
+/* calls f(ctx, key, i, j, k) for every triangle of ROW i (i < j < k) in lexicographic (j,k) order */
 typedef void (*tri_fn)(void* ctx, uint32_t key, uint32_t i, uint32_t j, uint32_t k);
-static void for_each_triangle(const float* S, const uint64_t* bits, const uint32_t* deg, int64_t n,
-                              int rank_mode, tri_fn f, void* ctx) {
+static void for_row_triangles(const float* S, const uint64_t* bits, const uint32_t* deg, int64_t n,
+                              int rank_mode, int64_t i, tri_fn f, void* ctx) {
   const int64_t W = (n + 63) / 64;
-  for (int64_t i = 0; i < n; i++) {
-    const uint64_t* bi = bits + i * W;
-    for (int64_t wj = i >> 6; wj < W; wj++) {
-      uint64_t mj = bi[wj];
-      if (wj == (i >> 6)) mj &= ((i & 63) == 63) ? 0 : (~(uint64_t)0 << ((i & 63) + 1));
-      while (mj) {
-        int64_t j = wj * 64 + __builtin_ctzll(mj);
-        mj &= mj - 1;
-        const uint64_t* bj = bits + j * W;
-        for (int64_t wk = j >> 6; wk < W; wk++) {
-          uint64_t mk = bi[wk] & bj[wk];
-          if (wk == (j >> 6)) mk &= ((j & 63) == 63) ? 0 : (~(uint64_t)0 << ((j & 63) + 1));
-          while (mk) {
-            int64_t k = wk * 64 + __builtin_ctzll(mk);
-            mk &= mk - 1;
-            f(ctx, tri_key(S, deg, n, rank_mode, i, j, k), (uint32_t)i, (uint32_t)j, (uint32_t)k);
-          }
+  const uint64_t* bi = bits + i * W;
+  for (int64_t wj = i >> 6; wj < W; wj++) {
+    uint64_t mj = bi[wj];
+    if (wj == (i >> 6)) mj &= ((i & 63) == 63) ? 0 : (~(uint64_t)0 << ((i & 63) + 1));
+    while (mj) {
+      int64_t j = wj * 64 + __builtin_ctzll(mj);
+      mj &= mj - 1;
+      const uint64_t* bj = bits + j * W;
+      for (int64_t wk = j >> 6; wk < W; wk++) {
+        uint64_t mk = bi[wk] & bj[wk];
+        if (wk == (j >> 6)) mk &= ((j & 63) == 63) ? 0 : (~(uint64_t)0 << ((j & 63) + 1));
+        while (mk) {
+          int64_t k = wk * 64 + __builtin_ctzll(mk);
+          mk &= mk - 1;
+          f(ctx, tri_key(S, deg, n, rank_mode, i, j, k), (uint32_t)i, (uint32_t)j, (uint32_t)k);
         }
       }
     }
   }
 }
 
+/* Pass kinds.  Rows are independent, so every pass runs over the rows in parallel (OpenMP, dynamic schedule: low rows
+ * hold more triangles); what is merged afterwards — histogram sums, per-row counts — does not depend on the thread
+ * count or on which thread took which row, so the result is identical for any n_threads. */
 typedef struct { uint64_t* hist; uint32_t prefix; int pass; uint64_t total; } hist_ctx;
 static void hist_cb(void* c, uint32_t key, uint32_t i, uint32_t j, uint32_t k) {
   hist_ctx* h = (hist_ctx*)c; (void)i; (void)j; (void)k;
   if (h->pass == 0) { h->hist[key >> 16]++; h->total++; }
   else if ((key >> 16) == h->prefix) h->hist[key & 0xFFFF]++;
 }
-typedef struct { so_tri* out; uint64_t n_out, cap; uint32_t kstar; uint64_t need_eq, got_eq; } emit_ctx;
+typedef struct { uint32_t kstar; uint64_t gt, eq; } count_ctx;
+static void count_cb(void* c, uint32_t key, uint32_t i, uint32_t j, uint32_t k) {
+  count_ctx* q = (count_ctx*)c; (void)i; (void)j; (void)k;
+  q->gt += key > q->kstar; q->eq += key == q->kstar;
+}
+/* eq_left: how many triangles with key == kstar this row may still take (the ties go to the lowest (i,j,k)) */
+typedef struct { so_tri* out; uint32_t kstar; uint64_t eq_left; } emit_ctx;
 static void emit_cb(void* c, uint32_t key, uint32_t i, uint32_t j, uint32_t k) {
   emit_ctx* e = (emit_ctx*)c;
   int take = 0;
   if (key > e->kstar) take = 1;
-  else if (key == e->kstar && e->got_eq < e->need_eq) { take = 1; e->got_eq++; }
-  if (take && e->n_out < e->cap) { so_tri t = {key, i, j, k}; e->out[e->n_out++] = t; }
+  else if (key == e->kstar && e->eq_left > 0) { take = 1; e->eq_left--; }
+  if (take) { so_tri t = {key, i, j, k}; *e->out++ = t; }
+}
+
+/* one histogram pass over all rows; returns the number of triangles seen (pass 0) */
+static int hist_pass(const float* S, const uint64_t* bits, const uint32_t* deg, int64_t n, int rank_mode, int pass,
+                     uint32_t prefix, uint64_t* hist, uint64_t* total, int n_threads) {
+  int nt = n_threads > 0 ? n_threads : 1;
+  uint64_t* th = (uint64_t*)calloc((size_t)nt * 65536, 8);
+  uint64_t* tt = (uint64_t*)calloc((size_t)nt, 8);
+  if (!th || !tt) { free(th); free(tt); return SO_ENOMEM; }
+#ifdef _OPENMP
+#pragma omp parallel num_threads(nt)
+#endif
+  {
+#ifdef _OPENMP
+    const int me = omp_get_thread_num();
+#else
+    const int me = 0;
+#endif
+    hist_ctx h = {th + (size_t)me * 65536, prefix, pass, 0};
+#ifdef _OPENMP
+#pragma omp for schedule(dynamic, 4)
+#endif
+    for (int64_t i = 0; i < n; i++) for_row_triangles(S, bits, deg, n, rank_mode, i, hist_cb, &h);
+    tt[me] = h.total;
+  }
+  memset(hist, 0, 65536 * 8);
+  uint64_t tot = 0;
+  for (int t = 0; t < nt; t++) {
+    tot += tt[t];
+    for (int b = 0; b < 65536; b++) hist[b] += th[(size_t)t * 65536 + b];
+  }
+  if (total) *total = tot;
+  free(th); free(tt);
+  return SO_OK;
 }
 
 /* tri: T*3 u32, key: T u32; *t_eff = number written; returns SO_OK; *tri_total = number of 3-cliques */
 int so_triangles(const float* S, const uint64_t* bits, const uint32_t* deg, int64_t n, int rank_mode,
-                 uint32_t T, uint32_t* tri, uint32_t* key, uint32_t* t_eff, uint64_t* tri_total) {
+                 uint32_t T, uint32_t* tri, uint32_t* key, uint32_t* t_eff, uint64_t* tri_total, int n_threads) {
   if (n < 3 || (rank_mode == 0 && !S) || (rank_mode == 1 && !deg) || !bits) return SO_EINVAL;
+  const int nt = n_threads > 0 ? n_threads : 1;
   uint64_t* hist = (uint64_t*)calloc(65536, 8);
   if (!hist) return SO_ENOMEM;
-  hist_ctx h = {hist, 0, 0, 0};
-  for_each_triangle(S, bits, deg, n, rank_mode, hist_cb, &h);
-  if (tri_total) *tri_total = h.total;
-  uint64_t want = T < h.total ? T : h.total;
+  uint64_t total = 0;
+  int rc = hist_pass(S, bits, deg, n, rank_mode, 0, 0, hist, &total, nt);
+  if (rc) { free(hist); return rc; }
+  if (tri_total) *tri_total = total;
+  uint64_t want = T < total ? T : total;
   *t_eff = (uint32_t)want;
   if (want == 0) { free(hist); return SO_OK; }
   /* level 1: high 16 bits */
   uint64_t above = 0; int32_t b = 65535;
   for (; b >= 0; b--) { if (above + hist[b] >= want) break; above += hist[b]; }
   uint32_t hi = (uint32_t)b;
-  memset(hist, 0, 65536 * 8);
-  h.pass = 1; h.prefix = hi;
-  for_each_triangle(S, bits, deg, n, rank_mode, hist_cb, &h);
+  rc = hist_pass(S, bits, deg, n, rank_mode, 1, hi, hist, NULL, nt);
+  if (rc) { free(hist); return rc; }
   for (b = 65535; b >= 0; b--) { if (above + hist[b] >= want) break; above += hist[b]; }
   uint32_t kstar = (hi << 16) | (uint32_t)b;
   free(hist);
+  const uint64_t need_eq = want - above;
+  /* per-row counts of keys above / equal to kstar, then their prefixes in row order: row i writes its survivors at
+   * gt_before + min(eq_before, need_eq) and may take need_eq - eq_before ties (lowest (i,j,k) first) */
+  uint64_t* rgt = (uint64_t*)malloc((size_t)(n + 1) * 8);
+  uint64_t* req = (uint64_t*)malloc((size_t)(n + 1) * 8);
   so_tri* buf = (so_tri*)malloc((size_t)want * sizeof(so_tri));
-  if (!buf) return SO_ENOMEM;
-  emit_ctx e = {buf, 0, want, kstar, want - above, 0};
-  for_each_triangle(S, bits, deg, n, rank_mode, emit_cb, &e);
-  qsort(buf, (size_t)e.n_out, sizeof(so_tri), tri_cmp);
-  for (uint64_t t = 0; t < e.n_out; t++) {
-    tri[3 * t] = buf[t].i; tri[3 * t + 1] = buf[t].j; tri[3 * t + 2] = buf[t].k;
-    if (key) key[t] = buf[t].key;
+  if (!rgt || !req || !buf) { free(rgt); free(req); free(buf); return SO_ENOMEM; }
+#ifdef _OPENMP
+#pragma omp parallel for schedule(dynamic, 4) num_threads(nt)
+#endif
+  for (int64_t i = 0; i < n; i++) {
+    count_ctx q = {kstar, 0, 0};
+    for_row_triangles(S, bits, deg, n, rank_mode, i, count_cb, &q);
+    rgt[i] = q.gt; req[i] = q.eq;
   }
-  free(buf);
-  return e.n_out == want ? SO_OK : SO_EINVAL;
+  uint64_t g = 0, q = 0;
+  for (int64_t i = 0; i < n; i++) { uint64_t a = rgt[i], c = req[i]; rgt[i] = g; req[i] = q; g += a; q += c; }
+  rgt[n] = g; req[n] = q;
+  rc = (g == above && q >= need_eq) ? SO_OK : SO_EINVAL;
+  if (rc == SO_OK) {
+#ifdef _OPENMP
+#pragma omp parallel for schedule(dynamic, 4) num_threads(nt)
+#endif
+    for (int64_t i = 0; i < n; i++) {
+      const uint64_t eqb = req[i] < need_eq ? req[i] : need_eq;
+      if (rgt[i + 1] == rgt[i] && (req[i + 1] == req[i] || req[i] >= need_eq)) continue; /* nothing to emit */
+      emit_ctx e = {buf + rgt[i] + eqb, kstar, need_eq - eqb};
+      for_row_triangles(S, bits, deg, n, rank_mode, i, emit_cb, &e);
+    }
+    qsort(buf, (size_t)want, sizeof(so_tri), tri_cmp);
+    for (uint64_t t = 0; t < want; t++) {
+      tri[3 * t] = buf[t].i; tri[3 * t + 1] = buf[t].j; tri[3 * t + 2] = buf[t].k;
+      if (key) key[t] = buf[t].key;
+    }
+  }
+  free(rgt); free(req); free(buf);
+  return rc;
 }
 
 /* ------------------------------------------------------------------------------------------------
@@ -479,7 +548,7 @@ int so_register(const float* src, const float* tgt, int64_t n, float sigma, floa
   uint64_t edges = 0;
   for (int64_t i = 0; i < n; i++) edges += deg[i];
   uint32_t t_eff = 0; uint64_t tri_total = 0;
-  rc = so_triangles(S, bits, deg, n, rank_mode, T, tri, key, &t_eff, &tri_total);
+  rc = so_triangles(S, bits, deg, n, rank_mode, T, tri, key, &t_eff, &tri_total, n_threads);
   double t2 = now_s();
   if (rc) goto done;
   so_kabsch3(src, tgt, n, tri, t_eff, Rt, n_threads);

@@ -192,3 +192,57 @@ def test_refine_against_lapack(pkg, O):
     assert pkg.synth.rotation_error_deg(Rt[:9].reshape(3, 3), sc.R_gt) < pkg.synth.rotation_error_deg(r["R"], sc.R_gt)
     none, Rt_same = O.refine(sc.src, sc.tgt, np.zeros(cfg.n, np.uint8), np.arange(12, dtype=np.float32))
     assert not none and np.array_equal(Rt_same, np.arange(12, dtype=np.float32))     # < 3 inliers: untouched
+
+
+@pytest.mark.parametrize("rank_mode", [0, 1])
+def test_stage_b_is_thread_count_independent(pkg, O, rank_mode):
+    """Stage B of the restatement runs its enumeration passes over the rows in parallel (OpenMP); the merged
+    histograms / per-row prefixes must give the same ranked list for any thread count — incl. massive ties."""
+    for sc, tau, T in ((pkg.synth.make_scene(600, 0.3, 1.0, 0.05, 3), 0.05, 5000),
+                       (pkg.synth.make_scene(150, 1.0, 1.0, 1e-7, 21), 0.05, 3000)):       # all weights nearly equal
+        S, bits, deg = O.compat(sc.src, sc.tgt, tau, 0.9, tau, tau)
+        ref = O.triangles(S, bits, deg, T, rank_mode, threads=1)
+        for th in (2, 3, 8):
+            got = O.triangles(S, bits, deg, T, rank_mode, threads=th)
+            assert got[2] == ref[2] and np.array_equal(got[0], ref[0]) and np.array_equal(got[1], ref[1])
+
+
+def test_restatement_under_address_and_ub_sanitizers():
+    """the CPU restatement runs clean under -fsanitize=address,undefined (oracle/Makefile `asan`), on the
+    whole path for C0 with 1 and 4 threads and on the degenerate inputs, in a child process (the sanitizer runtime
+    has to be the first library loaded)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    subprocess.check_call(["make", "-C", os.path.join(root, "oracle"), "-s", "asan"])
+    libasan = subprocess.check_output(["gcc", "-print-file-name=libasan.so"]).decode().strip()
+    code = r'''
+import ctypes as C, os, sys
+import numpy as np
+sys.path.insert(0, %r)
+import __graft_entry__ as ge
+pkg = ge.load_package()
+from oracle import oracle as O
+O._LIB = None
+_build = O.build
+O.build = lambda: os.path.join(os.path.dirname(_build()), "libsaccot_oracle_asan.so")
+cfg, scene = pkg.synth.make_config_scene("C0")
+a = O.register(scene.src, scene.tgt, threads=1, **cfg.params())
+b = O.register(scene.src, scene.tgt, threads=4, **cfg.params())
+assert a["rc"] == b["rc"] == 0 and a["best_rank"] == b["best_rank"] and np.array_equal(a["mask"], b["mask"])
+kw = dict(cfg.params(), rank_mode=1, max_triangles=10**7)
+c = O.register(scene.src, scene.tgt, threads=4, **kw)          # T > number of triangles, degree ranking
+assert c["rc"] == 0 and c["t_eff"] == c["tri_total"]
+rng = np.random.default_rng(5)
+src = rng.uniform(-1, 1, (40, 3)).astype(np.float32)
+d = O.register(src, (src * 37).astype(np.float32), threads=2, **cfg.params())   # no edge at all
+assert d["rc"] == -5
+done, Rt = O.refine(scene.src, scene.tgt, a["mask"], np.concatenate([a["R"].ravel(), a["t"]]))
+assert done
+print("asan-ok")
+''' % root
+    env = dict(os.environ, LD_PRELOAD=libasan, ASAN_OPTIONS="detect_leaks=0:abort_on_error=1",
+               UBSAN_OPTIONS="halt_on_error=1:print_stacktrace=1")
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "asan-ok" in r.stdout, (r.stdout[-2000:], r.stderr[-4000:])
+    assert "runtime error" not in r.stderr and "AddressSanitizer" not in r.stderr, r.stderr[-4000:]
