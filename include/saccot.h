@@ -151,7 +151,7 @@ typedef struct sc_debug {
   uint32_t score_split;       /* share (of 256) of the hypotheses scored by the f32-MFMA body of C2 */
   uint32_t compat_one_phase;  /* 1: stage A runs the exact chain on every pair of an interior tile            */
   uint32_t compat_rows;       /* stage A tile height: 16 (default) or 64                                      */
-  uint32_t reserved;
+  uint32_t compat_store_mode; /* stage A stores of S: bit 0 = 4 bytes per lane (default 16), bit 1 = non-temporal */
 } sc_debug;
 int         sc_set_debug(sc_ctx* ctx, const sc_debug* dbg);
 

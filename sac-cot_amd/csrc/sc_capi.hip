@@ -165,14 +165,16 @@ int stage_inputs(sc_ctx* c, const float* d_src, const float* d_tgt, int64_t n, c
   return SC_OK;
 }
 
-int run_compat(sc_ctx* c) {
+// dense: also write the n x n weight matrix S (SC_FLAG_NO_DENSE_S clears it: nothing after stage A reads S)
+int run_compat(sc_ctx* c, bool dense) {
   const size_t n = c->n, ld = c->ld, W = ld >> 6;
-  ENSURE(c, c->S, n * ld * sizeof(float));
+  if (dense) ENSURE(c, c->S, n * ld * sizeof(float));
   ENSURE(c, c->bits, n * W * sizeof(uint64_t));
   ENSURE(c, c->deg, n * sizeof(uint32_t));
   ENSURE(c, c->degp, n * sizeof(uint32_t));
   ENSURE(c, c->wpre, n * W * sizeof(uint32_t));
-  launch_compat(points_of(c), c->dv, c->S.as<float>(), c->bits.as<uint64_t>(), c->tn, c->stream);
+  launch_compat(points_of(c), c->dv, dense ? c->S.as<float>() : nullptr, c->bits.as<uint64_t>(), 0, c->n, c->tn,
+                c->stream);
   return SC_OK;
 }
 
@@ -561,6 +563,7 @@ int sc_set_debug(sc_ctx* c, const sc_debug* d) {
   t.score_split = d->score_split;
   t.compat_one_phase = d->compat_one_phase != 0;
   t.compat_rows = d->compat_rows == 64 ? 64 : 16;
+  t.compat_store_mode = d->compat_store_mode & 3u;
   c->tn = t;
   return SC_OK;
 }
@@ -588,7 +591,7 @@ int hyp_begin(sc_ctx* c, const float* d_src, const float* d_tgt, int64_t n, cons
   if ((rc = rec(c, 0))) return rc;
   if ((rc = stage_inputs(c, d_src, d_tgt, n, p))) return rc;
   if ((rc = rec(c, 1))) return rc;
-  if ((rc = run_compat(c))) return rc;
+  if ((rc = run_compat(c, !(p->flags & SC_FLAG_NO_DENSE_S)))) return rc;
   if ((rc = rec(c, 2))) return rc;
   if ((rc = run_row_stats(c, may_prune(p)))) return rc;
   if ((rc = run_edges(c, p, d_hist, part, parts))) return rc;
@@ -762,8 +765,10 @@ int sc_compat_host(sc_ctx* c, const float* src, const float* tgt, int64_t n, con
   c->timing = c->timing_hot = false;
   c->cap_bytes = p->max_workspace ? p->max_workspace : (64ull << 30);
   c->dv = derive(p);
+  const bool dense = S != nullptr && !(p->flags & SC_FLAG_NO_DENSE_S);
+  if (S && !dense) { c->last_error = "sc_compat_host: S requested together with SC_FLAG_NO_DENSE_S"; return SC_EINVAL; }
   if ((rc = host_to_planes(c, src, tgt, n, p))) return rc;
-  if ((rc = run_compat(c))) return rc;
+  if ((rc = run_compat(c, dense))) return rc;
   if ((rc = run_row_stats(c, false))) return rc;
   if ((rc = check_flag(c))) return rc;
   const size_t W = (size_t)c->ld >> 6;
@@ -788,7 +793,7 @@ int sc_triangles_host(sc_ctx* c, const float* src, const float* tgt, int64_t n, 
   c->cap_bytes = p->max_workspace ? p->max_workspace : (64ull << 30);
   c->dv = derive(p);
   if ((rc = host_to_planes(c, src, tgt, n, p))) return rc;
-  if ((rc = run_compat(c))) return rc;
+  if ((rc = run_compat(c, false))) return rc;  // the ranked list needs the bit rows only
   if ((rc = run_row_stats(c, may_prune(p)))) return rc;
   sc_params pe = *p;
   pe.flags |= SC_FLAG_EXACT_TOTAL;  // the hook reports the 3-clique count of the whole graph

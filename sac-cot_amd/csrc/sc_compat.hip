@@ -71,25 +71,55 @@ __device__ __forceinline__ float bcast(float v, int src) {
 }
 
 
-// TILE_R rows per tile (16 or 32): 64 / TILE_R tiles stack into one 64-row block
-template <int TILE_R, int COMPAT_WAVES>
+// S stores: 16 bytes per lane by default (4 consecutive floats of one row piece: a quarter of the store instructions
+// and of the addresses the texture path has to process), optionally non-temporal (S is never read again on this
+// path: no reason to keep it in L2 / Infinity Cache).  `mode` bit 0: 4-byte stores (round 1's form, kept for A/B),
+// bit 1: non-temporal.
+typedef float f32x4s __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void store_s4(float* p, float a, float b, float c, float d, bool nt) {
+  const f32x4s v = {a, b, c, d};
+  if (nt) __builtin_nontemporal_store(v, reinterpret_cast<f32x4s*>(p));
+  else *reinterpret_cast<f32x4s*>(p) = v;
+}
+__device__ __forceinline__ void store_s1(float* p, float a, bool nt) {
+  if (nt) __builtin_nontemporal_store(a, p);
+  else *p = a;
+}
+
+// TILE_R rows per tile (16 or 64): 64 / TILE_R tiles stack into one 64-row block.
+// DENSE: write the weight matrix S (false: SC_FLAG_NO_DENSE_S — adjacency bits only, no LDS tile image, no S traffic).
+// RECT:  one-sided form for a ROW BLOCK [row0, row1) x all columns (stage A sharded by row blocks):
+//        every tile writes its direct half only — the mirrored half belongs to another rank — and S holds the rows
+//        of the block only (row i at S[(i - row0) * ld]).  Bit rows go to `bits` at their global row index.
+template <int TILE_R, int COMPAT_WAVES, bool DENSE, bool RECT>
 __global__ __launch_bounds__(64 * COMPAT_WAVES) void compat_tiles_kernel(const float* __restrict__ planes, int n,
                                                                          int ld, float d_thr, float min_len,
                                                                          float nis, float* __restrict__ S,
                                                                          uint64_t* __restrict__ bits, int n_tiles,
-                                                                         int two_phase) {
+                                                                         int two_phase, int row0, int row1,
+                                                                         int mode) {
   constexpr int TILE_PAD = TILE_R + 1;  // LDS row stride of the transposed tile: conflict-free both ways
   constexpr int SUB = 64 / TILE_R;      // tiles per 64-row block
-  __shared__ float tileT[COMPAT_WAVES][64 * TILE_PAD];  // [column][row] per wave
+  __shared__ float tileT[DENSE ? COMPAT_WAVES : 1][DENSE ? 64 * TILE_PAD : 1];  // [column][row] per wave
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int t = blockIdx.x * COMPAT_WAVES + wave;
   if (t >= n_tiles) return;  // whole wave; no block-level barrier is used below
   const int W = ld >> 6;
-  // tile t -> (column block J, row sub-block h):  t = SUB J (J + 1) / 2 + h,  0 <= h < SUB (J + 1)
-  int J = (int)((__builtin_sqrtf(8.0f * (float)(t / SUB) + 1.0f) - 1.0f) * 0.5f);
-  while (SUB * (J + 1) * (J + 2) / 2 <= t) J++;
-  while (SUB * J * (J + 1) / 2 > t) J--;
-  const int h = t - SUB * J * (J + 1) / 2;
+  const bool nt = (mode & 2) != 0, st4 = (mode & 1) != 0;
+  int J, h;
+  if (RECT) {
+    // column block fastest: consecutive waves write adjacent 256-byte pieces of the same rows
+    J = t % W;
+    h = t / W + row0 / TILE_R;  // row0 is a multiple of 64
+  } else {
+    // tile t -> (column block J, row sub-block h):  t = SUB J (J + 1) / 2 + h,  0 <= h < SUB (J + 1)
+    J = (int)((__builtin_sqrtf(8.0f * (float)(t / SUB) + 1.0f) - 1.0f) * 0.5f);
+    while (SUB * (J + 1) * (J + 2) / 2 <= t) J++;
+    while (SUB * J * (J + 1) / 2 > t) J--;
+    h = t - SUB * J * (J + 1) / 2;
+  }
+  const int rlim = RECT ? row1 : n;     // rows at or beyond it are not this launch's
+  const int srow = RECT ? row0 : 0;     // S row offset
   const int i0 = h * TILE_R;
   const int j = J * 64 + lane;
   const bool diag = (h / SUB) == J;
@@ -101,11 +131,11 @@ __global__ __launch_bounds__(64 * COMPAT_WAVES) void compat_tiles_kernel(const f
   const float* qz = planes + 5 * (size_t)ld;
   const float jpx = px[j], jpy = py[j], jpz = pz[j], jqx = qx[j], jqy = qy[j], jqz = qz[j];
   const int i0s = __builtin_amdgcn_readfirstlane(i0);  // provably wave-uniform row base
-  float* myT = tileT[wave];
+  float* myT = tileT[DENSE ? wave : 0];
   uint64_t rowword = 0;      // lane r: adjacency word of row i0 + r over this column block
   uint64_t colword = 0;      // lane c: bit r = edge (row i0 + r, column j)
   // Interior tiles (every row and column real, not on the diagonal) are ~97 % of the work.
-  const bool interior = !diag && (i0 + TILE_R <= n) && (J * 64 + 64 <= n);
+  const bool interior = !diag && (i0 + TILE_R <= rlim) && (J * 64 + 64 <= n);
   if (interior && two_phase) {
     // ---- two-phase form ----------------------------------------------------------------------------------
     // Only ~4 % of the pairs are edges, yet the exact chain (two correctly rounded square roots, the exponential)
@@ -133,9 +163,10 @@ __global__ __launch_bounds__(64 * COMPAT_WAVES) void compat_tiles_kernel(const f
     uint16_t* myQ = queue[wave];
     unsigned long long* myRB = rowbits[wave];
     unsigned long long* myCB = colbits[wave];
-    for (int k = lane; k < 64 * TILE_PAD; k += 64) myT[k] = 0.0f;
+    if (DENSE)
+      for (int k = lane; k < 64 * TILE_PAD; k += 64) myT[k] = 0.0f;
     if (lane < TILE_R) myRB[lane] = 0ull;
-    myCB[lane] = 0ull;
+    if (!RECT) myCB[lane] = 0ull;
     const RowPt* __restrict__ aos = reinterpret_cast<const RowPt*>(planes + 6 * (size_t)ld);
     // lane r (< TILE_R) keeps row point i0 + r in registers: phase 2 fetches both points of a candidate with
     // ds_bpermute (no memory latency in the drain — with ~1.5 tiles per wave slot the kernel's time is a wave's latency)
@@ -159,9 +190,9 @@ __global__ __launch_bounds__(64 * COMPAT_WAVES) void compat_tiles_kernel(const f
         bool edge;
         const float s = pair_weight(dp, dq, d_thr, min_len, nis, edge);
         if (valid && edge) {
-          myT[c * TILE_PAD + r] = s;
+          if (DENSE) myT[c * TILE_PAD + r] = s;
           atomicOr(&myRB[r], 1ull << c);
-          atomicOr(&myCB[c], 1ull << r);
+          if (!RECT) atomicOr(&myCB[c], 1ull << r);
         }
       }
       __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -195,17 +226,45 @@ __global__ __launch_bounds__(64 * COMPAT_WAVES) void compat_tiles_kernel(const f
     }
     if (cnt) drain();
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    // direct half: row i0 + r, one 256-byte store per row from the tile image ([column][row], stride TILE_PAD)
+    // direct half from the tile image ([column][row], stride TILE_PAD): 16 bytes per lane — lane (r', c4) stores four
+    // consecutive columns of row r' (four rows x 256 bytes per instruction; the LDS reads are conflict-free:
+    // bank = 4 (lane % 16) + 17 u + lane / 16) — or, mode bit 0, one 256-byte row per instruction with 4-byte stores
+    if (DENSE) {
+      if (!st4) {
+        const int c4 = (lane & 15) * 4, rr = lane >> 4;
 #pragma unroll 4
-    for (int r = 0; r < TILE_R; r++) S[(size_t)(i0 + r) * ld + j] = myT[lane * TILE_PAD + r];
+        for (int q = 0; q < TILE_R; q += 4) {
+          const int r = q + rr;
+          store_s4(&S[(size_t)(i0 - srow + r) * ld + J * 64 + c4], myT[c4 * TILE_PAD + r], myT[(c4 + 1) * TILE_PAD + r],
+                   myT[(c4 + 2) * TILE_PAD + r], myT[(c4 + 3) * TILE_PAD + r], nt);
+        }
+      } else {
+#pragma unroll 4
+        for (int r = 0; r < TILE_R; r++) store_s1(&S[(size_t)(i0 - srow + r) * ld + j], myT[lane * TILE_PAD + r], nt);
+      }
+    }
     if (lane < TILE_R) bits[(size_t)(i0 + lane) * W + J] = myRB[lane];
-    colword = myCB[lane];
-    {
-      const int r = lane & (TILE_R - 1), hi = lane / TILE_R;
+    if (!RECT) {
+      colword = myCB[lane];
+      if (DENSE) {
+        if (!st4) {
+          // mirrored half: row J*64 + cc of S, columns i0 .. i0 + TILE_R - 1; a row piece is TILE_R / 4 lanes x 16 bytes
+          constexpr int LP = TILE_R / 4, RPI = 64 / LP;  // lanes per piece, pieces (output rows) per instruction
+          const int r4 = (lane % LP) * 4, co = lane / LP;
 #pragma unroll 4
-      for (int c = 0; c < 64; c += SUB) {
-        const int cc = c + hi;
-        S[(size_t)(J * 64 + cc) * ld + i0 + r] = myT[cc * TILE_PAD + r];
+          for (int c = 0; c < 64; c += RPI) {
+            const int cc = c + co;
+            store_s4(&S[(size_t)(J * 64 + cc) * ld + i0 + r4], myT[cc * TILE_PAD + r4], myT[cc * TILE_PAD + r4 + 1],
+                     myT[cc * TILE_PAD + r4 + 2], myT[cc * TILE_PAD + r4 + 3], nt);
+          }
+        } else {
+          const int r = lane & (TILE_R - 1), hi = lane / TILE_R;
+#pragma unroll 4
+          for (int c = 0; c < 64; c += SUB) {
+            const int cc = c + hi;
+            store_s1(&S[(size_t)(J * 64 + cc) * ld + i0 + r], myT[cc * TILE_PAD + r], nt);
+          }
+        }
       }
       if (TILE_R == 64) bits[(size_t)j * W + (i0 >> 6)] = colword;
       else if (TILE_R == 32) reinterpret_cast<uint32_t*>(bits)[((size_t)j * W + (i0 >> 6)) * 2 + (h % SUB)] = (uint32_t)colword;
@@ -233,8 +292,8 @@ __global__ __launch_bounds__(64 * COMPAT_WAVES) void compat_tiles_kernel(const f
     bool ea = (da <= d_thr) && (dpa >= min_len) && (dqa >= min_len);
     bool eb = (db <= d_thr) && (dpb >= min_len) && (dqb >= min_len);
     if (G) {
-      ea = ea && (j != ia) && (j < n) && (ia < n);
-      eb = eb && (j != ib) && (j < n) && (ib < n);
+      ea = ea && (j != ia) && (j < n) && (ia < rlim);
+      eb = eb && (j != ib) && (j < n) && (ib < rlim);
     }
     const uint64_t worda = __ballot(ea), wordb = __ballot(eb);
     float sa = 0.0f, sb = 0.0f;
@@ -243,12 +302,16 @@ __global__ __launch_bounds__(64 * COMPAT_WAVES) void compat_tiles_kernel(const f
       sa = ea ? va : 0.0f;
       sb = eb ? vb : 0.0f;
     }
-    if (!G || ia < n) S[(size_t)ia * ld + j] = sa;
-    if (!G || ib < n) S[(size_t)ib * ld + j] = sb;
+    if (DENSE) {
+      if (!G || ia < rlim) store_s1(&S[(size_t)(ia - srow) * ld + j], sa, nt);
+      if (!G || ib < rlim) store_s1(&S[(size_t)(ib - srow) * ld + j], sb, nt);
+    }
     if (lane == r) rowword = worda;
     if (lane == r + 1) rowword = wordb;
-    colword |= (ea ? (1ull << r) : 0ull) | (eb ? (2ull << r) : 0ull);
-    if (!diag) { myT[lane * TILE_PAD + r] = sa; myT[lane * TILE_PAD + r + 1] = sb; }
+    if (!RECT) {
+      colword |= (ea ? (1ull << r) : 0ull) | (eb ? (2ull << r) : 0ull);
+      if (DENSE && !diag) { myT[lane * TILE_PAD + r] = sa; myT[lane * TILE_PAD + r + 1] = sb; }
+    }
   };
   if (interior) {
 #pragma unroll 2
@@ -257,16 +320,18 @@ __global__ __launch_bounds__(64 * COMPAT_WAVES) void compat_tiles_kernel(const f
 #pragma unroll 2
     for (int r = 0; r < TILE_R; r += 2) row_pair(r, std::true_type{});
   }
-  if (lane < TILE_R && i0 + lane < n) bits[(size_t)(i0 + lane) * W + J] = rowword;
-  if (!diag) {
+  if (lane < TILE_R && i0 + lane < rlim) bits[(size_t)(i0 + lane) * W + J] = rowword;
+  if (!RECT && !diag) {
     // mirrored half: row j of S, columns i0 .. i0 + TILE_R - 1; SUB output rows per instruction
-    const int r = lane & (TILE_R - 1), hi = lane / TILE_R;
+    if (DENSE) {
+      const int r = lane & (TILE_R - 1), hi = lane / TILE_R;
 #pragma unroll 4
-    for (int c = 0; c < 64; c += SUB) {
-      const int cc = c + hi;
-      const float v = myT[cc * TILE_PAD + r];
-      const int jj = J * 64 + cc;
-      if (jj < n) S[(size_t)jj * ld + i0 + r] = v;
+      for (int c = 0; c < 64; c += SUB) {
+        const int cc = c + hi;
+        const float v = myT[cc * TILE_PAD + r];
+        const int jj = J * 64 + cc;
+        if (jj < n) store_s1(&S[(size_t)jj * ld + i0 + r], v, nt);
+      }
     }
     // mirrored adjacency: row j, piece (h % SUB) of word (i0 / 64)
     if (j < n) {
@@ -312,22 +377,38 @@ __global__ __launch_bounds__(256) void row_stats_kernel(const uint64_t* __restri
   if (lane == 0) { deg[i] = d_all; degp[i] = d_up; }
 }
 
-void launch_compat(const Points& pts, const Derived& dv, float* S, uint64_t* bits, const Tuning& tn, hipStream_t st) {
+// rows [row0, row1) of the graph (row0 a multiple of 64, row1 <= n); the whole matrix (symmetric tiles, each pair
+// evaluated once) when the range is [0, n).  S == nullptr: adjacency bits only (SC_FLAG_NO_DENSE_S).  For a proper
+// sub-range S holds the rows of the range only (row i at S + (i - row0) * ld).
+void launch_compat(const Points& pts, const Derived& dv, float* S, uint64_t* bits, int row0, int row1, const Tuning& tn,
+                   hipStream_t st) {
   const int W = pts.ld >> 6;
   const int two_phase = tn.compat_one_phase ? 0 : 1;  // the one-phase interior form stays for A/B and parity
+  const int mode = (int)(tn.compat_store_mode & 3u);
+  const bool rect = !(row0 == 0 && row1 >= pts.n);
+#define SC_COMPAT_ARGS pts.planes, pts.n, pts.ld, dv.d_thr, dv.min_len, dv.neg_inv2sig2, S, bits, n_tiles, two_phase, row0, row1, mode
+  if (rect) {
+    if (row1 <= row0) return;
+    // one-sided 16-row tiles over the rectangle (every pair of the block evaluated by this rank)
+    const int n_tiles = ((row1 - row0 + 15) / 16) * W;
+    if (S) hipLaunchKernelGGL((compat_tiles_kernel<16, 4, true, true>), dim3((n_tiles + 3) / 4), dim3(256), 0, st, SC_COMPAT_ARGS);
+    else hipLaunchKernelGGL((compat_tiles_kernel<16, 4, false, true>), dim3((n_tiles + 3) / 4), dim3(256), 0, st, SC_COMPAT_ARGS);
+    return;
+  }
   // tile height: 16 rows (4.3 KiB LDS image per wave, 4 waves per workgroup; default) or 64 rows (16.6 KiB, one wave
   // per workgroup; the mirrored half is then written as full 256-byte segments).  Measured: C2 28 vs 49 us, C3 432 vs
   // 435 us — bigger mirrored pieces do not pay for the lost occupancy.  Tuning::compat_rows = 64 selects it (experiments).
   const int tr = tn.compat_rows == 64 ? 64 : 16;
   if (tr == 64) {
     const int n_tiles = W * (W + 1) / 2;
-    hipLaunchKernelGGL((compat_tiles_kernel<64, 1>), dim3(n_tiles), dim3(64), 0, st, pts.planes, pts.n, pts.ld, dv.d_thr,
-                       dv.min_len, dv.neg_inv2sig2, S, bits, n_tiles, two_phase);
+    if (S) hipLaunchKernelGGL((compat_tiles_kernel<64, 1, true, false>), dim3(n_tiles), dim3(64), 0, st, SC_COMPAT_ARGS);
+    else hipLaunchKernelGGL((compat_tiles_kernel<64, 1, false, false>), dim3(n_tiles), dim3(64), 0, st, SC_COMPAT_ARGS);
   } else {
     const int n_tiles = 4 * W * (W + 1) / 2;
-    hipLaunchKernelGGL((compat_tiles_kernel<16, 4>), dim3((n_tiles + 3) / 4), dim3(256), 0, st, pts.planes, pts.n, pts.ld,
-                       dv.d_thr, dv.min_len, dv.neg_inv2sig2, S, bits, n_tiles, two_phase);
+    if (S) hipLaunchKernelGGL((compat_tiles_kernel<16, 4, true, false>), dim3((n_tiles + 3) / 4), dim3(256), 0, st, SC_COMPAT_ARGS);
+    else hipLaunchKernelGGL((compat_tiles_kernel<16, 4, false, false>), dim3((n_tiles + 3) / 4), dim3(256), 0, st, SC_COMPAT_ARGS);
   }
+#undef SC_COMPAT_ARGS
 }
 
 void launch_row_stats(const Points& pts, const uint64_t* bits, uint32_t* deg, uint32_t* degp, uint32_t* wpre,

@@ -29,6 +29,7 @@ struct Tuning {
   uint32_t score_split = 0;        // share (of 256) of the hypotheses scored on the matrix pipe
   bool compat_one_phase = false;   // exact chain on every pair of an interior tile
   int compat_rows = 16;            // tile height of stage A: 16 or 64
+  uint32_t compat_store_mode = 0;  // bit 0: 4-byte S stores (round 1's form), bit 1: non-temporal S stores
 };
 
 // Device view of the padded SoA point planes: px py pz qx qy qz, each `ld` floats (ld = roundup(n,64)),
@@ -49,7 +50,10 @@ void launch_stage_points(const float* d_src, const float* d_tgt, int n, int ld, 
 
 // ---- stage A: compat_graph -----------------------------------------------------------------------
 // S: n x ld fp32 (row-major, symmetric, zero diagonal / pad columns); bits: n x (ld/64) u64;
-void launch_compat(const Points& pts, const Derived& dv, float* S, uint64_t* bits, const Tuning& tn, hipStream_t st);
+// rows [row0, row1) (row0 a multiple of 64): the whole matrix by symmetric tiles for [0, n), one-sided tiles for a
+// row block (then S, if given, holds the rows of the block only).  S == nullptr: adjacency bits only.
+void launch_compat(const Points& pts, const Derived& dv, float* S, uint64_t* bits, int row0, int row1, const Tuning& tn,
+                   hipStream_t st);
 // deg[i] = edges of i; degp[i] = edges (i,j) with j > i; wpre: n x (ld/64) u32, set bits of row i in words [0,w).
 // zero_rows (optional): an n x W u64 matrix cleared on the way (the pruned bit matrix of stage B).
 void launch_row_stats(const Points& pts, const uint64_t* bits, uint32_t* deg, uint32_t* degp, uint32_t* wpre,

@@ -84,6 +84,42 @@ def test_compat_threshold_sweep_on_a_scaled_scene(pkg, O, eps, scale, one_phase)
     assert np.array_equal(S1.view(np.uint32), S0.view(np.uint32))
 
 
+@pytest.mark.parametrize("mode", [0, 1, 2, 3])
+def test_compat_store_forms_bit_exact(pkg, O, mode):
+    """Stage A writes S with 16-byte stores by default; sc_debug.compat_store_mode selects round 1's 4-byte stores
+    (bit 0) and non-temporal stores (bit 1).  Same bits in S, the bit rows and the degrees in every form, ragged N."""
+    sc = pkg.synth.make_scene(1337, 0.3, 1.0, 0.05, seed=5)
+    kw = _params(pkg, 0.05, 10)
+    r = pkg.Registrar(0)
+    try:
+        r.set_debug(compat_store_mode=mode)
+        S, bits, deg = r.compat(sc.src, sc.tgt, pkg.make_params(**kw))
+    finally:
+        r.close()
+    S0, bits0, deg0 = O.compat(sc.src, sc.tgt, kw["sigma"], kw["t_cmp"], kw["min_len"], kw["tau"])
+    assert np.array_equal(bits, bits0) and np.array_equal(deg, deg0)
+    assert np.array_equal(S.view(np.uint32), S0.view(np.uint32))
+
+
+@pytest.mark.parametrize("name", ["C0", "C1", "C2"])
+def test_no_dense_S_changes_nothing(pkg, O, reg, name):
+    """SC_FLAG_NO_DENSE_S: stage A writes the adjacency bit rows only.  Nothing after stage A reads S (edge weights are
+    recomputed from the points with the same chain), so the bit rows, degrees and the whole result equal the
+    restatement's exactly as with the dense matrix; asking the stage hook for S together with the flag is an error."""
+    cfg, scene = pkg.synth.make_config_scene(name)
+    kw = cfg.params()
+    _, bits, deg = reg.compat(scene.src, scene.tgt, pkg.make_params(flags=pkg.SC_FLAG_NO_DENSE_S, **kw), want_S=False)
+    _, bits0, deg0 = O.compat(scene.src, scene.tgt, kw["sigma"], kw["t_cmp"], kw["min_len"], kw["tau"], threads=8, want_S=False)
+    assert np.array_equal(bits, bits0) and np.array_equal(deg, deg0)
+    got = reg.register(scene.src, scene.tgt, flags=pkg.SC_FLAG_NO_DENSE_S | pkg.SC_FLAG_EXACT_TOTAL, **kw)
+    ref = O.register(scene.src, scene.tgt, threads=8, **kw)
+    assert got["status"] == ref["rc"] == 0
+    assert (got["stats"]["edges"], got["stats"]["tri_total"], got["stats"]["best_rank"]) == (ref["edges"], ref["tri_total"], ref["best_rank"])
+    assert np.array_equal(got["mask"], ref["mask"]) and nan_equal_bits(got["R"], ref["R"]) and nan_equal_bits(got["t"], ref["t"])
+    with pytest.raises(pkg.SacCotError):
+        reg.compat(scene.src, scene.tgt, pkg.make_params(flags=pkg.SC_FLAG_NO_DENSE_S, **kw), want_S=True)
+
+
 def test_compat_soa_layout_and_min_len_zero(pkg, O, reg):
     sc = _scene(pkg, 300, seed=11)
     kw = _params(pkg, 0.05, 10, min_len=0.0)
