@@ -34,7 +34,7 @@ extern "C" {
 #endif
 
 #define SC_VERSION_MAJOR 0
-#define SC_VERSION_MINOR 3   /* 0.3: sc_set_debug (no environment variables), SC_FLAG_NO_DENSE_S; 0.2: SC_FLAG_TIMING_HOT,
+#define SC_VERSION_MINOR 3   /* 0.3: sc_set_debug (no environment variables), SC_FLAG_NO_DENSE_S, sc_shard_* (stages A and B sharded); 0.2: SC_FLAG_TIMING_HOT,
                                 SC_STREAM_DEFAULT, sc_hypothesize_begin/end_device, sc_finalize_gathered_device */
 
 /* status codes */
@@ -151,7 +151,7 @@ typedef struct sc_debug {
   uint32_t score_split;       /* share (of 256) of the hypotheses scored by the f32-MFMA body of C2 */
   uint32_t compat_one_phase;  /* 1: stage A runs the exact chain on every pair of an interior tile            */
   uint32_t compat_rows;       /* stage A tile height: 16 (default) or 64                                      */
-  uint32_t compat_store_mode; /* stage A stores of S: bit 0 = 4 bytes per lane (default 16), bit 1 = non-temporal */
+  uint32_t compat_store_mode; /* stage A stores of S: 0 = by size; bit 0 = 4 bytes per lane, bit 2 = 16 bytes, bit 1 = non-temporal */
 } sc_debug;
 int         sc_set_debug(sc_ctx* ctx, const sc_debug* dbg);
 
@@ -207,6 +207,39 @@ int sc_finalize_gathered_device(sc_ctx* ctx, const uint64_t* d_keys, int n_pairs
 int sc_hypothesize_begin_device(sc_ctx* ctx, const float* d_src, const float* d_tgt, int64_t n,
                                 const sc_params* params, uint32_t* d_hist, sc_stats* stats);
 int sc_hypothesize_end_device(sc_ctx* ctx, const uint32_t* d_hist, uint64_t* d_key, sc_stats* stats);
+
+/* ---- stages A and B sharded too: phase API, one context per GPU / rank ------------------
+ * With the two-phase form above every rank repeats stages A and B.  Here rank r computes the row block
+ * [r * rows_per_rank, ...) of the adjacency bit rows (and of S, kept local, unless SC_FLAG_NO_DENSE_S) and enumerates
+ * the triangles of a contiguous, equally heavy range of rows; what the ranks exchange lives in CALLER buffers, and the
+ * caller runs the collectives between the phases (RCCL through torch.distributed in this repo's host layer, RCCL
+ * directly in sc_register_multi below; on one GPU the "ranks" of a test simply share the buffers):
+ *     sc_shard_compat_device (d_bits_all)      -> all-gather, in place, of bits_bytes_per_rank per rank
+ *     sc_shard_edges_device  (d_hist)          -> all-reduce SUM of SC_HIST_WORDS u32 (1 KiB)
+ *     sc_shard_select_device (d_hist, d_mine)  -> all-gather of cand_bytes_per_rank per rank into d_cand_all
+ *     sc_shard_score_device  (d_cand_all, d_key) -> all-gather of the 16-byte key pairs
+ *     sc_finalize_gathered_device (d_keys, shard_world, ...)
+ * d_bits_all: bits_bytes_total bytes; rank r's slice starts at r * bits_bytes_per_rank (its rows at their global
+ * index).  A candidate blob holds a rank's own top-T triangles in (i,j,k) order; the row ranges ascend with the rank,
+ * so the concatenated blobs are in global (i,j,k) order and the merge is the same exact select + compaction every
+ * rank runs on one GPU: winner, (R,t) and mask are bit-identical to the unsharded call.  Every rank must pass the
+ * same n and parameters (shard_rank aside).  shard_world <= 64; shard_world == 1 works (no collective needed).
+ * Each phase leaves its last kernels queued on the context's stream; enqueue the collective on the same stream. */
+typedef struct sc_shard_plan {
+  uint32_t size;                 /* = sizeof(sc_shard_plan), set by the caller                              */
+  uint32_t rows_per_rank;        /* rows of the adjacency matrix rank r computes: [r * rows_per_rank, ...)   */
+  uint32_t words_per_row;        /* u64 words per bit row                                                   */
+  uint32_t reserved;
+  uint64_t bits_bytes_per_rank;  /* rows_per_rank * words_per_row * 8                                       */
+  uint64_t bits_bytes_total;     /* shard_world * bits_bytes_per_rank: size of d_bits_all                    */
+  uint64_t cand_bytes_per_rank;  /* size of one candidate blob; d_cand_all holds shard_world of them         */
+} sc_shard_plan;
+int sc_shard_plan_query(const sc_params* params, int64_t n, sc_shard_plan* plan);
+int sc_shard_compat_device(sc_ctx* ctx, const float* d_src, const float* d_tgt, int64_t n, const sc_params* params,
+                           void* d_bits_all);
+int sc_shard_edges_device(sc_ctx* ctx, uint32_t* d_hist);
+int sc_shard_select_device(sc_ctx* ctx, const uint32_t* d_hist, void* d_cand_mine);
+int sc_shard_score_device(sc_ctx* ctx, const void* d_cand_all, uint64_t* d_key, sc_stats* stats);
 
 /* ---- stage-level hooks (host pointers in and out) so every kernel is parity-testable alone --------
  * All take SoA or AoS input per params->layout and run ONLY the named stage(s) on the GPU. */

@@ -25,6 +25,8 @@ SC_HIST_WORDS = 256  # u32 words of the pruning-sample histogram (sc_hypothesize
 EXPORTS = ["sc_version", "sc_strerror", "sc_default_params", "sc_create", "sc_destroy", "sc_set_stream",
            "sc_last_error", "sc_set_debug", "sc_register", "sc_register_device", "sc_hypothesize_device", "sc_finalize_device",
            "sc_hypothesize_begin_device", "sc_hypothesize_end_device", "sc_finalize_gathered_device",
+           "sc_shard_plan_query", "sc_shard_compat_device", "sc_shard_edges_device", "sc_shard_select_device",
+           "sc_shard_score_device",
            "sc_compat_host", "sc_triangles_host", "sc_kabsch_host", "sc_score_host", "sc_mask_host"]
 
 
@@ -46,6 +48,13 @@ class ScStats(C.Structure):
 
     def as_dict(self) -> dict:
         return {k: getattr(self, k) for k, _ in self._fields_ if k != "size"}
+
+
+class ScShardPlan(C.Structure):
+    """Mirror of `sc_shard_plan` (include/saccot.h): sizes of the buffers the ranks exchange when A and B are sharded."""
+    _fields_ = [("size", C.c_uint32), ("rows_per_rank", C.c_uint32), ("words_per_row", C.c_uint32),
+                ("reserved", C.c_uint32), ("bits_bytes_per_rank", C.c_uint64), ("bits_bytes_total", C.c_uint64),
+                ("cand_bytes_per_rank", C.c_uint64)]
 
 
 class ScDebug(C.Structure):
@@ -100,6 +109,11 @@ def load_library() -> C.CDLL:
     L.sc_hypothesize_begin_device.argtypes = [vp, vp, vp, C.c_int64, pp, vp, sp]
     L.sc_hypothesize_end_device.argtypes = [vp, vp, vp, sp]
     L.sc_finalize_gathered_device.argtypes = [vp, vp, C.c_int, vp, vp, sp]
+    L.sc_shard_plan_query.argtypes = [pp, C.c_int64, C.POINTER(ScShardPlan)]
+    L.sc_shard_compat_device.argtypes = [vp, vp, vp, C.c_int64, pp, vp]
+    L.sc_shard_edges_device.argtypes = [vp, vp]
+    L.sc_shard_select_device.argtypes = [vp, vp, vp]
+    L.sc_shard_score_device.argtypes = [vp, vp, vp, sp]
     L.sc_compat_host.argtypes = [vp, f32p, f32p, C.c_int64, pp, f32p, u64p, u32p]
     L.sc_triangles_host.argtypes = [vp, f32p, f32p, C.c_int64, pp, u32p, u32p, u32p, u64p, u64p]
     L.sc_kabsch_host.argtypes = [vp, f32p, f32p, C.c_int64, pp, u32p, C.c_uint32, f32p]
@@ -113,6 +127,15 @@ def make_params(sigma=0.1, t_cmp=0.9, tau=0.1, min_len=0.1, max_triangles=50000,
                 layout=SC_AOS, shard_rank=0, shard_world=1, shard_block=1024, flags=0, max_workspace=0) -> ScParams:
     return ScParams(C.sizeof(ScParams), sigma, t_cmp, tau, min_len, max_triangles, rank_mode, layout, shard_rank,
                     shard_world, shard_block, flags, max_workspace)
+
+
+def shard_plan(params: ScParams, n: int) -> ScShardPlan:
+    """sc_shard_plan_query: sizes of d_bits_all / the candidate blobs for `params` (shard_world) and n correspondences."""
+    plan = ScShardPlan(size=C.sizeof(ScShardPlan))
+    rc = load_library().sc_shard_plan_query(C.byref(params), n, C.byref(plan))
+    if rc != SC_OK:
+        raise SacCotError(rc, "sc_shard_plan_query")
+    return plan
 
 
 def _p(a, t):
@@ -226,6 +249,25 @@ class Registrar:
         rc = self._check(self._lib.sc_finalize_gathered_device(self._h, d_keys, n_pairs, d_Rt, d_mask, C.byref(st)),
                          allow=(SC_ENOHYP,))
         return rc, st.as_dict()
+
+    # ---- stages A and B sharded too (include/saccot.h "phase API") ----------------------------
+    def shard_compat_device(self, d_src: int, d_tgt: int, n: int, params: ScParams, d_bits_all: int):
+        """Phase 1: this rank's row block of the adjacency bit rows into the shared d_bits_all -> all-gather in place."""
+        self._check(self._lib.sc_shard_compat_device(self._h, d_src, d_tgt, n, C.byref(params), d_bits_all))
+
+    def shard_edges_device(self, d_hist: int):
+        """Phase 2 (bit rows gathered): degrees, edge list, this rank's share of the pruning sample -> all-reduce SUM."""
+        self._check(self._lib.sc_shard_edges_device(self._h, d_hist))
+
+    def shard_select_device(self, d_hist: int, d_cand_mine: int):
+        """Phase 3: this rank's own top-T triangles (its contiguous row range) into its candidate blob -> all-gather."""
+        self._check(self._lib.sc_shard_select_device(self._h, d_hist, d_cand_mine))
+
+    def shard_score_device(self, d_cand_all: int, d_key: int):
+        """Phase 4: merge of the gathered blobs, then C1 + C2 on this rank's blocks -> key pair -> all-gather, finalize."""
+        st = ScStats(C.sizeof(ScStats))
+        self._check(self._lib.sc_shard_score_device(self._h, d_cand_all, d_key, C.byref(st)))
+        return st.as_dict()
 
     # ---- stage hooks -----------------------------------------------------------------------------------------
     def compat(self, src, tgt, params: ScParams, want_S=True):

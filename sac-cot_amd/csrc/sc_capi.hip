@@ -46,7 +46,7 @@ struct sc_ctx {
   // workspace
   Buf in_src, in_tgt, planes, S, bits, deg, degp, wpre, ebase, edge_off, scan_tmp, ei, ej, es, ebi, ebj, tcnt, toff, wkey, kcol, ctl, events, blk_gt,
       blk_eq, blk_minmax, bits2, off_gt, off_eq, sel_ord, sel_key, sortkey, sorted, sort_tmp, tri, tri_rk, key_rk, rt, rt_aos, partial, cnt, key, rt12,
-      mask, refine_tmp, amx_pairs, strong;
+      mask, refine_tmp, amx_pairs, strong, rowcost, cost_pre;
 
   // state of the last hypothesize call (consumed by finalize)
   int n = 0, ld = 0;
@@ -65,6 +65,14 @@ struct sc_ctx {
   const uint64_t* mbits = nullptr;
   const float* smin_ptr = nullptr;
   Tuning tn;  // defaults unless sc_set_debug() changed them; the library reads no environment variable
+  // the adjacency bit matrix of the running call: the context's own buffer, or — sharded stage A — the caller's
+  // all-gathered one
+  uint64_t* bits_cur = nullptr;
+  // sharded A + B (sc_shard_*_device): phase reached (0: none), the gathered candidate blobs
+  bool sharded_ab = false;
+  int shard_phase = 0;
+  const void* cand_all = nullptr;
+  size_t cand_bytes = 0;
 };
 
 namespace {
@@ -134,13 +142,24 @@ inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
 
 Points points_of(const sc_ctx* c) { return Points{c->planes.as<float>(), c->n, c->ld}; }
 Graph graph_of(const sc_ctx* c) {
-  return Graph{c->bits.as<uint64_t>(), c->S.as<float>(), c->deg.as<uint32_t>(), c->degp.as<uint32_t>(),
+  return Graph{c->bits_cur, c->S.as<float>(), c->deg.as<uint32_t>(), c->degp.as<uint32_t>(),
                c->wpre.as<uint32_t>(), c->n, c->ld, c->ld >> 6};
+}
+// sharded stage B: the device-side edge range [lo, hi) this rank enumerates (nullptr: every edge)
+const uint64_t* own_range_of(const sc_ctx* c) {
+  return c->sharded_ab ? c->ctl.as<ControlBlock>()->own_edge : nullptr;
 }
 
 // event i of the per-stage timing; SC_FLAG_TIMING_HOT keeps only the bracket of the dominant (score) kernel
 TriSource tri_source_of(const sc_ctx* c) {
-  return TriSource{c->sel_ord.as<uint64_t>(), c->kcol.as<uint2>(), c->ei.as<uint32_t>(), c->ej.as<uint32_t>()};
+  TriSource ts{c->sel_ord.as<uint64_t>(), c->kcol.as<uint2>(), c->ei.as<uint32_t>(), c->ej.as<uint32_t>(), nullptr, 0, 0};
+  if (c->sharded_ab && c->cand_all) {  // the selection indexes the gathered candidate blobs
+    const uint32_t T = c->params.max_triangles;
+    ts.cand_recs = cand_blob(const_cast<void*>(c->cand_all), T).recs;
+    ts.cand_seg = cand_cap(T);
+    ts.cand_stride = c->cand_bytes / 16;
+  }
+  return ts;
 }
 
 int rec(sc_ctx* c, int i) {
@@ -173,8 +192,9 @@ int run_compat(sc_ctx* c, bool dense) {
   ENSURE(c, c->deg, n * sizeof(uint32_t));
   ENSURE(c, c->degp, n * sizeof(uint32_t));
   ENSURE(c, c->wpre, n * W * sizeof(uint32_t));
-  launch_compat(points_of(c), c->dv, dense ? c->S.as<float>() : nullptr, c->bits.as<uint64_t>(), 0, c->n, c->tn,
-                c->stream);
+  c->bits_cur = c->bits.as<uint64_t>();
+  c->sharded_ab = false; c->shard_phase = 0; c->cand_all = nullptr;
+  launch_compat(points_of(c), c->dv, dense ? c->S.as<float>() : nullptr, c->bits_cur, 0, c->n, c->tn, c->stream);
   return SC_OK;
 }
 
@@ -185,8 +205,13 @@ int run_row_stats(sc_ctx* c, bool will_prune) {
     ENSURE(c, c->bits2, (size_t)c->n * (c->ld >> 6) * sizeof(uint64_t));
     zero_rows = c->bits2.as<uint64_t>();
   }
-  launch_row_stats(points_of(c), c->bits.as<uint64_t>(), c->deg.as<uint32_t>(), c->degp.as<uint32_t>(),
-                   c->wpre.as<uint32_t>(), zero_rows, c->stream);
+  uint32_t* rowcost = nullptr;
+  if (c->sharded_ab) {  // per-row work estimate: its prefix splits the rows between the ranks
+    ENSURE(c, c->rowcost, (size_t)c->n * 4);
+    rowcost = c->rowcost.as<uint32_t>();
+  }
+  launch_row_stats(points_of(c), c->bits_cur, c->deg.as<uint32_t>(), c->degp.as<uint32_t>(),
+                   c->wpre.as<uint32_t>(), zero_rows, rowcost, c->stream);
   return SC_OK;
 }
 
@@ -229,7 +254,17 @@ int run_edges(sc_ctx* c, const sc_params* p, uint32_t* hist, uint32_t part, uint
   ENSURE(c, c->scan_tmp, scan_temp_bytes(n));
   // read-back #1: the scan kernel itself writes the edge count to host-pinned memory (no copy kernel)
   arm_word(c, 0);
-  launch_scan_u32(c->degp.as<uint32_t>(), n, c->edge_off.as<uint64_t>(), c->scan_tmp.p, c->tn, st, &c->pinned[0]);
+  if (c->sharded_ab) {
+    // also the prefix of the per-row work estimate and, from it, this rank's contiguous row / edge range
+    ENSURE(c, c->cost_pre, (n + 1) * sizeof(uint64_t));
+    launch_scan_u32_pair(c->degp.as<uint32_t>(), c->edge_off.as<uint64_t>(), c->rowcost.as<uint32_t>(),
+                         c->cost_pre.as<uint64_t>(), n, c->scan_tmp.p, c->tn, st, &c->pinned[0]);
+    ControlBlock* ctl = c->ctl.as<ControlBlock>();
+    launch_shard_split(c->cost_pre.as<uint64_t>(), c->edge_off.as<uint64_t>(), c->n, (uint32_t)p->shard_rank,
+                       (uint32_t)p->shard_world, ctl->own_row, ctl->own_edge, st);
+  } else {
+    launch_scan_u32(c->degp.as<uint32_t>(), n, c->edge_off.as<uint64_t>(), c->scan_tmp.p, c->tn, st, &c->pinned[0]);
+  }
   // While the host polls for the edge count, edge_fill already runs into the edge arrays this context holds from
   // earlier calls (it needs no host-side count: one wave per row, offsets from the scan).  Writes beyond their
   // capacity are dropped by the kernel; in that case, or on a first call, it runs (again) after the read-back.
@@ -266,7 +301,7 @@ int run_edges(sc_ctx* c, const sc_params* p, uint32_t* hist, uint32_t part, uint
     ControlBlock* ctl = c->ctl.as<ControlBlock>();
     if (p->flags & SC_FLAG_EXACT_TOTAL) {  // statistics only: 3-cliques of the whole graph
       launch_tri_count(g, g.bits, c->es.as<float>(), nullptr, c->ei.as<uint32_t>(), c->ej.as<uint32_t>(), E,
-                       c->tcnt.as<uint32_t>(), c->tn, st);
+                       c->tcnt.as<uint32_t>(), nullptr, c->tn, st);
       launch_scan_u32(c->tcnt.as<uint32_t>(), E, c->toff.as<uint64_t>(), c->scan_tmp.p, c->tn, st, &c->pinned[4]);
       c->have_total = true;
     }
@@ -298,7 +333,7 @@ int run_select(sc_ctx* c, const sc_params* p, const uint32_t* hist, bool want_li
     }
     launch_prune_bits(g, hist ? hist : ctl->prune_hist, c->ei.as<uint32_t>(), c->ej.as<uint32_t>(), c->es.as<float>(), E,
                       p->max_triangles, 3.0f * p->t_cmp * 0.999f, c->bits2.as<uint64_t>(), &ctl->smin, &ctl->klb, sl,
-                      c->tcnt.as<uint32_t>(), st);
+                      c->tcnt.as<uint32_t>(), own_range_of(c), st);
     mbits = c->bits2.as<uint64_t>();
     smin = &ctl->smin;
   }
@@ -317,7 +352,7 @@ int run_select(sc_ctx* c, const sc_params* p, const uint32_t* hist, bool want_li
                             c->ej.as<uint32_t>(), E, p->rank_mode, c->tcnt.as<uint32_t>(), ev, c->tn, st);
   } else {
     launch_tri_count(g, mbits, c->es.as<float>(), smin, c->ei.as<uint32_t>(), c->ej.as<uint32_t>(), E,
-                     c->tcnt.as<uint32_t>(), c->tn, st);
+                     c->tcnt.as<uint32_t>(), own_range_of(c), c->tn, st);
   }
   // read-back #2: triangle count (of the pruned graph when pruning), written to pinned memory by the scan
   arm_word(c, 2);
@@ -376,18 +411,19 @@ int run_select(sc_ctx* c, const sc_params* p, const uint32_t* hist, bool want_li
   } else {
     launch_tri_keys(g, mbits, smin, c->ebase.as<uint32_t>(), c->ei.as<uint32_t>(), c->ej.as<uint32_t>(),
                     c->es.as<float>(), c->toff.as<uint64_t>(), E, p->rank_mode, c->wkey.as<uint32_t>(),
-                    c->kcol.as<uint2>(), c->blk_minmax.as<uint32_t>(), sel, T_eff, c->tn, st);
+                    c->kcol.as<uint2>(), c->blk_minmax.as<uint32_t>(), sel, T_eff, own_range_of(c), c->tn, st);
   }
   if (c->timing) HIPCHK(c, hipEventRecord(c->ev[10], st));
   c->timed_trikeys = c->timing;
-  launch_select_rounds(c->wkey.as<uint32_t>(), M, sel, fast_window ? 2 : 3, c->tn, st);
-  launch_compact_count(c->wkey.as<uint32_t>(), M, sel, c->blk_gt.as<uint32_t>(), c->blk_eq.as<uint32_t>(), st);
+  const KeyView view = plain_view(c->wkey.as<uint32_t>(), M);
+  launch_select_rounds(view, sel, fast_window ? 2 : 3, c->tn, st);
+  launch_compact_count(view, sel, c->blk_gt.as<uint32_t>(), c->blk_eq.as<uint32_t>(), st);
   // few tiles (and M < 2^32): compact_write adds up the tile counts itself, no scan launch in between
   const bool self_off = nb <= c->tn.compact_self_max && M < (1ull << 32);  // (a test sets 0: the scanned offsets)
   if (!self_off)
     launch_scan_u32_pair(c->blk_gt.as<uint32_t>(), c->off_gt.as<uint64_t>(), c->blk_eq.as<uint32_t>(),
                          c->off_eq.as<uint64_t>(), nb, c->scan_tmp.p, c->tn, st);
-  launch_compact_write(c->wkey.as<uint32_t>(), M, sel, c->blk_gt.as<uint32_t>(), c->blk_eq.as<uint32_t>(),
+  launch_compact_write(view, sel, c->blk_gt.as<uint32_t>(), c->blk_eq.as<uint32_t>(),
                        self_off ? nullptr : c->off_gt.as<uint64_t>(), self_off ? nullptr : c->off_eq.as<uint64_t>(),
                        c->sel_ord.as<uint64_t>(), c->sel_key.as<uint32_t>(), st);
   // the list stays in ordinal order: no sort on the hot path (the winner is found by (count, key, position))
@@ -521,7 +557,7 @@ void sc_destroy(sc_ctx* c) {
   Buf* bufs[] = {&c->in_src, &c->in_tgt, &c->planes, &c->S, &c->bits, &c->deg, &c->degp, &c->wpre, &c->ebase, &c->edge_off, &c->scan_tmp,
                  &c->ei, &c->ej, &c->es, &c->ebi, &c->ebj, &c->tcnt, &c->toff, &c->wkey, &c->kcol, &c->ctl, &c->events, &c->blk_gt, &c->blk_eq, &c->blk_minmax, &c->bits2, &c->off_gt,
                  &c->off_eq, &c->sel_ord, &c->sel_key, &c->sortkey, &c->sorted, &c->sort_tmp, &c->tri, &c->tri_rk, &c->key_rk, &c->rt,
-                 &c->rt_aos, &c->partial, &c->cnt, &c->key, &c->rt12, &c->mask, &c->refine_tmp, &c->amx_pairs, &c->strong};
+                 &c->rt_aos, &c->partial, &c->cnt, &c->key, &c->rt12, &c->mask, &c->refine_tmp, &c->amx_pairs, &c->strong, &c->rowcost, &c->cost_pre};
   for (Buf* b : bufs) if (b->p) (void)hipFree(b->p);
   for (int i = 0; i < N_EVENTS; i++) if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
   if (c->pinned) (void)hipHostFree(c->pinned);
@@ -563,7 +599,7 @@ int sc_set_debug(sc_ctx* c, const sc_debug* d) {
   t.score_split = d->score_split;
   t.compat_one_phase = d->compat_one_phase != 0;
   t.compat_rows = d->compat_rows == 64 ? 64 : 16;
-  t.compat_store_mode = d->compat_store_mode & 3u;
+  t.compat_store_mode = d->compat_store_mode & 7u;
   c->tn = t;
   return SC_OK;
 }
@@ -599,12 +635,21 @@ int hyp_begin(sc_ctx* c, const float* d_src, const float* d_tgt, int64_t n, cons
   return SC_OK;
 }
 
+int run_stage_c(sc_ctx* c, uint64_t* d_key, sc_stats* stats);
+
 // phase 1, second half: prune with the (summed) histogram, enumerate, select, then stage C on this rank's share
 int hyp_end(sc_ctx* c, const uint32_t* d_hist, uint64_t* d_key, sc_stats* stats) {
   const sc_params* p = &c->params;
   int rc;
   c->begun = false;
   if ((rc = run_select(c, p, d_hist, false))) return rc;
+  return run_stage_c(c, d_key, stats);
+}
+
+// stage C on this rank's blocks of the (replicated) selection: C1, C2, arg-max key pair -> d_key
+int run_stage_c(sc_ctx* c, uint64_t* d_key, sc_stats* stats) {
+  const sc_params* p = &c->params;
+  int rc;
   if ((rc = rec(c, 3))) return rc;
   Shard sh;
   sh.T_eff = c->T_eff;
@@ -661,6 +706,138 @@ int sc_hypothesize_end_device(sc_ctx* c, const uint32_t* d_hist, uint64_t* d_key
   if (!c->begun) { c->last_error = "sc_hypothesize_end_device without a preceding sc_hypothesize_begin_device"; return SC_EINVAL; }
   HIPCHK(c, hipSetDevice(c->device));
   return hyp_end(c, d_hist, d_key, stats);
+}
+
+// ---- sharded A + B ------------------------------------------------------------------------
+
+int sc_shard_plan_query(const sc_params* p, int64_t n, sc_shard_plan* out) {
+  if (!out || out->size != sizeof(sc_shard_plan)) return SC_EINVAL;
+  const int rc = check_params(p);
+  if (rc) return rc;
+  if (n < 3 || n > (1 << 24) || p->shard_world > 64) return SC_EINVAL;
+  const uint64_t ld = (uint64_t)round_up((int)n, 64), W = ld >> 6, G = (uint64_t)p->shard_world;
+  const uint64_t R = (((uint64_t)n + G - 1) / G + 63) / 64 * 64;  // rows per rank, a multiple of the tile block
+  out->rows_per_rank = (uint32_t)R;
+  out->words_per_row = (uint32_t)W;
+  out->bits_bytes_per_rank = R * W * 8;
+  out->bits_bytes_total = G * R * W * 8;
+  out->cand_bytes_per_rank = cand_blob_bytes(p->max_triangles);
+  return SC_OK;
+}
+
+int sc_shard_compat_device(sc_ctx* c, const float* d_src, const float* d_tgt, int64_t n, const sc_params* p,
+                           void* d_bits_all) {
+  if (!c || !d_src || !d_tgt || !d_bits_all) return SC_EINVAL;
+  int rc = check_params(p);
+  if (rc) return rc;
+  if (p->shard_world > 64) return SC_EINVAL;
+  HIPCHK(c, hipSetDevice(c->device));
+  c->have_hyp = false; c->begun = false; c->timed_trikeys = false;
+  c->timing = (p->flags & SC_FLAG_TIMING) != 0;
+  c->timing_hot = !c->timing && (p->flags & SC_FLAG_TIMING_HOT) != 0;
+  if ((c->timing || c->timing_hot) && (rc = calibrate_events(c))) return rc;
+  c->refine = (p->flags & SC_FLAG_REFINE) != 0;
+  c->cap_bytes = p->max_workspace ? p->max_workspace : (64ull << 30);
+  c->dv = derive(p);
+  c->params = *p;
+  c->shard_phase = 0; c->cand_all = nullptr;
+  if ((rc = rec(c, 0))) return rc;
+  if ((rc = stage_inputs(c, d_src, d_tgt, n, p))) return rc;
+  if ((rc = rec(c, 1))) return rc;
+  sc_shard_plan plan; plan.size = sizeof plan;
+  if ((rc = sc_shard_plan_query(p, n, &plan))) return rc;
+  const int R = (int)plan.rows_per_rank;
+  const int r0 = p->shard_rank * R < c->n ? p->shard_rank * R : c->n, r1 = r0 + R < c->n ? r0 + R : c->n;
+  const size_t W = (size_t)c->ld >> 6;
+  const bool dense = !(p->flags & SC_FLAG_NO_DENSE_S);
+  if (dense && r1 > r0) ENSURE(c, c->S, (size_t)(r1 - r0) * c->ld * sizeof(float));  // this rank's rows of S only
+  ENSURE(c, c->deg, (size_t)c->n * sizeof(uint32_t));
+  ENSURE(c, c->degp, (size_t)c->n * sizeof(uint32_t));
+  ENSURE(c, c->wpre, (size_t)c->n * W * sizeof(uint32_t));
+  c->bits_cur = static_cast<uint64_t*>(d_bits_all);
+  c->sharded_ab = true;
+  // world == 1: [0, n) -> the symmetric tiles; else the one-sided row-block form, bit rows at their global index
+  launch_compat(points_of(c), c->dv, dense ? c->S.as<float>() : nullptr, c->bits_cur, r0, r1, c->tn, c->stream);
+  if ((rc = rec(c, 2))) return rc;
+  HIPCHK(c, hipGetLastError());
+  c->shard_phase = 1;
+  return SC_OK;
+}
+
+int sc_shard_edges_device(sc_ctx* c, uint32_t* d_hist) {
+  if (!c || !d_hist) return SC_EINVAL;
+  if (!c->sharded_ab || c->shard_phase != 1) { c->last_error = "sc_shard_edges_device: call sc_shard_compat_device first"; return SC_EINVAL; }
+  HIPCHK(c, hipSetDevice(c->device));
+  const sc_params* p = &c->params;
+  c->shard_phase = 0;
+  HIPCHK(c, hipMemsetAsync(d_hist, 0, SC_HIST_WORDS * sizeof(uint32_t), c->stream));
+  int rc;
+  if ((rc = run_row_stats(c, may_prune(p)))) return rc;
+  if ((rc = run_edges(c, p, d_hist, (uint32_t)p->shard_rank, (uint32_t)p->shard_world))) return rc;
+  c->shard_phase = 2;
+  return SC_OK;
+}
+
+int sc_shard_select_device(sc_ctx* c, const uint32_t* d_hist, void* d_cand_mine) {
+  if (!c || !d_hist || !d_cand_mine) return SC_EINVAL;
+  if (!c->sharded_ab || c->shard_phase != 2) { c->last_error = "sc_shard_select_device: call sc_shard_edges_device first"; return SC_EINVAL; }
+  HIPCHK(c, hipSetDevice(c->device));
+  const sc_params* p = &c->params;
+  c->shard_phase = 0;
+  int rc;
+  if ((rc = run_select(c, p, d_hist, false))) return rc;   // this rank's own top-T, in (i,j,k) order
+  const CandBlob b = cand_blob(d_cand_mine, p->max_triangles);
+  if (c->M == 0) {  // nothing enumerated here (also E == 0): an empty blob
+    HIPCHK(c, hipMemsetAsync(b.hdr, 0, CAND_HDR_WORDS * 8, c->stream));
+  } else {
+    launch_cand_emit(c->sel_ord.as<uint64_t>(), c->sel_key.as<uint32_t>(), c->kcol.as<uint2>(), c->ei.as<uint32_t>(),
+                     c->ej.as<uint32_t>(), &c->ctl.as<ControlBlock>()->sel, c->toff.as<uint64_t>(), c->E, c->T_eff, b,
+                     c->stream);
+  }
+  HIPCHK(c, hipGetLastError());
+  c->shard_phase = 3;
+  return SC_OK;
+}
+
+int sc_shard_score_device(sc_ctx* c, const void* d_cand_all, uint64_t* d_key, sc_stats* stats) {
+  if (!c || !d_cand_all || !d_key) return SC_EINVAL;
+  if (!c->sharded_ab || c->shard_phase != 3) { c->last_error = "sc_shard_score_device: call sc_shard_select_device first"; return SC_EINVAL; }
+  HIPCHK(c, hipSetDevice(c->device));
+  const sc_params* p = &c->params;
+  c->shard_phase = 0;
+  hipStream_t st = c->stream;
+  const uint32_t T = p->max_triangles, G = (uint32_t)p->shard_world;
+  const size_t blob_bytes = cand_blob_bytes(T);
+  c->cand_all = d_cand_all; c->cand_bytes = blob_bytes;
+  // Merge: the same exact select + (i,j,k)-order compaction as on one GPU, over the concatenated candidate keys.
+  ControlBlock* ctl = c->ctl.as<ControlBlock>();
+  SelectState* sel = &ctl->sel;
+  const bool window_known = p->rank_mode == SC_RANK_WEIGHT && 3.0f * p->t_cmp * 0.999f >= 2.0f;
+  const KeyView view = cand_view(d_cand_all, blob_bytes, G, T);
+  const size_t nb = compact_blocks(view.M);
+  ENSURE(c, c->blk_gt, nb * 4);
+  ENSURE(c, c->blk_eq, nb * 4);
+  ENSURE(c, c->off_gt, (nb + 1) * 8);
+  ENSURE(c, c->off_eq, (nb + 1) * 8);
+  ENSURE(c, c->scan_tmp, scan_temp_bytes(nb));
+  ENSURE(c, c->sel_ord, (size_t)T * 8);
+  ENSURE(c, c->sel_key, (size_t)T * 4);
+  arm_word(c, 6);
+  launch_merge_prepare(d_cand_all, blob_bytes, G, T, window_known, &ctl->klb, sel, &c->pinned[6], st);
+  launch_select_rounds(view, sel, window_known ? 2 : 3, c->tn, st);
+  launch_compact_count(view, sel, c->blk_gt.as<uint32_t>(), c->blk_eq.as<uint32_t>(), st);
+  const bool self_off = nb <= c->tn.compact_self_max && view.M < (1ull << 32);
+  if (!self_off)
+    launch_scan_u32_pair(c->blk_gt.as<uint32_t>(), c->off_gt.as<uint64_t>(), c->blk_eq.as<uint32_t>(),
+                         c->off_eq.as<uint64_t>(), nb, c->scan_tmp.p, c->tn, st);
+  launch_compact_write(view, sel, c->blk_gt.as<uint32_t>(), c->blk_eq.as<uint32_t>(),
+                       self_off ? nullptr : c->off_gt.as<uint64_t>(), self_off ? nullptr : c->off_eq.as<uint64_t>(),
+                       c->sel_ord.as<uint64_t>(), c->sel_key.as<uint32_t>(), st);
+  // the merged length, published by merge_prepare long before the compaction ends: the poll costs no GPU time
+  { const int wrc = wait_word(c, 6); if (wrc) return wrc; }
+  c->T_eff = (uint32_t)c->pinned[6];
+  c->M = c->M_total = c->pinned[7];
+  return run_stage_c(c, d_key, stats);
 }
 
 int sc_finalize_device(sc_ctx* c, const uint64_t* d_key, float* d_Rt, uint8_t* d_mask, sc_stats* stats) {

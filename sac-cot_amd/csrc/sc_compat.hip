@@ -73,8 +73,8 @@ __device__ __forceinline__ float bcast(float v, int src) {
 
 // S stores: 16 bytes per lane by default (4 consecutive floats of one row piece: a quarter of the store instructions
 // and of the addresses the texture path has to process), optionally non-temporal (S is never read again on this
-// path: no reason to keep it in L2 / Infinity Cache).  `mode` bit 0: 4-byte stores (round 1's form, kept for A/B),
-// bit 1: non-temporal.
+// path: no reason to keep it in L2 / Infinity Cache).  `mode` bit 0: 4-byte stores (round 1's form: better on small
+// matrices, see launch_compat), bit 1: non-temporal.
 typedef float f32x4s __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ void store_s4(float* p, float a, float b, float c, float d, bool nt) {
   const f32x4s v = {a, b, c, d};
@@ -343,16 +343,21 @@ __global__ __launch_bounds__(64 * COMPAT_WAVES) void compat_tiles_kernel(const f
 }
 
 // deg[i], degp[i] (bits above i) and wpre[i][w] = #set bits of row i in words [0, w): one wave per row.
+// rowcost (optional): estimate of stage B's work for the edges (i, j), j > i, of row i — the words the counting pass
+// ANDs for each of them plus a constant: sum over j of (W - j / 64 + 4), saturated to u32.  Its prefix over the rows
+// splits the rows into contiguous, equally heavy ranges when stage B is sharded.
 __global__ __launch_bounds__(256) void row_stats_kernel(const uint64_t* __restrict__ bits, int n, int W,
                                                         uint32_t* __restrict__ deg, uint32_t* __restrict__ degp,
                                                         uint32_t* __restrict__ wpre,
-                                                        uint64_t* __restrict__ zero_rows) {
+                                                        uint64_t* __restrict__ zero_rows,
+                                                        uint32_t* __restrict__ rowcost) {
   const int lane = threadIdx.x & 63;
   const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (i >= n) return;
   if (zero_rows)
     for (int w = lane; w < W; w += 64) zero_rows[(size_t)i * W + w] = 0ull;
   uint32_t d_all = 0, d_up = 0;
+  uint64_t cost = 0;
   for (int wb = 0; wb < W; wb += 64) {
     const int w = wb + lane;
     const uint64_t v = w < W ? bits[(size_t)i * W + w] : 0ull;
@@ -369,12 +374,46 @@ __global__ __launch_bounds__(256) void row_stats_kernel(const uint64_t* __restri
       if (w < (i >> 6)) up = 0;
       else if (w == (i >> 6)) up &= ((i & 63) == 63) ? 0ull : (~0ull << ((i & 63) + 1));
       d_up += __popcll(up);
+      cost += (uint64_t)__popcll(up) * (uint64_t)(W - w + 4);
     }
     d_all += __shfl(inc, 63);
   }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) d_up += __shfl_xor(d_up, o);
-  if (lane == 0) { deg[i] = d_all; degp[i] = d_up; }
+  if (rowcost) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) cost += __shfl_xor(cost, o);
+  }
+  if (lane == 0) {
+    deg[i] = d_all; degp[i] = d_up;
+    if (rowcost) rowcost[i] = cost > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)cost;
+  }
+}
+
+// Contiguous row range of one rank: rows [lo, hi) with lo = first row whose cost prefix reaches rank / world of the
+// total (row 0 for rank 0, n for the end of the last rank).  own_row[0..1] and the CSR edge range own_edge[0..1] of
+// those rows go to the control block; every rank computes the same boundaries from the same replicated arrays.
+__global__ __launch_bounds__(64) void shard_split_kernel(const uint64_t* __restrict__ cost_pre,
+                                                         const uint64_t* __restrict__ edge_off, int n, uint32_t rank,
+                                                         uint32_t world, uint32_t* __restrict__ own_row,
+                                                         uint64_t* __restrict__ own_edge) {
+  if (threadIdx.x >= 2) return;
+  const uint32_t l = rank + threadIdx.x;  // boundary index: rank (lo) or rank + 1 (hi)
+  int row;
+  if (l == 0) row = 0;
+  else if (l >= world) row = n;
+  else {
+    const uint64_t total = cost_pre[n];
+    const uint64_t target = (uint64_t)(((unsigned __int128)total * l) / world);
+    int lo = 0, hi = n;  // first row r in [0, n] with cost_pre[r] >= target
+    while (lo < hi) {
+      const int mid = (lo + hi) >> 1;
+      if (cost_pre[mid] >= target) hi = mid; else lo = mid + 1;
+    }
+    row = lo;
+  }
+  own_row[threadIdx.x] = (uint32_t)row;
+  own_edge[threadIdx.x] = edge_off[row];
 }
 
 // rows [row0, row1) of the graph (row0 a multiple of 64, row1 <= n); the whole matrix (symmetric tiles, each pair
@@ -384,8 +423,16 @@ void launch_compat(const Points& pts, const Derived& dv, float* S, uint64_t* bit
                    hipStream_t st) {
   const int W = pts.ld >> 6;
   const int two_phase = tn.compat_one_phase ? 0 : 1;  // the one-phase interior form stays for A/B and parity
-  const int mode = (int)(tn.compat_store_mode & 3u);
   const bool rect = !(row0 == 0 && row1 >= pts.n);
+  // S stores: 16 bytes per lane pay on big matrices (C3, N = 20 000: 346 vs 404 us = 4.8 vs 4.1 TB/s) and cost a little
+  // on small ones, where the kernel's time is a wave's latency (C2, N = 5000: 25.8 vs 23.7 us) — measured r02,
+  // profiles/r02_ab_compat_stores.txt; non-temporal stores changed nothing at either size.  Tuning::compat_store_mode
+  // forces a form (bit 0: 4-byte, bit 2: 16-byte) and adds the nt hint (bit 1).
+  const long long tiles_all = rect ? (long long)((row1 - row0 + 15) / 16) * W : 2ll * W * (W + 1);
+  int mode = (tiles_all >= 32768 || rect) ? 0 : 1;
+  if (tn.compat_store_mode & 1u) mode = 1;
+  if (tn.compat_store_mode & 4u) mode = 0;
+  mode |= (int)(tn.compat_store_mode & 2u);
 #define SC_COMPAT_ARGS pts.planes, pts.n, pts.ld, dv.d_thr, dv.min_len, dv.neg_inv2sig2, S, bits, n_tiles, two_phase, row0, row1, mode
   if (rect) {
     if (row1 <= row0) return;
@@ -412,9 +459,14 @@ void launch_compat(const Points& pts, const Derived& dv, float* S, uint64_t* bit
 }
 
 void launch_row_stats(const Points& pts, const uint64_t* bits, uint32_t* deg, uint32_t* degp, uint32_t* wpre,
-                      uint64_t* zero_rows, hipStream_t st) {
+                      uint64_t* zero_rows, uint32_t* rowcost, hipStream_t st) {
   hipLaunchKernelGGL(row_stats_kernel, dim3((pts.n + 3) / 4), dim3(256), 0, st, bits, pts.n, pts.ld >> 6, deg, degp,
-                     wpre, zero_rows);
+                     wpre, zero_rows, rowcost);
+}
+
+void launch_shard_split(const uint64_t* cost_pre, const uint64_t* edge_off, int n, uint32_t rank, uint32_t world,
+                        uint32_t* own_row, uint64_t* own_edge, hipStream_t st) {
+  hipLaunchKernelGGL(shard_split_kernel, dim3(1), dim3(64), 0, st, cost_pre, edge_off, n, rank, world, own_row, own_edge);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -522,15 +574,15 @@ __global__ __launch_bounds__(1024) void scan_small_kernel(const uint32_t* __rest
   }
 }
 
-constexpr size_t SCAN_SMALL_MAX = 32768;
+constexpr size_t SCAN_SMALL_MAX = 8192;  // one pass of the single block; beyond it the tiled form is faster (N = 20 000: 26 -> ~9 us)
 // Tuning::scan_self_max (4096 tiles = 16.7 M elements): beyond it the scan of sums is its own launch
 
 void launch_scan_u32_pair(const uint32_t* in0, uint64_t* out0, const uint32_t* in1, uint64_t* out1, size_t n,
-                          void* temp, const Tuning& tn, hipStream_t st) {
+                          void* temp, const Tuning& tn, hipStream_t st, uint64_t* host_total) {
   if (n <= SCAN_SMALL_MAX) {
-    hipLaunchKernelGGL(scan_small_kernel, dim3(1), dim3(1024), 0, st, in0, out0, in1, out1, n, (uint64_t*)nullptr);
+    hipLaunchKernelGGL(scan_small_kernel, dim3(1), dim3(1024), 0, st, in0, out0, in1, out1, n, host_total);
   } else {
-    launch_scan_u32(in0, n, out0, temp, tn, st);
+    launch_scan_u32(in0, n, out0, temp, tn, st, host_total);
     if (in1) launch_scan_u32(in1, n, out1, temp, tn, st);
   }
 }

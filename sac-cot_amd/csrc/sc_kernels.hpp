@@ -29,7 +29,7 @@ struct Tuning {
   uint32_t score_split = 0;        // share (of 256) of the hypotheses scored on the matrix pipe
   bool compat_one_phase = false;   // exact chain on every pair of an interior tile
   int compat_rows = 16;            // tile height of stage A: 16 or 64
-  uint32_t compat_store_mode = 0;  // bit 0: 4-byte S stores (round 1's form), bit 1: non-temporal S stores
+  uint32_t compat_store_mode = 0;  // 0: by size; bit 0: force 4-byte S stores, bit 2: force 16-byte, bit 1: non-temporal
 };
 
 // Device view of the padded SoA point planes: px py pz qx qy qz, each `ld` floats (ld = roundup(n,64)),
@@ -56,8 +56,13 @@ void launch_compat(const Points& pts, const Derived& dv, float* S, uint64_t* bit
                    hipStream_t st);
 // deg[i] = edges of i; degp[i] = edges (i,j) with j > i; wpre: n x (ld/64) u32, set bits of row i in words [0,w).
 // zero_rows (optional): an n x W u64 matrix cleared on the way (the pruned bit matrix of stage B).
+// rowcost (optional, n u32): per-row estimate of stage B's work (see row_stats_kernel), for launch_shard_split.
 void launch_row_stats(const Points& pts, const uint64_t* bits, uint32_t* deg, uint32_t* degp, uint32_t* wpre,
-                      uint64_t* zero_rows, hipStream_t st);
+                      uint64_t* zero_rows, uint32_t* rowcost, hipStream_t st);
+// this rank's contiguous, equally heavy row range (own_row[0..1]) and its CSR edge range (own_edge[0..1])
+// from the exclusive prefix of rowcost (n + 1 entries) — device-side, identical on every rank.
+void launch_shard_split(const uint64_t* cost_pre, const uint64_t* edge_off, int n, uint32_t rank, uint32_t world,
+                        uint32_t* own_row, uint64_t* own_edge, hipStream_t st);
 
 // ---- exclusive scan u32 -> u64 (out has n+1 entries; out[n] = total) -----------------------------
 // host_total (optional): host-pinned u64 that also receives the total, written by the kernel itself — the host
@@ -65,9 +70,9 @@ void launch_row_stats(const Points& pts, const uint64_t* bits, uint32_t* deg, ui
 size_t scan_temp_bytes(size_t n);
 void launch_scan_u32(const uint32_t* in, size_t n, uint64_t* out, void* temp, const Tuning& tn, hipStream_t st,
                      uint64_t* host_total = nullptr);
-// two arrays of the same length in one go (one launch when n is small); in1/out1 may be null
+// two arrays of the same length in one go (one launch when n is small); in1/out1 may be null; host_total: of array 0
 void launch_scan_u32_pair(const uint32_t* in0, uint64_t* out0, const uint32_t* in1, uint64_t* out1, size_t n,
-                          void* temp, const Tuning& tn, hipStream_t st);
+                          void* temp, const Tuning& tn, hipStream_t st, uint64_t* host_total = nullptr);
 
 // ---- stage B: triangles_topT ---------------------------------------------------------------------
 struct Graph {
@@ -87,7 +92,8 @@ void launch_edge_fill(const Graph& g, const Points& pts, const Derived& dv, cons
 // tcnt[e] = #k > j adjacent (in `mbits`) to both ends of edge e = (i,j); edges with es[e] < *smin count 0
 // (smin == nullptr: no pruning, mbits = g.bits).
 void launch_tri_count(const Graph& g, const uint64_t* mbits, const float* es, const float* smin, const uint32_t* ei,
-                      const uint32_t* ej, uint64_t E, uint32_t* tcnt, const Tuning& tn, hipStream_t st);
+                      const uint32_t* ej, uint64_t E, uint32_t* tcnt, const uint64_t* own, const Tuning& tn,
+                      hipStream_t st);  // own (optional, device): [lo, hi) of the edges this rank enumerates
 // Compact list of the strong edges (those of the pruned graph), written by the pruning kernel in ST_SHARDS regions of
 // `cap` entries (fill[r] = entries of region r; ST_SHARDS zeroed counters of the control block).  list == nullptr: off.
 constexpr int ST_SHARDS = 256;
@@ -112,7 +118,7 @@ void launch_sample_hist(const Graph& g, const uint32_t* ebi, const uint32_t* ebj
                         uint32_t parts, uint32_t* hist, const Tuning& tn, hipStream_t st);
 void launch_prune_bits(const Graph& g, const uint32_t* hist, const uint32_t* ei, const uint32_t* ej, const float* es,
                        uint64_t E, uint64_t want, float key_floor, uint64_t* mbits, float* smin, uint32_t* klb,
-                       const StrongList& sl, uint32_t* tcnt, hipStream_t st);
+                       const StrongList& sl, uint32_t* tcnt, const uint64_t* own, hipStream_t st);
 
 // Event list of stage B (sc_tri.hip 2b): one record per non-zero member word of a strong edge, SoA, split into
 // EV_SHARDS regions of shard_cap records; fill[shard] = records appended to that region.
@@ -160,9 +166,11 @@ struct ControlBlock {
   uint32_t amx_ticket;       // blocks-finished counter of score_argmax_kernel
   uint32_t klb;              // key of the certified lower bound of the pruning (0: none)
   uint32_t fin_rank, fin_ticket;  // finalize_kernel: rank-count accumulator, blocks-finished counter (left zero)
-  uint32_t pad0[11];
+  uint32_t own_row[2];       // sharded stage B: this rank's row range [lo, hi) ...
+  uint32_t pad0[9];
   uint64_t key2[2];          // internal winner key pair (sc_register_device)
-  uint64_t pad1[6];
+  uint64_t own_edge[2];      // ... and its CSR edge range (launch_shard_split)
+  uint64_t pad1[4];
   SelectState sel;
 };
 static_assert(offsetof(ControlBlock, sel) % 16 == 0, "ControlBlock::sel must be 16-byte aligned");
@@ -172,7 +180,7 @@ static_assert(offsetof(ControlBlock, sel) % 16 == 0, "ControlBlock::sel must be 
 void launch_tri_keys(const Graph& g, const uint64_t* mbits, const float* smin, const uint32_t* ebase,
                      const uint32_t* ei, const uint32_t* ej, const float* es, const uint64_t* toff, uint64_t E,
                      int rank_mode, uint32_t* wkey, uint2* kcol, uint32_t* blk_minmax, SelectState* s,
-                     uint64_t want, const Tuning& tn, hipStream_t st);  // kcol[ordinal] = {the triangle's third vertex, its edge id}
+                     uint64_t want, const uint64_t* own, const Tuning& tn, hipStream_t st);  // kcol[ordinal] = {the triangle's third vertex, its edge id}
 // keys from the event list (replaces launch_tri_keys when no region overflowed)
 void launch_tri_keys_events(const Graph& g, const float* es, const uint64_t* toff, int rank_mode,
                             const EventList& ev, uint32_t* wkey, uint2* kcol, uint32_t* blk_minmax,
@@ -180,15 +188,48 @@ void launch_tri_keys_events(const Graph& g, const float* es, const uint64_t* tof
                             const Tuning& tn, hipStream_t st);  // cap: entries of wkey / kcol (writes beyond are dropped); want is clipped to toff[E]
 // klb != nullptr (weight ranking, every edge weight >= 2/3): the kernel presets the select window to
 // [*klb or 2.0, 3.0] and no key-range pass runs; two select rounds then always suffice.
+// A key array as the select / compaction kernels see it.  Plain (seg_len == 0): M keys at base.  Segmented (the
+// all-gathered candidate blobs of sharded stage B): M = segments x seg_len logical entries, seg_len a multiple of 1024;
+// segment s holds valid[s * valid_stride] real keys at base + s * seg_stride, the rest of it reads as 0.
+struct KeyView {
+  const uint32_t* base;
+  uint64_t M;
+  uint64_t seg_len;
+  uint64_t seg_stride;    // u32 words between segment starts
+  const uint64_t* valid;  // real keys of segment s: valid[s * valid_stride]
+  uint64_t valid_stride;  // u64 words
+};
+KeyView plain_view(const uint32_t* wkey, uint64_t M);
 // `rounds` launches (histogram + pick by the last block to finish; 12 key bits each) find the exact threshold key
-void launch_select_rounds(const uint32_t* wkey, uint64_t M, SelectState* s, int rounds, const Tuning& tn, hipStream_t st);
+void launch_select_rounds(const KeyView& view, SelectState* s, int rounds, const Tuning& tn, hipStream_t st);
 // compaction of the selected keys in ordinal order
 size_t compact_blocks(uint64_t M);
-void launch_compact_count(const uint32_t* wkey, uint64_t M, const SelectState* s, uint32_t* blk_gt,
-                          uint32_t* blk_eq, hipStream_t st);
-void launch_compact_write(const uint32_t* wkey, uint64_t M, const SelectState* s, const uint32_t* blk_gt,
+void launch_compact_count(const KeyView& view, const SelectState* s, uint32_t* blk_gt, uint32_t* blk_eq,
+                          hipStream_t st);
+void launch_compact_write(const KeyView& view, const SelectState* s, const uint32_t* blk_gt,
                           const uint32_t* blk_eq, const uint64_t* off_gt, const uint64_t* off_eq,
                           uint64_t* sel_ord, uint32_t* sel_key, hipStream_t st);
+
+// ---- sharded stage B: the candidate blob a rank sends, and the merge of the gathered blobs ----
+constexpr int CAND_HDR_WORDS = 32;  // u64 words: [0] triangles enumerated, [1] entries sent, [2] local threshold key,
+                                    // [3] / [4] a key range containing every key sent
+struct CandBlob {
+  uint64_t* hdr;
+  uint32_t* keys;  // cap entries, (i,j,k) ascending
+  uint4* recs;     // cap entries {i, j, k, key}
+  size_t cap;
+};
+size_t cand_cap(uint32_t T);         // entries per blob: T rounded up to 1024 (a rank never contributes more than T)
+size_t cand_blob_bytes(uint32_t T);  // bytes per rank
+CandBlob cand_blob(void* blob, uint32_t T);
+// this rank's selection (sel_ord / sel_key, n_max an upper bound of its length) -> blob
+void launch_cand_emit(const uint64_t* sel_ord, const uint32_t* sel_key, const uint2* kcol, const uint32_t* ei,
+                      const uint32_t* ej, const SelectState* sel, const uint64_t* toff, uint64_t E, uint32_t n_max,
+                      const CandBlob& b, hipStream_t st);
+// sums the gathered headers, arms `sel` for the merge select; host_out[0] <- T_eff (polled), host_out[1] <- triangles
+void launch_merge_prepare(const void* blobs, size_t blob_bytes, uint32_t world, uint32_t T, bool fast, const uint32_t* klb,
+                          SelectState* sel, uint64_t* host_out, hipStream_t st);
+KeyView cand_view(const void* blobs, size_t blob_bytes, uint32_t world, uint32_t T);
 // ranked order: sortkey ascending = (key desc, ordinal asc).  Implemented with rocPRIM (sc_sort.hip).
 size_t sort_temp_bytes(size_t n);
 void launch_sort_u64(const uint64_t* in, uint64_t* out, size_t n, void* temp, size_t temp_bytes, hipStream_t st);
@@ -215,6 +256,10 @@ struct TriSource {
   const uint2* kcol;
   const uint32_t* ei;
   const uint32_t* ej;
+  // sharded stage B: sel_ord[g] is a logical position in the gathered candidate blobs; its record {i, j, k, key}
+  // is cand_recs[(pos / cand_seg) * cand_stride + pos % cand_seg]   (cand_recs == nullptr: the local form above)
+  const uint4* cand_recs;
+  uint64_t cand_seg, cand_stride;  // entries per blob; uint4 units between blob record arrays
 };
 // C1: RtSoA[c * ld_local + l], c = 0..11, for the local hypotheses of the shard (global rank index derived).
 void launch_kabsch(const Points& pts, const TriSource& ts, const Shard& sh, float* RtSoA, hipStream_t st);

@@ -53,6 +53,12 @@ __device__ __forceinline__ void load_triangle(const float* __restrict__ planes, 
 
 // triangle g of the selected list, straight from the selection (two dependent lookups, no materialised list)
 __device__ __forceinline__ void tri_lookup(const TriSource& ts, uint32_t g, uint32_t v[3]) {
+  if (ts.cand_recs) {  // sharded stage B: the record travels with the candidate
+    const uint64_t pos = ts.sel_ord[g], sg = pos / ts.cand_seg;
+    const uint4 rec = ts.cand_recs[sg * ts.cand_stride + (pos - sg * ts.cand_seg)];
+    v[0] = rec.x; v[1] = rec.y; v[2] = rec.z;
+    return;
+  }
   const uint2 ke = ts.kcol[ts.sel_ord[g]];
   v[0] = ts.ei[ke.y];
   v[1] = ts.ej[ke.y];

@@ -158,9 +158,12 @@ __global__ __launch_bounds__(256) void tri_count_kernel(const uint64_t* __restri
                                                         const uint32_t* __restrict__ ej,
                                                         const float* __restrict__ es,
                                                         const float* __restrict__ smin, uint64_t E,
-                                                        uint32_t* __restrict__ tcnt) {
+                                                        uint32_t* __restrict__ tcnt,
+                                                        const uint64_t* __restrict__ own) {
+  // own (optional): [lo, hi) of the edges this rank enumerates (sharded stage B); the others count 0
   const int gl = threadIdx.x & (TG - 1);
   const float s_floor = smin ? *smin : -1.0f;
+  const uint64_t own_lo = own ? own[0] : 0ull, own_hi = own ? own[1] : E;
   const uint64_t groups = (uint64_t)gridDim.x * (256 / TG);
   const uint64_t g0 = (uint64_t)blockIdx.x * (256 / TG) + (threadIdx.x / TG);
   for (uint64_t e0 = g0 * EB; e0 < E; e0 += groups * EB) {  // a group owns EB consecutive edges per trip
@@ -174,7 +177,7 @@ __global__ __launch_bounds__(256) void tri_count_kernel(const uint64_t* __restri
       const uint64_t ec = on[q] ? e : 0;
       const float s = es[ec];
       const uint32_t i = ei[ec], j = ej[ec];
-      on[q] = on[q] && (s >= s_floor);
+      on[q] = on[q] && (s >= s_floor) && e >= own_lo && e < own_hi;
       rowi[q] = i * (uint32_t)W; rowj[q] = j * (uint32_t)W;
       w0[q] = (int)(j >> 6); jb[q] = (int)(j & 63);
       c[q] = 0;
@@ -208,13 +211,14 @@ __global__ __launch_bounds__(256) void tri_count_kernel(const uint64_t* __restri
 }
 
 void launch_tri_count(const Graph& g, const uint64_t* mbits, const float* es, const float* smin, const uint32_t* ei,
-                      const uint32_t* ej, uint64_t E, uint32_t* tcnt, const Tuning& tn, hipStream_t st) {
+                      const uint32_t* ej, uint64_t E, uint32_t* tcnt, const uint64_t* own, const Tuning& tn,
+                      hipStream_t st) {
   if (E == 0) return;
   const int tg = tn.tg_count;
   const uint64_t per = (uint64_t)(256 / tg) * EB;
   uint64_t nb = (E + per - 1) / per;
   if (nb > 4096) nb = 4096;
-#define SC_LAUNCH_COUNT(TGV) hipLaunchKernelGGL(tri_count_kernel<TGV>, dim3((unsigned)nb), dim3(256), 0, st, mbits, g.W, ei, ej, es, smin, E, tcnt)
+#define SC_LAUNCH_COUNT(TGV) hipLaunchKernelGGL(tri_count_kernel<TGV>, dim3((unsigned)nb), dim3(256), 0, st, mbits, g.W, ei, ej, es, smin, E, tcnt, own)
   if (tg == 4) SC_LAUNCH_COUNT(4); else if (tg == 8) SC_LAUNCH_COUNT(8); else if (tg == 32) SC_LAUNCH_COUNT(32); else SC_LAUNCH_COUNT(16);
 #undef SC_LAUNCH_COUNT
 }
@@ -242,9 +246,11 @@ __global__ __launch_bounds__(256) void tri_keys_kernel(const uint64_t* __restric
                                                        int rank_mode, uint32_t* __restrict__ wkey,
                                                        uint2* __restrict__ kcol,
                                                        uint32_t* __restrict__ blk_min,
-                                                       uint32_t* __restrict__ blk_max) {
+                                                       uint32_t* __restrict__ blk_max,
+                                                       const uint64_t* __restrict__ own) {
   __shared__ uint32_t lmin[4], lmax[4];
   const int gl = threadIdx.x & (TG - 1);
+  const uint64_t own_lo = own ? own[0] : 0ull, own_hi = own ? own[1] : E;
   const uint64_t gmask = (TG == 64) ? ~0ull : (((1ull << TG) - 1ull) << ((threadIdx.x & 63) & ~(TG - 1)));
   uint32_t kmin = 0xFFFFFFFFu, kmax = 0;
   const uint64_t groups = (uint64_t)gridDim.x * (256 / TG);
@@ -252,7 +258,7 @@ __global__ __launch_bounds__(256) void tri_keys_kernel(const uint64_t* __restric
   const float s_floor = smin ? *smin : -1.0f;
   for (uint64_t e = (uint64_t)blockIdx.x * (256 / TG) + (threadIdx.x / TG); e < E; e += groups) {
     const float s_ij = es[e];
-    if (s_ij < s_floor) continue;  // group-uniform: the edge is outside the pruned graph
+    if (s_ij < s_floor || e < own_lo || e >= own_hi) continue;  // group-uniform: outside the pruned graph / not this rank's
     const uint32_t i = ei[e], j = ej[e];
     const uint32_t rowi = i * (uint32_t)W, rowj = j * (uint32_t)W;  // word offsets: n * W < 2^32
     const int w0 = j >> 6;
@@ -355,11 +361,11 @@ size_t tri_keys_blocks(uint64_t E, int tg) {
 void launch_tri_keys(const Graph& g, const uint64_t* mbits, const float* smin, const uint32_t* ebase,
                      const uint32_t* ei, const uint32_t* ej, const float* es, const uint64_t* toff, uint64_t E,
                      int rank_mode, uint32_t* wkey, uint2* kcol, uint32_t* blk_minmax, SelectState* s,
-                     uint64_t want, const Tuning& tn, hipStream_t st) {
+                     uint64_t want, const uint64_t* own, const Tuning& tn, hipStream_t st) {
   if (E == 0) return;
   const int tg = tn.tg_keys;
   const int nb = (int)tri_keys_blocks(E, tg);
-#define SC_LAUNCH_KEYS(TGV) hipLaunchKernelGGL(tri_keys_kernel<TGV>, dim3(nb), dim3(256), 0, st, g.bits, mbits, smin, g.W, g.deg, g.wpre, ebase, ei, ej, es, toff, E, rank_mode, wkey, kcol, blk_minmax, blk_minmax + TK_MAX_BLOCKS)
+#define SC_LAUNCH_KEYS(TGV) hipLaunchKernelGGL(tri_keys_kernel<TGV>, dim3(nb), dim3(256), 0, st, g.bits, mbits, smin, g.W, g.deg, g.wpre, ebase, ei, ej, es, toff, E, rank_mode, wkey, kcol, blk_minmax, blk_minmax + TK_MAX_BLOCKS, own)
   if (tg == 4) SC_LAUNCH_KEYS(4); else if (tg == 8) SC_LAUNCH_KEYS(8); else if (tg == 32) SC_LAUNCH_KEYS(32); else if (tg == 64) SC_LAUNCH_KEYS(64); else SC_LAUNCH_KEYS(16);
 #undef SC_LAUNCH_KEYS
   hipLaunchKernelGGL(key_range_kernel, dim3(1), dim3(1024), 0, st, blk_minmax, blk_minmax + TK_MAX_BLOCKS, nb, s, want);
@@ -751,7 +757,8 @@ __global__ __launch_bounds__(256) void prune_bits_kernel(const uint32_t* __restr
                                                          unsigned long long* __restrict__ mbits,
                                                          float* __restrict__ smin_out,
                                                          uint32_t* __restrict__ klb_out, StrongList sl,
-                                                         uint32_t* __restrict__ tcnt) {
+                                                         uint32_t* __restrict__ tcnt,
+                                                         const uint64_t* __restrict__ own) {
   __shared__ uint64_t lds[8];
   __shared__ float s_smin;
   __shared__ uint32_t s_klb, s_base, s_wcnt[4];
@@ -770,11 +777,13 @@ __global__ __launch_bounds__(256) void prune_bits_kernel(const uint32_t* __restr
   const float smin = s_smin;
   if (blockIdx.x == 0 && threadIdx.x == 0) { *smin_out = smin; *klb_out = s_klb; }
   const uint64_t e = (uint64_t)blockIdx.x * 256 + threadIdx.x;
-  const bool strong = e < E && es[e] >= smin;
-  if (strong) {
+  bool strong = e < E && es[e] >= smin;
+  if (strong) {  // the strong bit matrix is whole on every rank: membership of ANY vertex pair is looked up in it
     const uint32_t i = ei[e], j = ej[e];
     atomicOr(&mbits[(size_t)i * W + (j >> 6)], 1ull << (j & 63));
   }
+  // sharded stage B: only this rank's edge range [own[0], own[1]) enters the list of edges to enumerate
+  if (own) strong = strong && e >= own[0] && e < own[1];
   if (sl.list) {
     // the strong edges, compacted (any order: everything downstream is indexed by the edge id): one atomic per block
     // on one of ST_SHARDS counters; region r receives the blocks with blockIdx % ST_SHARDS == r, so sl.cap =
@@ -844,11 +853,11 @@ void launch_sample_hist(const Graph& g, const uint32_t* ebi, const uint32_t* ebj
 
 void launch_prune_bits(const Graph& g, const uint32_t* hist, const uint32_t* ei, const uint32_t* ej, const float* es,
                        uint64_t E, uint64_t want, float key_floor, uint64_t* mbits, float* smin, uint32_t* klb,
-                       const StrongList& sl, uint32_t* tcnt, hipStream_t st) {
+                       const StrongList& sl, uint32_t* tcnt, const uint64_t* own, hipStream_t st) {
   uint32_t klo, shift;
   prune_window(key_floor, &klo, &shift);
   hipLaunchKernelGGL(prune_bits_kernel, dim3((unsigned)((E + 255) / 256)), dim3(256), 0, st, hist, want, klo, shift, ei,
-                     ej, es, E, g.W, reinterpret_cast<unsigned long long*>(mbits), smin, klb, sl, tcnt);
+                     ej, es, E, g.W, reinterpret_cast<unsigned long long*>(mbits), smin, klb, sl, tcnt, own);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -906,8 +915,28 @@ __device__ __forceinline__ void hist_add(uint32_t* lh, bool in, uint32_t bin) {
 // one launch per round instead of a histogram launch plus a pick launch.  Hand-off per cdna guide §6 G16, counter
 // form: hist adds are device-scope atomics; each block fences (release) before its ticket; the last block fences
 // (acquire) and reads the bins with device-scope atomic loads.
-__global__ __launch_bounds__(SEL_THREADS) void select_round_kernel(const uint32_t* __restrict__ wkey, uint64_t M,
-                                                                   SelectState* __restrict__ sel, int rounds_left) {
+// four keys of the view at logical positions 4q .. 4q + 3 (entries beyond a segment's valid count read as 0, which
+// no window and no threshold ever admits: real keys are positive)
+template <bool SEG>
+__device__ __forceinline__ uint4 view_load4(const KeyView& v, uint64_t q) {
+  if (!SEG) return reinterpret_cast<const uint4*>(v.base)[q];
+  const uint64_t x = q << 2, sg = x / v.seg_len, off = x - sg * v.seg_len;  // seg_len % 4 == 0: no straddling
+  const uint64_t nv = v.valid[sg * v.valid_stride];
+  uint4 k = make_uint4(0u, 0u, 0u, 0u);
+  if (off < nv) {
+    k = *reinterpret_cast<const uint4*>(v.base + sg * v.seg_stride + off);
+    if (off + 1 >= nv) k.y = 0u;
+    if (off + 2 >= nv) k.z = 0u;
+    if (off + 3 >= nv) k.w = 0u;
+  }
+  return k;
+}
+
+template <bool SEG>
+__global__ __launch_bounds__(SEL_THREADS) void select_round_kernel(KeyView view, SelectState* __restrict__ sel,
+                                                                   int rounds_left) {
+  const uint64_t M = view.M;
+  const uint32_t* __restrict__ wkey = view.base;
   __shared__ uint32_t lh[SEL_BINS];
   __shared__ uint64_t lds[8];
   __shared__ uint32_t s_bin, s_last;
@@ -920,10 +949,9 @@ __global__ __launch_bounds__(SEL_THREADS) void select_round_kernel(const uint32_
   const uint64_t want = sel->want, above0 = sel->above;
   const uint64_t width = 1ull << win.wbits;
   const uint64_t M4 = M >> 2;  // whole uint4 groups (wkey comes from hipMalloc: 16-byte aligned)
-  const uint4* __restrict__ wkey4 = reinterpret_cast<const uint4*>(wkey);
   const uint64_t stride = (uint64_t)gridDim.x * SEL_THREADS;
   for (uint64_t q = (uint64_t)blockIdx.x * SEL_THREADS + threadIdx.x; q < M4; q += stride) {
-    const uint4 k4 = wkey4[q];
+    const uint4 k4 = view_load4<SEG>(view, q);
     const uint32_t ks[4] = {k4.x, k4.y, k4.z, k4.w};
 #pragma unroll
     for (int c = 0; c < 4; c++) {
@@ -931,7 +959,7 @@ __global__ __launch_bounds__(SEL_THREADS) void select_round_kernel(const uint32_
       hist_add(lh, (ks[c] >= win.lo) && (rel < width), (uint32_t)(rel >> win.shift));
     }
   }
-  if (blockIdx.x == 0 && threadIdx.x < (M & 3)) {  // tail
+  if (!SEG && blockIdx.x == 0 && threadIdx.x < (M & 3)) {  // tail (a segmented view is a whole number of groups)
     const uint32_t key = wkey[(M4 << 2) + threadIdx.x];
     const uint64_t rel = (uint64_t)key - (uint64_t)win.lo;
     if ((key >= win.lo) && (rel < width)) atomicAdd(&lh[(uint32_t)(rel >> win.shift)], 1u);
@@ -975,12 +1003,16 @@ __global__ __launch_bounds__(SEL_THREADS) void select_round_kernel(const uint32_
   if (threadIdx.x == 0) { s_bin = 0; s_above = above0; }
   uint64_t tot;
   const uint64_t before = above0 + block_exscan_u64(mine, lds, &tot);
+  // A window may hold fewer than want - above0 keys only where a rank selects among ITS triangles alone (sharded
+  // stage B: the certified bound promises T keys above it in the whole graph, not in one rank's share): then every key
+  // of the window is taken.  (Unsharded, the window always holds enough and this changes nothing.)
+  const uint64_t want_eff = want < above0 + tot ? want : above0 + tot;
   // the crossing thread: before < want <= before + mine (exactly one: the window holds >= want - above0 keys)
-  if (before < want && want <= before + mine) {
+  if (before < want_eff && want_eff <= before + mine) {
     uint64_t run = before;
 #pragma unroll
     for (int k = 0; k < SEL_PER; k++) {
-      if (k < per && run < want && want <= run + h[k]) { s_bin = (uint32_t)(nbins - 1 - ((int)threadIdx.x * per + k)); s_above = run; }
+      if (k < per && run < want_eff && want_eff <= run + h[k]) { s_bin = (uint32_t)(nbins - 1 - ((int)threadIdx.x * per + k)); s_above = run; }
       run += h[k];
     }
   }
@@ -993,11 +1025,15 @@ __global__ __launch_bounds__(SEL_THREADS) void select_round_kernel(const uint32_
     sel->wbits = win.shift;  // the chosen bin is the next window
     sel->started = 1;
     sel->ticket = 0;
-    if (win.shift == 0) { sel->done = 1; sel->kstar = nlo; sel->need_eq = want - s_above; }
+    sel->want = want_eff;
+    if (win.shift == 0) { sel->done = 1; sel->kstar = nlo; sel->need_eq = want_eff - s_above; }
   }
 }
 
-void launch_select_rounds(const uint32_t* wkey, uint64_t M, SelectState* s, int rounds, const Tuning& tn, hipStream_t st) {
+KeyView plain_view(const uint32_t* wkey, uint64_t M) { return KeyView{wkey, M, 0, 0, nullptr, 0}; }
+
+void launch_select_rounds(const KeyView& view, SelectState* s, int rounds, const Tuning& tn, hipStream_t st) {
+  const uint64_t M = view.M;
   if (M == 0) return;
   uint64_t blocks = (M + (uint64_t)SEL_THREADS * SEL_ITEMS - 1) / ((uint64_t)SEL_THREADS * SEL_ITEMS);
   // 256 blocks measured best on C2 (1.5 M keys): every block pays an agent-scope release for its ticket
@@ -1005,8 +1041,10 @@ void launch_select_rounds(const uint32_t* wkey, uint64_t M, SelectState* s, int 
   if (tn.sel_blocks >= 1) cap = tn.sel_blocks;
   if (blocks > cap) blocks = cap;
   if (blocks == 0) blocks = 1;
-  for (int round = 0; round < rounds; round++)
-    hipLaunchKernelGGL(select_round_kernel, dim3((unsigned)blocks), dim3(SEL_THREADS), 0, st, wkey, M, s, rounds - round);
+  for (int round = 0; round < rounds; round++) {
+    if (view.seg_len) hipLaunchKernelGGL(select_round_kernel<true>, dim3((unsigned)blocks), dim3(SEL_THREADS), 0, st, view, s, rounds - round);
+    else hipLaunchKernelGGL(select_round_kernel<false>, dim3((unsigned)blocks), dim3(SEL_THREADS), 0, st, view, s, rounds - round);
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1018,8 +1056,16 @@ constexpr int CP_TILE = CP_THREADS * CP_ITEMS;
 
 size_t compact_blocks(uint64_t M) { return (size_t)((M + CP_TILE - 1) / CP_TILE); }
 
-__device__ __forceinline__ void load_tile_keys(const uint32_t* __restrict__ wkey, uint64_t M, uint64_t base,
-                                               uint32_t keys[CP_ITEMS], int& valid) {
+template <bool SEG>
+__device__ __forceinline__ void load_tile_keys(const KeyView& view, uint64_t base, uint32_t keys[CP_ITEMS], int& valid) {
+  const uint32_t* __restrict__ wkey = view.base;
+  const uint64_t M = view.M;
+  if (SEG) {  // CP_ITEMS == 4 and seg_len % 4 == 0: one group of the view
+    const uint4 k4 = base < M ? view_load4<true>(view, base >> 2) : make_uint4(0u, 0u, 0u, 0u);
+    keys[0] = k4.x; keys[1] = k4.y; keys[2] = k4.z; keys[3] = k4.w;
+    valid = base < M ? CP_ITEMS : 0;
+    return;
+  }
   if (base + CP_ITEMS <= M) {
     const uint4 k4 = *reinterpret_cast<const uint4*>(wkey + base);
     keys[0] = k4.x; keys[1] = k4.y; keys[2] = k4.z; keys[3] = k4.w;
@@ -1031,7 +1077,9 @@ __device__ __forceinline__ void load_tile_keys(const uint32_t* __restrict__ wkey
   }
 }
 
-__global__ __launch_bounds__(CP_THREADS) void compact_count_kernel(const uint32_t* __restrict__ wkey, uint64_t M,
+static_assert(CP_ITEMS == 4, "load_tile_keys reads one uint4 group of a segmented view");
+template <bool SEG>
+__global__ __launch_bounds__(CP_THREADS) void compact_count_kernel(KeyView view,
                                                                    const SelectState* __restrict__ sel,
                                                                    uint32_t* __restrict__ blk_gt,
                                                                    uint32_t* __restrict__ blk_eq) {
@@ -1040,7 +1088,7 @@ __global__ __launch_bounds__(CP_THREADS) void compact_count_kernel(const uint32_
   const uint64_t base = (uint64_t)blockIdx.x * CP_TILE + (uint64_t)threadIdx.x * CP_ITEMS;
   uint32_t keys[CP_ITEMS];
   int valid;
-  load_tile_keys(wkey, M, base, keys, valid);
+  load_tile_keys<SEG>(view, base, keys, valid);
   uint32_t g = 0, q = 0;
 #pragma unroll
   for (int k = 0; k < CP_ITEMS; k++)
@@ -1055,14 +1103,16 @@ __global__ __launch_bounds__(CP_THREADS) void compact_count_kernel(const uint32_
   }
 }
 
-void launch_compact_count(const uint32_t* wkey, uint64_t M, const SelectState* s, uint32_t* blk_gt,
-                          uint32_t* blk_eq, hipStream_t st) {
-  if (M == 0) return;
-  hipLaunchKernelGGL(compact_count_kernel, dim3((unsigned)compact_blocks(M)), dim3(CP_THREADS), 0, st, wkey, M, s,
-                     blk_gt, blk_eq);
+void launch_compact_count(const KeyView& view, const SelectState* s, uint32_t* blk_gt, uint32_t* blk_eq,
+                          hipStream_t st) {
+  if (view.M == 0) return;
+  const dim3 grid((unsigned)compact_blocks(view.M));
+  if (view.seg_len) hipLaunchKernelGGL(compact_count_kernel<true>, grid, dim3(CP_THREADS), 0, st, view, s, blk_gt, blk_eq);
+  else hipLaunchKernelGGL(compact_count_kernel<false>, grid, dim3(CP_THREADS), 0, st, view, s, blk_gt, blk_eq);
 }
 
-__global__ __launch_bounds__(CP_THREADS) void compact_write_kernel(const uint32_t* __restrict__ wkey, uint64_t M,
+template <bool SEG>
+__global__ __launch_bounds__(CP_THREADS) void compact_write_kernel(KeyView view,
                                                                    const SelectState* __restrict__ sel,
                                                                    const uint32_t* __restrict__ blk_gt,
                                                                    const uint32_t* __restrict__ blk_eq,
@@ -1089,7 +1139,7 @@ __global__ __launch_bounds__(CP_THREADS) void compact_write_kernel(const uint32_
   const uint64_t base = (uint64_t)blockIdx.x * CP_TILE + (uint64_t)threadIdx.x * CP_ITEMS;
   uint32_t keys[CP_ITEMS];
   int valid;
-  load_tile_keys(wkey, M, base, keys, valid);
+  load_tile_keys<SEG>(view, base, keys, valid);
   uint32_t g = 0, q = 0;
 #pragma unroll
   for (int k = 0; k < CP_ITEMS; k++)
@@ -1115,12 +1165,128 @@ __global__ __launch_bounds__(CP_THREADS) void compact_write_kernel(const uint32_
   }
 }
 
-void launch_compact_write(const uint32_t* wkey, uint64_t M, const SelectState* s, const uint32_t* blk_gt,
+void launch_compact_write(const KeyView& view, const SelectState* s, const uint32_t* blk_gt,
                           const uint32_t* blk_eq, const uint64_t* off_gt, const uint64_t* off_eq,
                           uint64_t* sel_ord, uint32_t* sel_key, hipStream_t st) {
-  if (M == 0) return;
-  hipLaunchKernelGGL(compact_write_kernel, dim3((unsigned)compact_blocks(M)), dim3(CP_THREADS), 0, st, wkey, M, s,
-                     blk_gt, blk_eq, off_gt, off_eq, sel_ord, sel_key);
+  if (view.M == 0) return;
+  const dim3 grid((unsigned)compact_blocks(view.M));
+  if (view.seg_len)
+    hipLaunchKernelGGL(compact_write_kernel<true>, grid, dim3(CP_THREADS), 0, st, view, s, blk_gt, blk_eq, off_gt, off_eq,
+                       sel_ord, sel_key);
+  else
+    hipLaunchKernelGGL(compact_write_kernel<false>, grid, dim3(CP_THREADS), 0, st, view, s, blk_gt, blk_eq, off_gt, off_eq,
+                       sel_ord, sel_key);
+}
+
+// ------------------------------------------------------------------------------------------------
+// 5b. sharded stage B: candidate exchange
+//
+// A rank enumerates the triangles of ITS contiguous row range, selects its own top-T among them (the same select and
+// compaction as above, on its own keys) and writes them — in (i,j,k) order — into a fixed-size record, the *blob*, that
+// the caller all-gathers:  header (CAND_HDR_WORDS x u64) | keys[cap] u32 | recs[cap] uint4 {i, j, k, key}.
+// The global top-T is a subset of the union of the ranks' top-T lists, and because the row ranges are contiguous and
+// ascending with the rank, the concatenation of the blobs in rank order IS in global (i,j,k) order: the merge is the
+// same exact select + ordinal-order compaction over the concatenated keys (a segmented KeyView), and every rank gets
+// the identical selected list.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void cand_emit_kernel(const uint64_t* __restrict__ sel_ord,
+                                                        const uint32_t* __restrict__ sel_key,
+                                                        const uint2* __restrict__ kcol,
+                                                        const uint32_t* __restrict__ ei,
+                                                        const uint32_t* __restrict__ ej,
+                                                        const SelectState* __restrict__ sel,
+                                                        const uint64_t* __restrict__ toff, uint64_t E,
+                                                        uint64_t* __restrict__ hdr, uint32_t* __restrict__ keys,
+                                                        uint4* __restrict__ recs, uint64_t cap) {
+  const uint64_t n_sent = sel->want < cap ? sel->want : cap;  // the select clamps want to what its window held
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    hdr[0] = toff[E];      // triangles this rank enumerated
+    hdr[1] = n_sent;
+    hdr[2] = sel->kstar;
+    hdr[3] = sel->kmin;    // a range containing every key sent
+    hdr[4] = sel->kmax;
+  }
+  const uint64_t p = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  if (p >= n_sent) return;
+  const uint2 ke = kcol[sel_ord[p]];
+  const uint32_t key = sel_key[p];
+  keys[p] = key;
+  recs[p] = make_uint4(ei[ke.y], ej[ke.y], ke.x, key);
+}
+
+size_t cand_cap(uint32_t T) { return ((size_t)T + 1023) / 1024 * 1024; }
+size_t cand_blob_bytes(uint32_t T) { return CAND_HDR_WORDS * 8 + cand_cap(T) * (4 + 16); }
+
+CandBlob cand_blob(void* blob, uint32_t T) {
+  CandBlob b;
+  unsigned char* p = static_cast<unsigned char*>(blob);
+  b.hdr = reinterpret_cast<uint64_t*>(p);
+  b.cap = cand_cap(T);
+  b.keys = reinterpret_cast<uint32_t*>(p + CAND_HDR_WORDS * 8);
+  b.recs = reinterpret_cast<uint4*>(p + CAND_HDR_WORDS * 8 + b.cap * 4);
+  return b;
+}
+
+void launch_cand_emit(const uint64_t* sel_ord, const uint32_t* sel_key, const uint2* kcol, const uint32_t* ei,
+                      const uint32_t* ej, const SelectState* sel, const uint64_t* toff, uint64_t E, uint32_t n_max,
+                      const CandBlob& b, hipStream_t st) {
+  const unsigned blocks = n_max ? (n_max + 255) / 256 : 1;
+  hipLaunchKernelGGL(cand_emit_kernel, dim3(blocks), dim3(256), 0, st, sel_ord, sel_key, kcol, ei, ej, sel, toff, E, b.hdr,
+                     b.keys, b.recs, (uint64_t)b.cap);
+}
+
+// One wave: adds up the headers of the `world` gathered blobs and arms the select state for the merge.
+//   want = min(T, candidates sent);   window: [certified bound or 2.0, 3.0] when known a priori (fast != 0), else the
+//   union of the ranks' key ranges.   host_out[0..1] (pinned): T_eff, triangles enumerated by all ranks.
+__global__ __launch_bounds__(64) void merge_prepare_kernel(const uint64_t* __restrict__ blobs, uint64_t blob_words,
+                                                           uint32_t world, uint32_t T, int fast,
+                                                           const uint32_t* __restrict__ klb,
+                                                           SelectState* __restrict__ sel,
+                                                           uint64_t* __restrict__ host_out) {
+  const uint32_t r = threadIdx.x;
+  uint64_t m = 0, ns = 0;
+  uint32_t kmin = 0xFFFFFFFFu, kmax = 0u;
+  for (uint32_t q = r; q < world; q += 64) {
+    const uint64_t* h = blobs + (uint64_t)q * blob_words;
+    m += h[0]; ns += h[1];
+    if (h[1] != 0) { kmin = min(kmin, (uint32_t)h[3]); kmax = max(kmax, (uint32_t)h[4]); }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    m += __shfl_xor(m, o); ns += __shfl_xor(ns, o);
+    kmin = min(kmin, (uint32_t)__shfl_xor(kmin, o)); kmax = max(kmax, (uint32_t)__shfl_xor(kmax, o));
+  }
+  if (r != 0) return;
+  const uint64_t want = ns < (uint64_t)T ? ns : (uint64_t)T;
+  sel->want = want; sel->above = 0; sel->done = 0; sel->ticket = 0;
+  if (fast) {
+    const uint32_t lo = *klb ? *klb : 0x40000000u, hi = 0x40400000u;  // 2.0f, 3.0f
+    const uint32_t range_m1 = hi - lo;
+    sel->lo = lo; sel->wbits = range_m1 == 0 ? 0u : (uint32_t)(32 - __builtin_clz(range_m1));
+    sel->kmin = lo; sel->kmax = hi; sel->started = 1;
+  } else {
+    sel->kmin = kmin <= kmax ? kmin : 0u; sel->kmax = kmin <= kmax ? kmax : 0u; sel->started = 0;
+  }
+  host_out[1] = m;
+  publish_host(host_out, want);
+}
+
+void launch_merge_prepare(const void* blobs, size_t blob_bytes, uint32_t world, uint32_t T, bool fast, const uint32_t* klb,
+                          SelectState* sel, uint64_t* host_out, hipStream_t st) {
+  hipLaunchKernelGGL(merge_prepare_kernel, dim3(1), dim3(64), 0, st, static_cast<const uint64_t*>(blobs),
+                     (uint64_t)(blob_bytes / 8), world, T, fast ? 1 : 0, klb, sel, host_out);
+}
+
+KeyView cand_view(const void* blobs, size_t blob_bytes, uint32_t world, uint32_t T) {
+  const unsigned char* p = static_cast<const unsigned char*>(blobs);
+  KeyView v;
+  v.base = reinterpret_cast<const uint32_t*>(p + CAND_HDR_WORDS * 8);
+  v.seg_len = cand_cap(T);
+  v.M = (uint64_t)world * v.seg_len;
+  v.seg_stride = blob_bytes / 4;
+  v.valid = reinterpret_cast<const uint64_t*>(p) + 1;  // hdr[1] = entries sent
+  v.valid_stride = blob_bytes / 8;
+  return v;
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -84,10 +84,11 @@ def test_compat_threshold_sweep_on_a_scaled_scene(pkg, O, eps, scale, one_phase)
     assert np.array_equal(S1.view(np.uint32), S0.view(np.uint32))
 
 
-@pytest.mark.parametrize("mode", [0, 1, 2, 3])
+@pytest.mark.parametrize("mode", [0, 1, 4, 3, 6])
 def test_compat_store_forms_bit_exact(pkg, O, mode):
-    """Stage A writes S with 16-byte stores by default; sc_debug.compat_store_mode selects round 1's 4-byte stores
-    (bit 0) and non-temporal stores (bit 1).  Same bits in S, the bit rows and the degrees in every form, ragged N."""
+    """Stage A writes S with 4-byte or 16-byte stores depending on the matrix size; sc_debug.compat_store_mode forces
+    either form (bit 0 / bit 2) and adds the non-temporal hint (bit 1).  Same bits in S, the bit rows and the degrees
+    in every form, ragged N."""
     sc = pkg.synth.make_scene(1337, 0.3, 1.0, 0.05, seed=5)
     kw = _params(pkg, 0.05, 10)
     r = pkg.Registrar(0)
@@ -652,3 +653,125 @@ def test_refine_matches_oracle_and_improves(pkg, O, reg, name):
     e0 = pkg.synth.rotation_error_deg(base["R"], scene.R_gt); e1 = pkg.synth.rotation_error_deg(got["R"], scene.R_gt)
     assert e1 <= e0 + 1e-3 and e1 < 0.5
     assert np.linalg.norm(got["t"] - scene.t_gt) <= np.linalg.norm(base["t"] - scene.t_gt) + 1e-4
+
+
+# ---------------------------------------------------------------------------------------------------------
+# stages A and B sharded: the phase API, every "rank" a context of its own on this one GPU
+# ---------------------------------------------------------------------------------------------------------
+def _run_sharded_ab(pkg, n, kw, d_src, d_tgt, world, flags=0, regs=None, block=256):
+    """The whole sharded call for `world` ranks on one GPU.  The ranks share the exchange buffers, which is exactly what
+    the collectives deliver: the in-place all-gather of the bit rows and of the candidate blobs are no-ops here, the
+    histogram all-reduce is a host-side sum.  Returns (rc, stats, Rt, mask, per-rank enumerated)."""
+    import torch
+    dev = torch.device("cuda:0")
+    own = regs is None
+    regs = regs or [pkg.Registrar(0) for _ in range(world)]
+    try:
+        ps = [pkg.make_params(shard_rank=r, shard_world=world, shard_block=block, flags=flags, **kw) for r in range(world)]
+        plan = pkg.shard_plan(ps[0], n)
+        d_bits = torch.zeros(plan.bits_bytes_total // 8, dtype=torch.int64, device=dev)
+        d_hists = [torch.zeros(pkg.SC_HIST_WORDS, dtype=torch.int32, device=dev) for _ in range(world)]
+        d_cand = torch.zeros(world * plan.cand_bytes_per_rank // 8, dtype=torch.int64, device=dev)
+        d_keys = torch.zeros(2 * world, dtype=torch.int64, device=dev)
+        d_Rt = torch.zeros(12, dtype=torch.float32, device=dev); d_mask = torch.zeros(n, dtype=torch.uint8, device=dev)
+        torch.cuda.synchronize()
+        for r in range(world):
+            regs[r].shard_compat_device(d_src.data_ptr(), d_tgt.data_ptr(), n, ps[r], d_bits.data_ptr())
+        torch.cuda.synchronize()                                   # (all-gather of the bit rows: shared buffer)
+        for r in range(world):
+            regs[r].shard_edges_device(d_hists[r].data_ptr())
+        torch.cuda.synchronize()
+        total = sum(h.cpu().numpy().view(np.uint32).astype(np.uint64) for h in d_hists)
+        summed = torch.from_numpy((total & np.uint64(0xFFFFFFFF)).astype(np.uint32).view(np.int32)).to(dev)
+        for r in range(world):                                     # (all-reduce SUM of the sample histograms)
+            d_hists[r].copy_(summed)
+        torch.cuda.synchronize()
+        for r in range(world):
+            regs[r].shard_select_device(d_hists[r].data_ptr(), d_cand.data_ptr() + r * plan.cand_bytes_per_rank)
+        torch.cuda.synchronize()                                   # (all-gather of the candidate blobs: shared buffer)
+        hdr = d_cand.cpu().numpy().view(np.uint64).reshape(world, -1)[:, :2]
+        scored = 0
+        for r in range(world):
+            st = regs[r].shard_score_device(d_cand.data_ptr(), d_keys.data_ptr() + 16 * r)
+            scored += st["tri_scored"]
+        torch.cuda.synchronize()                                   # (all-gather of the key pairs: shared buffer)
+        out = []
+        for r in range(world):
+            rc, st = regs[r].finalize_gathered_device(d_keys.data_ptr(), world, d_Rt.data_ptr(), d_mask.data_ptr())
+            torch.cuda.synchronize()
+            out.append((rc, st, d_Rt.cpu().numpy().copy(), d_mask.cpu().numpy().copy()))
+        for o in out[1:]:                                          # every rank ends with the same answer
+            assert o[0] == out[0][0] and o[2].tobytes() == out[0][2].tobytes() and np.array_equal(o[3], out[0][3])
+            assert o[1]["best_rank"] == out[0][1]["best_rank"]
+        rc, st, Rt, mask = out[0]
+        assert scored == st["tri_kept"]
+        return rc, st, Rt, mask, hdr
+    finally:
+        if own:
+            for g in regs:
+                g.close()
+
+
+@pytest.mark.parametrize("name,worlds", [("C0", (1, 2, 5)), ("C1", (1, 2, 3, 8)), ("C2", (2, 8))])
+def test_sharded_A_and_B_equal_unsharded(pkg, O, reg, name, worlds):
+    """stage A by row blocks, stage B by contiguous row ranges, candidates merged with the same total
+    order.  For every world size the winner, its rank index, (R,t) and the mask must equal the unsharded run's (and the
+    CPU restatement's) bit for bit, and the ranks' row ranges must partition the enumeration."""
+    import torch
+    cfg, scene = pkg.synth.make_config_scene(name)
+    kw = cfg.params()
+    base = reg.register(scene.src, scene.tgt, **kw)
+    ref = O.register(scene.src, scene.tgt, threads=8, **kw)
+    assert base["stats"]["best_rank"] == ref["best_rank"]
+    dev = torch.device("cuda:0")
+    d_src = torch.from_numpy(scene.src).to(dev); d_tgt = torch.from_numpy(scene.tgt).to(dev)
+    for world in worlds:
+        rc, st, Rt, mask, hdr = _run_sharded_ab(pkg, cfg.n, kw, d_src, d_tgt, world)
+        assert rc == 0, world
+        assert (st["best_rank"], st["best_count"], st["tri_kept"]) == (ref["best_rank"], ref["best_count"], ref["t_eff"]), world
+        assert st["edges"] == ref["edges"] and np.array_equal(mask, ref["mask"]), world
+        assert Rt.tobytes() == np.concatenate([ref["R"].ravel(), ref["t"]]).astype(np.float32).tobytes(), world
+        assert int(hdr[:, 0].sum()) == st["tri_total"] == base["stats"]["tri_total"], world   # the ranges partition the enumeration
+        if world > 1 and name != "C0":
+            share = hdr[:, 0].astype(np.float64) / hdr[:, 0].sum()
+            assert share.max() < 2.5 / world, (world, share)        # equally heavy row ranges, roughly
+
+
+@pytest.mark.parametrize("extra", [dict(rank_mode=1), dict(flags=4), dict(flags=32), dict(t_cmp=0.5), dict(max_triangles=10_000_000)])
+def test_sharded_A_and_B_other_modes(pkg, O, extra):
+    """The sharded phases where the certificate does not run (degree ranking, SC_FLAG_NO_PRUNE), without the dense
+    matrix, with the key window taken from the data (t_cmp < 2/3) and with T larger than the number of triangles."""
+    import torch
+    cfg, scene = pkg.synth.make_config_scene("C1" if "max_triangles" not in extra else "C0")
+    kw = dict(cfg.params(), **{k: v for k, v in extra.items() if k != "flags"})
+    flags = extra.get("flags", 0)
+    ref = O.register(scene.src, scene.tgt, threads=8, **kw)
+    dev = torch.device("cuda:0")
+    d_src = torch.from_numpy(scene.src).to(dev); d_tgt = torch.from_numpy(scene.tgt).to(dev)
+    for world in (2, 3):
+        rc, st, Rt, mask, _ = _run_sharded_ab(pkg, cfg.n, kw, d_src, d_tgt, world, flags=flags)
+        assert rc == ref["rc"] == 0
+        assert (st["best_rank"], st["best_count"], st["tri_kept"]) == (ref["best_rank"], ref["best_count"], ref["t_eff"])
+        assert np.array_equal(mask, ref["mask"])
+        assert Rt.tobytes() == np.concatenate([ref["R"].ravel(), ref["t"]]).astype(np.float32).tobytes()
+
+
+def test_sharded_A_and_B_massive_ties_and_no_triangles(pkg, O):
+    """Ties decide almost the whole selection on a noise-free all-inlier scene (the concatenation order of the blobs
+    must then BE the (i,j,k) order), and a scene without any edge must end in SC_ENOHYP on every rank."""
+    import torch
+    dev = torch.device("cuda:0")
+    sc = pkg.synth.make_scene(150, 1.0, 1.0, 1e-7, 21)
+    kw = _params(pkg, 0.05, 3000)
+    ref = O.register(sc.src, sc.tgt, threads=4, **kw)
+    d_src = torch.from_numpy(sc.src).to(dev); d_tgt = torch.from_numpy(sc.tgt).to(dev)
+    for world in (2, 4):
+        rc, st, Rt, mask, _ = _run_sharded_ab(pkg, 150, kw, d_src, d_tgt, world, block=64)
+        assert rc == 0 and (st["best_rank"], st["best_count"], st["tri_kept"]) == (ref["best_rank"], ref["best_count"], ref["t_eff"])
+        assert np.array_equal(mask, ref["mask"]) and Rt.tobytes() == np.concatenate([ref["R"].ravel(), ref["t"]]).astype(np.float32).tobytes()
+    rng = np.random.default_rng(5)
+    src = rng.uniform(-1, 1, (40, 3)).astype(np.float32)
+    tgt = (src * 37.0).astype(np.float32)
+    d_src = torch.from_numpy(src).to(dev); d_tgt = torch.from_numpy(tgt).to(dev)
+    rc, st, Rt, mask, _ = _run_sharded_ab(pkg, 40, _params(pkg, 0.001, 100), d_src, d_tgt, 2)
+    assert rc == pkg.SC_ENOHYP and not mask.any() and st["edges"] == 0
