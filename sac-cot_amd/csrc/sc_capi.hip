@@ -254,21 +254,23 @@ int run_edges(sc_ctx* c, const sc_params* p, uint32_t* hist, uint32_t part, uint
   ENSURE(c, c->scan_tmp, scan_temp_bytes(n));
   // read-back #1: the scan kernel itself writes the edge count to host-pinned memory (no copy kernel)
   arm_word(c, 0);
+  ENSURE(c, c->ebase, n * 4);
+  ScanExtra xe;  // the scan of deg+ also writes the per-row CSR bases edge_fill reads
+  xe.deg = c->deg.as<uint32_t>(); xe.degp = c->degp.as<uint32_t>(); xe.ebase = c->ebase.as<uint32_t>();
   if (c->sharded_ab) {
     // also the prefix of the per-row work estimate and, from it, this rank's contiguous row / edge range
     ENSURE(c, c->cost_pre, (n + 1) * sizeof(uint64_t));
     launch_scan_u32_pair(c->degp.as<uint32_t>(), c->edge_off.as<uint64_t>(), c->rowcost.as<uint32_t>(),
-                         c->cost_pre.as<uint64_t>(), n, c->scan_tmp.p, c->tn, st, &c->pinned[0]);
+                         c->cost_pre.as<uint64_t>(), n, c->scan_tmp.p, c->tn, st, &c->pinned[0], &xe);
     ControlBlock* ctl = c->ctl.as<ControlBlock>();
     launch_shard_split(c->cost_pre.as<uint64_t>(), c->edge_off.as<uint64_t>(), c->n, (uint32_t)p->shard_rank,
                        (uint32_t)p->shard_world, ctl->own_row, ctl->own_edge, st);
   } else {
-    launch_scan_u32(c->degp.as<uint32_t>(), n, c->edge_off.as<uint64_t>(), c->scan_tmp.p, c->tn, st, &c->pinned[0]);
+    launch_scan_u32(c->degp.as<uint32_t>(), n, c->edge_off.as<uint64_t>(), c->scan_tmp.p, c->tn, st, &c->pinned[0], &xe);
   }
   // While the host polls for the edge count, edge_fill already runs into the edge arrays this context holds from
   // earlier calls (it needs no host-side count: one wave per row, offsets from the scan).  Writes beyond their
   // capacity are dropped by the kernel; in that case, or on a first call, it runs (again) after the read-back.
-  ENSURE(c, c->ebase, n * 4);
   const Graph g = graph_of(c);
   uint64_t spec_cap = c->es.cap / 4 >= 2 ? c->es.cap / 4 - 2 : 0;  // es carries two pad entries
   for (const Buf* b : {&c->ei, &c->ej, &c->ebi, &c->ebj}) spec_cap = b->cap / 4 < spec_cap ? b->cap / 4 : spec_cap;
@@ -281,6 +283,8 @@ int run_edges(sc_ctx* c, const sc_params* p, uint32_t* hist, uint32_t part, uint
   if ((uint32_t)c->pinned[1] != 0) { c->last_error = "non-finite input coordinate"; return SC_EINVAL; }
   const uint64_t E = c->E = c->pinned[0];
   c->M = 0; c->M_total = 0; c->T_eff = 0; c->pruned = false; c->use_events = false; c->have_total = false;
+  // an exchanged histogram is written on every path (zeros where no sample runs: the control block's copies are zero)
+  if (hist && (E == 0 || !(may_prune(p) && E >= 4096))) launch_hist_reduce(c->ctl.as<ControlBlock>()->prune_hist, hist, st);
   if (E == 0) return SC_OK;
   // edge ids, CSR bases and the strong list are u32 (include/saccot.h, limits): a graph beyond that is refused, not wrapped
   if (E >= (1ull << 32)) { c->last_error = "the compatibility graph has 2^32 or more edges"; return SC_ETOOMANY; }
@@ -308,7 +312,8 @@ int run_edges(sc_ctx* c, const sc_params* p, uint32_t* hist, uint32_t part, uint
     // the smallest possible weight is ~3 t_cmp (every edge has s >= t_cmp up to rounding); 0.1 % slack
     launch_sample_hist(g, c->ebi.as<uint32_t>(), c->ebj.as<uint32_t>(), c->ei.as<uint32_t>(), c->ej.as<uint32_t>(),
                        c->es.as<float>(), E, p->max_triangles, 3.0f * p->t_cmp * 0.999f, part, parts,
-                       hist ? hist : ctl->prune_hist, c->tn, st);
+                       ctl->prune_hist, c->tn, st);
+    if (hist) launch_hist_reduce(ctl->prune_hist, hist, st);  // the exchanged form: one 256-bin histogram
   }
   return SC_OK;
 }
@@ -331,7 +336,7 @@ int run_select(sc_ctx* c, const sc_params* p, const uint32_t* hist, bool want_li
       ENSURE(c, c->strong, strong_list_bytes(E));
       sl = StrongList{c->strong.as<uint32_t>(), ctl->st_fill, strong_list_cap(E)};
     }
-    launch_prune_bits(g, hist ? hist : ctl->prune_hist, c->ei.as<uint32_t>(), c->ej.as<uint32_t>(), c->es.as<float>(), E,
+    launch_prune_bits(g, hist ? hist : ctl->prune_hist, hist == nullptr, c->ei.as<uint32_t>(), c->ej.as<uint32_t>(), c->es.as<float>(), E,
                       p->max_triangles, 3.0f * p->t_cmp * 0.999f, c->bits2.as<uint64_t>(), &ctl->smin, &ctl->klb, sl,
                       c->tcnt.as<uint32_t>(), own_range_of(c), st);
     mbits = c->bits2.as<uint64_t>();
@@ -356,7 +361,9 @@ int run_select(sc_ctx* c, const sc_params* p, const uint32_t* hist, bool want_li
   }
   // read-back #2: triangle count (of the pruned graph when pruning), written to pinned memory by the scan
   arm_word(c, 2);
-  launch_scan_u32(c->tcnt.as<uint32_t>(), E, c->toff.as<uint64_t>(), c->scan_tmp.p, c->tn, st, &c->pinned[2]);
+  ScanExtra xr;  // sharded: the counts outside this rank's edge range are zero — their tiles are skipped
+  xr.range = own_range_of(c);
+  launch_scan_u32(c->tcnt.as<uint32_t>(), E, c->toff.as<uint64_t>(), c->scan_tmp.p, c->tn, st, &c->pinned[2], &xr);
   // While the host polls for the count, the key kernel already runs into the key arrays this context holds from earlier
   // calls (it takes everything else from device memory).  Only in the common form — events, a-priori select window —
   // and not when every stage is bracketed by events; re-run below if the count outgrew the arrays or a region overflowed.
@@ -582,7 +589,7 @@ int sc_set_debug(sc_ctx* c, const sc_debug* d) {
   if (!d) { c->tn = Tuning(); return SC_OK; }
   if (d->size != sizeof(sc_debug)) return SC_EINVAL;
   auto tg_ok = [](uint32_t t) { return t == 0 || t == 4 || t == 8 || t == 16 || t == 32 || t == 64; };
-  if (!tg_ok(d->tg_count) || !tg_ok(d->tg_keys) || !tg_ok(d->tg_sample)) return SC_EINVAL;
+  if (!tg_ok(d->tg_count) || !tg_ok(d->tg_keys) || !tg_ok(d->tg_sample) || !tg_ok(d->tg_events)) return SC_EINVAL;
   if (d->tg_count == 64) return SC_EINVAL;  // the plain counting kernel has no 64-lane form
   if (d->score_split > 256 || (d->compat_rows != 0 && d->compat_rows != 16 && d->compat_rows != 64)) return SC_EINVAL;
   if (d->event_cap != 0 && d->event_cap < 256) return SC_EINVAL;
@@ -595,6 +602,7 @@ int sc_set_debug(sc_ctx* c, const sc_debug* d) {
   if (d->tg_count) t.tg_count = (int)d->tg_count;
   if (d->tg_keys) t.tg_keys = (int)d->tg_keys;
   if (d->tg_sample) t.tg_sample = (int)d->tg_sample;
+  if (d->tg_events) t.tg_events = (int)d->tg_events;
   t.sample_edges = d->sample_edges;
   t.score_split = d->score_split;
   t.compat_one_phase = d->compat_one_phase != 0;
@@ -695,7 +703,6 @@ int sc_hypothesize_begin_device(sc_ctx* c, const float* d_src, const float* d_tg
   if (!c || !d_src || !d_tgt || !d_hist) return SC_EINVAL;
   if (!p || p->size != sizeof(sc_params)) return SC_EINVAL;
   HIPCHK(c, hipSetDevice(c->device));
-  HIPCHK(c, hipMemsetAsync(d_hist, 0, SC_HIST_WORDS * sizeof(uint32_t), c->stream));
   const int rc = hyp_begin(c, d_src, d_tgt, n, p, d_hist, (uint32_t)p->shard_rank, (uint32_t)p->shard_world);
   if (rc == SC_OK) fill_stats(c, stats);
   return rc;
@@ -770,7 +777,6 @@ int sc_shard_edges_device(sc_ctx* c, uint32_t* d_hist) {
   HIPCHK(c, hipSetDevice(c->device));
   const sc_params* p = &c->params;
   c->shard_phase = 0;
-  HIPCHK(c, hipMemsetAsync(d_hist, 0, SC_HIST_WORDS * sizeof(uint32_t), c->stream));
   int rc;
   if ((rc = run_row_stats(c, may_prune(p)))) return rc;
   if ((rc = run_edges(c, p, d_hist, (uint32_t)p->shard_rank, (uint32_t)p->shard_world))) return rc;

@@ -397,23 +397,33 @@ __global__ __launch_bounds__(64) void shard_split_kernel(const uint64_t* __restr
                                                          const uint64_t* __restrict__ edge_off, int n, uint32_t rank,
                                                          uint32_t world, uint32_t* __restrict__ own_row,
                                                          uint64_t* __restrict__ own_edge) {
-  if (threadIdx.x >= 2) return;
-  const uint32_t l = rank + threadIdx.x;  // boundary index: rank (lo) or rank + 1 (hi)
-  int row;
-  if (l == 0) row = 0;
-  else if (l >= world) row = n;
-  else {
-    const uint64_t total = cost_pre[n];
-    const uint64_t target = (uint64_t)(((unsigned __int128)total * l) / world);
-    int lo = 0, hi = n;  // first row r in [0, n] with cost_pre[r] >= target
-    while (lo < hi) {
-      const int mid = (lo + hi) >> 1;
-      if (cost_pre[mid] >= target) hi = mid; else lo = mid + 1;
+  // one wave; both boundaries (lo = boundary `rank`, hi = boundary `rank + 1`) by a 64-ary search: every step the 64
+  // lanes probe 64 evenly spaced rows at once (3 steps for n = 20 000 instead of 15 dependent loads)
+  const int lane = threadIdx.x;
+  const uint64_t total = cost_pre[n];
+  for (int which = 0; which < 2; which++) {
+    const uint32_t l = rank + (uint32_t)which;
+    int row;
+    if (l == 0) row = 0;
+    else if (l >= world) row = n;
+    else {
+      const uint64_t target = (uint64_t)(((unsigned __int128)total * l) / world);
+      int lo = 0, hi = n;  // invariant: the answer (first r in [0, n] with cost_pre[r] >= target) lies in [lo, hi]
+      while (hi - lo > 0) {
+        const int span = hi - lo, step = (span + 63) / 64;
+        const int probe = lo + lane * step;                   // probes lo, lo + step, ... (those < hi are real)
+        const bool ge = probe < hi ? (cost_pre[probe] >= target) : true;
+        const uint64_t m = __ballot(ge);
+        // first probe at or above the target; none (the last real probe is still below it): the answer lies above it
+        const int first = m ? __builtin_ctzll(m) : 64;
+        if (first == 0) { hi = lo; }                                                // cost_pre[lo] >= target
+        else if (first == 64) { lo = lo + 63 * step + 1; }                          // in (probe[63], hi]
+        else { const int plo = lo + (first - 1) * step + 1; hi = min(hi, lo + first * step); lo = plo; }  // in (probe[first-1], probe[first]]
+      }
+      row = lo;
     }
-    row = lo;
+    if (lane == 0) { own_row[which] = (uint32_t)row; own_edge[which] = edge_off[row]; }
   }
-  own_row[threadIdx.x] = (uint32_t)row;
-  own_edge[threadIdx.x] = edge_off[row];
 }
 
 // rows [row0, row1) of the graph (row0 a multiple of 64, row1 <= n); the whole matrix (symmetric tiles, each pair
@@ -477,9 +487,19 @@ constexpr int SCAN_THREADS = 256;
 constexpr int SCAN_ITEMS = 16;
 constexpr int SCAN_TILE = SCAN_THREADS * SCAN_ITEMS;
 
+// range (optional, device): [lo, hi) outside which every input is known to be zero (sharded stage B: the per-edge
+// triangle counts of the edges other ranks enumerate) — tiles wholly outside are neither read nor written.
+__device__ __forceinline__ bool scan_tile_dead(const uint64_t* __restrict__ range, size_t tile) {
+  if (!range) return false;
+  const uint64_t t0 = (uint64_t)tile * SCAN_TILE;
+  return t0 + SCAN_TILE <= range[0] || t0 >= range[1];
+}
+
 __global__ __launch_bounds__(SCAN_THREADS) void scan_block_sums_kernel(const uint32_t* __restrict__ in, size_t n,
-                                                                       uint64_t* __restrict__ bsum) {
+                                                                       uint64_t* __restrict__ bsum,
+                                                                       const uint64_t* __restrict__ range) {
   __shared__ uint64_t lds[8];
+  if (scan_tile_dead(range, blockIdx.x)) { if (threadIdx.x == 0) bsum[blockIdx.x] = 0; return; }
   const size_t base = (size_t)blockIdx.x * SCAN_TILE + (size_t)threadIdx.x * SCAN_ITEMS;
   uint64_t s = 0;
 #pragma unroll
@@ -509,13 +529,20 @@ __global__ __launch_bounds__(1024) void scan_of_sums_kernel(uint64_t* __restrict
 
 // SELF: every block sums the raw block sums before it by itself (<= SCAN_SELF_MAX of them, from L2) and the last one
 // writes the total — the single-block scan-of-sums launch (a ~4.6 us floor) disappears.
+// eb (optional): also ebase[i] = (u32) out[i] - (deg[i] - degp[i]), the CSR base of row i (see launch_edge_fill)
+struct ScanEbase { const uint32_t* deg; const uint32_t* degp; uint32_t* ebase; };
+
 template <bool SELF>
 __global__ __launch_bounds__(SCAN_THREADS) void scan_downsweep_kernel(const uint32_t* __restrict__ in, size_t n,
                                                                       const uint64_t* __restrict__ bsum,
                                                                       uint64_t* __restrict__ out,
-                                                                      uint64_t* __restrict__ host_total) {
+                                                                      uint64_t* __restrict__ host_total,
+                                                                      const uint64_t* __restrict__ range,
+                                                                      ScanEbase eb) {
   __shared__ uint64_t lds[8];
   const size_t base = (size_t)blockIdx.x * SCAN_TILE + (size_t)threadIdx.x * SCAN_ITEMS;
+  const bool dead = scan_tile_dead(range, blockIdx.x) && !(SELF && blockIdx.x == gridDim.x - 1);  // block-uniform
+  if (dead) return;
   uint32_t v[SCAN_ITEMS];
   uint64_t s = 0;
 #pragma unroll
@@ -532,7 +559,10 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_downsweep_kernel(const uint
   uint64_t run = pre + block_exscan_u64(s, lds, &tot);
 #pragma unroll
   for (int k = 0; k < SCAN_ITEMS; k++) {
-    if (base + k < n) out[base + k] = run;
+    if (base + k < n) {
+      out[base + k] = run;
+      if (eb.ebase) eb.ebase[base + k] = (uint32_t)run - (eb.deg[base + k] - eb.degp[base + k]);
+    }
     run += v[k];
   }
   if (SELF && blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) {
@@ -544,7 +574,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_downsweep_kernel(const uint
 // small inputs: ONE block scans up to two arrays in one launch (three launches of the tiled scan are pure latency there)
 __global__ __launch_bounds__(1024) void scan_small_kernel(const uint32_t* __restrict__ in0, uint64_t* __restrict__ out0,
                                                           const uint32_t* __restrict__ in1, uint64_t* __restrict__ out1,
-                                                          size_t n, uint64_t* __restrict__ host_total) {
+                                                          size_t n, uint64_t* __restrict__ host_total, ScanEbase eb) {
   __shared__ uint64_t lds[16];
   constexpr int PER = 8;  // consecutive elements per thread and pass: 8192 per pass, so a few passes at most
   const int arrays = in1 ? 2 : 1;
@@ -562,7 +592,10 @@ __global__ __launch_bounds__(1024) void scan_small_kernel(const uint32_t* __rest
       uint64_t run = carry + block_exscan_u64(sum, lds, &tot);
 #pragma unroll
       for (int k = 0; k < PER; k++) {
-        if (base + k < n) out[base + k] = run;
+        if (base + k < n) {
+          out[base + k] = run;
+          if (a == 0 && eb.ebase) eb.ebase[base + k] = (uint32_t)run - (eb.deg[base + k] - eb.degp[base + k]);
+        }
         run += v[k];
       }
       carry += tot;
@@ -578,11 +611,12 @@ constexpr size_t SCAN_SMALL_MAX = 8192;  // one pass of the single block; beyond
 // Tuning::scan_self_max (4096 tiles = 16.7 M elements): beyond it the scan of sums is its own launch
 
 void launch_scan_u32_pair(const uint32_t* in0, uint64_t* out0, const uint32_t* in1, uint64_t* out1, size_t n,
-                          void* temp, const Tuning& tn, hipStream_t st, uint64_t* host_total) {
+                          void* temp, const Tuning& tn, hipStream_t st, uint64_t* host_total, const ScanExtra* x0) {
   if (n <= SCAN_SMALL_MAX) {
-    hipLaunchKernelGGL(scan_small_kernel, dim3(1), dim3(1024), 0, st, in0, out0, in1, out1, n, host_total);
+    const ScanEbase eb{x0 ? x0->deg : nullptr, x0 ? x0->degp : nullptr, x0 ? x0->ebase : nullptr};
+    hipLaunchKernelGGL(scan_small_kernel, dim3(1), dim3(1024), 0, st, in0, out0, in1, out1, n, host_total, eb);
   } else {
-    launch_scan_u32(in0, n, out0, temp, tn, st, host_total);
+    launch_scan_u32(in0, n, out0, temp, tn, st, host_total, x0);
     if (in1) launch_scan_u32(in1, n, out1, temp, tn, st);
   }
 }
@@ -590,23 +624,25 @@ void launch_scan_u32_pair(const uint32_t* in0, uint64_t* out0, const uint32_t* i
 size_t scan_temp_bytes(size_t n) { return ((n + SCAN_TILE - 1) / SCAN_TILE + 1) * sizeof(uint64_t); }
 
 void launch_scan_u32(const uint32_t* in, size_t n, uint64_t* out, void* temp, const Tuning& tn, hipStream_t st,
-                     uint64_t* host_total) {
+                     uint64_t* host_total, const ScanExtra* x) {
+  const ScanEbase eb{x ? x->deg : nullptr, x ? x->degp : nullptr, x ? x->ebase : nullptr};
+  const uint64_t* range = x ? x->range : nullptr;
   if (n <= SCAN_SMALL_MAX) {
     hipLaunchKernelGGL(scan_small_kernel, dim3(1), dim3(1024), 0, st, in, out, (const uint32_t*)nullptr,
-                       (uint64_t*)nullptr, n, host_total);
+                       (uint64_t*)nullptr, n, host_total, eb);
     return;
   }
   uint64_t* bsum = static_cast<uint64_t*>(temp);
   const size_t nb = (n + SCAN_TILE - 1) / SCAN_TILE;
   if (nb == 0) return;  // n == 0 is handled by the small path above
-  hipLaunchKernelGGL(scan_block_sums_kernel, dim3((unsigned)nb), dim3(SCAN_THREADS), 0, st, in, n, bsum);
+  hipLaunchKernelGGL(scan_block_sums_kernel, dim3((unsigned)nb), dim3(SCAN_THREADS), 0, st, in, n, bsum, range);
   if (nb <= tn.scan_self_max) {  // (a test sets scan_self_max = 0 to force the three-kernel form)
     hipLaunchKernelGGL(scan_downsweep_kernel<true>, dim3((unsigned)nb), dim3(SCAN_THREADS), 0, st, in, n, bsum, out,
-                       host_total);
+                       host_total, range, eb);
   } else {
     hipLaunchKernelGGL(scan_of_sums_kernel, dim3(1), dim3(1024), 0, st, bsum, nb, out + n, host_total);
     hipLaunchKernelGGL(scan_downsweep_kernel<false>, dim3((unsigned)nb), dim3(SCAN_THREADS), 0, st, in, n, bsum, out,
-                       (uint64_t*)nullptr);
+                       (uint64_t*)nullptr, range, eb);
   }
 }
 

@@ -24,7 +24,8 @@ struct Tuning {
   size_t compact_self_max = 4096;  // tiles up to which compact_write adds up the tile counts by itself
   size_t scan_self_max = 4096;     // tiles up to which the scan's down-sweep adds up the block sums by itself
   uint32_t cnt_blocks = 0, keys_blocks = 0, sel_blocks = 0;  // grid sizes (0: automatic)
-  int tg_count = 8, tg_keys = 8, tg_sample = 8;              // lanes per edge
+  int tg_count = 8, tg_keys = 8, tg_sample = 0;              // lanes per edge (tg_sample 0: by row width)
+  int tg_events = 0;               // lanes per edge of the event-recording counting pass (0: by row width)
   uint64_t sample_edges = 0;       // edges of the pruning sample (0: automatic, ~5T/8)
   uint32_t score_split = 0;        // share (of 256) of the hypotheses scored on the matrix pipe
   bool compat_one_phase = false;   // exact chain on every pair of an interior tile
@@ -67,12 +68,24 @@ void launch_shard_split(const uint64_t* cost_pre, const uint64_t* edge_off, int 
 // ---- exclusive scan u32 -> u64 (out has n+1 entries; out[n] = total) -----------------------------
 // host_total (optional): host-pinned u64 that also receives the total, written by the kernel itself — the host
 // reads it after its next stream synchronise, with no copy kernel in between.
+// Extras a scan can do on its way (all optional):
+//   range (device, [lo, hi)): outside it every input is known to be zero — tiles wholly outside are neither read nor
+//     written (sharded stage B: the triangle counts of the edges other ranks enumerate); out[n] is still the total;
+//   deg / degp / ebase: also ebase[i] = (u32) out[i] - (deg[i] - degp[i]), the CSR base of row i (launch_edge_fill).
+struct ScanExtra {
+  const uint64_t* range = nullptr;
+  const uint32_t* deg = nullptr;
+  const uint32_t* degp = nullptr;
+  uint32_t* ebase = nullptr;
+};
 size_t scan_temp_bytes(size_t n);
 void launch_scan_u32(const uint32_t* in, size_t n, uint64_t* out, void* temp, const Tuning& tn, hipStream_t st,
-                     uint64_t* host_total = nullptr);
-// two arrays of the same length in one go (one launch when n is small); in1/out1 may be null; host_total: of array 0
+                     uint64_t* host_total = nullptr, const ScanExtra* x = nullptr);
+// two arrays of the same length in one go (one launch when n is small); in1/out1 may be null; host_total and x0: of
+// array 0
 void launch_scan_u32_pair(const uint32_t* in0, uint64_t* out0, const uint32_t* in1, uint64_t* out1, size_t n,
-                          void* temp, const Tuning& tn, hipStream_t st, uint64_t* host_total = nullptr);
+                          void* temp, const Tuning& tn, hipStream_t st, uint64_t* host_total = nullptr,
+                          const ScanExtra* x0 = nullptr);
 
 // ---- stage B: triangles_topT ---------------------------------------------------------------------
 struct Graph {
@@ -86,8 +99,9 @@ struct Graph {
 // CSR edge list of the upper triangle, rows ascending, columns ascending: ei/ej/es (es = S[i][j]).
 // ebase[i] (u32, modular): CSR index of edge (i,k), k > i, is ebase[i] + wpre[i][k/64] + popc(bits[i][k/64] below k).
 // ebi[e] / ebj[e]: the bases of both ends of edge e (so an edge is fetched in one memory level).
+// ebase: the per-row CSR bases, READ here (written by the scan of degp: ScanExtra)
 void launch_edge_fill(const Graph& g, const Points& pts, const Derived& dv, const uint64_t* edge_off, uint32_t* ei,
-                      uint32_t* ej, float* es, uint32_t* ebase, uint32_t* ebi, uint32_t* ebj, uint64_t cap,
+                      uint32_t* ej, float* es, const uint32_t* ebase, uint32_t* ebi, uint32_t* ebj, uint64_t cap,
                       hipStream_t st);
 // tcnt[e] = #k > j adjacent (in `mbits`) to both ends of edge e = (i,j); edges with es[e] < *smin count 0
 // (smin == nullptr: no pruning, mbits = g.bits).
@@ -116,7 +130,11 @@ size_t strong_list_bytes(uint64_t E);
 void launch_sample_hist(const Graph& g, const uint32_t* ebi, const uint32_t* ebj, const uint32_t* ei,
                         const uint32_t* ej, const float* es, uint64_t E, uint64_t want, float key_floor, uint32_t part,
                         uint32_t parts, uint32_t* hist, const Tuning& tn, hipStream_t st);
-void launch_prune_bits(const Graph& g, const uint32_t* hist, const uint32_t* ei, const uint32_t* ej, const float* es,
+// launch_sample_hist ALWAYS accumulates into PR_HCOPIES x 256 words (`hist` = the control block's copies);
+// launch_hist_reduce sums them into one 256-bin histogram (the exchanged form); launch_prune_bits reads either
+// (hist_is_copies).
+void launch_hist_reduce(const uint32_t* copies, uint32_t* out, hipStream_t st);
+void launch_prune_bits(const Graph& g, const uint32_t* hist, bool hist_is_copies, const uint32_t* ei, const uint32_t* ej, const float* es,
                        uint64_t E, uint64_t want, float key_floor, uint64_t* mbits, float* smin, uint32_t* klb,
                        const StrongList& sl, uint32_t* tcnt, const uint64_t* own, hipStream_t st);
 
@@ -157,10 +175,11 @@ struct SelectState {
 };
 static_assert(offsetof(SelectState, hist) % 16 == 0, "SelectState::hist must be 16-byte aligned");
 
+constexpr int PR_HCOPIES = 16;  // global copies of the pruning-sample histogram (block b adds into copy b % 16)
 // Per-call control block (device memory, zeroed by the staging kernel at the start of every call).
 struct ControlBlock {
   uint32_t ev_fill[1024];    // event-list region fill counters (EV_SHARDS)
-  uint32_t prune_hist[256];  // sampled key histogram of the certified pruning
+  uint32_t prune_hist[PR_HCOPIES * 256];  // sampled key histogram of the certified pruning, PR_HCOPIES partial copies
   uint32_t st_fill[256];     // strong-edge list region fill counters (ST_SHARDS)
   float smin;                // strong-edge threshold (written by prune_bits_kernel)
   uint32_t amx_ticket;       // blocks-finished counter of score_argmax_kernel

@@ -67,9 +67,8 @@ __global__ __launch_bounds__(256) void edge_fill_kernel(const uint64_t* __restri
                                                         const uint64_t* __restrict__ edge_off,
                                                         uint32_t* __restrict__ ei, uint32_t* __restrict__ ej,
                                                         float* __restrict__ es,
-                                                        const uint32_t* __restrict__ deg,
-                                                        const uint32_t* __restrict__ degp,
-                                                        uint32_t* __restrict__ ebase, uint32_t* __restrict__ ebi,
+                                                        const uint32_t* __restrict__ ebase,
+                                                        uint32_t* __restrict__ ebi,
                                                         uint32_t* __restrict__ ebj, uint64_t cap) {
   // cap: entries the edge arrays hold.  The host may launch this kernel BEFORE it knows the edge count (into the
   // arrays of the previous call, while it polls for the count); writes beyond cap are dropped and the host re-runs.
@@ -79,9 +78,8 @@ __global__ __launch_bounds__(256) void edge_fill_kernel(const uint64_t* __restri
   const int i = blockIdx.x * 4 + wave;
   if (i >= n) return;  // whole waves leave: there is no workgroup barrier below
   uint64_t base = edge_off[i];
-  // (# bits of row i at or below i) = deg - deg+; modular u32 arithmetic (edge indices are < 2^32)
-  const uint32_t my_base = (uint32_t)base - (deg[i] - degp[i]);
-  if (lane == 0) ebase[i] = my_base;
+  // CSR base of row i: edge_off[i] - (# bits of row i at or below i), modular u32 — written by the scan of deg+
+  const uint32_t my_base = ebase[i];
   const int w0 = i >> 6;
   const float pix = planes[i], piy = planes[ld + i], piz = planes[2 * ld + i];  // wave-uniform: scalar loads
   const float qix = planes[3 * ld + i], qiy = planes[4 * ld + i], qiz = planes[5 * ld + i];
@@ -123,7 +121,7 @@ __global__ __launch_bounds__(256) void edge_fill_kernel(const uint64_t* __restri
         es[e] = sw;
         // both CSR bases travel with the edge, so stage B fetches an edge in ONE memory level
         ebi[e] = my_base;
-        ebj[e] = (uint32_t)edge_off[j] - (deg[j] - degp[j]);
+        ebj[e] = ebase[j];  // one gather (the base is precomputed per row: was edge_off[j], deg[j], degp[j])
       }
       __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     }
@@ -132,10 +130,10 @@ __global__ __launch_bounds__(256) void edge_fill_kernel(const uint64_t* __restri
 }
 
 void launch_edge_fill(const Graph& g, const Points& pts, const Derived& dv, const uint64_t* edge_off, uint32_t* ei,
-                      uint32_t* ej, float* es, uint32_t* ebase, uint32_t* ebi, uint32_t* ebj, uint64_t cap,
+                      uint32_t* ej, float* es, const uint32_t* ebase, uint32_t* ebi, uint32_t* ebj, uint64_t cap,
                       hipStream_t st) {
   hipLaunchKernelGGL(edge_fill_kernel, dim3((g.n + 3) / 4), dim3(256), 0, st, g.bits, pts.planes, dv, g.n, g.ld, g.W,
-                     edge_off, ei, ej, es, g.deg, g.degp, ebase, ebi, ebj, cap);
+                     edge_off, ei, ej, es, ebase, ebi, ebj, cap);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -619,15 +617,18 @@ void launch_tri_count_events(const Graph& g, const uint64_t* mbits, const Strong
                              const uint32_t* ebj, const uint32_t* ei, const uint32_t* ej, uint64_t E, int rank_mode,
                              uint32_t* tcnt, const EventList& ev, const Tuning& tn, hipStream_t st) {
   if (E == 0) return;
-  constexpr int TGV = 8;
-  const uint64_t per = 256 / TGV;
+  // lanes per edge: a lane walks (W - j / 64) / TG words one dependent round after the other, so wide rows want wide
+  // groups (Tuning::tg_events forces one; measured r02: see DESIGN.md)
+  int tg = tn.tg_events ? tn.tg_events : (g.W <= 128 ? 8 : (g.W <= 512 ? 16 : 32));
+  const uint64_t per = 256 / tg;
   // the strong edges are a fraction of E that only the device knows (20 - 45 % on C1 .. C4): size the grid for ~E/3
   uint64_t nb = (E / 3 + per - 1) / per;
   if (nb < 256) nb = 256;
   if (nb > 4096) nb = 4096;
   if (tn.cnt_blocks >= 1 && tn.cnt_blocks <= 65535) nb = tn.cnt_blocks;
-  hipLaunchKernelGGL(tri_count_events_kernel<TGV>, dim3((unsigned)nb), dim3(256), 0, st, mbits, g.W, g.deg, ebi, ebj, ei,
-                     ej, sl, rank_mode, tcnt, ev);
+#define SC_LAUNCH_CE(TGV) hipLaunchKernelGGL(tri_count_events_kernel<TGV>, dim3((unsigned)nb), dim3(256), 0, st, mbits, g.W, g.deg, ebi, ebj, ei, ej, sl, rank_mode, tcnt, ev)
+  if (tg == 4) SC_LAUNCH_CE(4); else if (tg == 16) SC_LAUNCH_CE(16); else if (tg == 32) SC_LAUNCH_CE(32); else if (tg == 64) SC_LAUNCH_CE(64); else SC_LAUNCH_CE(8);
+#undef SC_LAUNCH_CE
 }
 
 void launch_tri_keys_events(const Graph& g, const float* es, const uint64_t* toff, int rank_mode,
@@ -739,17 +740,31 @@ __global__ __launch_bounds__(256) void tri_sample_hist_kernel(const uint64_t* __
     }
   }
   __syncthreads();
+  // flush into one of PR_HCOPIES global copies (by block): a thousand blocks adding into the SAME 256 words serialise
+  // at the memory side (~12 ns per add and address); the copies are summed by the reader
+  uint32_t* __restrict__ myh = hist + (size_t)(blockIdx.x & (PR_HCOPIES - 1)) * PR_BINS;
   for (int b = threadIdx.x; b < PR_BINS; b += 256) {
     uint32_t v = 0;
 #pragma unroll
     for (int c = 0; c < PR_COPIES; c++) v += lh[b * PR_COPIES + ((c + threadIdx.x) & (PR_COPIES - 1))];
-    if (v) atomicAdd(&hist[b], v);
+    if (v) atomicAdd(&myh[b], v);
   }
+}
+
+// sum of the copies -> one 256-bin histogram (the form the ranks exchange)
+__global__ __launch_bounds__(256) void hist_reduce_kernel(const uint32_t* __restrict__ copies, uint32_t* __restrict__ out) {
+  uint32_t v = 0;
+#pragma unroll
+  for (int c = 0; c < PR_HCOPIES; c++) v += copies[c * PR_BINS + threadIdx.x];
+  out[threadIdx.x] = v;
+}
+void launch_hist_reduce(const uint32_t* copies, uint32_t* out, hipStream_t st) {
+  hipLaunchKernelGGL(hist_reduce_kernel, dim3(1), dim3(256), 0, st, copies, out);
 }
 
 // every block derives smin from the histogram (256 bins: cheap) and sets the strong bits of its edges in `mbits`
 // (zeroed beforehand; only upper-triangle entries are needed: bit j of row i for i < j).  Block 0 publishes smin.
-__global__ __launch_bounds__(256) void prune_bits_kernel(const uint32_t* __restrict__ hist, uint64_t want,
+__global__ __launch_bounds__(256) void prune_bits_kernel(const uint32_t* __restrict__ hist, int copies, uint64_t want,
                                                          uint32_t klo, uint32_t shift,
                                                          const uint32_t* __restrict__ ei,
                                                          const uint32_t* __restrict__ ej,
@@ -764,7 +779,8 @@ __global__ __launch_bounds__(256) void prune_bits_kernel(const uint32_t* __restr
   __shared__ uint32_t s_klb, s_base, s_wcnt[4];
   static_assert(PR_BINS == 256, "one bin per thread, walked from the top");
   const uint32_t bin = PR_BINS - 1 - threadIdx.x;
-  const uint64_t mine = hist[bin];
+  uint64_t mine = 0;
+  for (int c = 0; c < copies; c++) mine += hist[c * PR_BINS + bin];  // copies: PR_HCOPIES (the sample's own) or 1 (summed)
   if (threadIdx.x == 0) { s_smin = -1.0f; s_klb = 0u; }  // default: no certified bound -> every edge is strong
   uint64_t tot;
   const uint64_t before = block_exscan_u64(mine, lds, &tot);
@@ -842,7 +858,7 @@ void launch_sample_hist(const Graph& g, const uint32_t* ebi, const uint32_t* ebj
   const uint64_t n_s = (E + stride - 1) / stride;
   const uint64_t n_loc = n_s > part ? (n_s - part + parts - 1) / parts : 0;
   if (n_loc == 0) return;
-  const int tg = tn.tg_sample;
+  const int tg = tn.tg_sample ? tn.tg_sample : 8;
   uint64_t nb = (n_loc + (256 / tg) - 1) / (256 / tg);
   // about one sampled edge per group (measured: 256 blocks 70 us, 1024+ blocks 35 us on C2)
   if (nb > 4096) nb = 4096;
@@ -851,12 +867,13 @@ void launch_sample_hist(const Graph& g, const uint32_t* ebi, const uint32_t* ebj
 #undef SC_LAUNCH_SAMPLE
 }
 
-void launch_prune_bits(const Graph& g, const uint32_t* hist, const uint32_t* ei, const uint32_t* ej, const float* es,
+void launch_prune_bits(const Graph& g, const uint32_t* hist, bool hist_is_copies, const uint32_t* ei, const uint32_t* ej, const float* es,
                        uint64_t E, uint64_t want, float key_floor, uint64_t* mbits, float* smin, uint32_t* klb,
                        const StrongList& sl, uint32_t* tcnt, const uint64_t* own, hipStream_t st) {
   uint32_t klo, shift;
   prune_window(key_floor, &klo, &shift);
-  hipLaunchKernelGGL(prune_bits_kernel, dim3((unsigned)((E + 255) / 256)), dim3(256), 0, st, hist, want, klo, shift, ei,
+  hipLaunchKernelGGL(prune_bits_kernel, dim3((unsigned)((E + 255) / 256)), dim3(256), 0, st, hist,
+                     hist_is_copies ? PR_HCOPIES : 1, want, klo, shift, ei,
                      ej, es, E, g.W, reinterpret_cast<unsigned long long*>(mbits), smin, klb, sl, tcnt, own);
 }
 

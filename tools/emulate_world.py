@@ -1,47 +1,125 @@
 #!/usr/bin/env python3
-"""Per-rank step time at world = W on ONE GPU: stage A + B for T_total = 50k * W (replicated on every rank) and stage C
-for rank 0's share, no collective.  What bench.py --gpus W does per rank, minus the all-reduces.  From world 4 on the
-pruning sample is sharded as in bench.py: rank 0 samples its share and a device copy of the precomputed summed
-histogram (1 KiB) stands in for the all-reduce.  SPLIT=0 / SPLIT=1 in the environment forces either form."""
-import os, sys, time
+"""Per-rank step time of an N-GPU job, emulated on ONE GPU (no multi-GPU box is available to the builder).
+
+    python tools/emulate_world.py [--config C3] [--scaling strong|weak] [--mode shard_ab|replicated] [--nodense] 1 2 4 8
+
+shard_ab   (what bench.py runs for N > 1): every rank is a context of its own; the ranks share the
+           exchange buffers.  One untimed pass of ALL ranks fills them; then each rank's phases are timed alone, K times,
+           with everything the other ranks contribute already in place.  A device copy of the received bytes stands in
+           for each collective (bit rows, candidate blobs) and a 1 KiB copy for the histogram all-reduce — a copy inside
+           one HBM is NOT an xGMI transfer: the table lists the bytes per collective so the real cost can be priced
+           (7 links x ~153 GB/s per GPU, direct all-gather).  The step of the job is bounded by the SLOWEST rank: max and
+           mean over the ranks are printed.
+replicated (round 1's form): A and B on every rank, only stage C sharded.
+strong scaling: T_total = the config's T (BASELINE configs[3] / [4] as specified); weak: T per GPU fixed."""
+import argparse
+import os
+import sys
+import time
+
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
 import torch
 import __graft_entry__ as ge
+
+ap = argparse.ArgumentParser()
+ap.add_argument("worlds", nargs="*", type=int, default=[1, 2, 4, 8])
+ap.add_argument("--config", default="C3")
+ap.add_argument("--scaling", choices=("strong", "weak"), default="strong")
+ap.add_argument("--mode", choices=("shard_ab", "replicated"), default="shard_ab")
+ap.add_argument("--nodense", action="store_true")
+ap.add_argument("--iters", type=int, default=10)
+args = ap.parse_args()
+
 pkg = ge.load_package()
-cfg, scene = pkg.synth.make_config_scene("C2")
+cfg, scene = pkg.synth.make_config_scene(args.config)
 dev = torch.device("cuda", 0)
-reg = pkg.Registrar(0)
-reg.set_stream(torch.cuda.current_stream().cuda_stream)
 d_src = torch.from_numpy(scene.src).to(dev); d_tgt = torch.from_numpy(scene.tgt).to(dev)
-d_key = torch.zeros(2, dtype=torch.int64, device=dev)
-d_Rt = torch.zeros(12, dtype=torch.float32, device=dev); d_mask = torch.zeros(cfg.n, dtype=torch.uint8, device=dev)
-worlds = [int(w) for w in sys.argv[1:]] or [1, 2, 4, 8]
+flags = pkg.SC_FLAG_NO_DENSE_S if args.nodense else 0
+K = args.iters
+print(f"# {args.config}: N={cfg.n} T={cfg.T} scaling={args.scaling} mode={args.mode} dense_S={not args.nodense}")
 base = None
-for world in worlds:
-    kw = cfg.params(); kw["max_triangles"] = cfg.T * world
-    p = pkg.make_params(shard_rank=0, shard_world=world, shard_block=1000, flags=pkg.SC_FLAG_TIMING_HOT, **kw)
-    split = os.environ.get("SPLIT", "1" if world >= 4 else "0") == "1"
-    d_hist = torch.zeros(pkg.SC_HIST_WORDS, dtype=torch.int32, device=dev)
-    summed = torch.zeros_like(d_hist)
-    if split:  # what the all-reduce would deliver: the sum of every rank's share
+for world in args.worlds:
+    kw = cfg.params()
+    kw["max_triangles"] = cfg.T if args.scaling == "strong" else cfg.T * world
+    T_total = kw["max_triangles"]
+    block = max(64, min(1024, T_total // (world * 8)))
+    ps = [pkg.make_params(shard_rank=r, shard_world=world, shard_block=block, flags=flags, **kw) for r in range(world)]
+    d_Rt = torch.zeros(12, dtype=torch.float32, device=dev); d_mask = torch.zeros(cfg.n, dtype=torch.uint8, device=dev)
+    d_keys = torch.zeros(2 * world, dtype=torch.int64, device=dev)
+    if args.mode == "replicated" or world == 1:
+        reg = pkg.Registrar(0); reg.set_stream(torch.cuda.current_stream().cuda_stream)
+        def step(r):
+            reg.hypothesize_device(d_src.data_ptr(), d_tgt.data_ptr(), cfg.n, ps[r], d_keys.data_ptr() + 16 * r)
         for r in range(world):
-            pr = pkg.make_params(shard_rank=r, shard_world=world, shard_block=1000, **kw)
-            reg.hypothesize_begin_device(d_src.data_ptr(), d_tgt.data_ptr(), cfg.n, pr, d_hist.data_ptr())
-            summed += d_hist
+            step(r)
         torch.cuda.synchronize()
-    def one():
-        if split:
-            reg.hypothesize_begin_device(d_src.data_ptr(), d_tgt.data_ptr(), cfg.n, p, d_hist.data_ptr())
-            d_hist.copy_(summed)
-            reg.hypothesize_end_device(d_hist.data_ptr(), d_key.data_ptr())
-        else:
-            reg.hypothesize_device(d_src.data_ptr(), d_tgt.data_ptr(), cfg.n, p, d_key.data_ptr())
-        return reg.finalize_device(d_key.data_ptr(), d_Rt.data_ptr(), d_mask.data_ptr())
-    for _ in range(3):
-        one()
-    torch.cuda.synchronize(); t0 = time.perf_counter(); K = 30
-    for _ in range(K):
-        _, st = one()
-    torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / K
-    base = base or dt * world  # weak scaling: linear = the first row's rate per rank
-    print(f"world={world} T_total={cfg.T*world} per-rank step {dt*1e3:.3f} ms -> job {cfg.T*world/dt/1e6:.1f} M hyp/s (vs linear from the first row: {base/worlds[0]/dt*100:.0f}%)  tri_enum={st['tri_total']} score={st['us_score']:.0f}us scored={st['tri_scored']} sample={'sharded' if split else 'replicated'}")
+        times = []
+        for r in range(world if world <= 2 else 2):  # ranks are statistically alike here: two suffice
+            for _ in range(2):
+                step(r); reg.finalize_gathered_device(d_keys.data_ptr(), world, d_Rt.data_ptr(), d_mask.data_ptr())
+            torch.cuda.synchronize(); t0 = time.perf_counter()
+            for _ in range(K):
+                step(r); rc, st = reg.finalize_gathered_device(d_keys.data_ptr(), world, d_Rt.data_ptr(), d_mask.data_ptr())
+            torch.cuda.synchronize(); times.append((time.perf_counter() - t0) / K)
+        coll = "key pairs 16 B/rank"
+        reg.close()
+    else:
+        regs = [pkg.Registrar(0) for _ in range(world)]
+        for g in regs:
+            g.set_stream(torch.cuda.current_stream().cuda_stream)
+        plan = pkg.shard_plan(ps[0], cfg.n)
+        d_bits = torch.zeros(plan.bits_bytes_total // 8, dtype=torch.int64, device=dev)
+        d_bits_rx = torch.zeros_like(d_bits)
+        d_hist = [torch.zeros(pkg.SC_HIST_WORDS, dtype=torch.int32, device=dev) for _ in range(world)]
+        d_cand = torch.zeros(world * plan.cand_bytes_per_rank // 8, dtype=torch.int64, device=dev)
+        d_cand_rx = torch.zeros_like(d_cand)
+        # fill pass: every rank, phase by phase (what the collectives would have delivered ends up in the shared buffers)
+        for r in range(world):
+            regs[r].shard_compat_device(d_src.data_ptr(), d_tgt.data_ptr(), cfg.n, ps[r], d_bits.data_ptr())
+        for r in range(world):
+            regs[r].shard_edges_device(d_hist[r].data_ptr())
+        torch.cuda.synchronize()
+        summed = torch.from_numpy((sum(h.cpu().numpy().view(np.uint32).astype(np.uint64) for h in d_hist)
+                                   & np.uint64(0xFFFFFFFF)).astype(np.uint32).view(np.int32)).to(dev)
+        for r in range(world):
+            d_hist[r].copy_(summed)
+            regs[r].shard_select_device(d_hist[r].data_ptr(), d_cand.data_ptr() + r * plan.cand_bytes_per_rank)
+        for r in range(world):
+            regs[r].shard_score_device(d_cand.data_ptr(), d_keys.data_ptr() + 16 * r)
+        torch.cuda.synchronize()
+        hdr = d_cand.cpu().numpy().view(np.uint64).reshape(world, -1)[:, :2].copy()
+        rx_bits = (world - 1) * plan.bits_bytes_per_rank // 8       # int64 words a rank receives
+        rx_cand_words = plan.cand_bytes_per_rank // 8
+
+        def step(r):
+            g = regs[r]
+            g.shard_compat_device(d_src.data_ptr(), d_tgt.data_ptr(), cfg.n, ps[r], d_bits.data_ptr())
+            d_bits_rx[:rx_bits].copy_(d_bits[:rx_bits])                                  # stand-in: all-gather of the bit rows
+            g.shard_edges_device(d_hist[r].data_ptr())
+            d_hist[r].copy_(summed)                                                     # stand-in: 1 KiB all-reduce
+            g.shard_select_device(d_hist[r].data_ptr(), d_cand.data_ptr() + r * plan.cand_bytes_per_rank)
+            for q in range(world):                                                      # stand-in: all-gather of the blobs
+                if q != r:                                                              # (header + entries sent)
+                    nw = 32 + (int(hdr[q, 1]) * 20 + 7) // 8
+                    d_cand_rx[q * rx_cand_words: q * rx_cand_words + nw].copy_(d_cand[q * rx_cand_words: q * rx_cand_words + nw])
+            g.shard_score_device(d_cand.data_ptr(), d_keys.data_ptr() + 16 * r)
+            return g.finalize_gathered_device(d_keys.data_ptr(), world, d_Rt.data_ptr(), d_mask.data_ptr())
+        times = []
+        for r in range(world):
+            for _ in range(2):
+                step(r)
+            torch.cuda.synchronize(); t0 = time.perf_counter()
+            for _ in range(K):
+                rc, st = step(r)
+            torch.cuda.synchronize(); times.append((time.perf_counter() - t0) / K)
+        sent = hdr[:, 1].astype(np.int64)
+        coll = (f"bit rows {plan.bits_bytes_per_rank/1e6:.2f} MB/rank (rx {(world-1)*plan.bits_bytes_per_rank/1e6:.1f} MB), hist 1 KiB, "
+                f"candidates sent {sent.min()}..{sent.max()} of cap {T_total} (x20 B; blob {plan.cand_bytes_per_rank/1e6:.2f} MB), key pairs 16 B; "
+                f"enumerated per rank {hdr[:,0].min()}..{hdr[:,0].max()}")
+        for g in regs:
+            g.close()
+    tmax, tmean = max(times), sum(times) / len(times)
+    base = base or tmax
+    print(f"world={world} T_total={T_total} per-rank step: max {tmax*1e3:.3f} ms mean {tmean*1e3:.3f} ms -> job {T_total/tmax/1e6:.1f} M hyp/s, "
+          f"speed-up vs the first row {base/tmax:.2f}x | winner rank={st['best_rank']} inliers={st['best_count']} | {coll}", flush=True)
