@@ -62,6 +62,10 @@ extern "C" {
 #define SC_FLAG_TIMING       1u /* record a HIP event pair around every stage and fill sc_stats.us_* (each record  */
                                 /* costs ~5 us of stream time: diagnostics, not for the timed loop)               */
 #define SC_FLAG_TIMING_HOT  16u /* only the dominant kernel: us_score (2 records per call)                          */
+#define SC_FLAG_TIMING_ONE  64u /* ONE stage bracket (2 records per call), chosen by SC_TIMING_STAGE(k) in the flags: the   */
+                                /* call runs its hot path (speculative launches on), so per-stage times taken one stage per   */
+                                /* pass are times of the code that is actually timed end to end                                */
+#define SC_TIMING_STAGE(k)  (((uint32_t)(k) & 15u) << 8) /* k: 0 staging, 1 compat, 2 triangles, 3 kabsch, 4 score, 5 argmax, 6 mask */
 #define SC_FLAG_EXACT_TOTAL  2u /* sc_stats.tri_total = 3-cliques of the WHOLE graph (one extra counting pass);  */
                                 /* default: 3-cliques of the pruned graph the top-T search actually enumerated   */
 #define SC_FLAG_REFINE       8u /* after C3, replace (R,t) by the fp64 least-squares refit over the winner's inlier  */

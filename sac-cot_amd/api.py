@@ -20,6 +20,15 @@ SC_OK, SC_EINVAL, SC_ENOMEM, SC_EHIP, SC_ERCCL, SC_ENOHYP, SC_ETOOMANY = 0, -1, 
 SC_AOS, SC_SOA = 0, 1
 SC_RANK_WEIGHT, SC_RANK_DEGREE = 0, 1
 SC_FLAG_TIMING, SC_FLAG_EXACT_TOTAL, SC_FLAG_NO_PRUNE, SC_FLAG_REFINE, SC_FLAG_TIMING_HOT, SC_FLAG_NO_DENSE_S = 1, 2, 4, 8, 16, 32
+SC_FLAG_TIMING_ONE = 64
+
+
+def SC_TIMING_STAGE(k: int) -> int:
+    """flags bits selecting the one bracket of SC_FLAG_TIMING_ONE: 0 staging, 1 compat, 2 triangles, 3 kabsch, 4 score,
+    5 argmax, 6 mask"""
+    return (k & 15) << 8
+
+
 SC_HIST_WORDS = 256  # u32 words of the pruning-sample histogram (sc_hypothesize_begin_device)
 
 EXPORTS = ["sc_version", "sc_strerror", "sc_default_params", "sc_create", "sc_destroy", "sc_set_stream",

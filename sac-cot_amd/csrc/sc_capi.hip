@@ -59,6 +59,7 @@ struct sc_ctx {
   bool have_hyp = false, begun = false;
   sc_params params{};  // the parameters of the running call (begin -> end)
   bool timing = false, timing_hot = false;
+  int timing_one = -1;  // SC_FLAG_TIMING_ONE: the one stage bracket recorded this call (0 .. 6), -1: none
   float ev_overhead_us = -1.f;  // cost of one event record inside a bracket (calibrate_events); < 0: not measured yet
   bool timed_trikeys = false;
   bool refine = false;
@@ -162,9 +163,29 @@ TriSource tri_source_of(const sc_ctx* c) {
   return ts;
 }
 
+// stage brackets as (first event, second event): stage, compat, triangles, kabsch, score, argmax, mask
+constexpr int STAGE_EV[7][2] = {{0, 1}, {1, 2}, {2, 3}, {3, 4}, {4, 5}, {5, 6}, {7, 8}};
+
 int rec(sc_ctx* c, int i) {
   const bool hot = i == 4 || i == 5;
-  if (c->timing || (c->timing_hot && hot)) HIPCHK(c, hipEventRecord(c->ev[i], c->stream));
+  const bool one = c->timing_one >= 0 && (i == STAGE_EV[c->timing_one][0] || i == STAGE_EV[c->timing_one][1]);
+  if (c->timing || (c->timing_hot && hot) || one) HIPCHK(c, hipEventRecord(c->ev[i], c->stream));
+  return SC_OK;
+}
+
+int calibrate_events(sc_ctx* c);
+
+// SC_FLAG_TIMING / _HOT / _ONE -> the context's timing state for this call
+int set_timing(sc_ctx* c, const sc_params* p) {
+  c->timing = (p->flags & SC_FLAG_TIMING) != 0;
+  c->timing_hot = !c->timing && (p->flags & SC_FLAG_TIMING_HOT) != 0;
+  c->timing_one = -1;
+  if (!c->timing && !c->timing_hot && (p->flags & SC_FLAG_TIMING_ONE)) {
+    const int stage = (int)((p->flags >> 8) & 15u);
+    if (stage > 6) return SC_EINVAL;
+    c->timing_one = stage;
+  }
+  if (c->timing || c->timing_hot || c->timing_one >= 0) return calibrate_events(c);
   return SC_OK;
 }
 
@@ -276,7 +297,8 @@ int run_edges(sc_ctx* c, const sc_params* p, uint32_t* hist, uint32_t part, uint
   for (const Buf* b : {&c->ei, &c->ej, &c->ebi, &c->ebj}) spec_cap = b->cap / 4 < spec_cap ? b->cap / 4 : spec_cap;
   auto fill_edges = [&](uint64_t cap) {
     launch_edge_fill(g, points_of(c), c->dv, c->edge_off.as<uint64_t>(), c->ei.as<uint32_t>(), c->ej.as<uint32_t>(),
-                     c->es.as<float>(), c->ebase.as<uint32_t>(), c->ebi.as<uint32_t>(), c->ebj.as<uint32_t>(), cap, st);
+                     c->es.as<float>(), c->ebase.as<uint32_t>(), scan_writes_ebase(n), c->ebi.as<uint32_t>(),
+                     c->ebj.as<uint32_t>(), cap, st);
   };
   if (spec_cap) fill_edges(spec_cap);
   { const int wrc = wait_word(c, 0); if (wrc) return wrc; }
@@ -625,9 +647,7 @@ int hyp_begin(sc_ctx* c, const float* d_src, const float* d_tgt, int64_t n, cons
   c->have_hyp = false;
   c->begun = false;
   c->timed_trikeys = false;
-  c->timing = (p->flags & SC_FLAG_TIMING) != 0;
-  c->timing_hot = !c->timing && (p->flags & SC_FLAG_TIMING_HOT) != 0;
-  if ((c->timing || c->timing_hot) && (rc = calibrate_events(c))) return rc;
+  if ((rc = set_timing(c, p))) return rc;
   c->refine = (p->flags & SC_FLAG_REFINE) != 0;
   c->cap_bytes = p->max_workspace ? p->max_workspace : (64ull << 30);
   c->dv = derive(p);
@@ -740,9 +760,7 @@ int sc_shard_compat_device(sc_ctx* c, const float* d_src, const float* d_tgt, in
   if (p->shard_world > 64) return SC_EINVAL;
   HIPCHK(c, hipSetDevice(c->device));
   c->have_hyp = false; c->begun = false; c->timed_trikeys = false;
-  c->timing = (p->flags & SC_FLAG_TIMING) != 0;
-  c->timing_hot = !c->timing && (p->flags & SC_FLAG_TIMING_HOT) != 0;
-  if ((c->timing || c->timing_hot) && (rc = calibrate_events(c))) return rc;
+  if ((rc = set_timing(c, p))) return rc;
   c->refine = (p->flags & SC_FLAG_REFINE) != 0;
   c->cap_bytes = p->max_workspace ? p->max_workspace : (64ull << 30);
   c->dv = derive(p);
@@ -871,6 +889,7 @@ int sc_finalize_gathered_device(sc_ctx* c, const uint64_t* d_keys, int n_pairs, 
   // are complete in stream order, like any other work the caller enqueues there; on the context's private stream —
   // which the caller cannot order against — and when the per-stage events are read below, wait for everything.
   if (c->timing || c->stream == c->own_stream) HIPCHK(c, hipStreamSynchronize(c->stream));
+  else if (c->timing_one == 6) HIPCHK(c, hipEventSynchronize(c->ev[8]));  // the mask bracket ends after the kernel polled below
   if ((rc = wait_word(c, 8))) return rc;
   HIPCHK(c, hipGetLastError());
   if (c->pinned[11] != 0) {  // finalize_kernel: a pair decodes to a position outside the selection (outputs: identity, zero mask)
@@ -895,6 +914,10 @@ int sc_finalize_gathered_device(sc_ctx* c, const uint64_t* d_keys, int n_pairs, 
                         stats->us_score + stats->us_argmax + stats->us_mask;
     } else if (c->timing_hot) {
       stats->us_score = ev_us(c, 4, 5);
+    } else if (c->timing_one >= 0) {  // one bracket, recorded on the hot path (speculative launches on)
+      float* dst[7] = {&stats->us_stage, &stats->us_compat, &stats->us_triangles, &stats->us_kabsch, &stats->us_score,
+                       &stats->us_argmax, &stats->us_mask};
+      *dst[c->timing_one] = ev_us(c, STAGE_EV[c->timing_one][0], STAGE_EV[c->timing_one][1]);
     }
   }
   return key ? SC_OK : SC_ENOHYP;
@@ -945,7 +968,7 @@ int sc_compat_host(sc_ctx* c, const float* src, const float* tgt, int64_t n, con
   if (rc) return rc;
   HIPCHK(c, hipSetDevice(c->device));
   c->have_hyp = false;
-  c->timing = c->timing_hot = false;
+  c->timing = c->timing_hot = false; c->timing_one = -1;
   c->cap_bytes = p->max_workspace ? p->max_workspace : (64ull << 30);
   c->dv = derive(p);
   const bool dense = S != nullptr && !(p->flags & SC_FLAG_NO_DENSE_S);
@@ -972,7 +995,7 @@ int sc_triangles_host(sc_ctx* c, const float* src, const float* tgt, int64_t n, 
   if (rc) return rc;
   HIPCHK(c, hipSetDevice(c->device));
   c->have_hyp = false;
-  c->timing = c->timing_hot = false;
+  c->timing = c->timing_hot = false; c->timing_one = -1;
   c->cap_bytes = p->max_workspace ? p->max_workspace : (64ull << 30);
   c->dv = derive(p);
   if ((rc = host_to_planes(c, src, tgt, n, p))) return rc;

@@ -574,7 +574,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_downsweep_kernel(const uint
 // small inputs: ONE block scans up to two arrays in one launch (three launches of the tiled scan are pure latency there)
 __global__ __launch_bounds__(1024) void scan_small_kernel(const uint32_t* __restrict__ in0, uint64_t* __restrict__ out0,
                                                           const uint32_t* __restrict__ in1, uint64_t* __restrict__ out1,
-                                                          size_t n, uint64_t* __restrict__ host_total, ScanEbase eb) {
+                                                          size_t n, uint64_t* __restrict__ host_total) {
   __shared__ uint64_t lds[16];
   constexpr int PER = 8;  // consecutive elements per thread and pass: 8192 per pass, so a few passes at most
   const int arrays = in1 ? 2 : 1;
@@ -592,10 +592,7 @@ __global__ __launch_bounds__(1024) void scan_small_kernel(const uint32_t* __rest
       uint64_t run = carry + block_exscan_u64(sum, lds, &tot);
 #pragma unroll
       for (int k = 0; k < PER; k++) {
-        if (base + k < n) {
-          out[base + k] = run;
-          if (a == 0 && eb.ebase) eb.ebase[base + k] = (uint32_t)run - (eb.deg[base + k] - eb.degp[base + k]);
-        }
+        if (base + k < n) out[base + k] = run;
         run += v[k];
       }
       carry += tot;
@@ -613,13 +610,14 @@ constexpr size_t SCAN_SMALL_MAX = 8192;  // one pass of the single block; beyond
 void launch_scan_u32_pair(const uint32_t* in0, uint64_t* out0, const uint32_t* in1, uint64_t* out1, size_t n,
                           void* temp, const Tuning& tn, hipStream_t st, uint64_t* host_total, const ScanExtra* x0) {
   if (n <= SCAN_SMALL_MAX) {
-    const ScanEbase eb{x0 ? x0->deg : nullptr, x0 ? x0->degp : nullptr, x0 ? x0->ebase : nullptr};
-    hipLaunchKernelGGL(scan_small_kernel, dim3(1), dim3(1024), 0, st, in0, out0, in1, out1, n, host_total, eb);
+    hipLaunchKernelGGL(scan_small_kernel, dim3(1), dim3(1024), 0, st, in0, out0, in1, out1, n, host_total);
   } else {
     launch_scan_u32(in0, n, out0, temp, tn, st, host_total, x0);
     if (in1) launch_scan_u32(in1, n, out1, temp, tn, st);
   }
 }
+
+bool scan_writes_ebase(size_t n) { return n > SCAN_SMALL_MAX; }
 
 size_t scan_temp_bytes(size_t n) { return ((n + SCAN_TILE - 1) / SCAN_TILE + 1) * sizeof(uint64_t); }
 
@@ -629,7 +627,7 @@ void launch_scan_u32(const uint32_t* in, size_t n, uint64_t* out, void* temp, co
   const uint64_t* range = x ? x->range : nullptr;
   if (n <= SCAN_SMALL_MAX) {
     hipLaunchKernelGGL(scan_small_kernel, dim3(1), dim3(1024), 0, st, in, out, (const uint32_t*)nullptr,
-                       (uint64_t*)nullptr, n, host_total, eb);
+                       (uint64_t*)nullptr, n, host_total);
     return;
   }
   uint64_t* bsum = static_cast<uint64_t*>(temp);

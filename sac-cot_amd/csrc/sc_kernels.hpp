@@ -99,10 +99,12 @@ struct Graph {
 // CSR edge list of the upper triangle, rows ascending, columns ascending: ei/ej/es (es = S[i][j]).
 // ebase[i] (u32, modular): CSR index of edge (i,k), k > i, is ebase[i] + wpre[i][k/64] + popc(bits[i][k/64] below k).
 // ebi[e] / ebj[e]: the bases of both ends of edge e (so an edge is fetched in one memory level).
-// ebase: the per-row CSR bases, READ here (written by the scan of degp: ScanExtra)
+// ebase_ready: the per-row CSR bases were written by the scan of deg+ (ScanExtra, tiled form) and are READ here;
+// otherwise they are derived on the fly and this kernel writes them.  scan_writes_ebase(n) tells which.
+bool scan_writes_ebase(size_t n);
 void launch_edge_fill(const Graph& g, const Points& pts, const Derived& dv, const uint64_t* edge_off, uint32_t* ei,
-                      uint32_t* ej, float* es, const uint32_t* ebase, uint32_t* ebi, uint32_t* ebj, uint64_t cap,
-                      hipStream_t st);
+                      uint32_t* ej, float* es, uint32_t* ebase, bool ebase_ready, uint32_t* ebi, uint32_t* ebj,
+                      uint64_t cap, hipStream_t st);
 // tcnt[e] = #k > j adjacent (in `mbits`) to both ends of edge e = (i,j); edges with es[e] < *smin count 0
 // (smin == nullptr: no pruning, mbits = g.bits).
 void launch_tri_count(const Graph& g, const uint64_t* mbits, const float* es, const float* smin, const uint32_t* ei,
@@ -175,7 +177,9 @@ struct SelectState {
 };
 static_assert(offsetof(SelectState, hist) % 16 == 0, "SelectState::hist must be 16-byte aligned");
 
-constexpr int PR_HCOPIES = 16;  // global copies of the pruning-sample histogram (block b adds into copy b % 16)
+constexpr int PR_HCOPIES = 4;  // global copies of the pruning-sample histogram (block b adds into copy b % 4): with one
+                               // copy a thousand blocks' adds into the same 256 words serialise (C2 sample 34 -> 27 us);
+                               // with 16 the readers' 16 loads per bin cost prune_bits what the sample gained
 // Per-call control block (device memory, zeroed by the staging kernel at the start of every call).
 struct ControlBlock {
   uint32_t ev_fill[1024];    // event-list region fill counters (EV_SHARDS)

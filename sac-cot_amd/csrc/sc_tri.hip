@@ -67,7 +67,9 @@ __global__ __launch_bounds__(256) void edge_fill_kernel(const uint64_t* __restri
                                                         const uint64_t* __restrict__ edge_off,
                                                         uint32_t* __restrict__ ei, uint32_t* __restrict__ ej,
                                                         float* __restrict__ es,
-                                                        const uint32_t* __restrict__ ebase,
+                                                        const uint32_t* __restrict__ deg,
+                                                        const uint32_t* __restrict__ degp,
+                                                        uint32_t* __restrict__ ebase, int ebase_ready,
                                                         uint32_t* __restrict__ ebi,
                                                         uint32_t* __restrict__ ebj, uint64_t cap) {
   // cap: entries the edge arrays hold.  The host may launch this kernel BEFORE it knows the edge count (into the
@@ -78,8 +80,12 @@ __global__ __launch_bounds__(256) void edge_fill_kernel(const uint64_t* __restri
   const int i = blockIdx.x * 4 + wave;
   if (i >= n) return;  // whole waves leave: there is no workgroup barrier below
   uint64_t base = edge_off[i];
-  // CSR base of row i: edge_off[i] - (# bits of row i at or below i), modular u32 — written by the scan of deg+
-  const uint32_t my_base = ebase[i];
+  // CSR base of row i: edge_off[i] - (# bits of row i at or below i) = edge_off[i] - (deg - deg+), modular u32.
+  // ebase_ready: the (tiled) scan of deg+ wrote every row's base already, so the base of the OTHER end is one gather;
+  // otherwise (small n: a one-block scan, where the extra loads cost more than they save here) it is derived on the fly
+  // from three and this wave records its own row's.
+  const uint32_t my_base = ebase_ready ? ebase[i] : (uint32_t)base - (deg[i] - degp[i]);
+  if (!ebase_ready && lane == 0) ebase[i] = my_base;
   const int w0 = i >> 6;
   const float pix = planes[i], piy = planes[ld + i], piz = planes[2 * ld + i];  // wave-uniform: scalar loads
   const float qix = planes[3 * ld + i], qiy = planes[4 * ld + i], qiz = planes[5 * ld + i];
@@ -121,7 +127,7 @@ __global__ __launch_bounds__(256) void edge_fill_kernel(const uint64_t* __restri
         es[e] = sw;
         // both CSR bases travel with the edge, so stage B fetches an edge in ONE memory level
         ebi[e] = my_base;
-        ebj[e] = ebase[j];  // one gather (the base is precomputed per row: was edge_off[j], deg[j], degp[j])
+        ebj[e] = ebase_ready ? ebase[j] : (uint32_t)edge_off[j] - (deg[j] - degp[j]);
       }
       __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     }
@@ -130,10 +136,10 @@ __global__ __launch_bounds__(256) void edge_fill_kernel(const uint64_t* __restri
 }
 
 void launch_edge_fill(const Graph& g, const Points& pts, const Derived& dv, const uint64_t* edge_off, uint32_t* ei,
-                      uint32_t* ej, float* es, const uint32_t* ebase, uint32_t* ebi, uint32_t* ebj, uint64_t cap,
-                      hipStream_t st) {
+                      uint32_t* ej, float* es, uint32_t* ebase, bool ebase_ready, uint32_t* ebi, uint32_t* ebj,
+                      uint64_t cap, hipStream_t st) {
   hipLaunchKernelGGL(edge_fill_kernel, dim3((g.n + 3) / 4), dim3(256), 0, st, g.bits, pts.planes, dv, g.n, g.ld, g.W,
-                     edge_off, ei, ej, es, ebase, ebi, ebj, cap);
+                     edge_off, ei, ej, es, g.deg, g.degp, ebase, ebase_ready ? 1 : 0, ebi, ebj, cap);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -858,7 +864,9 @@ void launch_sample_hist(const Graph& g, const uint32_t* ebi, const uint32_t* ebj
   const uint64_t n_s = (E + stride - 1) / stride;
   const uint64_t n_loc = n_s > part ? (n_s - part + parts - 1) / parts : 0;
   if (n_loc == 0) return;
-  const int tg = tn.tg_sample ? tn.tg_sample : 8;
+  // lanes per sampled edge (r02 sweep, profiles/r02_ab_lanes_per_edge.txt): 16 while the sample is small enough for
+  // about one edge per group (C2 26.9 -> 19.8 us, C3 129 -> 112), 8 once groups take several trips (C4: 74 vs 81)
+  const int tg = tn.tg_sample ? tn.tg_sample : ((n_loc <= 131072 || g.W > 256) ? 16 : 8);
   uint64_t nb = (n_loc + (256 / tg) - 1) / (256 / tg);
   // about one sampled edge per group (measured: 256 blocks 70 us, 1024+ blocks 35 us on C2)
   if (nb > 4096) nb = 4096;

@@ -96,3 +96,61 @@ def allgather_best(key2, out):
     else:
         out[0:2].copy_(key2)
     return out
+
+
+# ---------------------------------------------------------------------------------------------------------
+# Stages A and B sharded too: host side of the phase API of include/saccot.h, one process per GPU.
+# ---------------------------------------------------------------------------------------------------------
+def allgather_inplace(buf, rank: int, world: int):
+    """In-place all-gather of a flat tensor made of `world` equal slices: rank r contributes slice r (which it has
+    already written) and receives the others.  RCCL (backend "nccl") takes the aliased form directly; backends
+    without all_gather_into_tensor (gloo) get a list of views and a copy of the own slice.  No host sync."""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or world == 1:
+        return buf
+    per = buf.numel() // world
+    mine = buf[rank * per:(rank + 1) * per]
+    try:
+        dist.all_gather_into_tensor(buf, mine)
+    except (RuntimeError, NotImplementedError):
+        dist.all_gather([buf[r * per:(r + 1) * per] for r in range(world)], mine.clone())
+    return buf
+
+
+class ShardedStep:
+    """One rank's buffers and phase sequence for the fully sharded path:
+         compat (row block) -> all-gather bit rows -> edges + sample share -> all-reduce histogram ->
+         own top-T -> all-gather candidate blobs -> merge + C1 + C2 -> all-gather key pairs -> finalize.
+    Every collective is torch.distributed's on the context's stream (backend "nccl" = RCCL over xGMI; "gloo" in the
+    CPU rehearsal).  With world == 1 no collective is issued."""
+
+    def __init__(self, pkg, reg, n: int, params, rank: int, world: int, device):
+        import torch
+        self.pkg, self.reg, self.n, self.p, self.rank, self.world = pkg, reg, n, params, rank, world
+        plan = pkg.shard_plan(params, n)
+        self.plan = plan
+        self.bits = torch.zeros(plan.bits_bytes_total // 8, dtype=torch.int64, device=device)
+        self.hist = torch.zeros(pkg.SC_HIST_WORDS, dtype=torch.int32, device=device)
+        self.cand = torch.zeros(world * plan.cand_bytes_per_rank // 8, dtype=torch.int64, device=device)
+        self.keys = torch.zeros(2 * world, dtype=torch.int64, device=device)
+        self.Rt = torch.zeros(12, dtype=torch.float32, device=device)
+        self.mask = torch.zeros(n, dtype=torch.uint8, device=device)
+
+    def bytes_exchanged(self) -> dict:
+        """Bytes this rank RECEIVES per step and collective (for pricing against the xGMI links)."""
+        w = self.world
+        return {"bit_rows": (w - 1) * int(self.plan.bits_bytes_per_rank), "histogram": 1024 if w > 1 else 0,
+                "candidates": (w - 1) * int(self.plan.cand_bytes_per_rank), "key_pairs": 16 * (w - 1)}
+
+    def step(self, d_src: int, d_tgt: int, params=None):
+        p = params or self.p
+        r, w, reg = self.rank, self.world, self.reg
+        reg.shard_compat_device(d_src, d_tgt, self.n, p, self.bits.data_ptr())
+        allgather_inplace(self.bits, r, w)
+        reg.shard_edges_device(self.hist.data_ptr())
+        allreduce_hist(self.hist)
+        reg.shard_select_device(self.hist.data_ptr(), self.cand.data_ptr() + r * int(self.plan.cand_bytes_per_rank))
+        allgather_inplace(self.cand, r, w)
+        reg.shard_score_device(self.cand.data_ptr(), self.keys.data_ptr() + 16 * r)
+        allgather_inplace(self.keys, r, w)
+        return reg.finalize_gathered_device(self.keys.data_ptr(), w, self.Rt.data_ptr(), self.mask.data_ptr())

@@ -118,3 +118,91 @@ def test_two_ranks_gloo_agree_with_single_rank(pkg, O, tmp_path, world, block):
     want = sum(_fake_hist(r, pkg.SC_HIST_WORDS).view(np.uint32).astype(np.uint64) for r in range(world))
     for o in outs:                                                     # summed histogram, identical on every rank
         assert np.array_equal(o["hist"].view(np.uint32).astype(np.uint64), want & np.uint64(0xFFFFFFFF))
+
+
+# ---------------------------------------------------------------------------------------------------------
+# stages A and B sharded: the collectives' host logic on CPU tensors over gloo, the per-rank
+# device work restated with the oracle — bit rows by row block, each rank's own top-T of a contiguous row
+# range, blobs in the library's layout, merged in rank order with "ties -> lowest position"
+# ---------------------------------------------------------------------------------------------------------
+def _rank_rows(n, world):
+    """contiguous row ranges (any partition into ascending contiguous ranges is valid for the merge; the library
+    balances them by a work estimate on the device)"""
+    cuts = [0] + [int(round(n * (1 - (1 - (r + 1) / world) ** 0.5))) for r in range(world - 1)] + [n]
+    return [(cuts[r], cuts[r + 1]) for r in range(world)]
+
+
+def _worker_ab(rank, world, port, out_dir):
+    import sys
+    import torch
+    import torch.distributed as dist
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import __graft_entry__ as ge
+    pkg = ge.load_package(); O = ge.load_oracle()
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    cfg, sc = pkg.synth.make_config_scene("C0")
+    kw = cfg.params()
+    T = kw["max_triangles"]
+    p = pkg.make_params(shard_rank=rank, shard_world=world, **kw)
+    plan = pkg.shard_plan(p, cfg.n)                     # needs no GPU
+    R, W = plan.rows_per_rank, plan.words_per_row
+    S, bits, deg = O.compat(sc.src, sc.tgt, kw["sigma"], kw["t_cmp"], kw["min_len"], kw["tau"])
+    # phase 1: this rank's row block of the bit rows into its slice of the shared buffer, then the in-place all-gather
+    buf = torch.zeros(plan.bits_bytes_total // 8, dtype=torch.int64)
+    r0, r1 = min(rank * R, cfg.n), min(rank * R + R, cfg.n)
+    view = buf.numpy().view(np.uint64).reshape(world * R, W)
+    view[r0:r1] = bits[r0:r1]
+    pkg.shard.allgather_inplace(buf, rank, world)
+    assert np.array_equal(view[:cfg.n], bits)
+    # phase 3: own top-T of a contiguous row range, as a blob in the library's layout
+    tri_all, key_all, total = O.triangles(S, bits, deg, 10 ** 9, 0)       # every triangle, ranked
+    lo, hi = _rank_rows(cfg.n, world)[rank]
+    own = np.nonzero((tri_all[:, 0] >= lo) & (tri_all[:, 0] < hi))[0]     # ranked order restricted to my rows
+    mine = own[:T]                                                        # my top-T ...
+    order = np.lexsort((tri_all[mine, 2], tri_all[mine, 1], tri_all[mine, 0]))
+    mine = mine[order]                                                    # ... in (i,j,k) order
+    blob_words = plan.cand_bytes_per_rank // 8
+    cand = torch.zeros(world * blob_words, dtype=torch.int64)
+    cap = (T + 1023) // 1024 * 1024
+    blob = cand.numpy().view(np.uint8)[rank * blob_words * 8:(rank + 1) * blob_words * 8]
+    hdr = blob[:256].view(np.uint64); keys = blob[256:256 + 4 * cap].view(np.uint32)
+    recs = blob[256 + 4 * cap:].view(np.uint32).reshape(cap, 4)
+    hdr[0], hdr[1] = len(own), len(mine)
+    keys[:len(mine)] = key_all[mine]
+    recs[:len(mine), :3] = tri_all[mine]; recs[:len(mine), 3] = key_all[mine]
+    pkg.shard.allgather_inplace(cand, rank, world)
+    # phase 4: merge — concatenation in rank order, exact threshold, ties to the lowest position
+    allk, allt = [], []
+    for r in range(world):
+        b = cand.numpy().view(np.uint8)[r * blob_words * 8:(r + 1) * blob_words * 8]
+        ns = int(b[:256].view(np.uint64)[1])
+        allk.append(b[256:256 + 4 * cap].view(np.uint32)[:ns].copy())
+        allt.append(b[256 + 4 * cap:].view(np.uint32).reshape(cap, 4)[:ns, :3].copy())
+    allk = np.concatenate(allk); allt = np.concatenate(allt)
+    assert np.all(np.lexsort((allt[:, 2], allt[:, 1], allt[:, 0])) == np.arange(len(allt)))   # global (i,j,k) order
+    want = min(T, len(allk))
+    kstar = np.sort(allk)[::-1][want - 1]
+    take = np.nonzero(allk > kstar)[0]
+    ties = np.nonzero(allk == kstar)[0][: want - len(take)]
+    sel = np.sort(np.concatenate([take, ties]))
+    np.savez(os.path.join(out_dir, f"ab{rank}.npz"), tri=allt[sel], key=allk[sel], total=np.int64(total))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_A_and_B_host_logic_gloo(pkg, O, tmp_path, world):
+    """Every rank ends with the same selection, and it is the restatement's top-T as a set (in (i,j,k) order)."""
+    import torch.multiprocessing as mp
+    port = _free_port()
+    mp.spawn(_worker_ab, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    cfg, sc = pkg.synth.make_config_scene("C0")
+    kw = cfg.params()
+    S, bits, deg = O.compat(sc.src, sc.tgt, kw["sigma"], kw["t_cmp"], kw["min_len"], kw["tau"])
+    tri, key, _ = O.triangles(S, bits, deg, kw["max_triangles"], 0)
+    order = np.lexsort((tri[:, 2], tri[:, 1], tri[:, 0]))
+    outs = [np.load(tmp_path / f"ab{r}.npz") for r in range(world)]
+    for o in outs:
+        assert np.array_equal(o["tri"], tri[order]) and np.array_equal(o["key"], key[order])
