@@ -42,7 +42,7 @@ extern "C" {
 #define SC_EINVAL   -1   /* bad argument: n < 3, null pointer, non-finite input, bad params.size ...        */
 #define SC_ENOMEM   -2   /* device or host allocation failed / workspace cap exceeded                       */
 #define SC_EHIP     -3   /* HIP runtime error (sc_last_error() has the string)                              */
-#define SC_ERCCL    -4   /* reserved: collective error (the all-reduce lives in the host layer, see below)  */
+#define SC_ERCCL    -4   /* RCCL error or librccl.so.1 not loadable (sc_create_multi / sc_register_multi)   */
 #define SC_ENOHYP   -5   /* no compatibility triangle / every inlier count is 0: R = I, t = 0, mask = 0     */
 #define SC_ETOOMANY -6   /* the graph has more triangles than the workspace cap can rank (see max_workspace),  */
                          /* or 2^32 or more edges (edge ids are 32-bit)                                      */
@@ -246,6 +246,26 @@ int sc_shard_compat_device(sc_ctx* ctx, const float* d_src, const float* d_tgt, 
 int sc_shard_edges_device(sc_ctx* ctx, uint32_t* d_hist);
 int sc_shard_select_device(sc_ctx* ctx, const uint32_t* d_hist, void* d_cand_mine);
 int sc_shard_score_device(sc_ctx* ctx, const void* d_cand_all, uint64_t* d_key, sc_stats* stats);
+
+/* ---- native multi-device entry: one process, n_dev GPUs, RCCL inside the library ------------
+ * For hosts without a collective layer of their own (C++, mex): host arrays in, (R, t, mask) out, like sc_register.
+ * One context per device, stages A, B and C all sharded (the phase API above), the four collectives of a call issued
+ * through RCCL on the devices' streams (all-gather of the bit rows, 1 KiB all-reduce, all-gather of the candidate
+ * blobs, all-gather of the key pairs).  One worker thread per device drives its GPU (a call is ~35 launches and four
+ * read-backs per device: from a single thread that is ~1 ms per step for eight GPUs); the calling convention stays
+ * single-caller.  RCCL is opened at run time (librccl.so.1) only when n_dev > 1: n_dev == 1 is exactly sc_register
+ * and makes no RCCL call.  device_ids must be distinct.  Results are bit-identical to sc_register for every n_dev.
+ * params->shard_* must be left at no sharding (rank 0, world 1).  stats: rank 0's, with tri_scored and
+ * workspace_bytes summed over the devices.  Errors: the first failing rank's status; sc_multi_last_error has its text.
+ * sc_create_multi_loopback: n_ranks ranks on ONE device with device copies in place of RCCL — a test hook that runs
+ * the whole orchestration on a one-GPU box (N > 1 over RCCL itself is unmeasured on hardware: DESIGN.md §7). */
+typedef struct sc_multi sc_multi;
+int         sc_create_multi(const int* device_ids, int n_dev, sc_multi** out);
+int         sc_create_multi_loopback(int device, int n_ranks, sc_multi** out);
+void        sc_destroy_multi(sc_multi* m);
+const char* sc_multi_last_error(const sc_multi* m);
+int         sc_register_multi(sc_multi* m, const float* src, const float* tgt, int64_t n, const sc_params* params,
+                              float R[9], float t[3], uint8_t* mask, sc_stats* stats);
 
 /* ---- stage-level hooks (host pointers in and out) so every kernel is parity-testable alone --------
  * All take SoA or AoS input per params->layout and run ONLY the named stage(s) on the GPU. */

@@ -35,7 +35,8 @@ EXPORTS = ["sc_version", "sc_strerror", "sc_default_params", "sc_create", "sc_de
            "sc_last_error", "sc_set_debug", "sc_register", "sc_register_device", "sc_hypothesize_device", "sc_finalize_device",
            "sc_hypothesize_begin_device", "sc_hypothesize_end_device", "sc_finalize_gathered_device",
            "sc_shard_plan_query", "sc_shard_compat_device", "sc_shard_edges_device", "sc_shard_select_device",
-           "sc_shard_score_device",
+           "sc_shard_score_device", "sc_create_multi", "sc_create_multi_loopback", "sc_destroy_multi",
+           "sc_multi_last_error", "sc_register_multi",
            "sc_compat_host", "sc_triangles_host", "sc_kabsch_host", "sc_score_host", "sc_mask_host"]
 
 
@@ -123,6 +124,11 @@ def load_library() -> C.CDLL:
     L.sc_shard_edges_device.argtypes = [vp, vp]
     L.sc_shard_select_device.argtypes = [vp, vp, vp]
     L.sc_shard_score_device.argtypes = [vp, vp, vp, sp]
+    L.sc_create_multi.argtypes = [C.POINTER(C.c_int), C.c_int, C.POINTER(vp)]
+    L.sc_create_multi_loopback.argtypes = [C.c_int, C.c_int, C.POINTER(vp)]
+    L.sc_destroy_multi.argtypes = [vp]; L.sc_destroy_multi.restype = None
+    L.sc_multi_last_error.argtypes = [vp]; L.sc_multi_last_error.restype = C.c_char_p
+    L.sc_register_multi.argtypes = [vp, f32p, f32p, C.c_int64, pp, f32p, f32p, u8p, sp]
     L.sc_compat_host.argtypes = [vp, f32p, f32p, C.c_int64, pp, f32p, u64p, u32p]
     L.sc_triangles_host.argtypes = [vp, f32p, f32p, C.c_int64, pp, u32p, u32p, u32p, u64p, u64p]
     L.sc_kabsch_host.argtypes = [vp, f32p, f32p, C.c_int64, pp, u32p, C.c_uint32, f32p]
@@ -326,6 +332,47 @@ class Registrar:
         self._check(self._lib.sc_mask_host(self._h, _p(src, C.c_float), _p(tgt, C.c_float), n, C.byref(params),
                                            _p(Rt12, C.c_float), _p(m, C.c_uint8)))
         return m
+
+
+class MultiRegistrar:
+    """sc_multi (include/saccot.h): one process, several GPUs, RCCL inside the library.  `devices`: distinct device
+    ids; `loopback_ranks` > 0 instead runs that many ranks on devices[0] with device copies in place of RCCL (test
+    hook: the whole orchestration on a one-GPU box)."""
+
+    def __init__(self, devices=(0,), loopback_ranks: int = 0):
+        self._lib = load_library()
+        h = C.c_void_p()
+        if loopback_ranks:
+            rc = self._lib.sc_create_multi_loopback(int(devices[0]), loopback_ranks, C.byref(h))
+        else:
+            ids = (C.c_int * len(devices))(*devices)
+            rc = self._lib.sc_create_multi(ids, len(devices), C.byref(h))
+        if rc != SC_OK:
+            raise SacCotError(rc, "sc_create_multi failed: " + self._lib.sc_strerror(rc).decode())
+        self._h = h
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.sc_destroy_multi(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def register(self, src, tgt, params: ScParams | None = None, **kw):
+        p = params or make_params(**kw)
+        src, tgt = _f32c(src), _f32c(tgt)
+        n = src.shape[0] if p.layout == SC_AOS else src.shape[1]
+        R = np.zeros(9, np.float32); t = np.zeros(3, np.float32); mask = np.zeros(n, np.uint8)
+        st = ScStats(C.sizeof(ScStats))
+        rc = self._lib.sc_register_multi(self._h, _p(src, C.c_float), _p(tgt, C.c_float), n, C.byref(p),
+                                         _p(R, C.c_float), _p(t, C.c_float), _p(mask, C.c_uint8), C.byref(st))
+        if rc not in (SC_OK, SC_ENOHYP):
+            raise SacCotError(rc, self._lib.sc_strerror(rc).decode() + " — " + self._lib.sc_multi_last_error(self._h).decode())
+        return dict(status=rc, R=R.reshape(3, 3), t=t, mask=mask, stats=st.as_dict())
 
 
 def register(src, tgt, device: int = 0, **kw):

@@ -8,7 +8,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libsaccot.so")
-SOURCES = ["sc_compat.hip", "sc_tri.hip", "sc_score.hip", "sc_sort.hip", "sc_capi.hip"]
+SOURCES = ["sc_compat.hip", "sc_tri.hip", "sc_score.hip", "sc_sort.hip", "sc_capi.hip", "sc_multi.hip"]
 HEADERS = ["sc_arith.hpp", "sc_block.hpp", "sc_kernels.hpp", os.path.join("..", "..", "include", "saccot.h")]
 # -ffp-contract=off: the canonical arithmetic (sc_arith.hpp) fuses only where it says fmaf.
 # -amdgpu-mfma-vgpr-form: MFMA results land in VGPRs (unified register file on gfx950), no v_accvgpr_read copies.
@@ -39,7 +39,7 @@ def build_library(force: bool = False, verbose: bool = False) -> str:
                 print(" ".join(cmd), file=sys.stderr)
             subprocess.check_call(cmd)
     if force or _stale(LIB, objs):
-        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs + ["-ldl", "-lpthread"]
         if verbose:
             print(" ".join(cmd), file=sys.stderr)
         subprocess.check_call(cmd)

@@ -11,7 +11,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 @pytest.mark.gpu
-def test_cpp_program_links_and_matches_the_oracle(pkg, O, tmp_path):
+@pytest.mark.parametrize("extra", [[], ["--devices", "0"], ["--loopback", "3"]])
+def test_cpp_program_links_and_matches_the_oracle(pkg, O, tmp_path, extra):
+    """plain sc_register; the native multi-device entry with one device (no RCCL call); and its loopback form (three
+    ranks on this one GPU: the whole sharded orchestration from compiled code)"""
     exe = str(tmp_path / "example_register")
     lib_dir = os.path.join(ROOT, "sac-cot_amd")
     subprocess.check_call(["g++", "-O2", "-std=c++17", "-I", os.path.join(ROOT, "include"),
@@ -20,7 +23,7 @@ def test_cpp_program_links_and_matches_the_oracle(pkg, O, tmp_path):
     cfg, scene = pkg.synth.make_config_scene("C1")
     path = str(tmp_path / "corr.txt")
     pkg.corrio.save_correspondences(path, scene.src, scene.tgt)          # %.9g: float32 round-trips exactly
-    out = subprocess.run([exe, path, repr(float(np.float32(cfg.tau))), str(cfg.T)], capture_output=True, text=True,
+    out = subprocess.run([exe, path, repr(float(np.float32(cfg.tau))), str(cfg.T)] + extra, capture_output=True, text=True,
                          timeout=120)
     assert out.returncode == 0, out.stderr
     head, rline, tline = out.stdout.strip().splitlines()

@@ -775,3 +775,55 @@ def test_sharded_A_and_B_massive_ties_and_no_triangles(pkg, O):
     d_src = torch.from_numpy(src).to(dev); d_tgt = torch.from_numpy(tgt).to(dev)
     rc, st, Rt, mask, _ = _run_sharded_ab(pkg, 40, _params(pkg, 0.001, 100), d_src, d_tgt, 2)
     assert rc == pkg.SC_ENOHYP and not mask.any() and st["edges"] == 0
+
+
+# ---------------------------------------------------------------------------------------------------------
+# native multi-device entry (sc_create_multi / sc_register_multi): one device, and the loopback transport
+# ---------------------------------------------------------------------------------------------------------
+def test_multi_one_device_is_sc_register(pkg, reg):
+    """n_dev == 1 makes no RCCL call and is exactly sc_register."""
+    cfg, scene = pkg.synth.make_config_scene("C1")
+    base = reg.register(scene.src, scene.tgt, **cfg.params())
+    m = pkg.MultiRegistrar((0,))
+    try:
+        got = m.register(scene.src, scene.tgt, **cfg.params())
+    finally:
+        m.close()
+    assert got["status"] == 0 and np.array_equal(got["mask"], base["mask"])
+    assert got["R"].tobytes() == base["R"].tobytes() and got["t"].tobytes() == base["t"].tobytes()
+    assert got["stats"]["best_rank"] == base["stats"]["best_rank"]
+    with pytest.raises(pkg.SacCotError) as e:                     # one rank per device
+        pkg.MultiRegistrar((0, 0))
+    assert e.value.status == pkg.SC_EINVAL
+
+
+@pytest.mark.parametrize("ranks", [2, 3, 5])
+def test_multi_loopback_equals_sc_register(pkg, O, reg, ranks):
+    """sc_create_multi_loopback: `ranks` ranks on this one GPU, worker thread each, device copies in place of the RCCL
+    collectives — buffers, phase order, error agreement and outputs of sc_register_multi, bit for bit against
+    sc_register and the CPU restatement; then an input error (every rank must report it, nobody may hang), a scene
+    without hypotheses, and the handle reused for another size."""
+    m = pkg.MultiRegistrar((0,), loopback_ranks=ranks)
+    try:
+        for name in ("C1", "C0"):
+            cfg, scene = pkg.synth.make_config_scene(name)
+            ref = O.register(scene.src, scene.tgt, threads=8, **cfg.params())
+            got = m.register(scene.src, scene.tgt, **cfg.params())
+            assert got["status"] == ref["rc"] == 0
+            st = got["stats"]
+            assert (st["edges"], st["tri_kept"], st["best_rank"], st["best_count"]) == (ref["edges"], ref["t_eff"], ref["best_rank"], ref["best_count"])
+            assert st["tri_scored"] == ref["t_eff"]                                   # summed over the ranks
+            assert np.array_equal(got["mask"], ref["mask"]) and nan_equal_bits(got["R"], ref["R"]) and nan_equal_bits(got["t"], ref["t"])
+        bad = scene.src.copy(); bad[3, 0] = np.inf
+        with pytest.raises(pkg.SacCotError) as e:
+            m.register(bad, scene.tgt, **cfg.params())
+        assert e.value.status == pkg.SC_EINVAL
+        rng = np.random.default_rng(5)
+        src = rng.uniform(-1, 1, (40, 3)).astype(np.float32)
+        out = m.register(src, (src * 37.0).astype(np.float32), **_params(pkg, 0.001, 100))
+        assert out["status"] == pkg.SC_ENOHYP and not out["mask"].any()
+        got = m.register(scene.src, scene.tgt, flags=pkg.SC_FLAG_REFINE | pkg.SC_FLAG_NO_DENSE_S, **cfg.params())
+        base = reg.register(scene.src, scene.tgt, flags=pkg.SC_FLAG_REFINE, **cfg.params())
+        assert got["R"].tobytes() == base["R"].tobytes() and np.array_equal(got["mask"], base["mask"])
+    finally:
+        m.close()
