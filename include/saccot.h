@@ -258,7 +258,8 @@ int sc_shard_score_device(sc_ctx* ctx, const void* d_cand_all, uint64_t* d_key, 
  * params->shard_* must be left at no sharding (rank 0, world 1).  stats: rank 0's, with tri_scored and
  * workspace_bytes summed over the devices.  Errors: the first failing rank's status; sc_multi_last_error has its text.
  * sc_create_multi_loopback: n_ranks ranks on ONE device with device copies in place of RCCL — a test hook that runs
- * the whole orchestration on a one-GPU box (N > 1 over RCCL itself is unmeasured on hardware: DESIGN.md §7). */
+ * the whole orchestration on a one-GPU box; with n_ranks == 1 it runs the rank machinery over a real single-rank RCCL
+ * communicator instead, which executes the RCCL calls themselves (N > 1 over RCCL is unmeasured on hardware: DESIGN.md §7). */
 typedef struct sc_multi sc_multi;
 int         sc_create_multi(const int* device_ids, int n_dev, sc_multi** out);
 int         sc_create_multi_loopback(int device, int n_ranks, sc_multi** out);

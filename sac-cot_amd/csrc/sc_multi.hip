@@ -96,6 +96,7 @@ struct Rank {
 struct sc_multi {
   int n = 0;
   bool loopback = false;
+  bool workers = false;  // the rank machinery (phase API + collectives); false: n == 1, plain sc_register
   std::vector<Rank> ranks;
   Rccl rccl;
   Barrier bar;
@@ -281,7 +282,11 @@ int create_common(const int* device_ids, int n_dev, bool loopback, sc_multi** ou
         if (device_ids[a] == device_ids[b]) return SC_EINVAL;  // one rank per device
   sc_multi* M = new (std::nothrow) sc_multi();
   if (!M) return SC_ENOMEM;
-  M->n = n_dev; M->loopback = loopback;
+  // loopback with ONE rank: the rank machinery over a real single-rank RCCL communicator — the one way to execute the
+  // RCCL calls themselves (dlopen, ncclCommInitAll, ncclAllGather, ncclAllReduce) on a one-GPU box
+  const bool rccl_single = loopback && n_dev == 1;
+  if (rccl_single) loopback = false;
+  M->n = n_dev; M->loopback = loopback; M->workers = n_dev > 1 || rccl_single;
   M->ranks.resize(n_dev);
   M->bar.n = n_dev;
   for (int r = 0; r < n_dev; r++) {
@@ -289,7 +294,7 @@ int create_common(const int* device_ids, int n_dev, bool loopback, sc_multi** ou
     rk.device = device_ids[r];
     const int rc = sc_create(rk.device, &rk.ctx);
     if (rc) { sc_destroy_multi(M); return rc; }
-    if (n_dev > 1) {
+    if (M->workers) {
       if (hipSetDevice(rk.device) != hipSuccess || hipStreamCreateWithFlags(&rk.stream, hipStreamNonBlocking) != hipSuccess ||
           hipMalloc(reinterpret_cast<void**>(&rk.hist), SC_HIST_WORDS * 4) != hipSuccess ||
           hipMalloc(reinterpret_cast<void**>(&rk.keys), 16 * (size_t)n_dev) != hipSuccess ||
@@ -297,14 +302,14 @@ int create_common(const int* device_ids, int n_dev, bool loopback, sc_multi** ou
       (void)sc_set_stream(rk.ctx, rk.stream);  // the collectives are ordered with the kernels on this stream
     }
   }
-  if (n_dev > 1 && !loopback) {  // n_dev == 1 never touches RCCL
+  if (M->workers && !loopback) {  // sc_create_multi with n_dev == 1 never touches RCCL
     if (!M->rccl.open(M->last_error)) { sc_destroy_multi(M); return SC_ERCCL; }
     std::vector<ncclComm_t> comms(n_dev);
     const ncclResult_t e = M->rccl.CommInitAll(comms.data(), n_dev, device_ids);
     if (e != ncclSuccess) { sc_destroy_multi(M); return SC_ERCCL; }
     for (int r = 0; r < n_dev; r++) M->ranks[r].comm = comms[r];
   }
-  if (n_dev > 1)
+  if (M->workers)
     for (int r = 0; r < n_dev; r++) M->ranks[r].worker = std::thread(worker_main, M, r);
   *out = M;
   return SC_OK;
@@ -349,7 +354,7 @@ int sc_register_multi(sc_multi* M, const float* src, const float* tgt, int64_t n
                       float t[3], uint8_t* mask, sc_stats* stats) {
   if (!M || !src || !tgt || !p || !R || !t || !mask || n < 3 || n > (1 << 24)) return SC_EINVAL;
   if (p->size != sizeof(sc_params) || p->shard_world != 1) return SC_EINVAL;  // the sharding is this call's business
-  if (M->n == 1) return sc_register(M->ranks[0].ctx, src, tgt, n, p, R, t, mask, stats);  // no RCCL call at all
+  if (!M->workers) return sc_register(M->ranks[0].ctx, src, tgt, n, p, R, t, mask, stats);  // no RCCL call at all
   M->src = src; M->tgt = tgt; M->npts = n; M->params = *p; M->R = R; M->t = t; M->mask = mask;
   M->bar.worst = SC_OK;
   {

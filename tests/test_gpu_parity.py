@@ -797,11 +797,12 @@ def test_multi_one_device_is_sc_register(pkg, reg):
     assert e.value.status == pkg.SC_EINVAL
 
 
-@pytest.mark.parametrize("ranks", [2, 3, 5])
+@pytest.mark.parametrize("ranks", [1, 2, 3, 5])
 def test_multi_loopback_equals_sc_register(pkg, O, reg, ranks):
     """sc_create_multi_loopback: `ranks` ranks on this one GPU, worker thread each, device copies in place of the RCCL
     collectives — buffers, phase order, error agreement and outputs of sc_register_multi, bit for bit against
-    sc_register and the CPU restatement; then an input error (every rank must report it, nobody may hang), a scene
+    sc_register and the CPU restatement (ranks == 1: the same machinery over a real single-rank RCCL communicator, so
+    librccl is opened and ncclCommInitAll / ncclAllGather / ncclAllReduce really execute); then an input error (every rank must report it, nobody may hang), a scene
     without hypotheses, and the handle reused for another size."""
     m = pkg.MultiRegistrar((0,), loopback_ranks=ranks)
     try:
