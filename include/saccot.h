@@ -58,6 +58,16 @@ extern "C" {
 #define SC_RANK_WEIGHT 0   /* w = (s_ij + s_ik) + s_jk, fp32, descending                     */
 #define SC_RANK_DEGREE 1   /* deg_i + deg_j + deg_k, u32, descending                         */
 
+/* hypothesis scoring (SURVEY §8f-2 `score_mode`).  The winner is the hypothesis with the largest score, ties as before
+ * (best ranking key, then lowest (i,j,k)); the inlier MASK is always the test |R p + t - q| < tau.  The truncated
+ * scores are sums of per-correspondence integers (10 fractional bits), so they are exact, order-free sums:
+ *   SC_SCORE_MSE:  sum over n of  floor(1024 * max(0, 1 - d2_n / tau^2))      (MSAC: truncated squared residual)
+ *   SC_SCORE_MAE:  sum over n of  floor(1024 * max(0, 1 - d_n / tau)),  d_n = sqrt(d2_n)  (truncated absolute residual)
+ * with d2_n the canonical squared residual, 1 / tau^2 and 1 / tau rounded once from fp64, the product by fma. */
+#define SC_SCORE_COUNT 0   /* number of inliers (default)                                      */
+#define SC_SCORE_MSE   1
+#define SC_SCORE_MAE   2
+
 /* flags */
 #define SC_FLAG_TIMING       1u /* record a HIP event pair around every stage and fill sc_stats.us_* (each record  */
                                 /* costs ~5 us of stream time: diagnostics, not for the timed loop)               */
@@ -92,6 +102,8 @@ typedef struct sc_params {
   uint32_t shard_block;     /* ranked triangles are dealt round-robin in blocks of this many (0 -> 1024) */
   uint32_t flags;           /* SC_FLAG_*                                                                */
   uint64_t max_workspace;   /* cap in bytes on the device workspace (0 -> 64 GiB)                       */
+  int32_t  score_mode;      /* SC_SCORE_COUNT / SC_SCORE_MSE / SC_SCORE_MAE                             */
+  int32_t  reserved;        /* 0                                                                        */
 } sc_params;
 
 /* Per-call statistics (all optional: pass NULL).  Times are device times from HIP events on the
@@ -106,7 +118,7 @@ typedef struct sc_stats {
   uint32_t tri_kept;        /* T_eff = min(T, tri_total)                                                */
   uint32_t tri_scored;      /* hypotheses scored by THIS rank                                           */
   uint32_t best_rank;       /* rank index (0-based) of the winning triangle in the ranked list          */
-  uint32_t best_count;      /* its inlier count                                                         */
+  uint32_t best_count;      /* its score: the inlier count, or the truncated score of params.score_mode   */
   float    us_stage;        /* input staging (layout -> padded planes, finiteness check)                */
   float    us_compat;       /* stage A: the compat_rows kernel alone                                    */
   float    us_triangles;    /* stage B: every kernel of it plus its two 8-byte read-backs               */

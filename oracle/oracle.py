@@ -46,6 +46,12 @@ def lib() -> C.CDLL:
         L.so_register.argtypes = [f32p, f32p, C.c_int64, C.c_float, C.c_float, C.c_float, C.c_float, C.c_uint32,
                                   C.c_int, C.c_int, f32p, f32p, u8p, u64p, f64p]
         L.so_refine.argtypes = [f32p, f32p, C.c_int64, u8p, f32p]
+        L.so_derive2.argtypes = [C.c_float, f32p]
+        L.so_derive2.restype = None
+        L.so_score_mode.argtypes = [f32p, f32p, C.c_int64, f32p, C.c_uint32, C.c_float, C.c_int, u32p, C.c_int]
+        L.so_score_mode.restype = None
+        L.so_register_mode.argtypes = [f32p, f32p, C.c_int64, C.c_float, C.c_float, C.c_float, C.c_float, C.c_uint32,
+                                       C.c_int, C.c_int, C.c_int, f32p, f32p, u8p, u64p, f64p]
         L.so_max_threads.restype = C.c_int
         _LIB = L
     return _LIB
@@ -116,13 +122,19 @@ def kabsch3(src: np.ndarray, tgt: np.ndarray, tri: np.ndarray, threads: int = 1)
     return Rt
 
 
-def score(src: np.ndarray, tgt: np.ndarray, Rt: np.ndarray, tau: float, threads: int = 1) -> np.ndarray:
-    """Stage C2.  Returns cnt (T,) u32."""
+def score(src: np.ndarray, tgt: np.ndarray, Rt: np.ndarray, tau: float, threads: int = 1, score_mode: int = 0) -> np.ndarray:
+    """Stage C2.  Returns cnt (T,) u32: inlier counts, or the truncated scores of score_mode 1 / 2."""
     n = src.shape[0]
     Rt = np.ascontiguousarray(Rt, dtype=np.float32)
     cnt = np.zeros(Rt.shape[0], dtype=np.uint32)
     tau2 = np.float32(np.float64(tau) * np.float64(tau))
     ps, qs = soa(src), soa(tgt)
+    if score_mode:
+        inv = np.zeros(2, dtype=np.float32)
+        lib().so_derive2(np.float32(tau), _p(inv, C.c_float))
+        lib().so_score_mode(_p(ps, C.c_float), _p(qs, C.c_float), n, _p(Rt, C.c_float), Rt.shape[0],
+                            inv[score_mode - 1], score_mode, _p(cnt, C.c_uint32), threads)
+        return cnt
     lib().so_score(_p(ps, C.c_float), _p(qs, C.c_float), n, _p(Rt, C.c_float), Rt.shape[0], tau2, _p(cnt, C.c_uint32), threads)
     return cnt
 
@@ -144,7 +156,7 @@ def mask(src: np.ndarray, tgt: np.ndarray, Rt12: np.ndarray, tau: float) -> np.n
 
 
 def register(src: np.ndarray, tgt: np.ndarray, sigma: float, t_cmp: float, tau: float, min_len: float,
-             max_triangles: int, rank_mode: int = 0, threads: int = 1):
+             max_triangles: int, rank_mode: int = 0, threads: int = 1, score_mode: int = 0):
     """Whole path.  Returns dict(rc, R, t, mask, edges, tri_total, t_eff, best_rank, best_count, stage_s)."""
     n = src.shape[0]
     ps, qs = soa(src), soa(tgt)
@@ -153,9 +165,9 @@ def register(src: np.ndarray, tgt: np.ndarray, sigma: float, t_cmp: float, tau: 
     m = np.zeros(n, dtype=np.uint8)
     st = np.zeros(5, dtype=np.uint64)
     ss = np.zeros(5, dtype=np.float64)
-    rc = lib().so_register(_p(ps, C.c_float), _p(qs, C.c_float), n, sigma, t_cmp, tau, min_len, max_triangles,
-                           rank_mode, threads, _p(R, C.c_float), _p(t, C.c_float), _p(m, C.c_uint8),
-                           _p(st, C.c_uint64), _p(ss, C.c_double))
+    rc = lib().so_register_mode(_p(ps, C.c_float), _p(qs, C.c_float), n, sigma, t_cmp, tau, min_len, max_triangles,
+                                rank_mode, score_mode, threads, _p(R, C.c_float), _p(t, C.c_float), _p(m, C.c_uint8),
+                                _p(st, C.c_uint64), _p(ss, C.c_double))
     return dict(rc=rc, R=R.reshape(3, 3), t=t, mask=m, edges=int(st[0]), tri_total=int(st[1]), t_eff=int(st[2]),
                 best_rank=int(st[3]), best_count=int(st[4]), stage_s=ss)
 

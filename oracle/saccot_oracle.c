@@ -387,6 +387,40 @@ static inline int finite12(const float* Rt) {
   return 1;
 }
 
+/* score_mode (include/saccot.h): 0 inlier count; 1 sum of floor(1024 max(0, 1 - d2 / tau^2));
+ * 2 sum of floor(1024 max(0, 1 - sqrt(d2) / tau)).  thr: tau^2, 1 / tau^2 or 1 / tau (so_derive2). */
+static inline uint32_t score_term(const float* Rt, float px, float py, float pz, float qx, float qy, float qz,
+                                  float thr, int mode) {
+  float ex = Rt[9]  + fmaf(Rt[2], pz, fmaf(Rt[1], py, fmaf(Rt[0], px, -qx)));
+  float ey = Rt[10] + fmaf(Rt[5], pz, fmaf(Rt[4], py, fmaf(Rt[3], px, -qy)));
+  float ez = Rt[11] + fmaf(Rt[8], pz, fmaf(Rt[7], py, fmaf(Rt[6], px, -qz)));
+  float d2 = fmaf(ez, ez, fmaf(ey, ey, ex * ex));
+  if (mode == 0) return d2 < thr;
+  float x = mode == 1 ? d2 : sqrtf(d2);
+  return (uint32_t)(fmaxf(fmaf(-x, thr, 1.0f), 0.0f) * 1024.0f);
+}
+
+void so_derive2(float tau, float* out) { /* out[0] = 1 / tau^2, out[1] = 1 / tau, from fp64 */
+  out[0] = (float)(1.0 / ((double)tau * (double)tau));
+  out[1] = (float)(1.0 / (double)tau);
+}
+
+void so_score_mode(const float* src, const float* tgt, int64_t n, const float* Rt, uint32_t T, float thr, int mode,
+                   uint32_t* cnt, int n_threads) {
+  const float *px = src, *py = src + n, *pz = src + 2 * n;
+  const float *qx = tgt, *qy = tgt + n, *qz = tgt + 2 * n;
+#ifdef _OPENMP
+#pragma omp parallel for schedule(static) num_threads(n_threads > 0 ? n_threads : 1)
+#endif
+  for (int64_t h = 0; h < (int64_t)T; h++) {
+    const float* M = Rt + 12 * h;
+    uint32_t c = 0;
+    if (finite12(M))
+      for (int64_t m = 0; m < n; m++) c += score_term(M, px[m], py[m], pz[m], qx[m], qy[m], qz[m], thr, mode);
+    cnt[h] = c;
+  }
+}
+
 void so_score(const float* src, const float* tgt, int64_t n, const float* Rt, uint32_t T, float tau2,
               uint32_t* cnt, int n_threads) {
   const float *px = src, *py = src + n, *pz = src + 2 * n;
@@ -525,10 +559,20 @@ static double now_s(void) {
 #endif
 }
 
+int so_register_mode(const float* src, const float* tgt, int64_t n, float sigma, float t_cmp, float tau,
+                     float min_len, uint32_t T, int rank_mode, int score_mode, int n_threads, float* R, float* t,
+                     uint8_t* mask, uint64_t* stats, double* stage_s);
+
 int so_register(const float* src, const float* tgt, int64_t n, float sigma, float t_cmp, float tau,
                 float min_len, uint32_t T, int rank_mode, int n_threads, float* R, float* t,
                 uint8_t* mask, uint64_t* stats, double* stage_s) {
-  if (n < 3 || T == 0) return SO_EINVAL;
+  return so_register_mode(src, tgt, n, sigma, t_cmp, tau, min_len, T, rank_mode, 0, n_threads, R, t, mask, stats, stage_s);
+}
+
+int so_register_mode(const float* src, const float* tgt, int64_t n, float sigma, float t_cmp, float tau,
+                     float min_len, uint32_t T, int rank_mode, int score_mode, int n_threads, float* R, float* t,
+                     uint8_t* mask, uint64_t* stats, double* stage_s) {
+  if (n < 3 || T == 0 || score_mode < 0 || score_mode > 2) return SO_EINVAL;
   float dv[3];
   if (so_derive(sigma, t_cmp, tau, dv)) return SO_EINVAL;
   for (int64_t m = 0; m < 3 * n; m++) if (!isfinite(src[m]) || !isfinite(tgt[m])) return SO_EINVAL;
@@ -553,7 +597,12 @@ int so_register(const float* src, const float* tgt, int64_t n, float sigma, floa
   if (rc) goto done;
   so_kabsch3(src, tgt, n, tri, t_eff, Rt, n_threads);
   double t3 = now_s();
-  so_score(src, tgt, n, Rt, t_eff, dv[2], cnt, n_threads);
+  if (score_mode == 0) so_score(src, tgt, n, Rt, t_eff, dv[2], cnt, n_threads);
+  else {
+    float inv[2];
+    so_derive2(tau, inv);
+    so_score_mode(src, tgt, n, Rt, t_eff, inv[score_mode - 1], score_mode, cnt, n_threads);
+  }
   uint64_t best = so_best_key(cnt, t_eff, NULL);
   double t4 = now_s();
   if (stats) { stats[0] = edges / 2; stats[1] = tri_total; stats[2] = t_eff; stats[3] = 0; stats[4] = 0; }

@@ -19,6 +19,7 @@ LIB_PATH = os.path.join(_HERE, "libsaccot.so")
 SC_OK, SC_EINVAL, SC_ENOMEM, SC_EHIP, SC_ERCCL, SC_ENOHYP, SC_ETOOMANY = 0, -1, -2, -3, -4, -5, -6
 SC_AOS, SC_SOA = 0, 1
 SC_RANK_WEIGHT, SC_RANK_DEGREE = 0, 1
+SC_SCORE_COUNT, SC_SCORE_MSE, SC_SCORE_MAE = 0, 1, 2
 SC_FLAG_TIMING, SC_FLAG_EXACT_TOTAL, SC_FLAG_NO_PRUNE, SC_FLAG_REFINE, SC_FLAG_TIMING_HOT, SC_FLAG_NO_DENSE_S = 1, 2, 4, 8, 16, 32
 SC_FLAG_TIMING_ONE = 64
 
@@ -44,7 +45,8 @@ class ScParams(C.Structure):
     _fields_ = [("size", C.c_uint32), ("sigma", C.c_float), ("t_cmp", C.c_float), ("tau", C.c_float),
                 ("min_len", C.c_float), ("max_triangles", C.c_uint32), ("rank_mode", C.c_int32),
                 ("layout", C.c_int32), ("shard_rank", C.c_int32), ("shard_world", C.c_int32),
-                ("shard_block", C.c_uint32), ("flags", C.c_uint32), ("max_workspace", C.c_uint64)]
+                ("shard_block", C.c_uint32), ("flags", C.c_uint32), ("max_workspace", C.c_uint64),
+                ("score_mode", C.c_int32), ("reserved", C.c_int32)]
 
 
 class ScStats(C.Structure):
@@ -139,9 +141,10 @@ def load_library() -> C.CDLL:
 
 
 def make_params(sigma=0.1, t_cmp=0.9, tau=0.1, min_len=0.1, max_triangles=50000, rank_mode=SC_RANK_WEIGHT,
-                layout=SC_AOS, shard_rank=0, shard_world=1, shard_block=1024, flags=0, max_workspace=0) -> ScParams:
+                layout=SC_AOS, shard_rank=0, shard_world=1, shard_block=1024, flags=0, max_workspace=0,
+                score_mode=0) -> ScParams:
     return ScParams(C.sizeof(ScParams), sigma, t_cmp, tau, min_len, max_triangles, rank_mode, layout, shard_rank,
-                    shard_world, shard_block, flags, max_workspace)
+                    shard_world, shard_block, flags, max_workspace, score_mode, 0)
 
 
 def shard_plan(params: ScParams, n: int) -> ScShardPlan:

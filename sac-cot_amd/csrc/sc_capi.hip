@@ -126,6 +126,7 @@ int check_params(const sc_params* p) {
   if (p->rank_mode != SC_RANK_WEIGHT && p->rank_mode != SC_RANK_DEGREE) return SC_EINVAL;
   if (p->layout != SC_AOS && p->layout != SC_SOA) return SC_EINVAL;
   if (p->shard_world < 1 || p->shard_rank < 0 || p->shard_rank >= p->shard_world) return SC_EINVAL;
+  if (p->score_mode < SC_SCORE_COUNT || p->score_mode > SC_SCORE_MAE) return SC_EINVAL;
   return SC_OK;
 }
 
@@ -136,6 +137,8 @@ Derived derive(const sc_params* p) {
   d.neg_inv2sig2 = (float)(-1.0 / (2.0 * (double)p->sigma * (double)p->sigma));
   d.tau2 = (float)((double)p->tau * (double)p->tau);
   d.min_len = p->min_len;
+  d.inv_tau2 = (float)(1.0 / ((double)p->tau * (double)p->tau));
+  d.inv_tau = (float)(1.0 / (double)p->tau);
   return d;
 }
 
@@ -192,6 +195,10 @@ int set_timing(sc_ctx* c, const sc_params* p) {
 // user points (device) -> padded planes; zero the "non-finite" flag first
 int stage_inputs(sc_ctx* c, const float* d_src, const float* d_tgt, int64_t n, const sc_params* p) {
   if (n < 3 || n > (1 << 24)) return SC_EINVAL;
+  if (p->score_mode != SC_SCORE_COUNT && n > (1 << 21)) {  // 1024 n must stay below 2^31 (the score rides a u32)
+    c->last_error = "score_mode MSE / MAE needs n <= 2^21";
+    return SC_EINVAL;
+  }
   c->n = (int)n;
   c->ld = round_up((int)n, 64);
   ENSURE(c, c->planes, (size_t)(6 + 8) * c->ld * sizeof(float));  // 6 SoA planes + the AoS copy (8 floats each)
@@ -552,6 +559,7 @@ void sc_default_params(sc_params* p) {
   p->layout = SC_AOS;
   p->shard_rank = 0; p->shard_world = 1; p->shard_block = 1024;
   p->flags = 0; p->max_workspace = 0;
+  p->score_mode = SC_SCORE_COUNT; p->reserved = 0;
 }
 
 int sc_create(int device, sc_ctx** out) {
@@ -694,7 +702,7 @@ int run_stage_c(sc_ctx* c, uint64_t* d_key, sc_stats* stats) {
     launch_kabsch(points_of(c), tri_source_of(c), sh, c->rt.as<float>(), c->stream);
   }
   if ((rc = rec(c, 4))) return rc;
-  launch_score(points_of(c), c->rt.as<float>(), sh, c->dv.tau2, c->partial.as<uint32_t>(), c->tn, c->stream);
+  launch_score(points_of(c), c->rt.as<float>(), sh, c->dv, p->score_mode, c->partial.as<uint32_t>(), c->tn, c->stream);
   if ((rc = rec(c, 5))) return rc;
   ENSURE(c, c->amx_pairs, argmax_scratch_bytes(sh.ld_local));
   launch_argmax(points_of(c), sh, c->partial.as<uint32_t>(), c->T_eff ? c->sel_key.as<uint32_t>() : nullptr,
@@ -1069,7 +1077,7 @@ int sc_score_host(sc_ctx* c, const float* src, const float* tgt, int64_t n, cons
     HIPCHK(c, hipMemcpyAsync(c->rt_aos.p, Rt, (size_t)n_hyp * 48, hipMemcpyHostToDevice, c->stream));
     launch_rt_to_soa(c->rt_aos.as<float>(), n_hyp, sh.ld_local, c->rt.as<float>(), c->stream);
   }
-  launch_score(points_of(c), c->rt.as<float>(), sh, c->dv.tau2, c->partial.as<uint32_t>(), c->tn, c->stream);
+  launch_score(points_of(c), c->rt.as<float>(), sh, c->dv, p->score_mode, c->partial.as<uint32_t>(), c->tn, c->stream);
   ENSURE(c, c->cnt, (size_t)(sh.ld_local ? sh.ld_local : 256) * 4);
   ENSURE(c, c->amx_pairs, argmax_scratch_bytes(sh.ld_local));
   launch_argmax(points_of(c), sh, c->partial.as<uint32_t>(), nullptr, c->cnt.as<uint32_t>(), c->amx_pairs.as<uint64_t>(),

@@ -13,6 +13,8 @@ struct Derived {
   float neg_inv2sig2;  // -1 / (2 sigma^2)
   float tau2;          // tau^2
   float min_len;
+  float inv_tau2;      // 1 / tau^2   (score modes MSE / MAE, include/saccot.h)
+  float inv_tau;       // 1 / tau
 };
 
 // Scheduling / fallback knobs of the kernels.  The shipped library reads NO environment variable: these defaults are
@@ -292,8 +294,9 @@ void launch_kabsch_aos(const Points& pts, const uint32_t* tri, uint32_t T, float
 void launch_rt_to_soa(const float* Rt, uint32_t T, uint32_t ld_local, float* RtSoA, hipStream_t st);
 // C2: inlier counts.  partial: n_chunks * ld_local u32 scratch.
 uint32_t score_chunks(int n, uint32_t ld_local);  // point chunks the scoring launch will use
-void launch_score(const Points& pts, const float* RtSoA, const Shard& sh, float tau2, uint32_t* partial,
-                  const Tuning& tn, hipStream_t st);
+// score_mode: 0 inlier count, 1 truncated squared residual, 2 truncated absolute residual (include/saccot.h)
+void launch_score(const Points& pts, const float* RtSoA, const Shard& sh, const Derived& dv, int score_mode,
+                  uint32_t* partial, const Tuning& tn, hipStream_t st);
 // Winner key pair key2[0..1] (written, not accumulated: no zeroing needed):
 //   key2[0] = max over hypotheses with count > 0 of  (count << 32) | second,   second = sel_key[g] (the triangle's
 //             ranking key) or, when sel_key == nullptr, 0xFFFFFFFF - g;

@@ -151,11 +151,19 @@ uint32_t score_chunks(int n, uint32_t ld_local) {
 
 // One inlier test, written so that hipcc keeps 17 single-issue VALU ops (build.py passes -fno-slp-vectorize:
 // SLP packing turns the chain into v_pk_* plus ~5 v_mov per test, which is slower on gfx950).
-__device__ __forceinline__ uint32_t inlier_bit(const float (&M)[12], const float4 a, const float2 b, float tau2) {
-  return resid2(M, a.x, a.y, a.z, a.w, b.x, b.y) < tau2 ? 1u : 0u;
+// MODE 0: 1 if inlier.  MODE 1 / 2 (include/saccot.h, SC_SCORE_MSE / _MAE): floor(1024 max(0, 1 - d2 / tau^2)) resp.
+// floor(1024 max(0, 1 - d / tau)) — integers, so the sum over the correspondences is exact in any order.  `thr` is
+// tau^2, 1 / tau^2 or 1 / tau.  (d2 = +inf -> fma = -inf -> 0; the float -> u32 conversion truncates.)
+template <int MODE>
+__device__ __forceinline__ uint32_t inlier_bit(const float (&M)[12], const float4 a, const float2 b, float thr) {
+  const float d2 = resid2(M, a.x, a.y, a.z, a.w, b.x, b.y);
+  if (MODE == 0) return d2 < thr ? 1u : 0u;
+  const float x = MODE == 1 ? d2 : sqrt_rn(d2);
+  return (uint32_t)(fmaxf(fma_(-x, thr, 1.0f), 0.0f) * 1024.0f);
 }
 
 // VALU body: lane = hypothesis.  bx = workgroup index along the hypotheses (256 per workgroup), hyp_base = first one.
+template <int MODE>
 __device__ __forceinline__ void score_valu_body(float4* __restrict__ smem, uint32_t hyp_base, int chunk,
                                                 const float* __restrict__ planes, int n, int ld,
                                                 const float* __restrict__ RtSoA, uint32_t ld_local, float tau2,
@@ -170,7 +178,7 @@ __device__ __forceinline__ void score_valu_body(float4* __restrict__ smem, uint3
     if (t < cnt_pts) {
       pA[t] = make_float4(planes[m], planes[(size_t)ld + m], planes[2 * (size_t)ld + m], planes[3 * (size_t)ld + m]);
       pB[t] = make_float2(planes[4 * (size_t)ld + m], planes[5 * (size_t)ld + m]);
-    } else {  // sentinel: p = 0, q = 1e30 -> residual ~1e30, squared = +inf, never < tau2, never NaN
+    } else {  // sentinel: p = 0, q = 1e30 -> residual ~1e30, squared = +inf: never < tau2, score 0, never NaN
       pA[t] = make_float4(0.f, 0.f, 0.f, 1e30f);
       pB[t] = make_float2(1e30f, 1e30f);
     }
@@ -186,10 +194,10 @@ __device__ __forceinline__ void score_valu_body(float4* __restrict__ smem, uint3
   for (int t = 0; t < padded; t += 4) {
     const float4 a0 = pA[t], a1 = pA[t + 1], a2 = pA[t + 2], a3 = pA[t + 3];
     const float2 b0 = pB[t], b1 = pB[t + 1], b2 = pB[t + 2], b3 = pB[t + 3];
-    c0 += inlier_bit(M, a0, b0, tau2);
-    c1 += inlier_bit(M, a1, b1, tau2);
-    c2 += inlier_bit(M, a2, b2, tau2);
-    c3 += inlier_bit(M, a3, b3, tau2);
+    c0 += inlier_bit<MODE>(M, a0, b0, tau2);
+    c1 += inlier_bit<MODE>(M, a1, b1, tau2);
+    c2 += inlier_bit<MODE>(M, a2, b2, tau2);
+    c3 += inlier_bit<MODE>(M, a3, b3, tau2);
   }
   partial[(size_t)chunk * ld_local + l] = ok ? (c0 + c1) + (c2 + c3) : 0u;
 }
@@ -283,6 +291,7 @@ __device__ __forceinline__ void score_mfma_body(float4* __restrict__ smem, uint3
 // and matrix pipes work at the same time (cdna guide: "MFMA and VALU pipes are separate").
 // __launch_bounds__(256, 8): <= 64 VGPRs, 8 waves per SIMD — plain v_fma_f32 needs that occupancy on gfx950
 // (measured 45 / 80 / 99 / 117 TFLOP/s at 1 / 2 / 4 / 8 waves per SIMD, tools/ubench_valu.hip).
+template <int MODE>
 __global__ __launch_bounds__(SCORE_THREADS, 8) void score_kernel(const float* __restrict__ planes, int n, int ld,
                                                                  const float* __restrict__ RtSoA, uint32_t ld_local,
                                                                  float tau2, int chunk_pts,
@@ -292,11 +301,11 @@ __global__ __launch_bounds__(SCORE_THREADS, 8) void score_kernel(const float* __
   const uint32_t bx = blockIdx.x, tot = nv + nm;
   // Bresenham spread of the nm MFMA workgroups among the nv VALU ones
   const uint32_t m_before = (uint32_t)(((uint64_t)bx * nm) / tot), m_after = (uint32_t)(((uint64_t)(bx + 1) * nm) / tot);
-  if (m_after != m_before)
+  if (MODE == 0 && m_after != m_before)  // the matrix-pipe body counts inliers only
     score_mfma_body(smem, nv * SCORE_THREADS + m_before * MF_HYPS_PER_BLOCK, blockIdx.y, planes, n, ld, RtSoA, ld_local,
                     tau2, chunk_pts, partial);
   else
-    score_valu_body(smem, (bx - m_before) * SCORE_THREADS, blockIdx.y, planes, n, ld, RtSoA, ld_local, tau2, chunk_pts,
+    score_valu_body<MODE>(smem, (bx - m_before) * SCORE_THREADS, blockIdx.y, planes, n, ld, RtSoA, ld_local, tau2, chunk_pts,
                     partial);
 }
 
@@ -365,17 +374,26 @@ __global__ __launch_bounds__(256) void score_argmax_kernel(const uint32_t* __res
 }
 
 // Tuning::score_split: share of the hypotheses (in 256ths) scored on the matrix pipe (default 0; experiments)
-void launch_score(const Points& pts, const float* RtSoA, const Shard& sh, float tau2, uint32_t* partial,
-                  const Tuning& tn, hipStream_t st) {
+void launch_score(const Points& pts, const float* RtSoA, const Shard& sh, const Derived& dv, int score_mode,
+                  uint32_t* partial, const Tuning& tn, hipStream_t st) {
   if (sh.n_local == 0) return;
   uint32_t chunks;
   int chunk_pts;
   score_plan(pts.n, sh.ld_local, &chunks, &chunk_pts);
   const uint32_t groups = sh.ld_local / SCORE_THREADS;            // 256-hypothesis groups
-  const uint32_t gm = (uint32_t)(((uint64_t)groups * (tn.score_split <= 256 ? tn.score_split : 256u) + 128) / 256);  // groups on the matrix pipe
+  const uint32_t split = score_mode == 0 ? (tn.score_split <= 256 ? tn.score_split : 256u) : 0u;
+  const uint32_t gm = (uint32_t)(((uint64_t)groups * split + 128) / 256);  // groups on the matrix pipe
   const uint32_t nv = groups - gm, nm = gm * (SCORE_THREADS / MF_HYPS_PER_BLOCK);
-  hipLaunchKernelGGL(score_kernel, dim3(nv + nm, chunks), dim3(SCORE_THREADS), 0, st, pts.planes, pts.n, pts.ld,
-                     RtSoA, sh.ld_local, tau2, chunk_pts, partial, nv, nm);
+  const dim3 grid(nv + nm, chunks);
+  if (score_mode == 1)
+    hipLaunchKernelGGL(score_kernel<1>, grid, dim3(SCORE_THREADS), 0, st, pts.planes, pts.n, pts.ld, RtSoA, sh.ld_local,
+                       dv.inv_tau2, chunk_pts, partial, nv, nm);
+  else if (score_mode == 2)
+    hipLaunchKernelGGL(score_kernel<2>, grid, dim3(SCORE_THREADS), 0, st, pts.planes, pts.n, pts.ld, RtSoA, sh.ld_local,
+                       dv.inv_tau, chunk_pts, partial, nv, nm);
+  else
+    hipLaunchKernelGGL(score_kernel<0>, grid, dim3(SCORE_THREADS), 0, st, pts.planes, pts.n, pts.ld, RtSoA, sh.ld_local,
+                       dv.tau2, chunk_pts, partial, nv, nm);
 }
 
 size_t argmax_scratch_bytes(uint32_t ld_local) { return (size_t)(ld_local / 256 + 1) * 2 * sizeof(uint64_t); }

@@ -36,7 +36,7 @@ def test_struct_layouts_match(pkg):
     L = pkg.load_library()
     p = pkg.ScParams()
     L.sc_default_params(C.byref(p))
-    assert p.size == C.sizeof(pkg.ScParams) == 56
+    assert p.size == C.sizeof(pkg.ScParams) == 64
     assert (p.t_cmp, p.max_triangles, p.shard_world, p.shard_block) == (pytest.approx(0.9), 50000, 1, 1024)
     # sc_stats: compile a probe against the header and compare sizeof
     exe = os.path.join(ROOT, "tests", ".abi_probe")

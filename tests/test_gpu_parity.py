@@ -828,3 +828,61 @@ def test_multi_loopback_equals_sc_register(pkg, O, reg, ranks):
         assert got["R"].tobytes() == base["R"].tobytes() and np.array_equal(got["mask"], base["mask"])
     finally:
         m.close()
+
+
+# ---------------------------------------------------------------------------------------------------------
+# SURVEY §8f-2 `score_mode`: truncated squared / absolute residual instead of the inlier count
+# ---------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("mode", [1, 2])
+def test_score_modes_bit_exact(pkg, O, reg, mode):
+    """Every hypothesis' truncated score (an exact integer sum), the winner key, and the whole path — unsharded, sharded
+    A + B and through the multi-device loopback — against the CPU restatement."""
+    import torch
+    n, T = 1100, 3000
+    sc = _scene(pkg, n, seed=n)
+    rng = np.random.default_rng(n)
+    inl = np.nonzero(sc.inlier)[0]
+    tri = np.sort(np.stack([rng.choice(inl if h % 2 else n, 3, replace=False) for h in range(T)]), axis=1).astype(np.uint32)
+    Rt0 = O.kabsch3(sc.src, sc.tgt, tri)
+    Rt0[5, 1] = np.nan
+    kw = _params(pkg, 0.05, T)
+    cnt, key = reg.score(sc.src, sc.tgt, pkg.make_params(score_mode=mode, **kw), Rt0)
+    cnt0 = O.score(sc.src, sc.tgt, Rt0, kw["tau"], score_mode=mode)
+    assert cnt0.max() > 50_000 and cnt0[5] == 0
+    assert np.array_equal(cnt, cnt0) and key == O.best_key(cnt0)
+    for name in ("C0", "C1", "C2"):
+        cfg, scene = pkg.synth.make_config_scene(name)
+        ref = O.register(scene.src, scene.tgt, threads=8, score_mode=mode, **cfg.params())
+        got = reg.register(scene.src, scene.tgt, score_mode=mode, **cfg.params())
+        assert got["status"] == ref["rc"] == 0
+        assert (got["stats"]["best_rank"], got["stats"]["best_count"]) == (ref["best_rank"], ref["best_count"])
+        assert np.array_equal(got["mask"], ref["mask"]) and nan_equal_bits(got["R"], ref["R"]) and nan_equal_bits(got["t"], ref["t"])
+        assert got["stats"]["best_count"] <= 1024 * int(ref["mask"].sum())
+    dev = torch.device("cuda:0")
+    d_src = torch.from_numpy(scene.src).to(dev); d_tgt = torch.from_numpy(scene.tgt).to(dev)
+    rc, st, Rt, mask, _ = _run_sharded_ab(pkg, cfg.n, dict(cfg.params(), score_mode=mode), d_src, d_tgt, 3)
+    assert rc == 0 and (st["best_rank"], st["best_count"]) == (ref["best_rank"], ref["best_count"]) and np.array_equal(mask, ref["mask"])
+    m = pkg.MultiRegistrar((0,), loopback_ranks=2)
+    try:
+        out = m.register(scene.src, scene.tgt, score_mode=mode, **cfg.params())
+    finally:
+        m.close()
+    assert out["stats"]["best_rank"] == ref["best_rank"] and np.array_equal(out["mask"], ref["mask"])
+
+
+def test_known_answer_bars_per_mode(pkg, reg):
+    """SURVEY §8c known-answer bars on synthetic ground truth, stated per mode: a raw 3-point hypothesis is coarse
+    (rotation < 3 deg, mask covers >= 90 % of the true inliers); with SC_FLAG_REFINE (the least-squares refit over the
+    winner's inliers) the survey's bars hold: rotation < 0.5 deg, translation < tau, mask >= 95 % of the true inliers."""
+    for name in ("C0", "C1", "C2"):
+        cfg, scene = pkg.synth.make_config_scene(name)
+        raw = reg.register(scene.src, scene.tgt, **cfg.params())
+        ref = reg.register(scene.src, scene.tgt, flags=pkg.SC_FLAG_REFINE, **cfg.params())
+        assert pkg.synth.rotation_error_deg(raw["R"], scene.R_gt) < 3.0
+        assert (raw["mask"].astype(bool) & scene.inlier).sum() >= 0.90 * scene.inlier.sum()
+        assert pkg.synth.rotation_error_deg(ref["R"], scene.R_gt) < 0.5
+        assert np.linalg.norm(ref["t"] - scene.t_gt) < cfg.tau
+        # the refit's own inlier set (the returned mask stays the fp32 winner's, by contract)
+        e = scene.src.astype(np.float64) @ ref["R"].astype(np.float64).T + ref["t"] - scene.tgt
+        refit_mask = (e * e).sum(1) < cfg.tau ** 2
+        assert (refit_mask & scene.inlier).sum() >= 0.95 * scene.inlier.sum()

@@ -246,3 +246,31 @@ print("asan-ok")
     r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "asan-ok" in r.stdout, (r.stdout[-2000:], r.stderr[-4000:])
     assert "runtime error" not in r.stderr and "AddressSanitizer" not in r.stderr, r.stderr[-4000:]
+
+
+@pytest.mark.parametrize("mode", [1, 2])
+def test_truncated_scores_against_fp64(pkg, O, mode):
+    """SURVEY §8f-2 `score_mode`: the truncated-MSE / truncated-MAE scores are sums of floor(1024 * max(0, 1 - x)) with
+    x = d2 / tau^2 resp. d / tau.  Against a float64 recomputation every term can differ by one unit at most (fp32
+    rounding of the residual at a quantisation step), and only terms that are positive on either side."""
+    sc = pkg.synth.make_scene(400, 0.4, 1.0, 0.05, 13)
+    rng = np.random.default_rng(13)
+    inl = np.nonzero(sc.inlier)[0]
+    tri = np.sort(np.stack([rng.choice(inl if h % 2 else 400, 3, replace=False) for h in range(300)]), axis=1).astype(np.uint32)
+    Rt = O.kabsch3(sc.src, sc.tgt, tri)
+    tau = 0.05
+    got = O.score(sc.src, sc.tgt, Rt, tau, score_mode=mode).astype(np.int64)
+    cnt = O.score(sc.src, sc.tgt, Rt, tau).astype(np.int64)
+    ok = np.isfinite(Rt).all(axis=1)
+    R = Rt[:, :9].reshape(-1, 3, 3).astype(np.float64); t = Rt[:, 9:].astype(np.float64)
+    e = np.einsum("hij,nj->hni", R, sc.src.astype(np.float64)) + t[:, None, :] - sc.tgt.astype(np.float64)[None]
+    d2 = (e * e).sum(-1)
+    x = d2 / tau ** 2 if mode == 1 else np.sqrt(d2) / tau
+    ref = np.floor(1024 * np.clip(1 - x, 0, None)).sum(-1)
+    pos = (x < 1 + 1e-4).sum(-1)
+    assert np.all(np.abs(got[ok] - ref[ok]) <= pos[ok] + 1)
+    assert np.all(got[ok] <= 1024 * cnt[ok]) and got[ok].max() > 20000 and not got[~ok].any()
+    for kw in (dict(), dict(score_mode=mode)):                              # the whole path runs in the new mode too
+        cfg, scene = pkg.synth.make_config_scene("C0")
+        res = O.register(scene.src, scene.tgt, threads=2, **cfg.params(), **kw)
+        assert res["rc"] == 0 and pkg.synth.rotation_error_deg(res["R"], scene.R_gt) < 3.0
