@@ -76,7 +76,8 @@ class ScDebug(C.Structure):
                 ("cnt_blocks", C.c_uint32), ("keys_blocks", C.c_uint32), ("sel_blocks", C.c_uint32),
                 ("tg_count", C.c_uint32), ("tg_keys", C.c_uint32), ("tg_sample", C.c_uint32),
                 ("sample_edges", C.c_uint64), ("score_split", C.c_uint32), ("compat_one_phase", C.c_uint32),
-                ("compat_rows", C.c_uint32), ("compat_store_mode", C.c_uint32), ("tg_events", C.c_uint32), ("reserved", C.c_uint32)]
+                ("compat_rows", C.c_uint32), ("compat_store_mode", C.c_uint32), ("tg_events", C.c_uint32), ("sample_mode", C.c_uint32),
+                ("sample_blocks", C.c_uint32), ("reserved", C.c_uint32)]
 
 
 class SacCotError(RuntimeError):

@@ -341,7 +341,7 @@ int run_edges(sc_ctx* c, const sc_params* p, uint32_t* hist, uint32_t part, uint
     // the smallest possible weight is ~3 t_cmp (every edge has s >= t_cmp up to rounding); 0.1 % slack
     launch_sample_hist(g, c->ebi.as<uint32_t>(), c->ebj.as<uint32_t>(), c->ei.as<uint32_t>(), c->ej.as<uint32_t>(),
                        c->es.as<float>(), E, p->max_triangles, 3.0f * p->t_cmp * 0.999f, part, parts,
-                       ctl->prune_hist, c->tn, st);
+                       ctl->prune_hist, ctl->es_hist, c->tn, st);
     if (hist) launch_hist_reduce(ctl->prune_hist, hist, st);  // the exchanged form: one 256-bin histogram
   }
   return SC_OK;
@@ -638,6 +638,8 @@ int sc_set_debug(sc_ctx* c, const sc_debug* d) {
   t.compat_one_phase = d->compat_one_phase != 0;
   t.compat_rows = d->compat_rows == 64 ? 64 : 16;
   t.compat_store_mode = d->compat_store_mode & 7u;
+  t.sample_mode = d->sample_mode ? 1u : 0u;
+  t.sample_blocks = d->sample_blocks;
   c->tn = t;
   return SC_OK;
 }

@@ -28,6 +28,8 @@ struct Tuning {
   uint32_t cnt_blocks = 0, keys_blocks = 0, sel_blocks = 0;  // grid sizes (0: automatic)
   int tg_count = 8, tg_keys = 8, tg_sample = 0;              // lanes per edge (tg_sample 0: by row width)
   int tg_events = 0;               // lanes per edge of the event-recording counting pass (0: by row width)
+  uint32_t sample_mode = 0;        // pruning sample: 0 the heaviest edges (weight histogram), 1 every stride-th edge
+  uint32_t sample_blocks = 0;      // grid of the heaviest-edge sample (0: one block per 1024 edges)
   uint64_t sample_edges = 0;       // edges of the pruning sample (0: automatic, ~5T/8)
   uint32_t score_split = 0;        // share (of 256) of the hypotheses scored on the matrix pipe
   bool compat_one_phase = false;   // exact chain on every pair of an interior tile
@@ -133,7 +135,8 @@ size_t strong_list_bytes(uint64_t E);
 //    with sl.list set also compacts the strong edges and zeroes tcnt of the weak ones.
 void launch_sample_hist(const Graph& g, const uint32_t* ebi, const uint32_t* ebj, const uint32_t* ei,
                         const uint32_t* ej, const float* es, uint64_t E, uint64_t want, float key_floor, uint32_t part,
-                        uint32_t parts, uint32_t* hist, const Tuning& tn, hipStream_t st);
+                        uint32_t parts, uint32_t* hist, uint32_t* es_hist, const Tuning& tn, hipStream_t st);
+// es_hist: PR_HCOPIES x 256 zeroed words (control block) for the weight histogram of the heaviest-edge sample
 // launch_sample_hist ALWAYS accumulates into PR_HCOPIES x 256 words (`hist` = the control block's copies);
 // launch_hist_reduce sums them into one 256-bin histogram (the exchanged form); launch_prune_bits reads either
 // (hist_is_copies).
@@ -186,6 +189,7 @@ constexpr int PR_HCOPIES = 4;  // global copies of the pruning-sample histogram 
 struct ControlBlock {
   uint32_t ev_fill[1024];    // event-list region fill counters (EV_SHARDS)
   uint32_t prune_hist[PR_HCOPIES * 256];  // sampled key histogram of the certified pruning, PR_HCOPIES partial copies
+  uint32_t es_hist[PR_HCOPIES * 256];     // edge-weight histogram (which edges the sample takes), same layout
   uint32_t st_fill[256];     // strong-edge list region fill counters (ST_SHARDS)
   float smin;                // strong-edge threshold (written by prune_bits_kernel)
   uint32_t amx_ticket;       // blocks-finished counter of score_argmax_kernel

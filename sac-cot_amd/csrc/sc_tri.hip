@@ -672,7 +672,41 @@ __device__ __forceinline__ uint32_t prune_bin(uint32_t key, uint32_t klo, uint32
   return b < (uint32_t)PR_BINS ? b : (uint32_t)(PR_BINS - 1);
 }
 
-template <int TG>
+// Which edges are sampled.  Any subset of genuine triangles certifies a bound; the question is which subset certifies
+// a TIGHT one for the fewest key evaluations.
+//   TOP = false: every stride-th edge (round 1).  The T-th largest sampled key is then about the (stride x T)-th key
+//     of the graph: with ~32 k sampled edges on C2 the certified subgraph still holds 1.47 M triangles for T = 50 k.
+//   TOP = true: the `target` HEAVIEST edges (weight at or above the lower edge of the bin of a 256-bin weight histogram
+//     where the count from the top reaches target; es_hist_kernel).  A top triangle has three heavy edges, so its first
+//     edge is far more likely to be in this set than in a uniform sample of the same size.  A block takes a contiguous
+//     chunk of the edge list, compacts the qualifying edges into LDS (coalesced read of es, ballot prefix) and deals
+//     them to its groups.
+constexpr int SM_CHUNK = 1024;  // edges per block and chunk in the TOP form
+
+__device__ __forceinline__ uint32_t weight_bin(uint32_t wbits, uint32_t wlo, uint32_t wshift) {
+  if (wbits <= wlo) return 0u;
+  const uint32_t b = (wbits - wlo) >> wshift;
+  return b < (uint32_t)PR_BINS ? b : (uint32_t)(PR_BINS - 1);
+}
+
+// 256-bin histogram of the edge weights over [wlo, 1.0], ES_HCOPIES global copies (block b adds into copy b % copies)
+__global__ __launch_bounds__(256) void es_hist_kernel(const float* __restrict__ es, uint64_t E, uint32_t wlo,
+                                                      uint32_t wshift, uint32_t* __restrict__ hist) {
+  __shared__ uint32_t lh[PR_BINS * PR_COPIES];
+  for (int b = threadIdx.x; b < PR_BINS * PR_COPIES; b += 256) lh[b] = 0;
+  __syncthreads();
+  const uint64_t stride = (uint64_t)gridDim.x * 256;
+  for (uint64_t e = (uint64_t)blockIdx.x * 256 + threadIdx.x; e < E; e += stride)
+    atomicAdd(&lh[weight_bin(__float_as_uint(es[e]), wlo, wshift) * PR_COPIES + (threadIdx.x & (PR_COPIES - 1))], 1u);
+  __syncthreads();
+  uint32_t* __restrict__ myh = hist + (size_t)(blockIdx.x & (PR_HCOPIES - 1)) * PR_BINS;
+  uint32_t v = 0;
+#pragma unroll
+  for (int c = 0; c < PR_COPIES; c++) v += lh[threadIdx.x * PR_COPIES + ((c + threadIdx.x) & (PR_COPIES - 1))];
+  if (v) atomicAdd(&myh[threadIdx.x], v);
+}
+
+template <int TG, bool TOP>
 __global__ __launch_bounds__(256) void tri_sample_hist_kernel(const uint64_t* __restrict__ bits, int W,
                                                               const uint32_t* __restrict__ wpre,
                                                               const uint32_t* __restrict__ ebi,
@@ -682,18 +716,58 @@ __global__ __launch_bounds__(256) void tri_sample_hist_kernel(const uint64_t* __
                                                               const float* __restrict__ es, uint64_t E,
                                                               uint32_t stride, uint32_t part, uint32_t parts,
                                                               uint32_t klo, uint32_t shift,
-                                                              uint32_t* __restrict__ hist) {
+                                                              uint32_t* __restrict__ hist,
+                                                              const uint32_t* __restrict__ es_hist, uint64_t target,
+                                                              uint32_t wlo, uint32_t wshift) {
   __shared__ uint32_t lh[PR_BINS * PR_COPIES];  // [bin][copy]
+  __shared__ uint32_t l_e[TOP ? SM_CHUNK : 1];  // TOP: the qualifying edges of the current chunk
+  __shared__ uint32_t s_theta, s_cnt, s_wtot[4];
+  __shared__ uint64_t plds[8];
   for (int b = threadIdx.x; b < PR_BINS * PR_COPIES; b += 256) lh[b] = 0;
+  if (TOP) {  // the weight bin at which the count from the top reaches `target` (no such bin: every edge qualifies)
+    static_assert(PR_BINS == 256, "one bin per thread, walked from the top");
+    const uint32_t bin = PR_BINS - 1 - threadIdx.x;
+    uint64_t mine = 0;
+    for (int c = 0; c < PR_HCOPIES; c++) mine += es_hist[c * PR_BINS + bin];
+    if (threadIdx.x == 0) s_theta = 0u;
+    uint64_t tot;
+    const uint64_t before = block_exscan_u64(mine, plds, &tot);  // (its barriers also order the s_theta default)
+    if (before < target && target <= before + mine) s_theta = bin;
+  }
   __syncthreads();
   const int gl = threadIdx.x & (TG - 1);
   const uint64_t n_s = (E + stride - 1) / stride;  // sampled edges: e = g * stride, g = 0 .. n_s - 1
   // this launch takes the sampled edges g = part, part + parts, ... (one process per GPU: every rank samples its share
   // and the histograms are summed by an all-reduce — distinct edges give distinct triangles, so the sum certifies)
   const uint64_t n_loc = n_s > part ? (n_s - part + parts - 1) / parts : 0;
-  const uint64_t groups = (uint64_t)gridDim.x * (256 / TG);
-  for (uint64_t q = (uint64_t)blockIdx.x * (256 / TG) + (threadIdx.x / TG); q < n_loc; q += groups) {
-    const uint64_t e = (q * parts + part) * stride;
+  const uint64_t groups = TOP ? (256 / TG) : (uint64_t)gridDim.x * (256 / TG);
+  const uint32_t theta = TOP ? s_theta : 0u;
+  const uint64_t n_chunks = TOP ? (E + SM_CHUNK - 1) / SM_CHUNK : 1;
+  for (uint64_t ch = TOP ? blockIdx.x : 0; ch < n_chunks; ch += TOP ? gridDim.x : 1) {
+  uint64_t q_end = n_loc;
+  if (TOP) {
+    // compaction of the chunk's qualifying edges, in edge order: four rounds of 256 edges (ballot prefix per wave,
+    // wave totals through LDS); part / parts: this rank takes the qualifying edges with e % parts == part
+    if (threadIdx.x == 0) s_cnt = 0u;
+    __syncthreads();
+    for (int r = 0; r < SM_CHUNK / 256; r++) {
+      const uint64_t e = ch * SM_CHUNK + (uint64_t)r * 256 + threadIdx.x;
+      const bool ok = e < E && weight_bin(__float_as_uint(es[e]), wlo, wshift) >= theta && (e % parts) == part;
+      const uint64_t bal = __ballot(ok);
+      const int wave = threadIdx.x >> 6;
+      if ((threadIdx.x & 63) == 0) s_wtot[wave] = (uint32_t)__popcll(bal);
+      __syncthreads();
+      uint32_t pos = s_cnt + __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
+      for (int w = 0; w < wave; w++) pos += s_wtot[w];
+      if (ok) l_e[pos] = (uint32_t)e;
+      __syncthreads();
+      if (threadIdx.x == 0) s_cnt += s_wtot[0] + s_wtot[1] + s_wtot[2] + s_wtot[3];
+      __syncthreads();
+    }
+    q_end = s_cnt;
+  }
+  for (uint64_t q = TOP ? (threadIdx.x / TG) : (uint64_t)blockIdx.x * (256 / TG) + (threadIdx.x / TG); q < q_end; q += groups) {
+    const uint64_t e = TOP ? (uint64_t)l_e[q] : (q * parts + part) * stride;
     const uint32_t i = ei[e], j = ej[e];
     const uint32_t rowi = i * (uint32_t)W, rowj = j * (uint32_t)W;
     const int w0 = j >> 6;
@@ -745,6 +819,8 @@ __global__ __launch_bounds__(256) void tri_sample_hist_kernel(const uint64_t* __
       }
     }
   }
+  if (TOP) __syncthreads();  // l_e is rewritten by the next chunk
+  }  // chunks
   __syncthreads();
   // flush into one of PR_HCOPIES global copies (by block): a thousand blocks adding into the SAME 256 words serialise
   // at the memory side (~12 ns per add and address); the copies are summed by the reader
@@ -849,9 +925,34 @@ static void prune_window(float key_floor, uint32_t* klo_out, uint32_t* shift_out
 
 void launch_sample_hist(const Graph& g, const uint32_t* ebi, const uint32_t* ebj, const uint32_t* ei,
                         const uint32_t* ej, const float* es, uint64_t E, uint64_t want, float key_floor, uint32_t part,
-                        uint32_t parts, uint32_t* hist, const Tuning& tn, hipStream_t st) {
+                        uint32_t parts, uint32_t* hist, uint32_t* es_hist, const Tuning& tn, hipStream_t st) {
   uint32_t klo, shift;
   prune_window(key_floor, &klo, &shift);
+  if (tn.sample_mode == 0 && es_hist) {
+    // the heaviest edges (TOP form): weight histogram over [key_floor / 3, 1.0], then the sample itself
+    uint32_t wlo, wshift;
+    {
+      const float wfloor = key_floor / 3.0f;
+      uint32_t lo; memcpy(&lo, &wfloor, 4);
+      const uint32_t hi = 0x3F800000u;  // 1.0f
+      if (!(wfloor > 0.f) || lo >= hi) lo = 0x3F000000u;  // 0.5f
+      const int bitsn = 32 - __builtin_clz(hi - lo);
+      wlo = lo; wshift = bitsn > 8 ? (uint32_t)(bitsn - 8) : 0u;
+    }
+    uint64_t target = tn.sample_edges ? tn.sample_edges : (want * 5 / 8 < 32768 ? 32768 : want * 5 / 8);
+    uint64_t hb = (E + 4095) / 4096;
+    if (hb > 1024) hb = 1024;
+    if (hb < 1) hb = 1;
+    hipLaunchKernelGGL(es_hist_kernel, dim3((unsigned)hb), dim3(256), 0, st, es, E, wlo, wshift, es_hist);
+    const int tg = tn.tg_sample ? tn.tg_sample : 16;
+    uint64_t nb = (E + SM_CHUNK - 1) / SM_CHUNK;
+    if (nb > 8192) nb = 8192;
+    if (tn.sample_blocks) nb = tn.sample_blocks;
+#define SC_LAUNCH_TOP(TGV) hipLaunchKernelGGL((tri_sample_hist_kernel<TGV, true>), dim3((unsigned)nb), dim3(256), 0, st, g.bits, g.W, g.wpre, ebi, ebj, ei, ej, es, E, 1u, part, parts, klo, shift, hist, es_hist, target, wlo, wshift)
+    if (tg == 4) SC_LAUNCH_TOP(4); else if (tg == 8) SC_LAUNCH_TOP(8); else if (tg == 32) SC_LAUNCH_TOP(32); else if (tg == 64) SC_LAUNCH_TOP(64); else SC_LAUNCH_TOP(16);
+#undef SC_LAUNCH_TOP
+    return;
+  }
   // every R-th edge.  The sample must grow with T: the bound is the T-th largest SAMPLED key, so a small sample of a
   // large T certifies little.  ~5T/8 sampled edges (>= 32k) is the sweet spot on C2 for T = 50k ... 400k (swept again
   // at the end of round 1); Tuning::sample_edges overrides.
@@ -870,7 +971,7 @@ void launch_sample_hist(const Graph& g, const uint32_t* ebi, const uint32_t* ebj
   uint64_t nb = (n_loc + (256 / tg) - 1) / (256 / tg);
   // about one sampled edge per group (measured: 256 blocks 70 us, 1024+ blocks 35 us on C2)
   if (nb > 4096) nb = 4096;
-#define SC_LAUNCH_SAMPLE(TGV) hipLaunchKernelGGL(tri_sample_hist_kernel<TGV>, dim3((unsigned)nb), dim3(256), 0, st, g.bits, g.W, g.wpre, ebi, ebj, ei, ej, es, E, (uint32_t)stride, part, parts, klo, shift, hist)
+#define SC_LAUNCH_SAMPLE(TGV) hipLaunchKernelGGL((tri_sample_hist_kernel<TGV, false>), dim3((unsigned)nb), dim3(256), 0, st, g.bits, g.W, g.wpre, ebi, ebj, ei, ej, es, E, (uint32_t)stride, part, parts, klo, shift, hist, (const uint32_t*)nullptr, (uint64_t)0, 0u, 0u)
   if (tg == 4) SC_LAUNCH_SAMPLE(4); else if (tg == 8) SC_LAUNCH_SAMPLE(8); else if (tg == 32) SC_LAUNCH_SAMPLE(32); else if (tg == 64) SC_LAUNCH_SAMPLE(64); else SC_LAUNCH_SAMPLE(16);
 #undef SC_LAUNCH_SAMPLE
 }

@@ -270,8 +270,9 @@ def test_certified_pruning_changes_nothing_but_the_work(pkg, reg, name):
 
 
 @pytest.mark.parametrize("knobs", [dict(cnt_blocks=37, keys_blocks=53, sel_blocks=7, sample_edges=5000),
-                                   dict(cnt_blocks=4096, keys_blocks=1, sel_blocks=1, sample_edges=1000000, tg_sample=32),
-                                   dict(no_events=1, tg_count=4, tg_keys=64, sel_blocks=3)])
+                                   dict(cnt_blocks=4096, keys_blocks=1, sel_blocks=1, sample_edges=1000000, tg_sample=32, sample_blocks=3),
+                                   dict(no_events=1, tg_count=4, tg_keys=64, sel_blocks=3, sample_mode=1),
+                                   dict(sample_mode=1, sample_edges=5000, tg_sample=4, tg_events=32)])
 def test_results_do_not_depend_on_grid_or_sample_size(pkg, O, knobs):
     """Stage B's launch geometry and the size of the pruning sample only change the amount of work (a looser or tighter
     certified bound, more or fewer workgroups) — never the result: odd values for every scheduling knob on C1 and C2,
