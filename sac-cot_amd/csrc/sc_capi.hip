@@ -638,7 +638,7 @@ int sc_set_debug(sc_ctx* c, const sc_debug* d) {
   t.compat_one_phase = d->compat_one_phase != 0;
   t.compat_rows = d->compat_rows == 64 ? 64 : 16;
   t.compat_store_mode = d->compat_store_mode & 7u;
-  t.sample_mode = d->sample_mode ? 1u : 0u;
+  t.sample_mode = d->sample_mode <= 2 ? d->sample_mode : 0u;
   t.sample_blocks = d->sample_blocks;
   c->tn = t;
   return SC_OK;

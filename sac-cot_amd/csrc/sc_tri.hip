@@ -683,10 +683,15 @@ __device__ __forceinline__ uint32_t prune_bin(uint32_t key, uint32_t klo, uint32
 //     them to its groups.
 constexpr int SM_CHUNK = 1024;  // edges per block and chunk in the TOP form
 
+// Weight -> bin, heavier = higher, LOGARITHMIC in 1 - s: the weights of good edges crowd against 1.0 (s = exp(-d^2 / 2
+// sigma^2) with d << sigma), so linear bins would put tens of thousands of edges into the top one and the sample could
+// not be sized.  1 - s is exact in fp32 for s >= 0.5; its exponent and top three mantissa bits give 8 bins per octave:
+// 1 - s in [2^-24, 2^-3) -> bins 255 .. 80, s == 1 -> 255, lighter edges -> the low bins.  (wlo / wshift: unused.)
 __device__ __forceinline__ uint32_t weight_bin(uint32_t wbits, uint32_t wlo, uint32_t wshift) {
-  if (wbits <= wlo) return 0u;
-  const uint32_t b = (wbits - wlo) >> wshift;
-  return b < (uint32_t)PR_BINS ? b : (uint32_t)(PR_BINS - 1);
+  (void)wlo; (void)wshift;
+  const uint32_t lb = __float_as_uint(1.0f - __uint_as_float(wbits)) >> 20;  // sign 0, exponent, 3 mantissa bits
+  const int b = (int)(103u << 3) + 255 - (int)lb;                              // 2^-24 has exponent field 103
+  return (uint32_t)(b < 0 ? 0 : (b > 255 ? 255 : b));
 }
 
 // 256-bin histogram of the edge weights over [wlo, 1.0], ES_HCOPIES global copies (block b adds into copy b % copies)
@@ -928,8 +933,15 @@ void launch_sample_hist(const Graph& g, const uint32_t* ebi, const uint32_t* ebj
                         uint32_t parts, uint32_t* hist, uint32_t* es_hist, const Tuning& tn, hipStream_t st) {
   uint32_t klo, shift;
   prune_window(key_floor, &klo, &shift);
-  if (tn.sample_mode == 0 && es_hist) {
-    // the heaviest edges (TOP form): weight histogram over [key_floor / 3, 1.0], then the sample itself
+  // Which form (r02 sweeps, profiles/r02_ab_heaviest_edge_sample.txt and r02_ab_sample_size.txt): the heaviest edges
+  // certify a much tighter bound per sampled edge, but each of them is a costly one (an edge between two inliers has
+  // hundreds of common neighbours).  That pays when T is a small part of the graph's triangles — C3 (N = 20 000, T = 200 k):
+  // stage B 962 -> 551 us, 10.6 M -> 2.1 M enumerated — is a wash on C2 (167 vs 165 us) and loses where T is most of
+  // what there is (C4, T = 500 k of 8.8 M triangles: the uniform sample at stride 1 already certifies 2 T: 211 vs 248 us).
+  // sample_mode: 0 = by this rule (8 T < E), 1 = every stride-th edge, 2 = the heaviest edges.
+  const bool top = tn.sample_mode == 2 || (tn.sample_mode == 0 && 8 * want < E);
+  if (top && es_hist) {
+    // the heaviest edges (TOP form): weight histogram, then the sample itself
     uint32_t wlo, wshift;
     {
       const float wfloor = key_floor / 3.0f;
@@ -939,7 +951,7 @@ void launch_sample_hist(const Graph& g, const uint32_t* ebi, const uint32_t* ebj
       const int bitsn = 32 - __builtin_clz(hi - lo);
       wlo = lo; wshift = bitsn > 8 ? (uint32_t)(bitsn - 8) : 0u;
     }
-    uint64_t target = tn.sample_edges ? tn.sample_edges : (want * 5 / 8 < 32768 ? 32768 : want * 5 / 8);
+    uint64_t target = tn.sample_edges ? tn.sample_edges : (want / 3 < 16384 ? 16384 : want / 3);
     uint64_t hb = (E + 4095) / 4096;
     if (hb > 1024) hb = 1024;
     if (hb < 1) hb = 1;
