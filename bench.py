@@ -307,8 +307,18 @@ def main() -> int:
 
         if world == 1 and not args.no_cpu_baseline:
             O = ge.load_oracle()
-            threads = min(O.max_threads(), os.cpu_count() or 1)
-            ref = O.register(scene.src, scene.tgt, threads=threads, **kw)  # warm-up pass, also the parity check
+            tmax = min(O.max_threads(), os.cpu_count() or 1)
+            ref = O.register(scene.src, scene.tgt, threads=tmax, **kw)  # warm-up pass, also the parity check
+            # the thread count the restatement runs fastest with on this host (more threads are not always faster:
+            # stage B merges one 512 KiB histogram per thread and pass) — two passes each, best kept
+            best_t, threads = None, tmax
+            for cand in sorted({tmax, max(1, tmax // 2), max(1, tmax // 4), min(tmax, 16)}, reverse=True):
+                tq = time.perf_counter()
+                for _ in range(2):
+                    O.register(scene.src, scene.tgt, threads=cand, **kw)
+                tq = (time.perf_counter() - tq) / 2
+                if best_t is None or tq < best_t:
+                    best_t, threads = tq, cand
             got_mask = d_mask.cpu().numpy()
             got_Rt = d_Rt.cpu().numpy()
             out["parity_vs_cpu_restatement"] = bool(
@@ -333,7 +343,9 @@ def main() -> int:
                                    "kind": "port", "ms_per_pass": el / passes * 1e3,
                                    "one_core": {"value": T_total * n1 / e1, "ms_per_pass": e1 / n1 * 1e3, "passes": n1},
                                    "cpu_model": cpu_model(),
-                                   "sample": f"{passes} full passes on {threads} threads (+ {n1} on one) of the same workload "
+                                   "host_threads_available": tmax,
+                                   "sample": f"{passes} full passes on {threads} threads — the fastest of {tmax}, {tmax // 2}, "
+                                             f"{tmax // 4}, 16 on this host — (+ {n1} on one) of the same workload "
                                              f"(N={n}, T={T_total}) through oracle/saccot_oracle.c — this repo's CPU "
                                              "restatement (the reference has no CPU path); OpenMP over rows in stages A "
                                              "and B and over hypotheses in C; a reported baseline, not a target"}
