@@ -170,7 +170,7 @@ typedef struct sc_debug {
   uint32_t compat_store_mode; /* stage A stores of S: 0 = by size; bit 0 = 4 bytes per lane, bit 2 = 16 bytes, bit 1 = non-temporal */
   uint32_t tg_events;         /* lanes per edge of the event-recording counting pass: 4 .. 64 (default: by row width) */
   uint32_t sample_mode;       /* stage B's pruning sample: 0 = chosen by size, 1 = every stride-th edge, 2 = the heaviest edges */
-  uint32_t sample_blocks;     /* grid size of the heaviest-edge sample (0 = one block per 1024 edges)              */
+  uint32_t sample_blocks;     /* grid size of the heaviest-edge sample (0 = one block per 256 edges)              */
   uint32_t reserved;
 } sc_debug;
 int         sc_set_debug(sc_ctx* ctx, const sc_debug* dbg);
