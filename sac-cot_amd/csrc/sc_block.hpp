@@ -45,4 +45,87 @@ __device__ __forceinline__ uint64_t block_exscan_u64(uint64_t v, uint64_t* lds, 
   return base + inc - v;
 }
 
+// ------------------------------------------------------------------------------------------------
+// Decoupled look-back (single-pass prefix over the tiles of one launch).  One 64-bit DESCRIPTOR per tile and value:
+//   [ epoch : 12 | status : 2 | value : 50 ]     status 0 = nothing yet, 1 = the tile's own sum, 2 = inclusive prefix
+// written and read as ONE 8-byte agent-scope atomic (global_store / global_load ... sc1): the value travels inside the
+// word that signals it, so no fence and no second hand-off is needed (cdna guide §6 G16 "data-tagged granule").  The
+// epoch makes words of earlier launches read as "nothing yet" — no memset between launches (the host zeroes the area
+// when the 12-bit epoch wraps or the buffer is new).  Tiles take their index from an atomic ticket, so every predecessor
+// of a running tile has started and will publish its sum without waiting for anyone: the look-back cannot deadlock.
+// Wave 0 of the tile looks back 64 predecessors per step.  A spin limit turns a protocol failure into a wrong result
+// plus an error flag instead of a hang.
+// ------------------------------------------------------------------------------------------------
+constexpr uint64_t LB_VALUE_MASK = (1ull << 50) - 1ull;
+constexpr uint32_t LB_SPIN_LIMIT = 1u << 22;
+__device__ __forceinline__ uint64_t lb_pack(uint32_t epoch, uint32_t status, uint64_t v) {
+  return ((uint64_t)(epoch & 0xFFFu) << 52) | ((uint64_t)status << 50) | (v & LB_VALUE_MASK);
+}
+__device__ __forceinline__ void lb_store(uint64_t* p, uint64_t v) {
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ uint64_t lb_load(const uint64_t* p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// Called by the 64 lanes of ONE wave of tile `tile` (every lane, converged).  NV values per tile (1 or 2), descriptor
+// arrays desc[v] of gridDim.x words each; own[v] = this tile's sums.  Returns the exclusive prefixes in pre[v] (the same
+// in every lane) and publishes the inclusive ones.  *err is set (lane 0) if the spin limit was hit.
+template <int NV>
+__device__ __forceinline__ void lb_lookback(uint64_t* const (&desc)[NV], uint32_t tile, uint32_t epoch,
+                                            const uint64_t (&own)[NV], uint64_t (&pre)[NV], uint32_t* err) {
+  const int lane = threadIdx.x & 63;
+#pragma unroll
+  for (int v = 0; v < NV; v++) pre[v] = 0;
+  if (tile == 0) {
+    if (lane == 0) {
+#pragma unroll
+      for (int v = 0; v < NV; v++) lb_store(&desc[v][0], lb_pack(epoch, 2u, own[v]));
+    }
+    return;
+  }
+  if (lane == 0) {
+#pragma unroll
+    for (int v = 0; v < NV; v++) lb_store(&desc[v][tile], lb_pack(epoch, 1u, own[v]));
+  }
+  int64_t hi = (int64_t)tile - 1;  // nearest predecessor not yet accounted for
+  uint32_t spins = 0;
+  for (;;) {
+    const int64_t idx = hi - lane;
+    uint64_t d[NV];
+    bool valid = true, isp = true;
+#pragma unroll
+    for (int v = 0; v < NV; v++) {
+      d[v] = idx >= 0 ? lb_load(&desc[v][idx]) : lb_pack(epoch, 2u, 0);  // below tile 0: a virtual prefix of 0
+      const uint32_t st = (uint32_t)(d[v] >> 50) & 3u;
+      const bool ok = (uint32_t)(d[v] >> 52) == (epoch & 0xFFFu) && st != 0u;
+      valid = valid && ok;
+      isp = isp && ok && st == 2u;
+    }
+    const uint64_t pm = __ballot(isp), vm = __ballot(valid);
+    const int k = pm ? __builtin_ctzll(pm) : 64;                          // first lane holding an inclusive prefix
+    const uint64_t need = k >= 63 ? ~0ull : ((1ull << (k + 1)) - 1ull);   // lanes 0 .. k (all 64 when there is none)
+    if ((vm & need) == need) {
+#pragma unroll
+      for (int v = 0; v < NV; v++) {
+        uint64_t x = lane <= k ? (d[v] & LB_VALUE_MASK) : 0ull;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o);
+        pre[v] += x;
+      }
+      if (k < 64) break;
+      hi -= 64;
+    } else if (++spins > LB_SPIN_LIMIT) {
+      if (lane == 0 && err) *err = 1u;
+      break;
+    } else {
+      __builtin_amdgcn_s_sleep(2);
+    }
+  }
+  if (lane == 0) {
+#pragma unroll
+    for (int v = 0; v < NV; v++) lb_store(&desc[v][tile], lb_pack(epoch, 2u, pre[v] + own[v]));
+  }
+}
+
 }  // namespace sc

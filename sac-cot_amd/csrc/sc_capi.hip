@@ -46,7 +46,7 @@ struct sc_ctx {
   // workspace
   Buf in_src, in_tgt, planes, S, bits, deg, degp, wpre, ebase, edge_off, scan_tmp, ei, ej, es, ebi, ebj, tcnt, toff, wkey, kcol, ctl, events, blk_gt,
       blk_eq, blk_minmax, bits2, off_gt, off_eq, sel_ord, sel_key, sortkey, sorted, sort_tmp, tri, tri_rk, key_rk, rt, rt_aos, partial, cnt, key, rt12,
-      mask, refine_tmp, amx_pairs, strong, rowcost, cost_pre;
+      mask, refine_tmp, amx_pairs, strong, rowcost, cost_pre, lb_state;
 
   // state of the last hypothesize call (consumed by finalize)
   int n = 0, ld = 0;
@@ -70,6 +70,10 @@ struct sc_ctx {
   // all-gathered one
   uint64_t* bits_cur = nullptr;
   // sharded A + B (sc_shard_*_device): phase reached (0: none), the gathered candidate blobs
+  // decoupled look-back launches (single-pass scan, fused compaction): their state area and its epoch
+  uint32_t lb_epoch = 0;
+  void* lb_zeroed = nullptr;
+  size_t lb_zeroed_cap = 0;
   bool sharded_ab = false;
   int shard_phase = 0;
   const void* cand_all = nullptr;
@@ -149,6 +153,18 @@ Graph graph_of(const sc_ctx* c) {
   return Graph{c->bits_cur, c->S.as<float>(), c->deg.as<uint32_t>(), c->degp.as<uint32_t>(),
                c->wpre.as<uint32_t>(), c->n, c->ld, c->ld >> 6};
 }
+// The look-back state area holds `words` u64 for this launch; hands out the launch's epoch.  The area is written by
+// look-back kernels only; it is zeroed when new, when it grew, and when the 12-bit epoch wraps.
+int lb_next(sc_ctx* c, size_t bytes, uint32_t* epoch) {
+  ENSURE(c, c->lb_state, bytes);
+  if (c->lb_state.p != c->lb_zeroed || c->lb_state.cap != c->lb_zeroed_cap || c->lb_epoch >= 4095u) {
+    HIPCHK(c, hipMemsetAsync(c->lb_state.p, 0, c->lb_state.cap, c->stream));
+    c->lb_zeroed = c->lb_state.p; c->lb_zeroed_cap = c->lb_state.cap; c->lb_epoch = 0;
+  }
+  *epoch = ++c->lb_epoch;
+  return SC_OK;
+}
+
 // sharded stage B: the device-side edge range [lo, hi) this rank enumerates (nullptr: every edge)
 const uint64_t* own_range_of(const sc_ctx* c) {
   return c->sharded_ab ? c->ctl.as<ControlBlock>()->own_edge : nullptr;
@@ -285,11 +301,19 @@ int run_edges(sc_ctx* c, const sc_params* p, uint32_t* hist, uint32_t part, uint
   ENSURE(c, c->ebase, n * 4);
   ScanExtra xe;  // the scan of deg+ also writes the per-row CSR bases edge_fill reads
   xe.deg = c->deg.as<uint32_t>(); xe.degp = c->degp.as<uint32_t>(); xe.ebase = c->ebase.as<uint32_t>();
+  ScanExtra xc;  // (sharded) the scan of the row costs
+  if (scan_writes_ebase(n)) {  // tiled scans: the single-pass form, each on its own half of the state area
+    const size_t half = scan_temp_bytes(n);
+    { const int lrc = lb_next(c, 2 * half, &xe.epoch); if (lrc) return lrc; }
+    xe.state = c->lb_state.p;
+    if (c->sharded_ab) { const int lrc = lb_next(c, 2 * half, &xc.epoch); if (lrc) return lrc; xc.state = static_cast<char*>(c->lb_state.p) + half; }
+    xe.state = c->lb_state.p;  // (lb_next may have moved the area)
+  }
   if (c->sharded_ab) {
     // also the prefix of the per-row work estimate and, from it, this rank's contiguous row / edge range
     ENSURE(c, c->cost_pre, (n + 1) * sizeof(uint64_t));
     launch_scan_u32_pair(c->degp.as<uint32_t>(), c->edge_off.as<uint64_t>(), c->rowcost.as<uint32_t>(),
-                         c->cost_pre.as<uint64_t>(), n, c->scan_tmp.p, c->tn, st, &c->pinned[0], &xe);
+                         c->cost_pre.as<uint64_t>(), n, c->scan_tmp.p, c->tn, st, &c->pinned[0], &xe, &xc);
     ControlBlock* ctl = c->ctl.as<ControlBlock>();
     launch_shard_split(c->cost_pre.as<uint64_t>(), c->edge_off.as<uint64_t>(), c->n, (uint32_t)p->shard_rank,
                        (uint32_t)p->shard_world, ctl->own_row, ctl->own_edge, st);
@@ -392,6 +416,8 @@ int run_select(sc_ctx* c, const sc_params* p, const uint32_t* hist, bool want_li
   arm_word(c, 2);
   ScanExtra xr;  // sharded: the counts outside this rank's edge range are zero — their tiles are skipped
   xr.range = own_range_of(c);
+  { const int lrc = lb_next(c, scan_temp_bytes(E), &xr.epoch); if (lrc) return lrc; }
+  xr.state = c->lb_state.p;
   launch_scan_u32(c->tcnt.as<uint32_t>(), E, c->toff.as<uint64_t>(), c->scan_tmp.p, c->tn, st, &c->pinned[2], &xr);
   // While the host polls for the count, the key kernel already runs into the key arrays this context holds from earlier
   // calls (it takes everything else from device memory).  Only in the common form — events, a-priori select window —
@@ -594,7 +620,7 @@ void sc_destroy(sc_ctx* c) {
   Buf* bufs[] = {&c->in_src, &c->in_tgt, &c->planes, &c->S, &c->bits, &c->deg, &c->degp, &c->wpre, &c->ebase, &c->edge_off, &c->scan_tmp,
                  &c->ei, &c->ej, &c->es, &c->ebi, &c->ebj, &c->tcnt, &c->toff, &c->wkey, &c->kcol, &c->ctl, &c->events, &c->blk_gt, &c->blk_eq, &c->blk_minmax, &c->bits2, &c->off_gt,
                  &c->off_eq, &c->sel_ord, &c->sel_key, &c->sortkey, &c->sorted, &c->sort_tmp, &c->tri, &c->tri_rk, &c->key_rk, &c->rt,
-                 &c->rt_aos, &c->partial, &c->cnt, &c->key, &c->rt12, &c->mask, &c->refine_tmp, &c->amx_pairs, &c->strong, &c->rowcost, &c->cost_pre};
+                 &c->rt_aos, &c->partial, &c->cnt, &c->key, &c->rt12, &c->mask, &c->refine_tmp, &c->amx_pairs, &c->strong, &c->rowcost, &c->cost_pre, &c->lb_state};
   for (Buf* b : bufs) if (b->p) (void)hipFree(b->p);
   for (int i = 0; i < N_EVENTS; i++) if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
   if (c->pinned) (void)hipHostFree(c->pinned);

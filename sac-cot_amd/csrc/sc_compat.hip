@@ -571,6 +571,55 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_downsweep_kernel(const uint
   }
 }
 
+// Single-pass form (decoupled look-back, sc_block.hpp): one launch instead of block sums + down-sweep.
+// state: [0] ticket (u32, zero between launches: the last tile resets it), [1] error flag, [2 ..] one descriptor per tile.
+__global__ __launch_bounds__(SCAN_THREADS) void scan_lookback_kernel(const uint32_t* __restrict__ in, size_t n,
+                                                                     uint64_t* __restrict__ out,
+                                                                     uint64_t* __restrict__ state, uint32_t epoch,
+                                                                     uint64_t* __restrict__ host_total,
+                                                                     const uint64_t* __restrict__ range, ScanEbase eb) {
+  __shared__ uint64_t lds[8];
+  __shared__ uint32_t s_tile;
+  __shared__ uint64_t s_prefix;
+  uint32_t* ticket = reinterpret_cast<uint32_t*>(state);
+  if (threadIdx.x == 0) s_tile = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __syncthreads();
+  const uint32_t tile = s_tile;
+  const size_t base = (size_t)tile * SCAN_TILE + (size_t)threadIdx.x * SCAN_ITEMS;
+  const bool dead = scan_tile_dead(range, tile);  // block-uniform: known zeros, neither read nor written
+  uint32_t v[SCAN_ITEMS];
+  uint64_t s = 0;
+#pragma unroll
+  for (int k = 0; k < SCAN_ITEMS; k++) { v[k] = (!dead && base + k < n) ? in[base + k] : 0u; s += v[k]; }
+  uint64_t tot;
+  const uint64_t ex = block_exscan_u64(s, lds, &tot);
+  if (threadIdx.x < 64) {
+    uint64_t* const desc[1] = {state + 2};
+    const uint64_t own[1] = {tot};
+    uint64_t pre[1];
+    lb_lookback<1>(desc, tile, epoch, own, pre, reinterpret_cast<uint32_t*>(state + 1));
+    if (threadIdx.x == 0) s_prefix = pre[0];
+  }
+  __syncthreads();
+  const uint64_t pre = s_prefix;
+  if (!dead) {
+    uint64_t run = pre + ex;
+#pragma unroll
+    for (int k = 0; k < SCAN_ITEMS; k++) {
+      if (base + k < n) {
+        out[base + k] = run;
+        if (eb.ebase) eb.ebase[base + k] = (uint32_t)run - (eb.deg[base + k] - eb.degp[base + k]);
+      }
+      run += v[k];
+    }
+  }
+  if (tile == gridDim.x - 1 && threadIdx.x == 0) {
+    out[n] = pre + tot;
+    if (host_total) publish_host(host_total, pre + tot);
+    __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // every tile has taken its ticket
+  }
+}
+
 // small inputs: ONE block scans up to two arrays in one launch (three launches of the tiled scan are pure latency there)
 __global__ __launch_bounds__(1024) void scan_small_kernel(const uint32_t* __restrict__ in0, uint64_t* __restrict__ out0,
                                                           const uint32_t* __restrict__ in1, uint64_t* __restrict__ out1,
@@ -608,18 +657,19 @@ constexpr size_t SCAN_SMALL_MAX = 8192;  // one pass of the single block; beyond
 // Tuning::scan_self_max (4096 tiles = 16.7 M elements): beyond it the scan of sums is its own launch
 
 void launch_scan_u32_pair(const uint32_t* in0, uint64_t* out0, const uint32_t* in1, uint64_t* out1, size_t n,
-                          void* temp, const Tuning& tn, hipStream_t st, uint64_t* host_total, const ScanExtra* x0) {
+                          void* temp, const Tuning& tn, hipStream_t st, uint64_t* host_total, const ScanExtra* x0,
+                          const ScanExtra* x1) {
   if (n <= SCAN_SMALL_MAX) {
     hipLaunchKernelGGL(scan_small_kernel, dim3(1), dim3(1024), 0, st, in0, out0, in1, out1, n, host_total);
   } else {
     launch_scan_u32(in0, n, out0, temp, tn, st, host_total, x0);
-    if (in1) launch_scan_u32(in1, n, out1, temp, tn, st);
+    if (in1) launch_scan_u32(in1, n, out1, temp, tn, st, nullptr, x1);
   }
 }
 
 bool scan_writes_ebase(size_t n) { return n > SCAN_SMALL_MAX; }
 
-size_t scan_temp_bytes(size_t n) { return ((n + SCAN_TILE - 1) / SCAN_TILE + 1) * sizeof(uint64_t); }
+size_t scan_temp_bytes(size_t n) { return ((n + SCAN_TILE - 1) / SCAN_TILE + 4) * sizeof(uint64_t); }
 
 void launch_scan_u32(const uint32_t* in, size_t n, uint64_t* out, void* temp, const Tuning& tn, hipStream_t st,
                      uint64_t* host_total, const ScanExtra* x) {
@@ -633,6 +683,11 @@ void launch_scan_u32(const uint32_t* in, size_t n, uint64_t* out, void* temp, co
   uint64_t* bsum = static_cast<uint64_t*>(temp);
   const size_t nb = (n + SCAN_TILE - 1) / SCAN_TILE;
   if (nb == 0) return;  // n == 0 is handled by the small path above
+  if (x && x->epoch && x->state && tn.scan_self_max != 0) {  // single-pass form (the caller keeps the state and its epoch)
+    hipLaunchKernelGGL(scan_lookback_kernel, dim3((unsigned)nb), dim3(SCAN_THREADS), 0, st, in, n, out,
+                       static_cast<uint64_t*>(x->state), x->epoch, host_total, range, eb);
+    return;
+  }
   hipLaunchKernelGGL(scan_block_sums_kernel, dim3((unsigned)nb), dim3(SCAN_THREADS), 0, st, in, n, bsum, range);
   if (nb <= tn.scan_self_max) {  // (a test sets scan_self_max = 0 to force the three-kernel form)
     hipLaunchKernelGGL(scan_downsweep_kernel<true>, dim3((unsigned)nb), dim3(SCAN_THREADS), 0, st, in, n, bsum, out,

@@ -76,7 +76,12 @@ void launch_shard_split(const uint64_t* cost_pre, const uint64_t* edge_off, int 
 //   range (device, [lo, hi)): outside it every input is known to be zero — tiles wholly outside are neither read nor
 //     written (sharded stage B: the triangle counts of the edges other ranks enumerate); out[n] is still the total;
 //   deg / degp / ebase: also ebase[i] = (u32) out[i] - (deg[i] - degp[i]), the CSR base of row i (launch_edge_fill).
+//   epoch != 0: the single-pass (decoupled look-back) form, on `state`: the caller's persistent state area of
+//     scan_temp_bytes(n) bytes that ONLY look-back launches write — zeroed once (and again whenever the 12-bit epoch
+//     wraps), epochs 1 .. 4095 handed out one per launch.
 struct ScanExtra {
+  uint32_t epoch = 0;
+  void* state = nullptr;
   const uint64_t* range = nullptr;
   const uint32_t* deg = nullptr;
   const uint32_t* degp = nullptr;
@@ -89,7 +94,7 @@ void launch_scan_u32(const uint32_t* in, size_t n, uint64_t* out, void* temp, co
 // array 0
 void launch_scan_u32_pair(const uint32_t* in0, uint64_t* out0, const uint32_t* in1, uint64_t* out1, size_t n,
                           void* temp, const Tuning& tn, hipStream_t st, uint64_t* host_total = nullptr,
-                          const ScanExtra* x0 = nullptr);
+                          const ScanExtra* x0 = nullptr, const ScanExtra* x1 = nullptr);
 
 // ---- stage B: triangles_topT ---------------------------------------------------------------------
 struct Graph {
