@@ -371,6 +371,30 @@ int run_edges(sc_ctx* c, const sc_params* p, uint32_t* hist, uint32_t part, uint
   return SC_OK;
 }
 
+// Ordinal-order compaction of the keys at or above the threshold the select found -> sel_ord / sel_key.
+// Default: ONE launch (counts of the earlier tiles by decoupled look-back).  Tuning::compact_self_max == 0 (a test) takes
+// the scanned three-launch form, a small non-zero value the two-launch form of round 1.
+int run_compaction(sc_ctx* c, const KeyView& view, size_t nb) {
+  hipStream_t st = c->stream;
+  SelectState* sel = &c->ctl.as<ControlBlock>()->sel;
+  if (c->tn.compact_self_max >= 4096) {
+    uint32_t epoch;
+    { const int lrc = lb_next(c, compact_state_bytes(view.M), &epoch); if (lrc) return lrc; }
+    launch_compact_fused(view, sel, c->lb_state.p, epoch, c->sel_ord.as<uint64_t>(), c->sel_key.as<uint32_t>(), st);
+    return SC_OK;
+  }
+  launch_compact_count(view, sel, c->blk_gt.as<uint32_t>(), c->blk_eq.as<uint32_t>(), st);
+  // few tiles (and M < 2^32): compact_write adds up the tile counts itself, no scan launch in between
+  const bool self_off = nb <= c->tn.compact_self_max && view.M < (1ull << 32);
+  if (!self_off)
+    launch_scan_u32_pair(c->blk_gt.as<uint32_t>(), c->off_gt.as<uint64_t>(), c->blk_eq.as<uint32_t>(),
+                         c->off_eq.as<uint64_t>(), nb, c->scan_tmp.p, c->tn, st);
+  launch_compact_write(view, sel, c->blk_gt.as<uint32_t>(), c->blk_eq.as<uint32_t>(),
+                       self_off ? nullptr : c->off_gt.as<uint64_t>(), self_off ? nullptr : c->off_eq.as<uint64_t>(),
+                       c->sel_ord.as<uint64_t>(), c->sel_key.as<uint32_t>(), st);
+  return SC_OK;
+}
+
 // Stage B, second half: prune with the (summed) sample histogram, enumerate, select.  On return c->M, c->T_eff are set
 // and sel_ord / sel_key hold the selection.  want_list: also materialise the T x 3 triangle list (stage hook; the hot
 // path reads triangles through TriSource).  hist == nullptr: the control block's own histogram.
@@ -479,15 +503,7 @@ int run_select(sc_ctx* c, const sc_params* p, const uint32_t* hist, bool want_li
   c->timed_trikeys = c->timing;
   const KeyView view = plain_view(c->wkey.as<uint32_t>(), M);
   launch_select_rounds(view, sel, fast_window ? 2 : 3, c->tn, st);
-  launch_compact_count(view, sel, c->blk_gt.as<uint32_t>(), c->blk_eq.as<uint32_t>(), st);
-  // few tiles (and M < 2^32): compact_write adds up the tile counts itself, no scan launch in between
-  const bool self_off = nb <= c->tn.compact_self_max && M < (1ull << 32);  // (a test sets 0: the scanned offsets)
-  if (!self_off)
-    launch_scan_u32_pair(c->blk_gt.as<uint32_t>(), c->off_gt.as<uint64_t>(), c->blk_eq.as<uint32_t>(),
-                         c->off_eq.as<uint64_t>(), nb, c->scan_tmp.p, c->tn, st);
-  launch_compact_write(view, sel, c->blk_gt.as<uint32_t>(), c->blk_eq.as<uint32_t>(),
-                       self_off ? nullptr : c->off_gt.as<uint64_t>(), self_off ? nullptr : c->off_eq.as<uint64_t>(),
-                       c->sel_ord.as<uint64_t>(), c->sel_key.as<uint32_t>(), st);
+  { const int crc = run_compaction(c, view, nb); if (crc) return crc; }
   // the list stays in ordinal order: no sort on the hot path (the winner is found by (count, key, position))
   if (want_list)
     launch_tri_decode(c->ei.as<uint32_t>(), c->ej.as<uint32_t>(), c->kcol.as<uint2>(), c->sel_ord.as<uint64_t>(), T_eff,
@@ -885,14 +901,7 @@ int sc_shard_score_device(sc_ctx* c, const void* d_cand_all, uint64_t* d_key, sc
   arm_word(c, 6);
   launch_merge_prepare(d_cand_all, blob_bytes, G, T, window_known, &ctl->klb, sel, &c->pinned[6], st);
   launch_select_rounds(view, sel, window_known ? 2 : 3, c->tn, st);
-  launch_compact_count(view, sel, c->blk_gt.as<uint32_t>(), c->blk_eq.as<uint32_t>(), st);
-  const bool self_off = nb <= c->tn.compact_self_max && view.M < (1ull << 32);
-  if (!self_off)
-    launch_scan_u32_pair(c->blk_gt.as<uint32_t>(), c->off_gt.as<uint64_t>(), c->blk_eq.as<uint32_t>(),
-                         c->off_eq.as<uint64_t>(), nb, c->scan_tmp.p, c->tn, st);
-  launch_compact_write(view, sel, c->blk_gt.as<uint32_t>(), c->blk_eq.as<uint32_t>(),
-                       self_off ? nullptr : c->off_gt.as<uint64_t>(), self_off ? nullptr : c->off_eq.as<uint64_t>(),
-                       c->sel_ord.as<uint64_t>(), c->sel_key.as<uint32_t>(), st);
+  { const int crc = run_compaction(c, view, nb); if (crc) return crc; }
   // the merged length, published by merge_prepare long before the compaction ends: the poll costs no GPU time
   { const int wrc = wait_word(c, 6); if (wrc) return wrc; }
   c->T_eff = (uint32_t)c->pinned[6];

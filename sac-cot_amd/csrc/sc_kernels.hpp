@@ -244,6 +244,12 @@ void launch_compact_write(const KeyView& view, const SelectState* s, const uint3
                           const uint32_t* blk_eq, const uint64_t* off_gt, const uint64_t* off_eq,
                           uint64_t* sel_ord, uint32_t* sel_key, hipStream_t st);
 
+// both in ONE launch (decoupled look-back over the tiles); state: compact_state_bytes(M) of the caller's look-back
+// state area, epoch: this launch's (ScanExtra)
+size_t compact_state_bytes(uint64_t M);
+void launch_compact_fused(const KeyView& view, const SelectState* s, void* state, uint32_t epoch, uint64_t* sel_ord,
+                          uint32_t* sel_key, hipStream_t st);
+
 // ---- sharded stage B: the candidate blob a rank sends, and the merge of the gathered blobs ----
 constexpr int CAND_HDR_WORDS = 32;  // u64 words: [0] triangles enumerated, [1] entries sent, [2] local threshold key,
                                     // [3] / [4] a key range containing every key sent

@@ -1303,6 +1303,76 @@ __global__ __launch_bounds__(CP_THREADS) void compact_write_kernel(KeyView view,
   }
 }
 
+// Count and write in ONE launch: the counts of the tiles before this one come by decoupled look-back (sc_block.hpp:
+// ticket-ordered tiles, one epoch-tagged 8-byte descriptor per tile and count) instead of from a counting launch.
+// state: [0] ticket, [1] error flag, [2 .. 2 + nb) descriptors of the "greater" counts, then nb of the "equal" counts.
+template <bool SEG>
+__global__ __launch_bounds__(CP_THREADS) void compact_fused_kernel(KeyView view, const SelectState* __restrict__ sel,
+                                                                   uint64_t* __restrict__ state, uint32_t epoch,
+                                                                   uint64_t* __restrict__ sel_ord,
+                                                                   uint32_t* __restrict__ sel_key) {
+  __shared__ uint64_t lds[8];
+  __shared__ uint32_t s_tile;
+  __shared__ uint64_t s_pre[2];
+  uint32_t* ticket = reinterpret_cast<uint32_t*>(state);
+  if (threadIdx.x == 0) s_tile = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __syncthreads();
+  const uint32_t tile = s_tile, nb = gridDim.x;
+  const uint32_t kstar = sel->kstar;
+  const uint64_t need_eq = sel->need_eq;
+  const uint64_t base = (uint64_t)tile * CP_TILE + (uint64_t)threadIdx.x * CP_ITEMS;
+  uint32_t keys[CP_ITEMS];
+  int valid;
+  load_tile_keys<SEG>(view, base, keys, valid);
+  uint32_t g = 0, q = 0;
+#pragma unroll
+  for (int k = 0; k < CP_ITEMS; k++)
+    if (k < valid) { g += keys[k] > kstar; q += keys[k] == kstar; }
+  uint64_t tot;
+  const uint64_t ex = block_exscan_u64(((uint64_t)g << 32) | q, lds, &tot);  // gt high, eq low: <= 1024 each per tile
+  if (threadIdx.x < 64) {
+    uint64_t* const desc[2] = {state + 2, state + 2 + nb};
+    const uint64_t own[2] = {tot >> 32, tot & 0xFFFFFFFFull};
+    uint64_t pre[2];
+    lb_lookback<2>(desc, tile, epoch, own, pre, reinterpret_cast<uint32_t*>(state + 1));
+    if (threadIdx.x == 0) { s_pre[0] = pre[0]; s_pre[1] = pre[1]; }
+  }
+  __syncthreads();
+  if (tile == nb - 1 && threadIdx.x == 0)
+    __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // every tile has taken its ticket
+  if (tot == 0) return;  // nothing of this tile is above or at the threshold (block-uniform)
+  uint64_t gt_before = s_pre[0] + (ex >> 32);
+  uint64_t eq_before = s_pre[1] + (ex & 0xFFFFFFFFull);
+#pragma unroll
+  for (int k = 0; k < CP_ITEMS; k++) {
+    if (k < valid) {
+      const uint32_t key = keys[k];
+      const bool isg = key > kstar, isq = key == kstar;
+      if (isg || (isq && eq_before < need_eq)) {
+        const uint64_t pos = gt_before + (eq_before < need_eq ? eq_before : need_eq);
+        sel_ord[pos] = base + k;
+        sel_key[pos] = key;
+      }
+      gt_before += isg;
+      eq_before += isq;
+    }
+  }
+}
+
+size_t compact_state_bytes(uint64_t M) { return (2 * compact_blocks(M) + 4) * sizeof(uint64_t); }
+
+void launch_compact_fused(const KeyView& view, const SelectState* s, void* state, uint32_t epoch, uint64_t* sel_ord,
+                          uint32_t* sel_key, hipStream_t st) {
+  if (view.M == 0) return;
+  const dim3 grid((unsigned)compact_blocks(view.M));
+  if (view.seg_len)
+    hipLaunchKernelGGL(compact_fused_kernel<true>, grid, dim3(CP_THREADS), 0, st, view, s, static_cast<uint64_t*>(state),
+                       epoch, sel_ord, sel_key);
+  else
+    hipLaunchKernelGGL(compact_fused_kernel<false>, grid, dim3(CP_THREADS), 0, st, view, s, static_cast<uint64_t*>(state),
+                       epoch, sel_ord, sel_key);
+}
+
 void launch_compact_write(const KeyView& view, const SelectState* s, const uint32_t* blk_gt,
                           const uint32_t* blk_eq, const uint64_t* off_gt, const uint64_t* off_eq,
                           uint64_t* sel_ord, uint32_t* sel_key, hipStream_t st) {
