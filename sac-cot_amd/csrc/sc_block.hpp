@@ -94,11 +94,16 @@ __device__ __forceinline__ void lb_lookback(uint64_t* const (&desc)[NV], uint32_
     const int64_t idx = hi - lane;
     uint64_t d[NV];
     bool valid = true, isp = true;
+    uint32_t st0 = 0;
 #pragma unroll
     for (int v = 0; v < NV; v++) {
       d[v] = idx >= 0 ? lb_load(&desc[v][idx]) : lb_pack(epoch, 2u, 0);  // below tile 0: a virtual prefix of 0
       const uint32_t st = (uint32_t)(d[v] >> 50) & 3u;
-      const bool ok = (uint32_t)(d[v] >> 52) == (epoch & 0xFFFu) && st != 0u;
+      if (v == 0) st0 = st;
+      // A tile publishes its NV words one after the other, twice (own sums, then prefixes).  A reader that catches it in
+      // between sees words of DIFFERENT status — a prefix in one, an own sum in the other — and must not mix them: the tile
+      // counts only once all its words carry the same status (each word's value always matches its own status).
+      const bool ok = (uint32_t)(d[v] >> 52) == (epoch & 0xFFFu) && st != 0u && st == st0;
       valid = valid && ok;
       isp = isp && ok && st == 2u;
     }

@@ -1341,6 +1341,8 @@ __global__ __launch_bounds__(CP_THREADS) void compact_fused_kernel(KeyView view,
   if (tile == nb - 1 && threadIdx.x == 0)
     __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // every tile has taken its ticket
   if (tot == 0) return;  // nothing of this tile is above or at the threshold (block-uniform)
+  const uint64_t n_sel = sel->want;  // entries the selection holds: a position beyond it can only come from a failed
+                                     // look-back (spin limit) and is dropped rather than written out of bounds
   uint64_t gt_before = s_pre[0] + (ex >> 32);
   uint64_t eq_before = s_pre[1] + (ex & 0xFFFFFFFFull);
 #pragma unroll
@@ -1350,8 +1352,7 @@ __global__ __launch_bounds__(CP_THREADS) void compact_fused_kernel(KeyView view,
       const bool isg = key > kstar, isq = key == kstar;
       if (isg || (isq && eq_before < need_eq)) {
         const uint64_t pos = gt_before + (eq_before < need_eq ? eq_before : need_eq);
-        sel_ord[pos] = base + k;
-        sel_key[pos] = key;
+        if (pos < n_sel) { sel_ord[pos] = base + k; sel_key[pos] = key; }
       }
       gt_before += isg;
       eq_before += isq;
