@@ -171,7 +171,7 @@ typedef struct sc_debug {
   uint32_t tg_events;         /* lanes per edge of the event-recording counting pass: 4 .. 64 (default: by row width) */
   uint32_t sample_mode;       /* stage B's pruning sample: 0 = chosen by size, 1 = every stride-th edge, 2 = the heaviest edges */
   uint32_t sample_blocks;     /* grid size of the heaviest-edge sample (0 = one block per 256 edges)              */
-  uint32_t reserved;
+  uint32_t compact_fused;     /* 1: compaction in one launch (look-back over the tiles) instead of count + write    */
 } sc_debug;
 int         sc_set_debug(sc_ctx* ctx, const sc_debug* dbg);
 

@@ -30,6 +30,7 @@ struct Tuning {
   int tg_events = 0;               // lanes per edge of the event-recording counting pass (0: by row width)
   uint32_t sample_mode = 0;        // pruning sample: 0 by size (launch_sample_hist), 1 every stride-th edge, 2 the heaviest edges
   uint32_t sample_blocks = 0;      // grid of the heaviest-edge sample (0: one block per 256 edges)
+  bool compact_fused = false;      // compaction in one launch (decoupled look-back) instead of count + write
   uint64_t sample_edges = 0;       // edges of the pruning sample (0: automatic, ~5T/8)
   uint32_t score_split = 0;        // share (of 256) of the hypotheses scored on the matrix pipe
   bool compat_one_phase = false;   // exact chain on every pair of an interior tile
