@@ -172,6 +172,8 @@ typedef struct sc_debug {
   uint32_t sample_mode;       /* stage B's pruning sample: 0 = chosen by size, 1 = every stride-th edge, 2 = the heaviest edges */
   uint32_t sample_blocks;     /* grid size of the heaviest-edge sample (0 = one block per 256 edges)              */
   uint32_t compact_fused;     /* 1: compaction in one launch (look-back over the tiles) instead of count + write    */
+  uint32_t rows_unfused;      /* 1: row statistics and the scans of the row counts as separate launches             */
+  uint32_t reserved;
 } sc_debug;
 int         sc_set_debug(sc_ctx* ctx, const sc_debug* dbg);
 

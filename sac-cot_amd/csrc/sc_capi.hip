@@ -74,6 +74,7 @@ struct sc_ctx {
   uint32_t lb_epoch = 0;
   void* lb_zeroed = nullptr;
   size_t lb_zeroed_cap = 0;
+  bool rows_fused = false;  // run_row_stats already produced edge_off / ebase / cost_pre and armed the edge count
   bool sharded_ab = false;
   int shard_phase = 0;
   const void* cand_all = nullptr;
@@ -243,7 +244,11 @@ int run_compat(sc_ctx* c, bool dense) {
 }
 
 // deg / deg+ / word-prefix popcounts from the bit rows (first kernel of stage B's timing bracket)
-int run_row_stats(sc_ctx* c, bool will_prune) {
+void arm_word(sc_ctx* c, int idx);
+
+// hot: the fused form (row statistics + CSR offsets + edge count in one launch; run_edges then launches no scan)
+int run_row_stats(sc_ctx* c, bool will_prune, bool hot = false) {
+  c->rows_fused = false;
   uint64_t* zero_rows = nullptr;
   if (will_prune) {  // the pruned bit matrix is cleared on the way (no separate memset)
     ENSURE(c, c->bits2, (size_t)c->n * (c->ld >> 6) * sizeof(uint64_t));
@@ -253,6 +258,21 @@ int run_row_stats(sc_ctx* c, bool will_prune) {
   if (c->sharded_ab) {  // per-row work estimate: its prefix splits the rows between the ranks
     ENSURE(c, c->rowcost, (size_t)c->n * 4);
     rowcost = c->rowcost.as<uint32_t>();
+  }
+  if (hot && !c->tn.rows_unfused) {
+    const size_t n = c->n;
+    ENSURE(c, c->edge_off, (n + 1) * sizeof(uint64_t));
+    ENSURE(c, c->ebase, n * 4);
+    uint64_t* cost_pre = nullptr;
+    if (c->sharded_ab) { ENSURE(c, c->cost_pre, (n + 1) * sizeof(uint64_t)); cost_pre = c->cost_pre.as<uint64_t>(); }
+    uint32_t epoch;
+    { const int lrc = lb_next(c, row_stats_scan_state_bytes(c->n), &epoch); if (lrc) return lrc; }
+    arm_word(c, 0);  // read-back #1 (the edge count) is published by this kernel
+    launch_row_stats_scan(points_of(c), c->bits_cur, c->deg.as<uint32_t>(), c->degp.as<uint32_t>(), c->wpre.as<uint32_t>(),
+                          zero_rows, c->edge_off.as<uint64_t>(), c->ebase.as<uint32_t>(), cost_pre, c->lb_state.p, epoch,
+                          &c->pinned[0], c->stream);
+    c->rows_fused = true;
+    return SC_OK;
   }
   launch_row_stats(points_of(c), c->bits_cur, c->deg.as<uint32_t>(), c->degp.as<uint32_t>(),
                    c->wpre.as<uint32_t>(), zero_rows, rowcost, c->stream);
@@ -297,12 +317,14 @@ int run_edges(sc_ctx* c, const sc_params* p, uint32_t* hist, uint32_t part, uint
   ENSURE(c, c->edge_off, (n + 1) * sizeof(uint64_t));
   ENSURE(c, c->scan_tmp, scan_temp_bytes(n));
   // read-back #1: the scan kernel itself writes the edge count to host-pinned memory (no copy kernel)
-  arm_word(c, 0);
+  const bool fused = c->rows_fused;
+  c->rows_fused = false;
+  if (!fused) arm_word(c, 0);
   ENSURE(c, c->ebase, n * 4);
   ScanExtra xe;  // the scan of deg+ also writes the per-row CSR bases edge_fill reads
   xe.deg = c->deg.as<uint32_t>(); xe.degp = c->degp.as<uint32_t>(); xe.ebase = c->ebase.as<uint32_t>();
   ScanExtra xc;  // (sharded) the scan of the row costs
-  if (scan_writes_ebase(n)) {  // tiled scans: the single-pass form, each on its own half of the state area
+  if (!fused && scan_writes_ebase(n)) {  // tiled scans: the single-pass form, each on its own half of the state area
     const size_t half = scan_temp_bytes(n);
     { const int lrc = lb_next(c, 2 * half, &xe.epoch); if (lrc) return lrc; }
     xe.state = c->lb_state.p;
@@ -312,12 +334,13 @@ int run_edges(sc_ctx* c, const sc_params* p, uint32_t* hist, uint32_t part, uint
   if (c->sharded_ab) {
     // also the prefix of the per-row work estimate and, from it, this rank's contiguous row / edge range
     ENSURE(c, c->cost_pre, (n + 1) * sizeof(uint64_t));
-    launch_scan_u32_pair(c->degp.as<uint32_t>(), c->edge_off.as<uint64_t>(), c->rowcost.as<uint32_t>(),
-                         c->cost_pre.as<uint64_t>(), n, c->scan_tmp.p, c->tn, st, &c->pinned[0], &xe, &xc);
+    if (!fused)
+      launch_scan_u32_pair(c->degp.as<uint32_t>(), c->edge_off.as<uint64_t>(), c->rowcost.as<uint32_t>(),
+                           c->cost_pre.as<uint64_t>(), n, c->scan_tmp.p, c->tn, st, &c->pinned[0], &xe, &xc);
     ControlBlock* ctl = c->ctl.as<ControlBlock>();
     launch_shard_split(c->cost_pre.as<uint64_t>(), c->edge_off.as<uint64_t>(), c->n, (uint32_t)p->shard_rank,
                        (uint32_t)p->shard_world, ctl->own_row, ctl->own_edge, st);
-  } else {
+  } else if (!fused) {
     launch_scan_u32(c->degp.as<uint32_t>(), n, c->edge_off.as<uint64_t>(), c->scan_tmp.p, c->tn, st, &c->pinned[0], &xe);
   }
   // While the host polls for the edge count, edge_fill already runs into the edge arrays this context holds from
@@ -328,7 +351,7 @@ int run_edges(sc_ctx* c, const sc_params* p, uint32_t* hist, uint32_t part, uint
   for (const Buf* b : {&c->ei, &c->ej, &c->ebi, &c->ebj}) spec_cap = b->cap / 4 < spec_cap ? b->cap / 4 : spec_cap;
   auto fill_edges = [&](uint64_t cap) {
     launch_edge_fill(g, points_of(c), c->dv, c->edge_off.as<uint64_t>(), c->ei.as<uint32_t>(), c->ej.as<uint32_t>(),
-                     c->es.as<float>(), c->ebase.as<uint32_t>(), scan_writes_ebase(n), c->ebi.as<uint32_t>(),
+                     c->es.as<float>(), c->ebase.as<uint32_t>(), fused || scan_writes_ebase(n), c->ebi.as<uint32_t>(),
                      c->ebj.as<uint32_t>(), cap, st);
   };
   if (spec_cap) fill_edges(spec_cap);
@@ -686,6 +709,7 @@ int sc_set_debug(sc_ctx* c, const sc_debug* d) {
   t.sample_mode = d->sample_mode <= 2 ? d->sample_mode : 0u;
   t.sample_blocks = d->sample_blocks;
   t.compact_fused = d->compact_fused != 0;
+  t.rows_unfused = d->rows_unfused != 0;
   c->tn = t;
   return SC_OK;
 }
@@ -713,7 +737,7 @@ int hyp_begin(sc_ctx* c, const float* d_src, const float* d_tgt, int64_t n, cons
   if ((rc = rec(c, 1))) return rc;
   if ((rc = run_compat(c, !(p->flags & SC_FLAG_NO_DENSE_S)))) return rc;
   if ((rc = rec(c, 2))) return rc;
-  if ((rc = run_row_stats(c, may_prune(p)))) return rc;
+  if ((rc = run_row_stats(c, may_prune(p), true))) return rc;
   if ((rc = run_edges(c, p, d_hist, part, parts))) return rc;
   c->begun = true;
   return SC_OK;
@@ -852,7 +876,7 @@ int sc_shard_edges_device(sc_ctx* c, uint32_t* d_hist) {
   const sc_params* p = &c->params;
   c->shard_phase = 0;
   int rc;
-  if ((rc = run_row_stats(c, may_prune(p)))) return rc;
+  if ((rc = run_row_stats(c, may_prune(p), true))) return rc;
   if ((rc = run_edges(c, p, d_hist, (uint32_t)p->shard_rank, (uint32_t)p->shard_world))) return rc;
   c->shard_phase = 2;
   return SC_OK;

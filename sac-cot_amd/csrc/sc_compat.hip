@@ -390,6 +390,104 @@ __global__ __launch_bounds__(256) void row_stats_kernel(const uint64_t* __restri
   }
 }
 
+// row_stats + the prefix over the rows in ONE launch ("fold row_stats ..."): a workgroup takes 64 rows
+// (16 waves x 4 rows), computes what row_stats_kernel computes, scans its 64 edge counts (and row costs) in one wave and
+// gets the sums of the tiles before it by decoupled look-back (sc_block.hpp) — so edge_off (the CSR row offsets), the
+// per-row CSR bases, the cost prefix and the edge count for the host all come out of the kernel that read the bit rows;
+// the separate scan launch(es) and their extra pass over deg / deg+ disappear.  79 tiles at N = 5000, 313 at 20 000.
+constexpr int RS_ROWS = 64;
+__global__ __launch_bounds__(1024) void row_stats_scan_kernel(const uint64_t* __restrict__ bits, int n, int W,
+                                                             uint32_t* __restrict__ deg, uint32_t* __restrict__ degp,
+                                                             uint32_t* __restrict__ wpre,
+                                                             uint64_t* __restrict__ zero_rows,
+                                                             uint64_t* __restrict__ edge_off,
+                                                             uint32_t* __restrict__ ebase,
+                                                             uint64_t* __restrict__ cost_pre,
+                                                             uint64_t* __restrict__ state, uint32_t epoch,
+                                                             uint64_t* __restrict__ host_total) {
+  __shared__ uint32_t l_degp[RS_ROWS], l_dlow[RS_ROWS];
+  __shared__ uint64_t l_cost[RS_ROWS];
+  __shared__ uint32_t s_tile;
+  uint32_t* ticket = reinterpret_cast<uint32_t*>(state);
+  if (threadIdx.x == 0) s_tile = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __syncthreads();
+  const uint32_t tile = s_tile, nb = gridDim.x;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int rr = 0; rr < 4; rr++) {
+    const int slot = wave * 4 + rr;
+    const int i = (int)tile * RS_ROWS + slot;
+    uint32_t d_all = 0, d_up = 0;
+    uint64_t cost = 0;
+    if (i < n) {  // wave-uniform
+      if (zero_rows)
+        for (int w = lane; w < W; w += 64) zero_rows[(size_t)i * W + w] = 0ull;
+      for (int wb = 0; wb < W; wb += 64) {
+        const int w = wb + lane;
+        const uint64_t v = w < W ? bits[(size_t)i * W + w] : 0ull;
+        const uint32_t pc = (uint32_t)__popcll(v);
+        uint32_t inc = pc;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+          const uint32_t t = __shfl_up(inc, o);
+          if (lane >= o) inc += t;
+        }
+        if (w < W) {
+          wpre[(size_t)i * W + w] = d_all + inc - pc;
+          uint64_t up = v;
+          if (w < (i >> 6)) up = 0;
+          else if (w == (i >> 6)) up &= ((i & 63) == 63) ? 0ull : (~0ull << ((i & 63) + 1));
+          d_up += __popcll(up);
+          cost += (uint64_t)__popcll(up) * (uint64_t)(W - w + 4);
+        }
+        d_all += __shfl(inc, 63);
+      }
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) { d_up += __shfl_xor(d_up, o); cost += __shfl_xor(cost, o); }
+    }
+    if (lane == 0) {
+      if (i < n) { deg[i] = d_all; degp[i] = d_up; }
+      l_degp[slot] = d_up; l_dlow[slot] = d_all - d_up; l_cost[slot] = cost;
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x >= 64) return;  // wave 0: scan of the tile's 64 rows, look-back, outputs
+  const uint64_t mine_e = l_degp[lane], mine_c = l_cost[lane];
+  uint64_t inc_e = mine_e, inc_c = mine_c;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const uint64_t te = __shfl_up(inc_e, o), tc = __shfl_up(inc_c, o);
+    if (lane >= o) { inc_e += te; inc_c += tc; }
+  }
+  const uint64_t tot_e = __shfl(inc_e, 63), tot_c = __shfl(inc_c, 63);
+  uint64_t* const desc[2] = {state + 2, state + 2 + nb};
+  const uint64_t own[2] = {tot_e, tot_c};
+  uint64_t pre[2];
+  lb_lookback<2>(desc, tile, epoch, own, pre, reinterpret_cast<uint32_t*>(state + 1));
+  const int i = (int)tile * RS_ROWS + lane;
+  if (i < n) {
+    const uint64_t off = pre[0] + inc_e - mine_e;
+    edge_off[i] = off;
+    ebase[i] = (uint32_t)off - l_dlow[lane];
+    if (cost_pre) cost_pre[i] = pre[1] + inc_c - mine_c;
+  }
+  if (tile == nb - 1 && lane == 0) {
+    edge_off[n] = pre[0] + tot_e;
+    if (cost_pre) cost_pre[n] = pre[1] + tot_c;
+    if (host_total) publish_host(host_total, pre[0] + tot_e);
+    __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // every tile has taken its ticket
+  }
+}
+
+size_t row_stats_scan_state_bytes(int n) { return (size_t)(2 * ((n + RS_ROWS - 1) / RS_ROWS) + 4) * sizeof(uint64_t); }
+
+void launch_row_stats_scan(const Points& pts, const uint64_t* bits, uint32_t* deg, uint32_t* degp, uint32_t* wpre,
+                           uint64_t* zero_rows, uint64_t* edge_off, uint32_t* ebase, uint64_t* cost_pre, void* state,
+                           uint32_t epoch, uint64_t* host_total, hipStream_t st) {
+  hipLaunchKernelGGL(row_stats_scan_kernel, dim3((pts.n + RS_ROWS - 1) / RS_ROWS), dim3(1024), 0, st, bits, pts.n,
+                     pts.ld >> 6, deg, degp, wpre, zero_rows, edge_off, ebase, cost_pre, static_cast<uint64_t*>(state), epoch,
+                     host_total);
+}
+
 // Contiguous row range of one rank: rows [lo, hi) with lo = first row whose cost prefix reaches rank / world of the
 // total (row 0 for rank 0, n for the end of the last rank).  own_row[0..1] and the CSR edge range own_edge[0..1] of
 // those rows go to the control block; every rank computes the same boundaries from the same replicated arrays.

@@ -31,6 +31,7 @@ struct Tuning {
   uint32_t sample_mode = 0;        // pruning sample: 0 by size (launch_sample_hist), 1 every stride-th edge, 2 the heaviest edges
   uint32_t sample_blocks = 0;      // grid of the heaviest-edge sample (0: one block per 256 edges)
   bool compact_fused = false;      // compaction in one launch (decoupled look-back) instead of count + write
+  bool rows_unfused = false;       // row_stats and the scan(s) of the row counts as separate launches (round 1's form)
   uint64_t sample_edges = 0;       // edges of the pruning sample (0: automatic, ~5T/8)
   uint32_t score_split = 0;        // share (of 256) of the hypotheses scored on the matrix pipe
   bool compat_one_phase = false;   // exact chain on every pair of an interior tile
@@ -65,6 +66,13 @@ void launch_compat(const Points& pts, const Derived& dv, float* S, uint64_t* bit
 // rowcost (optional, n u32): per-row estimate of stage B's work (see row_stats_kernel), for launch_shard_split.
 void launch_row_stats(const Points& pts, const uint64_t* bits, uint32_t* deg, uint32_t* degp, uint32_t* wpre,
                       uint64_t* zero_rows, uint32_t* rowcost, hipStream_t st);
+// row_stats and the prefixes over the rows in one launch (decoupled look-back over 64-row tiles): also edge_off (n + 1
+// CSR row offsets), ebase (n per-row CSR bases), cost_pre (optional, n + 1: prefix of the row costs) and the edge count
+// into host_total.  state: row_stats_scan_state_bytes(n) of the caller's look-back state area; epoch: this launch's.
+size_t row_stats_scan_state_bytes(int n);
+void launch_row_stats_scan(const Points& pts, const uint64_t* bits, uint32_t* deg, uint32_t* degp, uint32_t* wpre,
+                           uint64_t* zero_rows, uint64_t* edge_off, uint32_t* ebase, uint64_t* cost_pre, void* state,
+                           uint32_t epoch, uint64_t* host_total, hipStream_t st);
 // this rank's contiguous, equally heavy row range (own_row[0..1]) and its CSR edge range (own_edge[0..1])
 // from the exclusive prefix of rowcost (n + 1 entries) — device-side, identical on every rank.
 void launch_shard_split(const uint64_t* cost_pre, const uint64_t* edge_off, int n, uint32_t rank, uint32_t world,

@@ -273,6 +273,7 @@ def test_certified_pruning_changes_nothing_but_the_work(pkg, reg, name):
                                    dict(cnt_blocks=4096, keys_blocks=1, sel_blocks=1, sample_edges=1000000, tg_sample=32, sample_blocks=3, sample_mode=2),
                                    dict(sample_mode=2, sample_edges=700, tg_sample=8, compact_self_max=100000, scan_self_max=0),
                                    dict(compact_fused=1),          # one-launch compaction (decoupled look-back over 500+ tiles)
+                                   dict(rows_unfused=1, scan_self_max=0),   # round 1's separate row_stats + three-kernel scans
                                    dict(no_events=1, tg_count=4, tg_keys=64, sel_blocks=3, sample_mode=1),
                                    dict(sample_mode=1, sample_edges=5000, tg_sample=4, tg_events=32)])
 def test_results_do_not_depend_on_grid_or_sample_size(pkg, O, knobs):
