@@ -390,12 +390,13 @@ __global__ __launch_bounds__(256) void row_stats_kernel(const uint64_t* __restri
   }
 }
 
-// row_stats + the prefix over the rows in ONE launch ("fold row_stats ..."): a workgroup takes 64 rows
-// (16 waves x 4 rows), computes what row_stats_kernel computes, scans its 64 edge counts (and row costs) in one wave and
+// row_stats + the prefix over the rows in ONE launch ("fold row_stats ..."): a workgroup takes RS_ROWS rows
+// (16 waves x RS_RPW rows), computes what row_stats_kernel computes, scans its edge counts (and row costs) in one wave and
 // gets the sums of the tiles before it by decoupled look-back (sc_block.hpp) — so edge_off (the CSR row offsets), the
 // per-row CSR bases, the cost prefix and the edge count for the host all come out of the kernel that read the bit rows;
-// the separate scan launch(es) and their extra pass over deg / deg+ disappear.  79 tiles at N = 5000, 313 at 20 000.
-constexpr int RS_ROWS = 64;
+// the separate scan launch(es) and their extra pass over deg / deg+ disappear.  157 tiles at N = 5000, 625 at 20 000 (64-row tiles: 14.7 us on C2, fewer CUs busy).
+constexpr int RS_ROWS = 32;           // rows per tile: 16 waves x RS_RPW rows
+constexpr int RS_RPW = RS_ROWS / 16;  // rows a wave takes, one after the other
 __global__ __launch_bounds__(1024) void row_stats_scan_kernel(const uint64_t* __restrict__ bits, int n, int W,
                                                              uint32_t* __restrict__ deg, uint32_t* __restrict__ degp,
                                                              uint32_t* __restrict__ wpre,
@@ -413,8 +414,8 @@ __global__ __launch_bounds__(1024) void row_stats_scan_kernel(const uint64_t* __
   __syncthreads();
   const uint32_t tile = s_tile, nb = gridDim.x;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  for (int rr = 0; rr < 4; rr++) {
-    const int slot = wave * 4 + rr;
+  for (int rr = 0; rr < RS_RPW; rr++) {
+    const int slot = wave * RS_RPW + rr;
     const int i = (int)tile * RS_ROWS + slot;
     uint32_t d_all = 0, d_up = 0;
     uint64_t cost = 0;
@@ -451,7 +452,7 @@ __global__ __launch_bounds__(1024) void row_stats_scan_kernel(const uint64_t* __
   }
   __syncthreads();
   if (threadIdx.x >= 64) return;  // wave 0: scan of the tile's 64 rows, look-back, outputs
-  const uint64_t mine_e = l_degp[lane], mine_c = l_cost[lane];
+  const uint64_t mine_e = lane < RS_ROWS ? l_degp[lane] : 0u, mine_c = lane < RS_ROWS ? l_cost[lane] : 0ull;
   uint64_t inc_e = mine_e, inc_c = mine_c;
 #pragma unroll
   for (int o = 1; o < 64; o <<= 1) {
@@ -464,10 +465,10 @@ __global__ __launch_bounds__(1024) void row_stats_scan_kernel(const uint64_t* __
   uint64_t pre[2];
   lb_lookback<2>(desc, tile, epoch, own, pre, reinterpret_cast<uint32_t*>(state + 1));
   const int i = (int)tile * RS_ROWS + lane;
-  if (i < n) {
+  if (lane < RS_ROWS && i < n) {
     const uint64_t off = pre[0] + inc_e - mine_e;
     edge_off[i] = off;
-    ebase[i] = (uint32_t)off - l_dlow[lane];
+    ebase[i] = (uint32_t)off - l_dlow[lane];  // (lane < RS_ROWS here)
     if (cost_pre) cost_pre[i] = pre[1] + inc_c - mine_c;
   }
   if (tile == nb - 1 && lane == 0) {
