@@ -46,7 +46,7 @@ struct sc_ctx {
   // workspace
   Buf in_src, in_tgt, planes, S, bits, deg, degp, wpre, ebase, edge_off, scan_tmp, ei, ej, es, ebi, ebj, tcnt, toff, wkey, kcol, ctl, events, blk_gt,
       blk_eq, blk_minmax, bits2, off_gt, off_eq, sel_ord, sel_key, sortkey, sorted, sort_tmp, tri, tri_rk, key_rk, rt, rt_aos, partial, cnt, key, rt12,
-      mask, refine_tmp, amx_pairs, strong, rowcost, cost_pre, lb_state;
+      mask, refine_tmp, amx_pairs, strong, rowcost, cost_pre, lb_state, lb_ticket;
 
   // state of the last hypothesize call (consumed by finalize)
   int n = 0, ld = 0;
@@ -154,15 +154,26 @@ Graph graph_of(const sc_ctx* c) {
   return Graph{c->bits_cur, c->S.as<float>(), c->deg.as<uint32_t>(), c->degp.as<uint32_t>(),
                c->wpre.as<uint32_t>(), c->n, c->ld, c->ld >> 6};
 }
-// The look-back state area holds `words` u64 for this launch; hands out the launch's epoch.  The area is written by
-// look-back kernels only; it is zeroed when new, when it grew, and when the 12-bit epoch wraps.
-int lb_next(sc_ctx* c, size_t bytes, uint32_t* epoch) {
+// Look-back launches (single-pass scans, fused row kernel, fused compaction).  lb_state holds the tile descriptors and
+// is written by look-back kernels only: zeroed when new, when it grew, and when the 12-bit epoch wraps.  The TICKET and
+// error words live in a small buffer of their own (lb_ticket, zeroed once): a ticket inside the descriptor area would,
+// after a launch with another layout, sit on an old descriptor and hand out garbage tile indices (that was a GPU
+// memory fault at N = 20 000 sharded in development).  slot: which ticket (launches that may be in flight together on
+// the stream's order use different ones); desc_off: byte offset of this launch's descriptors inside the area.
+int lb_next(sc_ctx* c, size_t bytes, int slot, size_t desc_off, LbArgs* out) {
   ENSURE(c, c->lb_state, bytes);
+  if (!c->lb_ticket.p) {
+    ENSURE(c, c->lb_ticket, 256);
+    HIPCHK(c, hipMemsetAsync(c->lb_ticket.p, 0, c->lb_ticket.cap, c->stream));
+  }
   if (c->lb_state.p != c->lb_zeroed || c->lb_state.cap != c->lb_zeroed_cap || c->lb_epoch >= 4095u) {
     HIPCHK(c, hipMemsetAsync(c->lb_state.p, 0, c->lb_state.cap, c->stream));
     c->lb_zeroed = c->lb_state.p; c->lb_zeroed_cap = c->lb_state.cap; c->lb_epoch = 0;
   }
-  *epoch = ++c->lb_epoch;
+  out->epoch = ++c->lb_epoch;
+  out->ticket = c->lb_ticket.as<uint32_t>() + 2 * slot;  // 8 bytes apart
+  out->err = c->lb_ticket.as<uint32_t>() + 32 + slot;
+  out->desc = reinterpret_cast<uint64_t*>(static_cast<char*>(c->lb_state.p) + desc_off);
   return SC_OK;
 }
 
@@ -267,12 +278,12 @@ int run_row_stats(sc_ctx* c, bool will_prune, bool hot = false) {
     ENSURE(c, c->ebase, n * 4);
     uint64_t* cost_pre = nullptr;
     if (c->sharded_ab) { ENSURE(c, c->cost_pre, (n + 1) * sizeof(uint64_t)); cost_pre = c->cost_pre.as<uint64_t>(); }
-    uint32_t epoch;
-    { const int lrc = lb_next(c, row_stats_scan_state_bytes(c->n), &epoch); if (lrc) return lrc; }
+    LbArgs lb;
+    { const int lrc = lb_next(c, row_stats_scan_state_bytes(c->n), 0, 0, &lb); if (lrc) return lrc; }
     arm_word(c, 0);  // read-back #1 (the edge count) is published by this kernel
     launch_row_stats_scan(points_of(c), c->bits_cur, c->deg.as<uint32_t>(), c->degp.as<uint32_t>(), c->wpre.as<uint32_t>(),
-                          zero_rows, c->edge_off.as<uint64_t>(), c->ebase.as<uint32_t>(), cost_pre, c->lb_state.p, epoch,
-                          &c->pinned[0], c->stream);
+                          zero_rows, c->edge_off.as<uint64_t>(), c->ebase.as<uint32_t>(), cost_pre, lb, &c->pinned[0],
+                          c->stream);
     c->rows_fused = true;
     return SC_OK;
   }
@@ -328,10 +339,8 @@ int run_edges(sc_ctx* c, const sc_params* p, uint32_t* hist, uint32_t part, uint
   ScanExtra xc;  // (sharded) the scan of the row costs
   if (!fused && scan_writes_ebase(n)) {  // tiled scans: the single-pass form, each on its own half of the state area
     const size_t half = scan_temp_bytes(n);
-    { const int lrc = lb_next(c, 2 * half, &xe.epoch); if (lrc) return lrc; }
-    xe.state = c->lb_state.p;
-    if (c->sharded_ab) { const int lrc = lb_next(c, 2 * half, &xc.epoch); if (lrc) return lrc; xc.state = static_cast<char*>(c->lb_state.p) + half; }
-    xe.state = c->lb_state.p;  // (lb_next may have moved the area)
+    { const int lrc = lb_next(c, 2 * half, 0, 0, &xe.lb); if (lrc) return lrc; }
+    if (c->sharded_ab) { const int lrc = lb_next(c, 2 * half, 1, half, &xc.lb); if (lrc) return lrc; }  // (same size: the area stays)
   }
   if (c->sharded_ab) {
     // also the prefix of the per-row work estimate and, from it, this rank's contiguous row / edge range
@@ -406,9 +415,9 @@ int run_compaction(sc_ctx* c, const KeyView& view, size_t nb) {
   hipStream_t st = c->stream;
   SelectState* sel = &c->ctl.as<ControlBlock>()->sel;
   if (c->tn.compact_fused) {
-    uint32_t epoch;
-    { const int lrc = lb_next(c, compact_state_bytes(view.M), &epoch); if (lrc) return lrc; }
-    launch_compact_fused(view, sel, c->lb_state.p, epoch, c->sel_ord.as<uint64_t>(), c->sel_key.as<uint32_t>(), st);
+    LbArgs lb;
+    { const int lrc = lb_next(c, compact_state_bytes(view.M), 0, 0, &lb); if (lrc) return lrc; }
+    launch_compact_fused(view, sel, lb, c->sel_ord.as<uint64_t>(), c->sel_key.as<uint32_t>(), st);
     return SC_OK;
   }
   launch_compact_count(view, sel, c->blk_gt.as<uint32_t>(), c->blk_eq.as<uint32_t>(), st);
@@ -468,8 +477,7 @@ int run_select(sc_ctx* c, const sc_params* p, const uint32_t* hist, bool want_li
   arm_word(c, 2);
   ScanExtra xr;  // sharded: the counts outside this rank's edge range are zero — their tiles are skipped
   xr.range = own_range_of(c);
-  { const int lrc = lb_next(c, scan_temp_bytes(E), &xr.epoch); if (lrc) return lrc; }
-  xr.state = c->lb_state.p;
+  { const int lrc = lb_next(c, scan_temp_bytes(E), 0, 0, &xr.lb); if (lrc) return lrc; }
   launch_scan_u32(c->tcnt.as<uint32_t>(), E, c->toff.as<uint64_t>(), c->scan_tmp.p, c->tn, st, &c->pinned[2], &xr);
   // While the host polls for the count, the key kernel already runs into the key arrays this context holds from earlier
   // calls (it takes everything else from device memory).  Only in the common form — events, a-priori select window —
@@ -664,7 +672,7 @@ void sc_destroy(sc_ctx* c) {
   Buf* bufs[] = {&c->in_src, &c->in_tgt, &c->planes, &c->S, &c->bits, &c->deg, &c->degp, &c->wpre, &c->ebase, &c->edge_off, &c->scan_tmp,
                  &c->ei, &c->ej, &c->es, &c->ebi, &c->ebj, &c->tcnt, &c->toff, &c->wkey, &c->kcol, &c->ctl, &c->events, &c->blk_gt, &c->blk_eq, &c->blk_minmax, &c->bits2, &c->off_gt,
                  &c->off_eq, &c->sel_ord, &c->sel_key, &c->sortkey, &c->sorted, &c->sort_tmp, &c->tri, &c->tri_rk, &c->key_rk, &c->rt,
-                 &c->rt_aos, &c->partial, &c->cnt, &c->key, &c->rt12, &c->mask, &c->refine_tmp, &c->amx_pairs, &c->strong, &c->rowcost, &c->cost_pre, &c->lb_state};
+                 &c->rt_aos, &c->partial, &c->cnt, &c->key, &c->rt12, &c->mask, &c->refine_tmp, &c->amx_pairs, &c->strong, &c->rowcost, &c->cost_pre, &c->lb_state, &c->lb_ticket};
   for (Buf* b : bufs) if (b->p) (void)hipFree(b->p);
   for (int i = 0; i < N_EVENTS; i++) if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
   if (c->pinned) (void)hipHostFree(c->pinned);

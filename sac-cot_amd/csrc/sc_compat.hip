@@ -403,16 +403,17 @@ __global__ __launch_bounds__(1024) void row_stats_scan_kernel(const uint64_t* __
                                                              uint64_t* __restrict__ zero_rows,
                                                              uint64_t* __restrict__ edge_off,
                                                              uint32_t* __restrict__ ebase,
-                                                             uint64_t* __restrict__ cost_pre,
-                                                             uint64_t* __restrict__ state, uint32_t epoch,
+                                                             uint64_t* __restrict__ cost_pre, LbArgs lb,
                                                              uint64_t* __restrict__ host_total) {
   __shared__ uint32_t l_degp[RS_ROWS], l_dlow[RS_ROWS];
   __shared__ uint64_t l_cost[RS_ROWS];
   __shared__ uint32_t s_tile;
-  uint32_t* ticket = reinterpret_cast<uint32_t*>(state);
+  uint32_t* ticket = lb.ticket;
+  const uint32_t epoch = lb.epoch;
   if (threadIdx.x == 0) s_tile = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   __syncthreads();
   const uint32_t tile = s_tile, nb = gridDim.x;
+  if (tile >= nb) return;  // (a ticket that was not zero at launch: never index memory with it)
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   for (int rr = 0; rr < RS_RPW; rr++) {
     const int slot = wave * RS_RPW + rr;
@@ -460,10 +461,10 @@ __global__ __launch_bounds__(1024) void row_stats_scan_kernel(const uint64_t* __
     if (lane >= o) { inc_e += te; inc_c += tc; }
   }
   const uint64_t tot_e = __shfl(inc_e, 63), tot_c = __shfl(inc_c, 63);
-  uint64_t* const desc[2] = {state + 2, state + 2 + nb};
+  uint64_t* const desc[2] = {lb.desc, lb.desc + nb};
   const uint64_t own[2] = {tot_e, tot_c};
   uint64_t pre[2];
-  lb_lookback<2>(desc, tile, epoch, own, pre, reinterpret_cast<uint32_t*>(state + 1));
+  lb_lookback<2>(desc, tile, epoch, own, pre, lb.err);
   const int i = (int)tile * RS_ROWS + lane;
   if (lane < RS_ROWS && i < n) {
     const uint64_t off = pre[0] + inc_e - mine_e;
@@ -479,14 +480,13 @@ __global__ __launch_bounds__(1024) void row_stats_scan_kernel(const uint64_t* __
   }
 }
 
-size_t row_stats_scan_state_bytes(int n) { return (size_t)(2 * ((n + RS_ROWS - 1) / RS_ROWS) + 4) * sizeof(uint64_t); }
+size_t row_stats_scan_state_bytes(int n) { return (size_t)(2 * ((n + RS_ROWS - 1) / RS_ROWS)) * sizeof(uint64_t); }
 
 void launch_row_stats_scan(const Points& pts, const uint64_t* bits, uint32_t* deg, uint32_t* degp, uint32_t* wpre,
-                           uint64_t* zero_rows, uint64_t* edge_off, uint32_t* ebase, uint64_t* cost_pre, void* state,
-                           uint32_t epoch, uint64_t* host_total, hipStream_t st) {
+                           uint64_t* zero_rows, uint64_t* edge_off, uint32_t* ebase, uint64_t* cost_pre, const LbArgs& lb,
+                           uint64_t* host_total, hipStream_t st) {
   hipLaunchKernelGGL(row_stats_scan_kernel, dim3((pts.n + RS_ROWS - 1) / RS_ROWS), dim3(1024), 0, st, bits, pts.n,
-                     pts.ld >> 6, deg, degp, wpre, zero_rows, edge_off, ebase, cost_pre, static_cast<uint64_t*>(state), epoch,
-                     host_total);
+                     pts.ld >> 6, deg, degp, wpre, zero_rows, edge_off, ebase, cost_pre, lb, host_total);
 }
 
 // Contiguous row range of one rank: rows [lo, hi) with lo = first row whose cost prefix reaches rank / world of the
@@ -671,19 +671,20 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_downsweep_kernel(const uint
 }
 
 // Single-pass form (decoupled look-back, sc_block.hpp): one launch instead of block sums + down-sweep.
-// state: [0] ticket (u32, zero between launches: the last tile resets it), [1] error flag, [2 ..] one descriptor per tile.
+// lb: ticket (zero between launches: the last tile resets it), error flag, one descriptor per tile, this launch's epoch.
 __global__ __launch_bounds__(SCAN_THREADS) void scan_lookback_kernel(const uint32_t* __restrict__ in, size_t n,
-                                                                     uint64_t* __restrict__ out,
-                                                                     uint64_t* __restrict__ state, uint32_t epoch,
+                                                                     uint64_t* __restrict__ out, LbArgs lb,
                                                                      uint64_t* __restrict__ host_total,
                                                                      const uint64_t* __restrict__ range, ScanEbase eb) {
   __shared__ uint64_t lds[8];
   __shared__ uint32_t s_tile;
   __shared__ uint64_t s_prefix;
-  uint32_t* ticket = reinterpret_cast<uint32_t*>(state);
+  uint32_t* ticket = lb.ticket;
+  const uint32_t epoch = lb.epoch;
   if (threadIdx.x == 0) s_tile = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   __syncthreads();
   const uint32_t tile = s_tile;
+  if (tile >= gridDim.x) return;  // (a ticket that was not zero at launch: never index memory with it)
   const size_t base = (size_t)tile * SCAN_TILE + (size_t)threadIdx.x * SCAN_ITEMS;
   const bool dead = scan_tile_dead(range, tile);  // block-uniform: known zeros, neither read nor written
   uint32_t v[SCAN_ITEMS];
@@ -693,10 +694,10 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_lookback_kernel(const uint3
   uint64_t tot;
   const uint64_t ex = block_exscan_u64(s, lds, &tot);
   if (threadIdx.x < 64) {
-    uint64_t* const desc[1] = {state + 2};
+    uint64_t* const desc[1] = {lb.desc};
     const uint64_t own[1] = {tot};
     uint64_t pre[1];
-    lb_lookback<1>(desc, tile, epoch, own, pre, reinterpret_cast<uint32_t*>(state + 1));
+    lb_lookback<1>(desc, tile, epoch, own, pre, lb.err);
     if (threadIdx.x == 0) s_prefix = pre[0];
   }
   __syncthreads();
@@ -782,9 +783,9 @@ void launch_scan_u32(const uint32_t* in, size_t n, uint64_t* out, void* temp, co
   uint64_t* bsum = static_cast<uint64_t*>(temp);
   const size_t nb = (n + SCAN_TILE - 1) / SCAN_TILE;
   if (nb == 0) return;  // n == 0 is handled by the small path above
-  if (x && x->epoch && x->state && tn.scan_self_max != 0) {  // single-pass form (the caller keeps the state and its epoch)
-    hipLaunchKernelGGL(scan_lookback_kernel, dim3((unsigned)nb), dim3(SCAN_THREADS), 0, st, in, n, out,
-                       static_cast<uint64_t*>(x->state), x->epoch, host_total, range, eb);
+  if (x && x->lb.epoch && x->lb.desc && x->lb.ticket && tn.scan_self_max != 0) {  // single-pass form
+    hipLaunchKernelGGL(scan_lookback_kernel, dim3((unsigned)nb), dim3(SCAN_THREADS), 0, st, in, n, out, x->lb, host_total,
+                       range, eb);
     return;
   }
   hipLaunchKernelGGL(scan_block_sums_kernel, dim3((unsigned)nb), dim3(SCAN_THREADS), 0, st, in, n, bsum, range);

@@ -39,6 +39,18 @@ struct Tuning {
   uint32_t compat_store_mode = 0;  // 0: by size; bit 0: force 4-byte S stores, bit 2: force 16-byte, bit 1: non-temporal
 };
 
+// LbArgs: what a look-back launch needs from its caller.  desc: the tile descriptors (8 bytes per tile and value) in a
+// persistent area that ONLY look-back launches write — zeroed once, and again whenever the 12-bit epoch wraps; epochs
+// 1 .. 4095 are handed out one per launch, so words of earlier launches read as "nothing yet".  ticket / err: two
+// words that are NEVER descriptor storage (a ticket that aliased an old descriptor would hand out garbage tile
+// indices): the ticket is zero between launches (the last tile of a launch resets it).
+struct LbArgs {
+  uint32_t* ticket = nullptr;
+  uint32_t* err = nullptr;
+  uint64_t* desc = nullptr;
+  uint32_t epoch = 0;
+};
+
 // Device view of the padded SoA point planes: px py pz qx qy qz, each `ld` floats (ld = roundup(n,64)),
 // zero-filled beyond n — followed, at planes + 6 * ld, by an AoS copy of 8 floats per correspondence
 // (px py pz qx qy qz 0 0; 32-byte aligned) for the consumers that fetch one whole correspondence at a time.
@@ -71,8 +83,8 @@ void launch_row_stats(const Points& pts, const uint64_t* bits, uint32_t* deg, ui
 // into host_total.  state: row_stats_scan_state_bytes(n) of the caller's look-back state area; epoch: this launch's.
 size_t row_stats_scan_state_bytes(int n);
 void launch_row_stats_scan(const Points& pts, const uint64_t* bits, uint32_t* deg, uint32_t* degp, uint32_t* wpre,
-                           uint64_t* zero_rows, uint64_t* edge_off, uint32_t* ebase, uint64_t* cost_pre, void* state,
-                           uint32_t epoch, uint64_t* host_total, hipStream_t st);
+                           uint64_t* zero_rows, uint64_t* edge_off, uint32_t* ebase, uint64_t* cost_pre, const LbArgs& lb,
+                           uint64_t* host_total, hipStream_t st);
 // this rank's contiguous, equally heavy row range (own_row[0..1]) and its CSR edge range (own_edge[0..1])
 // from the exclusive prefix of rowcost (n + 1 entries) — device-side, identical on every rank.
 void launch_shard_split(const uint64_t* cost_pre, const uint64_t* edge_off, int n, uint32_t rank, uint32_t world,
@@ -85,12 +97,9 @@ void launch_shard_split(const uint64_t* cost_pre, const uint64_t* edge_off, int 
 //   range (device, [lo, hi)): outside it every input is known to be zero — tiles wholly outside are neither read nor
 //     written (sharded stage B: the triangle counts of the edges other ranks enumerate); out[n] is still the total;
 //   deg / degp / ebase: also ebase[i] = (u32) out[i] - (deg[i] - degp[i]), the CSR base of row i (launch_edge_fill).
-//   epoch != 0: the single-pass (decoupled look-back) form, on `state`: the caller's persistent state area of
-//     scan_temp_bytes(n) bytes that ONLY look-back launches write — zeroed once (and again whenever the 12-bit epoch
-//     wraps), epochs 1 .. 4095 handed out one per launch.
+//   lb.epoch != 0: the single-pass (decoupled look-back) form.
 struct ScanExtra {
-  uint32_t epoch = 0;
-  void* state = nullptr;
+  LbArgs lb;
   const uint64_t* range = nullptr;
   const uint32_t* deg = nullptr;
   const uint32_t* degp = nullptr;
@@ -256,7 +265,7 @@ void launch_compact_write(const KeyView& view, const SelectState* s, const uint3
 // both in ONE launch (decoupled look-back over the tiles); state: compact_state_bytes(M) of the caller's look-back
 // state area, epoch: this launch's (ScanExtra)
 size_t compact_state_bytes(uint64_t M);
-void launch_compact_fused(const KeyView& view, const SelectState* s, void* state, uint32_t epoch, uint64_t* sel_ord,
+void launch_compact_fused(const KeyView& view, const SelectState* s, const LbArgs& lb, uint64_t* sel_ord,
                           uint32_t* sel_key, hipStream_t st);
 
 // ---- sharded stage B: the candidate blob a rank sends, and the merge of the gathered blobs ----

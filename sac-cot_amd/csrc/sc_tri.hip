@@ -1305,19 +1305,20 @@ __global__ __launch_bounds__(CP_THREADS) void compact_write_kernel(KeyView view,
 
 // Count and write in ONE launch: the counts of the tiles before this one come by decoupled look-back (sc_block.hpp:
 // ticket-ordered tiles, one epoch-tagged 8-byte descriptor per tile and count) instead of from a counting launch.
-// state: [0] ticket, [1] error flag, [2 .. 2 + nb) descriptors of the "greater" counts, then nb of the "equal" counts.
+// lb.desc: nb descriptors of the "greater" counts, then nb of the "equal" counts.
 template <bool SEG>
 __global__ __launch_bounds__(CP_THREADS) void compact_fused_kernel(KeyView view, const SelectState* __restrict__ sel,
-                                                                   uint64_t* __restrict__ state, uint32_t epoch,
-                                                                   uint64_t* __restrict__ sel_ord,
+                                                                   LbArgs lb, uint64_t* __restrict__ sel_ord,
                                                                    uint32_t* __restrict__ sel_key) {
   __shared__ uint64_t lds[8];
   __shared__ uint32_t s_tile;
   __shared__ uint64_t s_pre[2];
-  uint32_t* ticket = reinterpret_cast<uint32_t*>(state);
+  uint32_t* ticket = lb.ticket;
+  const uint32_t epoch = lb.epoch;
   if (threadIdx.x == 0) s_tile = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   __syncthreads();
   const uint32_t tile = s_tile, nb = gridDim.x;
+  if (tile >= nb) return;  // (a ticket that was not zero at launch: never index memory with it)
   const uint32_t kstar = sel->kstar;
   const uint64_t need_eq = sel->need_eq;
   const uint64_t base = (uint64_t)tile * CP_TILE + (uint64_t)threadIdx.x * CP_ITEMS;
@@ -1331,10 +1332,10 @@ __global__ __launch_bounds__(CP_THREADS) void compact_fused_kernel(KeyView view,
   uint64_t tot;
   const uint64_t ex = block_exscan_u64(((uint64_t)g << 32) | q, lds, &tot);  // gt high, eq low: <= 1024 each per tile
   if (threadIdx.x < 64) {
-    uint64_t* const desc[2] = {state + 2, state + 2 + nb};
+    uint64_t* const desc[2] = {lb.desc, lb.desc + nb};
     const uint64_t own[2] = {tot >> 32, tot & 0xFFFFFFFFull};
     uint64_t pre[2];
-    lb_lookback<2>(desc, tile, epoch, own, pre, reinterpret_cast<uint32_t*>(state + 1));
+    lb_lookback<2>(desc, tile, epoch, own, pre, lb.err);
     if (threadIdx.x == 0) { s_pre[0] = pre[0]; s_pre[1] = pre[1]; }
   }
   __syncthreads();
@@ -1360,18 +1361,16 @@ __global__ __launch_bounds__(CP_THREADS) void compact_fused_kernel(KeyView view,
   }
 }
 
-size_t compact_state_bytes(uint64_t M) { return (2 * compact_blocks(M) + 4) * sizeof(uint64_t); }
+size_t compact_state_bytes(uint64_t M) { return 2 * compact_blocks(M) * sizeof(uint64_t); }
 
-void launch_compact_fused(const KeyView& view, const SelectState* s, void* state, uint32_t epoch, uint64_t* sel_ord,
+void launch_compact_fused(const KeyView& view, const SelectState* s, const LbArgs& lb, uint64_t* sel_ord,
                           uint32_t* sel_key, hipStream_t st) {
   if (view.M == 0) return;
   const dim3 grid((unsigned)compact_blocks(view.M));
   if (view.seg_len)
-    hipLaunchKernelGGL(compact_fused_kernel<true>, grid, dim3(CP_THREADS), 0, st, view, s, static_cast<uint64_t*>(state),
-                       epoch, sel_ord, sel_key);
+    hipLaunchKernelGGL(compact_fused_kernel<true>, grid, dim3(CP_THREADS), 0, st, view, s, lb, sel_ord, sel_key);
   else
-    hipLaunchKernelGGL(compact_fused_kernel<false>, grid, dim3(CP_THREADS), 0, st, view, s, static_cast<uint64_t*>(state),
-                       epoch, sel_ord, sel_key);
+    hipLaunchKernelGGL(compact_fused_kernel<false>, grid, dim3(CP_THREADS), 0, st, view, s, lb, sel_ord, sel_key);
 }
 
 void launch_compact_write(const KeyView& view, const SelectState* s, const uint32_t* blk_gt,

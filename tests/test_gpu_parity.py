@@ -890,3 +890,22 @@ def test_known_answer_bars_per_mode(pkg, reg):
         e = scene.src.astype(np.float64) @ ref["R"].astype(np.float64).T + ref["t"] - scene.tgt
         refit_mask = (e * e).sum(1) < cfg.tau ** 2
         assert (refit_mask & scene.inlier).sum() >= 0.95 * scene.inlier.sum()
+
+
+def test_sharded_A_and_B_beyond_the_one_block_scans(pkg, O):
+    """N > 8192: the row statistics and the row-count scans are separate launches again (two single-pass scans side by
+    side in sharded mode, each with its own ticket word) — a configuration C0 .. C2 never reach.  World 1 (unsharded
+    entry point), 2 and 3 on one context set reused across two scenes of different size."""
+    import torch
+    dev = torch.device("cuda:0")
+    for n, seed in ((9000, 3), (8300, 4)):
+        sc = pkg.synth.make_scene(n, 0.08, 3.0, 0.1, seed)
+        kw = dict(sigma=0.1, t_cmp=0.9, tau=0.1, min_len=0.1, max_triangles=6000, rank_mode=0)
+        ref = O.register(sc.src, sc.tgt, threads=8, **kw)
+        d_src = torch.from_numpy(sc.src).to(dev); d_tgt = torch.from_numpy(sc.tgt).to(dev)
+        for world in (1, 2, 3):
+            rc, st, Rt, mask, hdr = _run_sharded_ab(pkg, n, kw, d_src, d_tgt, world)
+            assert rc == ref["rc"] == 0
+            assert (st["edges"], st["best_rank"], st["best_count"], st["tri_kept"]) == (ref["edges"], ref["best_rank"], ref["best_count"], ref["t_eff"])
+            assert np.array_equal(mask, ref["mask"])
+            assert Rt.tobytes() == np.concatenate([ref["R"].ravel(), ref["t"]]).astype(np.float32).tobytes()
