@@ -12,11 +12,14 @@ for c in C1 C3 C4; do
   timeout -k 10 300 python bench.py --config $c --steps 20 --warmup 3 --no-cpu-baseline > $O/${TAG}_bench_$c.json 2> $O/${TAG}_bench_$c.err || { tail -5 $O/${TAG}_bench_$c.err; exit 1; }
   python3 -c "import json; d=json.load(open('$O/${TAG}_bench_$c.json')); print('$c ms/step %.4f value %.1f M/s' % (d['ms_per_step'], d['value']/1e6), d['stage_us'], d['roofline']['kernel'], d['roofline']['frac'], [ (r['kernel'], r['frac']) for r in d['roofline_other']])"
 done
-bash tools/pmc_collect.sh > $O/${TAG}_pmc.txt 2>&1 && python3 tools/pmc_summarize.py >> $O/${TAG}_pmc.txt 2>&1; tail -8 $O/${TAG}_pmc.txt
+bash tools/pmc_collect.sh > $O/${TAG}_pmc.txt 2>&1 && python3 tools/pmc_summarize.py >> $O/${TAG}_pmc.txt 2>&1 || { tail -8 $O/${TAG}_pmc.txt; exit 1; }
+tail -4 $O/${TAG}_pmc.txt | cut -c1-300
 cp profiles/pmc_summary.json $O/${TAG}_pmc_summary.json
 { timeout -k 10 300 python tools/emulate_world.py --config C3 1 2 4 8 && timeout -k 10 200 python tools/emulate_world.py --config C3 --mode replicated 8 &&
   timeout -k 10 200 python tools/emulate_world.py --config C3 --nodense 8 &&
-  timeout -k 10 300 python tools/emulate_world.py --config C4 1 2 4 8 && timeout -k 10 300 python tools/emulate_world.py --config C2 --scaling weak 1 2 4 8; } > $O/${TAG}_emulated_world.txt 2>&1
+  timeout -k 10 300 python tools/emulate_world.py --config C4 1 2 4 8 && timeout -k 10 300 python tools/emulate_world.py --config C2 --scaling weak 1 2 4 8; } > $O/${TAG}_emulated_world.txt 2>&1 \
+  || { tail -5 $O/${TAG}_emulated_world.txt; exit 1; }   # a failed GPU step ends the call: no further GPU step after it
 grep -v amdgpu.ids $O/${TAG}_emulated_world.txt | cut -c1-170
-bash tools/prof_emulate.sh ${TAG}_emuC3w8 C3 8 > $O/${TAG}_emulated_C3_world8_kernels.txt 2>&1; tail -30 $O/${TAG}_emulated_C3_world8_kernels.txt
+bash tools/prof_emulate.sh ${TAG}_emuC3w8 C3 8 > $O/${TAG}_emulated_C3_world8_kernels.txt 2>&1 || { tail -5 $O/${TAG}_emulated_C3_world8_kernels.txt; exit 1; }
+tail -30 $O/${TAG}_emulated_C3_world8_kernels.txt
 bash tools/rehearse_ranks.sh 2 4 > $O/${TAG}_rehearsal.txt 2>&1; cat $O/${TAG}_rehearsal.txt
