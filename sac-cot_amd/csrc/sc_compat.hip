@@ -783,7 +783,9 @@ void launch_scan_u32(const uint32_t* in, size_t n, uint64_t* out, void* temp, co
   uint64_t* bsum = static_cast<uint64_t*>(temp);
   const size_t nb = (n + SCAN_TILE - 1) / SCAN_TILE;
   if (nb == 0) return;  // n == 0 is handled by the small path above
-  if (x && x->lb.epoch && x->lb.desc && x->lb.ticket && tn.scan_self_max != 0) {  // single-pass form
+  // single-pass form while the look-back stays shallow (r02: 116 tiles 10.6 us against 4.9 + 7.9; 781 tiles 16.4 against
+  // 5.0 + 9.4 — every 64 tiles are one more dependent round of descriptor loads)
+  if (x && x->lb.epoch && x->lb.desc && x->lb.ticket && tn.scan_self_max != 0 && nb <= 256) {
     hipLaunchKernelGGL(scan_lookback_kernel, dim3((unsigned)nb), dim3(SCAN_THREADS), 0, st, in, n, out, x->lb, host_total,
                        range, eb);
     return;

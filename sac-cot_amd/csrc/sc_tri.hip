@@ -747,7 +747,10 @@ __global__ __launch_bounds__(256) void tri_sample_hist_kernel(const uint64_t* __
   const uint64_t n_loc = n_s > part ? (n_s - part + parts - 1) / parts : 0;
   const uint64_t groups = TOP ? (256 / TG) : (uint64_t)gridDim.x * (256 / TG);
   const uint32_t theta = TOP ? s_theta : 0u;
-  const uint64_t n_chunks = TOP ? (E + SM_CHUNK - 1) / SM_CHUNK : 1;
+  // a chunk is SM_CHUNK x parts consecutive edges, of which this rank considers every parts-th: the same number of
+  // candidates per block whatever the number of ranks sharing the sample (per-block fixed costs stay amortised)
+  const uint64_t chunk_edges = (uint64_t)SM_CHUNK * parts;
+  const uint64_t n_chunks = TOP ? (E + chunk_edges - 1) / chunk_edges : 1;
   for (uint64_t ch = TOP ? blockIdx.x : 0; ch < n_chunks; ch += TOP ? gridDim.x : 1) {
   uint64_t q_end = n_loc;
   if (TOP) {
@@ -755,9 +758,11 @@ __global__ __launch_bounds__(256) void tri_sample_hist_kernel(const uint64_t* __
     // wave totals through LDS); part / parts: this rank takes the qualifying edges with e % parts == part
     if (threadIdx.x == 0) s_cnt = 0u;
     __syncthreads();
-    for (int r = 0; r < SM_CHUNK / 256; r++) {
-      const uint64_t e = ch * SM_CHUNK + (uint64_t)r * 256 + threadIdx.x;
-      const bool ok = e < E && weight_bin(__float_as_uint(es[e]), wlo, wshift) >= theta && (e % parts) == part;
+    for (uint32_t r = 0; r < (SM_CHUNK / 256) * parts; r++) {
+      // thread t of round r looks at edge (chunk base + r * 256 + t) only if it is this rank's (e % parts == part):
+      // the edges are dealt so that consecutive threads of a round see consecutive edges of THIS rank
+      const uint64_t e = ch * chunk_edges + ((uint64_t)r * 256 + threadIdx.x);
+      const bool ok = e < E && (e % parts) == part && weight_bin(__float_as_uint(es[e]), wlo, wshift) >= theta;
       const uint64_t bal = __ballot(ok);
       const int wave = threadIdx.x >> 6;
       if ((threadIdx.x & 63) == 0) s_wtot[wave] = (uint32_t)__popcll(bal);
@@ -957,7 +962,7 @@ void launch_sample_hist(const Graph& g, const uint32_t* ebi, const uint32_t* ebj
     if (hb < 1) hb = 1;
     hipLaunchKernelGGL(es_hist_kernel, dim3((unsigned)hb), dim3(256), 0, st, es, E, wlo, wshift, es_hist);
     const int tg = tn.tg_sample ? tn.tg_sample : (g.W > 256 ? 32 : 16);  // C3 (W = 313): 134 (16) vs 107 us (32); C2: 24.4 vs 25.9
-    uint64_t nb = (E + SM_CHUNK - 1) / SM_CHUNK;
+    uint64_t nb = (E + (uint64_t)SM_CHUNK * parts - 1) / ((uint64_t)SM_CHUNK * parts);
     if (nb > 8192) nb = 8192;
     if (tn.sample_blocks) nb = tn.sample_blocks;
 #define SC_LAUNCH_TOP(TGV) hipLaunchKernelGGL((tri_sample_hist_kernel<TGV, true>), dim3((unsigned)nb), dim3(256), 0, st, g.bits, g.W, g.wpre, ebi, ebj, ei, ej, es, E, 1u, part, parts, klo, shift, hist, es_hist, target, wlo, wshift)

@@ -122,4 +122,5 @@ for world in args.worlds:
     tmax, tmean = max(times), sum(times) / len(times)
     base = base or tmax
     print(f"world={world} T_total={T_total} per-rank step: max {tmax*1e3:.3f} ms mean {tmean*1e3:.3f} ms -> job {T_total/tmax/1e6:.1f} M hyp/s, "
-          f"speed-up vs the first row {base/tmax:.2f}x | winner rank={st['best_rank']} inliers={st['best_count']} | {coll}", flush=True)
+          f"speed-up vs the first row {base/tmax:.2f}x | winner rank={st['best_rank']} inliers={st['best_count']} | {coll}"
+          f" | per rank ms: {' '.join(f'{t*1e3:.3f}' for t in times)}", flush=True)
