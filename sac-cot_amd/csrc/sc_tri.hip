@@ -943,11 +943,13 @@ void launch_sample_hist(const Graph& g, const uint32_t* ebi, const uint32_t* ebj
   // hundreds of common neighbours).  That pays when T is a small part of the graph's triangles — C3 (N = 20 000, T = 200 k):
   // stage B 962 -> 551 us, 10.6 M -> 2.1 M enumerated — is a wash on C2 (167 vs 165 us) and loses where T is most of
   // what there is (C4, T = 500 k of 8.8 M triangles: the uniform sample at stride 1 already certifies 2 T: 211 vs 248 us).
-  // C1 (N = 2000, T = 10 k) loses too: 94 vs 82 us.  What separates them is how small T is against the triangles the
-  // graph holds, for which E^2 / N is a proxy known before any is counted: C3 2550 T, C2 890 T, C1 320 T, C4 90 T.
-  // sample_mode: 0 = by this rule (E^2 / N >= 1500 T), 1 = every stride-th edge, 2 = the heaviest edges.
+  // C1 (N = 2000, T = 10 k) loses too: 94 vs 82 us; C2, a wash with every stage bracketed, gains on the hot path (stage B
+  // 154.5 -> 138.5 us: fewer keys also means the speculative launches finish sooner).  What separates them is how small T
+  // is against the triangles the graph holds, for which E^2 / N is a proxy known before any is counted: C3 2550 T, C2
+  // 890 T, C1 320 T, C4 90 T.
+  // sample_mode: 0 = by this rule (E^2 / N >= 600 T), 1 = every stride-th edge, 2 = the heaviest edges.
   const bool top = tn.sample_mode == 2 ||
-                   (tn.sample_mode == 0 && (double)E * (double)E / (double)(g.n > 0 ? g.n : 1) >= 1500.0 * (double)want);
+                   (tn.sample_mode == 0 && (double)E * (double)E / (double)(g.n > 0 ? g.n : 1) >= 600.0 * (double)want);
   if (top && es_hist) {
     // the heaviest edges (TOP form): weight histogram, then the sample itself
     uint32_t wlo, wshift;
