@@ -60,6 +60,9 @@ def main() -> int:
     ap.add_argument("--shard", choices=("ab", "replicated"), default="ab",
                     help="N > 1: shard stages A and B too (default) or replicate them (round 1's form)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--headline-only", action="store_true",
+                    help="only the timed loop and the per-stage passes (no cold call, host-I/O, varying-N, no-dense-S or CPU "
+                         "legs): what the rocprofv3 kernel-stats and PMC passes profile")
     ap.add_argument("--no-dense-s", action="store_true", help="SC_FLAG_NO_DENSE_S in the timed loop (bit rows only)")
     ap.add_argument("--debug", default="", help="sc_debug knobs for experiments: key=value,key=value")
     ap.add_argument("--split-sample", choices=("auto", "on", "off"), default="auto",
@@ -105,7 +108,7 @@ def main() -> int:
 
     # ---- cold call: a fresh context, host arrays in, outputs back (workspace allocation, first launches) ----------
     cold_ms = None
-    if world == 1:
+    if world == 1 and not args.headline_only:
         r0 = pkg.Registrar(local_rank)
         tc = time.perf_counter()
         r0.register(scene.src, scene.tgt, params=pkg.make_params(flags=base_flags, **kw))
@@ -261,7 +264,9 @@ def main() -> int:
         elif world > 1:
             out["config"]["pruning_sample"] = "sharded + 1 KiB all-reduce" if split else "replicated"
 
-        if world == 1:
+        if world == 1 and args.headline_only:
+            pass
+        elif world == 1:
             # ---- ms to best (R,t): SURVEY §8d metric (2) = host arrays in -> outputs back on the host (sc_register)
             reg.set_stream(None)
             p1 = pkg.make_params(flags=base_flags, **kw)
@@ -305,7 +310,7 @@ def main() -> int:
             out["ms_to_best_Rt"] = ms_per_step
             out["ms_to_best_Rt_note"] = "N > 1: the device-resident step (inputs already in every GPU's HBM)"
 
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and not args.headline_only:
             O = ge.load_oracle()
             tmax = min(O.max_threads(), os.cpu_count() or 1)
             ref = O.register(scene.src, scene.tgt, threads=tmax, **kw)  # warm-up pass, also the parity check

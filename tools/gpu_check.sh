@@ -13,7 +13,7 @@ import json; d=json.load(open("$R/gpurun_out/bench_$TAG.json"))
 print("value %.1f M hyp/s  ms/step %.4f  enumerated %d  ms_to_best_Rt %.4f cold %.2f" % (d["value"]/1e6, d["ms_per_step"], d["config"]["triangles_enumerated"], d["ms_to_best_Rt"], d["cold_call_ms"]))
 print(d["stage_us"]); print(d["roofline"]); print(d.get("no_dense_S")); print(d.get("cpu_baseline"))
 PY
-cd /tmp && export TMPDIR=/tmp && timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_$TAG -- python3 $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline > $R/gpurun_out/prof_$TAG.log 2>&1
+cd /tmp && export TMPDIR=/tmp && timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_$TAG -- python3 $R/bench.py --steps 20 --warmup 3 --headline-only > $R/gpurun_out/prof_$TAG.log 2>&1
 python - <<PY
 import csv,glob
 f=sorted(glob.glob("$R/gpurun_out/prof_$TAG/*/*_kernel_stats.csv"))[-1]

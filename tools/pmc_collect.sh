@@ -9,7 +9,7 @@ cd /tmp && export TMPDIR=/tmp
 run() {  # name counters...
   local name=$1; shift
   timeout -k 10 240 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d "$OUT/$name" -- \
-    python3 "$R/bench.py" --steps 3 --warmup 1 --no-cpu-baseline > "$OUT/$name.log" 2>&1 || { echo "pass $name failed"; tail -5 "$OUT/$name.log"; return 1; }
+    python3 "$R/bench.py" --steps 3 --warmup 1 --headline-only > "$OUT/$name.log" 2>&1 || { echo "pass $name failed"; tail -5 "$OUT/$name.log"; return 1; }
   echo "pass $name ok"
 }
 if [ "${PMC_ONLY_SQ:-0}" = "0" ]; then
