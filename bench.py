@@ -10,7 +10,8 @@ Workload at N = 1: BASELINE.json configs[2] ("3DMatch indoor pair, N~5k correspo
 the configuration BASELINE.json's `metric` is quoted on ("N=5k corrs") — as a synthetic scene of that shape (the
 reference ships no data).
 
-N > 1 (one process per GPU, RCCL through torch.distributed "nccl"), default `--shard ab`: stage A by row
+N > 1 (one process per GPU, RCCL through torch.distributed "nccl"), `--shard ab` (the default but for two
+ranks on a small graph, see --shard): stage A by row
 blocks, stage B by contiguous row ranges, stage C by blocks of the merged list; four collectives per step — all-gather
 of the bit rows, 1 KiB all-reduce of the pruning-sample histogram, all-gather of the candidate blobs, all-gather of
 the 16-byte winner key pairs.  `--shard replicated` is round 1's form (A and B on every rank, one or two collectives).
@@ -57,8 +58,10 @@ def main() -> int:
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--config", default="C2", help="synthetic scene template (default: the headline config C2)")
     ap.add_argument("--scaling", choices=("weak", "strong"), default="weak")
-    ap.add_argument("--shard", choices=("ab", "replicated"), default="ab",
-                    help="N > 1: shard stages A and B too (default) or replicate them (round 1's form)")
+    ap.add_argument("--shard", choices=("auto", "ab", "replicated"), default="auto",
+                    help="N > 1: shard stages A and B too (ab) or replicate them (round 1's form); auto = ab, except for two "
+                         "ranks on a small graph (n < 8192) under weak scaling, where both cost the same per rank in the "
+                         "emulation (0.337 vs 0.333 ms on C2) and the replicated form needs one collective instead of four")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--headline-only", action="store_true",
                     help="only the timed loop and the per-stage passes (no cold call, host-I/O, varying-N, no-dense-S or CPU "
@@ -123,7 +126,8 @@ def main() -> int:
     d_tgt = torch.from_numpy(scene.tgt).to(dev)
     torch.cuda.synchronize()
 
-    sharded_ab = world > 1 and args.shard == "ab"
+    sharded_ab = world > 1 and (args.shard == "ab" or (args.shard == "auto" and not (
+        world == 2 and cfg.n < 8192 and args.scaling == "weak")))
     split = (not sharded_ab) and (args.split_sample == "on" or (args.split_sample == "auto" and world >= 4))
     if sharded_ab:
         ss = pkg.shard.ShardedStep(pkg, reg, cfg.n, mk(pkg.SC_FLAG_TIMING_HOT), rank, world, dev)
