@@ -78,7 +78,7 @@ class ScDebug(C.Structure):
                 ("sample_edges", C.c_uint64), ("score_split", C.c_uint32), ("compat_one_phase", C.c_uint32),
                 ("compat_rows", C.c_uint32), ("compat_store_mode", C.c_uint32), ("tg_events", C.c_uint32), ("sample_mode", C.c_uint32),
                 ("sample_blocks", C.c_uint32), ("compact_fused", C.c_uint32), ("rows_unfused", C.c_uint32),
-                ("reserved", C.c_uint32)]
+                ("score_lds", C.c_uint32)]
 
 
 class SacCotError(RuntimeError):
@@ -215,7 +215,7 @@ class Registrar:
             return
         d = ScDebug(size=C.sizeof(ScDebug), compact_self_max=-1, scan_self_max=-1)
         for k, v in knobs.items():
-            if k not in dict(ScDebug._fields_) or k in ("size", "reserved"):
+            if k not in dict(ScDebug._fields_) or k == "size":
                 raise KeyError(f"sc_debug has no field {k!r}")
             setattr(d, k, int(v))
         self._check(self._lib.sc_set_debug(self._h, C.byref(d)))

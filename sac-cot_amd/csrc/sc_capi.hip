@@ -720,6 +720,7 @@ int sc_set_debug(sc_ctx* c, const sc_debug* d) {
   t.sample_blocks = d->sample_blocks;
   t.compact_fused = d->compact_fused != 0;
   t.rows_unfused = d->rows_unfused != 0;
+  t.score_lds = d->score_lds != 0;
   c->tn = t;
   return SC_OK;
 }
@@ -779,7 +780,7 @@ int run_stage_c(sc_ctx* c, uint64_t* d_key, sc_stats* stats) {
   c->sh = sh;
   if (sh.n_local) {
     ENSURE(c, c->rt, (size_t)12 * sh.ld_local * 4);
-    ENSURE(c, c->partial, (size_t)score_chunks(c->n, sh.ld_local) * sh.ld_local * 4);
+    ENSURE(c, c->partial, (size_t)score_chunks(c->n, sh.ld_local, score_is_scalar(p->score_mode, c->tn)) * sh.ld_local * 4);
     ENSURE(c, c->cnt, (size_t)sh.ld_local * 4);
     launch_kabsch(points_of(c), tri_source_of(c), sh, c->rt.as<float>(), c->stream);
   }
@@ -787,7 +788,8 @@ int run_stage_c(sc_ctx* c, uint64_t* d_key, sc_stats* stats) {
   launch_score(points_of(c), c->rt.as<float>(), sh, c->dv, p->score_mode, c->partial.as<uint32_t>(), c->tn, c->stream);
   if ((rc = rec(c, 5))) return rc;
   ENSURE(c, c->amx_pairs, argmax_scratch_bytes(sh.ld_local));
-  launch_argmax(points_of(c), sh, c->partial.as<uint32_t>(), c->T_eff ? c->sel_key.as<uint32_t>() : nullptr,
+  launch_argmax(points_of(c), sh, c->partial.as<uint32_t>(), score_chunks(c->n, sh.ld_local, score_is_scalar(p->score_mode, c->tn)),
+                c->T_eff ? c->sel_key.as<uint32_t>() : nullptr,
                 c->cnt.as<uint32_t>(), c->amx_pairs.as<uint64_t>(), &c->ctl.as<ControlBlock>()->amx_ticket, d_key,
                 c->stream);
   if ((rc = rec(c, 6))) return rc;
@@ -1148,14 +1150,15 @@ int sc_score_host(sc_ctx* c, const float* src, const float* tgt, int64_t n, cons
   if (n_hyp) {
     ENSURE(c, c->rt_aos, (size_t)n_hyp * 48);
     ENSURE(c, c->rt, (size_t)12 * sh.ld_local * 4);
-    ENSURE(c, c->partial, (size_t)score_chunks(c->n, sh.ld_local) * sh.ld_local * 4);
+    ENSURE(c, c->partial, (size_t)score_chunks(c->n, sh.ld_local, score_is_scalar(p->score_mode, c->tn)) * sh.ld_local * 4);
     HIPCHK(c, hipMemcpyAsync(c->rt_aos.p, Rt, (size_t)n_hyp * 48, hipMemcpyHostToDevice, c->stream));
     launch_rt_to_soa(c->rt_aos.as<float>(), n_hyp, sh.ld_local, c->rt.as<float>(), c->stream);
   }
   launch_score(points_of(c), c->rt.as<float>(), sh, c->dv, p->score_mode, c->partial.as<uint32_t>(), c->tn, c->stream);
   ENSURE(c, c->cnt, (size_t)(sh.ld_local ? sh.ld_local : 256) * 4);
   ENSURE(c, c->amx_pairs, argmax_scratch_bytes(sh.ld_local));
-  launch_argmax(points_of(c), sh, c->partial.as<uint32_t>(), nullptr, c->cnt.as<uint32_t>(), c->amx_pairs.as<uint64_t>(),
+  launch_argmax(points_of(c), sh, c->partial.as<uint32_t>(), score_chunks(c->n, sh.ld_local, score_is_scalar(p->score_mode, c->tn)),
+                nullptr, c->cnt.as<uint32_t>(), c->amx_pairs.as<uint64_t>(),
                 &c->ctl.as<ControlBlock>()->amx_ticket, c->key.as<uint64_t>(),
                 c->stream);  // positions in Rt ARE the rank indices here: single-stage key
   if ((rc = check_flag(c))) return rc;

@@ -125,6 +125,10 @@ void launch_rt_to_soa(const float* Rt, uint32_t T, uint32_t ld_local, float* RtS
 // C2
 // ------------------------------------------------------------------------------------------------
 constexpr int SCORE_THREADS = 256;
+// the lane = correspondence kernel (score_scalar_kernel, below)
+constexpr int SC_P = 8;                    // correspondences per lane
+constexpr int SC_CHUNK = 64 * SC_P;        // correspondences per wave and point chunk
+constexpr int SC_HYPS = 64;                // hypotheses per wave
 constexpr int SCORE_PC = 512;  // correspondences per chunk (LDS: 12 KiB per workgroup, 8 workgroups per CU)
 
 // Point chunking of C2: workgroups = (hypothesis groups of 256) x chunks.  Chunks are as long as LDS allows (512) for
@@ -143,7 +147,11 @@ void score_plan(int n, uint32_t ld_local, uint32_t* chunks, int* chunk_pts) {
   *chunk_pts = per;
   *chunks = (uint32_t)((n + per - 1) / per);
 }
-uint32_t score_chunks(int n, uint32_t ld_local) {
+// Which C2 kernel a call runs: the lane = correspondence mapping counts inliers only and has no matrix-pipe share.
+bool score_is_scalar(int score_mode, const Tuning& tn) { return score_mode == 0 && tn.score_split == 0 && !tn.score_lds; }
+
+uint32_t score_chunks(int n, uint32_t ld_local, bool scalar) {
+  if (scalar) return (uint32_t)((n + SC_CHUNK - 1) / SC_CHUNK);
   uint32_t c; int p;
   score_plan(n, ld_local, &c, &p);
   return c;
@@ -309,6 +317,58 @@ __global__ __launch_bounds__(SCORE_THREADS, 8) void score_kernel(const float* __
                     partial);
 }
 
+// ------------------------------------------------------------------------------------------------
+// C2, inlier count, second mapping (r02): lane = CORRESPONDENCE, hypothesis = wave-uniform.
+// A lane keeps SC_P correspondences in registers (6 floats each: no LDS at all); the wave walks its 64 hypotheses, whose 12
+// coefficients arrive by scalar loads and are SGPR operands of the same fma chain (one scalar source per instruction);
+// the inlier test is a v_cmp whose lane mask is counted on the SCALAR unit (s_bcnt1 + s_add) — so a test costs 16 VALU
+// instructions (12 for the residual, 3 for its square norm, 1 compare) instead of 17.5 + 1.5 LDS reads, and the counting
+// runs beside the vector pipe.  A hypothesis with a non-finite coefficient yields a non-finite d2 for every point
+// (finite x inf = inf or NaN, inf - inf = NaN, and squares keep them), i.e. no inlier: the same 0 the other mapping forces.
+// Counts of 64 hypotheses are collected in one VGPR (lane k keeps hypothesis k's) and stored coalesced per (point chunk,
+// hypothesis).
+// ------------------------------------------------------------------------------------------------
+
+__global__ __launch_bounds__(256, 8) void score_scalar_kernel(const float* __restrict__ planes, int n, int ld,
+                                                              const float* __restrict__ RtSoA, uint32_t ld_local,
+                                                              float tau2, uint32_t* __restrict__ partial) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int m0 = blockIdx.y * SC_CHUNK;
+  float px[SC_P], py[SC_P], pz[SC_P], qx[SC_P], qy[SC_P], qz[SC_P];
+#pragma unroll
+  for (int p = 0; p < SC_P; p++) {
+    const int m = m0 + p * 64 + lane;
+    const bool in = m < n;  // beyond n: p = 0, q = 1e30 -> d2 = +inf, never an inlier (planes are padded to ld >= m only up to ld)
+    px[p] = in ? planes[m] : 0.0f;
+    py[p] = in ? planes[(size_t)ld + m] : 0.0f;
+    pz[p] = in ? planes[2 * (size_t)ld + m] : 0.0f;
+    qx[p] = in ? planes[3 * (size_t)ld + m] : 1e30f;
+    qy[p] = in ? planes[4 * (size_t)ld + m] : 1e30f;
+    qz[p] = in ? planes[5 * (size_t)ld + m] : 1e30f;
+  }
+  const uint32_t h0 = __builtin_amdgcn_readfirstlane((blockIdx.x * 4 + wave) * SC_HYPS);  // first hypothesis of this wave
+  uint32_t acc = 0;  // lane k: count of hypothesis h0 + k over this wave's correspondences
+#pragma clang loop unroll(disable)
+  for (uint32_t k = 0; k < (uint32_t)SC_HYPS; k++) {
+    const uint32_t h = h0 + k;  // wave-uniform: the twelve loads below are scalar loads
+    const float r00 = RtSoA[h], r01 = RtSoA[(size_t)ld_local + h], r02 = RtSoA[2 * (size_t)ld_local + h];
+    const float r10 = RtSoA[3 * (size_t)ld_local + h], r11 = RtSoA[4 * (size_t)ld_local + h], r12 = RtSoA[5 * (size_t)ld_local + h];
+    const float r20 = RtSoA[6 * (size_t)ld_local + h], r21 = RtSoA[7 * (size_t)ld_local + h], r22 = RtSoA[8 * (size_t)ld_local + h];
+    const float t0 = RtSoA[9 * (size_t)ld_local + h], t1 = RtSoA[10 * (size_t)ld_local + h], t2 = RtSoA[11 * (size_t)ld_local + h];
+    uint32_t cnt = 0;  // scalar
+#pragma unroll
+    for (int p = 0; p < SC_P; p++) {
+      const float ex = t0 + fma_(r02, pz[p], fma_(r01, py[p], fma_(r00, px[p], -qx[p])));
+      const float ey = t1 + fma_(r12, pz[p], fma_(r11, py[p], fma_(r10, px[p], -qy[p])));
+      const float ez = t2 + fma_(r22, pz[p], fma_(r21, py[p], fma_(r20, px[p], -qz[p])));
+      const float d2 = fma_(ez, ez, fma_(ey, ey, ex * ex));
+      cnt += (uint32_t)__popcll(__ballot(d2 < tau2));
+    }
+    acc = ((uint32_t)lane == k) ? cnt : acc;  // lane k keeps hypothesis h0 + k's count (2 VALU per 128)
+  }
+  partial[(size_t)blockIdx.y * ld_local + h0 + lane] = acc;
+}
+
 __device__ __forceinline__ unsigned long long block_max_u64(unsigned long long k, unsigned long long* lds) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) {
@@ -377,6 +437,12 @@ __global__ __launch_bounds__(256) void score_argmax_kernel(const uint32_t* __res
 void launch_score(const Points& pts, const float* RtSoA, const Shard& sh, const Derived& dv, int score_mode,
                   uint32_t* partial, const Tuning& tn, hipStream_t st) {
   if (sh.n_local == 0) return;
+  if (score_is_scalar(score_mode, tn)) {  // 256 hypotheses per workgroup (4 waves x 64), one point chunk of 512 per wave
+    static_assert(4 * SC_HYPS == 256, "ld_local is a multiple of 256");
+    hipLaunchKernelGGL(score_scalar_kernel, dim3(sh.ld_local / 256, score_chunks(pts.n, sh.ld_local, true)), dim3(256), 0, st,
+                       pts.planes, pts.n, pts.ld, RtSoA, sh.ld_local, dv.tau2, partial);
+    return;
+  }
   uint32_t chunks;
   int chunk_pts;
   score_plan(pts.n, sh.ld_local, &chunks, &chunk_pts);
@@ -398,14 +464,13 @@ void launch_score(const Points& pts, const float* RtSoA, const Shard& sh, const 
 
 size_t argmax_scratch_bytes(uint32_t ld_local) { return (size_t)(ld_local / 256 + 1) * 2 * sizeof(uint64_t); }
 
-void launch_argmax(const Points& pts, const Shard& sh, const uint32_t* partial, const uint32_t* sel_key,
+void launch_argmax(const Points& pts, const Shard& sh, const uint32_t* partial, uint32_t n_chunks, const uint32_t* sel_key,
                    uint32_t* cnt, uint64_t* pairs, uint32_t* ticket, uint64_t* key2, hipStream_t st) {
   if (sh.n_local == 0) {  // nothing scored: the pair is (0, 0)
     (void)hipMemsetAsync(key2, 0, 2 * sizeof(uint64_t), st);
     return;
   }
-  hipLaunchKernelGGL(score_argmax_kernel, dim3(sh.ld_local / 256), dim3(256), 0, st, partial,
-                     score_chunks(pts.n, sh.ld_local), sh, sel_key, cnt,
+  hipLaunchKernelGGL(score_argmax_kernel, dim3(sh.ld_local / 256), dim3(256), 0, st, partial, n_chunks, sh, sel_key, cnt,
                      reinterpret_cast<unsigned long long*>(pairs), ticket, reinterpret_cast<unsigned long long*>(key2));
 }
 
