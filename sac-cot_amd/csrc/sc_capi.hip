@@ -782,10 +782,13 @@ int run_stage_c(sc_ctx* c, uint64_t* d_key, sc_stats* stats) {
     ENSURE(c, c->rt, (size_t)12 * sh.ld_local * 4);
     ENSURE(c, c->partial, (size_t)score_chunks(c->n, sh.ld_local, score_is_scalar(p->score_mode, c->tn)) * sh.ld_local * 4);
     ENSURE(c, c->cnt, (size_t)sh.ld_local * 4);
-    launch_kabsch(points_of(c), tri_source_of(c), sh, c->rt.as<float>(), c->stream);
+    const bool scalar = score_is_scalar(p->score_mode, c->tn);
+    if (scalar) ENSURE(c, c->rt_aos, (size_t)12 * sh.ld_local * 4);
+    launch_kabsch(points_of(c), tri_source_of(c), sh, c->rt.as<float>(), scalar ? c->rt_aos.as<float>() : nullptr, c->stream);
   }
   if ((rc = rec(c, 4))) return rc;
-  launch_score(points_of(c), c->rt.as<float>(), sh, c->dv, p->score_mode, c->partial.as<uint32_t>(), c->tn, c->stream);
+  launch_score(points_of(c), c->rt.as<float>(), c->rt_aos.as<float>(), sh, c->dv, p->score_mode, c->partial.as<uint32_t>(),
+               c->tn, c->stream);
   if ((rc = rec(c, 5))) return rc;
   ENSURE(c, c->amx_pairs, argmax_scratch_bytes(sh.ld_local));
   launch_argmax(points_of(c), sh, c->partial.as<uint32_t>(), score_chunks(c->n, sh.ld_local, score_is_scalar(p->score_mode, c->tn)),
@@ -1148,13 +1151,14 @@ int sc_score_host(sc_ctx* c, const float* src, const float* tgt, int64_t n, cons
   sh.ld_local = (uint32_t)(((uint64_t)n_hyp + 255u) / 256u * 256u);
   ENSURE(c, c->key, 64);
   if (n_hyp) {
-    ENSURE(c, c->rt_aos, (size_t)n_hyp * 48);
+    ENSURE(c, c->rt_aos, (size_t)sh.ld_local * 48);  // (the scoring kernel may read whole 256-hypothesis groups)
     ENSURE(c, c->rt, (size_t)12 * sh.ld_local * 4);
     ENSURE(c, c->partial, (size_t)score_chunks(c->n, sh.ld_local, score_is_scalar(p->score_mode, c->tn)) * sh.ld_local * 4);
     HIPCHK(c, hipMemcpyAsync(c->rt_aos.p, Rt, (size_t)n_hyp * 48, hipMemcpyHostToDevice, c->stream));
     launch_rt_to_soa(c->rt_aos.as<float>(), n_hyp, sh.ld_local, c->rt.as<float>(), c->stream);
   }
-  launch_score(points_of(c), c->rt.as<float>(), sh, c->dv, p->score_mode, c->partial.as<uint32_t>(), c->tn, c->stream);
+  launch_score(points_of(c), c->rt.as<float>(), c->rt_aos.as<float>(), sh, c->dv, p->score_mode, c->partial.as<uint32_t>(),
+               c->tn, c->stream);
   ENSURE(c, c->cnt, (size_t)(sh.ld_local ? sh.ld_local : 256) * 4);
   ENSURE(c, c->amx_pairs, argmax_scratch_bytes(sh.ld_local));
   launch_argmax(points_of(c), sh, c->partial.as<uint32_t>(), score_chunks(c->n, sh.ld_local, score_is_scalar(p->score_mode, c->tn)),

@@ -321,7 +321,8 @@ struct TriSource {
   uint64_t cand_seg, cand_stride;  // entries per blob; uint4 units between blob record arrays
 };
 // C1: RtSoA[c * ld_local + l], c = 0..11, for the local hypotheses of the shard (global rank index derived).
-void launch_kabsch(const Points& pts, const TriSource& ts, const Shard& sh, float* RtSoA, hipStream_t st);
+// RtAoS (optional): also 12 consecutive floats per local hypothesis (ld_local x 12), for the lane = correspondence kernel
+void launch_kabsch(const Points& pts, const TriSource& ts, const Shard& sh, float* RtSoA, float* RtAoS, hipStream_t st);
 // C1 on an explicit triangle list to AoS T x 12 (stage hook)
 void launch_kabsch_aos(const Points& pts, const uint32_t* tri, uint32_t T, float* Rt, hipStream_t st);
 // AoS T x 12 -> SoA planes (stage hook for sc_score_host)
@@ -333,8 +334,8 @@ void launch_rt_to_soa(const float* Rt, uint32_t T, uint32_t ld_local, float* RtS
 bool score_is_scalar(int score_mode, const Tuning& tn);
 uint32_t score_chunks(int n, uint32_t ld_local, bool scalar);
 // score_mode: 0 inlier count, 1 truncated squared residual, 2 truncated absolute residual (include/saccot.h)
-void launch_score(const Points& pts, const float* RtSoA, const Shard& sh, const Derived& dv, int score_mode,
-                  uint32_t* partial, const Tuning& tn, hipStream_t st);
+void launch_score(const Points& pts, const float* RtSoA, const float* RtAoS, const Shard& sh, const Derived& dv,
+                  int score_mode, uint32_t* partial, const Tuning& tn, hipStream_t st);
 // Winner key pair key2[0..1] (written, not accumulated: no zeroing needed):
 //   key2[0] = max over hypotheses with count > 0 of  (count << 32) | second,   second = sel_key[g] (the triangle's
 //             ranking key) or, when sel_key == nullptr, 0xFFFFFFFF - g;

@@ -66,7 +66,8 @@ __device__ __forceinline__ void tri_lookup(const TriSource& ts, uint32_t g, uint
 }
 
 __global__ __launch_bounds__(256) void kabsch_shard_kernel(const float* __restrict__ planes, int ld, TriSource ts,
-                                                           Shard sh, float* __restrict__ RtSoA) {
+                                                           Shard sh, float* __restrict__ RtSoA,
+                                                           float* __restrict__ RtAoS) {
   const uint32_t l = blockIdx.x * 256 + threadIdx.x;
   if (l >= sh.ld_local) return;
   float Rt[12];
@@ -83,12 +84,18 @@ __global__ __launch_bounds__(256) void kabsch_shard_kernel(const float* __restri
   }
 #pragma unroll
   for (int c = 0; c < 12; c++) RtSoA[(size_t)c * sh.ld_local + l] = Rt[c];
+  if (RtAoS) {  // 12 consecutive floats per hypothesis: what the lane = correspondence scoring kernel loads as scalars
+    float4* o = reinterpret_cast<float4*>(RtAoS + 12 * (size_t)l);
+    o[0] = make_float4(Rt[0], Rt[1], Rt[2], Rt[3]);
+    o[1] = make_float4(Rt[4], Rt[5], Rt[6], Rt[7]);
+    o[2] = make_float4(Rt[8], Rt[9], Rt[10], Rt[11]);
+  }
 }
 
-void launch_kabsch(const Points& pts, const TriSource& ts, const Shard& sh, float* RtSoA, hipStream_t st) {
+void launch_kabsch(const Points& pts, const TriSource& ts, const Shard& sh, float* RtSoA, float* RtAoS, hipStream_t st) {
   if (sh.ld_local == 0) return;
   hipLaunchKernelGGL(kabsch_shard_kernel, dim3(sh.ld_local / 256), dim3(256), 0, st, pts.planes, pts.ld, ts, sh,
-                     RtSoA);
+                     RtSoA, RtAoS);
 }
 
 __global__ __launch_bounds__(256) void kabsch_aos_kernel(const float* __restrict__ planes, int ld,
@@ -330,7 +337,7 @@ __global__ __launch_bounds__(SCORE_THREADS, 8) void score_kernel(const float* __
 // ------------------------------------------------------------------------------------------------
 
 __global__ __launch_bounds__(256, 8) void score_scalar_kernel(const float* __restrict__ planes, int n, int ld,
-                                                              const float* __restrict__ RtSoA, uint32_t ld_local,
+                                                              const float4* __restrict__ RtAoS, uint32_t ld_local,
                                                               float tau2, uint32_t* __restrict__ partial) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int m0 = blockIdx.y * SC_CHUNK;
@@ -348,13 +355,16 @@ __global__ __launch_bounds__(256, 8) void score_scalar_kernel(const float* __res
   }
   const uint32_t h0 = __builtin_amdgcn_readfirstlane((blockIdx.x * 4 + wave) * SC_HYPS);  // first hypothesis of this wave
   uint32_t acc = 0;  // lane k: count of hypothesis h0 + k over this wave's correspondences
-#pragma clang loop unroll(disable)
+  // The first form read the twelve coefficients from the SoA planes — twelve scalar loads with their own 64-bit address
+  // arithmetic, 59 SALU instructions per hypothesis — and the ONE scalar unit of the CU, shared by the four SIMDs, became
+  // the limiter (C2 122 us against 93 for the LDS kernel).  From the AoS copy they are three s_load_dwordx4 off one
+  // address; two hypotheses per trip so that one wait covers both loads.
+  const float4* __restrict__ myRt = RtAoS + 3 * (size_t)h0;
+#pragma clang loop unroll_count(2)
   for (uint32_t k = 0; k < (uint32_t)SC_HYPS; k++) {
-    const uint32_t h = h0 + k;  // wave-uniform: the twelve loads below are scalar loads
-    const float r00 = RtSoA[h], r01 = RtSoA[(size_t)ld_local + h], r02 = RtSoA[2 * (size_t)ld_local + h];
-    const float r10 = RtSoA[3 * (size_t)ld_local + h], r11 = RtSoA[4 * (size_t)ld_local + h], r12 = RtSoA[5 * (size_t)ld_local + h];
-    const float r20 = RtSoA[6 * (size_t)ld_local + h], r21 = RtSoA[7 * (size_t)ld_local + h], r22 = RtSoA[8 * (size_t)ld_local + h];
-    const float t0 = RtSoA[9 * (size_t)ld_local + h], t1 = RtSoA[10 * (size_t)ld_local + h], t2 = RtSoA[11 * (size_t)ld_local + h];
+    const float4 c0 = myRt[3 * k], c1 = myRt[3 * k + 1], c2 = myRt[3 * k + 2];  // wave-uniform: scalar loads
+    const float r00 = c0.x, r01 = c0.y, r02 = c0.z, r10 = c0.w, r11 = c1.x, r12 = c1.y, r20 = c1.z, r21 = c1.w, r22 = c2.x;
+    const float t0 = c2.y, t1 = c2.z, t2 = c2.w;
     uint32_t cnt = 0;  // scalar
 #pragma unroll
     for (int p = 0; p < SC_P; p++) {
@@ -434,13 +444,13 @@ __global__ __launch_bounds__(256) void score_argmax_kernel(const uint32_t* __res
 }
 
 // Tuning::score_split: share of the hypotheses (in 256ths) scored on the matrix pipe (default 0; experiments)
-void launch_score(const Points& pts, const float* RtSoA, const Shard& sh, const Derived& dv, int score_mode,
-                  uint32_t* partial, const Tuning& tn, hipStream_t st) {
+void launch_score(const Points& pts, const float* RtSoA, const float* RtAoS, const Shard& sh, const Derived& dv,
+                  int score_mode, uint32_t* partial, const Tuning& tn, hipStream_t st) {
   if (sh.n_local == 0) return;
   if (score_is_scalar(score_mode, tn)) {  // 256 hypotheses per workgroup (4 waves x 64), one point chunk of 512 per wave
     static_assert(4 * SC_HYPS == 256, "ld_local is a multiple of 256");
     hipLaunchKernelGGL(score_scalar_kernel, dim3(sh.ld_local / 256, score_chunks(pts.n, sh.ld_local, true)), dim3(256), 0, st,
-                       pts.planes, pts.n, pts.ld, RtSoA, sh.ld_local, dv.tau2, partial);
+                       pts.planes, pts.n, pts.ld, reinterpret_cast<const float4*>(RtAoS), sh.ld_local, dv.tau2, partial);
     return;
   }
   uint32_t chunks;
