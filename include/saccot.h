@@ -173,7 +173,7 @@ typedef struct sc_debug {
   uint32_t sample_blocks;     /* grid size of the heaviest-edge sample (0 = one block per 256 edges)              */
   uint32_t compact_fused;     /* 1: compaction in one launch (look-back over the tiles) instead of count + write    */
   uint32_t rows_unfused;      /* 1: row statistics and the scans of the row counts as separate launches             */
-  uint32_t score_lds;         /* 1: stage C2 counts inliers with the lane = hypothesis kernel (points in LDS) too    */
+  uint32_t score_scalar;      /* 1: stage C2 counts inliers with the lane = correspondence kernel (measured slower)  */
 } sc_debug;
 int         sc_set_debug(sc_ctx* ctx, const sc_debug* dbg);
 

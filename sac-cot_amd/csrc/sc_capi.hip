@@ -720,7 +720,7 @@ int sc_set_debug(sc_ctx* c, const sc_debug* d) {
   t.sample_blocks = d->sample_blocks;
   t.compact_fused = d->compact_fused != 0;
   t.rows_unfused = d->rows_unfused != 0;
-  t.score_lds = d->score_lds != 0;
+  t.score_scalar = d->score_scalar != 0;
   c->tn = t;
   return SC_OK;
 }

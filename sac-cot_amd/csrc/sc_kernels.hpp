@@ -32,7 +32,7 @@ struct Tuning {
   uint32_t sample_blocks = 0;      // grid of the heaviest-edge sample (0: one block per 256 edges)
   bool compact_fused = false;      // compaction in one launch (decoupled look-back) instead of count + write
   bool rows_unfused = false;       // row_stats and the scan(s) of the row counts as separate launches (round 1's form)
-  bool score_lds = false;          // C2: the lane = hypothesis kernel (points in LDS) also for the plain inlier count
+  bool score_scalar = false;       // C2: count inliers with the lane = correspondence kernel (coefficients as scalar operands)
   uint64_t sample_edges = 0;       // edges of the pruning sample (0: automatic, ~5T/8)
   uint32_t score_split = 0;        // share (of 256) of the hypotheses scored on the matrix pipe
   bool compat_one_phase = false;   // exact chain on every pair of an interior tile
@@ -328,9 +328,9 @@ void launch_kabsch_aos(const Points& pts, const uint32_t* tri, uint32_t T, float
 // AoS T x 12 -> SoA planes (stage hook for sc_score_host)
 void launch_rt_to_soa(const float* Rt, uint32_t T, uint32_t ld_local, float* RtSoA, hipStream_t st);
 // C2: inlier counts.  partial: n_chunks * ld_local u32 scratch.
-// Two C2 kernels: lane = hypothesis with the points in LDS (every score mode, the matrix-pipe share), and lane =
-// correspondence with the hypothesis in scalar registers (inlier count only; the default there).  score_is_scalar says
-// which one a call runs; score_chunks: point chunks that launch will use (rows of `partial`).
+// Two C2 kernels: lane = hypothesis with the points in LDS (the default; every score mode, the matrix-pipe share), and
+// lane = correspondence with the hypothesis in scalar registers (inlier count only; measured slower, Tuning::score_scalar).
+// score_is_scalar says which one a call runs; score_chunks: point chunks that launch will use (rows of `partial`).
 bool score_is_scalar(int score_mode, const Tuning& tn);
 uint32_t score_chunks(int n, uint32_t ld_local, bool scalar);
 // score_mode: 0 inlier count, 1 truncated squared residual, 2 truncated absolute residual (include/saccot.h)

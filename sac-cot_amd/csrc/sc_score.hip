@@ -155,7 +155,8 @@ void score_plan(int n, uint32_t ld_local, uint32_t* chunks, int* chunk_pts) {
   *chunks = (uint32_t)((n + per - 1) / per);
 }
 // Which C2 kernel a call runs: the lane = correspondence mapping counts inliers only and has no matrix-pipe share.
-bool score_is_scalar(int score_mode, const Tuning& tn) { return score_mode == 0 && tn.score_split == 0 && !tn.score_lds; }
+// (Measured r02 and NOT the default: 114.8 us against 93.9 on C2, 1534 against 1245 on C3 — see score_scalar_kernel.)
+bool score_is_scalar(int score_mode, const Tuning& tn) { return score_mode == 0 && tn.score_split == 0 && tn.score_scalar; }
 
 uint32_t score_chunks(int n, uint32_t ld_local, bool scalar) {
   if (scalar) return (uint32_t)((n + SC_CHUNK - 1) / SC_CHUNK);
@@ -325,7 +326,8 @@ __global__ __launch_bounds__(SCORE_THREADS, 8) void score_kernel(const float* __
 }
 
 // ------------------------------------------------------------------------------------------------
-// C2, inlier count, second mapping (r02): lane = CORRESPONDENCE, hypothesis = wave-uniform.
+// C2, inlier count, second mapping (r02; built, bit-exact, SLOWER, kept behind sc_debug.score_scalar):
+// lane = CORRESPONDENCE, hypothesis = wave-uniform.
 // A lane keeps SC_P correspondences in registers (6 floats each: no LDS at all); the wave walks its 64 hypotheses, whose 12
 // coefficients arrive by scalar loads and are SGPR operands of the same fma chain (one scalar source per instruction);
 // the inlier test is a v_cmp whose lane mask is counted on the SCALAR unit (s_bcnt1 + s_add) — so a test costs 16 VALU
@@ -334,6 +336,10 @@ __global__ __launch_bounds__(SCORE_THREADS, 8) void score_kernel(const float* __
 // (finite x inf = inf or NaN, inf - inf = NaN, and squares keep them), i.e. no inlier: the same 0 the other mapping forces.
 // Counts of 64 hypotheses are collected in one VGPR (lane k keeps hypothesis k's) and stored coalesced per (point chunk,
 // hypothesis).
+// Result on MI355X: 16.4 VALU instructions per 64 tests as planned (ISA checked), but they issue at 4.4 cycles each
+// against 3.04 in the lane = hypothesis kernel — VALU instructions that take a scalar-register operand (all of them here)
+// are the slower kind on this part, whatever the scalar unit does beside them (first form: 59 SALU per hypothesis, 122 us;
+// with 21: 114.8 us; the LDS kernel: 93.9 us).
 // ------------------------------------------------------------------------------------------------
 
 __global__ __launch_bounds__(256, 8) void score_scalar_kernel(const float* __restrict__ planes, int n, int ld,
