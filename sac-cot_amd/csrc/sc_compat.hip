@@ -533,10 +533,11 @@ void launch_compat(const Points& pts, const Derived& dv, float* S, uint64_t* bit
   const int W = pts.ld >> 6;
   const int two_phase = tn.compat_one_phase ? 0 : 1;  // the one-phase interior form stays for A/B and parity
   const bool rect = !(row0 == 0 && row1 >= pts.n);
-  // S stores: 16 bytes per lane pay on big matrices (C3, N = 20 000: 346 vs 404 us = 4.8 vs 4.1 TB/s) and cost a little
-  // on small ones, where the kernel's time is a wave's latency (C2, N = 5000: 25.8 vs 23.7 us) — measured r02,
-  // profiles/r02_ab_compat_stores.txt; non-temporal stores changed nothing at either size.  Tuning::compat_store_mode
-  // forces a form (bit 0: 4-byte, bit 2: 16-byte) and adds the nt hint (bit 1).
+  // S stores, measured r02 (profiles/r02_ab_compat_stores.txt): on the first box 16 bytes per lane paid on the big matrix
+  // (C3, N = 20 000: 346 vs 404 us, alternating with the form four times in one process) and cost a little on the small
+  // one, where the kernel's time is a wave's latency (C2: 25.8 vs 23.7 us); on another box, later, C3 ran 400-420 us in
+  // EVERY form.  So: 16-byte stores from ~N = 8000 on (never slower there), 4-byte below; non-temporal stores changed
+  // nothing anywhere.  Tuning::compat_store_mode forces a form (bit 0: 4-byte, bit 2: 16-byte), bit 1 adds the nt hint.
   const long long tiles_all = rect ? (long long)((row1 - row0 + 15) / 16) * W : 2ll * W * (W + 1);
   int mode = (tiles_all >= 32768 || rect) ? 0 : 1;
   if (tn.compat_store_mode & 1u) mode = 1;
