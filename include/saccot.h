@@ -47,6 +47,12 @@ extern "C" {
 #define SC_ETOOMANY -6   /* the graph has more triangles than the workspace cap can rank (see max_workspace),  */
                          /* or 2^32 or more edges (edge ids are 32-bit)                                      */
 
+#define SC_ERETRY   -7   /* sharded stages A + B only: a rank's candidate blob was too small for this input (its    */
+                         /* list was cut at a key the merged threshold does not clear).  Outputs are not valid;    */
+                         /* repeat the call on every rank with sc_params.shard_cand_level raised by one (every     */
+                         /* rank sees the same blobs, so every rank returns it together).  sc_register_multi does  */
+                         /* this by itself.                                                                        */
+
 /* Limits: 3 <= n <= 2^24; max_triangles <= 2^32 - 256; the compatibility graph must have fewer than 2^32 edges
  * (SC_ETOOMANY otherwise; with the default 64 GiB workspace cap a dense graph runs out of workspace long before). */
 
@@ -103,7 +109,8 @@ typedef struct sc_params {
   uint32_t flags;           /* SC_FLAG_*                                                                */
   uint64_t max_workspace;   /* cap in bytes on the device workspace (0 -> 64 GiB)                       */
   int32_t  score_mode;      /* SC_SCORE_COUNT / SC_SCORE_MSE / SC_SCORE_MAE                             */
-  int32_t  reserved;        /* 0                                                                        */
+  int32_t  shard_cand_level;/* sharded A + B: a candidate blob holds max(2T/world, 4096) << level entries (<= T):    */
+                            /* 0, raised by one after SC_ERETRY; negative values shrink the blob (tests)             */
 } sc_params;
 
 /* Per-call statistics (all optional: pass NULL).  Times are device times from HIP events on the
@@ -242,9 +249,11 @@ int sc_hypothesize_end_device(sc_ctx* ctx, const uint32_t* d_hist, uint64_t* d_k
  *     sc_shard_score_device  (d_cand_all, d_key) -> all-gather of the 16-byte key pairs
  *     sc_finalize_gathered_device (d_keys, shard_world, ...)
  * d_bits_all: bits_bytes_total bytes; rank r's slice starts at r * bits_bytes_per_rank (its rows at their global
- * index).  A candidate blob holds a rank's own top-T triangles in (i,j,k) order; the row ranges ascend with the rank,
- * so the concatenated blobs are in global (i,j,k) order and the merge is the same exact select + compaction every
- * rank runs on one GPU: winner, (R,t) and mask are bit-identical to the unsharded call.  Every rank must pass the
+ * index).  A candidate blob holds a rank's own best triangles in (i,j,k) order — up to max(2T/world, 4096) <<
+ * shard_cand_level of them, never more than T (a rank contributes ~T/world with equally heavy row ranges); the row
+ * ranges ascend with the rank, so the concatenated blobs are in global (i,j,k) order and the merge is the same exact
+ * select + compaction every rank runs on one GPU: winner, (R,t) and mask are bit-identical to the unsharded call.  If a
+ * rank had to cut its list and the cut could have mattered, the finalize call returns SC_ERETRY on every rank.  Every rank must pass the
  * same n and parameters (shard_rank aside).  shard_world <= 64; shard_world == 1 works (no collective needed).
  * Each phase leaves its last kernels queued on the context's stream; enqueue the collective on the same stream. */
 typedef struct sc_shard_plan {

@@ -16,7 +16,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libsaccot.so")
 
-SC_OK, SC_EINVAL, SC_ENOMEM, SC_EHIP, SC_ERCCL, SC_ENOHYP, SC_ETOOMANY = 0, -1, -2, -3, -4, -5, -6
+SC_OK, SC_EINVAL, SC_ENOMEM, SC_EHIP, SC_ERCCL, SC_ENOHYP, SC_ETOOMANY, SC_ERETRY = 0, -1, -2, -3, -4, -5, -6, -7
 SC_AOS, SC_SOA = 0, 1
 SC_RANK_WEIGHT, SC_RANK_DEGREE = 0, 1
 SC_SCORE_COUNT, SC_SCORE_MSE, SC_SCORE_MAE = 0, 1, 2
@@ -46,7 +46,7 @@ class ScParams(C.Structure):
                 ("min_len", C.c_float), ("max_triangles", C.c_uint32), ("rank_mode", C.c_int32),
                 ("layout", C.c_int32), ("shard_rank", C.c_int32), ("shard_world", C.c_int32),
                 ("shard_block", C.c_uint32), ("flags", C.c_uint32), ("max_workspace", C.c_uint64),
-                ("score_mode", C.c_int32), ("reserved", C.c_int32)]
+                ("score_mode", C.c_int32), ("shard_cand_level", C.c_int32)]
 
 
 class ScStats(C.Structure):
@@ -144,9 +144,9 @@ def load_library() -> C.CDLL:
 
 def make_params(sigma=0.1, t_cmp=0.9, tau=0.1, min_len=0.1, max_triangles=50000, rank_mode=SC_RANK_WEIGHT,
                 layout=SC_AOS, shard_rank=0, shard_world=1, shard_block=1024, flags=0, max_workspace=0,
-                score_mode=0) -> ScParams:
+                score_mode=0, shard_cand_level=0) -> ScParams:
     return ScParams(C.sizeof(ScParams), sigma, t_cmp, tau, min_len, max_triangles, rank_mode, layout, shard_rank,
-                    shard_world, shard_block, flags, max_workspace, score_mode, 0)
+                    shard_world, shard_block, flags, max_workspace, score_mode, shard_cand_level)
 
 
 def shard_plan(params: ScParams, n: int) -> ScShardPlan:
@@ -267,7 +267,7 @@ class Registrar:
         """Phase 2 on n_pairs all-gathered key pairs (shard.allgather_best): the reduction runs in the kernel."""
         st = ScStats(C.sizeof(ScStats))
         rc = self._check(self._lib.sc_finalize_gathered_device(self._h, d_keys, n_pairs, d_Rt, d_mask, C.byref(st)),
-                         allow=(SC_ENOHYP,))
+                         allow=(SC_ENOHYP, SC_ERETRY))  # SC_ERETRY (sharded A + B): repeat with shard_cand_level + 1
         return rc, st.as_dict()
 
     # ---- stages A and B sharded too (SURVEY §8f-1; include/saccot.h "phase API") ----------------------------

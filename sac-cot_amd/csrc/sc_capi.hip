@@ -132,6 +132,7 @@ int check_params(const sc_params* p) {
   if (p->layout != SC_AOS && p->layout != SC_SOA) return SC_EINVAL;
   if (p->shard_world < 1 || p->shard_rank < 0 || p->shard_rank >= p->shard_world) return SC_EINVAL;
   if (p->score_mode < SC_SCORE_COUNT || p->score_mode > SC_SCORE_MAE) return SC_EINVAL;
+  if (p->shard_cand_level < -16 || p->shard_cand_level > 30) return SC_EINVAL;
   return SC_OK;
 }
 
@@ -177,6 +178,14 @@ int lb_next(sc_ctx* c, size_t bytes, int slot, size_t desc_off, LbArgs* out) {
   return SC_OK;
 }
 
+// how many triangles stage B selects: T — or, when B is sharded, what one candidate blob holds (this rank's own best)
+uint32_t select_want(const sc_ctx* c, const sc_params* p) {
+  if (!c->sharded_ab) return p->max_triangles;
+  return (uint32_t)cand_cap(p->max_triangles, (uint32_t)p->shard_world, p->shard_cand_level) < p->max_triangles
+             ? (uint32_t)cand_cap(p->max_triangles, (uint32_t)p->shard_world, p->shard_cand_level)
+             : p->max_triangles;
+}
+
 // sharded stage B: the device-side edge range [lo, hi) this rank enumerates (nullptr: every edge)
 const uint64_t* own_range_of(const sc_ctx* c) {
   return c->sharded_ab ? c->ctl.as<ControlBlock>()->own_edge : nullptr;
@@ -186,9 +195,9 @@ const uint64_t* own_range_of(const sc_ctx* c) {
 TriSource tri_source_of(const sc_ctx* c) {
   TriSource ts{c->sel_ord.as<uint64_t>(), c->kcol.as<uint2>(), c->ei.as<uint32_t>(), c->ej.as<uint32_t>(), nullptr, 0, 0};
   if (c->sharded_ab && c->cand_all) {  // the selection indexes the gathered candidate blobs
-    const uint32_t T = c->params.max_triangles;
-    ts.cand_recs = cand_blob(const_cast<void*>(c->cand_all), T).recs;
-    ts.cand_seg = cand_cap(T);
+    const size_t cap = cand_cap(c->params.max_triangles, (uint32_t)c->params.shard_world, c->params.shard_cand_level);
+    ts.cand_recs = cand_blob(const_cast<void*>(c->cand_all), cap).recs;
+    ts.cand_seg = cap;
     ts.cand_stride = c->cand_bytes / 16;
   }
   return ts;
@@ -490,7 +499,7 @@ int run_select(sc_ctx* c, const sc_params* p, const uint32_t* hist, bool want_li
     if (spec_cap) {
       ENSURE(c, c->blk_minmax, 2 * 8192 * 4);
       launch_tri_keys_events(g, c->es.as<float>(), c->toff.as<uint64_t>(), p->rank_mode, ev, c->wkey.as<uint32_t>(),
-                             c->kcol.as<uint2>(), c->blk_minmax.as<uint32_t>(), sel, p->max_triangles,
+                             c->kcol.as<uint2>(), c->blk_minmax.as<uint32_t>(), sel, select_want(c, p),
                              &c->ctl.as<ControlBlock>()->klb, E, spec_cap, c->tn, st);
     }
   }
@@ -498,7 +507,8 @@ int run_select(sc_ctx* c, const sc_params* p, const uint32_t* hist, bool want_li
   c->M_total = have_total ? c->pinned[4] : c->pinned[2];
   const uint64_t M = c->M = c->pinned[2];
   if (M == 0) return SC_OK;
-  const uint32_t T_eff = c->T_eff = (uint32_t)(M < p->max_triangles ? M : p->max_triangles);
+  const uint32_t want_sel = select_want(c, p);
+  const uint32_t T_eff = c->T_eff = (uint32_t)(M < want_sel ? M : want_sel);
   if (M * 12 > c->cap_bytes) { c->last_error = "triangle keys exceed the workspace cap"; return SC_ETOOMANY; }
   const size_t nb = compact_blocks(M);
   ENSURE(c, c->wkey, M * 4);
@@ -623,6 +633,7 @@ const char* sc_strerror(int status) {
     case SC_ERCCL: return "collective error";
     case SC_ENOHYP: return "no hypothesis: the compatibility graph has no triangle with an inlier";
     case SC_ETOOMANY: return "too many triangles for the workspace cap";
+    case SC_ERETRY: return "a candidate blob was too small: repeat with sc_params.shard_cand_level + 1";
     default: return "unknown status";
   }
 }
@@ -637,7 +648,7 @@ void sc_default_params(sc_params* p) {
   p->layout = SC_AOS;
   p->shard_rank = 0; p->shard_world = 1; p->shard_block = 1024;
   p->flags = 0; p->max_workspace = 0;
-  p->score_mode = SC_SCORE_COUNT; p->reserved = 0;
+  p->score_mode = SC_SCORE_COUNT; p->shard_cand_level = 0;
 }
 
 int sc_create(int device, sc_ctx** out) {
@@ -843,7 +854,7 @@ int sc_shard_plan_query(const sc_params* p, int64_t n, sc_shard_plan* out) {
   out->words_per_row = (uint32_t)W;
   out->bits_bytes_per_rank = R * W * 8;
   out->bits_bytes_total = G * R * W * 8;
-  out->cand_bytes_per_rank = cand_blob_bytes(p->max_triangles);
+  out->cand_bytes_per_rank = cand_blob_bytes(cand_cap(p->max_triangles, (uint32_t)p->shard_world, p->shard_cand_level));
   return SC_OK;
 }
 
@@ -905,13 +916,14 @@ int sc_shard_select_device(sc_ctx* c, const uint32_t* d_hist, void* d_cand_mine)
   c->shard_phase = 0;
   int rc;
   if ((rc = run_select(c, p, d_hist, false))) return rc;   // this rank's own top-T, in (i,j,k) order
-  const CandBlob b = cand_blob(d_cand_mine, p->max_triangles);
+  const CandBlob b = cand_blob(d_cand_mine, cand_cap(p->max_triangles, (uint32_t)p->shard_world, p->shard_cand_level));
   if (c->M == 0) {  // nothing enumerated here (also E == 0): an empty blob
     HIPCHK(c, hipMemsetAsync(b.hdr, 0, CAND_HDR_WORDS * 8, c->stream));
   } else {
     launch_cand_emit(c->sel_ord.as<uint64_t>(), c->sel_key.as<uint32_t>(), c->kcol.as<uint2>(), c->ei.as<uint32_t>(),
-                     c->ej.as<uint32_t>(), &c->ctl.as<ControlBlock>()->sel, c->toff.as<uint64_t>(), c->E, c->T_eff, b,
-                     c->stream);
+                     c->ej.as<uint32_t>(), &c->ctl.as<ControlBlock>()->sel, c->toff.as<uint64_t>(), c->E, c->T_eff,
+                     // a full-length list (T entries) is never "cut": the global top-T takes at most T from one rank
+                     select_want(c, p) < p->max_triangles ? (uint64_t)c->T_eff : ~0ull, b, c->stream);
   }
   HIPCHK(c, hipGetLastError());
   c->shard_phase = 3;
@@ -926,13 +938,14 @@ int sc_shard_score_device(sc_ctx* c, const void* d_cand_all, uint64_t* d_key, sc
   c->shard_phase = 0;
   hipStream_t st = c->stream;
   const uint32_t T = p->max_triangles, G = (uint32_t)p->shard_world;
-  const size_t blob_bytes = cand_blob_bytes(T);
+  const size_t cap = cand_cap(T, G, p->shard_cand_level);
+  const size_t blob_bytes = cand_blob_bytes(cap);
   c->cand_all = d_cand_all; c->cand_bytes = blob_bytes;
   // Merge: the same exact select + (i,j,k)-order compaction as on one GPU, over the concatenated candidate keys.
   ControlBlock* ctl = c->ctl.as<ControlBlock>();
   SelectState* sel = &ctl->sel;
   const bool window_known = p->rank_mode == SC_RANK_WEIGHT && 3.0f * p->t_cmp * 0.999f >= 2.0f;
-  const KeyView view = cand_view(d_cand_all, blob_bytes, G, T);
+  const KeyView view = cand_view(d_cand_all, blob_bytes, G, cap);
   const size_t nb = compact_blocks(view.M);
   ENSURE(c, c->blk_gt, nb * 4);
   ENSURE(c, c->blk_eq, nb * 4);
@@ -944,6 +957,8 @@ int sc_shard_score_device(sc_ctx* c, const void* d_cand_all, uint64_t* d_key, sc
   arm_word(c, 6);
   launch_merge_prepare(d_cand_all, blob_bytes, G, T, window_known, &ctl->klb, sel, &c->pinned[6], st);
   launch_select_rounds(view, sel, window_known ? 2 : 3, c->tn, st);
+  c->pinned[12] = 0;  // "a cut candidate list could have mattered": read by the finalize call (SC_ERETRY)
+  launch_merge_check(d_cand_all, blob_bytes, G, sel, &c->pinned[12], st);
   { const int crc = run_compaction(c, view, nb); if (crc) return crc; }
   // the merged length, published by merge_prepare long before the compaction ends: the poll costs no GPU time
   { const int wrc = wait_word(c, 6); if (wrc) return wrc; }
@@ -980,6 +995,12 @@ int sc_finalize_gathered_device(sc_ctx* c, const uint64_t* d_keys, int n_pairs, 
   else if (c->timing_one == 6) HIPCHK(c, hipEventSynchronize(c->ev[8]));  // the mask bracket ends after the kernel polled below
   if ((rc = wait_word(c, 8))) return rc;
   HIPCHK(c, hipGetLastError());
+  if (c->sharded_ab && c->cand_all && c->pinned[12] != 0) {
+    // merge_check_kernel (an earlier kernel of this stream: its system-scope store is visible once the winner word is):
+    // some rank's candidate list was cut at a key the merged threshold does not clear
+    c->last_error = "a candidate blob was too small for this input: repeat the call with sc_params.shard_cand_level raised by one";
+    return SC_ERETRY;
+  }
   if (c->pinned[11] != 0) {  // finalize_kernel: a pair decodes to a position outside the selection (outputs: identity, zero mask)
     c->last_error = "a winner key pair points outside the selected list (stale / uninitialised pair, or ranks that disagree on T or the parameters)";
     return SC_EINVAL;

@@ -271,24 +271,34 @@ void launch_compact_fused(const KeyView& view, const SelectState* s, const LbArg
 
 // ---- sharded stage B: the candidate blob a rank sends, and the merge of the gathered blobs ----
 constexpr int CAND_HDR_WORDS = 32;  // u64 words: [0] triangles enumerated, [1] entries sent, [2] local threshold key,
-                                    // [3] / [4] a key range containing every key sent
+                                    // [3] / [4] a key range containing every key sent, [5] 1 = the rank had more
+                                    // candidates than the blob holds (its list is cut at its local threshold key)
 struct CandBlob {
   uint64_t* hdr;
   uint32_t* keys;  // cap entries, (i,j,k) ascending
   uint4* recs;     // cap entries {i, j, k, key}
   size_t cap;
 };
-size_t cand_cap(uint32_t T);         // entries per blob: T rounded up to 1024 (a rank never contributes more than T)
-size_t cand_blob_bytes(uint32_t T);  // bytes per rank
-CandBlob cand_blob(void* blob, uint32_t T);
+// Entries per blob.  A rank can contribute up to T triangles to the global top-T, but with equally heavy row ranges it
+// contributes about T / world: the blob holds twice that (at least 4096), times 2^level — `level` (sc_params.
+// shard_cand_level) is raised by the caller after SC_ERETRY, i.e. when the merge found that a cut list could have
+// mattered (launch_merge_check); negative levels shrink the blob (tests).  Never more than T rounded up to 1024.
+size_t cand_cap(uint32_t T, uint32_t world, int level);
+size_t cand_blob_bytes(size_t cap);  // bytes per rank
+CandBlob cand_blob(void* blob, size_t cap);
 // this rank's selection (sel_ord / sel_key, n_max an upper bound of its length) -> blob
 void launch_cand_emit(const uint64_t* sel_ord, const uint32_t* sel_key, const uint2* kcol, const uint32_t* ei,
                       const uint32_t* ej, const SelectState* sel, const uint64_t* toff, uint64_t E, uint32_t n_max,
-                      const CandBlob& b, hipStream_t st);
+                      uint64_t want_requested, const CandBlob& b, hipStream_t st);
 // sums the gathered headers, arms `sel` for the merge select; host_out[0] <- T_eff (polled), host_out[1] <- triangles
 void launch_merge_prepare(const void* blobs, size_t blob_bytes, uint32_t world, uint32_t T, bool fast, const uint32_t* klb,
                           SelectState* sel, uint64_t* host_out, hipStream_t st);
-KeyView cand_view(const void* blobs, size_t blob_bytes, uint32_t world, uint32_t T);
+KeyView cand_view(const void* blobs, size_t blob_bytes, uint32_t world, size_t cap);
+// After the merge select: a rank whose list was cut sent everything above its local threshold key k_r; the merged
+// selection is exact iff the merged threshold k* lies strictly above k_r for every such rank (everything it did not send
+// is then below k*).  Otherwise *host_flag = 1 (pinned; 0 is written otherwise): the call must be repeated with bigger blobs.
+void launch_merge_check(const void* blobs, size_t blob_bytes, uint32_t world, const SelectState* sel, uint64_t* host_flag,
+                        hipStream_t st);
 // ranked order: sortkey ascending = (key desc, ordinal asc).  Implemented with rocPRIM (sc_sort.hip).
 size_t sort_temp_bytes(size_t n);
 void launch_sort_u64(const uint64_t* in, uint64_t* out, size_t n, void* temp, size_t temp_bytes, hipStream_t st);

@@ -111,6 +111,7 @@ struct sc_multi {
   const float *src = nullptr, *tgt = nullptr;
   int64_t npts = 0;
   sc_params params{};
+  int cand_level = 0;  // sticky: raised whenever a call came back with SC_ERETRY (candidate blobs too small)
   float* R = nullptr; float* t = nullptr; uint8_t* mask = nullptr;
   std::vector<uint32_t> hist_host;  // loopback all-reduce
 };
@@ -180,6 +181,7 @@ int run_rank(sc_multi* M, int r) {
   const int64_t n = M->npts;
   sc_params p = M->params;
   p.shard_rank = r; p.shard_world = G;
+  p.shard_cand_level = M->cand_level;
   if (p.shard_block == 0) p.shard_block = 1024;
   int rc = SC_OK;
   sc_shard_plan plan; plan.size = sizeof plan;
@@ -239,6 +241,7 @@ int run_rank(sc_multi* M, int r) {
   phase([&]() -> int {
     memset(&rk.stats, 0, sizeof rk.stats); rk.stats.size = sizeof rk.stats;
     fin = sc_finalize_gathered_device(rk.ctx, rk.keys, G, rk.Rt, static_cast<uint8_t*>(rk.mask), &rk.stats);
+    if (fin == SC_ERETRY) { MHIP(rk, hipStreamSynchronize(rk.stream)); return SC_OK; }  // every rank alike: the caller re-runs
     if (fin != SC_OK && fin != SC_ENOHYP) return fail_from_ctx(fin);
     if (r == 0) {  // rank 0 returns the outputs (every rank holds the same ones)
       float Rt[12];
@@ -356,16 +359,24 @@ int sc_register_multi(sc_multi* M, const float* src, const float* tgt, int64_t n
   if (p->size != sizeof(sc_params) || p->shard_world != 1) return SC_EINVAL;  // the sharding is this call's business
   if (!M->workers) return sc_register(M->ranks[0].ctx, src, tgt, n, p, R, t, mask, stats);  // no RCCL call at all
   M->src = src; M->tgt = tgt; M->npts = n; M->params = *p; M->R = R; M->t = t; M->mask = mask;
-  M->bar.worst = SC_OK;
-  {
-    std::lock_guard<std::mutex> lk(M->m);
-    M->running = M->n;
-    M->job++;
-  }
-  M->cv_go.notify_all();
-  {
-    std::unique_lock<std::mutex> lk(M->m);
-    M->cv_done.wait(lk, [&] { return M->running == 0; });
+  for (int attempt = 0;; attempt++) {
+    M->bar.worst = SC_OK;
+    {
+      std::lock_guard<std::mutex> lk(M->m);
+      M->running = M->n;
+      M->job++;
+    }
+    M->cv_go.notify_all();
+    {
+      std::unique_lock<std::mutex> lk(M->m);
+      M->cv_done.wait(lk, [&] { return M->running == 0; });
+    }
+    // SC_ERETRY: a candidate blob was too small for this input.  Every rank sees the same blobs and reports it together;
+    // bigger blobs from now on (sticky), and the call runs again.
+    bool retry = true;
+    for (int r = 0; r < M->n; r++) retry = retry && M->ranks[r].status == SC_ERETRY;
+    if (!retry || attempt >= 16) break;
+    M->cand_level++;
   }
   int rc = SC_OK;
   for (int r = 0; r < M->n; r++) {

@@ -1415,7 +1415,8 @@ __global__ __launch_bounds__(256) void cand_emit_kernel(const uint64_t* __restri
                                                         const SelectState* __restrict__ sel,
                                                         const uint64_t* __restrict__ toff, uint64_t E,
                                                         uint64_t* __restrict__ hdr, uint32_t* __restrict__ keys,
-                                                        uint4* __restrict__ recs, uint64_t cap) {
+                                                        uint4* __restrict__ recs, uint64_t cap,
+                                                        uint64_t want_requested) {
   const uint64_t n_sent = sel->want < cap ? sel->want : cap;  // the select clamps want to what its window held
   if (blockIdx.x == 0 && threadIdx.x == 0) {
     hdr[0] = toff[E];      // triangles this rank enumerated
@@ -1423,6 +1424,9 @@ __global__ __launch_bounds__(256) void cand_emit_kernel(const uint64_t* __restri
     hdr[2] = sel->kstar;
     hdr[3] = sel->kmin;    // a range containing every key sent
     hdr[4] = sel->kmax;
+    // cut: the rank has more triangles than it was allowed to select, and the select window held that many — so keys at
+    // or below its threshold stayed behind (had the window held fewer, everything that can matter was sent)
+    hdr[5] = (toff[E] > want_requested && sel->want >= want_requested) ? 1ull : 0ull;
   }
   const uint64_t p = (uint64_t)blockIdx.x * 256 + threadIdx.x;
   if (p >= n_sent) return;
@@ -1432,14 +1436,24 @@ __global__ __launch_bounds__(256) void cand_emit_kernel(const uint64_t* __restri
   recs[p] = make_uint4(ei[ke.y], ej[ke.y], ke.x, key);
 }
 
-size_t cand_cap(uint32_t T) { return ((size_t)T + 1023) / 1024 * 1024; }
-size_t cand_blob_bytes(uint32_t T) { return CAND_HDR_WORDS * 8 + cand_cap(T) * (4 + 16); }
+size_t cand_cap(uint32_t T, uint32_t world, int level) {
+  const size_t full = ((size_t)T + 1023) / 1024 * 1024;
+  if (world <= 1) return full;
+  size_t base = 2 * (((size_t)T + world - 1) / world);
+  if (base < 4096) base = 4096;
+  if (level > 0) base = level >= 30 ? full : base << level;
+  if (level < 0) base = base >> (-level > 30 ? 30 : -level);
+  size_t c = (base + 1023) / 1024 * 1024;
+  if (c < 1024) c = 1024;
+  return c < full ? c : full;
+}
+size_t cand_blob_bytes(size_t cap) { return CAND_HDR_WORDS * 8 + cap * (4 + 16); }
 
-CandBlob cand_blob(void* blob, uint32_t T) {
+CandBlob cand_blob(void* blob, size_t cap) {
   CandBlob b;
   unsigned char* p = static_cast<unsigned char*>(blob);
   b.hdr = reinterpret_cast<uint64_t*>(p);
-  b.cap = cand_cap(T);
+  b.cap = cap;
   b.keys = reinterpret_cast<uint32_t*>(p + CAND_HDR_WORDS * 8);
   b.recs = reinterpret_cast<uint4*>(p + CAND_HDR_WORDS * 8 + b.cap * 4);
   return b;
@@ -1447,10 +1461,29 @@ CandBlob cand_blob(void* blob, uint32_t T) {
 
 void launch_cand_emit(const uint64_t* sel_ord, const uint32_t* sel_key, const uint2* kcol, const uint32_t* ei,
                       const uint32_t* ej, const SelectState* sel, const uint64_t* toff, uint64_t E, uint32_t n_max,
-                      const CandBlob& b, hipStream_t st) {
+                      uint64_t want_requested, const CandBlob& b, hipStream_t st) {
   const unsigned blocks = n_max ? (n_max + 255) / 256 : 1;
   hipLaunchKernelGGL(cand_emit_kernel, dim3(blocks), dim3(256), 0, st, sel_ord, sel_key, kcol, ei, ej, sel, toff, E, b.hdr,
-                     b.keys, b.recs, (uint64_t)b.cap);
+                     b.keys, b.recs, (uint64_t)b.cap, want_requested);
+}
+
+__global__ __launch_bounds__(64) void merge_check_kernel(const uint64_t* __restrict__ blobs, uint64_t blob_words,
+                                                         uint32_t world, const SelectState* __restrict__ sel,
+                                                         uint64_t* __restrict__ host_flag) {
+  bool bad = false;
+  const uint32_t kstar = sel->kstar;
+  for (uint32_t q = threadIdx.x; q < world; q += 64) {
+    const uint64_t* h = blobs + (uint64_t)q * blob_words;
+    if (h[5] != 0 && !(kstar > (uint32_t)h[2])) bad = true;  // a cut list whose threshold the merged one does not clear
+  }
+  const uint64_t any = __ballot(bad);
+  if (threadIdx.x == 0) publish_host(host_flag, any ? 1ull : 0ull);
+}
+
+void launch_merge_check(const void* blobs, size_t blob_bytes, uint32_t world, const SelectState* sel, uint64_t* host_flag,
+                        hipStream_t st) {
+  hipLaunchKernelGGL(merge_check_kernel, dim3(1), dim3(64), 0, st, static_cast<const uint64_t*>(blobs),
+                     (uint64_t)(blob_bytes / 8), world, sel, host_flag);
 }
 
 // One wave: adds up the headers of the `world` gathered blobs and arms the select state for the merge.
@@ -1495,11 +1528,11 @@ void launch_merge_prepare(const void* blobs, size_t blob_bytes, uint32_t world, 
                      (uint64_t)(blob_bytes / 8), world, T, fast ? 1 : 0, klb, sel, host_out);
 }
 
-KeyView cand_view(const void* blobs, size_t blob_bytes, uint32_t world, uint32_t T) {
+KeyView cand_view(const void* blobs, size_t blob_bytes, uint32_t world, size_t cap) {
   const unsigned char* p = static_cast<const unsigned char*>(blobs);
   KeyView v;
   v.base = reinterpret_cast<const uint32_t*>(p + CAND_HDR_WORDS * 8);
-  v.seg_len = cand_cap(T);
+  v.seg_len = cap;
   v.M = (uint64_t)world * v.seg_len;
   v.seg_stride = blob_bytes / 4;
   v.valid = reinterpret_cast<const uint64_t*>(p) + 1;  // hdr[1] = entries sent

@@ -126,8 +126,9 @@ class ShardedStep:
 
     def __init__(self, pkg, reg, n: int, params, rank: int, world: int, device):
         import torch
-        self.pkg, self.reg, self.n, self.p, self.rank, self.world = pkg, reg, n, params, rank, world
-        plan = pkg.shard_plan(params, n)
+        self.pkg, self.reg, self.n, self.p, self.rank, self.world, self.device = pkg, reg, n, params, rank, world, device
+        self.level = int(params.shard_cand_level)   # sticky: raised after SC_ERETRY (candidate blobs too small)
+        plan = pkg.shard_plan(self._with_level(params), n)
         self.plan = plan
         self.bits = torch.zeros(plan.bits_bytes_total // 8, dtype=torch.int64, device=device)
         self.hist = torch.zeros(pkg.SC_HIST_WORDS, dtype=torch.int32, device=device)
@@ -142,8 +143,25 @@ class ShardedStep:
         return {"bit_rows": (w - 1) * int(self.plan.bits_bytes_per_rank), "histogram": 1024 if w > 1 else 0,
                 "candidates": (w - 1) * int(self.plan.cand_bytes_per_rank), "key_pairs": 16 * (w - 1)}
 
+    def _with_level(self, p):
+        q = type(p).from_buffer_copy(p)
+        q.shard_cand_level = self.level
+        return q
+
     def step(self, d_src: int, d_tgt: int, params=None):
-        p = params or self.p
+        """One call of the path.  SC_ERETRY (a candidate blob was too small; every rank sees the same blobs, so every rank
+        gets it together) raises the blob level for good, reallocates the blobs and runs the call again."""
+        import torch
+        for _ in range(20):
+            rc, st = self._step_once(d_src, d_tgt, self._with_level(params or self.p))
+            if rc != self.pkg.SC_ERETRY:
+                return rc, st
+            self.level += 1
+            self.plan = self.pkg.shard_plan(self._with_level(self.p), self.n)
+            self.cand = torch.zeros(self.world * self.plan.cand_bytes_per_rank // 8, dtype=torch.int64, device=self.device)
+        return rc, st
+
+    def _step_once(self, d_src: int, d_tgt: int, p):
         r, w, reg = self.rank, self.world, self.reg
         reg.shard_compat_device(d_src, d_tgt, self.n, p, self.bits.data_ptr())
         allgather_inplace(self.bits, r, w)

@@ -672,7 +672,20 @@ def test_refine_matches_oracle_and_improves(pkg, O, reg, name):
 # ---------------------------------------------------------------------------------------------------------
 # stages A and B sharded: the phase API, every "rank" a context of its own on this one GPU
 # ---------------------------------------------------------------------------------------------------------
-def _run_sharded_ab(pkg, n, kw, d_src, d_tgt, world, flags=0, regs=None, block=256):
+def _run_sharded_ab(pkg, n, kw, d_src, d_tgt, world, flags=0, regs=None, block=256, level=0, levels_out=None):
+    """(see _run_sharded_ab_once)  SC_ERETRY — a candidate blob was too small — raises the level and runs again, as a
+    caller must; levels_out (a list) receives the level the call ended with."""
+    for _ in range(24):
+        out = _run_sharded_ab_once(pkg, n, dict(kw, shard_cand_level=level), d_src, d_tgt, world, flags, regs, block)
+        if out[0] != pkg.SC_ERETRY:
+            if levels_out is not None:
+                levels_out.append(level)
+            return out
+        level += 1
+    raise AssertionError("SC_ERETRY did not end")
+
+
+def _run_sharded_ab_once(pkg, n, kw, d_src, d_tgt, world, flags=0, regs=None, block=256):
     """The whole sharded call for `world` ranks on one GPU.  The ranks share the exchange buffers, which is exactly what
     the collectives deliver: the in-place all-gather of the bit rows and of the candidate blobs are no-ops here, the
     histogram all-reduce is a host-side sum.  Returns (rc, stats, Rt, mask, per-rank enumerated)."""
@@ -715,10 +728,13 @@ def _run_sharded_ab(pkg, n, kw, d_src, d_tgt, world, flags=0, regs=None, block=2
             torch.cuda.synchronize()
             out.append((rc, st, d_Rt.cpu().numpy().copy(), d_mask.cpu().numpy().copy()))
         for o in out[1:]:                                          # every rank ends with the same answer
-            assert o[0] == out[0][0] and o[2].tobytes() == out[0][2].tobytes() and np.array_equal(o[3], out[0][3])
-            assert o[1]["best_rank"] == out[0][1]["best_rank"]
+            assert o[0] == out[0][0]
+            if o[0] != pkg.SC_ERETRY:
+                assert o[2].tobytes() == out[0][2].tobytes() and np.array_equal(o[3], out[0][3])
+                assert o[1]["best_rank"] == out[0][1]["best_rank"]
         rc, st, Rt, mask = out[0]
-        assert scored == st["tri_kept"]
+        if rc != pkg.SC_ERETRY:
+            assert scored == st["tri_kept"]
         return rc, st, Rt, mask, hdr
     finally:
         if own:
@@ -919,3 +935,27 @@ def test_sharded_A_and_B_beyond_the_one_block_scans(pkg, O):
             assert (st["edges"], st["best_rank"], st["best_count"], st["tri_kept"]) == (ref["edges"], ref["best_rank"], ref["best_count"], ref["t_eff"])
             assert np.array_equal(mask, ref["mask"])
             assert Rt.tobytes() == np.concatenate([ref["R"].ravel(), ref["t"]]).astype(np.float32).tobytes()
+
+
+def test_sharded_candidate_blobs_too_small_are_detected_and_retried(pkg, O):
+    """A candidate blob holds max(2T/world, 4096) << shard_cand_level entries.  Started far too small (negative level:
+    1024 entries for T = 10 000 over 2 and 3 ranks), the merge must notice that a cut list could have mattered and every
+    rank must report SC_ERETRY together; after enough retries the result is the unsharded one.  The native multi-device
+    entry retries by itself."""
+    import torch
+    cfg, scene = pkg.synth.make_config_scene("C1")
+    kw = cfg.params()
+    ref = O.register(scene.src, scene.tgt, threads=8, **kw)
+    dev = torch.device("cuda:0")
+    d_src = torch.from_numpy(scene.src).to(dev); d_tgt = torch.from_numpy(scene.tgt).to(dev)
+    for world in (2, 3):
+        levels = []
+        rc, st, Rt, mask, hdr = _run_sharded_ab(pkg, cfg.n, kw, d_src, d_tgt, world, level=-4, levels_out=levels)
+        assert levels[0] > -4                                         # at least one SC_ERETRY happened
+        assert rc == 0 and (st["best_rank"], st["best_count"], st["tri_kept"]) == (ref["best_rank"], ref["best_count"], ref["t_eff"])
+        assert np.array_equal(mask, ref["mask"])
+        assert Rt.tobytes() == np.concatenate([ref["R"].ravel(), ref["t"]]).astype(np.float32).tobytes()
+    p_small = pkg.make_params(shard_cand_level=0, **dict(kw, max_triangles=40000))   # default level on a bigger T
+    plan = pkg.shard_plan(pkg.make_params(shard_world=8, **dict(kw, max_triangles=40000)), cfg.n)
+    assert plan.cand_bytes_per_rank == 256 + 20 * 10240                # max(2 * 40000 / 8, 4096) -> 10 240 entries
+    assert pkg.shard_plan(p_small, cfg.n).cand_bytes_per_rank == 256 + 20 * 40960    # world 1: T rounded up

@@ -132,7 +132,7 @@ def _rank_rows(n, world):
     return [(cuts[r], cuts[r + 1]) for r in range(world)]
 
 
-def _worker_ab(rank, world, port, out_dir):
+def _worker_ab(rank, world, port, out_dir, level):
     import sys
     import torch
     import torch.distributed as dist
@@ -144,6 +144,8 @@ def _worker_ab(rank, world, port, out_dir):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     cfg, sc = pkg.synth.make_config_scene("C0")
     kw = cfg.params()
+    if level < 0:
+        kw["max_triangles"] = 6000                      # enough for 1024-entry blobs to be too small
     T = kw["max_triangles"]
     p = pkg.make_params(shard_rank=rank, shard_world=world, **kw)
     plan = pkg.shard_plan(p, cfg.n)                     # needs no GPU
@@ -156,53 +158,76 @@ def _worker_ab(rank, world, port, out_dir):
     view[r0:r1] = bits[r0:r1]
     pkg.shard.allgather_inplace(buf, rank, world)
     assert np.array_equal(view[:cfg.n], bits)
-    # phase 3: own top-T of a contiguous row range, as a blob in the library's layout
     tri_all, key_all, total = O.triangles(S, bits, deg, 10 ** 9, 0)       # every triangle, ranked
     lo, hi = _rank_rows(cfg.n, world)[rank]
     own = np.nonzero((tri_all[:, 0] >= lo) & (tri_all[:, 0] < hi))[0]     # ranked order restricted to my rows
-    mine = own[:T]                                                        # my top-T ...
-    order = np.lexsort((tri_all[mine, 2], tri_all[mine, 1], tri_all[mine, 0]))
-    mine = mine[order]                                                    # ... in (i,j,k) order
-    blob_words = plan.cand_bytes_per_rank // 8
-    cand = torch.zeros(world * blob_words, dtype=torch.int64)
-    cap = (T + 1023) // 1024 * 1024
-    blob = cand.numpy().view(np.uint8)[rank * blob_words * 8:(rank + 1) * blob_words * 8]
-    hdr = blob[:256].view(np.uint64); keys = blob[256:256 + 4 * cap].view(np.uint32)
-    recs = blob[256 + 4 * cap:].view(np.uint32).reshape(cap, 4)
-    hdr[0], hdr[1] = len(own), len(mine)
-    keys[:len(mine)] = key_all[mine]
-    recs[:len(mine), :3] = tri_all[mine]; recs[:len(mine), 3] = key_all[mine]
-    pkg.shard.allgather_inplace(cand, rank, world)
-    # phase 4: merge — concatenation in rank order, exact threshold, ties to the lowest position
-    allk, allt = [], []
-    for r in range(world):
-        b = cand.numpy().view(np.uint8)[r * blob_words * 8:(r + 1) * blob_words * 8]
-        ns = int(b[:256].view(np.uint64)[1])
-        allk.append(b[256:256 + 4 * cap].view(np.uint32)[:ns].copy())
-        allt.append(b[256 + 4 * cap:].view(np.uint32).reshape(cap, 4)[:ns, :3].copy())
-    allk = np.concatenate(allk); allt = np.concatenate(allt)
-    assert np.all(np.lexsort((allt[:, 2], allt[:, 1], allt[:, 0])) == np.arange(len(allt)))   # global (i,j,k) order
-    want = min(T, len(allk))
-    kstar = np.sort(allk)[::-1][want - 1]
+    retries = 0
+    while True:
+        # phase 3: own best of a contiguous row range, as a blob in the library's layout; a blob holds `cap` entries
+        # (max(2T/world, 4096) << level, at most T rounded up): a list cut below T says so in its header
+        plan = pkg.shard_plan(pkg.make_params(shard_rank=rank, shard_world=world, shard_cand_level=level, **kw), cfg.n)
+        blob_words = plan.cand_bytes_per_rank // 8
+        cap = (plan.cand_bytes_per_rank - 256) // 20
+        assert cap % 1024 == 0 and cap <= (T + 1023) // 1024 * 1024
+        want_q = min(T, cap)
+        mine = own[:want_q]                                                   # my best ...
+        kstar_q = int(key_all[mine[-1]]) if len(mine) else 0
+        order = np.lexsort((tri_all[mine, 2], tri_all[mine, 1], tri_all[mine, 0]))
+        mine = mine[order]                                                    # ... in (i,j,k) order
+        cand = torch.zeros(world * blob_words, dtype=torch.int64)
+        blob = cand.numpy().view(np.uint8)[rank * blob_words * 8:(rank + 1) * blob_words * 8]
+        hdr = blob[:256].view(np.uint64); keys = blob[256:256 + 4 * cap].view(np.uint32)
+        recs = blob[256 + 4 * cap:].view(np.uint32).reshape(cap, 4)
+        hdr[0], hdr[1], hdr[2] = len(own), len(mine), kstar_q
+        hdr[5] = 1 if (want_q < T and len(own) > want_q) else 0
+        keys[:len(mine)] = key_all[mine]
+        recs[:len(mine), :3] = tri_all[mine]; recs[:len(mine), 3] = key_all[mine]
+        pkg.shard.allgather_inplace(cand, rank, world)
+        # phase 4: merge — concatenation in rank order, exact threshold, ties to the lowest position
+        allk, allt, cut = [], [], []
+        for r in range(world):
+            b = cand.numpy().view(np.uint8)[r * blob_words * 8:(r + 1) * blob_words * 8]
+            h = b[:256].view(np.uint64)
+            ns = int(h[1])
+            if h[5]:
+                cut.append(int(h[2]))
+            allk.append(b[256:256 + 4 * cap].view(np.uint32)[:ns].copy())
+            allt.append(b[256 + 4 * cap:].view(np.uint32).reshape(cap, 4)[:ns, :3].copy())
+        allk = np.concatenate(allk); allt = np.concatenate(allt)
+        assert np.all(np.lexsort((allt[:, 2], allt[:, 1], allt[:, 0])) == np.arange(len(allt)))   # global (i,j,k) order
+        want = min(T, len(allk))
+        kstar = int(np.sort(allk)[::-1][want - 1])
+        # the exactness check (merge_check_kernel): every cut list's threshold must lie strictly below the merged one —
+        # what such a rank kept back then cannot belong to the global top-T.  Same blobs everywhere: same verdict.
+        if all(kstar > kq for kq in cut):
+            break
+        level += 1; retries += 1
     take = np.nonzero(allk > kstar)[0]
     ties = np.nonzero(allk == kstar)[0][: want - len(take)]
     sel = np.sort(np.concatenate([take, ties]))
-    np.savez(os.path.join(out_dir, f"ab{rank}.npz"), tri=allt[sel], key=allk[sel], total=np.int64(total))
+    np.savez(os.path.join(out_dir, f"ab{rank}.npz"), tri=allt[sel], key=allk[sel], total=np.int64(total),
+             retries=np.int64(retries))
     dist.barrier()
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2, 3])
-def test_sharded_A_and_B_host_logic_gloo(pkg, O, tmp_path, world):
-    """Every rank ends with the same selection, and it is the restatement's top-T as a set (in (i,j,k) order)."""
+@pytest.mark.parametrize("world,level", [(2, 0), (3, 0), (2, -8)])
+def test_sharded_A_and_B_host_logic_gloo(pkg, O, tmp_path, world, level):
+    """Every rank ends with the same selection, and it is the restatement's top-T as a set (in (i,j,k) order) — also when
+    the candidate blobs start too small (level -8: 1024 entries) and the ranks have to agree on running again."""
     import torch.multiprocessing as mp
     port = _free_port()
-    mp.spawn(_worker_ab, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    mp.spawn(_worker_ab, args=(world, port, str(tmp_path), level), nprocs=world, join=True)
     cfg, sc = pkg.synth.make_config_scene("C0")
     kw = cfg.params()
+    if level < 0:
+        kw["max_triangles"] = 6000
     S, bits, deg = O.compat(sc.src, sc.tgt, kw["sigma"], kw["t_cmp"], kw["min_len"], kw["tau"])
-    tri, key, _ = O.triangles(S, bits, deg, kw["max_triangles"], 0)
+    tri, key, total = O.triangles(S, bits, deg, kw["max_triangles"], 0)
     order = np.lexsort((tri[:, 2], tri[:, 1], tri[:, 0]))
     outs = [np.load(tmp_path / f"ab{r}.npz") for r in range(world)]
     for o in outs:
         assert np.array_equal(o["tri"], tri[order]) and np.array_equal(o["key"], key[order])
+        assert int(o["retries"]) == int(outs[0]["retries"])
+    if level < 0:
+        assert total > 6000 and int(outs[0]["retries"]) >= 1

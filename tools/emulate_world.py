@@ -68,27 +68,38 @@ for world in args.worlds:
         regs = [pkg.Registrar(0) for _ in range(world)]
         for g in regs:
             g.set_stream(torch.cuda.current_stream().cuda_stream)
-        plan = pkg.shard_plan(ps[0], cfg.n)
-        d_bits = torch.zeros(plan.bits_bytes_total // 8, dtype=torch.int64, device=dev)
-        d_bits_rx = torch.zeros_like(d_bits)
-        d_hist = [torch.zeros(pkg.SC_HIST_WORDS, dtype=torch.int32, device=dev) for _ in range(world)]
-        d_cand = torch.zeros(world * plan.cand_bytes_per_rank // 8, dtype=torch.int64, device=dev)
-        d_cand_rx = torch.zeros_like(d_cand)
-        # fill pass: every rank, phase by phase (what the collectives would have delivered ends up in the shared buffers)
-        for r in range(world):
-            regs[r].shard_compat_device(d_src.data_ptr(), d_tgt.data_ptr(), cfg.n, ps[r], d_bits.data_ptr())
-        for r in range(world):
-            regs[r].shard_edges_device(d_hist[r].data_ptr())
-        torch.cuda.synchronize()
-        summed = torch.from_numpy((sum(h.cpu().numpy().view(np.uint32).astype(np.uint64) for h in d_hist)
-                                   & np.uint64(0xFFFFFFFF)).astype(np.uint32).view(np.int32)).to(dev)
-        for r in range(world):
-            d_hist[r].copy_(summed)
-            regs[r].shard_select_device(d_hist[r].data_ptr(), d_cand.data_ptr() + r * plan.cand_bytes_per_rank)
-        for r in range(world):
-            regs[r].shard_score_device(d_cand.data_ptr(), d_keys.data_ptr() + 16 * r)
-        torch.cuda.synchronize()
+        level = 0
+        while True:   # fill pass (repeated with bigger candidate blobs while the library answers SC_ERETRY)
+            ps = [pkg.make_params(shard_rank=r, shard_world=world, shard_block=block, flags=flags, shard_cand_level=level, **kw)
+                  for r in range(world)]
+            plan = pkg.shard_plan(ps[0], cfg.n)
+            d_bits = torch.zeros(plan.bits_bytes_total // 8, dtype=torch.int64, device=dev)
+            d_bits_rx = torch.zeros_like(d_bits)
+            d_hist = [torch.zeros(pkg.SC_HIST_WORDS, dtype=torch.int32, device=dev) for _ in range(world)]
+            d_cand = torch.zeros(world * plan.cand_bytes_per_rank // 8, dtype=torch.int64, device=dev)
+            d_cand_rx = torch.zeros_like(d_cand)
+            # every rank, phase by phase (what the collectives would have delivered ends up in the shared buffers)
+            for r in range(world):
+                regs[r].shard_compat_device(d_src.data_ptr(), d_tgt.data_ptr(), cfg.n, ps[r], d_bits.data_ptr())
+            for r in range(world):
+                regs[r].shard_edges_device(d_hist[r].data_ptr())
+            torch.cuda.synchronize()
+            summed = torch.from_numpy((sum(h.cpu().numpy().view(np.uint32).astype(np.uint64) for h in d_hist)
+                                       & np.uint64(0xFFFFFFFF)).astype(np.uint32).view(np.int32)).to(dev)
+            for r in range(world):
+                d_hist[r].copy_(summed)
+                regs[r].shard_select_device(d_hist[r].data_ptr(), d_cand.data_ptr() + r * plan.cand_bytes_per_rank)
+            for r in range(world):
+                regs[r].shard_score_device(d_cand.data_ptr(), d_keys.data_ptr() + 16 * r)
+            rcs = [regs[r].finalize_gathered_device(d_keys.data_ptr(), world, d_Rt.data_ptr(), d_mask.data_ptr())[0]
+                   for r in range(world)]
+            torch.cuda.synchronize()
+            if all(rc != pkg.SC_ERETRY for rc in rcs):
+                break
+            assert all(rc == pkg.SC_ERETRY for rc in rcs)
+            level += 1
         hdr = d_cand.cpu().numpy().view(np.uint64).reshape(world, -1)[:, :2].copy()
+        cap = (plan.cand_bytes_per_rank - 256) // 20
         rx_bits = (world - 1) * plan.bits_bytes_per_rank // 8       # int64 words a rank receives
         rx_cand_words = plan.cand_bytes_per_rank // 8
 
@@ -115,7 +126,7 @@ for world in args.worlds:
             torch.cuda.synchronize(); times.append((time.perf_counter() - t0) / K)
         sent = hdr[:, 1].astype(np.int64)
         coll = (f"bit rows {plan.bits_bytes_per_rank/1e6:.2f} MB/rank (rx {(world-1)*plan.bits_bytes_per_rank/1e6:.1f} MB), hist 1 KiB, "
-                f"candidates sent {sent.min()}..{sent.max()} of cap {T_total} (x20 B; blob {plan.cand_bytes_per_rank/1e6:.2f} MB), key pairs 16 B; "
+                f"candidates sent {sent.min()}..{sent.max()} of cap {cap} at level {level} (x20 B; blob {plan.cand_bytes_per_rank/1e6:.2f} MB), key pairs 16 B; "
                 f"enumerated per rank {hdr[:,0].min()}..{hdr[:,0].max()}")
         for g in regs:
             g.close()
