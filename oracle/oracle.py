@@ -127,7 +127,7 @@ def score(src: np.ndarray, tgt: np.ndarray, Rt: np.ndarray, tau: float, threads:
     n = src.shape[0]
     Rt = np.ascontiguousarray(Rt, dtype=np.float32)
     cnt = np.zeros(Rt.shape[0], dtype=np.uint32)
-    tau2 = np.float32(np.float64(tau) * np.float64(tau))
+    tau2 = np.float32(np.float64(np.float32(tau)) * np.float64(np.float32(tau)))  # tau is an fp32 parameter (sc_params.tau): round first
     ps, qs = soa(src), soa(tgt)
     if score_mode:
         inv = np.zeros(2, dtype=np.float32)
@@ -149,7 +149,7 @@ def mask(src: np.ndarray, tgt: np.ndarray, Rt12: np.ndarray, tau: float) -> np.n
     n = src.shape[0]
     Rt12 = np.ascontiguousarray(Rt12, dtype=np.float32)
     out = np.zeros(n, dtype=np.uint8)
-    tau2 = np.float32(np.float64(tau) * np.float64(tau))
+    tau2 = np.float32(np.float64(np.float32(tau)) * np.float64(np.float32(tau)))  # tau is an fp32 parameter (sc_params.tau): round first
     ps, qs = soa(src), soa(tgt)
     lib().so_mask(_p(ps, C.c_float), _p(qs, C.c_float), n, _p(Rt12, C.c_float), tau2, _p(out, C.c_uint8))
     return out

@@ -46,7 +46,8 @@ struct sc_ctx {
   // workspace
   Buf in_src, in_tgt, planes, S, bits, deg, degp, wpre, ebase, edge_off, scan_tmp, ei, ej, es, ebi, ebj, tcnt, toff, wkey, kcol, ctl, events, blk_gt,
       blk_eq, blk_minmax, bits2, off_gt, off_eq, sel_ord, sel_key, sortkey, sorted, sort_tmp, tri, tri_rk, key_rk, rt, rt_aos, partial, cnt, key, rt12,
-      mask, refine_tmp, amx_pairs, strong, rowcost, cost_pre, lb_state, lb_ticket;
+      mask, refine_tmp, amx_pairs, strong, rowcost, cost_pre, lb_state, lb_ticket, fx_tile, fx_state, fx_mx;
+  int fx_parity = 0;  // which pair of fx_mx this call's staging kernel fills (the filter's tile kernel clears the other)
 
   // state of the last hypothesize call (consumed by finalize)
   int n = 0, ld = 0;
@@ -243,9 +244,14 @@ int stage_inputs(sc_ctx* c, const float* d_src, const float* d_tgt, int64_t n, c
   ENSURE(c, c->ctl, sizeof(ControlBlock));
   static_assert(sizeof(ControlBlock) % 4 == 0, "cleared word-wise");
   c->pinned[1] = 0;  // "non-finite input" flag lives in host-pinned memory: the kernel only touches it on bad data
+  if (!c->fx_mx.p) {  // coordinate maxima for C2's filter: two pairs that alternate from call to call
+    ENSURE(c, c->fx_mx, 16);
+    HIPCHK(c, hipMemsetAsync(c->fx_mx.p, 0, 16, c->stream));
+  }
+  c->fx_parity ^= 1;
   launch_stage_points(d_src, d_tgt, c->n, c->ld, p->layout, c->planes.as<float>(),
                       reinterpret_cast<uint32_t*>(&c->pinned[1]), c->ctl.as<uint32_t>(),
-                      (uint32_t)(sizeof(ControlBlock) / 4), c->stream);
+                      (uint32_t)(sizeof(ControlBlock) / 4), c->fx_mx.as<uint32_t>() + 2 * c->fx_parity, c->stream);
   return SC_OK;
 }
 
@@ -732,6 +738,10 @@ int sc_set_debug(sc_ctx* c, const sc_debug* d) {
   t.compact_fused = d->compact_fused != 0;
   t.rows_unfused = d->rows_unfused != 0;
   t.score_scalar = d->score_scalar != 0;
+  t.score_filter = d->score_filter <= 2 ? d->score_filter : 0u;
+  t.filter_splits = d->filter_splits;
+  t.filter_queue_cap = d->filter_queue_cap;
+  t.filter_lds_queue = d->filter_lds_queue;
   c->tn = t;
   return SC_OK;
 }
@@ -767,6 +777,30 @@ int hyp_begin(sc_ctx* c, const float* d_src, const float* d_tgt, int64_t n, cons
 
 int run_stage_c(sc_ctx* c, uint64_t* d_key, sc_stats* stats);
 
+// C2: the counts of this shard's hypotheses into c->partial; *rows: rows of c->partial the arg-max has to add up.
+// SC_SCORE_COUNT runs the matrix-pipe filter + the exact fix-up (sc_score.hip); the truncated scores, and
+// sc_debug.score_filter = 1, the plain fp32 kernel.
+int run_score(sc_ctx* c, const sc_params* p, const Shard& sh, uint32_t* rows) {
+  if (score_uses_filter(p->score_mode, c->tn, c->n, sh.ld_local)) {
+    const FilterPlan fp = filter_plan(c->n, sh.ld_local, c->tn);
+    *rows = fp.splits;
+    ENSURE(c, c->partial, (size_t)fp.splits * sh.ld_local * 4);
+    ENSURE(c, c->fx_tile, fp.tile_bytes);
+    ENSURE(c, c->fx_state, fp.state_bytes);
+    uint32_t* mx = c->fx_mx.as<uint32_t>();
+    launch_filter_tile(points_of(c), fp, mx + 2 * c->fx_parity, mx + 2 * (c->fx_parity ^ 1), c->fx_tile.p, c->fx_state.p, c->stream);
+    launch_score_filter(points_of(c), c->rt.as<float>(), sh, c->dv, fp, c->fx_tile.p, c->fx_state.p, c->partial.as<uint32_t>(),
+                        c->tn, c->stream);
+    return SC_OK;
+  }
+  const bool scalar = score_is_scalar(p->score_mode, c->tn);
+  *rows = score_chunks(c->n, sh.ld_local, scalar);
+  if (sh.ld_local) ENSURE(c, c->partial, (size_t)*rows * sh.ld_local * 4);
+  launch_score(points_of(c), c->rt.as<float>(), c->rt_aos.as<float>(), sh, c->dv, p->score_mode, c->partial.as<uint32_t>(),
+               c->tn, c->stream);
+  return SC_OK;
+}
+
 // phase 1, second half: prune with the (summed) histogram, enumerate, select, then stage C on this rank's share
 int hyp_end(sc_ctx* c, const uint32_t* d_hist, uint64_t* d_key, sc_stats* stats) {
   const sc_params* p = &c->params;
@@ -791,18 +825,17 @@ int run_stage_c(sc_ctx* c, uint64_t* d_key, sc_stats* stats) {
   c->sh = sh;
   if (sh.n_local) {
     ENSURE(c, c->rt, (size_t)12 * sh.ld_local * 4);
-    ENSURE(c, c->partial, (size_t)score_chunks(c->n, sh.ld_local, score_is_scalar(p->score_mode, c->tn)) * sh.ld_local * 4);
     ENSURE(c, c->cnt, (size_t)sh.ld_local * 4);
     const bool scalar = score_is_scalar(p->score_mode, c->tn);
     if (scalar) ENSURE(c, c->rt_aos, (size_t)12 * sh.ld_local * 4);
     launch_kabsch(points_of(c), tri_source_of(c), sh, c->rt.as<float>(), scalar ? c->rt_aos.as<float>() : nullptr, c->stream);
   }
   if ((rc = rec(c, 4))) return rc;
-  launch_score(points_of(c), c->rt.as<float>(), c->rt_aos.as<float>(), sh, c->dv, p->score_mode, c->partial.as<uint32_t>(),
-               c->tn, c->stream);
+  uint32_t score_rows = 0;
+  if ((rc = run_score(c, p, sh, &score_rows))) return rc;
   if ((rc = rec(c, 5))) return rc;
   ENSURE(c, c->amx_pairs, argmax_scratch_bytes(sh.ld_local));
-  launch_argmax(points_of(c), sh, c->partial.as<uint32_t>(), score_chunks(c->n, sh.ld_local, score_is_scalar(p->score_mode, c->tn)),
+  launch_argmax(points_of(c), sh, c->partial.as<uint32_t>(), score_rows,
                 c->T_eff ? c->sel_key.as<uint32_t>() : nullptr,
                 c->cnt.as<uint32_t>(), c->amx_pairs.as<uint64_t>(), &c->ctl.as<ControlBlock>()->amx_ticket, d_key,
                 c->stream);
@@ -1174,15 +1207,14 @@ int sc_score_host(sc_ctx* c, const float* src, const float* tgt, int64_t n, cons
   if (n_hyp) {
     ENSURE(c, c->rt_aos, (size_t)sh.ld_local * 48);  // (the scoring kernel may read whole 256-hypothesis groups)
     ENSURE(c, c->rt, (size_t)12 * sh.ld_local * 4);
-    ENSURE(c, c->partial, (size_t)score_chunks(c->n, sh.ld_local, score_is_scalar(p->score_mode, c->tn)) * sh.ld_local * 4);
     HIPCHK(c, hipMemcpyAsync(c->rt_aos.p, Rt, (size_t)n_hyp * 48, hipMemcpyHostToDevice, c->stream));
     launch_rt_to_soa(c->rt_aos.as<float>(), n_hyp, sh.ld_local, c->rt.as<float>(), c->stream);
   }
-  launch_score(points_of(c), c->rt.as<float>(), c->rt_aos.as<float>(), sh, c->dv, p->score_mode, c->partial.as<uint32_t>(),
-               c->tn, c->stream);
+  uint32_t score_rows = 0;
+  if ((rc = run_score(c, p, sh, &score_rows))) return rc;
   ENSURE(c, c->cnt, (size_t)(sh.ld_local ? sh.ld_local : 256) * 4);
   ENSURE(c, c->amx_pairs, argmax_scratch_bytes(sh.ld_local));
-  launch_argmax(points_of(c), sh, c->partial.as<uint32_t>(), score_chunks(c->n, sh.ld_local, score_is_scalar(p->score_mode, c->tn)),
+  launch_argmax(points_of(c), sh, c->partial.as<uint32_t>(), score_rows,
                 nullptr, c->cnt.as<uint32_t>(), c->amx_pairs.as<uint64_t>(),
                 &c->ctl.as<ControlBlock>()->amx_ticket, c->key.as<uint64_t>(),
                 c->stream);  // positions in Rt ARE the rank indices here: single-stage key

@@ -17,10 +17,10 @@ __global__ __launch_bounds__(256) void stage_points_kernel(const float* __restri
                                                            const float* __restrict__ tgt, int n, int ld,
                                                            int layout, float* __restrict__ planes,
                                                            uint32_t* __restrict__ bad_flag,
-                                                           uint32_t* __restrict__ zero, uint32_t zero_words) {
+                                                           uint32_t* __restrict__ zero, uint32_t zero_words,
+                                                           uint32_t* __restrict__ coord_max) {
   int m = blockIdx.x * 256 + threadIdx.x;
   for (uint32_t z = (uint32_t)m; z < zero_words; z += gridDim.x * 256) zero[z] = 0u;  // the per-call control block
-  if (m >= ld) return;
   float v[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   if (m < n) {
 #pragma unroll
@@ -34,6 +34,13 @@ __global__ __launch_bounds__(256) void stage_points_kernel(const float* __restri
     for (int c = 0; c < 6; c++) ok = ok && (fabsf(v[c]) < __builtin_inff());
     if (!ok) atomicOr(bad_flag, 1u);
   }
+  if (coord_max) {  // largest |coordinate| of either cloud (C2's filter scales by it); non-negative floats order as integers
+    float mp = fmaxf(fabsf(v[0]), fmaxf(fabsf(v[1]), fabsf(v[2]))), mq = fmaxf(fabsf(v[3]), fmaxf(fabsf(v[4]), fabsf(v[5])));
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { mp = fmaxf(mp, __shfl_xor(mp, o)); mq = fmaxf(mq, __shfl_xor(mq, o)); }
+    if ((threadIdx.x & 63) == 0) { atomicMax(&coord_max[0], __float_as_uint(mp)); atomicMax(&coord_max[1], __float_as_uint(mq)); }
+  }
+  if (m >= ld) return;
 #pragma unroll
   for (int c = 0; c < 6; c++) planes[(size_t)c * ld + m] = v[c];
   // AoS copy behind the planes (8 floats per correspondence, 32-byte aligned): stage A fetches a ROW operand with one
@@ -44,9 +51,9 @@ __global__ __launch_bounds__(256) void stage_points_kernel(const float* __restri
 }
 
 void launch_stage_points(const float* d_src, const float* d_tgt, int n, int ld, int layout, float* planes,
-                         uint32_t* bad_flag, uint32_t* zero, uint32_t zero_words, hipStream_t st) {
+                         uint32_t* bad_flag, uint32_t* zero, uint32_t zero_words, uint32_t* coord_max, hipStream_t st) {
   hipLaunchKernelGGL(stage_points_kernel, dim3((ld + 255) / 256), dim3(256), 0, st, d_src, d_tgt, n, ld, layout,
-                     planes, bad_flag, zero, zero_words);
+                     planes, bad_flag, zero, zero_words, coord_max);
 }
 
 // ------------------------------------------------------------------------------------------------

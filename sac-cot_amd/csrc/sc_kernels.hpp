@@ -35,6 +35,10 @@ struct Tuning {
   bool score_scalar = false;       // C2: count inliers with the lane = correspondence kernel (coefficients as scalar operands)
   uint64_t sample_edges = 0;       // edges of the pruning sample (0: automatic, ~5T/8)
   uint32_t score_split = 0;        // share (of 256) of the hypotheses scored on the matrix pipe
+  uint32_t score_filter = 0;       // C2, inlier count: 0 = matrix-pipe filter + exact fix-up from ~1.3e8 tests up, 1 = never, 2 = always
+  uint32_t filter_splits = 0;      // grid.y of the filter (0: by size)
+  uint32_t filter_queue_cap = 0;   // entries of the filter's global queue (0: by size; tests force overflows with a small one)
+  uint32_t filter_lds_queue = 0;   // entries of a wave's LDS queue, 64 .. 256 (0: 256)
   bool compat_one_phase = false;   // exact chain on every pair of an interior tile
   int compat_rows = 16;            // tile height of stage A: 16 or 64
   uint32_t compat_store_mode = 0;  // 0: by size; bit 0: force 4-byte S stores, bit 2: force 16-byte, bit 1: non-temporal
@@ -65,8 +69,9 @@ struct Points {
 // user layout (AoS n x 3 or SoA 3 x n) -> padded planes; sets *bad_flag != 0 when a value is not finite.
 // bad_flag may be host-pinned memory: it is only touched (atomicOr) when a non-finite value is found.
 // zero / zero_words: a buffer (the per-call control block) the kernel clears on the way — saves a memset launch.
+// coord_max (optional, 2 x u32): atomicMax of the bit patterns of max |src coordinate| and max |tgt coordinate|.
 void launch_stage_points(const float* d_src, const float* d_tgt, int n, int ld, int layout, float* planes,
-                         uint32_t* bad_flag, uint32_t* zero, uint32_t zero_words, hipStream_t st);
+                         uint32_t* bad_flag, uint32_t* zero, uint32_t zero_words, uint32_t* coord_max, hipStream_t st);
 
 // ---- stage A: compat_graph -----------------------------------------------------------------------
 // S: n x ld fp32 (row-major, symmetric, zero diagonal / pad columns); bits: n x (ld/64) u64;
@@ -346,6 +351,20 @@ uint32_t score_chunks(int n, uint32_t ld_local, bool scalar);
 // score_mode: 0 inlier count, 1 truncated squared residual, 2 truncated absolute residual (include/saccot.h)
 void launch_score(const Points& pts, const float* RtSoA, const float* RtAoS, const Shard& sh, const Derived& dv,
                   int score_mode, uint32_t* partial, const Tuning& tn, hipStream_t st);
+// C2, inlier count, by filter + exact fix-up (sc_score.hip): which calls use it, what it needs, and its two launches.
+// The tile (fp16 image of the correspondences) depends on the points only: launch_filter_tile runs once per call, any
+// time after launch_stage_points (whose atomicMax fills mx_cur); mx_cur / mx_next are two u32 pairs that alternate
+// from call to call (the tile kernel clears the next call's).  partial: fp.splits rows of ld_local counts.
+struct FilterPlan {
+  uint32_t windows, splits, n_waves, rows, queue_cap;
+  size_t tile_bytes, state_bytes;
+};
+bool score_uses_filter(int score_mode, const Tuning& tn, int n, uint32_t ld_local);
+FilterPlan filter_plan(int n, uint32_t ld_local, const Tuning& tn);
+void launch_filter_tile(const Points& pts, const FilterPlan& fp, const uint32_t* mx_cur, uint32_t* mx_next, void* tile,
+                        void* state, hipStream_t st);
+void launch_score_filter(const Points& pts, const float* RtSoA, const Shard& sh, const Derived& dv, const FilterPlan& fp,
+                         const void* tile, void* state, uint32_t* partial, const Tuning& tn, hipStream_t st);
 // Winner key pair key2[0..1] (written, not accumulated: no zeroing needed):
 //   key2[0] = max over hypotheses with count > 0 of  (count << 32) | second,   second = sel_key[g] (the triangle's
 //             ranking key) or, when sel_key == nullptr, 0xFFFFFFFF - g;

@@ -449,6 +449,383 @@ __global__ __launch_bounds__(256) void score_argmax_kernel(const uint32_t* __res
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// C2, inlier count, the default since r02: a matrix-pipe FILTER decides almost every test, an EXACT pass settles the rest.
+//
+// The count of hypothesis h is  #{m : d2(h, m) < tau^2}  with d2 the canonical fp32 chain (resid2, above).  Two kernels:
+//
+//   F  score_filter_kernel   evaluates  E' = 1024 s (R p + t - q)  for 8 hypotheses x 32 correspondences per
+//      v_mfma_f32_32x32x16_f16: rows = (hypothesis, component) — three per hypothesis, the fourth idle — columns =
+//      correspondences, K = 16 slots:
+//          k0..8   (rh, rh, rl) x (Ph, Pl, Ph) for x, y, z     r = 1024 R and P = s p, each split in two fp16 halves
+//          k9..14  -1024 x (Qh, Ql) of the row's own component  Q = s q
+//          C       1024 s t (fp32)
+//      (s: the power of two that puts the largest |coordinate| of the call into [256, 512).)  A lane then holds the three
+//      components of ONE test; x = |E'|^2 - LO costs three fmas, its sign bit is shifted into a register (v_alignbit) and
+//      counted once per 32 tests.  4.6 vector instructions per test instead of 17.
+//      What F computes is NOT the canonical chain, so it only decides tests that are clear:
+//          |E'| < 1024 (s tau - eta)  inlier        |E'| >= 1024 (s tau + eta)  outlier         else  UNDECIDED
+//      eta bounds the distance between the two evaluations (below).  Undecided tests (about 1 in 10^4) go to a queue.
+//   X  score_exact_kernel    evaluates the queued tests with the canonical chain and adds them to the counts (integer
+//      atomics: order-free).  It also recounts, exactly, every (wave, split) F gave up on: a hypothesis outside the
+//      filter's range (non-finite, |R_ij| > 1.5, huge t), tau too small or too large against the coordinate scale, a
+//      queue that overflowed.  F never guesses; whatever it cannot bound it hands over.
+//
+// eta.  With |P|, |Q| <= Pmax, Qmax < 512, |t| s <= Tmax and sum_k |R_ck| <= 4.5, per component and in units of E'/1024:
+//   fp16 splits   x = hi + lo + rem, |rem| <= 2^-22 |x| (or 2^-25 absolute below the fp16 normal range; inputs flushed
+//                 to zero there would add < 1e-4): dropped rl Pl plus the two remainders <= 3.01 * 2^-22 sum|R| Pmax,
+//                 and 2^-22 Qmax for q; the products themselves (11 x 11 bits) and C are exact in fp32;
+//   accumulation  <= 17 additions, each off by <= 2^-23 of S = sum|R| Pmax + Qmax + Tmax (truncation allowed for);
+//   the canonical chain itself: 4 roundings, <= 4 * 2^-24 S.
+//   Sum <= 12.5 * 2^-22 S per component, sqrt(3) of it for the vector: < 2^-17.5 S.   eta = 2^-16 (2.6 Pmax + Qmax +
+//   Tmax) >= 2^-16 S / 1.73 leaves a factor 1.7; LO and HI carry another 4e-6 for the roundings of the squares, of
+//   sqrt(tau^2) and of d2 itself.  The parity suite compares every count with the canonical kernel's.
+// ------------------------------------------------------------------------------------------------
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+constexpr float FX_RS = 1024.0f;
+constexpr int FX_UNIT = 256;    // correspondences per staging unit (8 MFMA steps); LDS holds two
+constexpr int FX_WIN = 1024;    // correspondences per window: 32 steps, one 32-bit shift register per test
+constexpr int FX_NQ = 256;      // global sub-queues (one ticket counter for ~6000 waves costs ~50 us of same-address atomics)
+constexpr int FX_QL = 256;      // LDS queue entries per wave
+constexpr int FX_WAVES = 4;     // waves per workgroup, 8 hypotheses each
+struct FilterInfo { float s, pmax, qmax, pad; };
+
+struct FilterState {  // device view of the state buffer (filter_plan().state_bytes)
+  FilterInfo* info;   // written by the tile kernel
+  uint32_t* qcount;   // FX_NQ ticket counters, one per 128-byte line
+  uint32_t* redo;     // bit (split * n_waves + wave): X recounts the wave's 8 hypotheses over the split exactly
+  uint2* queue;       // FX_NQ sub-queues of cap_sq entries {correspondence, wave << 5 | lane half << 4 | tests}
+  uint32_t cap_sq;
+  uint32_t zero_words;  // counters + bitmap, cleared by the tile kernel
+};
+static FilterState filter_state(void* state, const FilterPlan& fp) {
+  FilterState f;
+  unsigned char* p = static_cast<unsigned char*>(state);
+  f.info = reinterpret_cast<FilterInfo*>(p); p += 128;
+  f.qcount = reinterpret_cast<uint32_t*>(p); p += (size_t)FX_NQ * 128;
+  f.redo = reinterpret_cast<uint32_t*>(p);
+  const size_t bm_words = ((size_t)fp.splits * fp.n_waves + 31) / 32;
+  p += (bm_words * 4 + 127) / 128 * 128;
+  f.queue = reinterpret_cast<uint2*>(p);
+  f.cap_sq = fp.queue_cap / FX_NQ;
+  f.zero_words = (uint32_t)(FX_NQ * 32 + bm_words);
+  return f;
+}
+
+// The filter pays a tile kernel, an exact pass and a few microseconds of set-up per workgroup: below ~1.3e8 tests the
+// plain kernel is as fast or faster (C1, 2e7 tests: 9 us plain, 20 us filtered; C2, 2.5e8: 86 -> 73; C3, 4e9: 1200 -> 835).
+bool score_uses_filter(int score_mode, const Tuning& tn, int n, uint32_t ld_local) {
+  if (score_mode != 0 || tn.score_filter == 1 || tn.score_split != 0 || tn.score_scalar) return false;
+  if (ld_local == 0 || ld_local / 8 >= (1u << 27)) return false;
+  return tn.score_filter == 2 || (uint64_t)ld_local * (uint64_t)n >= (1ull << 27);
+}
+
+FilterPlan filter_plan(int n, uint32_t ld_local, const Tuning& tn) {
+  FilterPlan fp;
+  fp.windows = (uint32_t)((n + FX_WIN - 1) / FX_WIN);
+  fp.n_waves = ld_local / 8;
+  // grid.y: the windows are split so that the launch has several generations of workgroups (6 per CU are resident) and
+  // the last one is well filled
+  const uint32_t groups = ld_local / (8 * FX_WAVES), slots = 256 * 6;
+  uint32_t best = 1; double best_eff = 0.0;
+  const uint32_t smax = fp.windows < 8 ? fp.windows : 8;
+  for (uint32_t sp = 1; sp <= smax; sp++) {
+    const uint32_t per = (fp.windows + sp - 1) / sp, used = (fp.windows + per - 1) / per;  // splits that get windows
+    if (used != sp) continue;
+    const double blocks = (double)groups * sp, gens = (double)((uint64_t)(blocks + slots - 1) / slots);
+    const double eff = blocks / (gens * slots) * (1.0 - 0.02 * sp);  // every workgroup pays its set-up once
+    if (eff > best_eff + 1e-9) { best_eff = eff; best = sp; }
+  }
+  fp.splits = tn.filter_splits && tn.filter_splits <= fp.windows ? tn.filter_splits : best;
+  {  // a forced value must still give every split at least one window
+    const uint32_t per = (fp.windows + fp.splits - 1) / fp.splits;
+    fp.splits = (fp.windows + per - 1) / per;
+  }
+  fp.rows = fp.windows * FX_WIN + FX_UNIT;
+  uint64_t cap = (uint64_t)ld_local * (uint64_t)n / 512;  // ~20x what the BASELINE scenes queue
+  if (cap < (1u << 16)) cap = 1u << 16;
+  if (cap > (1u << 23)) cap = 1u << 23;
+  if (tn.filter_queue_cap) cap = tn.filter_queue_cap;
+  fp.queue_cap = (uint32_t)(cap / FX_NQ * FX_NQ);
+  if (fp.queue_cap < FX_NQ) fp.queue_cap = FX_NQ;
+  fp.tile_bytes = (size_t)fp.rows * 32;
+  const size_t bm_words = ((size_t)fp.splits * fp.n_waves + 31) / 32;
+  fp.state_bytes = 128 + (size_t)FX_NQ * 128 + (bm_words * 4 + 127) / 128 * 128 + (size_t)fp.queue_cap * 8;
+  return fp;
+}
+
+// The fp16 image of the correspondences, 32 bytes each, in the K order of the B operand:
+//   [Pxh Pxl Pxh  Pyh Pyl Pyh  Pzh Pzl | Pzh  Qxh Qxl  Qyh Qyl  Qzh Qzl  0];  rows [n, rows) are sentinels (far away).
+// mx_cur: max |p| and max |q| of the call (bit patterns; stage_points_kernel's atomicMax).  Also clears the filter's
+// counters and bitmap for this call and the maxima of the NEXT call (the two alternate), so nothing needs a memset.
+__global__ __launch_bounds__(256) void filter_tile_kernel(const float* __restrict__ planes, int n, int ld, uint32_t rows,
+                                                          const uint32_t* __restrict__ mx_cur, uint32_t* __restrict__ mx_next,
+                                                          uint4* __restrict__ tile, FilterInfo* __restrict__ info,
+                                                          uint32_t* __restrict__ zero, uint32_t zero_words) {
+  const uint32_t m = blockIdx.x * 256 + threadIdx.x;
+  for (uint32_t z = m; z < zero_words; z += gridDim.x * 256) zero[z] = 0u;
+  const float Pmax = __uint_as_float(mx_cur[0]), Qmax = __uint_as_float(mx_cur[1]), mxv = fmaxf(Pmax, Qmax);
+  const int e = (int)((__float_as_uint(mxv) >> 23) & 255u) - 127;  // mxv in [2^e, 2^(e+1))
+  int k = 8 - e;
+  k = k > 100 ? 100 : (k < -100 ? -100 : k);
+  const float s = __uint_as_float((uint32_t)(k + 127) << 23);
+  if (m == 0) { *info = FilterInfo{s, Pmax, Qmax, 0.f}; mx_next[0] = 0u; mx_next[1] = 0u; }
+  if (m >= rows) return;
+  _Float16 hi[6], lo[6];
+#pragma unroll
+  for (int c = 0; c < 6; c++) {
+    const float X = m < (uint32_t)n ? planes[(size_t)c * ld + m] * s : (c < 3 ? 0.f : 32768.f);
+    hi[c] = (_Float16)X;
+    lo[c] = (_Float16)(X - (float)hi[c]);
+  }
+  half8 f0 = {hi[0], lo[0], hi[0], hi[1], lo[1], hi[1], hi[2], lo[2]};
+  half8 f1 = {hi[2], hi[3], lo[3], hi[4], lo[4], hi[5], lo[5], (_Float16)0.f};
+  tile[(size_t)m * 2] = *reinterpret_cast<uint4*>(&f0);
+  tile[(size_t)m * 2 + 1] = *reinterpret_cast<uint4*>(&f1);
+}
+
+// F.  Workgroup = FX_WAVES waves; wave w of workgroup b owns hypotheses 8 (FX_WAVES b + w) .. + 7 and never talks to
+// the others except through the B tile: a unit of 256 correspondences (8 KiB) is brought into LDS by LDS-DMA while
+// the previous one is being used (two buffers, one barrier per unit).  blockIdx.y = split of the windows.
+// 80 VGPRs: six waves per SIMD cover the MFMA and LDS latencies, so nothing is double-buffered inside a wave.
+template <int WAVES>
+__global__ __launch_bounds__(64 * WAVES, 6) void score_filter_kernel(const float* __restrict__ Rt, uint32_t ldl, float tau2,
+                                                                     const uint4* __restrict__ tile,
+                                                                     const FilterInfo* __restrict__ info, uint32_t windows,
+                                                                     uint32_t splits, uint32_t n_waves,
+                                                                     uint32_t* __restrict__ cnt_out, uint2* __restrict__ gq,
+                                                                     uint32_t cap_sq, uint32_t* __restrict__ qcount,
+                                                                     uint32_t* __restrict__ redo_bits, uint32_t ql) {
+  __shared__ uint4 Bt[2][FX_UNIT * 2];
+  __shared__ float4 Ttab[WAVES][8];
+  __shared__ uint32_t queue[WAVES][FX_QL];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int col = lane & 31, hf = lane >> 5;
+  const uint32_t per = (windows + splits - 1) / splits, w0 = blockIdx.y * per, w1 = min(windows, w0 + per);
+  const uint32_t wid = blockIdx.x * WAVES + wave, h0 = wid * 8;
+  const uint32_t u0 = w0 * (FX_WIN / FX_UNIT), u1 = w1 * (FX_WIN / FX_UNIT);  // staging units of this workgroup
+  // The DMA is issued through asm so that hipcc does not count it: with the builtin the compiler waits vmcnt(0) before
+  // the NEXT ds_read (it cannot tell the two buffers apart), which exposes the whole DMA latency in every unit.  Our own
+  // wait sits before the barrier that publishes the buffer.  (Uncounted loads only make the compiler's own vmcnt(N)
+  // waits stronger: the counter retires in order.)
+  auto stage = [&](uint32_t u, int buf) {
+#pragma unroll
+    for (int i = 0; i < 8 / WAVES; i++) {
+      const uint4* gsrc = tile + (size_t)u * (FX_UNIT * 2) + 64 * WAVES * i + tid;
+      const uint32_t lds_dst = __builtin_amdgcn_readfirstlane(
+          (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)(&Bt[buf][64 * WAVES * i + wave * 64]));
+      unsigned keep;
+      asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                   : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+    }
+  };
+  if (u0 < u1) stage(u0, 0);
+  const FilterInfo fi = *info;
+  // A fragment: row r = (hypothesis r >> 2, component r & 3); lane half 0 holds k0..7, half 1 k8..15
+  half8 A;
+  {
+    const int r = lane & 31, hy = r >> 2, c = r & 3;
+    float x[3];
+#pragma unroll
+    for (int kk = 0; kk < 3; kk++) x[kk] = Rt[(size_t)(3 * (c < 3 ? c : 0) + kk) * ldl + h0 + hy];  // unconditional: one round trip
+    _Float16 rh[3], rl[3];
+#pragma unroll
+    for (int kk = 0; kk < 3; kk++) {
+      const float v = c < 3 ? x[kk] * FX_RS : 0.f;
+      rh[kk] = (_Float16)v;
+      rl[kk] = (_Float16)(v - (float)rh[kk]);
+    }
+    const _Float16 z = (_Float16)0.f, mone = (_Float16)(-FX_RS);
+    const half8 a0 = {rh[0], rh[0], rl[0], rh[1], rh[1], rl[1], rh[2], rh[2]};
+    const half8 a1 = {rl[2], c == 0 ? mone : z, c == 0 ? mone : z, c == 1 ? mone : z, c == 1 ? mone : z, c == 2 ? mone : z, c == 2 ? mone : z, z};
+    A = hf ? a1 : a0;
+  }
+  float tmax = 0.f;
+  bool wild = false;
+  if (lane < 8) {
+    const uint32_t h = h0 + lane;
+    float v[12];
+#pragma unroll
+    for (int c = 0; c < 12; c++) v[c] = Rt[(size_t)c * ldl + h];  // all twelve in flight together
+    float rmax = 0.f, nanp = 0.f;
+#pragma unroll
+    for (int c = 0; c < 9; c++) rmax = fmaxf(rmax, fabsf(v[c]));
+    tmax = fmaxf(fabsf(v[9]), fmaxf(fabsf(v[10]), fabsf(v[11])));
+#pragma unroll
+    for (int c = 0; c < 12; c++) nanp += v[c] * 0.f;  // NaN or infinity anywhere poisons the sum (fmaxf drops NaNs)
+    wild = !(rmax <= 1.5f) || !(tmax < 1e30f) || !(nanp == 0.f);
+    Ttab[wave][lane] = make_float4(v[9] * FX_RS * fi.s, v[10] * FX_RS * fi.s, v[11] * FX_RS * fi.s, 0.f);
+  }
+#pragma unroll
+  for (int o = 4; o > 0; o >>= 1) tmax = fmaxf(tmax, __shfl_xor(tmax, o));
+  tmax = __shfl(tmax, 0);
+  const bool any_wild = __ballot(wild) != 0;
+  const float s = fi.s, st = s * sqrt_rn(tau2);
+  const float Sb = 2.6f * (fi.pmax * s) + fi.qmax * s + tmax * s;
+  const float eta = Sb * (1.0f / 65536.0f);
+  // the filter's range (every comparison is false on a NaN): the shell must stay thin against tau, the scaled
+  // quantities inside what the error bound assumes
+  const bool fast = !any_wild && (eta <= 0.25f * st) && (st <= 4096.f) && (tmax * s <= 2048.f) && (fi.pmax * s < 512.f) &&
+                    (fi.qmax * s < 512.f);
+  const float lo_e = FX_RS * (st - eta), hi_e = FX_RS * (st + eta);
+  const float LO = lo_e * lo_e * (1.0f - 4e-6f), HI = hi_e * hi_e * (1.0f + 4e-6f);
+  const uint32_t W2b = fast ? __float_as_uint(HI - LO) : 0u;
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // Ttab: written and read by this wave only
+  f32x16 C;
+#pragma unroll
+  for (int jj = 0; jj < 4; jj++) {
+    const float4 T = Ttab[wave][2 * jj + hf];
+    C[4 * jj] = T.x; C[4 * jj + 1] = T.y; C[4 * jj + 2] = T.z; C[4 * jj + 3] = 0.f;
+  }
+  uint32_t total[4] = {0, 0, 0, 0};
+  uint32_t sr[4] = {0, 0, 0, 0};
+  uint32_t qn = 0;
+  bool redo = !fast;
+  uint32_t* q = queue[wave];
+  auto flush = [&]() {  // the wave's queue -> its global sub-queue (one ticket)
+    const uint32_t sq = wid % FX_NQ;
+    uint32_t base = 0;
+    if (lane == 0) base = atomicAdd(&qcount[sq * 32], qn);
+    base = __shfl(base, 0);
+    // a ticket that does not fit leaves no hole: the part of it inside the sub-queue is filled with empty entries (the
+    // exact pass reads min(count, capacity) of them), and the wave asks for a recount
+    const bool fits = base + qn <= cap_sq;
+    for (uint32_t i = lane; i < qn && base + i < cap_sq; i += 64)
+      gq[(size_t)sq * cap_sq + base + i] = fits ? make_uint2(q[i] >> 5, (wid << 5) | (q[i] & 31u)) : make_uint2(0u, 0u);
+    if (!fits) redo = true;
+    qn = 0;
+  };
+  for (uint32_t u = u0; u < u1; u++) {
+    const int buf = (int)((u - u0) & 1u);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's part of unit u has landed
+    __syncthreads();                                   // ... everybody's has, and the other buffer is free
+    if (u + 1 < u1) stage(u + 1, buf ^ 1);
+    if (!redo) {
+      const half8* Bc = reinterpret_cast<const half8*>(Bt[buf]) + col * 2 + hf;
+      half8 b = Bc[0];
+#pragma unroll 2
+      for (int g = 0; g < FX_UNIT / 32; g++) {
+        const f32x16 D = __builtin_amdgcn_mfma_f32_32x32x16_f16(A, b, C, 0, 0, 0);
+        if (g + 1 < FX_UNIT / 32) b = Bc[64 * (g + 1)];
+        float x[4];
+        uint32_t mn = 0xFFFFFFFFu;
+#pragma unroll
+        for (int jj = 0; jj < 4; jj++) {
+          const float v = fma_(D[4 * jj + 2], D[4 * jj + 2], fma_(D[4 * jj + 1], D[4 * jj + 1], fma_(D[4 * jj], D[4 * jj], -LO)));
+          x[jj] = v;
+          sr[jj] = __builtin_amdgcn_alignbit(sr[jj], __float_as_uint(v), 31);  // sign bit: |E'|^2 < LO, a certain inlier
+          mn = min(mn, __float_as_uint(v));
+        }
+        const uint64_t hm = __ballot(mn < W2b);  // as unsigned integers: 0 <= x < HI - LO, the undecided shell
+        if (__builtin_expect(hm != 0, 0)) {
+          const uint32_t k2 = (uint32_t)__popcll(hm);
+          if (qn + k2 <= ql) {
+            uint32_t bits = 0;
+#pragma unroll
+            for (int t = 0; t < 4; t++) bits |= (__float_as_uint(x[t]) < W2b) ? (1u << t) : 0u;
+            if (mn < W2b) q[qn + __popcll(hm & ((1ull << lane) - 1ull))] = ((u * FX_UNIT + 32 * g + col) << 5) | ((uint32_t)hf << 4) | bits;
+            qn += k2;
+          } else {
+            redo = true;  // more undecided tests than the queue holds: the exact pass takes the whole (wave, split)
+          }
+        }
+      }
+      if ((u + 1) % (FX_WIN / FX_UNIT) == 0) {  // window boundary: 32 tests per register
+#pragma unroll
+        for (int t = 0; t < 4; t++) { total[t] += (uint32_t)__popc(sr[t]); sr[t] = 0; }
+      }
+      if (qn > ql / 2) flush();
+    }
+  }
+  if (qn && !redo) flush();
+  if (redo && lane == 0) {
+    const size_t bit = (size_t)blockIdx.y * n_waves + wid;
+    atomicOr(&redo_bits[bit >> 5], 1u << (bit & 31));
+  }
+#pragma unroll
+  for (int t = 0; t < 4; t++) {
+    uint32_t c = total[t];
+#pragma unroll
+    for (int o = 16; o > 0; o >>= 1) c += __shfl_xor(c, o, 32);
+    if (col == 0) cnt_out[(size_t)blockIdx.y * ldl + h0 + 2 * t + hf] = redo ? 0u : c;
+  }
+}
+
+// X.  First the queued tests (one per thread; workgroup b serves sub-queue b % FX_NQ), then the (wave, split) pairs F
+// gave up on (one per workgroup at a time).  Everything here is the canonical chain; the counts are integers.
+__global__ __launch_bounds__(256) void score_exact_kernel(const float* __restrict__ planes, int n, int ld,
+                                                          const float* __restrict__ Rt, uint32_t ldl, float tau2,
+                                                          uint32_t windows, uint32_t splits, uint32_t n_waves,
+                                                          const uint2* __restrict__ gq, uint32_t cap_sq,
+                                                          const uint32_t* __restrict__ qcount,
+                                                          const uint32_t* __restrict__ redo_bits,
+                                                          uint32_t* __restrict__ cnt_out) {
+  const uint32_t per = (windows + splits - 1) / splits;
+  const uint32_t sq = blockIdx.x % FX_NQ, nq = min(qcount[sq * 32], cap_sq);
+  for (uint32_t i = (blockIdx.x / FX_NQ) * 256 + threadIdx.x; i < nq; i += (gridDim.x / FX_NQ) * 256) {
+    const uint2 e = gq[(size_t)sq * cap_sq + i];
+    const uint32_t m = e.x, wid = e.y >> 5, ehf = (e.y >> 4) & 1u, sp = (m / FX_WIN) / per;
+    const size_t bit = (size_t)sp * n_waves + wid;
+    if ((redo_bits[bit >> 5] >> (bit & 31)) & 1u) continue;  // recounted as a whole below
+    for (uint32_t bits = e.y & 0xFu; bits; bits &= bits - 1) {
+      const uint32_t h = wid * 8 + 2 * (uint32_t)(__ffs(bits) - 1) + ehf;
+      float M[12];
+#pragma unroll
+      for (int c = 0; c < 12; c++) M[c] = Rt[(size_t)c * ldl + h];
+      const float d2 = resid2(M, planes[m], planes[(size_t)ld + m], planes[2 * (size_t)ld + m], planes[3 * (size_t)ld + m],
+                              planes[4 * (size_t)ld + m], planes[5 * (size_t)ld + m]);
+      if (finite12(M) && d2 < tau2) atomicAdd(&cnt_out[(size_t)sp * ldl + h], 1u);
+    }
+  }
+  const size_t nbits = (size_t)splits * n_waves;
+  for (size_t w = blockIdx.x; w < (nbits + 31) / 32; w += gridDim.x) {
+    uint32_t word = redo_bits[w];
+    while (word) {
+      const size_t bit = w * 32 + (size_t)(__ffs(word) - 1);
+      word &= word - 1;
+      const uint32_t sp = (uint32_t)(bit / n_waves), wid = (uint32_t)(bit % n_waves);
+      const uint32_t h = wid * 8 + (threadIdx.x & 7);
+      float M[12];
+#pragma unroll
+      for (int c = 0; c < 12; c++) M[c] = Rt[(size_t)c * ldl + h];
+      const bool ok = finite12(M);
+      const uint32_t m1 = min((uint32_t)n, min(windows, (sp + 1) * per) * FX_WIN);
+      uint32_t cnt = 0;
+      for (uint32_t m = sp * per * FX_WIN + (threadIdx.x >> 3); m < m1; m += 32) {
+        const float d2 = resid2(M, planes[m], planes[(size_t)ld + m], planes[2 * (size_t)ld + m], planes[3 * (size_t)ld + m],
+                                planes[4 * (size_t)ld + m], planes[5 * (size_t)ld + m]);
+        cnt += (ok && d2 < tau2) ? 1u : 0u;
+      }
+      cnt += __shfl_xor(cnt, 8);
+      cnt += __shfl_xor(cnt, 16);
+      cnt += __shfl_xor(cnt, 32);
+      if ((threadIdx.x & 63) < 8 && cnt) atomicAdd(&cnt_out[(size_t)sp * ldl + h], cnt);
+    }
+  }
+}
+
+void launch_filter_tile(const Points& pts, const FilterPlan& fp, const uint32_t* mx_cur, uint32_t* mx_next, void* tile,
+                        void* state, hipStream_t st) {
+  const FilterState f = filter_state(state, fp);
+  hipLaunchKernelGGL(filter_tile_kernel, dim3((fp.rows + 255) / 256), dim3(256), 0, st, pts.planes, pts.n, pts.ld, fp.rows,
+                     mx_cur, mx_next, static_cast<uint4*>(tile), f.info, f.qcount, f.zero_words);
+}
+
+void launch_score_filter(const Points& pts, const float* RtSoA, const Shard& sh, const Derived& dv, const FilterPlan& fp,
+                         const void* tile, void* state, uint32_t* partial, const Tuning& tn, hipStream_t st) {
+  if (sh.n_local == 0) return;
+  const FilterState f = filter_state(state, fp);
+  uint32_t ql = tn.filter_lds_queue ? tn.filter_lds_queue : (uint32_t)FX_QL;
+  if (ql > (uint32_t)FX_QL) ql = FX_QL;
+  if (ql < 64) ql = 64;  // one step can add 64 entries
+  hipLaunchKernelGGL(score_filter_kernel<FX_WAVES>, dim3(sh.ld_local / (8 * FX_WAVES), fp.splits), dim3(64 * FX_WAVES), 0, st,
+                     RtSoA, sh.ld_local, dv.tau2, static_cast<const uint4*>(tile), f.info, fp.windows, fp.splits, fp.n_waves,
+                     partial, f.queue, f.cap_sq, f.qcount, f.redo, ql);
+  hipLaunchKernelGGL(score_exact_kernel, dim3(FX_NQ * 2), dim3(256), 0, st, pts.planes, pts.n, pts.ld, RtSoA, sh.ld_local,
+                     dv.tau2, fp.windows, fp.splits, fp.n_waves, f.queue, f.cap_sq, f.qcount, f.redo, partial);
+}
+
 // Tuning::score_split: share of the hypotheses (in 256ths) scored on the matrix pipe (default 0; experiments)
 void launch_score(const Points& pts, const float* RtSoA, const float* RtAoS, const Shard& sh, const Derived& dv,
                   int score_mode, uint32_t* partial, const Tuning& tn, hipStream_t st) {

@@ -959,3 +959,103 @@ def test_sharded_candidate_blobs_too_small_are_detected_and_retried(pkg, O):
     plan = pkg.shard_plan(pkg.make_params(shard_world=8, **dict(kw, max_triangles=40000)), cfg.n)
     assert plan.cand_bytes_per_rank == 256 + 20 * 10240                # max(2 * 40000 / 8, 4096) -> 10 240 entries
     assert pkg.shard_plan(p_small, cfg.n).cand_bytes_per_rank == 256 + 20 * 40960    # world 1: T rounded up
+
+
+# ---------------------------------------------------------------------------------------------------------
+# C2 by filter + exact fix-up (sc_score.hip): every count must be the canonical fp32 kernel's / the oracle's
+# ---------------------------------------------------------------------------------------------------------
+def _hyps_near_truth(O, sc, T, seed):
+    """T hypotheses: half from inlier triangles (many inliers, residuals spread around tau), half from random ones."""
+    n = len(sc.src)
+    rng = np.random.default_rng(seed)
+    inl = np.nonzero(sc.inlier)[0]
+    tri = np.sort(np.stack([rng.choice(inl if h % 2 else n, 3, replace=False) for h in range(T)]), axis=1).astype(np.uint32)
+    return O.kabsch3(sc.src, sc.tgt, tri)
+
+
+@pytest.mark.parametrize("n,T,scale", [(1300, 5000, 1.0), (5000, 2048, 1.0), (2049, 700, 1e4), (1000, 300, 1e-4), (40, 9, 1.0)])
+def test_score_filter_counts_bit_exact(pkg, O, n, T, scale):
+    """sc_debug.score_filter = 2 forces the matrix-pipe filter on inputs of any size: ragged windows and hypothesis
+    counts, coordinates of very different magnitudes (the filter rescales by a power of two), hypotheses the filter
+    refuses (non-finite entries, entries beyond 1.5, a huge translation) — all counted exactly as the oracle does."""
+    reg = pkg.Registrar(0)
+    sc = _scene(pkg, n, seed=n + 5)
+    src = (sc.src * scale).astype(np.float32); tgt = (sc.tgt * scale).astype(np.float32)
+    tau = np.float32(0.05 * scale)
+
+    class S: pass
+    s2 = S(); s2.src, s2.tgt, s2.inlier = src, tgt, sc.inlier
+    Rt0 = _hyps_near_truth(O, s2, T, seed=n)
+    if T > 100:
+        Rt0[7, 4] = np.nan; Rt0[11, 9] = np.inf; Rt0[13, :9] *= 3.0; Rt0[17, 10] = 1e9 * scale; Rt0[19, 0] = -np.inf
+    kw = _params(pkg, float(tau), T)
+    cnt0 = O.score(src, tgt, Rt0, kw["tau"])
+    for knobs in (dict(score_filter=2), dict(score_filter=2, filter_splits=1), dict(score_filter=2, filter_splits=8),
+                  dict(score_filter=1)):
+        reg.set_debug(**knobs)
+        cnt, key = reg.score(src, tgt, pkg.make_params(**kw), Rt0)
+        assert np.array_equal(cnt, cnt0), knobs
+        assert key == O.best_key(cnt0)
+    assert cnt0.max() > (5 if n < 100 else 20)
+    reg.close()
+
+
+def test_score_filter_gives_up_exactly(pkg, O):
+    """What the filter cannot bound it hands to the exact pass: (1) tau far below the resolution of the fp16 splits and
+    (2) tau beyond the scaled range — every wave asks for a recount; (3) correspondences whose residual under EVERY
+    hypothesis sits within 1e-5 of tau — every test is undecided, the waves' queues overflow; (4) a global queue of 256
+    entries — the flushes fail.  Counts equal the oracle's each time."""
+    reg = pkg.Registrar(0)
+    n, T = 3000, 1024
+    sc = _scene(pkg, n, seed=77)
+    Rt0 = _hyps_near_truth(O, sc, T, seed=3)
+    reg.set_debug(score_filter=2)
+    for tau in (1e-6, 60.0):
+        kw = _params(pkg, tau, T)
+        cnt, _ = reg.score(sc.src, sc.tgt, pkg.make_params(**kw), Rt0)
+        assert np.array_equal(cnt, O.score(sc.src, sc.tgt, Rt0, kw["tau"])), tau
+    # (3) q = p + tau * u (1 + 1e-5 r): identity-like hypotheses see |residual| = tau up to 1e-5
+    rng = np.random.default_rng(5)
+    p = rng.uniform(-1, 1, (n, 3)).astype(np.float32)
+    u = rng.normal(size=(n, 3)); u /= np.linalg.norm(u, axis=1, keepdims=True)
+    tau = 0.05
+    q = (p.astype(np.float64) + tau * u * (1 + 1e-5 * rng.uniform(-1, 1, (n, 1)))).astype(np.float32)
+    Rt1 = np.zeros((T, 12), dtype=np.float32); Rt1[:, [0, 4, 8]] = 1.0
+    Rt1[:, 9:] = rng.uniform(-1e-7, 1e-7, (T, 3)).astype(np.float32)
+    kw = _params(pkg, tau, T)
+    ref = O.score(p, q, Rt1, kw["tau"])
+    assert 0.2 * n < ref.mean() < 0.8 * n                       # the canonical chain decides them one way or the other
+    for knobs in (dict(score_filter=2), dict(score_filter=2, filter_lds_queue=64), dict(score_filter=2, filter_queue_cap=256)):
+        reg.set_debug(**knobs)
+        cnt, _ = reg.score(p, q, pkg.make_params(**kw), Rt1)
+        assert np.array_equal(cnt, ref), knobs
+    # (4) on an ordinary scene
+    reg.set_debug(score_filter=2, filter_queue_cap=256)
+    kw = _params(pkg, 0.05, T)
+    cnt, _ = reg.score(sc.src, sc.tgt, pkg.make_params(**kw), Rt0)
+    assert np.array_equal(cnt, O.score(sc.src, sc.tgt, Rt0, kw["tau"]))
+    reg.close()
+
+
+def test_register_with_the_filter_forced_small_and_sharded(pkg, O):
+    """Whole path with the filter on a call it would not choose by size (C1), and with stage C sharded over 3 ranks."""
+    import torch
+    reg = pkg.Registrar(0)
+    reg.set_debug(score_filter=2)
+    cfg, scene = pkg.synth.make_config_scene("C1")
+    _check_register(pkg, O, reg, scene, cfg.params())
+    kw = cfg.params()
+    ref = O.register(scene.src, scene.tgt, threads=8, **kw)
+    dev = torch.device("cuda:0")
+    d_src = torch.from_numpy(scene.src).to(dev); d_tgt = torch.from_numpy(scene.tgt).to(dev)
+    world = 3
+    d_keys = torch.zeros(2 * world, dtype=torch.int64, device=dev)
+    d_Rt = torch.zeros(12, dtype=torch.float32, device=dev); d_mask = torch.zeros(cfg.n, dtype=torch.uint8, device=dev)
+    for r in range(world):
+        p = pkg.make_params(shard_rank=r, shard_world=world, shard_block=256, **kw)
+        reg.hypothesize_device(d_src.data_ptr(), d_tgt.data_ptr(), cfg.n, p, d_keys.data_ptr() + 16 * r)
+    rc, st = reg.finalize_gathered_device(d_keys.data_ptr(), world, d_Rt.data_ptr(), d_mask.data_ptr())
+    torch.cuda.synchronize()
+    assert rc == 0 and (st["best_rank"], st["best_count"]) == (ref["best_rank"], ref["best_count"])
+    assert np.array_equal(d_mask.cpu().numpy(), ref["mask"])
+    reg.close()
