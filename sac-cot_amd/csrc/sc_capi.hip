@@ -780,17 +780,29 @@ int run_stage_c(sc_ctx* c, uint64_t* d_key, sc_stats* stats);
 // C2: the counts of this shard's hypotheses into c->partial; *rows: rows of c->partial the arg-max has to add up.
 // SC_SCORE_COUNT runs the matrix-pipe filter + the exact fix-up (sc_score.hip); the truncated scores, and
 // sc_debug.score_filter = 1, the plain fp32 kernel.
-int run_score(sc_ctx* c, const sc_params* p, const Shard& sh, uint32_t* rows) {
+// the filter's buffers for this shard, and the job that fills the tile / clears the state
+int filter_job(sc_ctx* c, const Shard& sh, FilterTileJob* job) {
+  const FilterPlan fp = filter_plan(c->n, sh.ld_local, c->tn);
+  ENSURE(c, c->fx_tile, fp.tile_bytes);
+  ENSURE(c, c->fx_state, fp.state_bytes);
+  uint32_t* mx = c->fx_mx.as<uint32_t>();
+  *job = filter_tile_job(fp, mx + 2 * c->fx_parity, mx + 2 * (c->fx_parity ^ 1), c->fx_tile.p, c->fx_state.p);
+  return SC_OK;
+}
+
+int run_score(sc_ctx* c, const sc_params* p, const Shard& sh, uint32_t* rows, bool tile_done) {
   if (score_uses_filter(p->score_mode, c->tn, c->n, sh.ld_local)) {
     const FilterPlan fp = filter_plan(c->n, sh.ld_local, c->tn);
     *rows = fp.splits;
     ENSURE(c, c->partial, (size_t)fp.splits * sh.ld_local * 4);
-    ENSURE(c, c->fx_tile, fp.tile_bytes);
-    ENSURE(c, c->fx_state, fp.state_bytes);
-    uint32_t* mx = c->fx_mx.as<uint32_t>();
-    launch_filter_tile(points_of(c), fp, mx + 2 * c->fx_parity, mx + 2 * (c->fx_parity ^ 1), c->fx_tile.p, c->fx_state.p, c->stream);
-    launch_score_filter(points_of(c), c->rt.as<float>(), sh, c->dv, fp, c->fx_tile.p, c->fx_state.p, c->partial.as<uint32_t>(),
-                        c->tn, c->stream);
+    if (!tile_done) {  // (the stage hook; the path builds the tile inside the Kabsch launch)
+      FilterTileJob job;
+      int rc = filter_job(c, sh, &job);
+      if (rc) return rc;
+      launch_filter_tile(points_of(c), job, c->stream);
+    }
+    launch_score_filter(points_of(c), c->rt.as<float>(), c->rt_aos.as<float>(), sh, c->dv, fp, c->fx_tile.p, c->fx_state.p,
+                        c->partial.as<uint32_t>(), c->tn, c->stream);
     return SC_OK;
   }
   const bool scalar = score_is_scalar(p->score_mode, c->tn);
@@ -826,13 +838,17 @@ int run_stage_c(sc_ctx* c, uint64_t* d_key, sc_stats* stats) {
   if (sh.n_local) {
     ENSURE(c, c->rt, (size_t)12 * sh.ld_local * 4);
     ENSURE(c, c->cnt, (size_t)sh.ld_local * 4);
-    const bool scalar = score_is_scalar(p->score_mode, c->tn);
-    if (scalar) ENSURE(c, c->rt_aos, (size_t)12 * sh.ld_local * 4);
-    launch_kabsch(points_of(c), tri_source_of(c), sh, c->rt.as<float>(), scalar ? c->rt_aos.as<float>() : nullptr, c->stream);
+    const bool filter = score_uses_filter(p->score_mode, c->tn, c->n, sh.ld_local);
+    const bool aos = filter || score_is_scalar(p->score_mode, c->tn);  // both read 12 consecutive floats per hypothesis
+    if (aos) ENSURE(c, c->rt_aos, (size_t)12 * sh.ld_local * 4);
+    FilterTileJob job;
+    if (filter && (rc = filter_job(c, sh, &job))) return rc;
+    launch_kabsch(points_of(c), tri_source_of(c), sh, c->rt.as<float>(), aos ? c->rt_aos.as<float>() : nullptr,
+                  filter ? &job : nullptr, c->stream);
   }
   if ((rc = rec(c, 4))) return rc;
   uint32_t score_rows = 0;
-  if ((rc = run_score(c, p, sh, &score_rows))) return rc;
+  if ((rc = run_score(c, p, sh, &score_rows, true))) return rc;
   if ((rc = rec(c, 5))) return rc;
   ENSURE(c, c->amx_pairs, argmax_scratch_bytes(sh.ld_local));
   launch_argmax(points_of(c), sh, c->partial.as<uint32_t>(), score_rows,
@@ -1208,10 +1224,12 @@ int sc_score_host(sc_ctx* c, const float* src, const float* tgt, int64_t n, cons
     ENSURE(c, c->rt_aos, (size_t)sh.ld_local * 48);  // (the scoring kernel may read whole 256-hypothesis groups)
     ENSURE(c, c->rt, (size_t)12 * sh.ld_local * 4);
     HIPCHK(c, hipMemcpyAsync(c->rt_aos.p, Rt, (size_t)n_hyp * 48, hipMemcpyHostToDevice, c->stream));
+    if (sh.ld_local > n_hyp)  // the padding hypotheses read as zeros in both layouts
+      HIPCHK(c, hipMemsetAsync(c->rt_aos.as<char>() + (size_t)n_hyp * 48, 0, (size_t)(sh.ld_local - n_hyp) * 48, c->stream));
     launch_rt_to_soa(c->rt_aos.as<float>(), n_hyp, sh.ld_local, c->rt.as<float>(), c->stream);
   }
   uint32_t score_rows = 0;
-  if ((rc = run_score(c, p, sh, &score_rows))) return rc;
+  if ((rc = run_score(c, p, sh, &score_rows, false))) return rc;
   ENSURE(c, c->cnt, (size_t)(sh.ld_local ? sh.ld_local : 256) * 4);
   ENSURE(c, c->amx_pairs, argmax_scratch_bytes(sh.ld_local));
   launch_argmax(points_of(c), sh, c->partial.as<uint32_t>(), score_rows,

@@ -337,7 +337,11 @@ struct TriSource {
 };
 // C1: RtSoA[c * ld_local + l], c = 0..11, for the local hypotheses of the shard (global rank index derived).
 // RtAoS (optional): also 12 consecutive floats per local hypothesis (ld_local x 12), for the lane = correspondence kernel
-void launch_kabsch(const Points& pts, const TriSource& ts, const Shard& sh, float* RtSoA, float* RtAoS, hipStream_t st);
+// tile_job (optional): the filter's tile kernel rides in the same launch as extra workgroups (C1 alone leaves most of the
+// chip idle: T / 256 workgroups), which saves a launch on the critical path.
+struct FilterTileJob;
+void launch_kabsch(const Points& pts, const TriSource& ts, const Shard& sh, float* RtSoA, float* RtAoS,
+                   const FilterTileJob* tile_job, hipStream_t st);
 // C1 on an explicit triangle list to AoS T x 12 (stage hook)
 void launch_kabsch_aos(const Points& pts, const uint32_t* tri, uint32_t T, float* Rt, hipStream_t st);
 // AoS T x 12 -> SoA planes (stage hook for sc_score_host)
@@ -361,10 +365,14 @@ struct FilterPlan {
 };
 bool score_uses_filter(int score_mode, const Tuning& tn, int n, uint32_t ld_local);
 FilterPlan filter_plan(int n, uint32_t ld_local, const Tuning& tn);
-void launch_filter_tile(const Points& pts, const FilterPlan& fp, const uint32_t* mx_cur, uint32_t* mx_next, void* tile,
-                        void* state, hipStream_t st);
-void launch_score_filter(const Points& pts, const float* RtSoA, const Shard& sh, const Derived& dv, const FilterPlan& fp,
-                         const void* tile, void* state, uint32_t* partial, const Tuning& tn, hipStream_t st);
+struct FilterTileJob {  // what the tile kernel needs (filter_tile_job fills it)
+  uint32_t rows; const uint32_t* mx_cur; uint32_t* mx_next; void* tile; void* info; uint32_t* zero; uint32_t zero_words;
+};
+FilterTileJob filter_tile_job(const FilterPlan& fp, const uint32_t* mx_cur, uint32_t* mx_next, void* tile, void* state);
+void launch_filter_tile(const Points& pts, const FilterTileJob& job, hipStream_t st);  // on its own (stage hook sc_score_host)
+// RtAoS: 12 consecutive floats per hypothesis (what the exact pass loads; launch_kabsch / the stage hook write them)
+void launch_score_filter(const Points& pts, const float* RtSoA, const float* RtAoS, const Shard& sh, const Derived& dv,
+                         const FilterPlan& fp, const void* tile, void* state, uint32_t* partial, const Tuning& tn, hipStream_t st);
 // Winner key pair key2[0..1] (written, not accumulated: no zeroing needed):
 //   key2[0] = max over hypotheses with count > 0 of  (count << 32) | second,   second = sel_key[g] (the triangle's
 //             ranking key) or, when sel_key == nullptr, 0xFFFFFFFF - g;

@@ -65,9 +65,17 @@ __device__ __forceinline__ void tri_lookup(const TriSource& ts, uint32_t g, uint
   v[2] = ke.x;
 }
 
-__global__ __launch_bounds__(256) void kabsch_shard_kernel(const float* __restrict__ planes, int ld, TriSource ts,
+__device__ void filter_tile_block(const float* __restrict__ planes, int n, int ld, const FilterTileJob& job, uint32_t block,
+                                  uint32_t blocks);
+
+__global__ __launch_bounds__(256) void kabsch_shard_kernel(const float* __restrict__ planes, int n, int ld, TriSource ts,
                                                            Shard sh, float* __restrict__ RtSoA,
-                                                           float* __restrict__ RtAoS) {
+                                                           float* __restrict__ RtAoS, FilterTileJob job,
+                                                           uint32_t kabsch_blocks) {
+  if (blockIdx.x >= kabsch_blocks) {  // the extra workgroups: C2's fp16 tile of the correspondences (see filter_tile_block)
+    filter_tile_block(planes, n, ld, job, blockIdx.x - kabsch_blocks, gridDim.x - kabsch_blocks);
+    return;
+  }
   const uint32_t l = blockIdx.x * 256 + threadIdx.x;
   if (l >= sh.ld_local) return;
   float Rt[12];
@@ -92,10 +100,12 @@ __global__ __launch_bounds__(256) void kabsch_shard_kernel(const float* __restri
   }
 }
 
-void launch_kabsch(const Points& pts, const TriSource& ts, const Shard& sh, float* RtSoA, float* RtAoS, hipStream_t st) {
+void launch_kabsch(const Points& pts, const TriSource& ts, const Shard& sh, float* RtSoA, float* RtAoS,
+                   const FilterTileJob* tile_job, hipStream_t st) {
   if (sh.ld_local == 0) return;
-  hipLaunchKernelGGL(kabsch_shard_kernel, dim3(sh.ld_local / 256), dim3(256), 0, st, pts.planes, pts.ld, ts, sh,
-                     RtSoA, RtAoS);
+  const uint32_t kb = sh.ld_local / 256, tb = tile_job ? (tile_job->rows + 255) / 256 : 0u;
+  hipLaunchKernelGGL(kabsch_shard_kernel, dim3(kb + tb), dim3(256), 0, st, pts.planes, pts.n, pts.ld, ts, sh, RtSoA, RtAoS,
+                     tile_job ? *tile_job : FilterTileJob{}, kb);
 }
 
 __global__ __launch_bounds__(256) void kabsch_aos_kernel(const float* __restrict__ planes, int ld,
@@ -559,19 +569,17 @@ FilterPlan filter_plan(int n, uint32_t ld_local, const Tuning& tn) {
 //   [Pxh Pxl Pxh  Pyh Pyl Pyh  Pzh Pzl | Pzh  Qxh Qxl  Qyh Qyl  Qzh Qzl  0];  rows [n, rows) are sentinels (far away).
 // mx_cur: max |p| and max |q| of the call (bit patterns; stage_points_kernel's atomicMax).  Also clears the filter's
 // counters and bitmap for this call and the maxima of the NEXT call (the two alternate), so nothing needs a memset.
-__global__ __launch_bounds__(256) void filter_tile_kernel(const float* __restrict__ planes, int n, int ld, uint32_t rows,
-                                                          const uint32_t* __restrict__ mx_cur, uint32_t* __restrict__ mx_next,
-                                                          uint4* __restrict__ tile, FilterInfo* __restrict__ info,
-                                                          uint32_t* __restrict__ zero, uint32_t zero_words) {
-  const uint32_t m = blockIdx.x * 256 + threadIdx.x;
-  for (uint32_t z = m; z < zero_words; z += gridDim.x * 256) zero[z] = 0u;
-  const float Pmax = __uint_as_float(mx_cur[0]), Qmax = __uint_as_float(mx_cur[1]), mxv = fmaxf(Pmax, Qmax);
+__device__ void filter_tile_block(const float* __restrict__ planes, int n, int ld, const FilterTileJob& job, uint32_t block,
+                                  uint32_t blocks) {
+  const uint32_t m = block * 256 + threadIdx.x;
+  for (uint32_t z = m; z < job.zero_words; z += blocks * 256) job.zero[z] = 0u;
+  const float Pmax = __uint_as_float(job.mx_cur[0]), Qmax = __uint_as_float(job.mx_cur[1]), mxv = fmaxf(Pmax, Qmax);
   const int e = (int)((__float_as_uint(mxv) >> 23) & 255u) - 127;  // mxv in [2^e, 2^(e+1))
   int k = 8 - e;
   k = k > 100 ? 100 : (k < -100 ? -100 : k);
   const float s = __uint_as_float((uint32_t)(k + 127) << 23);
-  if (m == 0) { *info = FilterInfo{s, Pmax, Qmax, 0.f}; mx_next[0] = 0u; mx_next[1] = 0u; }
-  if (m >= rows) return;
+  if (m == 0) { *static_cast<FilterInfo*>(job.info) = FilterInfo{s, Pmax, Qmax, 0.f}; job.mx_next[0] = 0u; job.mx_next[1] = 0u; }
+  if (m >= job.rows) return;
   _Float16 hi[6], lo[6];
 #pragma unroll
   for (int c = 0; c < 6; c++) {
@@ -581,8 +589,12 @@ __global__ __launch_bounds__(256) void filter_tile_kernel(const float* __restric
   }
   half8 f0 = {hi[0], lo[0], hi[0], hi[1], lo[1], hi[1], hi[2], lo[2]};
   half8 f1 = {hi[2], hi[3], lo[3], hi[4], lo[4], hi[5], lo[5], (_Float16)0.f};
+  uint4* tile = static_cast<uint4*>(job.tile);
   tile[(size_t)m * 2] = *reinterpret_cast<uint4*>(&f0);
   tile[(size_t)m * 2 + 1] = *reinterpret_cast<uint4*>(&f1);
+}
+__global__ __launch_bounds__(256) void filter_tile_kernel(const float* __restrict__ planes, int n, int ld, FilterTileJob job) {
+  filter_tile_block(planes, n, ld, job, blockIdx.x, gridDim.x);
 }
 
 // F.  Workgroup = FX_WAVES waves; wave w of workgroup b owns hypotheses 8 (FX_WAVES b + w) .. + 7 and never talks to
@@ -754,8 +766,13 @@ __global__ __launch_bounds__(64 * WAVES, 6) void score_filter_kernel(const float
 
 // X.  First the queued tests (one per thread; workgroup b serves sub-queue b % FX_NQ), then the (wave, split) pairs F
 // gave up on (one per workgroup at a time).  Everything here is the canonical chain; the counts are integers.
+__device__ __forceinline__ void load_rt_aos(const float4* __restrict__ RtAoS, uint32_t h, float (&M)[12]) {
+  const float4 a = RtAoS[3 * (size_t)h], b = RtAoS[3 * (size_t)h + 1], c = RtAoS[3 * (size_t)h + 2];
+  M[0] = a.x; M[1] = a.y; M[2] = a.z; M[3] = a.w; M[4] = b.x; M[5] = b.y; M[6] = b.z; M[7] = b.w;
+  M[8] = c.x; M[9] = c.y; M[10] = c.z; M[11] = c.w;
+}
 __global__ __launch_bounds__(256) void score_exact_kernel(const float* __restrict__ planes, int n, int ld,
-                                                          const float* __restrict__ Rt, uint32_t ldl, float tau2,
+                                                          const float4* __restrict__ RtAoS, uint32_t ldl, float tau2,
                                                           uint32_t windows, uint32_t splits, uint32_t n_waves,
                                                           const uint2* __restrict__ gq, uint32_t cap_sq,
                                                           const uint32_t* __restrict__ qcount,
@@ -771,8 +788,7 @@ __global__ __launch_bounds__(256) void score_exact_kernel(const float* __restric
     for (uint32_t bits = e.y & 0xFu; bits; bits &= bits - 1) {
       const uint32_t h = wid * 8 + 2 * (uint32_t)(__ffs(bits) - 1) + ehf;
       float M[12];
-#pragma unroll
-      for (int c = 0; c < 12; c++) M[c] = Rt[(size_t)c * ldl + h];
+      load_rt_aos(RtAoS, h, M);
       const float d2 = resid2(M, planes[m], planes[(size_t)ld + m], planes[2 * (size_t)ld + m], planes[3 * (size_t)ld + m],
                               planes[4 * (size_t)ld + m], planes[5 * (size_t)ld + m]);
       if (finite12(M) && d2 < tau2) atomicAdd(&cnt_out[(size_t)sp * ldl + h], 1u);
@@ -787,8 +803,7 @@ __global__ __launch_bounds__(256) void score_exact_kernel(const float* __restric
       const uint32_t sp = (uint32_t)(bit / n_waves), wid = (uint32_t)(bit % n_waves);
       const uint32_t h = wid * 8 + (threadIdx.x & 7);
       float M[12];
-#pragma unroll
-      for (int c = 0; c < 12; c++) M[c] = Rt[(size_t)c * ldl + h];
+      load_rt_aos(RtAoS, h, M);
       const bool ok = finite12(M);
       const uint32_t m1 = min((uint32_t)n, min(windows, (sp + 1) * per) * FX_WIN);
       uint32_t cnt = 0;
@@ -805,15 +820,17 @@ __global__ __launch_bounds__(256) void score_exact_kernel(const float* __restric
   }
 }
 
-void launch_filter_tile(const Points& pts, const FilterPlan& fp, const uint32_t* mx_cur, uint32_t* mx_next, void* tile,
-                        void* state, hipStream_t st) {
+FilterTileJob filter_tile_job(const FilterPlan& fp, const uint32_t* mx_cur, uint32_t* mx_next, void* tile, void* state) {
   const FilterState f = filter_state(state, fp);
-  hipLaunchKernelGGL(filter_tile_kernel, dim3((fp.rows + 255) / 256), dim3(256), 0, st, pts.planes, pts.n, pts.ld, fp.rows,
-                     mx_cur, mx_next, static_cast<uint4*>(tile), f.info, f.qcount, f.zero_words);
+  return FilterTileJob{fp.rows, mx_cur, mx_next, tile, f.info, f.qcount, f.zero_words};
 }
 
-void launch_score_filter(const Points& pts, const float* RtSoA, const Shard& sh, const Derived& dv, const FilterPlan& fp,
-                         const void* tile, void* state, uint32_t* partial, const Tuning& tn, hipStream_t st) {
+void launch_filter_tile(const Points& pts, const FilterTileJob& job, hipStream_t st) {
+  hipLaunchKernelGGL(filter_tile_kernel, dim3((job.rows + 255) / 256), dim3(256), 0, st, pts.planes, pts.n, pts.ld, job);
+}
+
+void launch_score_filter(const Points& pts, const float* RtSoA, const float* RtAoS, const Shard& sh, const Derived& dv,
+                         const FilterPlan& fp, const void* tile, void* state, uint32_t* partial, const Tuning& tn, hipStream_t st) {
   if (sh.n_local == 0) return;
   const FilterState f = filter_state(state, fp);
   uint32_t ql = tn.filter_lds_queue ? tn.filter_lds_queue : (uint32_t)FX_QL;
@@ -822,8 +839,9 @@ void launch_score_filter(const Points& pts, const float* RtSoA, const Shard& sh,
   hipLaunchKernelGGL(score_filter_kernel<FX_WAVES>, dim3(sh.ld_local / (8 * FX_WAVES), fp.splits), dim3(64 * FX_WAVES), 0, st,
                      RtSoA, sh.ld_local, dv.tau2, static_cast<const uint4*>(tile), f.info, fp.windows, fp.splits, fp.n_waves,
                      partial, f.queue, f.cap_sq, f.qcount, f.redo, ql);
-  hipLaunchKernelGGL(score_exact_kernel, dim3(FX_NQ * 2), dim3(256), 0, st, pts.planes, pts.n, pts.ld, RtSoA, sh.ld_local,
-                     dv.tau2, fp.windows, fp.splits, fp.n_waves, f.queue, f.cap_sq, f.qcount, f.redo, partial);
+  hipLaunchKernelGGL(score_exact_kernel, dim3(FX_NQ * 2), dim3(256), 0, st, pts.planes, pts.n, pts.ld,
+                     reinterpret_cast<const float4*>(RtAoS), sh.ld_local, dv.tau2, fp.windows, fp.splits, fp.n_waves, f.queue,
+                     f.cap_sq, f.qcount, f.redo, partial);
 }
 
 // Tuning::score_split: share of the hypotheses (in 256ths) scored on the matrix pipe (default 0; experiments)
