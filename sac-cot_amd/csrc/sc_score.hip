@@ -544,7 +544,9 @@ FilterPlan filter_plan(int n, uint32_t ld_local, const Tuning& tn) {
     const uint32_t per = (fp.windows + sp - 1) / sp, used = (fp.windows + per - 1) / per;  // splits that get windows
     if (used != sp) continue;
     const double blocks = (double)groups * sp, gens = (double)((uint64_t)(blocks + slots - 1) / slots);
-    const double eff = blocks / (gens * slots) * (1.0 - 0.02 * sp);  // every workgroup pays its set-up once
+    // every workgroup pays its set-up once: ~6 % per extra split (C2: 71 / 61 / 61 / 66 us at 1 / 2 / 3 / 5 splits,
+    // C4: 476 / 492 / 514 / 555)
+    const double eff = blocks / (gens * slots) * (1.0 - 0.06 * (sp - 1));
     if (eff > best_eff + 1e-9) { best_eff = eff; best = sp; }
   }
   fp.splits = tn.filter_splits && tn.filter_splits <= fp.windows ? tn.filter_splits : best;
@@ -716,7 +718,7 @@ __global__ __launch_bounds__(64 * WAVES, 6) void score_filter_kernel(const float
     if (!redo) {
       const half8* Bc = reinterpret_cast<const half8*>(Bt[buf]) + col * 2 + hf;
       half8 b = Bc[0];
-#pragma unroll 2
+#pragma unroll 2  // (fully unrolled: 144 bytes of spills inside the loop, 64 -> 118 us on C2)
       for (int g = 0; g < FX_UNIT / 32; g++) {
         const f32x16 D = __builtin_amdgcn_mfma_f32_32x32x16_f16(A, b, C, 0, 0, 0);
         if (g + 1 < FX_UNIT / 32) b = Bc[64 * (g + 1)];
