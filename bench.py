@@ -213,11 +213,18 @@ def main() -> int:
                        "traffic": None, "algorithmic_bytes": int(compat_bytes), "avg_us": round(avg["compat"], 2),
                        "note": "duration: HIP-event bracket around this kernel alone, on the hot path (one bracket per pass)"
                                + ("" if dense else "; SC_FLAG_NO_DENSE_S: bit rows only, the kernel is arithmetic-bound")}
-        roof_score = {"kernel": "score_kernel", "bound": "valu", "achieved": round(score_tflops, 2),
+        ld_local = (n_local + 255) // 256 * 256
+        filtered = int(knobs.get("score_filter", 0)) != 1 and (int(knobs.get("score_filter", 0)) == 2 or ld_local * n >= 2 ** 27)
+        roof_score = {"kernel": "score_filter_kernel + score_exact_kernel" if filtered else "score_kernel", "bound": "valu",
+                      "achieved": round(score_tflops, 2),
                       "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(score_tflops / FP32_PEAK_TFLOPS, 4),
                       "traffic": None, "algorithmic_flops": score_flops, "avg_us": round(us_score, 2),
-                      "note": "fp32 vector kernel (not HBM-bound: ~8 MB moved); peak = fp32 vector rate = dense f32-input "
-                              "MFMA rate (157.3 TFLOP/s); duration from HIP events inside the timed steps"}
+                      "note": ("stage C2 = fp16-split matrix-pipe filter (4.6 vector instructions + 1/256 MFMA per test) + exact "
+                               "fp32 pass over the undecided tests; counts identical to the fp32 kernel. " if filtered else
+                               "fp32 vector kernel. ") +
+                              "ALGORITHMIC flops (27 per test, SURVEY 8d) over the duration of the whole C2 stage; not HBM-bound "
+                              "(~8 MB moved); peak = fp32 vector rate = dense f32-input MFMA rate (157.3 TFLOP/s); duration "
+                              "from HIP events inside the timed steps"}
         # HBM bytes per launch from the committed rocprofv3 --pmc passes of this same command (tools/pmc_collect.sh,
         # FETCH_SIZE doubled per the gfx950 correction, WRITE_SIZE as is); PMC counters cannot be read from inside the
         # process, so `traffic` is the committed measurement of this code state, valid for the headline workload only
@@ -239,8 +246,9 @@ def main() -> int:
                            "because SURVEY §8d asks; duration from a fully bracketed pass (speculation off there)"}
         roofs = sorted([roof_compat, roof_score, roof_tk], key=lambda r: -r["avg_us"])
         for r in roofs:
-            if pmc_all.get(r["kernel"], {}).get("hbm_bytes_per_launch") is not None:
-                r["traffic"] = pmc_all[r["kernel"]]["hbm_bytes_per_launch"]
+            pk = r["kernel"].split(" + ")[0]  # (the filtered C2 stage: the filter kernel's own traffic)
+            if pmc_all.get(pk, {}).get("hbm_bytes_per_launch") is not None:
+                r["traffic"] = pmc_all[pk]["hbm_bytes_per_launch"]
                 r["traffic_source"] = pmc_src
         dominant, other = roofs[0], roofs[1:]
 
