@@ -718,7 +718,7 @@ __global__ __launch_bounds__(64 * WAVES, 6) void score_filter_kernel(const float
     if (!redo) {
       const half8* Bc = reinterpret_cast<const half8*>(Bt[buf]) + col * 2 + hf;
       half8 b = Bc[0];
-#pragma unroll 2  // (fully unrolled: 144 bytes of spills inside the loop, 64 -> 118 us on C2)
+#pragma unroll 2  // (by 4: no gain; fully unrolled: 144 bytes of spills inside the loop, 64 -> 118 us on C2)
       for (int g = 0; g < FX_UNIT / 32; g++) {
         const f32x16 D = __builtin_amdgcn_mfma_f32_32x32x16_f16(A, b, C, 0, 0, 0);
         if (g + 1 < FX_UNIT / 32) b = Bc[64 * (g + 1)];
