@@ -1059,3 +1059,54 @@ def test_register_with_the_filter_forced_small_and_sharded(pkg, O):
     assert rc == 0 and (st["best_rank"], st["best_count"]) == (ref["best_rank"], ref["best_count"])
     assert np.array_equal(d_mask.cpu().numpy(), ref["mask"])
     reg.close()
+
+
+def test_score_filter_many_windows_and_wide_indices(pkg, O):
+    """70 000 correspondences (69 windows, point indices beyond 16 bits, several grid splits) x 2048 hypotheses: 1.4e8 tests,
+    so the filter is chosen by size; counts against the oracle."""
+    reg = pkg.Registrar(0)
+    n, T = 70_000, 2048
+    sc = _scene(pkg, n, seed=12)
+    Rt0 = _hyps_near_truth(O, sc, T, seed=8)
+    kw = _params(pkg, 0.05, T)
+    cnt0 = O.score(sc.src, sc.tgt, Rt0, kw["tau"], threads=8)
+    cnt, key = reg.score(sc.src, sc.tgt, pkg.make_params(**kw), Rt0)
+    assert np.array_equal(cnt, cnt0) and key == O.best_key(cnt0) and cnt0.max() > 1000
+    reg.set_debug(filter_splits=7)
+    cnt, _ = reg.score(sc.src, sc.tgt, pkg.make_params(**kw), Rt0)
+    assert np.array_equal(cnt, cnt0)
+    reg.close()
+
+
+def test_score_filter_equals_fp32_kernel_on_random_scenes(pkg, O):
+    """Property: on random scenes of random size, scale, tau and hypothesis quality the filtered counts equal the fp32
+    kernel's (GPU against GPU: the fp32 kernel is pinned to the oracle elsewhere)."""
+    reg_f = pkg.Registrar(0); reg_f.set_debug(score_filter=2)
+    reg_p = pkg.Registrar(0); reg_p.set_debug(score_filter=1)
+    rng = np.random.default_rng(2024)
+    undecided_seen = 0
+    for it in range(40):
+        n = int(rng.integers(3, 3000)); T = int(rng.integers(1, 600))
+        scale = float(10.0 ** rng.uniform(-3, 3)); tau_rel = float(10.0 ** rng.uniform(-3.5, -0.3))
+        p = (rng.uniform(-1, 1, (n, 3)) * scale).astype(np.float32)
+        ang = rng.uniform(0, np.pi); ax = rng.normal(size=3); ax /= np.linalg.norm(ax)
+        K = np.array([[0, -ax[2], ax[1]], [ax[2], 0, -ax[0]], [-ax[1], ax[0], 0]])
+        R = np.eye(3) + np.sin(ang) * K + (1 - np.cos(ang)) * K @ K
+        t = rng.uniform(-1, 1, 3) * scale
+        q = (p.astype(np.float64) @ R.T + t + rng.normal(size=(n, 3)) * tau_rel * scale * 0.5)
+        out = rng.random(n) < 0.5
+        q[out] = rng.uniform(-2, 2, (int(out.sum()), 3)) * scale
+        q = q.astype(np.float32)
+        # hypotheses: the truth perturbed at the scale of tau, so that many residuals land near the threshold
+        Rt = np.zeros((T, 12), dtype=np.float32)
+        for h in range(T):
+            dR = np.eye(3) + rng.normal(size=(3, 3)) * tau_rel * 0.3
+            Rt[h, :9] = (dR @ R).astype(np.float32).ravel()
+            Rt[h, 9:] = (t + rng.normal(size=3) * tau_rel * scale * 0.7).astype(np.float32)
+        kw = _params(pkg, tau_rel * scale, T)
+        c_f, k_f = reg_f.score(p, q, pkg.make_params(**kw), Rt)
+        c_p, k_p = reg_p.score(p, q, pkg.make_params(**kw), Rt)
+        assert np.array_equal(c_f, c_p) and k_f == k_p, (it, n, T, scale, tau_rel)
+        undecided_seen += int(c_p.max() > 0)
+    assert undecided_seen > 10
+    reg_f.close(); reg_p.close()
