@@ -420,15 +420,19 @@ __global__ __launch_bounds__(256) void score_argmax_kernel(const uint32_t* __res
                                                            unsigned long long* __restrict__ key2) {
   __shared__ unsigned long long lds[4];
   __shared__ uint32_t s_last;
-  const uint32_t l = blockIdx.x * 256 + threadIdx.x;
+  // grid-stride over the hypotheses: at most 256 workgroups take a ticket (2000 same-address atomics cost ~20 us: C4)
   unsigned long long k = 0, pos = 0;
-  if (l < sh.n_local) {
+  for (uint32_t l = blockIdx.x * 256 + threadIdx.x; l < sh.n_local; l += gridDim.x * 256) {
     uint32_t c = 0;
     for (uint32_t ch = 0; ch < n_chunks; ch++) c += partial[(size_t)ch * sh.ld_local + l];
     cnt_out[l] = c;
     const uint32_t g = shard_global_index(l, sh.block, sh.rank, sh.world);
     const uint32_t second = sel_key ? sel_key[g] : 0xFFFFFFFFu - g;
-    if (c) { k = ((unsigned long long)c << 32) | (unsigned long long)second; pos = (unsigned long long)(0xFFFFFFFFu - g); }
+    if (c) {
+      const unsigned long long kk = ((unsigned long long)c << 32) | (unsigned long long)second;
+      const unsigned long long pp = (unsigned long long)(0xFFFFFFFFu - g);
+      if (kk > k || (kk == k && pp > pos)) { k = kk; pos = pp; }
+    }
   }
   const unsigned long long bk = block_max_u64(k, lds);
   __syncthreads();
@@ -883,7 +887,8 @@ void launch_argmax(const Points& pts, const Shard& sh, const uint32_t* partial, 
     (void)hipMemsetAsync(key2, 0, 2 * sizeof(uint64_t), st);
     return;
   }
-  hipLaunchKernelGGL(score_argmax_kernel, dim3(sh.ld_local / 256), dim3(256), 0, st, partial, n_chunks, sh, sel_key, cnt,
+  const uint32_t blocks = sh.ld_local / 256 < 256 ? sh.ld_local / 256 : 256;
+  hipLaunchKernelGGL(score_argmax_kernel, dim3(blocks), dim3(256), 0, st, partial, n_chunks, sh, sel_key, cnt,
                      reinterpret_cast<unsigned long long*>(pairs), ticket, reinterpret_cast<unsigned long long*>(key2));
 }
 
