@@ -673,7 +673,7 @@ int sc_create(int device, sc_ctx** out) {
   }
   c->stream = c->own_stream;
   for (int i = 0; i < N_EVENTS; i++)
-    if (hipEventCreate(&c->ev[i]) != hipSuccess) { sc_destroy(c); return SC_EHIP; }
+    if (hipEventCreateWithFlags(&c->ev[i], hipEventDisableSystemFence) != hipSuccess) { sc_destroy(c); return SC_EHIP; }
   if (hipHostMalloc((void**)&c->pinned, N_PINNED * sizeof(uint64_t), hipHostMallocDefault) != hipSuccess) {
     sc_destroy(c);
     return SC_EHIP;
