@@ -318,6 +318,35 @@ def main() -> int:
                 p_chk = pkg.make_params(flags=base_flags, **kw)
                 reg.register_device(d_src.data_ptr(), d_tgt.data_ptr(), n, p_chk, d_Rt.data_ptr(), d_mask.data_ptr())
                 torch.cuda.synchronize()
+            # ---- throughput with TWO independent registrations in flight (two contexts, two streams, two host threads):
+            # the path is a chain of ~19 dependent launches, many of them small, so a second call fills the gaps.  NOT the
+            # headline (`value` is one call at a time); what a service that registers a stream of frames would see.
+            import threading
+            out["calls_in_flight"] = {"note": "independent registrations in flight at once: one context, stream and host thread "
+                                              "each, 25 calls per thread; hypotheses/s of all of them together; not `value`"}
+            for nfl in (2, 4):
+                regs2 = [pkg.Registrar(local_rank) for _ in range(nfl)]
+                streams2 = [torch.cuda.Stream(device=dev) for _ in range(nfl)]
+                outs2 = [(torch.zeros(12, dtype=torch.float32, device=dev), torch.zeros(n, dtype=torch.uint8, device=dev)) for _ in range(nfl)]
+                p2 = pkg.make_params(flags=base_flags, **kw)
+                res2 = [None] * nfl
+
+                def worker(i, steps):
+                    regs2[i].set_stream(streams2[i].cuda_stream)
+                    for _ in range(steps):
+                        res2[i] = regs2[i].register_device(d_src.data_ptr(), d_tgt.data_ptr(), n, p2, outs2[i][0].data_ptr(), outs2[i][1].data_ptr())
+                    streams2[i].synchronize()
+                for phase_steps in (3, 25):
+                    torch.cuda.synchronize(); tp0 = time.perf_counter()
+                    th = [threading.Thread(target=worker, args=(i, phase_steps)) for i in range(nfl)]
+                    for t_ in th: t_.start()
+                    for t_ in th: t_.join()
+                    tp = time.perf_counter() - tp0
+                same = all(r is not None and r[1]["best_rank"] == st["best_rank"] and r[1]["best_count"] == st["best_count"] for r in res2)
+                out["calls_in_flight"][str(nfl)] = {"ms_per_call": tp / (25 * nfl) * 1e3, "hypotheses_per_s": T_total * 25 * nfl / tp,
+                                                    "same_winner": bool(same)}
+                for g in regs2:
+                    g.close()
         else:
             out["ms_to_best_Rt"] = ms_per_step
             out["ms_to_best_Rt_note"] = "N > 1: the device-resident step (inputs already in every GPU's HBM)"
