@@ -185,6 +185,7 @@ typedef struct sc_debug {
   uint32_t filter_splits;     /* grid.y of the filter kernel (0 = by size)                                            */
   uint32_t filter_queue_cap;  /* entries of the filter's queue of undecided tests (0 = by size): a small one forces the recount path */
   uint32_t filter_lds_queue;  /* entries of a wave's own queue, 64 .. 256 (0 = 256)                                   */
+  uint32_t es_hist_unfused;   /* 1: stage B's edge-weight histogram by a launch of its own instead of inside edge_fill  */
 } sc_debug;
 int         sc_set_debug(sc_ctx* ctx, const sc_debug* dbg);
 

@@ -79,7 +79,7 @@ class ScDebug(C.Structure):
                 ("compat_rows", C.c_uint32), ("compat_store_mode", C.c_uint32), ("tg_events", C.c_uint32), ("sample_mode", C.c_uint32),
                 ("sample_blocks", C.c_uint32), ("compact_fused", C.c_uint32), ("rows_unfused", C.c_uint32),
                 ("score_scalar", C.c_uint32), ("score_filter", C.c_uint32), ("filter_splits", C.c_uint32),
-                ("filter_queue_cap", C.c_uint32), ("filter_lds_queue", C.c_uint32)]
+                ("filter_queue_cap", C.c_uint32), ("filter_lds_queue", C.c_uint32), ("es_hist_unfused", C.c_uint32)]
 
 
 class SacCotError(RuntimeError):

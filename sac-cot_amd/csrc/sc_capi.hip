@@ -375,10 +375,13 @@ int run_edges(sc_ctx* c, const sc_params* p, uint32_t* hist, uint32_t part, uint
   const Graph g = graph_of(c);
   uint64_t spec_cap = c->es.cap / 4 >= 2 ? c->es.cap / 4 - 2 : 0;  // es carries two pad entries
   for (const Buf* b : {&c->ei, &c->ej, &c->ebi, &c->ebj}) spec_cap = b->cap / 4 < spec_cap ? b->cap / 4 : spec_cap;
+  // the weight histogram of the heaviest-edge pruning sample is collected by the same kernel (sc_debug.sample_mode = ...
+  // any: it costs edge_fill ~1 us and saves a launch whenever that sample is chosen)
+  uint32_t* es_hist = c->tn.es_hist_unfused ? nullptr : c->ctl.as<ControlBlock>()->es_hist;
   auto fill_edges = [&](uint64_t cap) {
     launch_edge_fill(g, points_of(c), c->dv, c->edge_off.as<uint64_t>(), c->ei.as<uint32_t>(), c->ej.as<uint32_t>(),
                      c->es.as<float>(), c->ebase.as<uint32_t>(), fused || scan_writes_ebase(n), c->ebi.as<uint32_t>(),
-                     c->ebj.as<uint32_t>(), cap, st);
+                     c->ebj.as<uint32_t>(), cap, es_hist, st);
   };
   if (spec_cap) fill_edges(spec_cap);
   { const int wrc = wait_word(c, 0); if (wrc) return wrc; }
@@ -398,7 +401,10 @@ int run_edges(sc_ctx* c, const sc_params* p, uint32_t* hist, uint32_t part, uint
   ENSURE(c, c->ebj, E * 4);
   ENSURE(c, c->toff, (E + 1) * 8);
   ENSURE(c, c->scan_tmp, scan_temp_bytes(E));
-  if (E > spec_cap) fill_edges(E);  // first call, or the graph outgrew the arrays (just re-allocated above)
+  if (E > spec_cap) {  // first call, or the graph outgrew the arrays (just re-allocated above)
+    if (es_hist && spec_cap) HIPCHK(c, hipMemsetAsync(es_hist, 0, sizeof(uint32_t) * PR_HCOPIES * 256, st));  // the partial run's counts
+    fill_edges(E);
+  }
   // certified pruning (sc_tri.hip 3b): weight ranking only; pointless on tiny graphs
   c->pruned = may_prune(p) && E >= 4096;
   // counting pass + event list (sc_tri.hip 2b) on the pruned graph; Tuning::no_events keeps the row-walking pair
@@ -414,7 +420,7 @@ int run_edges(sc_ctx* c, const sc_params* p, uint32_t* hist, uint32_t part, uint
     // the smallest possible weight is ~3 t_cmp (every edge has s >= t_cmp up to rounding); 0.1 % slack
     launch_sample_hist(g, c->ebi.as<uint32_t>(), c->ebj.as<uint32_t>(), c->ei.as<uint32_t>(), c->ej.as<uint32_t>(),
                        c->es.as<float>(), E, p->max_triangles, 3.0f * p->t_cmp * 0.999f, part, parts,
-                       ctl->prune_hist, ctl->es_hist, c->tn, st);
+                       ctl->prune_hist, ctl->es_hist, es_hist != nullptr, c->tn, st);
     if (hist) launch_hist_reduce(ctl->prune_hist, hist, st);  // the exchanged form: one 256-bin histogram
   }
   return SC_OK;
@@ -738,6 +744,7 @@ int sc_set_debug(sc_ctx* c, const sc_debug* d) {
   t.compact_fused = d->compact_fused != 0;
   t.rows_unfused = d->rows_unfused != 0;
   t.score_scalar = d->score_scalar != 0;
+  t.es_hist_unfused = d->es_hist_unfused != 0;
   t.score_filter = d->score_filter <= 2 ? d->score_filter : 0u;
   t.filter_splits = d->filter_splits;
   t.filter_queue_cap = d->filter_queue_cap;

@@ -32,6 +32,7 @@ struct Tuning {
   uint32_t sample_blocks = 0;      // grid of the heaviest-edge sample (0: one block per 256 edges)
   bool compact_fused = false;      // compaction in one launch (decoupled look-back) instead of count + write
   bool rows_unfused = false;       // row_stats and the scan(s) of the row counts as separate launches (round 1's form)
+  bool es_hist_unfused = false;    // the weight histogram of the heaviest-edge sample by a launch of its own (not inside edge_fill)
   bool score_scalar = false;       // C2: count inliers with the lane = correspondence kernel (coefficients as scalar operands)
   uint64_t sample_edges = 0;       // edges of the pruning sample (0: automatic, ~5T/8)
   uint32_t score_split = 0;        // share (of 256) of the hypotheses scored on the matrix pipe
@@ -137,7 +138,7 @@ struct Graph {
 bool scan_writes_ebase(size_t n);
 void launch_edge_fill(const Graph& g, const Points& pts, const Derived& dv, const uint64_t* edge_off, uint32_t* ei,
                       uint32_t* ej, float* es, uint32_t* ebase, bool ebase_ready, uint32_t* ebi, uint32_t* ebj,
-                      uint64_t cap, hipStream_t st);
+                      uint64_t cap, uint32_t* es_hist, hipStream_t st);  // es_hist: see launch_sample_hist (optional)
 // tcnt[e] = #k > j adjacent (in `mbits`) to both ends of edge e = (i,j); edges with es[e] < *smin count 0
 // (smin == nullptr: no pruning, mbits = g.bits).
 void launch_tri_count(const Graph& g, const uint64_t* mbits, const float* es, const float* smin, const uint32_t* ei,
@@ -164,8 +165,9 @@ size_t strong_list_bytes(uint64_t E);
 //    with sl.list set also compacts the strong edges and zeroes tcnt of the weak ones.
 void launch_sample_hist(const Graph& g, const uint32_t* ebi, const uint32_t* ebj, const uint32_t* ei,
                         const uint32_t* ej, const float* es, uint64_t E, uint64_t want, float key_floor, uint32_t part,
-                        uint32_t parts, uint32_t* hist, uint32_t* es_hist, const Tuning& tn, hipStream_t st);
-// es_hist: PR_HCOPIES x 256 zeroed words (control block) for the weight histogram of the heaviest-edge sample
+                        uint32_t parts, uint32_t* hist, uint32_t* es_hist, bool es_hist_ready, const Tuning& tn, hipStream_t st);
+// es_hist: PR_HCOPIES x 256 words (control block) for the weight histogram of the heaviest-edge sample: zeroed, or —
+// es_hist_ready — already filled by launch_edge_fill
 // launch_sample_hist ALWAYS accumulates into PR_HCOPIES x 256 words (`hist` = the control block's copies);
 // launch_hist_reduce sums them into one 256-bin histogram (the exchanged form); launch_prune_bits reads either
 // (hist_is_copies).

@@ -61,6 +61,8 @@ __device__ __forceinline__ int pop4(uint64_t& m, int b[4]) {
 // same correctly rounded operations on the same operands give the same bits; the squares make the argument order
 // irrelevant) instead of being gathered from S: a gather moves a 64-byte sector of the n x n matrix for 4 useful
 // bytes (C3: 215 us), the recomputation is ~80 VALU operations on points that sit in L2.
+__device__ __forceinline__ uint32_t weight_bin(uint32_t wbits, uint32_t wlo, uint32_t wshift);  // §3b
+
 __global__ __launch_bounds__(256) void edge_fill_kernel(const uint64_t* __restrict__ bits,
                                                         const float* __restrict__ planes, Derived dv,
                                                         int n, int ld, int W,
@@ -71,14 +73,22 @@ __global__ __launch_bounds__(256) void edge_fill_kernel(const uint64_t* __restri
                                                         const uint32_t* __restrict__ degp,
                                                         uint32_t* __restrict__ ebase, int ebase_ready,
                                                         uint32_t* __restrict__ ebi,
-                                                        uint32_t* __restrict__ ebj, uint64_t cap) {
+                                                        uint32_t* __restrict__ ebj, uint64_t cap,
+                                                        uint32_t* __restrict__ es_hist) {
   // cap: entries the edge arrays hold.  The host may launch this kernel BEFORE it knows the edge count (into the
   // arrays of the previous call, while it polls for the count); writes beyond cap are dropped and the host re-runs.
+  // es_hist (optional): the 256-bin histogram of the edge weights that sizes the heaviest-edge pruning sample (§3b;
+  // PR_HCOPIES global copies) — collected here, where the weights are made, instead of by a launch of its own (7 us).
   constexpr int CH = 512;  // column indices staged per wave and chunk
   __shared__ uint32_t l_j[4][CH];
+  __shared__ uint32_t l_h[2][256];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int i = blockIdx.x * 4 + wave;
-  if (i >= n) return;  // whole waves leave: there is no workgroup barrier below
+  if (es_hist) {
+    l_h[0][threadIdx.x] = 0u; l_h[1][threadIdx.x] = 0u;
+    __syncthreads();
+  }
+  if (i < n) {
   uint64_t base = edge_off[i];
   // CSR base of row i: edge_off[i] - (# bits of row i at or below i) = edge_off[i] - (deg - deg+), modular u32.
   // ebase_ready: the (tiled) scan of deg+ wrote every row's base already, so the base of the OTHER end is one gather;
@@ -125,6 +135,7 @@ __global__ __launch_bounds__(256) void edge_fill_kernel(const uint64_t* __restri
         ei[e] = (uint32_t)i;
         ej[e] = j;
         es[e] = sw;
+        if (es_hist) atomicAdd(&l_h[lane & 1][weight_bin(__float_as_uint(sw), 0u, 0u)], 1u);  // integer sums: order-free
         // both CSR bases travel with the edge, so stage B fetches an edge in ONE memory level
         ebi[e] = my_base;
         ebj[e] = ebase_ready ? ebase[j] : (uint32_t)edge_off[j] - (deg[j] - degp[j]);
@@ -133,13 +144,19 @@ __global__ __launch_bounds__(256) void edge_fill_kernel(const uint64_t* __restri
     }
     base += tot;
   }
+  }  // i < n
+  if (es_hist) {
+    __syncthreads();
+    const uint32_t v = l_h[0][threadIdx.x] + l_h[1][threadIdx.x];
+    if (v) atomicAdd(&es_hist[(size_t)(blockIdx.x & (PR_HCOPIES - 1)) * 256 + threadIdx.x], v);
+  }
 }
 
 void launch_edge_fill(const Graph& g, const Points& pts, const Derived& dv, const uint64_t* edge_off, uint32_t* ei,
                       uint32_t* ej, float* es, uint32_t* ebase, bool ebase_ready, uint32_t* ebi, uint32_t* ebj,
-                      uint64_t cap, hipStream_t st) {
+                      uint64_t cap, uint32_t* es_hist, hipStream_t st) {
   hipLaunchKernelGGL(edge_fill_kernel, dim3((g.n + 3) / 4), dim3(256), 0, st, g.bits, pts.planes, dv, g.n, g.ld, g.W,
-                     edge_off, ei, ej, es, g.deg, g.degp, ebase, ebase_ready ? 1 : 0, ebi, ebj, cap);
+                     edge_off, ei, ej, es, g.deg, g.degp, ebase, ebase_ready ? 1 : 0, ebi, ebj, cap, es_hist);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -935,7 +952,7 @@ static void prune_window(float key_floor, uint32_t* klo_out, uint32_t* shift_out
 
 void launch_sample_hist(const Graph& g, const uint32_t* ebi, const uint32_t* ebj, const uint32_t* ei,
                         const uint32_t* ej, const float* es, uint64_t E, uint64_t want, float key_floor, uint32_t part,
-                        uint32_t parts, uint32_t* hist, uint32_t* es_hist, const Tuning& tn, hipStream_t st) {
+                        uint32_t parts, uint32_t* hist, uint32_t* es_hist, bool es_hist_ready, const Tuning& tn, hipStream_t st) {
   uint32_t klo, shift;
   prune_window(key_floor, &klo, &shift);
   // Which form (r02 sweeps, profiles/r02_ab_heaviest_edge_sample.txt and r02_ab_sample_size.txt): the heaviest edges
@@ -965,7 +982,7 @@ void launch_sample_hist(const Graph& g, const uint32_t* ebi, const uint32_t* ebj
     uint64_t hb = (E + 4095) / 4096;
     if (hb > 1024) hb = 1024;
     if (hb < 1) hb = 1;
-    hipLaunchKernelGGL(es_hist_kernel, dim3((unsigned)hb), dim3(256), 0, st, es, E, wlo, wshift, es_hist);
+    if (!es_hist_ready) hipLaunchKernelGGL(es_hist_kernel, dim3((unsigned)hb), dim3(256), 0, st, es, E, wlo, wshift, es_hist);
     const int tg = tn.tg_sample ? tn.tg_sample : (g.W > 256 ? 32 : 16);  // C3 (W = 313): 134 (16) vs 107 us (32); C2: 24.4 vs 25.9
     uint64_t nb = (E + (uint64_t)SM_CHUNK * parts - 1) / ((uint64_t)SM_CHUNK * parts);
     if (nb > 8192) nb = 8192;
