@@ -532,6 +532,9 @@ static FilterState filter_state(void* state, const FilterPlan& fp) {
 bool score_uses_filter(int score_mode, const Tuning& tn, int n, uint32_t ld_local) {
   if (score_mode != 0 || tn.score_filter == 1 || tn.score_split != 0 || tn.score_scalar) return false;
   if (ld_local == 0 || ld_local / 8 >= (1u << 27)) return false;
+  // beyond 2^36 tests the queue of undecided tests (sized T n / 512 entries: ~20x what the BASELINE scenes need) would
+  // pass 1 GB: such calls keep the plain kernel rather than a queue that may overflow into wholesale recounts
+  if ((uint64_t)ld_local * (uint64_t)n > (1ull << 36)) return false;
   return tn.score_filter == 2 || (uint64_t)ld_local * (uint64_t)n >= (1ull << 27);
 }
 
@@ -561,7 +564,7 @@ FilterPlan filter_plan(int n, uint32_t ld_local, const Tuning& tn) {
   fp.rows = fp.windows * FX_WIN + FX_UNIT;
   uint64_t cap = (uint64_t)ld_local * (uint64_t)n / 512;  // ~20x what the BASELINE scenes queue
   if (cap < (1u << 16)) cap = 1u << 16;
-  if (cap > (1u << 23)) cap = 1u << 23;
+  if (cap > (1u << 27)) cap = 1u << 27;
   if (tn.filter_queue_cap) cap = tn.filter_queue_cap;
   fp.queue_cap = (uint32_t)(cap / FX_NQ * FX_NQ);
   if (fp.queue_cap < FX_NQ) fp.queue_cap = FX_NQ;
