@@ -244,14 +244,16 @@ int stage_inputs(sc_ctx* c, const float* d_src, const float* d_tgt, int64_t n, c
   ENSURE(c, c->ctl, sizeof(ControlBlock));
   static_assert(sizeof(ControlBlock) % 4 == 0, "cleared word-wise");
   c->pinned[1] = 0;  // "non-finite input" flag lives in host-pinned memory: the kernel only touches it on bad data
-  if (!c->fx_mx.p) {  // coordinate maxima for C2's filter: two pairs that alternate from call to call
-    ENSURE(c, c->fx_mx, 16);
-    HIPCHK(c, hipMemsetAsync(c->fx_mx.p, 0, 16, c->stream));
+  if (!c->fx_mx.p) {  // coordinate maxima for C2's filter: two pairs that alternate from call to call, + a ticket
+    ENSURE(c, c->fx_mx, 32);
+    HIPCHK(c, hipMemsetAsync(c->fx_mx.p, 0, 32, c->stream));
   }
   c->fx_parity ^= 1;
+  c->pinned[13] = ~0ull;  // "maxima not known yet"
   launch_stage_points(d_src, d_tgt, c->n, c->ld, p->layout, c->planes.as<float>(),
                       reinterpret_cast<uint32_t*>(&c->pinned[1]), c->ctl.as<uint32_t>(),
-                      (uint32_t)(sizeof(ControlBlock) / 4), c->fx_mx.as<uint32_t>() + 2 * c->fx_parity, c->stream);
+                      (uint32_t)(sizeof(ControlBlock) / 4), c->fx_mx.as<uint32_t>() + 2 * c->fx_parity,
+                      c->fx_mx.as<uint32_t>() + 4, &c->pinned[13], c->stream);
   return SC_OK;
 }
 
@@ -787,6 +789,14 @@ int run_stage_c(sc_ctx* c, uint64_t* d_key, sc_stats* stats);
 // C2: the counts of this shard's hypotheses into c->partial; *rows: rows of c->partial the arg-max has to add up.
 // SC_SCORE_COUNT runs the matrix-pipe filter + the exact fix-up (sc_score.hip); the truncated scores, and
 // sc_debug.score_filter = 1, the plain fp32 kernel.
+// C2 by filter?  By mode / size / knobs (score_uses_filter), and — unless forced — only when tau is on a scale the filter
+// can bound (a tau below ~2.4e-4 of the scene's extent, or above 8 x, would send every wave to the exact recount, which
+// is slower than the plain kernel): the staging kernel has told the host the coordinate maxima long before this point.
+bool use_filter(const sc_ctx* c, const sc_params* p, const Shard& sh) {
+  if (!score_uses_filter(p->score_mode, c->tn, c->n, sh.ld_local)) return false;
+  return c->tn.score_filter == 2 || filter_in_range(c->pinned[13], c->dv.tau2);
+}
+
 // the filter's buffers for this shard, and the job that fills the tile / clears the state
 int filter_job(sc_ctx* c, const Shard& sh, FilterTileJob* job) {
   const FilterPlan fp = filter_plan(c->n, sh.ld_local, c->tn);
@@ -798,7 +808,7 @@ int filter_job(sc_ctx* c, const Shard& sh, FilterTileJob* job) {
 }
 
 int run_score(sc_ctx* c, const sc_params* p, const Shard& sh, uint32_t* rows, bool tile_done) {
-  if (score_uses_filter(p->score_mode, c->tn, c->n, sh.ld_local)) {
+  if (use_filter(c, p, sh)) {
     const FilterPlan fp = filter_plan(c->n, sh.ld_local, c->tn);
     *rows = fp.splits;
     ENSURE(c, c->partial, (size_t)fp.splits * sh.ld_local * 4);
@@ -845,7 +855,7 @@ int run_stage_c(sc_ctx* c, uint64_t* d_key, sc_stats* stats) {
   if (sh.n_local) {
     ENSURE(c, c->rt, (size_t)12 * sh.ld_local * 4);
     ENSURE(c, c->cnt, (size_t)sh.ld_local * 4);
-    const bool filter = score_uses_filter(p->score_mode, c->tn, c->n, sh.ld_local);
+    const bool filter = use_filter(c, p, sh);
     const bool aos = filter || score_is_scalar(p->score_mode, c->tn);  // both read 12 consecutive floats per hypothesis
     if (aos) ENSURE(c, c->rt_aos, (size_t)12 * sh.ld_local * 4);
     FilterTileJob job;

@@ -18,7 +18,9 @@ __global__ __launch_bounds__(256) void stage_points_kernel(const float* __restri
                                                            int layout, float* __restrict__ planes,
                                                            uint32_t* __restrict__ bad_flag,
                                                            uint32_t* __restrict__ zero, uint32_t zero_words,
-                                                           uint32_t* __restrict__ coord_max) {
+                                                           uint32_t* __restrict__ coord_max,
+                                                           uint32_t* __restrict__ mx_ticket,
+                                                           uint64_t* __restrict__ host_max) {
   int m = blockIdx.x * 256 + threadIdx.x;
   for (uint32_t z = (uint32_t)m; z < zero_words; z += gridDim.x * 256) zero[z] = 0u;  // the per-call control block
   float v[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -39,6 +41,21 @@ __global__ __launch_bounds__(256) void stage_points_kernel(const float* __restri
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) { mp = fmaxf(mp, __shfl_xor(mp, o)); mq = fmaxf(mq, __shfl_xor(mq, o)); }
     if ((threadIdx.x & 63) == 0) { atomicMax(&coord_max[0], __float_as_uint(mp)); atomicMax(&coord_max[1], __float_as_uint(mq)); }
+    // the block that takes the last ticket tells the HOST the two maxima (max |q| << 32 | max |p|, bit patterns): the
+    // host decides from them whether C2's filter can work at this tau (sc_capi.hip run_stage_c); nothing waits for it
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+      const uint32_t t = __hip_atomic_fetch_add(mx_ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (t == gridDim.x - 1) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        const uint32_t a = __hip_atomic_load(&coord_max[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const uint32_t b = __hip_atomic_load(&coord_max[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(mx_ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // ready for the next call
+        publish_host(host_max, ((uint64_t)b << 32) | a);
+      }
+    }
   }
   if (m >= ld) return;
 #pragma unroll
@@ -51,9 +68,10 @@ __global__ __launch_bounds__(256) void stage_points_kernel(const float* __restri
 }
 
 void launch_stage_points(const float* d_src, const float* d_tgt, int n, int ld, int layout, float* planes,
-                         uint32_t* bad_flag, uint32_t* zero, uint32_t zero_words, uint32_t* coord_max, hipStream_t st) {
+                         uint32_t* bad_flag, uint32_t* zero, uint32_t zero_words, uint32_t* coord_max, uint32_t* mx_ticket,
+                         uint64_t* host_max, hipStream_t st) {
   hipLaunchKernelGGL(stage_points_kernel, dim3((ld + 255) / 256), dim3(256), 0, st, d_src, d_tgt, n, ld, layout,
-                     planes, bad_flag, zero, zero_words, coord_max);
+                     planes, bad_flag, zero, zero_words, coord_max, mx_ticket, host_max);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -70,9 +70,14 @@ struct Points {
 // user layout (AoS n x 3 or SoA 3 x n) -> padded planes; sets *bad_flag != 0 when a value is not finite.
 // bad_flag may be host-pinned memory: it is only touched (atomicOr) when a non-finite value is found.
 // zero / zero_words: a buffer (the per-call control block) the kernel clears on the way — saves a memset launch.
-// coord_max (optional, 2 x u32): atomicMax of the bit patterns of max |src coordinate| and max |tgt coordinate|.
+// coord_max (optional, 2 x u32): atomicMax of the bit patterns of max |src coordinate| and max |tgt coordinate|; with it:
+// mx_ticket (a zeroed u32, left zero) and host_max (pinned u64: receives max|tgt| << 32 | max|src| once every block is done).
 void launch_stage_points(const float* d_src, const float* d_tgt, int n, int ld, int layout, float* planes,
-                         uint32_t* bad_flag, uint32_t* zero, uint32_t zero_words, uint32_t* coord_max, hipStream_t st);
+                         uint32_t* bad_flag, uint32_t* zero, uint32_t zero_words, uint32_t* coord_max, uint32_t* mx_ticket,
+                         uint64_t* host_max, hipStream_t st);
+// can C2's filter bound its error at this tau?  (the host-side twin of the test every wave of the filter makes; maxima as
+// the staging kernel published them, ~0 = not known: assume yes)
+bool filter_in_range(uint64_t host_max, float tau2);
 
 // ---- stage A: compat_graph -----------------------------------------------------------------------
 // S: n x ld fp32 (row-major, symmetric, zero diagonal / pad columns); bits: n x (ld/64) u64;

@@ -538,6 +538,20 @@ bool score_uses_filter(int score_mode, const Tuning& tn, int n, uint32_t ld_loca
   return tn.score_filter == 2 || (uint64_t)ld_local * (uint64_t)n >= (1ull << 27);
 }
 
+bool filter_in_range(uint64_t host_max, float tau2) {
+  if (host_max == ~0ull) return true;
+  union { uint32_t u; float f; } a, b, m;
+  a.u = (uint32_t)host_max; b.u = (uint32_t)(host_max >> 32);
+  const float pmax = a.f, qmax = b.f;
+  m.f = pmax > qmax ? pmax : qmax;
+  const uint32_t mb = m.u;
+  int k = 8 - ((int)((mb >> 23) & 255u) - 127);
+  k = k > 100 ? 100 : (k < -100 ? -100 : k);
+  const float s = ldexpf(1.0f, k), st = s * sqrtf(tau2);
+  const float eta = (2.6f * (pmax * s) + qmax * s) * (1.0f / 65536.0f);  // a wave adds its own |t| s to this
+  return (eta <= 0.25f * st) && (st <= 4096.f) && (pmax * s < 512.f) && (qmax * s < 512.f);  // false on NaN
+}
+
 FilterPlan filter_plan(int n, uint32_t ld_local, const Tuning& tn) {
   FilterPlan fp;
   fp.windows = (uint32_t)((n + FX_WIN - 1) / FX_WIN);

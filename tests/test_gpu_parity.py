@@ -1110,3 +1110,21 @@ def test_score_filter_equals_fp32_kernel_on_random_scenes(pkg, O):
         undecided_seen += int(c_p.max() > 0)
     assert undecided_seen > 10
     reg_f.close(); reg_p.close()
+
+
+def test_score_keeps_the_fp32_kernel_when_tau_is_off_the_filters_scale(pkg, O):
+    """A call big enough for the filter but with tau at 1e-5 of the scene's extent (or 100 x it): the staging kernel has
+    told the host the coordinate maxima, the host keeps the fp32 kernel (the filter would hand every wave to the exact
+    recount) — counts as the oracle's either way."""
+    reg = pkg.Registrar(0)
+    n, T = 70_000, 2048
+    sc = _scene(pkg, n, seed=13)
+    Rt0 = _hyps_near_truth(O, sc, T, seed=9)
+    for tau in (1e-5, 100.0):
+        kw = _params(pkg, tau, T)
+        cnt0 = O.score(sc.src, sc.tgt, Rt0, kw["tau"], threads=8)
+        for knobs in (dict(), dict(score_filter=2)):
+            reg.set_debug(**knobs)
+            cnt, key = reg.score(sc.src, sc.tgt, pkg.make_params(**kw), Rt0)
+            assert np.array_equal(cnt, cnt0) and key == O.best_key(cnt0), (tau, knobs)
+    reg.close()
