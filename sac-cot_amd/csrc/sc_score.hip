@@ -802,18 +802,19 @@ __global__ __launch_bounds__(256) void score_exact_kernel(const float* __restric
                                                           const uint32_t* __restrict__ redo_bits,
                                                           uint32_t* __restrict__ cnt_out) {
   const uint32_t per = (windows + splits - 1) / splits;
+  const float4* __restrict__ aos4 = reinterpret_cast<const float4*>(planes + 6 * (size_t)ld);  // 8 floats per correspondence
   const uint32_t sq = blockIdx.x % FX_NQ, nq = min(qcount[sq * 32], cap_sq);
   for (uint32_t i = (blockIdx.x / FX_NQ) * 256 + threadIdx.x; i < nq; i += (gridDim.x / FX_NQ) * 256) {
     const uint2 e = gq[(size_t)sq * cap_sq + i];
     const uint32_t m = e.x, wid = e.y >> 5, ehf = (e.y >> 4) & 1u, sp = (m / FX_WIN) / per;
     const size_t bit = (size_t)sp * n_waves + wid;
     if ((redo_bits[bit >> 5] >> (bit & 31)) & 1u) continue;  // recounted as a whole below
+    const float4 pa = aos4[2 * (size_t)m], pb = aos4[2 * (size_t)m + 1];  // the correspondence in two 16-byte loads
     for (uint32_t bits = e.y & 0xFu; bits; bits &= bits - 1) {
       const uint32_t h = wid * 8 + 2 * (uint32_t)(__ffs(bits) - 1) + ehf;
       float M[12];
       load_rt_aos(RtAoS, h, M);
-      const float d2 = resid2(M, planes[m], planes[(size_t)ld + m], planes[2 * (size_t)ld + m], planes[3 * (size_t)ld + m],
-                              planes[4 * (size_t)ld + m], planes[5 * (size_t)ld + m]);
+      const float d2 = resid2(M, pa.x, pa.y, pa.z, pa.w, pb.x, pb.y);
       if (finite12(M) && d2 < tau2) atomicAdd(&cnt_out[(size_t)sp * ldl + h], 1u);
     }
   }
@@ -831,8 +832,8 @@ __global__ __launch_bounds__(256) void score_exact_kernel(const float* __restric
       const uint32_t m1 = min((uint32_t)n, min(windows, (sp + 1) * per) * FX_WIN);
       uint32_t cnt = 0;
       for (uint32_t m = sp * per * FX_WIN + (threadIdx.x >> 3); m < m1; m += 32) {
-        const float d2 = resid2(M, planes[m], planes[(size_t)ld + m], planes[2 * (size_t)ld + m], planes[3 * (size_t)ld + m],
-                                planes[4 * (size_t)ld + m], planes[5 * (size_t)ld + m]);
+        const float4 pa = aos4[2 * (size_t)m], pb = aos4[2 * (size_t)m + 1];
+        const float d2 = resid2(M, pa.x, pa.y, pa.z, pa.w, pb.x, pb.y);
         cnt += (ok && d2 < tau2) ? 1u : 0u;
       }
       cnt += __shfl_xor(cnt, 8);
