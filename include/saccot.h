@@ -173,7 +173,7 @@ typedef struct sc_debug {
   uint64_t sample_edges;      /* edges in stage B's pruning sample (default ~5T/8, at least 32768)            */
   uint32_t score_split;       /* share (of 256) of the hypotheses scored by the f32-MFMA body of C2 */
   uint32_t compat_one_phase;  /* 1: stage A runs the exact chain on every pair of an interior tile            */
-  uint32_t compat_rows;       /* stage A tile height: 16 (default) or 64                                      */
+  uint32_t compat_rows;       /* stage A tile height: 0 = by size (16 rows below 10 000 correspondences, 32 from there), 16, 32, 64 */
   uint32_t compat_store_mode; /* stage A stores of S: 0 = by size; bit 0 = 4 bytes per lane, bit 2 = 16 bytes, bit 1 = non-temporal */
   uint32_t tg_events;         /* lanes per edge of the event-recording counting pass: 4 .. 64 (default: by row width) */
   uint32_t sample_mode;       /* stage B's pruning sample: 0 = chosen by size, 1 = every stride-th edge, 2 = the heaviest edges */

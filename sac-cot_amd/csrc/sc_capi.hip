@@ -730,7 +730,7 @@ int sc_set_debug(sc_ctx* c, const sc_debug* d) {
   auto tg_ok = [](uint32_t t) { return t == 0 || t == 4 || t == 8 || t == 16 || t == 32 || t == 64; };
   if (!tg_ok(d->tg_count) || !tg_ok(d->tg_keys) || !tg_ok(d->tg_sample) || !tg_ok(d->tg_events)) return SC_EINVAL;
   if (d->tg_count == 64) return SC_EINVAL;  // the plain counting kernel has no 64-lane form
-  if (d->score_split > 256 || (d->compat_rows != 0 && d->compat_rows != 16 && d->compat_rows != 64)) return SC_EINVAL;
+  if (d->score_split > 256 || (d->compat_rows != 0 && d->compat_rows != 16 && d->compat_rows != 32 && d->compat_rows != 64)) return SC_EINVAL;
   if (d->event_cap != 0 && d->event_cap < 256) return SC_EINVAL;
   Tuning t;
   t.no_events = d->no_events != 0;
@@ -745,7 +745,7 @@ int sc_set_debug(sc_ctx* c, const sc_debug* d) {
   t.sample_edges = d->sample_edges;
   t.score_split = d->score_split;
   t.compat_one_phase = d->compat_one_phase != 0;
-  t.compat_rows = d->compat_rows == 64 ? 64 : 16;
+  t.compat_rows = (int)d->compat_rows;  // 0 (by size), 16, 32, 64: checked above
   t.compat_store_mode = d->compat_store_mode & 7u;
   t.sample_mode = d->sample_mode <= 2 ? d->sample_mode : 0u;
   t.sample_blocks = d->sample_blocks;

@@ -577,11 +577,19 @@ void launch_compat(const Points& pts, const Derived& dv, float* S, uint64_t* bit
     else hipLaunchKernelGGL((compat_tiles_kernel<16, 4, false, true>), dim3((n_tiles + 3) / 4), dim3(256), 0, st, SC_COMPAT_ARGS);
     return;
   }
-  // tile height: 16 rows (4.3 KiB LDS image per wave, 4 waves per workgroup; default) or 64 rows (16.6 KiB, one wave
-  // per workgroup; the mirrored half is then written as full 256-byte segments).  Measured: C2 28 vs 49 us, C3 432 vs
+  // tile height: 16 rows (4.3 KiB LDS image per wave, 4 waves per workgroup), 32 rows (8.4 KiB, 2 waves per workgroup) or
+  // 64 rows (16.6 KiB, one wave per workgroup; the mirrored half is then written as full 256-byte segments).  Measured: C2 28 vs 49 us, C3 432 vs
   // 435 us — bigger mirrored pieces do not pay for the lost occupancy.  Tuning::compat_rows = 64 selects it (experiments).
-  const int tr = tn.compat_rows == 64 ? 64 : 16;
-  if (tr == 64) {
+  // r02, by size (HIP-event bracket around the kernel, alternating in one process): N = 6000 31 vs 40 us, 8000 52 vs 58,
+  // 10 000 97 vs 91, 12 000 137 vs 129, 16 000 264 vs 226, 20 000 (C3) 430 vs 372 for 16- vs 32-row tiles: from ~10 000
+  // correspondences on the launch has enough tiles that the taller tile's lower occupancy no longer shows, and its
+  // 128-byte mirrored pieces and half as many row operands per pair do.
+  const int tr = tn.compat_rows == 64 ? 64 : (tn.compat_rows == 32 ? 32 : (tn.compat_rows == 16 ? 16 : (pts.n >= 10000 ? 32 : 16)));
+  if (tr == 32) {
+    const int n_tiles = 2 * W * (W + 1) / 2;
+    if (S) hipLaunchKernelGGL((compat_tiles_kernel<32, 2, true, false>), dim3((n_tiles + 1) / 2), dim3(128), 0, st, SC_COMPAT_ARGS);
+    else hipLaunchKernelGGL((compat_tiles_kernel<32, 2, false, false>), dim3((n_tiles + 1) / 2), dim3(128), 0, st, SC_COMPAT_ARGS);
+  } else if (tr == 64) {
     const int n_tiles = W * (W + 1) / 2;
     if (S) hipLaunchKernelGGL((compat_tiles_kernel<64, 1, true, false>), dim3(n_tiles), dim3(64), 0, st, SC_COMPAT_ARGS);
     else hipLaunchKernelGGL((compat_tiles_kernel<64, 1, false, false>), dim3(n_tiles), dim3(64), 0, st, SC_COMPAT_ARGS);

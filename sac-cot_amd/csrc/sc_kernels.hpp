@@ -41,7 +41,7 @@ struct Tuning {
   uint32_t filter_queue_cap = 0;   // entries of the filter's global queue (0: by size; tests force overflows with a small one)
   uint32_t filter_lds_queue = 0;   // entries of a wave's LDS queue, 64 .. 256 (0: 256)
   bool compat_one_phase = false;   // exact chain on every pair of an interior tile
-  int compat_rows = 16;            // tile height of stage A: 16 or 64
+  int compat_rows = 0;             // tile height of stage A: 0 = by size (16 below 10 000 correspondences, 32 from there), 16, 32, 64
   uint32_t compat_store_mode = 0;  // 0: by size; bit 0: force 4-byte S stores, bit 2: force 16-byte, bit 1: non-temporal
 };
 

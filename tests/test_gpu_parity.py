@@ -38,7 +38,7 @@ def test_compat_bit_exact(pkg, O, reg, n, seed):
     assert np.array_equal(S, S.T) and not S.diagonal().any()
 
 
-@pytest.mark.parametrize("one_phase,rows", [(False, "16"), (True, "16"), (False, "64")])
+@pytest.mark.parametrize("one_phase,rows", [(False, "16"), (True, "16"), (False, "32"), (True, "32"), (False, "64")])
 @pytest.mark.parametrize("min_len_scale", [0.0, 1.0])
 def test_compat_both_interior_forms_bit_exact(pkg, O, one_phase, rows, min_len_scale):
     """Interior tiles of stage A run a conservative candidate test on squared lengths and the exact chain only on the
@@ -51,7 +51,7 @@ def test_compat_both_interior_forms_bit_exact(pkg, O, one_phase, rows, min_len_s
     kw = dict(sigma=0.05, t_cmp=0.9, tau=0.05, min_len=0.05 * min_len_scale)
     r = pkg.Registrar(0)
     try:
-        r.set_debug(compat_one_phase=int(one_phase), compat_rows=int(rows))  # 64-row tiles: the experimental variant
+        r.set_debug(compat_one_phase=int(one_phase), compat_rows=int(rows))  # 32-row tiles: the default from 10 000 correspondences; 64: experimental
         S1, b1, d1 = r.compat(src, tgt, pkg.make_params(**kw))
     finally:
         r.close()
