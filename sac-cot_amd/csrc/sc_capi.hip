@@ -257,7 +257,7 @@ int stage_inputs(sc_ctx* c, const float* d_src, const float* d_tgt, int64_t n, c
   launch_stage_points(d_src, d_tgt, c->n, c->ld, p->layout, c->planes.as<float>(),
                       reinterpret_cast<uint32_t*>(&c->pinned[1]), c->ctl.as<uint32_t>(),
                       (uint32_t)(sizeof(ControlBlock) / 4), c->fx_mx.as<uint32_t>() + 2 * c->fx_parity,
-                      c->fx_mx.as<uint32_t>() + 4, &c->pinned[13], c->stream);
+                      c->fx_mx.as<uint32_t>() + 2 * (c->fx_parity ^ 1), c->fx_mx.as<uint32_t>() + 4, &c->pinned[13], c->stream);
   return SC_OK;
 }
 

@@ -19,6 +19,7 @@ __global__ __launch_bounds__(256) void stage_points_kernel(const float* __restri
                                                            uint32_t* __restrict__ bad_flag,
                                                            uint32_t* __restrict__ zero, uint32_t zero_words,
                                                            uint32_t* __restrict__ coord_max,
+                                                           uint32_t* __restrict__ coord_max_next,
                                                            uint32_t* __restrict__ mx_ticket,
                                                            uint64_t* __restrict__ host_max) {
   int m = blockIdx.x * 256 + threadIdx.x;
@@ -53,6 +54,9 @@ __global__ __launch_bounds__(256) void stage_points_kernel(const float* __restri
         const uint32_t a = __hip_atomic_load(&coord_max[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const uint32_t b = __hip_atomic_load(&coord_max[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __hip_atomic_store(mx_ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // ready for the next call
+        // ... and so is the OTHER pair, which the next call accumulates into (nobody touches it during this one); done
+        // here, on every call, so that a maximum never outlives its scene
+        coord_max_next[0] = 0u; coord_max_next[1] = 0u;
         publish_host(host_max, ((uint64_t)b << 32) | a);
       }
     }
@@ -68,10 +72,10 @@ __global__ __launch_bounds__(256) void stage_points_kernel(const float* __restri
 }
 
 void launch_stage_points(const float* d_src, const float* d_tgt, int n, int ld, int layout, float* planes,
-                         uint32_t* bad_flag, uint32_t* zero, uint32_t zero_words, uint32_t* coord_max, uint32_t* mx_ticket,
-                         uint64_t* host_max, hipStream_t st) {
+                         uint32_t* bad_flag, uint32_t* zero, uint32_t zero_words, uint32_t* coord_max, uint32_t* coord_max_next,
+                         uint32_t* mx_ticket, uint64_t* host_max, hipStream_t st) {
   hipLaunchKernelGGL(stage_points_kernel, dim3((ld + 255) / 256), dim3(256), 0, st, d_src, d_tgt, n, ld, layout,
-                     planes, bad_flag, zero, zero_words, coord_max, mx_ticket, host_max);
+                     planes, bad_flag, zero, zero_words, coord_max, coord_max_next, mx_ticket, host_max);
 }
 
 // ------------------------------------------------------------------------------------------------

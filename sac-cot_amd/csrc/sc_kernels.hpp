@@ -71,10 +71,11 @@ struct Points {
 // bad_flag may be host-pinned memory: it is only touched (atomicOr) when a non-finite value is found.
 // zero / zero_words: a buffer (the per-call control block) the kernel clears on the way — saves a memset launch.
 // coord_max (optional, 2 x u32): atomicMax of the bit patterns of max |src coordinate| and max |tgt coordinate|; with it:
-// mx_ticket (a zeroed u32, left zero) and host_max (pinned u64: receives max|tgt| << 32 | max|src| once every block is done).
+// coord_max_next (the pair the NEXT call uses: cleared by the last block), mx_ticket (a zeroed u32, left zero) and
+// host_max (pinned u64: receives max|tgt| << 32 | max|src| once every block is done).
 void launch_stage_points(const float* d_src, const float* d_tgt, int n, int ld, int layout, float* planes,
-                         uint32_t* bad_flag, uint32_t* zero, uint32_t zero_words, uint32_t* coord_max, uint32_t* mx_ticket,
-                         uint64_t* host_max, hipStream_t st);
+                         uint32_t* bad_flag, uint32_t* zero, uint32_t zero_words, uint32_t* coord_max, uint32_t* coord_max_next,
+                         uint32_t* mx_ticket, uint64_t* host_max, hipStream_t st);
 // can C2's filter bound its error at this tau?  (the host-side twin of the test every wave of the filter makes; maxima as
 // the staging kernel published them, ~0 = not known: assume yes)
 bool filter_in_range(uint64_t host_max, float tau2);

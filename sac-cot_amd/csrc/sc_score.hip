@@ -591,7 +591,7 @@ FilterPlan filter_plan(int n, uint32_t ld_local, const Tuning& tn) {
 // The fp16 image of the correspondences, 32 bytes each, in the K order of the B operand:
 //   [Pxh Pxl Pxh  Pyh Pyl Pyh  Pzh Pzl | Pzh  Qxh Qxl  Qyh Qyl  Qzh Qzl  0];  rows [n, rows) are sentinels (far away).
 // mx_cur: max |p| and max |q| of the call (bit patterns; stage_points_kernel's atomicMax).  Also clears the filter's
-// counters and bitmap for this call and the maxima of the NEXT call (the two alternate), so nothing needs a memset.
+// counters and bitmap for this call, so nothing needs a memset.
 __device__ void filter_tile_block(const float* __restrict__ planes, int n, int ld, const FilterTileJob& job, uint32_t block,
                                   uint32_t blocks) {
   const uint32_t m = block * 256 + threadIdx.x;
@@ -601,7 +601,7 @@ __device__ void filter_tile_block(const float* __restrict__ planes, int n, int l
   int k = 8 - e;
   k = k > 100 ? 100 : (k < -100 ? -100 : k);
   const float s = __uint_as_float((uint32_t)(k + 127) << 23);
-  if (m == 0) { *static_cast<FilterInfo*>(job.info) = FilterInfo{s, Pmax, Qmax, 0.f}; job.mx_next[0] = 0u; job.mx_next[1] = 0u; }
+  if (m == 0) *static_cast<FilterInfo*>(job.info) = FilterInfo{s, Pmax, Qmax, 0.f};  // (the staging kernel clears the other pair of maxima)
   if (m >= job.rows) return;
   _Float16 hi[6], lo[6];
 #pragma unroll
