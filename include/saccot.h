@@ -34,7 +34,7 @@ extern "C" {
 #endif
 
 #define SC_VERSION_MAJOR 0
-#define SC_VERSION_MINOR 3   /* 0.3: sc_set_debug (no environment variables), SC_FLAG_NO_DENSE_S, sc_shard_* (stages A and B sharded); 0.2: SC_FLAG_TIMING_HOT,
+#define SC_VERSION_MINOR 4   /* 0.4: sc_debug_last / sc_debug_info, sc_debug.filter_blind; 0.3: sc_set_debug (no environment variables), SC_FLAG_NO_DENSE_S, sc_shard_* (stages A and B sharded); 0.2: SC_FLAG_TIMING_HOT,
                                 SC_STREAM_DEFAULT, sc_hypothesize_begin/end_device, sc_finalize_gathered_device */
 
 /* status codes */
@@ -186,8 +186,21 @@ typedef struct sc_debug {
   uint32_t filter_queue_cap;  /* entries of the filter's queue of undecided tests (0 = by size): a small one forces the recount path */
   uint32_t filter_lds_queue;  /* entries of a wave's own queue, 64 .. 256 (0 = 256)                                   */
   uint32_t es_hist_unfused;   /* 1: stage B's edge-weight histogram by a launch of its own instead of inside edge_fill  */
+  uint32_t filter_blind;      /* 1: the host picks stage C2's kernel as if the coordinate maxima had not arrived yet (it then assumes the filter applies; the filter's own range test sends what it cannot bound to the exact recount) */
 } sc_debug;
 int         sc_set_debug(sc_ctx* ctx, const sc_debug* dbg);
+
+/* Diagnostics of the LAST call on this context (test hook, like sc_set_debug): which stage C2 kernel it ran and, for the
+ * matrix-pipe filter, what it handed to the exact pass.  Synchronises the context's stream. */
+typedef struct sc_debug_info {
+  uint32_t size;              /* = sizeof(sc_debug_info), set by the caller                                          */
+  uint32_t c2_kernel;         /* 0: plain fp32 kernel (also the truncated scores); 1: matrix-pipe filter + exact pass  */
+  uint64_t filter_undecided;  /* queue entries (one per correspondence and wave half with >= 1 undecided test)         */
+  uint64_t filter_recounts;   /* (8-hypothesis wave, grid split) pairs recounted wholesale by the exact pass           */
+  uint32_t filter_splits;     /* grid.y of the filter launch                                                           */
+  uint32_t reserved;
+} sc_debug_info;
+int         sc_debug_last(sc_ctx* ctx, sc_debug_info* out);
 
 /* ---- the drop-in entry point: correspondences in, (R, t, inlier mask) out ------------------------
  * north_star: "keeping the reference's correspondence-in / (R,t,inlier-mask)-out function signature".

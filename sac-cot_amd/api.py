@@ -33,7 +33,7 @@ def SC_TIMING_STAGE(k: int) -> int:
 SC_HIST_WORDS = 256  # u32 words of the pruning-sample histogram (sc_hypothesize_begin_device)
 
 EXPORTS = ["sc_version", "sc_strerror", "sc_default_params", "sc_create", "sc_destroy", "sc_set_stream",
-           "sc_last_error", "sc_set_debug", "sc_register", "sc_register_device", "sc_hypothesize_device", "sc_finalize_device",
+           "sc_last_error", "sc_set_debug", "sc_debug_last", "sc_register", "sc_register_device", "sc_hypothesize_device", "sc_finalize_device",
            "sc_hypothesize_begin_device", "sc_hypothesize_end_device", "sc_finalize_gathered_device",
            "sc_shard_plan_query", "sc_shard_compat_device", "sc_shard_edges_device", "sc_shard_select_device",
            "sc_shard_score_device", "sc_create_multi", "sc_create_multi_loopback", "sc_destroy_multi",
@@ -79,7 +79,14 @@ class ScDebug(C.Structure):
                 ("compat_rows", C.c_uint32), ("compat_store_mode", C.c_uint32), ("tg_events", C.c_uint32), ("sample_mode", C.c_uint32),
                 ("sample_blocks", C.c_uint32), ("compact_fused", C.c_uint32), ("rows_unfused", C.c_uint32),
                 ("score_scalar", C.c_uint32), ("score_filter", C.c_uint32), ("filter_splits", C.c_uint32),
-                ("filter_queue_cap", C.c_uint32), ("filter_lds_queue", C.c_uint32), ("es_hist_unfused", C.c_uint32)]
+                ("filter_queue_cap", C.c_uint32), ("filter_lds_queue", C.c_uint32), ("es_hist_unfused", C.c_uint32),
+                ("filter_blind", C.c_uint32)]
+
+
+class ScDebugInfo(C.Structure):
+    """Mirror of `sc_debug_info` (include/saccot.h): which C2 kernel the last call ran, and the filter's hand-overs."""
+    _fields_ = [("size", C.c_uint32), ("c2_kernel", C.c_uint32), ("filter_undecided", C.c_uint64),
+                ("filter_recounts", C.c_uint64), ("filter_splits", C.c_uint32), ("reserved", C.c_uint32)]
 
 
 class SacCotError(RuntimeError):
@@ -117,6 +124,7 @@ def load_library() -> C.CDLL:
     L.sc_set_stream.argtypes = [vp, vp]
     L.sc_last_error.argtypes = [vp]; L.sc_last_error.restype = C.c_char_p
     L.sc_set_debug.argtypes = [vp, C.POINTER(ScDebug)]
+    L.sc_debug_last.argtypes = [vp, C.POINTER(ScDebugInfo)]
     L.sc_register.argtypes = [vp, f32p, f32p, C.c_int64, pp, f32p, f32p, u8p, sp]
     L.sc_register_device.argtypes = [vp, vp, vp, C.c_int64, pp, vp, vp, sp]
     L.sc_hypothesize_device.argtypes = [vp, vp, vp, C.c_int64, pp, vp, sp]
@@ -220,6 +228,13 @@ class Registrar:
                 raise KeyError(f"sc_debug has no field {k!r}")
             setattr(d, k, int(v))
         self._check(self._lib.sc_set_debug(self._h, C.byref(d)))
+
+    def debug_last(self) -> dict:
+        """sc_debug_last: which stage C2 kernel the last call ran (0 plain fp32, 1 filter + exact pass) and what the
+        filter handed to the exact pass.  Synchronises the context's stream."""
+        d = ScDebugInfo(size=C.sizeof(ScDebugInfo))
+        self._check(self._lib.sc_debug_last(self._h, C.byref(d)))
+        return {k: getattr(d, k) for k, _ in ScDebugInfo._fields_ if k not in ("size", "reserved")}
 
     # ---- drop-in entry point ----------------------------------------------------------------------------
     def register(self, src, tgt, params: ScParams | None = None, **kw):

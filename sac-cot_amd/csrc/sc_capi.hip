@@ -47,6 +47,8 @@ struct sc_ctx {
   Buf in_src, in_tgt, planes, S, bits, deg, degp, wpre, ebase, edge_off, scan_tmp, ei, ej, es, ebi, ebj, tcnt, toff, wkey, kcol, ctl, events, blk_gt,
       blk_eq, blk_minmax, bits2, off_gt, off_eq, sel_ord, sel_key, sortkey, sorted, sort_tmp, tri, tri_rk, key_rk, rt, rt_aos, partial, cnt, key, rt12,
       mask, refine_tmp, amx_pairs, strong, rowcost, cost_pre, lb_state, lb_ticket, fx_tile, fx_state, fx_mx;
+  bool filter_on = false;   // C2 of the running / last call goes through the matrix-pipe filter (decided ONCE per call)
+  FilterPlan fx_plan{};     // ... with this plan (sc_debug_last reads the filter's counters through it)
   int fx_parity = 0;  // which pair of fx_mx this call's staging kernel fills (the filter's tile kernel clears the other)
   // sc_register (host arrays in, host arrays out): pinned, device-mapped staging areas — the staging kernel reads the
   // correspondences straight from host memory and the finalize kernel writes (R, t, mask) straight into it: no copies
@@ -757,7 +759,20 @@ int sc_set_debug(sc_ctx* c, const sc_debug* d) {
   t.filter_splits = d->filter_splits;
   t.filter_queue_cap = d->filter_queue_cap;
   t.filter_lds_queue = d->filter_lds_queue;
+  t.filter_blind = d->filter_blind != 0;
   c->tn = t;
+  return SC_OK;
+}
+
+int sc_debug_last(sc_ctx* c, sc_debug_info* out) {
+  if (!c || !out || out->size != sizeof(sc_debug_info)) return SC_EINVAL;
+  HIPCHK(c, hipSetDevice(c->device));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  out->c2_kernel = c->filter_on ? 1u : 0u;
+  out->filter_splits = c->filter_on ? c->fx_plan.splits : 0u;
+  out->filter_undecided = 0; out->filter_recounts = 0;
+  if (c->filter_on && c->fx_state.p)
+    HIPCHK(c, filter_read_counters(c->fx_state.p, c->fx_plan, c->stream, &out->filter_undecided, &out->filter_recounts));
   return SC_OK;
 }
 
@@ -798,14 +813,24 @@ int run_stage_c(sc_ctx* c, uint64_t* d_key, sc_stats* stats);
 // C2 by filter?  By mode / size / knobs (score_uses_filter), and — unless forced — only when tau is on a scale the filter
 // can bound (a tau below ~2.4e-4 of the scene's extent, or above 8 x, would send every wave to the exact recount, which
 // is slower than the plain kernel): the staging kernel has told the host the coordinate maxima long before this point.
+// Evaluated ONCE per call (decide_filter stores the answer in the context): the word it reads is written by the GPU, so
+// two evaluations could disagree.  On the path the maxima have always arrived by then (the host has polled results of
+// later kernels of the same stream); the stage hook waits for the word.  Not known (sc_debug.filter_blind forces that
+// case) means "assume in range": the filter itself hands whatever it cannot bound to the exact recount, so the counts
+// are the same either way, only slower.
 bool use_filter(const sc_ctx* c, const sc_params* p, const Shard& sh) {
   if (!score_uses_filter(p->score_mode, c->tn, c->n, sh.ld_local)) return false;
-  return c->tn.score_filter == 2 || filter_in_range(c->pinned[13], c->dv.tau2);
+  const uint64_t mx = c->tn.filter_blind ? ~0ull : *const_cast<volatile uint64_t*>(&c->pinned[13]);
+  return c->tn.score_filter == 2 || filter_in_range(mx, c->dv.tau2);
+}
+void decide_filter(sc_ctx* c, const sc_params* p, const Shard& sh) {
+  c->filter_on = use_filter(c, p, sh);
+  if (c->filter_on) c->fx_plan = filter_plan(c->n, sh.ld_local, c->tn);
 }
 
 // the filter's buffers for this shard, and the job that fills the tile / clears the state
 int filter_job(sc_ctx* c, const Shard& sh, FilterTileJob* job) {
-  const FilterPlan fp = filter_plan(c->n, sh.ld_local, c->tn);
+  const FilterPlan& fp = c->fx_plan;
   ENSURE(c, c->fx_tile, fp.tile_bytes);
   ENSURE(c, c->fx_state, fp.state_bytes);
   uint32_t* mx = c->fx_mx.as<uint32_t>();
@@ -814,8 +839,8 @@ int filter_job(sc_ctx* c, const Shard& sh, FilterTileJob* job) {
 }
 
 int run_score(sc_ctx* c, const sc_params* p, const Shard& sh, uint32_t* rows, bool tile_done) {
-  if (use_filter(c, p, sh)) {
-    const FilterPlan fp = filter_plan(c->n, sh.ld_local, c->tn);
+  if (c->filter_on) {  // decide_filter() ran earlier in this call
+    const FilterPlan& fp = c->fx_plan;
     *rows = fp.splits;
     ENSURE(c, c->partial, (size_t)fp.splits * sh.ld_local * 4);
     if (!tile_done) {  // (the stage hook; the path builds the tile inside the Kabsch launch)
@@ -861,13 +886,16 @@ int run_stage_c(sc_ctx* c, uint64_t* d_key, sc_stats* stats) {
   if (sh.n_local) {
     ENSURE(c, c->rt, (size_t)12 * sh.ld_local * 4);
     ENSURE(c, c->cnt, (size_t)sh.ld_local * 4);
-    const bool filter = use_filter(c, p, sh);
+    decide_filter(c, p, sh);
+    const bool filter = c->filter_on;
     const bool aos = filter || score_is_scalar(p->score_mode, c->tn);  // both read 12 consecutive floats per hypothesis
     if (aos) ENSURE(c, c->rt_aos, (size_t)12 * sh.ld_local * 4);
     FilterTileJob job;
     if (filter && (rc = filter_job(c, sh, &job))) return rc;
     launch_kabsch(points_of(c), tri_source_of(c), sh, c->rt.as<float>(), aos ? c->rt_aos.as<float>() : nullptr,
                   filter ? &job : nullptr, c->stream);
+  } else {
+    c->filter_on = false;
   }
   if ((rc = rec(c, 4))) return rc;
   uint32_t score_rows = 0;
@@ -1285,6 +1313,11 @@ int sc_score_host(sc_ctx* c, const float* src, const float* tgt, int64_t n, cons
       HIPCHK(c, hipMemsetAsync(c->rt_aos.as<char>() + (size_t)n_hyp * 48, 0, (size_t)(sh.ld_local - n_hyp) * 48, c->stream));
     launch_rt_to_soa(c->rt_aos.as<float>(), n_hyp, sh.ld_local, c->rt.as<float>(), c->stream);
   }
+  // the choice of the C2 kernel looks at the coordinate maxima the staging kernel publishes: wait for them (the path
+  // proper never has to — it has polled later results of the same stream by the time it gets here)
+  if (!c->tn.filter_blind && (rc = wait_word(c, 13))) return rc;
+  c->sh = sh;
+  decide_filter(c, p, sh);
   uint32_t score_rows = 0;
   if ((rc = run_score(c, p, sh, &score_rows, false))) return rc;
   ENSURE(c, c->cnt, (size_t)(sh.ld_local ? sh.ld_local : 256) * 4);

@@ -40,6 +40,7 @@ struct Tuning {
   uint32_t filter_splits = 0;      // grid.y of the filter (0: by size)
   uint32_t filter_queue_cap = 0;   // entries of the filter's global queue (0: by size; tests force overflows with a small one)
   uint32_t filter_lds_queue = 0;   // entries of a wave's LDS queue, 64 .. 256 (0: 256)
+  bool filter_blind = false;       // the host decides C2's kernel WITHOUT the coordinate maxima (as if they had not arrived yet)
   bool compat_one_phase = false;   // exact chain on every pair of an interior tile
   int compat_rows = 0;             // tile height of stage A: 0 = by size (16 below 10 000 correspondences, 32 from there), 16, 32, 64
   uint32_t compat_store_mode = 0;  // 0: by size; bit 0: force 4-byte S stores, bit 2: force 16-byte, bit 1: non-temporal
@@ -381,6 +382,8 @@ void launch_filter_tile(const Points& pts, const FilterTileJob& job, hipStream_t
 // RtAoS: 12 consecutive floats per hypothesis (what the exact pass loads; launch_kabsch / the stage hook write them)
 void launch_score_filter(const Points& pts, const float* RtSoA, const float* RtAoS, const Shard& sh, const Derived& dv,
                          const FilterPlan& fp, const void* tile, void* state, uint32_t* partial, const Tuning& tn, hipStream_t st);
+// diagnostics (sc_debug_last): what the filter of the last launch handed to the exact pass.  Blocking copies on `st`.
+hipError_t filter_read_counters(const void* state, const FilterPlan& fp, hipStream_t st, uint64_t* undecided, uint64_t* recounts);
 // Winner key pair key2[0..1] (written, not accumulated: no zeroing needed):
 //   key2[0] = max over hypotheses with count > 0 of  (count << 32) | second,   second = sel_key[g] (the triangle's
 //             ranking key) or, when sel_key == nullptr, 0xFFFFFFFF - g;

@@ -14,6 +14,16 @@
 //    ncclGroupStart/End needed).  The calling convention stays single-caller, like sc_ctx.
 //  * RCCL is opened at run time (dlopen "librccl.so.1") when n_dev > 1: n_dev == 1 makes no RCCL call at all and
 //    the library carries no link-time dependency on it.
+//  * every wait between threads SPINS (with a pause, then yields): the workers are dedicated threads and a step is a few
+//    hundred microseconds, so a mutex + condition-variable wake-up (5-50 us each, ten per call in round 2) would be a
+//    large part of it.  Idle workers fall asleep on a condition variable after ~200 us without a job.
+//  * inputs go through ONE pinned, device-mapped host area every device reads directly (the staging kernel streams the
+//    24 n bytes over the host link), outputs come back through another one rank 0's finalize kernel writes: no
+//    pageable-memory hipMemcpy on the path (10-20 us of driver time each), exactly like sc_register.
+//  * errors: nobody enters a collective unless every rank finished the phase before it (agreement BEFORE: a rank must
+//    not compute on another rank's garbage), and every rank learns right AFTER the enqueue whether it succeeded everywhere
+//    (a collective one rank never joined blocks the others' streams for good: the communicators are then aborted and the
+//    handle refuses further calls).  Both agreements are spin barriers.
 //  * a LOOPBACK transport (sc_create_multi_loopback: n ranks on ONE device, device copies between the ranks' buffers
 //    behind host barriers) exists so that the whole orchestration — buffers, phase order, error agreement, outputs —
 //    is exercised bit for bit on a one-GPU box.  Only the RCCL calls themselves are then untested.
@@ -23,6 +33,7 @@
 #include <dlfcn.h>
 
 #include <atomic>
+#include <chrono>
 #include <condition_variable>
 #include <cstdio>
 #include <cstring>
@@ -40,6 +51,7 @@ struct Rccl {
   void* lib = nullptr;
   ncclResult_t (*CommInitAll)(ncclComm_t*, int, const int*) = nullptr;
   ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  ncclResult_t (*CommAbort)(ncclComm_t) = nullptr;  // optional
   ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
   ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
   const char* (*GetErrorString)(ncclResult_t) = nullptr;
@@ -53,24 +65,40 @@ struct Rccl {
     SC_SYM(CommInitAll, "ncclCommInitAll") SC_SYM(CommDestroy, "ncclCommDestroy") SC_SYM(AllGather, "ncclAllGather")
     SC_SYM(AllReduce, "ncclAllReduce") SC_SYM(GetErrorString, "ncclGetErrorString")
 #undef SC_SYM
+    CommAbort = reinterpret_cast<decltype(CommAbort)>(dlsym(lib, "ncclCommAbort"));
     return true;
   }
 };
 
-// sense-reversing barrier of the worker threads; also agrees on the worst status so far
+inline void spin_pause() {
+#if defined(__x86_64__)
+  __builtin_ia32_pause();
+#endif
+}
+// spin on `done()`; after a while give the core away between polls (more ranks than cores: the loopback tests)
+template <class F> inline void spin_until(F&& done) {
+  for (uint32_t spins = 0; !done(); spins++) {
+    if (spins < 4096) spin_pause();
+    else std::this_thread::yield();
+  }
+}
+
+// Sense-reversing SPIN barrier of the worker threads; also agrees on the first non-OK status reported this call.
+// Every worker arrives at every barrier of a call, whatever happened to it (it reports its status and skips the work).
 struct Barrier {
-  std::mutex m;
-  std::condition_variable cv;
-  int n = 0, waiting = 0;
-  uint64_t gen = 0;
-  int worst = SC_OK;
-  int arrive(int status) {  // returns the worst status any worker has reported this call
-    std::unique_lock<std::mutex> lk(m);
-    if (status != SC_OK && worst == SC_OK) worst = status;
-    const uint64_t g = gen;
-    if (++waiting == n) { waiting = 0; gen++; cv.notify_all(); }
-    else cv.wait(lk, [&] { return gen != g; });
-    return worst;
+  int n = 0;
+  std::atomic<uint32_t> count{0}, sense{0};
+  std::atomic<int> worst{SC_OK};
+  int arrive(int status) {  // returns the worst status any worker has reported so far this call
+    if (status != SC_OK) { int expected = SC_OK; worst.compare_exchange_strong(expected, status); }
+    const uint32_t s = sense.load(std::memory_order_acquire);
+    if (count.fetch_add(1, std::memory_order_acq_rel) + 1 == (uint32_t)n) {
+      count.store(0, std::memory_order_relaxed);        // before the flip that releases the others
+      sense.store(s + 1, std::memory_order_release);
+    } else {
+      spin_until([&] { return sense.load(std::memory_order_acquire) != s; });
+    }
+    return worst.load(std::memory_order_acquire);
   }
 };
 
@@ -97,26 +125,32 @@ struct sc_multi {
   int n = 0;
   bool loopback = false;
   bool workers = false;  // the rank machinery (phase API + collectives); false: n == 1, plain sc_register
+  std::atomic<bool> broken{false};   // a collective failed on some rank and the communicators were aborted: no further calls
   std::vector<Rank> ranks;
   Rccl rccl;
   Barrier bar;
   std::string last_error;
-  // job hand-off to the workers
+  // job hand-off to the workers: they spin on `job` for a while after a call, then sleep on cv_go
+  std::atomic<uint64_t> job{0};
+  std::atomic<int> running{0}, sleepers{0};
+  std::atomic<bool> quit{false};
   std::mutex m;
-  std::condition_variable cv_go, cv_done;
-  uint64_t job = 0;
-  int running = 0;
-  bool quit = false;
+  std::condition_variable cv_go;
   // the call in flight
   const float *src = nullptr, *tgt = nullptr;
   int64_t npts = 0;
   sc_params params{};
   int cand_level = 0;  // sticky: raised whenever a call came back with SC_ERETRY (candidate blobs too small)
   float* R = nullptr; float* t = nullptr; uint8_t* mask = nullptr;
-  std::vector<uint32_t> hist_host;  // loopback all-reduce
+  // pinned, device-mapped staging (portable: every device reads h_in, rank 0's finalize kernel writes h_out)
+  void* h_in = nullptr; size_t h_in_cap = 0;
+  void* h_out = nullptr; size_t h_out_cap = 0;
+  bool pinned_io = false;  // this call's inputs / outputs go through h_in / h_out
 };
 
 namespace {
+
+constexpr int64_t PINNED_MAX_N = 1 << 20;  // as sc_register: beyond 1 M correspondences plain copies
 
 #define MHIP(rk, expr)                                                                         \
   do {                                                                                         \
@@ -132,49 +166,71 @@ int grow(Rank& rk, void** p, size_t* cap, size_t bytes) {
   return SC_OK;
 }
 
-// ---- transports: in-place all-gather of `per` bytes per rank, and SUM all-reduce of n u32 ----------------------
-int xfer_allgather(sc_multi* M, int r, void* Rank::*buf, size_t per) {
+// ---- RCCL transport: in-place all-gather of `per` bytes per rank / SUM all-reduce of the histogram, on the rank's stream
+int rccl_allgather(sc_multi* M, int r, void* buf, size_t per) {
   Rank& rk = M->ranks[r];
-  char* mine = static_cast<char*>(rk.*buf);
-  if (!M->loopback) {
-    const ncclResult_t e = M->rccl.AllGather(mine + (size_t)r * per, mine, per, ncclUint8, rk.comm, rk.stream);
-    if (e != ncclSuccess) { rk.error = std::string("ncclAllGather: ") + M->rccl.GetErrorString(e); return SC_ERCCL; }
-    return SC_OK;
-  }
-  // loopback: every rank's slice must exist before anyone copies it, and nobody may move on (and overwrite) earlier
-  MHIP(rk, hipStreamSynchronize(rk.stream));
-  M->bar.arrive(SC_OK);
-  for (int q = 0; q < M->n; q++)
-    if (q != r)
-      MHIP(rk, hipMemcpyAsync(mine + (size_t)q * per, static_cast<char*>(M->ranks[q].*buf) + (size_t)q * per, per,
-                              hipMemcpyDeviceToDevice, rk.stream));
-  MHIP(rk, hipStreamSynchronize(rk.stream));
-  M->bar.arrive(SC_OK);
+  char* mine = static_cast<char*>(buf);
+  const ncclResult_t e = M->rccl.AllGather(mine + (size_t)r * per, mine, per, ncclUint8, rk.comm, rk.stream);
+  if (e != ncclSuccess) { rk.error = std::string("ncclAllGather: ") + M->rccl.GetErrorString(e); return SC_ERCCL; }
+  return SC_OK;
+}
+int rccl_allreduce_hist(sc_multi* M, int r) {
+  Rank& rk = M->ranks[r];
+  const ncclResult_t e = M->rccl.AllReduce(rk.hist, rk.hist, SC_HIST_WORDS, ncclUint32, ncclSum, rk.comm, rk.stream);
+  if (e != ncclSuccess) { rk.error = std::string("ncclAllReduce: ") + M->rccl.GetErrorString(e); return SC_ERCCL; }
   return SC_OK;
 }
 
-int xfer_allreduce_hist(sc_multi* M, int r) {
+// ---- loopback transport (all ranks on one device): device copies between the ranks' buffers behind the barrier.
+// `ok`: this rank and, as far as it knows, everybody else is fine — a rank that is not still ARRIVES at both inner
+// barriers (skipping the copies): a missing arrival would deadlock every worker.  Returns this rank's own status.
+template <class Buf> int loop_allgather(sc_multi* M, int r, bool ok, Buf&& buf_of, size_t per) {
   Rank& rk = M->ranks[r];
-  if (!M->loopback) {
-    const ncclResult_t e = M->rccl.AllReduce(rk.hist, rk.hist, SC_HIST_WORDS, ncclUint32, ncclSum, rk.comm, rk.stream);
-    if (e != ncclSuccess) { rk.error = std::string("ncclAllReduce: ") + M->rccl.GetErrorString(e); return SC_ERCCL; }
+  auto step = [&](auto&& body) -> int { return ok ? body() : SC_OK; };
+  // every rank's slice must exist before anyone copies it ...
+  int e = step([&]() -> int { MHIP(rk, hipStreamSynchronize(rk.stream)); return SC_OK; });
+  if (M->bar.arrive(e) != SC_OK) ok = false;
+  int e2 = step([&]() -> int {
+    char* mine = static_cast<char*>(buf_of(rk));
+    for (int q = 0; q < M->n; q++)
+      if (q != r)
+        MHIP(rk, hipMemcpyAsync(mine + (size_t)q * per, static_cast<char*>(buf_of(M->ranks[q])) + (size_t)q * per, per,
+                                hipMemcpyDeviceToDevice, rk.stream));
+    MHIP(rk, hipStreamSynchronize(rk.stream));
     return SC_OK;
-  }
-  MHIP(rk, hipStreamSynchronize(rk.stream));
-  M->bar.arrive(SC_OK);
+  });
+  M->bar.arrive(e2);  // ... and nobody may move on (and overwrite its slice) before everyone has read it
+  return e != SC_OK ? e : e2;
+}
+int loop_allreduce_hist(sc_multi* M, int r, bool ok) {
+  Rank& rk = M->ranks[r];
+  auto step = [&](auto&& body) -> int { return ok ? body() : SC_OK; };
+  int e = step([&]() -> int { MHIP(rk, hipStreamSynchronize(rk.stream)); return SC_OK; });
+  if (M->bar.arrive(e) != SC_OK) ok = false;
   std::vector<uint32_t> sum(SC_HIST_WORDS, 0u), one(SC_HIST_WORDS);
-  for (int q = 0; q < M->n; q++) {
-    MHIP(rk, hipMemcpy(one.data(), M->ranks[q].hist, SC_HIST_WORDS * 4, hipMemcpyDeviceToHost));
-    for (int b = 0; b < SC_HIST_WORDS; b++) sum[b] += one[b];
-  }
-  M->bar.arrive(SC_OK);  // everyone has read every histogram before anyone overwrites its own
-  MHIP(rk, hipMemcpy(rk.hist, sum.data(), SC_HIST_WORDS * 4, hipMemcpyHostToDevice));
-  return SC_OK;
+  int e2 = step([&]() -> int {
+    for (int q = 0; q < M->n; q++) {
+      MHIP(rk, hipMemcpy(one.data(), M->ranks[q].hist, SC_HIST_WORDS * 4, hipMemcpyDeviceToHost));
+      for (int b = 0; b < SC_HIST_WORDS; b++) sum[b] += one[b];
+    }
+    return SC_OK;
+  });
+  if (M->bar.arrive(e2) != SC_OK) ok = false;  // everyone has read every histogram before anyone overwrites its own
+  int e3 = step([&]() -> int { MHIP(rk, hipMemcpy(rk.hist, sum.data(), SC_HIST_WORDS * 4, hipMemcpyHostToDevice)); return SC_OK; });
+  return e != SC_OK ? e : (e2 != SC_OK ? e2 : e3);
+}
+
+// RCCL path, after a collective failed to enqueue on some rank: the others' streams wait for a peer that never joins.
+// Abort the communicators (that ends the stuck kernels) — the handle is unusable afterwards.
+void abort_comms(sc_multi* M, int r) {
+  Rank& rk = M->ranks[r];
+  if (rk.comm && M->rccl.CommAbort) { (void)M->rccl.CommAbort(rk.comm); rk.comm = nullptr; }
+  M->broken.store(true);
 }
 
 // One rank's part of a call.  Every rank reaches the same barriers in the same order whatever happens: a rank that
-// has failed keeps arriving (with its status) and skips the work, and nobody enters a collective unless every rank
-// got there without an error — a collective one rank never joins would hang the others.
+// has failed keeps arriving (with its status) and skips the work; nobody enters a collective unless every rank
+// got there without an error, and every rank knows right after a collective's enqueue whether all enqueues succeeded.
 int run_rank(sc_multi* M, int r) {
   Rank& rk = M->ranks[r];
   const int G = M->n;
@@ -184,73 +240,90 @@ int run_rank(sc_multi* M, int r) {
   p.shard_cand_level = M->cand_level;
   if (p.shard_block == 0) p.shard_block = 1024;
   int rc = SC_OK;
+  bool aborted = false;
   sc_shard_plan plan; plan.size = sizeof plan;
   auto fail_from_ctx = [&](int code) { rk.error = sc_last_error(rk.ctx); return code; };
-  auto phase = [&](auto&& body) {  // run `body` unless somebody failed; then agree
-    if (rc == SC_OK) rc = body();
+  auto compute = [&](auto&& body) {  // a phase of this rank's own work, then agreement BEFORE the collective that follows
+    if (rc == SC_OK && !aborted) rc = body();
     const int worst = M->bar.arrive(rc);
     if (rc == SC_OK && worst != SC_OK) rc = worst;  // another rank failed: stop here too (status of the first failure)
   };
-  phase([&]() -> int {
+  auto collective = [&](auto&& rccl_body, auto&& loop_body) {
+    if (M->loopback) {  // the transport's own barriers: every rank arrives, failed or not
+      const int e = loop_body(rc == SC_OK && !aborted);
+      if (rc == SC_OK) rc = e;
+      const int worst = M->bar.worst.load(std::memory_order_acquire);
+      if (rc == SC_OK && worst != SC_OK) rc = worst;
+      return;
+    }
+    int e = SC_OK;
+    if (rc == SC_OK && !aborted) e = rccl_body();
+    const int worst = M->bar.arrive(e);  // agreement AFTER the enqueue
+    if (rc == SC_OK && e != SC_OK) rc = e;
+    if (worst == SC_ERCCL && !aborted) { abort_comms(M, r); aborted = true; if (rc == SC_OK) rc = SC_ERCCL; }
+    else if (rc == SC_OK && worst != SC_OK) rc = worst;
+  };
+  const float *d_src = nullptr, *d_tgt = nullptr;
+  float* d_Rt = nullptr; uint8_t* d_mask = nullptr;
+  compute([&]() -> int {
     MHIP(rk, hipSetDevice(rk.device));
     int e = sc_shard_plan_query(&p, n, &plan);
     if (e) { rk.error = "bad parameters"; return e; }
     if ((e = grow(rk, &rk.bits, &rk.bits_cap, plan.bits_bytes_total))) return e;
     if ((e = grow(rk, &rk.cand, &rk.cand_cap, (size_t)G * plan.cand_bytes_per_rank))) return e;
-    if ((e = grow(rk, &rk.src, &rk.src_cap, (size_t)n * 12))) return e;
-    if ((e = grow(rk, &rk.tgt, &rk.tgt_cap, (size_t)n * 12))) return e;
-    if ((e = grow(rk, &rk.mask, &rk.mask_cap, (size_t)n))) return e;
-    MHIP(rk, hipMemcpyAsync(rk.src, M->src, (size_t)n * 12, hipMemcpyHostToDevice, rk.stream));
-    MHIP(rk, hipMemcpyAsync(rk.tgt, M->tgt, (size_t)n * 12, hipMemcpyHostToDevice, rk.stream));
-    e = sc_shard_compat_device(rk.ctx, static_cast<const float*>(rk.src), static_cast<const float*>(rk.tgt), n, &p, rk.bits);
+    if (M->pinned_io) {  // every device reads the one pinned host area; rank 0's finalize kernel writes the other
+      void *ds = nullptr, *dout = nullptr;
+      MHIP(rk, hipHostGetDevicePointer(&ds, M->h_in, 0));
+      d_src = static_cast<const float*>(ds); d_tgt = d_src + (size_t)n * 3;
+      if (r == 0) {
+        MHIP(rk, hipHostGetDevicePointer(&dout, M->h_out, 0));
+        d_Rt = static_cast<float*>(dout); d_mask = static_cast<uint8_t*>(dout) + 64;
+      }
+    } else {
+      if ((e = grow(rk, &rk.src, &rk.src_cap, (size_t)n * 12))) return e;
+      if ((e = grow(rk, &rk.tgt, &rk.tgt_cap, (size_t)n * 12))) return e;
+      MHIP(rk, hipMemcpyAsync(rk.src, M->src, (size_t)n * 12, hipMemcpyHostToDevice, rk.stream));
+      MHIP(rk, hipMemcpyAsync(rk.tgt, M->tgt, (size_t)n * 12, hipMemcpyHostToDevice, rk.stream));
+      d_src = static_cast<const float*>(rk.src); d_tgt = static_cast<const float*>(rk.tgt);
+    }
+    if (!d_mask) {  // the other ranks (and big inputs) finalize into device memory of their own
+      if ((e = grow(rk, &rk.mask, &rk.mask_cap, (size_t)n))) return e;
+      d_Rt = rk.Rt; d_mask = static_cast<uint8_t*>(rk.mask);
+    }
+    e = sc_shard_compat_device(rk.ctx, d_src, d_tgt, n, &p, rk.bits);
     return e ? fail_from_ctx(e) : SC_OK;
   });
-  phase([&]() -> int { return xfer_allgather(M, r, &Rank::bits, plan.bits_bytes_per_rank); });
-  phase([&]() -> int { const int e = sc_shard_edges_device(rk.ctx, rk.hist); return e ? fail_from_ctx(e) : SC_OK; });
-  phase([&]() -> int { return xfer_allreduce_hist(M, r); });
-  phase([&]() -> int {
+  collective([&] { return rccl_allgather(M, r, rk.bits, plan.bits_bytes_per_rank); },
+             [&](bool ok) { return loop_allgather(M, r, ok, [](Rank& q) { return q.bits; }, plan.bits_bytes_per_rank); });
+  compute([&]() -> int { const int e = sc_shard_edges_device(rk.ctx, rk.hist); return e ? fail_from_ctx(e) : SC_OK; });
+  collective([&] { return rccl_allreduce_hist(M, r); }, [&](bool ok) { return loop_allreduce_hist(M, r, ok); });
+  compute([&]() -> int {
     const int e = sc_shard_select_device(rk.ctx, rk.hist, static_cast<char*>(rk.cand) + (size_t)r * plan.cand_bytes_per_rank);
     return e ? fail_from_ctx(e) : SC_OK;
   });
-  phase([&]() -> int { return xfer_allgather(M, r, &Rank::cand, plan.cand_bytes_per_rank); });
-  phase([&]() -> int {
+  collective([&] { return rccl_allgather(M, r, rk.cand, plan.cand_bytes_per_rank); },
+             [&](bool ok) { return loop_allgather(M, r, ok, [](Rank& q) { return q.cand; }, plan.cand_bytes_per_rank); });
+  compute([&]() -> int {
     sc_stats st; memset(&st, 0, sizeof st); st.size = sizeof st;
     const int e = sc_shard_score_device(rk.ctx, rk.cand, rk.keys + 2 * r, &st);
     return e ? fail_from_ctx(e) : SC_OK;
   });
-  phase([&]() -> int {
-    // the key pairs: same in-place all-gather, 16 bytes per rank
-    Rank& me = rk;
-    char* mine = reinterpret_cast<char*>(me.keys);
-    if (!M->loopback) {
-      const ncclResult_t e = M->rccl.AllGather(mine + 16 * (size_t)r, mine, 16, ncclUint8, me.comm, me.stream);
-      if (e != ncclSuccess) { me.error = std::string("ncclAllGather: ") + M->rccl.GetErrorString(e); return SC_ERCCL; }
-      return SC_OK;
-    }
-    MHIP(me, hipStreamSynchronize(me.stream));
-    M->bar.arrive(SC_OK);
-    for (int q = 0; q < G; q++)
-      if (q != r)
-        MHIP(me, hipMemcpyAsync(mine + 16 * (size_t)q, reinterpret_cast<char*>(M->ranks[q].keys) + 16 * (size_t)q, 16,
-                                hipMemcpyDeviceToDevice, me.stream));
-    MHIP(me, hipStreamSynchronize(me.stream));
-    M->bar.arrive(SC_OK);
-    return SC_OK;
-  });
+  collective([&] { return rccl_allgather(M, r, rk.keys, 16); },   // the key pairs: 16 bytes per rank
+             [&](bool ok) { return loop_allgather(M, r, ok, [](Rank& q) { return static_cast<void*>(q.keys); }, 16); });
   int fin = SC_OK;
-  phase([&]() -> int {
+  compute([&]() -> int {
     memset(&rk.stats, 0, sizeof rk.stats); rk.stats.size = sizeof rk.stats;
-    fin = sc_finalize_gathered_device(rk.ctx, rk.keys, G, rk.Rt, static_cast<uint8_t*>(rk.mask), &rk.stats);
+    fin = sc_finalize_gathered_device(rk.ctx, rk.keys, G, d_Rt, d_mask, &rk.stats);
     if (fin == SC_ERETRY) { MHIP(rk, hipStreamSynchronize(rk.stream)); return SC_OK; }  // every rank alike: the caller re-runs
     if (fin != SC_OK && fin != SC_ENOHYP) return fail_from_ctx(fin);
-    if (r == 0) {  // rank 0 returns the outputs (every rank holds the same ones)
+    if (r == 0 && !M->pinned_io) {  // rank 0 returns the outputs (every rank holds the same ones)
       float Rt[12];
       MHIP(rk, hipMemcpyAsync(Rt, rk.Rt, 48, hipMemcpyDeviceToHost, rk.stream));
       MHIP(rk, hipMemcpyAsync(M->mask, rk.mask, (size_t)n, hipMemcpyDeviceToHost, rk.stream));
       MHIP(rk, hipStreamSynchronize(rk.stream));
       memcpy(M->R, Rt, 36); memcpy(M->t, Rt + 9, 12);
     } else {
-      MHIP(rk, hipStreamSynchronize(rk.stream));
+      MHIP(rk, hipStreamSynchronize(rk.stream));  // (pinned outputs: the caller's thread copies them out of h_out)
     }
     return SC_OK;
   });
@@ -260,19 +333,51 @@ int run_rank(sc_multi* M, int r) {
 void worker_main(sc_multi* M, int r) {
   uint64_t seen = 0;
   for (;;) {
-    {
-      std::unique_lock<std::mutex> lk(M->m);
-      M->cv_go.wait(lk, [&] { return M->quit || M->job != seen; });
-      if (M->quit) return;
-      seen = M->job;
+    // wait for a job: spin for ~200 us (calls in a row: a registration loop), then sleep
+    const auto t0 = std::chrono::steady_clock::now();
+    uint32_t spins = 0;
+    bool have = false;
+    for (;;) {
+      if (M->quit.load(std::memory_order_acquire)) return;
+      if (M->job.load(std::memory_order_acquire) != seen) { have = true; break; }
+      spin_pause();
+      if ((++spins & 255u) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(200)) break;
     }
+    if (!have) {
+      std::unique_lock<std::mutex> lk(M->m);
+      M->sleepers.fetch_add(1);
+      M->cv_go.wait(lk, [&] { return M->quit.load() || M->job.load() != seen; });
+      M->sleepers.fetch_sub(1);
+      if (M->quit.load()) return;
+    }
+    seen = M->job.load(std::memory_order_acquire);
     M->ranks[r].error.clear();
     M->ranks[r].status = run_rank(M, r);
-    {
-      std::lock_guard<std::mutex> lk(M->m);
-      if (--M->running == 0) M->cv_done.notify_all();
-    }
+    M->running.fetch_sub(1, std::memory_order_acq_rel);
   }
+}
+
+// wake the workers for job number job + 1 and wait until all of them are done with it
+void run_job(sc_multi* M) {
+  M->bar.worst.store(SC_OK, std::memory_order_relaxed);
+  M->running.store(M->n, std::memory_order_relaxed);
+  M->job.fetch_add(1);  // seq_cst: ordered against the sleepers count below (no lost wake-up)
+  if (M->sleepers.load() > 0) {
+    { std::lock_guard<std::mutex> lk(M->m); }  // a worker between its check and its wait holds the mutex
+    M->cv_go.notify_all();
+  }
+  spin_until([&] { return M->running.load(std::memory_order_acquire) == 0; });
+}
+
+int grow_pinned(sc_multi* M, void** p, size_t* cap, size_t want) {
+  if (*cap >= want) return SC_OK;
+  if (*p) { (void)hipHostFree(*p); *p = nullptr; *cap = 0; }  // (no call in flight: the workers are idle)
+  const size_t sz = want + want / 4 + 4096;
+  if (hipHostMalloc(p, sz, hipHostMallocPortable | hipHostMallocMapped) != hipSuccess) {
+    (void)hipGetLastError(); *p = nullptr; M->last_error = "hipHostMalloc failed (staging area)"; return SC_ENOMEM;
+  }
+  *cap = sz;
+  return SC_OK;
 }
 
 int create_common(const int* device_ids, int n_dev, bool loopback, sc_multi** out) {
@@ -334,19 +439,21 @@ void sc_destroy_multi(sc_multi* M) {
   if (!M) return;
   {
     std::lock_guard<std::mutex> lk(M->m);
-    M->quit = true;
+    M->quit.store(true);
   }
   M->cv_go.notify_all();
   for (Rank& rk : M->ranks) if (rk.worker.joinable()) rk.worker.join();
   for (Rank& rk : M->ranks) {
     (void)hipSetDevice(rk.device);
-    if (rk.stream) (void)hipStreamSynchronize(rk.stream);
+    if (rk.stream && !M->broken.load()) (void)hipStreamSynchronize(rk.stream);
     if (rk.comm && M->rccl.CommDestroy) (void)M->rccl.CommDestroy(rk.comm);
     if (rk.ctx) { (void)sc_set_stream(rk.ctx, nullptr); sc_destroy(rk.ctx); }
     for (void* p : {rk.bits, rk.cand, rk.src, rk.tgt, rk.mask, (void*)rk.hist, (void*)rk.keys, (void*)rk.Rt})
       if (p) (void)hipFree(p);
     if (rk.stream) (void)hipStreamDestroy(rk.stream);
   }
+  if (M->h_in) (void)hipHostFree(M->h_in);
+  if (M->h_out) (void)hipHostFree(M->h_out);
   if (M->rccl.lib) dlclose(M->rccl.lib);
   delete M;
 }
@@ -358,19 +465,19 @@ int sc_register_multi(sc_multi* M, const float* src, const float* tgt, int64_t n
   if (!M || !src || !tgt || !p || !R || !t || !mask || n < 3 || n > (1 << 24)) return SC_EINVAL;
   if (p->size != sizeof(sc_params) || p->shard_world != 1) return SC_EINVAL;  // the sharding is this call's business
   if (!M->workers) return sc_register(M->ranks[0].ctx, src, tgt, n, p, R, t, mask, stats);  // no RCCL call at all
+  if (M->broken.load()) { M->last_error = "an earlier collective failed and the communicators were aborted: create a new handle"; return SC_ERCCL; }
   M->src = src; M->tgt = tgt; M->npts = n; M->params = *p; M->R = R; M->t = t; M->mask = mask;
+  M->pinned_io = n <= PINNED_MAX_N;
+  if (M->pinned_io) {  // two memcpys on the caller's thread instead of 2 x n_dev pageable-memory copies
+    (void)hipSetDevice(M->ranks[0].device);
+    int e = grow_pinned(M, &M->h_in, &M->h_in_cap, (size_t)n * 24);
+    if (e == SC_OK) e = grow_pinned(M, &M->h_out, &M->h_out_cap, 64 + (size_t)n);
+    if (e != SC_OK) return e;
+    memcpy(M->h_in, src, (size_t)n * 12);
+    memcpy(static_cast<char*>(M->h_in) + (size_t)n * 12, tgt, (size_t)n * 12);
+  }
   for (int attempt = 0;; attempt++) {
-    M->bar.worst = SC_OK;
-    {
-      std::lock_guard<std::mutex> lk(M->m);
-      M->running = M->n;
-      M->job++;
-    }
-    M->cv_go.notify_all();
-    {
-      std::unique_lock<std::mutex> lk(M->m);
-      M->cv_done.wait(lk, [&] { return M->running == 0; });
-    }
+    run_job(M);
     // SC_ERETRY: a candidate blob was too small for this input.  Every rank sees the same blobs and reports it together;
     // bigger blobs from now on (sticky), and the call runs again.
     bool retry = true;
@@ -387,6 +494,11 @@ int sc_register_multi(sc_multi* M, const float* src, const float* tgt, int64_t n
     }
   }
   if (rc != SC_OK) return rc;
+  if (M->pinned_io) {
+    const float* Rt = static_cast<const float*>(M->h_out);
+    memcpy(R, Rt, 36); memcpy(t, Rt + 9, 12);
+    memcpy(mask, static_cast<const uint8_t*>(M->h_out) + 64, (size_t)n);
+  }
   if (stats && stats->size == sizeof(sc_stats)) {
     *stats = M->ranks[0].stats;
     uint64_t ws = 0; uint32_t scored = 0;

@@ -11,6 +11,8 @@
 //                   compare and one add-with-carry: 17 VALU instructions per test;
 //   grid          = ceil(T/256) x chunks, so a 50k x 5k problem is ~1000 workgroups (~4 waves per SIMD);
 //   partial counts are stored coalesced ([chunk][hypothesis]) and summed by the arg-max kernel.
+#include <vector>
+
 #include "sc_arith.hpp"
 #include "sc_block.hpp"
 #include "sc_kernels.hpp"
@@ -866,6 +868,20 @@ void launch_score_filter(const Points& pts, const float* RtSoA, const float* RtA
   hipLaunchKernelGGL(score_exact_kernel, dim3(FX_NQ * 2), dim3(256), 0, st, pts.planes, pts.n, pts.ld,
                      reinterpret_cast<const float4*>(RtAoS), sh.ld_local, dv.tau2, fp.windows, fp.splits, fp.n_waves, f.queue,
                      f.cap_sq, f.qcount, f.redo, partial);
+}
+
+hipError_t filter_read_counters(const void* state, const FilterPlan& fp, hipStream_t st, uint64_t* undecided, uint64_t* recounts) {
+  const FilterState f = filter_state(const_cast<void*>(state), fp);
+  const size_t bm_words = ((size_t)fp.splits * fp.n_waves + 31) / 32;
+  std::vector<uint32_t> h((size_t)FX_NQ * 32 + bm_words);
+  hipError_t e = hipMemcpyAsync(h.data(), f.qcount, h.size() * 4, hipMemcpyDeviceToHost, st);  // counters, then the bitmap
+  if (e == hipSuccess) e = hipStreamSynchronize(st);
+  if (e != hipSuccess) return e;
+  uint64_t u = 0, r = 0;
+  for (int q = 0; q < FX_NQ; q++) u += h[(size_t)q * 32];  // entries asked for (an overflowing sub-queue counts what was asked)
+  for (size_t w = 0; w < bm_words; w++) r += (uint64_t)__builtin_popcount(h[(size_t)FX_NQ * 32 + w]);
+  *undecided = u; *recounts = r;
+  return hipSuccess;
 }
 
 // Tuning::score_split: share of the hypotheses (in 256ths) scored on the matrix pipe (default 0; experiments)

@@ -83,15 +83,25 @@ def allreduce_hist(d_hist) -> None:
     dist.all_reduce(d_hist, op=dist.ReduceOp.SUM)
 
 
+def _flat_allgather_ok() -> bool:
+    """Which all-gather form this process group takes, decided from the BACKEND NAME — never by trying one form and
+    catching its exception: a RuntimeError raised on one rank only (an asynchronous RCCL error, a watchdog timeout)
+    would send that rank into a different collective from its peers and desynchronise the job instead of ending it.
+    "nccl" (= RCCL on ROCm) has all_gather_into_tensor, also with the output aliasing the input slice; gloo gets the
+    list form."""
+    import torch.distributed as dist
+    return "nccl" in str(dist.get_backend()).lower()
+
+
 def allgather_best(key2, out):
     """ONE all-gather of every rank's 16-byte winner key pair into `out` (int64 tensor of 2 * world entries, rank r's
     pair at out[2r : 2r + 2]) for Registrar.finalize_gathered_device, instead of the two dependent MAX all-reduces of
     allreduce_best.  Without a process group (or world 1) the pair is copied to out[0:2].  No host sync."""
     import torch.distributed as dist
     if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-        try:
+        if _flat_allgather_ok():
             dist.all_gather_into_tensor(out, key2)
-        except (RuntimeError, NotImplementedError):  # a backend without the flat form
+        else:
             dist.all_gather(list(out.view(-1, 2).unbind(0)), key2)
     else:
         out[0:2].copy_(key2)
@@ -110,9 +120,9 @@ def allgather_inplace(buf, rank: int, world: int):
         return buf
     per = buf.numel() // world
     mine = buf[rank * per:(rank + 1) * per]
-    try:
+    if _flat_allgather_ok():
         dist.all_gather_into_tensor(buf, mine)
-    except (RuntimeError, NotImplementedError):
+    else:
         dist.all_gather([buf[r * per:(r + 1) * per] for r in range(world)], mine.clone())
     return buf
 
@@ -152,12 +162,13 @@ class ShardedStep:
         """One call of the path.  SC_ERETRY (a candidate blob was too small; every rank sees the same blobs, so every rank
         gets it together) raises the blob level for good, reallocates the blobs and runs the call again."""
         import torch
+        p = params or self.p
         for _ in range(20):
-            rc, st = self._step_once(d_src, d_tgt, self._with_level(params or self.p))
+            rc, st = self._step_once(d_src, d_tgt, self._with_level(p))
             if rc != self.pkg.SC_ERETRY:
                 return rc, st
             self.level += 1
-            self.plan = self.pkg.shard_plan(self._with_level(self.p), self.n)
+            self.plan = self.pkg.shard_plan(self._with_level(p), self.n)   # the parameters actually in use
             self.cand = torch.zeros(self.world * self.plan.cand_bytes_per_rank // 8, dtype=torch.int64, device=self.device)
         return rc, st
 

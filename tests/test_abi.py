@@ -59,14 +59,15 @@ def test_product_reads_no_environment(pkg):
     und = subprocess.check_output(["nm", "-D", "--undefined-only", pkg.api.LIB_PATH]).decode()
     assert "getenv" not in und
     exe = os.path.join(ROOT, "tests", ".abi_probe_dbg")
-    src = '#include <stdio.h>\n#include <stddef.h>\n#include "saccot.h"\nint main(void){printf("%zu %zu %zu", sizeof(sc_debug), offsetof(sc_debug, sample_edges), offsetof(sc_debug, compat_rows));return 0;}\n'
+    src = '#include <stdio.h>\n#include <stddef.h>\n#include "saccot.h"\nint main(void){printf("%zu %zu %zu %zu %zu", sizeof(sc_debug), offsetof(sc_debug, sample_edges), offsetof(sc_debug, compat_rows), sizeof(sc_debug_info), offsetof(sc_debug_info, filter_recounts));return 0;}\n'
     subprocess.run(["gcc", "-I", os.path.join(ROOT, "include"), "-x", "c", "-", "-o", exe], input=src.encode(), check=True)
     try:
-        a, b, c = (int(x) for x in subprocess.check_output([exe]).decode().split())
+        a, b, c, d, e = (int(x) for x in subprocess.check_output([exe]).decode().split())
     finally:
         os.remove(exe)
-    D = pkg.api.ScDebug
+    D, I = pkg.api.ScDebug, pkg.api.ScDebugInfo
     assert (a, b, c) == (C.sizeof(D), D.sample_edges.offset, D.compat_rows.offset)
+    assert (d, e) == (C.sizeof(I), I.filter_recounts.offset)
 
 
 def test_version_and_strerror(pkg):

@@ -1128,3 +1128,283 @@ def test_score_keeps_the_fp32_kernel_when_tau_is_off_the_filters_scale(pkg, O):
             cnt, key = reg.score(sc.src, sc.tgt, pkg.make_params(**kw), Rt0)
             assert np.array_equal(cnt, cnt0) and key == O.best_key(cnt0), (tau, knobs)
     reg.close()
+
+
+# ---------------------------------------------------------------------------------------------------------
+# the BASELINE shapes in full — every count, and the 8-rank sharded forms
+# ---------------------------------------------------------------------------------------------------------
+_ORACLE_REGISTER = {}
+
+
+def _oracle_register(O, pkg, name):
+    """O.register of a BASELINE config, once per session (C3 is ~4e9 scoring tests on the host)."""
+    if name not in _ORACLE_REGISTER:
+        cfg, scene = pkg.synth.make_config_scene(name)
+        _ORACLE_REGISTER[name] = O.register(scene.src, scene.tgt, threads=min(O.max_threads(), 64), **cfg.params())
+    return _ORACLE_REGISTER[name]
+
+
+@pytest.mark.parametrize("name", ["C2", "C3", "C4"])
+def test_score_every_count_of_the_real_top_T_at_the_baseline_shapes(pkg, O, name):
+    """The C2 stage at the shapes the headline numbers are quoted on, with the hypotheses the path really scores there
+    (Kabsch of the ranked top-T list) and default knobs (so the matrix-pipe filter + exact pass is what runs): ALL T
+    counts against the CPU restatement — not only the winner's, which is all the whole-path tests can see.
+    C2: 50 000 x 5000, C3: 200 000 x 20 000 (4e9 tests), C4: 500 000 x 5000."""
+    cfg, scene = pkg.synth.make_config_scene(name)
+    reg = pkg.Registrar(0)
+    try:
+        p = pkg.make_params(**cfg.params())
+        tri, key, total, edges = reg.triangles(scene.src, scene.tgt, p)
+        assert len(tri) == cfg.T
+        threads = min(O.max_threads(), 64)
+        Rt0 = O.kabsch3(scene.src, scene.tgt, tri, threads=threads)
+        Rt = reg.kabsch(scene.src, scene.tgt, p, tri)
+        assert nan_equal_bits(Rt, Rt0)
+        cnt0 = O.score(scene.src, scene.tgt, Rt0, cfg.tau, threads=threads)
+        cnt, k = reg.score(scene.src, scene.tgt, p, Rt0)
+        bad = np.nonzero(cnt != cnt0)[0]
+        assert bad.size == 0, (name, bad[:10], cnt[bad[:10]], cnt0[bad[:10]])
+        assert k == O.best_key(cnt0)
+        info = reg.debug_last()
+        assert info["c2_kernel"] == 1 and info["filter_undecided"] > 0 and info["filter_recounts"] == 0, info
+        # the plain fp32 kernel at the same shape (what sc_debug.score_filter = 1 and the truncated scores run)
+        reg.set_debug(score_filter=1)
+        cnt1, k1 = reg.score(scene.src, scene.tgt, p, Rt0)
+        assert np.array_equal(cnt1, cnt0) and k1 == k and reg.debug_last()["c2_kernel"] == 0
+        ref = _oracle_register(O, pkg, name)
+        best = 0xFFFFFFFF - (k & 0xFFFFFFFF)
+        assert (best, int(cnt0[best])) == (ref["best_rank"], ref["best_count"])
+    finally:
+        reg.close()
+
+
+@pytest.mark.parametrize("name", ["C3", "C4"])
+def test_sharded_A_and_B_world_8_at_the_configs_it_exists_for(pkg, O, name):
+    """BASELINE configs[3] and [4] in their specified form: 8 ranks, stages A, B and C sharded (phase API; the ranks share
+    the exchange buffers on this one GPU), against the CPU restatement: winner, count, mask, (R,t), and the ranks' row
+    ranges partition the enumeration.  N = 20 000 is also the size at which the look-back ticket aliasing fault of
+    round 2 (fixed in 2fee6e3) occurred."""
+    import torch
+    cfg, scene = pkg.synth.make_config_scene(name)
+    kw = cfg.params()
+    ref = _oracle_register(O, pkg, name)
+    dev = torch.device("cuda:0")
+    d_src = torch.from_numpy(scene.src).to(dev); d_tgt = torch.from_numpy(scene.tgt).to(dev)
+    levels = []
+    rc, st, Rt, mask, hdr = _run_sharded_ab(pkg, cfg.n, kw, d_src, d_tgt, 8, levels_out=levels)
+    assert rc == ref["rc"] == 0 and levels == [0]                       # no SC_ERETRY at the default blob size
+    assert (st["edges"], st["best_rank"], st["best_count"], st["tri_kept"]) == (ref["edges"], ref["best_rank"], ref["best_count"], ref["t_eff"])
+    assert np.array_equal(mask, ref["mask"])
+    assert Rt.tobytes() == np.concatenate([ref["R"].ravel(), ref["t"]]).astype(np.float32).tobytes()
+    assert int(hdr[:, 0].sum()) == st["tri_total"]
+    share = hdr[:, 0].astype(np.float64) / hdr[:, 0].sum()
+    assert share.max() < 2.0 / 8, share
+
+
+# ---------------------------------------------------------------------------------------------------------
+# VERDICT r02 item 1(b): in-range worst cases for the matrix-pipe filter (sc_debug.score_filter = 2)
+# ---------------------------------------------------------------------------------------------------------
+def _filter_eta(p, q, Rt, tau):
+    """The filter's own scale s, shell half-width eta (in scaled units) and eta relative to tau — the formulas of
+    score_filter_kernel / filter_tile_block, with the call-wide max |t| (a wave uses its own 8 hypotheses' max)."""
+    pmax = float(np.abs(p).max()); qmax = float(np.abs(q).max())
+    e = int(np.floor(np.log2(max(pmax, qmax))))
+    s = 2.0 ** (8 - e)
+    tmax = float(np.abs(Rt[:, 9:]).max())
+    eta = (2.6 * pmax * s + qmax * s + tmax * s) / 65536.0
+    return s, eta, eta / (s * tau), pmax * s, qmax * s, tmax * s
+
+
+def _plant(p, Rt, tau, eta_rel, rng, ks=(0.5, 1.0, 2.0)):
+    """q such that correspondence m sits at residual tau * (1 +- k * eta) under hypothesis m mod T (k cycling through
+    `ks`, the sign alternating): q = R p + t - r u, computed in float64 from the fp32 values the kernels see, rounded
+    once to fp32 (that rounding is ~eta / 100).  Returns q and the k of every correspondence."""
+    n, T = len(p), len(Rt)
+    h = np.arange(n) % T
+    R = Rt[h, :9].astype(np.float64).reshape(n, 3, 3); t = Rt[h, 9:].astype(np.float64)
+    u = rng.normal(size=(n, 3)); u /= np.linalg.norm(u, axis=1, keepdims=True)
+    k = np.asarray(ks)[(np.arange(n) // T) % len(ks)]
+    sign = np.where((np.arange(n) // (T * len(ks))) % 2 == 0, 1.0, -1.0)
+    r = tau * (1.0 + sign * k * eta_rel)
+    q = np.einsum("nij,nj->ni", R, p.astype(np.float64)) + t - r[:, None] * u
+    return q.astype(np.float32), k
+
+
+def _check_filter_case(pkg, O, reg, p, q, Rt, tau, k, expect_fast=True):
+    kw = _params(pkg, float(tau), len(Rt))
+    cnt0 = O.score(p, q, Rt, kw["tau"], threads=4)
+    reg.set_debug(score_filter=2, filter_queue_cap=1 << 22)   # (these scenes queue ~1 % of their tests: 10 x a real one)
+    cnt, key = reg.score(p, q, pkg.make_params(**kw), Rt)
+    info = reg.debug_last()
+    bad = np.nonzero(cnt != cnt0)[0]
+    assert bad.size == 0, (bad[:8], cnt[bad[:8]], cnt0[bad[:8]])
+    assert key == O.best_key(cnt0)
+    assert info["c2_kernel"] == 1
+    if expect_fast:
+        assert info["filter_recounts"] == 0, info                      # the filter itself decided: nothing was refused
+        assert info["filter_undecided"] >= 0.9 * (k == 0.5).sum(), info  # ... and the planted shell tests really queued
+    reg.set_debug(score_filter=1)
+    cnt1, _ = reg.score(p, q, pkg.make_params(**kw), Rt)
+    assert np.array_equal(cnt1, cnt0)
+    return cnt0, info
+
+
+def test_score_filter_adversarial_large_R_entries(pkg, O):
+    """Every |R_ij| in [1.3, 1.5) with signs aligned with the points (all positive, points in the positive octant): the
+    row sums reach ~4.4 of the 4.5 the error bound allows for, |R p| is as large as it can get against |p|."""
+    reg = pkg.Registrar(0)
+    rng = np.random.default_rng(11)
+    n, T = 6144, 1024
+    p = rng.uniform(0.35, 1.0, (n, 3)).astype(np.float32)
+    R0 = rng.uniform(1.40, 1.49, (3, 3))
+    Rt = np.zeros((T, 12), dtype=np.float32)
+    Rt[:, :9] = np.clip(R0.ravel()[None, :] + rng.normal(size=(T, 9)) * 2e-3, 1.3, 1.4999).astype(np.float32)
+    Rt[:, 9:] = (np.array([0.3, -0.2, 0.1]) + rng.normal(size=(T, 3)) * 5e-3).astype(np.float32)
+    tau = 0.02
+    q0 = np.einsum("ij,nj->ni", R0, p.astype(np.float64)) + np.array([0.3, -0.2, 0.1])
+    s, eta, eta_rel, Ps, Qs, Ts = _filter_eta(p, q0, Rt, tau)
+    q, k = _plant(p, Rt, tau, eta_rel, rng)
+    assert np.abs(Rt[:, :9]).min() >= 1.3 and np.abs(Rt[:, :9]).max() < 1.5 and np.abs(Rt[:, :9]).reshape(T, 3, 3).sum(2).max() > 4.2
+    assert eta_rel < 0.25 and Qs < 512 and Ps < 512
+    cnt0, info = _check_filter_case(pkg, O, reg, p, q, Rt, tau, k)
+    assert cnt0.max() >= 3
+    reg.close()
+
+
+def test_score_filter_adversarial_large_translation_and_cancellation(pkg, O):
+    """|t| s in [1500, 2048) — as large as the filter accepts — which needs |R p| of the same size to land on a q inside
+    the scaled range: R entries ~1.45, p near (-1.6, -1.6, -1.6): R p + t cancels from ~7 down to a cloud of extent
+    ~0.5, the worst case for every rounding of both evaluations."""
+    reg = pkg.Registrar(0)
+    rng = np.random.default_rng(12)
+    n, T = 6144, 1024
+    R0 = rng.uniform(1.36, 1.49, (3, 3))
+    p0 = np.array([-1.7, -1.5, -1.6])
+    t0 = -R0 @ p0                                              # R0 p0 + t0 = 0: components ~ 6.9
+    p = (p0[None, :] + rng.uniform(-0.06, 0.06, (n, 3))).astype(np.float32)
+    assert 1.0 < np.abs(p).max() < 2.0                         # s = 256
+    Rt = np.zeros((T, 12), dtype=np.float32)
+    Rt[:, :9] = np.clip(R0.ravel()[None, :] + rng.normal(size=(T, 9)) * 1e-3, 1.3, 1.4999).astype(np.float32)
+    Rt[:, 9:] = (t0 + rng.normal(size=(T, 3)) * 3e-3).astype(np.float32)
+    tau = 0.02
+    q0 = np.einsum("ij,nj->ni", R0, p.astype(np.float64)) + t0
+    s, eta, eta_rel, Ps, Qs, Ts = _filter_eta(p, q0, Rt, tau)
+    assert s == 256.0 and 1500.0 <= Ts < 2048.0 and eta_rel < 0.25
+    q, k = _plant(p, Rt, tau, eta_rel, rng)
+    cnt0, info = _check_filter_case(pkg, O, reg, p, q, Rt, tau, k)
+    assert cnt0.max() >= 3
+    reg.close()
+
+
+def test_score_filter_adversarial_large_tau_and_translation(pkg, O):
+    """tau itself near the top of the filter's range (s tau ~ 3100 of 4096) with |t| ~ tau: proper rotations, a small
+    cloud, every residual about |t| — the shell sits at the far end of the scaled range."""
+    reg = pkg.Registrar(0)
+    rng = np.random.default_rng(13)
+    n, T = 6144, 1024
+    p = rng.uniform(-1.3, 1.3, (n, 3)).astype(np.float32)
+    p[0] = (1.5, -1.5, 1.5)
+    t0 = np.array([7.0, -6.5, 7.5])
+    Rt = np.zeros((T, 12), dtype=np.float32)
+    for h in range(T):
+        ax = rng.normal(size=3); ax /= np.linalg.norm(ax); ang = rng.uniform(0, 0.02)
+        K = np.array([[0, -ax[2], ax[1]], [ax[2], 0, -ax[0]], [-ax[1], ax[0], 0]])
+        Rt[h, :9] = (np.eye(3) + np.sin(ang) * K + (1 - np.cos(ang)) * K @ K).astype(np.float32).ravel()
+    Rt[:, 9:] = (t0 + rng.normal(size=(T, 3)) * 2e-2).astype(np.float32)
+    tau = float(np.linalg.norm(t0))                            # 12.13: s tau = 3106
+    # planted: q = R p + t - r u with u ~ t / |t| (+ a little spread), so that q stays a small cloud
+    h = np.arange(n) % T
+    R = Rt[h, :9].astype(np.float64).reshape(n, 3, 3); t = Rt[h, 9:].astype(np.float64)
+    u = t0 / np.linalg.norm(t0) + rng.normal(size=(n, 3)) * 0.01
+    u /= np.linalg.norm(u, axis=1, keepdims=True)
+    s, eta, eta_rel, Ps, Qs, Ts = _filter_eta(p, p, Rt, tau)
+    k = np.asarray((0.5, 1.0, 2.0))[(np.arange(n) // T) % 3]
+    sign = np.where((np.arange(n) // (3 * T)) % 2 == 0, 1.0, -1.0)
+    r = tau * (1.0 + sign * k * eta_rel)
+    q = (np.einsum("nij,nj->ni", R, p.astype(np.float64)) + t - r[:, None] * u).astype(np.float32)
+    s2, eta2, eta_rel2, Ps, Qs, Ts = _filter_eta(p, q, Rt, tau)
+    assert s2 == s == 256.0 and Qs < 512 and 2048 < s * tau <= 4096 and Ts <= 2048 and abs(eta2 - eta) < 0.1 * eta
+    cnt0, info = _check_filter_case(pkg, O, reg, p, q, Rt, tau, k)
+    assert 0.2 * n < cnt0.mean() < 0.8 * n                     # every hypothesis sees about every residual near tau
+    reg.close()
+
+
+@pytest.mark.parametrize("flat", [1e-6, 3e-5])
+def test_score_filter_adversarial_near_planar_cloud(pkg, O, flat):
+    """One coordinate `flat` times the others (a near-planar cloud, both sides): its scaled values sit at 5e-4 .. 1.5e-2,
+    so the fp16 low halves of the split are sub-normal (or flush to zero in the matrix pipe) — the case the bound's
+    comment only estimates."""
+    reg = pkg.Registrar(0)
+    rng = np.random.default_rng(14)
+    n, T = 6144, 1024
+    p = rng.uniform(-1.0, 1.0, (n, 3)); p[:, 2] *= flat
+    p = p.astype(np.float32)
+    Rt = np.zeros((T, 12), dtype=np.float32)
+    for h in range(T):
+        ang = 0.7 + rng.normal() * 2e-3; c, s_ = np.cos(ang), np.sin(ang)
+        N = rng.normal(size=(3, 3)) * 1e-4; N[2, :2] *= flat          # (nothing may lift the cloud out of its plane)
+        Rz = np.array([[c, -s_, 0], [s_, c, 0], [0, 0, 1.0]]) + N
+        Rt[h, :9] = Rz.astype(np.float32).ravel()
+    Rt[:, 9:] = (np.array([0.2, -0.1, 0.0]) + rng.normal(size=(T, 3)) * np.array([4e-3, 4e-3, 4e-3 * flat])).astype(np.float32)
+    tau = 0.01
+    s, eta, eta_rel, Ps, Qs, Ts = _filter_eta(p, p * 1.3, Rt, tau)
+    # planted in the plane (u_z scaled like the cloud), so that q stays near-planar too
+    h = np.arange(n) % T
+    R = Rt[h, :9].astype(np.float64).reshape(n, 3, 3); t = Rt[h, 9:].astype(np.float64)
+    u = rng.normal(size=(n, 3)); u[:, 2] *= flat; u /= np.linalg.norm(u, axis=1, keepdims=True)
+    k = np.asarray((0.5, 1.0, 2.0))[(np.arange(n) // T) % 3]
+    sign = np.where((np.arange(n) // (3 * T)) % 2 == 0, 1.0, -1.0)
+    r = tau * (1.0 + sign * k * eta_rel)
+    q = (np.einsum("nij,nj->ni", R, p.astype(np.float64)) + t - r[:, None] * u).astype(np.float32)
+    assert np.abs(q[:, 2]).max() < 20 * flat
+    s2, eta2, eta_rel2, Ps, Qs, Ts = _filter_eta(p, q, Rt, tau)
+    assert s2 == s and abs(eta2 - eta) < 0.25 * eta
+    cnt0, info = _check_filter_case(pkg, O, reg, p, q, Rt, tau, k)
+    reg.close()
+
+
+def test_score_filter_adversarial_one_far_outlier_sets_the_scale(pkg, O):
+    """A single correspondence 150 x further out than the cloud sets the power-of-two scale: the cloud's scaled
+    coordinates drop to ~2, its fp16 low halves to 1e-3 — and tau, still in range, is only ~6 eta."""
+    reg = pkg.Registrar(0)
+    rng = np.random.default_rng(15)
+    n, T = 6144, 1024
+    p = rng.uniform(-1.0, 1.0, (n, 3)).astype(np.float32)
+    p[n - 1] = (150.0, -20.0, 30.0)
+    Rt = np.zeros((T, 12), dtype=np.float32)
+    ax = np.array([0.3, -0.5, 0.8]); ax /= np.linalg.norm(ax)
+    for h in range(T):
+        ang = 1.1 + rng.normal() * 0.3                    # (hypotheses far apart against tau: the shell is 9 % of tau wide here)
+        K = np.array([[0, -ax[2], ax[1]], [ax[2], 0, -ax[0]], [-ax[1], ax[0], 0]])
+        Rt[h, :9] = (np.eye(3) + np.sin(ang) * K + (1 - np.cos(ang)) * K @ K).astype(np.float32).ravel()
+    Rt[:, 9:] = (np.array([0.1, 0.2, -0.3]) + rng.normal(size=(T, 3)) * 0.5).astype(np.float32)
+    tau = 0.1
+    q0 = np.einsum("ij,nj->ni", Rt[0, :9].astype(np.float64).reshape(3, 3), p.astype(np.float64)) + Rt[0, 9:]
+    s, eta, eta_rel, Ps, Qs, Ts = _filter_eta(p, q0, Rt, tau)
+    assert s <= 2.0 and eta_rel < 0.25, (s, eta_rel)
+    q, k = _plant(p, Rt, tau, eta_rel, rng)
+    s2, eta2, _, Ps, Qs, Ts = _filter_eta(p, q, Rt, tau)
+    assert s2 == s and Qs < 512
+    cnt0, info = _check_filter_case(pkg, O, reg, p, q, Rt, tau, k)
+    assert cnt0.max() >= 3
+    reg.close()
+
+
+def test_score_kernel_choice_without_the_maxima(pkg, O):
+    """The host decides ONCE per call which C2 kernel runs (sc_capi.hip decide_filter) from the coordinate maxima the
+    staging kernel publishes; sc_debug.filter_blind makes it decide as if they had not arrived: it then assumes the
+    filter applies, and with tau off the filter's scale every wave hands its work to the exact recount — same counts.
+    With the maxima (the default; the stage hook waits for them) the same call keeps the plain kernel."""
+    reg = pkg.Registrar(0)
+    n, T = 70_000, 2048
+    sc = _scene(pkg, n, seed=13)
+    Rt0 = _hyps_near_truth(O, sc, T, seed=9)
+    kw = _params(pkg, 1e-5, T)
+    cnt0 = O.score(sc.src, sc.tgt, Rt0, kw["tau"], threads=8)
+    cnt, _ = reg.score(sc.src, sc.tgt, pkg.make_params(**kw), Rt0)
+    assert np.array_equal(cnt, cnt0) and reg.debug_last()["c2_kernel"] == 0
+    reg.set_debug(filter_blind=1)
+    cnt, _ = reg.score(sc.src, sc.tgt, pkg.make_params(**kw), Rt0)
+    info = reg.debug_last()
+    assert np.array_equal(cnt, cnt0) and info["c2_kernel"] == 1 and info["filter_recounts"] == T // 8 * info["filter_splits"], info
+    reg.close()
