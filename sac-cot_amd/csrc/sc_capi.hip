@@ -29,7 +29,7 @@ struct Buf {
 };
 
 constexpr int N_EVENTS = 12;  // 0..8 stage brackets, 9..10 the key kernel (all reused by calibrate_events)
-constexpr int N_PINNED = 16;
+constexpr int N_PINNED = 32;  // [16..21]: the bounding boxes of the two clouds (stage_points_kernel)
 
 }  // namespace
 
@@ -46,10 +46,10 @@ struct sc_ctx {
   // workspace
   Buf in_src, in_tgt, planes, S, bits, deg, degp, wpre, ebase, edge_off, scan_tmp, ei, ej, es, ebi, ebj, tcnt, toff, wkey, kcol, ctl, events, blk_gt,
       blk_eq, blk_minmax, bits2, off_gt, off_eq, sel_ord, sel_key, sortkey, sorted, sort_tmp, tri, tri_rk, key_rk, rt, rt_aos, partial, cnt, key, rt12,
-      mask, refine_tmp, amx_pairs, strong, rowcost, cost_pre, lb_state, lb_ticket, fx_tile, fx_state, fx_mx;
-  bool filter_on = false;   // C2 of the running / last call goes through the matrix-pipe filter (decided ONCE per call)
+      mask, refine_tmp, amx_pairs, strong, rowcost, cost_pre, lb_state, lb_ticket, fx_tile, fx_state, fx_mx, fx_part;
+  bool filter_on = false;   // C2 of the running / last call goes through a matrix-pipe filter (decided ONCE per call)
+  int filter_mode = 0;      // ... which: 1 linear, 2 Gram (0: the plain fp32 kernel)
   FilterPlan fx_plan{};     // ... with this plan (sc_debug_last reads the filter's counters through it)
-  int fx_parity = 0;  // which pair of fx_mx this call's staging kernel fills (the filter's tile kernel clears the other)
   // sc_register (host arrays in, host arrays out): pinned, device-mapped staging areas — the staging kernel reads the
   // correspondences straight from host memory and the finalize kernel writes (R, t, mask) straight into it: no copies
   void* h_in = nullptr; size_t h_in_cap = 0;
@@ -250,16 +250,16 @@ int stage_inputs(sc_ctx* c, const float* d_src, const float* d_tgt, int64_t n, c
   ENSURE(c, c->ctl, sizeof(ControlBlock));
   static_assert(sizeof(ControlBlock) % 4 == 0, "cleared word-wise");
   c->pinned[1] = 0;  // "non-finite input" flag lives in host-pinned memory: the kernel only touches it on bad data
-  if (!c->fx_mx.p) {  // coordinate maxima for C2's filter: two pairs that alternate from call to call, + a ticket
-    ENSURE(c, c->fx_mx, 32);
-    HIPCHK(c, hipMemsetAsync(c->fx_mx.p, 0, 32, c->stream));
+  if (!c->fx_mx.p) {  // coordinate statistics for C2's filters (written whole by every call's staging kernel) + its ticket
+    ENSURE(c, c->fx_mx, (FX_MX_WORDS + 1) * 4);
+    HIPCHK(c, hipMemsetAsync(c->fx_mx.p, 0, (FX_MX_WORDS + 1) * 4, c->stream));
   }
-  c->fx_parity ^= 1;
+  ENSURE(c, c->fx_part, stage_part_words(c->ld) * 4);
   c->pinned[13] = ~0ull;  // "maxima not known yet"
   launch_stage_points(d_src, d_tgt, c->n, c->ld, p->layout, c->planes.as<float>(),
                       reinterpret_cast<uint32_t*>(&c->pinned[1]), c->ctl.as<uint32_t>(),
-                      (uint32_t)(sizeof(ControlBlock) / 4), c->fx_mx.as<uint32_t>() + 2 * c->fx_parity,
-                      c->fx_mx.as<uint32_t>() + 2 * (c->fx_parity ^ 1), c->fx_mx.as<uint32_t>() + 4, &c->pinned[13], c->stream);
+                      (uint32_t)(sizeof(ControlBlock) / 4), c->fx_mx.as<uint32_t>(), c->fx_part.as<uint32_t>(),
+                      c->fx_mx.as<uint32_t>() + FX_MX_WORDS, &c->pinned[13], &c->pinned[16], c->stream);
   return SC_OK;
 }
 
@@ -703,7 +703,7 @@ void sc_destroy(sc_ctx* c) {
   Buf* bufs[] = {&c->in_src, &c->in_tgt, &c->planes, &c->S, &c->bits, &c->deg, &c->degp, &c->wpre, &c->ebase, &c->edge_off, &c->scan_tmp,
                  &c->ei, &c->ej, &c->es, &c->ebi, &c->ebj, &c->tcnt, &c->toff, &c->wkey, &c->kcol, &c->ctl, &c->events, &c->blk_gt, &c->blk_eq, &c->blk_minmax, &c->bits2, &c->off_gt,
                  &c->off_eq, &c->sel_ord, &c->sel_key, &c->sortkey, &c->sorted, &c->sort_tmp, &c->tri, &c->tri_rk, &c->key_rk, &c->rt,
-                 &c->rt_aos, &c->partial, &c->cnt, &c->key, &c->rt12, &c->mask, &c->refine_tmp, &c->amx_pairs, &c->strong, &c->rowcost, &c->cost_pre, &c->lb_state, &c->lb_ticket};
+                 &c->rt_aos, &c->partial, &c->cnt, &c->key, &c->rt12, &c->mask, &c->refine_tmp, &c->amx_pairs, &c->strong, &c->rowcost, &c->cost_pre, &c->lb_state, &c->lb_ticket, &c->fx_tile, &c->fx_state, &c->fx_mx, &c->fx_part};
   for (Buf* b : bufs) if (b->p) (void)hipFree(b->p);
   for (int i = 0; i < N_EVENTS; i++) if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
   if (c->pinned) (void)hipHostFree(c->pinned);
@@ -755,11 +755,12 @@ int sc_set_debug(sc_ctx* c, const sc_debug* d) {
   t.rows_unfused = d->rows_unfused != 0;
   t.score_scalar = d->score_scalar != 0;
   t.es_hist_unfused = d->es_hist_unfused != 0;
-  t.score_filter = d->score_filter <= 2 ? d->score_filter : 0u;
+  t.score_filter = d->score_filter <= 3 ? d->score_filter : 0u;
   t.filter_splits = d->filter_splits;
   t.filter_queue_cap = d->filter_queue_cap;
   t.filter_lds_queue = d->filter_lds_queue;
   t.filter_blind = d->filter_blind != 0;
+  t.filter_variant = d->filter_variant;
   c->tn = t;
   return SC_OK;
 }
@@ -768,7 +769,7 @@ int sc_debug_last(sc_ctx* c, sc_debug_info* out) {
   if (!c || !out || out->size != sizeof(sc_debug_info)) return SC_EINVAL;
   HIPCHK(c, hipSetDevice(c->device));
   HIPCHK(c, hipStreamSynchronize(c->stream));
-  out->c2_kernel = c->filter_on ? 1u : 0u;
+  out->c2_kernel = c->filter_on ? (uint32_t)c->filter_mode : 0u;
   out->filter_splits = c->filter_on ? c->fx_plan.splits : 0u;
   out->filter_undecided = 0; out->filter_recounts = 0;
   if (c->filter_on && c->fx_state.p)
@@ -818,14 +819,18 @@ int run_stage_c(sc_ctx* c, uint64_t* d_key, sc_stats* stats);
 // later kernels of the same stream); the stage hook waits for the word.  Not known (sc_debug.filter_blind forces that
 // case) means "assume in range": the filter itself hands whatever it cannot bound to the exact recount, so the counts
 // are the same either way, only slower.
-bool use_filter(const sc_ctx* c, const sc_params* p, const Shard& sh) {
-  if (!score_uses_filter(p->score_mode, c->tn, c->n, sh.ld_local)) return false;
-  const uint64_t mx = c->tn.filter_blind ? ~0ull : *const_cast<volatile uint64_t*>(&c->pinned[13]);
-  return c->tn.score_filter == 2 || filter_in_range(mx, c->dv.tau2);
+int use_filter(const sc_ctx* c, const sc_params* p, const Shard& sh) {
+  const bool blind = c->tn.filter_blind;
+  const uint64_t mx = blind ? ~0ull : *const_cast<volatile uint64_t*>(&c->pinned[13]);
+  uint64_t box[6];
+  for (int k = 0; k < 6; k++) box[k] = *const_cast<volatile uint64_t*>(&c->pinned[16 + k]);  // (written before pinned[13])
+  std::atomic_thread_fence(std::memory_order_acquire);
+  return score_filter_mode(p->score_mode, c->tn, c->n, sh.ld_local, mx, (blind || mx == ~0ull) ? nullptr : box, c->dv.tau2);
 }
 void decide_filter(sc_ctx* c, const sc_params* p, const Shard& sh) {
-  c->filter_on = use_filter(c, p, sh);
-  if (c->filter_on) c->fx_plan = filter_plan(c->n, sh.ld_local, c->tn);
+  c->filter_mode = use_filter(c, p, sh);
+  c->filter_on = c->filter_mode != 0;
+  if (c->filter_on) c->fx_plan = filter_plan(c->n, sh.ld_local, c->tn, (uint32_t)c->filter_mode);
 }
 
 // the filter's buffers for this shard, and the job that fills the tile / clears the state
@@ -834,7 +839,7 @@ int filter_job(sc_ctx* c, const Shard& sh, FilterTileJob* job) {
   ENSURE(c, c->fx_tile, fp.tile_bytes);
   ENSURE(c, c->fx_state, fp.state_bytes);
   uint32_t* mx = c->fx_mx.as<uint32_t>();
-  *job = filter_tile_job(fp, mx + 2 * c->fx_parity, mx + 2 * (c->fx_parity ^ 1), c->fx_tile.p, c->fx_state.p);
+  *job = filter_tile_job(fp, mx, nullptr, c->fx_tile.p, c->fx_state.p);
   return SC_OK;
 }
 
@@ -895,7 +900,7 @@ int run_stage_c(sc_ctx* c, uint64_t* d_key, sc_stats* stats) {
     launch_kabsch(points_of(c), tri_source_of(c), sh, c->rt.as<float>(), aos ? c->rt_aos.as<float>() : nullptr,
                   filter ? &job : nullptr, c->stream);
   } else {
-    c->filter_on = false;
+    c->filter_on = false; c->filter_mode = 0;
   }
   if ((rc = rec(c, 4))) return rc;
   uint32_t score_rows = 0;

@@ -19,9 +19,10 @@ __global__ __launch_bounds__(256) void stage_points_kernel(const float* __restri
                                                            uint32_t* __restrict__ bad_flag,
                                                            uint32_t* __restrict__ zero, uint32_t zero_words,
                                                            uint32_t* __restrict__ coord_max,
-                                                           uint32_t* __restrict__ coord_max_next,
+                                                           uint32_t* __restrict__ coord_part,
                                                            uint32_t* __restrict__ mx_ticket,
-                                                           uint64_t* __restrict__ host_max) {
+                                                           uint64_t* __restrict__ host_max,
+                                                           uint64_t* __restrict__ host_box) {
   int m = blockIdx.x * 256 + threadIdx.x;
   for (uint32_t z = (uint32_t)m; z < zero_words; z += gridDim.x * 256) zero[z] = 0u;  // the per-call control block
   float v[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -37,27 +38,62 @@ __global__ __launch_bounds__(256) void stage_points_kernel(const float* __restri
     for (int c = 0; c < 6; c++) ok = ok && (fabsf(v[c]) < __builtin_inff());
     if (!ok) atomicOr(bad_flag, 1u);
   }
-  if (coord_max) {  // largest |coordinate| of either cloud (C2's filter scales by it); non-negative floats order as integers
-    float mp = fmaxf(fabsf(v[0]), fmaxf(fabsf(v[1]), fabsf(v[2]))), mq = fmaxf(fabsf(v[3]), fmaxf(fabsf(v[4]), fabsf(v[5])));
+  if (coord_max) {  // largest |coordinate| of either cloud and the two bounding boxes (C2's filters scale and centre by them)
+    // coord_max: FX_MX_WORDS words — [0] max |p|, [1] max |q| (non-negative floats order as integers), [2 + c] key(max of
+    // coordinate c), [8 + c] key(max of MINUS coordinate c), c = px py pz qx qy qz (float_key orders all floats as
+    // unsigned integers, key 0 = "nothing yet").  Pad lanes (m >= n) contribute nothing to the boxes.
+    // No same-address atomics (14 words of one cache line from every wave: 15 us): every block leaves its 14 maxima in
+    // its own row of coord_part; the block that takes the last ticket reduces the rows.
+    __shared__ uint32_t red[4][14];
+    uint32_t k14[14];
+    k14[0] = __float_as_uint(fmaxf(fabsf(v[0]), fmaxf(fabsf(v[1]), fabsf(v[2]))));
+    k14[1] = __float_as_uint(fmaxf(fabsf(v[3]), fmaxf(fabsf(v[4]), fabsf(v[5]))));
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) { mp = fmaxf(mp, __shfl_xor(mp, o)); mq = fmaxf(mq, __shfl_xor(mq, o)); }
-    if ((threadIdx.x & 63) == 0) { atomicMax(&coord_max[0], __float_as_uint(mp)); atomicMax(&coord_max[1], __float_as_uint(mq)); }
-    // the block that takes the last ticket tells the HOST the two maxima (max |q| << 32 | max |p|, bit patterns): the
-    // host decides from them whether C2's filter can work at this tau (sc_capi.hip run_stage_c); nothing waits for it
+    for (int c = 0; c < 6; c++) { k14[2 + c] = m < n ? float_key(v[c]) : 0u; k14[8 + c] = m < n ? float_key(-v[c]) : 0u; }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1)
+#pragma unroll
+      for (int c = 0; c < 14; c++) k14[c] = max(k14[c], (uint32_t)__shfl_xor(k14[c], o));
+    if ((threadIdx.x & 63) == 0)
+#pragma unroll
+      for (int c = 0; c < 14; c++) red[threadIdx.x >> 6][c] = k14[c];
+    __syncthreads();
+    if (threadIdx.x < 14)
+      coord_part[(size_t)blockIdx.x * 16 + threadIdx.x] = max(max(red[0][threadIdx.x], red[1][threadIdx.x]), max(red[2][threadIdx.x], red[3][threadIdx.x]));
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+    __shared__ uint32_t s_last;
     if (threadIdx.x == 0) {
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
       const uint32_t t = __hip_atomic_fetch_add(mx_ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if (t == gridDim.x - 1) {
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        const uint32_t a = __hip_atomic_load(&coord_max[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const uint32_t b = __hip_atomic_load(&coord_max[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      s_last = (t == gridDim.x - 1) ? 1u : 0u;
+      if (s_last) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    }
+    __syncthreads();
+    if (s_last) {  // (block-uniform) the last block: reduce the rows, publish
+      __shared__ uint32_t fin[16][16];
+      const uint32_t c = threadIdx.x & 15, r0 = threadIdx.x >> 4;  // 16 row groups x 16 words
+      uint32_t best = 0;
+      if (c < 14)
+        for (uint32_t r = r0; r < gridDim.x; r += 16)
+          best = max(best, __hip_atomic_load(&coord_part[(size_t)r * 16 + c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+      fin[r0][c] = best;
+      __syncthreads();
+      if (threadIdx.x < 14) {
+        uint32_t b2 = 0;
+        for (int r = 0; r < 16; r++) b2 = max(b2, fin[r][threadIdx.x]);
+        coord_max[threadIdx.x] = b2;   // (plain stores: the next kernels of the stream read them)
+        fin[0][threadIdx.x] = b2;
+      }
+      __syncthreads();
+      if (threadIdx.x == 0) {
+        // the host gets the two maxima (max |q| << 32 | max |p|, bit patterns) and the boxes: it decides from them which C2
+        // kernel can work at this tau (sc_capi.hip decide_filter); nothing waits for it
+        if (host_box)
+          for (int k = 0; k < 6; k++)  // (relaxed system-scope stores: the release of host_max below orders them)
+            __hip_atomic_store(&host_box[k], ((uint64_t)fin[0][8 + k] << 32) | fin[0][2 + k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         __hip_atomic_store(mx_ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // ready for the next call
-        // ... and so is the OTHER pair, which the next call accumulates into (nobody touches it during this one); done
-        // here, on every call, so that a maximum never outlives its scene
-        coord_max_next[0] = 0u; coord_max_next[1] = 0u;
-        publish_host(host_max, ((uint64_t)b << 32) | a);
+        publish_host(host_max, ((uint64_t)fin[0][1] << 32) | fin[0][0]);  // last: the host takes this word as "the boxes are there too"
       }
     }
   }
@@ -72,10 +108,10 @@ __global__ __launch_bounds__(256) void stage_points_kernel(const float* __restri
 }
 
 void launch_stage_points(const float* d_src, const float* d_tgt, int n, int ld, int layout, float* planes,
-                         uint32_t* bad_flag, uint32_t* zero, uint32_t zero_words, uint32_t* coord_max, uint32_t* coord_max_next,
-                         uint32_t* mx_ticket, uint64_t* host_max, hipStream_t st) {
+                         uint32_t* bad_flag, uint32_t* zero, uint32_t zero_words, uint32_t* coord_max, uint32_t* coord_part,
+                         uint32_t* mx_ticket, uint64_t* host_max, uint64_t* host_box, hipStream_t st) {
   hipLaunchKernelGGL(stage_points_kernel, dim3((ld + 255) / 256), dim3(256), 0, st, d_src, d_tgt, n, ld, layout,
-                     planes, bad_flag, zero, zero_words, coord_max, coord_max_next, mx_ticket, host_max);
+                     planes, bad_flag, zero, zero_words, coord_max, coord_part, mx_ticket, host_max, host_box);
 }
 
 // ------------------------------------------------------------------------------------------------

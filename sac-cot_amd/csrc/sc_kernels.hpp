@@ -36,10 +36,11 @@ struct Tuning {
   bool score_scalar = false;       // C2: count inliers with the lane = correspondence kernel (coefficients as scalar operands)
   uint64_t sample_edges = 0;       // edges of the pruning sample (0: automatic, ~5T/8)
   uint32_t score_split = 0;        // share (of 256) of the hypotheses scored on the matrix pipe
-  uint32_t score_filter = 0;       // C2, inlier count: 0 = matrix-pipe filter + exact fix-up from ~1.3e8 tests up, 1 = never, 2 = always
+  uint32_t score_filter = 0;       // C2, inlier count: 0 = by size and scale (plain kernel / linear filter / Gram filter), 1 = plain kernel, 2 = linear filter, 3 = Gram filter
   uint32_t filter_splits = 0;      // grid.y of the filter (0: by size)
   uint32_t filter_queue_cap = 0;   // entries of the filter's global queue (0: by size; tests force overflows with a small one)
   uint32_t filter_lds_queue = 0;   // entries of a wave's LDS queue, 64 .. 256 (0: 256)
+  uint32_t filter_variant = 0;     // body of the filter kernel (sc_score.hip): 0 default, bit-identical scheduling variants, >= 16 timing-only ablations
   bool filter_blind = false;       // the host decides C2's kernel WITHOUT the coordinate maxima (as if they had not arrived yet)
   bool compat_one_phase = false;   // exact chain on every pair of an interior tile
   int compat_rows = 0;             // tile height of stage A: 0 = by size (16 below 10 000 correspondences, 32 from there), 16, 32, 64
@@ -74,9 +75,25 @@ struct Points {
 // coord_max (optional, 2 x u32): atomicMax of the bit patterns of max |src coordinate| and max |tgt coordinate|; with it:
 // coord_max_next (the pair the NEXT call uses: cleared by the last block), mx_ticket (a zeroed u32, left zero) and
 // host_max (pinned u64: receives max|tgt| << 32 | max|src| once every block is done).
+// The coordinate statistics are FX_MX_WORDS u32 (coord_max, WRITTEN — not accumulated — by the last block of the launch):
+// [0] max |src coordinate|, [1] max |tgt coordinate| (bit patterns), [2 + c] / [8 + c]: float_key of the largest / of minus
+// the smallest value of coordinate c (px py pz qx qy qz): the bounding boxes.  coord_part: 16 u32 per block of the launch
+// (stage_part_words(ld)), scratch.  host_box (pinned, 6 x u64, optional): (key of -min) << 32 | key of max per
+// coordinate, written before host_max.
+constexpr int FX_MX_WORDS = 16;
+inline size_t stage_part_words(int ld) { return (size_t)((ld + 255) / 256) * 16; }
 void launch_stage_points(const float* d_src, const float* d_tgt, int n, int ld, int layout, float* planes,
-                         uint32_t* bad_flag, uint32_t* zero, uint32_t zero_words, uint32_t* coord_max, uint32_t* coord_max_next,
-                         uint32_t* mx_ticket, uint64_t* host_max, hipStream_t st);
+                         uint32_t* bad_flag, uint32_t* zero, uint32_t zero_words, uint32_t* coord_max, uint32_t* coord_part,
+                         uint32_t* mx_ticket, uint64_t* host_max, uint64_t* host_box, hipStream_t st);
+// order-preserving map float -> u32 (all finite floats and infinities; 0 is below every float) and back
+__host__ __device__ inline uint32_t float_key(float f) {
+  union { float f; uint32_t u; } x; x.f = f;
+  return (x.u & 0x80000000u) ? ~x.u : (x.u | 0x80000000u);
+}
+__host__ __device__ inline float float_unkey(uint32_t k) {
+  union { float f; uint32_t u; } x; x.u = (k & 0x80000000u) ? (k & 0x7FFFFFFFu) : ~k;
+  return x.f;
+}
 // can C2's filter bound its error at this tau?  (the host-side twin of the test every wave of the filter makes; maxima as
 // the staging kernel published them, ~0 = not known: assume yes)
 bool filter_in_range(uint64_t host_max, float tau2);
@@ -368,14 +385,26 @@ void launch_score(const Points& pts, const float* RtSoA, const float* RtAoS, con
 // The tile (fp16 image of the correspondences) depends on the points only: launch_filter_tile runs once per call, any
 // time after launch_stage_points (whose atomicMax fills mx_cur); mx_cur / mx_next are two u32 pairs that alternate
 // from call to call (the tile kernel clears the next call's).  partial: fp.splits rows of ld_local counts.
+// Two filters share the machinery (tile of the correspondences, queue of undecided tests, recount bitmap, exact pass):
+//   mode 1, "linear":  the MFMA gives the three residual components of 8 hypotheses x 32 correspondences, the vector
+//                      pipe squares and tests them (4.75 vector instructions per test);
+//   mode 2, "Gram":    the MFMA gives the SQUARED residual itself — |R p + t - q|^2 expanded into a 48-term dot product
+//                      of per-correspondence features and per-hypothesis coefficients, 32 hypotheses x 32 correspondences
+//                      per three chained MFMAs — and the vector pipe only tests its sign (1.6 instructions per test).
+//                      Squaring by inner products cancels: usable while tau is not too small against the clouds' extent.
 struct FilterPlan {
+  uint32_t mode;  // 1 linear, 2 Gram
   uint32_t windows, splits, n_waves, rows, queue_cap;
   size_t tile_bytes, state_bytes;
 };
-bool score_uses_filter(int score_mode, const Tuning& tn, int n, uint32_t ld_local);
-FilterPlan filter_plan(int n, uint32_t ld_local, const Tuning& tn);
+// which kernel stage C2 runs: 0 = plain fp32 kernel, 1 = linear filter, 2 = Gram filter.  By score mode, size, the knobs of
+// sc_debug and — unless forced — by whether tau is on a scale the filter can bound (host_max / host_box: the coordinate
+// maxima and bounding boxes the staging kernel published; ~0 = not known: assume the linear filter applies, never Gram).
+int score_filter_mode(int score_mode, const Tuning& tn, int n, uint32_t ld_local, uint64_t host_max, const uint64_t* host_box,
+                      float tau2);
+FilterPlan filter_plan(int n, uint32_t ld_local, const Tuning& tn, uint32_t mode);
 struct FilterTileJob {  // what the tile kernel needs (filter_tile_job fills it)
-  uint32_t rows; const uint32_t* mx_cur; uint32_t* mx_next; void* tile; void* info; uint32_t* zero; uint32_t zero_words;
+  uint32_t rows; const uint32_t* mx_cur; uint32_t* mx_next; void* tile; void* info; uint32_t* zero; uint32_t zero_words; uint32_t mode;
 };
 FilterTileJob filter_tile_job(const FilterPlan& fp, const uint32_t* mx_cur, uint32_t* mx_next, void* tile, void* state);
 void launch_filter_tile(const Points& pts, const FilterTileJob& job, hipStream_t st);  // on its own (stage hook sc_score_host)

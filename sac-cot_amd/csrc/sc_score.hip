@@ -529,15 +529,92 @@ static FilterState filter_state(void* state, const FilterPlan& fp) {
   return f;
 }
 
-// The filter pays a tile kernel, an exact pass and a few microseconds of set-up per workgroup: below ~1.3e8 tests the
-// plain kernel is as fast or faster (C1, 2e7 tests: 9 us plain, 20 us filtered; C2, 2.5e8: 86 -> 73; C3, 4e9: 1200 -> 835).
-bool score_uses_filter(int score_mode, const Tuning& tn, int n, uint32_t ld_local) {
-  if (score_mode != 0 || tn.score_filter == 1 || tn.score_split != 0 || tn.score_scalar) return false;
-  if (ld_local == 0 || ld_local / 8 >= (1u << 27)) return false;
+// ---- Gram filter: constants shared by host and device -------------------------------------------------------------
+constexpr int GX_UNIT = 256;     // correspondences per staging unit (8 MFMA steps of 32): 24 KiB; LDS holds two
+constexpr int GX_WAVES = 8;      // waves per workgroup, 32 hypotheses each: eight waves share a tile, so each of them issues three 1 KiB
+                                 // LDS-DMA pieces per eight steps (with 4 waves and 128-correspondence units the DMA issue alone cost a quarter of the kernel)
+constexpr int GX_QL = 128;       // LDS queue entries per wave (8 bytes each)
+constexpr float GX_RS = 256.0f;  // scale of the A operand (keeps the low halves of the coefficients out of fp16's sub-normal range)
+constexpr double GX_ACC = 2.1e-6;    // 34 x 2^-24: error of one MFMA per unit of its LARGEST term (model and probe: score_gram_kernel)
+constexpr double GX_Q = 7.5e-7;      // 3.01 x 2^-22 (+ margin): the dropped lo x lo products and split remainders per unit of sum |w F|
+constexpr double GX_CANON = 4.2e-7;  // sqrt(3) * 4 * 2^-24: deviation of the canonical fp32 residual VECTOR per unit of magnitude
+struct GramInfo {  // written by the tile kernel (thread 0), at offset 64 of the filter's info area
+  float s;         // power of two: the largest half extent of either bounding box -> [64, 128)
+  float cP[3], cQ[3];  // centres of the boxes (fp32; the shift is applied in fp64)
+  float Pn, Qn;    // upper bounds of |P'|, |Q'| (scaled, centred Euclidean norms)
+  float pmax_o, qmax_o;  // max |coordinate| of the original (unscaled, uncentred) clouds: what the canonical chain rounds at
+  float pad[5];
+};
+// scale, centres and norm bounds from the bounding boxes (keys as the staging kernel leaves them: [c] max, [6 + c] -min)
+__host__ __device__ inline GramInfo gram_info(const uint32_t* key_hi, const uint32_t* key_lo, float pmax_o, float qmax_o) {
+  GramInfo g;
+  double half[6], hmax = 0.0;
+  for (int c = 0; c < 6; c++) {
+    const float mx = float_unkey(key_hi[c]), mn = -float_unkey(key_lo[c]);
+    const float ctr = 0.5f * mx + 0.5f * mn;
+    (c < 3 ? g.cP[c] : g.cQ[c - 3]) = ctr;
+    const double a = (double)mx - (double)ctr, b = (double)ctr - (double)mn;
+    half[c] = a > b ? a : b;
+    hmax = half[c] > hmax ? half[c] : hmax;
+  }
+  int e = 0;
+  if (hmax > 0.0) {  // hmax in [2^e, 2^(e+1))
+    union { double d; uint64_t u; } x; x.d = hmax;
+    e = (int)((x.u >> 52) & 2047u) - 1023;
+  }
+  int k = 6 - e;
+  k = k > 100 ? 100 : (k < -100 ? -100 : k);
+  union { float f; uint32_t u; } sc; sc.u = (uint32_t)(k + 127) << 23;
+  g.s = sc.f;
+  const double s = (double)g.s;
+  const double pn = s * sqrt(half[0] * half[0] + half[1] * half[1] + half[2] * half[2]) * (1.0 + 1e-6);
+  const double qn = s * sqrt(half[3] * half[3] + half[4] * half[4] + half[5] * half[5]) * (1.0 + 1e-6);
+  g.Pn = (float)(pn * (1.0 + 1e-6)); g.Qn = (float)(qn * (1.0 + 1e-6));
+  g.pmax_o = pmax_o; g.qmax_o = qmax_o;
+  for (int i = 0; i < 5; i++) g.pad[i] = 0.f;
+  return g;
+}
+// shell half-width of a hypothesis with |T'| = Tn at st = s tau, in units of the scaled squared residual (the device adds its
+// own R^T R defect term per hypothesis).  Mh: the largest single term of the 48-term dot product (2 |Q'_i P'_j| <= Pn^2 + Qn^2);
+// Sl: the sum of the absolute values of the 15 split terms.
+__host__ __device__ inline double gram_eps(double Tn, double Pn, double Qn, double st) {
+  const double pq = Pn > Qn ? Pn : Qn;
+  double Mh = 1.05 * (Pn * Pn + Qn * Qn);
+  const double m2 = Tn * Tn + 1.5 * st * st, m3 = 2.1 * Tn * pq;
+  Mh = m2 > Mh ? m2 : Mh;
+  Mh = m3 > Mh ? m3 : Mh;
+  const double Sl = 3.5 * Pn * Qn + 2.02 * Tn * Pn + 2.0 * Tn * Qn;
+  return GX_ACC * Mh + GX_Q * Sl + 1e-4;
+}
+
+// Which kernel.  The filters pay a tile kernel, an exact pass and a few microseconds of set-up per workgroup: below ~1.3e8
+// tests the plain kernel is as fast or faster (C1, 2e7 tests: 9 us plain, 20 us filtered).
+int score_filter_mode(int score_mode, const Tuning& tn, int n, uint32_t ld_local, uint64_t host_max, const uint64_t* host_box,
+                      float tau2) {
+  if (score_mode != 0 || tn.score_filter == 1 || tn.score_split != 0 || tn.score_scalar) return 0;
+  if (ld_local == 0 || ld_local / 8 >= (1u << 27)) return 0;
   // beyond 2^36 tests the queue of undecided tests (sized T n / 512 entries: ~20x what the BASELINE scenes need) would
   // pass 1 GB: such calls keep the plain kernel rather than a queue that may overflow into wholesale recounts
-  if ((uint64_t)ld_local * (uint64_t)n > (1ull << 36)) return false;
-  return tn.score_filter == 2 || (uint64_t)ld_local * (uint64_t)n >= (1ull << 27);
+  const uint64_t tests = (uint64_t)ld_local * (uint64_t)n;
+  if (tests > (1ull << 36)) return 0;
+  const bool big = tests >= (1ull << 27);
+  if (tn.score_filter == 2) return 1;
+  const bool gram_fits = ld_local <= (1u << 20) && n <= (1 << 24);  // (the queue entry carries wave << 17)
+  if (tn.score_filter == 3) return gram_fits ? 2 : 1;
+  if (!big) return 0;
+  if (host_max == ~0ull) return 1;  // statistics not known: the linear filter sorts itself out (it recounts what it cannot bound)
+  if (gram_fits && host_box) {  // Gram: tau must stand well clear of the cancellation error of the squared form
+    uint32_t kh[6], kl[6];
+    for (int c = 0; c < 6; c++) { kh[c] = (uint32_t)host_box[c]; kl[c] = (uint32_t)(host_box[c] >> 32); }
+    union { uint32_t u; float f; } a, b;
+    a.u = (uint32_t)host_max; b.u = (uint32_t)(host_max >> 32);
+    const GramInfo g = gram_info(kh, kl, a.f, b.f);
+    const double st = (double)g.s * sqrt((double)tau2);
+    const double eps = gram_eps(0.25 * ((double)g.Pn + (double)g.Qn), g.Pn, g.Qn, st);  // a hypothesis a quarter of the clouds' size off centre
+    const double dE = GX_CANON * (double)g.s * ((double)g.qmax_o + 1.75 * (double)g.pmax_o + (double)g.qmax_o);
+    if (eps <= 0.03 * st * st && dE <= 0.02 * st && st <= 64.0 && st >= 0.5) return 2;
+  }
+  return filter_in_range(host_max, tau2) ? 1 : 0;
 }
 
 bool filter_in_range(uint64_t host_max, float tau2) {
@@ -554,13 +631,15 @@ bool filter_in_range(uint64_t host_max, float tau2) {
   return (eta <= 0.25f * st) && (st <= 4096.f) && (pmax * s < 512.f) && (qmax * s < 512.f);  // false on NaN
 }
 
-FilterPlan filter_plan(int n, uint32_t ld_local, const Tuning& tn) {
+FilterPlan filter_plan(int n, uint32_t ld_local, const Tuning& tn, uint32_t mode) {
   FilterPlan fp;
+  fp.mode = mode;
   fp.windows = (uint32_t)((n + FX_WIN - 1) / FX_WIN);
-  fp.n_waves = ld_local / 8;
-  // grid.y: the windows are split so that the launch has several generations of workgroups (6 per CU are resident) and
-  // the last one is well filled
-  const uint32_t groups = ld_local / (8 * FX_WAVES), slots = 256 * 6;
+  fp.n_waves = ld_local / 8;  // recount units: 8 hypotheses (a wave of the linear filter, a quarter of a Gram wave)
+  // grid.y: the windows are split so that the launch has several generations of workgroups and the last one is well filled
+  // (linear: 32 hypotheses per workgroup, 6 resident per CU; Gram: 256 hypotheses, 2 resident)
+  const uint32_t groups = mode == 2 ? (ld_local + 32 * GX_WAVES - 1) / (32 * GX_WAVES) : ld_local / (8 * FX_WAVES);
+  const uint32_t slots = mode == 2 ? 256 * 2 : 256 * 6;
   uint32_t best = 1; double best_eff = 0.0;
   const uint32_t smax = fp.windows < 8 ? fp.windows : 8;
   for (uint32_t sp = 1; sp <= smax; sp++) {
@@ -577,14 +656,14 @@ FilterPlan filter_plan(int n, uint32_t ld_local, const Tuning& tn) {
     const uint32_t per = (fp.windows + fp.splits - 1) / fp.splits;
     fp.splits = (fp.windows + per - 1) / per;
   }
-  fp.rows = fp.windows * FX_WIN + FX_UNIT;
+  fp.rows = fp.windows * FX_WIN + (mode == 2 ? GX_UNIT : FX_UNIT);
   uint64_t cap = (uint64_t)ld_local * (uint64_t)n / 512;  // ~20x what the BASELINE scenes queue
   if (cap < (1u << 16)) cap = 1u << 16;
   if (cap > (1u << 27)) cap = 1u << 27;
   if (tn.filter_queue_cap) cap = tn.filter_queue_cap;
   fp.queue_cap = (uint32_t)(cap / FX_NQ * FX_NQ);
   if (fp.queue_cap < FX_NQ) fp.queue_cap = FX_NQ;
-  fp.tile_bytes = (size_t)fp.rows * 32;
+  fp.tile_bytes = (size_t)fp.rows * (mode == 2 ? 96 : 32);
   const size_t bm_words = ((size_t)fp.splits * fp.n_waves + 31) / 32;
   fp.state_bytes = 128 + (size_t)FX_NQ * 128 + (bm_words * 4 + 127) / 128 * 128 + (size_t)fp.queue_cap * 8;
   return fp;
@@ -592,10 +671,14 @@ FilterPlan filter_plan(int n, uint32_t ld_local, const Tuning& tn) {
 
 // The fp16 image of the correspondences, 32 bytes each, in the K order of the B operand:
 //   [Pxh Pxl Pxh  Pyh Pyl Pyh  Pzh Pzl | Pzh  Qxh Qxl  Qyh Qyl  Qzh Qzl  0];  rows [n, rows) are sentinels (far away).
+// The two 16-byte halves of a correspondence are NOT adjacent: see the group layout at the end of filter_tile_block.
 // mx_cur: max |p| and max |q| of the call (bit patterns; stage_points_kernel's atomicMax).  Also clears the filter's
 // counters and bitmap for this call, so nothing needs a memset.
+__device__ void gram_tile_block(const float* __restrict__ planes, int n, int ld, const FilterTileJob& job, uint32_t block,
+                                uint32_t blocks);
 __device__ void filter_tile_block(const float* __restrict__ planes, int n, int ld, const FilterTileJob& job, uint32_t block,
                                   uint32_t blocks) {
+  if (job.mode == 2) { gram_tile_block(planes, n, ld, job, block, blocks); return; }
   const uint32_t m = block * 256 + threadIdx.x;
   for (uint32_t z = m; z < job.zero_words; z += blocks * 256) job.zero[z] = 0u;
   const float Pmax = __uint_as_float(job.mx_cur[0]), Qmax = __uint_as_float(job.mx_cur[1]), mxv = fmaxf(Pmax, Qmax);
@@ -603,7 +686,7 @@ __device__ void filter_tile_block(const float* __restrict__ planes, int n, int l
   int k = 8 - e;
   k = k > 100 ? 100 : (k < -100 ? -100 : k);
   const float s = __uint_as_float((uint32_t)(k + 127) << 23);
-  if (m == 0) *static_cast<FilterInfo*>(job.info) = FilterInfo{s, Pmax, Qmax, 0.f};  // (the staging kernel clears the other pair of maxima)
+  if (m == 0) *static_cast<FilterInfo*>(job.info) = FilterInfo{s, Pmax, Qmax, 0.f};
   if (m >= job.rows) return;
   _Float16 hi[6], lo[6];
 #pragma unroll
@@ -614,9 +697,14 @@ __device__ void filter_tile_block(const float* __restrict__ planes, int n, int l
   }
   half8 f0 = {hi[0], lo[0], hi[0], hi[1], lo[1], hi[1], hi[2], lo[2]};
   half8 f1 = {hi[2], hi[3], lo[3], hi[4], lo[4], hi[5], lo[5], (_Float16)0.f};
+  // per group of 32 correspondences (one MFMA step): the 32 first halves (k0..7), then the 32 second halves (k8..15) —
+  // lane l of a wave then reads the 16 bytes at 16 l of the group's 1 KiB: a linear, bank-conflict-free ds_read_b128
+  // (with the two halves of a correspondence side by side the lanes of a half stride 32 bytes: 2-way conflicts, +4
+  // cycles on each 8-cycle read by SQ_LDS_BANK_CONFLICT)
   uint4* tile = static_cast<uint4*>(job.tile);
-  tile[(size_t)m * 2] = *reinterpret_cast<uint4*>(&f0);
-  tile[(size_t)m * 2 + 1] = *reinterpret_cast<uint4*>(&f1);
+  const size_t slot = (size_t)(m >> 5) * 64 + (m & 31u);
+  tile[slot] = *reinterpret_cast<uint4*>(&f0);
+  tile[slot + 32] = *reinterpret_cast<uint4*>(&f1);
 }
 __global__ __launch_bounds__(256) void filter_tile_kernel(const float* __restrict__ planes, int n, int ld, FilterTileJob job) {
   filter_tile_block(planes, n, ld, job, blockIdx.x, gridDim.x);
@@ -626,8 +714,12 @@ __global__ __launch_bounds__(256) void filter_tile_kernel(const float* __restric
 // the others except through the B tile: a unit of 256 correspondences (8 KiB) is brought into LDS by LDS-DMA while
 // the previous one is being used (two buffers, one barrier per unit).  blockIdx.y = split of the windows.
 // 80 VGPRs: six waves per SIMD cover the MFMA and LDS latencies, so nothing is double-buffered inside a wave.
-template <int WAVES>
-__global__ __launch_bounds__(64 * WAVES, 6) void score_filter_kernel(const float* __restrict__ Rt, uint32_t ldl, float tau2,
+// VAR (Tuning::filter_variant): 0 = one MFMA, then its epilogue (the wave idles through the MFMA's latency; the other
+// waves of the SIMD fill it); bit 0 = the NEXT step's MFMA is issued before this step's epilogue (two accumulator sets,
+// 96 VGPRs, 5 waves per SIMD): vector and matrix work of ONE wave overlap; bit 1 = s_setprio 1 around the MFMA issue;
+// 16 / 32: timing-only ablations (no MFMA / no epilogue: wrong counts) for tools/ab_stage.py.
+template <int WAVES, int VAR>
+__global__ __launch_bounds__(64 * WAVES, (VAR & 128) ? 8 : ((VAR & 1) ? 5 : 6)) void score_filter_kernel(const float* __restrict__ Rt, uint32_t ldl, float tau2,
                                                                      const uint4* __restrict__ tile,
                                                                      const FilterInfo* __restrict__ info, uint32_t windows,
                                                                      uint32_t splits, uint32_t n_waves,
@@ -636,7 +728,9 @@ __global__ __launch_bounds__(64 * WAVES, 6) void score_filter_kernel(const float
                                                                      uint32_t* __restrict__ redo_bits, uint32_t ql) {
   __shared__ uint4 Bt[2][FX_UNIT * 2];
   __shared__ float4 Ttab[WAVES][8];
-  __shared__ uint32_t queue[WAVES][FX_QL];
+  constexpr int QL = (VAR & 128) ? FX_QL / 2 : FX_QL;  // (128: 8 workgroups per CU — their LDS must fit 160 KiB)
+  __shared__ uint32_t queue[WAVES][QL];
+  if (ql > (uint32_t)QL) ql = QL;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int col = lane & 31, hf = lane >> 5;
   const uint32_t per = (windows + splits - 1) / splits, w0 = blockIdx.y * per, w1 = min(windows, w0 + per);
@@ -735,16 +829,33 @@ __global__ __launch_bounds__(64 * WAVES, 6) void score_filter_kernel(const float
   };
   for (uint32_t u = u0; u < u1; u++) {
     const int buf = (int)((u - u0) & 1u);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's part of unit u has landed
-    __syncthreads();                                   // ... everybody's has, and the other buffer is free
+    if constexpr ((VAR & 256) == 0) {                    // (256: timing-only ablation, no barrier)
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's part of unit u has landed
+      __syncthreads();                                   // ... everybody's has, and the other buffer is free
+    }
     if (u + 1 < u1) stage(u + 1, buf ^ 1);
     if (!redo) {
-      const half8* Bc = reinterpret_cast<const half8*>(Bt[buf]) + col * 2 + hf;
-      half8 b = Bc[0];
-#pragma unroll 2  // (by 4: no gain; fully unrolled: 144 bytes of spills inside the loop, 64 -> 118 us on C2)
-      for (int g = 0; g < FX_UNIT / 32; g++) {
-        const f32x16 D = __builtin_amdgcn_mfma_f32_32x32x16_f16(A, b, C, 0, 0, 0);
-        if (g + 1 < FX_UNIT / 32) b = Bc[64 * (g + 1)];
+      const half8* Bc = reinterpret_cast<const half8*>(Bt[buf]) + lane;  // (tile layout: filter_tile_block)
+      auto mfma = [&](const half8& b) -> f32x16 {
+        if constexpr ((VAR & 16) != 0) {  // ablation: no matrix instruction (the operand stays live)
+          f32x16 D = C;
+          asm volatile("" ::"v"(b));
+#pragma unroll
+          for (int i = 0; i < 16; i++) asm volatile("" : "+v"(D[i]));  // opaque: nothing of the epilogue can be hoisted
+          return D;
+        } else {
+          if constexpr ((VAR & 2) != 0) __builtin_amdgcn_s_setprio(1);
+          const f32x16 D = __builtin_amdgcn_mfma_f32_32x32x16_f16(A, b, C, 0, 0, 0);
+          if constexpr ((VAR & 2) != 0) __builtin_amdgcn_s_setprio(0);
+          return D;
+        }
+      };
+      // the vector work of one step: x = |E'|^2 - LO per test, sign bit into the shift register, shell test, queue
+      auto epilogue = [&](const f32x16& D, int g) {
+        if constexpr ((VAR & 32) != 0) {  // ablation: no epilogue
+          sr[0] ^= __float_as_uint(D[0]) ^ __float_as_uint(D[5]) ^ __float_as_uint(D[10]) ^ __float_as_uint(D[14]);
+          return;
+        }
         float x[4];
         uint32_t mn = 0xFFFFFFFFu;
 #pragma unroll
@@ -754,6 +865,7 @@ __global__ __launch_bounds__(64 * WAVES, 6) void score_filter_kernel(const float
           sr[jj] = __builtin_amdgcn_alignbit(sr[jj], __float_as_uint(v), 31);  // sign bit: |E'|^2 < LO, a certain inlier
           mn = min(mn, __float_as_uint(v));
         }
+        if constexpr ((VAR & 512) != 0) { sr[0] ^= mn; return; }  // (512: timing-only ablation, no shell test)
         const uint64_t hm = __ballot(mn < W2b);  // as unsigned integers: 0 <= x < HI - LO, the undecided shell
         if (__builtin_expect(hm != 0, 0)) {
           const uint32_t k2 = (uint32_t)__popcll(hm);
@@ -766,6 +878,37 @@ __global__ __launch_bounds__(64 * WAVES, 6) void score_filter_kernel(const float
           } else {
             redo = true;  // more undecided tests than the queue holds: the exact pass takes the whole (wave, split)
           }
+        }
+        // The idle fourth rows of D stay "in use" up to here: otherwise the register allocator parks this epilogue's
+        // temporaries in the idle rows of the OTHER accumulator set — whose MFMA is still in flight — and has to pad the
+        // write-after-write hazard with s_nop until that MFMA has finished, which is the overlap this variant is after.
+        if constexpr ((VAR & 1) != 0) asm volatile("" ::"v"(D[3]), "v"(D[7]), "v"(D[11]), "v"(D[15]));
+      };
+      if constexpr ((VAR & 1) != 0) {
+        // software pipeline inside the unit: step g + 1's MFMA is in the matrix pipe while step g's epilogue issues
+        constexpr int G = FX_UNIT / 32;
+        half8 b0 = Bc[0], b1 = Bc[64];
+        f32x16 D0 = mfma(b0), D1;
+#pragma unroll 1
+        for (int g = 0; g < G; g += 2) {
+          D1 = mfma(b1);                                   // step g + 1
+          if (g + 2 < G) b0 = Bc[64 * (g + 2)];
+          epilogue(D0, g);
+          if (g + 2 < G) {
+            D0 = mfma(b0);                                 // step g + 2
+            b1 = Bc[64 * (g + 3)];
+          }
+          epilogue(D1, g + 1);
+        }
+      } else {
+        half8 b = Bc[0];
+#pragma unroll 2  // (by 4: no gain; fully unrolled: 144 bytes of spills inside the loop, 64 -> 118 us on C2)
+        for (int g = 0; g < FX_UNIT / 32; g++) {
+          const f32x16 D = mfma(b);
+          if constexpr ((VAR & 64) == 0) {  // (64: ablation, the operand is not re-read)
+            if (g + 1 < FX_UNIT / 32) b = Bc[64 * (g + 1)];
+          }
+          epilogue(D, g);
         }
       }
       if ((u + 1) % (FX_WIN / FX_UNIT) == 0) {  // window boundary: 32 tests per register
@@ -802,12 +945,26 @@ __global__ __launch_bounds__(256) void score_exact_kernel(const float* __restric
                                                           const uint2* __restrict__ gq, uint32_t cap_sq,
                                                           const uint32_t* __restrict__ qcount,
                                                           const uint32_t* __restrict__ redo_bits,
-                                                          uint32_t* __restrict__ cnt_out) {
+                                                          uint32_t* __restrict__ cnt_out, uint32_t gram) {
   const uint32_t per = (windows + splits - 1) / splits;
   const float4* __restrict__ aos4 = reinterpret_cast<const float4*>(planes + 6 * (size_t)ld);  // 8 floats per correspondence
   const uint32_t sq = blockIdx.x % FX_NQ, nq = min(qcount[sq * 32], cap_sq);
   for (uint32_t i = (blockIdx.x / FX_NQ) * 256 + threadIdx.x; i < nq; i += (gridDim.x / FX_NQ) * 256) {
     const uint2 e = gq[(size_t)sq * cap_sq + i];
+    if (gram) {  // Gram filter: {correspondence, wave of 32 << 17 | lane half << 16 | one bit per accumulator register}
+      const uint32_t m = e.x, w32 = e.y >> 17, ehf = (e.y >> 16) & 1u, sp = (m / FX_WIN) / per;
+      const float4 pa = aos4[2 * (size_t)m], pb = aos4[2 * (size_t)m + 1];
+      for (uint32_t bits = e.y & 0xFFFFu; bits; bits &= bits - 1) {
+        const uint32_t i16 = (uint32_t)(__ffs(bits) - 1), row = 8 * (i16 >> 2) + 4 * ehf + (i16 & 3u), h = w32 * 32 + row;
+        const size_t bit = (size_t)sp * n_waves + (h >> 3);
+        if ((redo_bits[bit >> 5] >> (bit & 31)) & 1u) continue;  // recounted as a whole below
+        float M[12];
+        load_rt_aos(RtAoS, h, M);
+        const float d2 = resid2(M, pa.x, pa.y, pa.z, pa.w, pb.x, pb.y);
+        if (finite12(M) && d2 < tau2) atomicAdd(&cnt_out[(size_t)sp * ldl + h], 1u);
+      }
+      continue;
+    }
     const uint32_t m = e.x, wid = e.y >> 5, ehf = (e.y >> 4) & 1u, sp = (m / FX_WIN) / per;
     const size_t bit = (size_t)sp * n_waves + wid;
     if ((redo_bits[bit >> 5] >> (bit & 31)) & 1u) continue;  // recounted as a whole below
@@ -846,9 +1003,318 @@ __global__ __launch_bounds__(256) void score_exact_kernel(const float* __restric
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// C2, inlier count, the GRAM filter (r03): the matrix pipe evaluates the squared residual itself.
+//
+// With P' = s (p - cP), Q' = s (q - cQ) (s a power of two, cP / cQ the centres of the clouds' bounding boxes, so that
+// every coordinate is below 128) and T' = s (t + R cP - cQ), in exact arithmetic
+//     s^2 |R p + t - q|^2 = |R P' + T' - Q'|^2
+//                        = P'^T (R^T R) P' + |Q'|^2 + |T'|^2 + 2 (R^T T') . P' - 2 T' . Q' - 2 sum_ij R_ij Q'_i P'_j .
+// For a rotation R^T R = I, and the right-hand side is a DOT PRODUCT of 16 features of the correspondence
+//     Q'_i P'_j (9), (|P'|^2 + |Q'|^2) / 2, P'_j (3), Q'_i (3)                       (tile kernel, fp64, once per call)
+// with 16 coefficients of the hypothesis  -2 R_ij, 2, 2 (R^T T')_j, -2 T'_i  plus the constant |T'|^2  (kernel prologue, fp64).
+// Features and coefficients are split into two fp16 halves (the norm feature into three pieces); hi x hi, hi x lo and
+// lo x hi products are kept: 48 slots = three chained v_mfma_f32_32x32x16_f16, rows = 32 hypotheses, columns = 32
+// correspondences, accumulator initialised to |T'|^2 - LO: a lane then holds x = D~ - LO for 16 hypotheses of one
+// correspondence — sign bit into a shift register (1 instruction), shell test 0 <= x < HI - LO as an unsigned min over
+// the 16 (0.5), nothing else: 1.6 vector instructions per test against the linear filter's 4.75, for the same matrix work
+// per test (96 cycles per 1024 tests against 4 x 32).  MFMA 1 holds the 16 hi x hi slots (the big, cancelling terms),
+// MFMAs 2 and 3 the 32 small ones.
+//
+// What it costs is precision: the squared form cancels (terms of size (|P'| + |Q'| + |T'|)^2 sum to ~tau'^2).  How the matrix
+// pipe adds the 16 products and C is not in the ISA text; tools/ubench/mfma_numerics.hip probes it (profiles/
+// r03_ubench_mfma_numerics.txt): the 17 terms are aligned to the largest exponent among them (a product counts as the sum
+// of its factors' exponents + 1) and cut to a 2^-25 fraction of it, added exactly, and rounded once to nearest-even; fp16
+// sub-normals are NOT flushed.  So one MFMA is off by < 17 x 2^-24 of its largest |term| plus 2^-24 of its result; the bound
+// below takes TWICE that (one alignment bit less than probed).  With Mh the largest term of a hypothesis (gram_eps),
+// Sl = sum |w F| over the split terms (sum_ij |R_ij Q_i P_j| <= 1.75 |Q| |P|), u = 2^-24, D* the exact value:
+//     MFMA 1       34 u Mh                                                                      (GX_ACC)
+//     MFMAs 2, 3   their terms are <= 2^-10 of MFMA 1's; their C is the running value: 34 u (|D*| + 2e-3 Mh) each — the part
+//                  proportional to D* (4e-6) is carried by the factors (1 -+ 1e-5) of LO / HI
+//     splits       x = hi + lo + rem, |rem| <= 2^-22 |x|;  w F - (wh Fh + wh Fl + wl Fh) = wl Fl + ... <= 3.01 x 2^-22 |w F|:
+//                  7.2e-7 Sl; the norm feature's three pieces leave 2^-33                          (GX_Q)
+//     accumulator  initial value |T'|^2 - LO rounded to fp32: u Mh (inside GX_ACC's margin)
+//     R^T R = I    defect g = max |(R^T R - I)_ab| measured per hypothesis in fp64: <= 3 g Pn^2 (beyond 1e-3: not a rotation,
+//                  the hypothesis is recounted exactly)
+//   sum: eps_h = 2.1e-6 Mh + 7.5e-7 Sl + 3 g Pn^2 + 1e-4                                                     (gram_eps)
+// (Under the weakest model — every one of the 48 additions rounded separately at the size of the whole sum, truncating —
+// the same terms give 3e-6 (|T'| + 1.75 Pn + Qn)^2, four to five times this shell; the parity suite compares EVERY count
+// with the canonical kernel's at the BASELINE shapes and on adversarial scenes, for both filters.)
+// The canonical fp32 chain itself deviates from exact arithmetic: its residual VECTOR by <= dE = sqrt(3) 4 u s (qmax + 1.75 pmax
+// + |t|max) (original, uncentred magnitudes), its square by 3 more roundings.  So, with st = s sqrt(tau2):
+//     D~ <  LO_h = (st - dE)^2 (1 - 1e-5) - eps_h   =>  canonical inlier;     D~ >= HI_h = (st + dE)^2 (1 + 1e-5) + eps_h  =>  outlier;
+// a wave uses the widest shell of its 32 hypotheses.  Hypotheses fall into four classes, decided in the prologue:
+//     normal   eps_h <= 0.25 st^2: filtered;        far      |T'| - 1.002 Pn - Qn >= st + dE + 1: no correspondence can be an inlier,
+//     padding  beyond n_local: count 0;              recount  everything else (non-finite, not a rotation, shell too wide): its
+//                                                             group of 8 hypotheses goes to the exact pass wholesale.
+// Usable while tau is not small against the clouds (score_filter_mode: eps <= 8 % of tau'^2 for a typical hypothesis — C2, C4;
+// not C3, whose tau is 1 % of the extent: the linear filter keeps those).
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void split2(double x, _Float16& hi, _Float16& lo) {
+  hi = (_Float16)(float)x;
+  lo = (_Float16)(float)(x - (double)(float)hi);
+}
+
+// tile: per group of 32 correspondences 6 x 32 uint4 — for MFMA k (0..2): the 32 first halves (slots 0..7), then the 32
+// second halves (slots 8..15), so that lane l reads uint4 number 64 k + l of the group (linear, conflict-free).
+//   slots   0..8 Q'_i P'_j (index 3 i + j)   9 norm piece   10..12 256 P'_j   13..15 256 Q'_i
+//   MFMA 1: hi halves, norm hi;   MFMA 2: lo halves, norm mid;   MFMA 3: hi halves again, norm lo
+__device__ void gram_tile_block(const float* __restrict__ planes, int n, int ld, const FilterTileJob& job, uint32_t block,
+                                uint32_t blocks) {
+  const uint32_t m = block * 256 + threadIdx.x;
+  for (uint32_t z = m; z < job.zero_words; z += blocks * 256) job.zero[z] = 0u;
+  const GramInfo gi = gram_info(job.mx_cur + 2, job.mx_cur + 8, __uint_as_float(job.mx_cur[0]), __uint_as_float(job.mx_cur[1]));
+  if (m == 0) *reinterpret_cast<GramInfo*>(static_cast<char*>(job.info) + 64) = gi;
+  if (m >= job.rows) return;
+  _Float16 h[16], l[16], n3[3];
+  if (m < (uint32_t)n) {
+    double P[3], Q[3];
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+      P[c] = (double)gi.s * ((double)planes[(size_t)c * ld + m] - (double)gi.cP[c]);        // exact
+      Q[c] = (double)gi.s * ((double)planes[(size_t)(3 + c) * ld + m] - (double)gi.cQ[c]);
+    }
+    double F[16];
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+      for (int j = 0; j < 3; j++) F[3 * i + j] = Q[i] * P[j];
+    const double N = 0.5 * (P[0] * P[0] + P[1] * P[1] + P[2] * P[2] + Q[0] * Q[0] + Q[1] * Q[1] + Q[2] * Q[2]);
+#pragma unroll
+    for (int c = 0; c < 3; c++) { F[10 + c] = 256.0 * P[c]; F[13 + c] = 256.0 * Q[c]; }
+    F[9] = 0.0;
+#pragma unroll
+    for (int k = 0; k < 16; k++) split2(F[k], h[k], l[k]);
+    n3[0] = (_Float16)(float)N;
+    const double r1 = N - (double)(float)n3[0];
+    n3[1] = (_Float16)(float)r1;
+    n3[2] = (_Float16)(float)(r1 - (double)(float)n3[1]);
+  } else {  // sentinel: far away under every hypothesis (D~ = 2 x 60000 + ...), never undecided
+#pragma unroll
+    for (int k = 0; k < 16; k++) { h[k] = (_Float16)0.f; l[k] = (_Float16)0.f; }
+    n3[0] = (_Float16)60000.f; n3[1] = (_Float16)0.f; n3[2] = (_Float16)0.f;
+  }
+  uint4* tile = static_cast<uint4*>(job.tile) + (size_t)(m >> 5) * 192 + (m & 31u);
+#pragma unroll
+  for (int k = 0; k < 3; k++) {
+    const _Float16* v = k == 1 ? l : h;
+    half8 f0 = {v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7]};
+    half8 f1 = {v[8], n3[k], v[10], v[11], v[12], v[13], v[14], v[15]};
+    tile[64 * k] = *reinterpret_cast<uint4*>(&f0);
+    tile[64 * k + 32] = *reinterpret_cast<uint4*>(&f1);
+  }
+}
+
+template <int VAR>  // (timing-only ablations for tools/ab_stage.py: 512 = no shell test, 256 = no barrier, 32 = no epilogue)
+__global__ __launch_bounds__(64 * GX_WAVES, 2) void score_gram_kernel(const float* __restrict__ Rt, uint32_t ldl, uint32_t n_local,
+                                                                     float tau2, const uint4* __restrict__ tile,
+                                                                     const GramInfo* __restrict__ info, uint32_t windows,
+                                                                     uint32_t splits, uint32_t n_waves8,
+                                                                     uint32_t* __restrict__ cnt_out, uint2* __restrict__ gq,
+                                                                     uint32_t cap_sq, uint32_t* __restrict__ qcount,
+                                                                     uint32_t* __restrict__ redo_bits, uint32_t ql) {
+  __shared__ uint4 Bt[2][GX_UNIT * 6];           // 2 x 12 KiB
+  __shared__ float Ctab[GX_WAVES][32];
+  __shared__ uint2 queue[GX_WAVES][GX_QL];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int col = lane & 31, hf = lane >> 5;
+  const uint32_t per = (windows + splits - 1) / splits, w0 = blockIdx.y * per, w1 = min(windows, w0 + per);
+  const uint32_t wid = blockIdx.x * GX_WAVES + wave;  // wave of 32 hypotheses
+  constexpr uint32_t UPW = FX_WIN / GX_UNIT;          // units per window
+  const uint32_t u0 = w0 * UPW, u1 = w1 * UPW;
+  auto stage = [&](uint32_t u, int buf) {  // (asm: see score_filter_kernel)
+#pragma unroll
+    for (int i = 0; i < GX_UNIT * 6 / (64 * GX_WAVES); i++) {
+      const uint4* gsrc = tile + (size_t)u * (GX_UNIT * 6) + 64 * GX_WAVES * i + tid;
+      const uint32_t lds_dst = __builtin_amdgcn_readfirstlane(
+          (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)(&Bt[buf][64 * GX_WAVES * i + wave * 64]));
+      unsigned keep;
+      asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                   : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+    }
+  };
+  if (u0 < u1) stage(u0, 0);
+  const GramInfo gi = *info;
+  // ---- prologue: lane (row, hf) builds the coefficients of hypothesis wid * 32 + row (both halves compute the same)
+  const uint32_t row = (uint32_t)col, h = wid * 32 + row;
+  const bool in_grid = h < ldl;  // (ldl is a multiple of 256; the last workgroup may reach beyond it when it is not one of 128)
+  float v[12];
+#pragma unroll
+  for (int c = 0; c < 12; c++) v[c] = in_grid ? Rt[(size_t)c * ldl + h] : 0.f;
+  const double s = (double)gi.s, st = s * (double)sqrt_rn(tau2);
+  double R[9], Tp[3];
+#pragma unroll
+  for (int c = 0; c < 9; c++) R[c] = (double)v[c];
+#pragma unroll
+  for (int i = 0; i < 3; i++)
+    Tp[i] = s * ((double)v[9 + i] + R[3 * i] * (double)gi.cP[0] + R[3 * i + 1] * (double)gi.cP[1] + R[3 * i + 2] * (double)gi.cP[2] - (double)gi.cQ[i]);
+  double gdef = 0.0;
+#pragma unroll
+  for (int a = 0; a < 3; a++)
+#pragma unroll
+    for (int b = a; b < 3; b++) {
+      const double g = R[a] * R[b] + R[3 + a] * R[3 + b] + R[6 + a] * R[6 + b] - (a == b ? 1.0 : 0.0);
+      gdef = fmax(gdef, fabs(g));
+    }
+  float nanp = 0.f;
+#pragma unroll
+  for (int c = 0; c < 12; c++) nanp += v[c] * 0.f;
+  const double Tn = sqrt(Tp[0] * Tp[0] + Tp[1] * Tp[1] + Tp[2] * Tp[2]);
+  const double Pn = (double)gi.Pn, Qn = (double)gi.Qn;
+  const double tmax_o = fmax(fabs((double)v[9]), fmax(fabs((double)v[10]), fabs((double)v[11])));
+  const double dE = GX_CANON * s * ((double)gi.qmax_o + 1.75 * (double)gi.pmax_o + tmax_o);
+  // coefficients (A operand), scaled by GX_RS; the P' / Q' features are stored x 256
+  double a16[16];
+#pragma unroll
+  for (int k = 0; k < 9; k++) a16[k] = -2.0 * (double)GX_RS * R[k];
+  a16[9] = 2.0 * (double)GX_RS;
+#pragma unroll
+  for (int j = 0; j < 3; j++) a16[10 + j] = 2.0 * (double)GX_RS / 256.0 * (R[j] * Tp[0] + R[3 + j] * Tp[1] + R[6 + j] * Tp[2]);
+#pragma unroll
+  for (int i = 0; i < 3; i++) a16[13 + i] = -2.0 * (double)GX_RS / 256.0 * Tp[i];
+  const double eps = gram_eps(Tn, Pn, Qn, st) + 3.0 * gdef * Pn * Pn;
+  const bool finite = nanp == 0.f;
+  const bool pad = !in_grid || h >= n_local;
+  const bool rot = finite && gdef <= 1e-3 && Tn < 1e6;
+  const bool far = rot && (Tn - 1.002 * Pn - Qn >= st + dE + 1.0);
+  // (st <= 64: the sentinel correspondences' 2 x 60000 must stay far above every threshold)
+  const bool normal = rot && !far && !pad && (eps <= 0.25 * st * st) && (dE <= 0.1 * st) && (st <= 64.0);
+  const bool recount = !pad && !far && !normal;
+  const double LOh = (st - dE) * (st - dE) * (1.0 - 1e-5) - eps, HIh = (st + dE) * (st + dE) * (1.0 + 1e-5) + eps;
+  // Every hypothesis keeps its OWN shell [LO_h, HI_h): its row is scaled by alpha_h = (widest shell of the wave) / (its own
+  // width), so that "0 <= x < W" with one W per wave tests exactly alpha_h RS (D~ - LO_h) in [0, alpha_h RS (HI_h - LO_h)) —
+  // one hypothesis with a large |T'| does not widen the shells of the 31 others (alpha <= 16: fp16 range of the row).
+  double width = normal ? HIh - LOh : 0.0, wmax = width;
+#pragma unroll
+  for (int o = 16; o > 0; o >>= 1) wmax = fmax(wmax, __shfl_xor(wmax, o, 32));
+  // alpha is cut to 11 significant bits (rounded to fp16 after shrinking by 2^-10, so never above the ratio): the norm
+  // feature's coefficient 2 RS alpha then has no low half, like 2 RS itself — its three pieces need three slots, not six
+  const double alpha = normal ? (double)(float)(_Float16)(float)(fmin(16.0, wmax / width) * (1.0 - 1.0 / 1024.0)) : 0.0;
+  const uint32_t normal_rows = (uint32_t)__ballot(normal);        // (both lane halves agree: bits 0..31)
+  uint32_t redo4 = 0;                                             // groups of 8 rows the exact pass recounts
+  {
+    const uint32_t rc = (uint32_t)__ballot(recount);
+#pragma unroll
+    for (int jj = 0; jj < 4; jj++) redo4 |= ((rc >> (8 * jj)) & 0xFFu) ? (1u << jj) : 0u;
+  }
+  const bool any_normal = normal_rows != 0u;
+  const uint32_t W2b = (any_normal && !(VAR & 512)) ? __float_as_uint((float)((double)GX_RS * wmax * (1.0 + 1e-6))) : 0u;
+  // accumulator start per row: alpha RS (|T'|^2 - LO_h) for a filtered hypothesis, +huge (never an inlier, never undecided)
+  // otherwise; rows of a group that is recounted anyway are switched off too
+  const bool live = normal && !((redo4 >> (row >> 3)) & 1u);
+  if (hf == 0) Ctab[wave][row] = live ? (float)(alpha * (double)GX_RS * (Tn * Tn - LOh)) : 1e30f;
+  _Float16 ah[16], al[16];
+#pragma unroll
+  for (int k = 0; k < 16; k++) split2(alpha * a16[k], ah[k], al[k]);
+  half8 A0, A1, A2;
+  {
+    const _Float16 z = (_Float16)0.f;
+#pragma unroll
+    for (int e = 0; e < 8; e++) {
+      const _Float16 xh = hf ? ah[8 + e] : ah[e], xl = hf ? al[8 + e] : al[e];  // (hf is lane-varying: select, not index)
+      A0[e] = live ? xh : z;   // hi x hi
+      A1[e] = live ? xh : z;   // hi x lo (the tile's second block holds the low halves)
+      A2[e] = live ? ((hf && e == 1) ? xh : xl) : z;   // lo x hi (slot 9: the norm's third piece, coefficient 2 RS alpha again)
+    }
+  }
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // Ctab: written and read by this wave only
+  f32x16 C;
+#pragma unroll
+  for (int i = 0; i < 16; i++) C[i] = Ctab[wave][8 * (i >> 2) + 4 * hf + (i & 3)];
+  uint32_t total[16], sr[16];
+#pragma unroll
+  for (int i = 0; i < 16; i++) { total[i] = 0; sr[i] = 0; }
+  uint32_t qn = 0;
+  uint2* q = queue[wave];
+  auto flush_queue = [&]() {  // the wave's queue -> its global sub-queue (one ticket); see score_filter_kernel
+    const uint32_t sq = wid % FX_NQ;
+    uint32_t base = 0;
+    if (lane == 0) base = atomicAdd(&qcount[sq * 32], qn);
+    base = __shfl(base, 0);
+    const bool fits = base + qn <= cap_sq;
+    for (uint32_t i = lane; i < qn && base + i < cap_sq; i += 64)
+      gq[(size_t)sq * cap_sq + base + i] = fits ? make_uint2(q[i].x, (wid << 17) | q[i].y) : make_uint2(0u, 0u);
+    if (!fits) redo4 = 0xFu;
+    qn = 0;
+  };
+  for (uint32_t u = u0; u < u1; u++) {
+    const int buf = (int)((u - u0) & 1u);
+    if constexpr ((VAR & 256) == 0) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's part of unit u has landed
+      __syncthreads();                                   // ... everybody's has, and the other buffer is free
+    }
+    if constexpr ((VAR & 64) == 0) {  // (64: timing-only ablation, the tile is staged once)
+      if (u + 1 < u1) stage(u + 1, buf ^ 1);
+    }
+    if (any_normal && redo4 != 0xFu) {
+      const half8* Bc = reinterpret_cast<const half8*>(Bt[buf]) + lane;
+      half8 b0 = Bc[0], b1 = Bc[64], b2 = Bc[128];
+#pragma unroll 1
+      for (int g = 0; g < GX_UNIT / 32; g++) {
+        f32x16 D = __builtin_amdgcn_mfma_f32_32x32x16_f16(A0, b0, C, 0, 0, 0);
+        D = __builtin_amdgcn_mfma_f32_32x32x16_f16(A1, b1, D, 0, 0, 0);
+        D = __builtin_amdgcn_mfma_f32_32x32x16_f16(A2, b2, D, 0, 0, 0);
+        if (g + 1 < GX_UNIT / 32) { b0 = Bc[192 * (g + 1)]; b1 = Bc[192 * (g + 1) + 64]; b2 = Bc[192 * (g + 1) + 128]; }
+        // sign bit: D~ < LO_h, a certain inlier.  Shell test 0 <= x < W as an unsigned minimum, kept per group of four
+        // registers: with 1024 tests per step a step has an undecided test one time in four, so the path that queues them
+        // must be short — it looks at the four group minima first and only at the registers of a group that hit.
+        if constexpr ((VAR & 32) != 0) { sr[0] ^= __float_as_uint(D[0]) ^ __float_as_uint(D[5]) ^ __float_as_uint(D[10]) ^ __float_as_uint(D[15]); continue; }
+        uint32_t gm[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+#pragma unroll
+          for (int i = 4 * j; i < 4 * j + 4; i++) sr[i] = __builtin_amdgcn_alignbit(sr[i], __float_as_uint(D[i]), 31);
+          gm[j] = min(min(min(__float_as_uint(D[4 * j]), __float_as_uint(D[4 * j + 1])), __float_as_uint(D[4 * j + 2])), __float_as_uint(D[4 * j + 3]));  // v_min3 + v_min
+        }
+        const uint32_t mn = min(min(min(gm[0], gm[1]), gm[2]), gm[3]);
+        const uint64_t hm = __ballot(mn < W2b);
+        if (__builtin_expect(hm != 0, 0)) {
+#pragma unroll
+          for (int j = 0; j < 4; j++) {
+            const uint64_t hj = __ballot(gm[j] < W2b);
+            if (hj == 0) continue;   // (wave-uniform)
+            const uint32_t k2 = (uint32_t)__popcll(hj);
+            if (qn + k2 <= ql) {
+              uint32_t bits = 0;
+#pragma unroll
+              for (int i = 0; i < 4; i++) bits |= (__float_as_uint(D[4 * j + i]) < W2b) ? (1u << (4 * j + i)) : 0u;
+              if (gm[j] < W2b) q[qn + __popcll(hj & ((1ull << lane) - 1ull))] = make_uint2(u * GX_UNIT + 32 * g + col, ((uint32_t)hf << 16) | bits);
+              qn += k2;
+            } else {
+              redo4 = 0xFu;  // more undecided tests than the queue holds: the exact pass takes the whole (wave, split)
+            }
+          }
+        }
+      }
+      if ((u + 1) % UPW == 0) {  // window boundary: 32 tests per register
+#pragma unroll
+        for (int i = 0; i < 16; i++) { total[i] += (uint32_t)__popc(sr[i]); sr[i] = 0; }
+      }
+      if (qn > ql / 2) flush_queue();
+    }
+  }
+  if (qn && redo4 != 0xFu) flush_queue();
+  if (lane == 0) {
+#pragma unroll
+    for (int jj = 0; jj < 4; jj++)
+      if (((redo4 >> jj) & 1u) && (wid * 4 + jj) < n_waves8) {
+        const size_t bit = (size_t)blockIdx.y * n_waves8 + wid * 4 + jj;
+        atomicOr(&redo_bits[bit >> 5], 1u << (bit & 31));
+      }
+  }
+#pragma unroll
+  for (int i = 0; i < 16; i++) {
+    uint32_t c = total[i];
+#pragma unroll
+    for (int o = 16; o > 0; o >>= 1) c += __shfl_xor(c, o, 32);
+    const uint32_t r = 8 * (i >> 2) + 4 * hf + (i & 3), hh = wid * 32 + r;
+    if (col == 0 && hh < ldl) cnt_out[(size_t)blockIdx.y * ldl + hh] = ((redo4 >> (i >> 2)) & 1u) ? 0u : c;
+  }
+}
+
 FilterTileJob filter_tile_job(const FilterPlan& fp, const uint32_t* mx_cur, uint32_t* mx_next, void* tile, void* state) {
   const FilterState f = filter_state(state, fp);
-  return FilterTileJob{fp.rows, mx_cur, mx_next, tile, f.info, f.qcount, f.zero_words};
+  return FilterTileJob{fp.rows, mx_cur, mx_next, tile, f.info, f.qcount, f.zero_words, fp.mode};
 }
 
 void launch_filter_tile(const Points& pts, const FilterTileJob& job, hipStream_t st) {
@@ -859,15 +1325,62 @@ void launch_score_filter(const Points& pts, const float* RtSoA, const float* RtA
                          const FilterPlan& fp, const void* tile, void* state, uint32_t* partial, const Tuning& tn, hipStream_t st) {
   if (sh.n_local == 0) return;
   const FilterState f = filter_state(state, fp);
+  if (fp.mode == 2) {
+    uint32_t ql = tn.filter_lds_queue ? tn.filter_lds_queue : (uint32_t)GX_QL;
+    if (ql > (uint32_t)GX_QL) ql = GX_QL;
+    if (ql < 64) ql = 64;
+#define SC_GRAM_LAUNCH(V)                                                                                                         \
+    hipLaunchKernelGGL(score_gram_kernel<V>, dim3((sh.ld_local + 32 * GX_WAVES - 1) / (32 * GX_WAVES), fp.splits), dim3(64 * GX_WAVES), \
+                       0, st, RtSoA, sh.ld_local, sh.n_local, dv.tau2, static_cast<const uint4*>(tile),                         \
+                       reinterpret_cast<const GramInfo*>(reinterpret_cast<const char*>(f.info) + 64), fp.windows, fp.splits,   \
+                       fp.n_waves, partial, f.queue, f.cap_sq, f.qcount, f.redo, ql)
+    switch (tn.filter_variant) {
+      case 512: SC_GRAM_LAUNCH(512); break;
+      case 256: SC_GRAM_LAUNCH(256); break;
+      case 768: SC_GRAM_LAUNCH(768); break;
+      case 32: SC_GRAM_LAUNCH(32); break;
+      case 288: SC_GRAM_LAUNCH(288); break;
+      case 352: SC_GRAM_LAUNCH(352); break;
+      case 320: SC_GRAM_LAUNCH(320); break;
+      default: SC_GRAM_LAUNCH(0); break;
+    }
+#undef SC_GRAM_LAUNCH
+    hipLaunchKernelGGL(score_exact_kernel, dim3(FX_NQ * 2), dim3(256), 0, st, pts.planes, pts.n, pts.ld,
+                       reinterpret_cast<const float4*>(RtAoS), sh.ld_local, dv.tau2, fp.windows, fp.splits, fp.n_waves, f.queue,
+                       f.cap_sq, f.qcount, f.redo, partial, 1u);
+    return;
+  }
   uint32_t ql = tn.filter_lds_queue ? tn.filter_lds_queue : (uint32_t)FX_QL;
   if (ql > (uint32_t)FX_QL) ql = FX_QL;
   if (ql < 64) ql = 64;  // one step can add 64 entries
-  hipLaunchKernelGGL(score_filter_kernel<FX_WAVES>, dim3(sh.ld_local / (8 * FX_WAVES), fp.splits), dim3(64 * FX_WAVES), 0, st,
-                     RtSoA, sh.ld_local, dv.tau2, static_cast<const uint4*>(tile), f.info, fp.windows, fp.splits, fp.n_waves,
-                     partial, f.queue, f.cap_sq, f.qcount, f.redo, ql);
+  const dim3 grid(sh.ld_local / (8 * FX_WAVES), fp.splits), block(64 * FX_WAVES);
+#define SC_FILTER_LAUNCH(V)                                                                                                  \
+  hipLaunchKernelGGL((score_filter_kernel<FX_WAVES, V>), grid, block, 0, st, RtSoA, sh.ld_local, dv.tau2,                    \
+                     static_cast<const uint4*>(tile), f.info, fp.windows, fp.splits, fp.n_waves, partial, f.queue, f.cap_sq, \
+                     f.qcount, f.redo, ql)
+  switch (tn.filter_variant) {
+    case 1: SC_FILTER_LAUNCH(1); break;
+    case 2: SC_FILTER_LAUNCH(2); break;
+    case 3: SC_FILTER_LAUNCH(3); break;
+    case 16: SC_FILTER_LAUNCH(16); break;
+    case 32: SC_FILTER_LAUNCH(32); break;
+    case 17: SC_FILTER_LAUNCH(17); break;
+    case 33: SC_FILTER_LAUNCH(33); break;
+    case 64: SC_FILTER_LAUNCH(64); break;
+    case 96: SC_FILTER_LAUNCH(96); break;
+    case 80: SC_FILTER_LAUNCH(80); break;
+    case 128: SC_FILTER_LAUNCH(128); break;
+    case 256: SC_FILTER_LAUNCH(256); break;
+    case 512: SC_FILTER_LAUNCH(512); break;
+    case 768: SC_FILTER_LAUNCH(768); break;
+    case 288: SC_FILTER_LAUNCH(288); break;
+    case 272: SC_FILTER_LAUNCH(272); break;
+    default: SC_FILTER_LAUNCH(0); break;
+  }
+#undef SC_FILTER_LAUNCH
   hipLaunchKernelGGL(score_exact_kernel, dim3(FX_NQ * 2), dim3(256), 0, st, pts.planes, pts.n, pts.ld,
                      reinterpret_cast<const float4*>(RtAoS), sh.ld_local, dv.tau2, fp.windows, fp.splits, fp.n_waves, f.queue,
-                     f.cap_sq, f.qcount, f.redo, partial);
+                     f.cap_sq, f.qcount, f.redo, partial, 0u);
 }
 
 hipError_t filter_read_counters(const void* state, const FilterPlan& fp, hipStream_t st, uint64_t* undecided, uint64_t* recounts) {

@@ -991,6 +991,7 @@ def test_score_filter_counts_bit_exact(pkg, O, n, T, scale):
     kw = _params(pkg, float(tau), T)
     cnt0 = O.score(src, tgt, Rt0, kw["tau"])
     for knobs in (dict(score_filter=2), dict(score_filter=2, filter_splits=1), dict(score_filter=2, filter_splits=8),
+                  dict(score_filter=3), dict(score_filter=3, filter_splits=1), dict(score_filter=3, filter_splits=8),
                   dict(score_filter=1)):
         reg.set_debug(**knobs)
         cnt, key = reg.score(src, tgt, pkg.make_params(**kw), Rt0)
@@ -1009,11 +1010,12 @@ def test_score_filter_gives_up_exactly(pkg, O):
     n, T = 3000, 1024
     sc = _scene(pkg, n, seed=77)
     Rt0 = _hyps_near_truth(O, sc, T, seed=3)
-    reg.set_debug(score_filter=2)
-    for tau in (1e-6, 60.0):
-        kw = _params(pkg, tau, T)
-        cnt, _ = reg.score(sc.src, sc.tgt, pkg.make_params(**kw), Rt0)
-        assert np.array_equal(cnt, O.score(sc.src, sc.tgt, Rt0, kw["tau"])), tau
+    for flt in (2, 3):
+        reg.set_debug(score_filter=flt)
+        for tau in (1e-6, 60.0):
+            kw = _params(pkg, tau, T)
+            cnt, _ = reg.score(sc.src, sc.tgt, pkg.make_params(**kw), Rt0)
+            assert np.array_equal(cnt, O.score(sc.src, sc.tgt, Rt0, kw["tau"])), (flt, tau)
     # (3) q = p + tau * u (1 + 1e-5 r): identity-like hypotheses see |residual| = tau up to 1e-5
     rng = np.random.default_rng(5)
     p = rng.uniform(-1, 1, (n, 3)).astype(np.float32)
@@ -1025,15 +1027,17 @@ def test_score_filter_gives_up_exactly(pkg, O):
     kw = _params(pkg, tau, T)
     ref = O.score(p, q, Rt1, kw["tau"])
     assert 0.2 * n < ref.mean() < 0.8 * n                       # the canonical chain decides them one way or the other
-    for knobs in (dict(score_filter=2), dict(score_filter=2, filter_lds_queue=64), dict(score_filter=2, filter_queue_cap=256)):
+    for knobs in (dict(score_filter=2), dict(score_filter=2, filter_lds_queue=64), dict(score_filter=2, filter_queue_cap=256),
+                  dict(score_filter=3), dict(score_filter=3, filter_lds_queue=64), dict(score_filter=3, filter_queue_cap=256)):
         reg.set_debug(**knobs)
         cnt, _ = reg.score(p, q, pkg.make_params(**kw), Rt1)
         assert np.array_equal(cnt, ref), knobs
     # (4) on an ordinary scene
-    reg.set_debug(score_filter=2, filter_queue_cap=256)
-    kw = _params(pkg, 0.05, T)
-    cnt, _ = reg.score(sc.src, sc.tgt, pkg.make_params(**kw), Rt0)
-    assert np.array_equal(cnt, O.score(sc.src, sc.tgt, Rt0, kw["tau"]))
+    for flt in (2, 3):
+        reg.set_debug(score_filter=flt, filter_queue_cap=256)
+        kw = _params(pkg, 0.05, T)
+        cnt, _ = reg.score(sc.src, sc.tgt, pkg.make_params(**kw), Rt0)
+        assert np.array_equal(cnt, O.score(sc.src, sc.tgt, Rt0, kw["tau"])), flt
     reg.close()
 
 
@@ -1082,6 +1086,7 @@ def test_score_filter_equals_fp32_kernel_on_random_scenes(pkg, O):
     """Property: on random scenes of random size, scale, tau and hypothesis quality the filtered counts equal the fp32
     kernel's (GPU against GPU: the fp32 kernel is pinned to the oracle elsewhere)."""
     reg_f = pkg.Registrar(0); reg_f.set_debug(score_filter=2)
+    reg_g = pkg.Registrar(0); reg_g.set_debug(score_filter=3)
     reg_p = pkg.Registrar(0); reg_p.set_debug(score_filter=1)
     rng = np.random.default_rng(2024)
     undecided_seen = 0
@@ -1106,10 +1111,12 @@ def test_score_filter_equals_fp32_kernel_on_random_scenes(pkg, O):
         kw = _params(pkg, tau_rel * scale, T)
         c_f, k_f = reg_f.score(p, q, pkg.make_params(**kw), Rt)
         c_p, k_p = reg_p.score(p, q, pkg.make_params(**kw), Rt)
+        c_g, k_g = reg_g.score(p, q, pkg.make_params(**kw), Rt)
         assert np.array_equal(c_f, c_p) and k_f == k_p, (it, n, T, scale, tau_rel)
+        assert np.array_equal(c_g, c_p) and k_g == k_p, ("gram", it, n, T, scale, tau_rel)
         undecided_seen += int(c_p.max() > 0)
     assert undecided_seen > 10
-    reg_f.close(); reg_p.close()
+    reg_f.close(); reg_p.close(); reg_g.close()
 
 
 def test_score_keeps_the_fp32_kernel_when_tau_is_off_the_filters_scale(pkg, O):
@@ -1166,11 +1173,16 @@ def test_score_every_count_of_the_real_top_T_at_the_baseline_shapes(pkg, O, name
         assert bad.size == 0, (name, bad[:10], cnt[bad[:10]], cnt0[bad[:10]])
         assert k == O.best_key(cnt0)
         info = reg.debug_last()
-        assert info["c2_kernel"] == 1 and info["filter_undecided"] > 0 and info["filter_recounts"] == 0, info
-        # the plain fp32 kernel at the same shape (what sc_debug.score_filter = 1 and the truncated scores run)
-        reg.set_debug(score_filter=1)
-        cnt1, k1 = reg.score(scene.src, scene.tgt, p, Rt0)
-        assert np.array_equal(cnt1, cnt0) and k1 == k and reg.debug_last()["c2_kernel"] == 0
+        # C2, C4: tau is 3 % of the clouds' extent, the Gram filter is chosen; C3 (1 %): the linear one
+        assert info["c2_kernel"] == (1 if name == "C3" else 2) and info["filter_undecided"] > 0 and info["filter_recounts"] == 0, info
+        # ... and each kernel forced: the linear filter, the Gram filter (at C3 it recounts what it cannot bound), the
+        # plain fp32 kernel (what sc_debug.score_filter = 1 and the truncated scores run)
+        for flt, kern in ((2, 1), (3, 2), (1, 0)):
+            reg.set_debug(score_filter=flt)
+            cnt1, k1 = reg.score(scene.src, scene.tgt, p, Rt0)
+            bad = np.nonzero(cnt1 != cnt0)[0]
+            assert bad.size == 0 and k1 == k, (name, flt, bad[:10], cnt1[bad[:10]], cnt0[bad[:10]], reg.debug_last())
+            assert reg.debug_last()["c2_kernel"] == kern
         ref = _oracle_register(O, pkg, name)
         best = 0xFFFFFFFF - (k & 0xFFFFFFFF)
         assert (best, int(cnt0[best])) == (ref["best_rank"], ref["best_count"])
@@ -1243,6 +1255,10 @@ def _check_filter_case(pkg, O, reg, p, q, Rt, tau, k, expect_fast=True):
     if expect_fast:
         assert info["filter_recounts"] == 0, info                      # the filter itself decided: nothing was refused
         assert info["filter_undecided"] >= 0.9 * (k == 0.5).sum(), info  # ... and the planted shell tests really queued
+    reg.set_debug(score_filter=3, filter_queue_cap=1 << 22)   # the Gram filter on the same inputs (it may refuse them: counts only)
+    cntg, keyg = reg.score(p, q, pkg.make_params(**kw), Rt)
+    badg = np.nonzero(cntg != cnt0)[0]
+    assert badg.size == 0 and keyg == key, ("gram", badg[:8], cntg[badg[:8]], cnt0[badg[:8]], reg.debug_last())
     reg.set_debug(score_filter=1)
     cnt1, _ = reg.score(p, q, pkg.make_params(**kw), Rt)
     assert np.array_equal(cnt1, cnt0)

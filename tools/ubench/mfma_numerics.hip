@@ -1,0 +1,70 @@
+// Probe: how v_mfma_f32_32x32x16_f16 rounds and accumulates (nothing in the ISA text pins it down; the Gram filter's error
+// bound — sc_score.hip — states which of these properties it relies on).  Each case sets the 16 products of D[0][0] and C.
+//   hipcc -O3 -w --offload-arch=gfx950 -mllvm -amdgpu-mfma-vgpr-form=1 tools/ubench/mfma_numerics.hip -o /tmp/mn && /tmp/mn
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cmath>
+#include <vector>
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+__global__ void k(const float* a16, const float* b16, float c, float* out) {
+  // row 0 of A = a16[0..15], column 0 of B = b16[0..15]; everything else zero.  lane l: row / column l % 32, k = 8 (l / 32) ..
+  const int lane = threadIdx.x, rc = lane & 31, hf = lane >> 5;
+  half8 A, B;
+  for (int e = 0; e < 8; e++) { A[e] = (_Float16)(rc == 0 ? a16[8 * hf + e] : 0.f); B[e] = (_Float16)(rc == 0 ? b16[8 * hf + e] : 0.f); }
+  f32x16 C; for (int i = 0; i < 16; i++) C[i] = c;
+  f32x16 D = __builtin_amdgcn_mfma_f32_32x32x16_f16(A, B, C, 0, 0, 0);
+  if (lane == 0) out[0] = D[0];
+}
+
+static float run(const std::vector<float>& a, const std::vector<float>& b, float c) {
+  float *da, *db, *dout; hipMalloc(&da, 64); hipMalloc(&db, 64); hipMalloc(&dout, 4);
+  hipMemcpy(da, a.data(), 64, hipMemcpyHostToDevice); hipMemcpy(db, b.data(), 64, hipMemcpyHostToDevice);
+  hipLaunchKernelGGL(k, dim3(1), dim3(64), 0, 0, da, db, c, dout);
+  float r; hipMemcpy(&r, dout, 4, hipMemcpyDeviceToHost);
+  hipFree(da); hipFree(db); hipFree(dout);
+  return r;
+}
+
+int main() {
+  auto Z = [] { return std::vector<float>(16, 0.f); };
+  const float P24 = 16777216.f;
+  { auto a = Z(), b = Z(); a[0] = 1.5f; b[0] = 1.f; printf("C = 2^24, + 1.5                      -> 2^24 + %g   (nearest: 2, truncation: 0)\n", run(a, b, P24) - P24); }
+  { auto a = Z(), b = Z(); a[0] = 1.0f; b[0] = 1.f; printf("C = 2^24, + 1.0 (tie)                -> 2^24 + %g   (ties-to-even: 0, half-up: 2)\n", run(a, b, P24) - P24); }
+  { auto a = Z(), b = Z(); a[0] = 3.0f; b[0] = 1.f; printf("C = 2^24, + 3.0 (tie)                -> 2^24 + %g   (ties-to-even: 4, truncation: 2)\n", run(a, b, P24) - P24); }
+  { auto a = Z(), b = Z(); a[0] = -1.5f; b[0] = 1.f; printf("C = -2^24, - 1.5                     -> -2^24 - %g  (nearest: 2, toward zero: 0)\n", -(run(a, b, -P24) + P24)); }
+  for (int pos = 0; pos < 3; pos++) {
+    // 2^24 and -2^24 as products, 1.5 as a third product, in different slots; C = 0
+    static const int slots[3][3] = {{0, 1, 2}, {0, 8, 15}, {3, 12, 7}};
+    auto a = Z(), b = Z();
+    a[slots[pos][0]] = 4096.f; b[slots[pos][0]] = 4096.f;
+    a[slots[pos][1]] = 1.5f; b[slots[pos][1]] = 1.f;
+    a[slots[pos][2]] = -4096.f; b[slots[pos][2]] = 4096.f;
+    printf("products 2^24 (slot %2d), 1.5 (slot %2d), -2^24 (slot %2d), C = 0   -> %g   (1.5: the dot product is summed exactly / widely; 2 or 0: fp32 steps)\n",
+           slots[pos][0], slots[pos][1], slots[pos][2], run(a, b, 0.f));
+  }
+  { // sixteen products of 0.75 on C = 2^24: exact sum 2^24 + 12
+    auto a = Z(), b = Z(); for (int i = 0; i < 16; i++) { a[i] = 0.75f; b[i] = 1.f; }
+    printf("C = 2^24, + 16 x 0.75                -> 2^24 + %g   (12: products summed before they meet C; 0: sequential truncation; 16/32: sequential nearest)\n", run(a, b, P24) - P24); }
+  { // C small against products: 2^24 product, C = 1.5, -2^24 product
+    auto a = Z(), b = Z(); a[0] = 4096.f; b[0] = 4096.f; a[1] = -4096.f; b[1] = 4096.f;
+    printf("products 2^24, -2^24, C = 1.5        -> %g   (1.5: C joins after / exactly; 2 or 0: C first, then fp32 steps)\n", run(a, b, 1.5f)); }
+  { // sub-normal fp16 inputs: 2^-20 x 2^10 (a sub-normal A) and the mirror
+    auto a = Z(), b = Z(); a[0] = 9.5367431640625e-07f; b[0] = 1024.f;
+    printf("sub-normal A 2^-20 x 1024, C = 0     -> %g   (expected 0.000976562 if sub-normals are kept, 0 if flushed)\n", run(a, b, 0.f));
+    auto a2 = Z(), b2 = Z(); a2[0] = 1024.f; b2[0] = 9.5367431640625e-07f;
+    printf("sub-normal B 2^-20 x 1024, C = 0     -> %g\n", run(a2, b2, 0.f)); }
+  { // random check: error against fp64 of a 16-term dot product with cancellation
+    srand(3); double worst = 0, worst_rel = 0;
+    for (int t = 0; t < 2000; t++) {
+      auto a = Z(), b = Z(); double ex = 0, sabs = 0;
+      for (int i = 0; i < 16; i++) { a[i] = (float)(_Float16)((rand() / (float)RAND_MAX - 0.5f) * 600.f); b[i] = (float)(_Float16)((rand() / (float)RAND_MAX - 0.5f) * 30000.f); ex += (double)a[i] * b[i]; sabs += fabs((double)a[i] * b[i]); }
+      const float c = (float)(-ex + (rand() / (float)RAND_MAX) * 100.0); ex += c; sabs += fabs(c);
+      const double err = fabs((double)run(a, b, c) - ex);
+      if (err / sabs > worst) worst = err / sabs;
+      if (err / (fabs(ex) + 1e-30) > worst_rel) worst_rel = err / fabs(ex);
+    }
+    printf("2000 random cancelling dot products: max |error| / sum|terms| = %.3g (u = 2^-24 = 5.96e-8), max |error| / |result| = %.3g\n", worst, worst_rel); }
+  return 0;
+}
