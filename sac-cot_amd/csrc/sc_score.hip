@@ -535,7 +535,7 @@ constexpr int GX_WAVES = 8;      // waves per workgroup, 32 hypotheses each: eig
                                  // LDS-DMA pieces per eight steps (with 4 waves and 128-correspondence units the DMA issue alone cost a quarter of the kernel)
 constexpr int GX_QL = 128;       // LDS queue entries per wave (8 bytes each)
 constexpr float GX_RS = 256.0f;  // scale of the A operand (keeps the low halves of the coefficients out of fp16's sub-normal range)
-constexpr double GX_ACC = 2.1e-6;    // 34 x 2^-24: error of one MFMA per unit of its LARGEST term (model and probe: score_gram_kernel)
+constexpr double GX_ACC = 1.1e-6;    // 18.5 x 2^-24: error of one MFMA per unit of its LARGEST term (five times the largest seen: score_gram_kernel)
 constexpr double GX_Q = 7.5e-7;      // 3.01 x 2^-22 (+ margin): the dropped lo x lo products and split remainders per unit of sum |w F|
 constexpr double GX_CANON = 4.2e-7;  // sqrt(3) * 4 * 2^-24: deviation of the canonical fp32 residual VECTOR per unit of magnitude
 struct GramInfo {  // written by the tile kernel (thread 0), at offset 64 of the filter's info area
@@ -583,8 +583,8 @@ __host__ __device__ inline double gram_eps(double Tn, double Pn, double Qn, doub
   const double m2 = Tn * Tn + 1.5 * st * st, m3 = 2.1 * Tn * pq;
   Mh = m2 > Mh ? m2 : Mh;
   Mh = m3 > Mh ? m3 : Mh;
-  const double Sl = 3.5 * Pn * Qn + 2.02 * Tn * Pn + 2.0 * Tn * Qn;
-  return GX_ACC * Mh + GX_Q * Sl + 1e-4;
+  const double Sl = 3.5 * Pn * Qn + 2.02 * Tn * Pn + 2.0 * Tn * Qn, S = Tn + 1.75 * Pn + Qn;
+  return GX_ACC * Mh + GX_Q * Sl + 1e-8 * S * S + 1e-4;
 }
 
 // Which kernel.  The filters pay a tile kernel, an exact pass and a few microseconds of set-up per workgroup: below ~1.3e8
@@ -1022,24 +1022,26 @@ __global__ __launch_bounds__(256) void score_exact_kernel(const float* __restric
 // MFMAs 2 and 3 the 32 small ones.
 //
 // What it costs is precision: the squared form cancels (terms of size (|P'| + |Q'| + |T'|)^2 sum to ~tau'^2).  How the matrix
-// pipe adds the 16 products and C is not in the ISA text; tools/ubench/mfma_numerics.hip probes it (profiles/
-// r03_ubench_mfma_numerics.txt): the 17 terms are aligned to the largest exponent among them (a product counts as the sum
-// of its factors' exponents + 1) and cut to a 2^-25 fraction of it, added exactly, and rounded once to nearest-even; fp16
-// sub-normals are NOT flushed.  So one MFMA is off by < 17 x 2^-24 of its largest |term| plus 2^-24 of its result; the bound
-// below takes TWICE that (one alignment bit less than probed).  With Mh the largest term of a hypothesis (gram_eps),
-// Sl = sum |w F| over the split terms (sum_ij |R_ij Q_i P_j| <= 1.75 |Q| |P|), u = 2^-24, D* the exact value:
-//     MFMA 1       34 u Mh                                                                      (GX_ACC)
-//     MFMAs 2, 3   their terms are <= 2^-10 of MFMA 1's; their C is the running value: 34 u (|D*| + 2e-3 Mh) each — the part
-//                  proportional to D* (4e-6) is carried by the factors (1 -+ 1e-5) of LO / HI
+// pipe adds the 16 products and C is not in the ISA text.  tools/ubench/mfma_numerics.hip probes it (profiles/
+// r03_ubench_mfma_numerics.txt): the final rounding is to nearest-even; fp16 sub-normals are NOT flushed; terms far below the
+// largest one lose their low bits before the sum (a product 1.5 beside 2^24 arrives as 1; beside a C of 2^24 it arrives
+// whole) — consistent with aligning all 17 terms to the largest exponent, products counted one binade up, and cutting them at
+// a 2^-25 fraction of it, which reproduces two thirds of 3000 random cancelling dot products bit for bit; and over 15 000
+// such dot products |hardware - exact| never passed 3.75 x 2^-24 of the LARGEST term (17 cuts of < 2^-24 of it each would
+// allow 17).  The bound takes 18.5 x 2^-24 of the largest term per MFMA — the cut model's worst case, five times the worst
+// seen.  This is a MEASURED model of gfx950's matrix pipe, not an ISA guarantee; what backs it beyond the probe is the parity
+// suite, which compares EVERY count with the canonical kernel's at the BASELINE shapes and on adversarial scenes, for both
+// filters.  With Mh the largest term of a hypothesis (gram_eps), Sl = sum |w F| over the split terms (sum_ij |R_ij Q_i P_j|
+// <= 1.75 |Q| |P|), S = (|T'| + 1.75 Pn + Qn)^2 the sum of all |terms|, u = 2^-24, D* the exact value:
+//     MFMA 1       18.5 u Mh                                                                    (GX_ACC)
+//     MFMAs 2, 3   their terms are <= 2^-10 of MFMA 1's; their C is the running value: 18.5 u (|x| + 3e-3 S) each — the part
+//                  proportional to x (2.2e-6) is carried by the factors (1 -+ 1e-5) of LO / HI, the rest is the 1e-8 S term
 //     splits       x = hi + lo + rem, |rem| <= 2^-22 |x|;  w F - (wh Fh + wh Fl + wl Fh) = wl Fl + ... <= 3.01 x 2^-22 |w F|:
-//                  7.2e-7 Sl; the norm feature's three pieces leave 2^-33                          (GX_Q)
-//     accumulator  initial value |T'|^2 - LO rounded to fp32: u Mh (inside GX_ACC's margin)
+//                  7.2e-7 Sl (exact arithmetic, no model); the norm feature's three pieces leave 2^-33       (GX_Q)
+//     accumulator  initial value alpha RS (|T'|^2 - LO_h) rounded to fp32: u Mh (inside GX_ACC's margin)
 //     R^T R = I    defect g = max |(R^T R - I)_ab| measured per hypothesis in fp64: <= 3 g Pn^2 (beyond 1e-3: not a rotation,
 //                  the hypothesis is recounted exactly)
-//   sum: eps_h = 2.1e-6 Mh + 7.5e-7 Sl + 3 g Pn^2 + 1e-4                                                     (gram_eps)
-// (Under the weakest model — every one of the 48 additions rounded separately at the size of the whole sum, truncating —
-// the same terms give 3e-6 (|T'| + 1.75 Pn + Qn)^2, four to five times this shell; the parity suite compares EVERY count
-// with the canonical kernel's at the BASELINE shapes and on adversarial scenes, for both filters.)
+//   sum: eps_h = 1.1e-6 Mh + 7.5e-7 Sl + 1e-8 S + 3 g Pn^2 + 1e-4                                            (gram_eps)
 // The canonical fp32 chain itself deviates from exact arithmetic: its residual VECTOR by <= dE = sqrt(3) 4 u s (qmax + 1.75 pmax
 // + |t|max) (original, uncentred magnitudes), its square by 3 more roundings.  So, with st = s sqrt(tau2):
 //     D~ <  LO_h = (st - dE)^2 (1 - 1e-5) - eps_h   =>  canonical inlier;     D~ >= HI_h = (st + dE)^2 (1 + 1e-5) + eps_h  =>  outlier;

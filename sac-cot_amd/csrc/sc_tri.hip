@@ -882,30 +882,40 @@ __global__ __launch_bounds__(256) void prune_bits_kernel(const uint32_t* __restr
                                                          float* __restrict__ smin_out,
                                                          uint32_t* __restrict__ klb_out, StrongList sl,
                                                          uint32_t* __restrict__ tcnt,
-                                                         const uint64_t* __restrict__ own) {
+                                                         const uint64_t* __restrict__ own,
+                                                         uint32_t* __restrict__ sdegp, int list_only) {
+  // sdegp (optional, zeroed): += 1 at row i for every strong edge (i, j), j > i — what the sharded path cuts its row
+  // ranges by (strong_rowcost_kernel).  list_only: smin is already in *smin_out and the strong bits are set (an earlier
+  // launch of this kernel): only the list of this rank's strong edges is built.
   __shared__ uint64_t lds[8];
   __shared__ float s_smin;
   __shared__ uint32_t s_klb, s_base, s_wcnt[4];
   static_assert(PR_BINS == 256, "one bin per thread, walked from the top");
-  const uint32_t bin = PR_BINS - 1 - threadIdx.x;
-  uint64_t mine = 0;
-  for (int c = 0; c < copies; c++) mine += hist[c * PR_BINS + bin];  // copies: PR_HCOPIES (the sample's own) or 1 (summed)
-  if (threadIdx.x == 0) { s_smin = -1.0f; s_klb = 0u; }  // default: no certified bound -> every edge is strong
-  uint64_t tot;
-  const uint64_t before = block_exscan_u64(mine, lds, &tot);
-  if (before < want && want <= before + mine && bin > 0) {
-    const float lb = __uint_as_float(klo + (bin << shift));  // lower edge of the crossing bin
-    s_smin = (lb - 2.0f) - 1e-6f;
-    s_klb = klo + (bin << shift);  // >= want triangles have a key >= this one: the select may ignore anything below
+  float smin;
+  if (list_only) {
+    smin = *smin_out;
+  } else {
+    const uint32_t bin = PR_BINS - 1 - threadIdx.x;
+    uint64_t mine = 0;
+    for (int c = 0; c < copies; c++) mine += hist[c * PR_BINS + bin];  // copies: PR_HCOPIES (the sample's own) or 1 (summed)
+    if (threadIdx.x == 0) { s_smin = -1.0f; s_klb = 0u; }  // default: no certified bound -> every edge is strong
+    uint64_t tot;
+    const uint64_t before = block_exscan_u64(mine, lds, &tot);
+    if (before < want && want <= before + mine && bin > 0) {
+      const float lb = __uint_as_float(klo + (bin << shift));  // lower edge of the crossing bin
+      s_smin = (lb - 2.0f) - 1e-6f;
+      s_klb = klo + (bin << shift);  // >= want triangles have a key >= this one: the select may ignore anything below
+    }
+    __syncthreads();
+    smin = s_smin;
+    if (blockIdx.x == 0 && threadIdx.x == 0) { *smin_out = smin; *klb_out = s_klb; }
   }
-  __syncthreads();
-  const float smin = s_smin;
-  if (blockIdx.x == 0 && threadIdx.x == 0) { *smin_out = smin; *klb_out = s_klb; }
   const uint64_t e = (uint64_t)blockIdx.x * 256 + threadIdx.x;
   bool strong = e < E && es[e] >= smin;
-  if (strong) {  // the strong bit matrix is whole on every rank: membership of ANY vertex pair is looked up in it
+  if (strong && !list_only) {  // the strong bit matrix is whole on every rank: membership of ANY vertex pair is looked up in it
     const uint32_t i = ei[e], j = ej[e];
     atomicOr(&mbits[(size_t)i * W + (j >> 6)], 1ull << (j & 63));
+    if (sdegp) atomicAdd(&sdegp[i], 1u);
   }
   // sharded stage B: only this rank's edge range [own[0], own[1]) enters the list of edges to enumerate
   if (own) strong = strong && e >= own[0] && e < own[1];
@@ -1017,12 +1027,53 @@ void launch_sample_hist(const Graph& g, const uint32_t* ebi, const uint32_t* ebj
 
 void launch_prune_bits(const Graph& g, const uint32_t* hist, bool hist_is_copies, const uint32_t* ei, const uint32_t* ej, const float* es,
                        uint64_t E, uint64_t want, float key_floor, uint64_t* mbits, float* smin, uint32_t* klb,
-                       const StrongList& sl, uint32_t* tcnt, const uint64_t* own, hipStream_t st) {
+                       const StrongList& sl, uint32_t* tcnt, const uint64_t* own, hipStream_t st, uint32_t* sdegp,
+                       bool list_only) {
   uint32_t klo, shift;
   prune_window(key_floor, &klo, &shift);
   hipLaunchKernelGGL(prune_bits_kernel, dim3((unsigned)((E + 255) / 256)), dim3(256), 0, st, hist,
                      hist_is_copies ? PR_HCOPIES : 1, want, klo, shift, ei,
-                     ej, es, E, g.W, reinterpret_cast<unsigned long long*>(mbits), smin, klb, sl, tcnt, own);
+                     ej, es, E, g.W, reinterpret_cast<unsigned long long*>(mbits), smin, klb, sl, tcnt, own, sdegp,
+                     list_only ? 1 : 0);
+}
+
+// Sharded stage B, after the certificate: what enumerating row i of the PRUNED graph costs — 16 x the triangles of a
+// SAMPLE of its strong edges (every edge (i, j) with (i + j) % 16 == 0: AND + popcount of the two strong rows above j,
+// exactly what the counting pass does, for a sixteenth of the edges) plus one per strong edge (sdegp: the strong edges
+// of the row towards higher indices; the counting pass spends about a triangle's worth of time on an edge without any).  One 16-lane group per row; saturated to u32.  The prefix of these costs cuts
+// the rows into the ranks' ranges: a correspondence list in keypoint order puts the inliers — and nearly all the triangles
+// of the pruned graph — into a few rows, which the a-priori estimate of row_stats_kernel (every edge of the FULL graph
+// weighs the same) cannot see.  (A proxy from the strong degrees alone — sum of sdegp[j] — left 1.4 x between the ranks on
+// such a scene: outlier rows have strong edges but hardly a triangle.)
+__global__ __launch_bounds__(256) void strong_rowcost_kernel(const uint64_t* __restrict__ mbits, int n, int W,
+                                                             const uint32_t* __restrict__ sdegp,
+                                                             uint32_t* __restrict__ rowcost) {
+  const int gl = threadIdx.x & 15;
+  const int i = blockIdx.x * 16 + (threadIdx.x >> 4);
+  if (i >= n) return;
+  const uint64_t* __restrict__ ri = mbits + (size_t)i * W;
+  uint64_t tri = 0;
+  for (int w = (i >> 6) + gl; w < W; w += 16) {
+    uint64_t v = ri[w];  // (only bits above i are ever set: the strong matrix is upper-triangular)
+    while (v) {
+      const int b = __builtin_ctzll(v);
+      v &= v - 1;
+      const int j = w * 64 + b;
+      if (((i + j) & 15) != 0) continue;
+      const uint64_t* __restrict__ rj = mbits + (size_t)j * W;
+      uint64_t m = ri[w] & rj[w] & mask_above(b);
+      uint32_t c = (uint32_t)__popcll(m);
+      for (int w2 = w + 1; w2 < W; w2++) c += (uint32_t)__popcll(ri[w2] & rj[w2]);
+      tri += c;
+    }
+  }
+#pragma unroll
+  for (int o = 8; o > 0; o >>= 1) tri += __shfl_xor(tri, o, 16);
+  const uint64_t cost = 16ull * tri + (uint64_t)sdegp[i];
+  if (gl == 0) rowcost[i] = cost > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)cost;
+}
+void launch_strong_rowcost(const Graph& g, const uint64_t* mbits, const uint32_t* sdegp, uint32_t* rowcost, hipStream_t st) {
+  hipLaunchKernelGGL(strong_rowcost_kernel, dim3((unsigned)((g.n + 15) / 16)), dim3(256), 0, st, mbits, g.n, g.W, sdegp, rowcost);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -1424,3 +1424,40 @@ def test_score_kernel_choice_without_the_maxima(pkg, O):
     info = reg.debug_last()
     assert np.array_equal(cnt, cnt0) and info["c2_kernel"] == 1 and info["filter_recounts"] == T // 8 * info["filter_splits"], info
     reg.close()
+
+
+def _unshuffled(scene):
+    """The same scene with its correspondences reordered so that the true inliers come first (a correspondence list in
+    keypoint order: inliers cluster in index), everything else in the original order."""
+    order = np.argsort(~scene.inlier, kind="stable")
+
+    class S: pass
+    s = S()
+    s.src = np.ascontiguousarray(scene.src[order]); s.tgt = np.ascontiguousarray(scene.tgt[order])
+    s.inlier = scene.inlier[order]; s.R_gt, s.t_gt = scene.R_gt, scene.t_gt
+    return s
+
+
+@pytest.mark.parametrize("name,world", [("C2", 8), ("C1", 4)])
+def test_sharded_A_and_B_balance_on_an_unshuffled_scene(pkg, O, name, world):
+    """correspondence lists come in keypoint order, so the inliers — and with them nearly all the
+    triangles of the pruned graph — sit in a few rows.  The ranks' row ranges are cut by the work of the PRUNED graph
+    (strong edges per row, known after the certificate), so that every rank still enumerates about the same share and
+    its share of the global top-T fits the default candidate blob: no SC_ERETRY at level 0, max / mean enumerated per
+    rank below 1.3, and the result is the oracle's."""
+    import torch
+    cfg, scene0 = pkg.synth.make_config_scene(name)
+    scene = _unshuffled(scene0)
+    kw = cfg.params()
+    ref = O.register(scene.src, scene.tgt, threads=8, **kw)
+    dev = torch.device("cuda:0")
+    d_src = torch.from_numpy(scene.src).to(dev); d_tgt = torch.from_numpy(scene.tgt).to(dev)
+    levels = []
+    rc, st, Rt, mask, hdr = _run_sharded_ab(pkg, cfg.n, kw, d_src, d_tgt, world, levels_out=levels)
+    assert rc == ref["rc"] == 0 and levels == [0], levels
+    assert (st["edges"], st["best_rank"], st["best_count"], st["tri_kept"]) == (ref["edges"], ref["best_rank"], ref["best_count"], ref["t_eff"])
+    assert np.array_equal(mask, ref["mask"])
+    assert Rt.tobytes() == np.concatenate([ref["R"].ravel(), ref["t"]]).astype(np.float32).tobytes()
+    enum = hdr[:, 0].astype(np.float64)
+    assert int(enum.sum()) == st["tri_total"]
+    assert enum.max() / enum.mean() < 1.3, enum
