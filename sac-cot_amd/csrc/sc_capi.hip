@@ -46,7 +46,7 @@ struct sc_ctx {
   // workspace
   Buf in_src, in_tgt, planes, S, bits, deg, degp, wpre, ebase, edge_off, scan_tmp, ei, ej, es, ebi, ebj, tcnt, toff, wkey, kcol, ctl, events, blk_gt,
       blk_eq, blk_minmax, bits2, off_gt, off_eq, sel_ord, sel_key, sortkey, sorted, sort_tmp, tri, tri_rk, key_rk, rt, rt_aos, partial, cnt, key, rt12,
-      mask, refine_tmp, amx_pairs, strong, rowcost, cost_pre, lb_state, lb_ticket, fx_tile, fx_state, fx_mx, fx_part, sdegp;
+      mask, refine_tmp, amx_pairs, strong, rowcost, cost_pre, lb_state, lb_ticket, fx_tile, fx_state, fx_mx, fx_part, sdegp, fx_coef;
   bool filter_on = false;   // C2 of the running / last call goes through a matrix-pipe filter (decided ONCE per call)
   int filter_mode = 0;      // ... which: 1 linear, 2 Gram (0: the plain fp32 kernel)
   FilterPlan fx_plan{};     // ... with this plan (sc_debug_last reads the filter's counters through it)
@@ -727,7 +727,7 @@ void sc_destroy(sc_ctx* c) {
   Buf* bufs[] = {&c->in_src, &c->in_tgt, &c->planes, &c->S, &c->bits, &c->deg, &c->degp, &c->wpre, &c->ebase, &c->edge_off, &c->scan_tmp,
                  &c->ei, &c->ej, &c->es, &c->ebi, &c->ebj, &c->tcnt, &c->toff, &c->wkey, &c->kcol, &c->ctl, &c->events, &c->blk_gt, &c->blk_eq, &c->blk_minmax, &c->bits2, &c->off_gt,
                  &c->off_eq, &c->sel_ord, &c->sel_key, &c->sortkey, &c->sorted, &c->sort_tmp, &c->tri, &c->tri_rk, &c->key_rk, &c->rt,
-                 &c->rt_aos, &c->partial, &c->cnt, &c->key, &c->rt12, &c->mask, &c->refine_tmp, &c->amx_pairs, &c->strong, &c->rowcost, &c->cost_pre, &c->lb_state, &c->lb_ticket, &c->fx_tile, &c->fx_state, &c->fx_mx, &c->fx_part, &c->sdegp};
+                 &c->rt_aos, &c->partial, &c->cnt, &c->key, &c->rt12, &c->mask, &c->refine_tmp, &c->amx_pairs, &c->strong, &c->rowcost, &c->cost_pre, &c->lb_state, &c->lb_ticket, &c->fx_tile, &c->fx_state, &c->fx_mx, &c->fx_part, &c->sdegp, &c->fx_coef};
   for (Buf* b : bufs) if (b->p) (void)hipFree(b->p);
   for (int i = 0; i < N_EVENTS; i++) if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
   if (c->pinned) (void)hipHostFree(c->pinned);
@@ -862,8 +862,9 @@ int filter_job(sc_ctx* c, const Shard& sh, FilterTileJob* job) {
   const FilterPlan& fp = c->fx_plan;
   ENSURE(c, c->fx_tile, fp.tile_bytes);
   ENSURE(c, c->fx_state, fp.state_bytes);
+  if (fp.coef_bytes) ENSURE(c, c->fx_coef, fp.coef_bytes);
   uint32_t* mx = c->fx_mx.as<uint32_t>();
-  *job = filter_tile_job(fp, mx, nullptr, c->fx_tile.p, c->fx_state.p);
+  *job = filter_tile_job(fp, mx, nullptr, c->fx_tile.p, c->fx_state.p, c->fx_coef.p, sh.ld_local, c->dv.tau2);
   return SC_OK;
 }
 
@@ -877,9 +878,10 @@ int run_score(sc_ctx* c, const sc_params* p, const Shard& sh, uint32_t* rows, bo
       int rc = filter_job(c, sh, &job);
       if (rc) return rc;
       launch_filter_tile(points_of(c), job, c->stream);
+      if (fp.mode == 2) launch_gram_coef(c->rt.as<float>(), sh, c->dv.tau2, c->fx_mx.as<uint32_t>(), job.coef, c->stream);
     }
     launch_score_filter(points_of(c), c->rt.as<float>(), c->rt_aos.as<float>(), sh, c->dv, fp, c->fx_tile.p, c->fx_state.p,
-                        c->partial.as<uint32_t>(), c->tn, c->stream);
+                        c->fx_coef.p, c->partial.as<uint32_t>(), c->tn, c->stream);
     return SC_OK;
   }
   const bool scalar = score_is_scalar(p->score_mode, c->tn);

@@ -400,8 +400,16 @@ void launch_score(const Points& pts, const float* RtSoA, const float* RtAoS, con
 struct FilterPlan {
   uint32_t mode;  // 1 linear, 2 Gram
   uint32_t windows, splits, n_waves, rows, queue_cap;
-  size_t tile_bytes, state_bytes;
+  size_t tile_bytes, state_bytes, coef_bytes;  // coef_bytes: the Gram filter's per-hypothesis coefficients (0 for the linear one)
 };
+// Gram filter: what its waves load instead of computing it (made once per call: launch_kabsch's threads, or launch_gram_coef)
+struct GramCoef {
+  void* A;            // 64 bytes per hypothesis: fp16 halves of its 16 coefficients
+  float* C;           // accumulator start value per hypothesis
+  uint2* wave;        // per 32 hypotheses: {shell width W (fp32 bits), recount groups | any row filtered << 4}
+  uint32_t n_waves32;
+};
+GramCoef gram_coef_view(void* buf, uint32_t ld_local);
 // which kernel stage C2 runs: 0 = plain fp32 kernel, 1 = linear filter, 2 = Gram filter.  By score mode, size, the knobs of
 // sc_debug and — unless forced — by whether tau is on a scale the filter can bound (host_max / host_box: the coordinate
 // maxima and bounding boxes the staging kernel published; ~0 = not known: assume the linear filter applies, never Gram).
@@ -410,12 +418,17 @@ int score_filter_mode(int score_mode, const Tuning& tn, int n, uint32_t ld_local
 FilterPlan filter_plan(int n, uint32_t ld_local, const Tuning& tn, uint32_t mode);
 struct FilterTileJob {  // what the tile kernel needs (filter_tile_job fills it)
   uint32_t rows; const uint32_t* mx_cur; uint32_t* mx_next; void* tile; void* info; uint32_t* zero; uint32_t zero_words; uint32_t mode;
+  GramCoef coef; float tau2;  // mode 2: the Kabsch threads of the same launch also write their hypotheses' coefficients
 };
-FilterTileJob filter_tile_job(const FilterPlan& fp, const uint32_t* mx_cur, uint32_t* mx_next, void* tile, void* state);
+FilterTileJob filter_tile_job(const FilterPlan& fp, const uint32_t* mx_cur, uint32_t* mx_next, void* tile, void* state,
+                              void* coef, uint32_t ld_local, float tau2);
+// the coefficients on their own (stage hook sc_score_host, which has no Kabsch launch)
+void launch_gram_coef(const float* RtSoA, const Shard& sh, float tau2, const uint32_t* mx, const GramCoef& coef, hipStream_t st);
 void launch_filter_tile(const Points& pts, const FilterTileJob& job, hipStream_t st);  // on its own (stage hook sc_score_host)
 // RtAoS: 12 consecutive floats per hypothesis (what the exact pass loads; launch_kabsch / the stage hook write them)
 void launch_score_filter(const Points& pts, const float* RtSoA, const float* RtAoS, const Shard& sh, const Derived& dv,
-                         const FilterPlan& fp, const void* tile, void* state, uint32_t* partial, const Tuning& tn, hipStream_t st);
+                         const FilterPlan& fp, const void* tile, void* state, void* coef, uint32_t* partial, const Tuning& tn,
+                         hipStream_t st);
 // diagnostics (sc_debug_last): what the filter of the last launch handed to the exact pass.  Blocking copies on `st`.
 hipError_t filter_read_counters(const void* state, const FilterPlan& fp, hipStream_t st, uint64_t* undecided, uint64_t* recounts);
 // Winner key pair key2[0..1] (written, not accumulated: no zeroing needed):

@@ -36,6 +36,64 @@ uint32_t shard_local_count(uint32_t T_eff, uint32_t block, uint32_t rank, uint32
   return (uint32_t)n;
 }
 
+// ---- Gram filter: constants shared by host and device -------------------------------------------------------------
+constexpr int GX_UNIT = 256;     // correspondences per staging unit (8 MFMA steps of 32): 24 KiB; LDS holds two
+constexpr int GX_WAVES = 8;      // waves per workgroup, 32 hypotheses each: eight waves share a tile, so each of them issues three 1 KiB
+                                 // LDS-DMA pieces per eight steps (with 4 waves and 128-correspondence units the DMA issue alone cost a quarter of the kernel)
+constexpr int GX_QL = 128;       // LDS queue entries per wave (8 bytes each)
+constexpr float GX_RS = 256.0f;  // scale of the A operand (keeps the low halves of the coefficients out of fp16's sub-normal range)
+constexpr double GX_ACC = 1.1e-6;    // 18.5 x 2^-24: error of one MFMA per unit of its LARGEST term (five times the largest seen: score_gram_kernel)
+constexpr double GX_Q = 7.5e-7;      // 3.01 x 2^-22 (+ margin): the dropped lo x lo products and split remainders per unit of sum |w F|
+constexpr double GX_CANON = 4.2e-7;  // sqrt(3) * 4 * 2^-24: deviation of the canonical fp32 residual VECTOR per unit of magnitude
+struct GramInfo {  // written by the tile kernel (thread 0), at offset 64 of the filter's info area
+  float s;         // power of two: the largest half extent of either bounding box -> [64, 128)
+  float cP[3], cQ[3];  // centres of the boxes (fp32; the shift is applied in fp64)
+  float Pn, Qn;    // upper bounds of |P'|, |Q'| (scaled, centred Euclidean norms)
+  float pmax_o, qmax_o;  // max |coordinate| of the original (unscaled, uncentred) clouds: what the canonical chain rounds at
+  float pad[5];
+};
+// scale, centres and norm bounds from the bounding boxes (keys as the staging kernel leaves them: [c] max, [6 + c] -min)
+__host__ __device__ inline GramInfo gram_info(const uint32_t* key_hi, const uint32_t* key_lo, float pmax_o, float qmax_o) {
+  GramInfo g;
+  double half[6], hmax = 0.0;
+  for (int c = 0; c < 6; c++) {
+    const float mx = float_unkey(key_hi[c]), mn = -float_unkey(key_lo[c]);
+    const float ctr = 0.5f * mx + 0.5f * mn;
+    (c < 3 ? g.cP[c] : g.cQ[c - 3]) = ctr;
+    const double a = (double)mx - (double)ctr, b = (double)ctr - (double)mn;
+    half[c] = a > b ? a : b;
+    hmax = half[c] > hmax ? half[c] : hmax;
+  }
+  int e = 0;
+  if (hmax > 0.0) {  // hmax in [2^e, 2^(e+1))
+    union { double d; uint64_t u; } x; x.d = hmax;
+    e = (int)((x.u >> 52) & 2047u) - 1023;
+  }
+  int k = 6 - e;
+  k = k > 100 ? 100 : (k < -100 ? -100 : k);
+  union { float f; uint32_t u; } sc; sc.u = (uint32_t)(k + 127) << 23;
+  g.s = sc.f;
+  const double s = (double)g.s;
+  const double pn = s * sqrt(half[0] * half[0] + half[1] * half[1] + half[2] * half[2]) * (1.0 + 1e-6);
+  const double qn = s * sqrt(half[3] * half[3] + half[4] * half[4] + half[5] * half[5]) * (1.0 + 1e-6);
+  g.Pn = (float)(pn * (1.0 + 1e-6)); g.Qn = (float)(qn * (1.0 + 1e-6));
+  g.pmax_o = pmax_o; g.qmax_o = qmax_o;
+  for (int i = 0; i < 5; i++) g.pad[i] = 0.f;
+  return g;
+}
+// shell half-width of a hypothesis with |T'| = Tn at st = s tau, in units of the scaled squared residual (the device adds its
+// own R^T R defect term per hypothesis).  Mh: the largest single term of the 48-term dot product (2 |Q'_i P'_j| <= Pn^2 + Qn^2);
+// Sl: the sum of the absolute values of the 15 split terms.
+__host__ __device__ inline double gram_eps(double Tn, double Pn, double Qn, double st) {
+  const double pq = Pn > Qn ? Pn : Qn;
+  double Mh = 1.05 * (Pn * Pn + Qn * Qn);
+  const double m2 = Tn * Tn + 1.5 * st * st, m3 = 2.1 * Tn * pq;
+  Mh = m2 > Mh ? m2 : Mh;
+  Mh = m3 > Mh ? m3 : Mh;
+  const double Sl = 3.5 * Pn * Qn + 2.02 * Tn * Pn + 2.0 * Tn * Qn, S = Tn + 1.75 * Pn + Qn;
+  return GX_ACC * Mh + GX_Q * Sl + 1e-8 * S * S + 1e-4;
+}
+
 // ------------------------------------------------------------------------------------------------
 // C1
 // ------------------------------------------------------------------------------------------------
@@ -69,6 +127,8 @@ __device__ __forceinline__ void tri_lookup(const TriSource& ts, uint32_t g, uint
 
 __device__ void filter_tile_block(const float* __restrict__ planes, int n, int ld, const FilterTileJob& job, uint32_t block,
                                   uint32_t blocks);
+__device__ void gram_coef_wave(const GramCoef& coef, const GramInfo& gi, const float v[12], uint32_t l, uint32_t ldl,
+                               uint32_t n_local, float tau2);
 
 __global__ __launch_bounds__(256) void kabsch_shard_kernel(const float* __restrict__ planes, int n, int ld, TriSource ts,
                                                            Shard sh, float* __restrict__ RtSoA,
@@ -77,6 +137,11 @@ __global__ __launch_bounds__(256) void kabsch_shard_kernel(const float* __restri
   if (blockIdx.x >= kabsch_blocks) {  // the extra workgroups: C2's fp16 tile of the correspondences (see filter_tile_block)
     filter_tile_block(planes, n, ld, job, blockIdx.x - kabsch_blocks, gridDim.x - kabsch_blocks);
     return;
+  }
+  __shared__ GramInfo s_gi;
+  if (job.mode == 2) {  // (block-uniform) the Gram filter's scale and centres, once per block
+    if (threadIdx.x == 0) s_gi = gram_info(job.mx_cur + 2, job.mx_cur + 8, __uint_as_float(job.mx_cur[0]), __uint_as_float(job.mx_cur[1]));
+    __syncthreads();
   }
   const uint32_t l = blockIdx.x * 256 + threadIdx.x;
   if (l >= sh.ld_local) return;
@@ -100,6 +165,8 @@ __global__ __launch_bounds__(256) void kabsch_shard_kernel(const float* __restri
     o[1] = make_float4(Rt[4], Rt[5], Rt[6], Rt[7]);
     o[2] = make_float4(Rt[8], Rt[9], Rt[10], Rt[11]);
   }
+  // the Gram filter's coefficients of this hypothesis (whole waves get here: ld_local is a multiple of 256)
+  if (job.mode == 2) gram_coef_wave(job.coef, s_gi, Rt, l, sh.ld_local, sh.n_local, job.tau2);
 }
 
 void launch_kabsch(const Points& pts, const TriSource& ts, const Shard& sh, float* RtSoA, float* RtAoS,
@@ -529,64 +596,6 @@ static FilterState filter_state(void* state, const FilterPlan& fp) {
   return f;
 }
 
-// ---- Gram filter: constants shared by host and device -------------------------------------------------------------
-constexpr int GX_UNIT = 256;     // correspondences per staging unit (8 MFMA steps of 32): 24 KiB; LDS holds two
-constexpr int GX_WAVES = 8;      // waves per workgroup, 32 hypotheses each: eight waves share a tile, so each of them issues three 1 KiB
-                                 // LDS-DMA pieces per eight steps (with 4 waves and 128-correspondence units the DMA issue alone cost a quarter of the kernel)
-constexpr int GX_QL = 128;       // LDS queue entries per wave (8 bytes each)
-constexpr float GX_RS = 256.0f;  // scale of the A operand (keeps the low halves of the coefficients out of fp16's sub-normal range)
-constexpr double GX_ACC = 1.1e-6;    // 18.5 x 2^-24: error of one MFMA per unit of its LARGEST term (five times the largest seen: score_gram_kernel)
-constexpr double GX_Q = 7.5e-7;      // 3.01 x 2^-22 (+ margin): the dropped lo x lo products and split remainders per unit of sum |w F|
-constexpr double GX_CANON = 4.2e-7;  // sqrt(3) * 4 * 2^-24: deviation of the canonical fp32 residual VECTOR per unit of magnitude
-struct GramInfo {  // written by the tile kernel (thread 0), at offset 64 of the filter's info area
-  float s;         // power of two: the largest half extent of either bounding box -> [64, 128)
-  float cP[3], cQ[3];  // centres of the boxes (fp32; the shift is applied in fp64)
-  float Pn, Qn;    // upper bounds of |P'|, |Q'| (scaled, centred Euclidean norms)
-  float pmax_o, qmax_o;  // max |coordinate| of the original (unscaled, uncentred) clouds: what the canonical chain rounds at
-  float pad[5];
-};
-// scale, centres and norm bounds from the bounding boxes (keys as the staging kernel leaves them: [c] max, [6 + c] -min)
-__host__ __device__ inline GramInfo gram_info(const uint32_t* key_hi, const uint32_t* key_lo, float pmax_o, float qmax_o) {
-  GramInfo g;
-  double half[6], hmax = 0.0;
-  for (int c = 0; c < 6; c++) {
-    const float mx = float_unkey(key_hi[c]), mn = -float_unkey(key_lo[c]);
-    const float ctr = 0.5f * mx + 0.5f * mn;
-    (c < 3 ? g.cP[c] : g.cQ[c - 3]) = ctr;
-    const double a = (double)mx - (double)ctr, b = (double)ctr - (double)mn;
-    half[c] = a > b ? a : b;
-    hmax = half[c] > hmax ? half[c] : hmax;
-  }
-  int e = 0;
-  if (hmax > 0.0) {  // hmax in [2^e, 2^(e+1))
-    union { double d; uint64_t u; } x; x.d = hmax;
-    e = (int)((x.u >> 52) & 2047u) - 1023;
-  }
-  int k = 6 - e;
-  k = k > 100 ? 100 : (k < -100 ? -100 : k);
-  union { float f; uint32_t u; } sc; sc.u = (uint32_t)(k + 127) << 23;
-  g.s = sc.f;
-  const double s = (double)g.s;
-  const double pn = s * sqrt(half[0] * half[0] + half[1] * half[1] + half[2] * half[2]) * (1.0 + 1e-6);
-  const double qn = s * sqrt(half[3] * half[3] + half[4] * half[4] + half[5] * half[5]) * (1.0 + 1e-6);
-  g.Pn = (float)(pn * (1.0 + 1e-6)); g.Qn = (float)(qn * (1.0 + 1e-6));
-  g.pmax_o = pmax_o; g.qmax_o = qmax_o;
-  for (int i = 0; i < 5; i++) g.pad[i] = 0.f;
-  return g;
-}
-// shell half-width of a hypothesis with |T'| = Tn at st = s tau, in units of the scaled squared residual (the device adds its
-// own R^T R defect term per hypothesis).  Mh: the largest single term of the 48-term dot product (2 |Q'_i P'_j| <= Pn^2 + Qn^2);
-// Sl: the sum of the absolute values of the 15 split terms.
-__host__ __device__ inline double gram_eps(double Tn, double Pn, double Qn, double st) {
-  const double pq = Pn > Qn ? Pn : Qn;
-  double Mh = 1.05 * (Pn * Pn + Qn * Qn);
-  const double m2 = Tn * Tn + 1.5 * st * st, m3 = 2.1 * Tn * pq;
-  Mh = m2 > Mh ? m2 : Mh;
-  Mh = m3 > Mh ? m3 : Mh;
-  const double Sl = 3.5 * Pn * Qn + 2.02 * Tn * Pn + 2.0 * Tn * Qn, S = Tn + 1.75 * Pn + Qn;
-  return GX_ACC * Mh + GX_Q * Sl + 1e-8 * S * S + 1e-4;
-}
-
 // Which kernel.  The filters pay a tile kernel, an exact pass and a few microseconds of set-up per workgroup: below ~1.3e8
 // tests the plain kernel is as fast or faster (C1, 2e7 tests: 9 us plain, 20 us filtered).
 int score_filter_mode(int score_mode, const Tuning& tn, int n, uint32_t ld_local, uint64_t host_max, const uint64_t* host_box,
@@ -666,6 +675,7 @@ FilterPlan filter_plan(int n, uint32_t ld_local, const Tuning& tn, uint32_t mode
   fp.tile_bytes = (size_t)fp.rows * (mode == 2 ? 96 : 32);
   const size_t bm_words = ((size_t)fp.splits * fp.n_waves + 31) / 32;
   fp.state_bytes = 128 + (size_t)FX_NQ * 128 + (bm_words * 4 + 127) / 128 * 128 + (size_t)fp.queue_cap * 8;
+  fp.coef_bytes = mode == 2 ? (size_t)ld_local * 64 + (size_t)ld_local * 4 + (size_t)(ld_local / 32) * 8 : 0;
   return fp;
 }
 
@@ -1107,42 +1117,15 @@ __device__ void gram_tile_block(const float* __restrict__ planes, int n, int ld,
   }
 }
 
-template <int VAR>  // (timing-only ablations for tools/ab_stage.py: 512 = no shell test, 256 = no barrier, 32 = no epilogue)
-__global__ __launch_bounds__(64 * GX_WAVES, 2) void score_gram_kernel(const float* __restrict__ Rt, uint32_t ldl, uint32_t n_local,
-                                                                     float tau2, const uint4* __restrict__ tile,
-                                                                     const GramInfo* __restrict__ info, uint32_t windows,
-                                                                     uint32_t splits, uint32_t n_waves8,
-                                                                     uint32_t* __restrict__ cnt_out, uint2* __restrict__ gq,
-                                                                     uint32_t cap_sq, uint32_t* __restrict__ qcount,
-                                                                     uint32_t* __restrict__ redo_bits, uint32_t ql) {
-  __shared__ uint4 Bt[2][GX_UNIT * 6];           // 2 x 12 KiB
-  __shared__ float Ctab[GX_WAVES][32];
-  __shared__ uint2 queue[GX_WAVES][GX_QL];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int col = lane & 31, hf = lane >> 5;
-  const uint32_t per = (windows + splits - 1) / splits, w0 = blockIdx.y * per, w1 = min(windows, w0 + per);
-  const uint32_t wid = blockIdx.x * GX_WAVES + wave;  // wave of 32 hypotheses
-  constexpr uint32_t UPW = FX_WIN / GX_UNIT;          // units per window
-  const uint32_t u0 = w0 * UPW, u1 = w1 * UPW;
-  auto stage = [&](uint32_t u, int buf) {  // (asm: see score_filter_kernel)
-#pragma unroll
-    for (int i = 0; i < GX_UNIT * 6 / (64 * GX_WAVES); i++) {
-      const uint4* gsrc = tile + (size_t)u * (GX_UNIT * 6) + 64 * GX_WAVES * i + tid;
-      const uint32_t lds_dst = __builtin_amdgcn_readfirstlane(
-          (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)(&Bt[buf][64 * GX_WAVES * i + wave * 64]));
-      unsigned keep;
-      asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                   : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
-    }
-  };
-  if (u0 < u1) stage(u0, 0);
-  const GramInfo gi = *info;
-  // ---- prologue: lane (row, hf) builds the coefficients of hypothesis wid * 32 + row (both halves compute the same)
-  const uint32_t row = (uint32_t)col, h = wid * 32 + row;
-  const bool in_grid = h < ldl;  // (ldl is a multiple of 256; the last workgroup may reach beyond it when it is not one of 128)
-  float v[12];
-#pragma unroll
-  for (int c = 0; c < 12; c++) v[c] = in_grid ? Rt[(size_t)c * ldl + h] : 0.f;
+// Per-hypothesis coefficients of the Gram filter, made ONCE per call (by the Kabsch launch's own threads, or by
+// gram_coef_kernel for the stage hook) instead of by every wave of every grid split of the filter: lane = hypothesis l of this
+// rank's shard; the 32 lanes of a half wave are the 32 rows of one filter wave (shuffles of width 32).
+//   coef.A      64 bytes per hypothesis: [hi halves of the 16 coefficients | lo halves, slot 9 = the hi half again]
+//   coef.C      the accumulator's start value of the row (alpha RS (|T'|^2 - LO_h), or +huge for a row that is switched off)
+//   coef.wave   per 32 hypotheses: {W as fp32 bits, recount groups (4 bits) | any row filtered << 4}
+__device__ void gram_coef_wave(const GramCoef& coef, const GramInfo& gi, const float v[12], uint32_t l, uint32_t ldl,
+                               uint32_t n_local, float tau2) {
+  const bool in_grid = l < ldl;
   const double s = (double)gi.s, st = s * (double)sqrt_rn(tau2);
   double R[9], Tp[3];
 #pragma unroll
@@ -1176,7 +1159,7 @@ __global__ __launch_bounds__(64 * GX_WAVES, 2) void score_gram_kernel(const floa
   for (int i = 0; i < 3; i++) a16[13 + i] = -2.0 * (double)GX_RS / 256.0 * Tp[i];
   const double eps = gram_eps(Tn, Pn, Qn, st) + 3.0 * gdef * Pn * Pn;
   const bool finite = nanp == 0.f;
-  const bool pad = !in_grid || h >= n_local;
+  const bool pad = !in_grid || l >= n_local;
   const bool rot = finite && gdef <= 1e-3 && Tn < 1e6;
   const bool far = rot && (Tn - 1.002 * Pn - Qn >= st + dE + 1.0);
   // (st <= 64: the sentinel correspondences' 2 x 60000 must stay far above every threshold)
@@ -1192,42 +1175,96 @@ __global__ __launch_bounds__(64 * GX_WAVES, 2) void score_gram_kernel(const floa
   // alpha is cut to 11 significant bits (rounded to fp16 after shrinking by 2^-10, so never above the ratio): the norm
   // feature's coefficient 2 RS alpha then has no low half, like 2 RS itself — its three pieces need three slots, not six
   const double alpha = normal ? (double)(float)(_Float16)(float)(fmin(16.0, wmax / width) * (1.0 - 1.0 / 1024.0)) : 0.0;
-  const uint32_t normal_rows = (uint32_t)__ballot(normal);        // (both lane halves agree: bits 0..31)
+  const int half = (int)((threadIdx.x >> 5) & 1u);                // which 32-lane half of the wave this lane sits in
+  const uint32_t normal_rows = (uint32_t)(__ballot(normal) >> (32 * half));
+  const uint32_t rc = (uint32_t)(__ballot(recount) >> (32 * half));
   uint32_t redo4 = 0;                                             // groups of 8 rows the exact pass recounts
-  {
-    const uint32_t rc = (uint32_t)__ballot(recount);
 #pragma unroll
-    for (int jj = 0; jj < 4; jj++) redo4 |= ((rc >> (8 * jj)) & 0xFFu) ? (1u << jj) : 0u;
-  }
+  for (int jj = 0; jj < 4; jj++) redo4 |= ((rc >> (8 * jj)) & 0xFFu) ? (1u << jj) : 0u;
   const bool any_normal = normal_rows != 0u;
-  const uint32_t W2b = (any_normal && !(VAR & 512)) ? __float_as_uint((float)((double)GX_RS * wmax * (1.0 + 1e-6))) : 0u;
-  // accumulator start per row: alpha RS (|T'|^2 - LO_h) for a filtered hypothesis, +huge (never an inlier, never undecided)
-  // otherwise; rows of a group that is recounted anyway are switched off too
+  const uint32_t W2b = any_normal ? __float_as_uint((float)((double)GX_RS * wmax * (1.0 + 1e-6))) : 0u;
+  const uint32_t row = l & 31u;
+  // rows of a group that is recounted anyway are switched off too
   const bool live = normal && !((redo4 >> (row >> 3)) & 1u);
-  if (hf == 0) Ctab[wave][row] = live ? (float)(alpha * (double)GX_RS * (Tn * Tn - LOh)) : 1e30f;
+  if (!in_grid) return;
+  coef.C[l] = live ? (float)(alpha * (double)GX_RS * (Tn * Tn - LOh)) : 1e30f;
+  if (row == 0) coef.wave[l >> 5] = make_uint2(W2b, redo4 | (any_normal ? 16u : 0u));
   _Float16 ah[16], al[16];
 #pragma unroll
-  for (int k = 0; k < 16; k++) split2(alpha * a16[k], ah[k], al[k]);
-  half8 A0, A1, A2;
-  {
-    const _Float16 z = (_Float16)0.f;
-#pragma unroll
-    for (int e = 0; e < 8; e++) {
-      const _Float16 xh = hf ? ah[8 + e] : ah[e], xl = hf ? al[8 + e] : al[e];  // (hf is lane-varying: select, not index)
-      A0[e] = live ? xh : z;   // hi x hi
-      A1[e] = live ? xh : z;   // hi x lo (the tile's second block holds the low halves)
-      A2[e] = live ? ((hf && e == 1) ? xh : xl) : z;   // lo x hi (slot 9: the norm's third piece, coefficient 2 RS alpha again)
-    }
+  for (int k = 0; k < 16; k++) {
+    split2(alpha * a16[k], ah[k], al[k]);
+    if (!live) { ah[k] = (_Float16)0.f; al[k] = (_Float16)0.f; }
   }
-  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // Ctab: written and read by this wave only
+  al[9] = ah[9];  // slot 9 of the third MFMA: the norm's third piece, coefficient 2 RS alpha again (it has no low half)
+  uint4* __restrict__ out = reinterpret_cast<uint4*>(coef.A) + (size_t)l * 4;
+  half8 q0 = {ah[0], ah[1], ah[2], ah[3], ah[4], ah[5], ah[6], ah[7]}, q1 = {ah[8], ah[9], ah[10], ah[11], ah[12], ah[13], ah[14], ah[15]};
+  half8 q2 = {al[0], al[1], al[2], al[3], al[4], al[5], al[6], al[7]}, q3 = {al[8], al[9], al[10], al[11], al[12], al[13], al[14], al[15]};
+  out[0] = *reinterpret_cast<uint4*>(&q0); out[1] = *reinterpret_cast<uint4*>(&q1);
+  out[2] = *reinterpret_cast<uint4*>(&q2); out[3] = *reinterpret_cast<uint4*>(&q3);
+}
+
+__global__ __launch_bounds__(256) void gram_coef_kernel(const float* __restrict__ RtSoA, uint32_t ldl, uint32_t n_local, float tau2,
+                                                        const uint32_t* __restrict__ mx, GramCoef coef) {
+  const uint32_t l = blockIdx.x * 256 + threadIdx.x;
+  const GramInfo gi = gram_info(mx + 2, mx + 8, __uint_as_float(mx[0]), __uint_as_float(mx[1]));
+  float v[12];
+#pragma unroll
+  for (int c = 0; c < 12; c++) v[c] = l < ldl ? RtSoA[(size_t)c * ldl + l] : 0.f;
+  gram_coef_wave(coef, gi, v, l, ldl, n_local, tau2);
+}
+
+template <int VAR>  // (timing-only ablations for tools/ab_stage.py: 512 = no shell test, 256 = no barrier, 32 = no epilogue)
+__global__ __launch_bounds__(64 * GX_WAVES, 2) void score_gram_kernel(GramCoef coef, uint32_t ldl,
+                                                                     const uint4* __restrict__ tile, uint32_t windows,
+                                                                     uint32_t splits, uint32_t n_waves8,
+                                                                     uint32_t* __restrict__ cnt_out, uint2* __restrict__ gq,
+                                                                     uint32_t cap_sq, uint32_t* __restrict__ qcount,
+                                                                     uint32_t* __restrict__ redo_bits, uint32_t ql) {
+  __shared__ uint4 Bt[2][GX_UNIT * 6];           // 2 x 24 KiB
+  __shared__ uint2 queue[GX_WAVES][GX_QL];
+  __shared__ uint32_t qfill[GX_WAVES];          // entries in each wave's queue (LDS atomics of the lanes that hit)
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int col = lane & 31, hf = lane >> 5;
+  const uint32_t per = (windows + splits - 1) / splits, w0 = blockIdx.y * per, w1 = min(windows, w0 + per);
+  const uint32_t wid = blockIdx.x * GX_WAVES + wave;  // wave of 32 hypotheses
+  constexpr uint32_t UPW = FX_WIN / GX_UNIT;          // units per window
+  const uint32_t u0 = w0 * UPW, u1 = w1 * UPW;
+  auto stage = [&](uint32_t u, int buf) {  // (asm: see score_filter_kernel)
+#pragma unroll
+    for (int i = 0; i < GX_UNIT * 6 / (64 * GX_WAVES); i++) {
+      const uint4* gsrc = tile + (size_t)u * (GX_UNIT * 6) + 64 * GX_WAVES * i + tid;
+      const uint32_t lds_dst = __builtin_amdgcn_readfirstlane(
+          (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)(&Bt[buf][64 * GX_WAVES * i + wave * 64]));
+      unsigned keep;
+      asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                   : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+    }
+  };
+  if (u0 < u1) stage(u0, 0);
+  // ---- prologue: the coefficients were made once per call by gram_coef_wave (lane (row, hf) takes the halves of its row)
+  const uint32_t row = (uint32_t)col, h = wid * 32 + row;
+  const bool in_grid = h < ldl;  // (ldl is a multiple of 256: the last workgroup cannot reach beyond it)
+  const uint4* __restrict__ ca = reinterpret_cast<const uint4*>(coef.A) + (size_t)(in_grid ? h : 0) * 4;
+  const uint4 a0 = ca[hf], a2 = ca[2 + hf];
+  half8 A0 = *reinterpret_cast<const half8*>(&a0), A2 = *reinterpret_cast<const half8*>(&a2);
+  const half8 A1 = A0;  // hi x lo: the tile's second block holds the low halves of the features
+  const uint2 wv = coef.wave[wid < coef.n_waves32 ? wid : 0];
+  const uint32_t W2b = (VAR & 512) ? 0u : wv.x;
+  uint32_t redo4 = wv.y & 0xFu;
+  const bool any_normal = (wv.y >> 4) & 1u;
   f32x16 C;
 #pragma unroll
-  for (int i = 0; i < 16; i++) C[i] = Ctab[wave][8 * (i >> 2) + 4 * hf + (i & 3)];
+  for (int jj = 0; jj < 4; jj++) {
+    const float4 c4 = *reinterpret_cast<const float4*>(coef.C + (size_t)wid * 32 + 8 * jj + 4 * hf);
+    C[4 * jj] = c4.x; C[4 * jj + 1] = c4.y; C[4 * jj + 2] = c4.z; C[4 * jj + 3] = c4.w;
+  }
   uint32_t total[16], sr[16];
 #pragma unroll
   for (int i = 0; i < 16; i++) { total[i] = 0; sr[i] = 0; }
   uint32_t qn = 0;
   uint2* q = queue[wave];
+  if (lane == 0) qfill[wave] = 0u;
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // (qfill[wave]: this wave's own word)
   auto flush_queue = [&]() {  // the wave's queue -> its global sub-queue (one ticket); see score_filter_kernel
     const uint32_t sq = wid % FX_NQ;
     uint32_t base = 0;
@@ -1238,6 +1275,9 @@ __global__ __launch_bounds__(64 * GX_WAVES, 2) void score_gram_kernel(const floa
       gq[(size_t)sq * cap_sq + base + i] = fits ? make_uint2(q[i].x, (wid << 17) | q[i].y) : make_uint2(0u, 0u);
     if (!fits) redo4 = 0xFu;
     qn = 0;
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // the entries were read before the fill is reset
+    if (lane == 0) qfill[wave] = 0u;
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
   };
   for (uint32_t u = u0; u < u1; u++) {
     const int buf = (int)((u - u0) & 1u);
@@ -1250,17 +1290,11 @@ __global__ __launch_bounds__(64 * GX_WAVES, 2) void score_gram_kernel(const floa
     }
     if (any_normal && redo4 != 0xFu) {
       const half8* Bc = reinterpret_cast<const half8*>(Bt[buf]) + lane;
-      half8 b0 = Bc[0], b1 = Bc[64], b2 = Bc[128];
-#pragma unroll 1
-      for (int g = 0; g < GX_UNIT / 32; g++) {
-        f32x16 D = __builtin_amdgcn_mfma_f32_32x32x16_f16(A0, b0, C, 0, 0, 0);
-        D = __builtin_amdgcn_mfma_f32_32x32x16_f16(A1, b1, D, 0, 0, 0);
-        D = __builtin_amdgcn_mfma_f32_32x32x16_f16(A2, b2, D, 0, 0, 0);
-        if (g + 1 < GX_UNIT / 32) { b0 = Bc[192 * (g + 1)]; b1 = Bc[192 * (g + 1) + 64]; b2 = Bc[192 * (g + 1) + 128]; }
-        // sign bit: D~ < LO_h, a certain inlier.  Shell test 0 <= x < W as an unsigned minimum, kept per group of four
-        // registers: with 1024 tests per step a step has an undecided test one time in four, so the path that queues them
-        // must be short — it looks at the four group minima first and only at the registers of a group that hit.
-        if constexpr ((VAR & 32) != 0) { sr[0] ^= __float_as_uint(D[0]) ^ __float_as_uint(D[5]) ^ __float_as_uint(D[10]) ^ __float_as_uint(D[15]); continue; }
+      // the vector work of one step.  sign bit: D~ < LO_h, a certain inlier.  Shell test 0 <= x < W as an unsigned minimum,
+      // kept per group of four registers: with 1024 tests per step a step has an undecided test one time in four, so the
+      // path that queues them must be short — it looks at the four group minima first and only at a group that hit.
+      auto epilogue = [&](const f32x16& D, int g) {
+        if constexpr ((VAR & 32) != 0) { sr[0] ^= __float_as_uint(D[0]) ^ __float_as_uint(D[5]) ^ __float_as_uint(D[10]) ^ __float_as_uint(D[15]); return; }
         uint32_t gm[4];
 #pragma unroll
         for (int j = 0; j < 4; j++) {
@@ -1269,25 +1303,39 @@ __global__ __launch_bounds__(64 * GX_WAVES, 2) void score_gram_kernel(const floa
           gm[j] = min(min(min(__float_as_uint(D[4 * j]), __float_as_uint(D[4 * j + 1])), __float_as_uint(D[4 * j + 2])), __float_as_uint(D[4 * j + 3]));  // v_min3 + v_min
         }
         const uint32_t mn = min(min(min(gm[0], gm[1]), gm[2]), gm[3]);
-        const uint64_t hm = __ballot(mn < W2b);
-        if (__builtin_expect(hm != 0, 0)) {
+        if (__builtin_expect(__ballot(mn < W2b) != 0, 0)) {
+          // Rare per test, not per step: no wave-wide bookkeeping here — a lane that hit takes a slot of the wave's LDS queue
+          // with an LDS atomic and writes its entry; the count is looked at once per unit.  Groups of four registers that
+          // no lane hit are skipped (wave-uniform branch).
 #pragma unroll
           for (int j = 0; j < 4; j++) {
-            const uint64_t hj = __ballot(gm[j] < W2b);
-            if (hj == 0) continue;   // (wave-uniform)
-            const uint32_t k2 = (uint32_t)__popcll(hj);
-            if (qn + k2 <= ql) {
+            if (__ballot(gm[j] < W2b) == 0) continue;
+            if (gm[j] < W2b) {
               uint32_t bits = 0;
 #pragma unroll
               for (int i = 0; i < 4; i++) bits |= (__float_as_uint(D[4 * j + i]) < W2b) ? (1u << (4 * j + i)) : 0u;
-              if (gm[j] < W2b) q[qn + __popcll(hj & ((1ull << lane) - 1ull))] = make_uint2(u * GX_UNIT + 32 * g + col, ((uint32_t)hf << 16) | bits);
-              qn += k2;
-            } else {
-              redo4 = 0xFu;  // more undecided tests than the queue holds: the exact pass takes the whole (wave, split)
+              const uint32_t slot = atomicAdd(&qfill[wave], 1u);
+              if (slot < ql) q[slot] = make_uint2(u * GX_UNIT + 32 * g + col, ((uint32_t)hf << 16) | bits);
             }
           }
         }
+      };
+      // One step after the other: issuing step g + 1's chain before step g's vector work (a software pipeline with two
+      // accumulator sets) was built and measured — hipcc rotates the loop into THREE sets with 16 moves per trip and
+      // spills in the queueing path: C4 335 -> 403 us, C2 52 -> 57.  The waves of a SIMD overlap each other instead.
+      half8 b0 = Bc[0], b1 = Bc[64], b2 = Bc[128];
+#pragma unroll 1
+      for (int g = 0; g < GX_UNIT / 32; g++) {
+        f32x16 D = __builtin_amdgcn_mfma_f32_32x32x16_f16(A0, b0, C, 0, 0, 0);
+        D = __builtin_amdgcn_mfma_f32_32x32x16_f16(A1, b1, D, 0, 0, 0);
+        D = __builtin_amdgcn_mfma_f32_32x32x16_f16(A2, b2, D, 0, 0, 0);
+        // the next step's operands: three 16-byte LDS reads, in flight under this step's vector work
+        if (g + 1 < GX_UNIT / 32) { b0 = Bc[192 * (g + 1)]; b1 = Bc[192 * (g + 1) + 64]; b2 = Bc[192 * (g + 1) + 128]; }
+        epilogue(D, g);
       }
+      // the queue's fill (LDS, this wave's own word): beyond ql entries were dropped — the exact pass takes the whole (wave, split)
+      qn = *(volatile uint32_t*)&qfill[wave];
+      if (qn > ql) { redo4 = 0xFu; qn = 0; *(volatile uint32_t*)&qfill[wave] = 0u; }
       if ((u + 1) % UPW == 0) {  // window boundary: 32 tests per register
 #pragma unroll
         for (int i = 0; i < 16; i++) { total[i] += (uint32_t)__popc(sr[i]); sr[i] = 0; }
@@ -1314,9 +1362,27 @@ __global__ __launch_bounds__(64 * GX_WAVES, 2) void score_gram_kernel(const floa
   }
 }
 
-FilterTileJob filter_tile_job(const FilterPlan& fp, const uint32_t* mx_cur, uint32_t* mx_next, void* tile, void* state) {
+GramCoef gram_coef_view(void* buf, uint32_t ld_local) {
+  GramCoef g;
+  unsigned char* p = static_cast<unsigned char*>(buf);
+  g.A = p; p += (size_t)ld_local * 64;
+  g.C = reinterpret_cast<float*>(p); p += (size_t)ld_local * 4;
+  g.wave = reinterpret_cast<uint2*>(p);
+  g.n_waves32 = ld_local / 32;
+  return g;
+}
+
+FilterTileJob filter_tile_job(const FilterPlan& fp, const uint32_t* mx_cur, uint32_t* mx_next, void* tile, void* state,
+                              void* coef, uint32_t ld_local, float tau2) {
   const FilterState f = filter_state(state, fp);
-  return FilterTileJob{fp.rows, mx_cur, mx_next, tile, f.info, f.qcount, f.zero_words, fp.mode};
+  FilterTileJob j{fp.rows, mx_cur, mx_next, tile, f.info, f.qcount, f.zero_words, fp.mode, GramCoef{nullptr, nullptr, nullptr, 0}, tau2};
+  if (fp.mode == 2) j.coef = gram_coef_view(coef, ld_local);
+  return j;
+}
+
+void launch_gram_coef(const float* RtSoA, const Shard& sh, float tau2, const uint32_t* mx, const GramCoef& coef, hipStream_t st) {
+  if (sh.ld_local == 0) return;
+  hipLaunchKernelGGL(gram_coef_kernel, dim3(sh.ld_local / 256), dim3(256), 0, st, RtSoA, sh.ld_local, sh.n_local, tau2, mx, coef);
 }
 
 void launch_filter_tile(const Points& pts, const FilterTileJob& job, hipStream_t st) {
@@ -1324,18 +1390,19 @@ void launch_filter_tile(const Points& pts, const FilterTileJob& job, hipStream_t
 }
 
 void launch_score_filter(const Points& pts, const float* RtSoA, const float* RtAoS, const Shard& sh, const Derived& dv,
-                         const FilterPlan& fp, const void* tile, void* state, uint32_t* partial, const Tuning& tn, hipStream_t st) {
+                         const FilterPlan& fp, const void* tile, void* state, void* coef, uint32_t* partial, const Tuning& tn,
+                         hipStream_t st) {
   if (sh.n_local == 0) return;
   const FilterState f = filter_state(state, fp);
   if (fp.mode == 2) {
     uint32_t ql = tn.filter_lds_queue ? tn.filter_lds_queue : (uint32_t)GX_QL;
     if (ql > (uint32_t)GX_QL) ql = GX_QL;
     if (ql < 64) ql = 64;
+    const GramCoef gc = gram_coef_view(coef, sh.ld_local);
 #define SC_GRAM_LAUNCH(V)                                                                                                         \
     hipLaunchKernelGGL(score_gram_kernel<V>, dim3((sh.ld_local + 32 * GX_WAVES - 1) / (32 * GX_WAVES), fp.splits), dim3(64 * GX_WAVES), \
-                       0, st, RtSoA, sh.ld_local, sh.n_local, dv.tau2, static_cast<const uint4*>(tile),                         \
-                       reinterpret_cast<const GramInfo*>(reinterpret_cast<const char*>(f.info) + 64), fp.windows, fp.splits,   \
-                       fp.n_waves, partial, f.queue, f.cap_sq, f.qcount, f.redo, ql)
+                       0, st, gc, sh.ld_local, static_cast<const uint4*>(tile), fp.windows, fp.splits, fp.n_waves, partial,         \
+                       f.queue, f.cap_sq, f.qcount, f.redo, ql)
     switch (tn.filter_variant) {
       case 512: SC_GRAM_LAUNCH(512); break;
       case 256: SC_GRAM_LAUNCH(256); break;
@@ -1344,6 +1411,7 @@ void launch_score_filter(const Points& pts, const float* RtSoA, const float* RtA
       case 288: SC_GRAM_LAUNCH(288); break;
       case 352: SC_GRAM_LAUNCH(352); break;
       case 320: SC_GRAM_LAUNCH(320); break;
+      case 1: SC_GRAM_LAUNCH(1); break;
       default: SC_GRAM_LAUNCH(0); break;
     }
 #undef SC_GRAM_LAUNCH
