@@ -74,24 +74,29 @@ N_SIMD = 256 * 4
 
 
 def issue_model(n: int, n_local: int, us: float, info: dict) -> dict:
-    """The filter kernel against its OWN issue limits: a step = one v_mfma_f32_32x32x16_f16 (8 hypotheses x
-    32 correspondences; 32 cycles = 8 passes of 4 on the matrix pipe) plus the vector instructions that consume it.
-    `cycles_per_step`: measured — duration of the whole C2 stage x clock / steps per SIMD (so it includes the exact pass,
-    set-up and tail).  `bound_*`: what a SIMD needs per step if (a) the vector instructions of other waves issue under a
-    wave's MFMA, each at the multi-wave rate of 2 cycles (MI355X_MICROARCH.md), against (b) fully serialised issue at 4."""
+    """The C2 filter kernel against its OWN issue limits, so that `roofline.frac` — an fp32-EQUIVALENT rate —
+    is not read as a utilisation.  A step = the MFMAs that produce one accumulator tile plus the vector instructions that
+    consume it:  linear filter: 1 MFMA (8 hypotheses x 32 correspondences, 256 tests), ~26 vector instructions;  Gram
+    filter: 3 chained MFMAs (32 hypotheses x 32 correspondences, 1024 tests), ~30 vector instructions.
+    `cycles_per_step`: measured — duration of the whole C2 stage x the NOMINAL clock / steps per SIMD (it includes the exact
+    pass, set-up and tail; under this load the chip holds 1.9 - 2.1 GHz, so real cycles are ~15 % fewer).
+    `bound_matrix_cycles`: 32 cycles per MFMA.  `bound_vector_cycles`: what tools/ubench/mfma_lds.hip measures for vector
+    instructions issued beside MFMAs on one SIMD: 8 cycles of issue per MFMA + 3.3 cycles per vector instruction (2.3
+    without MFMAs in flight; the 2-cycle figure of the guide is never reached here)."""
+    gram = info.get("c2_kernel") == 2
     windows = (n + 1023) // 1024
-    steps = (n_local / 8.0) * windows * 32          # MFMAs of the launch
+    hyp_per_wave, mfma_per_step, valu = (32, 3, 30.0) if gram else (8, 1, 26.0)
+    steps = (n_local / float(hyp_per_wave)) * windows * 32          # accumulator tiles of the launch
     per_simd = steps / N_SIMD
     cyc = us * 1e-6 * GPU_CLOCK_HZ / max(per_simd, 1.0)
-    valu = FILTER_VALU_PER_STEP
-    overlapped = max(32.0, valu * 2.0 + 8.0)      # MFMA holds the vector issue port for 8 of its 32 cycles
-    serial = valu * 4.0 + 32.0
-    return {"cycles_per_step": round(cyc, 1), "valu_per_step": valu, "bound_overlapped_cycles": overlapped,
-            "bound_serialised_cycles": serial, "frac_of_overlapped_bound": round(overlapped / cyc, 3),
-            "clock_hz": GPU_CLOCK_HZ, "undecided_entries": info.get("filter_undecided"), "recounts": info.get("filter_recounts")}
-
-
-FILTER_VALU_PER_STEP = 30.0  # vector instructions per step in the filter's inner loop (PMC: SQ_INSTS_VALU / MFMA count; DESIGN §5)
+    matrix = 32.0 * mfma_per_step
+    vector = 8.0 * mfma_per_step + 3.3 * valu
+    bound = max(matrix, vector)
+    return {"filter": "gram" if gram else "linear", "tests_per_step": 32 * hyp_per_wave, "cycles_per_step": round(cyc, 1),
+            "mfma_per_step": mfma_per_step, "valu_per_step": valu, "bound_matrix_cycles": matrix,
+            "bound_vector_cycles": round(vector, 1), "frac_of_issue_bound": round(bound / cyc, 3),
+            "clock_hz_nominal": GPU_CLOCK_HZ, "undecided_entries": info.get("filter_undecided"),
+            "recounts": info.get("filter_recounts")}
 
 
 def spawn_ranks(n: int) -> int:
@@ -282,8 +287,9 @@ def main() -> int:
                        "traffic": None, "algorithmic_bytes": int(compat_bytes), "avg_us": round(avg["compat"], 2),
                        "note": "duration: HIP-event bracket around this kernel alone, on the hot path (one bracket per pass)"
                                + ("" if dense else "; SC_FLAG_NO_DENSE_S: bit rows only, the kernel is arithmetic-bound")}
-        filtered = c2_info["c2_kernel"] == 1                           # what the library says it ran (sc_debug_last), not a guess
-        roof_score = {"kernel": "score_filter_kernel + score_exact_kernel" if filtered else "score_kernel",
+        filtered = c2_info["c2_kernel"] in (1, 2)                     # what the library says it ran (sc_debug_last), not a guess
+        fk = {0: "score_kernel", 1: "score_filter_kernel + score_exact_kernel", 2: "score_gram_kernel + score_exact_kernel"}[c2_info["c2_kernel"]]
+        roof_score = {"kernel": fk,
                       "bound": "fp32-equivalent" if filtered else "valu",
                       "achieved": round(score_tflops, 2),
                       "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(score_tflops / FP32_PEAK_TFLOPS, 4),
@@ -292,9 +298,11 @@ def main() -> int:
                       "note": ("`achieved` is an fp32-EQUIVALENT algorithmic rate (27 flop per test of the canonical chain), not a "
                                "utilisation of the vector pipe: the filter runs on the f16 matrix pipe and could pass 1.0 of this "
                                "yardstick; how far it is from its own issue limits is `issue_model`. " if filtered else "") +
-                              ("stage C2 = fp16-split matrix-pipe filter (4.6 vector instructions + 1/256 MFMA per test) + exact "
-                               "fp32 pass over the undecided tests; counts identical to the fp32 kernel. " if filtered else
-                               "fp32 vector kernel. ") +
+                              ({1: "stage C2 = fp16-split matrix-pipe filter on the residual VECTOR (4.75 vector instructions + 1/256 MFMA per "
+                                   "test) + exact fp32 pass over the undecided tests; counts identical to the fp32 kernel. ",
+                                2: "stage C2 = Gram-form matrix-pipe filter (the MFMA evaluates the SQUARED residual: 1.6 vector "
+                                   "instructions + 3/1024 MFMA per test) + exact fp32 pass over the undecided tests; counts identical to "
+                                   "the fp32 kernel. ", 0: "fp32 vector kernel. "}[c2_info["c2_kernel"]]) +
                               "ALGORITHMIC flops (27 per test, SURVEY 8d) over the duration of the whole C2 stage; not HBM-bound "
                               "(~8 MB moved); peak = fp32 vector rate = dense f32-input MFMA rate (157.3 TFLOP/s); duration "
                               "from HIP events inside the timed steps"}

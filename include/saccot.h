@@ -187,6 +187,7 @@ typedef struct sc_debug {
   uint32_t filter_lds_queue;  /* entries of a wave's own queue, 64 .. 256 (0 = 256)                                   */
   uint32_t es_hist_unfused;   /* 1: stage B's edge-weight histogram by a launch of its own instead of inside edge_fill  */
   uint32_t filter_variant;    /* body of the filter kernel: 0 = default; others = bit-identical scheduling variants and (>= 16) timing-only ablations (tools/ab_stage.py) */
+  uint32_t dense_async;       /* 1: stage A writes the dense matrix S from a second, low-priority stream while stage B already runs on the bit rows (measured: DESIGN.md) */
   uint32_t filter_blind;      /* 1: the host picks stage C2's kernel as if the coordinate maxima had not arrived yet (it then assumes the filter applies; the filter's own range test sends what it cannot bound to the exact recount) */
 } sc_debug;
 int         sc_set_debug(sc_ctx* ctx, const sc_debug* dbg);

@@ -80,7 +80,7 @@ class ScDebug(C.Structure):
                 ("sample_blocks", C.c_uint32), ("compact_fused", C.c_uint32), ("rows_unfused", C.c_uint32),
                 ("score_scalar", C.c_uint32), ("score_filter", C.c_uint32), ("filter_splits", C.c_uint32),
                 ("filter_queue_cap", C.c_uint32), ("filter_lds_queue", C.c_uint32), ("es_hist_unfused", C.c_uint32),
-                ("filter_variant", C.c_uint32), ("filter_blind", C.c_uint32)]
+                ("filter_variant", C.c_uint32), ("dense_async", C.c_uint32), ("filter_blind", C.c_uint32)]
 
 
 class ScDebugInfo(C.Structure):

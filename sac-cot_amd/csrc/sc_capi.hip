@@ -46,7 +46,10 @@ struct sc_ctx {
   // workspace
   Buf in_src, in_tgt, planes, S, bits, deg, degp, wpre, ebase, edge_off, scan_tmp, ei, ej, es, ebi, ebj, tcnt, toff, wkey, kcol, ctl, events, blk_gt,
       blk_eq, blk_minmax, bits2, off_gt, off_eq, sel_ord, sel_key, sortkey, sorted, sort_tmp, tri, tri_rk, key_rk, rt, rt_aos, partial, cnt, key, rt12,
-      mask, refine_tmp, amx_pairs, strong, rowcost, cost_pre, lb_state, lb_ticket, fx_tile, fx_state, fx_mx, fx_part, sdegp, fx_coef;
+      mask, refine_tmp, amx_pairs, strong, rowcost, cost_pre, lb_state, lb_ticket, fx_tile, fx_state, fx_mx, fx_part, sdegp, fx_coef, bits_s;
+  hipStream_t stream2 = nullptr;  // low-priority stream of the asynchronous dense-S launch (Tuning::dense_async)
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  bool dense_pending = false;
   bool filter_on = false;   // C2 of the running / last call goes through a matrix-pipe filter (decided ONCE per call)
   int filter_mode = 0;      // ... which: 1 linear, 2 Gram (0: the plain fp32 kernel)
   FilterPlan fx_plan{};     // ... with this plan (sc_debug_last reads the filter's counters through it)
@@ -264,7 +267,10 @@ int stage_inputs(sc_ctx* c, const float* d_src, const float* d_tgt, int64_t n, c
 }
 
 // dense: also write the n x n weight matrix S (SC_FLAG_NO_DENSE_S clears it: nothing after stage A reads S)
-int run_compat(sc_ctx* c, bool dense) {
+// Tuning::dense_async (hot path only): the dense matrix S — which nothing on the path reads — is written by a SECOND launch
+// on a low-priority stream of the context's own, concurrently with stage B, while the path continues from the bits-only
+// kernel; join_dense() makes the caller's stream wait for it before the call's last kernel.
+int run_compat(sc_ctx* c, bool dense, bool allow_async = false) {
   const size_t n = c->n, ld = c->ld, W = ld >> 6;
   if (dense) ENSURE(c, c->S, n * ld * sizeof(float));
   ENSURE(c, c->bits, n * W * sizeof(uint64_t));
@@ -273,7 +279,29 @@ int run_compat(sc_ctx* c, bool dense) {
   ENSURE(c, c->wpre, n * W * sizeof(uint32_t));
   c->bits_cur = c->bits.as<uint64_t>();
   c->sharded_ab = false; c->shard_phase = 0; c->cand_all = nullptr;
+  c->dense_pending = false;
+  if (dense && allow_async && c->tn.dense_async && !c->timing) {
+    if (!c->stream2) {
+      int lo = 0, hi = 0;
+      HIPCHK(c, hipDeviceGetStreamPriorityRange(&lo, &hi));  // lo: the numerically largest value = lowest priority
+      HIPCHK(c, hipStreamCreateWithPriority(&c->stream2, hipStreamNonBlocking, lo));
+      HIPCHK(c, hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
+      HIPCHK(c, hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
+    }
+    ENSURE(c, c->bits_s, n * W * sizeof(uint64_t));
+    launch_compat(points_of(c), c->dv, nullptr, c->bits_cur, 0, c->n, c->tn, c->stream);
+    HIPCHK(c, hipEventRecord(c->ev_fork, c->stream));               // (the planes are ready; the path's bit rows too)
+    HIPCHK(c, hipStreamWaitEvent(c->stream2, c->ev_fork, 0));
+    launch_compat(points_of(c), c->dv, c->S.as<float>(), c->bits_s.as<uint64_t>(), 0, c->n, c->tn, c->stream2);
+    HIPCHK(c, hipEventRecord(c->ev_join, c->stream2));
+    c->dense_pending = true;
+    return SC_OK;
+  }
   launch_compat(points_of(c), c->dv, dense ? c->S.as<float>() : nullptr, c->bits_cur, 0, c->n, c->tn, c->stream);
+  return SC_OK;
+}
+int join_dense(sc_ctx* c) {
+  if (c->dense_pending) { HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_join, 0)); c->dense_pending = false; }
   return SC_OK;
 }
 
@@ -727,12 +755,15 @@ void sc_destroy(sc_ctx* c) {
   Buf* bufs[] = {&c->in_src, &c->in_tgt, &c->planes, &c->S, &c->bits, &c->deg, &c->degp, &c->wpre, &c->ebase, &c->edge_off, &c->scan_tmp,
                  &c->ei, &c->ej, &c->es, &c->ebi, &c->ebj, &c->tcnt, &c->toff, &c->wkey, &c->kcol, &c->ctl, &c->events, &c->blk_gt, &c->blk_eq, &c->blk_minmax, &c->bits2, &c->off_gt,
                  &c->off_eq, &c->sel_ord, &c->sel_key, &c->sortkey, &c->sorted, &c->sort_tmp, &c->tri, &c->tri_rk, &c->key_rk, &c->rt,
-                 &c->rt_aos, &c->partial, &c->cnt, &c->key, &c->rt12, &c->mask, &c->refine_tmp, &c->amx_pairs, &c->strong, &c->rowcost, &c->cost_pre, &c->lb_state, &c->lb_ticket, &c->fx_tile, &c->fx_state, &c->fx_mx, &c->fx_part, &c->sdegp, &c->fx_coef};
+                 &c->rt_aos, &c->partial, &c->cnt, &c->key, &c->rt12, &c->mask, &c->refine_tmp, &c->amx_pairs, &c->strong, &c->rowcost, &c->cost_pre, &c->lb_state, &c->lb_ticket, &c->fx_tile, &c->fx_state, &c->fx_mx, &c->fx_part, &c->sdegp, &c->fx_coef, &c->bits_s};
   for (Buf* b : bufs) if (b->p) (void)hipFree(b->p);
   for (int i = 0; i < N_EVENTS; i++) if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
   if (c->pinned) (void)hipHostFree(c->pinned);
   if (c->h_in) (void)hipHostFree(c->h_in);
   if (c->h_out) (void)hipHostFree(c->h_out);
+  if (c->stream2) { (void)hipStreamSynchronize(c->stream2); (void)hipStreamDestroy(c->stream2); }
+  if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
+  if (c->ev_join) (void)hipEventDestroy(c->ev_join);
   if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
   delete c;
 }
@@ -785,6 +816,7 @@ int sc_set_debug(sc_ctx* c, const sc_debug* d) {
   t.filter_lds_queue = d->filter_lds_queue;
   t.filter_blind = d->filter_blind != 0;
   t.filter_variant = d->filter_variant;
+  t.dense_async = d->dense_async != 0;
   c->tn = t;
   return SC_OK;
 }
@@ -822,7 +854,7 @@ int hyp_begin(sc_ctx* c, const float* d_src, const float* d_tgt, int64_t n, cons
   if ((rc = rec(c, 0))) return rc;
   if ((rc = stage_inputs(c, d_src, d_tgt, n, p))) return rc;
   if ((rc = rec(c, 1))) return rc;
-  if ((rc = run_compat(c, !(p->flags & SC_FLAG_NO_DENSE_S)))) return rc;
+  if ((rc = run_compat(c, !(p->flags & SC_FLAG_NO_DENSE_S), true))) return rc;
   if ((rc = rec(c, 2))) return rc;
   if ((rc = run_row_stats(c, may_prune(p), true))) return rc;
   if ((rc = run_edges(c, p, d_hist, part, parts))) return rc;
@@ -1108,6 +1140,7 @@ int sc_finalize_gathered_device(sc_ctx* c, const uint64_t* d_keys, int n_pairs, 
   if (!c->have_hyp) { c->last_error = "sc_finalize_device without a preceding sc_hypothesize_device"; return SC_EINVAL; }
   HIPCHK(c, hipSetDevice(c->device));
   int rc;
+  if ((rc = join_dense(c))) return rc;  // the asynchronous dense-S launch (if any) ends inside this call
   if ((rc = rec(c, 7))) return rc;
   arm_word(c, 8);
   ControlBlock* ctl = c->ctl.as<ControlBlock>();

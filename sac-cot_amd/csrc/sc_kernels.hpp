@@ -41,6 +41,7 @@ struct Tuning {
   uint32_t filter_queue_cap = 0;   // entries of the filter's global queue (0: by size; tests force overflows with a small one)
   uint32_t filter_lds_queue = 0;   // entries of a wave's LDS queue, 64 .. 256 (0: 256)
   uint32_t filter_variant = 0;     // body of the filter kernel (sc_score.hip): 0 default, bit-identical scheduling variants, >= 16 timing-only ablations
+  bool dense_async = false;        // the dense matrix S by a second, low-priority launch concurrent with stage B (experiment)
   bool filter_blind = false;       // the host decides C2's kernel WITHOUT the coordinate maxima (as if they had not arrived yet)
   bool compat_one_phase = false;   // exact chain on every pair of an interior tile
   int compat_rows = 0;             // tile height of stage A: 0 = by size (16 below 10 000 correspondences, 32 from there), 16, 32, 64

@@ -21,6 +21,6 @@ for k, cs in sorted(agg.items()):
         d["hbm_bytes_per_launch"] = d["hbm_read_bytes_per_launch"] + d["hbm_write_bytes_per_launch"]
     out[k] = d
 json.dump(out, open(os.path.join(root, "profiles", "pmc_summary.json"), "w"), indent=1, sort_keys=True)
-for k in ("compat_tiles_kernel", "tri_keys_kernel", "score_kernel", "score_filter_kernel", "score_exact_kernel", "tri_sample_hist_kernel", "tri_count_kernel"):
+for k in ("compat_tiles_kernel", "tri_keys_kernel", "score_kernel", "score_filter_kernel", "score_gram_kernel", "score_exact_kernel", "tri_sample_hist_kernel", "tri_count_kernel"):
     if k in out:
         print(k, {c: (round(v, 1) if isinstance(v, float) else v) for c, v in out[k].items()})
