@@ -46,7 +46,7 @@ struct sc_ctx {
   // workspace
   Buf in_src, in_tgt, planes, S, bits, deg, degp, wpre, ebase, edge_off, scan_tmp, ei, ej, es, ebi, ebj, tcnt, toff, wkey, kcol, ctl, events, blk_gt,
       blk_eq, blk_minmax, bits2, off_gt, off_eq, sel_ord, sel_key, sortkey, sorted, sort_tmp, tri, tri_rk, key_rk, rt, rt_aos, partial, cnt, key, rt12,
-      mask, refine_tmp, amx_pairs, strong, rowcost, cost_pre, lb_state, lb_ticket, fx_tile, fx_state, fx_mx, fx_part, sdegp, fx_coef, bits_s;
+      mask, refine_tmp, amx_pairs, strong, rowcost, cost_pre, lb_state, lb_ticket, fx_tile, fx_state, fx_mx, fx_part, fx_coef, bits_s;
   hipStream_t stream2 = nullptr;  // low-priority stream of the asynchronous dense-S launch (Tuning::dense_async)
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   bool dense_pending = false;
@@ -507,32 +507,19 @@ int run_select(sc_ctx* c, const sc_params* p, const uint32_t* hist, bool want_li
       ENSURE(c, c->strong, strong_list_bytes(E));
       sl = StrongList{c->strong.as<uint32_t>(), ctl->st_fill, strong_list_cap(E)};
     }
-    if (c->sharded_ab && p->shard_world > 1) {
-      // Sharded: the ranks' row ranges are cut AFTER the certificate, by the work of the pruned graph (a
-      // correspondence list in keypoint order puts nearly every strong edge into a few rows).  Every rank holds the whole
-      // strong matrix, so every rank computes the same cut.  (1) strong bits + strong out-degrees, (2) cost per row,
-      // (3) its prefix and this rank's range, (4) the list of this rank's strong edges.
-      ENSURE(c, c->sdegp, (size_t)c->n * 4);
+    const bool recut = c->sharded_ab && p->shard_world > 1 && use_events;
+    // Sharded (event path): the ranks' row ranges are cut AFTER the certificate, by the work of the pruned graph (VERDICT r02
+    // #5: a correspondence list in keypoint order puts nearly every strong edge into a few rows).  Every rank holds the
+    // whole strong matrix, so every rank computes the same cut: the pruning kernel lists EVERY strong edge, two small
+    // launches make the cut, and the counting pass skips the edges of the other ranks.
+    launch_prune_bits(g, hist ? hist : ctl->prune_hist, hist == nullptr, c->ei.as<uint32_t>(), c->ej.as<uint32_t>(), c->es.as<float>(), E,
+                      p->max_triangles, 3.0f * p->t_cmp * 0.999f, c->bits2.as<uint64_t>(), &ctl->smin, &ctl->klb, sl,
+                      c->tcnt.as<uint32_t>(), recut ? nullptr : own_range_of(c), st);
+    if (recut) {
       ENSURE(c, c->rowcost, (size_t)c->n * 4);
-      ENSURE(c, c->cost_pre, ((size_t)c->n + 1) * sizeof(uint64_t));
-      ENSURE(c, c->scan_tmp, scan_temp_bytes((size_t)c->n));
-      HIPCHK(c, hipMemsetAsync(c->sdegp.p, 0, (size_t)c->n * 4, st));
-      launch_prune_bits(g, hist ? hist : ctl->prune_hist, hist == nullptr, c->ei.as<uint32_t>(), c->ej.as<uint32_t>(), c->es.as<float>(), E,
-                        p->max_triangles, 3.0f * p->t_cmp * 0.999f, c->bits2.as<uint64_t>(), &ctl->smin, &ctl->klb,
-                        StrongList{nullptr, nullptr, 0}, c->tcnt.as<uint32_t>(), nullptr, st, c->sdegp.as<uint32_t>(), false);
-      launch_strong_rowcost(g, c->bits2.as<uint64_t>(), c->sdegp.as<uint32_t>(), c->rowcost.as<uint32_t>(), st);
-      ScanExtra xs;
-      if (scan_writes_ebase((size_t)c->n)) { const int lrc = lb_next(c, 2 * scan_temp_bytes((size_t)c->n), 0, 0, &xs.lb); if (lrc) return lrc; }
-      launch_scan_u32(c->rowcost.as<uint32_t>(), (size_t)c->n, c->cost_pre.as<uint64_t>(), c->scan_tmp.p, c->tn, st, nullptr, &xs);
-      launch_shard_split(c->cost_pre.as<uint64_t>(), c->edge_off.as<uint64_t>(), c->n, (uint32_t)p->shard_rank,
-                         (uint32_t)p->shard_world, ctl->own_row, ctl->own_edge, st);
-      launch_prune_bits(g, hist ? hist : ctl->prune_hist, hist == nullptr, c->ei.as<uint32_t>(), c->ej.as<uint32_t>(), c->es.as<float>(), E,
-                        p->max_triangles, 3.0f * p->t_cmp * 0.999f, c->bits2.as<uint64_t>(), &ctl->smin, &ctl->klb, sl,
-                        c->tcnt.as<uint32_t>(), own_range_of(c), st, nullptr, true);
-    } else {
-      launch_prune_bits(g, hist ? hist : ctl->prune_hist, hist == nullptr, c->ei.as<uint32_t>(), c->ej.as<uint32_t>(), c->es.as<float>(), E,
-                        p->max_triangles, 3.0f * p->t_cmp * 0.999f, c->bits2.as<uint64_t>(), &ctl->smin, &ctl->klb, sl,
-                        c->tcnt.as<uint32_t>(), own_range_of(c), st);
+      launch_strong_rowcost(g, c->bits2.as<uint64_t>(), c->rowcost.as<uint32_t>(), st);
+      launch_cost_split(c->rowcost.as<uint32_t>(), c->edge_off.as<uint64_t>(), c->n, (uint32_t)p->shard_rank,
+                        (uint32_t)p->shard_world, ctl->own_row, ctl->own_edge, st);
     }
     mbits = c->bits2.as<uint64_t>();
     smin = &ctl->smin;
@@ -549,7 +536,7 @@ int run_select(sc_ctx* c, const sc_params* p, const uint32_t* hist, bool want_li
     ev = event_list(c->events.p, ev_cap, g.W, c->ctl.as<ControlBlock>()->ev_fill,
                     reinterpret_cast<uint32_t*>(&c->pinned[5]));
     launch_tri_count_events(g, mbits, sl, c->ebi.as<uint32_t>(), c->ebj.as<uint32_t>(), c->ei.as<uint32_t>(),
-                            c->ej.as<uint32_t>(), E, p->rank_mode, c->tcnt.as<uint32_t>(), ev, c->tn, st);
+                            c->ej.as<uint32_t>(), E, p->rank_mode, c->tcnt.as<uint32_t>(), ev, c->tn, st, own_range_of(c));
   } else {
     launch_tri_count(g, mbits, c->es.as<float>(), smin, c->ei.as<uint32_t>(), c->ej.as<uint32_t>(), E,
                      c->tcnt.as<uint32_t>(), own_range_of(c), c->tn, st);
@@ -755,7 +742,7 @@ void sc_destroy(sc_ctx* c) {
   Buf* bufs[] = {&c->in_src, &c->in_tgt, &c->planes, &c->S, &c->bits, &c->deg, &c->degp, &c->wpre, &c->ebase, &c->edge_off, &c->scan_tmp,
                  &c->ei, &c->ej, &c->es, &c->ebi, &c->ebj, &c->tcnt, &c->toff, &c->wkey, &c->kcol, &c->ctl, &c->events, &c->blk_gt, &c->blk_eq, &c->blk_minmax, &c->bits2, &c->off_gt,
                  &c->off_eq, &c->sel_ord, &c->sel_key, &c->sortkey, &c->sorted, &c->sort_tmp, &c->tri, &c->tri_rk, &c->key_rk, &c->rt,
-                 &c->rt_aos, &c->partial, &c->cnt, &c->key, &c->rt12, &c->mask, &c->refine_tmp, &c->amx_pairs, &c->strong, &c->rowcost, &c->cost_pre, &c->lb_state, &c->lb_ticket, &c->fx_tile, &c->fx_state, &c->fx_mx, &c->fx_part, &c->sdegp, &c->fx_coef, &c->bits_s};
+                 &c->rt_aos, &c->partial, &c->cnt, &c->key, &c->rt12, &c->mask, &c->refine_tmp, &c->amx_pairs, &c->strong, &c->rowcost, &c->cost_pre, &c->lb_state, &c->lb_ticket, &c->fx_tile, &c->fx_state, &c->fx_mx, &c->fx_part, &c->fx_coef, &c->bits_s};
   for (Buf* b : bufs) if (b->p) (void)hipFree(b->p);
   for (int i = 0; i < N_EVENTS; i++) if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
   if (c->pinned) (void)hipHostFree(c->pinned);

@@ -197,14 +197,14 @@ void launch_sample_hist(const Graph& g, const uint32_t* ebi, const uint32_t* ebj
 // launch_hist_reduce sums them into one 256-bin histogram (the exchanged form); launch_prune_bits reads either
 // (hist_is_copies).
 void launch_hist_reduce(const uint32_t* copies, uint32_t* out, hipStream_t st);
-//    sdegp (optional, n zeroed u32): also the number of strong edges of every row towards higher indices;
-//    list_only: *smin and the strong bits are there already (an earlier launch): only sl / tcnt for the range `own`.
 void launch_prune_bits(const Graph& g, const uint32_t* hist, bool hist_is_copies, const uint32_t* ei, const uint32_t* ej, const float* es,
                        uint64_t E, uint64_t want, float key_floor, uint64_t* mbits, float* smin, uint32_t* klb,
-                       const StrongList& sl, uint32_t* tcnt, const uint64_t* own, hipStream_t st, uint32_t* sdegp = nullptr,
-                       bool list_only = false);
-// sharded stage B: work estimate per row of the PRUNED graph (see strong_rowcost_kernel), for launch_shard_split
-void launch_strong_rowcost(const Graph& g, const uint64_t* mbits, const uint32_t* sdegp, uint32_t* rowcost, hipStream_t st);
+                       const StrongList& sl, uint32_t* tcnt, const uint64_t* own, hipStream_t st);
+// sharded stage B, after the certificate: work estimate per row of the PRUNED graph (strong_rowcost_kernel), and — in one
+// single-block launch — its prefix and this rank's row / edge range (the rule of launch_shard_split)
+void launch_strong_rowcost(const Graph& g, const uint64_t* mbits, uint32_t* rowcost, hipStream_t st);
+void launch_cost_split(const uint32_t* rowcost, const uint64_t* edge_off, int n, uint32_t rank, uint32_t world,
+                       uint32_t* own_row, uint64_t* own_edge, hipStream_t st);
 
 // Event list of stage B (sc_tri.hip 2b): one record per non-zero member word of a strong edge, SoA, split into
 // EV_SHARDS regions of shard_cap records; fill[shard] = records appended to that region.
@@ -226,7 +226,8 @@ EventList event_list(void* buf, uint64_t capacity, int W, uint32_t* fill, uint32
 // counting pass that also emits the events (replaces launch_tri_count when an event buffer is available)
 void launch_tri_count_events(const Graph& g, const uint64_t* mbits, const StrongList& sl, const uint32_t* ebi,
                              const uint32_t* ebj, const uint32_t* ei, const uint32_t* ej, uint64_t E, int rank_mode,
-                             uint32_t* tcnt, const EventList& ev, const Tuning& tn, hipStream_t st);
+                             uint32_t* tcnt, const EventList& ev, const Tuning& tn, hipStream_t st,
+                             const uint64_t* own = nullptr);  // own (optional, device): [lo, hi) of the edges this rank enumerates
 
 // Radix-select state.  Lives in the context's control block, which ONE memset zeroes per call; key_range_kernel
 // (end of launch_tri_keys) fills kmin / kmax / want.

@@ -423,7 +423,10 @@ __global__ __launch_bounds__(256) void tri_count_events_kernel(const uint64_t* _
                                                                const uint32_t* __restrict__ ei,
                                                                const uint32_t* __restrict__ ej,
                                                                StrongList sl, int rank_mode,
-                                                               uint32_t* __restrict__ tcnt, EventList ev) {
+                                                               uint32_t* __restrict__ tcnt, EventList ev,
+                                                               const uint64_t* __restrict__ own) {
+  // own (optional, sharded stage B): [lo, hi) of the edges this rank enumerates; the strong list holds every rank's, the
+  // others count 0 here (their tcnt entry is written too: the scan that follows reads zeros outside the range)
   constexpr int EVW = 192;  // records per wave segment: flush above 128, a round adds <= 64
   __shared__ uint64_t l_m[4 * EVW];
   __shared__ uint32_t l_wi[4 * EVW], l_wj[4 * EVW], l_a[4 * EVW], l_b[4 * EVW], l_e[4 * EVW], l_rb[4 * EVW];
@@ -473,12 +476,14 @@ __global__ __launch_bounds__(256) void tri_count_events_kernel(const uint64_t* _
 #pragma unroll
       for (int step = ST_SHARDS / 2; step > 0; step >>= 1) r += (l_pre[r + step] <= (uint32_t)x) ? step : 0;
       e = sl.list[(uint64_t)r * sl.cap + ((uint32_t)x - l_pre[r])];
-      const uint32_t i = ei[e], j = ej[e];
-      rowi = i * (uint32_t)W; rowj = j * (uint32_t)W;
-      fa = (rank_mode == 0) ? ebi[e] : deg[i] + deg[j];  // weight mode: CSR bases; degree mode: the degree sum
-      fb = (rank_mode == 0) ? ebj[e] : 0u;
-      w0 = (int)(j >> 6); jbit = (int)(j & 63);
-      rounds = (W - w0 + TG - 1) / TG;
+      if (!own || ((uint64_t)e >= own[0] && (uint64_t)e < own[1])) {
+        const uint32_t i = ei[e], j = ej[e];
+        rowi = i * (uint32_t)W; rowj = j * (uint32_t)W;
+        fa = (rank_mode == 0) ? ebi[e] : deg[i] + deg[j];  // weight mode: CSR bases; degree mode: the degree sum
+        fb = (rank_mode == 0) ? ebj[e] : 0u;
+        w0 = (int)(j >> 6); jbit = (int)(j & 63);
+        rounds = (W - w0 + TG - 1) / TG;
+      }
     }
     int wave_rounds = rounds;  // max over the wave: the loop below is wave-uniform
 #pragma unroll
@@ -638,7 +643,7 @@ EventList event_list(void* buf, uint64_t capacity, int W, uint32_t* fill, uint32
 
 void launch_tri_count_events(const Graph& g, const uint64_t* mbits, const StrongList& sl, const uint32_t* ebi,
                              const uint32_t* ebj, const uint32_t* ei, const uint32_t* ej, uint64_t E, int rank_mode,
-                             uint32_t* tcnt, const EventList& ev, const Tuning& tn, hipStream_t st) {
+                             uint32_t* tcnt, const EventList& ev, const Tuning& tn, hipStream_t st, const uint64_t* own) {
   if (E == 0) return;
   // lanes per edge: a lane walks (W - j / 64) / TG words one dependent round after the other, so wide rows want wide
   // groups (Tuning::tg_events forces one; measured r02: see DESIGN.md)
@@ -649,7 +654,7 @@ void launch_tri_count_events(const Graph& g, const uint64_t* mbits, const Strong
   if (nb < 256) nb = 256;
   if (nb > 4096) nb = 4096;
   if (tn.cnt_blocks >= 1 && tn.cnt_blocks <= 65535) nb = tn.cnt_blocks;
-#define SC_LAUNCH_CE(TGV) hipLaunchKernelGGL(tri_count_events_kernel<TGV>, dim3((unsigned)nb), dim3(256), 0, st, mbits, g.W, g.deg, ebi, ebj, ei, ej, sl, rank_mode, tcnt, ev)
+#define SC_LAUNCH_CE(TGV) hipLaunchKernelGGL(tri_count_events_kernel<TGV>, dim3((unsigned)nb), dim3(256), 0, st, mbits, g.W, g.deg, ebi, ebj, ei, ej, sl, rank_mode, tcnt, ev, own)
   if (tg == 4) SC_LAUNCH_CE(4); else if (tg == 16) SC_LAUNCH_CE(16); else if (tg == 32) SC_LAUNCH_CE(32); else if (tg == 64) SC_LAUNCH_CE(64); else SC_LAUNCH_CE(8);
 #undef SC_LAUNCH_CE
 }
@@ -882,40 +887,30 @@ __global__ __launch_bounds__(256) void prune_bits_kernel(const uint32_t* __restr
                                                          float* __restrict__ smin_out,
                                                          uint32_t* __restrict__ klb_out, StrongList sl,
                                                          uint32_t* __restrict__ tcnt,
-                                                         const uint64_t* __restrict__ own,
-                                                         uint32_t* __restrict__ sdegp, int list_only) {
-  // sdegp (optional, zeroed): += 1 at row i for every strong edge (i, j), j > i — what the sharded path cuts its row
-  // ranges by (strong_rowcost_kernel).  list_only: smin is already in *smin_out and the strong bits are set (an earlier
-  // launch of this kernel): only the list of this rank's strong edges is built.
+                                                         const uint64_t* __restrict__ own) {
   __shared__ uint64_t lds[8];
   __shared__ float s_smin;
   __shared__ uint32_t s_klb, s_base, s_wcnt[4];
   static_assert(PR_BINS == 256, "one bin per thread, walked from the top");
-  float smin;
-  if (list_only) {
-    smin = *smin_out;
-  } else {
-    const uint32_t bin = PR_BINS - 1 - threadIdx.x;
-    uint64_t mine = 0;
-    for (int c = 0; c < copies; c++) mine += hist[c * PR_BINS + bin];  // copies: PR_HCOPIES (the sample's own) or 1 (summed)
-    if (threadIdx.x == 0) { s_smin = -1.0f; s_klb = 0u; }  // default: no certified bound -> every edge is strong
-    uint64_t tot;
-    const uint64_t before = block_exscan_u64(mine, lds, &tot);
-    if (before < want && want <= before + mine && bin > 0) {
-      const float lb = __uint_as_float(klo + (bin << shift));  // lower edge of the crossing bin
-      s_smin = (lb - 2.0f) - 1e-6f;
-      s_klb = klo + (bin << shift);  // >= want triangles have a key >= this one: the select may ignore anything below
-    }
-    __syncthreads();
-    smin = s_smin;
-    if (blockIdx.x == 0 && threadIdx.x == 0) { *smin_out = smin; *klb_out = s_klb; }
+  const uint32_t bin = PR_BINS - 1 - threadIdx.x;
+  uint64_t mine = 0;
+  for (int c = 0; c < copies; c++) mine += hist[c * PR_BINS + bin];  // copies: PR_HCOPIES (the sample's own) or 1 (summed)
+  if (threadIdx.x == 0) { s_smin = -1.0f; s_klb = 0u; }  // default: no certified bound -> every edge is strong
+  uint64_t tot;
+  const uint64_t before = block_exscan_u64(mine, lds, &tot);
+  if (before < want && want <= before + mine && bin > 0) {
+    const float lb = __uint_as_float(klo + (bin << shift));  // lower edge of the crossing bin
+    s_smin = (lb - 2.0f) - 1e-6f;
+    s_klb = klo + (bin << shift);  // >= want triangles have a key >= this one: the select may ignore anything below
   }
+  __syncthreads();
+  const float smin = s_smin;
+  if (blockIdx.x == 0 && threadIdx.x == 0) { *smin_out = smin; *klb_out = s_klb; }
   const uint64_t e = (uint64_t)blockIdx.x * 256 + threadIdx.x;
   bool strong = e < E && es[e] >= smin;
-  if (strong && !list_only) {  // the strong bit matrix is whole on every rank: membership of ANY vertex pair is looked up in it
+  if (strong) {  // the strong bit matrix is whole on every rank: membership of ANY vertex pair is looked up in it
     const uint32_t i = ei[e], j = ej[e];
     atomicOr(&mbits[(size_t)i * W + (j >> 6)], 1ull << (j & 63));
-    if (sdegp) atomicAdd(&sdegp[i], 1u);
   }
   // sharded stage B: only this rank's edge range [own[0], own[1]) enters the list of edges to enumerate
   if (own) strong = strong && e >= own[0] && e < own[1];
@@ -1027,53 +1022,118 @@ void launch_sample_hist(const Graph& g, const uint32_t* ebi, const uint32_t* ebj
 
 void launch_prune_bits(const Graph& g, const uint32_t* hist, bool hist_is_copies, const uint32_t* ei, const uint32_t* ej, const float* es,
                        uint64_t E, uint64_t want, float key_floor, uint64_t* mbits, float* smin, uint32_t* klb,
-                       const StrongList& sl, uint32_t* tcnt, const uint64_t* own, hipStream_t st, uint32_t* sdegp,
-                       bool list_only) {
+                       const StrongList& sl, uint32_t* tcnt, const uint64_t* own, hipStream_t st) {
   uint32_t klo, shift;
   prune_window(key_floor, &klo, &shift);
   hipLaunchKernelGGL(prune_bits_kernel, dim3((unsigned)((E + 255) / 256)), dim3(256), 0, st, hist,
                      hist_is_copies ? PR_HCOPIES : 1, want, klo, shift, ei,
-                     ej, es, E, g.W, reinterpret_cast<unsigned long long*>(mbits), smin, klb, sl, tcnt, own, sdegp,
-                     list_only ? 1 : 0);
+                     ej, es, E, g.W, reinterpret_cast<unsigned long long*>(mbits), smin, klb, sl, tcnt, own);
 }
 
-// Sharded stage B, after the certificate: what enumerating row i of the PRUNED graph costs — 16 x the triangles of a
-// SAMPLE of its strong edges (every edge (i, j) with (i + j) % 16 == 0: AND + popcount of the two strong rows above j,
-// exactly what the counting pass does, for a sixteenth of the edges) plus one per strong edge (sdegp: the strong edges
-// of the row towards higher indices; the counting pass spends about a triangle's worth of time on an edge without any).  One 16-lane group per row; saturated to u32.  The prefix of these costs cuts
-// the rows into the ranks' ranges: a correspondence list in keypoint order puts the inliers — and nearly all the triangles
-// of the pruned graph — into a few rows, which the a-priori estimate of row_stats_kernel (every edge of the FULL graph
-// weighs the same) cannot see.  (A proxy from the strong degrees alone — sum of sdegp[j] — left 1.4 x between the ranks on
-// such a scene: outlier rows have strong edges but hardly a triangle.)
+// Sharded stage B, after the certificate: what enumerating row i of the PRUNED graph costs — 32 x the triangles of a
+// SAMPLE of its strong edges (every edge (i, j) with (i + j) % 32 == 0: AND + popcount of the two strong rows above j,
+// exactly what the counting pass does, for one edge in 32) plus one per strong edge (the counting pass spends
+// about a triangle's worth of time on an edge without any).  One wave per row: the sampled edges are taken one after the
+// other (wave-uniform), the 64 lanes AND the row words in parallel.  Saturated to u32.  The prefix of these costs cuts the
+// rows into the ranks' ranges: a correspondence list in keypoint order puts the inliers — and nearly all the triangles of
+// the pruned graph — into a few rows, which the a-priori estimate of row_stats_kernel (every edge of the FULL graph weighs
+// the same) cannot see.  (A proxy from the strong degrees alone left 1.4 x between the ranks on such a scene: outlier rows
+// have strong edges but hardly a triangle.)
 __global__ __launch_bounds__(256) void strong_rowcost_kernel(const uint64_t* __restrict__ mbits, int n, int W,
-                                                             const uint32_t* __restrict__ sdegp,
                                                              uint32_t* __restrict__ rowcost) {
-  const int gl = threadIdx.x & 15;
-  const int i = blockIdx.x * 16 + (threadIdx.x >> 4);
+  const int lane = threadIdx.x & 63;
+  const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (i >= n) return;
   const uint64_t* __restrict__ ri = mbits + (size_t)i * W;
-  uint64_t tri = 0;
-  for (int w = (i >> 6) + gl; w < W; w += 16) {
-    uint64_t v = ri[w];  // (only bits above i are ever set: the strong matrix is upper-triangular)
-    while (v) {
-      const int b = __builtin_ctzll(v);
-      v &= v - 1;
-      const int j = w * 64 + b;
-      if (((i + j) & 15) != 0) continue;
-      const uint64_t* __restrict__ rj = mbits + (size_t)j * W;
-      uint64_t m = ri[w] & rj[w] & mask_above(b);
-      uint32_t c = (uint32_t)__popcll(m);
-      for (int w2 = w + 1; w2 < W; w2++) c += (uint32_t)__popcll(ri[w2] & rj[w2]);
-      tri += c;
+  const uint64_t pattern = 0x0000000100000001ull << ((32 - (i & 31)) & 31);  // bits b of any word with (i + 64 w + b) % 32 == 0
+  uint64_t tri = 0, sdeg = 0;
+  for (int wb = i >> 6; wb < W; wb += 64) {
+    const int w = wb + lane;
+    const uint64_t v = w < W ? ri[w] : 0ull;  // (only bits above i are ever set: the strong matrix is upper-triangular)
+    sdeg += (uint64_t)__popcll(v);
+    const uint64_t sm = v & pattern;
+    uint64_t bal = __ballot(sm != 0);
+    while (bal) {  // wave-uniform: one lane's word after the other
+      const int L = __builtin_ctzll(bal);
+      bal &= bal - 1;
+      const int wL = wb + L;
+      uint64_t mL = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(sm >> 32), L) << 32) |
+                    (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)sm, L);
+      while (mL) {
+        const int bpos = __builtin_ctzll(mL);
+        mL &= mL - 1;
+        const uint64_t* __restrict__ rj = mbits + (size_t)(wL * 64 + bpos) * W;
+        for (int w2 = wL + lane; w2 < W; w2 += 64) {
+          uint64_t m = ri[w2] & rj[w2];
+          if (w2 == wL) m &= mask_above(bpos);
+          tri += (uint64_t)__popcll(m);
+        }
+      }
     }
   }
 #pragma unroll
-  for (int o = 8; o > 0; o >>= 1) tri += __shfl_xor(tri, o, 16);
-  const uint64_t cost = 16ull * tri + (uint64_t)sdegp[i];
-  if (gl == 0) rowcost[i] = cost > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)cost;
+  for (int o = 32; o > 0; o >>= 1) { tri += __shfl_xor(tri, o); sdeg += __shfl_xor(sdeg, o); }
+  const uint64_t cost = 32ull * tri + sdeg;
+  if (lane == 0) rowcost[i] = cost > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)cost;
 }
-void launch_strong_rowcost(const Graph& g, const uint64_t* mbits, const uint32_t* sdegp, uint32_t* rowcost, hipStream_t st) {
-  hipLaunchKernelGGL(strong_rowcost_kernel, dim3((unsigned)((g.n + 15) / 16)), dim3(256), 0, st, mbits, g.n, g.W, sdegp, rowcost);
+
+// prefix of the row costs AND this rank's range in one single-block launch (n values: 80 KB at N = 20 000): rows [lo, hi)
+// with lo = the first row whose cost prefix reaches rank / world of the total (the rule of shard_split_kernel).
+// Wave w of 16 takes the w-th sixteenth of the rows, 64 rows per step (coalesced loads, wave scans); the wave whose
+// segment holds a boundary walks it a second time.
+__global__ __launch_bounds__(1024) void cost_split_kernel(const uint32_t* __restrict__ rowcost,
+                                                          const uint64_t* __restrict__ edge_off, int n, uint32_t rank,
+                                                          uint32_t world, uint32_t* __restrict__ own_row,
+                                                          uint64_t* __restrict__ own_edge) {
+  __shared__ uint64_t s_tot[16];
+  __shared__ uint32_t s_row[2];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int seg = ((n + 15) / 16 + 63) / 64 * 64, r0 = wave * seg, r1 = min(n, r0 + seg);
+  uint64_t mine = 0;
+  for (int r = r0 + lane; r < r1; r += 64) mine += rowcost[r];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) mine += __shfl_xor(mine, o);
+  if (lane == 0) s_tot[wave] = mine;
+  if (threadIdx.x < 2) s_row[threadIdx.x] = (uint32_t)n;
+  __syncthreads();
+  uint64_t pre = 0, total = 0;
+  for (int w = 0; w < 16; w++) { if (w < wave) pre += s_tot[w]; total += s_tot[w]; }
+  for (int which = 0; which < 2; which++) {
+    const uint32_t l = rank + (uint32_t)which;
+    if (l == 0 || l >= world) continue;
+    const uint64_t target = (uint64_t)(((unsigned __int128)total * l) / world);
+    // the first row r with (sum of the costs before r) >= target lies in this wave's segment iff pre < target <= pre + mine,
+    // or it is the segment's first row (pre >= target and the wave before did not reach it: handled by the min below)
+    if (pre + mine < target && wave != 15) continue;       // (wave-uniform) beyond this segment
+    if (pre >= target) { if (lane == 0) atomicMin(&s_row[which], (uint32_t)min(r0, n)); continue; }
+    uint64_t run = pre;
+    for (int rb = r0; rb < r1; rb += 64) {
+      const int r = rb + lane;
+      const uint64_t v = r < r1 ? rowcost[r] : 0ull;
+      uint64_t inc = v;
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) { const uint64_t t = __shfl_up(inc, o); if (lane >= o) inc += t; }
+      const uint64_t before = run + inc - v;                 // sum of the costs before row r
+      const uint64_t hit = __ballot(r < r1 && before >= target);
+      if (hit) { if (lane == 0) atomicMin(&s_row[which], (uint32_t)(rb + __builtin_ctzll(hit))); break; }
+      run += __shfl(inc, 63);
+    }
+    // (no row of the segment reached it: the boundary is the first row of the next segment, or n — its wave reports r0)
+  }
+  __syncthreads();
+  if (threadIdx.x < 2) {
+    const uint32_t l = rank + threadIdx.x;
+    const uint32_t row = l == 0 ? 0u : (l >= world ? (uint32_t)n : s_row[threadIdx.x]);
+    own_row[threadIdx.x] = row;
+    own_edge[threadIdx.x] = edge_off[row];
+  }
+}
+void launch_cost_split(const uint32_t* rowcost, const uint64_t* edge_off, int n, uint32_t rank, uint32_t world,
+                       uint32_t* own_row, uint64_t* own_edge, hipStream_t st) {
+  hipLaunchKernelGGL(cost_split_kernel, dim3(1), dim3(1024), 0, st, rowcost, edge_off, n, rank, world, own_row, own_edge);
+}
+void launch_strong_rowcost(const Graph& g, const uint64_t* mbits, uint32_t* rowcost, hipStream_t st) {
+  hipLaunchKernelGGL(strong_rowcost_kernel, dim3((unsigned)((g.n + 3) / 4)), dim3(256), 0, st, mbits, g.n, g.W, rowcost);
 }
 
 // ------------------------------------------------------------------------------------------------

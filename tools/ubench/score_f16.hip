@@ -446,716 +446,13 @@ __global__ __launch_bounds__(256) void k_f16v2(const float* __restrict__ planes,
 }
 
 
-// ---------------------------------------------------------------------------------------------------------------
-// v3: v2 with the MFMA of step g+1 issued before the epilogue of step g (two result tiles per row block, loop unrolled
-// by two so that no tile is ever copied), B fragments prefetched two steps ahead, and the undecided tests handed to a
-// function outside the loop.
-// ---------------------------------------------------------------------------------------------------------------
-struct SlowCtx {
-  const float* planes; int ld; const float* Hc; uint32_t* fix; uint32_t* q; float tau2;
-};
-__device__ __noinline__ void drain_queue(const SlowCtx& sc, uint32_t qn) {
-  const int lane = threadIdx.x & 63;
-  for (uint32_t i = lane; i < qn; i += 64) {
-    const uint32_t ent = sc.q[i];
-    const int hl = ent >> 16, m = ent & 0xFFFF;
-    float p[6];
-#pragma unroll
-    for (int c = 0; c < 6; c++) p[c] = sc.planes[(size_t)c * sc.ld + m];
-    if (canon_d2(&sc.Hc[hl * 12], p) < sc.tau2) atomicAdd(&sc.fix[hl], 1u);
-  }
-}
-// appends the tests with 0 <= x < W2 (bits compare) of one batch; returns the new fill
-template <int NX>
-__device__ __noinline__ uint32_t enqueue(const SlowCtx& sc, uint32_t qn, const float (&x)[NX], uint32_t W2b, uint32_t wildmask,
-                                         uint32_t hl0, uint32_t m) {
-  const int lane = threadIdx.x & 63, hf = lane >> 5;
-#pragma unroll
-  for (int t = 0; t < NX; t++) {
-    const bool hit = __float_as_uint(x[t]) < W2b && !((wildmask >> t) & 1u);
-    const uint64_t hm = __ballot(hit);
-    if (hm) {
-      if (qn + 64 > QCAP) { drain_queue(sc, qn); qn = 0; }
-      if (hit) sc.q[qn + __popcll(hm & ((1ull << lane) - 1ull))] = ((hl0 + 2 * t + hf) << 16) | m;  // t = 4 rb + jj: hl = hw0 + 8 rb + 2 jj + hf
-      qn += (uint32_t)__popcll(hm);
-    }
-  }
-  return qn;
-}
+// (v3 .. v6 — the exact pass inside the filter kernel in four shapes: per-batch enqueue + drain through a non-inlined
+//  slow path, a double-buffered chunk loop, a 1280-entry workgroup queue, one row block per wave with the constants a chunk
+//  ahead — were removed from this file in round 3; their measurements are the "v3 .. v6" rows of
+//  profiles/r02_ubench_score_filter_prototype.txt and DESIGN.md §5: every one of them paid 27-50 us for cold code inside
+//  the hot loop.  What remains: the fp32 kernel, the first filter (v1), the tile + straight-from-global form with its
+//  ablations (v2), and the two LDS-DMA forms that led to the product kernel (v7, v8).)
 
-template <int RB>
-__global__ __launch_bounds__(256) void k_f16v3(const float* __restrict__ planes, int n, int ld, const float* __restrict__ Rt,
-                                               uint32_t ldl, float tau2, uint32_t* __restrict__ cnt_out, uint32_t* dbg,
-                                               const uint4* __restrict__ tile, const ChunkInfo* __restrict__ info, int chunks,
-                                               int splits) {
-  constexpr int HB = 4 * RB * 8;
-  __shared__ float Hc[HB * 12];
-  __shared__ float Tabs[HB];
-  __shared__ uint32_t wildf[HB];
-  __shared__ uint32_t fix[HB];
-  __shared__ uint32_t queue[4][QCAP];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  if (tid < HB) {
-    const uint32_t h = blockIdx.x * HB + tid;
-    float ta = 0.f; bool w = false;
-#pragma unroll
-    for (int c = 0; c < 12; c++) {
-      const float x = Rt[(size_t)c * ldl + h];
-      Hc[tid * 12 + c] = x;
-      if (c < 9) w = w || !(fabsf(x) <= 1.5f); else { ta = fmaxf(ta, fabsf(x)); w = w || !(fabsf(x) < 1e30f); }
-    }
-    Tabs[tid] = ta; wildf[tid] = w ? 1u : 0u; fix[tid] = 0u;
-  }
-  __syncthreads();
-  const int hw0 = wave * 8 * RB;
-  float tmax = 0.f;
-  if (lane < 8 * RB && !wildf[hw0 + lane]) tmax = Tabs[hw0 + lane];
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) tmax = fmaxf(tmax, __shfl_xor(tmax, o));
-  const int col = lane & 31, hf = lane >> 5;
-  half8 A[RB];
-  uint32_t wl = 0;  // bit 4 rb + jj
-#pragma unroll
-  for (int rb = 0; rb < RB; rb++) {
-    const int hy = (lane & 31) >> 2, c = lane & 3;
-    const float* M = &Hc[(hw0 + 8 * rb + hy) * 12];
-    _Float16 rh[3], rl[3];
-#pragma unroll
-    for (int kk = 0; kk < 3; kk++) {
-      const float x = c < 3 ? M[3 * c + kk] * RS : 0.f;
-      rh[kk] = (_Float16)x; rl[kk] = (_Float16)(x - (float)rh[kk]);
-    }
-    const _Float16 z = (_Float16)0.f, mone = (_Float16)(-RS);
-    const half8 a0 = {rh[0], rh[0], rl[0], rh[1], rh[1], rl[1], rh[2], rh[2]};
-    const half8 a1 = {rl[2], c == 0 ? mone : z, c == 0 ? mone : z, c == 1 ? mone : z, c == 1 ? mone : z, c == 2 ? mone : z, c == 2 ? mone : z, z};
-    A[rb] = hf ? a1 : a0;
-#pragma unroll
-    for (int jj = 0; jj < 4; jj++) wl |= wildf[hw0 + 8 * rb + 2 * jj + hf] ? (1u << (4 * rb + jj)) : 0u;
-  }
-  uint32_t total[RB * 4];
-#pragma unroll
-  for (int t = 0; t < RB * 4; t++) total[t] = 0;
-  uint32_t qn = 0, events = 0;
-  const SlowCtx sc{planes, ld, Hc, fix, queue[wave], tau2};
-  const half8* Th = reinterpret_cast<const half8*>(tile);
-  for (int ch = blockIdx.y; ch < chunks; ch += splits) {
-    const ChunkInfo ci = info[ch];
-    const int m0 = ch * PC, cntp = min(PC, n - m0), steps = (cntp + 31) >> 5;
-    const float s = ci.s, st = s * sqrtf(tau2);
-    const float Sb = 2.6f * (ci.pmax * s) + ci.qmax * s + tmax * s;
-    const float eta = Sb * (1.0f / 65536.0f);
-    const bool fast = (eta <= 0.25f * st) && (st <= 4096.f) && (tmax * s <= 2048.f);
-    const float lo_e = RS * (st - eta), hi_e = RS * (st + eta);
-    const float LO = lo_e * lo_e * (1.0f - 1e-6f), HI = hi_e * hi_e * (1.0f + 1e-6f);
-    const uint32_t W2b = fast ? __float_as_uint(HI - LO) : 0u;  // no filter for this chunk: nothing is "undecided", the lanes recount below
-    f32x16 C[RB];
-#pragma unroll
-    for (int rb = 0; rb < RB; rb++)
-#pragma unroll
-      for (int jj = 0; jj < 4; jj++) {
-        const float* T = &Hc[(hw0 + 8 * rb + 2 * jj + hf) * 12 + 9];
-        C[rb][4 * jj] = T[0] * s * RS; C[rb][4 * jj + 1] = T[1] * s * RS; C[rb][4 * jj + 2] = T[2] * s * RS; C[rb][4 * jj + 3] = 0.f;
-      }
-    uint32_t sr[RB * 4];
-#pragma unroll
-    for (int t = 0; t < RB * 4; t++) sr[t] = 0;
-    const half8* Bp = Th + ((size_t)m0 + col) * 2 + hf;  // step g: Bp[64 g]
-    // tile rows exist for whole chunks (512 points), so reading up to two steps past `steps` stays inside the chunk's
-    // rows or the next chunk's: the host pads the tile by one chunk
-    half8 b0 = Bp[0], b1 = Bp[64];
-    f32x16 Da[RB], Db[RB];
-#pragma unroll
-    for (int rb = 0; rb < RB; rb++) Da[rb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[rb], b0, C[rb], 0, 0, 0);
-    auto epilogue = [&](const f32x16 (&D)[RB], int g) {
-      float x[RB * 4];
-      uint32_t mn = 0xFFFFFFFFu;
-#pragma unroll
-      for (int rb = 0; rb < RB; rb++)
-#pragma unroll
-        for (int jj = 0; jj < 4; jj++) {
-          const float v = fma_(D[rb][4 * jj + 2], D[rb][4 * jj + 2], fma_(D[rb][4 * jj + 1], D[rb][4 * jj + 1], fma_(D[rb][4 * jj], D[rb][4 * jj], -LO)));
-          x[4 * rb + jj] = v;
-          sr[4 * rb + jj] = __builtin_amdgcn_alignbit(sr[4 * rb + jj], __float_as_uint(v), 31);
-          mn = min(mn, __float_as_uint(v));
-        }
-      if (__builtin_expect(__ballot(mn < W2b) != 0, 0)) {
-        const uint32_t q0 = qn;
-        qn = __builtin_amdgcn_readfirstlane(enqueue<RB * 4>(sc, qn, x, W2b, wl, (uint32_t)hw0, (uint32_t)(m0 + 32 * g + col)));
-        events += qn >= q0 ? qn - q0 : 0;
-      }
-    };
-    for (int g = 0; g < steps; g += 2) {
-      b0 = Bp[(size_t)64 * (g + 2)];
-#pragma unroll
-      for (int rb = 0; rb < RB; rb++) Db[rb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[rb], b1, C[rb], 0, 0, 0);
-      epilogue(Da, g);
-      if (g + 1 >= steps) break;
-      b1 = Bp[(size_t)64 * (g + 3)];
-#pragma unroll
-      for (int rb = 0; rb < RB; rb++) Da[rb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[rb], b0, C[rb], 0, 0, 0);
-      epilogue(Db, g + 1);
-    }
-#pragma unroll
-    for (int t = 0; t < RB * 4; t++) {
-      if (!fast || ((wl >> t) & 1u)) {
-        const int hl = hw0 + 2 * t + hf;
-        uint32_t bits = 0;
-        for (int g = 0; g < steps; g++) {
-          const int m = m0 + 32 * g + col;
-          float p[6];
-#pragma unroll
-          for (int c = 0; c < 6; c++) p[c] = m < n ? planes[(size_t)c * ld + m] : (c < 3 ? 0.f : 1e30f);
-          bits = (bits << 1) | (canon_d2(&Hc[hl * 12], p) < tau2 ? 1u : 0u);
-        }
-        sr[t] = bits;
-      }
-      total[t] += (uint32_t)__popc(sr[t]);
-    }
-  }
-  drain_queue(sc, qn);
-  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-#pragma unroll
-  for (int t = 0; t < RB * 4; t++) {
-    uint32_t c = total[t];
-#pragma unroll
-    for (int o = 16; o > 0; o >>= 1) c += __shfl_xor(c, o, 32);
-    const int hl = hw0 + 2 * t + hf;
-    if (col == 0) cnt_out[(size_t)blockIdx.y * ldl + blockIdx.x * HB + hl] = c + fix[hl];
-  }
-  if (dbg && lane == 0 && events) atomicAdd(dbg, events);
-}
-
-template <int RB>
-__global__ __launch_bounds__(256) void k_f16v4(const float* __restrict__ planes, int n, int ld, const float* __restrict__ Rt,
-                                               uint32_t ldl, float tau2, uint32_t* __restrict__ cnt_out, uint32_t* dbg,
-                                               const uint4* __restrict__ tile, const ChunkInfo* __restrict__ info, int chunks,
-                                               int splits) {
-  constexpr int HB = 4 * RB * 8;
-  __shared__ float Hc[HB * 12];
-  __shared__ float Tabs[HB];
-  __shared__ uint32_t wildf[HB];
-  __shared__ uint32_t fix[HB];
-  __shared__ uint32_t queue[4][1024];  // one entry per (lane, step) of a chunk at most: 16 steps x 64 lanes
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  if (tid < HB) {
-    const uint32_t h = blockIdx.x * HB + tid;
-    float ta = 0.f; bool w = false;
-#pragma unroll
-    for (int c = 0; c < 12; c++) {
-      const float x = Rt[(size_t)c * ldl + h];
-      Hc[tid * 12 + c] = x;
-      if (c < 9) w = w || !(fabsf(x) <= 1.5f); else { ta = fmaxf(ta, fabsf(x)); w = w || !(fabsf(x) < 1e30f); }
-    }
-    Tabs[tid] = ta; wildf[tid] = w ? 1u : 0u; fix[tid] = 0u;
-  }
-  __syncthreads();
-  const int hw0 = wave * 8 * RB;
-  float tmax = 0.f;
-  if (lane < 8 * RB && !wildf[hw0 + lane]) tmax = Tabs[hw0 + lane];
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) tmax = fmaxf(tmax, __shfl_xor(tmax, o));
-  const int col = lane & 31, hf = lane >> 5;
-  half8 A[RB];
-  uint32_t wl = 0;  // bit 4 rb + jj
-#pragma unroll
-  for (int rb = 0; rb < RB; rb++) {
-    const int hy = (lane & 31) >> 2, c = lane & 3;
-    const float* M = &Hc[(hw0 + 8 * rb + hy) * 12];
-    _Float16 rh[3], rl[3];
-#pragma unroll
-    for (int kk = 0; kk < 3; kk++) {
-      const float x = c < 3 ? M[3 * c + kk] * RS : 0.f;
-      rh[kk] = (_Float16)x; rl[kk] = (_Float16)(x - (float)rh[kk]);
-    }
-    const _Float16 z = (_Float16)0.f, mone = (_Float16)(-RS);
-    const half8 a0 = {rh[0], rh[0], rl[0], rh[1], rh[1], rl[1], rh[2], rh[2]};
-    const half8 a1 = {rl[2], c == 0 ? mone : z, c == 0 ? mone : z, c == 1 ? mone : z, c == 1 ? mone : z, c == 2 ? mone : z, c == 2 ? mone : z, z};
-    A[rb] = hf ? a1 : a0;
-#pragma unroll
-    for (int jj = 0; jj < 4; jj++) wl |= wildf[hw0 + 8 * rb + 2 * jj + hf] ? (1u << (4 * rb + jj)) : 0u;
-  }
-  uint32_t total[RB * 4];
-#pragma unroll
-  for (int t = 0; t < RB * 4; t++) total[t] = 0;
-  uint32_t qn = 0, events = 0;
-  uint32_t* q = queue[wave];
-  const half8* Th = reinterpret_cast<const half8*>(tile);
-  for (int ch = blockIdx.y; ch < chunks; ch += splits) {
-    const ChunkInfo ci = info[ch];
-    const int m0 = ch * PC, cntp = min(PC, n - m0), steps = (cntp + 31) >> 5;
-    const float s = ci.s, st = s * sqrtf(tau2);
-    const float Sb = 2.6f * (ci.pmax * s) + ci.qmax * s + tmax * s;
-    const float eta = Sb * (1.0f / 65536.0f);
-    const bool fast = (eta <= 0.25f * st) && (st <= 4096.f) && (tmax * s <= 2048.f);
-    const float lo_e = RS * (st - eta), hi_e = RS * (st + eta);
-    const float LO = lo_e * lo_e * (1.0f - 1e-6f), HI = hi_e * hi_e * (1.0f + 1e-6f);
-    const uint32_t W2b = fast ? __float_as_uint(HI - LO) : 0u;  // no filter for this chunk: nothing is "undecided", the lanes recount below
-    f32x16 C[RB];
-#pragma unroll
-    for (int rb = 0; rb < RB; rb++)
-#pragma unroll
-      for (int jj = 0; jj < 4; jj++) {
-        const float* T = &Hc[(hw0 + 8 * rb + 2 * jj + hf) * 12 + 9];
-        C[rb][4 * jj] = T[0] * s * RS; C[rb][4 * jj + 1] = T[1] * s * RS; C[rb][4 * jj + 2] = T[2] * s * RS; C[rb][4 * jj + 3] = 0.f;
-      }
-    uint32_t sr[RB * 4];
-#pragma unroll
-    for (int t = 0; t < RB * 4; t++) sr[t] = 0;
-    const half8* Bp = Th + ((size_t)m0 + col) * 2 + hf;  // step g: Bp[64 g]
-    // tile rows exist for whole chunks (512 points), so reading up to two steps past `steps` stays inside the chunk's
-    // rows or the next chunk's: the host pads the tile by one chunk
-    half8 b0 = Bp[0], b1 = Bp[64];
-    f32x16 Da[RB], Db[RB];
-#pragma unroll
-    for (int rb = 0; rb < RB; rb++) Da[rb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[rb], b0, C[rb], 0, 0, 0);
-    auto epilogue = [&](const f32x16 (&D)[RB], int g) {
-      float x[RB * 4];
-      uint32_t mn = 0xFFFFFFFFu;
-#pragma unroll
-      for (int rb = 0; rb < RB; rb++)
-#pragma unroll
-        for (int jj = 0; jj < 4; jj++) {
-          const float v = fma_(D[rb][4 * jj + 2], D[rb][4 * jj + 2], fma_(D[rb][4 * jj + 1], D[rb][4 * jj + 1], fma_(D[rb][4 * jj], D[rb][4 * jj], -LO)));
-          x[4 * rb + jj] = v;
-          sr[4 * rb + jj] = __builtin_amdgcn_alignbit(sr[4 * rb + jj], __float_as_uint(v), 31);
-          mn = min(mn, __float_as_uint(v));
-        }
-      const uint64_t hm = __ballot(mn < W2b);
-      if (__builtin_expect(hm != 0, 0)) {  // lanes holding an undecided test leave ONE entry: point, lane half, which tests
-        uint32_t bits = 0;
-#pragma unroll
-        for (int t = 0; t < RB * 4; t++) bits |= (__float_as_uint(x[t]) < W2b) ? (1u << t) : 0u;
-        bits &= ~wl;
-        if (mn < W2b) q[qn + __popcll(hm & ((1ull << lane) - 1ull))] = ((uint32_t)(32 * g + col) << 16) | ((uint32_t)hf << 15) | bits;
-        qn += (uint32_t)__popcll(hm);
-      }
-    };
-    for (int g = 0; g < steps; g += 2) {
-      b0 = Bp[(size_t)64 * (g + 2)];
-#pragma unroll
-      for (int rb = 0; rb < RB; rb++) Db[rb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[rb], b1, C[rb], 0, 0, 0);
-      epilogue(Da, g);
-      if (g + 1 >= steps) break;
-      b1 = Bp[(size_t)64 * (g + 3)];
-#pragma unroll
-      for (int rb = 0; rb < RB; rb++) Da[rb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[rb], b0, C[rb], 0, 0, 0);
-      epilogue(Db, g + 1);
-    }
-    // exact pass over the queued tests of this chunk, one entry per lane
-    for (uint32_t i = lane; i < qn; i += 64) {
-      const uint32_t ent = q[i];
-      const int m = m0 + (int)(ent >> 16), ehf = (ent >> 15) & 1;
-      float p[6];
-#pragma unroll
-      for (int c = 0; c < 6; c++) p[c] = planes[(size_t)c * ld + m];
-      for (uint32_t bits = ent & 0x7FFFu; bits; bits &= bits - 1) {
-        const int hl = hw0 + 2 * (__ffs(bits) - 1) + ehf;
-        if (canon_d2(&Hc[hl * 12], p) < tau2) atomicAdd(&fix[hl], 1u);
-      }
-    }
-    events += qn; qn = 0;
-#pragma unroll
-    for (int t = 0; t < RB * 4; t++) {
-      if (!fast || ((wl >> t) & 1u)) {
-        const int hl = hw0 + 2 * t + hf;
-        uint32_t bits = 0;
-        for (int g = 0; g < steps; g++) {
-          const int m = m0 + 32 * g + col;
-          float p[6];
-#pragma unroll
-          for (int c = 0; c < 6; c++) p[c] = m < n ? planes[(size_t)c * ld + m] : (c < 3 ? 0.f : 1e30f);
-          bits = (bits << 1) | (canon_d2(&Hc[hl * 12], p) < tau2 ? 1u : 0u);
-        }
-        sr[t] = bits;
-      }
-      total[t] += (uint32_t)__popc(sr[t]);
-    }
-  }
-  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-#pragma unroll
-  for (int t = 0; t < RB * 4; t++) {
-    uint32_t c = total[t];
-#pragma unroll
-    for (int o = 16; o > 0; o >>= 1) c += __shfl_xor(c, o, 32);
-    const int hl = hw0 + 2 * t + hf;
-    if (col == 0) cnt_out[(size_t)blockIdx.y * ldl + blockIdx.x * HB + hl] = c + fix[hl];
-  }
-  if (dbg && lane == 0 && events) atomicAdd(dbg, events);
-}
-
-
-
-// ---------------------------------------------------------------------------------------------------------------
-// v5: one continuous stream of steps over the block's chunk range: B fragments prefetched two steps ahead ACROSS chunk
-// boundaries, the next chunk's constants loaded early, the queue drained only when it is three quarters full or at the
-// end (an exact pass costs a global-load round trip: once per block, not once per chunk).
-// ---------------------------------------------------------------------------------------------------------------
-constexpr int Q5 = 1280;
-template <int RB>
-__global__ __launch_bounds__(256) void k_f16v5(const float* __restrict__ planes, int n, int ld, const float* __restrict__ Rt,
-                                               uint32_t ldl, float tau2, uint32_t* __restrict__ cnt_out, uint32_t* dbg,
-                                               const uint4* __restrict__ tile, const ChunkInfo* __restrict__ info, int chunks,
-                                               int splits) {
-  constexpr int HB = 4 * RB * 8, NT = 4 * RB;
-  __shared__ float Hc[HB * 12];
-  __shared__ float Tabs[HB];
-  __shared__ uint32_t wildf[HB];
-  __shared__ uint32_t fix[HB];
-  __shared__ uint32_t queue[4][Q5];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int col = lane & 31, hf = lane >> 5;
-  // this block's chunks: [c0, c1)
-  const int per = (chunks + splits - 1) / splits, c0 = blockIdx.y * per, c1 = min(chunks, c0 + per);
-  const half8* Th = reinterpret_cast<const half8*>(tile);
-  const half8* Bp = Th + ((size_t)c0 * PC + col) * 2 + hf;  // step k of the range: Bp[64 k]
-  half8 b0, b1;
-  if (c0 < c1) { b0 = Bp[0]; b1 = Bp[64]; }  // in flight while the hypotheses are staged
-  if (tid < HB) {
-    const uint32_t h = blockIdx.x * HB + tid;
-    float ta = 0.f; bool w = false;
-#pragma unroll
-    for (int c = 0; c < 12; c++) {
-      const float x = Rt[(size_t)c * ldl + h];
-      Hc[tid * 12 + c] = x;
-      if (c < 9) w = w || !(fabsf(x) <= 1.5f); else { ta = fmaxf(ta, fabsf(x)); w = w || !(fabsf(x) < 1e30f); }
-    }
-    Tabs[tid] = ta; wildf[tid] = w ? 1u : 0u; fix[tid] = 0u;
-  }
-  __syncthreads();
-  const int hw0 = wave * 8 * RB;
-  float tmax = 0.f;
-  if (lane < 8 * RB && !wildf[hw0 + lane]) tmax = Tabs[hw0 + lane];
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) tmax = fmaxf(tmax, __shfl_xor(tmax, o));
-  half8 A[RB];
-  uint32_t wl = 0;
-#pragma unroll
-  for (int rb = 0; rb < RB; rb++) {
-    const int hy = (lane & 31) >> 2, c = lane & 3;
-    const float* M = &Hc[(hw0 + 8 * rb + hy) * 12];
-    _Float16 rh[3], rl[3];
-#pragma unroll
-    for (int kk = 0; kk < 3; kk++) {
-      const float x = c < 3 ? M[3 * c + kk] * RS : 0.f;
-      rh[kk] = (_Float16)x; rl[kk] = (_Float16)(x - (float)rh[kk]);
-    }
-    const _Float16 z = (_Float16)0.f, mone = (_Float16)(-RS);
-    const half8 a0 = {rh[0], rh[0], rl[0], rh[1], rh[1], rl[1], rh[2], rh[2]};
-    const half8 a1 = {rl[2], c == 0 ? mone : z, c == 0 ? mone : z, c == 1 ? mone : z, c == 1 ? mone : z, c == 2 ? mone : z, c == 2 ? mone : z, z};
-    A[rb] = hf ? a1 : a0;
-#pragma unroll
-    for (int jj = 0; jj < 4; jj++) wl |= wildf[hw0 + 8 * rb + 2 * jj + hf] ? (1u << (4 * rb + jj)) : 0u;
-  }
-  float Tl[RB][4][3];  // this lane's translations (hypothesis 2 jj + hf of every row block), unscaled
-#pragma unroll
-  for (int rb = 0; rb < RB; rb++)
-#pragma unroll
-    for (int jj = 0; jj < 4; jj++)
-#pragma unroll
-      for (int i = 0; i < 3; i++) Tl[rb][jj][i] = Hc[(hw0 + 8 * rb + 2 * jj + hf) * 12 + 9 + i] * RS;
-  uint32_t total[NT];
-#pragma unroll
-  for (int t = 0; t < NT; t++) total[t] = 0;
-  uint32_t qn = 0, events = 0;
-  uint32_t* q = queue[wave];
-  auto drain = [&]() {
-    for (uint32_t i = lane; i < qn; i += 64) {
-      const uint32_t ent = q[i];
-      const int m = (int)(ent >> 9), ehf = (ent >> 8) & 1;
-      float p[6];
-#pragma unroll
-      for (int c = 0; c < 6; c++) p[c] = planes[(size_t)c * ld + m];
-      for (uint32_t bits = ent & 0xFFu; bits; bits &= bits - 1) {
-        const int hl = hw0 + 2 * (__ffs(bits) - 1) + ehf;
-        if (canon_d2(&Hc[hl * 12], p) < tau2) atomicAdd(&fix[hl], 1u);
-      }
-    }
-    events += qn; qn = 0;
-  };
-  ChunkInfo ci = c0 < c1 ? info[c0] : ChunkInfo{1.f, 0.f, 0.f, 0.f};
-  for (int ch = c0; ch < c1; ch++) {
-    const ChunkInfo cn = ch + 1 < c1 ? info[ch + 1] : ci;  // next chunk's constants: loaded a whole chunk ahead
-    const int m0 = ch * PC;
-    const float s = ci.s, st = s * sqrtf(tau2);
-    const float Sb = 2.6f * (ci.pmax * s) + ci.qmax * s + tmax * s;
-    const float eta = Sb * (1.0f / 65536.0f);
-    const bool fast = (eta <= 0.25f * st) && (st <= 4096.f) && (tmax * s <= 2048.f);
-    const float lo_e = RS * (st - eta), hi_e = RS * (st + eta);
-    const float LO = lo_e * lo_e * (1.0f - 1e-6f), HI = hi_e * hi_e * (1.0f + 1e-6f);
-    const uint32_t W2b = fast ? __float_as_uint(HI - LO) : 0u;
-    f32x16 C[RB];
-#pragma unroll
-    for (int rb = 0; rb < RB; rb++)
-#pragma unroll
-      for (int jj = 0; jj < 4; jj++) {
-        C[rb][4 * jj] = Tl[rb][jj][0] * s; C[rb][4 * jj + 1] = Tl[rb][jj][1] * s; C[rb][4 * jj + 2] = Tl[rb][jj][2] * s; C[rb][4 * jj + 3] = 0.f;
-      }
-    uint32_t sr[NT];
-#pragma unroll
-    for (int t = 0; t < NT; t++) sr[t] = 0;
-    const half8* Bc = Bp + (size_t)64 * 16 * (ch - c0);  // this chunk's first step
-    f32x16 Da[RB], Db[RB];
-#pragma unroll
-    for (int rb = 0; rb < RB; rb++) Da[rb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[rb], b0, C[rb], 0, 0, 0);
-    auto epilogue = [&](const f32x16 (&D)[RB], int g) {
-      float x[NT];
-      uint32_t mn = 0xFFFFFFFFu;
-#pragma unroll
-      for (int rb = 0; rb < RB; rb++)
-#pragma unroll
-        for (int jj = 0; jj < 4; jj++) {
-          const float v = fma_(D[rb][4 * jj + 2], D[rb][4 * jj + 2], fma_(D[rb][4 * jj + 1], D[rb][4 * jj + 1], fma_(D[rb][4 * jj], D[rb][4 * jj], -LO)));
-          x[4 * rb + jj] = v;
-          sr[4 * rb + jj] = __builtin_amdgcn_alignbit(sr[4 * rb + jj], __float_as_uint(v), 31);
-          mn = min(mn, __float_as_uint(v));
-        }
-      const uint64_t hm = __ballot(mn < W2b);
-      if (__builtin_expect(hm != 0, 0)) {
-        uint32_t bits = 0;
-#pragma unroll
-        for (int t = 0; t < NT; t++) bits |= (__float_as_uint(x[t]) < W2b) ? (1u << t) : 0u;
-        bits &= ~wl;
-        if (mn < W2b) q[qn + __popcll(hm & ((1ull << lane) - 1ull))] = ((uint32_t)(m0 + 32 * g + col) << 9) | ((uint32_t)hf << 8) | bits;
-        qn += (uint32_t)__popcll(hm);
-      }
-    };
-    // 16 steps; the tile is padded by one chunk, so the prefetches past the range's end read valid memory
-#pragma unroll 1
-    for (int g = 0; g < 16; g += 2) {
-      b0 = Bc[(size_t)64 * (g + 2)];
-#pragma unroll
-      for (int rb = 0; rb < RB; rb++) Db[rb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[rb], b1, C[rb], 0, 0, 0);
-      epilogue(Da, g);
-      b1 = Bc[(size_t)64 * (g + 3)];
-      if (g + 2 < 16) {
-#pragma unroll
-        for (int rb = 0; rb < RB; rb++) Da[rb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[rb], b0, C[rb], 0, 0, 0);
-      }
-      epilogue(Db, g + 1);
-    }
-    if (qn > Q5 - 1024) drain();
-#pragma unroll
-    for (int t = 0; t < NT; t++) {
-      if (!fast || ((wl >> t) & 1u)) {
-        const int hl = hw0 + 2 * t + hf;
-        uint32_t bits = 0;
-        for (int g = 0; g < 16; g++) {
-          const int m = m0 + 32 * g + col;
-          float p[6];
-#pragma unroll
-          for (int c = 0; c < 6; c++) p[c] = m < n ? planes[(size_t)c * ld + m] : (c < 3 ? 0.f : 1e30f);
-          bits = (bits << 1) | (canon_d2(&Hc[hl * 12], p) < tau2 ? 1u : 0u);
-        }
-        sr[t] = bits;
-      }
-      total[t] += (uint32_t)__popc(sr[t]);
-    }
-    ci = cn;
-  }
-  drain();
-  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-#pragma unroll
-  for (int t = 0; t < NT; t++) {
-    uint32_t c = total[t];
-#pragma unroll
-    for (int o = 16; o > 0; o >>= 1) c += __shfl_xor(c, o, 32);
-    const int hl = hw0 + 2 * t + hf;
-    if (col == 0) cnt_out[(size_t)blockIdx.y * ldl + blockIdx.x * HB + hl] = c + fix[hl];
-  }
-  if (dbg && lane == 0 && events) atomicAdd(dbg, events);
-}
-
-template <int RB>
-__global__ __launch_bounds__(256) void k_f16v6(const float* __restrict__ planes, int n, int ld, const float* __restrict__ Rt,
-                                               uint32_t ldl, float tau2, uint32_t* __restrict__ cnt_out, uint32_t* dbg,
-                                               const uint4* __restrict__ tile, const ChunkInfo* __restrict__ info, int chunks,
-                                               int splits) {
-  constexpr int HB = 4 * RB * 8, NT = 4 * RB;
-  __shared__ float Hc[HB * 12];
-  __shared__ float Tabs[HB];
-  __shared__ uint32_t wildf[HB];
-  __shared__ uint32_t fix[HB];
-  __shared__ uint32_t queue[4][Q5];
-  __shared__ uint4 Bt[2][PC * 2];  // the chunk's B tile, double buffered, filled by LDS-DMA
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int col = lane & 31, hf = lane >> 5;
-  // this block's chunks: [c0, c1)
-  const int per = (chunks + splits - 1) / splits, c0 = blockIdx.y * per, c1 = min(chunks, c0 + per);
-  auto stage = [&](int ch, int buf) {  // 16 KiB: four 16-byte LDS-DMA loads per lane, lane-linear image
-#pragma unroll
-    for (int i = 0; i < 4; i++)
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(tile + (size_t)ch * (PC * 2) + 256 * i + tid),
-                                       (__attribute__((address_space(3))) void*)(&Bt[buf][256 * i + wave * 64]), 16, 0, 0);
-  };
-  if (c0 < c1) stage(c0, 0);  // in flight while the hypotheses are staged
-  half8 b0, b1;
-  if (tid < HB) {
-    const uint32_t h = blockIdx.x * HB + tid;
-    float ta = 0.f; bool w = false;
-#pragma unroll
-    for (int c = 0; c < 12; c++) {
-      const float x = Rt[(size_t)c * ldl + h];
-      Hc[tid * 12 + c] = x;
-      if (c < 9) w = w || !(fabsf(x) <= 1.5f); else { ta = fmaxf(ta, fabsf(x)); w = w || !(fabsf(x) < 1e30f); }
-    }
-    Tabs[tid] = ta; wildf[tid] = w ? 1u : 0u; fix[tid] = 0u;
-  }
-  __syncthreads();
-  const int hw0 = wave * 8 * RB;
-  float tmax = 0.f;
-  if (lane < 8 * RB && !wildf[hw0 + lane]) tmax = Tabs[hw0 + lane];
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) tmax = fmaxf(tmax, __shfl_xor(tmax, o));
-  half8 A[RB];
-  uint32_t wl = 0;
-#pragma unroll
-  for (int rb = 0; rb < RB; rb++) {
-    const int hy = (lane & 31) >> 2, c = lane & 3;
-    const float* M = &Hc[(hw0 + 8 * rb + hy) * 12];
-    _Float16 rh[3], rl[3];
-#pragma unroll
-    for (int kk = 0; kk < 3; kk++) {
-      const float x = c < 3 ? M[3 * c + kk] * RS : 0.f;
-      rh[kk] = (_Float16)x; rl[kk] = (_Float16)(x - (float)rh[kk]);
-    }
-    const _Float16 z = (_Float16)0.f, mone = (_Float16)(-RS);
-    const half8 a0 = {rh[0], rh[0], rl[0], rh[1], rh[1], rl[1], rh[2], rh[2]};
-    const half8 a1 = {rl[2], c == 0 ? mone : z, c == 0 ? mone : z, c == 1 ? mone : z, c == 1 ? mone : z, c == 2 ? mone : z, c == 2 ? mone : z, z};
-    A[rb] = hf ? a1 : a0;
-#pragma unroll
-    for (int jj = 0; jj < 4; jj++) wl |= wildf[hw0 + 8 * rb + 2 * jj + hf] ? (1u << (4 * rb + jj)) : 0u;
-  }
-  float Tl[RB][4][3];  // this lane's translations (hypothesis 2 jj + hf of every row block), unscaled
-#pragma unroll
-  for (int rb = 0; rb < RB; rb++)
-#pragma unroll
-    for (int jj = 0; jj < 4; jj++)
-#pragma unroll
-      for (int i = 0; i < 3; i++) Tl[rb][jj][i] = Hc[(hw0 + 8 * rb + 2 * jj + hf) * 12 + 9 + i] * RS;
-  uint32_t total[NT];
-#pragma unroll
-  for (int t = 0; t < NT; t++) total[t] = 0;
-  uint32_t qn = 0, events = 0;
-  uint32_t* q = queue[wave];
-  auto drain = [&]() {
-    for (uint32_t i = lane; i < qn; i += 64) {
-      const uint32_t ent = q[i];
-      const int m = (int)(ent >> 9), ehf = (ent >> 8) & 1;
-      float p[6];
-#pragma unroll
-      for (int c = 0; c < 6; c++) p[c] = planes[(size_t)c * ld + m];
-      for (uint32_t bits = ent & 0xFFu; bits; bits &= bits - 1) {
-        const int hl = hw0 + 2 * (__ffs(bits) - 1) + ehf;
-        if (canon_d2(&Hc[hl * 12], p) < tau2) atomicAdd(&fix[hl], 1u);
-      }
-    }
-    events += qn; qn = 0;
-  };
-  ChunkInfo ci = c0 < c1 ? info[c0] : ChunkInfo{1.f, 0.f, 0.f, 0.f};
-  __syncthreads();  // chunk c0's tile has landed (the barrier waits for the DMA)
-  for (int ch = c0; ch < c1; ch++) {
-    const int buf = (ch - c0) & 1;
-    if (ch + 1 < c1) stage(ch + 1, buf ^ 1);
-    const half8* Bc = reinterpret_cast<const half8*>(Bt[buf]) + col * 2 + hf;  // step g: Bc[64 g]
-    b0 = Bc[0]; b1 = Bc[64];
-    const ChunkInfo cn = ch + 1 < c1 ? info[ch + 1] : ci;  // next chunk's constants: loaded a whole chunk ahead
-    const int m0 = ch * PC;
-    const float s = ci.s, st = s * sqrtf(tau2);
-    const float Sb = 2.6f * (ci.pmax * s) + ci.qmax * s + tmax * s;
-    const float eta = Sb * (1.0f / 65536.0f);
-    const bool fast = (eta <= 0.25f * st) && (st <= 4096.f) && (tmax * s <= 2048.f);
-    const float lo_e = RS * (st - eta), hi_e = RS * (st + eta);
-    const float LO = lo_e * lo_e * (1.0f - 1e-6f), HI = hi_e * hi_e * (1.0f + 1e-6f);
-    const uint32_t W2b = fast ? __float_as_uint(HI - LO) : 0u;
-    f32x16 C[RB];
-#pragma unroll
-    for (int rb = 0; rb < RB; rb++)
-#pragma unroll
-      for (int jj = 0; jj < 4; jj++) {
-        C[rb][4 * jj] = Tl[rb][jj][0] * s; C[rb][4 * jj + 1] = Tl[rb][jj][1] * s; C[rb][4 * jj + 2] = Tl[rb][jj][2] * s; C[rb][4 * jj + 3] = 0.f;
-      }
-    uint32_t sr[NT];
-#pragma unroll
-    for (int t = 0; t < NT; t++) sr[t] = 0;
-    f32x16 Da[RB], Db[RB];
-#pragma unroll
-    for (int rb = 0; rb < RB; rb++) Da[rb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[rb], b0, C[rb], 0, 0, 0);
-    auto epilogue = [&](const f32x16 (&D)[RB], int g) {
-      float x[NT];
-      uint32_t mn = 0xFFFFFFFFu;
-#pragma unroll
-      for (int rb = 0; rb < RB; rb++)
-#pragma unroll
-        for (int jj = 0; jj < 4; jj++) {
-          const float v = fma_(D[rb][4 * jj + 2], D[rb][4 * jj + 2], fma_(D[rb][4 * jj + 1], D[rb][4 * jj + 1], fma_(D[rb][4 * jj], D[rb][4 * jj], -LO)));
-          x[4 * rb + jj] = v;
-          sr[4 * rb + jj] = __builtin_amdgcn_alignbit(sr[4 * rb + jj], __float_as_uint(v), 31);
-          mn = min(mn, __float_as_uint(v));
-        }
-      const uint64_t hm = __ballot(mn < W2b);
-      if (__builtin_expect(hm != 0, 0)) {
-        uint32_t bits = 0;
-#pragma unroll
-        for (int t = 0; t < NT; t++) bits |= (__float_as_uint(x[t]) < W2b) ? (1u << t) : 0u;
-        bits &= ~wl;
-        if (mn < W2b) q[qn + __popcll(hm & ((1ull << lane) - 1ull))] = ((uint32_t)(m0 + 32 * g + col) << 9) | ((uint32_t)hf << 8) | bits;
-        qn += (uint32_t)__popcll(hm);
-      }
-    };
-    // 16 steps; the tile is padded by one chunk, so the prefetches past the range's end read valid memory
-#pragma unroll 1
-    for (int g = 0; g < 16; g += 2) {
-      if (g + 2 < 16) b0 = Bc[64 * (g + 2)];
-#pragma unroll
-      for (int rb = 0; rb < RB; rb++) Db[rb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[rb], b1, C[rb], 0, 0, 0);
-      epilogue(Da, g);
-      if (g + 3 < 16) b1 = Bc[64 * (g + 3)];
-      if (g + 2 < 16) {
-#pragma unroll
-        for (int rb = 0; rb < RB; rb++) Da[rb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[rb], b0, C[rb], 0, 0, 0);
-      }
-      epilogue(Db, g + 1);
-    }
-    if (qn > Q5 - 1024) drain();
-#pragma unroll
-    for (int t = 0; t < NT; t++) {
-      if (!fast || ((wl >> t) & 1u)) {
-        const int hl = hw0 + 2 * t + hf;
-        uint32_t bits = 0;
-        for (int g = 0; g < 16; g++) {
-          const int m = m0 + 32 * g + col;
-          float p[6];
-#pragma unroll
-          for (int c = 0; c < 6; c++) p[c] = m < n ? planes[(size_t)c * ld + m] : (c < 3 ? 0.f : 1e30f);
-          bits = (bits << 1) | (canon_d2(&Hc[hl * 12], p) < tau2 ? 1u : 0u);
-        }
-        sr[t] = bits;
-      }
-      total[t] += (uint32_t)__popc(sr[t]);
-    }
-    ci = cn;
-    __syncthreads();  // everyone is done with this buffer, and the next chunk's tile has landed
-  }
-  drain();
-  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-#pragma unroll
-  for (int t = 0; t < NT; t++) {
-    uint32_t c = total[t];
-#pragma unroll
-    for (int o = 16; o > 0; o >>= 1) c += __shfl_xor(c, o, 32);
-    const int hl = hw0 + 2 * t + hf;
-    if (col == 0) cnt_out[(size_t)blockIdx.y * ldl + blockIdx.x * HB + hl] = c + fix[hl];
-  }
-  if (dbg && lane == 0 && events) atomicAdd(dbg, events);
-}
-
-
-
-// ---------------------------------------------------------------------------------------------------------------
-// v7: lean.  One row block (8 hypotheses) per wave, <= 80 VGPRs (6 waves per SIMD hide the MFMA and LDS latencies, no
-// in-wave double buffering), the chunk's B tile staged ONCE per workgroup into LDS by LDS-DMA (single buffer: while one
-// workgroup waits for its DMA the other five on the CU compute), nothing else shared between the waves.
-// ---------------------------------------------------------------------------------------------------------------
 constexpr int Q7 = 640;
 template <int WAVES, int ABL = 0>
 __global__ __launch_bounds__(64 * WAVES, 6) void k_f16v7(const float* __restrict__ planes, int n, int ld, const float* __restrict__ Rt,
@@ -1554,11 +851,6 @@ int main(int argc, char** argv) {
   bench("v2 RB=4 s=2 no MFMA", L2A(4, 2, 2));
   bench("v2 RB=4 s=2 no event check", L2A(4, 2, 4));
   bench("v2 RB=4 s=2 no epilogue", L2A(4, 2, 8));
-#define L3(RB, SPL) [&] { hipLaunchKernelGGL((k_f16v3<RB>), dim3(T / (32 * RB), SPL), dim3(256), 0, 0, d_pl, n, ld, d_Rt, ldl, tau2, d_part, d_dbg, d_tile, d_info, chunks, SPL); }
-#define L4(RB, SPL) [&] { hipLaunchKernelGGL((k_f16v4<RB>), dim3(T / (32 * RB), SPL), dim3(256), 0, 0, d_pl, n, ld, d_Rt, ldl, tau2, d_part, d_dbg, d_tile, d_info, chunks, SPL); }
-#define L4C(RB, SPL, CH) [&] { hipLaunchKernelGGL((k_f16v4<RB>), dim3(T / (32 * RB), SPL), dim3(256), 0, 0, d_pl, n, ld, d_Rt, ldl, tau2, d_part, d_dbg, d_tile, d_info, CH, SPL); }
-#define L5(RB, SPL) [&] { hipLaunchKernelGGL((k_f16v5<RB>), dim3(T / (32 * RB), SPL), dim3(256), 0, 0, d_pl, n, ld, d_Rt, ldl, tau2, d_part, d_dbg, d_tile, d_info, chunks, SPL); }
-#define L6(RB, SPL) [&] { hipLaunchKernelGGL((k_f16v6<RB>), dim3(T / (32 * RB), SPL), dim3(256), 0, 0, d_pl, n, ld, d_Rt, ldl, tau2, d_part, d_dbg, d_tile, d_info, chunks, SPL); }
 #define L7(W, SPL) [&] { hipLaunchKernelGGL((k_f16v7<W>), dim3(T / (8 * W), SPL), dim3(64 * W), 0, 0, d_pl, n, ld, d_Rt, ldl, tau2, d_part, d_dbg, d_tile, d_info, chunks, SPL); }
 #define L7A(W, SPL, AB) [&] { hipLaunchKernelGGL((k_f16v7<W, AB>), dim3(T / (8 * W), SPL), dim3(64 * W), 0, 0, d_pl, n, ld, d_Rt, ldl, tau2, d_part, d_dbg, d_tile, d_info, chunks, SPL); }
 #define L8(W, SPL) [&] { hipLaunchKernelGGL((k_f16v8<W>), dim3(T / (8 * W), SPL), dim3(64 * W), 0, 0, d_pl, n, ld, d_Rt, ldl, tau2, d_part, d_dbg, d_tile, d_info, chunks, SPL); }
@@ -1582,37 +874,6 @@ int main(int argc, char** argv) {
   bench("v7 8 waves splits=5", L7(8, 5));
   bench("v7 16 waves splits=1", L7(16, 1));
   bench("v7 16 waves splits=2", L7(16, 2));
-  bench("v6 RB=1 splits=1", L6(1, 1));
-  bench("v6 RB=1 splits=2", L6(1, 2));
-  bench("v6 RB=1 splits=5", L6(1, 5));
-  bench("v6 RB=2 splits=1", L6(2, 1));
-  bench("v6 RB=2 splits=2", L6(2, 2));
-  bench("v6 RB=2 splits=5", L6(2, 5));
-  bench("v5 RB=1 splits=1", L5(1, 1));
-  bench("v5 RB=1 splits=2", L5(1, 2));
-  bench("v5 RB=1 splits=5", L5(1, 5));
-  bench("v5 RB=2 splits=1", L5(2, 1));
-  bench("v5 RB=2 splits=2", L5(2, 2));
-  bench("v5 RB=2 splits=5", L5(2, 5));
-  bench("v4 RB=1 splits=1 NO chunks", L4C(1, 1, 0));
-  bench("v4 RB=1 splits=5 NO chunks", L4C(1, 5, 0));
-  bench("v4 RB=1 splits=1 1 chunk", L4C(1, 1, 1));
-  bench("v4 RB=1 splits=1 2 chunks", L4C(1, 1, 2));
-  bench("v4 RB=1 splits=1 4 chunks", L4C(1, 1, 4));
-  bench("v4 RB=2 splits=1 NO chunks", L4C(2, 1, 0));
-  bench("v4 RB=2 splits=1 1 chunk", L4C(2, 1, 1));
-  bench("v4 RB=2 splits=1 4 chunks", L4C(2, 1, 4));
-  bench("v4 RB=1 splits=1", L4(1, 1));
-  bench("v4 RB=1 splits=2", L4(1, 2));
-  bench("v4 RB=1 splits=5", L4(1, 5));
-  bench("v4 RB=2 splits=1", L4(2, 1));
-  bench("v4 RB=2 splits=2", L4(2, 2));
-  bench("v4 RB=2 splits=5", L4(2, 5));
-  bench("v3 RB=1 splits=1", L3(1, 1));
-  bench("v3 RB=1 splits=2", L3(1, 2));
-  bench("v3 RB=2 splits=1", L3(2, 1));
-  bench("v3 RB=2 splits=2", L3(2, 2));
-  bench("v3 RB=2 splits=5", L3(2, 5));
   bench("v2 RB=1 splits=1", L2(1, 1));
   bench("v2 RB=1 splits=2", L2(1, 2));
   bench("v2 RB=2 splits=1", L2(2, 1));
