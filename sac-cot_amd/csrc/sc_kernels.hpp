@@ -386,8 +386,11 @@ void launch_rt_to_soa(const float* Rt, uint32_t T, uint32_t ld_local, float* RtS
 bool score_is_scalar(int score_mode, const Tuning& tn);
 uint32_t score_chunks(int n, uint32_t ld_local, bool scalar);
 // score_mode: 0 inlier count, 1 truncated squared residual, 2 truncated absolute residual (include/saccot.h)
+// ev0 / ev1 (both or neither): start and stop timestamps taken from the dispatch packets of the stage's first and last kernel
+// (hipExtLaunchKernelGGL) — no extra packet on the stream, unlike a bracket of hipEventRecord calls (~4.5 us each on this part)
 void launch_score(const Points& pts, const float* RtSoA, const float* RtAoS, const Shard& sh, const Derived& dv,
-                  int score_mode, uint32_t* partial, const Tuning& tn, hipStream_t st);
+                  int score_mode, uint32_t* partial, const Tuning& tn, hipStream_t st, hipEvent_t ev0 = nullptr,
+                  hipEvent_t ev1 = nullptr);
 // C2, inlier count, by filter + exact fix-up (sc_score.hip): which calls use it, what it needs, and its two launches.
 // The tile (fp16 image of the correspondences) depends on the points only: launch_filter_tile runs once per call, any
 // time after launch_stage_points (whose atomicMax fills mx_cur); mx_cur / mx_next are two u32 pairs that alternate
@@ -430,7 +433,7 @@ void launch_filter_tile(const Points& pts, const FilterTileJob& job, hipStream_t
 // RtAoS: 12 consecutive floats per hypothesis (what the exact pass loads; launch_kabsch / the stage hook write them)
 void launch_score_filter(const Points& pts, const float* RtSoA, const float* RtAoS, const Shard& sh, const Derived& dv,
                          const FilterPlan& fp, const void* tile, void* state, void* coef, uint32_t* partial, const Tuning& tn,
-                         hipStream_t st);
+                         hipStream_t st, hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr);
 // diagnostics (sc_debug_last): what the filter of the last launch handed to the exact pass.  Blocking copies on `st`.
 hipError_t filter_read_counters(const void* state, const FilterPlan& fp, hipStream_t st, uint64_t* undecided, uint64_t* recounts);
 // Winner key pair key2[0..1] (written, not accumulated: no zeroing needed):

@@ -12,6 +12,7 @@
 //   grid          = ceil(T/256) x chunks, so a 50k x 5k problem is ~1000 workgroups (~4 waves per SIMD);
 //   partial counts are stored coalesced ([chunk][hypothesis]) and summed by the arg-max kernel.
 #include <vector>
+#include <hip/hip_ext.h>
 
 #include "sc_arith.hpp"
 #include "sc_block.hpp"
@@ -37,13 +38,16 @@ uint32_t shard_local_count(uint32_t T_eff, uint32_t block, uint32_t rank, uint32
 }
 
 // ---- Gram filter: constants shared by host and device -------------------------------------------------------------
-constexpr int GX_UNIT = 256;     // correspondences per staging unit (8 MFMA steps of 32): 24 KiB; LDS holds two
+constexpr int GX_UNIT = 256;     // correspondences per staging unit (8 MFMA steps of 32): 16 KiB; LDS holds two
+constexpr int GX_TILE_B = 64;    // bytes of the tile per correspondence: hi halves and lo halves of its 16 features
+constexpr int GX_TILE_Q = GX_TILE_B / 16;  // ... in 16-byte pieces
 constexpr int GX_WAVES = 8;      // waves per workgroup, 32 hypotheses each: eight waves share a tile, so each of them issues three 1 KiB
                                  // LDS-DMA pieces per eight steps (with 4 waves and 128-correspondence units the DMA issue alone cost a quarter of the kernel)
 constexpr int GX_QL = 128;       // LDS queue entries per wave (8 bytes each)
 constexpr float GX_RS = 256.0f;  // scale of the A operand (keeps the low halves of the coefficients out of fp16's sub-normal range)
 constexpr double GX_ACC = 1.1e-6;    // 18.5 x 2^-24: error of one MFMA per unit of its LARGEST term (five times the largest seen: score_gram_kernel)
 constexpr double GX_Q = 7.5e-7;      // 3.01 x 2^-22 (+ margin): the dropped lo x lo products and split remainders per unit of sum |w F|
+constexpr double GX_NORM = 2.5e-7;   // 2^-22 (+ margin): what the norm feature's two fp16 pieces leave, per unit of Pn^2 + Qn^2
 constexpr double GX_CANON = 4.2e-7;  // sqrt(3) * 4 * 2^-24: deviation of the canonical fp32 residual VECTOR per unit of magnitude
 struct GramInfo {  // written by the tile kernel (thread 0), at offset 64 of the filter's info area
   float s;         // power of two: the largest half extent of either bounding box -> [64, 128)
@@ -91,7 +95,8 @@ __host__ __device__ inline double gram_eps(double Tn, double Pn, double Qn, doub
   Mh = m2 > Mh ? m2 : Mh;
   Mh = m3 > Mh ? m3 : Mh;
   const double Sl = 3.5 * Pn * Qn + 2.02 * Tn * Pn + 2.0 * Tn * Qn, S = Tn + 1.75 * Pn + Qn;
-  return GX_ACC * Mh + GX_Q * Sl + 1e-8 * S * S + 1e-4;
+  // GX_NORM: the norm feature travels in TWO fp16 pieces (22 bits), times its coefficient 2
+  return GX_ACC * Mh + GX_Q * Sl + GX_NORM * (Pn * Pn + Qn * Qn) + 1e-8 * S * S + 1e-4;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -672,7 +677,7 @@ FilterPlan filter_plan(int n, uint32_t ld_local, const Tuning& tn, uint32_t mode
   if (tn.filter_queue_cap) cap = tn.filter_queue_cap;
   fp.queue_cap = (uint32_t)(cap / FX_NQ * FX_NQ);
   if (fp.queue_cap < FX_NQ) fp.queue_cap = FX_NQ;
-  fp.tile_bytes = (size_t)fp.rows * (mode == 2 ? 96 : 32);
+  fp.tile_bytes = (size_t)fp.rows * (mode == 2 ? GX_TILE_B : 32);
   const size_t bm_words = ((size_t)fp.splits * fp.n_waves + 31) / 32;
   fp.state_bytes = 128 + (size_t)FX_NQ * 128 + (bm_words * 4 + 127) / 128 * 128 + (size_t)fp.queue_cap * 8;
   fp.coef_bytes = mode == 2 ? (size_t)ld_local * 64 + (size_t)ld_local * 4 + (size_t)(ld_local / 32) * 8 : 0;
@@ -1023,7 +1028,7 @@ __global__ __launch_bounds__(256) void score_exact_kernel(const float* __restric
 // For a rotation R^T R = I, and the right-hand side is a DOT PRODUCT of 16 features of the correspondence
 //     Q'_i P'_j (9), (|P'|^2 + |Q'|^2) / 2, P'_j (3), Q'_i (3)                       (tile kernel, fp64, once per call)
 // with 16 coefficients of the hypothesis  -2 R_ij, 2, 2 (R^T T')_j, -2 T'_i  plus the constant |T'|^2  (kernel prologue, fp64).
-// Features and coefficients are split into two fp16 halves (the norm feature into three pieces); hi x hi, hi x lo and
+// Features and coefficients are split into two fp16 halves; hi x hi, hi x lo and
 // lo x hi products are kept: 48 slots = three chained v_mfma_f32_32x32x16_f16, rows = 32 hypotheses, columns = 32
 // correspondences, accumulator initialised to |T'|^2 - LO: a lane then holds x = D~ - LO for 16 hypotheses of one
 // correspondence — sign bit into a shift register (1 instruction), shell test 0 <= x < HI - LO as an unsigned min over
@@ -1047,11 +1052,15 @@ __global__ __launch_bounds__(256) void score_exact_kernel(const float* __restric
 //     MFMAs 2, 3   their terms are <= 2^-10 of MFMA 1's; their C is the running value: 18.5 u (|x| + 3e-3 S) each — the part
 //                  proportional to x (2.2e-6) is carried by the factors (1 -+ 1e-5) of LO / HI, the rest is the 1e-8 S term
 //     splits       x = hi + lo + rem, |rem| <= 2^-22 |x|;  w F - (wh Fh + wh Fl + wl Fh) = wl Fl + ... <= 3.01 x 2^-22 |w F|:
-//                  7.2e-7 Sl (exact arithmetic, no model); the norm feature's three pieces leave 2^-33       (GX_Q)
+//                  7.2e-7 Sl (exact arithmetic, no model)                                                 (GX_Q)
+//     norm         the norm feature's coefficient 2 RS alpha has no low half, so of its three products only hi x hi and
+//                  hi x lo exist: its two pieces leave 2^-22 of it, 2.4e-7 (Pn^2 + Qn^2).  (Until r03c a third piece rode in
+//                  slot 9 of the third MFMA; dropping it makes that MFMA's B operand the FIRST one's — the tile is 64 bytes
+//                  per correspondence instead of 96: a third less LDS-DMA issue, LDS traffic and LDS space)   (GX_NORM)
 //     accumulator  initial value alpha RS (|T'|^2 - LO_h) rounded to fp32: u Mh (inside GX_ACC's margin)
 //     R^T R = I    defect g = max |(R^T R - I)_ab| measured per hypothesis in fp64: <= 3 g Pn^2 (beyond 1e-3: not a rotation,
 //                  the hypothesis is recounted exactly)
-//   sum: eps_h = 1.1e-6 Mh + 7.5e-7 Sl + 1e-8 S + 3 g Pn^2 + 1e-4                                            (gram_eps)
+//   sum: eps_h = 1.1e-6 Mh + 7.5e-7 Sl + 2.5e-7 (Pn^2 + Qn^2) + 1e-8 S + 3 g Pn^2 + 1e-4                     (gram_eps)
 // The canonical fp32 chain itself deviates from exact arithmetic: its residual VECTOR by <= dE = sqrt(3) 4 u s (qmax + 1.75 pmax
 // + |t|max) (original, uncentred magnitudes), its square by 3 more roundings.  So, with st = s sqrt(tau2):
 //     D~ <  LO_h = (st - dE)^2 (1 - 1e-5) - eps_h   =>  canonical inlier;     D~ >= HI_h = (st + dE)^2 (1 + 1e-5) + eps_h  =>  outlier;
@@ -1067,10 +1076,10 @@ __device__ __forceinline__ void split2(double x, _Float16& hi, _Float16& lo) {
   lo = (_Float16)(float)(x - (double)(float)hi);
 }
 
-// tile: per group of 32 correspondences 6 x 32 uint4 — for MFMA k (0..2): the 32 first halves (slots 0..7), then the 32
+// tile: per group of 32 correspondences 4 x 32 uint4 — for block k (0: hi halves, 1: lo halves): the 32 first halves (slots 0..7), then the 32
 // second halves (slots 8..15), so that lane l reads uint4 number 64 k + l of the group (linear, conflict-free).
 //   slots   0..8 Q'_i P'_j (index 3 i + j)   9 norm piece   10..12 256 P'_j   13..15 256 Q'_i
-//   MFMA 1: hi halves, norm hi;   MFMA 2: lo halves, norm mid;   MFMA 3: hi halves again, norm lo
+//   MFMA 1: coefficient hi x block 0 (norm hi);   MFMA 2: coefficient hi x block 1 (norm lo);   MFMA 3: coefficient lo x block 0
 __device__ void gram_tile_block(const float* __restrict__ planes, int n, int ld, const FilterTileJob& job, uint32_t block,
                                 uint32_t blocks) {
   const uint32_t m = block * 256 + threadIdx.x;
@@ -1078,7 +1087,7 @@ __device__ void gram_tile_block(const float* __restrict__ planes, int n, int ld,
   const GramInfo gi = gram_info(job.mx_cur + 2, job.mx_cur + 8, __uint_as_float(job.mx_cur[0]), __uint_as_float(job.mx_cur[1]));
   if (m == 0) *reinterpret_cast<GramInfo*>(static_cast<char*>(job.info) + 64) = gi;
   if (m >= job.rows) return;
-  _Float16 h[16], l[16], n3[3];
+  _Float16 h[16], l[16], n2[2];
   if (m < (uint32_t)n) {
     double P[3], Q[3];
 #pragma unroll
@@ -1097,21 +1106,19 @@ __device__ void gram_tile_block(const float* __restrict__ planes, int n, int ld,
     F[9] = 0.0;
 #pragma unroll
     for (int k = 0; k < 16; k++) split2(F[k], h[k], l[k]);
-    n3[0] = (_Float16)(float)N;
-    const double r1 = N - (double)(float)n3[0];
-    n3[1] = (_Float16)(float)r1;
-    n3[2] = (_Float16)(float)(r1 - (double)(float)n3[1]);
+    n2[0] = (_Float16)(float)N;
+    n2[1] = (_Float16)(float)(N - (double)(float)n2[0]);  // what is left: < 2^-22 N (GX_NORM)
   } else {  // sentinel: far away under every hypothesis (D~ = 2 x 60000 + ...), never undecided
 #pragma unroll
     for (int k = 0; k < 16; k++) { h[k] = (_Float16)0.f; l[k] = (_Float16)0.f; }
-    n3[0] = (_Float16)60000.f; n3[1] = (_Float16)0.f; n3[2] = (_Float16)0.f;
+    n2[0] = (_Float16)60000.f; n2[1] = (_Float16)0.f;
   }
-  uint4* tile = static_cast<uint4*>(job.tile) + (size_t)(m >> 5) * 192 + (m & 31u);
+  uint4* tile = static_cast<uint4*>(job.tile) + (size_t)(m >> 5) * (32 * GX_TILE_Q) + (m & 31u);
 #pragma unroll
-  for (int k = 0; k < 3; k++) {
+  for (int k = 0; k < 2; k++) {
     const _Float16* v = k == 1 ? l : h;
     half8 f0 = {v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7]};
-    half8 f1 = {v[8], n3[k], v[10], v[11], v[12], v[13], v[14], v[15]};
+    half8 f1 = {v[8], n2[k], v[10], v[11], v[12], v[13], v[14], v[15]};
     tile[64 * k] = *reinterpret_cast<uint4*>(&f0);
     tile[64 * k + 32] = *reinterpret_cast<uint4*>(&f1);
   }
@@ -1173,7 +1180,7 @@ __device__ void gram_coef_wave(const GramCoef& coef, const GramInfo& gi, const f
 #pragma unroll
   for (int o = 16; o > 0; o >>= 1) wmax = fmax(wmax, __shfl_xor(wmax, o, 32));
   // alpha is cut to 11 significant bits (rounded to fp16 after shrinking by 2^-10, so never above the ratio): the norm
-  // feature's coefficient 2 RS alpha then has no low half, like 2 RS itself — its three pieces need three slots, not six
+  // feature's coefficient 2 RS alpha then has no low half, like 2 RS itself — slot 9 of the third MFMA multiplies by zero
   const double alpha = normal ? (double)(float)(_Float16)(float)(fmin(16.0, wmax / width) * (1.0 - 1.0 / 1024.0)) : 0.0;
   const int half = (int)((threadIdx.x >> 5) & 1u);                // which 32-lane half of the wave this lane sits in
   const uint32_t normal_rows = (uint32_t)(__ballot(normal) >> (32 * half));
@@ -1195,7 +1202,7 @@ __device__ void gram_coef_wave(const GramCoef& coef, const GramInfo& gi, const f
     split2(alpha * a16[k], ah[k], al[k]);
     if (!live) { ah[k] = (_Float16)0.f; al[k] = (_Float16)0.f; }
   }
-  al[9] = ah[9];  // slot 9 of the third MFMA: the norm's third piece, coefficient 2 RS alpha again (it has no low half)
+  al[9] = (_Float16)0.f;  // (2 RS alpha has no low half: alpha is cut to 11 bits above)
   uint4* __restrict__ out = reinterpret_cast<uint4*>(coef.A) + (size_t)l * 4;
   half8 q0 = {ah[0], ah[1], ah[2], ah[3], ah[4], ah[5], ah[6], ah[7]}, q1 = {ah[8], ah[9], ah[10], ah[11], ah[12], ah[13], ah[14], ah[15]};
   half8 q2 = {al[0], al[1], al[2], al[3], al[4], al[5], al[6], al[7]}, q3 = {al[8], al[9], al[10], al[11], al[12], al[13], al[14], al[15]};
@@ -1213,6 +1220,17 @@ __global__ __launch_bounds__(256) void gram_coef_kernel(const float* __restrict_
   gram_coef_wave(coef, gi, v, l, ldl, n_local, tau2);
 }
 
+// sum of `v` over each aligned group of 32 lanes, valid in the group's upper 16 lanes (DPP: quad swaps, half mirror, mirror,
+// then lane 15 of the lower row broadcast into the upper row)
+__device__ __forceinline__ uint32_t dpp_sum32_upper(uint32_t v) {
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, false);   // quad_perm [1,0,3,2]
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xF, 0xF, false);   // quad_perm [2,3,0,1]
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x141, 0xF, 0xF, false);  // row_half_mirror
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x140, 0xF, 0xF, false);  // row_mirror: every lane holds its row's sum
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xA, 0xF, false);  // row_bcast15 into rows 1 and 3
+  return v;
+}
+
 template <int VAR>  // (timing-only ablations for tools/ab_stage.py: 512 = no shell test, 256 = no barrier, 32 = no epilogue)
 __global__ __launch_bounds__(64 * GX_WAVES, 2) void score_gram_kernel(GramCoef coef, uint32_t ldl,
                                                                      const uint4* __restrict__ tile, uint32_t windows,
@@ -1220,9 +1238,9 @@ __global__ __launch_bounds__(64 * GX_WAVES, 2) void score_gram_kernel(GramCoef c
                                                                      uint32_t* __restrict__ cnt_out, uint2* __restrict__ gq,
                                                                      uint32_t cap_sq, uint32_t* __restrict__ qcount,
                                                                      uint32_t* __restrict__ redo_bits, uint32_t ql) {
-  __shared__ uint4 Bt[2][GX_UNIT * 6];           // 2 x 24 KiB
+  __shared__ uint4 Bt[3][GX_UNIT * GX_TILE_Q];   // ring of three 16 KiB units: one being read, one landing, one being issued
   __shared__ uint2 queue[GX_WAVES][GX_QL];
-  __shared__ uint32_t qfill[GX_WAVES];          // entries in each wave's queue (LDS atomics of the lanes that hit)
+  constexpr int PIECES = GX_UNIT * GX_TILE_Q / (64 * GX_WAVES);  // LDS-DMA instructions per wave and unit
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int col = lane & 31, hf = lane >> 5;
   const uint32_t per = (windows + splits - 1) / splits, w0 = blockIdx.y * per, w1 = min(windows, w0 + per);
@@ -1231,8 +1249,8 @@ __global__ __launch_bounds__(64 * GX_WAVES, 2) void score_gram_kernel(GramCoef c
   const uint32_t u0 = w0 * UPW, u1 = w1 * UPW;
   auto stage = [&](uint32_t u, int buf) {  // (asm: see score_filter_kernel)
 #pragma unroll
-    for (int i = 0; i < GX_UNIT * 6 / (64 * GX_WAVES); i++) {
-      const uint4* gsrc = tile + (size_t)u * (GX_UNIT * 6) + 64 * GX_WAVES * i + tid;
+    for (int i = 0; i < PIECES; i++) {
+      const uint4* gsrc = tile + (size_t)u * (GX_UNIT * GX_TILE_Q) + 64 * GX_WAVES * i + tid;
       const uint32_t lds_dst = __builtin_amdgcn_readfirstlane(
           (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)(&Bt[buf][64 * GX_WAVES * i + wave * 64]));
       unsigned keep;
@@ -1241,6 +1259,7 @@ __global__ __launch_bounds__(64 * GX_WAVES, 2) void score_gram_kernel(GramCoef c
     }
   };
   if (u0 < u1) stage(u0, 0);
+  if (u0 + 1 < u1) stage(u0 + 1, 1);
   // ---- prologue: the coefficients were made once per call by gram_coef_wave (lane (row, hf) takes the halves of its row)
   const uint32_t row = (uint32_t)col, h = wid * 32 + row;
   const bool in_grid = h < ldl;  // (ldl is a multiple of 256: the last workgroup cannot reach beyond it)
@@ -1258,13 +1277,18 @@ __global__ __launch_bounds__(64 * GX_WAVES, 2) void score_gram_kernel(GramCoef c
     const float4 c4 = *reinterpret_cast<const float4*>(coef.C + (size_t)wid * 32 + 8 * jj + 4 * hf);
     C[4 * jj] = c4.x; C[4 * jj + 1] = c4.y; C[4 * jj + 2] = c4.z; C[4 * jj + 3] = c4.w;
   }
+  // The coefficients are USED here, so that the compiler's wait for these global loads sits here and not at their first real
+  // use — the first MFMA of the step loop, where an s_waitcnt vmcnt(0) in every trip also waited for the LDS-DMA of the units
+  // ahead (the compiler cannot see into the asm that issues them): until r03c every unit's first step stood still until the
+  // NEXT unit had landed, i.e. nothing was prefetched at all.
+  asm volatile("" ::"v"(A0), "v"(A2), "v"(C), "s"(W2b), "s"(redo4));
   uint32_t total[16], sr[16];
 #pragma unroll
   for (int i = 0; i < 16; i++) { total[i] = 0; sr[i] = 0; }
-  uint32_t qn = 0;
+  const int my_step = __builtin_amdgcn_readfirstlane(wave) & (GX_UNIT / 32 - 1);  // the step at which this wave issues its LDS-DMA
+  uint32_t qn = 0;  // entries in this wave's queue: wave-uniform, lives in a scalar register
   uint2* q = queue[wave];
-  if (lane == 0) qfill[wave] = 0u;
-  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // (qfill[wave]: this wave's own word)
+  bool flushed = false;  // a flush's global stores are younger than the LDS-DMA pieces in flight: the next wait is a full one
   auto flush_queue = [&]() {  // the wave's queue -> its global sub-queue (one ticket); see score_filter_kernel
     const uint32_t sq = wid % FX_NQ;
     uint32_t base = 0;
@@ -1275,18 +1299,26 @@ __global__ __launch_bounds__(64 * GX_WAVES, 2) void score_gram_kernel(GramCoef c
       gq[(size_t)sq * cap_sq + base + i] = fits ? make_uint2(q[i].x, (wid << 17) | q[i].y) : make_uint2(0u, 0u);
     if (!fits) redo4 = 0xFu;
     qn = 0;
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // the entries were read before the fill is reset
-    if (lane == 0) qfill[wave] = 0u;
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    flushed = true;
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // the entries were read before the queue is written again
   };
   for (uint32_t u = u0; u < u1; u++) {
-    const int buf = (int)((u - u0) & 1u);
+    const int buf = (int)((u - u0) % 3u);
     if constexpr ((VAR & 256) == 0) {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's part of unit u has landed
-      __syncthreads();                                   // ... everybody's has, and the other buffer is free
+      // this wave's part of unit u has landed: everything it issued except the youngest unit's pieces (loads return in order)
+      if (u + 1 < u1 && !flushed) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PIECES) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      flushed = false;
+      __syncthreads();  // ... everybody's has, and nobody reads unit u - 1's buffer any more (it takes unit u + 2)
     }
-    if constexpr ((VAR & 64) == 0) {  // (64: timing-only ablation, the tile is staged once)
-      if (u + 1 < u1) stage(u + 1, buf ^ 1);
+    // Unit u + 2 is issued right behind the barrier, TWO units ahead: with two buffers the pieces of unit u + 1 were issued here
+    // and — see the note on the coefficients above — waited for at once.  (VAR bit 0: each wave issues at a step of its own
+    // inside the step loop instead, so that the eight waves' LDS-DMA instructions, ~125 cycles apiece, do not queue up behind
+    // each other — tools/ubench/gram_loop.hip loses 20 % to that; here it measured 2 % SLOWER, C4 319 vs 313 us.)
+    const bool stage_ahead = (VAR & 64) == 0 && u + 2 < u1;
+    const int nbuf = buf == 0 ? 2 : buf - 1;
+    if constexpr ((VAR & 1) == 0) {
+      if (stage_ahead) stage(u + 2, nbuf);
     }
     if (any_normal && redo4 != 0xFu) {
       const half8* Bc = reinterpret_cast<const half8*>(Bt[buf]) + lane;
@@ -1304,43 +1336,51 @@ __global__ __launch_bounds__(64 * GX_WAVES, 2) void score_gram_kernel(GramCoef c
         }
         const uint32_t mn = min(min(min(gm[0], gm[1]), gm[2]), gm[3]);
         if (__builtin_expect(__ballot(mn < W2b) != 0, 0)) {
-          // Rare per test, not per step: no wave-wide bookkeeping here — a lane that hit takes a slot of the wave's LDS queue
-          // with an LDS atomic and writes its entry; the count is looked at once per unit.  Groups of four registers that
-          // no lane hit are skipped (wave-uniform branch).
+          // A step has an undecided test one time in three, and a wave that dawdles here holds up the seven others at the next
+          // barrier: nothing on this path waits for anything.  Groups of four registers that no lane hit are skipped (wave-
+          // uniform branch); in a group that hit, the lanes take consecutive slots of the wave's LDS queue by the ballot mask
+          // (v_mbcnt) above a fill count that lives in a scalar register — the LDS atomic with its returned value and the
+          // s_waitcnt behind it that did this before cost a third of the kernel (C4: 341 us, 228 without this path).
 #pragma unroll
           for (int j = 0; j < 4; j++) {
-            if (__ballot(gm[j] < W2b) == 0) continue;
+            const uint64_t hit = __ballot(gm[j] < W2b);
+            if (hit == 0) continue;
+            const uint32_t slot = qn + __builtin_amdgcn_mbcnt_hi((uint32_t)(hit >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)hit, 0u));
             if (gm[j] < W2b) {
               uint32_t bits = 0;
 #pragma unroll
               for (int i = 0; i < 4; i++) bits |= (__float_as_uint(D[4 * j + i]) < W2b) ? (1u << (4 * j + i)) : 0u;
-              const uint32_t slot = atomicAdd(&qfill[wave], 1u);
               if (slot < ql) q[slot] = make_uint2(u * GX_UNIT + 32 * g + col, ((uint32_t)hf << 16) | bits);
             }
+            qn += (uint32_t)__popcll(hit);
           }
         }
       };
       // One step after the other: issuing step g + 1's chain before step g's vector work (a software pipeline with two
       // accumulator sets) was built and measured — hipcc rotates the loop into THREE sets with 16 moves per trip and
       // spills in the queueing path: C4 335 -> 403 us, C2 52 -> 57.  The waves of a SIMD overlap each other instead.
-      half8 b0 = Bc[0], b1 = Bc[64], b2 = Bc[128];
+      half8 b0 = Bc[0], b1 = Bc[64];
 #pragma unroll 1
       for (int g = 0; g < GX_UNIT / 32; g++) {
         f32x16 D = __builtin_amdgcn_mfma_f32_32x32x16_f16(A0, b0, C, 0, 0, 0);
         D = __builtin_amdgcn_mfma_f32_32x32x16_f16(A1, b1, D, 0, 0, 0);
-        D = __builtin_amdgcn_mfma_f32_32x32x16_f16(A2, b2, D, 0, 0, 0);
-        // the next step's operands: three 16-byte LDS reads, in flight under this step's vector work
-        if (g + 1 < GX_UNIT / 32) { b0 = Bc[192 * (g + 1)]; b1 = Bc[192 * (g + 1) + 64]; b2 = Bc[192 * (g + 1) + 128]; }
+        D = __builtin_amdgcn_mfma_f32_32x32x16_f16(A2, b0, D, 0, 0, 0);  // lo x hi: the hi halves of the features again
+        // the next step's operands: two 16-byte LDS reads, in flight under this step's vector work
+        if (g + 1 < GX_UNIT / 32) { b0 = Bc[32 * GX_TILE_Q * (g + 1)]; b1 = Bc[32 * GX_TILE_Q * (g + 1) + 64]; }
+        if constexpr ((VAR & 1) != 0) {
+          if (stage_ahead && g == my_step) stage(u + 2, nbuf);
+        }
         epilogue(D, g);
       }
-      // the queue's fill (LDS, this wave's own word): beyond ql entries were dropped — the exact pass takes the whole (wave, split)
-      qn = *(volatile uint32_t*)&qfill[wave];
-      if (qn > ql) { redo4 = 0xFu; qn = 0; *(volatile uint32_t*)&qfill[wave] = 0u; }
+      // beyond ql entries were dropped — the exact pass takes the whole (wave, split)
+      if (qn > ql) { redo4 = 0xFu; qn = 0; }
       if ((u + 1) % UPW == 0) {  // window boundary: 32 tests per register
 #pragma unroll
         for (int i = 0; i < 16; i++) { total[i] += (uint32_t)__popc(sr[i]); sr[i] = 0; }
       }
       if (qn > ql / 2) flush_queue();
+    } else if ((VAR & 1) != 0 && stage_ahead) {
+      stage(u + 2, nbuf);  // (a wave with nothing to filter still brings its share of the tile)
     }
   }
   if (qn && redo4 != 0xFu) flush_queue();
@@ -1352,13 +1392,13 @@ __global__ __launch_bounds__(64 * GX_WAVES, 2) void score_gram_kernel(GramCoef c
         atomicOr(&redo_bits[bit >> 5], 1u << (bit & 31));
       }
   }
+  // the 32 columns of a lane half are two DPP rows: five v_add_dpp per register instead of five dependent ds_bpermute round
+  // trips (80 of them in a row were ~2.5 us at the end of every wave — a fifth of a wave's life at C2's 32 steps)
 #pragma unroll
   for (int i = 0; i < 16; i++) {
-    uint32_t c = total[i];
-#pragma unroll
-    for (int o = 16; o > 0; o >>= 1) c += __shfl_xor(c, o, 32);
+    const uint32_t c = dpp_sum32_upper(total[i]);
     const uint32_t r = 8 * (i >> 2) + 4 * hf + (i & 3), hh = wid * 32 + r;
-    if (col == 0 && hh < ldl) cnt_out[(size_t)blockIdx.y * ldl + hh] = ((redo4 >> (i >> 2)) & 1u) ? 0u : c;
+    if (col == 31 && hh < ldl) cnt_out[(size_t)blockIdx.y * ldl + hh] = ((redo4 >> (i >> 2)) & 1u) ? 0u : c;
   }
 }
 
@@ -1391,7 +1431,7 @@ void launch_filter_tile(const Points& pts, const FilterTileJob& job, hipStream_t
 
 void launch_score_filter(const Points& pts, const float* RtSoA, const float* RtAoS, const Shard& sh, const Derived& dv,
                          const FilterPlan& fp, const void* tile, void* state, void* coef, uint32_t* partial, const Tuning& tn,
-                         hipStream_t st) {
+                         hipStream_t st, hipEvent_t ev0, hipEvent_t ev1) {
   if (sh.n_local == 0) return;
   const FilterState f = filter_state(state, fp);
   if (fp.mode == 2) {
@@ -1400,9 +1440,9 @@ void launch_score_filter(const Points& pts, const float* RtSoA, const float* RtA
     if (ql < 64) ql = 64;
     const GramCoef gc = gram_coef_view(coef, sh.ld_local);
 #define SC_GRAM_LAUNCH(V)                                                                                                         \
-    hipLaunchKernelGGL(score_gram_kernel<V>, dim3((sh.ld_local + 32 * GX_WAVES - 1) / (32 * GX_WAVES), fp.splits), dim3(64 * GX_WAVES), \
-                       0, st, gc, sh.ld_local, static_cast<const uint4*>(tile), fp.windows, fp.splits, fp.n_waves, partial,         \
-                       f.queue, f.cap_sq, f.qcount, f.redo, ql)
+    hipExtLaunchKernelGGL(score_gram_kernel<V>, dim3((sh.ld_local + 32 * GX_WAVES - 1) / (32 * GX_WAVES), fp.splits), dim3(64 * GX_WAVES), \
+                          0, st, ev0, nullptr, 0, gc, sh.ld_local, static_cast<const uint4*>(tile), fp.windows, fp.splits, fp.n_waves, partial, \
+                          f.queue, f.cap_sq, f.qcount, f.redo, ql)
     switch (tn.filter_variant) {
       case 512: SC_GRAM_LAUNCH(512); break;
       case 256: SC_GRAM_LAUNCH(256); break;
@@ -1415,9 +1455,10 @@ void launch_score_filter(const Points& pts, const float* RtSoA, const float* RtA
       default: SC_GRAM_LAUNCH(0); break;
     }
 #undef SC_GRAM_LAUNCH
-    hipLaunchKernelGGL(score_exact_kernel, dim3(FX_NQ * 2), dim3(256), 0, st, pts.planes, pts.n, pts.ld,
-                       reinterpret_cast<const float4*>(RtAoS), sh.ld_local, dv.tau2, fp.windows, fp.splits, fp.n_waves, f.queue,
-                       f.cap_sq, f.qcount, f.redo, partial, 1u);
+    hipExtLaunchKernelGGL(score_exact_kernel, dim3(FX_NQ * 2), dim3(256), 0, st, nullptr, ev1, 0, pts.planes, pts.n, pts.ld,
+                          reinterpret_cast<const float4*>(RtAoS), sh.ld_local, dv.tau2, fp.windows, fp.splits, fp.n_waves,
+                          static_cast<const uint2*>(f.queue), f.cap_sq, static_cast<const uint32_t*>(f.qcount),
+                          static_cast<const uint32_t*>(f.redo), partial, 1u);
     return;
   }
   uint32_t ql = tn.filter_lds_queue ? tn.filter_lds_queue : (uint32_t)FX_QL;
@@ -1425,7 +1466,7 @@ void launch_score_filter(const Points& pts, const float* RtSoA, const float* RtA
   if (ql < 64) ql = 64;  // one step can add 64 entries
   const dim3 grid(sh.ld_local / (8 * FX_WAVES), fp.splits), block(64 * FX_WAVES);
 #define SC_FILTER_LAUNCH(V)                                                                                                  \
-  hipLaunchKernelGGL((score_filter_kernel<FX_WAVES, V>), grid, block, 0, st, RtSoA, sh.ld_local, dv.tau2,                    \
+  hipExtLaunchKernelGGL((score_filter_kernel<FX_WAVES, V>), grid, block, 0, st, ev0, nullptr, 0, RtSoA, sh.ld_local, dv.tau2, \
                      static_cast<const uint4*>(tile), f.info, fp.windows, fp.splits, fp.n_waves, partial, f.queue, f.cap_sq, \
                      f.qcount, f.redo, ql)
   switch (tn.filter_variant) {
@@ -1448,9 +1489,10 @@ void launch_score_filter(const Points& pts, const float* RtSoA, const float* RtA
     default: SC_FILTER_LAUNCH(0); break;
   }
 #undef SC_FILTER_LAUNCH
-  hipLaunchKernelGGL(score_exact_kernel, dim3(FX_NQ * 2), dim3(256), 0, st, pts.planes, pts.n, pts.ld,
-                     reinterpret_cast<const float4*>(RtAoS), sh.ld_local, dv.tau2, fp.windows, fp.splits, fp.n_waves, f.queue,
-                     f.cap_sq, f.qcount, f.redo, partial, 0u);
+  hipExtLaunchKernelGGL(score_exact_kernel, dim3(FX_NQ * 2), dim3(256), 0, st, nullptr, ev1, 0, pts.planes, pts.n, pts.ld,
+                        reinterpret_cast<const float4*>(RtAoS), sh.ld_local, dv.tau2, fp.windows, fp.splits, fp.n_waves,
+                        static_cast<const uint2*>(f.queue), f.cap_sq, static_cast<const uint32_t*>(f.qcount),
+                        static_cast<const uint32_t*>(f.redo), partial, 0u);
 }
 
 hipError_t filter_read_counters(const void* state, const FilterPlan& fp, hipStream_t st, uint64_t* undecided, uint64_t* recounts) {
@@ -1469,12 +1511,13 @@ hipError_t filter_read_counters(const void* state, const FilterPlan& fp, hipStre
 
 // Tuning::score_split: share of the hypotheses (in 256ths) scored on the matrix pipe (default 0; experiments)
 void launch_score(const Points& pts, const float* RtSoA, const float* RtAoS, const Shard& sh, const Derived& dv,
-                  int score_mode, uint32_t* partial, const Tuning& tn, hipStream_t st) {
+                  int score_mode, uint32_t* partial, const Tuning& tn, hipStream_t st, hipEvent_t ev0, hipEvent_t ev1) {
   if (sh.n_local == 0) return;
   if (score_is_scalar(score_mode, tn)) {  // 256 hypotheses per workgroup (4 waves x 64), one point chunk of 512 per wave
     static_assert(4 * SC_HYPS == 256, "ld_local is a multiple of 256");
-    hipLaunchKernelGGL(score_scalar_kernel, dim3(sh.ld_local / 256, score_chunks(pts.n, sh.ld_local, true)), dim3(256), 0, st,
-                       pts.planes, pts.n, pts.ld, reinterpret_cast<const float4*>(RtAoS), sh.ld_local, dv.tau2, partial);
+    hipExtLaunchKernelGGL(score_scalar_kernel, dim3(sh.ld_local / 256, score_chunks(pts.n, sh.ld_local, true)), dim3(256), 0, st,
+                          ev0, ev1, 0, pts.planes, pts.n, pts.ld, reinterpret_cast<const float4*>(RtAoS), sh.ld_local, dv.tau2,
+                          partial);
     return;
   }
   uint32_t chunks;
@@ -1486,14 +1529,14 @@ void launch_score(const Points& pts, const float* RtSoA, const float* RtAoS, con
   const uint32_t nv = groups - gm, nm = gm * (SCORE_THREADS / MF_HYPS_PER_BLOCK);
   const dim3 grid(nv + nm, chunks);
   if (score_mode == 1)
-    hipLaunchKernelGGL(score_kernel<1>, grid, dim3(SCORE_THREADS), 0, st, pts.planes, pts.n, pts.ld, RtSoA, sh.ld_local,
-                       dv.inv_tau2, chunk_pts, partial, nv, nm);
+    hipExtLaunchKernelGGL(score_kernel<1>, grid, dim3(SCORE_THREADS), 0, st, ev0, ev1, 0, pts.planes, pts.n, pts.ld, RtSoA,
+                          sh.ld_local, dv.inv_tau2, chunk_pts, partial, nv, nm);
   else if (score_mode == 2)
-    hipLaunchKernelGGL(score_kernel<2>, grid, dim3(SCORE_THREADS), 0, st, pts.planes, pts.n, pts.ld, RtSoA, sh.ld_local,
-                       dv.inv_tau, chunk_pts, partial, nv, nm);
+    hipExtLaunchKernelGGL(score_kernel<2>, grid, dim3(SCORE_THREADS), 0, st, ev0, ev1, 0, pts.planes, pts.n, pts.ld, RtSoA,
+                          sh.ld_local, dv.inv_tau, chunk_pts, partial, nv, nm);
   else
-    hipLaunchKernelGGL(score_kernel<0>, grid, dim3(SCORE_THREADS), 0, st, pts.planes, pts.n, pts.ld, RtSoA, sh.ld_local,
-                       dv.tau2, chunk_pts, partial, nv, nm);
+    hipExtLaunchKernelGGL(score_kernel<0>, grid, dim3(SCORE_THREADS), 0, st, ev0, ev1, 0, pts.planes, pts.n, pts.ld, RtSoA,
+                          sh.ld_local, dv.tau2, chunk_pts, partial, nv, nm);
 }
 
 size_t argmax_scratch_bytes(uint32_t ld_local) { return (size_t)(ld_local / 256 + 1) * 2 * sizeof(uint64_t); }
