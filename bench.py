@@ -10,8 +10,8 @@ Workload at N = 1: BASELINE.json configs[2] ("3DMatch indoor pair, N~5k correspo
 the configuration BASELINE.json's `metric` is quoted on ("N=5k corrs") — as a synthetic scene of that shape (the
 reference ships no data).
 
-N > 1 (one process per GPU, RCCL through torch.distributed "nccl"), `--shard ab` (the default but for two
-ranks on a small graph, see --shard): stage A by row
+N > 1 (one process per GPU, RCCL through torch.distributed "nccl"), `--shard ab` (the default for strong scaling
+and for graphs of 8192 correspondences and more, see --shard): stage A by row
 blocks, stage B by contiguous row ranges, stage C by blocks of the merged list; four collectives per step — all-gather
 of the bit rows, 1 KiB all-reduce of the pruning-sample histogram, all-gather of the candidate blobs, all-gather of
 the 16-byte winner key pairs.  `--shard replicated` is round 1's form (A and B on every rank, one or two collectives).
@@ -76,21 +76,22 @@ N_SIMD = 256 * 4
 def issue_model(n: int, n_local: int, us: float, info: dict) -> dict:
     """The C2 filter kernel against its OWN issue limits, so that `roofline.frac` — an fp32-EQUIVALENT rate —
     is not read as a utilisation.  A step = the MFMAs that produce one accumulator tile plus the vector instructions that
-    consume it:  linear filter: 1 MFMA (8 hypotheses x 32 correspondences, 256 tests), ~26 vector instructions;  Gram
-    filter: 3 chained MFMAs (32 hypotheses x 32 correspondences, 1024 tests), ~30 vector instructions.
+    consume it:  linear filter: 1 MFMA (8 hypotheses x 32 correspondences, 256 tests), 26 vector instructions on the path
+    without an undecided test;  Gram filter: 3 chained MFMAs (32 hypotheses x 32 correspondences, 1024 tests), 29.
     `cycles_per_step`: measured — duration of the whole C2 stage x the NOMINAL clock / steps per SIMD (it includes the exact
     pass, set-up and tail; under this load the chip holds 1.9 - 2.1 GHz, so real cycles are ~15 % fewer).
-    `bound_matrix_cycles`: 32 cycles per MFMA.  `bound_vector_cycles`: what tools/ubench/mfma_lds.hip measures for vector
-    instructions issued beside MFMAs on one SIMD: 8 cycles of issue per MFMA + 3.3 cycles per vector instruction (2.3
-    without MFMAs in flight; the 2-cycle figure of the guide is never reached here)."""
+    `bound_matrix_cycles`: 32 cycles per MFMA.  `bound_vector_cycles`: the SIMD's issue port — 8 cycles per MFMA + 4 per vector
+    instruction (MI355X_MICROARCH.md, 'costs add'); profiles/r03_pmc_gram_variants_C4.txt: the Gram kernel really issues 44 vector
+    instructions per step (queueing of undecided tests, staging, per-wave set-up on top of the 29) and its duration moves by
+    4.6 cycles per instruction added or removed — it is bound by that port, not by the matrix pipe."""
     gram = info.get("c2_kernel") == 2
     windows = (n + 1023) // 1024
-    hyp_per_wave, mfma_per_step, valu = (32, 3, 30.0) if gram else (8, 1, 26.0)
+    hyp_per_wave, mfma_per_step, valu = (32, 3, 29.0) if gram else (8, 1, 26.0)
     steps = (n_local / float(hyp_per_wave)) * windows * 32          # accumulator tiles of the launch
     per_simd = steps / N_SIMD
     cyc = us * 1e-6 * GPU_CLOCK_HZ / max(per_simd, 1.0)
     matrix = 32.0 * mfma_per_step
-    vector = 8.0 * mfma_per_step + 3.3 * valu
+    vector = 8.0 * mfma_per_step + 4.0 * valu
     bound = max(matrix, vector)
     return {"filter": "gram" if gram else "linear", "tests_per_step": 32 * hyp_per_wave, "cycles_per_step": round(cyc, 1),
             "mfma_per_step": mfma_per_step, "valu_per_step": valu, "bound_matrix_cycles": matrix,
@@ -129,9 +130,11 @@ def main() -> int:
     ap.add_argument("--config", default="C2", help="synthetic scene template (default: the headline config C2)")
     ap.add_argument("--scaling", choices=("weak", "strong"), default="weak")
     ap.add_argument("--shard", choices=("auto", "ab", "replicated"), default="auto",
-                    help="N > 1: shard stages A and B too (ab) or replicate them (round 1's form); auto = ab, except for two "
-                         "ranks on a small graph (n < 8192) under weak scaling, where both cost the same per rank in the "
-                         "emulation (0.337 vs 0.333 ms on C2) and the replicated form needs one collective instead of four")
+                    help="N > 1: shard stages A and B too (ab) or replicate them (round 1's form); auto = ab, except under weak "
+                         "scaling on a small graph (n < 8192): there one rank's emulated step is 0.30 / 0.31 / 0.38 ms replicated "
+                         "against 0.36 / 0.32 / 0.36 ms sharded at 2 / 4 / 8 ranks (profiles/r03_emulated_world_scaling.txt, "
+                         "copies standing in for the collectives) and the replicated form needs one or two collectives per "
+                         "step instead of four, whose latency the emulation does not contain")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--headline-only", action="store_true",
                     help="only the timed loop and the per-stage passes (no cold call, host-I/O, varying-N, no-dense-S or CPU "
@@ -200,7 +203,7 @@ def main() -> int:
     torch.cuda.synchronize()
 
     sharded_ab = world > 1 and (args.shard == "ab" or (args.shard == "auto" and not (
-        world == 2 and cfg.n < 8192 and args.scaling == "weak")))
+        cfg.n < 8192 and args.scaling == "weak")))
     split = (not sharded_ab) and (args.split_sample == "on" or (args.split_sample == "auto" and world >= 4))
     if sharded_ab:
         ss = pkg.shard.ShardedStep(pkg, reg, cfg.n, mk(pkg.SC_FLAG_TIMING_HOT), rank, world, dev)

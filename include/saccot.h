@@ -181,7 +181,7 @@ typedef struct sc_debug {
   uint32_t compact_fused;     /* 1: compaction in one launch (look-back over the tiles) instead of count + write    */
   uint32_t rows_unfused;      /* 1: row statistics and the scans of the row counts as separate launches             */
   uint32_t score_scalar;      /* 1: stage C2 counts inliers with the lane = correspondence kernel (measured slower)  */
-  uint32_t score_filter;      /* stage C2, inlier count: 0 = matrix-pipe filter + exact fix-up for large calls, plain fp32 kernel for small ones; 1 = always plain; 2 = always filtered */
+  uint32_t score_filter;      /* stage C2, inlier count: 0 = by size and scale (plain fp32 kernel for small calls; for large ones a matrix-pipe filter + exact fix-up: the Gram filter where tau is not small against the clouds, else the linear one); 1 = always plain; 2 = always the linear filter; 3 = always the Gram filter */
   uint32_t filter_splits;     /* grid.y of the filter kernel (0 = by size)                                            */
   uint32_t filter_queue_cap;  /* entries of the filter's queue of undecided tests (0 = by size): a small one forces the recount path */
   uint32_t filter_lds_queue;  /* entries of a wave's own queue, 64 .. 256 (0 = 256)                                   */
@@ -196,8 +196,8 @@ int         sc_set_debug(sc_ctx* ctx, const sc_debug* dbg);
  * matrix-pipe filter, what it handed to the exact pass.  Synchronises the context's stream. */
 typedef struct sc_debug_info {
   uint32_t size;              /* = sizeof(sc_debug_info), set by the caller                                          */
-  uint32_t c2_kernel;         /* 0: plain fp32 kernel (also the truncated scores); 1: matrix-pipe filter + exact pass  */
-  uint64_t filter_undecided;  /* queue entries (one per correspondence and wave half with >= 1 undecided test)         */
+  uint32_t c2_kernel;         /* 0: plain fp32 kernel (also the truncated scores); 1: linear filter + exact pass; 2: Gram filter + exact pass */
+  uint64_t filter_undecided;  /* queue entries (linear: one per correspondence and wave half with >= 1 undecided test; Gram: one per correspondence, lane half and group of four hypotheses) */
   uint64_t filter_recounts;   /* (8-hypothesis wave, grid split) pairs recounted wholesale by the exact pass           */
   uint32_t filter_splits;     /* grid.y of the filter launch                                                           */
   uint32_t reserved;

@@ -176,6 +176,10 @@ struct StrongList {
   uint32_t* list;
   uint32_t* fill;
   uint32_t cap;
+  // 0: region r takes the pruning kernel's blocks with block % 256 == r.  > 0: region r takes `region_blocks` CONSECUTIVE
+  // blocks (256 edges each), so a region is a contiguous range of edge ids — a rank of the sharded stage B then walks only the
+  // regions its own edge range touches (the pruning kernel also zeroes every tcnt entry in this form)
+  uint32_t region_blocks;
 };
 uint32_t strong_list_cap(uint64_t E);
 size_t strong_list_bytes(uint64_t E);

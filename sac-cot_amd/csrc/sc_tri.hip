@@ -443,10 +443,23 @@ __global__ __launch_bounds__(256) void tri_count_events_kernel(const uint64_t* _
   }
   __syncthreads();
   const uint64_t S = l_pre[ST_SHARDS];  // strong edges (only they can carry a triangle of the pruned graph)
+  // the part of the flat list this rank walks: everything, or — regions being contiguous edge ranges — the regions its own
+  // edge range touches (the others' tcnt entries were zeroed by the pruning kernel)
+  uint64_t x0 = 0, x1 = S;
+  if (own && sl.region_blocks) {
+    const uint64_t per_region = (uint64_t)sl.region_blocks * 256;
+    if (own[1] > own[0]) {
+      const uint64_t r_lo = min(own[0] / per_region, (uint64_t)(ST_SHARDS - 1));
+      const uint64_t r_hi = min((own[1] - 1) / per_region, (uint64_t)(ST_SHARDS - 1));
+      x0 = l_pre[r_lo]; x1 = l_pre[r_hi + 1];
+    } else {
+      x1 = 0;
+    }
+  }
   const uint64_t groups = (uint64_t)gridDim.x * (256 / TG);
   const uint64_t g0 = (uint64_t)blockIdx.x * (256 / TG) + (threadIdx.x / TG);
   const uint32_t shard = (blockIdx.x * 4 + wave) & (EV_SHARDS - 1);
-  const uint64_t trips = (S + groups - 1) / groups;  // the same for every lane of the wave
+  const uint64_t trips = (x1 - x0 + groups - 1) / groups;  // the same for every lane of the wave
   const int wbase = wave * EVW;
   uint32_t scnt = 0;  // records staged by this wave (wave-uniform)
   auto flush = [&]() {  // wave-uniform
@@ -467,8 +480,8 @@ __global__ __launch_bounds__(256) void tri_count_events_kernel(const uint64_t* _
     scnt = 0;
   };
   for (uint64_t trip = 0; trip < trips; trip++) {
-    const uint64_t x = g0 + trip * groups;  // position in the flat strong list
-    const bool on = x < S;                  // group-uniform
+    const uint64_t x = x0 + g0 + trip * groups;  // position in the flat strong list
+    const bool on = x < x1;                      // group-uniform
     uint32_t e = 0, rowi = 0, rowj = 0, fa = 0, fb = 0, c = 0;
     int w0 = 0, jbit = 0, rounds = 0;
     if (on) {
@@ -906,7 +919,12 @@ __global__ __launch_bounds__(256) void prune_bits_kernel(const uint32_t* __restr
   __syncthreads();
   const float smin = s_smin;
   if (blockIdx.x == 0 && threadIdx.x == 0) { *smin_out = smin; *klb_out = s_klb; }
-  const uint64_t e = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  // region = blockIdx % ST_SHARDS in both forms (blocks that run side by side add to different counters: with consecutive
+  // blocks on one counter this kernel took 61 us instead of 33 at C3); with contiguous regions the block's 256 EDGES are what
+  // moves: block b takes chunk (b % ST_SHARDS) * region_blocks + b / ST_SHARDS
+  const uint32_t region = blockIdx.x & (ST_SHARDS - 1);
+  const uint64_t chunk = sl.region_blocks ? (uint64_t)region * sl.region_blocks + blockIdx.x / ST_SHARDS : (uint64_t)blockIdx.x;
+  const uint64_t e = (sl.region_blocks && blockIdx.x / ST_SHARDS >= sl.region_blocks) ? E : chunk * 256 + threadIdx.x;
   bool strong = e < E && es[e] >= smin;
   if (strong) {  // the strong bit matrix is whole on every rank: membership of ANY vertex pair is looked up in it
     const uint32_t i = ei[e], j = ej[e];
@@ -916,22 +934,23 @@ __global__ __launch_bounds__(256) void prune_bits_kernel(const uint32_t* __restr
   if (own) strong = strong && e >= own[0] && e < own[1];
   if (sl.list) {
     // the strong edges, compacted (any order: everything downstream is indexed by the edge id): one atomic per block
-    // on one of ST_SHARDS counters; region r receives the blocks with blockIdx % ST_SHARDS == r, so sl.cap =
-    // ceil(blocks / ST_SHARDS) * 256 entries can never overflow.  Weak edges carry no triangle: count 0.
-    if (e < E && !strong) tcnt[e] = 0u;
+    // on one of ST_SHARDS counters; region r receives the blocks with blockIdx % ST_SHARDS == r (or, StrongList::region_blocks,
+    // a run of consecutive blocks: ceil(blocks / ST_SHARDS) of them), so sl.cap = ceil(blocks / ST_SHARDS) * 256 entries can
+    // never overflow.  Weak edges carry no triangle: count 0.
+    if (e < E && (!strong || sl.region_blocks)) tcnt[e] = 0u;
     const uint64_t bal = __ballot(strong);
     const int wave = threadIdx.x >> 6;
     if ((threadIdx.x & 63) == 0) s_wcnt[wave] = (uint32_t)__popcll(bal);
     __syncthreads();
     if (threadIdx.x == 0) {  // ONE atomic per block (returning atomics on a shared address cost ~170 ns each here)
       const uint32_t tot = s_wcnt[0] + s_wcnt[1] + s_wcnt[2] + s_wcnt[3];
-      s_base = tot ? atomicAdd(&sl.fill[blockIdx.x & (ST_SHARDS - 1)], tot) : 0u;
+      s_base = tot ? atomicAdd(&sl.fill[region], tot) : 0u;
     }
     __syncthreads();
     if (strong) {
       uint32_t pos = s_base + __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
       for (int w = 0; w < wave; w++) pos += s_wcnt[w];
-      sl.list[(uint64_t)(blockIdx.x & (ST_SHARDS - 1)) * sl.cap + pos] = (uint32_t)e;
+      sl.list[(uint64_t)region * sl.cap + pos] = (uint32_t)e;
     }
   }
 }
@@ -1025,7 +1044,8 @@ void launch_prune_bits(const Graph& g, const uint32_t* hist, bool hist_is_copies
                        const StrongList& sl, uint32_t* tcnt, const uint64_t* own, hipStream_t st) {
   uint32_t klo, shift;
   prune_window(key_floor, &klo, &shift);
-  hipLaunchKernelGGL(prune_bits_kernel, dim3((unsigned)((E + 255) / 256)), dim3(256), 0, st, hist,
+  const uint64_t blocks = sl.region_blocks ? (uint64_t)sl.region_blocks * ST_SHARDS : (E + 255) / 256;
+  hipLaunchKernelGGL(prune_bits_kernel, dim3((unsigned)blocks), dim3(256), 0, st, hist,
                      hist_is_copies ? PR_HCOPIES : 1, want, klo, shift, ei,
                      ej, es, E, g.W, reinterpret_cast<unsigned long long*>(mbits), smin, klb, sl, tcnt, own);
 }
@@ -1079,8 +1099,17 @@ __global__ __launch_bounds__(256) void strong_rowcost_kernel(const uint64_t* __r
 
 // prefix of the row costs AND this rank's range in one single-block launch (n values: 80 KB at N = 20 000): rows [lo, hi)
 // with lo = the first row whose cost prefix reaches rank / world of the total (the rule of shard_split_kernel).
-// Wave w of 16 takes the w-th sixteenth of the rows, 64 rows per step (coalesced loads, wave scans); the wave whose
-// segment holds a boundary walks it a second time.
+// Wave w of 16 takes the w-th sixteenth of the rows, 256 rows per step (a lane loads four consecutive rows with one 16-byte
+// load: a quarter of the dependent trips the 4-byte form made — at N = 20 000 this launch took 20 us, nearly all of it load
+// latency); the wave whose segment holds a boundary walks it a second time.  rowcost holds roundup(n, 4) + 1024 entries.
+__device__ __forceinline__ uint4 cost4(const uint32_t* __restrict__ rowcost, int r, int r1) {  // rows r .. r + 3, zero from r1 on
+  uint4 v = *reinterpret_cast<const uint4*>(rowcost + r);
+  if (r + 0 >= r1) v.x = 0u;
+  if (r + 1 >= r1) v.y = 0u;
+  if (r + 2 >= r1) v.z = 0u;
+  if (r + 3 >= r1) v.w = 0u;
+  return v;
+}
 __global__ __launch_bounds__(1024) void cost_split_kernel(const uint32_t* __restrict__ rowcost,
                                                           const uint64_t* __restrict__ edge_off, int n, uint32_t rank,
                                                           uint32_t world, uint32_t* __restrict__ own_row,
@@ -1088,9 +1117,13 @@ __global__ __launch_bounds__(1024) void cost_split_kernel(const uint32_t* __rest
   __shared__ uint64_t s_tot[16];
   __shared__ uint32_t s_row[2];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int seg = ((n + 15) / 16 + 63) / 64 * 64, r0 = wave * seg, r1 = min(n, r0 + seg);
+  const int seg = ((n + 15) / 16 + 255) / 256 * 256, r0 = min(n, wave * seg), r1 = min(n, r0 + seg);
   uint64_t mine = 0;
-  for (int r = r0 + lane; r < r1; r += 64) mine += rowcost[r];
+#pragma unroll 4
+  for (int rb = r0; rb < r1; rb += 256) {
+    const uint4 v = cost4(rowcost, rb + 4 * lane, r1);
+    mine += (uint64_t)v.x + v.y + v.z + v.w;
+  }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) mine += __shfl_xor(mine, o);
   if (lane == 0) s_tot[wave] = mine;
@@ -1107,15 +1140,24 @@ __global__ __launch_bounds__(1024) void cost_split_kernel(const uint32_t* __rest
     if (pre + mine < target && wave != 15) continue;       // (wave-uniform) beyond this segment
     if (pre >= target) { if (lane == 0) atomicMin(&s_row[which], (uint32_t)min(r0, n)); continue; }
     uint64_t run = pre;
-    for (int rb = r0; rb < r1; rb += 64) {
-      const int r = rb + lane;
-      const uint64_t v = r < r1 ? rowcost[r] : 0ull;
-      uint64_t inc = v;
+    for (int rb = r0; rb < r1; rb += 256) {
+      const int r = rb + 4 * lane;
+      const uint4 v = cost4(rowcost, r, r1);
+      const uint64_t lane_sum = (uint64_t)v.x + v.y + v.z + v.w;
+      uint64_t inc = lane_sum;
 #pragma unroll
       for (int o = 1; o < 64; o <<= 1) { const uint64_t t = __shfl_up(inc, o); if (lane >= o) inc += t; }
-      const uint64_t before = run + inc - v;                 // sum of the costs before row r
-      const uint64_t hit = __ballot(r < r1 && before >= target);
-      if (hit) { if (lane == 0) atomicMin(&s_row[which], (uint32_t)(rb + __builtin_ctzll(hit))); break; }
+      const uint64_t b0 = run + inc - lane_sum;              // sum of the costs before row r
+      const uint64_t b1 = b0 + v.x, b2 = b1 + v.y, b3 = b2 + v.z;
+      // the first of this lane's four rows whose "before" reaches the target (4: none)
+      const int k = (r < r1 && b0 >= target) ? 0 : ((r + 1 < r1 && b1 >= target) ? 1 : ((r + 2 < r1 && b2 >= target) ? 2 : ((r + 3 < r1 && b3 >= target) ? 3 : 4)));
+      const uint64_t hit = __ballot(k < 4);
+      if (hit) {
+        const int L = __builtin_ctzll(hit);  // "before" grows with the row: the lowest lane that hit holds the first such row
+        const int kk = __shfl(k, L);
+        if (lane == 0) atomicMin(&s_row[which], (uint32_t)(rb + 4 * L + kk));
+        break;
+      }
       run += __shfl(inc, 63);
     }
     // (no row of the segment reached it: the boundary is the first row of the next segment, or n — its wave reports r0)

@@ -4,7 +4,7 @@
 set -u
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 CFG=${1:-C4}; shift || true
-OUT=$R/gpurun_out/pmcg
+OUT=$R/gpurun_out/pmcg_$CFG
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 for V in "$@"; do
