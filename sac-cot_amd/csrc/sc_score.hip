@@ -1434,6 +1434,11 @@ void launch_score_filter(const Points& pts, const float* RtSoA, const float* RtA
                          hipStream_t st, hipEvent_t ev0, hipEvent_t ev1) {
   if (sh.n_local == 0) return;
   const FilterState f = filter_state(state, fp);
+  // exact pass: one thread per queue entry, grid-stride — a chain of dependent loads per entry, so big calls want more
+  // threads in flight: workgroups per sub-queue by the number of tests (C4, 2.5e9 tests, 0.9 M entries: 36 -> 28 us at 8;
+  // C2's 0.15 M entries are served by 2, more only adds launch tail)
+  const uint64_t tests = (uint64_t)pts.n * sh.ld_local;
+  const uint32_t exact_mult = tests >= (1ull << 31) ? 8u : (tests >= (1ull << 29) ? 4u : 2u);
   if (fp.mode == 2) {
     uint32_t ql = tn.filter_lds_queue ? tn.filter_lds_queue : (uint32_t)GX_QL;
     if (ql > (uint32_t)GX_QL) ql = GX_QL;
@@ -1455,7 +1460,7 @@ void launch_score_filter(const Points& pts, const float* RtSoA, const float* RtA
       default: SC_GRAM_LAUNCH(0); break;
     }
 #undef SC_GRAM_LAUNCH
-    hipExtLaunchKernelGGL(score_exact_kernel, dim3(FX_NQ * 2), dim3(256), 0, st, nullptr, ev1, 0, pts.planes, pts.n, pts.ld,
+    hipExtLaunchKernelGGL(score_exact_kernel, dim3(FX_NQ * exact_mult), dim3(256), 0, st, nullptr, ev1, 0, pts.planes, pts.n, pts.ld,
                           reinterpret_cast<const float4*>(RtAoS), sh.ld_local, dv.tau2, fp.windows, fp.splits, fp.n_waves,
                           static_cast<const uint2*>(f.queue), f.cap_sq, static_cast<const uint32_t*>(f.qcount),
                           static_cast<const uint32_t*>(f.redo), partial, 1u);
@@ -1489,7 +1494,7 @@ void launch_score_filter(const Points& pts, const float* RtSoA, const float* RtA
     default: SC_FILTER_LAUNCH(0); break;
   }
 #undef SC_FILTER_LAUNCH
-  hipExtLaunchKernelGGL(score_exact_kernel, dim3(FX_NQ * 2), dim3(256), 0, st, nullptr, ev1, 0, pts.planes, pts.n, pts.ld,
+  hipExtLaunchKernelGGL(score_exact_kernel, dim3(FX_NQ * exact_mult), dim3(256), 0, st, nullptr, ev1, 0, pts.planes, pts.n, pts.ld,
                         reinterpret_cast<const float4*>(RtAoS), sh.ld_local, dv.tau2, fp.windows, fp.splits, fp.n_waves,
                         static_cast<const uint2*>(f.queue), f.cap_sq, static_cast<const uint32_t*>(f.qcount),
                         static_cast<const uint32_t*>(f.redo), partial, 0u);
