@@ -1461,3 +1461,34 @@ def test_sharded_A_and_B_balance_on_an_unshuffled_scene(pkg, O, name, world):
     enum = hdr[:, 0].astype(np.float64)
     assert int(enum.sum()) == st["tri_total"]
     assert enum.max() / enum.mean() < 1.3, enum
+
+
+# ---------------------------------------------------------------------------------------------------------
+# timing flags: diagnostics only — they must not change a result, and what they report must be sane
+# ---------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("score_filter", [1, 2, 3])
+def test_timing_flags_change_nothing_and_report_sane_times(pkg, reg, score_filter):
+    """SC_FLAG_TIMING (every stage bracketed by event records, speculative launches off), SC_FLAG_TIMING_HOT (the score
+    stage from the dispatch packets of its own kernels: what bench.py's `roofline` is made of) and SC_FLAG_TIMING_ONE (one
+    bracket on the hot path) — for each of the three stage-C2 kernels: same winner, mask and (R, t) as the untimed call;
+    the hot figure agrees with the fully bracketed one; every single bracket is positive and below the call's wall time."""
+    cfg, scene = pkg.synth.make_config_scene("C1")
+    reg.set_debug(score_filter=score_filter)
+    base = reg.register(scene.src, scene.tgt, **cfg.params())
+    assert reg.debug_last()["c2_kernel"] == score_filter - 1
+    full = reg.register(scene.src, scene.tgt, flags=pkg.SC_FLAG_TIMING, **cfg.params())
+    hot = reg.register(scene.src, scene.tgt, flags=pkg.SC_FLAG_TIMING_HOT, **cfg.params())
+    for got in (full, hot):
+        assert got["stats"]["best_rank"] == base["stats"]["best_rank"] and got["stats"]["best_count"] == base["stats"]["best_count"]
+        assert np.array_equal(got["mask"], base["mask"]) and nan_equal_bits(got["R"], base["R"]) and nan_equal_bits(got["t"], base["t"])
+    us_full, us_hot = full["stats"]["us_score"], hot["stats"]["us_score"]
+    assert 1.0 < us_hot < 5000.0 and 1.0 < us_full < 5000.0
+    assert 0.4 < us_hot / us_full < 2.5, (us_hot, us_full)   # two clocks around the same kernels
+    assert hot["stats"]["us_compat"] == 0.0                  # only the hot bracket is taken
+    names = ["us_stage", "us_compat", "us_triangles", "us_kabsch", "us_score", "us_argmax", "us_mask"]
+    for k, name in enumerate(names):
+        one = reg.register(scene.src, scene.tgt, flags=pkg.SC_FLAG_TIMING_ONE | pkg.SC_TIMING_STAGE(k), **cfg.params())
+        assert one["stats"]["best_rank"] == base["stats"]["best_rank"] and np.array_equal(one["mask"], base["mask"])
+        assert 0.0 < one["stats"][name] < 5000.0, (name, one["stats"][name])
+        assert all(one["stats"][o] == 0.0 for o in names if o != name)
+    reg.set_debug()
