@@ -131,8 +131,8 @@ def main() -> int:
     ap.add_argument("--scaling", choices=("weak", "strong"), default="weak")
     ap.add_argument("--shard", choices=("auto", "ab", "replicated"), default="auto",
                     help="N > 1: shard stages A and B too (ab) or replicate them (round 1's form); auto = ab, except under weak "
-                         "scaling on a small graph (n < 8192): there one rank's emulated step is 0.30 / 0.31 / 0.38 ms replicated "
-                         "against 0.36 / 0.32 / 0.36 ms sharded at 2 / 4 / 8 ranks (profiles/r03_emulated_world_scaling.txt, "
+                         "scaling on a small graph (n < 8192): there one rank's emulated step is 0.31 / 0.32 / 0.38 ms replicated "
+                         "against 0.32 / 0.31 / 0.34 ms sharded at 2 / 4 / 8 ranks (profiles/r03_emulated_world_scaling.txt, "
                          "copies standing in for the collectives) and the replicated form needs one or two collectives per "
                          "step instead of four, whose latency the emulation does not contain")
     ap.add_argument("--no-cpu-baseline", action="store_true")
