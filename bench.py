@@ -219,6 +219,10 @@ def main() -> int:
         d_all = torch.zeros(2 * world, dtype=torch.int64, device=dev)  # every rank's key pair (one all-gather)
 
         def step(prm):
+            if world == 1:
+                # the drop-in entry with everything resident in HBM: sc_register_device (a repeated shape is enqueued without a
+                # host wait in the middle of the call — include/saccot.h; `fast_path` below says how the timed calls ran)
+                return reg.register_device(d_src.data_ptr(), d_tgt.data_ptr(), cfg.n, prm, d_Rt.data_ptr(), d_mask.data_ptr())
             if split:
                 reg.hypothesize_begin_device(d_src.data_ptr(), d_tgt.data_ptr(), cfg.n, prm, d_hist.data_ptr())
                 pkg.shard.allreduce_hist(d_hist)
@@ -242,13 +246,17 @@ def main() -> int:
     for _ in range(args.warmup):
         step(p_hot)
     hot_score = 0.0
+    step_s = []
     fence()
     t0 = time.perf_counter()
     for _ in range(args.steps):
+        ts0 = time.perf_counter()
         rc, st = step(p_hot)
+        step_s.append(time.perf_counter() - ts0)   # (every step ends with the winner on the host: its own wall time is meaningful)
         hot_score += st["us_score"]
     fence()
     dt = time.perf_counter() - t0
+    fast_path_timed = reg.debug_last().get("fast_path") if world == 1 else None
     # ---- per-stage times of THE SAME code path: one bracket per pass (SC_FLAG_TIMING_ONE: two event records per call,
     # speculative launches on), a few passes per stage; then one fully bracketed pass for the key kernel alone
     n_diag = max(3, min(8, args.steps))
@@ -340,7 +348,8 @@ def main() -> int:
         out = {
             "metric": "triangle-hypotheses scored/sec (end-to-end: compat graph + ranked triangles + SVD + scoring + mask)",
             "value": value, "unit": "hypotheses/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": args.scaling,
+            "ms_per_step": ms_per_step, "ms_per_step_median": float(np.median(step_s)) * 1e3,
+            "higher_is_better": True, "scaling": args.scaling,
             "vs_baseline": None, "dtype": "f32", "data": "synthetic" + (" (REHEARSAL: all ranks on one GPU over gloo)" if rehearsal else ""),
             "config": {"workload": f"{cfg.name}: N={n} synthetic correspondences ({cfg.rho:.0%} inliers, L={cfg.L}, "
                                    f"tau={cfg.tau}), T_total={T_total} ranked triangles scored per step "
@@ -353,6 +362,11 @@ def main() -> int:
             "stage_us_note": "one HIP-event bracket per pass on the hot path (SC_FLAG_TIMING_ONE); `triangles` includes its "
                              "read-backs" + (" and the collectives between the phases" if sharded_ab else ""),
             "winner": {"rank": st["best_rank"], "inliers": st["best_count"], "status": rc},
+            "host_gap_us": round(ms_per_step * 1e3 - sum(avg.values()), 1),
+            "host_gap_note": "step minus the sum of the stage brackets: launch of the first kernel into an idle queue, the "
+                             "winner's way back to the host, Python between the calls",
+            "fast_path": fast_path_timed,
+            "bytes_moved_algorithmic": st.get("bytes_moved"),
             "roofline": dominant, "roofline_other": other,
         }
         if sharded_ab:
@@ -436,6 +450,37 @@ def main() -> int:
                             "I/O of sc_register; N > 1 over RCCL is unmeasured on hardware"}
             except Exception as ex:  # RCCL not loadable on this box: report, do not fail the headline
                 out["native_multi"] = {"error": str(ex)}
+            # ---- a STREAM of frames on ONE stream: two contexts alternate, frame k + 1 is enqueued (host-free) before frame k is
+            # waited for, so the GPU runs the frames back to back and never waits for the host.  Strictly serial on the GPU —
+            # unlike `calls_in_flight` below nothing overlaps on the device.  NOT `value` (which ends every step with its
+            # winner on the host); what the kernels alone allow.
+            try:
+                reg.set_stream(torch.cuda.current_stream().cuda_stream)
+                regB = pkg.Registrar(local_rank)
+                regB.set_stream(torch.cuda.current_stream().cuda_stream)
+                pair = [reg, regB]
+                outs = [(d_Rt, d_mask), (torch.zeros(12, dtype=torch.float32, device=dev), torch.zeros(n, dtype=torch.uint8, device=dev))]
+                p_pl = pkg.make_params(flags=base_flags, **kw)
+                for g_, o_ in zip(pair, outs):
+                    for _ in range(3):
+                        g_.register_device(d_src.data_ptr(), d_tgt.data_ptr(), n, p_pl, o_[0].data_ptr(), o_[1].data_ptr())
+                KP = 40
+                torch.cuda.synchronize(); tp0 = time.perf_counter()
+                pair[0].register_device_async(d_src.data_ptr(), d_tgt.data_ptr(), n, p_pl, outs[0][0].data_ptr(), outs[0][1].data_ptr())
+                okp = True
+                for k in range(1, KP):
+                    pair[k & 1].register_device_async(d_src.data_ptr(), d_tgt.data_ptr(), n, p_pl, outs[k & 1][0].data_ptr(), outs[k & 1][1].data_ptr())
+                    _, sp_ = pair[(k - 1) & 1].wait()
+                    okp = okp and sp_["best_rank"] == st["best_rank"] and sp_["best_count"] == st["best_count"]
+                _, sp_ = pair[(KP - 1) & 1].wait()
+                torch.cuda.synchronize(); tpl = time.perf_counter() - tp0
+                out["frames_back_to_back"] = {"ms_per_call": tpl / KP * 1e3, "hypotheses_per_s": T_total * KP / tpl, "same_winner": bool(okp),
+                                              "fast_path": [g_.debug_last()["fast_path"] for g_ in pair],
+                                              "note": "two contexts on ONE stream, call k + 1 enqueued before call k is waited for "
+                                                      "(sc_register_device_async / sc_wait): serial on the GPU, the host off the critical path"}
+                regB.close()
+            except Exception as ex:
+                out["frames_back_to_back"] = {"error": str(ex)}
             reg.set_stream(None)
             # ---- throughput with TWO independent registrations in flight (two contexts, two streams, two host threads):
             # the path is a chain of ~19 dependent launches, many of them small, so a second call fills the gaps.  NOT the

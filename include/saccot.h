@@ -34,7 +34,8 @@ extern "C" {
 #endif
 
 #define SC_VERSION_MAJOR 0
-#define SC_VERSION_MINOR 4   /* 0.4: sc_debug_last / sc_debug_info, sc_debug.filter_blind; 0.3: sc_set_debug (no environment variables), SC_FLAG_NO_DENSE_S, sc_shard_* (stages A and B sharded); 0.2: SC_FLAG_TIMING_HOT,
+#define SC_VERSION_MINOR 5   /* 0.5: sc_register_device_async / sc_wait (host-free enqueue), sc_stats.bytes_moved, the debug hooks moved to
+                                saccot_debug.h; 0.4: sc_debug_last / sc_debug_info, sc_debug.filter_blind; 0.3: sc_set_debug (no environment variables), SC_FLAG_NO_DENSE_S, sc_shard_* (stages A and B sharded); 0.2: SC_FLAG_TIMING_HOT,
                                 SC_STREAM_DEFAULT, sc_hypothesize_begin/end_device, sc_finalize_gathered_device */
 
 /* status codes */
@@ -136,6 +137,10 @@ typedef struct sc_stats {
   float    us_mask;         /* stage C3: winner re-solve + mask                                         */
   float    us_total;        /* sum of the above                                                         */
   uint64_t workspace_bytes; /* device bytes currently held by the context                               */
+  uint64_t bytes_moved;     /* ALGORITHMIC bytes this call's kernels read and wrote in device memory, from the counts of   */
+                            /* the call (SURVEY §5 / §8d formulas: stage A 4n^2 + n^2/8 + 24n (n^2/8 + 24n without S),   */
+                            /* stage B n^2/8 + 20 E + 12 M + 16 T_eff, stage C 52 T_scored + 24 n + n): a yardstick for    */
+                            /* achieved-bandwidth figures, not a hardware counter                                          */
 } sc_stats;
 
 /* ---- library ---------------------------------------------------------------------------------- */
@@ -158,51 +163,7 @@ int         sc_set_stream(sc_ctx* ctx, void* hip_stream); /* enqueue on a caller
 #define SC_STREAM_DEFAULT ((void*)1)
 const char* sc_last_error(const sc_ctx* ctx);          /* last HIP error text seen by this context    */
 
-/* Test / tuning hook, NOT part of the drop-in surface.  The library reads no environment variable; the scheduling
- * knobs and forced fallbacks the parity tests and the sweeps drive live in this per-context struct.  None of them can
- * change a result — only launch geometry, or which of two bit-identical code paths runs.  0 = default everywhere
- * (-1 for the two *_self_max fields).  sc_set_debug(ctx, NULL) restores the defaults. */
-typedef struct sc_debug {
-  uint32_t size;              /* = sizeof(sc_debug)                                                          */
-  uint32_t no_events;         /* 1: stage B walks the bit rows twice instead of recording an event list       */
-  uint64_t event_cap;         /* event records per call (>= 256): forces the overflow fallback when too small  */
-  int64_t  compact_self_max;  /* key tiles up to which the compaction sums the tile counts itself (-1: 4096)  */
-  int64_t  scan_self_max;     /* scan tiles up to which the down-sweep sums the block sums itself (-1: 4096)  */
-  uint32_t cnt_blocks, keys_blocks, sel_blocks;   /* grid sizes of the counting / key / select kernels        */
-  uint32_t tg_count, tg_keys, tg_sample;          /* lanes per edge: 4, 8 (default), 16, 32 (64: keys, sample)*/
-  uint64_t sample_edges;      /* edges in stage B's pruning sample (default ~5T/8, at least 32768)            */
-  uint32_t score_split;       /* share (of 256) of the hypotheses scored by the f32-MFMA body of C2 */
-  uint32_t compat_one_phase;  /* 1: stage A runs the exact chain on every pair of an interior tile            */
-  uint32_t compat_rows;       /* stage A tile height: 0 = by size (16 rows below 10 000 correspondences, 32 from there), 16, 32, 64 */
-  uint32_t compat_store_mode; /* stage A stores of S: 0 = by size; bit 0 = 4 bytes per lane, bit 2 = 16 bytes, bit 1 = non-temporal */
-  uint32_t tg_events;         /* lanes per edge of the event-recording counting pass: 4 .. 64 (default: by row width) */
-  uint32_t sample_mode;       /* stage B's pruning sample: 0 = chosen by size, 1 = every stride-th edge, 2 = the heaviest edges */
-  uint32_t sample_blocks;     /* grid size of the heaviest-edge sample (0 = one block per 256 edges)              */
-  uint32_t compact_fused;     /* 1: compaction in one launch (look-back over the tiles) instead of count + write    */
-  uint32_t rows_unfused;      /* 1: row statistics and the scans of the row counts as separate launches             */
-  uint32_t score_scalar;      /* 1: stage C2 counts inliers with the lane = correspondence kernel (measured slower)  */
-  uint32_t score_filter;      /* stage C2, inlier count: 0 = by size and scale (plain fp32 kernel for small calls; for large ones a matrix-pipe filter + exact fix-up: the Gram filter where tau is not small against the clouds, else the linear one); 1 = always plain; 2 = always the linear filter; 3 = always the Gram filter */
-  uint32_t filter_splits;     /* grid.y of the filter kernel (0 = by size)                                            */
-  uint32_t filter_queue_cap;  /* entries of the filter's queue of undecided tests (0 = by size): a small one forces the recount path */
-  uint32_t filter_lds_queue;  /* entries of a wave's own queue, 64 .. 256 (0 = 256)                                   */
-  uint32_t es_hist_unfused;   /* 1: stage B's edge-weight histogram by a launch of its own instead of inside edge_fill  */
-  uint32_t filter_variant;    /* body of the filter kernel: 0 = default; others = bit-identical scheduling variants and (>= 16) timing-only ablations (tools/ab_stage.py) */
-  uint32_t dense_async;       /* 1: stage A writes the dense matrix S from a second, low-priority stream while stage B already runs on the bit rows (measured: DESIGN.md) */
-  uint32_t filter_blind;      /* 1: the host picks stage C2's kernel as if the coordinate maxima had not arrived yet (it then assumes the filter applies; the filter's own range test sends what it cannot bound to the exact recount) */
-} sc_debug;
-int         sc_set_debug(sc_ctx* ctx, const sc_debug* dbg);
-
-/* Diagnostics of the LAST call on this context (test hook, like sc_set_debug): which stage C2 kernel it ran and, for the
- * matrix-pipe filter, what it handed to the exact pass.  Synchronises the context's stream. */
-typedef struct sc_debug_info {
-  uint32_t size;              /* = sizeof(sc_debug_info), set by the caller                                          */
-  uint32_t c2_kernel;         /* 0: plain fp32 kernel (also the truncated scores); 1: linear filter + exact pass; 2: Gram filter + exact pass */
-  uint64_t filter_undecided;  /* queue entries (linear: one per correspondence and wave half with >= 1 undecided test; Gram: one per correspondence, lane half and group of four hypotheses) */
-  uint64_t filter_recounts;   /* (8-hypothesis wave, grid split) pairs recounted wholesale by the exact pass           */
-  uint32_t filter_splits;     /* grid.y of the filter launch                                                           */
-  uint32_t reserved;
-} sc_debug_info;
-int         sc_debug_last(sc_ctx* ctx, sc_debug_info* out);
+/* Test / tuning hooks (sc_set_debug, sc_debug_last) are NOT part of the drop-in surface: include/saccot_debug.h. */
 
 /* ---- the drop-in entry point: correspondences in, (R, t, inlier mask) out ------------------------
  * north_star: "keeping the reference's correspondence-in / (R,t,inlier-mask)-out function signature".
@@ -217,6 +178,24 @@ int sc_register(sc_ctx* ctx, const float* src, const float* tgt, int64_t n, cons
  * for sc_finalize_device below: complete on return with the private stream, stream-ordered with a caller stream. */
 int sc_register_device(sc_ctx* ctx, const float* d_src, const float* d_tgt, int64_t n,
                        const sc_params* params, float* d_Rt, uint8_t* d_mask, sc_stats* stats);
+
+/* The same call in two halves, for callers that register a STREAM of frames: sc_register_device_async enqueues the
+ * whole path on the context's stream and returns without waiting for the GPU; sc_wait delivers the status and the
+ * statistics of that call (and is where the host first looks at anything the GPU produced).  Between the two the host
+ * is free — e.g. to enqueue the next frame on a SECOND context bound to the same stream (sc_set_stream): the GPU then
+ * runs the frames back to back and never waits for the host.  At most ONE call may be outstanding per context
+ * (SC_EINVAL otherwise); d_src / d_tgt must stay valid and unchanged until sc_wait returns, d_Rt / d_mask are complete
+ * when it does (as for sc_register_device).
+ * How it can return early: a call whose shape (n, parameters) equals the previous call's on this context is enqueued
+ * "host-free" — its launches are sized by what the previous call needed (plus slack) and read the two data-dependent
+ * counts of stage B (edges, triangles of the pruned graph) from device memory instead of from the host.  sc_wait
+ * validates: had a count outgrown what the launches covered (or had any other of the waiting path's fallbacks been
+ * needed), it repeats the call the waiting way before it returns — results are identical either way, bit for bit.
+ * The first call on a context, and every call whose shape differs from the one before, simply waits inside
+ * sc_register_device_async as sc_register_device always did.  sc_register_device is async + wait. */
+int sc_register_device_async(sc_ctx* ctx, const float* d_src, const float* d_tgt, int64_t n,
+                             const sc_params* params, float* d_Rt, uint8_t* d_mask);
+int sc_wait(sc_ctx* ctx, sc_stats* stats);
 
 /* ---- two-phase form for one-process-per-GPU sharding --------------------------------
  * Phase 1: A and B replicated, C1+C2 on this rank's blocks of the top-T list; writes this rank's winner key

@@ -1,0 +1,73 @@
+/*
+ * saccot_debug.h — test / tuning hooks of libsaccot.so.  NOT part of the drop-in surface (include/saccot.h): a caller of
+ * the registration path never needs this header.  The parity tests, the A/B sweeps under tools/ and bench.py do.
+ *
+ * The library reads no environment variable (SURVEY.md §5 "config / flags"): the scheduling knobs and forced fallbacks
+ * live in the per-context struct below.  None of them can change a result — only launch geometry, or which of two
+ * bit-identical code paths runs.  (Timing-only ablation bodies of the C2 filters, which DO return wrong counts, exist only
+ * in a library built with -DSC_ABLATIONS: the default build rejects their filter_variant values with SC_EINVAL.)
+ */
+#ifndef SACCOT_DEBUG_H
+#define SACCOT_DEBUG_H
+
+#include "saccot.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* 0 = default everywhere (-1 for the two *_self_max fields).  sc_set_debug(ctx, NULL) restores the defaults. */
+typedef struct sc_debug {
+  uint32_t size;              /* = sizeof(sc_debug)                                                          */
+  uint32_t no_events;         /* 1: stage B walks the bit rows twice instead of recording an event list       */
+  uint64_t event_cap;         /* event records per call (>= 256): forces the overflow fallback when too small  */
+  int64_t  compact_self_max;  /* key tiles up to which the compaction sums the tile counts itself (-1: 4096)  */
+  int64_t  scan_self_max;     /* scan tiles up to which the down-sweep sums the block sums itself (-1: 4096)  */
+  uint32_t cnt_blocks, keys_blocks, sel_blocks;   /* grid sizes of the counting / key / select kernels        */
+  uint32_t tg_count, tg_keys, tg_sample;          /* lanes per edge: 4, 8 (default), 16, 32 (64: keys, sample)*/
+  uint64_t sample_edges;      /* edges in stage B's pruning sample (default ~5T/8, at least 32768)            */
+  uint32_t score_split;       /* share (of 256) of the hypotheses scored by the f32-MFMA body of C2 */
+  uint32_t compat_one_phase;  /* 1: stage A runs the exact chain on every pair of an interior tile            */
+  uint32_t compat_rows;       /* stage A tile height: 0 = by size (16 rows below 10 000 correspondences, 32 from there), 16, 32, 64 */
+  uint32_t compat_store_mode; /* stage A stores of S: 0 = by size; bit 0 = 4 bytes per lane, bit 2 = 16 bytes, bit 1 = non-temporal */
+  uint32_t tg_events;         /* lanes per edge of the event-recording counting pass: 4 .. 64 (default: by row width) */
+  uint32_t sample_mode;       /* stage B's pruning sample: 0 = chosen by size, 1 = every stride-th edge, 2 = the heaviest edges */
+  uint32_t sample_blocks;     /* grid size of the heaviest-edge sample (0 = one block per 256 edges)              */
+  uint32_t compact_fused;     /* 1: compaction in one launch (look-back over the tiles) instead of count + write    */
+  uint32_t rows_unfused;      /* 1: row statistics and the scans of the row counts as separate launches             */
+  uint32_t score_scalar;      /* 1: stage C2 counts inliers with the lane = correspondence kernel (measured slower)  */
+  uint32_t score_filter;      /* stage C2, inlier count: 0 = by size and scale (plain fp32 kernel for small calls; for large ones a matrix-pipe filter + exact fix-up: the Gram filter where tau is not small against the clouds, else the linear one); 1 = always plain; 2 = always the linear filter; 3 = always the Gram filter */
+  uint32_t filter_splits;     /* grid.y of the filter kernel (0 = by size)                                            */
+  uint32_t filter_queue_cap;  /* entries of the filter's queue of undecided tests (0 = by size): a small one forces the recount path */
+  uint32_t filter_lds_queue;  /* entries of a wave's own queue, 64 .. 256 (0 = 256)                                   */
+  uint32_t es_hist_unfused;   /* 1: stage B's edge-weight histogram by a launch of its own instead of inside edge_fill  */
+  uint32_t filter_variant;    /* body of the filter kernel: 0 = default, 1 .. 3 = bit-identical scheduling variants; the timing-only ablations (>= 16, wrong counts) only in a -DSC_ABLATIONS build (SC_EINVAL otherwise) */
+  uint32_t dense_async;       /* (removed in 0.5: ignored) */
+  uint32_t filter_blind;      /* 1: the host picks stage C2's kernel as if the coordinate maxima had not arrived yet (it then assumes the filter applies; the filter's own range test sends what it cannot bound to the exact recount) */
+  uint32_t no_fast;           /* 1: sc_register_device always waits for stage B's two counts in the middle of the call (the form every other entry point uses) instead of enqueueing the whole chain of a repeated shape host-free */
+  uint32_t gram_guard_fail;   /* 1: the run-time probe of the matrix pipe's accumulation model reports a violation (tests: the Gram filter must then never be chosen) */
+  uint32_t tail_unfused;      /* 1: the exact pass, the arg-max and the winner / mask kernel as three launches (r03's form) instead of one */
+  uint32_t reserved[5];
+} sc_debug;
+int         sc_set_debug(sc_ctx* ctx, const sc_debug* dbg);
+
+/* Diagnostics of the LAST call on this context: which stage C2 kernel it ran and, for the matrix-pipe filter, what it
+ * handed to the exact pass; how the call was enqueued.  Synchronises the context's stream. */
+typedef struct sc_debug_info {
+  uint32_t size;              /* = sizeof(sc_debug_info), set by the caller                                          */
+  uint32_t c2_kernel;         /* 0: plain fp32 kernel (also the truncated scores); 1: linear filter + exact pass; 2: Gram filter + exact pass */
+  uint64_t filter_undecided;  /* queue entries (linear: one per correspondence and wave half with >= 1 undecided test; Gram: one per correspondence, lane half and group of four hypotheses) */
+  uint64_t filter_recounts;   /* (8-hypothesis wave, grid split) pairs recounted wholesale by the exact pass           */
+  uint32_t filter_splits;     /* grid.y of the filter launch                                                           */
+  uint32_t fast_path;         /* sc_register_device: 0 = the call waited for stage B's counts; 1 = enqueued host-free and validated at its end; 2 = enqueued host-free, failed validation (a count outgrew what the launches covered, fewer triangles than T, event overflow), repeated the waiting way */
+  uint32_t gram_guard;        /* run-time probe of the matrix pipe's accumulation arithmetic (once per context, before the first call that could choose the Gram filter): 0 = not run yet, 1 = the model the Gram bound assumes holds, 2 = violated: the Gram filter is disabled for this context */
+  uint32_t reserved;
+  float    gram_guard_worst;  /* largest |hardware - exact| / largest term the probe saw, in units of 2^-24 (the bound assumes 18.5) */
+  uint32_t reserved2;
+} sc_debug_info;
+int         sc_debug_last(sc_ctx* ctx, sc_debug_info* out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SACCOT_DEBUG_H */

@@ -33,7 +33,8 @@ def SC_TIMING_STAGE(k: int) -> int:
 SC_HIST_WORDS = 256  # u32 words of the pruning-sample histogram (sc_hypothesize_begin_device)
 
 EXPORTS = ["sc_version", "sc_strerror", "sc_default_params", "sc_create", "sc_destroy", "sc_set_stream",
-           "sc_last_error", "sc_set_debug", "sc_debug_last", "sc_register", "sc_register_device", "sc_hypothesize_device", "sc_finalize_device",
+           "sc_last_error", "sc_set_debug", "sc_debug_last", "sc_register", "sc_register_device", "sc_register_device_async", "sc_wait",
+           "sc_hypothesize_device", "sc_finalize_device",
            "sc_hypothesize_begin_device", "sc_hypothesize_end_device", "sc_finalize_gathered_device",
            "sc_shard_plan_query", "sc_shard_compat_device", "sc_shard_edges_device", "sc_shard_select_device",
            "sc_shard_score_device", "sc_create_multi", "sc_create_multi_loopback", "sc_destroy_multi",
@@ -56,7 +57,7 @@ class ScStats(C.Structure):
                 ("us_trikeys", C.c_float),
                 ("us_kabsch", C.c_float), ("us_score", C.c_float), ("us_argmax", C.c_float), ("us_mask", C.c_float),
                 ("us_total", C.c_float),
-                ("workspace_bytes", C.c_uint64)]
+                ("workspace_bytes", C.c_uint64), ("bytes_moved", C.c_uint64)]
 
     def as_dict(self) -> dict:
         return {k: getattr(self, k) for k, _ in self._fields_ if k != "size"}
@@ -70,7 +71,7 @@ class ScShardPlan(C.Structure):
 
 
 class ScDebug(C.Structure):
-    """Mirror of `sc_debug` (include/saccot.h): test / tuning hook, 0 = default (-1 for the *_self_max fields)."""
+    """Mirror of `sc_debug` (include/saccot_debug.h): test / tuning hook, 0 = default (-1 for the *_self_max fields)."""
     _fields_ = [("size", C.c_uint32), ("no_events", C.c_uint32), ("event_cap", C.c_uint64),
                 ("compact_self_max", C.c_int64), ("scan_self_max", C.c_int64),
                 ("cnt_blocks", C.c_uint32), ("keys_blocks", C.c_uint32), ("sel_blocks", C.c_uint32),
@@ -80,13 +81,18 @@ class ScDebug(C.Structure):
                 ("sample_blocks", C.c_uint32), ("compact_fused", C.c_uint32), ("rows_unfused", C.c_uint32),
                 ("score_scalar", C.c_uint32), ("score_filter", C.c_uint32), ("filter_splits", C.c_uint32),
                 ("filter_queue_cap", C.c_uint32), ("filter_lds_queue", C.c_uint32), ("es_hist_unfused", C.c_uint32),
-                ("filter_variant", C.c_uint32), ("dense_async", C.c_uint32), ("filter_blind", C.c_uint32)]
+                ("filter_variant", C.c_uint32), ("dense_async", C.c_uint32), ("filter_blind", C.c_uint32),
+                ("no_fast", C.c_uint32), ("gram_guard_fail", C.c_uint32), ("tail_unfused", C.c_uint32),
+                ("reserved", C.c_uint32 * 5)]
 
 
 class ScDebugInfo(C.Structure):
-    """Mirror of `sc_debug_info` (include/saccot.h): which C2 kernel the last call ran, and the filter's hand-overs."""
+    """Mirror of `sc_debug_info` (include/saccot_debug.h): which C2 kernel the last call ran, the filter's hand-overs,
+    how the call was enqueued (fast_path: 0 waited, 1 host-free, 2 host-free then repeated), the matrix-pipe probe."""
     _fields_ = [("size", C.c_uint32), ("c2_kernel", C.c_uint32), ("filter_undecided", C.c_uint64),
-                ("filter_recounts", C.c_uint64), ("filter_splits", C.c_uint32), ("reserved", C.c_uint32)]
+                ("filter_recounts", C.c_uint64), ("filter_splits", C.c_uint32), ("fast_path", C.c_uint32),
+                ("gram_guard", C.c_uint32), ("reserved", C.c_uint32), ("gram_guard_worst", C.c_float),
+                ("reserved2", C.c_uint32)]
 
 
 class SacCotError(RuntimeError):
@@ -127,6 +133,8 @@ def load_library() -> C.CDLL:
     L.sc_debug_last.argtypes = [vp, C.POINTER(ScDebugInfo)]
     L.sc_register.argtypes = [vp, f32p, f32p, C.c_int64, pp, f32p, f32p, u8p, sp]
     L.sc_register_device.argtypes = [vp, vp, vp, C.c_int64, pp, vp, vp, sp]
+    L.sc_register_device_async.argtypes = [vp, vp, vp, C.c_int64, pp, vp, vp]
+    L.sc_wait.argtypes = [vp, sp]
     L.sc_hypothesize_device.argtypes = [vp, vp, vp, C.c_int64, pp, vp, sp]
     L.sc_finalize_device.argtypes = [vp, vp, vp, vp, sp]
     L.sc_hypothesize_begin_device.argtypes = [vp, vp, vp, C.c_int64, pp, vp, sp]
@@ -224,17 +232,18 @@ class Registrar:
             return
         d = ScDebug(size=C.sizeof(ScDebug), compact_self_max=-1, scan_self_max=-1)
         for k, v in knobs.items():
-            if k not in dict(ScDebug._fields_) or k == "size":
+            if k not in dict(ScDebug._fields_) or k in ("size", "reserved"):
                 raise KeyError(f"sc_debug has no field {k!r}")
             setattr(d, k, int(v))
         self._check(self._lib.sc_set_debug(self._h, C.byref(d)))
 
     def debug_last(self) -> dict:
-        """sc_debug_last: which stage C2 kernel the last call ran (0 plain fp32, 1 filter + exact pass) and what the
-        filter handed to the exact pass.  Synchronises the context's stream."""
+        """sc_debug_last: which stage C2 kernel the last call ran (0 plain fp32, 1 linear filter + exact pass, 2 Gram
+        filter + exact pass), what the filter handed to the exact pass, how the call was enqueued (fast_path) and the result
+        of the matrix-pipe probe (gram_guard).  Synchronises the context's stream."""
         d = ScDebugInfo(size=C.sizeof(ScDebugInfo))
         self._check(self._lib.sc_debug_last(self._h, C.byref(d)))
-        return {k: getattr(d, k) for k, _ in ScDebugInfo._fields_ if k not in ("size", "reserved")}
+        return {k: getattr(d, k) for k, _ in ScDebugInfo._fields_ if k not in ("size", "reserved", "reserved2")}
 
     # ---- drop-in entry point ----------------------------------------------------------------------------
     def register(self, src, tgt, params: ScParams | None = None, **kw):
@@ -254,6 +263,16 @@ class Registrar:
         st = ScStats(C.sizeof(ScStats))
         rc = self._check(self._lib.sc_register_device(self._h, d_src, d_tgt, n, C.byref(params), d_Rt, d_mask,
                                                       C.byref(st)), allow=(SC_ENOHYP,))
+        return rc, st.as_dict()
+
+    def register_device_async(self, d_src: int, d_tgt: int, n: int, params: ScParams, d_Rt: int, d_mask: int):
+        """sc_register_device_async: enqueue the whole path and return; `wait()` delivers status and statistics.  At most
+        one call outstanding per Registrar; inputs must stay valid until wait() returns."""
+        self._check(self._lib.sc_register_device_async(self._h, d_src, d_tgt, n, C.byref(params), d_Rt, d_mask))
+
+    def wait(self):
+        st = ScStats(C.sizeof(ScStats))
+        rc = self._check(self._lib.sc_wait(self._h, C.byref(st)), allow=(SC_ENOHYP,))
         return rc, st.as_dict()
 
     def hypothesize_device(self, d_src: int, d_tgt: int, n: int, params: ScParams, d_key: int):

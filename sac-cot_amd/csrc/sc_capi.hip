@@ -16,6 +16,7 @@
 #include <string>
 
 #include "../../include/saccot.h"
+#include "../../include/saccot_debug.h"
 #include "sc_kernels.hpp"
 
 using namespace sc;
@@ -46,10 +47,7 @@ struct sc_ctx {
   // workspace
   Buf in_src, in_tgt, planes, S, bits, deg, degp, wpre, ebase, edge_off, scan_tmp, ei, ej, es, ebi, ebj, tcnt, toff, wkey, kcol, ctl, events, blk_gt,
       blk_eq, blk_minmax, bits2, off_gt, off_eq, sel_ord, sel_key, sortkey, sorted, sort_tmp, tri, tri_rk, key_rk, rt, rt_aos, partial, cnt, key, rt12,
-      mask, refine_tmp, amx_pairs, strong, rowcost, cost_pre, lb_state, lb_ticket, fx_tile, fx_state, fx_mx, fx_part, fx_coef, bits_s;
-  hipStream_t stream2 = nullptr;  // low-priority stream of the asynchronous dense-S launch (Tuning::dense_async)
-  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
-  bool dense_pending = false;
+      mask, refine_tmp, amx_pairs, strong, rowcost, cost_pre, lb_state, lb_ticket, fx_tile, fx_state, fx_mx, fx_part, fx_coef;
   bool filter_on = false;   // C2 of the running / last call goes through a matrix-pipe filter (decided ONCE per call)
   int filter_mode = 0;      // ... which: 1 linear, 2 Gram (0: the plain fp32 kernel)
   FilterPlan fx_plan{};     // ... with this plan (sc_debug_last reads the filter's counters through it)
@@ -86,6 +84,25 @@ struct sc_ctx {
   void* lb_zeroed = nullptr;
   size_t lb_zeroed_cap = 0;
   bool rows_fused = false;  // run_row_stats already produced edge_off / ebase / cost_pre and armed the edge count
+  // ---- host-free enqueue (sc_register_device_async; see include/saccot.h).  A call of the same shape as the last one does
+  // not wait for stage B's two counts: its launches cover E_cov edges / M_cov keys and read the real counts from device
+  // memory; sc_wait validates (spec_validate) and repeats the call the waiting way when a count outgrew the cover.
+  bool spec_on = false;      // the running call is enqueued host-free
+  bool fast_ok = false;      // the last completed call was regular (events, a-priori window, T triangles found): the next may try
+  int fast_state = 0;        // last call: 0 waited, 1 host-free and valid, 2 host-free, failed validation, repeated
+  uint64_t E_cov = 0, M_cov = 0, E_last = 0, M_last = 0;
+  int last_n = 0;
+  sc_params last_p{};
+  // the outstanding call of sc_register_device_async (at most one per context)
+  bool regular = false;      // the running / last call met every assumption of the host-free form (run_select, finalize_wait)
+  bool pending = false;
+  bool pend_done = false;    // ... and it was a waited call: complete, status in pending_rc
+  int pending_rc = 0;        // status already known when the async half returned (a waited call is complete by then)
+  const float* pend_src = nullptr; const float* pend_tgt = nullptr; float* pend_Rt = nullptr; uint8_t* pend_mask = nullptr;
+  int64_t pend_n = 0; sc_params pend_p{}; sc_stats pend_stats{};
+  // run-time probe of the matrix pipe's accumulation model (sc_score.hip gram_guard): 0 not run, 1 holds, 2 violated
+  int gram_guard = 0;
+  float gram_guard_worst = 0.f;
   bool sharded_ab = false;
   int shard_phase = 0;
   const void* cand_all = nullptr;
@@ -204,7 +221,8 @@ const uint64_t* own_range_of(const sc_ctx* c) {
 
 // event i of the per-stage timing; SC_FLAG_TIMING_HOT keeps only the bracket of the dominant (score) kernel
 TriSource tri_source_of(const sc_ctx* c) {
-  TriSource ts{c->sel_ord.as<uint64_t>(), c->kcol.as<uint2>(), c->ei.as<uint32_t>(), c->ej.as<uint32_t>(), nullptr, 0, 0};
+  TriSource ts{c->sel_ord.as<uint64_t>(), c->kcol.as<uint2>(), c->ei.as<uint32_t>(), c->ej.as<uint32_t>(), nullptr, 0, 0, 0u, 0u, 0ull};
+  if (c->spec_on) { ts.lim_vertex = (uint32_t)c->n; ts.lim_edge = (uint32_t)c->E_cov; ts.lim_ord = c->M_cov; }
   if (c->sharded_ab && c->cand_all) {  // the selection indexes the gathered candidate blobs
     const size_t cap = cand_cap(c->params.max_triangles, (uint32_t)c->params.shard_world, c->params.shard_cand_level);
     ts.cand_recs = cand_blob(const_cast<void*>(c->cand_all), cap).recs;
@@ -268,10 +286,9 @@ int stage_inputs(sc_ctx* c, const float* d_src, const float* d_tgt, int64_t n, c
 }
 
 // dense: also write the n x n weight matrix S (SC_FLAG_NO_DENSE_S clears it: nothing after stage A reads S)
-// Tuning::dense_async (hot path only): the dense matrix S — which nothing on the path reads — is written by a SECOND launch
-// on a low-priority stream of the context's own, concurrently with stage B, while the path continues from the bits-only
-// kernel; join_dense() makes the caller's stream wait for it before the call's last kernel.
-int run_compat(sc_ctx* c, bool dense, bool allow_async = false) {
+// (r02 / r03 experiment, removed in r04: S from a second, low-priority stream while stage B runs — slower on every config,
+// DESIGN.md §5 "measured and dropped")
+int run_compat(sc_ctx* c, bool dense) {
   const size_t n = c->n, ld = c->ld, W = ld >> 6;
   if (dense) ENSURE(c, c->S, n * ld * sizeof(float));
   ENSURE(c, c->bits, n * W * sizeof(uint64_t));
@@ -280,29 +297,7 @@ int run_compat(sc_ctx* c, bool dense, bool allow_async = false) {
   ENSURE(c, c->wpre, n * W * sizeof(uint32_t));
   c->bits_cur = c->bits.as<uint64_t>();
   c->sharded_ab = false; c->shard_phase = 0; c->cand_all = nullptr;
-  c->dense_pending = false;
-  if (dense && allow_async && c->tn.dense_async && !c->timing) {
-    if (!c->stream2) {
-      int lo = 0, hi = 0;
-      HIPCHK(c, hipDeviceGetStreamPriorityRange(&lo, &hi));  // lo: the numerically largest value = lowest priority
-      HIPCHK(c, hipStreamCreateWithPriority(&c->stream2, hipStreamNonBlocking, lo));
-      HIPCHK(c, hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
-      HIPCHK(c, hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
-    }
-    ENSURE(c, c->bits_s, n * W * sizeof(uint64_t));
-    launch_compat(points_of(c), c->dv, nullptr, c->bits_cur, 0, c->n, c->tn, c->stream);
-    HIPCHK(c, hipEventRecord(c->ev_fork, c->stream));               // (the planes are ready; the path's bit rows too)
-    HIPCHK(c, hipStreamWaitEvent(c->stream2, c->ev_fork, 0));
-    launch_compat(points_of(c), c->dv, c->S.as<float>(), c->bits_s.as<uint64_t>(), 0, c->n, c->tn, c->stream2);
-    HIPCHK(c, hipEventRecord(c->ev_join, c->stream2));
-    c->dense_pending = true;
-    return SC_OK;
-  }
   launch_compat(points_of(c), c->dv, dense ? c->S.as<float>() : nullptr, c->bits_cur, 0, c->n, c->tn, c->stream);
-  return SC_OK;
-}
-int join_dense(sc_ctx* c) {
-  if (c->dense_pending) { HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_join, 0)); c->dense_pending = false; }
   return SC_OK;
 }
 
@@ -421,9 +416,15 @@ int run_edges(sc_ctx* c, const sc_params* p, uint32_t* hist, uint32_t part, uint
                      c->ebj.as<uint32_t>(), cap, es_hist, st);
   };
   if (spec_cap) fill_edges(spec_cap);
-  { const int wrc = wait_word(c, 0); if (wrc) return wrc; }
-  if ((uint32_t)c->pinned[1] != 0) { c->last_error = "non-finite input coordinate"; return SC_EINVAL; }
-  const uint64_t E = c->E = c->pinned[0];
+  // Host-free call (c->spec_on; fast_plan() made sure E_cov <= spec_cap): no wait.  E is then what the launches and arrays
+  // COVER; the kernels below take the real count from edge_off[n] (E_dev) and the end of the call validates it.
+  const bool spec = c->spec_on;
+  const uint64_t* E_dev = spec ? c->edge_off.as<uint64_t>() + n : nullptr;
+  if (!spec) {
+    { const int wrc = wait_word(c, 0); if (wrc) return wrc; }
+    if ((uint32_t)c->pinned[1] != 0) { c->last_error = "non-finite input coordinate"; return SC_EINVAL; }
+  }
+  const uint64_t E = c->E = spec ? c->E_cov : c->pinned[0];
   c->M = 0; c->M_total = 0; c->T_eff = 0; c->pruned = false; c->use_events = false; c->have_total = false;
   // an exchanged histogram is written on every path (zeros where no sample runs: the control block's copies are zero)
   if (hist && (E == 0 || !(may_prune(p) && E >= 4096))) launch_hist_reduce(c->ctl.as<ControlBlock>()->prune_hist, hist, st);
@@ -457,7 +458,7 @@ int run_edges(sc_ctx* c, const sc_params* p, uint32_t* hist, uint32_t part, uint
     // the smallest possible weight is ~3 t_cmp (every edge has s >= t_cmp up to rounding); 0.1 % slack
     launch_sample_hist(g, c->ebi.as<uint32_t>(), c->ebj.as<uint32_t>(), c->ei.as<uint32_t>(), c->ej.as<uint32_t>(),
                        c->es.as<float>(), E, p->max_triangles, 3.0f * p->t_cmp * 0.999f, part, parts,
-                       ctl->prune_hist, ctl->es_hist, es_hist != nullptr, c->tn, st);
+                       ctl->prune_hist, ctl->es_hist, es_hist != nullptr, c->tn, st, E_dev, spec ? c->E_last : 0);
     if (hist) launch_hist_reduce(ctl->prune_hist, hist, st);  // the exchanged form: one 256-bin histogram
   }
   return SC_OK;
@@ -486,7 +487,8 @@ int run_compaction(sc_ctx* c, const KeyView& view, size_t nb) {
                          c->off_eq.as<uint64_t>(), nb, c->scan_tmp.p, c->tn, st);
   launch_compact_write(view, sel, c->blk_gt.as<uint32_t>(), c->blk_eq.as<uint32_t>(),
                        self_off ? nullptr : c->off_gt.as<uint64_t>(), self_off ? nullptr : c->off_eq.as<uint64_t>(),
-                       c->sel_ord.as<uint64_t>(), c->sel_key.as<uint32_t>(), st);
+                       c->sel_ord.as<uint64_t>(), c->sel_key.as<uint32_t>(),
+                       c->sel_ord.cap / 8 < c->sel_key.cap / 4 ? c->sel_ord.cap / 8 : c->sel_key.cap / 4, st);
   return SC_OK;
 }
 
@@ -497,6 +499,8 @@ int run_select(sc_ctx* c, const sc_params* p, const uint32_t* hist, bool want_li
   hipStream_t st = c->stream;
   const uint64_t E = c->E;
   if (E == 0) return SC_OK;
+  const bool spec = c->spec_on;  // host-free call: E is the cover, the real count sits in edge_off[n] (see run_edges)
+  const uint64_t* E_dev = spec ? c->edge_off.as<uint64_t>() + c->n : nullptr;
   const Graph g = graph_of(c);
   const bool use_events = c->use_events, have_total = c->have_total;
   StrongList sl{nullptr, nullptr, 0};
@@ -518,7 +522,7 @@ int run_select(sc_ctx* c, const sc_params* p, const uint32_t* hist, bool want_li
     // launches make the cut, and the counting pass skips the edges of the other ranks.
     launch_prune_bits(g, hist ? hist : ctl->prune_hist, hist == nullptr, c->ei.as<uint32_t>(), c->ej.as<uint32_t>(), c->es.as<float>(), E,
                       p->max_triangles, 3.0f * p->t_cmp * 0.999f, c->bits2.as<uint64_t>(), &ctl->smin, &ctl->klb, sl,
-                      c->tcnt.as<uint32_t>(), recut ? nullptr : own_range_of(c), st);
+                      c->tcnt.as<uint32_t>(), recut ? nullptr : own_range_of(c), st, E_dev);
     if (recut) {
       ENSURE(c, c->rowcost, ((size_t)c->n + 4 + 1024) * 4);  // (cost_split_kernel reads whole 16-byte pieces)
       launch_strong_rowcost(g, c->bits2.as<uint64_t>(), c->rowcost.as<uint32_t>(), st);
@@ -540,7 +544,7 @@ int run_select(sc_ctx* c, const sc_params* p, const uint32_t* hist, bool want_li
     ev = event_list(c->events.p, ev_cap, g.W, c->ctl.as<ControlBlock>()->ev_fill,
                     reinterpret_cast<uint32_t*>(&c->pinned[5]));
     launch_tri_count_events(g, mbits, sl, c->ebi.as<uint32_t>(), c->ebj.as<uint32_t>(), c->ei.as<uint32_t>(),
-                            c->ej.as<uint32_t>(), E, p->rank_mode, c->tcnt.as<uint32_t>(), ev, c->tn, st, own_range_of(c));
+                            c->ej.as<uint32_t>(), spec ? c->E_last : E, p->rank_mode, c->tcnt.as<uint32_t>(), ev, c->tn, st, own_range_of(c));
   } else {
     launch_tri_count(g, mbits, c->es.as<float>(), smin, c->ei.as<uint32_t>(), c->ej.as<uint32_t>(), E,
                      c->tcnt.as<uint32_t>(), own_range_of(c), c->tn, st);
@@ -559,6 +563,7 @@ int run_select(sc_ctx* c, const sc_params* p, const uint32_t* hist, bool want_li
   uint64_t spec_cap = 0;
   if (use_events && window_known && !c->timing) {
     spec_cap = c->wkey.cap / 4 < c->kcol.cap / 8 ? c->wkey.cap / 4 : c->kcol.cap / 8;
+    if (spec) spec_cap = c->M_cov;  // (<= that capacity: fast_plan)
     if (spec_cap) {
       ENSURE(c, c->blk_minmax, 2 * 8192 * 4);
       launch_tri_keys_events(g, c->es.as<float>(), c->toff.as<uint64_t>(), p->rank_mode, ev, c->wkey.as<uint32_t>(),
@@ -566,9 +571,11 @@ int run_select(sc_ctx* c, const sc_params* p, const uint32_t* hist, bool want_li
                              &c->ctl.as<ControlBlock>()->klb, E, spec_cap, c->tn, st);
     }
   }
-  { const int wrc = wait_word(c, 2); if (wrc) return wrc; }
-  c->M_total = have_total ? c->pinned[4] : c->pinned[2];
-  const uint64_t M = c->M = c->pinned[2];
+  // host-free call: no wait — M is what the key arrays and the launches below cover, T_eff the requested T; the kernels
+  // read the real count from toff[E] (= the scan's total: the counts of [real E, E) are zero) and sc_wait validates
+  if (!spec) { const int wrc = wait_word(c, 2); if (wrc) return wrc; }
+  c->M_total = spec ? c->M_cov : (have_total ? c->pinned[4] : c->pinned[2]);
+  const uint64_t M = c->M = spec ? c->M_cov : c->pinned[2];
   if (M == 0) return SC_OK;
   const uint32_t want_sel = select_want(c, p);
   const uint32_t T_eff = c->T_eff = (uint32_t)(M < want_sel ? M : want_sel);
@@ -587,7 +594,7 @@ int run_select(sc_ctx* c, const sc_params* p, const uint32_t* hist, bool want_li
   if (want_list) ENSURE(c, c->tri, (size_t)T_eff * 12);
   if (c->timing) HIPCHK(c, hipEventRecord(c->ev[9], st));
   bool events_ok = use_events;
-  if (use_events && (uint32_t)c->pinned[5] != 0) {  // a region overflowed: this call walks the rows again
+  if (!spec && use_events && (uint32_t)c->pinned[5] != 0) {  // a region overflowed: this call walks the rows again
     events_ok = false;
     uint64_t want_cap = c->ev_capacity * 2;          // every event holds >= 1 triangle, so M bounds the need
     if (want_cap < M + M / 4) want_cap = M + M / 4;
@@ -610,13 +617,16 @@ int run_select(sc_ctx* c, const sc_params* p, const uint32_t* hist, bool want_li
   }
   if (c->timing) HIPCHK(c, hipEventRecord(c->ev[10], st));
   c->timed_trikeys = c->timing;
-  const KeyView view = plain_view(c->wkey.as<uint32_t>(), M);
+  KeyView view = plain_view(c->wkey.as<uint32_t>(), M);
+  if (spec) view.M_dev = c->toff.as<uint64_t>() + E;
   launch_select_rounds(view, sel, fast_window ? 2 : 3, c->tn, st);
   { const int crc = run_compaction(c, view, nb); if (crc) return crc; }
   // the list stays in ordinal order: no sort on the hot path (the winner is found by (count, key, position))
   if (want_list)
     launch_tri_decode(c->ei.as<uint32_t>(), c->ej.as<uint32_t>(), c->kcol.as<uint2>(), c->sel_ord.as<uint64_t>(), T_eff,
                       c->tri.as<uint32_t>(), st);
+  // the shape a host-free repetition of this call assumes (fast_plan / finalize_wait)
+  c->regular = !spec && events_ok && fast_window && !have_total && !c->timing && M >= want_sel && hist == nullptr;
   return SC_OK;
 }
 
@@ -635,6 +645,12 @@ void fill_stats(const sc_ctx* c, sc_stats* s) {
   s->tri_kept = c->T_eff;
   s->tri_scored = c->sh.n_local;
   s->workspace_bytes = c->held;
+  // algorithmic bytes of this call (include/saccot.h): SURVEY §8d's per-stage formulas with the call's own counts
+  const uint64_t n = (uint64_t)c->n, nn8 = n * n / 8;
+  const bool dense = !(c->params.flags & SC_FLAG_NO_DENSE_S);
+  s->bytes_moved = (dense ? 4 * n * n : 0) + nn8 + 24 * n          // A: S, bit rows, the correspondences
+                   + nn8 + 20 * c->E + 12 * c->M + 16 * (uint64_t)c->T_eff  // B: bit rows once, edge records, keys + {vertex, edge}, selection
+                   + 52 * (uint64_t)c->sh.n_local + 24 * n + n;   // C: (R,t) out and in, counts, the correspondences, the mask
 }
 
 // A bracket of two event records contains the cost of one record (a barrier packet with a timestamp: ~4-5 us of
@@ -755,15 +771,12 @@ void sc_destroy(sc_ctx* c) {
   Buf* bufs[] = {&c->in_src, &c->in_tgt, &c->planes, &c->S, &c->bits, &c->deg, &c->degp, &c->wpre, &c->ebase, &c->edge_off, &c->scan_tmp,
                  &c->ei, &c->ej, &c->es, &c->ebi, &c->ebj, &c->tcnt, &c->toff, &c->wkey, &c->kcol, &c->ctl, &c->events, &c->blk_gt, &c->blk_eq, &c->blk_minmax, &c->bits2, &c->off_gt,
                  &c->off_eq, &c->sel_ord, &c->sel_key, &c->sortkey, &c->sorted, &c->sort_tmp, &c->tri, &c->tri_rk, &c->key_rk, &c->rt,
-                 &c->rt_aos, &c->partial, &c->cnt, &c->key, &c->rt12, &c->mask, &c->refine_tmp, &c->amx_pairs, &c->strong, &c->rowcost, &c->cost_pre, &c->lb_state, &c->lb_ticket, &c->fx_tile, &c->fx_state, &c->fx_mx, &c->fx_part, &c->fx_coef, &c->bits_s};
+                 &c->rt_aos, &c->partial, &c->cnt, &c->key, &c->rt12, &c->mask, &c->refine_tmp, &c->amx_pairs, &c->strong, &c->rowcost, &c->cost_pre, &c->lb_state, &c->lb_ticket, &c->fx_tile, &c->fx_state, &c->fx_mx, &c->fx_part, &c->fx_coef};
   for (Buf* b : bufs) if (b->p) (void)hipFree(b->p);
   for (int i = 0; i < N_EVENTS; i++) if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
   if (c->pinned) (void)hipHostFree(c->pinned);
   if (c->h_in) (void)hipHostFree(c->h_in);
   if (c->h_out) (void)hipHostFree(c->h_out);
-  if (c->stream2) { (void)hipStreamSynchronize(c->stream2); (void)hipStreamDestroy(c->stream2); }
-  if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
-  if (c->ev_join) (void)hipEventDestroy(c->ev_join);
   if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
   delete c;
 }
@@ -782,7 +795,7 @@ const char* sc_last_error(const sc_ctx* c) { return c ? c->last_error.c_str() : 
 
 int sc_set_debug(sc_ctx* c, const sc_debug* d) {
   if (!c) return SC_EINVAL;
-  if (!d) { c->tn = Tuning(); return SC_OK; }
+  if (!d) { c->tn = Tuning(); c->fast_ok = false; return SC_OK; }
   if (d->size != sizeof(sc_debug)) return SC_EINVAL;
   auto tg_ok = [](uint32_t t) { return t == 0 || t == 4 || t == 8 || t == 16 || t == 32 || t == 64; };
   if (!tg_ok(d->tg_count) || !tg_ok(d->tg_keys) || !tg_ok(d->tg_sample) || !tg_ok(d->tg_events)) return SC_EINVAL;
@@ -816,8 +829,11 @@ int sc_set_debug(sc_ctx* c, const sc_debug* d) {
   t.filter_lds_queue = d->filter_lds_queue;
   t.filter_blind = d->filter_blind != 0;
   t.filter_variant = d->filter_variant;
-  t.dense_async = d->dense_async != 0;
+  t.no_fast = d->no_fast != 0;
+  t.gram_guard_fail = d->gram_guard_fail != 0;
+  t.tail_unfused = d->tail_unfused != 0;
   c->tn = t;
+  c->fast_ok = false;  // (the next call waits: its launch geometry may differ from the last call's)
   return SC_OK;
 }
 
@@ -828,6 +844,9 @@ int sc_debug_last(sc_ctx* c, sc_debug_info* out) {
   out->c2_kernel = c->filter_on ? (uint32_t)c->filter_mode : 0u;
   out->filter_splits = c->filter_on ? c->fx_plan.splits : 0u;
   out->filter_undecided = 0; out->filter_recounts = 0;
+  out->fast_path = (uint32_t)c->fast_state;
+  out->gram_guard = (uint32_t)c->gram_guard; out->gram_guard_worst = c->gram_guard_worst;
+  out->reserved = 0; out->reserved2 = 0;
   if (c->filter_on && c->fx_state.p)
     HIPCHK(c, filter_read_counters(c->fx_state.p, c->fx_plan, c->stream, &out->filter_undecided, &out->filter_recounts));
   return SC_OK;
@@ -846,6 +865,7 @@ int hyp_begin(sc_ctx* c, const float* d_src, const float* d_tgt, int64_t n, cons
   c->have_hyp = false;
   c->begun = false;
   c->timed_trikeys = false;
+  c->regular = false;
   if ((rc = set_timing(c, p))) return rc;
   c->refine = (p->flags & SC_FLAG_REFINE) != 0;
   c->cap_bytes = p->max_workspace ? p->max_workspace : (64ull << 30);
@@ -854,7 +874,7 @@ int hyp_begin(sc_ctx* c, const float* d_src, const float* d_tgt, int64_t n, cons
   if ((rc = rec(c, 0))) return rc;
   if ((rc = stage_inputs(c, d_src, d_tgt, n, p))) return rc;
   if ((rc = rec(c, 1))) return rc;
-  if ((rc = run_compat(c, !(p->flags & SC_FLAG_NO_DENSE_S), true))) return rc;
+  if ((rc = run_compat(c, !(p->flags & SC_FLAG_NO_DENSE_S)))) return rc;
   if ((rc = rec(c, 2))) return rc;
   if ((rc = run_row_stats(c, may_prune(p), true))) return rc;
   if ((rc = run_edges(c, p, d_hist, part, parts))) return rc;
@@ -956,8 +976,10 @@ int run_stage_c(sc_ctx* c, uint64_t* d_key, sc_stats* stats) {
     if (aos) ENSURE(c, c->rt_aos, (size_t)12 * sh.ld_local * 4);
     FilterTileJob job;
     if (filter && (rc = filter_job(c, sh, &job))) return rc;
+    // host-free call: the selection may turn out shorter than the T this launch was sized for (then the call is repeated);
+    // its real length is what the select left in sel.want
     launch_kabsch(points_of(c), tri_source_of(c), sh, c->rt.as<float>(), aos ? c->rt_aos.as<float>() : nullptr,
-                  filter ? &job : nullptr, c->stream);
+                  filter ? &job : nullptr, c->stream, c->spec_on ? &c->ctl.as<ControlBlock>()->sel.want : nullptr);
   } else {
     c->filter_on = false; c->filter_mode = 0;
   }
@@ -1139,13 +1161,15 @@ int sc_finalize_device(sc_ctx* c, const uint64_t* d_key, float* d_Rt, uint8_t* d
   return sc_finalize_gathered_device(c, d_key, 1, d_Rt, d_mask, stats);
 }
 
-int sc_finalize_gathered_device(sc_ctx* c, const uint64_t* d_keys, int n_pairs, float* d_Rt, uint8_t* d_mask,
-                                sc_stats* stats) {
-  if (!c || !d_keys || !d_Rt || !d_mask || n_pairs < 1 || n_pairs > 4096) return SC_EINVAL;
-  if (!c->have_hyp) { c->last_error = "sc_finalize_device without a preceding sc_hypothesize_device"; return SC_EINVAL; }
-  HIPCHK(c, hipSetDevice(c->device));
+}  // extern "C" (the halves of the finalize step and the host-free machinery are internal)
+
+namespace {
+
+constexpr int SC_ESPEC = -100;  // internal: a host-free call failed validation (never leaves the library)
+
+// phase 2, first half: the winner / mask kernel (and the optional refit) are enqueued; nothing is waited for
+int finalize_enqueue(sc_ctx* c, const uint64_t* d_keys, int n_pairs, float* d_Rt, uint8_t* d_mask) {
   int rc;
-  if ((rc = join_dense(c))) return rc;  // the asynchronous dense-S launch (if any) ends inside this call
   if ((rc = rec(c, 7))) return rc;
   arm_word(c, 8);
   ControlBlock* ctl = c->ctl.as<ControlBlock>();
@@ -1156,7 +1180,22 @@ int sc_finalize_gathered_device(sc_ctx* c, const uint64_t* d_keys, int n_pairs, 
     ENSURE(c, c->refine_tmp, refine_scratch_bytes(c->n));
     launch_refine(points_of(c), d_mask, ctl->key2, c->refine_tmp.as<double>(), d_Rt, c->stream);
   }
-  if ((rc = rec(c, 8))) return rc;
+  return rec(c, 8);
+}
+
+// what the next call on this context may assume (fast_plan): the call that just completed was a "regular" one
+void note_completed(sc_ctx* c, bool regular) {
+  c->fast_ok = regular && !c->sharded_ab && c->params.shard_world == 1 && c->E >= 4096 && c->T_eff == c->params.max_triangles;
+  c->E_last = c->E; c->M_last = c->M; c->last_n = c->n;
+  c->last_p = c->params;
+  // room for the event list of a call like this one: an event holds >= 1 triangle, so 2 M records can only overflow a region
+  // on a fill 2 x off the mean (the regions fill evenly: a wave moves to the next one with every flush)
+  if (c->use_events && c->ev_capacity < 2 * c->M) c->ev_capacity = 2 * c->M < (1ull << 28) ? 2 * c->M : (1ull << 28);
+}
+
+// phase 2, second half: wait for the winner; a host-free call is validated here
+int finalize_wait(sc_ctx* c, sc_stats* stats) {
+  int rc;
   // The finalize kernel publishes key / position / rank.  On a caller-provided stream (sc_set_stream) d_Rt and d_mask
   // are complete in stream order, like any other work the caller enqueues there; on the context's private stream —
   // which the caller cannot order against — and when the per-stage events are read below, wait for everything.
@@ -1164,6 +1203,30 @@ int sc_finalize_gathered_device(sc_ctx* c, const uint64_t* d_keys, int n_pairs, 
   else if (c->timing_one == 6) HIPCHK(c, hipEventSynchronize(c->ev[8]));  // the mask bracket ends after the kernel polled below
   if ((rc = wait_word(c, 8))) return rc;
   HIPCHK(c, hipGetLastError());
+  if (c->spec_on) {
+    // Host-free call: every kernel of it has finished (the winner word is the last thing the stream writes), so the two
+    // counts and the flags are final.  The launches covered E_cov edges and M_cov keys and assumed T triangles exist, an
+    // event list that did not overflow and a graph big enough to prune: anything else and the outputs are void — the
+    // caller (sc_wait) repeats the call the waiting way, which handles every one of these cases.
+    c->spec_on = false;
+    if ((uint32_t)c->pinned[1] != 0) { c->fast_ok = false; c->last_error = "non-finite input coordinate"; return SC_EINVAL; }
+    const uint64_t E = c->pinned[0], M = c->pinned[2];
+    const bool ok = E != PIN_PENDING && M != PIN_PENDING && E >= 4096 && E <= c->E_cov && M <= c->M_cov &&
+                    M >= (uint64_t)c->params.max_triangles && (uint32_t)c->pinned[5] == 0;
+    if (!ok) {
+      char buf[256];  // (why, for sc_last_error: the repeat itself is silent)
+      snprintf(buf, sizeof buf, "host-free call repeated: edges %llu (covered %llu), triangles %llu (covered %llu, T %u), event overflow %u",
+               (unsigned long long)E, (unsigned long long)c->E_cov, (unsigned long long)M, (unsigned long long)c->M_cov,
+               c->params.max_triangles, (uint32_t)c->pinned[5]);
+      c->last_error = buf;
+      c->fast_ok = false;
+      if ((uint32_t)c->pinned[5] != 0 && c->ev_capacity < (1ull << 28)) c->ev_capacity *= 2;  // (the repeat must not overflow again)
+      return SC_ESPEC;
+    }
+    c->E = E; c->M = c->M_total = M;
+    c->fast_state = 1;
+    c->regular = true;
+  }
   if (c->sharded_ab && c->cand_all && c->pinned[12] != 0) {
     // merge_check_kernel (an earlier kernel of this stream: its system-scope store is visible once the winner word is):
     // some rank's candidate list was cut at a key the merged threshold does not clear
@@ -1174,6 +1237,7 @@ int sc_finalize_gathered_device(sc_ctx* c, const uint64_t* d_keys, int n_pairs, 
     c->last_error = "a winner key pair points outside the selected list (stale / uninitialised pair, or ranks that disagree on T or the parameters)";
     return SC_EINVAL;
   }
+  note_completed(c, c->regular);
   const uint64_t key = c->pinned[8];
   if (stats && stats->size == sizeof(sc_stats)) {
     fill_stats(c, stats);
@@ -1201,14 +1265,102 @@ int sc_finalize_gathered_device(sc_ctx* c, const uint64_t* d_keys, int n_pairs, 
   return key ? SC_OK : SC_ENOHYP;
 }
 
-int sc_register_device(sc_ctx* c, const float* d_src, const float* d_tgt, int64_t n, const sc_params* p,
-                       float* d_Rt, uint8_t* d_mask, sc_stats* stats) {
-  if (!c || !d_Rt || !d_mask) return SC_EINVAL;
-  if (p && p->size == sizeof(sc_params) && p->shard_world != 1) return SC_EINVAL;
-  ENSURE(c, c->key, 64);
+// May this call be enqueued host-free?  Only a repetition of the last call's shape on this context, and only when that call
+// was regular (note_completed); sets what the launches cover: the last counts plus half, within what the arrays hold.
+bool fast_plan(sc_ctx* c, int64_t n, const sc_params* p) {
+  if (!c->fast_ok || c->tn.no_fast || c->tn.no_events || n != c->last_n) return false;
+  if (p->flags & (SC_FLAG_TIMING | SC_FLAG_EXACT_TOTAL | SC_FLAG_NO_PRUNE)) return false;
+  constexpr uint32_t TIMING_BITS = SC_FLAG_TIMING | SC_FLAG_TIMING_HOT | SC_FLAG_TIMING_ONE | (15u << 8);
+  const sc_params& q = c->last_p;
+  if (p->sigma != q.sigma || p->t_cmp != q.t_cmp || p->tau != q.tau || p->min_len != q.min_len ||
+      p->max_triangles != q.max_triangles || p->rank_mode != q.rank_mode || p->layout != q.layout ||
+      p->shard_world != 1 || q.shard_world != 1 || p->score_mode != q.score_mode ||
+      (p->flags & ~TIMING_BITS) != (q.flags & ~TIMING_BITS))
+    return false;
+  if (!(p->rank_mode == SC_RANK_WEIGHT && 3.0f * p->t_cmp * 0.999f >= 2.0f)) return false;  // the a-priori select window
+  uint64_t ecap = c->es.cap / 4 >= 2 ? c->es.cap / 4 - 2 : 0;
+  for (const Buf* b : {&c->ei, &c->ej, &c->ebi, &c->ebj}) ecap = b->cap / 4 < ecap ? b->cap / 4 : ecap;
+  const uint64_t kcap = c->wkey.cap / 4 < c->kcol.cap / 8 ? c->wkey.cap / 4 : c->kcol.cap / 8;
+  uint64_t ecov = c->E_last + c->E_last / 2 + 4096, mcov = c->M_last + c->M_last / 2 + 4096;
+  if (ecov > ecap) ecov = ecap;
+  if (mcov > kcap) mcov = kcap;
+  if (ecov < c->E_last || ecov < 4096 || ecov >= (1ull << 32) || mcov < c->M_last || mcov < p->max_triangles) return false;
+  c->E_cov = ecov; c->M_cov = mcov;
+  return true;
+}
+
+// the whole path the waiting way (what sc_register_device always did): complete on return
+int register_waited(sc_ctx* c, const float* d_src, const float* d_tgt, int64_t n, const sc_params* p, float* d_Rt,
+                    uint8_t* d_mask, sc_stats* stats) {
+  c->spec_on = false;
   int rc = sc_hypothesize_device(c, d_src, d_tgt, n, p, c->key.as<uint64_t>(), stats);
   if (rc) return rc;
   return sc_finalize_device(c, c->key.as<uint64_t>(), d_Rt, d_mask, stats);
+}
+
+}  // namespace
+
+extern "C" {
+
+int sc_finalize_gathered_device(sc_ctx* c, const uint64_t* d_keys, int n_pairs, float* d_Rt, uint8_t* d_mask,
+                                sc_stats* stats) {
+  if (!c || !d_keys || !d_Rt || !d_mask || n_pairs < 1 || n_pairs > 4096) return SC_EINVAL;
+  if (!c->have_hyp) { c->last_error = "sc_finalize_device without a preceding sc_hypothesize_device"; return SC_EINVAL; }
+  HIPCHK(c, hipSetDevice(c->device));
+  const int rc = finalize_enqueue(c, d_keys, n_pairs, d_Rt, d_mask);
+  return rc ? rc : finalize_wait(c, stats);
+}
+
+int sc_register_device_async(sc_ctx* c, const float* d_src, const float* d_tgt, int64_t n, const sc_params* p,
+                             float* d_Rt, uint8_t* d_mask) {
+  if (!c || !d_src || !d_tgt || !d_Rt || !d_mask) return SC_EINVAL;
+  if (c->pending) { c->last_error = "sc_register_device_async: a call is already outstanding on this context (sc_wait first)"; return SC_EINVAL; }
+  int rc = check_params(p);
+  if (rc) return rc;
+  if (p->shard_world != 1) return SC_EINVAL;
+  HIPCHK(c, hipSetDevice(c->device));
+  ENSURE(c, c->key, 64);
+  c->pend_src = d_src; c->pend_tgt = d_tgt; c->pend_n = n; c->pend_p = *p; c->pend_Rt = d_Rt; c->pend_mask = d_mask;
+  memset(&c->pend_stats, 0, sizeof c->pend_stats);
+  c->pend_stats.size = sizeof(sc_stats);
+  c->fast_state = 0;
+  if (fast_plan(c, n, p)) {
+    // host-free: the whole chain is enqueued without looking at anything the GPU produces; sc_wait validates
+    c->spec_on = true;
+    rc = hyp_begin(c, d_src, d_tgt, n, p, nullptr, 0, 1);
+    if (!rc) rc = hyp_end(c, nullptr, c->key.as<uint64_t>(), &c->pend_stats);
+    if (!rc) rc = finalize_enqueue(c, c->key.as<uint64_t>(), 1, d_Rt, d_mask);
+    if (rc) { c->spec_on = false; c->fast_ok = false; return rc; }  // (a launch or allocation failed: nothing is outstanding)
+    c->pending = true; c->pend_done = false;
+    return SC_OK;
+  }
+  rc = register_waited(c, d_src, d_tgt, n, p, d_Rt, d_mask, &c->pend_stats);
+  if (rc != SC_OK && rc != SC_ENOHYP) return rc;
+  c->pending = true; c->pend_done = true; c->pending_rc = rc;
+  return SC_OK;
+}
+
+int sc_wait(sc_ctx* c, sc_stats* stats) {
+  if (!c) return SC_EINVAL;
+  if (!c->pending) { c->last_error = "sc_wait without an outstanding sc_register_device_async"; return SC_EINVAL; }
+  HIPCHK(c, hipSetDevice(c->device));
+  c->pending = false;
+  int rc = c->pending_rc;
+  if (!c->pend_done) {
+    rc = finalize_wait(c, &c->pend_stats);
+    if (rc == SC_ESPEC) {  // a count outgrew what the launches covered (or another fallback was needed): the waiting way
+      rc = register_waited(c, c->pend_src, c->pend_tgt, c->pend_n, &c->pend_p, c->pend_Rt, c->pend_mask, &c->pend_stats);
+      c->fast_state = 2;
+    }
+  }
+  if (stats && stats->size == sizeof(sc_stats)) *stats = c->pend_stats;
+  return rc;
+}
+
+int sc_register_device(sc_ctx* c, const float* d_src, const float* d_tgt, int64_t n, const sc_params* p,
+                       float* d_Rt, uint8_t* d_mask, sc_stats* stats) {
+  const int rc = sc_register_device_async(c, d_src, d_tgt, n, p, d_Rt, d_mask);
+  return rc ? rc : sc_wait(c, stats);
 }
 
 int sc_register(sc_ctx* c, const float* src, const float* tgt, int64_t n, const sc_params* p, float R[9],

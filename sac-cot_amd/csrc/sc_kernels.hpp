@@ -41,7 +41,9 @@ struct Tuning {
   uint32_t filter_queue_cap = 0;   // entries of the filter's global queue (0: by size; tests force overflows with a small one)
   uint32_t filter_lds_queue = 0;   // entries of a wave's LDS queue, 64 .. 256 (0: 256)
   uint32_t filter_variant = 0;     // body of the filter kernel (sc_score.hip): 0 default, bit-identical scheduling variants, >= 16 timing-only ablations
-  bool dense_async = false;        // the dense matrix S by a second, low-priority launch concurrent with stage B (experiment)
+  bool no_fast = false;            // sc_register_device never enqueues host-free (always waits for stage B's two counts)
+  bool gram_guard_fail = false;    // the matrix-pipe probe reports a violation (tests of the guard)
+  bool tail_unfused = false;       // exact pass, arg-max and winner / mask as three launches (r03's form)
   bool filter_blind = false;       // the host decides C2's kernel WITHOUT the coordinate maxima (as if they had not arrived yet)
   bool compat_one_phase = false;   // exact chain on every pair of an interior tile
   int compat_rows = 0;             // tile height of stage A: 0 = by size (16 below 10 000 correspondences, 32 from there), 16, 32, 64
@@ -192,9 +194,13 @@ size_t strong_list_bytes(uint64_t E);
 //  launch_prune_bits: derives the strong-edge threshold *smin (device float; -1 = nothing certified) and *klb (key of
 //    the bound or 0) from the histogram, builds the strong upper-triangle bit matrix `mbits` (n x W, already zero), and
 //    with sl.list set also compacts the strong edges and zeroes tcnt of the weak ones.
+// E_dev (optional, device): the true edge count when the host launches before it knows it (host-free path, sc_capi.hip):
+// the kernels then work on min(E, *E_dev) edges — E is what the grids and arrays cover; E_hint (0: E): the edge count the
+// host-side choices (sample form, stride) are made with.
 void launch_sample_hist(const Graph& g, const uint32_t* ebi, const uint32_t* ebj, const uint32_t* ei,
                         const uint32_t* ej, const float* es, uint64_t E, uint64_t want, float key_floor, uint32_t part,
-                        uint32_t parts, uint32_t* hist, uint32_t* es_hist, bool es_hist_ready, const Tuning& tn, hipStream_t st);
+                        uint32_t parts, uint32_t* hist, uint32_t* es_hist, bool es_hist_ready, const Tuning& tn, hipStream_t st,
+                        const uint64_t* E_dev = nullptr, uint64_t E_hint = 0);
 // es_hist: PR_HCOPIES x 256 words (control block) for the weight histogram of the heaviest-edge sample: zeroed, or —
 // es_hist_ready — already filled by launch_edge_fill
 // launch_sample_hist ALWAYS accumulates into PR_HCOPIES x 256 words (`hist` = the control block's copies);
@@ -203,7 +209,8 @@ void launch_sample_hist(const Graph& g, const uint32_t* ebi, const uint32_t* ebj
 void launch_hist_reduce(const uint32_t* copies, uint32_t* out, hipStream_t st);
 void launch_prune_bits(const Graph& g, const uint32_t* hist, bool hist_is_copies, const uint32_t* ei, const uint32_t* ej, const float* es,
                        uint64_t E, uint64_t want, float key_floor, uint64_t* mbits, float* smin, uint32_t* klb,
-                       const StrongList& sl, uint32_t* tcnt, const uint64_t* own, hipStream_t st);
+                       const StrongList& sl, uint32_t* tcnt, const uint64_t* own, hipStream_t st,
+                       const uint64_t* E_dev = nullptr);  // E_dev: as above; with sl.list the tcnt entries of [*E_dev, E) are zeroed too
 // sharded stage B, after the certificate: work estimate per row of the PRUNED graph (strong_rowcost_kernel), and — in one
 // single-block launch — its prefix and this rank's row / edge range (the rule of launch_shard_split)
 void launch_strong_rowcost(const Graph& g, const uint64_t* mbits, uint32_t* rowcost, hipStream_t st);
@@ -293,6 +300,9 @@ struct KeyView {
   uint64_t seg_stride;    // u32 words between segment starts
   const uint64_t* valid;  // real keys of segment s: valid[s * valid_stride]
   uint64_t valid_stride;  // u64 words
+  // plain view only, optional (device): the true key count when the host launched before it knew it — the kernels then
+  // look at min(M, *M_dev) keys; M is what the grids cover (host-free path, sc_capi.hip)
+  const uint64_t* M_dev;
 };
 KeyView plain_view(const uint32_t* wkey, uint64_t M);
 // `rounds` launches (histogram + pick by the last block to finish; 12 key bits each) find the exact threshold key
@@ -303,7 +313,7 @@ void launch_compact_count(const KeyView& view, const SelectState* s, uint32_t* b
                           hipStream_t st);
 void launch_compact_write(const KeyView& view, const SelectState* s, const uint32_t* blk_gt,
                           const uint32_t* blk_eq, const uint64_t* off_gt, const uint64_t* off_eq,
-                          uint64_t* sel_ord, uint32_t* sel_key, hipStream_t st);
+                          uint64_t* sel_ord, uint32_t* sel_key, uint64_t n_sel, hipStream_t st);  // n_sel: entries sel_ord / sel_key hold
 
 // both in ONE launch (decoupled look-back over the tiles); state: compact_state_bytes(M) of the caller's look-back
 // state area, epoch: this launch's (ScanExtra)
@@ -371,14 +381,20 @@ struct TriSource {
   // is cand_recs[(pos / cand_seg) * cand_stride + pos % cand_seg]   (cand_recs == nullptr: the local form above)
   const uint4* cand_recs;
   uint64_t cand_seg, cand_stride;  // entries per blob; uint4 units between blob record arrays
+  // host-free calls only (0: unchecked): what a looked-up {vertex, edge} must stay below — a call that turns out to have
+  // been launched on wrong assumptions (and is repeated) may find anything in the selection, and must not follow it
+  uint32_t lim_vertex, lim_edge;
+  uint64_t lim_ord;
 };
 // C1: RtSoA[c * ld_local + l], c = 0..11, for the local hypotheses of the shard (global rank index derived).
 // RtAoS (optional): also 12 consecutive floats per local hypothesis (ld_local x 12), for the lane = correspondence kernel
 // tile_job (optional): the filter's tile kernel rides in the same launch as extra workgroups (C1 alone leaves most of the
 // chip idle: T / 256 workgroups), which saves a launch on the critical path.
 struct FilterTileJob;
+// t_eff_dev (optional, device u64): the true length of the selection when the host launched with sh.T_eff = the requested
+// T before it knew (host-free path): positions at or beyond it are treated as padding and never looked up
 void launch_kabsch(const Points& pts, const TriSource& ts, const Shard& sh, float* RtSoA, float* RtAoS,
-                   const FilterTileJob* tile_job, hipStream_t st);
+                   const FilterTileJob* tile_job, hipStream_t st, const uint64_t* t_eff_dev = nullptr);
 // C1 on an explicit triangle list to AoS T x 12 (stage hook)
 void launch_kabsch_aos(const Points& pts, const uint32_t* tri, uint32_t T, float* Rt, hipStream_t st);
 // AoS T x 12 -> SoA planes (stage hook for sc_score_host)

@@ -117,17 +117,22 @@ __device__ __forceinline__ void load_triangle(const float* __restrict__ planes, 
 }
 
 // triangle g of the selected list, straight from the selection (two dependent lookups, no materialised list)
-__device__ __forceinline__ void tri_lookup(const TriSource& ts, uint32_t g, uint32_t v[3]) {
+// false: the selection holds something that must not be followed (TriSource::lim_*: host-free calls that will be repeated)
+__device__ __forceinline__ bool tri_lookup(const TriSource& ts, uint32_t g, uint32_t v[3]) {
   if (ts.cand_recs) {  // sharded stage B: the record travels with the candidate
     const uint64_t pos = ts.sel_ord[g], sg = pos / ts.cand_seg;
     const uint4 rec = ts.cand_recs[sg * ts.cand_stride + (pos - sg * ts.cand_seg)];
     v[0] = rec.x; v[1] = rec.y; v[2] = rec.z;
-    return;
+    return true;
   }
-  const uint2 ke = ts.kcol[ts.sel_ord[g]];
+  const uint64_t ord = ts.sel_ord[g];
+  if (ts.lim_ord && ord >= ts.lim_ord) return false;
+  const uint2 ke = ts.kcol[ord];
+  if (ts.lim_edge && ke.y >= ts.lim_edge) return false;
   v[0] = ts.ei[ke.y];
   v[1] = ts.ej[ke.y];
   v[2] = ke.x;
+  return !ts.lim_vertex || (v[0] < ts.lim_vertex && v[1] < ts.lim_vertex && v[2] < ts.lim_vertex);
 }
 
 __device__ void filter_tile_block(const float* __restrict__ planes, int n, int ld, const FilterTileJob& job, uint32_t block,
@@ -138,7 +143,8 @@ __device__ void gram_coef_wave(const GramCoef& coef, const GramInfo& gi, const f
 __global__ __launch_bounds__(256) void kabsch_shard_kernel(const float* __restrict__ planes, int n, int ld, TriSource ts,
                                                            Shard sh, float* __restrict__ RtSoA,
                                                            float* __restrict__ RtAoS, FilterTileJob job,
-                                                           uint32_t kabsch_blocks) {
+                                                           uint32_t kabsch_blocks,
+                                                           const uint64_t* __restrict__ t_eff_dev) {
   if (blockIdx.x >= kabsch_blocks) {  // the extra workgroups: C2's fp16 tile of the correspondences (see filter_tile_block)
     filter_tile_block(planes, n, ld, job, blockIdx.x - kabsch_blocks, gridDim.x - kabsch_blocks);
     return;
@@ -151,10 +157,11 @@ __global__ __launch_bounds__(256) void kabsch_shard_kernel(const float* __restri
   const uint32_t l = blockIdx.x * 256 + threadIdx.x;
   if (l >= sh.ld_local) return;
   float Rt[12];
-  if (l < sh.n_local) {
-    const uint32_t g = shard_global_index(l, sh.block, sh.rank, sh.world);
-    uint32_t v[3];
-    tri_lookup(ts, g, v);
+  // t_eff_dev: the launch was sized for sh.T_eff = the requested T before the host knew how many triangles there are; a
+  // position beyond the real selection holds nothing that may be dereferenced (the host repeats such a call: sc_capi.hip)
+  const uint32_t g = l < sh.n_local ? shard_global_index(l, sh.block, sh.rank, sh.world) : 0u;
+  uint32_t v[3];
+  if (l < sh.n_local && (!t_eff_dev || (uint64_t)g < *t_eff_dev) && tri_lookup(ts, g, v)) {
     float P[9], Q[9];
     load_triangle(planes, ld, v, P, Q);
     kabsch3(P, Q, Rt);
@@ -175,11 +182,11 @@ __global__ __launch_bounds__(256) void kabsch_shard_kernel(const float* __restri
 }
 
 void launch_kabsch(const Points& pts, const TriSource& ts, const Shard& sh, float* RtSoA, float* RtAoS,
-                   const FilterTileJob* tile_job, hipStream_t st) {
+                   const FilterTileJob* tile_job, hipStream_t st, const uint64_t* t_eff_dev) {
   if (sh.ld_local == 0) return;
   const uint32_t kb = sh.ld_local / 256, tb = tile_job ? (tile_job->rows + 255) / 256 : 0u;
   hipLaunchKernelGGL(kabsch_shard_kernel, dim3(kb + tb), dim3(256), 0, st, pts.planes, pts.n, pts.ld, ts, sh, RtSoA, RtAoS,
-                     tile_job ? *tile_job : FilterTileJob{}, kb);
+                     tile_job ? *tile_job : FilterTileJob{}, kb, t_eff_dev);
 }
 
 __global__ __launch_bounds__(256) void kabsch_aos_kernel(const float* __restrict__ planes, int ld,
@@ -1605,9 +1612,8 @@ __global__ __launch_bounds__(256) void finalize_kernel(const float* __restrict__
     }
   } else if (threadIdx.x == 0) {
     float Rt[12] = {1.f, 0.f, 0.f, 0.f, 1.f, 0.f, 0.f, 0.f, 1.f, 0.f, 0.f, 0.f};
-    if (k0 != 0) {
-      uint32_t v[3];
-      tri_lookup(ts, g, v);
+    uint32_t v[3];
+    if (k0 != 0 && tri_lookup(ts, g, v)) {
       float P[9], Q[9];
       load_triangle(planes, ld, v, P, Q);
       kabsch3(P, Q, Rt);

@@ -458,25 +458,35 @@ __global__ __launch_bounds__(256) void tri_count_events_kernel(const uint64_t* _
   }
   const uint64_t groups = (uint64_t)gridDim.x * (256 / TG);
   const uint64_t g0 = (uint64_t)blockIdx.x * (256 / TG) + (threadIdx.x / TG);
-  const uint32_t shard = (blockIdx.x * 4 + wave) & (EV_SHARDS - 1);
+  // region of this wave's NEXT ticket: it moves on by one with every ticket, so a wave with many events spreads them over
+  // the regions (r03: every wave kept one region and a region overflowed in one C4 call in three at 2.2 records of capacity
+  // per event — the call then fell back to the row-walking key kernel)
+  uint32_t shard = (blockIdx.x * 4 + wave) & (EV_SHARDS - 1);
   const uint64_t trips = (x1 - x0 + groups - 1) / groups;  // the same for every lane of the wave
   const int wbase = wave * EVW;
   uint32_t scnt = 0;  // records staged by this wave (wave-uniform)
   auto flush = [&]() {  // wave-uniform
-    uint32_t base = 0;
-    if (lane == 0) base = atomicAdd(&ev.fill[shard], scnt);
-    base = __builtin_amdgcn_readfirstlane(base);
-    for (uint32_t k = lane; k < scnt; k += 64) {
-      const uint64_t pos = (uint64_t)base + k;
-      if (pos < ev.shard_cap) {
-        const uint64_t o = (uint64_t)shard * ev.shard_cap + pos;
-        const int q = wbase + (int)k;
+    // A ticket that does not fit whole leaves no hole: the part inside the region is written (the key kernel reads
+    // min(fill, capacity) records of a region), the rest moves on to the next region.  So the list overflows only when the
+    // regions are full TOGETHER — a single region filling early (the strong list keeps the edges of a row together, so a run
+    // of waves inside the inlier clique stages several times the mean) costs a second ticket, not the whole call's event path.
+    uint32_t start = 0;  // records [start, scnt) are still to be placed
+    for (int tries = 0; tries < EV_SHARDS && start < scnt; tries++) {
+      const uint32_t cnt = scnt - start;
+      uint32_t base = 0;
+      if (lane == 0) base = atomicAdd(&ev.fill[shard], cnt);
+      base = __builtin_amdgcn_readfirstlane(base);
+      const uint32_t fit = (uint64_t)base >= ev.shard_cap ? 0u : (uint32_t)min((uint64_t)cnt, ev.shard_cap - (uint64_t)base);
+      for (uint32_t k = lane; k < fit; k += 64) {
+        const uint64_t o = (uint64_t)shard * ev.shard_cap + (uint64_t)base + k;
+        const int q = wbase + (int)(start + k);
         ev.m[o] = l_m[q]; ev.wi[o] = l_wi[q]; ev.wj[o] = l_wj[q]; ev.a[o] = l_a[q]; ev.b[o] = l_b[q];
         ev.e[o] = l_e[q]; ev.rb[o] = l_rb[q];
-      } else {
-        *ev.overflow = 1u;
       }
+      start += fit;
+      shard = (shard + 1u) & (EV_SHARDS - 1);
     }
+    if (start < scnt && lane == 0) *ev.overflow = 1u;
     scnt = 0;
   };
   for (uint64_t trip = 0; trip < trips; trip++) {
@@ -758,7 +768,12 @@ __global__ __launch_bounds__(256) void tri_sample_hist_kernel(const uint64_t* __
                                                               uint32_t klo, uint32_t shift,
                                                               uint32_t* __restrict__ hist,
                                                               const uint32_t* __restrict__ es_hist, uint64_t target,
-                                                              uint32_t wlo, uint32_t wshift) {
+                                                              uint32_t wlo, uint32_t wshift,
+                                                              const uint64_t* __restrict__ E_dev) {
+  // Launched before the host knew the count (E: what the arrays hold).  More edges than that: the CSR indices this kernel
+  // derives from the bit rows would point beyond the edge arrays — nothing may run (the host repeats the call: sc_capi.hip).
+  if (E_dev && *E_dev > E) return;
+  if (E_dev) E = *E_dev;
   __shared__ uint32_t lh[PR_BINS * PR_COPIES];  // [bin][copy]
   __shared__ uint32_t l_e[TOP ? SM_CHUNK : 1];  // TOP: the qualifying edges of the current chunk
   __shared__ uint32_t s_theta, s_cnt, s_wtot[4];
@@ -900,7 +915,13 @@ __global__ __launch_bounds__(256) void prune_bits_kernel(const uint32_t* __restr
                                                          float* __restrict__ smin_out,
                                                          uint32_t* __restrict__ klb_out, StrongList sl,
                                                          uint32_t* __restrict__ tcnt,
-                                                         const uint64_t* __restrict__ own) {
+                                                         const uint64_t* __restrict__ own,
+                                                         const uint64_t* __restrict__ E_dev) {
+  // E: what the grid and the arrays cover; Ea: the edges there really are (E_dev: launched before the host knew).  More than
+  // the arrays hold: nothing may run — no strong edge is listed, so the counting and key kernels that follow find no work
+  // (the host repeats the call)
+  if (E_dev && *E_dev > E) return;
+  const uint64_t Ea = E_dev ? *E_dev : E;
   __shared__ uint64_t lds[8];
   __shared__ float s_smin;
   __shared__ uint32_t s_klb, s_base, s_wcnt[4];
@@ -925,7 +946,7 @@ __global__ __launch_bounds__(256) void prune_bits_kernel(const uint32_t* __restr
   const uint32_t region = blockIdx.x & (ST_SHARDS - 1);
   const uint64_t chunk = sl.region_blocks ? (uint64_t)region * sl.region_blocks + blockIdx.x / ST_SHARDS : (uint64_t)blockIdx.x;
   const uint64_t e = (sl.region_blocks && blockIdx.x / ST_SHARDS >= sl.region_blocks) ? E : chunk * 256 + threadIdx.x;
-  bool strong = e < E && es[e] >= smin;
+  bool strong = e < Ea && es[e] >= smin;
   if (strong) {  // the strong bit matrix is whole on every rank: membership of ANY vertex pair is looked up in it
     const uint32_t i = ei[e], j = ej[e];
     atomicOr(&mbits[(size_t)i * W + (j >> 6)], 1ull << (j & 63));
@@ -976,9 +997,11 @@ static void prune_window(float key_floor, uint32_t* klo_out, uint32_t* shift_out
 
 void launch_sample_hist(const Graph& g, const uint32_t* ebi, const uint32_t* ebj, const uint32_t* ei,
                         const uint32_t* ej, const float* es, uint64_t E, uint64_t want, float key_floor, uint32_t part,
-                        uint32_t parts, uint32_t* hist, uint32_t* es_hist, bool es_hist_ready, const Tuning& tn, hipStream_t st) {
+                        uint32_t parts, uint32_t* hist, uint32_t* es_hist, bool es_hist_ready, const Tuning& tn, hipStream_t st,
+                        const uint64_t* E_dev, uint64_t E_hint) {
   uint32_t klo, shift;
   prune_window(key_floor, &klo, &shift);
+  const uint64_t Ed = E_hint ? E_hint : E;  // the count the host-side choices are made with
   // Which form (r02 sweeps, profiles/r02_ab_heaviest_edge_sample.txt and r02_ab_sample_size.txt): the heaviest edges
   // certify a much tighter bound per sampled edge, but each of them is a costly one (an edge between two inliers has
   // hundreds of common neighbours).  That pays when T is a small part of the graph's triangles — C3 (N = 20 000, T = 200 k):
@@ -990,7 +1013,7 @@ void launch_sample_hist(const Graph& g, const uint32_t* ebi, const uint32_t* ebj
   // 890 T, C1 320 T, C4 90 T.
   // sample_mode: 0 = by this rule (E^2 / N >= 600 T), 1 = every stride-th edge, 2 = the heaviest edges.
   const bool top = tn.sample_mode == 2 ||
-                   (tn.sample_mode == 0 && (double)E * (double)E / (double)(g.n > 0 ? g.n : 1) >= 600.0 * (double)want);
+                   (tn.sample_mode == 0 && (double)Ed * (double)Ed / (double)(g.n > 0 ? g.n : 1) >= 600.0 * (double)want);
   if (top && es_hist) {
     // the heaviest edges (TOP form): weight histogram, then the sample itself
     uint32_t wlo, wshift;
@@ -1011,7 +1034,7 @@ void launch_sample_hist(const Graph& g, const uint32_t* ebi, const uint32_t* ebj
     uint64_t nb = (E + (uint64_t)SM_CHUNK * parts - 1) / ((uint64_t)SM_CHUNK * parts);
     if (nb > 8192) nb = 8192;
     if (tn.sample_blocks) nb = tn.sample_blocks;
-#define SC_LAUNCH_TOP(TGV) hipLaunchKernelGGL((tri_sample_hist_kernel<TGV, true>), dim3((unsigned)nb), dim3(256), 0, st, g.bits, g.W, g.wpre, ebi, ebj, ei, ej, es, E, 1u, part, parts, klo, shift, hist, es_hist, target, wlo, wshift)
+#define SC_LAUNCH_TOP(TGV) hipLaunchKernelGGL((tri_sample_hist_kernel<TGV, true>), dim3((unsigned)nb), dim3(256), 0, st, g.bits, g.W, g.wpre, ebi, ebj, ei, ej, es, E, 1u, part, parts, klo, shift, hist, es_hist, target, wlo, wshift, E_dev)
     if (tg == 4) SC_LAUNCH_TOP(4); else if (tg == 8) SC_LAUNCH_TOP(8); else if (tg == 32) SC_LAUNCH_TOP(32); else if (tg == 64) SC_LAUNCH_TOP(64); else SC_LAUNCH_TOP(16);
 #undef SC_LAUNCH_TOP
     return;
@@ -1022,7 +1045,7 @@ void launch_sample_hist(const Graph& g, const uint32_t* ebi, const uint32_t* ebj
   uint64_t target = want * 5 / 8;
   if (target < 32768) target = 32768;
   if (tn.sample_edges) target = tn.sample_edges;
-  uint64_t stride = E / (target ? target : 1);
+  uint64_t stride = Ed / (target ? target : 1);
   if (stride < 1) stride = 1;
   if (stride > 64) stride = 64;
   const uint64_t n_s = (E + stride - 1) / stride;
@@ -1034,20 +1057,20 @@ void launch_sample_hist(const Graph& g, const uint32_t* ebi, const uint32_t* ebj
   uint64_t nb = (n_loc + (256 / tg) - 1) / (256 / tg);
   // about one sampled edge per group (measured: 256 blocks 70 us, 1024+ blocks 35 us on C2)
   if (nb > 4096) nb = 4096;
-#define SC_LAUNCH_SAMPLE(TGV) hipLaunchKernelGGL((tri_sample_hist_kernel<TGV, false>), dim3((unsigned)nb), dim3(256), 0, st, g.bits, g.W, g.wpre, ebi, ebj, ei, ej, es, E, (uint32_t)stride, part, parts, klo, shift, hist, (const uint32_t*)nullptr, (uint64_t)0, 0u, 0u)
+#define SC_LAUNCH_SAMPLE(TGV) hipLaunchKernelGGL((tri_sample_hist_kernel<TGV, false>), dim3((unsigned)nb), dim3(256), 0, st, g.bits, g.W, g.wpre, ebi, ebj, ei, ej, es, E, (uint32_t)stride, part, parts, klo, shift, hist, (const uint32_t*)nullptr, (uint64_t)0, 0u, 0u, E_dev)
   if (tg == 4) SC_LAUNCH_SAMPLE(4); else if (tg == 8) SC_LAUNCH_SAMPLE(8); else if (tg == 32) SC_LAUNCH_SAMPLE(32); else if (tg == 64) SC_LAUNCH_SAMPLE(64); else SC_LAUNCH_SAMPLE(16);
 #undef SC_LAUNCH_SAMPLE
 }
 
 void launch_prune_bits(const Graph& g, const uint32_t* hist, bool hist_is_copies, const uint32_t* ei, const uint32_t* ej, const float* es,
                        uint64_t E, uint64_t want, float key_floor, uint64_t* mbits, float* smin, uint32_t* klb,
-                       const StrongList& sl, uint32_t* tcnt, const uint64_t* own, hipStream_t st) {
+                       const StrongList& sl, uint32_t* tcnt, const uint64_t* own, hipStream_t st, const uint64_t* E_dev) {
   uint32_t klo, shift;
   prune_window(key_floor, &klo, &shift);
   const uint64_t blocks = sl.region_blocks ? (uint64_t)sl.region_blocks * ST_SHARDS : (E + 255) / 256;
   hipLaunchKernelGGL(prune_bits_kernel, dim3((unsigned)blocks), dim3(256), 0, st, hist,
                      hist_is_copies ? PR_HCOPIES : 1, want, klo, shift, ei,
-                     ej, es, E, g.W, reinterpret_cast<unsigned long long*>(mbits), smin, klb, sl, tcnt, own);
+                     ej, es, E, g.W, reinterpret_cast<unsigned long long*>(mbits), smin, klb, sl, tcnt, own, E_dev);
 }
 
 // Sharded stage B, after the certificate: what enumerating row i of the PRUNED graph costs — 32 x the triangles of a
@@ -1235,6 +1258,9 @@ __device__ __forceinline__ void hist_add(uint32_t* lh, bool in, uint32_t bin) {
 // (acquire) and reads the bins with device-scope atomic loads.
 // four keys of the view at logical positions 4q .. 4q + 3 (entries beyond a segment's valid count read as 0, which
 // no window and no threshold ever admits: real keys are positive)
+// keys the view really holds (M_dev: the launch was sized before the host knew the count)
+__device__ __forceinline__ uint64_t view_count(const KeyView& v) { return v.M_dev ? min(v.M, *v.M_dev) : v.M; }
+
 template <bool SEG>
 __device__ __forceinline__ uint4 view_load4(const KeyView& v, uint64_t q) {
   if (!SEG) return reinterpret_cast<const uint4*>(v.base)[q];
@@ -1253,7 +1279,7 @@ __device__ __forceinline__ uint4 view_load4(const KeyView& v, uint64_t q) {
 template <bool SEG>
 __global__ __launch_bounds__(SEL_THREADS) void select_round_kernel(KeyView view, SelectState* __restrict__ sel,
                                                                    int rounds_left) {
-  const uint64_t M = view.M;
+  const uint64_t M = view_count(view);
   const uint32_t* __restrict__ wkey = view.base;
   __shared__ uint32_t lh[SEL_BINS];
   __shared__ uint64_t lds[8];
@@ -1348,7 +1374,7 @@ __global__ __launch_bounds__(SEL_THREADS) void select_round_kernel(KeyView view,
   }
 }
 
-KeyView plain_view(const uint32_t* wkey, uint64_t M) { return KeyView{wkey, M, 0, 0, nullptr, 0}; }
+KeyView plain_view(const uint32_t* wkey, uint64_t M) { return KeyView{wkey, M, 0, 0, nullptr, 0, nullptr}; }
 
 void launch_select_rounds(const KeyView& view, SelectState* s, int rounds, const Tuning& tn, hipStream_t st) {
   const uint64_t M = view.M;
@@ -1377,7 +1403,7 @@ size_t compact_blocks(uint64_t M) { return (size_t)((M + CP_TILE - 1) / CP_TILE)
 template <bool SEG>
 __device__ __forceinline__ void load_tile_keys(const KeyView& view, uint64_t base, uint32_t keys[CP_ITEMS], int& valid) {
   const uint32_t* __restrict__ wkey = view.base;
-  const uint64_t M = view.M;
+  const uint64_t M = view_count(view);
   if (SEG) {  // CP_ITEMS == 4 and seg_len % 4 == 0: one group of the view
     const uint4 k4 = base < M ? view_load4<true>(view, base >> 2) : make_uint4(0u, 0u, 0u, 0u);
     keys[0] = k4.x; keys[1] = k4.y; keys[2] = k4.z; keys[3] = k4.w;
@@ -1437,7 +1463,9 @@ __global__ __launch_bounds__(CP_THREADS) void compact_write_kernel(KeyView view,
                                                                    const uint64_t* __restrict__ off_gt,
                                                                    const uint64_t* __restrict__ off_eq,
                                                                    uint64_t* __restrict__ sel_ord,
-                                                                   uint32_t* __restrict__ sel_key) {
+                                                                   uint32_t* __restrict__ sel_key, uint64_t n_sel) {
+  // n_sel: entries sel_ord / sel_key hold.  A position at or beyond it cannot come out of a consistent select; a call that
+  // was launched before the host knew the counts (and is about to be repeated) may hold anything, and must stay in bounds.
   __shared__ uint64_t lds[8];
   const uint32_t kstar = sel->kstar;
   const uint64_t need_eq = sel->need_eq;
@@ -1474,8 +1502,7 @@ __global__ __launch_bounds__(CP_THREADS) void compact_write_kernel(KeyView view,
       const bool isg = key > kstar, isq = key == kstar;
       if (isg || (isq && eq_before < need_eq)) {
         const uint64_t pos = gt_before + (eq_before < need_eq ? eq_before : need_eq);
-        sel_ord[pos] = base + k;
-        sel_key[pos] = key;
+        if (pos < n_sel) { sel_ord[pos] = base + k; sel_key[pos] = key; }
       }
       gt_before += isg;
       eq_before += isq;
@@ -1555,15 +1582,15 @@ void launch_compact_fused(const KeyView& view, const SelectState* s, const LbArg
 
 void launch_compact_write(const KeyView& view, const SelectState* s, const uint32_t* blk_gt,
                           const uint32_t* blk_eq, const uint64_t* off_gt, const uint64_t* off_eq,
-                          uint64_t* sel_ord, uint32_t* sel_key, hipStream_t st) {
+                          uint64_t* sel_ord, uint32_t* sel_key, uint64_t n_sel, hipStream_t st) {
   if (view.M == 0) return;
   const dim3 grid((unsigned)compact_blocks(view.M));
   if (view.seg_len)
     hipLaunchKernelGGL(compact_write_kernel<true>, grid, dim3(CP_THREADS), 0, st, view, s, blk_gt, blk_eq, off_gt, off_eq,
-                       sel_ord, sel_key);
+                       sel_ord, sel_key, n_sel);
   else
     hipLaunchKernelGGL(compact_write_kernel<false>, grid, dim3(CP_THREADS), 0, st, view, s, blk_gt, blk_eq, off_gt, off_eq,
-                       sel_ord, sel_key);
+                       sel_ord, sel_key, n_sel);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1707,6 +1734,7 @@ KeyView cand_view(const void* blobs, size_t blob_bytes, uint32_t world, size_t c
   v.seg_stride = blob_bytes / 4;
   v.valid = reinterpret_cast<const uint64_t*>(p) + 1;  // hdr[1] = entries sent
   v.valid_stride = blob_bytes / 8;
+  v.M_dev = nullptr;
   return v;
 }
 

@@ -11,7 +11,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def _declared():
-    text = open(os.path.join(ROOT, "include", "saccot.h")).read()
+    # the drop-in surface (saccot.h) and the test / tuning hooks (saccot_debug.h)
+    text = open(os.path.join(ROOT, "include", "saccot.h")).read() + open(os.path.join(ROOT, "include", "saccot_debug.h")).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
     return sorted(set(re.findall(r"\b(sc_[a-z_]+)\s*\(", text)))
 
@@ -59,7 +60,7 @@ def test_product_reads_no_environment(pkg):
     und = subprocess.check_output(["nm", "-D", "--undefined-only", pkg.api.LIB_PATH]).decode()
     assert "getenv" not in und
     exe = os.path.join(ROOT, "tests", ".abi_probe_dbg")
-    src = '#include <stdio.h>\n#include <stddef.h>\n#include "saccot.h"\nint main(void){printf("%zu %zu %zu %zu %zu", sizeof(sc_debug), offsetof(sc_debug, sample_edges), offsetof(sc_debug, compat_rows), sizeof(sc_debug_info), offsetof(sc_debug_info, filter_recounts));return 0;}\n'
+    src = '#include <stdio.h>\n#include <stddef.h>\n#include "saccot_debug.h"\nint main(void){printf("%zu %zu %zu %zu %zu", sizeof(sc_debug), offsetof(sc_debug, sample_edges), offsetof(sc_debug, compat_rows), sizeof(sc_debug_info), offsetof(sc_debug_info, filter_recounts));return 0;}\n'
     subprocess.run(["gcc", "-I", os.path.join(ROOT, "include"), "-x", "c", "-", "-o", exe], input=src.encode(), check=True)
     try:
         a, b, c, d, e = (int(x) for x in subprocess.check_output([exe]).decode().split())

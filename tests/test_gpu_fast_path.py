@@ -1,0 +1,168 @@
+"""GPU: the host-free form of sc_register_device (include/saccot.h, sc_register_device_async / sc_wait).
+
+A call that repeats the shape of the previous call on its context enqueues the whole chain without waiting for stage B's
+two counts; sc_wait validates and, when a count outgrew what the launches covered (or the graph had fewer triangles than
+T), repeats the call the waiting way.  Either way every output must be the waiting path's, bit for bit — and that path
+is what tests/test_gpu_parity.py pins to the CPU restatement.
+"""
+import numpy as np
+import pytest
+
+from conftest import nan_equal_bits
+
+pytestmark = pytest.mark.gpu
+
+
+def _dev(torch, scene, dev):
+    return torch.from_numpy(scene.src).to(dev), torch.from_numpy(scene.tgt).to(dev)
+
+
+def _same(a, b):
+    return (np.array_equal(a["mask"], b["mask"]) and nan_equal_bits(a["Rt"], b["Rt"]) and a["rc"] == b["rc"]
+            and all(a["st"][k] == b["st"][k] for k in ("edges", "tri_total", "tri_kept", "tri_scored", "best_rank", "best_count")))
+
+
+def _run(torch, r, ds, dt, n, p, dev):
+    d_Rt = torch.zeros(12, dtype=torch.float32, device=dev)
+    d_mask = torch.full((n,), 7, dtype=torch.uint8, device=dev)
+    rc, st = r.register_device(ds.data_ptr(), dt.data_ptr(), n, p, d_Rt.data_ptr(), d_mask.data_ptr())
+    torch.cuda.synchronize()
+    return dict(rc=rc, st=st, Rt=d_Rt.cpu().numpy(), mask=d_mask.cpu().numpy(), fast=r.debug_last()["fast_path"])
+
+
+@pytest.mark.parametrize("name", ["C1", "C2", "C4"])
+def test_host_free_repeats_are_the_waited_call(pkg, O, name):
+    import torch
+    dev = torch.device("cuda:0")
+    cfg, scene = pkg.synth.make_config_scene(name)
+    ds, dt = _dev(torch, scene, dev)
+    p = pkg.make_params(**cfg.params())
+    r = pkg.Registrar(0)
+    try:
+        r.set_stream(torch.cuda.current_stream().cuda_stream)
+        first = _run(torch, r, ds, dt, cfg.n, p, dev)
+        assert first["fast"] == 0                                   # a first call waits
+        for _ in range(3):
+            again = _run(torch, r, ds, dt, cfg.n, p, dev)
+            assert again["fast"] == 1, "a repeated shape did not take the host-free form: " + r._lib.sc_last_error(r._h).decode()
+            assert _same(again, first)
+        assert first["st"]["bytes_moved"] > 4 * cfg.n * cfg.n      # (dense S alone is 4 n^2)
+        r.set_debug(no_fast=1)
+        for _ in range(2):
+            waited = _run(torch, r, ds, dt, cfg.n, p, dev)
+            assert waited["fast"] == 0 and _same(waited, first)
+    finally:
+        r.close()
+    ref = O.register(scene.src, scene.tgt, threads=8, **cfg.params())
+    assert np.array_equal(first["mask"], ref["mask"]) and first["st"]["best_rank"] == ref["best_rank"]
+    assert nan_equal_bits(first["Rt"], np.concatenate([ref["R"].ravel(), ref["t"]]))
+
+
+def test_host_free_call_that_fails_validation_is_repeated(pkg, O):
+    """Same n and parameters, different graphs: far fewer triangles than T, outliers only, an edge count far beyond what
+    the last call's launches cover.  Each is detected at sc_wait and repeated; results equal a fresh context's."""
+    import torch
+    dev = torch.device("cuda:0")
+    n, tau, T = 2000, 0.02, 10000
+    kw = dict(sigma=tau, t_cmp=0.9, tau=tau, min_len=tau, max_triangles=T, rank_mode=0)
+    p = pkg.make_params(**kw)
+    scenes = dict(regular=pkg.synth.make_scene(n, 0.20, 1.0, tau, 1001),
+                  sparse=pkg.synth.make_scene(n, 0.01, 6.0, tau, 55),      # 6053 edges, 310 triangles: fewer than T
+                  tiny=pkg.synth.make_scene(n, 0.01, 10.0, tau, 55),       # 3690 edges: below the size that is pruned at all
+                  outliers=pkg.synth.make_scene(n, 0.0, 1.0, tau, 56),     # 27 481 edges, 4870 triangles
+                  dense=pkg.synth.make_scene(n, 0.60, 1.0, tau, 57))       # ~9 x the edges
+    r = pkg.Registrar(0)
+    fresh = {}
+    try:
+        r.set_stream(torch.cuda.current_stream().cuda_stream)
+        for nm, sc in scenes.items():
+            f = pkg.Registrar(0)
+            f.set_stream(torch.cuda.current_stream().cuda_stream)
+            ds, dt = _dev(torch, sc, dev)
+            fresh[nm] = _run(torch, f, ds, dt, n, p, dev)
+            f.close()
+        assert fresh["sparse"]["st"]["tri_kept"] < T and fresh["dense"]["st"]["edges"] > 3 * fresh["regular"]["st"]["edges"]
+        # (scene, the fast_path state(s) the call must report; None: either)
+        seq = [("regular", 0), ("regular", 1), ("sparse", 2), ("regular", 0), ("regular", 1), ("tiny", 2), ("regular", 0),
+               ("regular", 1), ("outliers", 2), ("regular", 0), ("regular", 1), ("dense", 2), ("dense", 1), ("dense", 1),
+               ("regular", None), ("regular", None), ("regular", 1), ("sparse", 2)]
+        for nm, ef in seq:
+            ds, dt = _dev(torch, scenes[nm], dev)
+            got = _run(torch, r, ds, dt, n, p, dev)
+            assert ef is None or got["fast"] == ef, (nm, got["fast"], ef)
+            assert _same(got, fresh[nm]), nm
+    finally:
+        r.close()
+    for nm in ("sparse", "tiny", "outliers"):
+        ref = O.register(scenes[nm].src, scenes[nm].tgt, threads=8, **kw)
+        assert fresh[nm]["rc"] == ref["rc"] and np.array_equal(fresh[nm]["mask"], ref["mask"])
+        assert fresh[nm]["st"]["best_rank"] == ref["best_rank"] and fresh[nm]["st"]["tri_kept"] == ref["t_eff"]
+
+
+def test_async_two_contexts_on_one_stream(pkg):
+    """A stream of frames: two contexts bound to the same stream alternate, each call enqueued before the previous one is
+    waited for.  Every frame's outputs equal the synchronous call's; at most one call may be outstanding per context."""
+    import torch
+    dev = torch.device("cuda:0")
+    cfg, scene = pkg.synth.make_config_scene("C1")
+    cfg0, scene0 = pkg.synth.make_config_scene("C0")
+    p, p0 = pkg.make_params(**cfg.params()), pkg.make_params(**cfg0.params())
+    ds, dt = _dev(torch, scene, dev)
+    ds0, dt0 = _dev(torch, scene0, dev)
+    regs = [pkg.Registrar(0), pkg.Registrar(0)]
+    try:
+        st = torch.cuda.current_stream().cuda_stream
+        for r in regs:
+            r.set_stream(st)
+        base = _run(torch, regs[0], ds, dt, cfg.n, p, dev)
+        base0 = _run(torch, regs[0], ds0, dt0, cfg0.n, p0, dev)
+        outs = [(torch.zeros(12, dtype=torch.float32, device=dev), torch.zeros(cfg.n, dtype=torch.uint8, device=dev)) for _ in regs]
+        for r, o in zip(regs, outs):                                 # warm both contexts on the big shape
+            r.register_device(ds.data_ptr(), dt.data_ptr(), cfg.n, p, o[0].data_ptr(), o[1].data_ptr())
+        results, n_fast = [], 0
+        regs[0].register_device_async(ds.data_ptr(), dt.data_ptr(), cfg.n, p, outs[0][0].data_ptr(), outs[0][1].data_ptr())
+        with pytest.raises(pkg.SacCotError):                         # a second outstanding call on the same context
+            regs[0].register_device_async(ds.data_ptr(), dt.data_ptr(), cfg.n, p, outs[0][0].data_ptr(), outs[0][1].data_ptr())
+        for k in range(1, 9):
+            cur, prev = k & 1, (k - 1) & 1
+            regs[cur].register_device_async(ds.data_ptr(), dt.data_ptr(), cfg.n, p, outs[cur][0].data_ptr(), outs[cur][1].data_ptr())
+            rc, s = regs[prev].wait()
+            n_fast += regs[prev].debug_last()["fast_path"] == 1
+            results.append((rc, s, outs[prev][0].cpu().numpy().copy(), outs[prev][1].cpu().numpy().copy()))
+        rc, s = regs[0].wait()
+        results.append((rc, s, outs[0][0].cpu().numpy().copy(), outs[0][1].cpu().numpy().copy()))
+        assert n_fast >= 6
+        for rc, s, Rt, mask in results:
+            assert rc == base["rc"] and s["best_rank"] == base["st"]["best_rank"] and s["edges"] == base["st"]["edges"]
+            assert np.array_equal(mask, base["mask"]) and nan_equal_bits(Rt, base["Rt"])
+        with pytest.raises(pkg.SacCotError):                         # nothing outstanding
+            regs[1].wait()
+        # a different shape in between is simply a waited call; the shape after it waits once, then is host-free again
+        got0 = _run(torch, regs[1], ds0, dt0, cfg0.n, p0, dev)
+        assert got0["fast"] == 0 and _same(got0, base0)
+        a = _run(torch, regs[1], ds, dt, cfg.n, p, dev)
+        b = _run(torch, regs[1], ds, dt, cfg.n, p, dev)
+        assert (a["fast"], b["fast"]) == (0, 1) and _same(a, base) and _same(b, base)
+    finally:
+        for r in regs:
+            r.close()
+
+
+def test_host_free_through_the_host_entry_and_with_flags(pkg, O):
+    """sc_register (host arrays) sits on the same machinery; refinement, the truncated scores and SC_FLAG_NO_DENSE_S ride
+    along; a flag or parameter that differs from the last call's makes the call wait."""
+    cfg, scene = pkg.synth.make_config_scene("C1")
+    r = pkg.Registrar(0)
+    try:
+        for extra in (dict(), dict(flags=pkg.SC_FLAG_REFINE), dict(score_mode=1), dict(flags=pkg.SC_FLAG_NO_DENSE_S)):
+            kw = dict(cfg.params(), **extra)
+            a = r.register(scene.src, scene.tgt, **kw)
+            assert r.debug_last()["fast_path"] == 0, extra
+            b = r.register(scene.src, scene.tgt, **kw)
+            assert r.debug_last()["fast_path"] == 1, extra
+            assert np.array_equal(a["mask"], b["mask"]) and nan_equal_bits(a["R"], b["R"]) and nan_equal_bits(a["t"], b["t"])
+            assert a["stats"]["best_rank"] == b["stats"]["best_rank"] and a["stats"]["best_count"] == b["stats"]["best_count"]
+            ref = O.register(scene.src, scene.tgt, threads=8, score_mode=extra.get("score_mode", 0), **cfg.params())
+            assert np.array_equal(b["mask"], ref["mask"]) and b["stats"]["best_rank"] == ref["best_rank"]
+    finally:
+        r.close()
