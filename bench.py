@@ -100,26 +100,81 @@ def issue_model(n: int, n_local: int, us: float, info: dict) -> dict:
             "recounts": info.get("filter_recounts")}
 
 
-def spawn_ranks(n: int) -> int:
+def spawn_ranks(n: int, deadline_s: float = 1500.0) -> int:
     """`python bench.py --gpus N` started WITHOUT a launcher (WORLD_SIZE unset): start the N ranks as fresh child
     processes — this parent has not touched the GPU (torch is not even imported yet) and never does; no re-exec.  The
     children get the environment torch.distributed.run would give them; rank 0 prints the one JSON line, which passes
-    through; the exit code is the worst of the children's."""
+    through; the exit code is the worst of the children's.
+    The children are SUPERVISED: a rank that dies early (import error, HIP initialisation, an assert) would
+    leave its peers blocked in the rendezvous or in a collective until the backend's own timeout — minutes of a held GPU
+    lease and no JSON line.  So the parent polls all of them; on the first non-zero exit, or at the overall deadline, the
+    others are terminated (killed after a grace period) and that code is returned.  The rendezvous port is picked by
+    bind-then-close, which another process can take before rank 0 binds it: a start that fails within the first seconds with
+    an address-in-use message on rank 0's stderr is repeated once on a fresh port."""
     import socket
     import subprocess
-    with socket.socket() as sk:
-        sk.bind(("127.0.0.1", 0))
-        port = sk.getsockname()[1]
-    procs = []
-    for r in range(n):
-        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
-                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
-        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
-    rc = 0
-    for pr in procs:
-        rc = max(rc, abs(pr.wait()))
-    return rc
+    import tempfile
+    import time
+
+    def free_port() -> int:
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            return sk.getsockname()[1]
+
+    def stop(procs) -> None:
+        for pr in procs:
+            if pr.poll() is None:
+                pr.terminate()
+        t_end = time.monotonic() + 10.0
+        for pr in procs:
+            try:
+                pr.wait(timeout=max(0.1, t_end - time.monotonic()))
+            except subprocess.TimeoutExpired:
+                pr.kill()
+                pr.wait()
+
+    for attempt in range(2):
+        port = free_port()
+        procs, errs = [], []
+        t0 = time.monotonic()
+        for r in range(n):
+            env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                       MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+            env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+            # rank 0's stderr goes through a file so that an address-in-use failure can be recognised; it is replayed below
+            ef = tempfile.TemporaryFile(mode="w+b") if r == 0 else None
+            errs.append(ef)
+            procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                          stderr=ef if ef is not None else None))
+        rc = 0
+        while True:
+            codes = [pr.poll() for pr in procs]
+            bad = [abs(c) for c in codes if c not in (None, 0)]
+            if bad:
+                rc = max(bad)
+                stop(procs)
+                break
+            if all(c == 0 for c in codes):
+                break
+            if time.monotonic() - t0 > deadline_s:
+                print(f"bench.py: ranks still running after {deadline_s:.0f} s: terminating them", file=sys.stderr)
+                stop(procs)
+                rc = 124
+                break
+            time.sleep(0.05)
+        text = b""
+        if errs[0] is not None:
+            errs[0].seek(0)
+            text = errs[0].read()
+            errs[0].close()
+        in_use = rc != 0 and time.monotonic() - t0 < 60.0 and (b"EADDRINUSE" in text or b"ddress already in use" in text)
+        if in_use and attempt == 0:
+            print("bench.py: the rendezvous port was taken before rank 0 bound it: starting the ranks once more", file=sys.stderr)
+            continue
+        sys.stderr.buffer.write(text)
+        sys.stderr.flush()
+        return rc
+    return 1
 
 
 def main() -> int:
@@ -147,6 +202,11 @@ def main() -> int:
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         return spawn_ranks(args.gpus)
+    if os.environ.get("SC_BENCH_SUPERVISION_TEST") and "WORLD_SIZE" in os.environ:
+        # tests/test_shard_gloo.py: rank 1 dies at once, the others would wait for it forever — the parent must end them
+        if int(os.environ.get("RANK", "0")) == 1:
+            return 7
+        __import__("time").sleep(3600)
 
     import torch
     import torch.distributed as dist

@@ -24,9 +24,14 @@ def _stale(target: str, deps: list[str]) -> bool:
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build_library(force: bool = False, verbose: bool = False) -> str:
+def build_library(force: bool = False, verbose: bool = False, ablations: bool = False) -> str:
+    """ablations: also compile the scheduling / timing-only variants of the C2 filter kernels (-DSC_ABLATIONS; the lab
+    build tools/pmc_gram_variants.sh and tools/ab_stage.py sweeps use).  The default build — what ships and what the tests
+    load — holds variant 0 only; the two builds keep their objects in different directories and share the .so name, so an
+    ablation build must be followed by a default build before anything else runs."""
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    objdir = os.path.join(CSRC, "build")
+    objdir = os.path.join(CSRC, "build_ablations" if ablations else "build")
+    flags = FLAGS + (["-DSC_ABLATIONS"] if ablations else [])
     os.makedirs(objdir, exist_ok=True)
     hdrs = [os.path.join(CSRC, h) for h in HEADERS] + [os.path.abspath(__file__)]
     objs = []
@@ -35,17 +40,22 @@ def build_library(force: bool = False, verbose: bool = False) -> str:
         obj = os.path.join(objdir, s.replace(".hip", ".o"))
         objs.append(obj)
         if force or _stale(obj, [src] + hdrs):
-            cmd = [hipcc] + FLAGS + ["-c", src, "-o", obj]
+            cmd = [hipcc] + flags + ["-c", src, "-o", obj]
             if verbose:
                 print(" ".join(cmd), file=sys.stderr)
             subprocess.check_call(cmd)
-    if force or _stale(LIB, objs):
+    tag = os.path.join(CSRC, "build", ".linked_from")  # which object set the .so was last linked from
+    os.makedirs(os.path.dirname(tag), exist_ok=True)
+    last = open(tag).read().strip() if os.path.exists(tag) else ""
+    if force or _stale(LIB, objs) or last != objdir:
         cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs + ["-ldl", "-lpthread"]
         if verbose:
             print(" ".join(cmd), file=sys.stderr)
         subprocess.check_call(cmd)
+        with open(tag, "w") as f:
+            f.write(objdir)
     return LIB
 
 
 if __name__ == "__main__":
-    print(build_library(force="--force" in sys.argv, verbose=True))
+    print(build_library(force="--force" in sys.argv, verbose=True, ablations="--ablations" in sys.argv))

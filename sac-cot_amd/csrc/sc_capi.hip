@@ -47,7 +47,7 @@ struct sc_ctx {
   // workspace
   Buf in_src, in_tgt, planes, S, bits, deg, degp, wpre, ebase, edge_off, scan_tmp, ei, ej, es, ebi, ebj, tcnt, toff, wkey, kcol, ctl, events, blk_gt,
       blk_eq, blk_minmax, bits2, off_gt, off_eq, sel_ord, sel_key, sortkey, sorted, sort_tmp, tri, tri_rk, key_rk, rt, rt_aos, partial, cnt, key, rt12,
-      mask, refine_tmp, amx_pairs, strong, rowcost, cost_pre, lb_state, lb_ticket, fx_tile, fx_state, fx_mx, fx_part, fx_coef;
+      mask, refine_tmp, amx_pairs, strong, rowcost, cost_pre, lb_state, lb_ticket, fx_tile, fx_state, fx_mx, fx_part, fx_coef, guard_tmp;
   bool filter_on = false;   // C2 of the running / last call goes through a matrix-pipe filter (decided ONCE per call)
   int filter_mode = 0;      // ... which: 1 linear, 2 Gram (0: the plain fp32 kernel)
   FilterPlan fx_plan{};     // ... with this plan (sc_debug_last reads the filter's counters through it)
@@ -771,7 +771,7 @@ void sc_destroy(sc_ctx* c) {
   Buf* bufs[] = {&c->in_src, &c->in_tgt, &c->planes, &c->S, &c->bits, &c->deg, &c->degp, &c->wpre, &c->ebase, &c->edge_off, &c->scan_tmp,
                  &c->ei, &c->ej, &c->es, &c->ebi, &c->ebj, &c->tcnt, &c->toff, &c->wkey, &c->kcol, &c->ctl, &c->events, &c->blk_gt, &c->blk_eq, &c->blk_minmax, &c->bits2, &c->off_gt,
                  &c->off_eq, &c->sel_ord, &c->sel_key, &c->sortkey, &c->sorted, &c->sort_tmp, &c->tri, &c->tri_rk, &c->key_rk, &c->rt,
-                 &c->rt_aos, &c->partial, &c->cnt, &c->key, &c->rt12, &c->mask, &c->refine_tmp, &c->amx_pairs, &c->strong, &c->rowcost, &c->cost_pre, &c->lb_state, &c->lb_ticket, &c->fx_tile, &c->fx_state, &c->fx_mx, &c->fx_part, &c->fx_coef};
+                 &c->rt_aos, &c->partial, &c->cnt, &c->key, &c->rt12, &c->mask, &c->refine_tmp, &c->amx_pairs, &c->strong, &c->rowcost, &c->cost_pre, &c->lb_state, &c->lb_ticket, &c->fx_tile, &c->fx_state, &c->fx_mx, &c->fx_part, &c->fx_coef, &c->guard_tmp};
   for (Buf* b : bufs) if (b->p) (void)hipFree(b->p);
   for (int i = 0; i < N_EVENTS; i++) if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
   if (c->pinned) (void)hipHostFree(c->pinned);
@@ -802,6 +802,10 @@ int sc_set_debug(sc_ctx* c, const sc_debug* d) {
   if (d->tg_count == 64) return SC_EINVAL;  // the plain counting kernel has no 64-lane form
   if (d->score_split > 256 || (d->compat_rows != 0 && d->compat_rows != 16 && d->compat_rows != 32 && d->compat_rows != 64)) return SC_EINVAL;
   if (d->event_cap != 0 && d->event_cap < 256) return SC_EINVAL;
+  if (d->filter_variant != 0 && !filter_ablations_built()) {  // (most of them are timing-only bodies that return wrong counts)
+    c->last_error = "sc_debug.filter_variant needs a library built with -DSC_ABLATIONS";
+    return SC_EINVAL;
+  }
   Tuning t;
   t.no_events = d->no_events != 0;
   t.event_cap = d->event_cap;
@@ -845,7 +849,7 @@ int sc_debug_last(sc_ctx* c, sc_debug_info* out) {
   out->filter_splits = c->filter_on ? c->fx_plan.splits : 0u;
   out->filter_undecided = 0; out->filter_recounts = 0;
   out->fast_path = (uint32_t)c->fast_state;
-  out->gram_guard = (uint32_t)c->gram_guard; out->gram_guard_worst = c->gram_guard_worst;
+  out->gram_guard = c->tn.gram_guard_fail && c->gram_guard != 0 ? 2u : (uint32_t)c->gram_guard; out->gram_guard_worst = c->gram_guard_worst;
   out->reserved = 0; out->reserved2 = 0;
   if (c->filter_on && c->fx_state.p)
     HIPCHK(c, filter_read_counters(c->fx_state.p, c->fx_plan, c->stream, &out->filter_undecided, &out->filter_recounts));
@@ -897,16 +901,41 @@ int run_stage_c(sc_ctx* c, uint64_t* d_key, sc_stats* stats);
 // are the same either way, only slower.
 int use_filter(const sc_ctx* c, const sc_params* p, const Shard& sh) {
   const bool blind = c->tn.filter_blind;
-  const uint64_t mx = blind ? ~0ull : *const_cast<volatile uint64_t*>(&c->pinned[13]);
+  // flag, THEN data: the staging kernel writes the six box words before the word of maxima, so the maxima are loaded with
+  // acquire semantics and the boxes only afterwards (the fence used to sit behind both loads, which only the
+  // load order of x86 made right)
+  const uint64_t mx = blind ? ~0ull : __atomic_load_n(&c->pinned[13], __ATOMIC_ACQUIRE);
   uint64_t box[6];
-  for (int k = 0; k < 6; k++) box[k] = *const_cast<volatile uint64_t*>(&c->pinned[16 + k]);  // (written before pinned[13])
-  std::atomic_thread_fence(std::memory_order_acquire);
+  for (int k = 0; k < 6; k++) box[k] = *const_cast<volatile uint64_t*>(&c->pinned[16 + k]);
   return score_filter_mode(p->score_mode, c->tn, c->n, sh.ld_local, mx, (blind || mx == ~0ull) ? nullptr : box, c->dv.tau2);
 }
-void decide_filter(sc_ctx* c, const sc_params* p, const Shard& sh) {
+// The Gram filter's bound rests on a measured model of the matrix pipe (sc_score.hip, gram_guard_kernel): probe the pipe this
+// context runs on, once, the first time a call would choose that filter.  0 not run, 1 the model holds, 2 violated.
+int run_gram_guard(sc_ctx* c) {
+  if (c->gram_guard != 0) return SC_OK;
+  ENSURE(c, c->guard_tmp, 64);
+  float worst = 0.f; bool sub_ok = false; uint32_t compared = 0;
+  const hipError_t e = gram_guard_probe(c->guard_tmp.p, c->stream, &worst, &sub_ok, &compared);
+  if (e != hipSuccess) return fail_hip(c, e, "gram_guard_probe");
+  c->gram_guard_worst = worst;
+  c->gram_guard = (sub_ok && compared != 0 && worst <= gram_guard_limit()) ? 1 : 2;
+  return SC_OK;
+}
+int decide_filter(sc_ctx* c, const sc_params* p, const Shard& sh) {
   c->filter_mode = use_filter(c, p, sh);
+  if (c->filter_mode == 2) {
+    const int rc = run_gram_guard(c);
+    if (rc) return rc;
+    if (c->gram_guard == 2 || c->tn.gram_guard_fail) {
+      // this pipe does not add the way the Gram bound assumes (or a test says so): the linear filter, whose bound allows a
+      // truncating accumulation, where tau is on its scale; the plain kernel otherwise
+      const uint64_t mx = c->tn.filter_blind ? ~0ull : __atomic_load_n(&c->pinned[13], __ATOMIC_ACQUIRE);
+      c->filter_mode = filter_in_range(mx, c->dv.tau2) ? 1 : 0;
+    }
+  }
   c->filter_on = c->filter_mode != 0;
   if (c->filter_on) c->fx_plan = filter_plan(c->n, sh.ld_local, c->tn, (uint32_t)c->filter_mode);
+  return SC_OK;
 }
 
 // the filter's buffers for this shard, and the job that fills the tile / clears the state
@@ -970,7 +999,7 @@ int run_stage_c(sc_ctx* c, uint64_t* d_key, sc_stats* stats) {
   if (sh.n_local) {
     ENSURE(c, c->rt, (size_t)12 * sh.ld_local * 4);
     ENSURE(c, c->cnt, (size_t)sh.ld_local * 4);
-    decide_filter(c, p, sh);
+    if ((rc = decide_filter(c, p, sh))) return rc;
     const bool filter = c->filter_on;
     const bool aos = filter || score_is_scalar(p->score_mode, c->tn);  // both read 12 consecutive floats per hypothesis
     if (aos) ENSURE(c, c->rt_aos, (size_t)12 * sh.ld_local * 4);
@@ -1538,7 +1567,7 @@ int sc_score_host(sc_ctx* c, const float* src, const float* tgt, int64_t n, cons
   // proper never has to — it has polled later results of the same stream by the time it gets here)
   if (!c->tn.filter_blind && (rc = wait_word(c, 13))) return rc;
   c->sh = sh;
-  decide_filter(c, p, sh);
+  if ((rc = decide_filter(c, p, sh))) return rc;
   uint32_t score_rows = 0;
   if ((rc = run_score(c, p, sh, &score_rows, false))) return rc;
   ENSURE(c, c->cnt, (size_t)(sh.ld_local ? sh.ld_local : 256) * 4);

@@ -454,6 +454,12 @@ void launch_filter_tile(const Points& pts, const FilterTileJob& job, hipStream_t
 void launch_score_filter(const Points& pts, const float* RtSoA, const float* RtAoS, const Shard& sh, const Derived& dv,
                          const FilterPlan& fp, const void* tile, void* state, void* coef, uint32_t* partial, const Tuning& tn,
                          hipStream_t st, hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr);
+// Run-time probe of the matrix pipe's accumulation arithmetic (the model the Gram filter's bound assumes; sc_score.hip):
+// blocking, ~1e6 cancelling dot products.  scratch: 16 bytes of device memory.  worst_units: largest |hardware - exact| /
+// largest term seen, in units of 2^-24 (the bound assumes 18.5; gram_guard_limit() is what a context tolerates).
+hipError_t gram_guard_probe(void* scratch, hipStream_t st, float* worst_units, bool* subnormals_kept, uint32_t* compared);
+float gram_guard_limit();
+bool filter_ablations_built();  // -DSC_ABLATIONS: the scheduling / timing-only variants of the filter kernels exist (Tuning::filter_variant)
 // diagnostics (sc_debug_last): what the filter of the last launch handed to the exact pass.  Blocking copies on `st`.
 hipError_t filter_read_counters(const void* state, const FilterPlan& fp, hipStream_t st, uint64_t* undecided, uint64_t* recounts);
 // Winner key pair key2[0..1] (written, not accumulated: no zeroing needed):

@@ -1075,7 +1075,7 @@ __global__ __launch_bounds__(256) void score_exact_kernel(const float* __restric
 //     normal   eps_h <= 0.25 st^2: filtered;        far      |T'| - 1.002 Pn - Qn >= st + dE + 1: no correspondence can be an inlier,
 //     padding  beyond n_local: count 0;              recount  everything else (non-finite, not a rotation, shell too wide): its
 //                                                             group of 8 hypotheses goes to the exact pass wholesale.
-// Usable while tau is not small against the clouds (score_filter_mode: eps <= 8 % of tau'^2 for a typical hypothesis — C2, C4;
+// Usable while tau is not small against the clouds (score_filter_mode: eps <= 3 % of tau'^2 for a typical hypothesis — C2, C4;
 // not C3, whose tau is 1 % of the extent: the linear filter keeps those).
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ void split2(double x, _Float16& hi, _Float16& lo) {
@@ -1225,6 +1225,132 @@ __global__ __launch_bounds__(256) void gram_coef_kernel(const float* __restrict_
 #pragma unroll
   for (int c = 0; c < 12; c++) v[c] = l < ldl ? RtSoA[(size_t)c * ldl + l] : 0.f;
   gram_coef_wave(coef, gi, v, l, ldl, n_local, tau2);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Run-time guard of the Gram filter's error model.  GX_ACC — "one v_mfma_f32_32x32x16_f16 is off by at most 18.5 x 2^-24 of
+// its LARGEST term" — is a measured property of gfx950's matrix pipe (tools/ubench/mfma_numerics.hip), not an ISA guarantee,
+// and the Gram filter's shells are only as wide as it says.  So every context probes the pipe it actually runs on, once,
+// before the first call that would choose the Gram filter: GUARD_WAVES x GUARD_ITERS MFMAs of pseudo-random, strongly
+// cancelling dot products (the microbenchmark's recipe: 1 .. 16 non-zero slots, factors spread over 12 / 14 binades, C = minus
+// the exact sum within 10 % plus noise, or zero), each of the 1024 results of an instruction compared with the fp64 value of
+// the same sum — fp16 x fp16 products are exact in fp64 and seventeen of them add with ~2^-49 of error, nothing against
+// 2^-24.  The probe reports the largest |hardware - exact| / largest |term| it saw, in units of 2^-24, and whether fp16
+// sub-normal operands were kept (the low halves of small features are sub-normal: a pipe that flushes them breaks GX_Q).
+// A context whose pipe exceeds GUARD_LIMIT (half of what the bound allows; this silicon shows ~4) or flushes sub-normals
+// never runs the Gram filter: its calls take the linear filter, whose bound allows a truncating accumulation.
+// ------------------------------------------------------------------------------------------------
+constexpr int GUARD_WAVES = 64, GUARD_ITERS = 16;
+constexpr float GUARD_LIMIT = 9.25f;  // x 2^-24 of the largest term: GX_ACC / 2
+
+__device__ __forceinline__ uint64_t guard_hash(uint64_t x) {  // splitmix64 finaliser
+  x += 0x9E3779B97F4A7C15ull;
+  x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+  x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+  return x ^ (x >> 31);
+}
+// operand (which = 0: A row / 1: B column) `rc`, slot k of MFMA number `id`: an fp16 value any lane can re-derive
+__device__ __forceinline__ float guard_operand(uint32_t id, int which, int rc, int k, int nz) {
+  if (k >= nz) return 0.f;
+  const uint64_t hsh = guard_hash(((uint64_t)id << 20) | ((uint64_t)which << 16) | ((uint64_t)rc << 8) | (uint64_t)k);
+  const float u = (float)(hsh & 0xFFFFFFu) * (1.0f / 16777216.0f) - 0.5f;
+  const int e = (int)((hsh >> 24) % (which ? 14u : 12u));
+  return (float)(_Float16)ldexpf(u, e);
+}
+
+__global__ __launch_bounds__(64) void gram_guard_kernel(uint32_t* __restrict__ out) {
+  // out[0]: max over all results of |hw - exact| / largest term (fp32 bits of a non-negative value: atomicMax orders them);
+  // out[1]: sub-normal operands kept (1 set by the wave that tests it); out[2]: results compared
+  const int lane = threadIdx.x, rc = lane & 31, hf = lane >> 5;
+  float worst = 0.f;
+  for (int it = 0; it < GUARD_ITERS; it++) {
+    const uint32_t id = blockIdx.x * GUARD_ITERS + it;
+    const int nz = 1 + (int)(guard_hash(0xABCD0000ull + id) % 16u);
+    half8 A, B;
+#pragma unroll
+    for (int e = 0; e < 8; e++) {
+      A[e] = (_Float16)guard_operand(id, 0, rc, 8 * hf + e, nz);
+      B[e] = (_Float16)guard_operand(id, 1, rc, 8 * hf + e, nz);
+    }
+    // lane (col = rc, hf) receives D[i] for rows 8 (i >> 2) + 4 hf + (i & 3): it re-derives those rows' operands for the exact sums
+    double bcol[16];
+#pragma unroll
+    for (int k = 0; k < 16; k++) bcol[k] = (double)guard_operand(id, 1, rc, k, nz);
+    f32x16 C;
+    double want[16], big[16];
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+      const int r = 8 * (i >> 2) + 4 * hf + (i & 3);
+      double ex = 0.0, mx = 0.0;
+      for (int k = 0; k < 16; k++) {
+        const double t = (double)guard_operand(id, 0, r, k, nz) * bcol[k];
+        ex += t;
+        mx = fmax(mx, fabs(t));
+      }
+      const uint64_t hc = guard_hash(0x5EED000000ull + ((uint64_t)id << 12) + (uint64_t)(r * 32 + rc));
+      const double u1 = (double)(hc & 0xFFFFFu) / 1048576.0, u2 = (double)((hc >> 20) & 0xFFFFFu) / 1048576.0;
+      const float c = ((hc >> 40) % 3u == 0u) ? 0.f : (float)(-ex * (0.9 + 0.2 * u1) + (u2 - 0.5) * 64.0);
+      C[i] = c;
+      want[i] = ex + (double)c;
+      big[i] = fmax(mx, fabs((double)c));
+    }
+    const f32x16 D = __builtin_amdgcn_mfma_f32_32x32x16_f16(A, B, C, 0, 0, 0);
+#pragma unroll
+    for (int i = 0; i < 16; i++)
+      if (big[i] > 0.0) worst = fmaxf(worst, (float)(fabs((double)D[i] - want[i]) / big[i] * 16777216.0));
+  }
+  if (!(worst >= 0.f)) worst = 1e30f;  // NaN: a violation
+  atomicMax(&out[0], __float_as_uint(worst));
+  if (lane == 0) atomicAdd(&out[2], (uint32_t)(GUARD_ITERS * 1024));
+  if (blockIdx.x == 0) {  // sub-normal operands: 2^-20 x 1024 on either side must arrive as 2^-10
+    half8 A, B;
+#pragma unroll
+    for (int e = 0; e < 8; e++) { A[e] = (_Float16)0.f; B[e] = (_Float16)0.f; }
+    if (hf == 0) {  // slot 0 only: rows 0 .. 15 of A hold the sub-normal 2^-20, rows 16 .. 31 hold 1024; B holds 1024
+      A[0] = (_Float16)(rc < 16 ? 9.5367431640625e-07f : 1024.f);
+      B[0] = (_Float16)1024.f;
+    }
+    // second product: the sub-normal on the B side (columns 16 .. 31), met by the rows of A that hold 1024
+    half8 B2 = B;
+    if (hf == 0 && rc >= 16) B2[0] = (_Float16)9.5367431640625e-07f;
+    f32x16 Z;
+#pragma unroll
+    for (int i = 0; i < 16; i++) Z[i] = 0.f;
+    const f32x16 D1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(A, B, Z, 0, 0, 0);   // rows 0..15: 2^-20 x 1024
+    const f32x16 D2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(A, B2, Z, 0, 0, 0);  // columns 16..31 x rows 16..31: 1024 x 2^-20
+    bool ok = true;
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+      const int r = 8 * (i >> 2) + 4 * hf + (i & 3);
+      if (r < 16) ok = ok && D1[i] == 0.0009765625f;
+      if (r >= 16 && rc >= 16) ok = ok && D2[i] == 0.0009765625f;
+    }
+    const uint64_t all = __ballot(ok);
+    if (lane == 0) out[1] = (all == ~0ull) ? 1u : 0u;
+  }
+}
+
+hipError_t gram_guard_probe(void* scratch, hipStream_t st, float* worst_units, bool* subnormals_kept, uint32_t* compared) {
+  uint32_t h[4] = {0, 0, 0, 0};
+  hipError_t e = hipMemsetAsync(scratch, 0, 16, st);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(gram_guard_kernel, dim3(GUARD_WAVES), dim3(64), 0, st, static_cast<uint32_t*>(scratch));
+  e = hipMemcpyAsync(h, scratch, 16, hipMemcpyDeviceToHost, st);
+  if (e == hipSuccess) e = hipStreamSynchronize(st);
+  if (e != hipSuccess) return e;
+  union { uint32_t u; float f; } w; w.u = h[0];
+  *worst_units = w.f;
+  *subnormals_kept = h[1] == 1u;
+  if (compared) *compared = h[2];
+  return hipSuccess;
+}
+float gram_guard_limit() { return GUARD_LIMIT; }
+bool filter_ablations_built() {
+#ifdef SC_ABLATIONS
+  return true;
+#else
+  return false;
+#endif
 }
 
 // sum of `v` over each aligned group of 32 lanes, valid in the group's upper 16 lanes (DPP: quad swaps, half mirror, mirror,
@@ -1455,7 +1581,11 @@ void launch_score_filter(const Points& pts, const float* RtSoA, const float* RtA
     hipExtLaunchKernelGGL(score_gram_kernel<V>, dim3((sh.ld_local + 32 * GX_WAVES - 1) / (32 * GX_WAVES), fp.splits), dim3(64 * GX_WAVES), \
                           0, st, ev0, nullptr, 0, gc, sh.ld_local, static_cast<const uint4*>(tile), fp.windows, fp.splits, fp.n_waves, partial, \
                           f.queue, f.cap_sq, f.qcount, f.redo, ql)
+    // The shipped library holds variant 0 only.  -DSC_ABLATIONS (sac-cot_amd/build.py --ablations; tools/pmc_gram_variants.sh)
+    // also instantiates the bit-identical scheduling variant 1 and the TIMING-ONLY bodies (no shell test / no barrier / no
+    // epilogue: wrong counts by design), which sc_set_debug refuses without it.
     switch (tn.filter_variant) {
+#ifdef SC_ABLATIONS
       case 512: SC_GRAM_LAUNCH(512); break;
       case 256: SC_GRAM_LAUNCH(256); break;
       case 768: SC_GRAM_LAUNCH(768); break;
@@ -1464,6 +1594,7 @@ void launch_score_filter(const Points& pts, const float* RtSoA, const float* RtA
       case 352: SC_GRAM_LAUNCH(352); break;
       case 320: SC_GRAM_LAUNCH(320); break;
       case 1: SC_GRAM_LAUNCH(1); break;
+#endif
       default: SC_GRAM_LAUNCH(0); break;
     }
 #undef SC_GRAM_LAUNCH
@@ -1482,6 +1613,7 @@ void launch_score_filter(const Points& pts, const float* RtSoA, const float* RtA
                      static_cast<const uint4*>(tile), f.info, fp.windows, fp.splits, fp.n_waves, partial, f.queue, f.cap_sq, \
                      f.qcount, f.redo, ql)
   switch (tn.filter_variant) {
+#ifdef SC_ABLATIONS
     case 1: SC_FILTER_LAUNCH(1); break;
     case 2: SC_FILTER_LAUNCH(2); break;
     case 3: SC_FILTER_LAUNCH(3); break;
@@ -1498,6 +1630,7 @@ void launch_score_filter(const Points& pts, const float* RtSoA, const float* RtA
     case 768: SC_FILTER_LAUNCH(768); break;
     case 288: SC_FILTER_LAUNCH(288); break;
     case 272: SC_FILTER_LAUNCH(272); break;
+#endif
     default: SC_FILTER_LAUNCH(0); break;
   }
 #undef SC_FILTER_LAUNCH

@@ -101,3 +101,23 @@ def test_product_never_touches_the_oracle():
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", text, flags=re.M), f
     out = subprocess.check_output(["readelf", "-d", os.path.join(pk, "libsaccot.so")]).decode()
     assert "oracle" not in out
+
+
+def test_mex_gateway_compiles_against_the_header(pkg, tmp_path):
+    """integration/saccot_mex.cpp cannot run here — no MATLAB / Octave in the image — but it must at least
+    meet a compiler: against the declarations-only tests/mex_stub/mex.h and include/saccot.h, warnings as errors, so that
+    drift between the gateway and the C ABI breaks THIS test.  (The GPU suite goes further and runs its mexFunction from a
+    stand-in runtime: tests/test_gpu_cabi_example.py.)"""
+    root = ROOT
+    obj = str(tmp_path / "saccot_mex.o")
+    subprocess.check_call(["g++", "-std=c++17", "-Wall", "-Wextra", "-Werror", "-c", "-fPIC",
+                           "-I", os.path.join(root, "tests", "mex_stub"), "-I", os.path.join(root, "include"),
+                           os.path.join(root, "integration", "saccot_mex.cpp"), "-o", obj])
+    syms = subprocess.check_output(["nm", "-g", "--defined-only", obj], text=True)
+    assert " T mexFunction" in syms
+    undefined = subprocess.check_output(["nm", "-u", obj], text=True)
+    used = sorted({ln.split()[-1] for ln in undefined.splitlines() if ln.split() and ln.split()[-1].startswith("sc_")})
+    assert used, undefined
+    L = pkg.load_library()
+    for s in used:  # every ABI symbol the gateway binds is exported by the library
+        assert hasattr(L, s), s

@@ -231,3 +231,19 @@ def test_sharded_A_and_B_host_logic_gloo(pkg, O, tmp_path, world, level):
         assert int(o["retries"]) == int(outs[0]["retries"])
     if level < 0:
         assert total > 6000 and int(outs[0]["retries"]) >= 1
+
+
+def test_bench_parent_ends_the_ranks_when_one_dies():
+    """bench.py --gpus N without a launcher supervises the ranks it starts: rank 1 exits with a code at once,
+    the others sleep as if stuck in a rendezvous — the parent must return that code promptly instead of waiting on them."""
+    import subprocess
+    import sys
+    import time
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    env["SC_BENCH_SUPERVISION_TEST"] = "1"
+    t0 = time.monotonic()
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "3", "--steps", "1", "--warmup", "0"],
+                       env=env, capture_output=True, timeout=120)
+    assert r.returncode == 7, (r.returncode, r.stderr.decode()[-500:])
+    assert time.monotonic() - t0 < 60

@@ -1,6 +1,8 @@
 #!/bin/bash
 # SQ_INSTS_VALU / MFMA / wave cycles of the Gram filter kernel for timing-only variants (sc_debug.filter_variant):
 #   bash tools/pmc_gram_variants.sh C4 0 512 32      (one rocprofv3 --pmc pass per variant, kernel-trace only)
+# The variants only exist in the lab build (-DSC_ABLATIONS): build it first, on the CPU box, with
+#   python sac-cot_amd/build.py --ablations     and afterwards restore the product library:   python sac-cot_amd/build.py
 set -u
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 CFG=${1:-C4}; shift || true
