@@ -31,7 +31,7 @@ typedef struct sc_debug {
   uint32_t compat_rows;       /* stage A tile height: 0 = by size (16 rows below 10 000 correspondences, 32 from there), 16, 32, 64 */
   uint32_t compat_store_mode; /* stage A stores of S: 0 = by size; bit 0 = 4 bytes per lane, bit 2 = 16 bytes, bit 1 = non-temporal */
   uint32_t tg_events;         /* lanes per edge of the event-recording counting pass: 4 .. 64 (default: by row width) */
-  uint32_t sample_mode;       /* stage B's pruning sample: 0 = chosen by size, 1 = every stride-th edge, 2 = the heaviest edges */
+  uint32_t sample_mode;       /* stage B's pruning sample: 0 = chosen by entry point and size (an estimating sample where the call can be repeated, else one of the two certifying ones), 1 = every stride-th edge, 2 = the heaviest edges (1, 2: certifying) */
   uint32_t sample_blocks;     /* grid size of the heaviest-edge sample (0 = one block per 256 edges)              */
   uint32_t compact_fused;     /* 1: compaction in one launch (look-back over the tiles) instead of count + write    */
   uint32_t rows_unfused;      /* 1: row statistics and the scans of the row counts as separate launches             */
@@ -47,7 +47,9 @@ typedef struct sc_debug {
   uint32_t no_fast;           /* 1: sc_register_device always waits for stage B's two counts in the middle of the call (the form every other entry point uses) instead of enqueueing the whole chain of a repeated shape host-free */
   uint32_t gram_guard_fail;   /* 1: the run-time probe of the matrix pipe's accumulation model reports a violation (tests: the Gram filter must then never be chosen) */
   uint32_t tail_unfused;      /* 1: the exact pass, the arg-max and the winner / mask kernel as three launches (r03's form) instead of one */
-  uint32_t reserved[5];
+  uint32_t no_estimate;       /* 1: stage B never prunes by an ESTIMATED bound (verified by the select, call repeated when it was too high) — always by a certifying sample, as every entry point other than sc_register / sc_register_device(_async) does anyway */
+  uint32_t est_margin_pct;    /* the estimated bound aims at the key of rank (pct / 100) x T (0 = 200); a small value forces the failure-and-repeat path (tests) */
+  uint32_t reserved[3];
 } sc_debug;
 int         sc_set_debug(sc_ctx* ctx, const sc_debug* dbg);
 
@@ -61,7 +63,7 @@ typedef struct sc_debug_info {
   uint32_t filter_splits;     /* grid.y of the filter launch                                                           */
   uint32_t fast_path;         /* sc_register_device: 0 = the call waited for stage B's counts; 1 = enqueued host-free and validated at its end; 2 = enqueued host-free, failed validation (a count outgrew what the launches covered, fewer triangles than T, event overflow), repeated the waiting way */
   uint32_t gram_guard;        /* run-time probe of the matrix pipe's accumulation arithmetic (once per context, before the first call that could choose the Gram filter): 0 = not run yet, 1 = the model the Gram bound assumes holds, 2 = violated: the Gram filter is disabled for this context */
-  uint32_t reserved;
+  uint32_t prune_bound;       /* stage B's pruning bound in the last call: 0 = certified by the sample (or no pruning), 1 = estimated from a 1-in-64 sample of the triangles and verified by the select, 2 = estimated, found too high by the select, call repeated with a certifying sample */
   float    gram_guard_worst;  /* largest |hardware - exact| / largest term the probe saw, in units of 2^-24 (the bound assumes 18.5) */
   uint32_t reserved2;
 } sc_debug_info;

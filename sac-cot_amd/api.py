@@ -83,7 +83,7 @@ class ScDebug(C.Structure):
                 ("filter_queue_cap", C.c_uint32), ("filter_lds_queue", C.c_uint32), ("es_hist_unfused", C.c_uint32),
                 ("filter_variant", C.c_uint32), ("dense_async", C.c_uint32), ("filter_blind", C.c_uint32),
                 ("no_fast", C.c_uint32), ("gram_guard_fail", C.c_uint32), ("tail_unfused", C.c_uint32),
-                ("reserved", C.c_uint32 * 5)]
+                ("no_estimate", C.c_uint32), ("est_margin_pct", C.c_uint32), ("reserved", C.c_uint32 * 3)]
 
 
 class ScDebugInfo(C.Structure):
@@ -91,7 +91,7 @@ class ScDebugInfo(C.Structure):
     how the call was enqueued (fast_path: 0 waited, 1 host-free, 2 host-free then repeated), the matrix-pipe probe."""
     _fields_ = [("size", C.c_uint32), ("c2_kernel", C.c_uint32), ("filter_undecided", C.c_uint64),
                 ("filter_recounts", C.c_uint64), ("filter_splits", C.c_uint32), ("fast_path", C.c_uint32),
-                ("gram_guard", C.c_uint32), ("reserved", C.c_uint32), ("gram_guard_worst", C.c_float),
+                ("gram_guard", C.c_uint32), ("prune_bound", C.c_uint32), ("gram_guard_worst", C.c_float),
                 ("reserved2", C.c_uint32)]
 
 

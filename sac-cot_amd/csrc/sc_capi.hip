@@ -100,6 +100,15 @@ struct sc_ctx {
   int pending_rc = 0;        // status already known when the async half returned (a waited call is complete by then)
   const float* pend_src = nullptr; const float* pend_tgt = nullptr; float* pend_Rt = nullptr; uint8_t* pend_mask = nullptr;
   int64_t pend_n = 0; sc_params pend_p{}; sc_stats pend_stats{};
+  // pruning by an ESTIMATED bound (sc_tri.hip 3c): only where this file can repeat the call itself (sc_register_device /
+  // _async / sc_register), never through the phase API; the select verifies the bound, finalize_wait reads the verdict
+  bool est_allowed = false;  // the running call came in through an entry point that can repeat it
+  bool est_active = false;   // ... and prunes by an estimate
+  bool est_void = false;     // ... which could not be verified on the path taken (event overflow): repeat
+  bool est_failed = false;   // sticky: an estimate failed on this context — it certifies from now on (sc_set_debug resets)
+  int est_state = 0;         // last pass: 0 certified bound (or no pruning), 1 estimated and verified
+  bool est_failed_call = false;  // the running / last call saw its estimate fail and was repeated (sc_debug_last: prune_bound 2)
+  SamplePlan plan{false, 1u, 0};
   // run-time probe of the matrix pipe's accumulation model (sc_score.hip gram_guard): 0 not run, 1 holds, 2 violated
   int gram_guard = 0;
   float gram_guard_worst = 0.f;
@@ -426,6 +435,8 @@ int run_edges(sc_ctx* c, const sc_params* p, uint32_t* hist, uint32_t part, uint
   }
   const uint64_t E = c->E = spec ? c->E_cov : c->pinned[0];
   c->M = 0; c->M_total = 0; c->T_eff = 0; c->pruned = false; c->use_events = false; c->have_total = false;
+  c->est_active = false; c->est_void = false; c->plan = SamplePlan{false, 1u, p->max_triangles};
+  c->pinned[14] = 0;  // "the select found fewer keys above the pruning bound than it promised" (select_round_kernel)
   // an exchanged histogram is written on every path (zeros where no sample runs: the control block's copies are zero)
   if (hist && (E == 0 || !(may_prune(p) && E >= 4096))) launch_hist_reduce(c->ctl.as<ControlBlock>()->prune_hist, hist, st);
   if (E == 0) return SC_OK;
@@ -456,9 +467,19 @@ int run_edges(sc_ctx* c, const sc_params* p, uint32_t* hist, uint32_t part, uint
       c->have_total = true;
     }
     // the smallest possible weight is ~3 t_cmp (every edge has s >= t_cmp up to rounding); 0.1 % slack
-    launch_sample_hist(g, c->ebi.as<uint32_t>(), c->ebj.as<uint32_t>(), c->ei.as<uint32_t>(), c->ej.as<uint32_t>(),
-                       c->es.as<float>(), E, p->max_triangles, 3.0f * p->t_cmp * 0.999f, part, parts,
-                       ctl->prune_hist, ctl->es_hist, es_hist != nullptr, c->tn, st, E_dev, spec ? c->E_last : 0);
+    // An ESTIMATED bound where the call can be repeated should the select find it too high (sc_tri.hip 3c): the common
+    // form only — event list, a-priori select window (the check rides the window's first round), the whole sample here
+    const bool window_known = p->rank_mode == SC_RANK_WEIGHT && 3.0f * p->t_cmp * 0.999f >= 2.0f;
+    c->plan = sample_plan(p->max_triangles, c->est_allowed && !c->est_failed && hist == nullptr && parts == 1 && !c->sharded_ab &&
+                                                c->use_events && window_known, c->tn);
+    c->est_active = c->plan.estimate;
+    if (c->plan.estimate)
+      launch_sample_estimate(g, c->ebi.as<uint32_t>(), c->ebj.as<uint32_t>(), c->ei.as<uint32_t>(), c->ej.as<uint32_t>(),
+                             c->es.as<float>(), E, 3.0f * p->t_cmp * 0.999f, c->plan.rate, ctl->prune_hist, c->tn, st, E_dev);
+    else
+      launch_sample_hist(g, c->ebi.as<uint32_t>(), c->ebj.as<uint32_t>(), c->ei.as<uint32_t>(), c->ej.as<uint32_t>(),
+                         c->es.as<float>(), E, p->max_triangles, 3.0f * p->t_cmp * 0.999f, part, parts,
+                         ctl->prune_hist, ctl->es_hist, es_hist != nullptr, c->tn, st, E_dev, spec ? c->E_last : 0);
     if (hist) launch_hist_reduce(ctl->prune_hist, hist, st);  // the exchanged form: one 256-bin histogram
   }
   return SC_OK;
@@ -521,8 +542,8 @@ int run_select(sc_ctx* c, const sc_params* p, const uint32_t* hist, bool want_li
     // whole strong matrix, so every rank computes the same cut: the pruning kernel lists EVERY strong edge, two small
     // launches make the cut, and the counting pass skips the edges of the other ranks.
     launch_prune_bits(g, hist ? hist : ctl->prune_hist, hist == nullptr, c->ei.as<uint32_t>(), c->ej.as<uint32_t>(), c->es.as<float>(), E,
-                      p->max_triangles, 3.0f * p->t_cmp * 0.999f, c->bits2.as<uint64_t>(), &ctl->smin, &ctl->klb, sl,
-                      c->tcnt.as<uint32_t>(), recut ? nullptr : own_range_of(c), st, E_dev);
+                      c->est_active ? c->plan.hist_want : (uint64_t)p->max_triangles, 3.0f * p->t_cmp * 0.999f, c->bits2.as<uint64_t>(), &ctl->smin, &ctl->klb, sl,
+                      c->tcnt.as<uint32_t>(), recut ? nullptr : own_range_of(c), st, E_dev, c->est_active);
     if (recut) {
       ENSURE(c, c->rowcost, ((size_t)c->n + 4 + 1024) * 4);  // (cost_split_kernel reads whole 16-byte pieces)
       launch_strong_rowcost(g, c->bits2.as<uint64_t>(), c->rowcost.as<uint32_t>(), st);
@@ -568,7 +589,7 @@ int run_select(sc_ctx* c, const sc_params* p, const uint32_t* hist, bool want_li
       ENSURE(c, c->blk_minmax, 2 * 8192 * 4);
       launch_tri_keys_events(g, c->es.as<float>(), c->toff.as<uint64_t>(), p->rank_mode, ev, c->wkey.as<uint32_t>(),
                              c->kcol.as<uint2>(), c->blk_minmax.as<uint32_t>(), sel, select_want(c, p),
-                             &c->ctl.as<ControlBlock>()->klb, E, spec_cap, c->tn, st);
+                             &c->ctl.as<ControlBlock>()->klb, E, spec_cap, c->tn, st, !c->sharded_ab);
     }
   }
   // host-free call: no wait — M is what the key arrays and the launches below cover, T_eff the requested T; the kernels
@@ -608,8 +629,8 @@ int run_select(sc_ctx* c, const sc_params* p, const uint32_t* hist, bool want_li
     // nothing to do
   } else if (events_ok) {
     launch_tri_keys_events(g, c->es.as<float>(), c->toff.as<uint64_t>(), p->rank_mode, ev, c->wkey.as<uint32_t>(),
-                           c->kcol.as<uint2>(), c->blk_minmax.as<uint32_t>(), sel, T_eff,
-                           fast_window ? &c->ctl.as<ControlBlock>()->klb : nullptr, E, M, c->tn, st);
+                           c->kcol.as<uint2>(), c->blk_minmax.as<uint32_t>(), sel, fast_window ? (uint64_t)select_want(c, p) : (uint64_t)T_eff,
+                           fast_window ? &c->ctl.as<ControlBlock>()->klb : nullptr, E, M, c->tn, st, !c->sharded_ab);
   } else {
     launch_tri_keys(g, mbits, smin, c->ebase.as<uint32_t>(), c->ei.as<uint32_t>(), c->ej.as<uint32_t>(),
                     c->es.as<float>(), c->toff.as<uint64_t>(), E, p->rank_mode, c->wkey.as<uint32_t>(),
@@ -619,7 +640,9 @@ int run_select(sc_ctx* c, const sc_params* p, const uint32_t* hist, bool want_li
   c->timed_trikeys = c->timing;
   KeyView view = plain_view(c->wkey.as<uint32_t>(), M);
   if (spec) view.M_dev = c->toff.as<uint64_t>() + E;
-  launch_select_rounds(view, sel, fast_window ? 2 : 3, c->tn, st);
+  // an estimated bound is verified by the first round over the a-priori window; any other path leaves it unverified
+  if (c->est_active && !fast_window) c->est_void = true;
+  launch_select_rounds(view, sel, fast_window ? 2 : 3, c->tn, st, c->sharded_ab ? nullptr : &c->pinned[14]);
   { const int crc = run_compaction(c, view, nb); if (crc) return crc; }
   // the list stays in ordinal order: no sort on the hot path (the winner is found by (count, key, position))
   if (want_list)
@@ -795,7 +818,7 @@ const char* sc_last_error(const sc_ctx* c) { return c ? c->last_error.c_str() : 
 
 int sc_set_debug(sc_ctx* c, const sc_debug* d) {
   if (!c) return SC_EINVAL;
-  if (!d) { c->tn = Tuning(); c->fast_ok = false; return SC_OK; }
+  if (!d) { c->tn = Tuning(); c->fast_ok = false; c->est_failed = false; return SC_OK; }
   if (d->size != sizeof(sc_debug)) return SC_EINVAL;
   auto tg_ok = [](uint32_t t) { return t == 0 || t == 4 || t == 8 || t == 16 || t == 32 || t == 64; };
   if (!tg_ok(d->tg_count) || !tg_ok(d->tg_keys) || !tg_ok(d->tg_sample) || !tg_ok(d->tg_events)) return SC_EINVAL;
@@ -821,7 +844,7 @@ int sc_set_debug(sc_ctx* c, const sc_debug* d) {
   t.compat_one_phase = d->compat_one_phase != 0;
   t.compat_rows = (int)d->compat_rows;  // 0 (by size), 16, 32, 64: checked above
   t.compat_store_mode = d->compat_store_mode & 7u;
-  t.sample_mode = d->sample_mode <= 2 ? d->sample_mode : 0u;
+  t.sample_mode = d->sample_mode <= 2 ? d->sample_mode : 0u;  // (!= 0 also keeps the estimate off: a certifying form was asked for)
   t.sample_blocks = d->sample_blocks;
   t.compact_fused = d->compact_fused != 0;
   t.rows_unfused = d->rows_unfused != 0;
@@ -836,8 +859,11 @@ int sc_set_debug(sc_ctx* c, const sc_debug* d) {
   t.no_fast = d->no_fast != 0;
   t.gram_guard_fail = d->gram_guard_fail != 0;
   t.tail_unfused = d->tail_unfused != 0;
+  t.no_estimate = d->no_estimate != 0;
+  t.est_margin_pct = d->est_margin_pct;
   c->tn = t;
   c->fast_ok = false;  // (the next call waits: its launch geometry may differ from the last call's)
+  c->est_failed = false;
   return SC_OK;
 }
 
@@ -850,7 +876,7 @@ int sc_debug_last(sc_ctx* c, sc_debug_info* out) {
   out->filter_undecided = 0; out->filter_recounts = 0;
   out->fast_path = (uint32_t)c->fast_state;
   out->gram_guard = c->tn.gram_guard_fail && c->gram_guard != 0 ? 2u : (uint32_t)c->gram_guard; out->gram_guard_worst = c->gram_guard_worst;
-  out->reserved = 0; out->reserved2 = 0;
+  out->prune_bound = c->est_failed_call ? 2u : (uint32_t)c->est_state; out->reserved2 = 0;
   if (c->filter_on && c->fx_state.p)
     HIPCHK(c, filter_read_counters(c->fx_state.p, c->fx_plan, c->stream, &out->filter_undecided, &out->filter_recounts));
   return SC_OK;
@@ -870,6 +896,7 @@ int hyp_begin(sc_ctx* c, const float* d_src, const float* d_tgt, int64_t n, cons
   c->begun = false;
   c->timed_trikeys = false;
   c->regular = false;
+  if (!c->est_allowed) c->est_failed_call = false;  // (an entry point that never estimates)
   if ((rc = set_timing(c, p))) return rc;
   c->refine = (p->flags & SC_FLAG_REFINE) != 0;
   c->cap_bytes = p->max_workspace ? p->max_workspace : (64ull << 30);
@@ -1256,6 +1283,19 @@ int finalize_wait(sc_ctx* c, sc_stats* stats) {
     c->fast_state = 1;
     c->regular = true;
   }
+  c->est_state = c->est_active ? 1 : 0;
+  if (c->pinned[14] != 0 || (c->est_active && c->est_void)) {
+    // select_round_kernel: fewer keys at or above the pruning bound than it promised (or the bound went unverified)
+    if (!c->est_active) {  // a CERTIFIED bound holds by construction: this would be a defect, not an input
+      c->last_error = "internal: the select found fewer keys above a certified pruning bound than the certificate counted";
+      return SC_EHIP;
+    }
+    c->last_error = "estimated pruning bound too high: call repeated with a certifying sample";
+    c->est_failed = true;  // this context certifies from now on
+    c->est_failed_call = true;
+    c->fast_ok = false;
+    return SC_ESPEC;
+  }
   if (c->sharded_ab && c->cand_all && c->pinned[12] != 0) {
     // merge_check_kernel (an earlier kernel of this stream: its system-scope store is visible once the winner word is):
     // some rank's candidate list was cut at a key the merged threshold does not clear
@@ -1318,13 +1358,26 @@ bool fast_plan(sc_ctx* c, int64_t n, const sc_params* p) {
   return true;
 }
 
-// the whole path the waiting way (what sc_register_device always did): complete on return
+// the whole path the waiting way (what sc_register_device always did): complete on return.  The only caller of the phases
+// that may prune by an ESTIMATED bound (it can repeat the call): a failed estimate comes back as SC_ESPEC from finalize_wait
+// and has switched estimating off for this context, so the second pass certifies.
 int register_waited(sc_ctx* c, const float* d_src, const float* d_tgt, int64_t n, const sc_params* p, float* d_Rt,
                     uint8_t* d_mask, sc_stats* stats) {
   c->spec_on = false;
-  int rc = sc_hypothesize_device(c, d_src, d_tgt, n, p, c->key.as<uint64_t>(), stats);
-  if (rc) return rc;
-  return sc_finalize_device(c, c->key.as<uint64_t>(), d_Rt, d_mask, stats);
+  int rc = SC_OK;
+  for (int pass = 0; pass < 2; pass++) {
+    c->est_allowed = true;
+    rc = hyp_begin(c, d_src, d_tgt, n, p, nullptr, 0, 1);
+    if (!rc) rc = hyp_end(c, nullptr, c->key.as<uint64_t>(), stats);
+    c->est_allowed = false;
+    if (rc) return rc;
+    HIPCHK(c, hipSetDevice(c->device));
+    rc = finalize_enqueue(c, c->key.as<uint64_t>(), 1, d_Rt, d_mask);
+    if (!rc) rc = finalize_wait(c, stats);
+    if (rc != SC_ESPEC) return rc;
+  }
+  c->last_error = "internal: a call was asked to repeat twice";
+  return SC_EHIP;
 }
 
 }  // namespace
@@ -1353,11 +1406,14 @@ int sc_register_device_async(sc_ctx* c, const float* d_src, const float* d_tgt, 
   memset(&c->pend_stats, 0, sizeof c->pend_stats);
   c->pend_stats.size = sizeof(sc_stats);
   c->fast_state = 0;
+  c->est_failed_call = false;
   if (fast_plan(c, n, p)) {
     // host-free: the whole chain is enqueued without looking at anything the GPU produces; sc_wait validates
     c->spec_on = true;
+    c->est_allowed = true;  // (sc_wait repeats a call whose estimated pruning bound fails, like any other failed assumption)
     rc = hyp_begin(c, d_src, d_tgt, n, p, nullptr, 0, 1);
     if (!rc) rc = hyp_end(c, nullptr, c->key.as<uint64_t>(), &c->pend_stats);
+    c->est_allowed = false;
     if (!rc) rc = finalize_enqueue(c, c->key.as<uint64_t>(), 1, d_Rt, d_mask);
     if (rc) { c->spec_on = false; c->fast_ok = false; return rc; }  // (a launch or allocation failed: nothing is outstanding)
     c->pending = true; c->pend_done = false;

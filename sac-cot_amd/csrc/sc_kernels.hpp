@@ -28,7 +28,9 @@ struct Tuning {
   uint32_t cnt_blocks = 0, keys_blocks = 0, sel_blocks = 0;  // grid sizes (0: automatic)
   int tg_count = 8, tg_keys = 8, tg_sample = 0;              // lanes per edge (tg_sample 0: by row width)
   int tg_events = 0;               // lanes per edge of the event-recording counting pass (0: by row width)
-  uint32_t sample_mode = 0;        // pruning sample: 0 by size (launch_sample_hist), 1 every stride-th edge, 2 the heaviest edges
+  uint32_t sample_mode = 0;        // pruning sample: 0 by size (launch_sample_hist), 1 every stride-th edge, 2 the heaviest edges (both CERTIFY their bound)
+  bool no_estimate = false;        // never prune by an ESTIMATED bound (sc_tri.hip 3c): always one of the certifying samples
+  uint32_t est_margin_pct = 0;     // the estimate aims at the (pct / 100 x T)-th key (0: 200; tests force failures with a small one)
   uint32_t sample_blocks = 0;      // grid of the heaviest-edge sample (0: one block per 256 edges)
   bool compact_fused = false;      // compaction in one launch (decoupled look-back) instead of count + write
   bool rows_unfused = false;       // row_stats and the scan(s) of the row counts as separate launches (round 1's form)
@@ -201,6 +203,19 @@ void launch_sample_hist(const Graph& g, const uint32_t* ebi, const uint32_t* ebj
                         const uint32_t* ej, const float* es, uint64_t E, uint64_t want, float key_floor, uint32_t part,
                         uint32_t parts, uint32_t* hist, uint32_t* es_hist, bool es_hist_ready, const Tuning& tn, hipStream_t st,
                         const uint64_t* E_dev = nullptr, uint64_t E_hint = 0);
+// The ESTIMATING sample (r04, sc_tri.hip 3c): one sampled 64-column word in `rate` of every edge's row pair, its triangles'
+// keys into `hist` — a uniform 1-in-rate sample of ALL the graph's triangles.  launch_prune_bits then takes the bin where
+// rate x (count from the top) reaches margin x T as the bound: an estimate, not a certificate — the select verifies it
+// (SelectState::want_req) and the caller repeats the call with a certifying sample when it was too high.
+struct SamplePlan {
+  bool estimate;       // true: launch_sample_estimate / hist_want below; false: launch_sample_hist (certifying), hist_want = T
+  uint32_t rate;       // power of two
+  uint64_t hist_want;  // what launch_prune_bits looks for in the histogram
+};
+SamplePlan sample_plan(uint64_t want, bool allow_estimate, const Tuning& tn);
+void launch_sample_estimate(const Graph& g, const uint32_t* ebi, const uint32_t* ebj, const uint32_t* ei, const uint32_t* ej,
+                            const float* es, uint64_t E, float key_floor, uint32_t rate, uint32_t* hist, const Tuning& tn,
+                            hipStream_t st, const uint64_t* E_dev = nullptr);
 // es_hist: PR_HCOPIES x 256 words (control block) for the weight histogram of the heaviest-edge sample: zeroed, or —
 // es_hist_ready — already filled by launch_edge_fill
 // launch_sample_hist ALWAYS accumulates into PR_HCOPIES x 256 words (`hist` = the control block's copies);
@@ -210,7 +225,8 @@ void launch_hist_reduce(const uint32_t* copies, uint32_t* out, hipStream_t st);
 void launch_prune_bits(const Graph& g, const uint32_t* hist, bool hist_is_copies, const uint32_t* ei, const uint32_t* ej, const float* es,
                        uint64_t E, uint64_t want, float key_floor, uint64_t* mbits, float* smin, uint32_t* klb,
                        const StrongList& sl, uint32_t* tcnt, const uint64_t* own, hipStream_t st,
-                       const uint64_t* E_dev = nullptr);  // E_dev: as above; with sl.list the tcnt entries of [*E_dev, E) are zeroed too
+                       const uint64_t* E_dev = nullptr,   // E_dev: as above; with sl.list the tcnt entries of [*E_dev, E) are zeroed too
+                       bool logbins = false);             // hist comes from launch_sample_estimate (logarithmic bins of 3.0 - key)
 // sharded stage B, after the certificate: work estimate per row of the PRUNED graph (strong_rowcost_kernel), and — in one
 // single-block launch — its prefix and this rank's row / edge range (the rule of launch_shard_split)
 void launch_strong_rowcost(const Graph& g, const uint64_t* mbits, uint32_t* rowcost, hipStream_t st);
@@ -250,7 +266,8 @@ struct SelectState {
   uint64_t want;           // number of keys to keep
   uint64_t above;          // keys strictly above the current window
   uint64_t need_eq;        // how many keys == kstar to keep (lowest ordinals first)
-  uint64_t pad;            // keeps hist 16-byte aligned (it is read and cleared with 16-byte accesses)
+  uint64_t want_req;       // != 0: the window's floor is a bound that must have this many keys at or above it (the last block of
+                           // a select round reports a shortfall: an ESTIMATED pruning bound that was too high, sc_tri.hip 3c)
   uint32_t hist[4096];
 };
 static_assert(offsetof(SelectState, hist) % 16 == 0, "SelectState::hist must be 16-byte aligned");
@@ -287,7 +304,8 @@ void launch_tri_keys(const Graph& g, const uint64_t* mbits, const float* smin, c
 void launch_tri_keys_events(const Graph& g, const float* es, const uint64_t* toff, int rank_mode,
                             const EventList& ev, uint32_t* wkey, uint2* kcol, uint32_t* blk_minmax,
                             SelectState* s, uint64_t want, const uint32_t* klb, uint64_t E, uint64_t cap,
-                            const Tuning& tn, hipStream_t st);  // cap: entries of wkey / kcol (writes beyond are dropped); want is clipped to toff[E]
+                            const Tuning& tn, hipStream_t st, bool check_bound = false);  // cap: entries of wkey / kcol (writes beyond are dropped); want is clipped to toff[E]
+// check_bound: with a pruning bound in *klb the select must find `want` keys at or above it (SelectState::want_req)
 // klb != nullptr (weight ranking, every edge weight >= 2/3): the kernel presets the select window to
 // [*klb or 2.0, 3.0] and no key-range pass runs; two select rounds then always suffice.
 // A key array as the select / compaction kernels see it.  Plain (seg_len == 0): M keys at base.  Segmented (the
@@ -306,7 +324,10 @@ struct KeyView {
 };
 KeyView plain_view(const uint32_t* wkey, uint64_t M);
 // `rounds` launches (histogram + pick by the last block to finish; 12 key bits each) find the exact threshold key
-void launch_select_rounds(const KeyView& view, SelectState* s, int rounds, const Tuning& tn, hipStream_t st);
+// host_short (optional, pinned u64): set to 1 when SelectState::want_req keys were promised above the window's floor and
+// fewer are there
+void launch_select_rounds(const KeyView& view, SelectState* s, int rounds, const Tuning& tn, hipStream_t st,
+                          uint64_t* host_short = nullptr);
 // compaction of the selected keys in ordinal order
 size_t compact_blocks(uint64_t M);
 void launch_compact_count(const KeyView& view, const SelectState* s, uint32_t* blk_gt, uint32_t* blk_eq,

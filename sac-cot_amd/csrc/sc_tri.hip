@@ -370,6 +370,7 @@ __global__ __launch_bounds__(1024) void key_range_kernel(const uint32_t* __restr
     for (int w = 1; w < 16; w++) { kmin = min(kmin, lmin[w]); kmax = max(kmax, lmax[w]); }
     sel->kmin = kmin; sel->kmax = kmax; sel->want = want;
     sel->started = 0; sel->done = 0; sel->above = 0;  // (a speculative key pass may have preset a window)
+    sel->want_req = 0;
   }
 }
 
@@ -549,7 +550,7 @@ __global__ __launch_bounds__(256) void tri_keys_events_kernel(const uint64_t* __
                                                               uint32_t* __restrict__ blk_max,
                                                               SelectState* __restrict__ preset,
                                                               const uint32_t* __restrict__ klb, uint64_t want,
-                                                              uint64_t E, uint64_t cap) {
+                                                              uint64_t E, uint64_t cap, int check_bound) {
   // cap: entries wkey / kcol hold.  The host may launch this kernel BEFORE it knows the triangle count (into the
   // arrays of the previous call, while it polls for the count): writes beyond cap are dropped and the host re-runs.
   // For the same reason `want` is clipped here to the count the scan left in toff[E].
@@ -565,6 +566,10 @@ __global__ __launch_bounds__(256) void tri_keys_events_kernel(const uint64_t* __
     preset->wbits = range_m1 == 0 ? 0u : (uint32_t)(32 - __builtin_clz(range_m1));
     preset->kmin = lo; preset->kmax = hi;
     preset->started = 1; preset->done = 0; preset->above = 0; preset->want = min(want, (uint64_t)toff[E]);
+    // a pruning bound promises `want` keys at or above it — a certified one by construction, an ESTIMATED one (3c) unless
+    // it was set too high: the select's last block compares (the UNclipped want: a pruned graph with fewer triangles than
+    // that proves nothing about the full one)
+    preset->want_req = (check_bound && *klb) ? want : 0ull;
   }  // exclusive prefix of the region fills: one flat index space over all events
   {
     constexpr int PT = EV_SHARDS / 256;  // regions per thread
@@ -685,11 +690,12 @@ void launch_tri_count_events(const Graph& g, const uint64_t* mbits, const Strong
 void launch_tri_keys_events(const Graph& g, const float* es, const uint64_t* toff, int rank_mode,
                             const EventList& ev, uint32_t* wkey, uint2* kcol, uint32_t* blk_minmax,
                             SelectState* s, uint64_t want, const uint32_t* klb, uint64_t E, uint64_t cap,
-                            const Tuning& tn, hipStream_t st) {
+                            const Tuning& tn, hipStream_t st, bool check_bound) {
   int nb = 2048;
   if (tn.keys_blocks >= 1 && tn.keys_blocks <= (uint32_t)TK_MAX_BLOCKS) nb = (int)tn.keys_blocks;
   hipLaunchKernelGGL(tri_keys_events_kernel, dim3(nb), dim3(256), 0, st, g.bits, g.wpre, g.deg, es, toff, rank_mode,
-                     ev, wkey, kcol, blk_minmax, blk_minmax + TK_MAX_BLOCKS, klb ? s : (SelectState*)nullptr, klb, want, E, cap);
+                     ev, wkey, kcol, blk_minmax, blk_minmax + TK_MAX_BLOCKS, klb ? s : (SelectState*)nullptr, klb, want, E, cap,
+                     check_bound ? 1 : 0);
   if (!klb)  // no a-priori window: the key range comes from the per-block extremes
     hipLaunchKernelGGL(key_range_kernel, dim3(1), dim3(1024), 0, st, blk_minmax, blk_minmax + TK_MAX_BLOCKS, nb, s, want);
 }
@@ -716,6 +722,20 @@ __device__ __forceinline__ uint32_t prune_bin(uint32_t key, uint32_t klo, uint32
   const uint32_t b = (key - klo) >> shift;
   return b < (uint32_t)PR_BINS ? b : (uint32_t)(PR_BINS - 1);
 }
+
+// The ESTIMATING sample (3c) bins by d = 3.0 - key instead — exact in fp32 for keys in [2, 3] — LOGARITHMICALLY, 16 bins per
+// octave of d over [2^-17, 2^-1): the top-T keys crowd against 3.0 (three weights near 1), where linear bins of 0.002
+// cannot tell the key of rank T from the key of rank 5 T; a bin 4.4 % wide in d is ~13 % wide in rank.  Bin 0: d >= 0.5
+// (nothing can be said), bin 255: d < 2^-17 (1 + 1/16).  Selected by shift == PR_LOGBINS.
+constexpr uint32_t PR_LOGBINS = 0xFFFFFFFFu;
+__device__ __forceinline__ uint32_t est_bin(uint32_t key) {
+  const float d = 3.0f - __uint_as_float(key);
+  if (!(d > 0.0f)) return (uint32_t)(PR_BINS - 1);
+  const uint32_t u = __float_as_uint(d) >> 19;  // exponent and four mantissa bits
+  return u >= 2016u ? 0u : (u <= 1761u ? (uint32_t)(PR_BINS - 1) : 2016u - u);
+}
+// a value every key of bin b (>= 1) lies strictly ABOVE: 3.0 - (upper edge of the bin's d interval), exact in fp32
+__device__ __forceinline__ float est_bin_floor(uint32_t b) { return 3.0f - __uint_as_float((2017u - b) << 19); }
 
 // Which edges are sampled.  Any subset of genuine triangles certifies a bound; the question is which subset certifies
 // a TIGHT one for the fewest key evaluations.
@@ -893,6 +913,92 @@ __global__ __launch_bounds__(256) void tri_sample_hist_kernel(const uint64_t* __
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// 3c. pruning by an ESTIMATED bound (r04)
+//
+// The certifying samples above pay for their certificate: to exhibit T genuine triangles above the bound they evaluate
+// 4 - 8 M keys at C2 (25 us, the largest launch of stage B), and the bound they can certify sits well below the T-th
+// key, so the pruned graph still holds 10 T triangles.  But the bound need not be certified BEFORE it is used: it can be
+// verified AFTERWARDS, for free.  Take ANY value LB, prune with smin = LB - 2 - 1e-6, enumerate, select.  If the strong
+// subgraph turns out to hold >= T triangles with key >= LB, the proof of 3b applies word for word (it only needs "at least
+// T triangles have key >= LB") and the selection is the full graph's top-T, ties included; if not, nothing is known and the
+// call is repeated with a certifying sample.  The select's first round already counts the keys in [LB, 3.0] — the check
+// is one comparison in its last block (SelectState::want_req).
+// So LB only has to be a good GUESS of a key of rank ~2 T: the lower edge of the histogram bin where
+// rate x (sampled count from the top) reaches margin x T, from a uniform 1-in-rate sample of ALL the graph's triangles.
+// The sample: a triangle (i, j, k), i < j < k, is found from its edge (i, j) in the 64-column word k / 64 of the row pair;
+// edge e looks at the words w >= j / 64 with w = hash(e) (mod rate) only — every (edge, word) pair, hence every triangle,
+// with probability exactly 1 / rate, independently across edges and words, so the sample is not dominated by a few edges
+// (an inlier-inlier edge has hundreds of triangles; a sampled word holds a handful).  One lane per edge: an edge record,
+// two gathered row words and — where they meet — the two prefix words and two weights per triangle: 0.36 M key
+// evaluations at C2 instead of 4 M, no block-level step at all.
+// With margin = 2 the estimate fails when the sample overstates the density of the top keys twofold: at >= 1000 expected
+// samples above the bound that is > 10 sigma even with word-sized clusters.  Failing costs a repeated call, never a wrong
+// result; a context that has seen one failure stops estimating (sc_capi.hip).
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t edge_hash(uint32_t e) {
+  e ^= e >> 16; e *= 0x7FEB352Du; e ^= e >> 15; e *= 0x846CA68Bu; e ^= e >> 16;  // (lowbias32)
+  return e;
+}
+
+__global__ __launch_bounds__(256) void tri_sample_words_kernel(const uint64_t* __restrict__ bits, int W,
+                                                               const uint32_t* __restrict__ wpre,
+                                                               const uint32_t* __restrict__ ebi,
+                                                               const uint32_t* __restrict__ ebj,
+                                                               const uint32_t* __restrict__ ei,
+                                                               const uint32_t* __restrict__ ej,
+                                                               const float* __restrict__ es, uint64_t E, uint32_t rmask,
+                                                               uint32_t* __restrict__ hist,
+                                                               const uint64_t* __restrict__ E_dev) {
+  if (E_dev && *E_dev > E) return;  // (launched before the host knew the count: see tri_sample_hist_kernel)
+  if (E_dev) E = *E_dev;
+  __shared__ uint32_t lh[PR_BINS * PR_COPIES];
+  for (int b = threadIdx.x; b < PR_BINS * PR_COPIES; b += 256) lh[b] = 0;
+  __syncthreads();
+  const uint64_t stride = (uint64_t)gridDim.x * 256;
+  for (uint64_t e = (uint64_t)blockIdx.x * 256 + threadIdx.x; e < E; e += stride) {
+    const uint32_t j = ej[e];
+    const int w0 = (int)(j >> 6);
+    int w = w0 + (int)((edge_hash((uint32_t)e) - (uint32_t)w0) & rmask);  // the first word >= w0 in this edge's residue class
+    if (w >= W) continue;
+    const uint32_t i = ei[e];
+    const uint32_t rowi = i * (uint32_t)W, rowj = j * (uint32_t)W;
+    const float s_ij = es[e];
+    const uint32_t bi = ebi[e], bj = ebj[e];
+    for (; w < W; w += (int)rmask + 1) {
+      const uint64_t ai = bits[rowi + w], aj = bits[rowj + w];
+      uint64_t m = ai & aj;
+      if (w == w0) m &= mask_above((int)(j & 63));
+      if (m == 0) continue;
+      const uint32_t pi = bi + wpre[rowi + w], pj = bj + wpre[rowj + w];
+      while (m) {
+        int b[4];
+        const int nbits = pop4(m, b);
+        float s_ik[4], s_jk[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+          const uint64_t below = (1ull << b[q]) - 1ull;
+          const bool live = q < nbits;
+          s_ik[q] = es[live ? pi + (uint32_t)__popcll(ai & below) : 0u];
+          s_jk[q] = es[live ? pj + (uint32_t)__popcll(aj & below) : 0u];
+        }
+#pragma unroll
+        for (int q = 0; q < 4; q++)
+          if (q < nbits)
+            atomicAdd(&lh[est_bin(__float_as_uint((s_ij + s_ik[q]) + s_jk[q])) * PR_COPIES + (threadIdx.x & (PR_COPIES - 1))], 1u);
+      }
+    }
+  }
+  __syncthreads();
+  uint32_t* __restrict__ myh = hist + (size_t)(blockIdx.x & (PR_HCOPIES - 1)) * PR_BINS;
+  for (int b = threadIdx.x; b < PR_BINS; b += 256) {
+    uint32_t v = 0;
+#pragma unroll
+    for (int c = 0; c < PR_COPIES; c++) v += lh[b * PR_COPIES + ((c + threadIdx.x) & (PR_COPIES - 1))];
+    if (v) atomicAdd(&myh[b], v);
+  }
+}
+
 // sum of the copies -> one 256-bin histogram (the form the ranks exchange)
 __global__ __launch_bounds__(256) void hist_reduce_kernel(const uint32_t* __restrict__ copies, uint32_t* __restrict__ out) {
   uint32_t v = 0;
@@ -933,9 +1039,9 @@ __global__ __launch_bounds__(256) void prune_bits_kernel(const uint32_t* __restr
   uint64_t tot;
   const uint64_t before = block_exscan_u64(mine, lds, &tot);
   if (before < want && want <= before + mine && bin > 0) {
-    const float lb = __uint_as_float(klo + (bin << shift));  // lower edge of the crossing bin
+    const float lb = shift == PR_LOGBINS ? est_bin_floor(bin) : __uint_as_float(klo + (bin << shift));  // lower edge of the crossing bin
     s_smin = (lb - 2.0f) - 1e-6f;
-    s_klb = klo + (bin << shift);  // >= want triangles have a key >= this one: the select may ignore anything below
+    s_klb = __float_as_uint(lb);  // >= want triangles have a key >= this one: the select may ignore anything below
   }
   __syncthreads();
   const float smin = s_smin;
@@ -1062,11 +1168,48 @@ void launch_sample_hist(const Graph& g, const uint32_t* ebi, const uint32_t* ebj
 #undef SC_LAUNCH_SAMPLE
 }
 
+SamplePlan sample_plan(uint64_t want, bool allow_estimate, const Tuning& tn) {
+  SamplePlan sp{false, 1u, want};
+  if (!allow_estimate || tn.no_estimate || tn.sample_mode != 0 || want == 0) return sp;
+  // rate: 64 while 2 T still leaves >= 1024 expected samples above the bound, halved below that, never under 8 (a whole-graph
+  // enumeration is what the pruning is there to avoid)
+  uint32_t rate = 64;
+  while (rate > 8 && 2 * want / rate < 1024) rate >>= 1;
+  // the rank the bound aims at, in % of T: T plus eight standard deviations of the sampled count at rank T — a sampled word
+  // brings its triangles together, ~8 at a time — within [115, 200] (C2 181, C3 140, C4 126)
+  uint64_t margin = tn.est_margin_pct;
+  if (!margin) {
+    const double at_T = (double)want / rate;
+    double m = 1.0 + 8.0 * __builtin_sqrt(8.0 / (at_T > 1.0 ? at_T : 1.0));
+    m = m < 1.15 ? 1.15 : (m > 2.0 ? 2.0 : m);
+    margin = (uint64_t)(m * 100.0 + 0.5);
+  }
+  const uint64_t aim = (want * margin + 99) / 100;
+  uint64_t hw = (aim + rate - 1) / rate;
+  if (hw < 128 && !tn.est_margin_pct) hw = 128;
+  if (hw < 1) hw = 1;
+  sp.estimate = true; sp.rate = rate; sp.hist_want = hw;
+  return sp;
+}
+
+void launch_sample_estimate(const Graph& g, const uint32_t* ebi, const uint32_t* ebj, const uint32_t* ei, const uint32_t* ej,
+                            const float* es, uint64_t E, float key_floor, uint32_t rate, uint32_t* hist, const Tuning& tn,
+                            hipStream_t st, const uint64_t* E_dev) {
+  if (E == 0) return;
+  (void)key_floor;  // (the logarithmic bins need no window)
+  uint64_t nb = (E + 255) / 256;
+  if (nb > 4096) nb = 4096;
+  if (tn.sample_blocks) nb = tn.sample_blocks;
+  hipLaunchKernelGGL(tri_sample_words_kernel, dim3((unsigned)nb), dim3(256), 0, st, g.bits, g.W, g.wpre, ebi, ebj, ei, ej, es, E,
+                     rate - 1u, hist, E_dev);
+}
+
 void launch_prune_bits(const Graph& g, const uint32_t* hist, bool hist_is_copies, const uint32_t* ei, const uint32_t* ej, const float* es,
                        uint64_t E, uint64_t want, float key_floor, uint64_t* mbits, float* smin, uint32_t* klb,
-                       const StrongList& sl, uint32_t* tcnt, const uint64_t* own, hipStream_t st, const uint64_t* E_dev) {
+                       const StrongList& sl, uint32_t* tcnt, const uint64_t* own, hipStream_t st, const uint64_t* E_dev, bool logbins) {
   uint32_t klo, shift;
   prune_window(key_floor, &klo, &shift);
+  if (logbins) shift = PR_LOGBINS;  // the histogram of launch_sample_estimate
   const uint64_t blocks = sl.region_blocks ? (uint64_t)sl.region_blocks * ST_SHARDS : (E + 255) / 256;
   hipLaunchKernelGGL(prune_bits_kernel, dim3((unsigned)blocks), dim3(256), 0, st, hist,
                      hist_is_copies ? PR_HCOPIES : 1, want, klo, shift, ei,
@@ -1278,7 +1421,7 @@ __device__ __forceinline__ uint4 view_load4(const KeyView& v, uint64_t q) {
 
 template <bool SEG>
 __global__ __launch_bounds__(SEL_THREADS) void select_round_kernel(KeyView view, SelectState* __restrict__ sel,
-                                                                   int rounds_left) {
+                                                                   int rounds_left, uint64_t* __restrict__ host_short) {
   const uint64_t M = view_count(view);
   const uint32_t* __restrict__ wkey = view.base;
   __shared__ uint32_t lh[SEL_BINS];
@@ -1351,6 +1494,9 @@ __global__ __launch_bounds__(SEL_THREADS) void select_round_kernel(KeyView view,
   // stage B: the certified bound promises T keys above it in the whole graph, not in one rank's share): then every key
   // of the window is taken.  (Unsharded, the window always holds enough and this changes nothing.)
   const uint64_t want_eff = want < above0 + tot ? want : above0 + tot;
+  // a pruning bound that promised want_req keys at or above the window's floor and did not keep it (an estimate set too
+  // high — sc_tri.hip 3c): the selection of this call proves nothing; the host repeats it with a certifying sample
+  if (threadIdx.x == 0 && host_short && sel->want_req != 0 && above0 + tot < sel->want_req) publish_host(host_short, 1ull);
   // the crossing thread: before < want <= before + mine (exactly one: the window holds >= want - above0 keys)
   if (before < want_eff && want_eff <= before + mine) {
     uint64_t run = before;
@@ -1376,7 +1522,8 @@ __global__ __launch_bounds__(SEL_THREADS) void select_round_kernel(KeyView view,
 
 KeyView plain_view(const uint32_t* wkey, uint64_t M) { return KeyView{wkey, M, 0, 0, nullptr, 0, nullptr}; }
 
-void launch_select_rounds(const KeyView& view, SelectState* s, int rounds, const Tuning& tn, hipStream_t st) {
+void launch_select_rounds(const KeyView& view, SelectState* s, int rounds, const Tuning& tn, hipStream_t st,
+                          uint64_t* host_short) {
   const uint64_t M = view.M;
   if (M == 0) return;
   uint64_t blocks = (M + (uint64_t)SEL_THREADS * SEL_ITEMS - 1) / ((uint64_t)SEL_THREADS * SEL_ITEMS);
@@ -1386,8 +1533,8 @@ void launch_select_rounds(const KeyView& view, SelectState* s, int rounds, const
   if (blocks > cap) blocks = cap;
   if (blocks == 0) blocks = 1;
   for (int round = 0; round < rounds; round++) {
-    if (view.seg_len) hipLaunchKernelGGL(select_round_kernel<true>, dim3((unsigned)blocks), dim3(SEL_THREADS), 0, st, view, s, rounds - round);
-    else hipLaunchKernelGGL(select_round_kernel<false>, dim3((unsigned)blocks), dim3(SEL_THREADS), 0, st, view, s, rounds - round);
+    if (view.seg_len) hipLaunchKernelGGL(select_round_kernel<true>, dim3((unsigned)blocks), dim3(SEL_THREADS), 0, st, view, s, rounds - round, host_short);
+    else hipLaunchKernelGGL(select_round_kernel<false>, dim3((unsigned)blocks), dim3(SEL_THREADS), 0, st, view, s, rounds - round, host_short);
   }
 }
 
@@ -1706,7 +1853,7 @@ __global__ __launch_bounds__(64) void merge_prepare_kernel(const uint64_t* __res
   }
   if (r != 0) return;
   const uint64_t want = ns < (uint64_t)T ? ns : (uint64_t)T;
-  sel->want = want; sel->above = 0; sel->done = 0; sel->ticket = 0;
+  sel->want = want; sel->above = 0; sel->done = 0; sel->ticket = 0; sel->want_req = 0;
   if (fast) {
     const uint32_t lo = *klb ? *klb : 0x40000000u, hi = 0x40400000u;  // 2.0f, 3.0f
     const uint32_t range_m1 = hi - lo;

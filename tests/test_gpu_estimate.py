@@ -1,0 +1,107 @@
+"""GPU: stage B pruned by an ESTIMATED bound (sc_tri.hip 3c).
+
+sc_register / sc_register_device(_async) prune the graph by a bound guessed from a 1-in-64 sample of its triangles instead
+of one certified by a 4 M-key sample; the select verifies the guess (it must find T keys at or above it) and a call whose
+guess was too high is repeated with a certifying sample.  Either way the outputs are the certified path's, bit for bit —
+and that path is what tests/test_gpu_parity.py pins to the CPU restatement.
+"""
+import numpy as np
+import pytest
+
+from conftest import nan_equal_bits
+
+pytestmark = pytest.mark.gpu
+
+KEYS = ("edges", "tri_kept", "tri_scored", "best_rank", "best_count")
+
+
+def _same(a, b):
+    return (a["status"] == b["status"] and np.array_equal(a["mask"], b["mask"]) and nan_equal_bits(a["R"], b["R"])
+            and nan_equal_bits(a["t"], b["t"]) and all(a["stats"][k] == b["stats"][k] for k in KEYS))
+
+
+@pytest.mark.parametrize("name", ["C1", "C2", "C3", "C4"])
+def test_estimated_bound_is_verified_and_changes_nothing_but_the_work(pkg, O, name):
+    cfg, scene = pkg.synth.make_config_scene(name)
+    r = pkg.Registrar(0)
+    try:
+        est = r.register(scene.src, scene.tgt, **cfg.params())
+        assert r.debug_last()["prune_bound"] == 1, r.debug_last()
+        again = r.register(scene.src, scene.tgt, **cfg.params())       # the host-free repetition estimates too
+        d = r.debug_last()
+        assert d["prune_bound"] == 1 and d["fast_path"] == 1 and _same(again, est)
+        r.set_debug(no_estimate=1)
+        cert = r.register(scene.src, scene.tgt, **cfg.params())
+        assert r.debug_last()["prune_bound"] == 0
+        assert _same(est, cert)
+        assert cfg.T <= est["stats"]["tri_total"]
+        print(name, "triangles enumerated: estimated bound", est["stats"]["tri_total"], "certified", cert["stats"]["tri_total"])
+    finally:
+        r.close()
+    if name != "C3":   # (the oracle's C3 pass is minutes of host time; test_gpu_parity.py covers that shape)
+        ref = O.register(scene.src, scene.tgt, threads=8, **cfg.params())
+        assert np.array_equal(est["mask"], ref["mask"]) and est["stats"]["best_rank"] == ref["best_rank"]
+        assert nan_equal_bits(np.concatenate([est["R"].ravel(), est["t"]]), np.concatenate([ref["R"].ravel(), ref["t"]]))
+
+
+@pytest.mark.parametrize("name", ["C1", "C2"])
+def test_estimate_that_is_too_high_is_caught_and_the_call_repeated(pkg, name):
+    """est_margin_pct = 1 aims the bound at the key of rank T / 100: the pruned graph then holds far fewer than T triangles
+    above it, the select reports the shortfall, the call is repeated with a certifying sample — same outputs — and the
+    context certifies from then on."""
+    import torch
+    dev = torch.device("cuda:0")
+    cfg, scene = pkg.synth.make_config_scene(name)
+    ref_r = pkg.Registrar(0); ref_r.set_debug(no_estimate=1)
+    ref = ref_r.register(scene.src, scene.tgt, **cfg.params())
+    ref_r.close()
+    r = pkg.Registrar(0)
+    try:
+        r.set_debug(est_margin_pct=1)
+        got = r.register(scene.src, scene.tgt, **cfg.params())
+        assert r.debug_last()["prune_bound"] == 2, r.debug_last()
+        assert _same(got, ref) and got["stats"]["tri_total"] == ref["stats"]["tri_total"]
+        nxt = r.register(scene.src, scene.tgt, **cfg.params())          # sticky: no second failure on this context
+        assert r.debug_last()["prune_bound"] == 0 and _same(nxt, ref)
+        # the same through the host-free form: a good call, then the knob makes the REPEATED shape's estimate fail
+        r.set_debug()                                                   # (also forgets the failure)
+        ds = torch.from_numpy(scene.src).to(dev); dt = torch.from_numpy(scene.tgt).to(dev)
+        p = pkg.make_params(**cfg.params())
+        outs = []
+        for k in range(3):
+            d_Rt = torch.zeros(12, dtype=torch.float32, device=dev); d_mask = torch.zeros(cfg.n, dtype=torch.uint8, device=dev)
+            rc, st = r.register_device(ds.data_ptr(), dt.data_ptr(), cfg.n, p, d_Rt.data_ptr(), d_mask.data_ptr())
+            torch.cuda.synchronize()
+            outs.append((rc, st, d_Rt.cpu().numpy(), d_mask.cpu().numpy(), r.debug_last()))
+        assert [o[4]["prune_bound"] for o in outs] == [1, 1, 1] and [o[4]["fast_path"] for o in outs] == [0, 1, 1]
+        for rc, st, Rt, mask, _ in outs:
+            assert rc == ref["status"] and np.array_equal(mask, ref["mask"]) and st["best_rank"] == ref["stats"]["best_rank"]
+            assert nan_equal_bits(Rt, np.concatenate([ref["R"].ravel(), ref["t"]]))
+    finally:
+        r.close()
+
+
+def test_estimate_on_graphs_with_few_or_tied_triangles(pkg, O):
+    """Fewer triangles than T (the sample never reaches its count: no pruning at all), massive ties (all weights equal:
+    every key in one bin), T far above and far below the sample's resolution."""
+    r = pkg.Registrar(0)
+    try:
+        n, tau = 2000, 0.02
+        for rho, L, T in ((0.01, 6.0, 10000), (0.20, 1.0, 50), (0.20, 1.0, 3_000_000), (0.0, 1.0, 10000)):
+            sc = pkg.synth.make_scene(n, rho, L, tau, 77)
+            kw = dict(sigma=tau, t_cmp=0.9, tau=tau, min_len=tau, max_triangles=T, rank_mode=0)
+            got = r.register(sc.src, sc.tgt, **kw)
+            ref = O.register(sc.src, sc.tgt, threads=8, **kw)
+            assert got["status"] == ref["rc"] and np.array_equal(got["mask"], ref["mask"]), (rho, L, T)
+            assert got["stats"]["best_rank"] == ref["best_rank"] and got["stats"]["tri_kept"] == ref["t_eff"], (rho, L, T)
+        # massive ties: a lattice moved rigidly, sigma huge -> every edge weight rounds to the same value
+        g = np.stack(np.meshgrid(np.arange(12), np.arange(12), np.arange(6), indexing="ij"), -1).reshape(-1, 3).astype(np.float32)
+        src = g * 0.5
+        tgt = src + np.float32(0.25)
+        kw = dict(sigma=1e4, t_cmp=0.9, tau=0.01, min_len=0.1, max_triangles=5000, rank_mode=0)
+        got = r.register(src, tgt, **kw)
+        ref = O.register(src, tgt, threads=8, **kw)
+        assert got["status"] == ref["rc"] and np.array_equal(got["mask"], ref["mask"])
+        assert got["stats"]["best_rank"] == ref["best_rank"] and got["stats"]["tri_kept"] == ref["t_eff"]
+    finally:
+        r.close()

@@ -750,7 +750,9 @@ def test_sharded_A_and_B_equal_unsharded(pkg, O, reg, name, worlds):
     import torch
     cfg, scene = pkg.synth.make_config_scene(name)
     kw = cfg.params()
-    base = reg.register(scene.src, scene.tgt, **kw)
+    certified = pkg.Registrar(0); certified.set_debug(no_estimate=1)   # the phase API certifies its pruning bound: so must the base
+    base = certified.register(scene.src, scene.tgt, **kw)
+    certified.close()
     ref = O.register(scene.src, scene.tgt, threads=8, **kw)
     assert base["stats"]["best_rank"] == ref["best_rank"]
     dev = torch.device("cuda:0")
