@@ -409,6 +409,7 @@ def main() -> int:
             "metric": "triangle-hypotheses scored/sec (end-to-end: compat graph + ranked triangles + SVD + scoring + mask)",
             "value": value, "unit": "hypotheses/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "ms_per_step_median": float(np.median(step_s)) * 1e3,
+            "ms_per_step_min_max": [round(float(np.min(step_s)) * 1e3, 4), round(float(np.max(step_s)) * 1e3, 4)],
             "higher_is_better": True, "scaling": args.scaling,
             "vs_baseline": None, "dtype": "f32", "data": "synthetic" + (" (REHEARSAL: all ranks on one GPU over gloo)" if rehearsal else ""),
             "config": {"workload": f"{cfg.name}: N={n} synthetic correspondences ({cfg.rho:.0%} inliers, L={cfg.L}, "

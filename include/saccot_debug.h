@@ -49,7 +49,9 @@ typedef struct sc_debug {
   uint32_t tail_unfused;      /* 1: the exact pass, the arg-max and the winner / mask kernel as three launches (r03's form) instead of one */
   uint32_t no_estimate;       /* 1: stage B never prunes by an ESTIMATED bound (verified by the select, call repeated when it was too high) — always by a certifying sample, as every entry point other than sc_register / sc_register_device(_async) does anyway */
   uint32_t est_margin_pct;    /* the estimated bound aims at the key of rank (pct / 100) x T (0 = 200); a small value forces the failure-and-repeat path (tests) */
-  uint32_t reserved[3];
+  uint32_t no_edge_build;     /* 1: row statistics, edge list and the estimating sample as three launches instead of the hot path's one (launch_edge_build) */
+  uint32_t build_sample;      /* 1: the fused edge kernel also takes the estimating sample (instead of a launch of its own) */
+  uint32_t reserved[1];
 } sc_debug;
 int         sc_set_debug(sc_ctx* ctx, const sc_debug* dbg);
 

@@ -109,6 +109,7 @@ struct sc_ctx {
   int est_state = 0;         // last pass: 0 certified bound (or no pruning), 1 estimated and verified
   bool est_failed_call = false;  // the running / last call saw its estimate fail and was repeated (sc_debug_last: prune_bound 2)
   SamplePlan plan{false, 1u, 0};
+  bool build = false;        // the running call takes launch_edge_build (row statistics + edge list + estimating sample in one launch)
   // run-time probe of the matrix pipe's accumulation model (sc_score.hip gram_guard): 0 not run, 1 holds, 2 violated
   int gram_guard = 0;
   float gram_guard_worst = 0.f;
@@ -287,10 +288,12 @@ int stage_inputs(sc_ctx* c, const float* d_src, const float* d_tgt, int64_t n, c
   }
   ENSURE(c, c->fx_part, stage_part_words(c->ld) * 4);
   c->pinned[13] = ~0ull;  // "maxima not known yet"
+  if (c->build) ENSURE(c, c->degp, (size_t)c->ld * sizeof(uint32_t));  // stage A accumulates deg+ there: cleared on the way
   launch_stage_points(d_src, d_tgt, c->n, c->ld, p->layout, c->planes.as<float>(),
                       reinterpret_cast<uint32_t*>(&c->pinned[1]), c->ctl.as<uint32_t>(),
                       (uint32_t)(sizeof(ControlBlock) / 4), c->fx_mx.as<uint32_t>(), c->fx_part.as<uint32_t>(),
-                      c->fx_mx.as<uint32_t>() + FX_MX_WORDS, &c->pinned[13], &c->pinned[16], c->stream);
+                      c->fx_mx.as<uint32_t>() + FX_MX_WORDS, &c->pinned[13], &c->pinned[16], c->stream,
+                      c->build ? c->degp.as<uint32_t>() : nullptr, c->build ? (uint32_t)c->ld : 0u);
   return SC_OK;
 }
 
@@ -302,11 +305,12 @@ int run_compat(sc_ctx* c, bool dense) {
   if (dense) ENSURE(c, c->S, n * ld * sizeof(float));
   ENSURE(c, c->bits, n * W * sizeof(uint64_t));
   ENSURE(c, c->deg, n * sizeof(uint32_t));
-  ENSURE(c, c->degp, n * sizeof(uint32_t));
+  ENSURE(c, c->degp, ld * sizeof(uint32_t));
   ENSURE(c, c->wpre, n * W * sizeof(uint32_t));
   c->bits_cur = c->bits.as<uint64_t>();
   c->sharded_ab = false; c->shard_phase = 0; c->cand_all = nullptr;
-  launch_compat(points_of(c), c->dv, dense ? c->S.as<float>() : nullptr, c->bits_cur, 0, c->n, c->tn, c->stream);
+  launch_compat(points_of(c), c->dv, dense ? c->S.as<float>() : nullptr, c->bits_cur, 0, c->n, c->tn, c->stream,
+                c->build ? c->degp.as<uint32_t>() : nullptr);
   return SC_OK;
 }
 
@@ -316,6 +320,10 @@ void arm_word(sc_ctx* c, int idx);
 // hot: the fused form (row statistics + CSR offsets + edge count in one launch; run_edges then launches no scan)
 int run_row_stats(sc_ctx* c, bool will_prune, bool hot = false) {
   c->rows_fused = false;
+  if (hot && c->build) {  // launch_edge_build (run_edges) does all of it
+    ENSURE(c, c->bits2, (size_t)c->n * (c->ld >> 6) * sizeof(uint64_t));
+    return SC_OK;
+  }
   uint64_t* zero_rows = nullptr;
   if (will_prune) {  // the pruned bit matrix is cleared on the way (no separate memset)
     ENSURE(c, c->bits2, (size_t)c->n * (c->ld >> 6) * sizeof(uint64_t));
@@ -376,6 +384,16 @@ int wait_word(sc_ctx* c, int idx) {
 
 bool may_prune(const sc_params* p) { return p->rank_mode == SC_RANK_WEIGHT && !(p->flags & SC_FLAG_NO_PRUNE); }
 
+// The hot path's fused form of row_stats_scan + edge_fill + the estimating sample (sc_tri.hip 1'): where the pruning bound
+// will be an estimate (the same conditions as sample_plan's in run_edges, minus what only the edge count decides) and the
+// bit rows are short enough for the kernel
+bool edge_build_ok(const sc_ctx* c, const sc_params* p, int64_t n) {
+  const bool window_known = p->rank_mode == SC_RANK_WEIGHT && 3.0f * p->t_cmp * 0.999f >= 2.0f;
+  return c->est_allowed && !c->est_failed && window_known && may_prune(p) && !c->tn.no_events && !c->tn.no_estimate &&
+         c->tn.sample_mode == 0 && !c->tn.no_edge_build && !c->tn.rows_unfused && edge_build_fits((int)n) && p->shard_world == 1 &&
+         p->max_triangles != 0;
+}
+
 // stage B; on return c->E, c->M, c->T_eff are set and tri/trikey hold the ranked list
 // Stage B, first half: CSR edge list and this process's share (`part` of `parts`) of the pruning sample, accumulated
 // into `hist` (256 u32 on the device, already zero; nullptr = the control block's own histogram).  Sets c->E and the
@@ -386,9 +404,11 @@ int run_edges(sc_ctx* c, const sc_params* p, uint32_t* hist, uint32_t part, uint
   ENSURE(c, c->edge_off, (n + 1) * sizeof(uint64_t));
   ENSURE(c, c->scan_tmp, scan_temp_bytes(n));
   // read-back #1: the scan kernel itself writes the edge count to host-pinned memory (no copy kernel)
-  const bool fused = c->rows_fused;
+  const bool build = c->build && hist == nullptr && parts == 1;
+  if (c->build && !build) { c->last_error = "internal: the fused edge kernel was chosen for a call that shares its sample"; return SC_EHIP; }
+  const bool fused = c->rows_fused || build;
   c->rows_fused = false;
-  if (!fused) arm_word(c, 0);
+  if (!fused || build) arm_word(c, 0);
   ENSURE(c, c->ebase, n * 4);
   ScanExtra xe;  // the scan of deg+ also writes the per-row CSR bases edge_fill reads
   xe.deg = c->deg.as<uint32_t>(); xe.degp = c->degp.as<uint32_t>(); xe.ebase = c->ebase.as<uint32_t>();
@@ -415,16 +435,24 @@ int run_edges(sc_ctx* c, const sc_params* p, uint32_t* hist, uint32_t part, uint
   // capacity are dropped by the kernel; in that case, or on a first call, it runs (again) after the read-back.
   const Graph g = graph_of(c);
   uint64_t spec_cap = c->es.cap / 4 >= 2 ? c->es.cap / 4 - 2 : 0;  // es carries two pad entries
-  for (const Buf* b : {&c->ei, &c->ej, &c->ebi, &c->ebj}) spec_cap = b->cap / 4 < spec_cap ? b->cap / 4 : spec_cap;
+  for (const Buf* b : {&c->ei, &c->ej}) spec_cap = b->cap / 4 < spec_cap ? b->cap / 4 : spec_cap;
+  if (!build) for (const Buf* b : {&c->ebi, &c->ebj}) spec_cap = b->cap / 4 < spec_cap ? b->cap / 4 : spec_cap;
   // the weight histogram of the heaviest-edge pruning sample is collected by the same kernel (sc_debug.sample_mode = ...
   // any: it costs edge_fill ~1 us and saves a launch whenever that sample is chosen)
   uint32_t* es_hist = c->tn.es_hist_unfused ? nullptr : c->ctl.as<ControlBlock>()->es_hist;
+  const SamplePlan plan0 = sample_plan(p->max_triangles, build, c->tn);  // (build: the sample rides the edge kernel)
   auto fill_edges = [&](uint64_t cap) {
+    if (build) {
+      launch_edge_build(g, points_of(c), c->dv, c->bits2.as<uint64_t>(), c->edge_off.as<uint64_t>(), c->ebase.as<uint32_t>(),
+                        c->ei.as<uint32_t>(), c->ej.as<uint32_t>(), c->es.as<float>(), cap, &c->pinned[0], plan0.rate,
+                        c->tn.build_sample ? c->ctl.as<ControlBlock>()->prune_hist : nullptr, st);
+      return;
+    }
     launch_edge_fill(g, points_of(c), c->dv, c->edge_off.as<uint64_t>(), c->ei.as<uint32_t>(), c->ej.as<uint32_t>(),
                      c->es.as<float>(), c->ebase.as<uint32_t>(), fused || scan_writes_ebase(n), c->ebi.as<uint32_t>(),
                      c->ebj.as<uint32_t>(), cap, es_hist, st);
   };
-  if (spec_cap) fill_edges(spec_cap);
+  if (spec_cap || build) fill_edges(spec_cap);  // (the fused kernel also makes the row statistics and the count itself)
   // Host-free call (c->spec_on; fast_plan() made sure E_cov <= spec_cap): no wait.  E is then what the launches and arrays
   // COVER; the kernels below take the real count from edge_off[n] (E_dev) and the end of the call validates it.
   const bool spec = c->spec_on;
@@ -446,12 +474,12 @@ int run_edges(sc_ctx* c, const sc_params* p, uint32_t* hist, uint32_t part, uint
   ENSURE(c, c->ej, E * 4);
   ENSURE(c, c->es, (E + 2) * 4);  // +1: the 4-way unrolled gathers of idle slots may touch index E
   ENSURE(c, c->tcnt, E * 4);
-  ENSURE(c, c->ebi, E * 4);
-  ENSURE(c, c->ebj, E * 4);
+  if (!build) { ENSURE(c, c->ebi, E * 4); ENSURE(c, c->ebj, E * 4); }
   ENSURE(c, c->toff, (E + 1) * 8);
   ENSURE(c, c->scan_tmp, scan_temp_bytes(E));
   if (E > spec_cap) {  // first call, or the graph outgrew the arrays (just re-allocated above)
-    if (es_hist && spec_cap) HIPCHK(c, hipMemsetAsync(es_hist, 0, sizeof(uint32_t) * PR_HCOPIES * 256, st));  // the partial run's counts
+    if (es_hist && spec_cap && !build) HIPCHK(c, hipMemsetAsync(es_hist, 0, sizeof(uint32_t) * PR_HCOPIES * 256, st));  // the partial run's counts
+    if (build && c->tn.build_sample) HIPCHK(c, hipMemsetAsync(c->ctl.as<ControlBlock>()->prune_hist, 0, sizeof(uint32_t) * PR_HCOPIES * 256, st));  // (the first run's sample)
     fill_edges(E);
   }
   // certified pruning (sc_tri.hip 3b): weight ranking only; pointless on tiny graphs
@@ -473,9 +501,13 @@ int run_edges(sc_ctx* c, const sc_params* p, uint32_t* hist, uint32_t part, uint
     c->plan = sample_plan(p->max_triangles, c->est_allowed && !c->est_failed && hist == nullptr && parts == 1 && !c->sharded_ab &&
                                                 c->use_events && window_known, c->tn);
     c->est_active = c->plan.estimate;
-    if (c->plan.estimate)
-      launch_sample_estimate(g, c->ebi.as<uint32_t>(), c->ebj.as<uint32_t>(), c->ei.as<uint32_t>(), c->ej.as<uint32_t>(),
-                             c->es.as<float>(), E, 3.0f * p->t_cmp * 0.999f, c->plan.rate, ctl->prune_hist, c->tn, st, E_dev);
+    if (build && !c->plan.estimate) { c->last_error = "internal: the fused edge kernel ran but the bound is not an estimate"; return SC_EHIP; }
+    if (build && c->tn.build_sample) {
+      // (the sample's histogram came out of launch_edge_build)
+    } else if (c->plan.estimate)
+      launch_sample_estimate(g, build ? nullptr : c->ebi.as<uint32_t>(), build ? nullptr : c->ebj.as<uint32_t>(), c->ei.as<uint32_t>(),
+                             c->ej.as<uint32_t>(), c->es.as<float>(), E, 3.0f * p->t_cmp * 0.999f, c->plan.rate, ctl->prune_hist, c->tn,
+                             st, E_dev, c->ebase.as<uint32_t>());
     else
       launch_sample_hist(g, c->ebi.as<uint32_t>(), c->ebj.as<uint32_t>(), c->ei.as<uint32_t>(), c->ej.as<uint32_t>(),
                          c->es.as<float>(), E, p->max_triangles, 3.0f * p->t_cmp * 0.999f, part, parts,
@@ -564,8 +596,9 @@ int run_select(sc_ctx* c, const sc_params* p, const uint32_t* hist, bool want_li
     c->pinned[5] = 0;
     ev = event_list(c->events.p, ev_cap, g.W, c->ctl.as<ControlBlock>()->ev_fill,
                     reinterpret_cast<uint32_t*>(&c->pinned[5]));
-    launch_tri_count_events(g, mbits, sl, c->ebi.as<uint32_t>(), c->ebj.as<uint32_t>(), c->ei.as<uint32_t>(),
-                            c->ej.as<uint32_t>(), spec ? c->E_last : E, p->rank_mode, c->tcnt.as<uint32_t>(), ev, c->tn, st, own_range_of(c));
+    launch_tri_count_events(g, mbits, sl, c->build ? nullptr : c->ebi.as<uint32_t>(), c->build ? nullptr : c->ebj.as<uint32_t>(), c->ei.as<uint32_t>(),
+                            c->ej.as<uint32_t>(), spec ? c->E_last : E, p->rank_mode, c->tcnt.as<uint32_t>(), ev, c->tn, st, own_range_of(c),
+                            c->ebase.as<uint32_t>());
   } else {
     launch_tri_count(g, mbits, c->es.as<float>(), smin, c->ei.as<uint32_t>(), c->ej.as<uint32_t>(), E,
                      c->tcnt.as<uint32_t>(), own_range_of(c), c->tn, st);
@@ -715,6 +748,7 @@ float ev_us(sc_ctx* c, int a, int b) {
 }
 
 int host_to_planes(sc_ctx* c, const float* src, const float* tgt, int64_t n, const sc_params* p) {
+  c->build = false;  // (stage hooks: the separate kernels)
   if (!src || !tgt || n < 3 || n > (1 << 24)) return SC_EINVAL;
   ENSURE(c, c->in_src, (size_t)n * 12);
   ENSURE(c, c->in_tgt, (size_t)n * 12);
@@ -860,6 +894,8 @@ int sc_set_debug(sc_ctx* c, const sc_debug* d) {
   t.gram_guard_fail = d->gram_guard_fail != 0;
   t.tail_unfused = d->tail_unfused != 0;
   t.no_estimate = d->no_estimate != 0;
+  t.no_edge_build = d->no_edge_build != 0;
+  t.build_sample = d->build_sample != 0;
   t.est_margin_pct = d->est_margin_pct;
   c->tn = t;
   c->fast_ok = false;  // (the next call waits: its launch geometry may differ from the last call's)
@@ -902,6 +938,7 @@ int hyp_begin(sc_ctx* c, const float* d_src, const float* d_tgt, int64_t n, cons
   c->cap_bytes = p->max_workspace ? p->max_workspace : (64ull << 30);
   c->dv = derive(p);
   c->params = *p;
+  c->build = d_hist == nullptr && parts == 1 && edge_build_ok(c, p, n);
   if ((rc = rec(c, 0))) return rc;
   if ((rc = stage_inputs(c, d_src, d_tgt, n, p))) return rc;
   if ((rc = rec(c, 1))) return rc;
@@ -1118,6 +1155,7 @@ int sc_shard_compat_device(sc_ctx* c, const float* d_src, const float* d_tgt, in
   c->dv = derive(p);
   c->params = *p;
   c->shard_phase = 0; c->cand_all = nullptr;
+  c->build = false;
   if ((rc = rec(c, 0))) return rc;
   if ((rc = stage_inputs(c, d_src, d_tgt, n, p))) return rc;
   if ((rc = rec(c, 1))) return rc;
@@ -1348,7 +1386,11 @@ bool fast_plan(sc_ctx* c, int64_t n, const sc_params* p) {
     return false;
   if (!(p->rank_mode == SC_RANK_WEIGHT && 3.0f * p->t_cmp * 0.999f >= 2.0f)) return false;  // the a-priori select window
   uint64_t ecap = c->es.cap / 4 >= 2 ? c->es.cap / 4 - 2 : 0;
-  for (const Buf* b : {&c->ei, &c->ej, &c->ebi, &c->ebj}) ecap = b->cap / 4 < ecap ? b->cap / 4 : ecap;
+  for (const Buf* b : {&c->ei, &c->ej}) ecap = b->cap / 4 < ecap ? b->cap / 4 : ecap;
+  c->est_allowed = true;  // (what the entry points that come here set for the call: see edge_build_ok)
+  const bool will_build = edge_build_ok(c, p, n);
+  c->est_allowed = false;
+  if (!will_build) for (const Buf* b : {&c->ebi, &c->ebj}) ecap = b->cap / 4 < ecap ? b->cap / 4 : ecap;  // (the fused edge kernel writes no per-edge bases)
   const uint64_t kcap = c->wkey.cap / 4 < c->kcol.cap / 8 ? c->wkey.cap / 4 : c->kcol.cap / 8;
   uint64_t ecov = c->E_last + c->E_last / 2 + 4096, mcov = c->M_last + c->M_last / 2 + 4096;
   if (ecov > ecap) ecov = ecap;

@@ -22,9 +22,11 @@ __global__ __launch_bounds__(256) void stage_points_kernel(const float* __restri
                                                            uint32_t* __restrict__ coord_part,
                                                            uint32_t* __restrict__ mx_ticket,
                                                            uint64_t* __restrict__ host_max,
-                                                           uint64_t* __restrict__ host_box) {
+                                                           uint64_t* __restrict__ host_box,
+                                                           uint32_t* __restrict__ zero2, uint32_t zero2_words) {
   int m = blockIdx.x * 256 + threadIdx.x;
   for (uint32_t z = (uint32_t)m; z < zero_words; z += gridDim.x * 256) zero[z] = 0u;  // the per-call control block
+  for (uint32_t z = (uint32_t)m; z < zero2_words; z += gridDim.x * 256) zero2[z] = 0u;  // (stage A's deg+ accumulators)
   float v[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   if (m < n) {
 #pragma unroll
@@ -109,9 +111,11 @@ __global__ __launch_bounds__(256) void stage_points_kernel(const float* __restri
 
 void launch_stage_points(const float* d_src, const float* d_tgt, int n, int ld, int layout, float* planes,
                          uint32_t* bad_flag, uint32_t* zero, uint32_t zero_words, uint32_t* coord_max, uint32_t* coord_part,
-                         uint32_t* mx_ticket, uint64_t* host_max, uint64_t* host_box, hipStream_t st) {
+                         uint32_t* mx_ticket, uint64_t* host_max, uint64_t* host_box, hipStream_t st, uint32_t* zero2,
+                         uint32_t zero2_words) {
   hipLaunchKernelGGL(stage_points_kernel, dim3((ld + 255) / 256), dim3(256), 0, st, d_src, d_tgt, n, ld, layout,
-                     planes, bad_flag, zero, zero_words, coord_max, coord_part, mx_ticket, host_max, host_box);
+                     planes, bad_flag, zero, zero_words, coord_max, coord_part, mx_ticket, host_max, host_box, zero2,
+                     zero2_words);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -162,7 +166,7 @@ __global__ __launch_bounds__(64 * COMPAT_WAVES) void compat_tiles_kernel(const f
                                                                          float nis, float* __restrict__ S,
                                                                          uint64_t* __restrict__ bits, int n_tiles,
                                                                          int two_phase, int row0, int row1,
-                                                                         int mode) {
+                                                                         int mode, uint32_t* __restrict__ degp) {
   constexpr int TILE_PAD = TILE_R + 1;  // LDS row stride of the transposed tile: conflict-free both ways
   constexpr int SUB = 64 / TILE_R;      // tiles per 64-row block
   __shared__ float tileT[DENSE ? COMPAT_WAVES : 1][DENSE ? 64 * TILE_PAD : 1];  // [column][row] per wave
@@ -309,6 +313,13 @@ __global__ __launch_bounds__(64 * COMPAT_WAVES) void compat_tiles_kernel(const f
       }
     }
     if (lane < TILE_R) bits[(size_t)(i0 + lane) * W + J] = myRB[lane];
+    // deg+ (edges to higher indices) of the tile's rows, accumulated where the adjacency words are made (degp zeroed by the
+    // staging kernel): the row kernel that used to re-read the whole bit matrix for it is gone from the hot path — the
+    // tiles on or above the diagonal hold exactly the upper triangle.  Integer sums: order-free.
+    if (!RECT && degp && lane < TILE_R) {
+      const uint32_t pc = (uint32_t)__popcll(myRB[lane]);
+      if (pc) atomicAdd(&degp[i0 + lane], pc);
+    }
     if (!RECT) {
       colword = myCB[lane];
       if (DENSE) {
@@ -386,6 +397,12 @@ __global__ __launch_bounds__(64 * COMPAT_WAVES) void compat_tiles_kernel(const f
     for (int r = 0; r < TILE_R; r += 2) row_pair(r, std::true_type{});
   }
   if (lane < TILE_R && i0 + lane < rlim) bits[(size_t)(i0 + lane) * W + J] = rowword;
+  if (!RECT && degp && lane < TILE_R && i0 + lane < rlim) {  // (a tile on the diagonal: only the columns beyond the row itself)
+    const int b = (i0 + lane) & 63;
+    const uint64_t up = diag ? (b == 63 ? 0ull : (rowword & (~0ull << (b + 1)))) : rowword;
+    const uint32_t pc = (uint32_t)__popcll(up);
+    if (pc) atomicAdd(&degp[i0 + lane], pc);
+  }
   if (!RECT && !diag) {
     // mirrored half: row j of S, columns i0 .. i0 + TILE_R - 1; SUB output rows per instruction
     if (DENSE) {
@@ -594,7 +611,7 @@ __global__ __launch_bounds__(64) void shard_split_kernel(const uint64_t* __restr
 // evaluated once) when the range is [0, n).  S == nullptr: adjacency bits only (SC_FLAG_NO_DENSE_S).  For a proper
 // sub-range S holds the rows of the range only (row i at S + (i - row0) * ld).
 void launch_compat(const Points& pts, const Derived& dv, float* S, uint64_t* bits, int row0, int row1, const Tuning& tn,
-                   hipStream_t st) {
+                   hipStream_t st, uint32_t* degp) {
   const int W = pts.ld >> 6;
   const int two_phase = tn.compat_one_phase ? 0 : 1;  // the one-phase interior form stays for A/B and parity
   const bool rect = !(row0 == 0 && row1 >= pts.n);
@@ -608,7 +625,7 @@ void launch_compat(const Points& pts, const Derived& dv, float* S, uint64_t* bit
   if (tn.compat_store_mode & 1u) mode = 1;
   if (tn.compat_store_mode & 4u) mode = 0;
   mode |= (int)(tn.compat_store_mode & 2u);
-#define SC_COMPAT_ARGS pts.planes, pts.n, pts.ld, dv.d_thr, dv.min_len, dv.neg_inv2sig2, S, bits, n_tiles, two_phase, row0, row1, mode
+#define SC_COMPAT_ARGS pts.planes, pts.n, pts.ld, dv.d_thr, dv.min_len, dv.neg_inv2sig2, S, bits, n_tiles, two_phase, row0, row1, mode, degp
   if (rect) {
     if (row1 <= row0) return;
     // one-sided 16-row tiles over the rectangle (every pair of the block evaluated by this rank)

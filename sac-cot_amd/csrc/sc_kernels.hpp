@@ -29,6 +29,8 @@ struct Tuning {
   int tg_count = 8, tg_keys = 8, tg_sample = 0;              // lanes per edge (tg_sample 0: by row width)
   int tg_events = 0;               // lanes per edge of the event-recording counting pass (0: by row width)
   uint32_t sample_mode = 0;        // pruning sample: 0 by size (launch_sample_hist), 1 every stride-th edge, 2 the heaviest edges (both CERTIFY their bound)
+  bool no_edge_build = false;      // row statistics and edge list as separate launches (not launch_edge_build)
+  bool build_sample = false;       // launch_edge_build also takes the estimating sample (measured slower: see edge_build_kernel)
   bool no_estimate = false;        // never prune by an ESTIMATED bound (sc_tri.hip 3c): always one of the certifying samples
   uint32_t est_margin_pct = 0;     // the estimate aims at the (pct / 100 x T)-th key (0: 200; tests force failures with a small one)
   uint32_t sample_blocks = 0;      // grid of the heaviest-edge sample (0: one block per 256 edges)
@@ -89,7 +91,8 @@ constexpr int FX_MX_WORDS = 16;
 inline size_t stage_part_words(int ld) { return (size_t)((ld + 255) / 256) * 16; }
 void launch_stage_points(const float* d_src, const float* d_tgt, int n, int ld, int layout, float* planes,
                          uint32_t* bad_flag, uint32_t* zero, uint32_t zero_words, uint32_t* coord_max, uint32_t* coord_part,
-                         uint32_t* mx_ticket, uint64_t* host_max, uint64_t* host_box, hipStream_t st);
+                         uint32_t* mx_ticket, uint64_t* host_max, uint64_t* host_box, hipStream_t st,
+                         uint32_t* zero2 = nullptr, uint32_t zero2_words = 0);  // zero2: a second buffer cleared on the way
 // order-preserving map float -> u32 (all finite floats and infinities; 0 is below every float) and back
 __host__ __device__ inline uint32_t float_key(float f) {
   union { float f; uint32_t u; } x; x.f = f;
@@ -107,8 +110,9 @@ bool filter_in_range(uint64_t host_max, float tau2);
 // S: n x ld fp32 (row-major, symmetric, zero diagonal / pad columns); bits: n x (ld/64) u64;
 // rows [row0, row1) (row0 a multiple of 64): the whole matrix by symmetric tiles for [0, n), one-sided tiles for a
 // row block (then S, if given, holds the rows of the block only).  S == nullptr: adjacency bits only.
+// degp (optional, whole-matrix form only; n u32, ZEROED): also accumulates deg+[i] = edges (i, j) with j > i (atomics).
 void launch_compat(const Points& pts, const Derived& dv, float* S, uint64_t* bits, int row0, int row1, const Tuning& tn,
-                   hipStream_t st);
+                   hipStream_t st, uint32_t* degp = nullptr);
 // deg[i] = edges of i; degp[i] = edges (i,j) with j > i; wpre: n x (ld/64) u32, set bits of row i in words [0,w).
 // zero_rows (optional): an n x W u64 matrix cleared on the way (the pruned bit matrix of stage B).
 // rowcost (optional, n u32): per-row estimate of stage B's work (see row_stats_kernel), for launch_shard_split.
@@ -168,6 +172,14 @@ bool scan_writes_ebase(size_t n);
 void launch_edge_fill(const Graph& g, const Points& pts, const Derived& dv, const uint64_t* edge_off, uint32_t* ei,
                       uint32_t* ej, float* es, uint32_t* ebase, bool ebase_ready, uint32_t* ebi, uint32_t* ebj,
                       uint64_t cap, uint32_t* es_hist, hipStream_t st);  // es_hist: see launch_sample_hist (optional)
+// The hot path's form (r04; n <= 8192, weight ranking, estimated pruning bound): row statistics (wpre), CSR offsets and
+// bases from g.degp — which launch_compat accumulated —, the strong-bit rows cleared, the edge list (ei / ej / es; NO ebi /
+// ebj: launch_tri_count_events looks the bases up) and the estimating sample's histogram (PR_HCOPIES x 256 words, zeroed),
+// in one launch.  host_total (pinned) receives the edge count, which also lands in edge_off[n].
+bool edge_build_fits(int n);
+void launch_edge_build(const Graph& g, const Points& pts, const Derived& dv, uint64_t* zero_rows, uint64_t* edge_off, uint32_t* ebase,
+                       uint32_t* ei, uint32_t* ej, float* es, uint64_t cap, uint64_t* host_total, uint32_t rate, uint32_t* hist,
+                       hipStream_t st);
 // tcnt[e] = #k > j adjacent (in `mbits`) to both ends of edge e = (i,j); edges with es[e] < *smin count 0
 // (smin == nullptr: no pruning, mbits = g.bits).
 void launch_tri_count(const Graph& g, const uint64_t* mbits, const float* es, const float* smin, const uint32_t* ei,
@@ -215,7 +227,7 @@ struct SamplePlan {
 SamplePlan sample_plan(uint64_t want, bool allow_estimate, const Tuning& tn);
 void launch_sample_estimate(const Graph& g, const uint32_t* ebi, const uint32_t* ebj, const uint32_t* ei, const uint32_t* ej,
                             const float* es, uint64_t E, float key_floor, uint32_t rate, uint32_t* hist, const Tuning& tn,
-                            hipStream_t st, const uint64_t* E_dev = nullptr);
+                            hipStream_t st, const uint64_t* E_dev = nullptr, const uint32_t* ebase = nullptr);  // ebase: with ebi == ebj == nullptr
 // es_hist: PR_HCOPIES x 256 words (control block) for the weight histogram of the heaviest-edge sample: zeroed, or —
 // es_hist_ready — already filled by launch_edge_fill
 // launch_sample_hist ALWAYS accumulates into PR_HCOPIES x 256 words (`hist` = the control block's copies);
@@ -254,7 +266,8 @@ EventList event_list(void* buf, uint64_t capacity, int W, uint32_t* fill, uint32
 void launch_tri_count_events(const Graph& g, const uint64_t* mbits, const StrongList& sl, const uint32_t* ebi,
                              const uint32_t* ebj, const uint32_t* ei, const uint32_t* ej, uint64_t E, int rank_mode,
                              uint32_t* tcnt, const EventList& ev, const Tuning& tn, hipStream_t st,
-                             const uint64_t* own = nullptr);  // own (optional, device): [lo, hi) of the edges this rank enumerates
+                             const uint64_t* own = nullptr,   // own (optional, device): [lo, hi) of the edges this rank enumerates
+                             const uint32_t* ebase = nullptr);  // with ebi == ebj == nullptr: the per-row CSR bases (launch_edge_build)
 
 // Radix-select state.  Lives in the context's control block, which ONE memset zeroes per call; key_range_kernel
 // (end of launch_tri_keys) fills kmin / kmax / want.

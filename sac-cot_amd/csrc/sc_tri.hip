@@ -425,7 +425,9 @@ __global__ __launch_bounds__(256) void tri_count_events_kernel(const uint64_t* _
                                                                const uint32_t* __restrict__ ej,
                                                                StrongList sl, int rank_mode,
                                                                uint32_t* __restrict__ tcnt, EventList ev,
-                                                               const uint64_t* __restrict__ own) {
+                                                               const uint64_t* __restrict__ own,
+                                                               const uint32_t* __restrict__ ebase) {
+  // ebase (with ebi == ebj == nullptr): the per-row CSR bases are looked up (edge_build_kernel does not write them per edge)
   // own (optional, sharded stage B): [lo, hi) of the edges this rank enumerates; the strong list holds every rank's, the
   // others count 0 here (their tcnt entry is written too: the scan that follows reads zeros outside the range)
   constexpr int EVW = 192;  // records per wave segment: flush above 128, a round adds <= 64
@@ -503,8 +505,8 @@ __global__ __launch_bounds__(256) void tri_count_events_kernel(const uint64_t* _
       if (!own || ((uint64_t)e >= own[0] && (uint64_t)e < own[1])) {
         const uint32_t i = ei[e], j = ej[e];
         rowi = i * (uint32_t)W; rowj = j * (uint32_t)W;
-        fa = (rank_mode == 0) ? ebi[e] : deg[i] + deg[j];  // weight mode: CSR bases; degree mode: the degree sum
-        fb = (rank_mode == 0) ? ebj[e] : 0u;
+        fa = (rank_mode == 0) ? (ebi ? ebi[e] : ebase[i]) : deg[i] + deg[j];  // weight mode: CSR bases; degree mode: the degree sum
+        fb = (rank_mode == 0) ? (ebj ? ebj[e] : ebase[j]) : 0u;
         w0 = (int)(j >> 6); jbit = (int)(j & 63);
         rounds = (W - w0 + TG - 1) / TG;
       }
@@ -671,7 +673,8 @@ EventList event_list(void* buf, uint64_t capacity, int W, uint32_t* fill, uint32
 
 void launch_tri_count_events(const Graph& g, const uint64_t* mbits, const StrongList& sl, const uint32_t* ebi,
                              const uint32_t* ebj, const uint32_t* ei, const uint32_t* ej, uint64_t E, int rank_mode,
-                             uint32_t* tcnt, const EventList& ev, const Tuning& tn, hipStream_t st, const uint64_t* own) {
+                             uint32_t* tcnt, const EventList& ev, const Tuning& tn, hipStream_t st, const uint64_t* own,
+                             const uint32_t* ebase) {
   if (E == 0) return;
   // lanes per edge: a lane walks (W - j / 64) / TG words one dependent round after the other, so wide rows want wide
   // groups (Tuning::tg_events forces one; measured r02: see DESIGN.md)
@@ -682,7 +685,7 @@ void launch_tri_count_events(const Graph& g, const uint64_t* mbits, const Strong
   if (nb < 256) nb = 256;
   if (nb > 4096) nb = 4096;
   if (tn.cnt_blocks >= 1 && tn.cnt_blocks <= 65535) nb = tn.cnt_blocks;
-#define SC_LAUNCH_CE(TGV) hipLaunchKernelGGL(tri_count_events_kernel<TGV>, dim3((unsigned)nb), dim3(256), 0, st, mbits, g.W, g.deg, ebi, ebj, ei, ej, sl, rank_mode, tcnt, ev, own)
+#define SC_LAUNCH_CE(TGV) hipLaunchKernelGGL(tri_count_events_kernel<TGV>, dim3((unsigned)nb), dim3(256), 0, st, mbits, g.W, g.deg, ebi, ebj, ei, ej, sl, rank_mode, tcnt, ev, own, ebase)
   if (tg == 4) SC_LAUNCH_CE(4); else if (tg == 16) SC_LAUNCH_CE(16); else if (tg == 32) SC_LAUNCH_CE(32); else if (tg == 64) SC_LAUNCH_CE(64); else SC_LAUNCH_CE(8);
 #undef SC_LAUNCH_CE
 }
@@ -949,7 +952,9 @@ __global__ __launch_bounds__(256) void tri_sample_words_kernel(const uint64_t* _
                                                                const uint32_t* __restrict__ ej,
                                                                const float* __restrict__ es, uint64_t E, uint32_t rmask,
                                                                uint32_t* __restrict__ hist,
-                                                               const uint64_t* __restrict__ E_dev) {
+                                                               const uint64_t* __restrict__ E_dev,
+                                                               const uint32_t* __restrict__ ebase) {
+  // ebase (with ebi == ebj == nullptr): the per-row CSR bases are looked up (after launch_edge_build)
   if (E_dev && *E_dev > E) return;  // (launched before the host knew the count: see tri_sample_hist_kernel)
   if (E_dev) E = *E_dev;
   __shared__ uint32_t lh[PR_BINS * PR_COPIES];
@@ -957,14 +962,14 @@ __global__ __launch_bounds__(256) void tri_sample_words_kernel(const uint64_t* _
   __syncthreads();
   const uint64_t stride = (uint64_t)gridDim.x * 256;
   for (uint64_t e = (uint64_t)blockIdx.x * 256 + threadIdx.x; e < E; e += stride) {
-    const uint32_t j = ej[e];
+    const uint32_t j = ej[e], i = ei[e];
     const int w0 = (int)(j >> 6);
-    int w = w0 + (int)((edge_hash((uint32_t)e) - (uint32_t)w0) & rmask);  // the first word >= w0 in this edge's residue class
+    // the first word >= w0 in this edge's residue class (hashed by its END POINTS, as edge_build_kernel does: same sample)
+    int w = w0 + (int)((edge_hash(i * 0x9E3779B1u + j) - (uint32_t)w0) & rmask);
     if (w >= W) continue;
-    const uint32_t i = ei[e];
     const uint32_t rowi = i * (uint32_t)W, rowj = j * (uint32_t)W;
     const float s_ij = es[e];
-    const uint32_t bi = ebi[e], bj = ebj[e];
+    const uint32_t bi = ebi ? ebi[e] : ebase[i], bj = ebj ? ebj[e] : ebase[j];
     for (; w < W; w += (int)rmask + 1) {
       const uint64_t ai = bits[rowi + w], aj = bits[rowj + w];
       uint64_t m = ai & aj;
@@ -997,6 +1002,200 @@ __global__ __launch_bounds__(256) void tri_sample_words_kernel(const uint64_t* _
     for (int c = 0; c < PR_COPIES; c++) v += lh[b * PR_COPIES + ((c + threadIdx.x) & (PR_COPIES - 1))];
     if (v) atomicAdd(&myh[b], v);
   }
+}
+
+// ------------------------------------------------------------------------------------------------
+// 1'. edge_build (r04): everything between stage A and the pruning in ONE launch — the hot path's form of
+//     row_stats_scan + edge_fill + the estimating sample (three launches, 43 us at C2).
+//
+// What made the row kernel a launch of its own was the prefix over the rows: a wave cannot place row i's edges before it
+// knows how many edges the rows before it hold, and counting them meant reading their bit rows.  Stage A now leaves
+// deg+[i] behind (atomics where the adjacency words are made, sc_compat.hip), so a workgroup of EBK_ROWS waves sums
+// deg+[0 .. its first row) itself — a few 16-byte loads per thread, no look-back, no cross-workgroup dependency — and then
+// each wave, for its row: word-prefix popcounts (wpre), the CSR offset and base, the strong-bit row cleared, the row's
+// edges with their recomputed weights (as edge_fill_kernel), and the row's share of the ESTIMATING sample (3c).
+// The sample cannot look up s_ik / s_jk in the edge arrays — they are being written by this very launch — so it recomputes
+// them from the three correspondences with the same chain (bit-identical, though an estimate would not need that): sampled
+// triangles are collected in a per-wave LDS queue and evaluated 64 at a time, all lanes busy (evaluating them where they
+// are found would cost a divergent ~170-instruction body per set bit).
+// The CSR bases of an edge's OTHER end (ebj) are not known here (row j's wave may not have run): the counting pass looks
+// them up in ebase instead (one more gather, beside its row loads).  n <= 64 * EBK_WMAX only.
+// ------------------------------------------------------------------------------------------------
+constexpr int EBK_ROWS = 8;     // rows (waves) per workgroup
+constexpr int EBK_CH = 256;     // column indices staged per wave and chunk
+constexpr int EBK_WMAX = 128;   // words per bit row (n <= 8192)
+constexpr int EBK_Q = 128;      // sampled triangles queued per wave (drained at 64)
+constexpr int EBK_HC = 4;       // LDS copies of the key histogram
+
+__global__ __launch_bounds__(64 * EBK_ROWS) void edge_build_kernel(const uint64_t* __restrict__ bits,
+                                                                   const float* __restrict__ planes, Derived dv, int n,
+                                                                   int ld, int W, const uint32_t* __restrict__ degp,
+                                                                   uint32_t* __restrict__ wpre,
+                                                                   uint64_t* __restrict__ zero_rows,
+                                                                   uint64_t* __restrict__ edge_off,
+                                                                   uint32_t* __restrict__ ebase,
+                                                                   uint32_t* __restrict__ ei, uint32_t* __restrict__ ej,
+                                                                   float* __restrict__ es, uint64_t cap,
+                                                                   uint64_t* __restrict__ host_total, uint32_t rmask,
+                                                                   uint32_t* __restrict__ hist) {
+  __shared__ uint64_t s_red[EBK_ROWS];
+  __shared__ uint32_t l_j[EBK_ROWS][EBK_CH];
+  __shared__ uint64_t l_row[EBK_ROWS][EBK_WMAX];
+  __shared__ uint32_t q_j[EBK_ROWS][EBK_Q], q_k[EBK_ROWS][EBK_Q];
+  __shared__ float q_s[EBK_ROWS][EBK_Q];
+  __shared__ uint32_t lh[PR_BINS * EBK_HC];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r0 = blockIdx.x * EBK_ROWS, i = r0 + wave;
+  for (int b = tid; b < PR_BINS * EBK_HC; b += 64 * EBK_ROWS) lh[b] = 0u;
+  // edges of the rows before this workgroup's (r0 is a multiple of 4: whole 16-byte pieces)
+  uint64_t acc = 0;
+  for (int q = tid * 4; q < r0; q += 64 * EBK_ROWS * 4) {
+    const uint4 v = *reinterpret_cast<const uint4*>(degp + q);
+    acc += (uint64_t)v.x + v.y + v.z + v.w;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+  if (lane == 0) s_red[wave] = acc;
+  __syncthreads();
+  if (i < n) {
+    uint64_t my_off = 0;
+#pragma unroll
+    for (int w8 = 0; w8 < EBK_ROWS; w8++) my_off += s_red[w8];
+    for (int r = r0; r < i; r++) my_off += degp[r];  // wave-uniform: scalar loads
+    const int wi = i >> 6, bi = i & 63;
+    const float4* __restrict__ aos4 = reinterpret_cast<const float4*>(planes + 6 * (size_t)ld);
+    const float pix = planes[i], piy = planes[ld + i], piz = planes[2 * ld + i];
+    const float qix = planes[3 * ld + i], qiy = planes[4 * ld + i], qiz = planes[5 * ld + i];
+    uint64_t* const myrow = l_row[wave];
+    // ---- the row's words: prefix popcounts, the strong row cleared, the words kept for the sample
+    uint32_t d_all = 0, d_low = 0;
+    uint64_t up[EBK_WMAX / 64];
+#pragma unroll
+    for (int c = 0; c < EBK_WMAX / 64; c++) {
+      const int w = 64 * c + lane;
+      const uint64_t v = w < W ? bits[(size_t)i * W + w] : 0ull;
+      myrow[w] = v;
+      const uint32_t pc = (uint32_t)__popcll(v);
+      uint32_t tot;
+      const uint32_t ex = group_exscan<64>(pc, &tot);
+      if (w < W) {
+        wpre[(size_t)i * W + w] = d_all + ex;
+        zero_rows[(size_t)i * W + w] = 0ull;
+      }
+      d_all += tot;
+      const uint64_t below = (1ull << bi) - 1ull;
+      d_low += w < wi ? pc : (w == wi ? (uint32_t)__popcll(v & below) : 0u);
+      up[c] = w < wi ? 0ull : (w == wi ? (v & mask_above(bi)) : v);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) d_low += __shfl_xor(d_low, o);
+    const uint32_t my_base = (uint32_t)my_off - d_low;
+    if (lane == 0) { edge_off[i] = my_off; ebase[i] = my_base; }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // myrow is read by index below (LDS is in-order within a wave)
+    // ---- edges, chunk by chunk, and the sampled triangles they own
+    uint32_t qn = 0;  // sampled triangles queued (wave-uniform)
+    auto evaluate = [&](uint32_t idx) {  // the key of queued triangle idx -> histogram
+      const uint32_t j = q_j[wave][idx], k = q_k[wave][idx];
+      const float s_ij = q_s[wave][idx];
+      const float4 ja = aos4[2 * (size_t)j], jb = aos4[2 * (size_t)j + 1];
+      const float4 ka = aos4[2 * (size_t)k], kb = aos4[2 * (size_t)k + 1];
+      bool edge;
+      const float s_ik = pair_weight(dist3(pix, piy, piz, ka.x, ka.y, ka.z), dist3(qix, qiy, qiz, ka.w, kb.x, kb.y), dv.d_thr,
+                                     dv.min_len, dv.neg_inv2sig2, edge);
+      const float s_jk = pair_weight(dist3(ja.x, ja.y, ja.z, ka.x, ka.y, ka.z), dist3(ja.w, jb.x, jb.y, ka.w, kb.x, kb.y), dv.d_thr,
+                                     dv.min_len, dv.neg_inv2sig2, edge);
+      atomicAdd(&lh[est_bin(__float_as_uint((s_ij + s_ik) + s_jk)) * EBK_HC + (lane & (EBK_HC - 1))], 1u);
+    };
+    uint64_t ebase_row = my_off;
+#pragma unroll 1
+    for (int c = 0; c < EBK_WMAX / 64; c++) {
+      const int w = 64 * c + lane;
+      const uint64_t v = up[c];
+      uint32_t tot;
+      const uint32_t r = group_exscan<64>((uint32_t)__popcll(v), &tot);
+      for (uint32_t c0 = 0; c0 < tot; c0 += EBK_CH) {  // wave-uniform
+        uint64_t vv = v;
+        uint32_t rr = r - c0;  // modular: positions outside [0, EBK_CH) are skipped
+        while (vv) {
+          const int b = __builtin_ctzll(vv);
+          vv &= vv - 1;
+          if (rr < (uint32_t)EBK_CH) l_j[wave][rr] = (uint32_t)(w * 64 + b);
+          rr++;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        const uint32_t cnt = min((uint32_t)EBK_CH, tot - c0);
+        for (uint32_t t0 = 0; t0 < cnt; t0 += 64) {  // wave-uniform
+          const uint32_t t = t0 + lane;
+          const bool on = t < cnt;
+          const uint32_t j = on ? l_j[wave][t] : 0u;
+          float sw = 0.f;
+          int ws = W;  // the next sampled word of this lane's edge (W: none)
+          if (on) {
+            const uint64_t e = ebase_row + c0 + t;
+            const float4 a4 = aos4[2 * (size_t)j], b4 = aos4[2 * (size_t)j + 1];
+            bool edge;
+            sw = pair_weight(dist3(pix, piy, piz, a4.x, a4.y, a4.z), dist3(qix, qiy, qiz, a4.w, b4.x, b4.y), dv.d_thr, dv.min_len,
+                             dv.neg_inv2sig2, edge);
+            if (e < cap) { ei[e] = (uint32_t)i; ej[e] = j; es[e] = sw; }
+            const int w0 = (int)(j >> 6);
+            if (hist) ws = w0 + (int)((edge_hash((uint32_t)i * 0x9E3779B1u + j) - (uint32_t)w0) & rmask);  // (hist == nullptr: no sample here)
+          }
+          // sampled words of the 64 edges: found triangles go to the queue, one per lane and trip
+          while (__ballot(ws < W) != 0) {  // wave-uniform
+            uint64_t m = 0;
+            const int wcur = ws;
+            if (ws < W) {
+              m = myrow[ws] & bits[(size_t)j * W + ws];
+              if (ws == (int)(j >> 6)) m &= mask_above((int)(j & 63));
+              ws += (int)rmask + 1;
+            }
+            uint64_t bal;
+            while ((bal = __ballot(m != 0)) != 0) {  // wave-uniform
+              if (m != 0) {
+                const uint32_t slot = qn + __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
+                q_j[wave][slot] = j; q_k[wave][slot] = (uint32_t)(wcur * 64 + __builtin_ctzll(m)); q_s[wave][slot] = sw;
+                m &= m - 1;
+              }
+              qn += (uint32_t)__popcll(bal);
+              if (qn >= 64u) {  // (qn < 64 before the push, <= 127 after: EBK_Q = 128 holds it)
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                qn -= 64u;
+                evaluate(qn + (uint32_t)lane);
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+              }
+            }
+          }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // l_j is rewritten by the next chunk
+      }
+      ebase_row += tot;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    if ((uint32_t)lane < qn) evaluate((uint32_t)lane);
+    if (i == n - 1 && lane == 0) {  // the last row's wave knows the edge count: the host polls for it
+      edge_off[n] = ebase_row;
+      publish_host(host_total, ebase_row);
+    }
+  }
+  if (!hist) return;  // (kernel-uniform)
+  __syncthreads();
+  uint32_t* __restrict__ myh = hist + (size_t)(blockIdx.x & (PR_HCOPIES - 1)) * PR_BINS;
+  for (int b = tid; b < PR_BINS; b += 64 * EBK_ROWS) {
+    uint32_t v = 0;
+#pragma unroll
+    for (int c = 0; c < EBK_HC; c++) v += lh[b * EBK_HC + c];
+    if (v) atomicAdd(&myh[b], v);
+  }
+}
+
+bool edge_build_fits(int n) { return n <= 64 * EBK_WMAX; }
+
+void launch_edge_build(const Graph& g, const Points& pts, const Derived& dv, uint64_t* zero_rows, uint64_t* edge_off, uint32_t* ebase,
+                       uint32_t* ei, uint32_t* ej, float* es, uint64_t cap, uint64_t* host_total, uint32_t rate, uint32_t* hist,
+                       hipStream_t st) {
+  hipLaunchKernelGGL(edge_build_kernel, dim3((g.n + EBK_ROWS - 1) / EBK_ROWS), dim3(64 * EBK_ROWS), 0, st, g.bits, pts.planes, dv,
+                     g.n, g.ld, g.W, g.degp, const_cast<uint32_t*>(g.wpre), zero_rows, edge_off, ebase, ei, ej, es, cap, host_total,
+                     rate - 1u, hist);
 }
 
 // sum of the copies -> one 256-bin histogram (the form the ranks exchange)
@@ -1194,14 +1393,14 @@ SamplePlan sample_plan(uint64_t want, bool allow_estimate, const Tuning& tn) {
 
 void launch_sample_estimate(const Graph& g, const uint32_t* ebi, const uint32_t* ebj, const uint32_t* ei, const uint32_t* ej,
                             const float* es, uint64_t E, float key_floor, uint32_t rate, uint32_t* hist, const Tuning& tn,
-                            hipStream_t st, const uint64_t* E_dev) {
+                            hipStream_t st, const uint64_t* E_dev, const uint32_t* ebase) {
   if (E == 0) return;
   (void)key_floor;  // (the logarithmic bins need no window)
   uint64_t nb = (E + 255) / 256;
   if (nb > 4096) nb = 4096;
   if (tn.sample_blocks) nb = tn.sample_blocks;
   hipLaunchKernelGGL(tri_sample_words_kernel, dim3((unsigned)nb), dim3(256), 0, st, g.bits, g.W, g.wpre, ebi, ebj, ei, ej, es, E,
-                     rate - 1u, hist, E_dev);
+                     rate - 1u, hist, E_dev, ebase);
 }
 
 void launch_prune_bits(const Graph& g, const uint32_t* hist, bool hist_is_copies, const uint32_t* ei, const uint32_t* ej, const float* es,

@@ -105,3 +105,29 @@ def test_estimate_on_graphs_with_few_or_tied_triangles(pkg, O):
         assert got["stats"]["best_rank"] == ref["best_rank"] and got["stats"]["tri_kept"] == ref["t_eff"]
     finally:
         r.close()
+
+
+@pytest.mark.parametrize("name", ["C0", "C1", "C2", "C4"])
+def test_fused_edge_kernel_equals_the_separate_launches(pkg, O, name):
+    """launch_edge_build — row statistics, CSR offsets (from the deg+ stage A accumulates), edge list and the estimating
+    sample in one launch — against the three launches it replaces on the hot path (sc_debug.no_edge_build): same edges,
+    same bound (the fused sample recomputes the weights it cannot look up yet: bit-identical, so even the number of
+    triangles enumerated agrees), same outputs; first call, host-free repetition, a different size in between."""
+    cfg, scene = pkg.synth.make_config_scene(name)
+    cfg0, scene0 = pkg.synth.make_config_scene("C0")
+    a = pkg.Registrar(0)
+    b = pkg.Registrar(0); b.set_debug(no_edge_build=1)
+    try:
+        for k in range(3):
+            ra = a.register(scene.src, scene.tgt, **cfg.params())
+            rb = b.register(scene.src, scene.tgt, **cfg.params())
+            assert _same(ra, rb) and ra["stats"]["tri_total"] == rb["stats"]["tri_total"], (name, k)
+            assert a.debug_last()["prune_bound"] == b.debug_last()["prune_bound"]
+            if k == 1:
+                x = a.register(scene0.src, scene0.tgt, **cfg0.params())
+                y = b.register(scene0.src, scene0.tgt, **cfg0.params())
+                assert _same(x, y)
+    finally:
+        a.close(); b.close()
+    ref = O.register(scene.src, scene.tgt, threads=8, **cfg.params())
+    assert np.array_equal(ra["mask"], ref["mask"]) and ra["stats"]["best_rank"] == ref["best_rank"] and ra["stats"]["edges"] == ref["edges"]
