@@ -51,7 +51,9 @@ typedef struct sc_debug {
   uint32_t est_margin_pct;    /* the estimated bound aims at the key of rank (pct / 100) x T (0 = 200); a small value forces the failure-and-repeat path (tests) */
   uint32_t no_edge_build;     /* 1: row statistics, edge list and the estimating sample as three launches instead of the hot path's one (launch_edge_build) */
   uint32_t build_sample;      /* 1: the fused edge kernel also takes the estimating sample (instead of a launch of its own) */
-  uint32_t reserved[1];
+  uint32_t reserved[1];       /* development hook (a kernel under study stops early: WRONG results); leave 0 */
+  uint32_t select_final;      /* 1: the select as ONE launch after a key kernel that also takes round 1's histogram, instead of round 1 + round 2 + per-tile count (built, bit-exact, measured no faster: off by default) */
+  uint32_t pad_;
 } sc_debug;
 int         sc_set_debug(sc_ctx* ctx, const sc_debug* dbg);
 

@@ -84,7 +84,8 @@ class ScDebug(C.Structure):
                 ("filter_variant", C.c_uint32), ("dense_async", C.c_uint32), ("filter_blind", C.c_uint32),
                 ("no_fast", C.c_uint32), ("gram_guard_fail", C.c_uint32), ("tail_unfused", C.c_uint32),
                 ("no_estimate", C.c_uint32), ("est_margin_pct", C.c_uint32), ("no_edge_build", C.c_uint32),
-                ("build_sample", C.c_uint32), ("reserved", C.c_uint32 * 1)]
+                ("build_sample", C.c_uint32), ("reserved", C.c_uint32 * 1), ("select_final", C.c_uint32),
+                ("pad_", C.c_uint32)]
 
 
 class ScDebugInfo(C.Structure):

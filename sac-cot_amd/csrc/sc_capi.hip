@@ -47,7 +47,7 @@ struct sc_ctx {
   // workspace
   Buf in_src, in_tgt, planes, S, bits, deg, degp, wpre, ebase, edge_off, scan_tmp, ei, ej, es, ebi, ebj, tcnt, toff, wkey, kcol, ctl, events, blk_gt,
       blk_eq, blk_minmax, bits2, off_gt, off_eq, sel_ord, sel_key, sortkey, sorted, sort_tmp, tri, tri_rk, key_rk, rt, rt_aos, partial, cnt, key, rt12,
-      mask, refine_tmp, amx_pairs, strong, rowcost, cost_pre, lb_state, lb_ticket, fx_tile, fx_state, fx_mx, fx_part, fx_coef, guard_tmp;
+      mask, refine_tmp, amx_pairs, strong, rowcost, cost_pre, lb_state, lb_ticket, fx_tile, fx_state, fx_mx, fx_part, fx_coef, guard_tmp, sel_list;
   bool filter_on = false;   // C2 of the running / last call goes through a matrix-pipe filter (decided ONCE per call)
   int filter_mode = 0;      // ... which: 1 linear, 2 Gram (0: the plain fp32 kernel)
   FilterPlan fx_plan{};     // ... with this plan (sc_debug_last reads the filter's counters through it)
@@ -233,6 +233,9 @@ const uint64_t* own_range_of(const sc_ctx* c) {
 TriSource tri_source_of(const sc_ctx* c) {
   TriSource ts{c->sel_ord.as<uint64_t>(), c->kcol.as<uint2>(), c->ei.as<uint32_t>(), c->ej.as<uint32_t>(), nullptr, 0, 0, 0u, 0u, 0ull};
   if (c->spec_on) { ts.lim_vertex = (uint32_t)c->n; ts.lim_edge = (uint32_t)c->E_cov; ts.lim_ord = c->M_cov; }
+  // an ESTIMATED pruning bound that turns out too high leaves a selection shorter than the T_eff the launches were sized for
+  // (the call is then repeated): what lies beyond it in sel_ord must not be followed
+  else if (c->est_active) { ts.lim_vertex = (uint32_t)c->n; ts.lim_edge = (uint32_t)c->E; ts.lim_ord = c->M; }
   if (c->sharded_ab && c->cand_all) {  // the selection indexes the gathered candidate blobs
     const size_t cap = cand_cap(c->params.max_triangles, (uint32_t)c->params.shard_world, c->params.shard_cand_level);
     ts.cand_recs = cand_blob(const_cast<void*>(c->cand_all), cap).recs;
@@ -523,9 +526,14 @@ int run_edges(sc_ctx* c, const sc_params* p, uint32_t* hist, uint32_t part, uint
 // bit-exact, but slower: 16.4 us against 4.7 + 4.7 on C2 (525 tiles of 1024 keys publish their counts at the same moment,
 // so the prefixes trickle through ~8 dependent 64-tile windows); the same look-back does pay in the scan, whose tiles
 // are 4096 elements and few.  Tuning::compact_self_max == 0 (a test) takes the scanned three-launch form.
-int run_compaction(sc_ctx* c, const KeyView& view, size_t nb) {
+int run_compaction(sc_ctx* c, const KeyView& view, size_t nb, bool counted = false) {
   hipStream_t st = c->stream;
   SelectState* sel = &c->ctl.as<ControlBlock>()->sel;
+  if (counted) {  // launch_select_final left the per-tile counts: the writing launch alone (it sums the counts before its tile itself)
+    launch_compact_write(view, sel, c->blk_gt.as<uint32_t>(), c->blk_eq.as<uint32_t>(), nullptr, nullptr, c->sel_ord.as<uint64_t>(),
+                         c->sel_key.as<uint32_t>(), c->sel_ord.cap / 8 < c->sel_key.cap / 4 ? c->sel_ord.cap / 8 : c->sel_key.cap / 4, st);
+    return SC_OK;
+  }
   if (c->tn.compact_fused) {
     LbArgs lb;
     { const int lrc = lb_next(c, compact_state_bytes(view.M), 0, 0, &lb); if (lrc) return lrc; }
@@ -614,6 +622,9 @@ int run_select(sc_ctx* c, const sc_params* p, const uint32_t* hist, bool want_li
   // and not when every stage is bracketed by events; re-run below if the count outgrew the arrays or a region overflowed.
   SelectState* sel = &c->ctl.as<ControlBlock>()->sel;
   const bool window_known = p->rank_mode == SC_RANK_WEIGHT && 3.0f * p->t_cmp * 0.999f >= 2.0f;
+  // the hot path's select: round 1's histogram rides the key kernel, launch_select_final does the rest (sc_tri.hip 4')
+  const bool sel2_ok = use_events && window_known && !c->sharded_ab && c->tn.select_final && !c->tn.compact_fused;
+  bool hist_dirty = false;  // a key pass has added to sel->hist
   uint64_t spec_cap = 0;
   if (use_events && window_known && !c->timing) {
     spec_cap = c->wkey.cap / 4 < c->kcol.cap / 8 ? c->wkey.cap / 4 : c->kcol.cap / 8;
@@ -622,7 +633,8 @@ int run_select(sc_ctx* c, const sc_params* p, const uint32_t* hist, bool want_li
       ENSURE(c, c->blk_minmax, 2 * 8192 * 4);
       launch_tri_keys_events(g, c->es.as<float>(), c->toff.as<uint64_t>(), p->rank_mode, ev, c->wkey.as<uint32_t>(),
                              c->kcol.as<uint2>(), c->blk_minmax.as<uint32_t>(), sel, select_want(c, p),
-                             &c->ctl.as<ControlBlock>()->klb, E, spec_cap, c->tn, st, !c->sharded_ab);
+                             &c->ctl.as<ControlBlock>()->klb, E, spec_cap, c->tn, st, !c->sharded_ab, sel2_ok, c->ctl.as<ControlBlock>()->sel_r1);
+      hist_dirty = sel2_ok;
     }
   }
   // host-free call: no wait — M is what the key arrays and the launches below cover, T_eff the requested T; the kernels
@@ -658,12 +670,17 @@ int run_select(sc_ctx* c, const sc_params* p, const uint32_t* hist, bool want_li
   // weight keys of a graph whose edges all weigh >= 2/3 (0.1 % slack) lie in [2.0, 3.0]: window known a priori
   const bool fast_window = events_ok && window_known;
   const bool keys_done = spec_cap != 0 && events_ok && M <= spec_cap;  // the speculative pass wrote every key
+  const bool sel2 = sel2_ok && fast_window && nb <= c->tn.compact_self_max && M < (1ull << 32);
+  if (hist_dirty && !keys_done && sel2) {  // the key kernel runs again, histogram included: the speculative pass's counts go
+    HIPCHK(c, hipMemsetAsync(c->ctl.as<ControlBlock>()->sel_r1, 0, sizeof(uint32_t) * SEL2_COPIES * 4096, st));
+    hist_dirty = false;
+  }
   if (keys_done) {
     // nothing to do
   } else if (events_ok) {
     launch_tri_keys_events(g, c->es.as<float>(), c->toff.as<uint64_t>(), p->rank_mode, ev, c->wkey.as<uint32_t>(),
                            c->kcol.as<uint2>(), c->blk_minmax.as<uint32_t>(), sel, fast_window ? (uint64_t)select_want(c, p) : (uint64_t)T_eff,
-                           fast_window ? &c->ctl.as<ControlBlock>()->klb : nullptr, E, M, c->tn, st, !c->sharded_ab);
+                           fast_window ? &c->ctl.as<ControlBlock>()->klb : nullptr, E, M, c->tn, st, !c->sharded_ab, sel2, c->ctl.as<ControlBlock>()->sel_r1);
   } else {
     launch_tri_keys(g, mbits, smin, c->ebase.as<uint32_t>(), c->ei.as<uint32_t>(), c->ej.as<uint32_t>(),
                     c->es.as<float>(), c->toff.as<uint64_t>(), E, p->rank_mode, c->wkey.as<uint32_t>(),
@@ -675,8 +692,15 @@ int run_select(sc_ctx* c, const sc_params* p, const uint32_t* hist, bool want_li
   if (spec) view.M_dev = c->toff.as<uint64_t>() + E;
   // an estimated bound is verified by the first round over the a-priori window; any other path leaves it unverified
   if (c->est_active && !fast_window) c->est_void = true;
-  launch_select_rounds(view, sel, fast_window ? 2 : 3, c->tn, st, c->sharded_ab ? nullptr : &c->pinned[14]);
-  { const int crc = run_compaction(c, view, nb); if (crc) return crc; }
+  if (sel2) {
+    ENSURE(c, c->sel_list, select_final_list_words(M) * 4);
+    uint32_t* lists = c->sel_list.as<uint32_t>();  // the tiles' key lists (128 bytes each), then their lengths
+    launch_select_final(view, sel, c->ctl.as<ControlBlock>()->sel_r1, c->ctl.as<ControlBlock>()->sel2_hist, c->blk_gt.as<uint32_t>(),
+                        c->blk_eq.as<uint32_t>(), lists, lists + compact_blocks(M) * 32, &c->pinned[14], st);
+  } else {
+    launch_select_rounds(view, sel, fast_window ? 2 : 3, c->tn, st, c->sharded_ab ? nullptr : &c->pinned[14]);
+  }
+  { const int crc = run_compaction(c, view, nb, sel2); if (crc) return crc; }
   // the list stays in ordinal order: no sort on the hot path (the winner is found by (count, key, position))
   if (want_list)
     launch_tri_decode(c->ei.as<uint32_t>(), c->ej.as<uint32_t>(), c->kcol.as<uint2>(), c->sel_ord.as<uint64_t>(), T_eff,
@@ -828,7 +852,7 @@ void sc_destroy(sc_ctx* c) {
   Buf* bufs[] = {&c->in_src, &c->in_tgt, &c->planes, &c->S, &c->bits, &c->deg, &c->degp, &c->wpre, &c->ebase, &c->edge_off, &c->scan_tmp,
                  &c->ei, &c->ej, &c->es, &c->ebi, &c->ebj, &c->tcnt, &c->toff, &c->wkey, &c->kcol, &c->ctl, &c->events, &c->blk_gt, &c->blk_eq, &c->blk_minmax, &c->bits2, &c->off_gt,
                  &c->off_eq, &c->sel_ord, &c->sel_key, &c->sortkey, &c->sorted, &c->sort_tmp, &c->tri, &c->tri_rk, &c->key_rk, &c->rt,
-                 &c->rt_aos, &c->partial, &c->cnt, &c->key, &c->rt12, &c->mask, &c->refine_tmp, &c->amx_pairs, &c->strong, &c->rowcost, &c->cost_pre, &c->lb_state, &c->lb_ticket, &c->fx_tile, &c->fx_state, &c->fx_mx, &c->fx_part, &c->fx_coef, &c->guard_tmp};
+                 &c->rt_aos, &c->partial, &c->cnt, &c->key, &c->rt12, &c->mask, &c->refine_tmp, &c->amx_pairs, &c->strong, &c->rowcost, &c->cost_pre, &c->lb_state, &c->lb_ticket, &c->fx_tile, &c->fx_state, &c->fx_mx, &c->fx_part, &c->fx_coef, &c->guard_tmp, &c->sel_list};
   for (Buf* b : bufs) if (b->p) (void)hipFree(b->p);
   for (int i = 0; i < N_EVENTS; i++) if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
   if (c->pinned) (void)hipHostFree(c->pinned);
@@ -896,6 +920,8 @@ int sc_set_debug(sc_ctx* c, const sc_debug* d) {
   t.no_estimate = d->no_estimate != 0;
   t.no_edge_build = d->no_edge_build != 0;
   t.build_sample = d->build_sample != 0;
+  t.select_final = d->select_final != 0;
+  t.dbg_stop = d->reserved[0];
   t.est_margin_pct = d->est_margin_pct;
   c->tn = t;
   c->fast_ok = false;  // (the next call waits: its launch geometry may differ from the last call's)
@@ -1072,7 +1098,7 @@ int run_stage_c(sc_ctx* c, uint64_t* d_key, sc_stats* stats) {
     // host-free call: the selection may turn out shorter than the T this launch was sized for (then the call is repeated);
     // its real length is what the select left in sel.want
     launch_kabsch(points_of(c), tri_source_of(c), sh, c->rt.as<float>(), aos ? c->rt_aos.as<float>() : nullptr,
-                  filter ? &job : nullptr, c->stream, c->spec_on ? &c->ctl.as<ControlBlock>()->sel.want : nullptr);
+                  filter ? &job : nullptr, c->stream, (c->spec_on || c->est_active) ? &c->ctl.as<ControlBlock>()->sel.want : nullptr);
   } else {
     c->filter_on = false; c->filter_mode = 0;
   }

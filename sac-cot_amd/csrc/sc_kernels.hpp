@@ -30,7 +30,9 @@ struct Tuning {
   int tg_events = 0;               // lanes per edge of the event-recording counting pass (0: by row width)
   uint32_t sample_mode = 0;        // pruning sample: 0 by size (launch_sample_hist), 1 every stride-th edge, 2 the heaviest edges (both CERTIFY their bound)
   bool no_edge_build = false;      // row statistics and edge list as separate launches (not launch_edge_build)
+  bool select_final = false;       // the select as ONE launch after a key kernel that takes round 1's histogram (launch_select_final): built, bit-exact, NOT faster (sc_tri.hip 4'), off by default
   bool build_sample = false;       // launch_edge_build also takes the estimating sample (measured slower: see edge_build_kernel)
+  uint32_t dbg_stop = 0;           // development only: a kernel under study returns after phase dbg_stop (WRONG results)
   bool no_estimate = false;        // never prune by an ESTIMATED bound (sc_tri.hip 3c): always one of the certifying samples
   uint32_t est_margin_pct = 0;     // the estimate aims at the (pct / 100 x T)-th key (0: 200; tests force failures with a small one)
   uint32_t sample_blocks = 0;      // grid of the heaviest-edge sample (0: one block per 256 edges)
@@ -285,6 +287,7 @@ struct SelectState {
 };
 static_assert(offsetof(SelectState, hist) % 16 == 0, "SelectState::hist must be 16-byte aligned");
 
+constexpr int SEL2_COPIES = 4;  // global copies of the select's round-1 histogram when the key kernel takes it (sc_tri.hip 4')
 constexpr int PR_HCOPIES = 4;  // global copies of the pruning-sample histogram (block b adds into copy b % 4): with one
                                // copy a thousand blocks' adds into the same 256 words serialise (C2 sample 34 -> 27 us);
                                // with 16 the readers' 16 loads per bin cost prune_bits what the sample gained
@@ -304,6 +307,8 @@ struct ControlBlock {
   uint64_t own_edge[2];      // ... and its CSR edge range (launch_shard_split)
   uint64_t pad1[4];
   SelectState sel;
+  uint32_t sel2_hist[2048];  // round 2 of launch_select_final
+  uint32_t sel_r1[SEL2_COPIES * 4096];  // round 1, taken by the key kernel: SEL2_COPIES copies by workgroup index
 };
 static_assert(offsetof(ControlBlock, sel) % 16 == 0, "ControlBlock::sel must be 16-byte aligned");
 
@@ -317,7 +322,8 @@ void launch_tri_keys(const Graph& g, const uint64_t* mbits, const float* smin, c
 void launch_tri_keys_events(const Graph& g, const float* es, const uint64_t* toff, int rank_mode,
                             const EventList& ev, uint32_t* wkey, uint2* kcol, uint32_t* blk_minmax,
                             SelectState* s, uint64_t want, const uint32_t* klb, uint64_t E, uint64_t cap,
-                            const Tuning& tn, hipStream_t st, bool check_bound = false);  // cap: entries of wkey / kcol (writes beyond are dropped); want is clipped to toff[E]
+                            const Tuning& tn, hipStream_t st, bool check_bound = false,  // cap: entries of wkey / kcol (writes beyond are dropped); want is clipped to toff[E]
+                            bool round1 = false, uint32_t* r1hist = nullptr);  // with klb: also the histogram of the select's first round into r1hist (ControlBlock::sel_r1, zeroed): launch_select_final follows
 // check_bound: with a pruning bound in *klb the select must find `want` keys at or above it (SelectState::want_req)
 // klb != nullptr (weight ranking, every edge weight >= 2/3): the kernel presets the select window to
 // [*klb or 2.0, 3.0] and no key-range pass runs; two select rounds then always suffice.
@@ -341,6 +347,12 @@ KeyView plain_view(const uint32_t* wkey, uint64_t M);
 // fewer are there
 void launch_select_rounds(const KeyView& view, SelectState* s, int rounds, const Tuning& tn, hipStream_t st,
                           uint64_t* host_short = nullptr);
+// The hot path's select (plain view, a-priori window, round 1's histogram taken by launch_tri_keys_events(round1 = true)): ONE
+// launch finds the threshold key and leaves the per-tile counts launch_compact_write takes (blk_gt / blk_eq: compact_blocks(M)
+// entries each) — select round 1, round 2 and launch_compact_count in one.  lists: select_final_list_words(M) u32 of scratch.
+size_t select_final_list_words(uint64_t M);
+void launch_select_final(const KeyView& view, SelectState* s, const uint32_t* r1hist, uint32_t* hist2, uint32_t* blk_gt, uint32_t* blk_eq,
+                         uint32_t* mlist, uint32_t* mcnt, uint64_t* host_short, hipStream_t st);  // r1hist / hist2: ControlBlock::sel_r1 / sel2_hist
 // compaction of the selected keys in ordinal order
 size_t compact_blocks(uint64_t M);
 void launch_compact_count(const KeyView& view, const SelectState* s, uint32_t* blk_gt, uint32_t* blk_eq,

@@ -426,7 +426,7 @@ __global__ __launch_bounds__(256) void tri_count_events_kernel(const uint64_t* _
                                                                StrongList sl, int rank_mode,
                                                                uint32_t* __restrict__ tcnt, EventList ev,
                                                                const uint64_t* __restrict__ own,
-                                                               const uint32_t* __restrict__ ebase) {
+                                                               const uint32_t* __restrict__ ebase, int dbg_stop) {
   // ebase (with ebi == ebj == nullptr): the per-row CSR bases are looked up (edge_build_kernel does not write them per edge)
   // own (optional, sharded stage B): [lo, hi) of the edges this rank enumerates; the strong list holds every rank's, the
   // others count 0 here (their tcnt entry is written too: the scan that follows reads zeros outside the range)
@@ -445,6 +445,7 @@ __global__ __launch_bounds__(256) void tri_count_events_kernel(const uint64_t* _
     if (threadIdx.x == 0) l_pre[ST_SHARDS] = (uint32_t)tot;
   }
   __syncthreads();
+  if (dbg_stop == 1) return;
   const uint64_t S = l_pre[ST_SHARDS];  // strong edges (only they can carry a triangle of the pruned graph)
   // the part of the flat list this rank walks: everything, or — regions being contiguous edge ranges — the regions its own
   // edge range touches (the others' tcnt entries were zeroed by the pruning kernel)
@@ -511,6 +512,7 @@ __global__ __launch_bounds__(256) void tri_count_events_kernel(const uint64_t* _
         rounds = (W - w0 + TG - 1) / TG;
       }
     }
+    if (dbg_stop == 2) { if (gl == 0 && on) tcnt[e] = rowi + rowj + fa + fb; continue; }
     int wave_rounds = rounds;  // max over the wave: the loop below is wave-uniform
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) wave_rounds = max(wave_rounds, __shfl_xor(wave_rounds, o));
@@ -537,7 +539,27 @@ __global__ __launch_bounds__(256) void tri_count_events_kernel(const uint64_t* _
     }
     if (gl == 0 && on) tcnt[e] = c;  // weak edges were zeroed by prune_bits_kernel
   }
+  if (dbg_stop == 3) return;
   if (scnt) flush();
+}
+
+// The select over the a-priori window [lo, 3.0] in two rounds that split its bits evenly (at most 11 + 11: the window is at
+// most the binade [2, 4)); shared by the key kernel (which takes round 1's histogram) and select_final_kernel.
+constexpr int SEL2_BINS = 4096;   // bins of round 1 (12 bits at most)
+constexpr int SEL2_BINS2 = 2048;  // bins of round 2 (11 bits at most: exact key values)
+static_assert(SEL2_COPIES == 4 && SEL2_BINS == 4096, "ControlBlock::sel_r1");
+struct Sel2Split { uint32_t wbits, shift1, nbins1; };
+__device__ __forceinline__ Sel2Split sel2_split(uint32_t lo) {
+  const uint32_t range_m1 = 0x40400000u - lo;  // 3.0f
+  Sel2Split s;
+  s.wbits = range_m1 == 0 ? 0u : (uint32_t)(32 - __builtin_clz(range_m1));
+  // round 1 takes as many bits as it may (12): its bins are filled by global atomics from every workgroup of the key kernel, and
+  // what those cost is the number of adds that meet on ONE address (~12 ns each, serialised) — with the bits split evenly (512
+  // bins at C2) the key kernel went from 9 to 20 us; round 2's bins are exact key values either way
+  const uint32_t b1 = s.wbits < 12u ? s.wbits : 12u;
+  s.shift1 = s.wbits - b1;
+  s.nbins1 = 1u << b1;
+  return s;
 }
 
 // one lane per event
@@ -552,12 +574,27 @@ __global__ __launch_bounds__(256) void tri_keys_events_kernel(const uint64_t* __
                                                               uint32_t* __restrict__ blk_max,
                                                               SelectState* __restrict__ preset,
                                                               const uint32_t* __restrict__ klb, uint64_t want,
-                                                              uint64_t E, uint64_t cap, int check_bound) {
+                                                              uint64_t E, uint64_t cap, int check_bound,
+                                                              uint32_t* __restrict__ r1hist) {
+  // r1hist (optional, with preset; SEL2_BINS zeroed words): the histogram of the select's FIRST round over the a-priori window,
+  // taken here, where the keys are made (select_final_kernel reads it: one launch instead of select round 1)
   // cap: entries wkey / kcol hold.  The host may launch this kernel BEFORE it knows the triangle count (into the
   // arrays of the previous call, while it polls for the count): writes beyond cap are dropped and the host re-runs.
   // For the same reason `want` is clipped here to the count the scan left in toff[E].
   __shared__ uint32_t lmin[4], lmax[4];
   __shared__ uint64_t pre[EV_SHARDS + 1];
+  // What the histogram costs is the number of adds that meet on ONE global address (~12 ns each, serialised at the memory side):
+  // with a key per add, or 2048 workgroups each adding its own LDS copy, the hottest bin held the launch back by 9 - 11 us.  So:
+  // few workgroups (launch_tri_keys_events: 512 when the histogram rides along — about an event per thread at C2), an LDS copy
+  // each, and SEL2_COPIES global copies by workgroup index: at most 128 adds per address.
+  __shared__ uint32_t lh1[SEL2_BINS];
+  uint32_t h_lo = 0, h_shift = 0, h_bins = 0;
+  if (r1hist) {  // (kernel-uniform) the window every block bins by: the one block 0 presets below
+    h_lo = *klb ? *klb : 0x40000000u;
+    const Sel2Split sp = sel2_split(h_lo);
+    h_shift = sp.shift1; h_bins = sp.nbins1;
+    for (uint32_t b = threadIdx.x; b < h_bins; b += 256) lh1[b] = 0u;
+  }
   // Weight keys of a graph whose edges all weigh >= 2/3 live in one binade, [2.0, 3.0]: the select window is known
   // before a single key exists — [certified bound (or 2.0), 3.0] — so no key-range pass, and two 12-bit rounds
   // always resolve it.  (Keys below a certified bound cannot be among the `want` largest: sc_tri.hip 3b.)
@@ -619,6 +656,7 @@ __global__ __launch_bounds__(256) void tri_keys_events_kernel(const uint64_t* __
             if (q < nbits) {
               const uint32_t key = __float_as_uint((s_ij + s_ik[q]) + s_jk[q]);
               if (out < cap) { kcol[out] = make_uint2(kbase + (uint32_t)b[q], e); wkey[out] = key; }
+              if (r1hist && key >= h_lo) atomicAdd(&lh1[(key - h_lo) >> h_shift], 1u);  // (keys never pass 3.0: inside the window)
               out++;
               kmin = min(kmin, key);
               kmax = max(kmax, key);
@@ -648,6 +686,13 @@ __global__ __launch_bounds__(256) void tri_keys_events_kernel(const uint64_t* __
   if (threadIdx.x == 0) {
     blk_min[blockIdx.x] = min(min(lmin[0], lmin[1]), min(lmin[2], lmin[3]));
     blk_max[blockIdx.x] = max(max(lmax[0], lmax[1]), max(lmax[2], lmax[3]));
+  }
+  if (r1hist) {  // (the barrier above also orders the LDS adds)
+    uint32_t* __restrict__ mine = r1hist + (size_t)(blockIdx.x & (SEL2_COPIES - 1)) * SEL2_BINS;
+    for (uint32_t b = threadIdx.x; b < h_bins; b += 256) {
+      const uint32_t v = lh1[b];
+      if (v) atomicAdd(&mine[b], v);
+    }
   }
 }
 
@@ -685,7 +730,7 @@ void launch_tri_count_events(const Graph& g, const uint64_t* mbits, const Strong
   if (nb < 256) nb = 256;
   if (nb > 4096) nb = 4096;
   if (tn.cnt_blocks >= 1 && tn.cnt_blocks <= 65535) nb = tn.cnt_blocks;
-#define SC_LAUNCH_CE(TGV) hipLaunchKernelGGL(tri_count_events_kernel<TGV>, dim3((unsigned)nb), dim3(256), 0, st, mbits, g.W, g.deg, ebi, ebj, ei, ej, sl, rank_mode, tcnt, ev, own, ebase)
+#define SC_LAUNCH_CE(TGV) hipLaunchKernelGGL(tri_count_events_kernel<TGV>, dim3((unsigned)nb), dim3(256), 0, st, mbits, g.W, g.deg, ebi, ebj, ei, ej, sl, rank_mode, tcnt, ev, own, ebase, (int)tn.dbg_stop)
   if (tg == 4) SC_LAUNCH_CE(4); else if (tg == 16) SC_LAUNCH_CE(16); else if (tg == 32) SC_LAUNCH_CE(32); else if (tg == 64) SC_LAUNCH_CE(64); else SC_LAUNCH_CE(8);
 #undef SC_LAUNCH_CE
 }
@@ -693,12 +738,12 @@ void launch_tri_count_events(const Graph& g, const uint64_t* mbits, const Strong
 void launch_tri_keys_events(const Graph& g, const float* es, const uint64_t* toff, int rank_mode,
                             const EventList& ev, uint32_t* wkey, uint2* kcol, uint32_t* blk_minmax,
                             SelectState* s, uint64_t want, const uint32_t* klb, uint64_t E, uint64_t cap,
-                            const Tuning& tn, hipStream_t st, bool check_bound) {
-  int nb = 2048;
+                            const Tuning& tn, hipStream_t st, bool check_bound, bool round1, uint32_t* r1hist) {
+  int nb = (klb && round1) ? 512 : 2048;  // (with the histogram: few workgroups — see the kernel)
   if (tn.keys_blocks >= 1 && tn.keys_blocks <= (uint32_t)TK_MAX_BLOCKS) nb = (int)tn.keys_blocks;
   hipLaunchKernelGGL(tri_keys_events_kernel, dim3(nb), dim3(256), 0, st, g.bits, g.wpre, g.deg, es, toff, rank_mode,
                      ev, wkey, kcol, blk_minmax, blk_minmax + TK_MAX_BLOCKS, klb ? s : (SelectState*)nullptr, klb, want, E, cap,
-                     check_bound ? 1 : 0);
+                     check_bound ? 1 : 0, (klb && round1) ? r1hist : (uint32_t*)nullptr);
   if (!klb)  // no a-priori window: the key range comes from the per-block extremes
     hipLaunchKernelGGL(key_range_kernel, dim3(1), dim3(1024), 0, st, blk_minmax, blk_minmax + TK_MAX_BLOCKS, nb, s, want);
 }
@@ -968,13 +1013,14 @@ __global__ __launch_bounds__(256) void tri_sample_words_kernel(const uint64_t* _
     int w = w0 + (int)((edge_hash(i * 0x9E3779B1u + j) - (uint32_t)w0) & rmask);
     if (w >= W) continue;
     const uint32_t rowi = i * (uint32_t)W, rowj = j * (uint32_t)W;
-    const float s_ij = es[e];
-    const uint32_t bi = ebi ? ebi[e] : ebase[i], bj = ebj ? ebj[e] : ebase[j];
     for (; w < W; w += (int)rmask + 1) {
       const uint64_t ai = bits[rowi + w], aj = bits[rowj + w];
       uint64_t m = ai & aj;
       if (w == w0) m &= mask_above((int)(j & 63));
       if (m == 0) continue;
+      // only the lanes that found a triangle pay for the edge's weight and CSR bases (one memory level, beside the prefix words)
+      const float s_ij = es[e];
+      const uint32_t bi = ebi ? ebi[e] : ebase[i], bj = ebj ? ebj[e] : ebase[j];
       const uint32_t pi = bi + wpre[rowi + w], pj = bj + wpre[rowj + w];
       while (m) {
         int b[4];
@@ -1718,6 +1764,198 @@ __global__ __launch_bounds__(SEL_THREADS) void select_round_kernel(KeyView view,
     if (win.shift == 0) { sel->done = 1; sel->kstar = nlo; sel->need_eq = want_eff - s_above; }
   }
 }
+
+// ------------------------------------------------------------------------------------------------
+// 4'. the select in ONE launch after the key kernel (r04; VERDICT r03 #2 (i) asked for round 1's histogram inside
+//     tri_keys_events).  BUILT, BIT-EXACT, NOT FASTER — off by default (sc_debug.select_final):
+//       C2, 186 k keys:  key kernel 8.9 us + round 1 7.7 + round 2 7.7 + compact_count 4.7 = 29.0 us   (the default)
+//                        key kernel with the histogram 13.7 + select_final 17.7               = 31.4 us   (this)
+//     Why: a histogram filled by global atomics costs the adds that meet on its hottest address (~12 ns each): one add per key
+//     20 us for the key kernel, an LDS copy per workgroup of 2048 18 - 20 us, 512 workgroups and four global copies 13.7 — and
+//     then every workgroup of the select walks 4 x 4096 bins before it can start.  The two rounds it replaces are ~5 us of
+//     launch floor + ticket each; there is little left to win.
+//   What it does:
+//   round 1's histogram arrives with the keys (tri_keys_events_kernel); every workgroup here walks it (2048 bins at most:
+//   a block scan) and knows the window of round 2 — one bin of round 1, at most 2^11 keys wide, so its bins are EXACT keys;
+//   a workgroup takes whole 1024-key tiles: keys above the window are selected for sure and counted per tile; keys inside it
+//   (a few hundred in the whole array) go into round 2's histogram and into the tile's short list;
+//   the workgroup that takes the last ticket finds k* and the number of keys == k* to keep, and settles the listed keys:
+//   per tile #(> k*) joins the sure count, #(== k*) is the tile's "equal" count — exactly what compact_write_kernel wants.
+// A tile with more in-window keys than its list holds (massive ties) is recounted by the last workgroup from the keys.
+// ------------------------------------------------------------------------------------------------
+constexpr int SEL2_SEG = 32;  // in-window keys a tile can list (sc_capi.hip lays the lists out by this)
+
+__global__ __launch_bounds__(256) void select_final_kernel(const uint32_t* __restrict__ wkey, uint64_t M,
+                                                           const uint64_t* __restrict__ M_dev,
+                                                           SelectState* __restrict__ sel, uint32_t* __restrict__ blk_gt,
+                                                           uint32_t* __restrict__ blk_eq, uint32_t* __restrict__ mlist,
+                                                           uint32_t* __restrict__ mcnt, uint64_t* __restrict__ host_short,
+                                                           uint32_t* __restrict__ hist2, const uint32_t* __restrict__ r1hist) {
+  // r1hist: round 1's histogram as the key kernel left it (SEL2_COPIES copies of SEL2_BINS words)
+  // hist2: SEL2_BINS2 words of round 2's histogram, zeroed (control block)
+  __shared__ uint64_t lds[8];
+  __shared__ uint32_t lh2[SEL2_BINS2];
+  __shared__ uint32_t s_bin, s_last, s_wsum[4], s_lcnt;
+  __shared__ uint64_t s_above;
+  __shared__ uint32_t s_list[SEL2_SEG];
+  const uint64_t ntiles = (M + 1023) / 1024;  // of what the launch COVERS: compact_write_kernel runs as many workgroups
+  if (M_dev) M = min(M, *M_dev);
+  const uint32_t lo = sel->lo;
+  const Sel2Split sp = sel2_split(lo);
+  const uint64_t want = sel->want;
+  const int nbins1 = (int)sp.nbins1;
+  // ---- round 1's pick, by every workgroup: thread t owns `per` bins counted from the top
+  const int per = nbins1 >= 256 ? nbins1 / 256 : 1;
+  const bool owner = (int)threadIdx.x * per < nbins1;
+  uint32_t h[SEL2_BINS / 256];
+  uint64_t mine = 0;
+#pragma unroll
+  for (int k = 0; k < SEL2_BINS / 256; k++) {
+    h[k] = 0u;
+    if (owner && k < per) {
+      const int bin = nbins1 - 1 - ((int)threadIdx.x * per + k);
+#pragma unroll
+      for (int c = 0; c < SEL2_COPIES; c++) h[k] += r1hist[c * SEL2_BINS + bin];
+    }
+    mine += h[k];
+  }
+  if (threadIdx.x == 0) { s_bin = 0; s_above = 0; }
+  uint64_t tot;
+  const uint64_t before = block_exscan_u64(mine, lds, &tot);  // (its barriers also order the defaults above)
+  const uint64_t want_eff = want < tot ? want : tot;
+  if (before < want_eff && want_eff <= before + mine) {
+    uint64_t run = before;
+#pragma unroll
+    for (int k = 0; k < SEL2_BINS / 256; k++) {
+      if (k < per && run < want_eff && want_eff <= run + h[k]) { s_bin = (uint32_t)(nbins1 - 1 - ((int)threadIdx.x * per + k)); s_above = run; }
+      run += h[k];
+    }
+  }
+  // (see select_round_kernel: an estimated pruning bound that promised more keys above it than there are)
+  if (blockIdx.x == 0 && threadIdx.x == 0 && host_short && sel->want_req != 0 && tot < sel->want_req) publish_host(host_short, 1ull);
+  for (int b = threadIdx.x; b < SEL2_BINS2; b += 256) lh2[b] = 0u;
+  __syncthreads();
+  const uint32_t lo2 = lo + (s_bin << sp.shift1);
+  const uint64_t width2 = 1ull << sp.shift1;  // <= 2^11: one bin per key value
+  const uint64_t above1 = s_above;
+  // ---- the tiles
+  for (uint64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const uint64_t base = tile * 1024 + (uint64_t)threadIdx.x * 4;
+    uint32_t keys[4];
+    int valid;
+    if (base + 4 <= M) {
+      const uint4 k4 = *reinterpret_cast<const uint4*>(wkey + base);
+      keys[0] = k4.x; keys[1] = k4.y; keys[2] = k4.z; keys[3] = k4.w;
+      valid = 4;
+    } else {
+      valid = base < M ? (int)(M - base) : 0;
+#pragma unroll
+      for (int k = 0; k < 4; k++) keys[k] = k < valid ? wkey[base + k] : 0u;
+    }
+    if (threadIdx.x == 0) s_lcnt = 0u;
+    __syncthreads();
+    uint32_t g = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      if (k >= valid || keys[k] < lo2) continue;
+      const uint64_t rel = (uint64_t)keys[k] - lo2;
+      if (rel >= width2) { g++; continue; }
+      atomicAdd(&lh2[(uint32_t)rel], 1u);
+      const uint32_t slot = atomicAdd(&s_lcnt, 1u);  // (LDS: a handful per tile)
+      if (slot < (uint32_t)SEL2_SEG) s_list[slot] = keys[k];
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) g += __shfl_xor(g, o);
+    if ((threadIdx.x & 63) == 0) s_wsum[threadIdx.x >> 6] = g;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      blk_gt[tile] = s_wsum[0] + s_wsum[1] + s_wsum[2] + s_wsum[3];
+      blk_eq[tile] = 0u;
+      mcnt[tile] = s_lcnt;
+    }
+    if (threadIdx.x < (uint32_t)SEL2_SEG && threadIdx.x < s_lcnt) mlist[tile * SEL2_SEG + threadIdx.x] = s_list[threadIdx.x];
+    __syncthreads();
+  }
+  // round 2's histogram (zeroed with the control block)
+  for (int b = threadIdx.x; b < SEL2_BINS2; b += 256) {
+    const uint32_t v = lh2[b];
+    if (v) atomicAdd(&hist2[b], v);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const uint32_t t = __hip_atomic_fetch_add(&sel->ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    s_last = (t == gridDim.x - 1) ? 1u : 0u;
+  }
+  __syncthreads();
+  if (!s_last) return;
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  // ---- the last workgroup: k* = the largest key v of the window with above1 + #(keys >= v) >= want_eff
+  {
+    const int nb2 = (int)width2;  // bins = key values lo2 .. lo2 + nb2 - 1
+    const int per2 = nb2 >= 256 ? nb2 / 256 : 1;
+    const bool own2 = (int)threadIdx.x * per2 < nb2;
+    uint32_t h2[SEL2_BINS2 / 256];
+    uint64_t mine2 = 0;
+#pragma unroll
+    for (int k = 0; k < SEL2_BINS2 / 256; k++) {
+      h2[k] = (own2 && k < per2) ? hist2[nb2 - 1 - ((int)threadIdx.x * per2 + k)] : 0u;  // (plain loads: every wave acquired above)
+      mine2 += h2[k];
+    }
+    if (threadIdx.x == 0) { s_bin = 0; s_above = above1; }
+    uint64_t tot2;
+    const uint64_t before2 = above1 + block_exscan_u64(mine2, lds, &tot2);
+    if (before2 < want_eff && want_eff <= before2 + mine2) {
+      uint64_t run = before2;
+#pragma unroll
+      for (int k = 0; k < SEL2_BINS2 / 256; k++) {
+        if (k < per2 && run < want_eff && want_eff <= run + h2[k]) { s_bin = (uint32_t)(nb2 - 1 - ((int)threadIdx.x * per2 + k)); s_above = run; }
+        run += h2[k];
+      }
+    }
+    __syncthreads();
+  }
+  const uint32_t kstar = lo2 + s_bin;
+  const uint64_t need_eq = want_eff - s_above;
+  // ---- settle the listed keys, a tile per thread
+  for (uint64_t tile = threadIdx.x; tile < ntiles; tile += 256) {
+    const uint32_t cnt = mcnt[tile];
+    uint32_t gt = 0, eq = 0;
+    if (cnt <= (uint32_t)SEL2_SEG) {
+      const uint4* __restrict__ l4 = reinterpret_cast<const uint4*>(mlist + tile * SEL2_SEG);
+      for (uint32_t k = 0; k < cnt; k += 4) {  // (entries beyond cnt hold stale keys: masked)
+        const uint4 v = l4[k >> 2];
+        gt += (v.x > kstar) + (k + 1 < cnt && v.y > kstar) + (k + 2 < cnt && v.z > kstar) + (k + 3 < cnt && v.w > kstar);
+        eq += (v.x == kstar) + (k + 1 < cnt && v.y == kstar) + (k + 2 < cnt && v.z == kstar) + (k + 3 < cnt && v.w == kstar);
+      }
+    } else {  // the list overflowed (heavy ties inside the window): the tile's keys themselves
+      const uint64_t k0 = tile * 1024, k1 = min(M, k0 + 1024);
+      const uint64_t top = (uint64_t)lo2 + width2;
+      for (uint64_t q = k0; q < k1; q++) {
+        const uint32_t key = wkey[q];
+        gt += (key > kstar && (uint64_t)key < top); eq += key == kstar;
+      }
+    }
+    if (gt) blk_gt[tile] = blk_gt[tile] + gt;
+    blk_eq[tile] = eq;
+  }
+  if (threadIdx.x == 0) {
+    sel->above = s_above; sel->lo = kstar; sel->wbits = 0; sel->started = 1; sel->ticket = 0; sel->want = want_eff;
+    sel->done = 1; sel->kstar = kstar; sel->need_eq = need_eq;
+  }
+}
+
+void launch_select_final(const KeyView& view, SelectState* s, const uint32_t* r1hist, uint32_t* hist2, uint32_t* blk_gt, uint32_t* blk_eq,
+                         uint32_t* mlist, uint32_t* mcnt, uint64_t* host_short, hipStream_t st) {
+  if (view.M == 0) return;
+  uint64_t nb = (view.M + 1023) / 1024;
+  if (nb > 1024) nb = 1024;
+  hipLaunchKernelGGL(select_final_kernel, dim3((unsigned)nb), dim3(256), 0, st, view.base, view.M, view.M_dev, s, blk_gt, blk_eq, mlist,
+                     mcnt, host_short, hist2, r1hist);
+}
+size_t select_final_list_words(uint64_t M) { return (size_t)((M + 1023) / 1024) * (SEL2_SEG + 1); }
 
 KeyView plain_view(const uint32_t* wkey, uint64_t M) { return KeyView{wkey, M, 0, 0, nullptr, 0, nullptr}; }
 
