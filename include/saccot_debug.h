@@ -53,7 +53,7 @@ typedef struct sc_debug {
   uint32_t build_sample;      /* 1: the fused edge kernel also takes the estimating sample (instead of a launch of its own) */
   uint32_t reserved[1];       /* development hook (a kernel under study stops early: WRONG results); leave 0 */
   uint32_t select_final;      /* 1: the select as ONE launch after a key kernel that also takes round 1's histogram, instead of round 1 + round 2 + per-tile count (built, bit-exact, measured no faster: off by default) */
-  uint32_t pad_;
+  uint32_t pad_;              /* compat_linear_order: 1 = stage A's 64 x 64 blocks in index order instead of the XCD-aware order */
 } sc_debug;
 int         sc_set_debug(sc_ctx* ctx, const sc_debug* dbg);
 

@@ -47,7 +47,9 @@ struct sc_ctx {
   // workspace
   Buf in_src, in_tgt, planes, S, bits, deg, degp, wpre, ebase, edge_off, scan_tmp, ei, ej, es, ebi, ebj, tcnt, toff, wkey, kcol, ctl, events, blk_gt,
       blk_eq, blk_minmax, bits2, off_gt, off_eq, sel_ord, sel_key, sortkey, sorted, sort_tmp, tri, tri_rk, key_rk, rt, rt_aos, partial, cnt, key, rt12,
-      mask, refine_tmp, amx_pairs, strong, rowcost, cost_pre, lb_state, lb_ticket, fx_tile, fx_state, fx_mx, fx_part, fx_coef, guard_tmp, sel_list;
+      mask, refine_tmp, amx_pairs, strong, rowcost, cost_pre, lb_state, lb_ticket, fx_tile, fx_state, fx_mx, fx_part, fx_coef, guard_tmp, sel_list, wg_map;
+  int wg_map_W = 0;          // the row width (words) the XCD-aware block order of stage A in wg_map was made for
+  uint32_t wg_map_len = 0;
   bool filter_on = false;   // C2 of the running / last call goes through a matrix-pipe filter (decided ONCE per call)
   int filter_mode = 0;      // ... which: 1 linear, 2 Gram (0: the plain fp32 kernel)
   FilterPlan fx_plan{};     // ... with this plan (sc_debug_last reads the filter's counters through it)
@@ -312,8 +314,23 @@ int run_compat(sc_ctx* c, bool dense) {
   ENSURE(c, c->wpre, n * W * sizeof(uint32_t));
   c->bits_cur = c->bits.as<uint64_t>();
   c->sharded_ab = false; c->shard_phase = 0; c->cand_all = nullptr;
+  const uint32_t* map = nullptr;
+  // The XCD-aware block order (sc_compat.hip compat_wg_map; made once per row width).  Measured r04 (profiles/r04_pmc_compat_xcd_order.txt):
+  // HBM write bytes C2 115.8 -> 106.9 MB (algorithmic 103.2: 1.035 x), bits only 13.0 -> 5.1 MB; C3 1820 -> 1683 MB (1.02 x).  Time:
+  // C2 25.0 -> 23.7 us, but at C3 the index order is FASTER (352 vs 369 - 389 us, alternating three times in one process) although it
+  // writes more: each XCD then streams its S rows into one 512 x 512 corner of the matrix at a time.  So: by size, like the tile height.
+  if (!c->tn.compat_linear_order && c->tn.compat_rows != 64 && (c->n < 10000 || c->tn.compat_rows == 16)) {
+    if (c->wg_map_W != (int)W) {
+      const std::vector<uint32_t> m = compat_wg_map((int)W);
+      ENSURE(c, c->wg_map, m.size() * 4);
+      HIPCHK(c, hipMemcpyAsync(c->wg_map.p, m.data(), m.size() * 4, hipMemcpyHostToDevice, c->stream));
+      HIPCHK(c, hipStreamSynchronize(c->stream));  // (m is a local: the copy must have left it; once per size)
+      c->wg_map_W = (int)W; c->wg_map_len = (uint32_t)m.size();
+    }
+    map = c->wg_map.as<uint32_t>();
+  }
   launch_compat(points_of(c), c->dv, dense ? c->S.as<float>() : nullptr, c->bits_cur, 0, c->n, c->tn, c->stream,
-                c->build ? c->degp.as<uint32_t>() : nullptr);
+                c->build ? c->degp.as<uint32_t>() : nullptr, map, c->wg_map_len);
   return SC_OK;
 }
 
@@ -852,7 +869,7 @@ void sc_destroy(sc_ctx* c) {
   Buf* bufs[] = {&c->in_src, &c->in_tgt, &c->planes, &c->S, &c->bits, &c->deg, &c->degp, &c->wpre, &c->ebase, &c->edge_off, &c->scan_tmp,
                  &c->ei, &c->ej, &c->es, &c->ebi, &c->ebj, &c->tcnt, &c->toff, &c->wkey, &c->kcol, &c->ctl, &c->events, &c->blk_gt, &c->blk_eq, &c->blk_minmax, &c->bits2, &c->off_gt,
                  &c->off_eq, &c->sel_ord, &c->sel_key, &c->sortkey, &c->sorted, &c->sort_tmp, &c->tri, &c->tri_rk, &c->key_rk, &c->rt,
-                 &c->rt_aos, &c->partial, &c->cnt, &c->key, &c->rt12, &c->mask, &c->refine_tmp, &c->amx_pairs, &c->strong, &c->rowcost, &c->cost_pre, &c->lb_state, &c->lb_ticket, &c->fx_tile, &c->fx_state, &c->fx_mx, &c->fx_part, &c->fx_coef, &c->guard_tmp, &c->sel_list};
+                 &c->rt_aos, &c->partial, &c->cnt, &c->key, &c->rt12, &c->mask, &c->refine_tmp, &c->amx_pairs, &c->strong, &c->rowcost, &c->cost_pre, &c->lb_state, &c->lb_ticket, &c->fx_tile, &c->fx_state, &c->fx_mx, &c->fx_part, &c->fx_coef, &c->guard_tmp, &c->sel_list, &c->wg_map};
   for (Buf* b : bufs) if (b->p) (void)hipFree(b->p);
   for (int i = 0; i < N_EVENTS; i++) if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
   if (c->pinned) (void)hipHostFree(c->pinned);
@@ -921,6 +938,7 @@ int sc_set_debug(sc_ctx* c, const sc_debug* d) {
   t.no_edge_build = d->no_edge_build != 0;
   t.build_sample = d->build_sample != 0;
   t.select_final = d->select_final != 0;
+  t.compat_linear_order = d->pad_ != 0;
   t.dbg_stop = d->reserved[0];
   t.est_margin_pct = d->est_margin_pct;
   c->tn = t;

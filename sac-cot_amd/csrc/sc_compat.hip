@@ -2,7 +2,9 @@
 //
 // Stage A's output is 4 N^2 bytes of weights + N^2/8 bytes of adjacency bits (103 MB at N = 5000): the HBM write
 // roofline is its bound; see the stage-A section below for the tiling that gets the arithmetic out of the way.
+#include <algorithm>
 #include <type_traits>
+#include <vector>
 
 #include "sc_arith.hpp"
 #include "sc_block.hpp"
@@ -166,12 +168,17 @@ __global__ __launch_bounds__(64 * COMPAT_WAVES) void compat_tiles_kernel(const f
                                                                          float nis, float* __restrict__ S,
                                                                          uint64_t* __restrict__ bits, int n_tiles,
                                                                          int two_phase, int row0, int row1,
-                                                                         int mode, uint32_t* __restrict__ degp) {
+                                                                         int mode, uint32_t* __restrict__ degp,
+                                                                         const uint32_t* __restrict__ wg_map) {
   constexpr int TILE_PAD = TILE_R + 1;  // LDS row stride of the transposed tile: conflict-free both ways
   constexpr int SUB = 64 / TILE_R;      // tiles per 64-row block
   __shared__ float tileT[DENSE ? COMPAT_WAVES : 1][DENSE ? 64 * TILE_PAD : 1];  // [column][row] per wave
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int t = blockIdx.x * COMPAT_WAVES + wave;
+  // wg_map (whole-matrix form, COMPAT_WAVES == SUB: a workgroup = one 64 x 64 block of the matrix): which block this
+  // workgroup takes — the XCD-aware order of compat_wg_map() below; ~0: a padding workgroup
+  const uint32_t wg = wg_map ? wg_map[blockIdx.x] : blockIdx.x;
+  if (wg == 0xFFFFFFFFu) return;
+  const int t = (int)wg * COMPAT_WAVES + wave;
   if (t >= n_tiles) return;  // whole wave; no block-level barrier is used below
   const int W = ld >> 6;
   const bool nt = (mode & 2) != 0, st4 = (mode & 1) != 0;
@@ -610,8 +617,43 @@ __global__ __launch_bounds__(64) void shard_split_kernel(const uint64_t* __restr
 // rows [row0, row1) of the graph (row0 a multiple of 64, row1 <= n); the whole matrix (symmetric tiles, each pair
 // evaluated once) when the range is [0, n).  S == nullptr: adjacency bits only (SC_FLAG_NO_DENSE_S).  For a proper
 // sub-range S holds the rows of the range only (row i at S + (i - row0) * ld).
+// XCD-aware order of the 64 x 64 blocks (m, J), m <= J, of the symmetric form.  A 64-byte line of a bit row holds 8 adjacency
+// words, and they are written by 8 DIFFERENT workgroups: row block m's words J = 8 k .. 8 k + 7 by the direct halves of (m, 8 k ..),
+// and — the mirrored half — column block J's words m = 8 k' .. by (8 k' .., J).  Workgroups go to the 8 XCDs round-robin by
+// index, each XCD has its own L2, and a line assembled in eight L2s leaves each of them as a partial write: the bits-only
+// form of the kernel wrote 12.2 MB for 3.2 MB of bit rows (profiles/r03_pmc_compat_writes.txt).  So the blocks are dealt to
+// the XCDs by 8 x 8 SUPER-blocks (all eight writers of a line in one super-block, hence one L2, and close together in its
+// dispatch order): entry b of the map is the block workgroup b takes — workgroup b runs on XCD b % 8 —, ~0 pads the XCDs'
+// lists to one length.  Super-blocks are dealt largest first to the XCD with the least work so far.
+std::vector<uint32_t> compat_wg_map(int W) {
+  const int SB = (W + 7) / 8;
+  struct Super { int sj, sm; int tiles; };
+  std::vector<Super> sup;
+  for (int sj = 0; sj < SB; sj++)
+    for (int sm = 0; sm <= sj; sm++) {
+      int tiles = 0;
+      for (int J = sj * 8; J < W && J < sj * 8 + 8; J++)
+        for (int m = sm * 8; m <= J && m < sm * 8 + 8; m++) tiles++;
+      if (tiles) sup.push_back(Super{sj, sm, tiles});
+    }
+  std::stable_sort(sup.begin(), sup.end(), [](const Super& a, const Super& b) { return a.tiles > b.tiles; });
+  std::vector<uint32_t> lists[8];
+  for (const Super& su : sup) {
+    int best = 0;
+    for (int x = 1; x < 8; x++) if (lists[x].size() < lists[best].size()) best = x;
+    for (int J = su.sj * 8; J < W && J < su.sj * 8 + 8; J++)
+      for (int m = su.sm * 8; m <= J && m < su.sm * 8 + 8; m++) lists[best].push_back((uint32_t)(J * (J + 1) / 2 + m));
+  }
+  size_t len = 0;
+  for (int x = 0; x < 8; x++) len = lists[x].size() > len ? lists[x].size() : len;
+  std::vector<uint32_t> map(8 * len, 0xFFFFFFFFu);
+  for (int x = 0; x < 8; x++)
+    for (size_t k = 0; k < lists[x].size(); k++) map[8 * k + x] = lists[x][k];
+  return map;
+}
+
 void launch_compat(const Points& pts, const Derived& dv, float* S, uint64_t* bits, int row0, int row1, const Tuning& tn,
-                   hipStream_t st, uint32_t* degp) {
+                   hipStream_t st, uint32_t* degp, const uint32_t* wg_map, uint32_t wg_map_len) {
   const int W = pts.ld >> 6;
   const int two_phase = tn.compat_one_phase ? 0 : 1;  // the one-phase interior form stays for A/B and parity
   const bool rect = !(row0 == 0 && row1 >= pts.n);
@@ -625,7 +667,8 @@ void launch_compat(const Points& pts, const Derived& dv, float* S, uint64_t* bit
   if (tn.compat_store_mode & 1u) mode = 1;
   if (tn.compat_store_mode & 4u) mode = 0;
   mode |= (int)(tn.compat_store_mode & 2u);
-#define SC_COMPAT_ARGS pts.planes, pts.n, pts.ld, dv.d_thr, dv.min_len, dv.neg_inv2sig2, S, bits, n_tiles, two_phase, row0, row1, mode, degp
+#define SC_COMPAT_ARGS pts.planes, pts.n, pts.ld, dv.d_thr, dv.min_len, dv.neg_inv2sig2, S, bits, n_tiles, two_phase, row0, row1, mode, degp, map_arg
+  const uint32_t* map_arg = nullptr;  // (only the symmetric 16- and 32-row forms take the map: there a workgroup is a 64 x 64 block)
   if (rect) {
     if (row1 <= row0) return;
     // one-sided 16-row tiles over the rectangle (every pair of the block evaluated by this rank)
@@ -644,16 +687,20 @@ void launch_compat(const Points& pts, const Derived& dv, float* S, uint64_t* bit
   const int tr = tn.compat_rows == 64 ? 64 : (tn.compat_rows == 32 ? 32 : (tn.compat_rows == 16 ? 16 : (pts.n >= 10000 ? 32 : 16)));
   if (tr == 32) {
     const int n_tiles = 2 * W * (W + 1) / 2;
-    if (S) hipLaunchKernelGGL((compat_tiles_kernel<32, 2, true, false>), dim3((n_tiles + 1) / 2), dim3(128), 0, st, SC_COMPAT_ARGS);
-    else hipLaunchKernelGGL((compat_tiles_kernel<32, 2, false, false>), dim3((n_tiles + 1) / 2), dim3(128), 0, st, SC_COMPAT_ARGS);
+    map_arg = wg_map;
+    const unsigned grid = wg_map ? wg_map_len : (unsigned)((n_tiles + 1) / 2);
+    if (S) hipLaunchKernelGGL((compat_tiles_kernel<32, 2, true, false>), dim3(grid), dim3(128), 0, st, SC_COMPAT_ARGS);
+    else hipLaunchKernelGGL((compat_tiles_kernel<32, 2, false, false>), dim3(grid), dim3(128), 0, st, SC_COMPAT_ARGS);
   } else if (tr == 64) {
     const int n_tiles = W * (W + 1) / 2;
     if (S) hipLaunchKernelGGL((compat_tiles_kernel<64, 1, true, false>), dim3(n_tiles), dim3(64), 0, st, SC_COMPAT_ARGS);
     else hipLaunchKernelGGL((compat_tiles_kernel<64, 1, false, false>), dim3(n_tiles), dim3(64), 0, st, SC_COMPAT_ARGS);
   } else {
     const int n_tiles = 4 * W * (W + 1) / 2;
-    if (S) hipLaunchKernelGGL((compat_tiles_kernel<16, 4, true, false>), dim3((n_tiles + 3) / 4), dim3(256), 0, st, SC_COMPAT_ARGS);
-    else hipLaunchKernelGGL((compat_tiles_kernel<16, 4, false, false>), dim3((n_tiles + 3) / 4), dim3(256), 0, st, SC_COMPAT_ARGS);
+    map_arg = wg_map;
+    const unsigned grid = wg_map ? wg_map_len : (unsigned)((n_tiles + 3) / 4);
+    if (S) hipLaunchKernelGGL((compat_tiles_kernel<16, 4, true, false>), dim3(grid), dim3(256), 0, st, SC_COMPAT_ARGS);
+    else hipLaunchKernelGGL((compat_tiles_kernel<16, 4, false, false>), dim3(grid), dim3(256), 0, st, SC_COMPAT_ARGS);
   }
 #undef SC_COMPAT_ARGS
 }

@@ -4,8 +4,11 @@
 #include <cstddef>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <vector>
 
 namespace sc {
+
+std::vector<uint32_t> compat_wg_map(int W);  // sc_compat.hip: which 64 x 64 block workgroup b of stage A takes (XCD-aware)
 
 // Derived fp32 constants, computed once per call on the host in fp64.
 struct Derived {
@@ -30,6 +33,7 @@ struct Tuning {
   int tg_events = 0;               // lanes per edge of the event-recording counting pass (0: by row width)
   uint32_t sample_mode = 0;        // pruning sample: 0 by size (launch_sample_hist), 1 every stride-th edge, 2 the heaviest edges (both CERTIFY their bound)
   bool no_edge_build = false;      // row statistics and edge list as separate launches (not launch_edge_build)
+  bool compat_linear_order = false;  // stage A's 64 x 64 blocks in index order (r03) instead of the XCD-aware order
   bool select_final = false;       // the select as ONE launch after a key kernel that takes round 1's histogram (launch_select_final): built, bit-exact, NOT faster (sc_tri.hip 4'), off by default
   bool build_sample = false;       // launch_edge_build also takes the estimating sample (measured slower: see edge_build_kernel)
   uint32_t dbg_stop = 0;           // development only: a kernel under study returns after phase dbg_stop (WRONG results)
@@ -113,8 +117,10 @@ bool filter_in_range(uint64_t host_max, float tau2);
 // rows [row0, row1) (row0 a multiple of 64): the whole matrix by symmetric tiles for [0, n), one-sided tiles for a
 // row block (then S, if given, holds the rows of the block only).  S == nullptr: adjacency bits only.
 // degp (optional, whole-matrix form only; n u32, ZEROED): also accumulates deg+[i] = edges (i, j) with j > i (atomics).
+// wg_map / wg_map_len (optional, whole-matrix form): the XCD-aware order of the 64 x 64 blocks, compat_wg_map(ld / 64) on the
+// device — the launch then has wg_map_len workgroups.
 void launch_compat(const Points& pts, const Derived& dv, float* S, uint64_t* bits, int row0, int row1, const Tuning& tn,
-                   hipStream_t st, uint32_t* degp = nullptr);
+                   hipStream_t st, uint32_t* degp = nullptr, const uint32_t* wg_map = nullptr, uint32_t wg_map_len = 0);
 // deg[i] = edges of i; degp[i] = edges (i,j) with j > i; wpre: n x (ld/64) u32, set bits of row i in words [0,w).
 // zero_rows (optional): an n x W u64 matrix cleared on the way (the pruned bit matrix of stage B).
 // rowcost (optional, n u32): per-row estimate of stage B's work (see row_stats_kernel), for launch_shard_split.
