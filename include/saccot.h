@@ -48,6 +48,8 @@ extern "C" {
 #define SC_ETOOMANY -6   /* the graph has more triangles than the workspace cap can rank (see max_workspace),  */
                          /* or 2^32 or more edges (edge ids are 32-bit)                                      */
 
+#define SC_EBOUND   -8   /* sharded stages A + B with SC_FLAG_EST_BOUND only: the ESTIMATED pruning bound was too high (the merged  */
+                        /* candidates hold fewer than T keys above it): nothing was returned; repeat the call WITHOUT the flag  */
 #define SC_ERETRY   -7   /* sharded stages A + B only: a rank's candidate blob was too small for this input (its    */
                          /* list was cut at a key the merged threshold does not clear).  Outputs are not valid;    */
                          /* repeat the call on every rank with sc_params.shard_cand_level raised by one (every     */
@@ -88,6 +90,12 @@ extern "C" {
 #define SC_FLAG_REFINE       8u /* after C3, replace (R,t) by the fp64 least-squares refit over the winner's inlier  */
                                 /* mask; the mask itself stays the fp32 winner's                   */
 #define SC_FLAG_NO_PRUNE     4u /* disable the certified pruning of stage B (results are identical either way)    */
+#define SC_FLAG_EST_BOUND  128u /* phase API sc_shard_* only (sc_register / sc_register_device / sc_register_multi do this by themselves): */
+                                /* stage B prunes by a bound ESTIMATED from a 1-in-64 sample of the graph's triangles instead of a      */
+                                /* certified one.  EVERY rank takes the whole (cheap) sample, so sc_shard_edges_device leaves the same    */
+                                /* histogram on every rank and the all-reduce after it MUST BE SKIPPED — three collectives per call, not  */
+                                /* four.  The merge verifies the bound; when it was too high the finalize call returns SC_EBOUND on every  */
+                                /* rank (nothing returned): repeat the call without this flag.  Results are identical either way.         */
 #define SC_FLAG_NO_DENSE_S  32u /* stage A writes only the adjacency bit rows, not the dense n x n weight matrix S:   */
                                 /* nothing after stage A reads S (edge weights are recomputed from the points), so    */
                                 /* every result is identical; sc_compat_host returns S only without this flag         */

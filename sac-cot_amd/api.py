@@ -16,7 +16,8 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libsaccot.so")
 
-SC_OK, SC_EINVAL, SC_ENOMEM, SC_EHIP, SC_ERCCL, SC_ENOHYP, SC_ETOOMANY, SC_ERETRY = 0, -1, -2, -3, -4, -5, -6, -7
+SC_OK, SC_EINVAL, SC_ENOMEM, SC_EHIP, SC_ERCCL, SC_ENOHYP, SC_ETOOMANY, SC_ERETRY, SC_EBOUND = 0, -1, -2, -3, -4, -5, -6, -7, -8
+SC_FLAG_EST_BOUND = 128  # phase API sc_shard_*: prune by an estimated bound, no histogram all-reduce, SC_EBOUND -> repeat without it
 SC_AOS, SC_SOA = 0, 1
 SC_RANK_WEIGHT, SC_RANK_DEGREE = 0, 1
 SC_SCORE_COUNT, SC_SCORE_MSE, SC_SCORE_MAE = 0, 1, 2
@@ -304,7 +305,7 @@ class Registrar:
         """Phase 2 on n_pairs all-gathered key pairs (shard.allgather_best): the reduction runs in the kernel."""
         st = ScStats(C.sizeof(ScStats))
         rc = self._check(self._lib.sc_finalize_gathered_device(self._h, d_keys, n_pairs, d_Rt, d_mask, C.byref(st)),
-                         allow=(SC_ENOHYP, SC_ERETRY))  # SC_ERETRY (sharded A + B): repeat with shard_cand_level + 1
+                         allow=(SC_ENOHYP, SC_ERETRY, SC_EBOUND))  # SC_ERETRY (sharded A + B): repeat with shard_cand_level + 1; SC_EBOUND: repeat without SC_FLAG_EST_BOUND
         return rc, st.as_dict()
 
     # ---- stages A and B sharded too (SURVEY §8f-1; include/saccot.h "phase API") ----------------------------

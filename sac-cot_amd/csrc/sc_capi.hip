@@ -518,8 +518,11 @@ int run_edges(sc_ctx* c, const sc_params* p, uint32_t* hist, uint32_t part, uint
     // An ESTIMATED bound where the call can be repeated should the select find it too high (sc_tri.hip 3c): the common
     // form only — event list, a-priori select window (the check rides the window's first round), the whole sample here
     const bool window_known = p->rank_mode == SC_RANK_WEIGHT && 3.0f * p->t_cmp * 0.999f >= 2.0f;
-    c->plan = sample_plan(p->max_triangles, c->est_allowed && !c->est_failed && hist == nullptr && parts == 1 && !c->sharded_ab &&
-                                                c->use_events && window_known, c->tn);
+    // (sharded, SC_FLAG_EST_BOUND: every rank takes the WHOLE sample — it is cheaper than the latency of the all-reduce that
+    // would sum the ranks' shares — and the merge of the candidates verifies the bound: sc_shard_score_device)
+    const bool est_local = c->est_allowed && !c->est_failed && hist == nullptr && parts == 1 && !c->sharded_ab;
+    const bool est_shard = c->sharded_ab && hist != nullptr && (p->flags & SC_FLAG_EST_BOUND) != 0;
+    c->plan = sample_plan(p->max_triangles, (est_local || est_shard) && c->use_events && window_known, c->tn);
     c->est_active = c->plan.estimate;
     if (build && !c->plan.estimate) { c->last_error = "internal: the fused edge kernel ran but the bound is not an estimate"; return SC_EHIP; }
     if (build && c->tn.build_sample) {
@@ -820,6 +823,7 @@ const char* sc_strerror(int status) {
     case SC_ENOHYP: return "no hypothesis: the compatibility graph has no triangle with an inlier";
     case SC_ETOOMANY: return "too many triangles for the workspace cap";
     case SC_ERETRY: return "a candidate blob was too small: repeat with sc_params.shard_cand_level + 1";
+    case SC_EBOUND: return "the estimated pruning bound was too high: repeat without SC_FLAG_EST_BOUND";
     default: return "unknown status";
   }
 }
@@ -982,6 +986,7 @@ int hyp_begin(sc_ctx* c, const float* d_src, const float* d_tgt, int64_t n, cons
   c->cap_bytes = p->max_workspace ? p->max_workspace : (64ull << 30);
   c->dv = derive(p);
   c->params = *p;
+  if (p->flags & SC_FLAG_EST_BOUND) { c->last_error = "SC_FLAG_EST_BOUND belongs to the sc_shard_* phase API"; return SC_EINVAL; }
   c->build = d_hist == nullptr && parts == 1 && edge_build_ok(c, p, n);
   if ((rc = rec(c, 0))) return rc;
   if ((rc = stage_inputs(c, d_src, d_tgt, n, p))) return rc;
@@ -1283,7 +1288,9 @@ int sc_shard_score_device(sc_ctx* c, const void* d_cand_all, uint64_t* d_key, sc
   ENSURE(c, c->sel_ord, (size_t)T * 8);
   ENSURE(c, c->sel_key, (size_t)T * 4);
   arm_word(c, 6);
-  launch_merge_prepare(d_cand_all, blob_bytes, G, T, window_known, &ctl->klb, sel, &c->pinned[6], st);
+  c->pinned[15] = 0;  // "an estimated bound promised T keys above it and the merged candidates hold fewer" (merge_prepare_kernel)
+  launch_merge_prepare(d_cand_all, blob_bytes, G, T, window_known, &ctl->klb, sel, &c->pinned[6], st,
+                       c->est_active ? &c->pinned[15] : nullptr);
   launch_select_rounds(view, sel, window_known ? 2 : 3, c->tn, st);
   c->pinned[12] = 0;  // "a cut candidate list could have mattered": read by the finalize call (SC_ERETRY)
   launch_merge_check(d_cand_all, blob_bytes, G, sel, &c->pinned[12], st);
@@ -1366,6 +1373,12 @@ int finalize_wait(sc_ctx* c, sc_stats* stats) {
     c->regular = true;
   }
   c->est_state = c->est_active ? 1 : 0;
+  if (c->sharded_ab && c->est_active && (c->pinned[15] != 0 || c->est_void)) {
+    // SC_FLAG_EST_BOUND: every rank holds the same gathered blobs, so every rank ends here together; the caller repeats the call
+    // without the flag (include/saccot.h)
+    c->last_error = "the estimated pruning bound was too high for this input: repeat the call without SC_FLAG_EST_BOUND";
+    return SC_EBOUND;
+  }
   if (c->pinned[14] != 0 || (c->est_active && c->est_void)) {
     // select_round_kernel: fewer keys at or above the pruning bound than it promised (or the bound went unverified)
     if (!c->est_active) {  // a CERTIFIED bound holds by construction: this would be a defect, not an input

@@ -396,7 +396,8 @@ void launch_cand_emit(const uint64_t* sel_ord, const uint32_t* sel_key, const ui
                       uint64_t want_requested, const CandBlob& b, hipStream_t st);
 // sums the gathered headers, arms `sel` for the merge select; host_out[0] <- T_eff (polled), host_out[1] <- triangles
 void launch_merge_prepare(const void* blobs, size_t blob_bytes, uint32_t world, uint32_t T, bool fast, const uint32_t* klb,
-                          SelectState* sel, uint64_t* host_out, hipStream_t st);
+                          SelectState* sel, uint64_t* host_out, hipStream_t st,
+                          uint64_t* host_short = nullptr);  // host_short (pinned): set when *klb is an ESTIMATED bound and fewer than T candidates came
 KeyView cand_view(const void* blobs, size_t blob_bytes, uint32_t world, size_t cap);
 // After the merge select: a rank whose list was cut sent everything above its local threshold key k_r; the merged
 // selection is exact iff the merged threshold k* lies strictly above k_r for every such rank (everything it did not send

@@ -141,6 +141,7 @@ struct sc_multi {
   int64_t npts = 0;
   sc_params params{};
   int cand_level = 0;  // sticky: raised whenever a call came back with SC_ERETRY (candidate blobs too small)
+  bool estimate = true;  // SC_FLAG_EST_BOUND (stage B pruned by an estimated bound, no histogram all-reduce); sticky off after SC_EBOUND
   float* R = nullptr; float* t = nullptr; uint8_t* mask = nullptr;
   // pinned, device-mapped staging (portable: every device reads h_in, rank 0's finalize kernel writes h_out)
   void* h_in = nullptr; size_t h_in_cap = 0;
@@ -238,6 +239,8 @@ int run_rank(sc_multi* M, int r) {
   sc_params p = M->params;
   p.shard_rank = r; p.shard_world = G;
   p.shard_cand_level = M->cand_level;
+  const bool est = M->estimate && G > 1;
+  if (est) p.flags |= SC_FLAG_EST_BOUND; else p.flags &= ~SC_FLAG_EST_BOUND;
   if (p.shard_block == 0) p.shard_block = 1024;
   int rc = SC_OK;
   bool aborted = false;
@@ -296,7 +299,8 @@ int run_rank(sc_multi* M, int r) {
   collective([&] { return rccl_allgather(M, r, rk.bits, plan.bits_bytes_per_rank); },
              [&](bool ok) { return loop_allgather(M, r, ok, [](Rank& q) { return q.bits; }, plan.bits_bytes_per_rank); });
   compute([&]() -> int { const int e = sc_shard_edges_device(rk.ctx, rk.hist); return e ? fail_from_ctx(e) : SC_OK; });
-  collective([&] { return rccl_allreduce_hist(M, r); }, [&](bool ok) { return loop_allreduce_hist(M, r, ok); });
+  if (!est)  // (SC_FLAG_EST_BOUND: every rank took the whole sample — one collective fewer; `est` is the same on every rank)
+    collective([&] { return rccl_allreduce_hist(M, r); }, [&](bool ok) { return loop_allreduce_hist(M, r, ok); });
   compute([&]() -> int {
     const int e = sc_shard_select_device(rk.ctx, rk.hist, static_cast<char*>(rk.cand) + (size_t)r * plan.cand_bytes_per_rank);
     return e ? fail_from_ctx(e) : SC_OK;
@@ -314,7 +318,7 @@ int run_rank(sc_multi* M, int r) {
   compute([&]() -> int {
     memset(&rk.stats, 0, sizeof rk.stats); rk.stats.size = sizeof rk.stats;
     fin = sc_finalize_gathered_device(rk.ctx, rk.keys, G, d_Rt, d_mask, &rk.stats);
-    if (fin == SC_ERETRY) { MHIP(rk, hipStreamSynchronize(rk.stream)); return SC_OK; }  // every rank alike: the caller re-runs
+    if (fin == SC_ERETRY || fin == SC_EBOUND) { MHIP(rk, hipStreamSynchronize(rk.stream)); return SC_OK; }  // every rank alike: the caller re-runs
     if (fin != SC_OK && fin != SC_ENOHYP) return fail_from_ctx(fin);
     if (r == 0 && !M->pinned_io) {  // rank 0 returns the outputs (every rank holds the same ones)
       float Rt[12];
@@ -480,8 +484,9 @@ int sc_register_multi(sc_multi* M, const float* src, const float* tgt, int64_t n
     run_job(M);
     // SC_ERETRY: a candidate blob was too small for this input.  Every rank sees the same blobs and reports it together;
     // bigger blobs from now on (sticky), and the call runs again.
-    bool retry = true;
-    for (int r = 0; r < M->n; r++) retry = retry && M->ranks[r].status == SC_ERETRY;
+    bool retry = true, bound = true;
+    for (int r = 0; r < M->n; r++) { retry = retry && M->ranks[r].status == SC_ERETRY; bound = bound && M->ranks[r].status == SC_EBOUND; }
+    if (bound && M->estimate && attempt < 16) { M->estimate = false; continue; }  // the estimated bound failed: certify from now on
     if (!retry || attempt >= 16) break;
     M->cand_level++;
   }

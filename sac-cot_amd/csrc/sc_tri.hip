@@ -2274,7 +2274,8 @@ __global__ __launch_bounds__(64) void merge_prepare_kernel(const uint64_t* __res
                                                            uint32_t world, uint32_t T, int fast,
                                                            const uint32_t* __restrict__ klb,
                                                            SelectState* __restrict__ sel,
-                                                           uint64_t* __restrict__ host_out) {
+                                                           uint64_t* __restrict__ host_out,
+                                                           uint64_t* __restrict__ host_short) {
   const uint32_t r = threadIdx.x;
   uint64_t m = 0, ns = 0;
   uint32_t kmin = 0xFFFFFFFFu, kmax = 0u;
@@ -2299,14 +2300,18 @@ __global__ __launch_bounds__(64) void merge_prepare_kernel(const uint64_t* __res
   } else {
     sel->kmin = kmin <= kmax ? kmin : 0u; sel->kmax = kmin <= kmax ? kmax : 0u; sel->started = 0;
   }
+  // SC_FLAG_EST_BOUND: the bound in *klb was an estimate.  A rank only ever sends keys at or above it (its select window's
+  // floor), so fewer than T entries in all means fewer than T triangles of the whole graph lie above it — unless it certified
+  // nothing (0: no pruning) — and the top-T of the pruned graph proves nothing about the full one (sc_tri.hip 3c)
+  if (host_short && *klb != 0u && ns < (uint64_t)T) publish_host(host_short, 1ull);
   host_out[1] = m;
   publish_host(host_out, want);
 }
 
 void launch_merge_prepare(const void* blobs, size_t blob_bytes, uint32_t world, uint32_t T, bool fast, const uint32_t* klb,
-                          SelectState* sel, uint64_t* host_out, hipStream_t st) {
+                          SelectState* sel, uint64_t* host_out, hipStream_t st, uint64_t* host_short) {
   hipLaunchKernelGGL(merge_prepare_kernel, dim3(1), dim3(64), 0, st, static_cast<const uint64_t*>(blobs),
-                     (uint64_t)(blob_bytes / 8), world, T, fast ? 1 : 0, klb, sel, host_out);
+                     (uint64_t)(blob_bytes / 8), world, T, fast ? 1 : 0, klb, sel, host_out, host_short);
 }
 
 KeyView cand_view(const void* blobs, size_t blob_bytes, uint32_t world, size_t cap) {

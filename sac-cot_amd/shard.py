@@ -129,8 +129,8 @@ def allgather_inplace(buf, rank: int, world: int):
 
 class ShardedStep:
     """One rank's buffers and phase sequence for the fully sharded path:
-         compat (row block) -> all-gather bit rows -> edges + sample share -> all-reduce histogram ->
-         own top-T -> all-gather candidate blobs -> merge + C1 + C2 -> all-gather key pairs -> finalize.
+         compat (row block) -> all-gather bit rows -> edges + sample [share -> all-reduce histogram: only without
+         SC_FLAG_EST_BOUND] -> own top-T -> all-gather candidate blobs -> merge + C1 + C2 -> all-gather key pairs -> finalize.
     Every collective is torch.distributed's on the context's stream (backend "nccl" = RCCL over xGMI; "gloo" in the
     CPU rehearsal).  With world == 1 no collective is issued."""
 
@@ -138,6 +138,10 @@ class ShardedStep:
         import torch
         self.pkg, self.reg, self.n, self.p, self.rank, self.world, self.device = pkg, reg, n, params, rank, world, device
         self.level = int(params.shard_cand_level)   # sticky: raised after SC_ERETRY (candidate blobs too small)
+        # SC_FLAG_EST_BOUND: stage B pruned by an ESTIMATED bound — every rank takes the whole (cheap) sample, so the histogram
+        # all-reduce is skipped: three collectives per step, not four.  Sticky off after SC_EBOUND (the estimate was too high
+        # for this kind of input: every rank gets that status together, the step is repeated with the certifying sample).
+        self.estimate = True
         plan = pkg.shard_plan(self._with_level(params), n)
         self.plan = plan
         self.bits = torch.zeros(plan.bits_bytes_total // 8, dtype=torch.int64, device=device)
@@ -150,12 +154,16 @@ class ShardedStep:
     def bytes_exchanged(self) -> dict:
         """Bytes this rank RECEIVES per step and collective (for pricing against the xGMI links)."""
         w = self.world
-        return {"bit_rows": (w - 1) * int(self.plan.bits_bytes_per_rank), "histogram": 1024 if w > 1 else 0,
+        return {"bit_rows": (w - 1) * int(self.plan.bits_bytes_per_rank), "histogram": 1024 if (w > 1 and not self.estimate) else 0,
                 "candidates": (w - 1) * int(self.plan.cand_bytes_per_rank), "key_pairs": 16 * (w - 1)}
 
     def _with_level(self, p):
         q = type(p).from_buffer_copy(p)
         q.shard_cand_level = self.level
+        if self.estimate and self.world > 1:
+            q.flags |= self.pkg.SC_FLAG_EST_BOUND
+        else:
+            q.flags &= ~self.pkg.SC_FLAG_EST_BOUND
         return q
 
     def step(self, d_src: int, d_tgt: int, params=None):
@@ -165,6 +173,9 @@ class ShardedStep:
         p = params or self.p
         for _ in range(20):
             rc, st = self._step_once(d_src, d_tgt, self._with_level(p))
+            if rc == self.pkg.SC_EBOUND:   # (every rank alike) the estimated bound failed: certify from now on
+                self.estimate = False
+                continue
             if rc != self.pkg.SC_ERETRY:
                 return rc, st
             self.level += 1
@@ -177,7 +188,8 @@ class ShardedStep:
         reg.shard_compat_device(d_src, d_tgt, self.n, p, self.bits.data_ptr())
         allgather_inplace(self.bits, r, w)
         reg.shard_edges_device(self.hist.data_ptr())
-        allreduce_hist(self.hist)
+        if not (p.flags & self.pkg.SC_FLAG_EST_BOUND):   # (with the flag every rank already holds the whole sample)
+            allreduce_hist(self.hist)
         reg.shard_select_device(self.hist.data_ptr(), self.cand.data_ptr() + r * int(self.plan.cand_bytes_per_rank))
         allgather_inplace(self.cand, r, w)
         reg.shard_score_device(self.cand.data_ptr(), self.keys.data_ptr() + 16 * r)

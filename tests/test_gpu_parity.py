@@ -708,10 +708,14 @@ def _run_sharded_ab_once(pkg, n, kw, d_src, d_tgt, world, flags=0, regs=None, bl
         for r in range(world):
             regs[r].shard_edges_device(d_hists[r].data_ptr())
         torch.cuda.synchronize()
-        total = sum(h.cpu().numpy().view(np.uint32).astype(np.uint64) for h in d_hists)
-        summed = torch.from_numpy((total & np.uint64(0xFFFFFFFF)).astype(np.uint32).view(np.int32)).to(dev)
-        for r in range(world):                                     # (all-reduce SUM of the sample histograms)
-            d_hists[r].copy_(summed)
+        if flags & pkg.SC_FLAG_EST_BOUND:                          # every rank took the whole sample: NO all-reduce, identical histograms
+            h0 = d_hists[0].cpu().numpy()
+            assert all(np.array_equal(h.cpu().numpy(), h0) for h in d_hists[1:])
+        else:
+            total = sum(h.cpu().numpy().view(np.uint32).astype(np.uint64) for h in d_hists)
+            summed = torch.from_numpy((total & np.uint64(0xFFFFFFFF)).astype(np.uint32).view(np.int32)).to(dev)
+            for r in range(world):                                 # (all-reduce SUM of the sample histograms)
+                d_hists[r].copy_(summed)
         torch.cuda.synchronize()
         for r in range(world):
             regs[r].shard_select_device(d_hists[r].data_ptr(), d_cand.data_ptr() + r * plan.cand_bytes_per_rank)
@@ -729,11 +733,11 @@ def _run_sharded_ab_once(pkg, n, kw, d_src, d_tgt, world, flags=0, regs=None, bl
             out.append((rc, st, d_Rt.cpu().numpy().copy(), d_mask.cpu().numpy().copy()))
         for o in out[1:]:                                          # every rank ends with the same answer
             assert o[0] == out[0][0]
-            if o[0] != pkg.SC_ERETRY:
+            if o[0] not in (pkg.SC_ERETRY, pkg.SC_EBOUND):
                 assert o[2].tobytes() == out[0][2].tobytes() and np.array_equal(o[3], out[0][3])
                 assert o[1]["best_rank"] == out[0][1]["best_rank"]
         rc, st, Rt, mask = out[0]
-        if rc != pkg.SC_ERETRY:
+        if rc not in (pkg.SC_ERETRY, pkg.SC_EBOUND):
             assert scored == st["tri_kept"]
         return rc, st, Rt, mask, hdr
     finally:
@@ -767,6 +771,41 @@ def test_sharded_A_and_B_equal_unsharded(pkg, O, reg, name, worlds):
         if world > 1 and name != "C0":
             share = hdr[:, 0].astype(np.float64) / hdr[:, 0].sum()
             assert share.max() < 2.5 / world, (world, share)        # equally heavy row ranges, roughly
+
+
+@pytest.mark.parametrize("name,worlds", [("C1", (2, 3, 8)), ("C2", (2, 8)), ("C4", (8,))])
+def test_sharded_with_an_estimated_bound_equals_unsharded(pkg, O, name, worlds):
+    """SC_FLAG_EST_BOUND: every rank takes the whole estimating sample (identical histograms, NO all-reduce: three collectives
+    per call), prunes by the estimated bound, and the merge verifies it.  Same winner, (R,t), mask and selection as the
+    oracle's; fewer triangles enumerated than with the certified bound.  Then the failure path: an estimate aimed at rank
+    T / 100 (sc_debug.est_margin_pct on every rank) must come back as SC_EBOUND from EVERY rank, and the same call without the
+    flag succeeds."""
+    import torch
+    cfg, scene = pkg.synth.make_config_scene(name)
+    kw = cfg.params()
+    ref = O.register(scene.src, scene.tgt, threads=8, **kw)
+    dev = torch.device("cuda:0")
+    d_src = torch.from_numpy(scene.src).to(dev); d_tgt = torch.from_numpy(scene.tgt).to(dev)
+    for world in worlds:
+        rc, st, Rt, mask, hdr = _run_sharded_ab(pkg, cfg.n, kw, d_src, d_tgt, world, flags=pkg.SC_FLAG_EST_BOUND)
+        assert rc == 0, world
+        assert (st["best_rank"], st["best_count"], st["tri_kept"]) == (ref["best_rank"], ref["best_count"], ref["t_eff"]), world
+        assert np.array_equal(mask, ref["mask"]) and Rt.tobytes() == np.concatenate([ref["R"].ravel(), ref["t"]]).astype(np.float32).tobytes()
+        rc2, st2, _, _, hdr2 = _run_sharded_ab(pkg, cfg.n, kw, d_src, d_tgt, world)
+        assert rc2 == 0 and int(hdr[:, 0].sum()) == st["tri_total"]
+        print(name, "world", world, "enumerated: estimated bound", st["tri_total"], "certified", st2["tri_total"])
+    world = worlds[0]
+    regs = [pkg.Registrar(0) for _ in range(world)]
+    try:
+        for g in regs:
+            g.set_debug(est_margin_pct=1)
+        out = _run_sharded_ab_once(pkg, cfg.n, dict(kw, shard_cand_level=0), d_src, d_tgt, world, flags=pkg.SC_FLAG_EST_BOUND, regs=regs)
+        assert out[0] == pkg.SC_EBOUND
+        out = _run_sharded_ab_once(pkg, cfg.n, dict(kw, shard_cand_level=0), d_src, d_tgt, world, regs=regs)
+        assert out[0] == 0 and out[1]["best_rank"] == ref["best_rank"] and np.array_equal(out[3], ref["mask"])
+    finally:
+        for g in regs:
+            g.close()
 
 
 @pytest.mark.parametrize("extra", [dict(rank_mode=1), dict(flags=4), dict(flags=32), dict(t_cmp=0.5), dict(max_triangles=10_000_000)])

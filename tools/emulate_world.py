@@ -29,6 +29,10 @@ ap.add_argument("--scaling", choices=("strong", "weak"), default="strong")
 ap.add_argument("--mode", choices=("shard_ab", "replicated"), default="shard_ab")
 ap.add_argument("--nodense", action="store_true")
 ap.add_argument("--iters", type=int, default=10)
+ap.add_argument("--certified", action="store_true",
+                help="shard_ab without SC_FLAG_EST_BOUND: certifying sample shared by the ranks + the 1 KiB histogram all-reduce "
+                     "(r03's form: four collectives per step instead of three)")
+ap.add_argument("--no-latency", action="store_true", help="skip the measurement of a collective's latency (below)")
 args = ap.parse_args()
 
 pkg = ge.load_package()
@@ -36,7 +40,33 @@ cfg, scene = pkg.synth.make_config_scene(args.config)
 dev = torch.device("cuda", 0)
 d_src = torch.from_numpy(scene.src).to(dev); d_tgt = torch.from_numpy(scene.tgt).to(dev)
 flags = pkg.SC_FLAG_NO_DENSE_S if args.nodense else 0
+est = 0 if args.certified else pkg.SC_FLAG_EST_BOUND
 K = args.iters
+
+# What ONE collective costs before any byte moves (VERDICT r03 #6c): RCCL on a ONE-rank communicator of this GPU — the enqueue,
+# RCCL's own kernel and its completion on the stream, no link involved — timed as the stream time K back-to-back calls add.
+# A real N-rank collective cannot be cheaper than this; the table adds (collectives per step) x this figure in a column of its
+# own.  The transfer itself is priced from the bytes (7 links x ~153 GB/s) in DESIGN.md, not here.
+coll_us = {}
+if not args.no_latency:
+    import torch.distributed as dist
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0)); port = sk.getsockname()[1]
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1)
+    small = torch.zeros(2, dtype=torch.int64, device=dev); big = torch.zeros(1 << 20, dtype=torch.int64, device=dev)
+    h = torch.zeros(256, dtype=torch.int32, device=dev)
+    def lat(fn, n=200):
+        for _ in range(20): fn()
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        for _ in range(n): fn()
+        torch.cuda.synchronize(); return (time.perf_counter() - t0) / n * 1e6
+    coll_us = {"all_gather 16 B": lat(lambda: dist.all_gather_into_tensor(small, small)),
+               "all_gather 8 MB": lat(lambda: dist.all_gather_into_tensor(big, big)),
+               "all_reduce 1 KiB": lat(lambda: dist.all_reduce(h))}
+    print("# one collective on a ONE-rank RCCL communicator of this GPU (enqueue + RCCL kernel, no link): " +
+          ", ".join(f"{k} {v:.1f} us" for k, v in coll_us.items()))
+    dist.destroy_process_group()
 print(f"# {args.config}: N={cfg.n} T={cfg.T} scaling={args.scaling} mode={args.mode} dense_S={not args.nodense}")
 base = None
 for world in args.worlds:
@@ -70,7 +100,7 @@ for world in args.worlds:
             g.set_stream(torch.cuda.current_stream().cuda_stream)
         level = 0
         while True:   # fill pass (repeated with bigger candidate blobs while the library answers SC_ERETRY)
-            ps = [pkg.make_params(shard_rank=r, shard_world=world, shard_block=block, flags=flags, shard_cand_level=level, **kw)
+            ps = [pkg.make_params(shard_rank=r, shard_world=world, shard_block=block, flags=flags | est, shard_cand_level=level, **kw)
                   for r in range(world)]
             plan = pkg.shard_plan(ps[0], cfg.n)
             d_bits = torch.zeros(plan.bits_bytes_total // 8, dtype=torch.int64, device=dev)
@@ -87,13 +117,17 @@ for world in args.worlds:
             summed = torch.from_numpy((sum(h.cpu().numpy().view(np.uint32).astype(np.uint64) for h in d_hist)
                                        & np.uint64(0xFFFFFFFF)).astype(np.uint32).view(np.int32)).to(dev)
             for r in range(world):
-                d_hist[r].copy_(summed)
+                if not est:
+                    d_hist[r].copy_(summed)
                 regs[r].shard_select_device(d_hist[r].data_ptr(), d_cand.data_ptr() + r * plan.cand_bytes_per_rank)
             for r in range(world):
                 regs[r].shard_score_device(d_cand.data_ptr(), d_keys.data_ptr() + 16 * r)
             rcs = [regs[r].finalize_gathered_device(d_keys.data_ptr(), world, d_Rt.data_ptr(), d_mask.data_ptr())[0]
                    for r in range(world)]
             torch.cuda.synchronize()
+            if est and all(rc == pkg.SC_EBOUND for rc in rcs):   # the estimate failed on this input: the certified form
+                est = 0
+                continue
             if all(rc != pkg.SC_ERETRY for rc in rcs):
                 break
             assert all(rc == pkg.SC_ERETRY for rc in rcs)
@@ -108,7 +142,8 @@ for world in args.worlds:
             g.shard_compat_device(d_src.data_ptr(), d_tgt.data_ptr(), cfg.n, ps[r], d_bits.data_ptr())
             d_bits_rx[:rx_bits].copy_(d_bits[:rx_bits])                                  # stand-in: all-gather of the bit rows
             g.shard_edges_device(d_hist[r].data_ptr())
-            d_hist[r].copy_(summed)                                                     # stand-in: 1 KiB all-reduce
+            if not est:
+                d_hist[r].copy_(summed)                                                 # stand-in: 1 KiB all-reduce
             g.shard_select_device(d_hist[r].data_ptr(), d_cand.data_ptr() + r * plan.cand_bytes_per_rank)
             for q in range(world):                                                      # stand-in: all-gather of the blobs
                 if q != r:                                                              # (header + entries sent)
@@ -125,13 +160,18 @@ for world in args.worlds:
                 rc, st = step(r)
             torch.cuda.synchronize(); times.append((time.perf_counter() - t0) / K)
         sent = hdr[:, 1].astype(np.int64)
-        coll = (f"bit rows {plan.bits_bytes_per_rank/1e6:.2f} MB/rank (rx {(world-1)*plan.bits_bytes_per_rank/1e6:.1f} MB), hist 1 KiB, "
+        coll = (f"{'estimated bound: 3 collectives' if est else 'certified bound: 4 collectives'}; bit rows {plan.bits_bytes_per_rank/1e6:.2f} MB/rank (rx {(world-1)*plan.bits_bytes_per_rank/1e6:.1f} MB), {'no histogram exchange' if est else 'hist 1 KiB'}, "
                 f"candidates sent {sent.min()}..{sent.max()} of cap {cap} at level {level} (x20 B; blob {plan.cand_bytes_per_rank/1e6:.2f} MB), key pairs 16 B; "
                 f"enumerated per rank {hdr[:,0].min()}..{hdr[:,0].max()}")
         for g in regs:
             g.close()
     tmax, tmean = max(times), sum(times) / len(times)
     base = base or tmax
+    ncoll = 0 if world == 1 else (1 if (args.mode == "replicated") else (3 if est else 4))
+    extra = ""
+    if coll_us and ncoll:
+        add = (coll_us["all_gather 16 B"] + ((coll_us["all_gather 8 MB"] * 2 + (0 if est else coll_us["all_reduce 1 KiB"])) if ncoll > 1 else 0)) * 1e-6
+        extra = f" | + {ncoll} collective latencies (measured, single-rank RCCL): {(tmax + add)*1e3:.3f} ms"
     print(f"world={world} T_total={T_total} per-rank step: max {tmax*1e3:.3f} ms mean {tmean*1e3:.3f} ms -> job {T_total/tmax/1e6:.1f} M hyp/s, "
           f"speed-up vs the first row {base/tmax:.2f}x | winner rank={st['best_rank']} inliers={st['best_count']} | {coll}"
-          f" | per rank ms: {' '.join(f'{t*1e3:.3f}' for t in times)}", flush=True)
+          f"{extra} | per rank ms: {' '.join(f'{t*1e3:.3f}' for t in times)}", flush=True)
