@@ -239,7 +239,9 @@ int run_rank(sc_multi* M, int r) {
   sc_params p = M->params;
   p.shard_rank = r; p.shard_world = G;
   p.shard_cand_level = M->cand_level;
-  const bool est = M->estimate && G > 1;
+  // (only on graphs below 8192 correspondences: beyond that a replicated sample costs more than the shared certifying one — measured
+  // by tools/emulate_world.py at C3, see sac-cot_amd/shard.py)
+  const bool est = M->estimate && G > 1 && n < 8192;
   if (est) p.flags |= SC_FLAG_EST_BOUND; else p.flags &= ~SC_FLAG_EST_BOUND;
   if (p.shard_block == 0) p.shard_block = 1024;
   int rc = SC_OK;

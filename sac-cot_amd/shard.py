@@ -141,7 +141,10 @@ class ShardedStep:
         # SC_FLAG_EST_BOUND: stage B pruned by an ESTIMATED bound — every rank takes the whole (cheap) sample, so the histogram
         # all-reduce is skipped: three collectives per step, not four.  Sticky off after SC_EBOUND (the estimate was too high
         # for this kind of input: every rank gets that status together, the step is repeated with the certifying sample).
-        self.estimate = True
+        # Only on graphs below 8192 correspondences: there the whole sample costs a rank ~14 us — less than the all-reduce it saves —
+        # and the tighter bound shrinks everything after it (emulated C2 weak / 8 ranks 0.34 -> 0.32 ms, C4 strong / 8 0.35 -> 0.31);
+        # at C3 (N = 20 000) the replicated sample costs more than a shared certifying one (0.69 vs 0.61 ms per rank-step at 8 ranks).
+        self.estimate = n < 8192
         plan = pkg.shard_plan(self._with_level(params), n)
         self.plan = plan
         self.bits = torch.zeros(plan.bits_bytes_total // 8, dtype=torch.int64, device=device)
