@@ -46,7 +46,7 @@ typedef struct sc_debug {
   uint32_t filter_blind;      /* 1: the host picks stage C2's kernel as if the coordinate maxima had not arrived yet (it then assumes the filter applies; the filter's own range test sends what it cannot bound to the exact recount) */
   uint32_t no_fast;           /* 1: sc_register_device always waits for stage B's two counts in the middle of the call (the form every other entry point uses) instead of enqueueing the whole chain of a repeated shape host-free */
   uint32_t gram_guard_fail;   /* 1: the run-time probe of the matrix pipe's accumulation model reports a violation (tests: the Gram filter must then never be chosen) */
-  uint32_t tail_unfused;      /* 1: the exact pass, the arg-max and the winner / mask kernel as three launches (r03's form) instead of one */
+  uint32_t tail_fused;        /* 1: sc_register / sc_register_device let the arg-max launch's last workgroup do the winner / mask step (C3, rank index, (R, t)) instead of a launch of its own.  Built, bit-exact, SLOWER (one workgroup's dependent load rounds: the arg-max launch 8.6 -> 33 us at C2 against 6.4 us for finalize_kernel): off by default */
   uint32_t no_estimate;       /* 1: stage B never prunes by an ESTIMATED bound (verified by the select, call repeated when it was too high) — always by a certifying sample, as every entry point other than sc_register / sc_register_device(_async) does anyway */
   uint32_t est_margin_pct;    /* the estimated bound aims at the key of rank (pct / 100) x T (0 = 200); a small value forces the failure-and-repeat path (tests) */
   uint32_t no_edge_build;     /* 1: row statistics, edge list and the estimating sample as three launches instead of the hot path's one (launch_edge_build) */

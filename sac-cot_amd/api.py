@@ -83,7 +83,7 @@ class ScDebug(C.Structure):
                 ("score_scalar", C.c_uint32), ("score_filter", C.c_uint32), ("filter_splits", C.c_uint32),
                 ("filter_queue_cap", C.c_uint32), ("filter_lds_queue", C.c_uint32), ("es_hist_unfused", C.c_uint32),
                 ("filter_variant", C.c_uint32), ("dense_async", C.c_uint32), ("filter_blind", C.c_uint32),
-                ("no_fast", C.c_uint32), ("gram_guard_fail", C.c_uint32), ("tail_unfused", C.c_uint32),
+                ("no_fast", C.c_uint32), ("gram_guard_fail", C.c_uint32), ("tail_fused", C.c_uint32),
                 ("no_estimate", C.c_uint32), ("est_margin_pct", C.c_uint32), ("no_edge_build", C.c_uint32),
                 ("build_sample", C.c_uint32), ("reserved", C.c_uint32 * 1), ("select_final", C.c_uint32),
                 ("pad_", C.c_uint32)]

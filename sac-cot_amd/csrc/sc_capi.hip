@@ -111,6 +111,10 @@ struct sc_ctx {
   int est_state = 0;         // last pass: 0 certified bound (or no pruning), 1 estimated and verified
   bool est_failed_call = false;  // the running / last call saw its estimate fail and was repeated (sc_debug_last: prune_bound 2)
   SamplePlan plan{false, 1u, 0};
+  // the winner / mask step inside the arg-max launch (sc_score.hip argmax_tail): the entry points that own the whole call
+  // (register_waited, sc_register_device_async) say where the outputs go before stage C is enqueued
+  float* tail_Rt = nullptr; uint8_t* tail_mask = nullptr;
+  bool tail_done = false;    // the running call's arg-max launch did the finalize step too
   bool build = false;        // the running call takes launch_edge_build (row statistics + edge list + estimating sample in one launch)
   // run-time probe of the matrix pipe's accumulation model (sc_score.hip gram_guard): 0 not run, 1 holds, 2 violated
   int gram_guard = 0;
@@ -937,7 +941,7 @@ int sc_set_debug(sc_ctx* c, const sc_debug* d) {
   t.filter_variant = d->filter_variant;
   t.no_fast = d->no_fast != 0;
   t.gram_guard_fail = d->gram_guard_fail != 0;
-  t.tail_unfused = d->tail_unfused != 0;
+  t.tail_fused = d->tail_fused != 0;
   t.no_estimate = d->no_estimate != 0;
   t.no_edge_build = d->no_edge_build != 0;
   t.build_sample = d->build_sample != 0;
@@ -980,6 +984,7 @@ int hyp_begin(sc_ctx* c, const float* d_src, const float* d_tgt, int64_t n, cons
   c->begun = false;
   c->timed_trikeys = false;
   c->regular = false;
+  c->tail_done = false;
   if (!c->est_allowed) c->est_failed_call = false;  // (an entry point that never estimates)
   if ((rc = set_timing(c, p))) return rc;
   c->refine = (p->flags & SC_FLAG_REFINE) != 0;
@@ -1134,10 +1139,13 @@ int run_stage_c(sc_ctx* c, uint64_t* d_key, sc_stats* stats) {
   if ((rc = run_score(c, p, sh, &score_rows, true, hot_ext ? c->ev[4] : nullptr, hot_ext ? c->ev[5] : nullptr))) return rc;
   if (!hot_ext && (rc = rec(c, 5))) return rc;
   ENSURE(c, c->amx_pairs, argmax_scratch_bytes(sh.ld_local));
+  c->tail_done = c->tail_mask != nullptr && c->tn.tail_fused && c->T_eff != 0 && argmax_tail_fits(c->n, c->T_eff, sh);
+  if (c->tail_done) arm_word(c, 8);
   launch_argmax(points_of(c), sh, c->partial.as<uint32_t>(), score_rows,
                 c->T_eff ? c->sel_key.as<uint32_t>() : nullptr,
                 c->cnt.as<uint32_t>(), c->amx_pairs.as<uint64_t>(), &c->ctl.as<ControlBlock>()->amx_ticket, d_key,
-                c->stream);
+                c->stream, c->tail_done ? c->rt.as<float>() : nullptr, c->dv.tau2, c->tail_done ? c->tail_Rt : nullptr,
+                c->tail_done ? c->tail_mask : nullptr, c->ctl.as<ControlBlock>()->key2, &c->pinned[8]);
   if ((rc = rec(c, 6))) return rc;
   HIPCHK(c, hipGetLastError());
   c->have_hyp = true;
@@ -1316,8 +1324,16 @@ constexpr int SC_ESPEC = -100;  // internal: a host-free call failed validation 
 int finalize_enqueue(sc_ctx* c, const uint64_t* d_keys, int n_pairs, float* d_Rt, uint8_t* d_mask) {
   int rc;
   if ((rc = rec(c, 7))) return rc;
-  arm_word(c, 8);
   ControlBlock* ctl = c->ctl.as<ControlBlock>();
+  if (c->tail_done) {  // the arg-max launch already did this step (run_stage_c); only the optional refit is left
+    c->pinned[11] = 0;
+    if (c->refine) {
+      ENSURE(c, c->refine_tmp, refine_scratch_bytes(c->n));
+      launch_refine(points_of(c), d_mask, ctl->key2, c->refine_tmp.as<double>(), d_Rt, c->stream);
+    }
+    return rec(c, 8);
+  }
+  arm_word(c, 8);
   launch_finalize(points_of(c), tri_source_of(c), c->sh, c->sh.n_local ? c->rt.as<float>() : nullptr,
                   c->T_eff ? c->sel_key.as<uint32_t>() : nullptr, c->T_eff, d_keys, n_pairs,
                   ctl->key2, c->dv.tau2, d_Rt, d_mask, &ctl->fin_rank, &ctl->fin_ticket, &c->pinned[8], c->stream);
@@ -1466,9 +1482,11 @@ int register_waited(sc_ctx* c, const float* d_src, const float* d_tgt, int64_t n
   int rc = SC_OK;
   for (int pass = 0; pass < 2; pass++) {
     c->est_allowed = true;
+    c->tail_Rt = d_Rt; c->tail_mask = d_mask;
     rc = hyp_begin(c, d_src, d_tgt, n, p, nullptr, 0, 1);
     if (!rc) rc = hyp_end(c, nullptr, c->key.as<uint64_t>(), stats);
     c->est_allowed = false;
+    c->tail_Rt = nullptr; c->tail_mask = nullptr;
     if (rc) return rc;
     HIPCHK(c, hipSetDevice(c->device));
     rc = finalize_enqueue(c, c->key.as<uint64_t>(), 1, d_Rt, d_mask);
@@ -1510,9 +1528,11 @@ int sc_register_device_async(sc_ctx* c, const float* d_src, const float* d_tgt, 
     // host-free: the whole chain is enqueued without looking at anything the GPU produces; sc_wait validates
     c->spec_on = true;
     c->est_allowed = true;  // (sc_wait repeats a call whose estimated pruning bound fails, like any other failed assumption)
+    c->tail_Rt = d_Rt; c->tail_mask = d_mask;
     rc = hyp_begin(c, d_src, d_tgt, n, p, nullptr, 0, 1);
     if (!rc) rc = hyp_end(c, nullptr, c->key.as<uint64_t>(), &c->pend_stats);
     c->est_allowed = false;
+    c->tail_Rt = nullptr; c->tail_mask = nullptr;
     if (!rc) rc = finalize_enqueue(c, c->key.as<uint64_t>(), 1, d_Rt, d_mask);
     if (rc) { c->spec_on = false; c->fast_ok = false; return rc; }  // (a launch or allocation failed: nothing is outstanding)
     c->pending = true; c->pend_done = false;

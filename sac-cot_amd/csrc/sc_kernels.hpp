@@ -53,7 +53,7 @@ struct Tuning {
   uint32_t filter_variant = 0;     // body of the filter kernel (sc_score.hip): 0 default, bit-identical scheduling variants, >= 16 timing-only ablations
   bool no_fast = false;            // sc_register_device never enqueues host-free (always waits for stage B's two counts)
   bool gram_guard_fail = false;    // the matrix-pipe probe reports a violation (tests of the guard)
-  bool tail_unfused = false;       // exact pass, arg-max and winner / mask as three launches (r03's form)
+  bool tail_fused = false;         // the register path's winner / mask step inside the arg-max launch (measured slower: off)
   bool filter_blind = false;       // the host decides C2's kernel WITHOUT the coordinate maxima (as if they had not arrived yet)
   bool compat_one_phase = false;   // exact chain on every pair of an interior tile
   int compat_rows = 0;             // tile height of stage A: 0 = by size (16 below 10 000 correspondences, 32 from there), 16, 32, 64
@@ -524,8 +524,14 @@ hipError_t filter_read_counters(const void* state, const FilterPlan& fp, hipStre
 // cnt (n_local u32): the per-hypothesis counts (the stage hook returns them).  pairs: argmax_scratch_bytes() of
 // per-block (key, position) pairs; ticket: a zeroed u32 in the control block (left zero).
 size_t argmax_scratch_bytes(uint32_t ld_local);
+// tail_* (all or none; argmax_tail_fits: unsharded, T <= 65536, n <= 32768, sel_key given): the workgroup that takes the last
+// ticket also does launch_finalize's work — winner (R, t) into tail_Rt12, mask, rank index, the pair into tail_key_out, and
+// tail_host_out (pinned, 4 x u64, [0] polled) — so no finalize launch follows.
+bool argmax_tail_fits(int n, uint32_t T, const Shard& sh);
 void launch_argmax(const Points& pts, const Shard& sh, const uint32_t* partial, uint32_t n_chunks, const uint32_t* sel_key,
-                   uint32_t* cnt, uint64_t* pairs, uint32_t* ticket, uint64_t* key2, hipStream_t st);
+                   uint32_t* cnt, uint64_t* pairs, uint32_t* ticket, uint64_t* key2, hipStream_t st,
+                   const float* tail_RtSoA = nullptr, float tau2 = 0.f, float* tail_Rt12 = nullptr, uint8_t* tail_mask = nullptr,
+                   uint64_t* tail_key_out = nullptr, uint64_t* tail_host_out = nullptr);
 // C3: winner decode + re-solve + mask.  Rt12 receives R (row-major) and t; identity / zero mask when key2[0] == 0.
 // sel_key / T: the ordinal-ordered ranking keys (for the winner's rank index); host_out (pinned, 3 x u64) receives
 // key2[0], the winner's position and its rank index.

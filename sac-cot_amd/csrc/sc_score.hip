@@ -493,12 +493,71 @@ __device__ __forceinline__ unsigned long long block_max_u64(unsigned long long k
 // the keys: every block reduces its hypotheses to (best key, lowest position attaining it) and stores the pair; the
 // block that takes the last ticket reduces the pairs and writes key2[0..1] (so key2 needs no zeroing).
 //   key = (count << 32) | second, second = sel_key[g] or, without sel_key, 0xFFFFFFFF - g;  position = 0xFFFFFFFF - g.
+// The winner's own work — C3 (mask), its rank index, (R, t) and the words the host polls for — by ONE workgroup: what
+// finalize_kernel does with a grid, for the unsharded path and selections short enough for a single workgroup's pass over
+// the keys (launch_argmax: the workgroup that takes the arg-max's last ticket goes straight on, no launch in between).
+// BUILT, BIT-EXACT, SLOWER, off by default (sc_debug.tail_fused): one workgroup walks 5000 correspondences and 50 000 keys in
+// ~70 dependent load rounds — the arg-max launch went from 8.6 to 33 us at C2, against 6.4 us for finalize_kernel's grid.
+struct ArgmaxTail {
+  const float* planes; int n, ld;
+  const float* RtSoA;       // the (R, t) planes of this launch's hypotheses (world 1: position g = local index g)
+  uint32_t T;               // entries of sel_key
+  float tau2;
+  float* Rt12; uint8_t* mask;
+  unsigned long long* key_out;   // ControlBlock::key2 (launch_refine reads it)
+  unsigned long long* host_out;  // pinned: [0] key (published last), [1] position, [2] rank index, [3] 0
+};
+__device__ void argmax_tail(const ArgmaxTail& t, const Shard& sh, const uint32_t* __restrict__ sel_key, unsigned long long K,
+                            unsigned long long P) {
+  __shared__ uint64_t lds[8];
+  __shared__ float sRt[12];
+  const uint32_t g = K ? 0xFFFFFFFFu - (uint32_t)(P & 0xFFFFFFFFull) : 0u;  // (a position this very launch produced: < T)
+  if (threadIdx.x < 12) {
+    const float v = K ? t.RtSoA[(size_t)threadIdx.x * sh.ld_local + g] : ((threadIdx.x % 4 == 0 && threadIdx.x < 9) ? 1.f : 0.f);
+    sRt[threadIdx.x] = v;
+    t.Rt12[threadIdx.x] = v;
+  }
+  uint32_t r = 0;
+  if (K) {
+    const uint32_t wk = sel_key[g];
+    const uint32_t T4 = t.T >> 2;
+    const uint4* __restrict__ k4 = reinterpret_cast<const uint4*>(sel_key);
+    for (uint32_t q = threadIdx.x; q < T4; q += 256) {
+      const uint4 v = k4[q];
+      const uint32_t p = q << 2;
+      r += (v.x > wk) || (v.x == wk && p < g);
+      r += (v.y > wk) || (v.y == wk && p + 1 < g);
+      r += (v.z > wk) || (v.z == wk && p + 2 < g);
+      r += (v.w > wk) || (v.w == wk && p + 3 < g);
+    }
+    const uint32_t p = (T4 << 2) + threadIdx.x;
+    if (p < t.T) { const uint32_t kt = sel_key[p]; r += (kt > wk) || (kt == wk && p < g); }
+  }
+  const uint64_t rank = block_reduce_u64(r, lds);  // (also the barrier that publishes sRt)
+  float M[12];
+#pragma unroll
+  for (int c = 0; c < 12; c++) M[c] = sRt[c];
+  const bool live = K != 0ull && finite12(M);
+  for (int m = threadIdx.x; m < t.n; m += 256) {
+    const float d2 = resid2(M, t.planes[m], t.planes[(size_t)t.ld + m], t.planes[2 * (size_t)t.ld + m], t.planes[3 * (size_t)t.ld + m],
+                            t.planes[4 * (size_t)t.ld + m], t.planes[5 * (size_t)t.ld + m]);
+    t.mask[m] = (live && d2 < t.tau2) ? 1 : 0;
+  }
+  if (threadIdx.x == 0) {
+    t.key_out[0] = K; t.key_out[1] = K ? P : 0ull;
+    t.host_out[3] = 0ull;
+    t.host_out[1] = g;
+    t.host_out[2] = K ? rank : 0ull;
+    publish_host(reinterpret_cast<uint64_t*>(t.host_out), K);  // [0] last: the host polls it
+  }
+}
+
 __global__ __launch_bounds__(256) void score_argmax_kernel(const uint32_t* __restrict__ partial, uint32_t n_chunks,
                                                            Shard sh, const uint32_t* __restrict__ sel_key,
                                                            uint32_t* __restrict__ cnt_out,
                                                            unsigned long long* __restrict__ pairs,
                                                            uint32_t* __restrict__ ticket,
-                                                           unsigned long long* __restrict__ key2) {
+                                                           unsigned long long* __restrict__ key2, ArgmaxTail tail) {
   __shared__ unsigned long long lds[4];
   __shared__ uint32_t s_last;
   // grid-stride over the hypotheses: at most 256 workgroups take a ticket (2000 same-address atomics cost ~20 us: C4)
@@ -541,6 +600,10 @@ __global__ __launch_bounds__(256) void score_argmax_kernel(const uint32_t* __res
     key2[0] = K;
     key2[1] = (K != 0 && sel_key) ? P : 0ull;
     __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // ready for the next launch
+  }
+  if (tail.mask) {  // (kernel-uniform) the winner's mask, rank index and (R, t) right here: no finalize launch follows
+    __syncthreads();
+    argmax_tail(tail, sh, sel_key, K, P);
   }
 }
 
@@ -1686,15 +1749,25 @@ void launch_score(const Points& pts, const float* RtSoA, const float* RtAoS, con
 
 size_t argmax_scratch_bytes(uint32_t ld_local) { return (size_t)(ld_local / 256 + 1) * 2 * sizeof(uint64_t); }
 
+bool argmax_tail_fits(int n, uint32_t T, const Shard& sh) {
+  return sh.world == 1 && sh.n_local != 0 && sh.n_local == T && T <= 65536u && n <= 32768;
+}
+
 void launch_argmax(const Points& pts, const Shard& sh, const uint32_t* partial, uint32_t n_chunks, const uint32_t* sel_key,
-                   uint32_t* cnt, uint64_t* pairs, uint32_t* ticket, uint64_t* key2, hipStream_t st) {
+                   uint32_t* cnt, uint64_t* pairs, uint32_t* ticket, uint64_t* key2, hipStream_t st, const float* tail_RtSoA,
+                   float tau2, float* tail_Rt12, uint8_t* tail_mask, uint64_t* tail_key_out, uint64_t* tail_host_out) {
   if (sh.n_local == 0) {  // nothing scored: the pair is (0, 0)
     (void)hipMemsetAsync(key2, 0, 2 * sizeof(uint64_t), st);
     return;
   }
+  ArgmaxTail tail{};
+  if (tail_mask) {
+    tail = ArgmaxTail{pts.planes, pts.n, pts.ld, tail_RtSoA, sh.T_eff, tau2, tail_Rt12, tail_mask,
+                      reinterpret_cast<unsigned long long*>(tail_key_out), reinterpret_cast<unsigned long long*>(tail_host_out)};
+  }
   const uint32_t blocks = sh.ld_local / 256 < 256 ? sh.ld_local / 256 : 256;
   hipLaunchKernelGGL(score_argmax_kernel, dim3(blocks), dim3(256), 0, st, partial, n_chunks, sh, sel_key, cnt,
-                     reinterpret_cast<unsigned long long*>(pairs), ticket, reinterpret_cast<unsigned long long*>(key2));
+                     reinterpret_cast<unsigned long long*>(pairs), ticket, reinterpret_cast<unsigned long long*>(key2), tail);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -169,3 +169,35 @@ def test_one_launch_select_equals_the_three_it_replaces(pkg, O, name):
     ref = O.register(src, tgt, threads=8, **kw)
     assert ra["status"] == ref["rc"] and np.array_equal(ra["mask"], ref["mask"])
     assert ra["stats"]["best_rank"] == ref["best_rank"] and ra["stats"]["tri_kept"] == ref["t_eff"]
+
+
+@pytest.mark.parametrize("name", ["C0", "C1", "C2", "nohyp"])
+def test_winner_step_inside_the_argmax_launch_equals_its_own_launch(pkg, O, name):
+    """sc_debug.tail_fused: the arg-max launch's last workgroup does the finalize step (C3 mask, rank index, (R, t), the host's
+    words) instead of finalize_kernel — built, measured slower (one workgroup's dependent load rounds), off by default.  Same outputs — also with the
+    fp64 refit behind it, with a truncated score, and when no hypothesis has an inlier (identity, zero mask, SC_ENOHYP)."""
+    if name == "nohyp":
+        rng = np.random.default_rng(3)
+        src = rng.uniform(-1, 1, (700, 3)).astype(np.float32); tgt = rng.uniform(-1, 1, (700, 3)).astype(np.float32)
+        kws = [dict(sigma=0.05, t_cmp=0.9, tau=1e-6, min_len=0.05, max_triangles=500, rank_mode=0)]
+    else:
+        cfg, scene = pkg.synth.make_config_scene(name)
+        src, tgt = scene.src, scene.tgt
+        kws = [cfg.params(), dict(cfg.params(), flags=pkg.SC_FLAG_REFINE), dict(cfg.params(), score_mode=1)]
+    a = pkg.Registrar(0); a.set_debug(tail_fused=1)
+    b = pkg.Registrar(0)
+    try:
+        for kw in kws:
+            for k in range(2):
+                ra = a.register(src, tgt, **kw); rb = b.register(src, tgt, **kw)
+                assert _same(ra, rb), (name, kw.get("flags"), kw.get("score_mode"), k)
+            if name == "nohyp":
+                assert ra["status"] == pkg.SC_ENOHYP and not ra["mask"].any() and np.array_equal(ra["R"], np.eye(3, dtype=np.float32))
+    finally:
+        a.close(); b.close()
+    if name != "nohyp":
+        ref = O.register(src, tgt, threads=8, **cfg.params())
+        got = pkg.Registrar(0)
+        r0 = got.register(src, tgt, **cfg.params()); got.close()
+        assert np.array_equal(r0["mask"], ref["mask"]) and r0["stats"]["best_rank"] == ref["best_rank"]
+        assert nan_equal_bits(np.concatenate([r0["R"].ravel(), r0["t"]]), np.concatenate([ref["R"].ravel(), ref["t"]]))
