@@ -947,6 +947,8 @@ int sc_set_debug(sc_ctx* c, const sc_debug* d) {
   t.build_sample = d->build_sample != 0;
   t.select_final = d->select_final != 0;
   t.compat_linear_order = d->pad_ != 0;
+  // development hook (a kernel under study returns after a phase: WRONG results) — lab builds only, like the filter ablations
+  if (d->reserved[0] != 0 && !filter_ablations_built()) { c->last_error = "sc_debug.reserved[0] (phase stop) needs a library built with -DSC_ABLATIONS"; return SC_EINVAL; }
   t.dbg_stop = d->reserved[0];
   t.est_margin_pct = d->est_margin_pct;
   c->tn = t;

@@ -998,7 +998,7 @@ __global__ __launch_bounds__(256) void tri_sample_words_kernel(const uint64_t* _
                                                                const float* __restrict__ es, uint64_t E, uint32_t rmask,
                                                                uint32_t* __restrict__ hist,
                                                                const uint64_t* __restrict__ E_dev,
-                                                               const uint32_t* __restrict__ ebase) {
+                                                               const uint32_t* __restrict__ ebase, int dbg_stop) {
   // ebase (with ebi == ebj == nullptr): the per-row CSR bases are looked up (after launch_edge_build)
   if (E_dev && *E_dev > E) return;  // (launched before the host knew the count: see tri_sample_hist_kernel)
   if (E_dev) E = *E_dev;
@@ -1012,12 +1012,14 @@ __global__ __launch_bounds__(256) void tri_sample_words_kernel(const uint64_t* _
     // the first word >= w0 in this edge's residue class (hashed by its END POINTS, as edge_build_kernel does: same sample)
     int w = w0 + (int)((edge_hash(i * 0x9E3779B1u + j) - (uint32_t)w0) & rmask);
     if (w >= W) continue;
+    if (dbg_stop == 1) { if (i == 0xFFFFFFFFu) lh[0] = j; continue; }
     const uint32_t rowi = i * (uint32_t)W, rowj = j * (uint32_t)W;
     for (; w < W; w += (int)rmask + 1) {
       const uint64_t ai = bits[rowi + w], aj = bits[rowj + w];
       uint64_t m = ai & aj;
       if (w == w0) m &= mask_above((int)(j & 63));
       if (m == 0) continue;
+      if (dbg_stop == 2) { atomicAdd(&lh[(uint32_t)__popcll(m) * PR_COPIES], 1u); continue; }
       // only the lanes that found a triangle pay for the edge's weight and CSR bases (one memory level, beside the prefix words)
       const float s_ij = es[e];
       const uint32_t bi = ebi ? ebi[e] : ebase[i], bj = ebj ? ebj[e] : ebase[j];
@@ -1446,7 +1448,7 @@ void launch_sample_estimate(const Graph& g, const uint32_t* ebi, const uint32_t*
   if (nb > 4096) nb = 4096;
   if (tn.sample_blocks) nb = tn.sample_blocks;
   hipLaunchKernelGGL(tri_sample_words_kernel, dim3((unsigned)nb), dim3(256), 0, st, g.bits, g.W, g.wpre, ebi, ebj, ei, ej, es, E,
-                     rate - 1u, hist, E_dev, ebase);
+                     rate - 1u, hist, E_dev, ebase, (int)tn.dbg_stop);
 }
 
 void launch_prune_bits(const Graph& g, const uint32_t* hist, bool hist_is_copies, const uint32_t* ei, const uint32_t* ej, const float* es,

@@ -1,4 +1,4 @@
-# bash tools/r4/stop.sh <kernel-regex> <config> stops...
+# bash tools/r4/stop.sh <kernel-regex> <config> stops...      (needs the lab build: python sac-cot_amd/build.py --ablations)
 FILT=$1; CFG=$2; shift 2
 R=${GRAFT_REPO_ROOT:-$(pwd)}; mkdir -p $R/gpurun_out; cd /tmp; export TMPDIR=/tmp
 for s in "$@"; do

@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
-"""Soak: one context, thousands of calls over alternating problem sizes and both phase-1 forms; every result must be
-byte-identical to the first one of its configuration (tickets, polled read-backs and speculative launches are exercised
-on buffers left over from other sizes).   python tools/soak.py [seconds]"""
+"""Soak: one context, thousands of calls over alternating problem sizes and three forms of the call — the two phase-1 forms of
+the phase API (certified pruning bound, host waits in the middle) and sc_register_device (r04: estimated bound, fused edge
+kernel, host-free enqueue of a repeated shape); every result must be byte-identical to the first one of its configuration
+(tickets, polled read-backs, speculative launches and the validate-and-repeat paths are exercised on buffers left over from
+other sizes).   python tools/soak.py [seconds]"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -19,6 +21,7 @@ for name, T in (("C0", 200), ("C1", 10000), ("C2", 50000), ("C1", 3000), ("C2", 
     kw = cfg.params(); kw["max_triangles"] = T
     cases.append((f"{name}/T={T}", cfg.n, kw, torch.from_numpy(sc.src).to(dev), torch.from_numpy(sc.tgt).to(dev)))
 first = {}
+forms = [0, 0, 0]   # sc_register_device calls by sc_debug_last.fast_path: waited / host-free / host-free then repeated
 calls = mism = 0
 t0 = time.time()
 rng = np.random.default_rng(0)
@@ -29,25 +32,32 @@ with torch.cuda.stream(stream):
     d_Rt = torch.zeros(12, dtype=torch.float32, device=dev)
     while time.time() - t0 < budget:
         name, n, kw, s, t = cases[int(rng.integers(len(cases)))]
-        split = bool(rng.integers(2))
+        form = int(rng.integers(3))
+        split = form == 1
         p = pkg.make_params(**kw)
         d_mask = torch.zeros(n, dtype=torch.uint8, device=dev)
-        if split:
-            reg.hypothesize_begin_device(s.data_ptr(), t.data_ptr(), n, p, d_hist.data_ptr())
-            reg.hypothesize_end_device(d_hist.data_ptr(), d_key.data_ptr())
+        if form == 2:
+            rc, st = reg.register_device(s.data_ptr(), t.data_ptr(), n, p, d_Rt.data_ptr(), d_mask.data_ptr())
+            forms[reg.debug_last()["fast_path"]] += 1
         else:
-            reg.hypothesize_device(s.data_ptr(), t.data_ptr(), n, p, d_key.data_ptr())
-        rc, st = reg.finalize_device(d_key.data_ptr(), d_Rt.data_ptr(), d_mask.data_ptr())
+            if split:
+                reg.hypothesize_begin_device(s.data_ptr(), t.data_ptr(), n, p, d_hist.data_ptr())
+                reg.hypothesize_end_device(d_hist.data_ptr(), d_key.data_ptr())
+            else:
+                reg.hypothesize_device(s.data_ptr(), t.data_ptr(), n, p, d_key.data_ptr())
+            rc, st = reg.finalize_device(d_key.data_ptr(), d_Rt.data_ptr(), d_mask.data_ptr())
         stream.synchronize()
-        sig = (rc, st["edges"], st["tri_total"], st["tri_kept"], st["best_rank"], st["best_count"],
-               d_Rt.cpu().numpy().tobytes(), d_mask.cpu().numpy().tobytes(), tuple(int(x) for x in d_key.cpu()))
+        # (tri_total — the triangles ENUMERATED — depends on the pruning bound, certified or estimated: not part of the result)
+        sig = (rc, st["edges"], st["tri_kept"], st["best_rank"], st["best_count"],
+               d_Rt.cpu().numpy().tobytes(), d_mask.cpu().numpy().tobytes())
         if name not in first:
             first[name] = sig
         elif first[name] != sig:
             mism += 1
-            print("MISMATCH", name, "split" if split else "plain", sig[:6], "vs", first[name][:6], flush=True)
+            print("MISMATCH", name, ("plain", "split", "register")[form], sig[:5], "vs", first[name][:5], flush=True)
         calls += 1
         if calls % 2000 == 0:
             print(f"{calls} calls, {mism} mismatches, {time.time() - t0:.0f} s", flush=True)
-print(f"soak: {calls} calls over {len(first)} configurations in {time.time() - t0:.0f} s, {mism} mismatches")
+print(f"soak: {calls} calls over {len(first)} configurations in {time.time() - t0:.0f} s, {mism} mismatches; "
+      f"sc_register_device calls: {forms[0]} waited, {forms[1]} host-free, {forms[2]} host-free and repeated")
 sys.exit(1 if mism else 0)
