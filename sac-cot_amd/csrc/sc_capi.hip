@@ -526,7 +526,8 @@ int run_edges(sc_ctx* c, const sc_params* p, uint32_t* hist, uint32_t part, uint
     // would sum the ranks' shares — and the merge of the candidates verifies the bound: sc_shard_score_device)
     const bool est_local = c->est_allowed && !c->est_failed && hist == nullptr && parts == 1 && !c->sharded_ab;
     const bool est_shard = c->sharded_ab && hist != nullptr && (p->flags & SC_FLAG_EST_BOUND) != 0;
-    c->plan = sample_plan(p->max_triangles, (est_local || est_shard) && c->use_events && window_known, c->tn);
+    c->plan = sample_plan(p->max_triangles, (est_local || est_shard) && c->use_events && window_known, c->tn,
+                          (build && c->tn.build_sample) ? 0 : (spec ? c->E_last : E), g.W);  // (a sample taken by the edge kernel was taken before E was known)
     c->est_active = c->plan.estimate;
     if (build && !c->plan.estimate) { c->last_error = "internal: the fused edge kernel ran but the bound is not an estimate"; return SC_EHIP; }
     if (build && c->tn.build_sample) {

@@ -180,7 +180,7 @@ bool scan_writes_ebase(size_t n);
 void launch_edge_fill(const Graph& g, const Points& pts, const Derived& dv, const uint64_t* edge_off, uint32_t* ei,
                       uint32_t* ej, float* es, uint32_t* ebase, bool ebase_ready, uint32_t* ebi, uint32_t* ebj,
                       uint64_t cap, uint32_t* es_hist, hipStream_t st);  // es_hist: see launch_sample_hist (optional)
-// The hot path's form (r04; n <= 8192, weight ranking, estimated pruning bound): row statistics (wpre), CSR offsets and
+// The hot path's form (r04; n <= 20 480, weight ranking, estimated pruning bound): row statistics (wpre), CSR offsets and
 // bases from g.degp — which launch_compat accumulated —, the strong-bit rows cleared, the edge list (ei / ej / es; NO ebi /
 // ebj: launch_tri_count_events looks the bases up) and the estimating sample's histogram (PR_HCOPIES x 256 words, zeroed),
 // in one launch.  host_total (pinned) receives the edge count, which also lands in edge_off[n].
@@ -232,7 +232,7 @@ struct SamplePlan {
   uint32_t rate;       // power of two
   uint64_t hist_want;  // what launch_prune_bits looks for in the histogram
 };
-SamplePlan sample_plan(uint64_t want, bool allow_estimate, const Tuning& tn);
+SamplePlan sample_plan(uint64_t want, bool allow_estimate, const Tuning& tn, uint64_t E = 0, int W = 0);  // E, W: the graph (0: not known: rate <= 64)
 void launch_sample_estimate(const Graph& g, const uint32_t* ebi, const uint32_t* ebj, const uint32_t* ei, const uint32_t* ej,
                             const float* es, uint64_t E, float key_floor, uint32_t rate, uint32_t* hist, const Tuning& tn,
                             hipStream_t st, const uint64_t* E_dev = nullptr, const uint32_t* ebase = nullptr);  // ebase: with ebi == ebj == nullptr

@@ -1071,10 +1071,11 @@ __global__ __launch_bounds__(256) void tri_sample_words_kernel(const uint64_t* _
 // ------------------------------------------------------------------------------------------------
 constexpr int EBK_ROWS = 8;     // rows (waves) per workgroup
 constexpr int EBK_CH = 256;     // column indices staged per wave and chunk
-constexpr int EBK_WMAX = 128;   // words per bit row (n <= 8192)
+constexpr int EBK_WMAX = 320;   // words per bit row it can handle (n <= 20 480): NCH = 2 chunks of 64 words up to 8192, 5 beyond
 constexpr int EBK_Q = 128;      // sampled triangles queued per wave (drained at 64)
 constexpr int EBK_HC = 4;       // LDS copies of the key histogram
 
+template <int NCH>  // 64-word chunks of a bit row: W <= 64 NCH
 __global__ __launch_bounds__(64 * EBK_ROWS) void edge_build_kernel(const uint64_t* __restrict__ bits,
                                                                    const float* __restrict__ planes, Derived dv, int n,
                                                                    int ld, int W, const uint32_t* __restrict__ degp,
@@ -1088,7 +1089,7 @@ __global__ __launch_bounds__(64 * EBK_ROWS) void edge_build_kernel(const uint64_
                                                                    uint32_t* __restrict__ hist) {
   __shared__ uint64_t s_red[EBK_ROWS];
   __shared__ uint32_t l_j[EBK_ROWS][EBK_CH];
-  __shared__ uint64_t l_row[EBK_ROWS][EBK_WMAX];
+  __shared__ uint64_t l_row[EBK_ROWS][64 * NCH];
   __shared__ uint32_t q_j[EBK_ROWS][EBK_Q], q_k[EBK_ROWS][EBK_Q];
   __shared__ float q_s[EBK_ROWS][EBK_Q];
   __shared__ uint32_t lh[PR_BINS * EBK_HC];
@@ -1117,9 +1118,9 @@ __global__ __launch_bounds__(64 * EBK_ROWS) void edge_build_kernel(const uint64_
     uint64_t* const myrow = l_row[wave];
     // ---- the row's words: prefix popcounts, the strong row cleared, the words kept for the sample
     uint32_t d_all = 0, d_low = 0;
-    uint64_t up[EBK_WMAX / 64];
+    uint64_t up[NCH];
 #pragma unroll
-    for (int c = 0; c < EBK_WMAX / 64; c++) {
+    for (int c = 0; c < NCH; c++) {
       const int w = 64 * c + lane;
       const uint64_t v = w < W ? bits[(size_t)i * W + w] : 0ull;
       myrow[w] = v;
@@ -1155,8 +1156,8 @@ __global__ __launch_bounds__(64 * EBK_ROWS) void edge_build_kernel(const uint64_
       atomicAdd(&lh[est_bin(__float_as_uint((s_ij + s_ik) + s_jk)) * EBK_HC + (lane & (EBK_HC - 1))], 1u);
     };
     uint64_t ebase_row = my_off;
-#pragma unroll 1
-    for (int c = 0; c < EBK_WMAX / 64; c++) {
+#pragma unroll
+    for (int c = 0; c < NCH; c++) {
       const int w = 64 * c + lane;
       const uint64_t v = up[c];
       uint32_t tot;
@@ -1241,9 +1242,13 @@ bool edge_build_fits(int n) { return n <= 64 * EBK_WMAX; }
 void launch_edge_build(const Graph& g, const Points& pts, const Derived& dv, uint64_t* zero_rows, uint64_t* edge_off, uint32_t* ebase,
                        uint32_t* ei, uint32_t* ej, float* es, uint64_t cap, uint64_t* host_total, uint32_t rate, uint32_t* hist,
                        hipStream_t st) {
-  hipLaunchKernelGGL(edge_build_kernel, dim3((g.n + EBK_ROWS - 1) / EBK_ROWS), dim3(64 * EBK_ROWS), 0, st, g.bits, pts.planes, dv,
-                     g.n, g.ld, g.W, g.degp, const_cast<uint32_t*>(g.wpre), zero_rows, edge_off, ebase, ei, ej, es, cap, host_total,
-                     rate - 1u, hist);
+  const dim3 grid((g.n + EBK_ROWS - 1) / EBK_ROWS), block(64 * EBK_ROWS);
+  if (g.W <= 128)
+    hipLaunchKernelGGL(edge_build_kernel<2>, grid, block, 0, st, g.bits, pts.planes, dv, g.n, g.ld, g.W, g.degp,
+                       const_cast<uint32_t*>(g.wpre), zero_rows, edge_off, ebase, ei, ej, es, cap, host_total, rate - 1u, hist);
+  else
+    hipLaunchKernelGGL(edge_build_kernel<5>, grid, block, 0, st, g.bits, pts.planes, dv, g.n, g.ld, g.W, g.degp,
+                       const_cast<uint32_t*>(g.wpre), zero_rows, edge_off, ebase, ei, ej, es, cap, host_total, rate - 1u, hist);
 }
 
 // sum of the copies -> one 256-bin histogram (the form the ranks exchange)
@@ -1415,13 +1420,16 @@ void launch_sample_hist(const Graph& g, const uint32_t* ebi, const uint32_t* ebj
 #undef SC_LAUNCH_SAMPLE
 }
 
-SamplePlan sample_plan(uint64_t want, bool allow_estimate, const Tuning& tn) {
+SamplePlan sample_plan(uint64_t want, bool allow_estimate, const Tuning& tn, uint64_t E, int W) {
   SamplePlan sp{false, 1u, want};
   if (!allow_estimate || tn.no_estimate || tn.sample_mode != 0 || want == 0) return sp;
   // rate: 64 while 2 T still leaves >= 1024 expected samples above the bound, halved below that, never under 8 (a whole-graph
   // enumeration is what the pruning is there to avoid)
   uint32_t rate = 64;
   while (rate > 8 && 2 * want / rate < 1024) rate >>= 1;
+  // ... and beyond 64 on big graphs: the sample looks at E x (row words) / rate word pairs — 16 M random 8-byte gathers at C3
+  // (N = 20 000, rate 64: 156 us) for 6000 samples above the bound where 1500 do (rate 256: 45 us)
+  while (rate < 512 && 2 * want / (2 * rate) >= 1024 && (double)E * (double)(W > 0 ? W : 1) / 2.0 / rate > 2.0e6) rate <<= 1;  // (an edge has ~W / 2 words beyond its higher end)
   // the rank the bound aims at, in % of T: T plus eight standard deviations of the sampled count at rank T — a sampled word
   // brings its triangles together, ~8 at a time — within [115, 200] (C2 181, C3 140, C4 126)
   uint64_t margin = tn.est_margin_pct;
