@@ -1431,7 +1431,7 @@ SamplePlan sample_plan(uint64_t want, bool allow_estimate, const Tuning& tn, uin
   // (N = 20 000, rate 64: 156 us) for 6000 samples above the bound where 1500 do (rate 256: 45 us)
   while (rate < 512 && 2 * want / (2 * rate) >= 1024 && (double)E * (double)(W > 0 ? W : 1) / 2.0 / rate > 2.0e6) rate <<= 1;  // (an edge has ~W / 2 words beyond its higher end)
   // the rank the bound aims at, in % of T: T plus eight standard deviations of the sampled count at rank T — a sampled word
-  // brings its triangles together, ~8 at a time — within [115, 200] (C2 181, C3 140, C4 126)
+  // brings its triangles together, ~8 at a time — within [115, 200] (C2 181, C3 181 at its rate of 256, C4 126)
   uint64_t margin = tn.est_margin_pct;
   if (!margin) {
     const double at_T = (double)want / rate;

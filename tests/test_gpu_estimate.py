@@ -201,3 +201,22 @@ def test_winner_step_inside_the_argmax_launch_equals_its_own_launch(pkg, O, name
         r0 = got.register(src, tgt, **cfg.params()); got.close()
         assert np.array_equal(r0["mask"], ref["mask"]) and r0["stats"]["best_rank"] == ref["best_rank"]
         assert nan_equal_bits(np.concatenate([r0["R"].ravel(), r0["t"]]), np.concatenate([ref["R"].ravel(), ref["t"]]))
+
+
+@pytest.mark.parametrize("n,rho,L,tau,T", [(8200, 0.12, 3.0, 0.1, 30000), (10007, 0.10, 8.0, 0.2, 60000), (12345, 0.08, 20.0, 0.5, 5000)])
+def test_fused_edge_kernel_on_rows_beyond_128_words(pkg, O, n, rho, L, tau, T):
+    """edge_build_kernel<5> (bit rows of 129 .. 320 words; C3 is the only BASELINE shape there): ragged sizes, against the
+    separate launches and the oracle."""
+    sc = pkg.synth.make_scene(n, rho, L, tau, 4242 + n)
+    kw = dict(sigma=tau, t_cmp=0.9, tau=tau, min_len=tau, max_triangles=T, rank_mode=0)
+    a = pkg.Registrar(0)
+    b = pkg.Registrar(0); b.set_debug(no_edge_build=1)
+    try:
+        ra = a.register(sc.src, sc.tgt, **kw); rb = b.register(sc.src, sc.tgt, **kw)
+        ra2 = a.register(sc.src, sc.tgt, **kw)
+        assert _same(ra, rb) and _same(ra2, rb) and ra["stats"]["tri_total"] == rb["stats"]["tri_total"]
+    finally:
+        a.close(); b.close()
+    ref = O.register(sc.src, sc.tgt, threads=8, **kw)
+    assert ra["status"] == ref["rc"] and np.array_equal(ra["mask"], ref["mask"]) and ra["stats"]["edges"] == ref["edges"]
+    assert ra["stats"]["best_rank"] == ref["best_rank"] and ra["stats"]["tri_kept"] == ref["t_eff"]
