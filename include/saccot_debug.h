@@ -42,7 +42,7 @@ typedef struct sc_debug {
   uint32_t filter_lds_queue;  /* entries of a wave's own queue, 64 .. 256 (0 = 256)                                   */
   uint32_t es_hist_unfused;   /* 1: stage B's edge-weight histogram by a launch of its own instead of inside edge_fill  */
   uint32_t filter_variant;    /* body of the filter kernel: 0 = default, 1 .. 3 = bit-identical scheduling variants; the timing-only ablations (>= 16, wrong counts) only in a -DSC_ABLATIONS build (SC_EINVAL otherwise) */
-  uint32_t dense_async;       /* (removed in 0.5: ignored) */
+  uint32_t dense_async;       /* (the r02 / r03 knob of this name is gone) now gram_pers: 1 = the Gram filter's persistent form — ONE generation of workgroups, each walking a contiguous run of (hypothesis group, 256-correspondence unit) items, counts accumulated by atomics, recounts per unit — instead of the grid of hypothesis groups x window splits.  Built, bit-exact, measured 3 - 4 % slower: off by default */
   uint32_t filter_blind;      /* 1: the host picks stage C2's kernel as if the coordinate maxima had not arrived yet (it then assumes the filter applies; the filter's own range test sends what it cannot bound to the exact recount) */
   uint32_t no_fast;           /* 1: sc_register_device always waits for stage B's two counts in the middle of the call (the form every other entry point uses) instead of enqueueing the whole chain of a repeated shape host-free */
   uint32_t gram_guard_fail;   /* 1: the run-time probe of the matrix pipe's accumulation model reports a violation (tests: the Gram filter must then never be chosen) */

@@ -940,6 +940,7 @@ int sc_set_debug(sc_ctx* c, const sc_debug* d) {
   t.filter_lds_queue = d->filter_lds_queue;
   t.filter_blind = d->filter_blind != 0;
   t.filter_variant = d->filter_variant;
+  t.gram_pers = d->dense_async != 0;  // (the slot of the removed dense_async knob)
   t.no_fast = d->no_fast != 0;
   t.gram_guard_fail = d->gram_guard_fail != 0;
   t.tail_fused = d->tail_fused != 0;
@@ -1066,7 +1067,9 @@ int filter_job(sc_ctx* c, const Shard& sh, FilterTileJob* job) {
   ENSURE(c, c->fx_state, fp.state_bytes);
   if (fp.coef_bytes) ENSURE(c, c->fx_coef, fp.coef_bytes);
   uint32_t* mx = c->fx_mx.as<uint32_t>();
-  *job = filter_tile_job(fp, mx, nullptr, c->fx_tile.p, c->fx_state.p, c->fx_coef.p, sh.ld_local, c->dv.tau2);
+  if (fp.units) ENSURE(c, c->partial, (size_t)fp.splits * sh.ld_local * 4);  // (the persistent Gram form's count row: cleared by the job)
+  *job = filter_tile_job(fp, mx, nullptr, c->fx_tile.p, c->fx_state.p, c->fx_coef.p, sh.ld_local, c->dv.tau2,
+                         fp.units ? c->partial.as<uint32_t>() : nullptr);
   return SC_OK;
 }
 

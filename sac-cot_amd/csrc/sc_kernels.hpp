@@ -51,6 +51,7 @@ struct Tuning {
   uint32_t filter_queue_cap = 0;   // entries of the filter's global queue (0: by size; tests force overflows with a small one)
   uint32_t filter_lds_queue = 0;   // entries of a wave's LDS queue, 64 .. 256 (0: 256)
   uint32_t filter_variant = 0;     // body of the filter kernel (sc_score.hip): 0 default, bit-identical scheduling variants, >= 16 timing-only ablations
+  bool gram_pers = false;          // the Gram filter's persistent one-generation form (score_gram_pers_kernel): built, bit-exact, 3 - 4 % SLOWER than the grid of hypothesis groups x window splits: off
   bool no_fast = false;            // sc_register_device never enqueues host-free (always waits for stage B's two counts)
   bool gram_guard_fail = false;    // the matrix-pipe probe reports a violation (tests of the guard)
   bool tail_fused = false;         // the register path's winner / mask step inside the arg-max launch (measured slower: off)
@@ -478,6 +479,10 @@ void launch_score(const Points& pts, const float* RtSoA, const float* RtAoS, con
 struct FilterPlan {
   uint32_t mode;  // 1 linear, 2 Gram
   uint32_t windows, splits, n_waves, rows, queue_cap;
+  // Gram filter, persistent form (r04; sc_debug gram_pers, NOT the default — measured slower): the launch is ONE generation of workgroups, each walking a contiguous run
+  // of (hypothesis group, 256-correspondence unit) items; counts are accumulated into ONE row (splits == 1) by atomics and the
+  // exact pass's wholesale recounts are per (8 hypotheses, unit): bm_rows == units.  0: the split form (bm_rows == splits).
+  uint32_t units, bm_rows;
   size_t tile_bytes, state_bytes, coef_bytes;  // coef_bytes: the Gram filter's per-hypothesis coefficients (0 for the linear one)
 };
 // Gram filter: what its waves load instead of computing it (made once per call: launch_kabsch's threads, or launch_gram_coef)
@@ -497,9 +502,11 @@ FilterPlan filter_plan(int n, uint32_t ld_local, const Tuning& tn, uint32_t mode
 struct FilterTileJob {  // what the tile kernel needs (filter_tile_job fills it)
   uint32_t rows; const uint32_t* mx_cur; uint32_t* mx_next; void* tile; void* info; uint32_t* zero; uint32_t zero_words; uint32_t mode;
   GramCoef coef; float tau2;  // mode 2: the Kabsch threads of the same launch also write their hypotheses' coefficients
+  uint32_t* zero2; uint32_t zero2_words;  // a second buffer cleared on the way (the persistent Gram filter's count row: it ADDS)
 };
+// partial (optional): the count row of the persistent Gram form (ld_local words), cleared by the tile job
 FilterTileJob filter_tile_job(const FilterPlan& fp, const uint32_t* mx_cur, uint32_t* mx_next, void* tile, void* state,
-                              void* coef, uint32_t ld_local, float tau2);
+                              void* coef, uint32_t ld_local, float tau2, uint32_t* partial = nullptr);
 // the coefficients on their own (stage hook sc_score_host, which has no Kabsch launch)
 void launch_gram_coef(const float* RtSoA, const Shard& sh, float tau2, const uint32_t* mx, const GramCoef& coef, hipStream_t st);
 void launch_filter_tile(const Points& pts, const FilterTileJob& job, hipStream_t st);  // on its own (stage hook sc_score_host)

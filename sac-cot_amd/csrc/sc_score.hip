@@ -663,7 +663,7 @@ static FilterState filter_state(void* state, const FilterPlan& fp) {
   f.info = reinterpret_cast<FilterInfo*>(p); p += 128;
   f.qcount = reinterpret_cast<uint32_t*>(p); p += (size_t)FX_NQ * 128;
   f.redo = reinterpret_cast<uint32_t*>(p);
-  const size_t bm_words = ((size_t)fp.splits * fp.n_waves + 31) / 32;
+  const size_t bm_words = ((size_t)fp.bm_rows * fp.n_waves + 31) / 32;
   p += (bm_words * 4 + 127) / 128 * 128;
   f.queue = reinterpret_cast<uint2*>(p);
   f.cap_sq = fp.queue_cap / FX_NQ;
@@ -740,6 +740,12 @@ FilterPlan filter_plan(int n, uint32_t ld_local, const Tuning& tn, uint32_t mode
     const uint32_t per = (fp.windows + fp.splits - 1) / fp.splits;
     fp.splits = (fp.windows + per - 1) / per;
   }
+  fp.units = 0; fp.bm_rows = fp.splits;
+  if (mode == 2 && tn.gram_pers && !tn.filter_splits) {  // the persistent form (see score_gram_pers_kernel)
+    fp.units = fp.windows * (FX_WIN / GX_UNIT);
+    fp.splits = 1;
+    fp.bm_rows = fp.units;
+  }
   fp.rows = fp.windows * FX_WIN + (mode == 2 ? GX_UNIT : FX_UNIT);
   uint64_t cap = (uint64_t)ld_local * (uint64_t)n / 512;  // ~20x what the BASELINE scenes queue
   if (cap < (1u << 16)) cap = 1u << 16;
@@ -748,7 +754,7 @@ FilterPlan filter_plan(int n, uint32_t ld_local, const Tuning& tn, uint32_t mode
   fp.queue_cap = (uint32_t)(cap / FX_NQ * FX_NQ);
   if (fp.queue_cap < FX_NQ) fp.queue_cap = FX_NQ;
   fp.tile_bytes = (size_t)fp.rows * (mode == 2 ? GX_TILE_B : 32);
-  const size_t bm_words = ((size_t)fp.splits * fp.n_waves + 31) / 32;
+  const size_t bm_words = ((size_t)fp.bm_rows * fp.n_waves + 31) / 32;
   fp.state_bytes = 128 + (size_t)FX_NQ * 128 + (bm_words * 4 + 127) / 128 * 128 + (size_t)fp.queue_cap * 8;
   fp.coef_bytes = mode == 2 ? (size_t)ld_local * 64 + (size_t)ld_local * 4 + (size_t)(ld_local / 32) * 8 : 0;
   return fp;
@@ -1037,7 +1043,8 @@ __global__ __launch_bounds__(256) void score_exact_kernel(const float* __restric
   for (uint32_t i = (blockIdx.x / FX_NQ) * 256 + threadIdx.x; i < nq; i += (gridDim.x / FX_NQ) * 256) {
     const uint2 e = gq[(size_t)sq * cap_sq + i];
     if (gram) {  // Gram filter: {correspondence, wave of 32 << 17 | lane half << 16 | one bit per accumulator register}
-      const uint32_t m = e.x, w32 = e.y >> 17, ehf = (e.y >> 16) & 1u, sp = (m / FX_WIN) / per;
+      // gram == 2 (the persistent form): recounts are per (8 hypotheses, 256-correspondence UNIT) and the counts live in ONE row
+      const uint32_t m = e.x, w32 = e.y >> 17, ehf = (e.y >> 16) & 1u, sp = gram == 2 ? m / (uint32_t)GX_UNIT : (m / FX_WIN) / per;
       const float4 pa = aos4[2 * (size_t)m], pb = aos4[2 * (size_t)m + 1];
       for (uint32_t bits = e.y & 0xFFFFu; bits; bits &= bits - 1) {
         const uint32_t i16 = (uint32_t)(__ffs(bits) - 1), row = 8 * (i16 >> 2) + 4 * ehf + (i16 & 3u), h = w32 * 32 + row;
@@ -1046,7 +1053,7 @@ __global__ __launch_bounds__(256) void score_exact_kernel(const float* __restric
         float M[12];
         load_rt_aos(RtAoS, h, M);
         const float d2 = resid2(M, pa.x, pa.y, pa.z, pa.w, pb.x, pb.y);
-        if (finite12(M) && d2 < tau2) atomicAdd(&cnt_out[(size_t)sp * ldl + h], 1u);
+        if (finite12(M) && d2 < tau2) atomicAdd(&cnt_out[(gram == 2 ? (size_t)0 : (size_t)sp * ldl) + h], 1u);
       }
       continue;
     }
@@ -1062,7 +1069,7 @@ __global__ __launch_bounds__(256) void score_exact_kernel(const float* __restric
       if (finite12(M) && d2 < tau2) atomicAdd(&cnt_out[(size_t)sp * ldl + h], 1u);
     }
   }
-  const size_t nbits = (size_t)splits * n_waves;
+  const size_t nbits = (size_t)(gram == 2 ? windows * (uint32_t)(FX_WIN / GX_UNIT) : splits) * n_waves;
   for (size_t w = blockIdx.x; w < (nbits + 31) / 32; w += gridDim.x) {
     uint32_t word = redo_bits[w];
     while (word) {
@@ -1073,9 +1080,10 @@ __global__ __launch_bounds__(256) void score_exact_kernel(const float* __restric
       float M[12];
       load_rt_aos(RtAoS, h, M);
       const bool ok = finite12(M);
-      const uint32_t m1 = min((uint32_t)n, min(windows, (sp + 1) * per) * FX_WIN);
+      const uint32_t m0 = gram == 2 ? sp * (uint32_t)GX_UNIT : sp * per * FX_WIN;
+      const uint32_t m1 = gram == 2 ? min((uint32_t)n, (sp + 1) * (uint32_t)GX_UNIT) : min((uint32_t)n, min(windows, (sp + 1) * per) * FX_WIN);
       uint32_t cnt = 0;
-      for (uint32_t m = sp * per * FX_WIN + (threadIdx.x >> 3); m < m1; m += 32) {
+      for (uint32_t m = m0 + (threadIdx.x >> 3); m < m1; m += 32) {
         const float4 pa = aos4[2 * (size_t)m], pb = aos4[2 * (size_t)m + 1];
         const float d2 = resid2(M, pa.x, pa.y, pa.z, pa.w, pb.x, pb.y);
         cnt += (ok && d2 < tau2) ? 1u : 0u;
@@ -1083,7 +1091,7 @@ __global__ __launch_bounds__(256) void score_exact_kernel(const float* __restric
       cnt += __shfl_xor(cnt, 8);
       cnt += __shfl_xor(cnt, 16);
       cnt += __shfl_xor(cnt, 32);
-      if ((threadIdx.x & 63) < 8 && cnt) atomicAdd(&cnt_out[(size_t)sp * ldl + h], cnt);
+      if ((threadIdx.x & 63) < 8 && cnt) atomicAdd(&cnt_out[(gram == 2 ? (size_t)0 : (size_t)sp * ldl) + h], cnt);
     }
   }
 }
@@ -1154,6 +1162,7 @@ __device__ void gram_tile_block(const float* __restrict__ planes, int n, int ld,
                                 uint32_t blocks) {
   const uint32_t m = block * 256 + threadIdx.x;
   for (uint32_t z = m; z < job.zero_words; z += blocks * 256) job.zero[z] = 0u;
+  for (uint32_t z = m; z < job.zero2_words; z += blocks * 256) job.zero2[z] = 0u;
   const GramInfo gi = gram_info(job.mx_cur + 2, job.mx_cur + 8, __uint_as_float(job.mx_cur[0]), __uint_as_float(job.mx_cur[1]));
   if (m == 0) *reinterpret_cast<GramInfo*>(static_cast<char*>(job.info) + 64) = gi;
   if (m >= job.rows) return;
@@ -1598,6 +1607,208 @@ __global__ __launch_bounds__(64 * GX_WAVES, 2) void score_gram_kernel(GramCoef c
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// The Gram filter, persistent form (r04).  BUILT, BIT-EXACT, 3 - 4 % SLOWER than the split form — off by default
+// (sc_debug: gram_pers).  VERDICT r03 #4 proposed it ("persistent waves that loop over several tiles ..."): the premise was that
+// the split form loses to its two generations of workgroups at C2.  Measured, alternating in one process
+// (profiles/r04_ab_gram_persistent.txt): C2 stage 47.3 - 48.4 us against 45.6 - 46.4, C4 331 against 319.  The generations of the
+// split form overlap (a workgroup of the second starts the moment one of the first ends), so their start-up is already hidden;
+// what bounds both forms is the per-step rate — ~380 cycles per 1024-test step and SIMD against 264 by the issue model.
+// Same arithmetic, same tile, same queue and exact pass as score_gram_kernel above — what changes is how the launch is cut.  The split form is a grid of (groups of 256 hypotheses) x
+// (splits of the windows): at C2 980 workgroups for 512 resident slots, i.e. TWO generations, each paying the workgroup's
+// start-up (dispatch, coefficient loads, the first units' LDS-DMA through a cold pipeline) and tail (80 DPP adds, stores) for only
+// 32 steps per wave; its timing-only body with no vector work at all takes 28 us at C2 for 12 us of matrix-pipe work.  Here the
+// launch is ONE generation: min(slots, items) workgroups, each walking a CONTIGUOUS run of the items (hypothesis group g, unit u)
+// — 3920 items over 512 workgroups at C2: 7 or 8 units each, the ring of three LDS buffers never drains between them, and a
+// workgroup changes its hypothesis group at most once or twice (coefficients reloaded, totals flushed).  Because a group's
+// units are now shared by several workgroups,
+//   * the counts of a hypothesis are ACCUMULATED into one row by atomicAdd (the row is cleared by the tile job; the arg-max
+//     then reads one row instead of `splits`),
+//   * the exact pass's wholesale recounts are per (8 hypotheses, UNIT) — a queue that overflows costs the recount of 256
+//     correspondences, not of a whole split, and the wave carries on with the next unit: the unit's sign bits are dropped from
+//     the shift registers and its queue entries from the LDS queue, so nothing is counted twice.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64 * GX_WAVES, 2) void score_gram_pers_kernel(GramCoef coef, uint32_t ldl,
+                                                                          const uint4* __restrict__ tile, uint32_t units,
+                                                                          uint32_t groups, uint32_t n_waves8,
+                                                                          uint32_t* __restrict__ cnt_out, uint2* __restrict__ gq,
+                                                                          uint32_t cap_sq, uint32_t* __restrict__ qcount,
+                                                                          uint32_t* __restrict__ redo_bits, uint32_t ql) {
+  __shared__ uint4 Bt[3][GX_UNIT * GX_TILE_Q];
+  __shared__ uint2 queue[GX_WAVES][GX_QL];
+  constexpr int PIECES = GX_UNIT * GX_TILE_Q / (64 * GX_WAVES);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int col = lane & 31, hf = lane >> 5;
+  const uint64_t items = (uint64_t)groups * units;  // (< 2^28: score_filter_mode keeps ld_local <= 2^20 and n <= 2^24 for this filter)
+  const uint32_t k0 = (uint32_t)(items * blockIdx.x / gridDim.x), k1 = (uint32_t)(items * (blockIdx.x + 1) / gridDim.x);
+  if (k0 >= k1) return;  // (workgroup-uniform)
+  // (g, u) of the running item are kept incrementally: a 64-bit division per unit and wave — three, with the units staged
+  // ahead — doubled the kernel's instruction count in its first form (47.7 us against the split form's 41.6)
+  uint32_t g = k0 / units, u = k0 - g * units;
+  auto unit_after = [&](uint32_t uu, uint32_t d) { uu += d; return uu >= units ? uu - units : uu; };  // (d <= 2 <= units)
+  auto stage = [&](uint32_t u, int buf) {
+#pragma unroll
+    for (int i = 0; i < PIECES; i++) {
+      const uint4* gsrc = tile + (size_t)u * (GX_UNIT * GX_TILE_Q) + 64 * GX_WAVES * i + tid;
+      const uint32_t lds_dst = __builtin_amdgcn_readfirstlane(
+          (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)(&Bt[buf][64 * GX_WAVES * i + wave * 64]));
+      unsigned keep;
+      asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                   : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+    }
+  };
+  stage(u, 0);
+  if (k0 + 1 < k1) stage(units > 1 ? unit_after(u, 1) : 0u, 1);
+  // ---- per hypothesis group: coefficients and accumulators
+  half8 A0, A2;
+  f32x16 C;
+  uint32_t W2b = 0, redo4 = 0, wid = 0;
+  bool any_normal = false;
+  uint32_t total[16], sr[16];
+  uint32_t sr_units = 0;          // units whose sign bits sit in sr (flushed into total at four: 32 steps)
+  uint32_t qn = 0;
+  uint2* q = queue[wave];
+  bool flushed = false;
+  auto load_group = [&](uint32_t g) {
+    wid = g * GX_WAVES + (uint32_t)wave;
+    const uint32_t h = wid * 32 + (uint32_t)col;
+    const bool in_grid = h < ldl;
+    const uint4* __restrict__ ca = reinterpret_cast<const uint4*>(coef.A) + (size_t)(in_grid ? h : 0) * 4;
+    const uint4 a0 = ca[hf], a2 = ca[2 + hf];
+    A0 = *reinterpret_cast<const half8*>(&a0); A2 = *reinterpret_cast<const half8*>(&a2);
+    const uint2 wv = coef.wave[wid < coef.n_waves32 ? wid : 0];
+    W2b = wid < coef.n_waves32 ? wv.x : 0u;
+    redo4 = wid < coef.n_waves32 ? (wv.y & 0xFu) : 0u;
+    any_normal = wid < coef.n_waves32 && ((wv.y >> 4) & 1u);
+#pragma unroll
+    for (int jj = 0; jj < 4; jj++) {
+      const float4 c4 = *reinterpret_cast<const float4*>(coef.C + (size_t)(wid < coef.n_waves32 ? wid : 0) * 32 + 8 * jj + 4 * hf);
+      C[4 * jj] = c4.x; C[4 * jj + 1] = c4.y; C[4 * jj + 2] = c4.z; C[4 * jj + 3] = c4.w;
+    }
+    asm volatile("" ::"v"(A0), "v"(A2), "v"(C), "s"(W2b), "s"(redo4));  // (the wait for these loads sits HERE: see score_gram_kernel)
+#pragma unroll
+    for (int i = 0; i < 16; i++) { total[i] = 0; sr[i] = 0; }
+    sr_units = 0;
+    flushed = true;  // (the loads above are younger than the LDS-DMA pieces in flight: the next wait is a full one)
+  };
+  auto flush_queue = [&]() {
+    const uint32_t sq = wid % FX_NQ;
+    uint32_t base = 0;
+    if (lane == 0) base = atomicAdd(&qcount[sq * 32], qn);
+    base = __shfl(base, 0);
+    // a sub-queue that is full takes nothing: its entries' units are recounted instead (marked by the caller)
+    for (uint32_t i = lane; i < qn && base + i < cap_sq; i += 64) gq[(size_t)sq * cap_sq + base + i] = make_uint2(q[i].x, (wid << 17) | q[i].y);
+    const bool fits = base + qn <= cap_sq;
+    qn = 0;
+    flushed = true;
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    return fits;
+  };
+  auto mark_unit = [&](uint32_t u, uint32_t groups4) {  // the exact pass recounts these groups of 8 hypotheses over unit u
+    if (lane == 0) {
+#pragma unroll
+      for (int jj = 0; jj < 4; jj++)
+        if (((groups4 >> jj) & 1u) && (wid * 4 + jj) < n_waves8) {
+          const size_t bit = (size_t)u * n_waves8 + wid * 4 + jj;
+          atomicOr(&redo_bits[bit >> 5], 1u << (bit & 31));
+        }
+    }
+  };
+  auto finish_group = [&]() {  // the group's counts so far -> the count row
+    if (sr_units) {
+#pragma unroll
+      for (int i = 0; i < 16; i++) total[i] += (uint32_t)__popc(sr[i]);
+    }
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+      const uint32_t c = dpp_sum32_upper(total[i]);
+      const uint32_t r = 8 * (i >> 2) + 4 * hf + (i & 3), hh = wid * 32 + r;
+      if (col == 31 && hh < ldl && c != 0u && !((redo4 >> (i >> 2)) & 1u)) atomicAdd(&cnt_out[hh], c);
+    }
+  };
+  // A wave adds a group's counts only when it is done with the group (finish_group), so a GLOBAL sub-queue that turns out full
+  // can still be undone: the wave gives the rest of its run of this group up — every unit of the run, past and to come, is
+  // marked for the exact pass (which then skips the run's queue entries that did get through) and nothing is added.
+  uint32_t seg_first = 0;  // first unit of the current group's run in this workgroup
+  auto give_up = [&](uint32_t u_now) {
+    for (uint32_t x = seg_first; x <= u_now; x++) mark_unit(x, 0xFu & ~redo4);
+    redo4 = 0xFu;  // (the units still to come are marked as they are reached; finish_group adds nothing)
+  };
+  int64_t cur_g = -1;
+  int buf = 0;
+  for (uint32_t k = k0; k < k1; k++, buf = buf == 2 ? 0 : buf + 1, u = (u + 1 == units) ? 0u : u + 1, g += (u == 0u) ? 1u : 0u) {
+    if ((int64_t)g != cur_g) {  // (workgroup-uniform)
+      if (cur_g >= 0) {
+        if (qn && redo4 != 0xFu && !flush_queue()) give_up(units - 1);  // (the previous group's run ended at its last unit)
+        finish_group();
+      }
+      load_group(g);
+      qn = 0;
+      cur_g = g; seg_first = u;
+    }
+    if (k + 1 < k1 && !flushed) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PIECES) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    flushed = false;
+    __syncthreads();
+    if (k + 2 < k1) stage(units > 2 ? unit_after(u, 2) : (units == 2 ? u : 0u), buf == 0 ? 2 : buf - 1);
+    if (redo4 != 0u) mark_unit(u, redo4);  // groups the prologue classified "recount" (their rows are switched off)
+    if (any_normal && redo4 != 0xFu) {
+      const half8* Bc = reinterpret_cast<const half8*>(Bt[buf]) + lane;
+      const uint32_t qn_unit = qn;  // the queue's fill at the start of the unit
+      auto epilogue = [&](const f32x16& D, int gstep) {
+        uint32_t gm[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+#pragma unroll
+          for (int i = 4 * j; i < 4 * j + 4; i++) sr[i] = __builtin_amdgcn_alignbit(sr[i], __float_as_uint(D[i]), 31);
+          gm[j] = min(min(min(__float_as_uint(D[4 * j]), __float_as_uint(D[4 * j + 1])), __float_as_uint(D[4 * j + 2])), __float_as_uint(D[4 * j + 3]));
+        }
+        const uint32_t mn = min(min(min(gm[0], gm[1]), gm[2]), gm[3]);
+        if (__builtin_expect(__ballot(mn < W2b) != 0, 0)) {
+#pragma unroll
+          for (int j = 0; j < 4; j++) {
+            const uint64_t hit = __ballot(gm[j] < W2b);
+            if (hit == 0) continue;
+            const uint32_t slot = qn + __builtin_amdgcn_mbcnt_hi((uint32_t)(hit >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)hit, 0u));
+            if (gm[j] < W2b) {
+              uint32_t bits = 0;
+#pragma unroll
+              for (int i = 0; i < 4; i++) bits |= (__float_as_uint(D[4 * j + i]) < W2b) ? (1u << (4 * j + i)) : 0u;
+              if (slot < ql) q[slot] = make_uint2(u * GX_UNIT + 32 * gstep + col, ((uint32_t)hf << 16) | bits);
+            }
+            qn += (uint32_t)__popcll(hit);
+          }
+        }
+      };
+      half8 b0 = Bc[0], b1 = Bc[64];
+#pragma unroll 1
+      for (int gstep = 0; gstep < GX_UNIT / 32; gstep++) {
+        f32x16 D = __builtin_amdgcn_mfma_f32_32x32x16_f16(A0, b0, C, 0, 0, 0);
+        D = __builtin_amdgcn_mfma_f32_32x32x16_f16(A0, b1, D, 0, 0, 0);
+        D = __builtin_amdgcn_mfma_f32_32x32x16_f16(A2, b0, D, 0, 0, 0);
+        if (gstep + 1 < GX_UNIT / 32) { b0 = Bc[32 * GX_TILE_Q * (gstep + 1)]; b1 = Bc[32 * GX_TILE_Q * (gstep + 1) + 64]; }
+        epilogue(D, gstep);
+      }
+      if (qn > ql) {
+        // the unit's entries beyond ql were dropped: the exact pass takes the whole (wave, unit); its sign bits (the low 8 of
+        // every shift register) and its queue entries go, so nothing of it is counted here
+        mark_unit(u, 0xFu & ~redo4);
+#pragma unroll
+        for (int i = 0; i < 16; i++) sr[i] &= ~0xFFu;
+        qn = qn_unit;
+      }
+      if (++sr_units == (uint32_t)(FX_WIN / GX_UNIT)) {
+#pragma unroll
+        for (int i = 0; i < 16; i++) { total[i] += (uint32_t)__popc(sr[i]); sr[i] = 0; }
+        sr_units = 0;
+      }
+      if (qn > ql / 2 && !flush_queue()) give_up(u);
+    }
+  }
+  if (qn && redo4 != 0xFu && !flush_queue()) give_up((uint32_t)(((uint64_t)k1 - 1) % units));
+  finish_group();
+}
+
 GramCoef gram_coef_view(void* buf, uint32_t ld_local) {
   GramCoef g;
   unsigned char* p = static_cast<unsigned char*>(buf);
@@ -1609,10 +1820,12 @@ GramCoef gram_coef_view(void* buf, uint32_t ld_local) {
 }
 
 FilterTileJob filter_tile_job(const FilterPlan& fp, const uint32_t* mx_cur, uint32_t* mx_next, void* tile, void* state,
-                              void* coef, uint32_t ld_local, float tau2) {
+                              void* coef, uint32_t ld_local, float tau2, uint32_t* partial) {
   const FilterState f = filter_state(state, fp);
-  FilterTileJob j{fp.rows, mx_cur, mx_next, tile, f.info, f.qcount, f.zero_words, fp.mode, GramCoef{nullptr, nullptr, nullptr, 0}, tau2};
+  FilterTileJob j{fp.rows, mx_cur, mx_next, tile, f.info, f.qcount, f.zero_words, fp.mode, GramCoef{nullptr, nullptr, nullptr, 0}, tau2,
+                  nullptr, 0u};
   if (fp.mode == 2) j.coef = gram_coef_view(coef, ld_local);
+  if (fp.mode == 2 && fp.units && partial) { j.zero2 = partial; j.zero2_words = ld_local; }
   return j;
 }
 
@@ -1640,6 +1853,22 @@ void launch_score_filter(const Points& pts, const float* RtSoA, const float* RtA
     if (ql > (uint32_t)GX_QL) ql = GX_QL;
     if (ql < 64) ql = 64;
     const GramCoef gc = gram_coef_view(coef, sh.ld_local);
+    if (fp.units) {  // the persistent form: one generation of workgroups (two per CU), contiguous runs of (group, unit) items
+      const uint32_t groups = (sh.ld_local + 32 * GX_WAVES - 1) / (32 * GX_WAVES);
+      const uint64_t items = (uint64_t)groups * fp.units;
+      int dev = 0, cus = 256;
+      (void)hipGetDevice(&dev);
+      (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+      uint64_t nb = 2ull * (uint64_t)(cus > 0 ? cus : 256);
+      if (nb > items) nb = items;
+      hipExtLaunchKernelGGL(score_gram_pers_kernel, dim3((unsigned)nb), dim3(64 * GX_WAVES), 0, st, ev0, nullptr, 0, gc, sh.ld_local,
+                            static_cast<const uint4*>(tile), fp.units, groups, fp.n_waves, partial, f.queue, f.cap_sq, f.qcount, f.redo, ql);
+      hipExtLaunchKernelGGL(score_exact_kernel, dim3(FX_NQ * exact_mult), dim3(256), 0, st, nullptr, ev1, 0, pts.planes, pts.n, pts.ld,
+                            reinterpret_cast<const float4*>(RtAoS), sh.ld_local, dv.tau2, fp.windows, fp.splits, fp.n_waves,
+                            static_cast<const uint2*>(f.queue), f.cap_sq, static_cast<const uint32_t*>(f.qcount),
+                            static_cast<const uint32_t*>(f.redo), partial, 2u);
+      return;
+    }
 #define SC_GRAM_LAUNCH(V)                                                                                                         \
     hipExtLaunchKernelGGL(score_gram_kernel<V>, dim3((sh.ld_local + 32 * GX_WAVES - 1) / (32 * GX_WAVES), fp.splits), dim3(64 * GX_WAVES), \
                           0, st, ev0, nullptr, 0, gc, sh.ld_local, static_cast<const uint4*>(tile), fp.windows, fp.splits, fp.n_waves, partial, \
@@ -1705,7 +1934,7 @@ void launch_score_filter(const Points& pts, const float* RtSoA, const float* RtA
 
 hipError_t filter_read_counters(const void* state, const FilterPlan& fp, hipStream_t st, uint64_t* undecided, uint64_t* recounts) {
   const FilterState f = filter_state(const_cast<void*>(state), fp);
-  const size_t bm_words = ((size_t)fp.splits * fp.n_waves + 31) / 32;
+  const size_t bm_words = ((size_t)fp.bm_rows * fp.n_waves + 31) / 32;
   std::vector<uint32_t> h((size_t)FX_NQ * 32 + bm_words);
   hipError_t e = hipMemcpyAsync(h.data(), f.qcount, h.size() * 4, hipMemcpyDeviceToHost, st);  // counters, then the bitmap
   if (e == hipSuccess) e = hipStreamSynchronize(st);
