@@ -47,9 +47,12 @@ struct sc_ctx {
   // workspace
   Buf in_src, in_tgt, planes, S, bits, deg, degp, wpre, ebase, edge_off, scan_tmp, ei, ej, es, ebi, ebj, tcnt, toff, wkey, kcol, ctl, events, blk_gt,
       blk_eq, blk_minmax, bits2, off_gt, off_eq, sel_ord, sel_key, sortkey, sorted, sort_tmp, tri, tri_rk, key_rk, rt, rt_aos, partial, cnt, key, rt12,
-      mask, refine_tmp, amx_pairs, strong, rowcost, cost_pre, lb_state, lb_ticket, fx_tile, fx_state, fx_mx, fx_part, fx_coef, guard_tmp, sel_list, wg_map;
-  int wg_map_W = 0;          // the row width (words) the XCD-aware block order of stage A in wg_map was made for
-  uint32_t wg_map_len = 0;
+      mask, refine_tmp, amx_pairs, strong, rowcost, cost_pre, lb_state, lb_ticket, fx_tile, fx_state, fx_mx, fx_part, fx_coef, guard_tmp, sel_list;
+  // the XCD-aware block orders of stage A (compat_wg_map), one per row width met so far: a context that alternates between a few
+  // sizes must not rebuild and upload the map on every call (that cost 2 ms per call in bench.py's varying-n leg)
+  static constexpr int N_WG_MAPS = 8;
+  struct WgMap { int W = 0; uint32_t len = 0; Buf buf; uint64_t used = 0; } wg_maps[N_WG_MAPS];
+  uint64_t wg_map_clock = 0;
   bool filter_on = false;   // C2 of the running / last call goes through a matrix-pipe filter (decided ONCE per call)
   int filter_mode = 0;      // ... which: 1 linear, 2 Gram (0: the plain fp32 kernel)
   FilterPlan fx_plan{};     // ... with this plan (sc_debug_last reads the filter's counters through it)
@@ -319,22 +322,28 @@ int run_compat(sc_ctx* c, bool dense) {
   c->bits_cur = c->bits.as<uint64_t>();
   c->sharded_ab = false; c->shard_phase = 0; c->cand_all = nullptr;
   const uint32_t* map = nullptr;
+  uint32_t map_len = 0;
   // The XCD-aware block order (sc_compat.hip compat_wg_map; made once per row width).  Measured r04 (profiles/r04_pmc_compat_xcd_order.txt):
   // HBM write bytes C2 115.8 -> 106.9 MB (algorithmic 103.2: 1.035 x), bits only 13.0 -> 5.1 MB; C3 1820 -> 1683 MB (1.02 x).  Time:
   // C2 25.0 -> 23.7 us, but at C3 the index order is FASTER (352 vs 369 - 389 us, alternating three times in one process) although it
   // writes more: each XCD then streams its S rows into one 512 x 512 corner of the matrix at a time.  So: by size, like the tile height.
   if (!c->tn.compat_linear_order && c->tn.compat_rows != 64 && (c->n < 10000 || c->tn.compat_rows == 16)) {
-    if (c->wg_map_W != (int)W) {
+    sc_ctx::WgMap* slot = nullptr;
+    for (sc_ctx::WgMap& m : c->wg_maps) if (m.W == (int)W) slot = &m;
+    if (!slot) {  // a width not met before (or evicted): the least recently used slot
+      slot = &c->wg_maps[0];
+      for (sc_ctx::WgMap& m : c->wg_maps) if (m.used < slot->used) slot = &m;
       const std::vector<uint32_t> m = compat_wg_map((int)W);
-      ENSURE(c, c->wg_map, m.size() * 4);
-      HIPCHK(c, hipMemcpyAsync(c->wg_map.p, m.data(), m.size() * 4, hipMemcpyHostToDevice, c->stream));
+      ENSURE(c, slot->buf, m.size() * 4);
+      HIPCHK(c, hipMemcpyAsync(slot->buf.p, m.data(), m.size() * 4, hipMemcpyHostToDevice, c->stream));
       HIPCHK(c, hipStreamSynchronize(c->stream));  // (m is a local: the copy must have left it; once per size)
-      c->wg_map_W = (int)W; c->wg_map_len = (uint32_t)m.size();
+      slot->W = (int)W; slot->len = (uint32_t)m.size();
     }
-    map = c->wg_map.as<uint32_t>();
+    slot->used = ++c->wg_map_clock;
+    map = slot->buf.as<uint32_t>(); map_len = slot->len;
   }
   launch_compat(points_of(c), c->dv, dense ? c->S.as<float>() : nullptr, c->bits_cur, 0, c->n, c->tn, c->stream,
-                c->build ? c->degp.as<uint32_t>() : nullptr, map, c->wg_map_len);
+                c->build ? c->degp.as<uint32_t>() : nullptr, map, map_len);
   return SC_OK;
 }
 
@@ -878,7 +887,8 @@ void sc_destroy(sc_ctx* c) {
   Buf* bufs[] = {&c->in_src, &c->in_tgt, &c->planes, &c->S, &c->bits, &c->deg, &c->degp, &c->wpre, &c->ebase, &c->edge_off, &c->scan_tmp,
                  &c->ei, &c->ej, &c->es, &c->ebi, &c->ebj, &c->tcnt, &c->toff, &c->wkey, &c->kcol, &c->ctl, &c->events, &c->blk_gt, &c->blk_eq, &c->blk_minmax, &c->bits2, &c->off_gt,
                  &c->off_eq, &c->sel_ord, &c->sel_key, &c->sortkey, &c->sorted, &c->sort_tmp, &c->tri, &c->tri_rk, &c->key_rk, &c->rt,
-                 &c->rt_aos, &c->partial, &c->cnt, &c->key, &c->rt12, &c->mask, &c->refine_tmp, &c->amx_pairs, &c->strong, &c->rowcost, &c->cost_pre, &c->lb_state, &c->lb_ticket, &c->fx_tile, &c->fx_state, &c->fx_mx, &c->fx_part, &c->fx_coef, &c->guard_tmp, &c->sel_list, &c->wg_map};
+                 &c->rt_aos, &c->partial, &c->cnt, &c->key, &c->rt12, &c->mask, &c->refine_tmp, &c->amx_pairs, &c->strong, &c->rowcost, &c->cost_pre, &c->lb_state, &c->lb_ticket, &c->fx_tile, &c->fx_state, &c->fx_mx, &c->fx_part, &c->fx_coef, &c->guard_tmp, &c->sel_list};
+  for (sc_ctx::WgMap& m : c->wg_maps) if (m.buf.p) (void)hipFree(m.buf.p);
   for (Buf* b : bufs) if (b->p) (void)hipFree(b->p);
   for (int i = 0; i < N_EVENTS; i++) if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
   if (c->pinned) (void)hipHostFree(c->pinned);
