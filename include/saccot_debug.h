@@ -42,7 +42,7 @@ typedef struct sc_debug {
   uint32_t filter_lds_queue;  /* entries of a wave's own queue, 64 .. 256 (0 = 256)                                   */
   uint32_t es_hist_unfused;   /* 1: stage B's edge-weight histogram by a launch of its own instead of inside edge_fill  */
   uint32_t filter_variant;    /* body of the filter kernel: 0 = default, 1 .. 3 = bit-identical scheduling variants; the timing-only ablations (>= 16, wrong counts) only in a -DSC_ABLATIONS build (SC_EINVAL otherwise) */
-  uint32_t dense_async;       /* (the r02 / r03 knob of this name is gone) now gram_pers: 1 = the Gram filter's persistent form — ONE generation of workgroups, each walking a contiguous run of (hypothesis group, 256-correspondence unit) items, counts accumulated by atomics, recounts per unit — instead of the grid of hypothesis groups x window splits.  Built, bit-exact, measured 3 - 4 % slower: off by default */
+  uint32_t gram_kappa_q4;     /* the Gram filter's cut: a hypothesis counts as NEAR the call's reference frame while its reach stays under (value / 16) x tau; 0 = 8 tau (default), 1 = practically no cut (every workgroup walks every correspondence).  (Slot of the persistent-form knob of round 4, whose code is gone.) */
   uint32_t filter_blind;      /* 1: the host picks stage C2's kernel as if the coordinate maxima had not arrived yet (it then assumes the filter applies; the filter's own range test sends what it cannot bound to the exact recount) */
   uint32_t no_fast;           /* 1: sc_register_device always waits for stage B's two counts in the middle of the call (the form every other entry point uses) instead of enqueueing the whole chain of a repeated shape host-free */
   uint32_t gram_guard_fail;   /* 1: the run-time probe of the matrix pipe's accumulation model reports a violation (tests: the Gram filter must then never be chosen) */
@@ -54,6 +54,8 @@ typedef struct sc_debug {
   uint32_t reserved[1];       /* development hook (a kernel under study stops early: WRONG results); leave 0 */
   uint32_t select_final;      /* 1: the select as ONE launch after a key kernel that also takes round 1's histogram, instead of round 1 + round 2 + per-tile count (built, bit-exact, measured no faster: off by default) */
   uint32_t pad_;              /* compat_linear_order: 1 = stage A's 64 x 64 blocks in index order instead of the XCD-aware order */
+  uint32_t gram_ref_late;     /* 1: the Gram filter's reference frame is voted after the selection, in a launch of its own (what every path but sc_register / sc_register_device does anyway), instead of by an extra workgroup of stage B's counting pass among the estimating sample's best triangles */
+  uint32_t pad2_;
 } sc_debug;
 int         sc_set_debug(sc_ctx* ctx, const sc_debug* dbg);
 
@@ -70,6 +72,12 @@ typedef struct sc_debug_info {
   uint32_t prune_bound;       /* stage B's pruning bound in the last call: 0 = certified by the sample (or no pruning), 1 = estimated from a 1-in-64 sample of the triangles and verified by the select, 2 = estimated, found too high by the select, call repeated with a certifying sample */
   float    gram_guard_worst;  /* largest |hardware - exact| / largest term the probe saw, in units of 2^-24 (the bound assumes 18.5) */
   uint32_t reserved2;
+  /* the Gram filter's cut in the last call (c2_kernel == 2): of `gram_rows` coefficient rows (hypotheses of this rank, padded to 256)
+   * `gram_near_hyp` are near the reference frame and look only at the `gram_near_corr` correspondences near it */
+  uint32_t gram_near_corr, gram_near_hyp, gram_rows;
+  uint32_t gram_ref;          /* position (in this rank's share of the ranked list) of the hypothesis voted reference frame; 0xFFFFFFFF: none (box-centre frame) */
+  uint32_t gram_ref_votes_q8; /* its soft vote count x 256 (of 64 voters) */
+  uint32_t reserved3;
 } sc_debug_info;
 int         sc_debug_last(sc_ctx* ctx, sc_debug_info* out);
 

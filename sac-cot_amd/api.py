@@ -82,11 +82,11 @@ class ScDebug(C.Structure):
                 ("sample_blocks", C.c_uint32), ("compact_fused", C.c_uint32), ("rows_unfused", C.c_uint32),
                 ("score_scalar", C.c_uint32), ("score_filter", C.c_uint32), ("filter_splits", C.c_uint32),
                 ("filter_queue_cap", C.c_uint32), ("filter_lds_queue", C.c_uint32), ("es_hist_unfused", C.c_uint32),
-                ("filter_variant", C.c_uint32), ("dense_async", C.c_uint32), ("filter_blind", C.c_uint32),
+                ("filter_variant", C.c_uint32), ("gram_kappa_q4", C.c_uint32), ("filter_blind", C.c_uint32),
                 ("no_fast", C.c_uint32), ("gram_guard_fail", C.c_uint32), ("tail_fused", C.c_uint32),
                 ("no_estimate", C.c_uint32), ("est_margin_pct", C.c_uint32), ("no_edge_build", C.c_uint32),
                 ("build_sample", C.c_uint32), ("reserved", C.c_uint32 * 1), ("select_final", C.c_uint32),
-                ("pad_", C.c_uint32)]
+                ("pad_", C.c_uint32), ("gram_ref_late", C.c_uint32), ("pad2_", C.c_uint32)]
 
 
 class ScDebugInfo(C.Structure):
@@ -95,7 +95,9 @@ class ScDebugInfo(C.Structure):
     _fields_ = [("size", C.c_uint32), ("c2_kernel", C.c_uint32), ("filter_undecided", C.c_uint64),
                 ("filter_recounts", C.c_uint64), ("filter_splits", C.c_uint32), ("fast_path", C.c_uint32),
                 ("gram_guard", C.c_uint32), ("prune_bound", C.c_uint32), ("gram_guard_worst", C.c_float),
-                ("reserved2", C.c_uint32)]
+                ("reserved2", C.c_uint32), ("gram_near_corr", C.c_uint32), ("gram_near_hyp", C.c_uint32),
+                ("gram_rows", C.c_uint32), ("gram_ref", C.c_uint32), ("gram_ref_votes_q8", C.c_uint32),
+                ("reserved3", C.c_uint32)]
 
 
 class SacCotError(RuntimeError):
@@ -246,7 +248,7 @@ class Registrar:
         of the matrix-pipe probe (gram_guard).  Synchronises the context's stream."""
         d = ScDebugInfo(size=C.sizeof(ScDebugInfo))
         self._check(self._lib.sc_debug_last(self._h, C.byref(d)))
-        return {k: getattr(d, k) for k, _ in ScDebugInfo._fields_ if k not in ("size", "reserved", "reserved2")}
+        return {k: getattr(d, k) for k, _ in ScDebugInfo._fields_ if k not in ("size", "reserved", "reserved2", "reserved3")}
 
     # ---- drop-in entry point ----------------------------------------------------------------------------
     def register(self, src, tgt, params: ScParams | None = None, **kw):

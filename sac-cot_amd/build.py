@@ -9,7 +9,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libsaccot.so")
 SOURCES = ["sc_compat.hip", "sc_tri.hip", "sc_score.hip", "sc_sort.hip", "sc_capi.hip", "sc_multi.hip"]
-HEADERS = ["sc_arith.hpp", "sc_block.hpp", "sc_kernels.hpp", os.path.join("..", "..", "include", "saccot.h"),
+HEADERS = ["sc_arith.hpp", "sc_block.hpp", "sc_kernels.hpp", "sc_gramref.hpp", os.path.join("..", "..", "include", "saccot.h"),
            os.path.join("..", "..", "include", "saccot_debug.h")]
 # -ffp-contract=off: the canonical arithmetic (sc_arith.hpp) fuses only where it says fmaf.
 # -amdgpu-mfma-vgpr-form: MFMA results land in VGPRs (unified register file on gfx950), no v_accvgpr_read copies.

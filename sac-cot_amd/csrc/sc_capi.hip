@@ -18,6 +18,7 @@
 #include "../../include/saccot.h"
 #include "../../include/saccot_debug.h"
 #include "sc_kernels.hpp"
+#include "sc_gramref.hpp"
 
 using namespace sc;
 
@@ -47,7 +48,7 @@ struct sc_ctx {
   // workspace
   Buf in_src, in_tgt, planes, S, bits, deg, degp, wpre, ebase, edge_off, scan_tmp, ei, ej, es, ebi, ebj, tcnt, toff, wkey, kcol, ctl, events, blk_gt,
       blk_eq, blk_minmax, bits2, off_gt, off_eq, sel_ord, sel_key, sortkey, sorted, sort_tmp, tri, tri_rk, key_rk, rt, rt_aos, partial, cnt, key, rt12,
-      mask, refine_tmp, amx_pairs, strong, rowcost, cost_pre, lb_state, lb_ticket, fx_tile, fx_state, fx_mx, fx_part, fx_coef, guard_tmp, sel_list;
+      mask, refine_tmp, amx_pairs, strong, rowcost, cost_pre, lb_state, lb_ticket, fx_tile, fx_state, fx_mx, fx_part, fx_coef, guard_tmp, sel_list, fx_frame, ref_cand;
   // the XCD-aware block orders of stage A (compat_wg_map), one per row width met so far: a context that alternates between a few
   // sizes must not rebuild and upload the map on every call (that cost 2 ms per call in bench.py's varying-n leg)
   static constexpr int N_WG_MAPS = 8;
@@ -118,6 +119,11 @@ struct sc_ctx {
   // (register_waited, sc_register_device_async) say where the outputs go before stage C is enqueued
   float* tail_Rt = nullptr; uint8_t* tail_mask = nullptr;
   bool tail_done = false;    // the running call's arg-max launch did the finalize step too
+  // stage C2's reference frame (sc_gramref.hpp): on the hot path the estimating sample leaves candidate triangles behind
+  // (ref_cand_n of them) and the counting pass carries the vote as an extra workgroup (ref_done); everywhere else stage C
+  // votes in a launch of its own
+  uint32_t ref_cand_n = 0;
+  bool ref_done = false;
   bool build = false;        // the running call takes launch_edge_build (row statistics + edge list + estimating sample in one launch)
   // run-time probe of the matrix pipe's accumulation model (sc_score.hip gram_guard): 0 not run, 1 holds, 2 violated
   int gram_guard = 0;
@@ -431,9 +437,19 @@ bool edge_build_ok(const sc_ctx* c, const sc_params* p, int64_t n) {
 // Stage B, first half: CSR edge list and this process's share (`part` of `parts`) of the pruning sample, accumulated
 // into `hist` (256 u32 on the device, already zero; nullptr = the control block's own histogram).  Sets c->E and the
 // decisions the second half needs.
+// the Gram filter's frame (sc_gramref.hpp): 512 bytes per context
+int ensure_frame(sc_ctx* c) {
+  if (!c->fx_frame.p) {
+    ENSURE(c, c->fx_frame, gram_frame_bytes());
+    HIPCHK(c, hipMemsetAsync(c->fx_frame.p, 0, gram_frame_bytes(), c->stream));
+  }
+  return SC_OK;
+}
+
 int run_edges(sc_ctx* c, const sc_params* p, uint32_t* hist, uint32_t part, uint32_t parts) {
   const size_t n = c->n;
   hipStream_t st = c->stream;
+  c->ref_cand_n = 0; c->ref_done = false;
   ENSURE(c, c->edge_off, (n + 1) * sizeof(uint64_t));
   ENSURE(c, c->scan_tmp, scan_temp_bytes(n));
   // read-back #1: the scan kernel itself writes the edge count to host-pinned memory (no copy kernel)
@@ -541,11 +557,23 @@ int run_edges(sc_ctx* c, const sc_params* p, uint32_t* hist, uint32_t part, uint
     if (build && !c->plan.estimate) { c->last_error = "internal: the fused edge kernel ran but the bound is not an estimate"; return SC_EHIP; }
     if (build && c->tn.build_sample) {
       // (the sample's histogram came out of launch_edge_build)
-    } else if (c->plan.estimate)
+    } else if (c->plan.estimate) {
+      // the single-GPU hot path, inlier count, a call big enough for stage C2's Gram filter to be in question: the sample also
+      // leaves its workgroups' best triangles behind — the voters of that filter's reference frame (run_select passes them on)
+      uint4* cand = nullptr;
+      if (est_local && p->score_mode == 0 && c->tn.score_filter != 1 && c->tn.score_filter != 2 && !c->tn.gram_ref_late &&
+          (uint64_t)p->max_triangles * (uint64_t)c->n >= (1ull << 27)) {
+        if (!c->ref_cand.p) {
+          ENSURE(c, c->ref_cand, 4096 * sizeof(uint4));
+          HIPCHK(c, hipMemsetAsync(c->ref_cand.p, 0, 4096 * sizeof(uint4), st));
+        }
+        cand = c->ref_cand.as<uint4>();
+        c->ref_cand_n = sample_estimate_blocks(E, c->tn);
+      }
       launch_sample_estimate(g, build ? nullptr : c->ebi.as<uint32_t>(), build ? nullptr : c->ebj.as<uint32_t>(), c->ei.as<uint32_t>(),
                              c->ej.as<uint32_t>(), c->es.as<float>(), E, 3.0f * p->t_cmp * 0.999f, c->plan.rate, ctl->prune_hist, c->tn,
-                             st, E_dev, c->ebase.as<uint32_t>());
-    else
+                             st, E_dev, c->ebase.as<uint32_t>(), cand, cand ? ctl->ref_slot : nullptr);
+    } else
       launch_sample_hist(g, c->ebi.as<uint32_t>(), c->ebj.as<uint32_t>(), c->ei.as<uint32_t>(), c->ej.as<uint32_t>(),
                          c->es.as<float>(), E, p->max_triangles, 3.0f * p->t_cmp * 0.999f, part, parts,
                          ctl->prune_hist, ctl->es_hist, es_hist != nullptr, c->tn, st, E_dev, spec ? c->E_last : 0);
@@ -638,9 +666,17 @@ int run_select(sc_ctx* c, const sc_params* p, const uint32_t* hist, bool want_li
     c->pinned[5] = 0;
     ev = event_list(c->events.p, ev_cap, g.W, c->ctl.as<ControlBlock>()->ev_fill,
                     reinterpret_cast<uint32_t*>(&c->pinned[5]));
+    GramRefJob ref{};
+    if (c->ref_cand_n) {  // (run_edges) one extra workgroup votes for stage C2's reference frame under this launch
+      int frc = ensure_frame(c);
+      if (frc) return frc;
+      ref = gram_ref_job(points_of(c), c->fx_mx.as<uint32_t>(), c->dv.tau2, c->tn, c->fx_frame.p);
+      ref.src.cand = c->ref_cand.as<uint4>(); ref.src.n_cand = c->ref_cand_n; ref.src.cand_slot = c->ctl.as<ControlBlock>()->ref_slot;
+      c->ref_done = true;
+    }
     launch_tri_count_events(g, mbits, sl, c->build ? nullptr : c->ebi.as<uint32_t>(), c->build ? nullptr : c->ebj.as<uint32_t>(), c->ei.as<uint32_t>(),
                             c->ej.as<uint32_t>(), spec ? c->E_last : E, p->rank_mode, c->tcnt.as<uint32_t>(), ev, c->tn, st, own_range_of(c),
-                            c->ebase.as<uint32_t>());
+                            c->ebase.as<uint32_t>(), ref.out ? &ref : nullptr);
   } else {
     launch_tri_count(g, mbits, c->es.as<float>(), smin, c->ei.as<uint32_t>(), c->ej.as<uint32_t>(), E,
                      c->tcnt.as<uint32_t>(), own_range_of(c), c->tn, st);
@@ -887,7 +923,7 @@ void sc_destroy(sc_ctx* c) {
   Buf* bufs[] = {&c->in_src, &c->in_tgt, &c->planes, &c->S, &c->bits, &c->deg, &c->degp, &c->wpre, &c->ebase, &c->edge_off, &c->scan_tmp,
                  &c->ei, &c->ej, &c->es, &c->ebi, &c->ebj, &c->tcnt, &c->toff, &c->wkey, &c->kcol, &c->ctl, &c->events, &c->blk_gt, &c->blk_eq, &c->blk_minmax, &c->bits2, &c->off_gt,
                  &c->off_eq, &c->sel_ord, &c->sel_key, &c->sortkey, &c->sorted, &c->sort_tmp, &c->tri, &c->tri_rk, &c->key_rk, &c->rt,
-                 &c->rt_aos, &c->partial, &c->cnt, &c->key, &c->rt12, &c->mask, &c->refine_tmp, &c->amx_pairs, &c->strong, &c->rowcost, &c->cost_pre, &c->lb_state, &c->lb_ticket, &c->fx_tile, &c->fx_state, &c->fx_mx, &c->fx_part, &c->fx_coef, &c->guard_tmp, &c->sel_list};
+                 &c->rt_aos, &c->partial, &c->cnt, &c->key, &c->rt12, &c->mask, &c->refine_tmp, &c->amx_pairs, &c->strong, &c->rowcost, &c->cost_pre, &c->lb_state, &c->lb_ticket, &c->fx_tile, &c->fx_state, &c->fx_mx, &c->fx_part, &c->fx_coef, &c->guard_tmp, &c->sel_list, &c->fx_frame, &c->ref_cand};
   for (sc_ctx::WgMap& m : c->wg_maps) if (m.buf.p) (void)hipFree(m.buf.p);
   for (Buf* b : bufs) if (b->p) (void)hipFree(b->p);
   for (int i = 0; i < N_EVENTS; i++) if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
@@ -950,7 +986,8 @@ int sc_set_debug(sc_ctx* c, const sc_debug* d) {
   t.filter_lds_queue = d->filter_lds_queue;
   t.filter_blind = d->filter_blind != 0;
   t.filter_variant = d->filter_variant;
-  t.gram_pers = d->dense_async != 0;  // (the slot of the removed dense_async knob)
+  t.gram_kappa_q4 = d->gram_kappa_q4;
+  t.gram_ref_late = d->gram_ref_late != 0;
   t.no_fast = d->no_fast != 0;
   t.gram_guard_fail = d->gram_guard_fail != 0;
   t.tail_fused = d->tail_fused != 0;
@@ -979,8 +1016,14 @@ int sc_debug_last(sc_ctx* c, sc_debug_info* out) {
   out->fast_path = (uint32_t)c->fast_state;
   out->gram_guard = c->tn.gram_guard_fail && c->gram_guard != 0 ? 2u : (uint32_t)c->gram_guard; out->gram_guard_worst = c->gram_guard_worst;
   out->prune_bound = c->est_failed_call ? 2u : (uint32_t)c->est_state; out->reserved2 = 0;
+  out->gram_near_corr = out->gram_near_hyp = out->gram_rows = out->gram_ref_votes_q8 = 0u; out->gram_ref = 0xFFFFFFFFu;
   if (c->filter_on && c->fx_state.p)
     HIPCHK(c, filter_read_counters(c->fx_state.p, c->fx_plan, c->stream, &out->filter_undecided, &out->filter_recounts));
+  if (c->filter_on && c->filter_mode == 2 && c->fx_frame.p) {
+    uint32_t fr[5];
+    HIPCHK(c, filter_read_frame(c->fx_frame.p, c->stream, fr));
+    out->gram_near_corr = fr[0]; out->gram_near_hyp = fr[1]; out->gram_rows = fr[2]; out->gram_ref = fr[3]; out->gram_ref_votes_q8 = fr[4];
+  }
   return SC_OK;
 }
 
@@ -1077,9 +1120,8 @@ int filter_job(sc_ctx* c, const Shard& sh, FilterTileJob* job) {
   ENSURE(c, c->fx_state, fp.state_bytes);
   if (fp.coef_bytes) ENSURE(c, c->fx_coef, fp.coef_bytes);
   uint32_t* mx = c->fx_mx.as<uint32_t>();
-  if (fp.units) ENSURE(c, c->partial, (size_t)fp.splits * sh.ld_local * 4);  // (the persistent Gram form's count row: cleared by the job)
-  *job = filter_tile_job(fp, mx, nullptr, c->fx_tile.p, c->fx_state.p, c->fx_coef.p, sh.ld_local, c->dv.tau2,
-                         fp.units ? c->partial.as<uint32_t>() : nullptr);
+  if (fp.mode == 2) { const int frc = ensure_frame(c); if (frc) return frc; }
+  *job = filter_tile_job(fp, mx, nullptr, c->fx_tile.p, c->fx_state.p, c->fx_coef.p, sh.ld_local, c->dv.tau2, c->fx_frame.p);
   return SC_OK;
 }
 
@@ -1093,11 +1135,14 @@ int run_score(sc_ctx* c, const sc_params* p, const Shard& sh, uint32_t* rows, bo
       FilterTileJob job;
       int rc = filter_job(c, sh, &job);
       if (rc) return rc;
+      if (fp.mode == 2)  // the frame first: tile and coefficients are made in it (the hypotheses exist already: it votes among them)
+        launch_gram_ref(points_of(c), TriSource{}, sh, c->rt.as<float>(), nullptr, c->fx_mx.as<uint32_t>(), c->dv.tau2, c->tn,
+                        c->fx_frame.p, c->stream);
       launch_filter_tile(points_of(c), job, c->stream);
-      if (fp.mode == 2) launch_gram_coef(c->rt.as<float>(), sh, c->dv.tau2, c->fx_mx.as<uint32_t>(), job.coef, c->stream);
+      if (fp.mode == 2) launch_gram_coef(c->rt.as<float>(), sh, c->dv.tau2, job.coef, c->stream);
     }
     launch_score_filter(points_of(c), c->rt.as<float>(), c->rt_aos.as<float>(), sh, c->dv, fp, c->fx_tile.p, c->fx_state.p,
-                        c->fx_coef.p, c->partial.as<uint32_t>(), c->tn, c->stream, ev0, ev1);
+                        c->fx_coef.p, c->fx_frame.p, c->partial.as<uint32_t>(), c->tn, c->stream, ev0, ev1);
     return SC_OK;
   }
   const bool scalar = score_is_scalar(p->score_mode, c->tn);
@@ -1141,8 +1186,12 @@ int run_stage_c(sc_ctx* c, uint64_t* d_key, sc_stats* stats) {
     if (filter && (rc = filter_job(c, sh, &job))) return rc;
     // host-free call: the selection may turn out shorter than the T this launch was sized for (then the call is repeated);
     // its real length is what the select left in sel.want
+    const uint64_t* t_eff_dev = (c->spec_on || c->est_active) ? &c->ctl.as<ControlBlock>()->sel.want : nullptr;
+    if (filter && c->fx_plan.mode == 2 && !c->ref_done)  // the Gram filter's reference frame, where the counting pass did not carry the vote: among 64 hypotheses of the selection
+      launch_gram_ref(points_of(c), tri_source_of(c), sh, nullptr, t_eff_dev, c->fx_mx.as<uint32_t>(), c->dv.tau2, c->tn,
+                      c->fx_frame.p, c->stream);
     launch_kabsch(points_of(c), tri_source_of(c), sh, c->rt.as<float>(), aos ? c->rt_aos.as<float>() : nullptr,
-                  filter ? &job : nullptr, c->stream, (c->spec_on || c->est_active) ? &c->ctl.as<ControlBlock>()->sel.want : nullptr);
+                  filter ? &job : nullptr, c->stream, t_eff_dev);
   } else {
     c->filter_on = false; c->filter_mode = 0;
   }

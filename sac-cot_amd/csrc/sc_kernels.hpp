@@ -51,7 +51,8 @@ struct Tuning {
   uint32_t filter_queue_cap = 0;   // entries of the filter's global queue (0: by size; tests force overflows with a small one)
   uint32_t filter_lds_queue = 0;   // entries of a wave's LDS queue, 64 .. 256 (0: 256)
   uint32_t filter_variant = 0;     // body of the filter kernel (sc_score.hip): 0 default, bit-identical scheduling variants, >= 16 timing-only ablations
-  bool gram_pers = false;          // the Gram filter's persistent one-generation form (score_gram_pers_kernel): built, bit-exact, 3 - 4 % SLOWER than the grid of hypothesis groups x window splits: off
+  uint32_t gram_kappa_q4 = 0;      // the Gram filter's cut: hypotheses whose reach stays under (value / 16) tau' count as NEAR the reference (0 = GX_KAPPA = 8; 1 = practically no cut)
+  bool gram_ref_late = false;      // the Gram filter's reference frame is voted after the selection, in a launch of its own (what every path but the hot one does anyway), instead of under the counting pass
   bool no_fast = false;            // sc_register_device never enqueues host-free (always waits for stage B's two counts)
   bool gram_guard_fail = false;    // the matrix-pipe probe reports a violation (tests of the guard)
   bool tail_fused = false;         // the register path's winner / mask step inside the arg-max launch (measured slower: off)
@@ -236,7 +237,9 @@ struct SamplePlan {
 SamplePlan sample_plan(uint64_t want, bool allow_estimate, const Tuning& tn, uint64_t E = 0, int W = 0);  // E, W: the graph (0: not known: rate <= 64)
 void launch_sample_estimate(const Graph& g, const uint32_t* ebi, const uint32_t* ebj, const uint32_t* ei, const uint32_t* ej,
                             const float* es, uint64_t E, float key_floor, uint32_t rate, uint32_t* hist, const Tuning& tn,
-                            hipStream_t st, const uint64_t* E_dev = nullptr, const uint32_t* ebase = nullptr);  // ebase: with ebi == ebj == nullptr
+                            hipStream_t st, const uint64_t* E_dev = nullptr, const uint32_t* ebase = nullptr,  // ebase: with ebi == ebj == nullptr
+                            uint4* cand = nullptr, unsigned long long* cand_slot = nullptr);  // cand (optional, sample_estimate_blocks() entries): the best-keyed triangle each workgroup sampled {key bits, i, j, k} — the voters of stage C2's reference frame (sc_gramref.hpp)
+uint32_t sample_estimate_blocks(uint64_t E, const Tuning& tn);  // workgroups launch_sample_estimate uses
 // es_hist: PR_HCOPIES x 256 words (control block) for the weight histogram of the heaviest-edge sample: zeroed, or —
 // es_hist_ready — already filled by launch_edge_fill
 // launch_sample_hist ALWAYS accumulates into PR_HCOPIES x 256 words (`hist` = the control block's copies);
@@ -269,6 +272,7 @@ struct EventList {
   uint32_t* overflow;  // host-pinned flag, set when a region is full
   int W;
 };
+struct GramRefJob;
 size_t event_bytes(uint64_t capacity);
 EventList event_list(void* buf, uint64_t capacity, int W, uint32_t* fill, uint32_t* overflow_host);
 // counting pass that also emits the events (replaces launch_tri_count when an event buffer is available)
@@ -276,7 +280,8 @@ void launch_tri_count_events(const Graph& g, const uint64_t* mbits, const Strong
                              const uint32_t* ebj, const uint32_t* ei, const uint32_t* ej, uint64_t E, int rank_mode,
                              uint32_t* tcnt, const EventList& ev, const Tuning& tn, hipStream_t st,
                              const uint64_t* own = nullptr,   // own (optional, device): [lo, hi) of the edges this rank enumerates
-                             const uint32_t* ebase = nullptr);  // with ebi == ebj == nullptr: the per-row CSR bases (launch_edge_build)
+                             const uint32_t* ebase = nullptr,  // with ebi == ebj == nullptr: the per-row CSR bases (launch_edge_build)
+                             const GramRefJob* ref = nullptr); // one extra workgroup votes for stage C2's reference frame (sc_gramref.hpp)
 
 // Radix-select state.  Lives in the context's control block, which ONE memset zeroes per call; key_range_kernel
 // (end of launch_tri_keys) fills kmin / kmax / want.
@@ -315,7 +320,9 @@ struct ControlBlock {
   uint64_t pad1[4];
   SelectState sel;
   uint32_t sel2_hist[2048];  // round 2 of launch_select_final
-  uint32_t sel_r1[SEL2_COPIES * 4096];  // round 1, taken by the key kernel: SEL2_COPIES copies by workgroup index
+  uint32_t sel_r1[SEL2_COPIES * 4096];  // round 1, taken by the key kernel: SEL2_COPIES copies by workgroup index  // stage C2's reference frame (sc_gramref.hpp): slot v = the best (key bits << 32 | workgroup) among the workgroups = v (mod 64) of the
+  // estimating sample — its voter v is that workgroup's candidate triangle
+  alignas(8) unsigned long long ref_slot[64];
 };
 static_assert(offsetof(ControlBlock, sel) % 16 == 0, "ControlBlock::sel must be 16-byte aligned");
 
@@ -479,20 +486,21 @@ void launch_score(const Points& pts, const float* RtSoA, const float* RtAoS, con
 struct FilterPlan {
   uint32_t mode;  // 1 linear, 2 Gram
   uint32_t windows, splits, n_waves, rows, queue_cap;
-  // Gram filter, persistent form (r04; sc_debug gram_pers, NOT the default — measured slower): the launch is ONE generation of workgroups, each walking a contiguous run
-  // of (hypothesis group, 256-correspondence unit) items; counts are accumulated into ONE row (splits == 1) by atomics and the
-  // exact pass's wholesale recounts are per (8 hypotheses, unit): bm_rows == units.  0: the split form (bm_rows == splits).
-  uint32_t units, bm_rows;
-  size_t tile_bytes, state_bytes, coef_bytes;  // coef_bytes: the Gram filter's per-hypothesis coefficients (0 for the linear one)
+  size_t tile_bytes, state_bytes, coef_bytes;  // coef_bytes: the Gram filter's per-hypothesis coefficients and its two permutations (0 for the linear one)
 };
-// Gram filter: what its waves load instead of computing it (made once per call: launch_kabsch's threads, or launch_gram_coef)
+// Gram filter: what its waves load instead of computing it (made once per call: launch_kabsch's threads, or launch_gram_coef).
+// Rows are PERMUTED: hypotheses near the call's reference frame first (sc_score.hip, "the cut"); so are the tile's rows.
+struct GramFrame;
 struct GramCoef {
-  void* A;            // 64 bytes per hypothesis: fp16 halves of its 16 coefficients
-  float* C;           // accumulator start value per hypothesis
-  uint2* wave;        // per 32 hypotheses: {shell width W (fp32 bits), recount groups | any row filtered << 4}
-  uint32_t n_waves32;
+  void* A;            // 64 bytes per row: fp16 halves of its 16 coefficients
+  float* C;           // accumulator start value per row
+  float* W;           // shell width per row (0: not filtered)
+  uint32_t* flag;     // bit 0 filtered, bit 1 recount, bits 8.. log2 of the largest alpha
+  uint32_t* hperm;    // coefficient row -> hypothesis of this rank's shard
+  uint32_t* pperm;    // tile row -> correspondence
+  GramFrame* frame;   // the call's frame and the four class counters (in the filter's state buffer)
 };
-GramCoef gram_coef_view(void* buf, uint32_t ld_local);
+GramCoef gram_coef_view(void* buf, uint32_t ld_local, void* frame);
 // which kernel stage C2 runs: 0 = plain fp32 kernel, 1 = linear filter, 2 = Gram filter.  By score mode, size, the knobs of
 // sc_debug and — unless forced — by whether tau is on a scale the filter can bound (host_max / host_box: the coordinate
 // maxima and bounding boxes the staging kernel published; ~0 = not known: assume the linear filter applies, never Gram).
@@ -502,17 +510,25 @@ FilterPlan filter_plan(int n, uint32_t ld_local, const Tuning& tn, uint32_t mode
 struct FilterTileJob {  // what the tile kernel needs (filter_tile_job fills it)
   uint32_t rows; const uint32_t* mx_cur; uint32_t* mx_next; void* tile; void* info; uint32_t* zero; uint32_t zero_words; uint32_t mode;
   GramCoef coef; float tau2;  // mode 2: the Kabsch threads of the same launch also write their hypotheses' coefficients
-  uint32_t* zero2; uint32_t zero2_words;  // a second buffer cleared on the way (the persistent Gram filter's count row: it ADDS)
 };
-// partial (optional): the count row of the persistent Gram form (ld_local words), cleared by the tile job
 FilterTileJob filter_tile_job(const FilterPlan& fp, const uint32_t* mx_cur, uint32_t* mx_next, void* tile, void* state,
-                              void* coef, uint32_t ld_local, float tau2, uint32_t* partial = nullptr);
+                              void* coef, uint32_t ld_local, float tau2, void* frame);
+// Gram filter: the call's reference frame (sc_gramref.hpp; `frame`: gram_frame_bytes() of device memory, per context).  One
+// workgroup votes for it among 64 hypotheses and clears the class counters — BEFORE the tile and the coefficients are made.  In a
+// launch of its own (launch_gram_ref: RtSoA = the hypotheses if they exist already — stage hook —, else null: they are solved
+// from the selection `ts`), or, on the hot path, as an extra workgroup of the counting pass (launch_tri_count_events, `ref`) fed
+// by the candidate triangles the estimating sample leaves behind (launch_sample_estimate, `cand`).
+size_t gram_frame_bytes();
+struct GramRefJob;
+GramRefJob gram_ref_job(const Points& pts, const uint32_t* mx, float tau2, const Tuning& tn, void* frame);  // (source left empty)
+void launch_gram_ref(const Points& pts, const TriSource& ts, const Shard& sh, const float* RtSoA, const uint64_t* t_eff_dev,
+                     const uint32_t* mx, float tau2, const Tuning& tn, void* frame, hipStream_t st);
 // the coefficients on their own (stage hook sc_score_host, which has no Kabsch launch)
-void launch_gram_coef(const float* RtSoA, const Shard& sh, float tau2, const uint32_t* mx, const GramCoef& coef, hipStream_t st);
+void launch_gram_coef(const float* RtSoA, const Shard& sh, float tau2, const GramCoef& coef, hipStream_t st);
 void launch_filter_tile(const Points& pts, const FilterTileJob& job, hipStream_t st);  // on its own (stage hook sc_score_host)
 // RtAoS: 12 consecutive floats per hypothesis (what the exact pass loads; launch_kabsch / the stage hook write them)
 void launch_score_filter(const Points& pts, const float* RtSoA, const float* RtAoS, const Shard& sh, const Derived& dv,
-                         const FilterPlan& fp, const void* tile, void* state, void* coef, uint32_t* partial, const Tuning& tn,
+                         const FilterPlan& fp, const void* tile, void* state, void* coef, void* frame, uint32_t* partial, const Tuning& tn,
                          hipStream_t st, hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr);
 // Run-time probe of the matrix pipe's accumulation arithmetic (the model the Gram filter's bound assumes; sc_score.hip):
 // blocking, ~1e6 cancelling dot products.  scratch: 16 bytes of device memory.  worst_units: largest |hardware - exact| /
@@ -522,6 +538,8 @@ float gram_guard_limit();
 bool filter_ablations_built();  // -DSC_ABLATIONS: the scheduling / timing-only variants of the filter kernels exist (Tuning::filter_variant)
 // diagnostics (sc_debug_last): what the filter of the last launch handed to the exact pass.  Blocking copies on `st`.
 hipError_t filter_read_counters(const void* state, const FilterPlan& fp, hipStream_t st, uint64_t* undecided, uint64_t* recounts);
+// Gram filter: {near correspondences, near hypotheses, hypotheses in the grid, the reference's position in the shard (~0: none), its vote x 256}
+hipError_t filter_read_frame(const void* frame, hipStream_t st, uint32_t out[5]);
 // Winner key pair key2[0..1] (written, not accumulated: no zeroing needed):
 //   key2[0] = max over hypotheses with count > 0 of  (count << 32) | second,   second = sel_key[g] (the triangle's
 //             ranking key) or, when sel_key == nullptr, 0xFFFFFFFF - g;

@@ -11,22 +11,20 @@
 //                   compare and one add-with-carry: 17 VALU instructions per test;
 //   grid          = ceil(T/256) x chunks, so a 50k x 5k problem is ~1000 workgroups (~4 waves per SIMD);
 //   partial counts are stored coalesced ([chunk][hypothesis]) and summed by the arg-max kernel.
+#include <cstddef>
 #include <vector>
 #include <hip/hip_ext.h>
 
 #include "sc_arith.hpp"
 #include "sc_block.hpp"
 #include "sc_kernels.hpp"
+#include "sc_gramref.hpp"
 
 namespace sc {
 
 // ------------------------------------------------------------------------------------------------
 // sharding of the ranked list: blocks of `block` triangles dealt round-robin to ranks
 // ------------------------------------------------------------------------------------------------
-__host__ __device__ __forceinline__ uint32_t shard_global_index(uint32_t l, uint32_t block, uint32_t rank,
-                                                                uint32_t world) {
-  return ((l / block) * world + rank) * block + (l % block);
-}
 
 uint32_t shard_local_count(uint32_t T_eff, uint32_t block, uint32_t rank, uint32_t world) {
   uint64_t n = 0;
@@ -38,7 +36,7 @@ uint32_t shard_local_count(uint32_t T_eff, uint32_t block, uint32_t rank, uint32
 }
 
 // ---- Gram filter: constants shared by host and device -------------------------------------------------------------
-constexpr int GX_UNIT = 256;     // correspondences per staging unit (8 MFMA steps of 32): 16 KiB; LDS holds two
+constexpr int GX_UNIT = 256;     // correspondences per staging unit (8 MFMA steps of 32): 16 KiB; LDS holds three
 constexpr int GX_TILE_B = 64;    // bytes of the tile per correspondence: hi halves and lo halves of its 16 features
 constexpr int GX_TILE_Q = GX_TILE_B / 16;  // ... in 16-byte pieces
 constexpr int GX_WAVES = 8;      // waves per workgroup, 32 hypotheses each: eight waves share a tile, so each of them issues three 1 KiB
@@ -47,98 +45,33 @@ constexpr int GX_QL = 128;       // LDS queue entries per wave (8 bytes each)
 constexpr float GX_RS = 256.0f;  // scale of the A operand (keeps the low halves of the coefficients out of fp16's sub-normal range)
 constexpr double GX_ACC = 1.1e-6;    // 18.5 x 2^-24: error of one MFMA per unit of its LARGEST term (five times the largest seen: score_gram_kernel)
 constexpr double GX_Q = 7.5e-7;      // 3.01 x 2^-22 (+ margin): the dropped lo x lo products and split remainders per unit of sum |w F|
-constexpr double GX_NORM = 2.5e-7;   // 2^-22 (+ margin): what the norm feature's two fp16 pieces leave, per unit of Pn^2 + Qn^2
+constexpr double GX_NORM = 2.5e-7;   // 2^-22 (+ margin): what the norm feature's two fp16 pieces leave, per unit of max |V'|^2
 constexpr double GX_CANON = 4.2e-7;  // sqrt(3) * 4 * 2^-24: deviation of the canonical fp32 residual VECTOR per unit of magnitude
-struct GramInfo {  // written by the tile kernel (thread 0), at offset 64 of the filter's info area
-  float s;         // power of two: the largest half extent of either bounding box -> [64, 128)
-  float cP[3], cQ[3];  // centres of the boxes (fp32; the shift is applied in fp64)
-  float Pn, Qn;    // upper bounds of |P'|, |Q'| (scaled, centred Euclidean norms)
-  float pmax_o, qmax_o;  // max |coordinate| of the original (unscaled, uncentred) clouds: what the canonical chain rounds at
-  float pad[5];
-};
-// scale, centres and norm bounds from the bounding boxes (keys as the staging kernel leaves them: [c] max, [6 + c] -min)
-__host__ __device__ inline GramInfo gram_info(const uint32_t* key_hi, const uint32_t* key_lo, float pmax_o, float qmax_o) {
-  GramInfo g;
-  double half[6], hmax = 0.0;
-  for (int c = 0; c < 6; c++) {
-    const float mx = float_unkey(key_hi[c]), mn = -float_unkey(key_lo[c]);
-    const float ctr = 0.5f * mx + 0.5f * mn;
-    (c < 3 ? g.cP[c] : g.cQ[c - 3]) = ctr;
-    const double a = (double)mx - (double)ctr, b = (double)ctr - (double)mn;
-    half[c] = a > b ? a : b;
-    hmax = half[c] > hmax ? half[c] : hmax;
-  }
-  int e = 0;
-  if (hmax > 0.0) {  // hmax in [2^e, 2^(e+1))
-    union { double d; uint64_t u; } x; x.d = hmax;
-    e = (int)((x.u >> 52) & 2047u) - 1023;
-  }
-  int k = 6 - e;
-  k = k > 100 ? 100 : (k < -100 ? -100 : k);
-  union { float f; uint32_t u; } sc; sc.u = (uint32_t)(k + 127) << 23;
-  g.s = sc.f;
-  const double s = (double)g.s;
-  const double pn = s * sqrt(half[0] * half[0] + half[1] * half[1] + half[2] * half[2]) * (1.0 + 1e-6);
-  const double qn = s * sqrt(half[3] * half[3] + half[4] * half[4] + half[5] * half[5]) * (1.0 + 1e-6);
-  g.Pn = (float)(pn * (1.0 + 1e-6)); g.Qn = (float)(qn * (1.0 + 1e-6));
-  g.pmax_o = pmax_o; g.qmax_o = qmax_o;
-  for (int i = 0; i < 5; i++) g.pad[i] = 0.f;
-  return g;
+// shell half-width of a hypothesis, in units of the scaled squared residual.  F = |dM|_F, m = max |dM_ij|, Tn = |tau'|, g = the defect of
+// R^T R; the correspondences it is tested against have |V'| <= vb and |Q'| <= Qb.  Mh: the largest single term of the 48-term
+// dot product; Sl: the sum of the absolute values of the 15 split terms; S: the sum of all |terms|.  (Derivation: score_gram_kernel.)
+__host__ __device__ inline double gram_eps(double F, double m, double Tn, double g, double Pn, double Qb, double vb, double st) {
+  const double t1 = 2.0 * (m + 1.5 * g) * Qb * Pn, t2 = vb * vb, t3 = 2.0 * F * Tn * Pn, t4 = 2.0 * Tn * vb, t5 = Tn * Tn + 1.5 * st * st;
+  double Mh = t1;
+  Mh = t2 > Mh ? t2 : Mh; Mh = t3 > Mh ? t3 : Mh; Mh = t4 > Mh ? t4 : Mh; Mh = t5 > Mh ? t5 : Mh;
+  Mh *= 1.05;
+  const double Sl = 2.0 * (F + 4.5 * g) * Qb * Pn + t3 + t4, S = Sl + t2 + t5;
+  return GX_ACC * Mh + GX_Q * Sl + GX_NORM * t2 + 1e-8 * S + 3.0 * g * vb * Pn + 1e-4;
 }
-// shell half-width of a hypothesis with |T'| = Tn at st = s tau, in units of the scaled squared residual (the device adds its
-// own R^T R defect term per hypothesis).  Mh: the largest single term of the 48-term dot product (2 |Q'_i P'_j| <= Pn^2 + Qn^2);
-// Sl: the sum of the absolute values of the 15 split terms.
-__host__ __device__ inline double gram_eps(double Tn, double Pn, double Qn, double st) {
-  const double pq = Pn > Qn ? Pn : Qn;
-  double Mh = 1.05 * (Pn * Pn + Qn * Qn);
-  const double m2 = Tn * Tn + 1.5 * st * st, m3 = 2.1 * Tn * pq;
-  Mh = m2 > Mh ? m2 : Mh;
-  Mh = m3 > Mh ? m3 : Mh;
-  const double Sl = 3.5 * Pn * Qn + 2.02 * Tn * Pn + 2.0 * Tn * Qn, S = Tn + 1.75 * Pn + Qn;
-  // GX_NORM: the norm feature travels in TWO fp16 pieces (22 bits), times its coefficient 2
-  return GX_ACC * Mh + GX_Q * Sl + GX_NORM * (Pn * Pn + Qn * Qn) + 1e-8 * S * S + 1e-4;
+// the same with the SUM of the terms in place of their maximum: an upper bound of gram_eps that is a quadratic in vb with positive
+// coefficients (gram_coef_block: a shell made for |V'| <= vb_h is safe beyond vb_h if this stays under 0.1 tau'^2)
+__host__ __device__ inline double gram_eps_sum(double F, double m, double Tn, double g, double Pn, double Qb, double vb, double st) {
+  const double t1 = 2.0 * (m + 1.5 * g) * Qb * Pn, t2 = vb * vb, t3 = 2.0 * F * Tn * Pn, t4 = 2.0 * Tn * vb, t5 = Tn * Tn + 1.5 * st * st;
+  const double Sl = 2.0 * (F + 4.5 * g) * Qb * Pn + t3 + t4, S = Sl + t2 + t5;
+  return GX_ACC * 1.05 * (t1 + t2 + t3 + t4 + t5) + GX_Q * Sl + GX_NORM * t2 + 1e-8 * S + 3.0 * g * vb * Pn + 1e-4;
 }
 
 // ------------------------------------------------------------------------------------------------
 // C1
 // ------------------------------------------------------------------------------------------------
-// the three correspondences of a triangle, from the AoS copy behind the planes (8 floats each: two 16-byte loads per
-// vertex instead of six scattered 4-byte gathers)
-__device__ __forceinline__ void load_triangle(const float* __restrict__ planes, int ld, const uint32_t* tri3,
-                                              float P[9], float Q[9]) {
-  const float4* __restrict__ aos4 = reinterpret_cast<const float4*>(planes + 6 * (size_t)ld);
-#pragma unroll
-  for (int m = 0; m < 3; m++) {
-    const uint32_t v = tri3[m];
-    const float4 a = aos4[2 * (size_t)v], b = aos4[2 * (size_t)v + 1];
-    P[3 * m] = a.x; P[3 * m + 1] = a.y; P[3 * m + 2] = a.z;
-    Q[3 * m] = a.w; Q[3 * m + 1] = b.x; Q[3 * m + 2] = b.y;
-  }
-}
-
-// triangle g of the selected list, straight from the selection (two dependent lookups, no materialised list)
-// false: the selection holds something that must not be followed (TriSource::lim_*: host-free calls that will be repeated)
-__device__ __forceinline__ bool tri_lookup(const TriSource& ts, uint32_t g, uint32_t v[3]) {
-  if (ts.cand_recs) {  // sharded stage B: the record travels with the candidate
-    const uint64_t pos = ts.sel_ord[g], sg = pos / ts.cand_seg;
-    const uint4 rec = ts.cand_recs[sg * ts.cand_stride + (pos - sg * ts.cand_seg)];
-    v[0] = rec.x; v[1] = rec.y; v[2] = rec.z;
-    return true;
-  }
-  const uint64_t ord = ts.sel_ord[g];
-  if (ts.lim_ord && ord >= ts.lim_ord) return false;
-  const uint2 ke = ts.kcol[ord];
-  if (ts.lim_edge && ke.y >= ts.lim_edge) return false;
-  v[0] = ts.ei[ke.y];
-  v[1] = ts.ej[ke.y];
-  v[2] = ke.x;
-  return !ts.lim_vertex || (v[0] < ts.lim_vertex && v[1] < ts.lim_vertex && v[2] < ts.lim_vertex);
-}
-
 __device__ void filter_tile_block(const float* __restrict__ planes, int n, int ld, const FilterTileJob& job, uint32_t block,
                                   uint32_t blocks);
-__device__ void gram_coef_wave(const GramCoef& coef, const GramInfo& gi, const float v[12], uint32_t l, uint32_t ldl,
-                               uint32_t n_local, float tau2);
+__device__ void gram_coef_block(const GramCoef& coef, const float v[12], uint32_t l, uint32_t ldl, uint32_t n_local, float tau2);
 
 __global__ __launch_bounds__(256) void kabsch_shard_kernel(const float* __restrict__ planes, int n, int ld, TriSource ts,
                                                            Shard sh, float* __restrict__ RtSoA,
@@ -149,13 +82,7 @@ __global__ __launch_bounds__(256) void kabsch_shard_kernel(const float* __restri
     filter_tile_block(planes, n, ld, job, blockIdx.x - kabsch_blocks, gridDim.x - kabsch_blocks);
     return;
   }
-  __shared__ GramInfo s_gi;
-  if (job.mode == 2) {  // (block-uniform) the Gram filter's scale and centres, once per block
-    if (threadIdx.x == 0) s_gi = gram_info(job.mx_cur + 2, job.mx_cur + 8, __uint_as_float(job.mx_cur[0]), __uint_as_float(job.mx_cur[1]));
-    __syncthreads();
-  }
-  const uint32_t l = blockIdx.x * 256 + threadIdx.x;
-  if (l >= sh.ld_local) return;
+  const uint32_t l = blockIdx.x * 256 + threadIdx.x;  // < ld_local: a multiple of 256, kabsch_blocks = ld_local / 256
   float Rt[12];
   // t_eff_dev: the launch was sized for sh.T_eff = the requested T before the host knew how many triangles there are; a
   // position beyond the real selection holds nothing that may be dereferenced (the host repeats such a call: sc_capi.hip)
@@ -177,8 +104,8 @@ __global__ __launch_bounds__(256) void kabsch_shard_kernel(const float* __restri
     o[1] = make_float4(Rt[4], Rt[5], Rt[6], Rt[7]);
     o[2] = make_float4(Rt[8], Rt[9], Rt[10], Rt[11]);
   }
-  // the Gram filter's coefficients of this hypothesis (whole waves get here: ld_local is a multiple of 256)
-  if (job.mode == 2) gram_coef_wave(job.coef, s_gi, Rt, l, sh.ld_local, sh.n_local, job.tau2);
+  // the Gram filter's coefficients of this hypothesis (whole workgroups get here: ld_local is a multiple of 256)
+  if (job.mode == 2) gram_coef_block(job.coef, Rt, l, sh.ld_local, sh.n_local, job.tau2);
 }
 
 void launch_kabsch(const Points& pts, const TriSource& ts, const Shard& sh, float* RtSoA, float* RtAoS,
@@ -648,6 +575,7 @@ constexpr int FX_NQ = 256;      // global sub-queues (one ticket counter for ~60
 constexpr int FX_QL = 256;      // LDS queue entries per wave
 constexpr int FX_WAVES = 4;     // waves per workgroup, 8 hypotheses each
 struct FilterInfo { float s, pmax, qmax, pad; };
+constexpr size_t FX_INFO_BYTES = 512;
 
 struct FilterState {  // device view of the state buffer (filter_plan().state_bytes)
   FilterInfo* info;   // written by the tile kernel
@@ -660,10 +588,10 @@ struct FilterState {  // device view of the state buffer (filter_plan().state_by
 static FilterState filter_state(void* state, const FilterPlan& fp) {
   FilterState f;
   unsigned char* p = static_cast<unsigned char*>(state);
-  f.info = reinterpret_cast<FilterInfo*>(p); p += 128;
+  f.info = reinterpret_cast<FilterInfo*>(p); p += FX_INFO_BYTES;  // (the Gram filter's frame sits at offset 64)
   f.qcount = reinterpret_cast<uint32_t*>(p); p += (size_t)FX_NQ * 128;
   f.redo = reinterpret_cast<uint32_t*>(p);
-  const size_t bm_words = ((size_t)fp.bm_rows * fp.n_waves + 31) / 32;
+  const size_t bm_words = ((size_t)fp.splits * fp.n_waves + 31) / 32;
   p += (bm_words * 4 + 127) / 128 * 128;
   f.queue = reinterpret_cast<uint2*>(p);
   f.cap_sq = fp.queue_cap / FX_NQ;
@@ -687,16 +615,30 @@ int score_filter_mode(int score_mode, const Tuning& tn, int n, uint32_t ld_local
   if (tn.score_filter == 3) return gram_fits ? 2 : 1;
   if (!big) return 0;
   if (host_max == ~0ull) return 1;  // statistics not known: the linear filter sorts itself out (it recounts what it cannot bound)
-  if (gram_fits && host_box) {  // Gram: tau must stand well clear of the cancellation error of the squared form
-    uint32_t kh[6], kl[6];
-    for (int c = 0; c < 6; c++) { kh[c] = (uint32_t)host_box[c]; kl[c] = (uint32_t)(host_box[c] >> 32); }
-    union { uint32_t u; float f; } a, b;
-    a.u = (uint32_t)host_max; b.u = (uint32_t)(host_max >> 32);
-    const GramInfo g = gram_info(kh, kl, a.f, b.f);
-    const double st = (double)g.s * sqrt((double)tau2);
-    const double eps = gram_eps(0.25 * ((double)g.Pn + (double)g.Qn), g.Pn, g.Qn, st);  // a hypothesis a quarter of the clouds' size off centre
-    const double dE = GX_CANON * (double)g.s * ((double)g.qmax_o + 1.75 * (double)g.pmax_o + (double)g.qmax_o);
-    if (eps <= 0.03 * st * st && dE <= 0.02 * st && st <= 64.0 && st >= 0.5) return 2;
+  if (gram_fits && host_box) {
+    // Gram: even a hypothesis FAR from the call's reference frame (dM of size 1, tau' a quarter of the clouds, every
+    // correspondence looked at) must keep its shell well inside tau'^2 — the NEAR ones are two orders of magnitude better off.
+    // The frame itself is voted on the device later; here it is taken to map one box's centre onto the other's.
+    double hP2 = 0.0, hQ2 = 0.0, hmax = 0.0;
+    for (int c = 0; c < 6; c++) {
+      const float mx = float_unkey((uint32_t)host_box[c]), mn = -float_unkey((uint32_t)(host_box[c] >> 32));
+      const float ctr = 0.5f * mx + 0.5f * mn;
+      const double a = (double)mx - (double)ctr, b = (double)ctr - (double)mn, h = a > b ? a : b;
+      (c < 3 ? hP2 : hQ2) += h * h;
+      if (c < 3 && h > hmax) hmax = h;
+    }
+    const double hQn = sqrt(hQ2);
+    hmax = hQn > hmax ? hQn : hmax;
+    union { uint32_t u; float f; } pa, qa;
+    pa.u = (uint32_t)host_max; qa.u = (uint32_t)(host_max >> 32);
+    if (hmax > 0.0 && hmax < 1e30) {
+      int e = 0;
+      (void)frexp(hmax, &e);  // hmax in [2^(e-1), 2^e)
+      const double s = ldexp(1.0, 6 - e), Pn = s * sqrt(hP2), Qn = s * hQn, st = s * sqrt((double)tau2);
+      const double eps = gram_eps(2.0, 1.0, 0.25 * (Pn + Qn), 3e-7, Pn, Qn, Pn + Qn, st);
+      const double dE = GX_CANON * s * ((double)qa.f + 1.75 * (double)pa.f + (double)qa.f);
+      if (eps <= 0.2 * st * st && dE <= 0.02 * st && st <= 32.0 && st >= 0.2) return 2;
+    }
   }
   return filter_in_range(host_max, tau2) ? 1 : 0;
 }
@@ -740,12 +682,6 @@ FilterPlan filter_plan(int n, uint32_t ld_local, const Tuning& tn, uint32_t mode
     const uint32_t per = (fp.windows + fp.splits - 1) / fp.splits;
     fp.splits = (fp.windows + per - 1) / per;
   }
-  fp.units = 0; fp.bm_rows = fp.splits;
-  if (mode == 2 && tn.gram_pers && !tn.filter_splits) {  // the persistent form (see score_gram_pers_kernel)
-    fp.units = fp.windows * (FX_WIN / GX_UNIT);
-    fp.splits = 1;
-    fp.bm_rows = fp.units;
-  }
   fp.rows = fp.windows * FX_WIN + (mode == 2 ? GX_UNIT : FX_UNIT);
   uint64_t cap = (uint64_t)ld_local * (uint64_t)n / 512;  // ~20x what the BASELINE scenes queue
   if (cap < (1u << 16)) cap = 1u << 16;
@@ -754,9 +690,10 @@ FilterPlan filter_plan(int n, uint32_t ld_local, const Tuning& tn, uint32_t mode
   fp.queue_cap = (uint32_t)(cap / FX_NQ * FX_NQ);
   if (fp.queue_cap < FX_NQ) fp.queue_cap = FX_NQ;
   fp.tile_bytes = (size_t)fp.rows * (mode == 2 ? GX_TILE_B : 32);
-  const size_t bm_words = ((size_t)fp.bm_rows * fp.n_waves + 31) / 32;
-  fp.state_bytes = 128 + (size_t)FX_NQ * 128 + (bm_words * 4 + 127) / 128 * 128 + (size_t)fp.queue_cap * 8;
-  fp.coef_bytes = mode == 2 ? (size_t)ld_local * 64 + (size_t)ld_local * 4 + (size_t)(ld_local / 32) * 8 : 0;
+  const size_t bm_words = ((size_t)fp.splits * fp.n_waves + 31) / 32;
+  fp.state_bytes = FX_INFO_BYTES + (size_t)FX_NQ * 128 + (bm_words * 4 + 127) / 128 * 128 + (size_t)fp.queue_cap * 8;
+  // Gram: per coefficient row 64 bytes of fp16 halves + C, W, flag, hperm; per tile row pperm
+  fp.coef_bytes = mode == 2 ? (size_t)ld_local * (64 + 16) + (size_t)fp.rows * 4 : 0;
   return fp;
 }
 
@@ -1036,24 +973,30 @@ __global__ __launch_bounds__(256) void score_exact_kernel(const float* __restric
                                                           const uint2* __restrict__ gq, uint32_t cap_sq,
                                                           const uint32_t* __restrict__ qcount,
                                                           const uint32_t* __restrict__ redo_bits,
-                                                          uint32_t* __restrict__ cnt_out, uint32_t gram) {
+                                                          uint32_t* __restrict__ cnt_out,
+                                                          const uint32_t* __restrict__ hperm,
+                                                          const uint32_t* __restrict__ pperm) {
+  // hperm / pperm (the Gram filter; null for the linear one): its rows are PERMUTED — coefficient row -> hypothesis, tile row ->
+  // correspondence.  Queue entries and recount bits speak of rows; the counts and the canonical chain of hypotheses and correspondences.
+  const bool gram = hperm != nullptr;
   const uint32_t per = (windows + splits - 1) / splits;
   const float4* __restrict__ aos4 = reinterpret_cast<const float4*>(planes + 6 * (size_t)ld);  // 8 floats per correspondence
   const uint32_t sq = blockIdx.x % FX_NQ, nq = min(qcount[sq * 32], cap_sq);
   for (uint32_t i = (blockIdx.x / FX_NQ) * 256 + threadIdx.x; i < nq; i += (gridDim.x / FX_NQ) * 256) {
     const uint2 e = gq[(size_t)sq * cap_sq + i];
-    if (gram) {  // Gram filter: {correspondence, wave of 32 << 17 | lane half << 16 | one bit per accumulator register}
-      // gram == 2 (the persistent form): recounts are per (8 hypotheses, 256-correspondence UNIT) and the counts live in ONE row
-      const uint32_t m = e.x, w32 = e.y >> 17, ehf = (e.y >> 16) & 1u, sp = gram == 2 ? m / (uint32_t)GX_UNIT : (m / FX_WIN) / per;
+    if (gram) {  // {tile row, wave of 32 rows << 17 | lane half << 16 | one bit per accumulator register}
+      const uint32_t mr = e.x, w32 = e.y >> 17, ehf = (e.y >> 16) & 1u, sp = (mr / FX_WIN) / per;
+      const uint32_t m = pperm[mr];
       const float4 pa = aos4[2 * (size_t)m], pb = aos4[2 * (size_t)m + 1];
       for (uint32_t bits = e.y & 0xFFFFu; bits; bits &= bits - 1) {
-        const uint32_t i16 = (uint32_t)(__ffs(bits) - 1), row = 8 * (i16 >> 2) + 4 * ehf + (i16 & 3u), h = w32 * 32 + row;
-        const size_t bit = (size_t)sp * n_waves + (h >> 3);
+        const uint32_t i16 = (uint32_t)(__ffs(bits) - 1), row = 8 * (i16 >> 2) + 4 * ehf + (i16 & 3u), hr = w32 * 32 + row;
+        const size_t bit = (size_t)sp * n_waves + (hr >> 3);
         if ((redo_bits[bit >> 5] >> (bit & 31)) & 1u) continue;  // recounted as a whole below
+        const uint32_t h = hperm[hr];
         float M[12];
         load_rt_aos(RtAoS, h, M);
         const float d2 = resid2(M, pa.x, pa.y, pa.z, pa.w, pb.x, pb.y);
-        if (finite12(M) && d2 < tau2) atomicAdd(&cnt_out[(gram == 2 ? (size_t)0 : (size_t)sp * ldl) + h], 1u);
+        if (finite12(M) && d2 < tau2) atomicAdd(&cnt_out[(size_t)sp * ldl + h], 1u);
       }
       continue;
     }
@@ -1069,21 +1012,22 @@ __global__ __launch_bounds__(256) void score_exact_kernel(const float* __restric
       if (finite12(M) && d2 < tau2) atomicAdd(&cnt_out[(size_t)sp * ldl + h], 1u);
     }
   }
-  const size_t nbits = (size_t)(gram == 2 ? windows * (uint32_t)(FX_WIN / GX_UNIT) : splits) * n_waves;
+  const size_t nbits = (size_t)splits * n_waves;
   for (size_t w = blockIdx.x; w < (nbits + 31) / 32; w += gridDim.x) {
     uint32_t word = redo_bits[w];
     while (word) {
       const size_t bit = w * 32 + (size_t)(__ffs(word) - 1);
       word &= word - 1;
       const uint32_t sp = (uint32_t)(bit / n_waves), wid = (uint32_t)(bit % n_waves);
-      const uint32_t h = wid * 8 + (threadIdx.x & 7);
+      const uint32_t hr = wid * 8 + (threadIdx.x & 7), h = gram ? hperm[hr] : hr;
       float M[12];
       load_rt_aos(RtAoS, h, M);
       const bool ok = finite12(M);
-      const uint32_t m0 = gram == 2 ? sp * (uint32_t)GX_UNIT : sp * per * FX_WIN;
-      const uint32_t m1 = gram == 2 ? min((uint32_t)n, (sp + 1) * (uint32_t)GX_UNIT) : min((uint32_t)n, min(windows, (sp + 1) * per) * FX_WIN);
+      // (every row of the split: for a NEAR hypothesis that is more than its filter workgroup looked at — exact all the same)
+      const uint32_t m0 = sp * per * FX_WIN, m1 = min((uint32_t)n, min(windows, (sp + 1) * per) * FX_WIN);
       uint32_t cnt = 0;
-      for (uint32_t m = m0 + (threadIdx.x >> 3); m < m1; m += 32) {
+      for (uint32_t mr = m0 + (threadIdx.x >> 3); mr < m1; mr += 32) {
+        const uint32_t m = gram ? pperm[mr] : mr;
         const float4 pa = aos4[2 * (size_t)m], pb = aos4[2 * (size_t)m + 1];
         const float d2 = resid2(M, pa.x, pa.y, pa.z, pa.w, pb.x, pb.y);
         cnt += (ok && d2 < tau2) ? 1u : 0u;
@@ -1091,30 +1035,46 @@ __global__ __launch_bounds__(256) void score_exact_kernel(const float* __restric
       cnt += __shfl_xor(cnt, 8);
       cnt += __shfl_xor(cnt, 16);
       cnt += __shfl_xor(cnt, 32);
-      if ((threadIdx.x & 63) < 8 && cnt) atomicAdd(&cnt_out[(gram == 2 ? (size_t)0 : (size_t)sp * ldl) + h], cnt);
+      if ((threadIdx.x & 63) < 8 && cnt) atomicAdd(&cnt_out[(size_t)sp * ldl + h], cnt);
     }
   }
 }
 
 // ------------------------------------------------------------------------------------------------
-// C2, inlier count, the GRAM filter (r03): the matrix pipe evaluates the squared residual itself.
+// C2, inlier count, the GRAM filter (r03): the matrix pipe evaluates the squared residual itself — since r04b in the FRAME OF A
+// REFERENCE HYPOTHESIS, which (a) makes the cancelling terms small exactly where precision is needed and (b) lets most tests be
+// skipped with a proof instead of being evaluated.
 //
-// With P' = s (p - cP), Q' = s (q - cQ) (s a power of two, cP / cQ the centres of the clouds' bounding boxes, so that
-// every coordinate is below 128) and T' = s (t + R cP - cQ), in exact arithmetic
-//     s^2 |R p + t - q|^2 = |R P' + T' - Q'|^2
-//                        = P'^T (R^T R) P' + |Q'|^2 + |T'|^2 + 2 (R^T T') . P' - 2 T' . Q' - 2 sum_ij R_ij Q'_i P'_j .
-// For a rotation R^T R = I, and the right-hand side is a DOT PRODUCT of 16 features of the correspondence
-//     Q'_i P'_j (9), (|P'|^2 + |Q'|^2) / 2, P'_j (3), Q'_i (3)                       (tile kernel, fp64, once per call)
-// with 16 coefficients of the hypothesis  -2 R_ij, 2, 2 (R^T T')_j, -2 T'_i  plus the constant |T'|^2  (kernel prologue, fp64).
-// Features and coefficients are split into two fp16 halves; hi x hi, hi x lo and
-// lo x hi products are kept: 48 slots = three chained v_mfma_f32_32x32x16_f16, rows = 32 hypotheses, columns = 32
-// correspondences, accumulator initialised to |T'|^2 - LO: a lane then holds x = D~ - LO for 16 hypotheses of one
+// The frame.  gram_ref_kernel lets GX_VOTE hypotheses spread over the ranked list vote for the one most of them agree with
+// (R0, t0; R0 rebuilt orthogonal in fp64 — ANY rotation is a valid frame, a good one is only faster).  With c the centre of the
+// source cloud's box and s a power of two,
+//     P' = s (p - c),   Q' = s (R0^T (q - t0) - c),   V' = Q' - P'          (per correspondence; every |coordinate| < 64)
+//     M  = R0^T R_h,    dM = M - I,    tau' = s (R0^T (t_h - t0) + dM c)     (per hypothesis; fp64)
+// and because R0 is orthogonal, in exact arithmetic
+//     s^2 |R_h p + t_h - q|^2 = |dM P' + tau' - V'|^2
+//         = sum_ij (-2 dM_ij + G_ij) Q'_i P'_j + |V'|^2 + |tau'|^2 + 2 (dM^T tau') . P' - 2 tau' . V'  -  V'^T G P' ,
+// G = R_h^T R_h - I the hypothesis' own defect (~1e-7 for a Kabsch result; the last term, <= 3 g |V'| |P'|, goes into the bound).
+// That is a DOT PRODUCT of 16 features of the correspondence
+//     Q'_i P'_j (9), |V'|^2 / 2, 256 P'_j (3), 256 V'_i (3)                         (tile workgroups of the Kabsch launch, fp64)
+// with 16 coefficients of the hypothesis  -2 dM_ij + G_ij, 2, 2 (dM^T tau')_j / 256, -2 tau'_i / 256  plus the constant |tau'|^2
+// (the Kabsch launch's own threads, fp64).  For a hypothesis NEAR the reference dM is small (C2: 0.02 - 0.05) and so is every
+// term: the nine products that cancelled at the size of the CLOUDS in r03's form (|P'|^2 + |Q'|^2 against tau'^2) now cancel at
+// dM times that, and a true correspondence has a small V' besides.  Features and coefficients are split into two fp16 halves; hi x hi,
+// hi x lo and lo x hi products are kept: 48 slots = three chained v_mfma_f32_32x32x16_f16, rows = 32 hypotheses, columns = 32
+// correspondences, accumulator initialised to |tau'|^2 - LO: a lane then holds x = D~ - LO for 16 hypotheses of one
 // correspondence — sign bit into a shift register (1 instruction), shell test 0 <= x < HI - LO as an unsigned min over
-// the 16 (0.5), nothing else: 1.6 vector instructions per test against the linear filter's 4.75, for the same matrix work
-// per test (96 cycles per 1024 tests against 4 x 32).  MFMA 1 holds the 16 hi x hi slots (the big, cancelling terms),
-// MFMAs 2 and 3 the 32 small ones.
+// the 16 (0.5), nothing else: 1.6 vector instructions per test against the linear filter's 4.75.
 //
-// What it costs is precision: the squared form cancels (terms of size (|P'| + |Q'| + |T'|)^2 sum to ~tau'^2).  How the matrix
+// The cut.  reach_h = |dM|_F Pn + |tau'| bounds |dM P' + tau'| over the whole cloud, so a correspondence with
+// |V'| > reach_h + tau' + dE_h + margin is an outlier of h by the triangle inequality — whatever the canonical chain's roundings
+// (dE_h, below).  Correspondences are dealt into NEAR (|V'| <= th_v: first tile rows) and FAR (last rows), hypotheses into NEAR
+// (reach_h + dE_h <= th_h = GX_KAPPA tau': first coefficient rows) and the rest (last rows) — both by one atomic per workgroup inside
+// the Kabsch launch; th_v = th_h + 1.05 tau' + 1e-3.  A filter workgroup whose 256 rows are all NEAR hypotheses walks the NEAR
+// units only.  On the BASELINE scenes ~90 % of the ranked hypotheses are near the voted reference and 11 - 20 % of the
+// correspondences are near (the inliers and what lies around them): three quarters of the tests are never made.  The order inside
+// each class is whatever the atomics give — the counts are integers, every permutation gives the same ones; hperm / pperm lead back.
+//
+// What the squared form costs is precision.  How the matrix
 // pipe adds the 16 products and C is not in the ISA text.  tools/ubench/mfma_numerics.hip probes it (profiles/
 // r03_ubench_mfma_numerics.txt): the final rounding is to nearest-even; fp16 sub-normals are NOT flushed; terms far below the
 // largest one lose their low bits before the sum (a product 1.5 beside 2^24 arrives as 1; beside a C of 2^24 it arrives
@@ -1122,77 +1082,130 @@ __global__ __launch_bounds__(256) void score_exact_kernel(const float* __restric
 // a 2^-25 fraction of it, which reproduces two thirds of 3000 random cancelling dot products bit for bit; and over 15 000
 // such dot products |hardware - exact| never passed 3.75 x 2^-24 of the LARGEST term (17 cuts of < 2^-24 of it each would
 // allow 17).  The bound takes 18.5 x 2^-24 of the largest term per MFMA — the cut model's worst case, five times the worst
-// seen.  This is a MEASURED model of gfx950's matrix pipe, not an ISA guarantee; what backs it beyond the probe is the parity
-// suite, which compares EVERY count with the canonical kernel's at the BASELINE shapes and on adversarial scenes, for both
-// filters.  With Mh the largest term of a hypothesis (gram_eps), Sl = sum |w F| over the split terms (sum_ij |R_ij Q_i P_j|
-// <= 1.75 |Q| |P|), S = (|T'| + 1.75 Pn + Qn)^2 the sum of all |terms|, u = 2^-24, D* the exact value:
+// seen.  This is a MEASURED model of gfx950's matrix pipe, not an ISA guarantee: every context probes its own pipe before the
+// first call that would use this filter (gram_guard_kernel), and the parity suite compares EVERY count with the canonical
+// kernel's at the BASELINE shapes, on adversarial scenes and on random degenerate clouds.  With F = |dM|_F, m = max |dM_ij|,
+// Tn = |tau'|, g = max |G_ab|, and the correspondences a row is tested against bounded by |V'| <= vb, |Q'| <= Qb (NEAR rows:
+// vb = th_v, Qb = Pn + th_v; the others: vb = Pn + Qn, Qb = Qn), u = 2^-24, D* the exact value:
+//     terms        2 (m + g/2) Qb Pn | vb^2 | 2 F Tn Pn | 2 Tn vb | Tn^2 + 1.5 tau'^2 (the constant):  Mh = 1.05 x the largest
 //     MFMA 1       18.5 u Mh                                                                    (GX_ACC)
 //     MFMAs 2, 3   their terms are <= 2^-10 of MFMA 1's; their C is the running value: 18.5 u (|x| + 3e-3 S) each — the part
 //                  proportional to x (2.2e-6) is carried by the factors (1 -+ 1e-5) of LO / HI, the rest is the 1e-8 S term
 //     splits       x = hi + lo + rem, |rem| <= 2^-22 |x|;  w F - (wh Fh + wh Fl + wl Fh) = wl Fl + ... <= 3.01 x 2^-22 |w F|:
-//                  7.2e-7 Sl (exact arithmetic, no model)                                                 (GX_Q)
+//                  7.2e-7 Sl, Sl = (2 F + 3 g) Qb Pn + 2 F Tn Pn + 2 Tn vb  (exact arithmetic, no model)          (GX_Q)
 //     norm         the norm feature's coefficient 2 RS alpha has no low half, so of its three products only hi x hi and
-//                  hi x lo exist: its two pieces leave 2^-22 of it, 2.4e-7 (Pn^2 + Qn^2).  (Until r03c a third piece rode in
-//                  slot 9 of the third MFMA; dropping it makes that MFMA's B operand the FIRST one's — the tile is 64 bytes
-//                  per correspondence instead of 96: a third less LDS-DMA issue, LDS traffic and LDS space)   (GX_NORM)
-//     accumulator  initial value alpha RS (|T'|^2 - LO_h) rounded to fp32: u Mh (inside GX_ACC's margin)
-//     R^T R = I    defect g = max |(R^T R - I)_ab| measured per hypothesis in fp64: <= 3 g Pn^2 (beyond 1e-3: not a rotation,
-//                  the hypothesis is recounted exactly)
-//   sum: eps_h = 1.1e-6 Mh + 7.5e-7 Sl + 2.5e-7 (Pn^2 + Qn^2) + 1e-8 S + 3 g Pn^2 + 1e-4                     (gram_eps)
+//                  hi x lo exist: its two pieces leave 2^-22 of it, 2.4e-7 vb^2                                   (GX_NORM)
+//     accumulator  initial value RS (|tau'|^2 - LO_h) rounded to fp32: u Mh (inside GX_ACC's margin)
+//     defect       - V'^T G P': <= 3 g vb Pn  (beyond g = 1e-3: not a rotation, the hypothesis is recounted exactly)
+//     frame        R0^T R0 = I to 3e-16, P' / Q' / dM / tau' evaluated in fp64: < 1e-9 in these units (inside the 1e-4)
+//   sum: eps_h = 1.1e-6 Mh + 7.5e-7 Sl + 2.5e-7 vb^2 + 1e-8 S + 3 g vb Pn + 1e-4                                  (gram_eps)
 // The canonical fp32 chain itself deviates from exact arithmetic: its residual VECTOR by <= dE = sqrt(3) 4 u s (qmax + 1.75 pmax
 // + |t|max) (original, uncentred magnitudes), its square by 3 more roundings.  So, with st = s sqrt(tau2):
 //     D~ <  LO_h = (st - dE)^2 (1 - 1e-5) - eps_h   =>  canonical inlier;     D~ >= HI_h = (st + dE)^2 (1 + 1e-5) + eps_h  =>  outlier;
-// a wave uses the widest shell of its 32 hypotheses.  Hypotheses fall into four classes, decided in the prologue:
-//     normal   eps_h <= 0.25 st^2: filtered;        far      |T'| - 1.002 Pn - Qn >= st + dE + 1: no correspondence can be an inlier,
+// Every hypothesis keeps its OWN shell: the filter wave scales row h by alpha_h = the largest power of two <= min(16, widest shell
+// of its 32 rows / the row's own width) — exact in fp16 / fp32 — so that "0 <= x < W" with one W per wave tests alpha_h RS (D~ - LO_h)
+// against at least alpha_h RS (HI_h - LO_h).  Hypotheses fall into four classes, decided with the coefficients:
+//     normal   eps_h <= 0.25 st^2: filtered;        far      |tau'| - F Pn - Vn >= 1.05 st + dE: no correspondence can be an inlier,
 //     padding  beyond n_local: count 0;              recount  everything else (non-finite, not a rotation, shell too wide): its
-//                                                             group of 8 hypotheses goes to the exact pass wholesale.
-// Usable while tau is not small against the clouds (score_filter_mode: eps <= 3 % of tau'^2 for a typical hypothesis — C2, C4;
-// not C3, whose tau is 1 % of the extent: the linear filter keeps those).
+//                                                             group of 8 rows goes to the exact pass wholesale.
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ void split2(double x, _Float16& hi, _Float16& lo) {
   hi = (_Float16)(float)x;
   lo = (_Float16)(float)(x - (double)(float)hi);
 }
 
-// tile: per group of 32 correspondences 4 x 32 uint4 — for block k (0: hi halves, 1: lo halves): the 32 first halves (slots 0..7), then the 32
+// the vote in a launch of its own (stage hook, sharded stage C, certified paths: wherever the counting pass did not carry it)
+__global__ __launch_bounds__(4 * GX_VOTE) void gram_ref_kernel(GramRefJob job) { gram_ref_block(job); }
+
+// exclusive rank of this thread among the threads of its 256-thread workgroup for which `flag` holds, and their number
+// (two barriers; every thread of the workgroup must call it)
+__device__ __forceinline__ uint32_t block_rank256(bool flag, uint32_t* __restrict__ s_w /* 4 words of LDS */, uint32_t* total) {
+  const uint64_t b = __ballot(flag);
+  const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+  if (lane == 0) s_w[wave] = (uint32_t)__popcll(b);
+  __syncthreads();
+  uint32_t pre = 0, tot = 0;
+#pragma unroll
+  for (uint32_t w = 0; w < 4; w++) { const uint32_t v = s_w[w]; pre += w < wave ? v : 0u; tot += v; }
+  __syncthreads();
+  *total = tot;
+  return pre + __builtin_amdgcn_mbcnt_hi((uint32_t)(b >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b, 0u));
+}
+
+// tile: per group of 32 rows 4 x 32 uint4 — for block k (0: hi halves, 1: lo halves): the 32 first halves (slots 0..7), then the 32
 // second halves (slots 8..15), so that lane l reads uint4 number 64 k + l of the group (linear, conflict-free).
-//   slots   0..8 Q'_i P'_j (index 3 i + j)   9 norm piece   10..12 256 P'_j   13..15 256 Q'_i
+//   slots   0..8 Q'_i P'_j (index 3 i + j)   9 norm piece   10..12 256 P'_j   13..15 256 V'_i
 //   MFMA 1: coefficient hi x block 0 (norm hi);   MFMA 2: coefficient hi x block 1 (norm lo);   MFMA 3: coefficient lo x block 0
+// Row of correspondence m: NEAR ones from the front in the order their workgroups' atomics arrive, FAR ones from row n - 1 down;
+// rows [n, rows) are sentinels.  pperm[row] = m.
+// one read of the frame per workgroup (all threads call; one barrier)
+__device__ __forceinline__ void load_frame(const GramFrame* __restrict__ fr, GramFrameRO* __restrict__ s_fr) {
+  static_assert(sizeof(GramFrameRO) == 176 && offsetof(GramFrame, pmax_o) == 168, "GramFrameRO is the head of GramFrame");
+  if (threadIdx.x < sizeof(GramFrameRO) / 8) reinterpret_cast<double*>(s_fr)[threadIdx.x] = reinterpret_cast<const double*>(fr)[threadIdx.x];
+  __syncthreads();
+}
+
 __device__ void gram_tile_block(const float* __restrict__ planes, int n, int ld, const FilterTileJob& job, uint32_t block,
                                 uint32_t blocks) {
+  __shared__ uint32_t s_w[4];
+  __shared__ uint32_t s_base[2];
+  __shared__ GramFrameRO s_fr;
   const uint32_t m = block * 256 + threadIdx.x;
   for (uint32_t z = m; z < job.zero_words; z += blocks * 256) job.zero[z] = 0u;
-  for (uint32_t z = m; z < job.zero2_words; z += blocks * 256) job.zero2[z] = 0u;
-  const GramInfo gi = gram_info(job.mx_cur + 2, job.mx_cur + 8, __uint_as_float(job.mx_cur[0]), __uint_as_float(job.mx_cur[1]));
-  if (m == 0) *reinterpret_cast<GramInfo*>(static_cast<char*>(job.info) + 64) = gi;
-  if (m >= job.rows) return;
-  _Float16 h[16], l[16], n2[2];
-  if (m < (uint32_t)n) {
-    double P[3], Q[3];
+  GramFrame* __restrict__ fr = job.coef.frame;
+  load_frame(fr, &s_fr);
+  const bool real = m < (uint32_t)n;
+  double P[3] = {0.0, 0.0, 0.0}, Q[3] = {0.0, 0.0, 0.0}, V[3] = {0.0, 0.0, 0.0}, vv = 0.0;
+  if (real) {
+    const double s = s_fr.s;
+    double dq[3];
 #pragma unroll
     for (int c = 0; c < 3; c++) {
-      P[c] = (double)gi.s * ((double)planes[(size_t)c * ld + m] - (double)gi.cP[c]);        // exact
-      Q[c] = (double)gi.s * ((double)planes[(size_t)(3 + c) * ld + m] - (double)gi.cQ[c]);
+      P[c] = s * ((double)planes[(size_t)c * ld + m] - s_fr.c[c]);
+      dq[c] = (double)planes[(size_t)(3 + c) * ld + m] - s_fr.t0[c];
     }
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+      Q[i] = s * ((s_fr.R0[i] * dq[0] + s_fr.R0[3 + i] * dq[1] + s_fr.R0[6 + i] * dq[2]) - s_fr.c[i]);  // (R0^T dq)_i
+      V[i] = Q[i] - P[i];
+      vv += V[i] * V[i];
+    }
+  }
+  const bool near = real && vv <= s_fr.th_v * s_fr.th_v;
+  uint32_t tot_near;
+  const uint32_t r_near = block_rank256(near, s_w, &tot_near);
+  // (the real correspondences of a workgroup are its first threads: rank among the FAR ones = thread - rank among the NEAR ones)
+  const uint32_t n_real = (uint32_t)n > block * 256 ? min(256u, (uint32_t)n - block * 256) : 0u, tot_far = n_real - tot_near;
+  const uint32_t r_far = threadIdx.x - r_near;
+  if (threadIdx.x == 0) {  // ONE atomic per workgroup: both counts in one 64-bit word
+    const unsigned long long was = n_real ? atomicAdd(&fr->pts, (unsigned long long)tot_near | ((unsigned long long)tot_far << 32)) : 0ull;
+    s_base[0] = (uint32_t)was; s_base[1] = (uint32_t)(was >> 32);
+  }
+  __syncthreads();
+  if (m >= job.rows) return;
+  const uint32_t row = near ? s_base[0] + r_near : (real ? (uint32_t)n - 1u - (s_base[1] + r_far) : m);
+  _Float16 h[16], l[16], n2[2];
+  if (real) {
     double F[16];
 #pragma unroll
     for (int i = 0; i < 3; i++)
 #pragma unroll
       for (int j = 0; j < 3; j++) F[3 * i + j] = Q[i] * P[j];
-    const double N = 0.5 * (P[0] * P[0] + P[1] * P[1] + P[2] * P[2] + Q[0] * Q[0] + Q[1] * Q[1] + Q[2] * Q[2]);
+    const double N = 0.5 * vv;
 #pragma unroll
-    for (int c = 0; c < 3; c++) { F[10 + c] = 256.0 * P[c]; F[13 + c] = 256.0 * Q[c]; }
+    for (int c = 0; c < 3; c++) { F[10 + c] = 256.0 * P[c]; F[13 + c] = 256.0 * V[c]; }
     F[9] = 0.0;
 #pragma unroll
     for (int k = 0; k < 16; k++) split2(F[k], h[k], l[k]);
     n2[0] = (_Float16)(float)N;
     n2[1] = (_Float16)(float)(N - (double)(float)n2[0]);  // what is left: < 2^-22 N (GX_NORM)
+    job.coef.pperm[row] = m;
   } else {  // sentinel: far away under every hypothesis (D~ = 2 x 60000 + ...), never undecided
 #pragma unroll
     for (int k = 0; k < 16; k++) { h[k] = (_Float16)0.f; l[k] = (_Float16)0.f; }
     n2[0] = (_Float16)60000.f; n2[1] = (_Float16)0.f;
   }
-  uint4* tile = static_cast<uint4*>(job.tile) + (size_t)(m >> 5) * (32 * GX_TILE_Q) + (m & 31u);
+  uint4* tile = static_cast<uint4*>(job.tile) + (size_t)(row >> 5) * (32 * GX_TILE_Q) + (row & 31u);
 #pragma unroll
   for (int k = 0; k < 2; k++) {
     const _Float16* v = k == 1 ? l : h;
@@ -1204,85 +1217,116 @@ __device__ void gram_tile_block(const float* __restrict__ planes, int n, int ld,
 }
 
 // Per-hypothesis coefficients of the Gram filter, made ONCE per call (by the Kabsch launch's own threads, or by
-// gram_coef_kernel for the stage hook) instead of by every wave of every grid split of the filter: lane = hypothesis l of this
-// rank's shard; the 32 lanes of a half wave are the 32 rows of one filter wave (shuffles of width 32).
-//   coef.A      64 bytes per hypothesis: [hi halves of the 16 coefficients | lo halves, slot 9 = the hi half again]
-//   coef.C      the accumulator's start value of the row (alpha RS (|T'|^2 - LO_h), or +huge for a row that is switched off)
-//   coef.wave   per 32 hypotheses: {W as fp32 bits, recount groups (4 bits) | any row filtered << 4}
-__device__ void gram_coef_wave(const GramCoef& coef, const GramInfo& gi, const float v[12], uint32_t l, uint32_t ldl,
-                               uint32_t n_local, float tau2) {
-  const bool in_grid = l < ldl;
-  const double s = (double)gi.s, st = s * (double)sqrt_rn(tau2);
-  double R[9], Tp[3];
+// gram_coef_kernel for the stage hook): thread = hypothesis l of this rank's shard, a whole 256-thread workgroup calls it.
+// The row a hypothesis gets: NEAR ones from the front, everything else from row ldl - 1 down (one atomic per workgroup and
+// class); hperm[row] = l.
+//   coef.A      64 bytes per row: [hi halves of the 16 coefficients | lo halves] (NOT yet scaled by the row's alpha)
+//   coef.C      RS (|tau'|^2 - LO_h), or +huge for a row that is switched off
+//   coef.W      RS (HI_h - LO_h), 0 for a row that is not filtered
+//   coef.flag   bit 0 normal (filtered), bit 1 recount (its group of 8 rows goes to the exact pass), bits 8.. log2 of the largest
+//               alpha the row's coefficients can take without leaving fp16's range
+__device__ void gram_coef_block(const GramCoef& coef, const float v[12], uint32_t l, uint32_t ldl, uint32_t n_local, float tau2) {
+  __shared__ uint32_t s_w[4];
+  __shared__ uint32_t s_base[2];
+  __shared__ GramFrameRO s_fr;
+  GramFrame* __restrict__ fr = coef.frame;
+  load_frame(fr, &s_fr);
+  const double s = s_fr.s, st = s_fr.st, Pn = s_fr.Pn, Qn = s_fr.Qn, Vn = Pn + Qn;
+  double R[9], dM[9], G[9], Tp[3];
 #pragma unroll
   for (int c = 0; c < 9; c++) R[c] = (double)v[c];
+  double F2 = 0.0, mm = 0.0, gdef = 0.0;
 #pragma unroll
   for (int i = 0; i < 3; i++)
-    Tp[i] = s * ((double)v[9 + i] + R[3 * i] * (double)gi.cP[0] + R[3 * i + 1] * (double)gi.cP[1] + R[3 * i + 2] * (double)gi.cP[2] - (double)gi.cQ[i]);
-  double gdef = 0.0;
 #pragma unroll
-  for (int a = 0; a < 3; a++)
+    for (int j = 0; j < 3; j++) {
+      const double Mij = s_fr.R0[i] * R[j] + s_fr.R0[3 + i] * R[3 + j] + s_fr.R0[6 + i] * R[6 + j];  // (R0^T R)_ij
+      const double d = Mij - (i == j ? 1.0 : 0.0);
+      dM[3 * i + j] = d;
+      F2 += d * d;
+      mm = fmax(mm, fabs(d));
+    }
 #pragma unroll
-    for (int b = a; b < 3; b++) {
-      const double g = R[a] * R[b] + R[3 + a] * R[3 + b] + R[6 + a] * R[6 + b] - (a == b ? 1.0 : 0.0);
+  for (int i = 0; i < 3; i++)
+#pragma unroll
+    for (int j = i; j < 3; j++) {  // (R^T R - I)_ij, symmetric
+      const double g = R[i] * R[j] + R[3 + i] * R[3 + j] + R[6 + i] * R[6 + j] - (i == j ? 1.0 : 0.0);
+      G[3 * i + j] = g; G[3 * j + i] = g;
       gdef = fmax(gdef, fabs(g));
     }
+  {
+    const double d0 = (double)v[9] - s_fr.t0[0], d1 = (double)v[10] - s_fr.t0[1], d2 = (double)v[11] - s_fr.t0[2];
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+      Tp[i] = s * ((s_fr.R0[i] * d0 + s_fr.R0[3 + i] * d1 + s_fr.R0[6 + i] * d2) +
+                   (dM[3 * i] * s_fr.c[0] + dM[3 * i + 1] * s_fr.c[1] + dM[3 * i + 2] * s_fr.c[2]));
+  }
   float nanp = 0.f;
 #pragma unroll
   for (int c = 0; c < 12; c++) nanp += v[c] * 0.f;
-  const double Tn = sqrt(Tp[0] * Tp[0] + Tp[1] * Tp[1] + Tp[2] * Tp[2]);
-  const double Pn = (double)gi.Pn, Qn = (double)gi.Qn;
+  // |dM|_F and |tau'|: fp32 square roots, pushed up / down by more than their rounding — every bound below is monotone in them
+  const double T2 = Tp[0] * Tp[0] + Tp[1] * Tp[1] + Tp[2] * Tp[2];
+  const double Fn = (double)sqrt_rn((float)F2) * (1.0 + 4e-7) + 1e-30, Tr = (double)sqrt_rn((float)T2);
+  const double Tn = Tr * (1.0 + 4e-7) + 1e-30, Tn_lo = Tr * (1.0 - 4e-7);
   const double tmax_o = fmax(fabs((double)v[9]), fmax(fabs((double)v[10]), fabs((double)v[11])));
-  const double dE = GX_CANON * s * ((double)gi.qmax_o + 1.75 * (double)gi.pmax_o + tmax_o);
-  // coefficients (A operand), scaled by GX_RS; the P' / Q' features are stored x 256
-  double a16[16];
+  const double dE = GX_CANON * s * ((double)s_fr.qmax_o + 1.75 * (double)s_fr.pmax_o + tmax_o);
+  const bool finite = nanp == 0.f;
+  const bool pad = l >= n_local;
+  const bool rot = finite && gdef <= 1e-3 && T2 < 1e12;
+  const bool far = rot && (Tn_lo - Fn * Pn - Vn >= 1.05 * st + dE + 1e-3);
+  // The hypothesis' own cut: a correspondence with |V'| > vb_h = reach_h + 1.05 st + dE_h is an outlier of h (triangle inequality),
+  // so the shell only has to hold for |V'| <= vb_h — PROVIDED the filter cannot call such a correspondence an inlier either: with
+  // U(v) the sum form of the bound, D~ >= (v - reach_h)^2 - U(v), which grows with v from vb_h on (its slope there is
+  // 2.1 st - U' > 0 for st >= 0.2), so U(vb_h) <= 0.1 st^2 < (1.05^2 - 1) st^2 keeps D~ above st^2 >= LO_h.  Otherwise the shell is made
+  // for every correspondence of the call (vb = Vn).
+  const double reach = Fn * Pn + Tn;
+  double vb = reach + 1.05 * st + dE + 1e-3, Qb = fmin(Qn, Pn + vb);
+  const bool own = rot && vb < Vn && st >= 0.2 && gram_eps_sum(Fn, mm, Tn, gdef, Pn, Qb, vb, st) <= 0.1 * st * st;
+  if (!own) { vb = Vn; Qb = Qn; }
+  const double eps = gram_eps(Fn, mm, Tn, gdef, Pn, Qb, vb, st);
+  // NEAR the reference: its workgroup of the filter looks only at the NEAR correspondences (|V'| <= th_v = th_h + 1.05 st + 1e-3)
+  const bool close = own && !far && !pad && (reach + dE <= s_fr.th_h);
+  // coefficients (A operand), scaled by GX_RS; the P' / V' features are stored x 256
+  double a16[16], cmax = 0.0;
 #pragma unroll
-  for (int k = 0; k < 9; k++) a16[k] = -2.0 * (double)GX_RS * R[k];
+  for (int k = 0; k < 9; k++) a16[k] = (double)GX_RS * (-2.0 * dM[k] + G[k]);
   a16[9] = 2.0 * (double)GX_RS;
 #pragma unroll
-  for (int j = 0; j < 3; j++) a16[10 + j] = 2.0 * (double)GX_RS / 256.0 * (R[j] * Tp[0] + R[3 + j] * Tp[1] + R[6 + j] * Tp[2]);
+  for (int j = 0; j < 3; j++) a16[10 + j] = 2.0 * (double)GX_RS / 256.0 * (dM[j] * Tp[0] + dM[3 + j] * Tp[1] + dM[6 + j] * Tp[2]);
 #pragma unroll
   for (int i = 0; i < 3; i++) a16[13 + i] = -2.0 * (double)GX_RS / 256.0 * Tp[i];
-  const double eps = gram_eps(Tn, Pn, Qn, st) + 3.0 * gdef * Pn * Pn;
-  const bool finite = nanp == 0.f;
-  const bool pad = !in_grid || l >= n_local;
-  const bool rot = finite && gdef <= 1e-3 && Tn < 1e6;
-  const bool far = rot && (Tn - 1.002 * Pn - Qn >= st + dE + 1.0);
-  // (st <= 64: the sentinel correspondences' 2 x 60000 must stay far above every threshold)
-  const bool normal = rot && !far && !pad && (eps <= 0.25 * st * st) && (dE <= 0.1 * st) && (st <= 64.0);
+#pragma unroll
+  for (int k = 0; k < 16; k++) cmax = fmax(cmax, fabs(a16[k]));
+  uint32_t lg = 4;  // alpha <= 16
+  while (lg > 0 && cmax * (double)(1u << lg) > 30000.0) lg--;
+  // (st <= 32: the sentinel correspondences' 2 x 60000 must stay far above every threshold)
+  const bool normal = rot && !far && !pad && (eps <= 0.25 * st * st) && (dE <= 0.1 * st) && (st <= 32.0) && (cmax <= 30000.0);
   const bool recount = !pad && !far && !normal;
+  const bool good = close && normal;
   const double LOh = (st - dE) * (st - dE) * (1.0 - 1e-5) - eps, HIh = (st + dE) * (st + dE) * (1.0 + 1e-5) + eps;
-  // Every hypothesis keeps its OWN shell [LO_h, HI_h): its row is scaled by alpha_h = (widest shell of the wave) / (its own
-  // width), so that "0 <= x < W" with one W per wave tests exactly alpha_h RS (D~ - LO_h) in [0, alpha_h RS (HI_h - LO_h)) —
-  // one hypothesis with a large |T'| does not widen the shells of the 31 others (alpha <= 16: fp16 range of the row).
-  double width = normal ? HIh - LOh : 0.0, wmax = width;
-#pragma unroll
-  for (int o = 16; o > 0; o >>= 1) wmax = fmax(wmax, __shfl_xor(wmax, o, 32));
-  // alpha is cut to 11 significant bits (rounded to fp16 after shrinking by 2^-10, so never above the ratio): the norm
-  // feature's coefficient 2 RS alpha then has no low half, like 2 RS itself — slot 9 of the third MFMA multiplies by zero
-  const double alpha = normal ? (double)(float)(_Float16)(float)(fmin(16.0, wmax / width) * (1.0 - 1.0 / 1024.0)) : 0.0;
-  const int half = (int)((threadIdx.x >> 5) & 1u);                // which 32-lane half of the wave this lane sits in
-  const uint32_t normal_rows = (uint32_t)(__ballot(normal) >> (32 * half));
-  const uint32_t rc = (uint32_t)(__ballot(recount) >> (32 * half));
-  uint32_t redo4 = 0;                                             // groups of 8 rows the exact pass recounts
-#pragma unroll
-  for (int jj = 0; jj < 4; jj++) redo4 |= ((rc >> (8 * jj)) & 0xFFu) ? (1u << jj) : 0u;
-  const bool any_normal = normal_rows != 0u;
-  const uint32_t W2b = any_normal ? __float_as_uint((float)((double)GX_RS * wmax * (1.0 + 1e-6))) : 0u;
-  const uint32_t row = l & 31u;
-  // rows of a group that is recounted anyway are switched off too
-  const bool live = normal && !((redo4 >> (row >> 3)) & 1u);
-  if (!in_grid) return;
-  coef.C[l] = live ? (float)(alpha * (double)GX_RS * (Tn * Tn - LOh)) : 1e30f;
-  if (row == 0) coef.wave[l >> 5] = make_uint2(W2b, redo4 | (any_normal ? 16u : 0u));
+  uint32_t n_good;
+  const uint32_t r_good = block_rank256(good, s_w, &n_good), r_bad = threadIdx.x - r_good, n_bad = 256u - n_good;
+  // this workgroup's segment of the coefficient rows (sc_gramref.hpp): NEAR hypotheses from its front, the others from its back
+  const uint32_t groups = ldl / 256u, S = gram_segments(groups), wg = l / 256u, sg = wg % S, seg_rows = 256u * ((groups - sg + S - 1u) / S);
+  if (threadIdx.x == 0) {  // ONE atomic per workgroup: both counts in one 64-bit word
+    const unsigned long long was = atomicAdd(&fr->seg[sg].cnt, (unsigned long long)n_good | ((unsigned long long)n_bad << 32));
+    s_base[0] = (uint32_t)was; s_base[1] = (uint32_t)(was >> 32);
+  }
+  __syncthreads();
+  if (l >= ldl) return;
+  const uint32_t row = gram_seg_row(good ? s_base[0] + r_good : seg_rows - 1u - (s_base[1] + r_bad), sg, S);
+  coef.hperm[row] = l;
+  coef.C[row] = normal ? (float)((double)GX_RS * (T2 - LOh)) : 1e30f;
+  coef.W[row] = normal ? (float)((double)GX_RS * (HIh - LOh) * (1.0 + 1e-6)) : 0.0f;
+  coef.flag[row] = (normal ? 1u : 0u) | (recount ? 2u : 0u) | (lg << 8);
   _Float16 ah[16], al[16];
 #pragma unroll
   for (int k = 0; k < 16; k++) {
-    split2(alpha * a16[k], ah[k], al[k]);
-    if (!live) { ah[k] = (_Float16)0.f; al[k] = (_Float16)0.f; }
+    split2(a16[k], ah[k], al[k]);
+    if (!normal) { ah[k] = (_Float16)0.f; al[k] = (_Float16)0.f; }
   }
-  al[9] = (_Float16)0.f;  // (2 RS alpha has no low half: alpha is cut to 11 bits above)
-  uint4* __restrict__ out = reinterpret_cast<uint4*>(coef.A) + (size_t)l * 4;
+  al[9] = (_Float16)0.f;  // (2 RS is a power of two: no low half)
+  uint4* __restrict__ out = reinterpret_cast<uint4*>(coef.A) + (size_t)row * 4;
   half8 q0 = {ah[0], ah[1], ah[2], ah[3], ah[4], ah[5], ah[6], ah[7]}, q1 = {ah[8], ah[9], ah[10], ah[11], ah[12], ah[13], ah[14], ah[15]};
   half8 q2 = {al[0], al[1], al[2], al[3], al[4], al[5], al[6], al[7]}, q3 = {al[8], al[9], al[10], al[11], al[12], al[13], al[14], al[15]};
   out[0] = *reinterpret_cast<uint4*>(&q0); out[1] = *reinterpret_cast<uint4*>(&q1);
@@ -1290,13 +1334,12 @@ __device__ void gram_coef_wave(const GramCoef& coef, const GramInfo& gi, const f
 }
 
 __global__ __launch_bounds__(256) void gram_coef_kernel(const float* __restrict__ RtSoA, uint32_t ldl, uint32_t n_local, float tau2,
-                                                        const uint32_t* __restrict__ mx, GramCoef coef) {
+                                                        GramCoef coef) {
   const uint32_t l = blockIdx.x * 256 + threadIdx.x;
-  const GramInfo gi = gram_info(mx + 2, mx + 8, __uint_as_float(mx[0]), __uint_as_float(mx[1]));
   float v[12];
 #pragma unroll
   for (int c = 0; c < 12; c++) v[c] = l < ldl ? RtSoA[(size_t)c * ldl + l] : 0.f;
-  gram_coef_wave(coef, gi, v, l, ldl, n_local, tau2);
+  gram_coef_block(coef, v, l, ldl, n_local, tau2);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1448,10 +1491,26 @@ __global__ __launch_bounds__(64 * GX_WAVES, 2) void score_gram_kernel(GramCoef c
   constexpr int PIECES = GX_UNIT * GX_TILE_Q / (64 * GX_WAVES);  // LDS-DMA instructions per wave and unit
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int col = lane & 31, hf = lane >> 5;
-  const uint32_t per = (windows + splits - 1) / splits, w0 = blockIdx.y * per, w1 = min(windows, w0 + per);
-  const uint32_t wid = blockIdx.x * GX_WAVES + wave;  // wave of 32 hypotheses
+  // The grid is one-dimensional, groups x splits workgroups, and the LONG ones go first: the row blocks that hold a hypothesis
+  // not near the reference are the LAST ones of their segment (sc_gramref.hpp: segment = row block % S) — the highest row blocks —
+  // and walk every correspondence, the others a few units of split 0 (dispatched in row order, the last workgroups to start were
+  // the longest: a tail as long as the kernel's useful part).
+  const GramFrame* __restrict__ fr = coef.frame;
+  const uint32_t groups = gridDim.x / splits, S = gram_segments(groups);
+  const uint32_t bx = groups - 1u - blockIdx.x / splits, by = blockIdx.x % splits;
+  const uint32_t per = (windows + splits - 1) / splits, w0 = by * per, w1 = min(windows, w0 + per);
+  const uint32_t wid = bx * GX_WAVES + wave;  // wave of 32 hypotheses
   constexpr uint32_t UPW = FX_WIN / GX_UNIT;          // units per window
-  const uint32_t u0 = w0 * UPW, u1 = w1 * UPW;
+  // The cut: a workgroup whose 256 rows are all hypotheses NEAR the reference walks the NEAR correspondences only — the tile's
+  // first rows; every other correspondence is an outlier of every one of them by the triangle inequality (see the header).
+  const uint32_t near_units = ((uint32_t)fr->pts + GX_UNIT - 1) / GX_UNIT;
+  const bool near_block = (bx / S + 1u) * (32u * GX_WAVES) <= (uint32_t)fr->seg[bx % S].cnt;  // all 256 rows are NEAR hypotheses
+  const uint32_t u0 = w0 * UPW, u1 = near_block ? min(w1 * UPW, near_units) : w1 * UPW;
+  if (u0 >= u1) {  // (workgroup-uniform) nothing to look at in this split
+    const uint32_t hh = wid * 32 + (uint32_t)col;
+    if (hf == 0 && hh < ldl) cnt_out[(size_t)by * ldl + coef.hperm[hh]] = 0u;
+    return;
+  }
   auto stage = [&](uint32_t u, int buf) {  // (asm: see score_filter_kernel)
 #pragma unroll
     for (int i = 0; i < PIECES; i++) {
@@ -1465,22 +1524,50 @@ __global__ __launch_bounds__(64 * GX_WAVES, 2) void score_gram_kernel(GramCoef c
   };
   if (u0 < u1) stage(u0, 0);
   if (u0 + 1 < u1) stage(u0 + 1, 1);
-  // ---- prologue: the coefficients were made once per call by gram_coef_wave (lane (row, hf) takes the halves of its row)
-  const uint32_t row = (uint32_t)col, h = wid * 32 + row;
-  const bool in_grid = h < ldl;  // (ldl is a multiple of 256: the last workgroup cannot reach beyond it)
-  const uint4* __restrict__ ca = reinterpret_cast<const uint4*>(coef.A) + (size_t)(in_grid ? h : 0) * 4;
+  // ---- prologue: the coefficients were made once per call by gram_coef_block (lane (row, hf) takes the halves of its row).  What
+  // belongs to the WAVE — the widest shell of its 32 rows, every row's alpha, the groups of 8 rows the exact pass recounts — is
+  // made here: the rows of a wave come from all over the ranked list (NEAR hypotheses first), only this kernel sees them together.
+  const uint32_t row = (uint32_t)col, h = wid * 32 + row;  // (< ldl: a multiple of 256, the grid has ldl / 256 workgroups)
+  const uint4* __restrict__ ca = reinterpret_cast<const uint4*>(coef.A) + (size_t)h * 4;
   const uint4 a0 = ca[hf], a2 = ca[2 + hf];
   half8 A0 = *reinterpret_cast<const half8*>(&a0), A2 = *reinterpret_cast<const half8*>(&a2);
+  const float wrow = coef.W[h];
+  const uint32_t frow = coef.flag[h];
+  float wmax = wrow;
+#pragma unroll
+  for (int o = 16; o > 0; o >>= 1) wmax = fmaxf(wmax, __shfl_xor(wmax, o, 32));  // (both lane halves hold the same 32 rows)
+  const uint32_t normal_rows = (uint32_t)__ballot((frow & 1u) != 0u), rc = (uint32_t)__ballot((frow & 2u) != 0u);
+  uint32_t redo4 = 0, live_rows = normal_rows;
+#pragma unroll
+  for (int jj = 0; jj < 4; jj++)
+    if ((rc >> (8 * jj)) & 0xFFu) { redo4 |= 1u << jj; live_rows &= ~(0xFFu << (8 * jj)); }  // rows of a group that is recounted anyway are switched off
+  const bool any_normal = live_rows != 0u;
+  // alpha: the largest power of two <= min(what the row's fp16 coefficients allow, widest shell / own shell) — scaling by it is exact
+  auto alpha_of = [&](float w, uint32_t fl) -> float {
+    const float a = fminf((float)(1u << ((fl >> 8) & 7u)), wmax / w);  // (>= 1 for a filtered row; w = 0 rows are not live)
+    return __uint_as_float(__float_as_uint(a) & 0xFF800000u);
+  };
+  {
+    const bool live = (live_rows >> row) & 1u;
+    const _Float16 am = (_Float16)(live ? alpha_of(wrow, frow) : 0.0f);
+    A0 = A0 * am; A2 = A2 * am;
+  }
   const half8 A1 = A0;  // hi x lo: the tile's second block holds the low halves of the features
-  const uint2 wv = coef.wave[wid < coef.n_waves32 ? wid : 0];
-  const uint32_t W2b = (VAR & 512) ? 0u : wv.x;
-  uint32_t redo4 = wv.y & 0xFu;
-  const bool any_normal = (wv.y >> 4) & 1u;
+  // alpha_h x own width <= wmax (1 + 2^-23): one W for the wave
+  const uint32_t W2b = ((VAR & 512) || !any_normal) ? 0u : __float_as_uint(wmax * (1.0f + 4e-7f));
   f32x16 C;
 #pragma unroll
   for (int jj = 0; jj < 4; jj++) {
-    const float4 c4 = *reinterpret_cast<const float4*>(coef.C + (size_t)wid * 32 + 8 * jj + 4 * hf);
-    C[4 * jj] = c4.x; C[4 * jj + 1] = c4.y; C[4 * jj + 2] = c4.z; C[4 * jj + 3] = c4.w;
+    const size_t base = (size_t)wid * 32 + 8 * jj + 4 * hf;
+    const float4 c4 = *reinterpret_cast<const float4*>(coef.C + base), w4 = *reinterpret_cast<const float4*>(coef.W + base);
+    const uint4 f4 = *reinterpret_cast<const uint4*>(coef.flag + base);
+    const float cc[4] = {c4.x, c4.y, c4.z, c4.w}, ww[4] = {w4.x, w4.y, w4.z, w4.w};
+    const uint32_t ff[4] = {f4.x, f4.y, f4.z, f4.w};
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      const bool live = (live_rows >> (8 * jj + 4 * hf + i)) & 1u;
+      C[4 * jj + i] = live ? cc[i] * alpha_of(ww[i], ff[i]) : 1e30f;
+    }
   }
   // The coefficients are USED here, so that the compiler's wait for these global loads sits here and not at their first real
   // use — the first MFMA of the step loop, where an s_waitcnt vmcnt(0) in every trip also waited for the LDS-DMA of the units
@@ -1593,7 +1680,7 @@ __global__ __launch_bounds__(64 * GX_WAVES, 2) void score_gram_kernel(GramCoef c
 #pragma unroll
     for (int jj = 0; jj < 4; jj++)
       if (((redo4 >> jj) & 1u) && (wid * 4 + jj) < n_waves8) {
-        const size_t bit = (size_t)blockIdx.y * n_waves8 + wid * 4 + jj;
+        const size_t bit = (size_t)by * n_waves8 + wid * 4 + jj;
         atomicOr(&redo_bits[bit >> 5], 1u << (bit & 31));
       }
   }
@@ -1601,237 +1688,62 @@ __global__ __launch_bounds__(64 * GX_WAVES, 2) void score_gram_kernel(GramCoef c
   // trips (80 of them in a row were ~2.5 us at the end of every wave — a fifth of a wave's life at C2's 32 steps)
 #pragma unroll
   for (int i = 0; i < 16; i++) {
-    const uint32_t c = dpp_sum32_upper(total[i]);
+    const uint32_t c = dpp_sum32_upper(total[i] + (uint32_t)__popc(sr[i]));  // (+ what a NEAR range that ends inside a window left in the shift register)
     const uint32_t r = 8 * (i >> 2) + 4 * hf + (i & 3), hh = wid * 32 + r;
-    if (col == 31 && hh < ldl) cnt_out[(size_t)blockIdx.y * ldl + hh] = ((redo4 >> (i >> 2)) & 1u) ? 0u : c;
+    if (col == 31 && hh < ldl) cnt_out[(size_t)by * ldl + coef.hperm[hh]] = ((redo4 >> (i >> 2)) & 1u) ? 0u : c;
   }
 }
 
-// ------------------------------------------------------------------------------------------------
-// The Gram filter, persistent form (r04).  BUILT, BIT-EXACT, 3 - 4 % SLOWER than the split form — off by default
-// (sc_debug: gram_pers).  VERDICT r03 #4 proposed it ("persistent waves that loop over several tiles ..."): the premise was that
-// the split form loses to its two generations of workgroups at C2.  Measured, alternating in one process
-// (profiles/r04_ab_gram_persistent.txt): C2 stage 47.3 - 48.4 us against 45.6 - 46.4, C4 331 against 319.  The generations of the
-// split form overlap (a workgroup of the second starts the moment one of the first ends), so their start-up is already hidden;
-// what bounds both forms is the per-step rate — ~380 cycles per 1024-test step and SIMD against 264 by the issue model.
-// Same arithmetic, same tile, same queue and exact pass as score_gram_kernel above — what changes is how the launch is cut.  The split form is a grid of (groups of 256 hypotheses) x
-// (splits of the windows): at C2 980 workgroups for 512 resident slots, i.e. TWO generations, each paying the workgroup's
-// start-up (dispatch, coefficient loads, the first units' LDS-DMA through a cold pipeline) and tail (80 DPP adds, stores) for only
-// 32 steps per wave; its timing-only body with no vector work at all takes 28 us at C2 for 12 us of matrix-pipe work.  Here the
-// launch is ONE generation: min(slots, items) workgroups, each walking a CONTIGUOUS run of the items (hypothesis group g, unit u)
-// — 3920 items over 512 workgroups at C2: 7 or 8 units each, the ring of three LDS buffers never drains between them, and a
-// workgroup changes its hypothesis group at most once or twice (coefficients reloaded, totals flushed).  Because a group's
-// units are now shared by several workgroups,
-//   * the counts of a hypothesis are ACCUMULATED into one row by atomicAdd (the row is cleared by the tile job; the arg-max
-//     then reads one row instead of `splits`),
-//   * the exact pass's wholesale recounts are per (8 hypotheses, UNIT) — a queue that overflows costs the recount of 256
-//     correspondences, not of a whole split, and the wave carries on with the next unit: the unit's sign bits are dropped from
-//     the shift registers and its queue entries from the LDS queue, so nothing is counted twice.
-// ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(64 * GX_WAVES, 2) void score_gram_pers_kernel(GramCoef coef, uint32_t ldl,
-                                                                          const uint4* __restrict__ tile, uint32_t units,
-                                                                          uint32_t groups, uint32_t n_waves8,
-                                                                          uint32_t* __restrict__ cnt_out, uint2* __restrict__ gq,
-                                                                          uint32_t cap_sq, uint32_t* __restrict__ qcount,
-                                                                          uint32_t* __restrict__ redo_bits, uint32_t ql) {
-  __shared__ uint4 Bt[3][GX_UNIT * GX_TILE_Q];
-  __shared__ uint2 queue[GX_WAVES][GX_QL];
-  constexpr int PIECES = GX_UNIT * GX_TILE_Q / (64 * GX_WAVES);
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int col = lane & 31, hf = lane >> 5;
-  const uint64_t items = (uint64_t)groups * units;  // (< 2^28: score_filter_mode keeps ld_local <= 2^20 and n <= 2^24 for this filter)
-  const uint32_t k0 = (uint32_t)(items * blockIdx.x / gridDim.x), k1 = (uint32_t)(items * (blockIdx.x + 1) / gridDim.x);
-  if (k0 >= k1) return;  // (workgroup-uniform)
-  // (g, u) of the running item are kept incrementally: a 64-bit division per unit and wave — three, with the units staged
-  // ahead — doubled the kernel's instruction count in its first form (47.7 us against the split form's 41.6)
-  uint32_t g = k0 / units, u = k0 - g * units;
-  auto unit_after = [&](uint32_t uu, uint32_t d) { uu += d; return uu >= units ? uu - units : uu; };  // (d <= 2 <= units)
-  auto stage = [&](uint32_t u, int buf) {
-#pragma unroll
-    for (int i = 0; i < PIECES; i++) {
-      const uint4* gsrc = tile + (size_t)u * (GX_UNIT * GX_TILE_Q) + 64 * GX_WAVES * i + tid;
-      const uint32_t lds_dst = __builtin_amdgcn_readfirstlane(
-          (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)(&Bt[buf][64 * GX_WAVES * i + wave * 64]));
-      unsigned keep;
-      asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                   : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
-    }
-  };
-  stage(u, 0);
-  if (k0 + 1 < k1) stage(units > 1 ? unit_after(u, 1) : 0u, 1);
-  // ---- per hypothesis group: coefficients and accumulators
-  half8 A0, A2;
-  f32x16 C;
-  uint32_t W2b = 0, redo4 = 0, wid = 0;
-  bool any_normal = false;
-  uint32_t total[16], sr[16];
-  uint32_t sr_units = 0;          // units whose sign bits sit in sr (flushed into total at four: 32 steps)
-  uint32_t qn = 0;
-  uint2* q = queue[wave];
-  bool flushed = false;
-  auto load_group = [&](uint32_t g) {
-    wid = g * GX_WAVES + (uint32_t)wave;
-    const uint32_t h = wid * 32 + (uint32_t)col;
-    const bool in_grid = h < ldl;
-    const uint4* __restrict__ ca = reinterpret_cast<const uint4*>(coef.A) + (size_t)(in_grid ? h : 0) * 4;
-    const uint4 a0 = ca[hf], a2 = ca[2 + hf];
-    A0 = *reinterpret_cast<const half8*>(&a0); A2 = *reinterpret_cast<const half8*>(&a2);
-    const uint2 wv = coef.wave[wid < coef.n_waves32 ? wid : 0];
-    W2b = wid < coef.n_waves32 ? wv.x : 0u;
-    redo4 = wid < coef.n_waves32 ? (wv.y & 0xFu) : 0u;
-    any_normal = wid < coef.n_waves32 && ((wv.y >> 4) & 1u);
-#pragma unroll
-    for (int jj = 0; jj < 4; jj++) {
-      const float4 c4 = *reinterpret_cast<const float4*>(coef.C + (size_t)(wid < coef.n_waves32 ? wid : 0) * 32 + 8 * jj + 4 * hf);
-      C[4 * jj] = c4.x; C[4 * jj + 1] = c4.y; C[4 * jj + 2] = c4.z; C[4 * jj + 3] = c4.w;
-    }
-    asm volatile("" ::"v"(A0), "v"(A2), "v"(C), "s"(W2b), "s"(redo4));  // (the wait for these loads sits HERE: see score_gram_kernel)
-#pragma unroll
-    for (int i = 0; i < 16; i++) { total[i] = 0; sr[i] = 0; }
-    sr_units = 0;
-    flushed = true;  // (the loads above are younger than the LDS-DMA pieces in flight: the next wait is a full one)
-  };
-  auto flush_queue = [&]() {
-    const uint32_t sq = wid % FX_NQ;
-    uint32_t base = 0;
-    if (lane == 0) base = atomicAdd(&qcount[sq * 32], qn);
-    base = __shfl(base, 0);
-    // a sub-queue that is full takes nothing: its entries' units are recounted instead (marked by the caller)
-    for (uint32_t i = lane; i < qn && base + i < cap_sq; i += 64) gq[(size_t)sq * cap_sq + base + i] = make_uint2(q[i].x, (wid << 17) | q[i].y);
-    const bool fits = base + qn <= cap_sq;
-    qn = 0;
-    flushed = true;
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    return fits;
-  };
-  auto mark_unit = [&](uint32_t u, uint32_t groups4) {  // the exact pass recounts these groups of 8 hypotheses over unit u
-    if (lane == 0) {
-#pragma unroll
-      for (int jj = 0; jj < 4; jj++)
-        if (((groups4 >> jj) & 1u) && (wid * 4 + jj) < n_waves8) {
-          const size_t bit = (size_t)u * n_waves8 + wid * 4 + jj;
-          atomicOr(&redo_bits[bit >> 5], 1u << (bit & 31));
-        }
-    }
-  };
-  auto finish_group = [&]() {  // the group's counts so far -> the count row
-    if (sr_units) {
-#pragma unroll
-      for (int i = 0; i < 16; i++) total[i] += (uint32_t)__popc(sr[i]);
-    }
-#pragma unroll
-    for (int i = 0; i < 16; i++) {
-      const uint32_t c = dpp_sum32_upper(total[i]);
-      const uint32_t r = 8 * (i >> 2) + 4 * hf + (i & 3), hh = wid * 32 + r;
-      if (col == 31 && hh < ldl && c != 0u && !((redo4 >> (i >> 2)) & 1u)) atomicAdd(&cnt_out[hh], c);
-    }
-  };
-  // A wave adds a group's counts only when it is done with the group (finish_group), so a GLOBAL sub-queue that turns out full
-  // can still be undone: the wave gives the rest of its run of this group up — every unit of the run, past and to come, is
-  // marked for the exact pass (which then skips the run's queue entries that did get through) and nothing is added.
-  uint32_t seg_first = 0;  // first unit of the current group's run in this workgroup
-  auto give_up = [&](uint32_t u_now) {
-    for (uint32_t x = seg_first; x <= u_now; x++) mark_unit(x, 0xFu & ~redo4);
-    redo4 = 0xFu;  // (the units still to come are marked as they are reached; finish_group adds nothing)
-  };
-  int64_t cur_g = -1;
-  int buf = 0;
-  for (uint32_t k = k0; k < k1; k++, buf = buf == 2 ? 0 : buf + 1, u = (u + 1 == units) ? 0u : u + 1, g += (u == 0u) ? 1u : 0u) {
-    if ((int64_t)g != cur_g) {  // (workgroup-uniform)
-      if (cur_g >= 0) {
-        if (qn && redo4 != 0xFu && !flush_queue()) give_up(units - 1);  // (the previous group's run ended at its last unit)
-        finish_group();
-      }
-      load_group(g);
-      qn = 0;
-      cur_g = g; seg_first = u;
-    }
-    if (k + 1 < k1 && !flushed) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PIECES) : "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    flushed = false;
-    __syncthreads();
-    if (k + 2 < k1) stage(units > 2 ? unit_after(u, 2) : (units == 2 ? u : 0u), buf == 0 ? 2 : buf - 1);
-    if (redo4 != 0u) mark_unit(u, redo4);  // groups the prologue classified "recount" (their rows are switched off)
-    if (any_normal && redo4 != 0xFu) {
-      const half8* Bc = reinterpret_cast<const half8*>(Bt[buf]) + lane;
-      const uint32_t qn_unit = qn;  // the queue's fill at the start of the unit
-      auto epilogue = [&](const f32x16& D, int gstep) {
-        uint32_t gm[4];
-#pragma unroll
-        for (int j = 0; j < 4; j++) {
-#pragma unroll
-          for (int i = 4 * j; i < 4 * j + 4; i++) sr[i] = __builtin_amdgcn_alignbit(sr[i], __float_as_uint(D[i]), 31);
-          gm[j] = min(min(min(__float_as_uint(D[4 * j]), __float_as_uint(D[4 * j + 1])), __float_as_uint(D[4 * j + 2])), __float_as_uint(D[4 * j + 3]));
-        }
-        const uint32_t mn = min(min(min(gm[0], gm[1]), gm[2]), gm[3]);
-        if (__builtin_expect(__ballot(mn < W2b) != 0, 0)) {
-#pragma unroll
-          for (int j = 0; j < 4; j++) {
-            const uint64_t hit = __ballot(gm[j] < W2b);
-            if (hit == 0) continue;
-            const uint32_t slot = qn + __builtin_amdgcn_mbcnt_hi((uint32_t)(hit >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)hit, 0u));
-            if (gm[j] < W2b) {
-              uint32_t bits = 0;
-#pragma unroll
-              for (int i = 0; i < 4; i++) bits |= (__float_as_uint(D[4 * j + i]) < W2b) ? (1u << (4 * j + i)) : 0u;
-              if (slot < ql) q[slot] = make_uint2(u * GX_UNIT + 32 * gstep + col, ((uint32_t)hf << 16) | bits);
-            }
-            qn += (uint32_t)__popcll(hit);
-          }
-        }
-      };
-      half8 b0 = Bc[0], b1 = Bc[64];
-#pragma unroll 1
-      for (int gstep = 0; gstep < GX_UNIT / 32; gstep++) {
-        f32x16 D = __builtin_amdgcn_mfma_f32_32x32x16_f16(A0, b0, C, 0, 0, 0);
-        D = __builtin_amdgcn_mfma_f32_32x32x16_f16(A0, b1, D, 0, 0, 0);
-        D = __builtin_amdgcn_mfma_f32_32x32x16_f16(A2, b0, D, 0, 0, 0);
-        if (gstep + 1 < GX_UNIT / 32) { b0 = Bc[32 * GX_TILE_Q * (gstep + 1)]; b1 = Bc[32 * GX_TILE_Q * (gstep + 1) + 64]; }
-        epilogue(D, gstep);
-      }
-      if (qn > ql) {
-        // the unit's entries beyond ql were dropped: the exact pass takes the whole (wave, unit); its sign bits (the low 8 of
-        // every shift register) and its queue entries go, so nothing of it is counted here
-        mark_unit(u, 0xFu & ~redo4);
-#pragma unroll
-        for (int i = 0; i < 16; i++) sr[i] &= ~0xFFu;
-        qn = qn_unit;
-      }
-      if (++sr_units == (uint32_t)(FX_WIN / GX_UNIT)) {
-#pragma unroll
-        for (int i = 0; i < 16; i++) { total[i] += (uint32_t)__popc(sr[i]); sr[i] = 0; }
-        sr_units = 0;
-      }
-      if (qn > ql / 2 && !flush_queue()) give_up(u);
-    }
-  }
-  if (qn && redo4 != 0xFu && !flush_queue()) give_up((uint32_t)(((uint64_t)k1 - 1) % units));
-  finish_group();
-}
+// (A persistent one-generation form of this kernel — contiguous runs of (hypothesis group, unit) items per workgroup, counts by
+// atomics, recounts per unit: what VERDICT r03 #4 proposed — was built in round 4, bit-exact, and measured 3 - 4 % SLOWER at C2 and
+// C4: profiles/r04_ab_gram_persistent.txt, DESIGN.md 5.0.  Its code left the tree when the reference-frame form below arrived.)
 
-GramCoef gram_coef_view(void* buf, uint32_t ld_local) {
+GramCoef gram_coef_view(void* buf, uint32_t ld_local, void* frame) {
   GramCoef g;
   unsigned char* p = static_cast<unsigned char*>(buf);
   g.A = p; p += (size_t)ld_local * 64;
   g.C = reinterpret_cast<float*>(p); p += (size_t)ld_local * 4;
-  g.wave = reinterpret_cast<uint2*>(p);
-  g.n_waves32 = ld_local / 32;
+  g.W = reinterpret_cast<float*>(p); p += (size_t)ld_local * 4;
+  g.flag = reinterpret_cast<uint32_t*>(p); p += (size_t)ld_local * 4;
+  g.hperm = reinterpret_cast<uint32_t*>(p); p += (size_t)ld_local * 4;
+  g.pperm = reinterpret_cast<uint32_t*>(p);
+  g.frame = static_cast<GramFrame*>(frame);
   return g;
 }
 
 FilterTileJob filter_tile_job(const FilterPlan& fp, const uint32_t* mx_cur, uint32_t* mx_next, void* tile, void* state,
-                              void* coef, uint32_t ld_local, float tau2, uint32_t* partial) {
+                              void* coef, uint32_t ld_local, float tau2, void* frame) {
   const FilterState f = filter_state(state, fp);
-  FilterTileJob j{fp.rows, mx_cur, mx_next, tile, f.info, f.qcount, f.zero_words, fp.mode, GramCoef{nullptr, nullptr, nullptr, 0}, tau2,
-                  nullptr, 0u};
-  if (fp.mode == 2) j.coef = gram_coef_view(coef, ld_local);
-  if (fp.mode == 2 && fp.units && partial) { j.zero2 = partial; j.zero2_words = ld_local; }
+  FilterTileJob j{fp.rows, mx_cur, mx_next, tile, f.info, f.qcount, f.zero_words, fp.mode,
+                  GramCoef{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}, tau2};
+  if (fp.mode == 2) j.coef = gram_coef_view(coef, ld_local, frame);
   return j;
 }
 
-void launch_gram_coef(const float* RtSoA, const Shard& sh, float tau2, const uint32_t* mx, const GramCoef& coef, hipStream_t st) {
+size_t gram_frame_bytes() { return sizeof(GramFrame); }  // (the class counters sit on 128-byte lines of their own)
+
+GramRefJob gram_ref_job(const Points& pts, const uint32_t* mx, float tau2, const Tuning& tn, void* frame) {
+  GramRefJob j{};
+  j.planes = pts.planes; j.n = pts.n; j.ld = pts.ld;
+  j.mx = mx; j.tau2 = tau2;
+  j.kappa = tn.gram_kappa_q4 ? (float)tn.gram_kappa_q4 / 16.0f : (float)GX_KAPPA;
+  j.out = static_cast<GramFrame*>(frame);
+  return j;
+}
+
+// the frame of this call's Gram filter in a launch of its own: before the tile / the coefficients are made (it also clears their
+// counters).  RtSoA: the hypotheses, if they exist already (stage hook); else they are solved from the selection `ts`.
+void launch_gram_ref(const Points& pts, const TriSource& ts, const Shard& sh, const float* RtSoA, const uint64_t* t_eff_dev,
+                     const uint32_t* mx, float tau2, const Tuning& tn, void* frame, hipStream_t st) {
+  if (sh.n_local == 0) return;
+  GramRefJob j = gram_ref_job(pts, mx, tau2, tn, frame);
+  j.src.RtSoA = RtSoA; j.src.ts = ts; j.src.sh = sh; j.src.t_eff_dev = t_eff_dev;
+  hipLaunchKernelGGL(gram_ref_kernel, dim3(1), dim3(4 * GX_VOTE), 0, st, j);
+}
+
+void launch_gram_coef(const float* RtSoA, const Shard& sh, float tau2, const GramCoef& coef, hipStream_t st) {
   if (sh.ld_local == 0) return;
-  hipLaunchKernelGGL(gram_coef_kernel, dim3(sh.ld_local / 256), dim3(256), 0, st, RtSoA, sh.ld_local, sh.n_local, tau2, mx, coef);
+  hipLaunchKernelGGL(gram_coef_kernel, dim3(sh.ld_local / 256), dim3(256), 0, st, RtSoA, sh.ld_local, sh.n_local, tau2, coef);
 }
 
 void launch_filter_tile(const Points& pts, const FilterTileJob& job, hipStream_t st) {
@@ -1839,7 +1751,7 @@ void launch_filter_tile(const Points& pts, const FilterTileJob& job, hipStream_t
 }
 
 void launch_score_filter(const Points& pts, const float* RtSoA, const float* RtAoS, const Shard& sh, const Derived& dv,
-                         const FilterPlan& fp, const void* tile, void* state, void* coef, uint32_t* partial, const Tuning& tn,
+                         const FilterPlan& fp, const void* tile, void* state, void* coef, void* frame, uint32_t* partial, const Tuning& tn,
                          hipStream_t st, hipEvent_t ev0, hipEvent_t ev1) {
   if (sh.n_local == 0) return;
   const FilterState f = filter_state(state, fp);
@@ -1852,25 +1764,9 @@ void launch_score_filter(const Points& pts, const float* RtSoA, const float* RtA
     uint32_t ql = tn.filter_lds_queue ? tn.filter_lds_queue : (uint32_t)GX_QL;
     if (ql > (uint32_t)GX_QL) ql = GX_QL;
     if (ql < 64) ql = 64;
-    const GramCoef gc = gram_coef_view(coef, sh.ld_local);
-    if (fp.units) {  // the persistent form: one generation of workgroups (two per CU), contiguous runs of (group, unit) items
-      const uint32_t groups = (sh.ld_local + 32 * GX_WAVES - 1) / (32 * GX_WAVES);
-      const uint64_t items = (uint64_t)groups * fp.units;
-      int dev = 0, cus = 256;
-      (void)hipGetDevice(&dev);
-      (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-      uint64_t nb = 2ull * (uint64_t)(cus > 0 ? cus : 256);
-      if (nb > items) nb = items;
-      hipExtLaunchKernelGGL(score_gram_pers_kernel, dim3((unsigned)nb), dim3(64 * GX_WAVES), 0, st, ev0, nullptr, 0, gc, sh.ld_local,
-                            static_cast<const uint4*>(tile), fp.units, groups, fp.n_waves, partial, f.queue, f.cap_sq, f.qcount, f.redo, ql);
-      hipExtLaunchKernelGGL(score_exact_kernel, dim3(FX_NQ * exact_mult), dim3(256), 0, st, nullptr, ev1, 0, pts.planes, pts.n, pts.ld,
-                            reinterpret_cast<const float4*>(RtAoS), sh.ld_local, dv.tau2, fp.windows, fp.splits, fp.n_waves,
-                            static_cast<const uint2*>(f.queue), f.cap_sq, static_cast<const uint32_t*>(f.qcount),
-                            static_cast<const uint32_t*>(f.redo), partial, 2u);
-      return;
-    }
+    const GramCoef gc = gram_coef_view(coef, sh.ld_local, frame);
 #define SC_GRAM_LAUNCH(V)                                                                                                         \
-    hipExtLaunchKernelGGL(score_gram_kernel<V>, dim3((sh.ld_local + 32 * GX_WAVES - 1) / (32 * GX_WAVES), fp.splits), dim3(64 * GX_WAVES), \
+    hipExtLaunchKernelGGL(score_gram_kernel<V>, dim3((sh.ld_local + 32 * GX_WAVES - 1) / (32 * GX_WAVES) * fp.splits), dim3(64 * GX_WAVES), \
                           0, st, ev0, nullptr, 0, gc, sh.ld_local, static_cast<const uint4*>(tile), fp.windows, fp.splits, fp.n_waves, partial, \
                           f.queue, f.cap_sq, f.qcount, f.redo, ql)
     // The shipped library holds variant 0 only.  -DSC_ABLATIONS (sac-cot_amd/build.py --ablations; tools/pmc_gram_variants.sh)
@@ -1893,7 +1789,8 @@ void launch_score_filter(const Points& pts, const float* RtSoA, const float* RtA
     hipExtLaunchKernelGGL(score_exact_kernel, dim3(FX_NQ * exact_mult), dim3(256), 0, st, nullptr, ev1, 0, pts.planes, pts.n, pts.ld,
                           reinterpret_cast<const float4*>(RtAoS), sh.ld_local, dv.tau2, fp.windows, fp.splits, fp.n_waves,
                           static_cast<const uint2*>(f.queue), f.cap_sq, static_cast<const uint32_t*>(f.qcount),
-                          static_cast<const uint32_t*>(f.redo), partial, 1u);
+                          static_cast<const uint32_t*>(f.redo), partial, static_cast<const uint32_t*>(gc.hperm),
+                          static_cast<const uint32_t*>(gc.pperm));
     return;
   }
   uint32_t ql = tn.filter_lds_queue ? tn.filter_lds_queue : (uint32_t)FX_QL;
@@ -1929,12 +1826,13 @@ void launch_score_filter(const Points& pts, const float* RtSoA, const float* RtA
   hipExtLaunchKernelGGL(score_exact_kernel, dim3(FX_NQ * exact_mult), dim3(256), 0, st, nullptr, ev1, 0, pts.planes, pts.n, pts.ld,
                         reinterpret_cast<const float4*>(RtAoS), sh.ld_local, dv.tau2, fp.windows, fp.splits, fp.n_waves,
                         static_cast<const uint2*>(f.queue), f.cap_sq, static_cast<const uint32_t*>(f.qcount),
-                        static_cast<const uint32_t*>(f.redo), partial, 0u);
+                        static_cast<const uint32_t*>(f.redo), partial, static_cast<const uint32_t*>(nullptr),
+                        static_cast<const uint32_t*>(nullptr));
 }
 
 hipError_t filter_read_counters(const void* state, const FilterPlan& fp, hipStream_t st, uint64_t* undecided, uint64_t* recounts) {
   const FilterState f = filter_state(const_cast<void*>(state), fp);
-  const size_t bm_words = ((size_t)fp.bm_rows * fp.n_waves + 31) / 32;
+  const size_t bm_words = ((size_t)fp.splits * fp.n_waves + 31) / 32;
   std::vector<uint32_t> h((size_t)FX_NQ * 32 + bm_words);
   hipError_t e = hipMemcpyAsync(h.data(), f.qcount, h.size() * 4, hipMemcpyDeviceToHost, st);  // counters, then the bitmap
   if (e == hipSuccess) e = hipStreamSynchronize(st);
@@ -1943,6 +1841,18 @@ hipError_t filter_read_counters(const void* state, const FilterPlan& fp, hipStre
   for (int q = 0; q < FX_NQ; q++) u += h[(size_t)q * 32];  // entries asked for (an overflowing sub-queue counts what was asked)
   for (size_t w = 0; w < bm_words; w++) r += (uint64_t)__builtin_popcount(h[(size_t)FX_NQ * 32 + w]);
   *undecided = u; *recounts = r;
+  return hipSuccess;
+}
+
+hipError_t filter_read_frame(const void* frame, hipStream_t st, uint32_t out[5]) {
+  std::vector<unsigned char> buf(sizeof(GramFrame));  // (8.5 KiB)
+  GramFrame& f = *reinterpret_cast<GramFrame*>(buf.data());
+  hipError_t e = hipMemcpyAsync(&f, frame, sizeof(GramFrame), hipMemcpyDeviceToHost, st);
+  if (e == hipSuccess) e = hipStreamSynchronize(st);
+  if (e != hipSuccess) return e;
+  uint32_t good = 0, all = 0;
+  for (int v = 0; v < 64; v++) { good += (uint32_t)f.seg[v].cnt; all += (uint32_t)f.seg[v].cnt + (uint32_t)(f.seg[v].cnt >> 32); }
+  out[0] = (uint32_t)f.pts; out[1] = good; out[2] = all; out[3] = f.ref_index; out[4] = f.ref_votes_q8;
   return hipSuccess;
 }
 

@@ -17,6 +17,7 @@
 #include "sc_arith.hpp"
 #include "sc_block.hpp"
 #include "sc_kernels.hpp"
+#include "sc_gramref.hpp"
 
 namespace sc {
 
@@ -426,7 +427,14 @@ __global__ __launch_bounds__(256) void tri_count_events_kernel(const uint64_t* _
                                                                StrongList sl, int rank_mode,
                                                                uint32_t* __restrict__ tcnt, EventList ev,
                                                                const uint64_t* __restrict__ own,
-                                                               const uint32_t* __restrict__ ebase, int dbg_stop) {
+                                                               const uint32_t* __restrict__ ebase, int dbg_stop,
+                                                               GramRefJob ref) {
+  // ref (ref.out != null): workgroup 0 is a RIDER — it does none of this kernel's work but votes for the reference frame of
+  // stage C2's Gram filter among the candidate triangles the estimating sample left behind (sc_gramref.hpp): ~10 us of one
+  // workgroup's latency that would otherwise stand between the selection and the Kabsch launch, hidden under this launch
+  const uint32_t rider = ref.out ? 1u : 0u;
+  if (rider && blockIdx.x == 0) { gram_ref_block(ref); return; }
+  const uint32_t bid = blockIdx.x - rider, nblk = gridDim.x - rider;
   // ebase (with ebi == ebj == nullptr): the per-row CSR bases are looked up (edge_build_kernel does not write them per edge)
   // own (optional, sharded stage B): [lo, hi) of the edges this rank enumerates; the strong list holds every rank's, the
   // others count 0 here (their tcnt entry is written too: the scan that follows reads zeros outside the range)
@@ -460,12 +468,12 @@ __global__ __launch_bounds__(256) void tri_count_events_kernel(const uint64_t* _
       x1 = 0;
     }
   }
-  const uint64_t groups = (uint64_t)gridDim.x * (256 / TG);
-  const uint64_t g0 = (uint64_t)blockIdx.x * (256 / TG) + (threadIdx.x / TG);
+  const uint64_t groups = (uint64_t)nblk * (256 / TG);
+  const uint64_t g0 = (uint64_t)bid * (256 / TG) + (threadIdx.x / TG);
   // region of this wave's NEXT ticket: it moves on by one with every ticket, so a wave with many events spreads them over
   // the regions (r03: every wave kept one region and a region overflowed in one C4 call in three at 2.2 records of capacity
   // per event — the call then fell back to the row-walking key kernel)
-  uint32_t shard = (blockIdx.x * 4 + wave) & (EV_SHARDS - 1);
+  uint32_t shard = (bid * 4 + wave) & (EV_SHARDS - 1);
   const uint64_t trips = (x1 - x0 + groups - 1) / groups;  // the same for every lane of the wave
   const int wbase = wave * EVW;
   uint32_t scnt = 0;  // records staged by this wave (wave-uniform)
@@ -719,7 +727,7 @@ EventList event_list(void* buf, uint64_t capacity, int W, uint32_t* fill, uint32
 void launch_tri_count_events(const Graph& g, const uint64_t* mbits, const StrongList& sl, const uint32_t* ebi,
                              const uint32_t* ebj, const uint32_t* ei, const uint32_t* ej, uint64_t E, int rank_mode,
                              uint32_t* tcnt, const EventList& ev, const Tuning& tn, hipStream_t st, const uint64_t* own,
-                             const uint32_t* ebase) {
+                             const uint32_t* ebase, const GramRefJob* ref) {
   if (E == 0) return;
   // lanes per edge: a lane walks (W - j / 64) / TG words one dependent round after the other, so wide rows want wide
   // groups (Tuning::tg_events forces one; measured r02: see DESIGN.md)
@@ -730,7 +738,9 @@ void launch_tri_count_events(const Graph& g, const uint64_t* mbits, const Strong
   if (nb < 256) nb = 256;
   if (nb > 4096) nb = 4096;
   if (tn.cnt_blocks >= 1 && tn.cnt_blocks <= 65535) nb = tn.cnt_blocks;
-#define SC_LAUNCH_CE(TGV) hipLaunchKernelGGL(tri_count_events_kernel<TGV>, dim3((unsigned)nb), dim3(256), 0, st, mbits, g.W, g.deg, ebi, ebj, ei, ej, sl, rank_mode, tcnt, ev, own, ebase, (int)tn.dbg_stop)
+  const GramRefJob rj = ref ? *ref : GramRefJob{};
+  if (rj.out) nb++;  // (workgroup 0 is the rider)
+#define SC_LAUNCH_CE(TGV) hipLaunchKernelGGL(tri_count_events_kernel<TGV>, dim3((unsigned)nb), dim3(256), 0, st, mbits, g.W, g.deg, ebi, ebj, ei, ej, sl, rank_mode, tcnt, ev, own, ebase, (int)tn.dbg_stop, rj)
   if (tg == 4) SC_LAUNCH_CE(4); else if (tg == 16) SC_LAUNCH_CE(16); else if (tg == 32) SC_LAUNCH_CE(32); else if (tg == 64) SC_LAUNCH_CE(64); else SC_LAUNCH_CE(8);
 #undef SC_LAUNCH_CE
 }
@@ -998,10 +1008,15 @@ __global__ __launch_bounds__(256) void tri_sample_words_kernel(const uint64_t* _
                                                                const float* __restrict__ es, uint64_t E, uint32_t rmask,
                                                                uint32_t* __restrict__ hist,
                                                                const uint64_t* __restrict__ E_dev,
-                                                               const uint32_t* __restrict__ ebase, int dbg_stop) {
+                                                               const uint32_t* __restrict__ ebase, int dbg_stop,
+                                                               uint4* __restrict__ cand,
+                                                               unsigned long long* __restrict__ cand_slot) {
   // ebase (with ebi == ebj == nullptr): the per-row CSR bases are looked up (after launch_edge_build)
+  // cand (optional): the best-keyed triangle this workgroup sampled, {key bits, i, j, k} (key 0: none) — the voters of stage
+  // C2's reference frame (sc_gramref.hpp)
   if (E_dev && *E_dev > E) return;  // (launched before the host knew the count: see tri_sample_hist_kernel)
   if (E_dev) E = *E_dev;
+  uint32_t best_key = 0u, best_i = 0u, best_j = 0u, best_k = 0u;
   __shared__ uint32_t lh[PR_BINS * PR_COPIES];
   for (int b = threadIdx.x; b < PR_BINS * PR_COPIES; b += 256) lh[b] = 0;
   __syncthreads();
@@ -1037,8 +1052,11 @@ __global__ __launch_bounds__(256) void tri_sample_words_kernel(const uint64_t* _
         }
 #pragma unroll
         for (int q = 0; q < 4; q++)
-          if (q < nbits)
-            atomicAdd(&lh[est_bin(__float_as_uint((s_ij + s_ik[q]) + s_jk[q])) * PR_COPIES + (threadIdx.x & (PR_COPIES - 1))], 1u);
+          if (q < nbits) {
+            const uint32_t kb = __float_as_uint((s_ij + s_ik[q]) + s_jk[q]);  // (keys are positive floats: their bits order like they do)
+            atomicAdd(&lh[est_bin(kb) * PR_COPIES + (threadIdx.x & (PR_COPIES - 1))], 1u);
+            if (kb > best_key) { best_key = kb; best_i = i; best_j = j; best_k = (uint32_t)(64 * w + b[q]); }
+          }
       }
     }
   }
@@ -1049,6 +1067,26 @@ __global__ __launch_bounds__(256) void tri_sample_words_kernel(const uint64_t* _
 #pragma unroll
     for (int c = 0; c < PR_COPIES; c++) v += lh[b * PR_COPIES + ((c + threadIdx.x) & (PR_COPIES - 1))];
     if (v) atomicAdd(&myh[b], v);
+  }
+  if (cand) {  // (kernel-uniform) the workgroup's best: by key, then by lowest thread — the sample is deterministic, so is this
+    __shared__ uint32_t s_best[4], s_who[4];
+    uint32_t bk = best_key, bt = threadIdx.x;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const uint32_t ok = (uint32_t)__shfl_xor((int)bk, o), ot = (uint32_t)__shfl_xor((int)bt, o);
+      if (ok > bk || (ok == bk && ot < bt)) { bk = ok; bt = ot; }
+    }
+    if ((threadIdx.x & 63) == 0) { s_best[threadIdx.x >> 6] = bk; s_who[threadIdx.x >> 6] = bt; }
+    __syncthreads();
+    uint32_t wk = s_best[0], wt = s_who[0];
+#pragma unroll
+    for (int v = 1; v < 4; v++)
+      if (s_best[v] > wk) { wk = s_best[v]; wt = s_who[v]; }  // (waves in order: equal keys keep the lower thread)
+    if (threadIdx.x == wt) {
+      cand[blockIdx.x] = wk ? make_uint4(best_key, best_i, best_j, best_k) : make_uint4(0u, 0u, 0u, 0u);
+      // voter v of the frame = the best candidate among the workgroups = v (mod 64): one 64-bit max per workgroup (ControlBlock::ref_slot, zeroed per call)
+      if (wk) atomicMax(&cand_slot[blockIdx.x & 63u], ((unsigned long long)wk << 32) | (unsigned long long)blockIdx.x);
+    }
   }
 }
 
@@ -1447,16 +1485,21 @@ SamplePlan sample_plan(uint64_t want, bool allow_estimate, const Tuning& tn, uin
   return sp;
 }
 
-void launch_sample_estimate(const Graph& g, const uint32_t* ebi, const uint32_t* ebj, const uint32_t* ei, const uint32_t* ej,
-                            const float* es, uint64_t E, float key_floor, uint32_t rate, uint32_t* hist, const Tuning& tn,
-                            hipStream_t st, const uint64_t* E_dev, const uint32_t* ebase) {
-  if (E == 0) return;
-  (void)key_floor;  // (the logarithmic bins need no window)
+uint32_t sample_estimate_blocks(uint64_t E, const Tuning& tn) {
   uint64_t nb = (E + 255) / 256;
   if (nb > 4096) nb = 4096;
   if (tn.sample_blocks) nb = tn.sample_blocks;
-  hipLaunchKernelGGL(tri_sample_words_kernel, dim3((unsigned)nb), dim3(256), 0, st, g.bits, g.W, g.wpre, ebi, ebj, ei, ej, es, E,
-                     rate - 1u, hist, E_dev, ebase, (int)tn.dbg_stop);
+  return (uint32_t)nb;
+}
+
+void launch_sample_estimate(const Graph& g, const uint32_t* ebi, const uint32_t* ebj, const uint32_t* ei, const uint32_t* ej,
+                            const float* es, uint64_t E, float key_floor, uint32_t rate, uint32_t* hist, const Tuning& tn,
+                            hipStream_t st, const uint64_t* E_dev, const uint32_t* ebase, uint4* cand, unsigned long long* cand_slot) {
+  if (E == 0) return;
+  (void)key_floor;  // (the logarithmic bins need no window)
+  const uint32_t nb = sample_estimate_blocks(E, tn);
+  hipLaunchKernelGGL(tri_sample_words_kernel, dim3(nb), dim3(256), 0, st, g.bits, g.W, g.wpre, ebi, ebj, ei, ej, es, E,
+                     rate - 1u, hist, E_dev, ebase, (int)tn.dbg_stop, cand_slot ? cand : nullptr, cand_slot);
 }
 
 void launch_prune_bits(const Graph& g, const uint32_t* hist, bool hist_is_copies, const uint32_t* ei, const uint32_t* ej, const float* es,
