@@ -74,6 +74,14 @@ GPU_CLOCK_HZ = 2.4e9       # same guide: peak engine clock
 N_SIMD = 256 * 4
 
 
+def executed_tests(n: int, info: dict) -> float:
+    """(hypothesis, correspondence) pairs the Gram filter's launch really evaluates (sc_debug_last): rows near the call's reference
+    frame walk the near correspondences only (whole 256-correspondence units), the others every unit of the padded list."""
+    near_units = (info["gram_near_corr"] + 255) // 256
+    n_pad = ((n + 1023) // 1024) * 1024
+    return float(info["gram_near_hyp"]) * near_units * 256 + float(info["gram_rows"] - info["gram_near_hyp"]) * n_pad
+
+
 def issue_model(n: int, n_local: int, us: float, info: dict) -> dict:
     """The C2 filter kernel against its OWN issue limits, so that `roofline.frac` — an fp32-EQUIVALENT rate —
     is not read as a utilisation.  A step = the MFMAs that produce one accumulator tile plus the vector instructions that
@@ -89,6 +97,8 @@ def issue_model(n: int, n_local: int, us: float, info: dict) -> dict:
     windows = (n + 1023) // 1024
     hyp_per_wave, mfma_per_step, valu = (32, 3, 29.0) if gram else (8, 1, 26.0)
     steps = (n_local / float(hyp_per_wave)) * windows * 32          # accumulator tiles of the launch
+    if gram and info.get("gram_rows"):                               # the cut: the tiles the launch really evaluates
+        steps = executed_tests(n, info) / (32.0 * hyp_per_wave)
     per_simd = steps / N_SIMD
     cyc = us * 1e-6 * GPU_CLOCK_HZ / max(per_simd, 1.0)
     matrix = 32.0 * mfma_per_step
@@ -372,7 +382,10 @@ def main() -> int:
         # an f16 matrix-pipe kernel can pass 1.0 of; that number stays as `fp32_equivalent`, and the distance from the SIMD's
         # issue port, which is what really bounds the kernel, as `issue_model`.
         mfma_per_test = {1: 128.0, 2: 96.0}.get(c2_info["c2_kernel"], 0.0)
-        mfma_tflops = mfma_per_test * n_local * n / (max(us_score, 1e-3) * 1e-6) / 1e12
+        # r04b: the Gram filter EVALUATES only part of the n_local x n tests — the rest are decided by the triangle inequality
+        # against the call's reference frame — so its executed flops are counted on what it evaluates
+        tests_exec = executed_tests(n, c2_info) if c2_info["c2_kernel"] == 2 and c2_info.get("gram_rows") else float(n_local) * n
+        mfma_tflops = mfma_per_test * tests_exec / (max(us_score, 1e-3) * 1e-6) / 1e12
         roof_score = {"kernel": fk,
                       "bound": "mfma" if filtered else "valu",
                       "achieved": round(mfma_tflops if filtered else score_tflops, 2),
@@ -381,6 +394,11 @@ def main() -> int:
                       "fp32_equivalent": {"achieved": round(score_tflops, 2), "peak": FP32_PEAK_TFLOPS,
                                           "frac": round(score_tflops / FP32_PEAK_TFLOPS, 4)} if filtered else None,
                       "traffic": None, "algorithmic_flops": score_flops, "avg_us": round(us_score, 2),
+                      "tests": {"decided": float(n_local) * n, "evaluated": tests_exec,
+                                "evaluated_frac": round(tests_exec / max(float(n_local) * n, 1.0), 4),
+                                "decided_per_s": round(float(n_local) * n / (max(us_score, 1e-3) * 1e-6), 1),
+                                "near_hypotheses": c2_info.get("gram_near_hyp"), "near_correspondences": c2_info.get("gram_near_corr"),
+                                "rows": c2_info.get("gram_rows")} if c2_info["c2_kernel"] == 2 else None,
                       "issue_model": issue_model(n, n_local, us_score, c2_info) if filtered else None,
                       "note": ("`achieved` = f16 MFMA flops EXECUTED per second over the whole C2 stage (filter + exact pass), `peak` the dense "
                                "f16 MFMA rate: the matrix pipe is far from saturated because the SIMD's issue port, shared with the vector "
@@ -389,9 +407,10 @@ def main() -> int:
                                "against the plain kernel, not a utilisation. " if filtered else "") +
                               ({1: "stage C2 = fp16-split matrix-pipe filter on the residual VECTOR (4.75 vector instructions + 1/256 MFMA per "
                                    "test) + exact fp32 pass over the undecided tests; counts identical to the fp32 kernel. ",
-                                2: "stage C2 = Gram-form matrix-pipe filter (the MFMA evaluates the SQUARED residual: 1.6 vector "
-                                   "instructions + 3/1024 MFMA per test) + exact fp32 pass over the undecided tests; counts identical to "
-                                   "the fp32 kernel. ", 0: "fp32 vector kernel. "}[c2_info["c2_kernel"]]) +
+                                2: "stage C2 = Gram-form matrix-pipe filter in the frame of a voted reference hypothesis (the MFMA "
+                                   "evaluates the SQUARED residual: 1.6 vector instructions + 3/1024 MFMA per evaluated test; hypotheses near "
+                                   "the frame skip every correspondence the triangle inequality rules out: `tests`) + exact fp32 pass over the "
+                                   "undecided tests; counts identical to the fp32 kernel. ", 0: "fp32 vector kernel. "}[c2_info["c2_kernel"]]) +
                               "not HBM-bound (~8 MB moved); duration from HIP events inside the timed steps (SC_FLAG_TIMING_HOT: the "
                               "dispatch packets' own timestamps)"}
         # HBM bytes per launch from the committed rocprofv3 --pmc passes of this same command (tools/pmc_collect.sh,
