@@ -568,7 +568,7 @@ int run_edges(sc_ctx* c, const sc_params* p, uint32_t* hist, uint32_t part, uint
           HIPCHK(c, hipMemsetAsync(c->ref_cand.p, 0, 4096 * sizeof(uint4), st));
         }
         cand = c->ref_cand.as<uint4>();
-        c->ref_cand_n = sample_estimate_blocks(E, c->tn);
+        c->ref_cand_n = sample_candidate_blocks(E, c->tn);
       }
       launch_sample_estimate(g, build ? nullptr : c->ebi.as<uint32_t>(), build ? nullptr : c->ebj.as<uint32_t>(), c->ei.as<uint32_t>(),
                              c->ej.as<uint32_t>(), c->es.as<float>(), E, 3.0f * p->t_cmp * 0.999f, c->plan.rate, ctl->prune_hist, c->tn,

@@ -107,10 +107,11 @@ struct GramRefJob {  // (all null / 0: no vote)
 // agreeing voters (its displacement field differs from the other's by less than ~6 tau anywhere in the source cloud's box; ties:
 // the lower lane) becomes (R0, t0).  Thread 0 then writes the frame and clears the class counters.  No finite voter, or
 // tau = 0: the frame that moves the centre of one box onto the other's, which is r03's form.
-__device__ inline void gram_ref_block(const GramRefJob& job) {
+constexpr int GX_REF_LDS_WORDS = GX_VOTE * 12 + 4 * GX_VOTE;  // LDS the vote needs (4 KiB): the caller lends it
+__device__ inline void gram_ref_block(const GramRefJob& job, float* __restrict__ lds) {
   static_assert(GX_VOTE == 64, "one wave of voters");
-  __shared__ float sR[GX_VOTE][12];
-  __shared__ float s_score[4][GX_VOTE];
+  float (*sR)[12] = reinterpret_cast<float (*)[12]>(lds);
+  float (*s_score)[GX_VOTE] = reinterpret_cast<float (*)[GX_VOTE]>(lds + GX_VOTE * 12);
   const float* __restrict__ planes = job.planes;
   const int n = job.n, ld = job.ld;
   const uint32_t* __restrict__ mx = job.mx;

@@ -240,6 +240,7 @@ void launch_sample_estimate(const Graph& g, const uint32_t* ebi, const uint32_t*
                             hipStream_t st, const uint64_t* E_dev = nullptr, const uint32_t* ebase = nullptr,  // ebase: with ebi == ebj == nullptr
                             uint4* cand = nullptr, unsigned long long* cand_slot = nullptr);  // cand (optional, sample_estimate_blocks() entries): the best-keyed triangle each workgroup sampled {key bits, i, j, k} — the voters of stage C2's reference frame (sc_gramref.hpp)
 uint32_t sample_estimate_blocks(uint64_t E, const Tuning& tn);  // workgroups launch_sample_estimate uses
+uint32_t sample_candidate_blocks(uint64_t E, const Tuning& tn);  // ... of which the first so many leave a candidate behind
 // es_hist: PR_HCOPIES x 256 words (control block) for the weight histogram of the heaviest-edge sample: zeroed, or —
 // es_hist_ready — already filled by launch_edge_fill
 // launch_sample_hist ALWAYS accumulates into PR_HCOPIES x 256 words (`hist` = the control block's copies);

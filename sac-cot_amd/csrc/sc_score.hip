@@ -682,6 +682,23 @@ FilterPlan filter_plan(int n, uint32_t ld_local, const Tuning& tn, uint32_t mode
     const uint32_t per = (fp.windows + fp.splits - 1) / fp.splits;
     fp.splits = (fp.windows + per - 1) / per;
   }
+  if (mode == 2) {
+    // The Gram filter cuts in UNITS (gram_geom), and only its rows FAR from the call's frame — a tenth of them on the BASELINE
+    // scenes — walk every unit.  Their workgroups must not outlast everything else (C3 at 3 splits of 27 units: 113 of the
+    // kernel's 120 us were those workgroups' own length), but every split is another workgroup per group of rows with its own
+    // set-up (C4: 112 / 127 / 138 / 150 us at 1 / 3 / 5 / 8 splits).  So: the fewest splits that keep a far workgroup's walk —
+    // ~4.2 us per unit — under half of what the whole launch should take if 15 % of the rows are far and a fifth of the
+    // correspondences near (0.32 units' worth per group and unit, over 512 resident workgroups), and never below 4 units.
+    // C2 5 splits (4 units), C3 5 (16), C4 2 (10).  (Empty workgroups cost nothing: tools/ubench/dispatch_rate.hip, 0.25 ns apiece.)
+    const uint32_t units = fp.windows * (uint32_t)(FX_WIN / GX_UNIT);
+    const double launch_units = 0.5 * (double)groups * 0.32 * (double)units / 512.0;  // half the launch, in units of one workgroup's walk
+    const uint32_t walk = launch_units < 4.0 ? 4u : (uint32_t)launch_units;
+    uint32_t sp = tn.filter_splits ? tn.filter_splits : (units + walk - 1) / walk;
+    sp = sp < 1u ? 1u : (sp > 8u ? 8u : sp);
+    if (sp > units) sp = units;
+    const uint32_t pu = (units + sp - 1) / sp;
+    fp.splits = (units + pu - 1) / pu;  // every split gets at least one unit
+  }
   fp.rows = fp.windows * FX_WIN + (mode == 2 ? GX_UNIT : FX_UNIT);
   uint64_t cap = (uint64_t)ld_local * (uint64_t)n / 512;  // ~20x what the BASELINE scenes queue
   if (cap < (1u << 16)) cap = 1u << 16;
@@ -960,6 +977,26 @@ __global__ __launch_bounds__(64 * WAVES, (VAR & 128) ? 8 : ((VAR & 1) ? 5 : 6)) 
   }
 }
 
+// How the Gram filter's launch cuts the tile's units (256 correspondences) into the `splits` workgroups of a group of 256 rows —
+// shared by the filter and the exact pass (which must find the split a queued test belongs to).
+//   rows not all near the frame: split y walks units [y pu_far, (y + 1) pu_far) of ALL the units;
+//   rows all near the frame:     only `ns` splits work — split y walks [y pu_near, (y + 1) pu_near) of the NEAR units —, and ns grows
+//                                beyond 1 only while the launch has fewer workgroups than the chip has slots (C2: 196 groups).
+struct GramGeom { uint32_t units, near_units, pu_far, ns, pu_near; };
+__device__ __forceinline__ GramGeom gram_geom(uint32_t windows, uint32_t splits, uint32_t groups, const GramFrame* __restrict__ fr) {
+  GramGeom g;
+  g.units = windows * (uint32_t)(FX_WIN / GX_UNIT);
+  g.near_units = min(g.units, ((uint32_t)fr->pts + GX_UNIT - 1) / GX_UNIT);
+  g.pu_far = (g.units + splits - 1) / splits;
+  const uint32_t room = 512u / max(groups, 1u);
+  g.ns = max(1u, min(min(splits, max(g.near_units, 1u)), room));
+  g.pu_near = (max(g.near_units, 1u) + g.ns - 1) / g.ns;
+  return g;
+}
+__device__ __forceinline__ bool gram_near_block(uint32_t bx, uint32_t S, const GramFrame* __restrict__ fr) {
+  return (bx / S + 1u) * (32u * GX_WAVES) <= (uint32_t)fr->seg[bx % S].cnt;  // all 256 rows are hypotheses near the frame
+}
+
 // X.  First the queued tests (one per thread; workgroup b serves sub-queue b % FX_NQ), then the (wave, split) pairs F
 // gave up on (one per workgroup at a time).  Everything here is the canonical chain; the counts are integers.
 __device__ __forceinline__ void load_rt_aos(const float4* __restrict__ RtAoS, uint32_t h, float (&M)[12]) {
@@ -975,17 +1012,23 @@ __global__ __launch_bounds__(256) void score_exact_kernel(const float* __restric
                                                           const uint32_t* __restrict__ redo_bits,
                                                           uint32_t* __restrict__ cnt_out,
                                                           const uint32_t* __restrict__ hperm,
-                                                          const uint32_t* __restrict__ pperm) {
+                                                          const uint32_t* __restrict__ pperm,
+                                                          const GramFrame* __restrict__ fr) {
   // hperm / pperm (the Gram filter; null for the linear one): its rows are PERMUTED — coefficient row -> hypothesis, tile row ->
   // correspondence.  Queue entries and recount bits speak of rows; the counts and the canonical chain of hypotheses and correspondences.
   const bool gram = hperm != nullptr;
   const uint32_t per = (windows + splits - 1) / splits;
+  // the Gram filter's splits are cut in units, differently for rows near the frame and the others (gram_geom)
+  const uint32_t groups = ldl / (32u * GX_WAVES), S = gram_segments(groups);
+  GramGeom gg{};
+  if (gram) gg = gram_geom(windows, splits, groups, fr);
   const float4* __restrict__ aos4 = reinterpret_cast<const float4*>(planes + 6 * (size_t)ld);  // 8 floats per correspondence
   const uint32_t sq = blockIdx.x % FX_NQ, nq = min(qcount[sq * 32], cap_sq);
   for (uint32_t i = (blockIdx.x / FX_NQ) * 256 + threadIdx.x; i < nq; i += (gridDim.x / FX_NQ) * 256) {
     const uint2 e = gq[(size_t)sq * cap_sq + i];
     if (gram) {  // {tile row, wave of 32 rows << 17 | lane half << 16 | one bit per accumulator register}
-      const uint32_t mr = e.x, w32 = e.y >> 17, ehf = (e.y >> 16) & 1u, sp = (mr / FX_WIN) / per;
+      const uint32_t mr = e.x, w32 = e.y >> 17, ehf = (e.y >> 16) & 1u;
+      const uint32_t sp = (mr / (uint32_t)GX_UNIT) / (gram_near_block(w32 / GX_WAVES, S, fr) ? gg.pu_near : gg.pu_far);
       const uint32_t m = pperm[mr];
       const float4 pa = aos4[2 * (size_t)m], pb = aos4[2 * (size_t)m + 1];
       for (uint32_t bits = e.y & 0xFFFFu; bits; bits &= bits - 1) {
@@ -1023,8 +1066,13 @@ __global__ __launch_bounds__(256) void score_exact_kernel(const float* __restric
       float M[12];
       load_rt_aos(RtAoS, h, M);
       const bool ok = finite12(M);
-      // (every row of the split: for a NEAR hypothesis that is more than its filter workgroup looked at — exact all the same)
-      const uint32_t m0 = sp * per * FX_WIN, m1 = min((uint32_t)n, min(windows, (sp + 1) * per) * FX_WIN);
+      uint32_t m0 = sp * per * FX_WIN, m1 = min((uint32_t)n, min(windows, (sp + 1) * per) * FX_WIN);
+      if (gram) {  // the units its filter workgroup walked (rows near the frame: of the near units only — the rest cannot hold an inlier)
+        const bool nb = gram_near_block(wid / 32u, S, fr);
+        const uint32_t pu = nb ? gg.pu_near : gg.pu_far, ue = nb ? gg.near_units : gg.units;
+        m0 = sp * pu * (uint32_t)GX_UNIT;
+        m1 = min((uint32_t)n, min(ue, (sp + 1) * pu) * (uint32_t)GX_UNIT);
+      }
       uint32_t cnt = 0;
       for (uint32_t mr = m0 + (threadIdx.x >> 3); mr < m1; mr += 32) {
         const uint32_t m = gram ? pperm[mr] : mr;
@@ -1115,7 +1163,10 @@ __device__ __forceinline__ void split2(double x, _Float16& hi, _Float16& lo) {
 }
 
 // the vote in a launch of its own (stage hook, sharded stage C, certified paths: wherever the counting pass did not carry it)
-__global__ __launch_bounds__(4 * GX_VOTE) void gram_ref_kernel(GramRefJob job) { gram_ref_block(job); }
+__global__ __launch_bounds__(4 * GX_VOTE) void gram_ref_kernel(GramRefJob job) {
+  __shared__ float lds[GX_REF_LDS_WORDS];
+  gram_ref_block(job, lds);
+}
 
 // exclusive rank of this thread among the threads of its 256-thread workgroup for which `flag` holds, and their number
 // (two barriers; every thread of the workgroup must call it)
@@ -1491,21 +1542,30 @@ __global__ __launch_bounds__(64 * GX_WAVES, 2) void score_gram_kernel(GramCoef c
   constexpr int PIECES = GX_UNIT * GX_TILE_Q / (64 * GX_WAVES);  // LDS-DMA instructions per wave and unit
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int col = lane & 31, hf = lane >> 5;
-  // The grid is one-dimensional, groups x splits workgroups, and the LONG ones go first: the row blocks that hold a hypothesis
-  // not near the reference are the LAST ones of their segment (sc_gramref.hpp: segment = row block % S) — the highest row blocks —
-  // and walk every correspondence, the others a few units of split 0 (dispatched in row order, the last workgroups to start were
-  // the longest: a tail as long as the kernel's useful part).
+  // The grid is one-dimensional, groups x splits workgroups, and within a split the LONG ones go first: the row blocks that hold
+  // a hypothesis not near the reference are the LAST ones of their segment (sc_gramref.hpp: segment = row block % S) — the highest
+  // row blocks — and walk every correspondence, the others a few near units (dispatched in row order, the last workgroups to
+  // start were the longest: a tail as long as the kernel's useful part).
   const GramFrame* __restrict__ fr = coef.frame;
   const uint32_t groups = gridDim.x / splits, S = gram_segments(groups);
-  const uint32_t bx = groups - 1u - blockIdx.x / splits, by = blockIdx.x % splits;
-  const uint32_t per = (windows + splits - 1) / splits, w0 = by * per, w1 = min(windows, w0 + per);
+  // (split-major: consecutive workgroups go to different XCDs — blockIdx % 8 — and with by = blockIdx % splits every WORKING
+  // workgroup of the near rows, by = 0, landed on the same XCD when splits was 8: C3 508 us instead of 150)
+  const uint32_t bx = groups - 1u - blockIdx.x % groups, by = blockIdx.x / groups;
   const uint32_t wid = bx * GX_WAVES + wave;  // wave of 32 hypotheses
-  constexpr uint32_t UPW = FX_WIN / GX_UNIT;          // units per window
   // The cut: a workgroup whose 256 rows are all hypotheses NEAR the reference walks the NEAR correspondences only — the tile's
   // first rows; every other correspondence is an outlier of every one of them by the triangle inequality (see the header).
-  const uint32_t near_units = ((uint32_t)fr->pts + GX_UNIT - 1) / GX_UNIT;
-  const bool near_block = (bx / S + 1u) * (32u * GX_WAVES) <= (uint32_t)fr->seg[bx % S].cnt;  // all 256 rows are NEAR hypotheses
-  const uint32_t u0 = w0 * UPW, u1 = near_block ? min(w1 * UPW, near_units) : w1 * UPW;
+  const GramGeom gg = gram_geom(windows, splits, groups, fr);
+  const bool near_block = gram_near_block(bx, S, fr);
+  if (near_block && by >= gg.ns) return;  // (its rows of these splits are cleared by split 0, below)
+  const uint32_t u0 = by * (near_block ? gg.pu_near : gg.pu_far);
+  const uint32_t u1 = near_block ? min(u0 + gg.pu_near, gg.near_units) : min(u0 + gg.pu_far, gg.units);
+  if (near_block && by == 0 && hf == 0) {  // the splits no workgroup of these rows works in count nothing
+    const uint32_t hh = wid * 32 + (uint32_t)col;
+    if (hh < ldl) {
+      const uint32_t hrow = coef.hperm[hh];
+      for (uint32_t y = gg.ns; y < splits; y++) cnt_out[(size_t)y * ldl + hrow] = 0u;
+    }
+  }
   if (u0 >= u1) {  // (workgroup-uniform) nothing to look at in this split
     const uint32_t hh = wid * 32 + (uint32_t)col;
     if (hf == 0 && hh < ldl) cnt_out[(size_t)by * ldl + coef.hperm[hh]] = 0u;
@@ -1666,7 +1726,7 @@ __global__ __launch_bounds__(64 * GX_WAVES, 2) void score_gram_kernel(GramCoef c
       }
       // beyond ql entries were dropped — the exact pass takes the whole (wave, split)
       if (qn > ql) { redo4 = 0xFu; qn = 0; }
-      if ((u + 1) % UPW == 0) {  // window boundary: 32 tests per register
+      if (((u - u0 + 1) & 3u) == 0) {  // every fourth unit: 32 tests per register
 #pragma unroll
         for (int i = 0; i < 16; i++) { total[i] += (uint32_t)__popc(sr[i]); sr[i] = 0; }
       }
@@ -1790,7 +1850,7 @@ void launch_score_filter(const Points& pts, const float* RtSoA, const float* RtA
                           reinterpret_cast<const float4*>(RtAoS), sh.ld_local, dv.tau2, fp.windows, fp.splits, fp.n_waves,
                           static_cast<const uint2*>(f.queue), f.cap_sq, static_cast<const uint32_t*>(f.qcount),
                           static_cast<const uint32_t*>(f.redo), partial, static_cast<const uint32_t*>(gc.hperm),
-                          static_cast<const uint32_t*>(gc.pperm));
+                          static_cast<const uint32_t*>(gc.pperm), static_cast<const GramFrame*>(gc.frame));
     return;
   }
   uint32_t ql = tn.filter_lds_queue ? tn.filter_lds_queue : (uint32_t)FX_QL;
@@ -1827,7 +1887,7 @@ void launch_score_filter(const Points& pts, const float* RtSoA, const float* RtA
                         reinterpret_cast<const float4*>(RtAoS), sh.ld_local, dv.tau2, fp.windows, fp.splits, fp.n_waves,
                         static_cast<const uint2*>(f.queue), f.cap_sq, static_cast<const uint32_t*>(f.qcount),
                         static_cast<const uint32_t*>(f.redo), partial, static_cast<const uint32_t*>(nullptr),
-                        static_cast<const uint32_t*>(nullptr));
+                        static_cast<const uint32_t*>(nullptr), static_cast<const GramFrame*>(nullptr));
 }
 
 hipError_t filter_read_counters(const void* state, const FilterPlan& fp, hipStream_t st, uint64_t* undecided, uint64_t* recounts) {

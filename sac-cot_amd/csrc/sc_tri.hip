@@ -433,7 +433,6 @@ __global__ __launch_bounds__(256) void tri_count_events_kernel(const uint64_t* _
   // stage C2's Gram filter among the candidate triangles the estimating sample left behind (sc_gramref.hpp): ~10 us of one
   // workgroup's latency that would otherwise stand between the selection and the Kabsch launch, hidden under this launch
   const uint32_t rider = ref.out ? 1u : 0u;
-  if (rider && blockIdx.x == 0) { gram_ref_block(ref); return; }
   const uint32_t bid = blockIdx.x - rider, nblk = gridDim.x - rider;
   // ebase (with ebi == ebj == nullptr): the per-row CSR bases are looked up (edge_build_kernel does not write them per edge)
   // own (optional, sharded stage B): [lo, hi) of the edges this rank enumerates; the strong list holds every rank's, the
@@ -442,6 +441,8 @@ __global__ __launch_bounds__(256) void tri_count_events_kernel(const uint64_t* _
   __shared__ uint64_t l_m[4 * EVW];
   __shared__ uint32_t l_wi[4 * EVW], l_wj[4 * EVW], l_a[4 * EVW], l_b[4 * EVW], l_e[4 * EVW], l_rb[4 * EVW];
   __shared__ uint32_t l_pre[ST_SHARDS + 1];  // exclusive prefix of the strong-list region fills
+  static_assert(sizeof(l_m) >= GX_REF_LDS_WORDS * sizeof(float), "the rider borrows the event staging area");
+  if (rider && blockIdx.x == 0) { gram_ref_block(ref, reinterpret_cast<float*>(l_m)); return; }
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int gl = threadIdx.x & (TG - 1);
   static_assert(ST_SHARDS == 256, "one region per thread");
@@ -999,6 +1000,7 @@ __device__ __forceinline__ uint32_t edge_hash(uint32_t e) {
   return e;
 }
 
+constexpr uint32_t SAMPLE_CAND_BLOCKS = 256;  // workgroups of the estimating sample that leave a candidate triangle behind
 __global__ __launch_bounds__(256) void tri_sample_words_kernel(const uint64_t* __restrict__ bits, int W,
                                                                const uint32_t* __restrict__ wpre,
                                                                const uint32_t* __restrict__ ebi,
@@ -1016,7 +1018,10 @@ __global__ __launch_bounds__(256) void tri_sample_words_kernel(const uint64_t* _
   // C2's reference frame (sc_gramref.hpp)
   if (E_dev && *E_dev > E) return;  // (launched before the host knew the count: see tri_sample_hist_kernel)
   if (E_dev) E = *E_dev;
-  uint32_t best_key = 0u, best_i = 0u, best_j = 0u, best_k = 0u;
+  uint32_t best_key = 0u, best_e = 0u, best_k = 0u;  // (E < 2^32)
+  // only the first SAMPLE_CAND_BLOCKS workgroups keep their best triangle (tracking it in every one cost the launch 3.6 us at C2;
+  // 64 voters want 64 good triangles, and the best of these workgroups' ~50 000 sampled keys per voter is that)
+  const bool track = cand != nullptr && blockIdx.x < SAMPLE_CAND_BLOCKS;
   __shared__ uint32_t lh[PR_BINS * PR_COPIES];
   for (int b = threadIdx.x; b < PR_BINS * PR_COPIES; b += 256) lh[b] = 0;
   __syncthreads();
@@ -1055,7 +1060,7 @@ __global__ __launch_bounds__(256) void tri_sample_words_kernel(const uint64_t* _
           if (q < nbits) {
             const uint32_t kb = __float_as_uint((s_ij + s_ik[q]) + s_jk[q]);  // (keys are positive floats: their bits order like they do)
             atomicAdd(&lh[est_bin(kb) * PR_COPIES + (threadIdx.x & (PR_COPIES - 1))], 1u);
-            if (kb > best_key) { best_key = kb; best_i = i; best_j = j; best_k = (uint32_t)(64 * w + b[q]); }
+            if (track && kb > best_key) { best_key = kb; best_e = (uint32_t)e; best_k = (uint32_t)(64 * w + b[q]); }
           }
       }
     }
@@ -1068,22 +1073,20 @@ __global__ __launch_bounds__(256) void tri_sample_words_kernel(const uint64_t* _
     for (int c = 0; c < PR_COPIES; c++) v += lh[b * PR_COPIES + ((c + threadIdx.x) & (PR_COPIES - 1))];
     if (v) atomicAdd(&myh[b], v);
   }
-  if (cand) {  // (kernel-uniform) the workgroup's best: by key, then by lowest thread — the sample is deterministic, so is this
+  if (track) {  // (workgroup-uniform) the workgroup's best: by key, then by lowest thread — the sample is deterministic, so is this
     __shared__ uint32_t s_best[4], s_who[4];
-    uint32_t bk = best_key, bt = threadIdx.x;
+    uint32_t bk = best_key;
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-      const uint32_t ok = (uint32_t)__shfl_xor((int)bk, o), ot = (uint32_t)__shfl_xor((int)bt, o);
-      if (ok > bk || (ok == bk && ot < bt)) { bk = ok; bt = ot; }
-    }
-    if ((threadIdx.x & 63) == 0) { s_best[threadIdx.x >> 6] = bk; s_who[threadIdx.x >> 6] = bt; }
+    for (int o = 32; o > 0; o >>= 1) bk = max(bk, (uint32_t)__shfl_xor((int)bk, o));
+    const uint64_t holders = __ballot(best_key == bk);
+    if ((threadIdx.x & 63) == 0) { s_best[threadIdx.x >> 6] = bk; s_who[threadIdx.x >> 6] = (threadIdx.x & ~63u) + (uint32_t)(__ffsll((unsigned long long)holders) - 1); }
     __syncthreads();
     uint32_t wk = s_best[0], wt = s_who[0];
 #pragma unroll
     for (int v = 1; v < 4; v++)
       if (s_best[v] > wk) { wk = s_best[v]; wt = s_who[v]; }  // (waves in order: equal keys keep the lower thread)
     if (threadIdx.x == wt) {
-      cand[blockIdx.x] = wk ? make_uint4(best_key, best_i, best_j, best_k) : make_uint4(0u, 0u, 0u, 0u);
+      cand[blockIdx.x] = wk ? make_uint4(best_key, ei[best_e], ej[best_e], best_k) : make_uint4(0u, 0u, 0u, 0u);
       // voter v of the frame = the best candidate among the workgroups = v (mod 64): one 64-bit max per workgroup (ControlBlock::ref_slot, zeroed per call)
       if (wk) atomicMax(&cand_slot[blockIdx.x & 63u], ((unsigned long long)wk << 32) | (unsigned long long)blockIdx.x);
     }
@@ -1490,6 +1493,10 @@ uint32_t sample_estimate_blocks(uint64_t E, const Tuning& tn) {
   if (nb > 4096) nb = 4096;
   if (tn.sample_blocks) nb = tn.sample_blocks;
   return (uint32_t)nb;
+}
+uint32_t sample_candidate_blocks(uint64_t E, const Tuning& tn) {  // how many of them write a candidate (launch_sample_estimate, cand)
+  const uint32_t nb = sample_estimate_blocks(E, tn);
+  return nb < SAMPLE_CAND_BLOCKS ? nb : SAMPLE_CAND_BLOCKS;
 }
 
 void launch_sample_estimate(const Graph& g, const uint32_t* ebi, const uint32_t* ebj, const uint32_t* ei, const uint32_t* ej,
