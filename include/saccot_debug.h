@@ -36,7 +36,7 @@ typedef struct sc_debug {
   uint32_t compact_fused;     /* 1: compaction in one launch (look-back over the tiles) instead of count + write    */
   uint32_t rows_unfused;      /* 1: row statistics and the scans of the row counts as separate launches             */
   uint32_t score_scalar;      /* 1: stage C2 counts inliers with the lane = correspondence kernel (measured slower)  */
-  uint32_t score_filter;      /* stage C2, inlier count: 0 = by size and scale (plain fp32 kernel for small calls; for large ones a matrix-pipe filter + exact fix-up: the Gram filter where tau is not small against the clouds, else the linear one); 1 = always plain; 2 = always the linear filter; 3 = always the Gram filter */
+  uint32_t score_filter;      /* stage C2, inlier count: 0 = by size and scale (plain fp32 kernel for small calls; for large ones a matrix-pipe filter + exact fix-up: the Gram filter — in the frame of a voted reference hypothesis, with its triangle-inequality cut — wherever its shells fit inside tau^2, else the linear one); 1 = always plain; 2 = always the linear filter; 3 = always the Gram filter */
   uint32_t filter_splits;     /* grid.y of the filter kernel (0 = by size)                                            */
   uint32_t filter_queue_cap;  /* entries of the filter's queue of undecided tests (0 = by size): a small one forces the recount path */
   uint32_t filter_lds_queue;  /* entries of a wave's own queue, 64 .. 256 (0 = 256)                                   */

@@ -588,7 +588,7 @@ struct FilterState {  // device view of the state buffer (filter_plan().state_by
 static FilterState filter_state(void* state, const FilterPlan& fp) {
   FilterState f;
   unsigned char* p = static_cast<unsigned char*>(state);
-  f.info = reinterpret_cast<FilterInfo*>(p); p += FX_INFO_BYTES;  // (the Gram filter's frame sits at offset 64)
+  f.info = reinterpret_cast<FilterInfo*>(p); p += FX_INFO_BYTES;
   f.qcount = reinterpret_cast<uint32_t*>(p); p += (size_t)FX_NQ * 128;
   f.redo = reinterpret_cast<uint32_t*>(p);
   const size_t bm_words = ((size_t)fp.splits * fp.n_waves + 31) / 32;
@@ -600,7 +600,9 @@ static FilterState filter_state(void* state, const FilterPlan& fp) {
 }
 
 // Which kernel.  The filters pay a tile kernel, an exact pass and a few microseconds of set-up per workgroup: below ~1.3e8
-// tests the plain kernel is as fast or faster (C1, 2e7 tests: 9 us plain, 20 us filtered).
+// tests the plain kernel is as fast or faster (C1, 2e7 tests: 9 us plain, 20 us filtered).  Big calls take the Gram filter
+// wherever even a hypothesis FAR from the call's reference frame keeps its shell inside tau'^2 (all four BASELINE scenes since
+// r04b; until then tau had to be > ~2 % of the clouds' extent, which left C3 to the linear filter), else the linear one.
 int score_filter_mode(int score_mode, const Tuning& tn, int n, uint32_t ld_local, uint64_t host_max, const uint64_t* host_box,
                       float tau2) {
   if (score_mode != 0 || tn.score_filter == 1 || tn.score_split != 0 || tn.score_scalar) return 0;
