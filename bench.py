@@ -196,11 +196,11 @@ def main() -> int:
     ap.add_argument("--config", default="C2", help="synthetic scene template (default: the headline config C2)")
     ap.add_argument("--scaling", choices=("weak", "strong"), default="weak")
     ap.add_argument("--shard", choices=("auto", "ab", "replicated"), default="auto",
-                    help="N > 1: shard stages A and B too (ab) or replicate them (round 1's form); auto = ab, except under weak "
-                         "scaling on a small graph (n < 8192): there one rank's emulated step is 0.31 / 0.32 / 0.38 ms replicated "
-                         "against 0.32 / 0.31 / 0.34 ms sharded at 2 / 4 / 8 ranks (profiles/r03_emulated_world_scaling.txt, "
-                         "copies standing in for the collectives) and the replicated form needs one or two collectives per "
-                         "step instead of four, whose latency the emulation does not contain")
+                    help="N > 1: shard stages A and B too (ab) or replicate them (round 1's form); auto = ab, except for 2 or 3 ranks "
+                         "weak-scaling a small graph (n < 8192): one rank's emulated step is 0.295 / 0.312 / 0.382 ms replicated "
+                         "against 0.271 / 0.276 / 0.305 ms sharded at 2 / 4 / 8 ranks (profiles/r04_emulated_world_scaling.txt, "
+                         "copies standing in for the collectives); the replicated form needs one or two collectives per "
+                         "step instead of three, at ~12 us apiece before a byte moves")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--headline-only", action="store_true",
                     help="only the timed loop and the per-stage passes (no cold call, host-I/O, varying-N, no-dense-S or CPU "
@@ -273,8 +273,11 @@ def main() -> int:
     d_tgt = torch.from_numpy(scene.tgt).to(dev)
     torch.cuda.synchronize()
 
+    # auto: A and B sharded too (phase API, three or four collectives per step) except for two or three ranks weak-scaling a small
+    # graph, where the replicated form's single collective still wins (emulated per-rank step at C2, r04b: sharded 0.271 / 0.276 /
+    # 0.305 ms at 2 / 4 / 8 ranks, replicated 0.295 / 0.312 / 0.382 — plus ~12 us per collective before a byte moves)
     sharded_ab = world > 1 and (args.shard == "ab" or (args.shard == "auto" and not (
-        cfg.n < 8192 and args.scaling == "weak")))
+        cfg.n < 8192 and args.scaling == "weak" and world < 4)))
     split = (not sharded_ab) and (args.split_sample == "on" or (args.split_sample == "auto" and world >= 4))
     if sharded_ab:
         ss = pkg.shard.ShardedStep(pkg, reg, cfg.n, mk(pkg.SC_FLAG_TIMING_HOT), rank, world, dev)

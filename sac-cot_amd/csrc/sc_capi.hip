@@ -558,10 +558,11 @@ int run_edges(sc_ctx* c, const sc_params* p, uint32_t* hist, uint32_t part, uint
     if (build && c->tn.build_sample) {
       // (the sample's histogram came out of launch_edge_build)
     } else if (c->plan.estimate) {
-      // the single-GPU hot path, inlier count, a call big enough for stage C2's Gram filter to be in question: the sample also
+      // an estimating sample (the single-GPU hot path; sharded, SC_FLAG_EST_BOUND: every rank takes the whole of it), inlier count, a call
+      // big enough for stage C2's Gram filter to be in question: the sample also
       // leaves its workgroups' best triangles behind — the voters of that filter's reference frame (run_select passes them on)
       uint4* cand = nullptr;
-      if (est_local && p->score_mode == 0 && c->tn.score_filter != 1 && c->tn.score_filter != 2 && !c->tn.gram_ref_late &&
+      if ((est_local || est_shard) && p->score_mode == 0 && c->tn.score_filter != 1 && c->tn.score_filter != 2 && !c->tn.gram_ref_late &&
           (uint64_t)p->max_triangles * (uint64_t)c->n >= (1ull << 27)) {
         if (!c->ref_cand.p) {
           ENSURE(c, c->ref_cand, 4096 * sizeof(uint4));
