@@ -196,11 +196,11 @@ def main() -> int:
     ap.add_argument("--config", default="C2", help="synthetic scene template (default: the headline config C2)")
     ap.add_argument("--scaling", choices=("weak", "strong"), default="weak")
     ap.add_argument("--shard", choices=("auto", "ab", "replicated"), default="auto",
-                    help="N > 1: shard stages A and B too (ab) or replicate them (round 1's form); auto = ab, except for 2 or 3 ranks "
-                         "weak-scaling a small graph (n < 8192): one rank's emulated step is 0.295 / 0.312 / 0.382 ms replicated "
-                         "against 0.271 / 0.276 / 0.305 ms sharded at 2 / 4 / 8 ranks (profiles/r04_emulated_world_scaling.txt, "
-                         "copies standing in for the collectives); the replicated form needs one or two collectives per "
-                         "step instead of three, at ~12 us apiece before a byte moves")
+                    help="N > 1: shard stages A and B too (ab) or replicate them (round 1's form); auto = ab, except under weak "
+                         "scaling on a small graph (n < 8192): one rank's emulated step is 0.219 / 0.232 / 0.256 ms replicated "
+                         "(stage B pruned by the estimated bound) against 0.271 / 0.276 / 0.305 ms sharded at 2 / 4 / 8 ranks "
+                         "(profiles/r04_emulated_world_scaling.txt, copies standing in for the collectives), and the replicated "
+                         "form needs one 16-byte collective per step instead of three")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--headline-only", action="store_true",
                     help="only the timed loop and the per-stage passes (no cold call, host-I/O, varying-N, no-dense-S or CPU "
@@ -208,7 +208,7 @@ def main() -> int:
     ap.add_argument("--no-dense-s", action="store_true", help="SC_FLAG_NO_DENSE_S in the timed loop (bit rows only)")
     ap.add_argument("--debug", default="", help="sc_debug knobs for experiments: key=value,key=value")
     ap.add_argument("--split-sample", choices=("auto", "on", "off"), default="auto",
-                    help="--shard replicated only: shard stage B's pruning sample (one extra 1 KiB all-reduce); auto: world >= 4")
+                    help="--shard replicated only: on = shard stage B's CERTIFYING pruning sample (one extra 1 KiB all-reduce); auto / off: every rank takes the whole ESTIMATING sample (SC_FLAG_EST_BOUND)")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -273,12 +273,14 @@ def main() -> int:
     d_tgt = torch.from_numpy(scene.tgt).to(dev)
     torch.cuda.synchronize()
 
-    # auto: A and B sharded too (phase API, three or four collectives per step) except for two or three ranks weak-scaling a small
-    # graph, where the replicated form's single collective still wins (emulated per-rank step at C2, r04b: sharded 0.271 / 0.276 /
-    # 0.305 ms at 2 / 4 / 8 ranks, replicated 0.295 / 0.312 / 0.382 — plus ~12 us per collective before a byte moves)
+    # auto: A and B sharded too (phase API, three or four collectives per step) except under weak scaling on a small graph, where
+    # the replicated form — every rank runs the single-GPU stages A and B for the job's T, pruned by the estimated bound
+    # (SC_FLAG_EST_BOUND on sc_hypothesize_device, r04b), and scores its share — needs ONE 16-byte all-gather per step: emulated
+    # per-rank step at C2 0.219 / 0.232 / 0.256 ms at 2 / 4 / 8 ranks against 0.271 / 0.276 / 0.305 sharded (three collectives)
     sharded_ab = world > 1 and (args.shard == "ab" or (args.shard == "auto" and not (
-        cfg.n < 8192 and args.scaling == "weak" and world < 4)))
-    split = (not sharded_ab) and (args.split_sample == "on" or (args.split_sample == "auto" and world >= 4))
+        cfg.n < 8192 and args.scaling == "weak")))
+    split = (not sharded_ab) and args.split_sample == "on"   # (auto: the estimated bound instead — every rank takes the whole, cheap sample)
+    rep_est = [True]   # replicated form: stage B pruned by the estimated bound until it fails once
     if sharded_ab:
         ss = pkg.shard.ShardedStep(pkg, reg, cfg.n, mk(pkg.SC_FLAG_TIMING_HOT), rank, world, dev)
         d_Rt, d_mask = ss.Rt, ss.mask
@@ -301,12 +303,22 @@ def main() -> int:
                 reg.hypothesize_begin_device(d_src.data_ptr(), d_tgt.data_ptr(), cfg.n, prm, d_hist.data_ptr())
                 pkg.shard.allreduce_hist(d_hist)
                 reg.hypothesize_end_device(d_hist.data_ptr(), d_key.data_ptr())
-            else:
-                reg.hypothesize_device(d_src.data_ptr(), d_tgt.data_ptr(), cfg.n, prm, d_key.data_ptr())
-            if world == 1:
-                return reg.finalize_device(d_key.data_ptr(), d_Rt.data_ptr(), d_mask.data_ptr())
-            pkg.shard.allgather_best(d_key, d_all)  # ONE collective (16 bytes per rank); the reduction runs in the kernel
-            return reg.finalize_gathered_device(d_all.data_ptr(), world, d_Rt.data_ptr(), d_mask.data_ptr())
+                pkg.shard.allgather_best(d_key, d_all)
+                return reg.finalize_gathered_device(d_all.data_ptr(), world, d_Rt.data_ptr(), d_mask.data_ptr())
+            # stages A and B replicated, stage B pruned by the ESTIMATED bound (SC_FLAG_EST_BOUND, r04b: what sc_register_device does
+            # on one GPU): every rank runs the same deterministic stages, so every rank gets SC_EBOUND together if the select finds the
+            # bound too high — then, and from then on, without the flag
+            for _ in range(2):
+                q = type(prm).from_buffer_copy(prm)
+                if rep_est[0]:
+                    q.flags |= pkg.SC_FLAG_EST_BOUND
+                reg.hypothesize_device(d_src.data_ptr(), d_tgt.data_ptr(), cfg.n, q, d_key.data_ptr())
+                pkg.shard.allgather_best(d_key, d_all)  # ONE collective (16 bytes per rank); the reduction runs in the kernel
+                rc, st_ = reg.finalize_gathered_device(d_all.data_ptr(), world, d_Rt.data_ptr(), d_mask.data_ptr())
+                if rc != pkg.SC_EBOUND:
+                    return rc, st_
+                rep_est[0] = False
+            return rc, st_
 
     def fence():
         torch.cuda.synchronize()

@@ -48,7 +48,7 @@ extern "C" {
 #define SC_ETOOMANY -6   /* the graph has more triangles than the workspace cap can rank (see max_workspace),  */
                          /* or 2^32 or more edges (edge ids are 32-bit)                                      */
 
-#define SC_EBOUND   -8   /* sharded stages A + B with SC_FLAG_EST_BOUND only: the ESTIMATED pruning bound was too high (the merged  */
+#define SC_EBOUND   -8   /* calls made with SC_FLAG_EST_BOUND only: the ESTIMATED pruning bound was too high (the merged           */
                         /* candidates hold fewer than T keys above it): nothing was returned; repeat the call WITHOUT the flag  */
 #define SC_ERETRY   -7   /* sharded stages A + B only: a rank's candidate blob was too small for this input (its    */
                          /* list was cut at a key the merged threshold does not clear).  Outputs are not valid;    */
@@ -96,6 +96,9 @@ extern "C" {
                                 /* histogram on every rank and the all-reduce after it MUST BE SKIPPED — three collectives per call, not  */
                                 /* four.  The merge verifies the bound; when it was too high the finalize call returns SC_EBOUND on every  */
                                 /* rank (nothing returned): repeat the call without this flag.  Results are identical either way.         */
+                                /* Also taken by sc_hypothesize_device (stages A and B replicated on every rank; NOT by the _begin / _end   */
+                                /* pair, whose shared histogram is a certifying sample's): sc_finalize_device / _gathered_device then      */
+                                /* returns SC_EBOUND when the select found the bound too high — on every rank alike.                     */
 #define SC_FLAG_NO_DENSE_S  32u /* stage A writes only the adjacency bit rows, not the dense n x n weight matrix S:   */
                                 /* nothing after stage A reads S (edge weights are recomputed from the points), so    */
                                 /* every result is identical; sc_compat_host returns S only without this flag         */

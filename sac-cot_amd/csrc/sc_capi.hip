@@ -429,7 +429,7 @@ bool may_prune(const sc_params* p) { return p->rank_mode == SC_RANK_WEIGHT && !(
 bool edge_build_ok(const sc_ctx* c, const sc_params* p, int64_t n) {
   const bool window_known = p->rank_mode == SC_RANK_WEIGHT && 3.0f * p->t_cmp * 0.999f >= 2.0f;
   return c->est_allowed && !c->est_failed && window_known && may_prune(p) && !c->tn.no_events && !c->tn.no_estimate &&
-         c->tn.sample_mode == 0 && !c->tn.no_edge_build && !c->tn.rows_unfused && edge_build_fits((int)n) && p->shard_world == 1 &&
+         c->tn.sample_mode == 0 && !c->tn.no_edge_build && !c->tn.rows_unfused && edge_build_fits((int)n) &&  // (stage C may be dealt over ranks: shard_world)
          p->max_triangles != 0;
 }
 
@@ -1049,7 +1049,12 @@ int hyp_begin(sc_ctx* c, const float* d_src, const float* d_tgt, int64_t n, cons
   c->cap_bytes = p->max_workspace ? p->max_workspace : (64ull << 30);
   c->dv = derive(p);
   c->params = *p;
-  if (p->flags & SC_FLAG_EST_BOUND) { c->last_error = "SC_FLAG_EST_BOUND belongs to the sc_shard_* phase API"; return SC_EINVAL; }
+  // SC_FLAG_EST_BOUND outside the sc_shard_* phase API: sc_hypothesize_device only (stages A and B replicated, every rank takes the
+  // whole estimating sample; a shared histogram — sc_hypothesize_begin / _end_device — is a certifying sample's)
+  if ((p->flags & SC_FLAG_EST_BOUND) && !(d_hist == nullptr && parts == 1 && c->est_allowed)) {
+    c->last_error = "SC_FLAG_EST_BOUND belongs to the sc_shard_* phase API and to sc_hypothesize_device";
+    return SC_EINVAL;
+  }
   c->build = d_hist == nullptr && parts == 1 && edge_build_ok(c, p, n);
   if ((rc = rec(c, 0))) return rc;
   if ((rc = stage_inputs(c, d_src, d_tgt, n, p))) return rc;
@@ -1226,8 +1231,16 @@ extern "C" {
 int sc_hypothesize_device(sc_ctx* c, const float* d_src, const float* d_tgt, int64_t n, const sc_params* p,
                           uint64_t* d_key, sc_stats* stats) {
   if (!c || !d_src || !d_tgt || !d_key) return SC_EINVAL;
-  const int rc = hyp_begin(c, d_src, d_tgt, n, p, nullptr, 0, 1);  // the whole sample, into the context's histogram
-  return rc ? rc : hyp_end(c, nullptr, d_key, stats);
+  // SC_FLAG_EST_BOUND (r04b): stage B pruned by an estimated bound, like sc_register_device's — the select verifies it and
+  // sc_finalize(_gathered)_device returns SC_EBOUND when it was too high (on every rank of a job alike: stages A and B are
+  // replicated and deterministic): the caller repeats both calls without the flag
+  const bool est = p && p->size == sizeof(sc_params) && (p->flags & SC_FLAG_EST_BOUND) != 0;
+  c->est_allowed = est;
+  if (est) c->est_failed = false;  // (the CALLER decides when to stop estimating on this entry)
+  int rc = hyp_begin(c, d_src, d_tgt, n, p, nullptr, 0, 1);  // the whole sample, into the context's histogram
+  if (rc == SC_OK) rc = hyp_end(c, nullptr, d_key, stats);
+  c->est_allowed = false;
+  return rc;
 }
 
 int sc_hypothesize_begin_device(sc_ctx* c, const float* d_src, const float* d_tgt, int64_t n, const sc_params* p,
@@ -1466,6 +1479,11 @@ int finalize_wait(sc_ctx* c, sc_stats* stats) {
     if (!c->est_active) {  // a CERTIFIED bound holds by construction: this would be a defect, not an input
       c->last_error = "internal: the select found fewer keys above a certified pruning bound than the certificate counted";
       return SC_EHIP;
+    }
+    if (c->params.flags & SC_FLAG_EST_BOUND) {  // sc_hypothesize_device + sc_finalize*_device: the caller repeats (every rank alike)
+      c->last_error = "the estimated pruning bound was too high for this input: repeat the call without SC_FLAG_EST_BOUND";
+      c->est_failed_call = true;
+      return SC_EBOUND;
     }
     c->last_error = "estimated pruning bound too high: call repeated with a certifying sample";
     c->est_failed = true;  // this context certifies from now on

@@ -220,3 +220,45 @@ def test_fused_edge_kernel_on_rows_beyond_128_words(pkg, O, n, rho, L, tau, T):
     ref = O.register(sc.src, sc.tgt, threads=8, **kw)
     assert ra["status"] == ref["rc"] and np.array_equal(ra["mask"], ref["mask"]) and ra["stats"]["edges"] == ref["edges"]
     assert ra["stats"]["best_rank"] == ref["best_rank"] and ra["stats"]["tri_kept"] == ref["t_eff"]
+
+
+def test_replicated_ranks_prune_by_the_estimated_bound_too(pkg):
+    """SC_FLAG_EST_BOUND on sc_hypothesize_device (r04b; stages A and B replicated, stage C dealt over 3 ranks): same winner, mask and
+    motion as the certified form; a bound that is too high comes back as SC_EBOUND from the finalize call, on the rank that made it as on
+    every other, and the repeat without the flag succeeds; the _begin / _end pair (a SHARED, certifying sample) refuses the flag."""
+    import torch
+    dev = torch.device("cuda:0")
+    cfg, scene = pkg.synth.make_config_scene("C2")
+    world, block = 3, 1024
+    d_src = torch.from_numpy(scene.src).to(dev); d_tgt = torch.from_numpy(scene.tgt).to(dev)
+    d_keys = torch.zeros(2 * world, dtype=torch.int64, device=dev)
+    d_Rt = torch.zeros(12, dtype=torch.float32, device=dev); d_mask = torch.zeros(cfg.n, dtype=torch.uint8, device=dev)
+    r = pkg.Registrar(0)
+    try:
+        def run(flags):
+            for k in range(world):
+                p = pkg.make_params(shard_rank=k, shard_world=world, shard_block=block, flags=flags, **cfg.params())
+                r.hypothesize_device(d_src.data_ptr(), d_tgt.data_ptr(), cfg.n, p, d_keys.data_ptr() + 16 * k)
+            rc, st = r.finalize_gathered_device(d_keys.data_ptr(), world, d_Rt.data_ptr(), d_mask.data_ptr())
+            torch.cuda.synchronize()
+            return rc, st, d_Rt.cpu().numpy().copy(), d_mask.cpu().numpy().copy(), r.debug_last()
+        rc0, st0, Rt0, m0, d0 = run(0)
+        assert rc0 == 0 and d0["prune_bound"] == 0
+        rc1, st1, Rt1, m1, d1 = run(pkg.SC_FLAG_EST_BOUND)
+        assert rc1 == 0 and d1["prune_bound"] == 1, d1
+        assert np.array_equal(m0, m1) and np.array_equal(Rt0.view(np.uint32), Rt1.view(np.uint32))
+        assert st0["best_rank"] == st1["best_rank"] and st0["best_count"] == st1["best_count"]
+        assert st1["tri_total"] < st0["tri_total"]                         # (the estimated bound prunes harder)
+        r.set_debug(est_margin_pct=1)                                      # aims at rank T / 100: too high
+        rc2, _, _, _, d2 = run(pkg.SC_FLAG_EST_BOUND)
+        assert rc2 == pkg.SC_EBOUND and d2["prune_bound"] == 2, (rc2, d2)
+        rc3, st3, Rt3, m3, d3 = run(0)                                     # the repeat the caller owes
+        assert rc3 == 0 and np.array_equal(m0, m3) and np.array_equal(Rt0.view(np.uint32), Rt3.view(np.uint32))
+        r.set_debug()
+        p = pkg.make_params(shard_rank=0, shard_world=world, shard_block=block, flags=pkg.SC_FLAG_EST_BOUND, **cfg.params())
+        d_hist = torch.zeros(pkg.SC_HIST_WORDS, dtype=torch.int32, device=dev)
+        with pytest.raises(pkg.SacCotError) as e:
+            r.hypothesize_begin_device(d_src.data_ptr(), d_tgt.data_ptr(), cfg.n, p, d_hist.data_ptr())
+        assert e.value.status == pkg.SC_EINVAL
+    finally:
+        r.close()

@@ -80,6 +80,10 @@ for world in args.worlds:
     d_keys = torch.zeros(2 * world, dtype=torch.int64, device=dev)
     if args.mode == "replicated" or world == 1:
         reg = pkg.Registrar(0); reg.set_stream(torch.cuda.current_stream().cuda_stream)
+        # (replicated, world > 1: stage B pruned by the estimated bound, as bench.py's replicated form does — SC_FLAG_EST_BOUND on
+        # sc_hypothesize_device; --certified keeps the certifying sample)
+        if world > 1 and not args.certified:
+            ps = [pkg.make_params(shard_rank=r, shard_world=world, shard_block=block, flags=flags | pkg.SC_FLAG_EST_BOUND, **kw) for r in range(world)]
         def step(r):
             reg.hypothesize_device(d_src.data_ptr(), d_tgt.data_ptr(), cfg.n, ps[r], d_keys.data_ptr() + 16 * r)
         for r in range(world):
