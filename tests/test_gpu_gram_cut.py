@@ -161,3 +161,35 @@ def test_whole_path_vote_under_the_counting_pass_equals_vote_after_the_selection
               {k: db[k] for k in db if k.startswith("gram_n") or k.startswith("gram_r")})
     finally:
         r.close()
+
+
+@pytest.mark.parametrize("block", range(3))
+def test_whole_path_on_random_scenes_equals_the_fp32_kernel(pkg, block):
+    """sc_register on 5 x 3 random synthetic scenes — size, inlier ratio, tau against the extent, T (all big enough for the host to
+    pick a matrix-pipe filter) drawn at random — with everything at its default (estimated bound, fused edge kernel, vote under the
+    counting pass, Gram filter in the voted frame with its cut) against the same call with the plain fp32 scoring kernel and the
+    certifying sample: identical mask, motion bits, winner rank and count; and the default did run the Gram filter in most draws."""
+    rng = np.random.default_rng(7100 + block)
+    gram = 0
+    a = pkg.Registrar(0); b = pkg.Registrar(0)
+    try:
+        b.set_debug(score_filter=1, no_estimate=1)
+        for it in range(5):
+            n = int(rng.integers(3000, 9001))
+            rho = float(rng.uniform(0.06, 0.4))
+            L = float(10.0 ** rng.uniform(-1, 2))
+            tau = L * float(10.0 ** rng.uniform(np.log10(0.006), np.log10(0.05)))
+            T = int(((1 << 27) // n + int(rng.integers(1, 40000))) // 256 * 256)
+            sc = pkg.synth.make_scene(n, rho, L, tau, int(rng.integers(1, 1 << 30)))
+            kw = dict(sigma=tau, t_cmp=0.9, tau=tau, min_len=tau, max_triangles=T, rank_mode=0)
+            ra = a.register(sc.src, sc.tgt, **kw); da = a.debug_last()
+            rb = b.register(sc.src, sc.tgt, **kw)
+            tag = (block, it, n, rho, L, tau, T, da)
+            assert ra["status"] == rb["status"], tag
+            assert np.array_equal(ra["mask"], rb["mask"]) and np.array_equal(ra["R"].view(np.uint32), rb["R"].view(np.uint32)), tag
+            assert np.array_equal(ra["t"].view(np.uint32), rb["t"].view(np.uint32)), tag
+            assert ra["stats"]["best_rank"] == rb["stats"]["best_rank"] and ra["stats"]["best_count"] == rb["stats"]["best_count"], tag
+            gram += int(da["c2_kernel"] == 2)
+        assert gram >= 3, gram
+    finally:
+        a.close(); b.close()
