@@ -298,7 +298,7 @@ int stage_inputs(sc_ctx* c, const float* d_src, const float* d_tgt, int64_t n, c
   ENSURE(c, c->planes, (size_t)(6 + 8) * c->ld * sizeof(float));  // 6 SoA planes + the AoS copy (8 floats each)
   // per-call control block (flags, histograms, counters, select state): cleared by the staging kernel itself
   ENSURE(c, c->ctl, sizeof(ControlBlock));
-  static_assert(sizeof(ControlBlock) % 4 == 0, "cleared word-wise");
+  static_assert(sizeof(ControlBlock) % 4 == 0 && offsetof(ControlBlock, sel2_hist) % 4 == 0, "cleared word-wise");
   c->pinned[1] = 0;  // "non-finite input" flag lives in host-pinned memory: the kernel only touches it on bad data
   if (!c->fx_mx.p) {  // coordinate statistics for C2's filters (written whole by every call's staging kernel) + its ticket
     ENSURE(c, c->fx_mx, (FX_MX_WORDS + 1) * 4);
@@ -309,7 +309,7 @@ int stage_inputs(sc_ctx* c, const float* d_src, const float* d_tgt, int64_t n, c
   if (c->build) ENSURE(c, c->degp, (size_t)c->ld * sizeof(uint32_t));  // stage A accumulates deg+ there: cleared on the way
   launch_stage_points(d_src, d_tgt, c->n, c->ld, p->layout, c->planes.as<float>(),
                       reinterpret_cast<uint32_t*>(&c->pinned[1]), c->ctl.as<uint32_t>(),
-                      (uint32_t)(sizeof(ControlBlock) / 4), c->fx_mx.as<uint32_t>(), c->fx_part.as<uint32_t>(),
+                      (uint32_t)((c->tn.select_final ? sizeof(ControlBlock) : offsetof(ControlBlock, sel2_hist)) / 4), c->fx_mx.as<uint32_t>(), c->fx_part.as<uint32_t>(),
                       c->fx_mx.as<uint32_t>() + FX_MX_WORDS, &c->pinned[13], &c->pinned[16], c->stream,
                       c->build ? c->degp.as<uint32_t>() : nullptr, c->build ? (uint32_t)c->ld : 0u);
   return SC_OK;

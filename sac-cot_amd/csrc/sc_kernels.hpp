@@ -320,10 +320,12 @@ struct ControlBlock {
   uint64_t own_edge[2];      // ... and its CSR edge range (launch_shard_split)
   uint64_t pad1[4];
   SelectState sel;
-  uint32_t sel2_hist[2048];  // round 2 of launch_select_final
-  uint32_t sel_r1[SEL2_COPIES * 4096];  // round 1, taken by the key kernel: SEL2_COPIES copies by workgroup index  // stage C2's reference frame (sc_gramref.hpp): slot v = the best (key bits << 32 | workgroup) among the workgroups = v (mod 64) of the
+  // stage C2's reference frame (sc_gramref.hpp): slot v = the best (key bits << 32 | workgroup) among the workgroups = v (mod 64) of the
   // estimating sample — its voter v is that workgroup's candidate triangle
   alignas(8) unsigned long long ref_slot[64];
+  // --- everything below is used (and cleared per call) only with sc_debug.select_final: 72 KiB the staging kernel need not touch otherwise
+  uint32_t sel2_hist[2048];  // round 2 of launch_select_final
+  uint32_t sel_r1[SEL2_COPIES * 4096];  // round 1, taken by the key kernel: SEL2_COPIES copies by workgroup index
 };
 static_assert(offsetof(ControlBlock, sel) % 16 == 0, "ControlBlock::sel must be 16-byte aligned");
 
