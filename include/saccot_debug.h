@@ -77,7 +77,7 @@ typedef struct sc_debug_info {
   uint32_t gram_near_corr, gram_near_hyp, gram_rows;
   uint32_t gram_ref;          /* position (in this rank's share of the ranked list) of the hypothesis voted reference frame; 0xFFFFFFFF: none (box-centre frame) */
   uint32_t gram_ref_votes_q8; /* its soft vote count x 256 (of 64 voters) */
-  uint32_t reserved3;
+  float    us_c2_filter;      /* SC_FLAG_TIMING_HOT, a filtered stage C2: the FILTER kernel's own duration, from its dispatch packet's timestamps (sc_stats.us_score spans filter + exact pass); 0 otherwise */
 } sc_debug_info;
 int         sc_debug_last(sc_ctx* ctx, sc_debug_info* out);
 

@@ -97,7 +97,7 @@ class ScDebugInfo(C.Structure):
                 ("gram_guard", C.c_uint32), ("prune_bound", C.c_uint32), ("gram_guard_worst", C.c_float),
                 ("reserved2", C.c_uint32), ("gram_near_corr", C.c_uint32), ("gram_near_hyp", C.c_uint32),
                 ("gram_rows", C.c_uint32), ("gram_ref", C.c_uint32), ("gram_ref_votes_q8", C.c_uint32),
-                ("reserved3", C.c_uint32)]
+                ("us_c2_filter", C.c_float)]
 
 
 class SacCotError(RuntimeError):
@@ -248,7 +248,7 @@ class Registrar:
         of the matrix-pipe probe (gram_guard).  Synchronises the context's stream."""
         d = ScDebugInfo(size=C.sizeof(ScDebugInfo))
         self._check(self._lib.sc_debug_last(self._h, C.byref(d)))
-        return {k: getattr(d, k) for k, _ in ScDebugInfo._fields_ if k not in ("size", "reserved", "reserved2", "reserved3")}
+        return {k: getattr(d, k) for k, _ in ScDebugInfo._fields_ if k not in ("size", "reserved", "reserved2")}
 
     # ---- drop-in entry point ----------------------------------------------------------------------------
     def register(self, src, tgt, params: ScParams | None = None, **kw):

@@ -30,7 +30,7 @@ struct Buf {
   template <class T> T* as() const { return static_cast<T*>(p); }
 };
 
-constexpr int N_EVENTS = 12;  // 0..8 stage brackets, 9..10 the key kernel (all reused by calibrate_events)
+constexpr int N_EVENTS = 12;  // 0..8 stage brackets, 9..10 the key kernel (all reused by calibrate_events), 11 the stop of stage C2's filter kernel (SC_FLAG_TIMING_HOT)
 constexpr int N_PINNED = 32;  // [16..21]: the bounding boxes of the two clouds (stage_points_kernel)
 
 }  // namespace
@@ -1018,6 +1018,7 @@ int sc_debug_last(sc_ctx* c, sc_debug_info* out) {
   out->gram_guard = c->tn.gram_guard_fail && c->gram_guard != 0 ? 2u : (uint32_t)c->gram_guard; out->gram_guard_worst = c->gram_guard_worst;
   out->prune_bound = c->est_failed_call ? 2u : (uint32_t)c->est_state; out->reserved2 = 0;
   out->gram_near_corr = out->gram_near_hyp = out->gram_rows = out->gram_ref_votes_q8 = 0u; out->gram_ref = 0xFFFFFFFFu;
+  out->us_c2_filter = (c->hot_ext && c->filter_on) ? ev_us_raw(c, 4, 11) : 0.f;
   if (c->filter_on && c->fx_state.p)
     HIPCHK(c, filter_read_counters(c->fx_state.p, c->fx_plan, c->stream, &out->filter_undecided, &out->filter_recounts));
   if (c->filter_on && c->filter_mode == 2 && c->fx_frame.p) {
@@ -1132,7 +1133,7 @@ int filter_job(sc_ctx* c, const Shard& sh, FilterTileJob* job) {
 }
 
 int run_score(sc_ctx* c, const sc_params* p, const Shard& sh, uint32_t* rows, bool tile_done, hipEvent_t ev0 = nullptr,
-              hipEvent_t ev1 = nullptr) {
+              hipEvent_t ev1 = nullptr, hipEvent_t ev_mid = nullptr) {
   if (c->filter_on) {  // decide_filter() ran earlier in this call
     const FilterPlan& fp = c->fx_plan;
     *rows = fp.splits;
@@ -1148,7 +1149,7 @@ int run_score(sc_ctx* c, const sc_params* p, const Shard& sh, uint32_t* rows, bo
       if (fp.mode == 2) launch_gram_coef(c->rt.as<float>(), sh, c->dv.tau2, job.coef, c->stream);
     }
     launch_score_filter(points_of(c), c->rt.as<float>(), c->rt_aos.as<float>(), sh, c->dv, fp, c->fx_tile.p, c->fx_state.p,
-                        c->fx_coef.p, c->fx_frame.p, c->partial.as<uint32_t>(), c->tn, c->stream, ev0, ev1);
+                        c->fx_coef.p, c->fx_frame.p, c->partial.as<uint32_t>(), c->tn, c->stream, ev0, ev1, ev_mid);
     return SC_OK;
   }
   const bool scalar = score_is_scalar(p->score_mode, c->tn);
@@ -1207,7 +1208,7 @@ int run_stage_c(sc_ctx* c, uint64_t* d_key, sc_stats* stats) {
   c->hot_ext = hot_ext;
   if (!hot_ext && (rc = rec(c, 4))) return rc;
   uint32_t score_rows = 0;
-  if ((rc = run_score(c, p, sh, &score_rows, true, hot_ext ? c->ev[4] : nullptr, hot_ext ? c->ev[5] : nullptr))) return rc;
+  if ((rc = run_score(c, p, sh, &score_rows, true, hot_ext ? c->ev[4] : nullptr, hot_ext ? c->ev[5] : nullptr, hot_ext ? c->ev[11] : nullptr))) return rc;
   if (!hot_ext && (rc = rec(c, 5))) return rc;
   ENSURE(c, c->amx_pairs, argmax_scratch_bytes(sh.ld_local));
   c->tail_done = c->tail_mask != nullptr && c->tn.tail_fused && c->T_eff != 0 && argmax_tail_fits(c->n, c->T_eff, sh);

@@ -532,7 +532,8 @@ void launch_filter_tile(const Points& pts, const FilterTileJob& job, hipStream_t
 // RtAoS: 12 consecutive floats per hypothesis (what the exact pass loads; launch_kabsch / the stage hook write them)
 void launch_score_filter(const Points& pts, const float* RtSoA, const float* RtAoS, const Shard& sh, const Derived& dv,
                          const FilterPlan& fp, const void* tile, void* state, void* coef, void* frame, uint32_t* partial, const Tuning& tn,
-                         hipStream_t st, hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr);
+                         hipStream_t st, hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr,
+                         hipEvent_t ev_mid = nullptr);  // ev_mid (optional): stop timestamp of the FILTER kernel's own dispatch (ev0 .. ev_mid = that kernel alone)
 // Run-time probe of the matrix pipe's accumulation arithmetic (the model the Gram filter's bound assumes; sc_score.hip):
 // blocking, ~1e6 cancelling dot products.  scratch: 16 bytes of device memory.  worst_units: largest |hardware - exact| /
 // largest term seen, in units of 2^-24 (the bound assumes 18.5; gram_guard_limit() is what a context tolerates).

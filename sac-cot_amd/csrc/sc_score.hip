@@ -1814,7 +1814,7 @@ void launch_filter_tile(const Points& pts, const FilterTileJob& job, hipStream_t
 
 void launch_score_filter(const Points& pts, const float* RtSoA, const float* RtAoS, const Shard& sh, const Derived& dv,
                          const FilterPlan& fp, const void* tile, void* state, void* coef, void* frame, uint32_t* partial, const Tuning& tn,
-                         hipStream_t st, hipEvent_t ev0, hipEvent_t ev1) {
+                         hipStream_t st, hipEvent_t ev0, hipEvent_t ev1, hipEvent_t ev_mid) {
   if (sh.n_local == 0) return;
   const FilterState f = filter_state(state, fp);
   // exact pass: one thread per queue entry, grid-stride — a chain of dependent loads per entry, so big calls want more
@@ -1829,7 +1829,7 @@ void launch_score_filter(const Points& pts, const float* RtSoA, const float* RtA
     const GramCoef gc = gram_coef_view(coef, sh.ld_local, frame);
 #define SC_GRAM_LAUNCH(V)                                                                                                         \
     hipExtLaunchKernelGGL(score_gram_kernel<V>, dim3((sh.ld_local + 32 * GX_WAVES - 1) / (32 * GX_WAVES) * fp.splits), dim3(64 * GX_WAVES), \
-                          0, st, ev0, nullptr, 0, gc, sh.ld_local, static_cast<const uint4*>(tile), fp.windows, fp.splits, fp.n_waves, partial, \
+                          0, st, ev0, ev_mid, 0, gc, sh.ld_local, static_cast<const uint4*>(tile), fp.windows, fp.splits, fp.n_waves, partial, \
                           f.queue, f.cap_sq, f.qcount, f.redo, ql)
     // The shipped library holds variant 0 only.  -DSC_ABLATIONS (sac-cot_amd/build.py --ablations; tools/pmc_gram_variants.sh)
     // also instantiates the bit-identical scheduling variant 1 and the TIMING-ONLY bodies (no shell test / no barrier / no
@@ -1860,7 +1860,7 @@ void launch_score_filter(const Points& pts, const float* RtSoA, const float* RtA
   if (ql < 64) ql = 64;  // one step can add 64 entries
   const dim3 grid(sh.ld_local / (8 * FX_WAVES), fp.splits), block(64 * FX_WAVES);
 #define SC_FILTER_LAUNCH(V)                                                                                                  \
-  hipExtLaunchKernelGGL((score_filter_kernel<FX_WAVES, V>), grid, block, 0, st, ev0, nullptr, 0, RtSoA, sh.ld_local, dv.tau2, \
+  hipExtLaunchKernelGGL((score_filter_kernel<FX_WAVES, V>), grid, block, 0, st, ev0, ev_mid, 0, RtSoA, sh.ld_local, dv.tau2, \
                      static_cast<const uint4*>(tile), f.info, fp.windows, fp.splits, fp.n_waves, partial, f.queue, f.cap_sq, \
                      f.qcount, f.redo, ql)
   switch (tn.filter_variant) {
