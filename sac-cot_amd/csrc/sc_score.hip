@@ -1234,10 +1234,7 @@ __device__ void gram_tile_block(const float* __restrict__ planes, int n, int ld,
     const unsigned long long was = n_real ? atomicAdd(&fr->pts, (unsigned long long)tot_near | ((unsigned long long)tot_far << 32)) : 0ull;
     s_base[0] = (uint32_t)was; s_base[1] = (uint32_t)(was >> 32);
   }
-  __syncthreads();
-  if (m >= job.rows) return;
-  const uint32_t row = near ? s_base[0] + r_near : (real ? (uint32_t)n - 1u - (s_base[1] + r_far) : m);
-  _Float16 h[16], l[16], n2[2];
+  _Float16 h[16], l[16], n2[2];  // (made while thread 0's atomic is on its way)
   if (real) {
     double F[16];
 #pragma unroll
@@ -1252,12 +1249,15 @@ __device__ void gram_tile_block(const float* __restrict__ planes, int n, int ld,
     for (int k = 0; k < 16; k++) split2(F[k], h[k], l[k]);
     n2[0] = (_Float16)(float)N;
     n2[1] = (_Float16)(float)(N - (double)(float)n2[0]);  // what is left: < 2^-22 N (GX_NORM)
-    job.coef.pperm[row] = m;
   } else {  // sentinel: far away under every hypothesis (D~ = 2 x 60000 + ...), never undecided
 #pragma unroll
     for (int k = 0; k < 16; k++) { h[k] = (_Float16)0.f; l[k] = (_Float16)0.f; }
     n2[0] = (_Float16)60000.f; n2[1] = (_Float16)0.f;
   }
+  __syncthreads();
+  if (m >= job.rows) return;
+  const uint32_t row = near ? s_base[0] + r_near : (real ? (uint32_t)n - 1u - (s_base[1] + r_far) : m);
+  if (real) job.coef.pperm[row] = m;
   uint4* tile = static_cast<uint4*>(job.tile) + (size_t)(row >> 5) * (32 * GX_TILE_Q) + (row & 31u);
 #pragma unroll
   for (int k = 0; k < 2; k++) {
@@ -1365,13 +1365,7 @@ __device__ void gram_coef_block(const GramCoef& coef, const float v[12], uint32_
     const unsigned long long was = atomicAdd(&fr->seg[sg].cnt, (unsigned long long)n_good | ((unsigned long long)n_bad << 32));
     s_base[0] = (uint32_t)was; s_base[1] = (uint32_t)(was >> 32);
   }
-  __syncthreads();
-  if (l >= ldl) return;
-  const uint32_t row = gram_seg_row(good ? s_base[0] + r_good : seg_rows - 1u - (s_base[1] + r_bad), sg, S);
-  coef.hperm[row] = l;
-  coef.C[row] = normal ? (float)((double)GX_RS * (T2 - LOh)) : 1e30f;
-  coef.W[row] = normal ? (float)((double)GX_RS * (HIh - LOh) * (1.0 + 1e-6)) : 0.0f;
-  coef.flag[row] = (normal ? 1u : 0u) | (recount ? 2u : 0u) | (lg << 8);
+  // (the fp16 halves are made while thread 0's atomic is on its way: ~1.5 us of latency every workgroup used to sit out)
   _Float16 ah[16], al[16];
 #pragma unroll
   for (int k = 0; k < 16; k++) {
@@ -1379,6 +1373,15 @@ __device__ void gram_coef_block(const GramCoef& coef, const float v[12], uint32_
     if (!normal) { ah[k] = (_Float16)0.f; al[k] = (_Float16)0.f; }
   }
   al[9] = (_Float16)0.f;  // (2 RS is a power of two: no low half)
+  const float c_row = normal ? (float)((double)GX_RS * (T2 - LOh)) : 1e30f;
+  const float w_row = normal ? (float)((double)GX_RS * (HIh - LOh) * (1.0 + 1e-6)) : 0.0f;
+  __syncthreads();
+  if (l >= ldl) return;
+  const uint32_t row = gram_seg_row(good ? s_base[0] + r_good : seg_rows - 1u - (s_base[1] + r_bad), sg, S);
+  coef.hperm[row] = l;
+  coef.C[row] = c_row;
+  coef.W[row] = w_row;
+  coef.flag[row] = (normal ? 1u : 0u) | (recount ? 2u : 0u) | (lg << 8);
   uint4* __restrict__ out = reinterpret_cast<uint4*>(coef.A) + (size_t)row * 4;
   half8 q0 = {ah[0], ah[1], ah[2], ah[3], ah[4], ah[5], ah[6], ah[7]}, q1 = {ah[8], ah[9], ah[10], ah[11], ah[12], ah[13], ah[14], ah[15]};
   half8 q2 = {al[0], al[1], al[2], al[3], al[4], al[5], al[6], al[7]}, q3 = {al[8], al[9], al[10], al[11], al[12], al[13], al[14], al[15]};
