@@ -1,9 +1,9 @@
 #!/usr/bin/env python3
-"""Soak: one context, thousands of calls over alternating problem sizes and three forms of the call — the two phase-1 forms of
+"""Soak: one context, thousands of calls over alternating problem sizes and four forms of the call — the two phase-1 forms of
 the phase API (certified pruning bound, host waits in the middle) and sc_register_device (r04: estimated bound, fused edge
 kernel, host-free enqueue of a repeated shape); every result must be byte-identical to the first one of its configuration
 (tickets, polled read-backs, speculative launches and the validate-and-repeat paths are exercised on buffers left over from
-other sizes).   python tools/soak.py [seconds]"""
+other sizes).   python tools/soak.py [seconds] [--big]"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -12,11 +12,12 @@ import __graft_entry__ as ge
 
 pkg = ge.load_package()
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
+big = "--big" in sys.argv   # also C3 and C4 (the Gram filter's cut at its largest shapes; ~1 ms per call)
 dev = torch.device("cuda", 0)
 reg = pkg.Registrar(0)
 stream = torch.cuda.Stream(device=dev)
 cases = []
-for name, T in (("C0", 200), ("C1", 10000), ("C2", 50000), ("C1", 3000), ("C2", 200000)):
+for name, T in (("C0", 200), ("C1", 10000), ("C2", 50000), ("C1", 3000), ("C2", 200000)) + ((("C3", 200000), ("C4", 500000)) if big else ()):
     cfg, sc = pkg.synth.make_config_scene(name)
     kw = cfg.params(); kw["max_triangles"] = T
     cases.append((f"{name}/T={T}", cfg.n, kw, torch.from_numpy(sc.src).to(dev), torch.from_numpy(sc.tgt).to(dev)))
@@ -32,9 +33,9 @@ with torch.cuda.stream(stream):
     d_Rt = torch.zeros(12, dtype=torch.float32, device=dev)
     while time.time() - t0 < budget:
         name, n, kw, s, t = cases[int(rng.integers(len(cases)))]
-        form = int(rng.integers(3))
+        form = int(rng.integers(4))   # 0 hypothesize + finalize, 1 its split-sample form, 2 sc_register_device, 3 form 0 with SC_FLAG_EST_BOUND (r04b)
         split = form == 1
-        p = pkg.make_params(**kw)
+        p = pkg.make_params(flags=pkg.SC_FLAG_EST_BOUND if form == 3 else 0, **kw)
         d_mask = torch.zeros(n, dtype=torch.uint8, device=dev)
         if form == 2:
             rc, st = reg.register_device(s.data_ptr(), t.data_ptr(), n, p, d_Rt.data_ptr(), d_mask.data_ptr())
@@ -54,7 +55,7 @@ with torch.cuda.stream(stream):
             first[name] = sig
         elif first[name] != sig:
             mism += 1
-            print("MISMATCH", name, ("plain", "split", "register")[form], sig[:5], "vs", first[name][:5], flush=True)
+            print("MISMATCH", name, ("plain", "split", "register", "plain + estimated bound")[form], sig[:5], "vs", first[name][:5], flush=True)
         calls += 1
         if calls % 2000 == 0:
             print(f"{calls} calls, {mism} mismatches, {time.time() - t0:.0f} s", flush=True)
