@@ -20,6 +20,12 @@
 #include "sc_kernels.hpp"
 #include "sc_gramref.hpp"
 
+#ifdef SC_ABLATIONS
+#define SC_TICK(c, k) ((c)->tick[k] = std::chrono::steady_clock::now())
+#else
+#define SC_TICK(c, k) ((void)0)
+#endif
+
 using namespace sc;
 
 namespace {
@@ -124,6 +130,9 @@ struct sc_ctx {
   // votes in a launch of its own
   uint32_t ref_cand_n = 0;
   bool ref_done = false;
+#ifdef SC_ABLATIONS
+  std::chrono::steady_clock::time_point tick[16];  // lab build: host-side time stamps along the enqueue (sc_debug.reserved[0] == 99 prints them)
+#endif
   bool build = false;        // the running call takes launch_edge_build (row statistics + edge list + estimating sample in one launch)
   // run-time probe of the matrix pipe's accumulation model (sc_score.hip gram_guard): 0 not run, 1 holds, 2 violated
   int gram_guard = 0;
@@ -1058,12 +1067,16 @@ int hyp_begin(sc_ctx* c, const float* d_src, const float* d_tgt, int64_t n, cons
   }
   c->build = d_hist == nullptr && parts == 1 && edge_build_ok(c, p, n);
   if ((rc = rec(c, 0))) return rc;
+  SC_TICK(c, 1);
   if ((rc = stage_inputs(c, d_src, d_tgt, n, p))) return rc;
+  SC_TICK(c, 2);
   if ((rc = rec(c, 1))) return rc;
   if ((rc = run_compat(c, !(p->flags & SC_FLAG_NO_DENSE_S)))) return rc;
+  SC_TICK(c, 3);
   if ((rc = rec(c, 2))) return rc;
   if ((rc = run_row_stats(c, may_prune(p), true))) return rc;
   if ((rc = run_edges(c, p, d_hist, part, parts))) return rc;
+  SC_TICK(c, 4);
   c->begun = true;
   return SC_OK;
 }
@@ -1609,6 +1622,7 @@ int sc_register_device_async(sc_ctx* c, const float* d_src, const float* d_tgt, 
   c->pend_stats.size = sizeof(sc_stats);
   c->fast_state = 0;
   c->est_failed_call = false;
+  SC_TICK(c, 0);
   if (fast_plan(c, n, p)) {
     // host-free: the whole chain is enqueued without looking at anything the GPU produces; sc_wait validates
     c->spec_on = true;
@@ -1616,9 +1630,11 @@ int sc_register_device_async(sc_ctx* c, const float* d_src, const float* d_tgt, 
     c->tail_Rt = d_Rt; c->tail_mask = d_mask;
     rc = hyp_begin(c, d_src, d_tgt, n, p, nullptr, 0, 1);
     if (!rc) rc = hyp_end(c, nullptr, c->key.as<uint64_t>(), &c->pend_stats);
+    SC_TICK(c, 5);
     c->est_allowed = false;
     c->tail_Rt = nullptr; c->tail_mask = nullptr;
     if (!rc) rc = finalize_enqueue(c, c->key.as<uint64_t>(), 1, d_Rt, d_mask);
+    SC_TICK(c, 6);
     if (rc) { c->spec_on = false; c->fast_ok = false; return rc; }  // (a launch or allocation failed: nothing is outstanding)
     c->pending = true; c->pend_done = false;
     return SC_OK;
@@ -1635,8 +1651,17 @@ int sc_wait(sc_ctx* c, sc_stats* stats) {
   HIPCHK(c, hipSetDevice(c->device));
   c->pending = false;
   int rc = c->pending_rc;
+  SC_TICK(c, 7);
   if (!c->pend_done) {
     rc = finalize_wait(c, &c->pend_stats);
+    SC_TICK(c, 8);
+#ifdef SC_ABLATIONS
+    if (c->tn.dbg_stop == 99) {
+      auto us = [&](int a, int b) { return std::chrono::duration<double, std::micro>(c->tick[b] - c->tick[a]).count(); };
+      fprintf(stderr, "host us: entry->stage_launch %.1f | stage launch %.1f | ->compat launched %.1f | ->edges+sample launched %.1f | ->rest of hyp_end %.1f | finalize enq %.1f | to sc_wait %.1f | wait %.1f | total %.1f\n",
+              us(0, 1), us(1, 2), us(2, 3), us(3, 4), us(4, 5), us(5, 6), us(6, 7), us(7, 8), us(0, 8));
+    }
+#endif
     if (rc == SC_ESPEC) {  // a count outgrew what the launches covered (or another fallback was needed): the waiting way
       rc = register_waited(c, c->pend_src, c->pend_tgt, c->pend_n, &c->pend_p, c->pend_Rt, c->pend_mask, &c->pend_stats);
       c->fast_state = 2;
