@@ -1608,9 +1608,12 @@ __global__ __launch_bounds__(64 * GX_WAVES, 2) void score_gram_kernel(GramCoef c
     if ((rc >> (8 * jj)) & 0xFFu) { redo4 |= 1u << jj; live_rows &= ~(0xFFu << (8 * jj)); }  // rows of a group that is recounted anyway are switched off
   const bool any_normal = live_rows != 0u;
   // alpha: the largest power of two <= min(what the row's fp16 coefficients allow, widest shell / own shell) — scaling by it is exact
-  auto alpha_of = [&](float w, uint32_t fl) -> float {
-    const float a = fminf((float)(1u << ((fl >> 8) & 7u)), wmax / w);  // (>= 1 for a filtered row; w = 0 rows are not live)
-    return __uint_as_float(__float_as_uint(a) & 0xFF800000u);
+  auto alpha_of = [&](float w, uint32_t fl) -> float {  // (no division: w 2^k is exact, the comparisons decide; 17 correctly rounded divides per lane cost the prologue ~350 instructions)
+    const int cap = (int)((fl >> 8) & 7u);
+    float a = 1.0f;
+#pragma unroll
+    for (int k = 1; k <= 4; k++) a = (k <= cap && w * (float)(1 << k) <= wmax) ? (float)(1 << k) : a;
+    return a;
   };
   {
     const bool live = (live_rows >> row) & 1u;
@@ -1618,7 +1621,7 @@ __global__ __launch_bounds__(64 * GX_WAVES, 2) void score_gram_kernel(GramCoef c
     A0 = A0 * am; A2 = A2 * am;
   }
   const half8 A1 = A0;  // hi x lo: the tile's second block holds the low halves of the features
-  // alpha_h x own width <= wmax (1 + 2^-23): one W for the wave
+  // alpha_h x own width <= wmax: one W for the wave (a hair above wmax)
   const uint32_t W2b = ((VAR & 512) || !any_normal) ? 0u : __float_as_uint(wmax * (1.0f + 4e-7f));
   f32x16 C;
 #pragma unroll
