@@ -34,7 +34,7 @@ extern "C" {
 #endif
 
 #define SC_VERSION_MAJOR 0
-#define SC_VERSION_MINOR 5   /* 0.5: sc_register_device_async / sc_wait (host-free enqueue), SC_FLAG_EST_BOUND / SC_EBOUND (sharded stage B pruned by an estimated bound), sc_stats.bytes_moved, the debug hooks moved to
+#define SC_VERSION_MINOR 6   /* 0.6: SC_FLAG_EST_BOUND also on sc_hypothesize_device (SC_EBOUND from the finalize call); sc_debug / sc_debug_info grew (the Gram filter's frame and cut: saccot_debug.h).  0.5: sc_register_device_async / sc_wait (host-free enqueue), SC_FLAG_EST_BOUND / SC_EBOUND (sharded stage B pruned by an estimated bound), sc_stats.bytes_moved, the debug hooks moved to
                                 saccot_debug.h; 0.4: sc_debug_last / sc_debug_info, sc_debug.filter_blind; 0.3: sc_set_debug (no environment variables), SC_FLAG_NO_DENSE_S, sc_shard_* (stages A and B sharded); 0.2: SC_FLAG_TIMING_HOT,
                                 SC_STREAM_DEFAULT, sc_hypothesize_begin/end_device, sc_finalize_gathered_device */
 
