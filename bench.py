@@ -196,11 +196,11 @@ def main() -> int:
     ap.add_argument("--config", default="C2", help="synthetic scene template (default: the headline config C2)")
     ap.add_argument("--scaling", choices=("weak", "strong"), default="weak")
     ap.add_argument("--shard", choices=("auto", "ab", "replicated"), default="auto",
-                    help="N > 1: shard stages A and B too (ab) or replicate them (round 1's form); auto = ab, except under weak "
-                         "scaling on a small graph (n < 8192): one rank's emulated step is 0.219 / 0.232 / 0.256 ms replicated "
-                         "(stage B pruned by the estimated bound) against 0.271 / 0.276 / 0.305 ms sharded at 2 / 4 / 8 ranks "
-                         "(profiles/r04_emulated_world_scaling.txt, copies standing in for the collectives), and the replicated "
-                         "form needs one 16-byte collective per step instead of three")
+                    help="N > 1: shard stages A and B too (ab) or replicate them (round 1's form); auto = ab from 8192 correspondences "
+                         "on, replicated below: there one rank's emulated step is 0.219 / 0.232 / 0.256 ms replicated (stage B pruned "
+                         "by the estimated bound) against 0.271 / 0.276 / 0.305 ms sharded at 2 / 4 / 8 ranks weak-scaling C2, 0.329 / "
+                         "0.283 / 0.270 against 0.378 / 0.316 / 0.318 strong-scaling C4 (profiles/r04_emulated_world_scaling.txt, copies "
+                         "standing in for the collectives), and the replicated form needs one 16-byte collective per step instead of three")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--headline-only", action="store_true",
                     help="only the timed loop and the per-stage passes (no cold call, host-I/O, varying-N, no-dense-S or CPU "
@@ -273,12 +273,12 @@ def main() -> int:
     d_tgt = torch.from_numpy(scene.tgt).to(dev)
     torch.cuda.synchronize()
 
-    # auto: A and B sharded too (phase API, three or four collectives per step) except under weak scaling on a small graph, where
+    # auto: A and B sharded too (phase API, three or four collectives per step) on graphs of 8192 correspondences and more; below,
     # the replicated form — every rank runs the single-GPU stages A and B for the job's T, pruned by the estimated bound
-    # (SC_FLAG_EST_BOUND on sc_hypothesize_device, r04b), and scores its share — needs ONE 16-byte all-gather per step: emulated
-    # per-rank step at C2 0.219 / 0.232 / 0.256 ms at 2 / 4 / 8 ranks against 0.271 / 0.276 / 0.305 sharded (three collectives)
-    sharded_ab = world > 1 and (args.shard == "ab" or (args.shard == "auto" and not (
-        cfg.n < 8192 and args.scaling == "weak")))
+    # (SC_FLAG_EST_BOUND on sc_hypothesize_device, r04b), and scores its share: ONE 16-byte all-gather per step.  Emulated per-rank
+    # step, replicated against sharded: C2 weak 0.219 / 0.232 / 0.256 ms at 2 / 4 / 8 ranks against 0.271 / 0.276 / 0.305; C4 strong
+    # 0.329 / 0.283 / 0.270 against 0.378 / 0.316 / 0.318; C3 (20 000 correspondences) strong at 8: 0.86 against 0.55 — sharded there.
+    sharded_ab = world > 1 and (args.shard == "ab" or (args.shard == "auto" and cfg.n >= 8192))
     split = (not sharded_ab) and args.split_sample == "on"   # (auto: the estimated bound instead — every rank takes the whole, cheap sample)
     rep_est = [True]   # replicated form: stage B pruned by the estimated bound until it fails once
     if sharded_ab:
