@@ -34,7 +34,7 @@ extern "C" {
 #endif
 
 #define SC_VERSION_MAJOR 0
-#define SC_VERSION_MINOR 6   /* 0.6: SC_FLAG_EST_BOUND also on sc_hypothesize_device (SC_EBOUND from the finalize call); sc_debug / sc_debug_info grew (the Gram filter's frame and cut: saccot_debug.h).  0.5: sc_register_device_async / sc_wait (host-free enqueue), SC_FLAG_EST_BOUND / SC_EBOUND (sharded stage B pruned by an estimated bound), sc_stats.bytes_moved, the debug hooks moved to
+#define SC_VERSION_MINOR 6   /* 0.6: SC_FLAG_EST_BOUND also on sc_hypothesize_device (SC_EBOUND from the finalize call); SC_FLAG_SHARD_AB (sc_register_multi replicates stages A and B on small graphs unless told otherwise); sc_debug / sc_debug_info grew (the Gram filter's frame and cut: saccot_debug.h).  0.5: sc_register_device_async / sc_wait (host-free enqueue), SC_FLAG_EST_BOUND / SC_EBOUND (sharded stage B pruned by an estimated bound), sc_stats.bytes_moved, the debug hooks moved to
                                 saccot_debug.h; 0.4: sc_debug_last / sc_debug_info, sc_debug.filter_blind; 0.3: sc_set_debug (no environment variables), SC_FLAG_NO_DENSE_S, sc_shard_* (stages A and B sharded); 0.2: SC_FLAG_TIMING_HOT,
                                 SC_STREAM_DEFAULT, sc_hypothesize_begin/end_device, sc_finalize_gathered_device */
 
@@ -99,6 +99,10 @@ extern "C" {
                                 /* Also taken by sc_hypothesize_device (stages A and B replicated on every rank; NOT by the _begin / _end   */
                                 /* pair, whose shared histogram is a certifying sample's): sc_finalize_device / _gathered_device then      */
                                 /* returns SC_EBOUND when the select found the bound too high — on every rank alike.                     */
+#define SC_FLAG_SHARD_AB 4096u /* sc_register_multi only: shard stages A and B over the devices at EVERY size.  By default it does so from   */
+                                /* 8192 correspondences on; below, every device runs stages A and B for the whole job (pruned by the      */
+                                /* estimated bound) and scores its share — one 16-byte exchange per call instead of three collectives.    */
+                                /* Results are identical either way.                                                                    */
 #define SC_FLAG_NO_DENSE_S  32u /* stage A writes only the adjacency bit rows, not the dense n x n weight matrix S:   */
                                 /* nothing after stage A reads S (edge weights are recomputed from the points), so    */
                                 /* every result is identical; sc_compat_host returns S only without this flag         */

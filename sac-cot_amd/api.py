@@ -17,6 +17,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libsaccot.so")
 
 SC_OK, SC_EINVAL, SC_ENOMEM, SC_EHIP, SC_ERCCL, SC_ENOHYP, SC_ETOOMANY, SC_ERETRY, SC_EBOUND = 0, -1, -2, -3, -4, -5, -6, -7, -8
+SC_FLAG_SHARD_AB = 4096  # sc_register_multi: shard stages A and B at every size (default: replicated below 8192 correspondences)
 SC_FLAG_EST_BOUND = 128  # phase API sc_shard_*: prune by an estimated bound, no histogram all-reduce, SC_EBOUND -> repeat without it
 SC_AOS, SC_SOA = 0, 1
 SC_RANK_WEIGHT, SC_RANK_DEGREE = 0, 1

@@ -242,6 +242,12 @@ int run_rank(sc_multi* M, int r) {
   // (only on graphs below 8192 correspondences: beyond that a replicated sample costs more than the shared certifying one — measured
   // by tools/emulate_world.py at C3, see sac-cot_amd/shard.py)
   const bool est = M->estimate && G > 1 && n < 8192;
+  // r04b: on those small graphs stages A and B are REPLICATED — every device runs them for the whole job, pruned by the estimated bound
+  // (sc_hypothesize_device with SC_FLAG_EST_BOUND), and scores its share: ONE exchange of the 16-byte key pairs per call instead of
+  // three collectives (one rank's emulated step, C2 weak / C4 strong at 8 ranks: 0.26 / 0.27 ms against 0.31 / 0.32 sharded).
+  // SC_FLAG_SHARD_AB keeps the sharded form; so does a context whose estimate failed once (M->estimate).
+  const bool replicated = est && !(p.flags & SC_FLAG_SHARD_AB);
+  p.flags &= ~SC_FLAG_SHARD_AB;
   if (est) p.flags |= SC_FLAG_EST_BOUND; else p.flags &= ~SC_FLAG_EST_BOUND;
   if (p.shard_block == 0) p.shard_block = 1024;
   int rc = SC_OK;
@@ -270,12 +276,15 @@ int run_rank(sc_multi* M, int r) {
   };
   const float *d_src = nullptr, *d_tgt = nullptr;
   float* d_Rt = nullptr; uint8_t* d_mask = nullptr;
-  compute([&]() -> int {
+  auto setup_io = [&](bool sharded) -> int {  // this rank's buffers and where its inputs / outputs live
     MHIP(rk, hipSetDevice(rk.device));
-    int e = sc_shard_plan_query(&p, n, &plan);
-    if (e) { rk.error = "bad parameters"; return e; }
-    if ((e = grow(rk, &rk.bits, &rk.bits_cap, plan.bits_bytes_total))) return e;
-    if ((e = grow(rk, &rk.cand, &rk.cand_cap, (size_t)G * plan.cand_bytes_per_rank))) return e;
+    int e = SC_OK;
+    if (sharded) {
+      e = sc_shard_plan_query(&p, n, &plan);
+      if (e) { rk.error = "bad parameters"; return e; }
+      if ((e = grow(rk, &rk.bits, &rk.bits_cap, plan.bits_bytes_total))) return e;
+      if ((e = grow(rk, &rk.cand, &rk.cand_cap, (size_t)G * plan.cand_bytes_per_rank))) return e;
+    }
     if (M->pinned_io) {  // every device reads the one pinned host area; rank 0's finalize kernel writes the other
       void *ds = nullptr, *dout = nullptr;
       MHIP(rk, hipHostGetDevicePointer(&ds, M->h_in, 0));
@@ -295,6 +304,20 @@ int run_rank(sc_multi* M, int r) {
       if ((e = grow(rk, &rk.mask, &rk.mask_cap, (size_t)n))) return e;
       d_Rt = rk.Rt; d_mask = static_cast<uint8_t*>(rk.mask);
     }
+    return SC_OK;
+  };
+  if (replicated) {
+    compute([&]() -> int {
+      int e = setup_io(false);
+      if (e) return e;
+      sc_stats st; memset(&st, 0, sizeof st); st.size = sizeof st;
+      e = sc_hypothesize_device(rk.ctx, d_src, d_tgt, n, &p, rk.keys + 2 * r, &st);  // A, B for the whole job; C1 + C2 on this rank's blocks
+      return e ? fail_from_ctx(e) : SC_OK;
+    });
+  } else {
+  compute([&]() -> int {
+    int e = setup_io(true);
+    if (e) return e;
     e = sc_shard_compat_device(rk.ctx, d_src, d_tgt, n, &p, rk.bits);
     return e ? fail_from_ctx(e) : SC_OK;
   });
@@ -314,6 +337,7 @@ int run_rank(sc_multi* M, int r) {
     const int e = sc_shard_score_device(rk.ctx, rk.cand, rk.keys + 2 * r, &st);
     return e ? fail_from_ctx(e) : SC_OK;
   });
+  }
   collective([&] { return rccl_allgather(M, r, rk.keys, 16); },   // the key pairs: 16 bytes per rank
              [&](bool ok) { return loop_allgather(M, r, ok, [](Rank& q) { return static_cast<void*>(q.keys); }, 16); });
   int fin = SC_OK;

@@ -877,10 +877,12 @@ def test_multi_loopback_equals_sc_register(pkg, O, reg, ranks):
     without hypotheses, and the handle reused for another size."""
     m = pkg.MultiRegistrar((0,), loopback_ranks=ranks)
     try:
-        for name in ("C1", "C0"):
+        # both forms of the multi-device call: stages A and B replicated with the estimated bound (the default below 8192
+        # correspondences, r04b: one key-pair exchange) and all three stages sharded (SC_FLAG_SHARD_AB: three or four collectives)
+        for name, fl in (("C1", 0), ("C1", pkg.SC_FLAG_SHARD_AB), ("C0", pkg.SC_FLAG_SHARD_AB), ("C0", 0)):
             cfg, scene = pkg.synth.make_config_scene(name)
             ref = O.register(scene.src, scene.tgt, threads=8, **cfg.params())
-            got = m.register(scene.src, scene.tgt, **cfg.params())
+            got = m.register(scene.src, scene.tgt, flags=fl, **cfg.params())
             assert got["status"] == ref["rc"] == 0
             st = got["stats"]
             assert (st["edges"], st["tri_kept"], st["best_rank"], st["best_count"]) == (ref["edges"], ref["t_eff"], ref["best_rank"], ref["best_count"])
