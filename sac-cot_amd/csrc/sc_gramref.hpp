@@ -15,8 +15,9 @@ __host__ __device__ __forceinline__ uint32_t shard_global_index(uint32_t l, uint
 }
 
 constexpr double GX_KAPPA = 8.0;     // a hypothesis is NEAR the reference while its reach (below) stays under GX_KAPPA tau'
-constexpr int GX_VOTE = 64;          // hypotheses that vote for the reference frame (gram_ref_kernel)
-// The frame of one call's Gram filter: made by gram_ref_kernel (one wave, before the Kabsch launch), read by every workgroup of
+constexpr int GX_VOTE = 64;          // hypotheses that vote for the reference frame (gram_ref_block)
+// The frame of one call's Gram filter: made by gram_ref_block (one workgroup: a launch of its own before the Kabsch launch, or an
+// extra workgroup of stage B's counting pass), read by every workgroup of
 // the Kabsch launch (tile and coefficients), by the filter and by the exact pass.  A buffer of its own per context (128-aligned).
 struct GramFrame {
   double R0[9], t0[3];  // the reference motion: R0 orthogonal to ~1e-16 (rebuilt in fp64 from a unit quaternion), t0
