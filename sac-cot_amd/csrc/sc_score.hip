@@ -1564,18 +1564,37 @@ __global__ __launch_bounds__(64 * GX_WAVES, 2) void score_gram_kernel(GramCoef c
   if (near_block && by >= gg.ns) return;  // (its rows of these splits are cleared by split 0, below)
   const uint32_t u0 = by * (near_block ? gg.pu_near : gg.pu_far);
   const uint32_t u1 = near_block ? min(u0 + gg.pu_near, gg.near_units) : min(u0 + gg.pu_far, gg.units);
-  if (near_block && by == 0 && hf == 0) {  // the splits no workgroup of these rows works in count nothing
-    const uint32_t hh = wid * 32 + (uint32_t)col;
-    if (hh < ldl) {
-      const uint32_t hrow = coef.hperm[hh];
-      for (uint32_t y = gg.ns; y < splits; y++) cnt_out[(size_t)y * ldl + hrow] = 0u;
-    }
+  // ---- every global read of the prologue is ISSUED here, before anything waits: the coefficients of this lane's row, the
+  // per-row words of the wave's 16 accumulator rows.  (Written where they are used, each group of four rows became a load ->
+  // wait -> branch chain of its own, and the epilogue sixteen load -> wait -> store round trips: by the lab build's timestamps
+  // a workgroup of C2 spent 4 - 5.7 us before its first step and 3.1 - 4.1 us after its last one, as long as in the 4.6 - 7.9 us
+  // of steps between them.)  Behind the early exit, not before it: issued first of all — under the frame's own two dependent
+  // reads — the workgroups with nothing to do, most of C2's grid, read ~230 bytes per thread for nothing: 24.1 -> 26.2 us.
+  const uint32_t row = (uint32_t)col, h = wid * 32 + row;  // (< ldl: a multiple of 256, the grid has ldl / 256 workgroups)
+  const uint4* __restrict__ ca = reinterpret_cast<const uint4*>(coef.A) + (size_t)h * 4;
+  typedef float f32q __attribute__((ext_vector_type(4)));
+  typedef uint32_t u32q __attribute__((ext_vector_type(4)));
+  const u32q a0 = *reinterpret_cast<const u32q*>(ca + hf), a2 = *reinterpret_cast<const u32q*>(ca + 2 + hf);
+  const float wrow = coef.W[h];
+  const uint32_t frow = coef.flag[h], hrow = coef.hperm[h];
+  f32q c4[4], w4[4];
+  u32q f4[4];
+#pragma unroll
+  for (int jj = 0; jj < 4; jj++) {
+    const size_t base = (size_t)wid * 32 + 8 * jj + 4 * hf;
+    c4[jj] = *reinterpret_cast<const f32q*>(coef.C + base);
+    w4[jj] = *reinterpret_cast<const f32q*>(coef.W + base);
+    f4[jj] = *reinterpret_cast<const u32q*>(coef.flag + base);
   }
-  if (u0 >= u1) {  // (workgroup-uniform) nothing to look at in this split
-    const uint32_t hh = wid * 32 + (uint32_t)col;
-    if (hf == 0 && hh < ldl) cnt_out[(size_t)by * ldl + coef.hperm[hh]] = 0u;
-    return;
-  }
+  // the places in the ranked list of this lane's 16 accumulator rows (read at the end, 16 registers the step loop has no room for)
+  auto ranked_rows = [&](uint32_t* hp) {
+    u32q hp4[4];
+#pragma unroll
+    for (int jj = 0; jj < 4; jj++) hp4[jj] = *reinterpret_cast<const u32q*>(coef.hperm + (size_t)wid * 32 + 8 * jj + 4 * hf);
+    asm volatile("" ::"v"(hp4[0]), "v"(hp4[1]), "v"(hp4[2]), "v"(hp4[3]));  // (four loads, ONE wait)
+#pragma unroll
+    for (int jj = 0; jj < 4; jj++) { hp[4 * jj] = hp4[jj].x; hp[4 * jj + 1] = hp4[jj].y; hp[4 * jj + 2] = hp4[jj].z; hp[4 * jj + 3] = hp4[jj].w; }
+  };
   auto stage = [&](uint32_t u, int buf) {  // (asm: see score_filter_kernel)
 #pragma unroll
     for (int i = 0; i < PIECES; i++) {
@@ -1589,15 +1608,20 @@ __global__ __launch_bounds__(64 * GX_WAVES, 2) void score_gram_kernel(GramCoef c
   };
   if (u0 < u1) stage(u0, 0);
   if (u0 + 1 < u1) stage(u0 + 1, 1);
+  // (the asm pins the loads above the branches below: nothing is sunk into the block that uses it)
+  asm volatile("" ::"v"(a0), "v"(a2), "v"(wrow), "v"(frow), "v"(c4[0]), "v"(c4[1]), "v"(c4[2]), "v"(c4[3]), "v"(w4[0]), "v"(w4[1]),
+               "v"(w4[2]), "v"(w4[3]));
+  asm volatile("" ::"v"(f4[0]), "v"(f4[1]), "v"(f4[2]), "v"(f4[3]), "v"(hrow));
+  if (near_block && by == 0 && hf == 0 && h < ldl)  // the splits no workgroup of these rows works in count nothing
+    for (uint32_t y = gg.ns; y < splits; y++) cnt_out[(size_t)y * ldl + hrow] = 0u;
+  if (u0 >= u1) {  // (workgroup-uniform) nothing to look at in this split
+    if (hf == 0 && h < ldl) cnt_out[(size_t)by * ldl + hrow] = 0u;
+    return;
+  }
   // ---- prologue: the coefficients were made once per call by gram_coef_block (lane (row, hf) takes the halves of its row).  What
   // belongs to the WAVE — the widest shell of its 32 rows, every row's alpha, the groups of 8 rows the exact pass recounts — is
   // made here: the rows of a wave come from all over the ranked list (NEAR hypotheses first), only this kernel sees them together.
-  const uint32_t row = (uint32_t)col, h = wid * 32 + row;  // (< ldl: a multiple of 256, the grid has ldl / 256 workgroups)
-  const uint4* __restrict__ ca = reinterpret_cast<const uint4*>(coef.A) + (size_t)h * 4;
-  const uint4 a0 = ca[hf], a2 = ca[2 + hf];
   half8 A0 = *reinterpret_cast<const half8*>(&a0), A2 = *reinterpret_cast<const half8*>(&a2);
-  const float wrow = coef.W[h];
-  const uint32_t frow = coef.flag[h];
   float wmax = wrow;
 #pragma unroll
   for (int o = 16; o > 0; o >>= 1) wmax = fmaxf(wmax, __shfl_xor(wmax, o, 32));  // (both lane halves hold the same 32 rows)
@@ -1626,11 +1650,8 @@ __global__ __launch_bounds__(64 * GX_WAVES, 2) void score_gram_kernel(GramCoef c
   f32x16 C;
 #pragma unroll
   for (int jj = 0; jj < 4; jj++) {
-    const size_t base = (size_t)wid * 32 + 8 * jj + 4 * hf;
-    const float4 c4 = *reinterpret_cast<const float4*>(coef.C + base), w4 = *reinterpret_cast<const float4*>(coef.W + base);
-    const uint4 f4 = *reinterpret_cast<const uint4*>(coef.flag + base);
-    const float cc[4] = {c4.x, c4.y, c4.z, c4.w}, ww[4] = {w4.x, w4.y, w4.z, w4.w};
-    const uint32_t ff[4] = {f4.x, f4.y, f4.z, f4.w};
+    const float cc[4] = {c4[jj].x, c4[jj].y, c4[jj].z, c4[jj].w}, ww[4] = {w4[jj].x, w4[jj].y, w4[jj].z, w4[jj].w};
+    const uint32_t ff[4] = {f4[jj].x, f4[jj].y, f4[jj].z, f4[jj].w};
 #pragma unroll
     for (int i = 0; i < 4; i++) {
       const bool live = (live_rows >> (8 * jj + 4 * hf + i)) & 1u;
@@ -1744,6 +1765,8 @@ __global__ __launch_bounds__(64 * GX_WAVES, 2) void score_gram_kernel(GramCoef c
     }
   }
   if (qn && redo4 != 0xFu) flush_queue();
+  uint32_t hp[16];
+  ranked_rows(hp);
   if (lane == 0) {
 #pragma unroll
     for (int jj = 0; jj < 4; jj++)
@@ -1758,7 +1781,7 @@ __global__ __launch_bounds__(64 * GX_WAVES, 2) void score_gram_kernel(GramCoef c
   for (int i = 0; i < 16; i++) {
     const uint32_t c = dpp_sum32_upper(total[i] + (uint32_t)__popc(sr[i]));  // (+ what a NEAR range that ends inside a window left in the shift register)
     const uint32_t r = 8 * (i >> 2) + 4 * hf + (i & 3), hh = wid * 32 + r;
-    if (col == 31 && hh < ldl) cnt_out[(size_t)by * ldl + coef.hperm[hh]] = ((redo4 >> (i >> 2)) & 1u) ? 0u : c;
+    if (col == 31 && hh < ldl) cnt_out[(size_t)by * ldl + hp[i]] = ((redo4 >> (i >> 2)) & 1u) ? 0u : c;
   }
 }
 
