@@ -21,6 +21,10 @@ strong` is BASELINE configs[3] as specified (200k triangles over 8 GPUs) and C4 
 
 `value` = hypotheses scored per second by the whole job = T_total * K / wall time of the K timed steps (barrier +
 synchronize on both sides, MAX over ranks): the end-to-end rate, stages A, B and the mask included.
+At N = 1 the K steps are a STREAM of frames (--frames-in-flight 2, r04c): step k + 1 is enqueued before the host waits for step
+k's winner, the way a registration pipeline feeds the library; every step runs every kernel on the inputs and delivers its winner,
+statistics, (R, t) and mask like any other call.  The form of rounds 1 - 3 (a step begins when the previous winner has reached the
+host: ~19 us of idle GPU per step) is timed right after it over the same number of steps and reported as `waited`.
 """
 from __future__ import annotations
 
@@ -201,6 +205,10 @@ def main() -> int:
                          "by the estimated bound) against 0.271 / 0.276 / 0.305 ms sharded at 2 / 4 / 8 ranks weak-scaling C2, 0.329 / "
                          "0.283 / 0.270 against 0.378 / 0.316 / 0.318 strong-scaling C4 (profiles/r04_emulated_world_scaling.txt, copies "
                          "standing in for the collectives), and the replicated form needs one 16-byte collective per step instead of three")
+    ap.add_argument("--frames-in-flight", type=int, choices=(1, 2), default=2,
+                    help="N = 1: 2 (default) = a STREAM of frames — step k + 1 is enqueued (sc_register_device_async, a second context on "
+                         "the same stream) before step k's winner is waited for (sc_wait), so the GPU runs the steps back to back; 1 = every "
+                         "step ends with its winner on the host before the next begins (rounds 1 - 3; still reported as `waited`)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--headline-only", action="store_true",
                     help="only the timed loop and the per-stage passes (no cold call, host-I/O, varying-N, no-dense-S or CPU "
@@ -338,15 +346,69 @@ def main() -> int:
     # timed code allocates is cyclic; what exists so far is frozen, reference counting keeps freeing the rest.
     import gc
     gc.collect(); gc.freeze(); gc.disable()
-    fence()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        ts0 = time.perf_counter()
-        rc, st = step(p_hot)
-        step_s.append(time.perf_counter() - ts0)   # (every step ends with the winner on the host: its own wall time is meaningful)
-        hot_score += st["us_score"]
-    fence()
-    dt = time.perf_counter() - t0
+    pipelined = world == 1 and args.frames_in_flight == 2
+    waited = None
+    if pipelined:
+        # two contexts on ONE stream: strictly serial on the GPU, nothing overlaps on the device; the host is off the critical path
+        regB = pkg.Registrar(local_rank)
+        if knobs:
+            regB.set_debug(**{k: int(v) for k, v in knobs.items()})
+        regB.set_stream(torch.cuda.current_stream().cuda_stream)
+        pair = [reg, regB]
+        outs = [(d_Rt, d_mask), (torch.zeros(12, dtype=torch.float32, device=dev), torch.zeros(cfg.n, dtype=torch.uint8, device=dev))]
+        for _ in range(max(args.warmup, 2)):
+            regB.register_device(d_src.data_ptr(), d_tgt.data_ptr(), cfg.n, p_hot, outs[1][0].data_ptr(), outs[1][1].data_ptr())
+
+        def enqueue(k):
+            pair[k & 1].register_device_async(d_src.data_ptr(), d_tgt.data_ptr(), cfg.n, p_hot, outs[k & 1][0].data_ptr(), outs[k & 1][1].data_ptr())
+
+        winners = set()
+        fence()
+        t0 = time.perf_counter()
+        enqueue(0)
+        tl = t0
+        for k in range(1, args.steps + 1):
+            if k < args.steps:
+                enqueue(k)
+            rc, st = pair[(k - 1) & 1].wait()     # step k - 1: status, statistics; (R, t) and mask complete
+            tn_ = time.perf_counter()
+            step_s.append(tn_ - tl); tl = tn_     # (winner to winner)
+            hot_score += st["us_score"]
+            winners.add((rc, st["best_rank"], st["best_count"]))
+        fence()
+        dt = time.perf_counter() - t0
+        fast_path_pair = [g_.debug_last().get("fast_path") for g_ in pair]
+        if len(winners) != 1:
+            print(f"bench.py: the frames of the stream disagree: {sorted(winners)}", file=sys.stderr)
+            return 1
+        # the waited form, same number of steps, same context and parameters
+        w_s = []
+        fence()
+        tw0 = time.perf_counter()
+        for _ in range(args.steps):
+            ts0 = time.perf_counter()
+            rcw, stw = step(p_hot)
+            w_s.append(time.perf_counter() - ts0)
+        fence()
+        dtw = time.perf_counter() - tw0
+        if (rcw, stw["best_rank"], stw["best_count"]) not in winners:
+            print(f"bench.py: waited and streamed steps disagree: {(rcw, stw['best_rank'], stw['best_count'])} vs {sorted(winners)}", file=sys.stderr)
+            return 1
+        waited = {"ms_per_step": dtw / args.steps * 1e3, "ms_per_step_median": float(np.median(w_s)) * 1e3,
+                  "hypotheses_per_s": T_total * args.steps / dtw,
+                  "note": "the same steps, each begun only when the previous winner has reached the host (--frames-in-flight 1: "
+                          "the headline form of rounds 1 - 3)"}
+        regB.close()
+    else:
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            ts0 = time.perf_counter()
+            rc, st = step(p_hot)
+            step_s.append(time.perf_counter() - ts0)   # (every step ends with the winner on the host: its own wall time is meaningful)
+            hot_score += st["us_score"]
+        fence()
+        dt = time.perf_counter() - t0
     fast_path_timed = reg.debug_last().get("fast_path") if world == 1 else None
     # ---- per-stage times of THE SAME code path: one bracket per pass (SC_FLAG_TIMING_ONE: two event records per call,
     # speculative launches on), a few passes per stage; then one fully bracketed pass for the key kernel alone
@@ -484,9 +546,12 @@ def main() -> int:
                              "read-backs" + (" and the collectives between the phases" if sharded_ab else ""),
             "winner": {"rank": st["best_rank"], "inliers": st["best_count"], "status": rc},
             "host_gap_us": round(ms_per_step * 1e3 - sum(avg.values()), 1),
-            "host_gap_note": "step minus the sum of the stage brackets: launch of the first kernel into an idle queue, the "
-                             "winner's way back to the host, Python between the calls",
-            "fast_path": fast_path_timed,
+            "host_gap_note": "step minus the sum of the stage brackets (taken on waited calls): the ramps between the stages; in the waited "
+                             "form also the launch of the first kernel into an idle queue, the winner's way back to the host, Python between the calls",
+            "fast_path": fast_path_pair if pipelined else fast_path_timed,
+            "step_form": ("stream of frames: step k + 1 enqueued before step k's winner is waited for (sc_register_device_async / sc_wait, two "
+                          "contexts on one stream; serial on the GPU)") if pipelined else "waited: a step begins when the previous winner is on the host",
+            "waited": waited,
             "bytes_moved_algorithmic": st.get("bytes_moved"),
             "roofline": dominant, "roofline_other": other,
         }
@@ -578,37 +643,6 @@ def main() -> int:
                             "I/O of sc_register; N > 1 over RCCL is unmeasured on hardware"}
             except Exception as ex:  # RCCL not loadable on this box: report, do not fail the headline
                 out["native_multi"] = {"error": str(ex)}
-            # ---- a STREAM of frames on ONE stream: two contexts alternate, frame k + 1 is enqueued (host-free) before frame k is
-            # waited for, so the GPU runs the frames back to back and never waits for the host.  Strictly serial on the GPU —
-            # unlike `calls_in_flight` below nothing overlaps on the device.  NOT `value` (which ends every step with its
-            # winner on the host); what the kernels alone allow.
-            try:
-                reg.set_stream(torch.cuda.current_stream().cuda_stream)
-                regB = pkg.Registrar(local_rank)
-                regB.set_stream(torch.cuda.current_stream().cuda_stream)
-                pair = [reg, regB]
-                outs = [(d_Rt, d_mask), (torch.zeros(12, dtype=torch.float32, device=dev), torch.zeros(n, dtype=torch.uint8, device=dev))]
-                p_pl = pkg.make_params(flags=base_flags, **kw)
-                for g_, o_ in zip(pair, outs):
-                    for _ in range(3):
-                        g_.register_device(d_src.data_ptr(), d_tgt.data_ptr(), n, p_pl, o_[0].data_ptr(), o_[1].data_ptr())
-                KP = 40
-                torch.cuda.synchronize(); tp0 = time.perf_counter()
-                pair[0].register_device_async(d_src.data_ptr(), d_tgt.data_ptr(), n, p_pl, outs[0][0].data_ptr(), outs[0][1].data_ptr())
-                okp = True
-                for k in range(1, KP):
-                    pair[k & 1].register_device_async(d_src.data_ptr(), d_tgt.data_ptr(), n, p_pl, outs[k & 1][0].data_ptr(), outs[k & 1][1].data_ptr())
-                    _, sp_ = pair[(k - 1) & 1].wait()
-                    okp = okp and sp_["best_rank"] == st["best_rank"] and sp_["best_count"] == st["best_count"]
-                _, sp_ = pair[(KP - 1) & 1].wait()
-                torch.cuda.synchronize(); tpl = time.perf_counter() - tp0
-                out["frames_back_to_back"] = {"ms_per_call": tpl / KP * 1e3, "hypotheses_per_s": T_total * KP / tpl, "same_winner": bool(okp),
-                                              "fast_path": [g_.debug_last()["fast_path"] for g_ in pair],
-                                              "note": "two contexts on ONE stream, call k + 1 enqueued before call k is waited for "
-                                                      "(sc_register_device_async / sc_wait): serial on the GPU, the host off the critical path"}
-                regB.close()
-            except Exception as ex:
-                out["frames_back_to_back"] = {"error": str(ex)}
             reg.set_stream(None)
             # ---- throughput with TWO independent registrations in flight (two contexts, two streams, two host threads):
             # the path is a chain of ~19 dependent launches, many of them small, so a second call fills the gaps.  NOT the

@@ -1547,6 +1547,13 @@ __global__ __launch_bounds__(64 * GX_WAVES, 2) void score_gram_kernel(GramCoef c
   constexpr int PIECES = GX_UNIT * GX_TILE_Q / (64 * GX_WAVES);  // LDS-DMA instructions per wave and unit
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int col = lane & 31, hf = lane >> 5;
+#ifdef SC_ABLATIONS  // lab build: where a workgroup's life goes (tools/r4/gramtick.py; ql == 127 switches the printing on)
+  long long tk[5];
+  tk[0] = wall_clock64();
+#define SC_GRAM_TICK(i) tk[i] = wall_clock64()
+#else
+#define SC_GRAM_TICK(i)
+#endif
   // The grid is one-dimensional, groups x splits workgroups, and within a split the LONG ones go first: the row blocks that hold
   // a hypothesis not near the reference are the LAST ones of their segment (sc_gramref.hpp: segment = row block % S) — the highest
   // row blocks — and walk every correspondence, the others a few near units (dispatched in row order, the last workgroups to
@@ -1663,6 +1670,7 @@ __global__ __launch_bounds__(64 * GX_WAVES, 2) void score_gram_kernel(GramCoef c
   // ahead (the compiler cannot see into the asm that issues them): until r03c every unit's first step stood still until the
   // NEXT unit had landed, i.e. nothing was prefetched at all.
   asm volatile("" ::"v"(A0), "v"(A2), "v"(C), "s"(W2b), "s"(redo4));
+  SC_GRAM_TICK(1);
   uint32_t total[16], sr[16];
 #pragma unroll
   for (int i = 0; i < 16; i++) { total[i] = 0; sr[i] = 0; }
@@ -1692,6 +1700,9 @@ __global__ __launch_bounds__(64 * GX_WAVES, 2) void score_gram_kernel(GramCoef c
       flushed = false;
       __syncthreads();  // ... everybody's has, and nobody reads unit u - 1's buffer any more (it takes unit u + 2)
     }
+#ifdef SC_ABLATIONS
+    if (u == u0) tk[2] = wall_clock64();
+#endif
     // Unit u + 2 is issued right behind the barrier, TWO units ahead: with two buffers the pieces of unit u + 1 were issued here
     // and — see the note on the coefficients above — waited for at once.  (VAR bit 0: each wave issues at a step of its own
     // inside the step loop instead, so that the eight waves' LDS-DMA instructions, ~125 cycles apiece, do not queue up behind
@@ -1764,6 +1775,7 @@ __global__ __launch_bounds__(64 * GX_WAVES, 2) void score_gram_kernel(GramCoef c
       stage(u + 2, nbuf);  // (a wave with nothing to filter still brings its share of the tile)
     }
   }
+  SC_GRAM_TICK(3);
   if (qn && redo4 != 0xFu) flush_queue();
   uint32_t hp[16];
   ranked_rows(hp);
@@ -1783,6 +1795,13 @@ __global__ __launch_bounds__(64 * GX_WAVES, 2) void score_gram_kernel(GramCoef c
     const uint32_t r = 8 * (i >> 2) + 4 * hf + (i & 3), hh = wid * 32 + r;
     if (col == 31 && hh < ldl) cnt_out[(size_t)by * ldl + hp[i]] = ((redo4 >> (i >> 2)) & 1u) ? 0u : c;
   }
+#ifdef SC_ABLATIONS
+  SC_GRAM_TICK(4);
+  if (ql == 127 && tid == 0 && blockIdx.x % 97 == 0)  // (wall_clock64: 100 MHz)
+    printf("gram wg %u near %d units %u: prologue %lld, first unit %lld, steps %lld, tail %lld (x 10 ns)\n", blockIdx.x, (int)near_block,
+           u1 - u0, tk[1] - tk[0], tk[2] - tk[1], tk[3] - tk[2], tk[4] - tk[3]);
+#endif
+#undef SC_GRAM_TICK
 }
 
 // (A persistent one-generation form of this kernel — contiguous runs of (hypothesis group, unit) items per workgroup, counts by

@@ -166,3 +166,41 @@ def test_host_free_through_the_host_entry_and_with_flags(pkg, O):
             assert np.array_equal(b["mask"], ref["mask"]) and b["stats"]["best_rank"] == ref["best_rank"]
     finally:
         r.close()
+
+
+def test_a_frame_enqueued_ahead_picks_stage_c2s_kernel_by_the_last_calls_maxima(pkg):
+    """A frame enqueued while the previous one still runs (a second context on the stream) reaches the choice of stage C2's
+    kernel before its own staging kernel has published the coordinate maxima: it decides by the words of the last call of
+    its context — the same shape — instead of blind (blind, every such frame of C2 ran the linear filter: 53 us against 27).
+    Whatever it picks, the outputs are the waited call's."""
+    import torch
+    dev = torch.device("cuda:0")
+    cfg, scene = pkg.synth.make_config_scene("C2")
+    p = pkg.make_params(**cfg.params())
+    ds, dt = _dev(torch, scene, dev)
+    regs = [pkg.Registrar(0), pkg.Registrar(0)]
+    try:
+        st = torch.cuda.current_stream().cuda_stream
+        for r in regs:
+            r.set_stream(st)
+        base = _run(torch, regs[0], ds, dt, cfg.n, p, dev)
+        assert regs[0].debug_last()["c2_kernel"] == 2              # (what the waited call chooses at C2: the Gram filter)
+        outs = [(torch.zeros(12, dtype=torch.float32, device=dev), torch.zeros(cfg.n, dtype=torch.uint8, device=dev)) for _ in regs]
+        for r, o in zip(regs, outs):
+            for _ in range(2):
+                r.register_device(ds.data_ptr(), dt.data_ptr(), cfg.n, p, o[0].data_ptr(), o[1].data_ptr())
+        kernels = []
+        regs[0].register_device_async(ds.data_ptr(), dt.data_ptr(), cfg.n, p, outs[0][0].data_ptr(), outs[0][1].data_ptr())
+        for k in range(1, 13):
+            cur, prev = k & 1, (k - 1) & 1
+            regs[cur].register_device_async(ds.data_ptr(), dt.data_ptr(), cfg.n, p, outs[cur][0].data_ptr(), outs[cur][1].data_ptr())
+            rc, s = regs[prev].wait()
+            d = regs[prev].debug_last()
+            kernels.append((d["fast_path"], d["c2_kernel"]))
+            assert rc == base["rc"] and s["best_rank"] == base["st"]["best_rank"] and s["best_count"] == base["st"]["best_count"]
+            assert np.array_equal(outs[prev][1].cpu().numpy(), base["mask"]) and nan_equal_bits(outs[prev][0].cpu().numpy(), base["Rt"])
+        regs[0].wait()
+        assert all(kd == (1, 2) for kd in kernels[1:]), kernels    # (the first frame was enqueued into an idle stream)
+    finally:
+        for r in regs:
+            r.close()
