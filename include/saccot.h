@@ -34,7 +34,7 @@ extern "C" {
 #endif
 
 #define SC_VERSION_MAJOR 0
-#define SC_VERSION_MINOR 6   /* 0.6: SC_FLAG_EST_BOUND also on sc_hypothesize_device (SC_EBOUND from the finalize call); SC_FLAG_SHARD_AB (sc_register_multi replicates stages A and B on small graphs unless told otherwise); sc_debug / sc_debug_info grew (the Gram filter's frame and cut: saccot_debug.h).  0.5: sc_register_device_async / sc_wait (host-free enqueue), SC_FLAG_EST_BOUND / SC_EBOUND (sharded stage B pruned by an estimated bound), sc_stats.bytes_moved, the debug hooks moved to
+#define SC_VERSION_MINOR 7   /* 0.7: sc_finalize_gathered_device_async (+ sc_wait), sc_hypothesize_device with SC_FLAG_EST_BOUND host-free on a repeated shape.  0.6: SC_FLAG_EST_BOUND also on sc_hypothesize_device (SC_EBOUND from the finalize call); SC_FLAG_SHARD_AB (sc_register_multi replicates stages A and B on small graphs unless told otherwise); sc_debug / sc_debug_info grew (the Gram filter's frame and cut: saccot_debug.h).  0.5: sc_register_device_async / sc_wait (host-free enqueue), SC_FLAG_EST_BOUND / SC_EBOUND (sharded stage B pruned by an estimated bound), sc_stats.bytes_moved, the debug hooks moved to
                                 saccot_debug.h; 0.4: sc_debug_last / sc_debug_info, sc_debug.filter_blind; 0.3: sc_set_debug (no environment variables), SC_FLAG_NO_DENSE_S, sc_shard_* (stages A and B sharded); 0.2: SC_FLAG_TIMING_HOT,
                                 SC_STREAM_DEFAULT, sc_hypothesize_begin/end_device, sc_finalize_gathered_device */
 
@@ -49,7 +49,8 @@ extern "C" {
                          /* or 2^32 or more edges (edge ids are 32-bit)                                      */
 
 #define SC_EBOUND   -8   /* calls made with SC_FLAG_EST_BOUND only: the ESTIMATED pruning bound was too high (the merged           */
-                        /* candidates hold fewer than T keys above it): nothing was returned; repeat the call WITHOUT the flag  */
+                        /* candidates hold fewer than T keys above it) — or, sc_hypothesize_device, a host-free enqueue did not */
+                        /* cover this input's counts: nothing was returned; repeat the call(s) WITHOUT the flag                */
 #define SC_ERETRY   -7   /* sharded stages A + B only: a rank's candidate blob was too small for this input (its    */
                          /* list was cut at a key the merged threshold does not clear).  Outputs are not valid;    */
                          /* repeat the call on every rank with sc_params.shard_cand_level raised by one (every     */
@@ -238,6 +239,13 @@ int sc_finalize_device(sc_ctx* ctx, const uint64_t* d_key, float* d_Rt, uint8_t*
  * finalize kernel.  One collective per call instead of two dependent ones; sc_finalize_device is the n_pairs = 1 case. */
 int sc_finalize_gathered_device(sc_ctx* ctx, const uint64_t* d_keys, int n_pairs, float* d_Rt, uint8_t* d_mask,
                                 sc_stats* stats);
+/* The same in two halves (0.7), for ranks that register a STREAM of frames: the finalize kernel is enqueued and the call returns;
+ * sc_wait(ctx, stats) delivers what sc_finalize_gathered_device returns.  Between the two the rank's host thread is free — e.g. to
+ * run sc_hypothesize_device, the exchange and this call for the job's NEXT frame on a second context bound to the same stream, so
+ * that the GPU never waits for a winner's way to the host.  With SC_FLAG_EST_BOUND a sc_hypothesize_device call that repeats the
+ * last call's shape on its context is itself enqueued without a host wait (as sc_register_device_async's calls are); its
+ * validation happens in the finalize call / sc_wait, and a failed one is one more reason for SC_EBOUND — on every rank alike. */
+int sc_finalize_gathered_device_async(sc_ctx* ctx, const uint64_t* d_keys, int n_pairs, float* d_Rt, uint8_t* d_mask);
 
 /* Phase 1 in two halves, for large T_total over several GPUs: stage B's certificate (sc_tri.hip 3b) samples ~5T/8
  * edges, which every rank would otherwise repeat (126 us at T_total = 400 k against 33 us at 50 k).  `begin` runs A,

@@ -37,7 +37,7 @@ SC_HIST_WORDS = 256  # u32 words of the pruning-sample histogram (sc_hypothesize
 EXPORTS = ["sc_version", "sc_strerror", "sc_default_params", "sc_create", "sc_destroy", "sc_set_stream",
            "sc_last_error", "sc_set_debug", "sc_debug_last", "sc_register", "sc_register_device", "sc_register_device_async", "sc_wait",
            "sc_hypothesize_device", "sc_finalize_device",
-           "sc_hypothesize_begin_device", "sc_hypothesize_end_device", "sc_finalize_gathered_device",
+           "sc_hypothesize_begin_device", "sc_hypothesize_end_device", "sc_finalize_gathered_device", "sc_finalize_gathered_device_async",
            "sc_shard_plan_query", "sc_shard_compat_device", "sc_shard_edges_device", "sc_shard_select_device",
            "sc_shard_score_device", "sc_create_multi", "sc_create_multi_loopback", "sc_destroy_multi",
            "sc_multi_last_error", "sc_register_multi",
@@ -146,6 +146,7 @@ def load_library() -> C.CDLL:
     L.sc_hypothesize_begin_device.argtypes = [vp, vp, vp, C.c_int64, pp, vp, sp]
     L.sc_hypothesize_end_device.argtypes = [vp, vp, vp, sp]
     L.sc_finalize_gathered_device.argtypes = [vp, vp, C.c_int, vp, vp, sp]
+    L.sc_finalize_gathered_device_async.argtypes = [vp, vp, C.c_int, vp, vp]
     L.sc_shard_plan_query.argtypes = [pp, C.c_int64, C.POINTER(ScShardPlan)]
     L.sc_shard_compat_device.argtypes = [vp, vp, vp, C.c_int64, pp, vp]
     L.sc_shard_edges_device.argtypes = [vp, vp]
@@ -277,8 +278,9 @@ class Registrar:
         self._check(self._lib.sc_register_device_async(self._h, d_src, d_tgt, n, C.byref(params), d_Rt, d_mask))
 
     def wait(self):
+        """sc_wait: the second half of register_device_async / finalize_gathered_device_async."""
         st = ScStats(C.sizeof(ScStats))
-        rc = self._check(self._lib.sc_wait(self._h, C.byref(st)), allow=(SC_ENOHYP,))
+        rc = self._check(self._lib.sc_wait(self._h, C.byref(st)), allow=(SC_ENOHYP, SC_ERETRY, SC_EBOUND))
         return rc, st.as_dict()
 
     def hypothesize_device(self, d_src: int, d_tgt: int, n: int, params: ScParams, d_key: int):
@@ -310,6 +312,10 @@ class Registrar:
         rc = self._check(self._lib.sc_finalize_gathered_device(self._h, d_keys, n_pairs, d_Rt, d_mask, C.byref(st)),
                          allow=(SC_ENOHYP, SC_ERETRY, SC_EBOUND))  # SC_ERETRY (sharded A + B): repeat with shard_cand_level + 1; SC_EBOUND: repeat without SC_FLAG_EST_BOUND
         return rc, st.as_dict()
+
+    def finalize_gathered_device_async(self, d_keys: int, n_pairs: int, d_Rt: int, d_mask: int):
+        """sc_finalize_gathered_device_async: the finalize kernel is enqueued; `wait()` delivers status and statistics."""
+        self._check(self._lib.sc_finalize_gathered_device_async(self._h, d_keys, n_pairs, d_Rt, d_mask))
 
     # ---- stages A and B sharded too (SURVEY §8f-1; include/saccot.h "phase API") ----------------------------
     def shard_compat_device(self, d_src: int, d_tgt: int, n: int, params: ScParams, d_bits_all: int):

@@ -113,6 +113,7 @@ struct sc_ctx {
   bool pending = false;
   bool pend_done = false;    // ... and it was a waited call: complete, status in pending_rc
   int pending_rc = 0;        // status already known when the async half returned (a waited call is complete by then)
+  bool pend_finalize = false;  // the outstanding call is sc_finalize_gathered_device_async's (sc_wait: no repeat inside the library)
   const float* pend_src = nullptr; const float* pend_tgt = nullptr; float* pend_Rt = nullptr; uint8_t* pend_mask = nullptr;
   int64_t pend_n = 0; sc_params pend_p{}; sc_stats pend_stats{};
   // pruning by an ESTIMATED bound (sc_tri.hip 3c): only where this file can repeat the call itself (sc_register_device /
@@ -283,6 +284,7 @@ int rec(sc_ctx* c, int i) {
 }
 
 int calibrate_events(sc_ctx* c);
+bool fast_plan(sc_ctx* c, int64_t n, const sc_params* p);
 
 // SC_FLAG_TIMING / _HOT / _ONE -> the context's timing state for this call
 int set_timing(sc_ctx* c, const sc_params* p) {
@@ -1260,11 +1262,20 @@ int sc_hypothesize_device(sc_ctx* c, const float* d_src, const float* d_tgt, int
   // sc_finalize(_gathered)_device returns SC_EBOUND when it was too high (on every rank of a job alike: stages A and B are
   // replicated and deterministic): the caller repeats both calls without the flag
   const bool est = p && p->size == sizeof(sc_params) && (p->flags & SC_FLAG_EST_BOUND) != 0;
+  if (c->pending) { c->last_error = "a call is outstanding on this context (sc_wait first)"; return SC_EINVAL; }
+  // r04c: with the flag, a call that repeats the last call's shape on this context is enqueued HOST-FREE, as sc_register_device's
+  // is (fast_plan): no wait for stage B's two counts — the rank's host thread is free to enqueue the job's next frame.  The
+  // finalize call validates; a count that outgrew what the launches covered comes back as SC_EBOUND too ("repeat both calls
+  // without the flag" — the waiting, certifying way handles every case), on every rank alike: stages A and B are replicated.
+  c->spec_on = false;
+  c->fast_state = 0;
+  if (est && check_params(p) == SC_OK && fast_plan(c, n, p)) c->spec_on = true;
   c->est_allowed = est;
   if (est) c->est_failed = false;  // (the CALLER decides when to stop estimating on this entry)
   int rc = hyp_begin(c, d_src, d_tgt, n, p, nullptr, 0, 1);  // the whole sample, into the context's histogram
   if (rc == SC_OK) rc = hyp_end(c, nullptr, d_key, stats);
   c->est_allowed = false;
+  if (rc != SC_OK && c->spec_on) { c->spec_on = false; c->fast_ok = false; }
   return rc;
 }
 
@@ -1450,7 +1461,7 @@ int finalize_enqueue(sc_ctx* c, const uint64_t* d_keys, int n_pairs, float* d_Rt
 
 // what the next call on this context may assume (fast_plan): the call that just completed was a "regular" one
 void note_completed(sc_ctx* c, bool regular) {
-  c->fast_ok = regular && !c->sharded_ab && c->params.shard_world == 1 && c->E >= 4096 && c->T_eff == c->params.max_triangles;
+  c->fast_ok = regular && !c->sharded_ab && c->E >= 4096 && c->T_eff == c->params.max_triangles;  // (stages A and B whole on this GPU: one rank, or replicated ranks)
   c->E_last = c->E; c->M_last = c->M; c->last_n = c->n;
   c->last_p = c->params;
   c->mx_last = __atomic_load_n(&c->pinned[13], __ATOMIC_ACQUIRE);  // (the call is complete: its staging kernel's words have arrived)
@@ -1565,7 +1576,7 @@ bool fast_plan(sc_ctx* c, int64_t n, const sc_params* p) {
   const sc_params& q = c->last_p;
   if (p->sigma != q.sigma || p->t_cmp != q.t_cmp || p->tau != q.tau || p->min_len != q.min_len ||
       p->max_triangles != q.max_triangles || p->rank_mode != q.rank_mode || p->layout != q.layout ||
-      p->shard_world != 1 || q.shard_world != 1 || p->score_mode != q.score_mode ||
+      p->shard_world != q.shard_world || p->shard_rank != q.shard_rank || p->shard_block != q.shard_block || p->score_mode != q.score_mode ||
       (p->flags & ~TIMING_BITS) != (q.flags & ~TIMING_BITS))
     return false;
   if (!(p->rank_mode == SC_RANK_WEIGHT && 3.0f * p->t_cmp * 0.999f >= 2.0f)) return false;  // the a-priori select window
@@ -1612,13 +1623,34 @@ int register_waited(sc_ctx* c, const float* d_src, const float* d_tgt, int64_t n
 
 extern "C" {
 
+// the finalize call of a HOST-FREE sc_hypothesize_device: a failed validation is the caller's to repeat (every rank alike)
+static int finalize_status(sc_ctx* c, int rc) {
+  if (rc != SC_ESPEC) return rc;
+  c->last_error += " — repeat sc_hypothesize_device and the finalize call without SC_FLAG_EST_BOUND";
+  return SC_EBOUND;
+}
+
 int sc_finalize_gathered_device(sc_ctx* c, const uint64_t* d_keys, int n_pairs, float* d_Rt, uint8_t* d_mask,
                                 sc_stats* stats) {
   if (!c || !d_keys || !d_Rt || !d_mask || n_pairs < 1 || n_pairs > 4096) return SC_EINVAL;
+  if (c->pending) { c->last_error = "a call is outstanding on this context (sc_wait first)"; return SC_EINVAL; }
   if (!c->have_hyp) { c->last_error = "sc_finalize_device without a preceding sc_hypothesize_device"; return SC_EINVAL; }
   HIPCHK(c, hipSetDevice(c->device));
   const int rc = finalize_enqueue(c, d_keys, n_pairs, d_Rt, d_mask);
-  return rc ? rc : finalize_wait(c, stats);
+  return rc ? rc : finalize_status(c, finalize_wait(c, stats));
+}
+
+int sc_finalize_gathered_device_async(sc_ctx* c, const uint64_t* d_keys, int n_pairs, float* d_Rt, uint8_t* d_mask) {
+  if (!c || !d_keys || !d_Rt || !d_mask || n_pairs < 1 || n_pairs > 4096) return SC_EINVAL;
+  if (c->pending) { c->last_error = "a call is outstanding on this context (sc_wait first)"; return SC_EINVAL; }
+  if (!c->have_hyp) { c->last_error = "sc_finalize_device without a preceding sc_hypothesize_device"; return SC_EINVAL; }
+  HIPCHK(c, hipSetDevice(c->device));
+  memset(&c->pend_stats, 0, sizeof c->pend_stats);
+  c->pend_stats.size = sizeof(sc_stats);
+  const int rc = finalize_enqueue(c, d_keys, n_pairs, d_Rt, d_mask);
+  if (rc) return rc;
+  c->pending = true; c->pend_done = false; c->pend_finalize = true;
+  return SC_OK;
 }
 
 int sc_register_device_async(sc_ctx* c, const float* d_src, const float* d_tgt, int64_t n, const sc_params* p,
@@ -1649,20 +1681,26 @@ int sc_register_device_async(sc_ctx* c, const float* d_src, const float* d_tgt, 
     if (!rc) rc = finalize_enqueue(c, c->key.as<uint64_t>(), 1, d_Rt, d_mask);
     SC_TICK(c, 6);
     if (rc) { c->spec_on = false; c->fast_ok = false; return rc; }  // (a launch or allocation failed: nothing is outstanding)
-    c->pending = true; c->pend_done = false;
+    c->pending = true; c->pend_done = false; c->pend_finalize = false;
     return SC_OK;
   }
   rc = register_waited(c, d_src, d_tgt, n, p, d_Rt, d_mask, &c->pend_stats);
   if (rc != SC_OK && rc != SC_ENOHYP) return rc;
-  c->pending = true; c->pend_done = true; c->pending_rc = rc;
+  c->pending = true; c->pend_done = true; c->pending_rc = rc; c->pend_finalize = false;
   return SC_OK;
 }
 
 int sc_wait(sc_ctx* c, sc_stats* stats) {
   if (!c) return SC_EINVAL;
-  if (!c->pending) { c->last_error = "sc_wait without an outstanding sc_register_device_async"; return SC_EINVAL; }
+  if (!c->pending) { c->last_error = "sc_wait without an outstanding sc_register_device_async / sc_finalize_gathered_device_async"; return SC_EINVAL; }
   HIPCHK(c, hipSetDevice(c->device));
   c->pending = false;
+  if (c->pend_finalize) {  // sc_finalize_gathered_device's second half
+    c->pend_finalize = false;
+    const int frc = finalize_status(c, finalize_wait(c, &c->pend_stats));
+    if (stats && stats->size == sizeof(sc_stats)) *stats = c->pend_stats;
+    return frc;
+  }
   int rc = c->pending_rc;
   SC_TICK(c, 7);
   if (!c->pend_done) {

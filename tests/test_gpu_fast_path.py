@@ -204,3 +204,77 @@ def test_a_frame_enqueued_ahead_picks_stage_c2s_kernel_by_the_last_calls_maxima(
     finally:
         for r in regs:
             r.close()
+
+
+def test_replicated_ranks_enqueue_host_free_and_finalize_in_two_halves(pkg):
+    """r04c: sc_hypothesize_device with SC_FLAG_EST_BOUND enqueues a repeated shape without a host wait (stages A and B
+    replicated on every rank), sc_finalize_gathered_device_async + sc_wait split the finalize step — two ranks of a job emulated
+    on one GPU, two frames in flight per rank (two contexts each, one stream).  Every frame's winner, motion and mask are the
+    single-GPU call's; a frame whose counts outgrow what the host-free launches covered comes back as SC_EBOUND from sc_wait and
+    the repeat without the flag succeeds."""
+    import torch
+    dev = torch.device("cuda:0")
+    n, tau, T, world, block = 2000, 0.02, 10000, 2, 500
+    kw = dict(sigma=tau, t_cmp=0.9, tau=tau, min_len=tau, max_triangles=T, rank_mode=0)
+    scenes = dict(regular=pkg.synth.make_scene(n, 0.20, 1.0, tau, 1001), dense=pkg.synth.make_scene(n, 0.60, 1.0, tau, 57))
+    st_ = torch.cuda.current_stream().cuda_stream
+    single = pkg.Registrar(0); single.set_stream(st_)
+    ctx = [[pkg.Registrar(0), pkg.Registrar(0)] for _ in range(world)]          # ctx[rank][frame parity]
+    try:
+        dsc = {nm: _dev(torch, sc, dev) for nm, sc in scenes.items()}
+        base = {nm: _run(torch, single, dsc[nm][0], dsc[nm][1], n, pkg.make_params(**kw), dev) for nm in scenes}
+        for pr in ctx:
+            for g in pr:
+                g.set_stream(st_)
+        prm = [pkg.make_params(shard_rank=r, shard_world=world, shard_block=block, flags=pkg.SC_FLAG_EST_BOUND, **kw) for r in range(world)]
+        prm0 = [pkg.make_params(shard_rank=r, shard_world=world, shard_block=block, **kw) for r in range(world)]
+        keys = [torch.zeros(2 * world, dtype=torch.int64, device=dev) for _ in range(2)]   # the "gathered" pairs of a frame
+        outs = [[(torch.zeros(12, dtype=torch.float32, device=dev), torch.zeros(n, dtype=torch.uint8, device=dev)) for _ in range(2)] for _ in range(world)]
+
+        def enqueue(k, nm, params):
+            i = k & 1
+            for r in range(world):    # (on real ranks these run side by side and an all-gather fills keys[i])
+                ctx[r][i].hypothesize_device(dsc[nm][0].data_ptr(), dsc[nm][1].data_ptr(), n, params[r], keys[i].data_ptr() + 16 * r)
+            for r in range(world):
+                ctx[r][i].finalize_gathered_device_async(keys[i].data_ptr(), world, outs[r][i][0].data_ptr(), outs[r][i][1].data_ptr())
+
+        def collect(k, nm):
+            i = k & 1
+            res = []
+            for r in range(world):
+                rc, s = ctx[r][i].wait()
+                res.append((rc, s, ctx[r][i].debug_last()["fast_path"]))
+            return res
+
+        def check(res, nm, k):
+            i = k & 1
+            torch.cuda.synchronize()
+            for r, (rc, s, _) in enumerate(res):
+                assert rc == base[nm]["rc"] and s["best_rank"] == base[nm]["st"]["best_rank"] and s["best_count"] == base[nm]["st"]["best_count"], (nm, k, r)
+                assert np.array_equal(outs[r][i][1].cpu().numpy(), base[nm]["mask"]) and nan_equal_bits(outs[r][i][0].cpu().numpy(), base[nm]["Rt"])
+
+        fast = []
+        enqueue(0, "regular", prm)
+        for k in range(1, 8):
+            enqueue(k, "regular", prm)
+            res = collect(k - 1, "regular")
+            check(res, "regular", k - 1)
+            fast.append([f for _, _, f in res])
+        res = collect(7, "regular"); check(res, "regular", 7)
+        assert fast[0] == [0, 0] and fast[1] == [0, 0] and all(f == [1, 1] for f in fast[2:]), fast   # (a context's first call waits)
+        with pytest.raises(pkg.SacCotError):                       # one call outstanding per context
+            ctx[0][0].finalize_gathered_device_async(keys[0].data_ptr(), world, outs[0][0][0].data_ptr(), outs[0][0][1].data_ptr())
+            ctx[0][0].finalize_gathered_device_async(keys[0].data_ptr(), world, outs[0][0][0].data_ptr(), outs[0][0][1].data_ptr())
+        ctx[0][0].wait()
+        # ~9 x the edges under the same shape: the host-free launches do not cover it -> SC_EBOUND on every rank, then the repeat
+        enqueue(0, "dense", prm)
+        res = collect(0, "dense")
+        assert [rc for rc, _, _ in res] == [pkg.SC_EBOUND] * world, res
+        enqueue(0, "dense", prm0)
+        res = collect(0, "dense"); check(res, "dense", 0)
+        assert [f for _, _, f in res] == [0, 0]
+    finally:
+        single.close()
+        for pr in ctx:
+            for g in pr:
+                g.close()

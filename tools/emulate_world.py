@@ -28,6 +28,9 @@ ap.add_argument("--config", default="C3")
 ap.add_argument("--scaling", choices=("strong", "weak"), default="strong")
 ap.add_argument("--mode", choices=("shard_ab", "replicated"), default="shard_ab")
 ap.add_argument("--nodense", action="store_true")
+ap.add_argument("--streamed", action="store_true",
+                help="replicated mode: a rank's frames as a STREAM (r04c: host-free sc_hypothesize_device, sc_finalize_gathered_device_async, "
+                     "frame k + 1 enqueued before frame k is waited for — two contexts on one stream), as bench.py times them")
 ap.add_argument("--iters", type=int, default=10)
 ap.add_argument("--certified", action="store_true",
                 help="shard_ab without SC_FLAG_EST_BOUND: certifying sample shared by the ranks + the 1 KiB histogram all-reduce "
@@ -93,11 +96,32 @@ for world in args.worlds:
         for r in range(world if world <= 2 else 2):  # ranks are statistically alike here: two suffice
             for _ in range(2):
                 step(r); reg.finalize_gathered_device(d_keys.data_ptr(), world, d_Rt.data_ptr(), d_mask.data_ptr())
+            if args.streamed:
+                regB = pkg.Registrar(0); regB.set_stream(torch.cuda.current_stream().cuda_stream)
+                pair = [reg, regB]
+                outs = [(d_Rt, d_mask), (torch.zeros(12, dtype=torch.float32, device=dev), torch.zeros(cfg.n, dtype=torch.uint8, device=dev))]
+                for _ in range(3):
+                    regB.hypothesize_device(d_src.data_ptr(), d_tgt.data_ptr(), cfg.n, ps[r], d_keys.data_ptr() + 16 * r)
+                    regB.finalize_gathered_device(d_keys.data_ptr(), world, outs[1][0].data_ptr(), outs[1][1].data_ptr())
+
+                def enqueue(k):
+                    pair[k & 1].hypothesize_device(d_src.data_ptr(), d_tgt.data_ptr(), cfg.n, ps[r], d_keys.data_ptr() + 16 * r)
+                    pair[k & 1].finalize_gathered_device_async(d_keys.data_ptr(), world, outs[k & 1][0].data_ptr(), outs[k & 1][1].data_ptr())
+                KS = 4 * K
+                torch.cuda.synchronize(); t0 = time.perf_counter()
+                enqueue(0)
+                for k in range(1, KS + 1):
+                    if k < KS:
+                        enqueue(k)
+                    rc, st = pair[(k - 1) & 1].wait()
+                torch.cuda.synchronize(); times.append((time.perf_counter() - t0) / KS)
+                regB.close()
+                continue
             torch.cuda.synchronize(); t0 = time.perf_counter()
             for _ in range(K):
                 step(r); rc, st = reg.finalize_gathered_device(d_keys.data_ptr(), world, d_Rt.data_ptr(), d_mask.data_ptr())
             torch.cuda.synchronize(); times.append((time.perf_counter() - t0) / K)
-        coll = "key pairs 16 B/rank"
+        coll = "key pairs 16 B/rank" + (" (streamed)" if args.streamed else "")
         reg.close()
     else:
         regs = [pkg.Registrar(0) for _ in range(world)]
