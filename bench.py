@@ -675,10 +675,10 @@ def main() -> int:
                 for _ in range(20):
                     ss1.step(d_src.data_ptr(), d_tgt.data_ptr())
                 torch.cuda.synchronize(); phase_ms = (time.perf_counter() - tq0) / 20 * 1e3
-                host_io_ms = out["ms_to_best_Rt"] - ms_per_step   # what host arrays in / out add to the device-resident step
+                host_io_ms = out["ms_to_best_Rt"] - (waited["ms_per_step"] if waited else ms_per_step)   # what host arrays in / out add to the device-resident (waited) step
                 out["native_multi"] = {
                     "sc_register_multi_loopback1_ms": multi_ms, "sc_register_ms": out["ms_to_best_Rt"],
-                    "phase_api_world1_device_resident_ms": phase_ms, "single_device_resident_ms": ms_per_step,
+                    "phase_api_world1_device_resident_ms": phase_ms, "single_device_resident_ms": (waited["ms_per_step"] if waited else ms_per_step),
                     "orchestration_us": round((multi_ms - phase_ms - host_io_ms) * 1e3, 1),
                     "same_result": bool(gm["stats"]["best_rank"] == st["best_rank"] and np.array_equal(gm["mask"], d_mask.cpu().numpy())),
                     "note": "orchestration_us = sc_register_multi (one rank, real single-rank RCCL communicator: worker thread, "

@@ -18,7 +18,9 @@ cp profiles/pmc_summary.json $O/${TAG}_pmc_summary.json
 { timeout -k 10 300 python tools/emulate_world.py --config C3 1 2 4 8 && timeout -k 10 200 python tools/emulate_world.py --config C3 --mode replicated 8 &&
   timeout -k 10 200 python tools/emulate_world.py --config C3 --nodense 8 &&
   timeout -k 10 300 python tools/emulate_world.py --config C4 1 2 4 8 && timeout -k 10 300 python tools/emulate_world.py --config C2 --scaling weak 1 2 4 8 &&
-  timeout -k 10 300 python tools/emulate_world.py --config C2 --scaling weak --mode replicated 1 2 4 8; } > $O/${TAG}_emulated_world.txt 2>&1 \
+  timeout -k 10 300 python tools/emulate_world.py --config C2 --scaling weak --mode replicated 1 2 4 8 &&
+  timeout -k 10 300 python tools/emulate_world.py --config C2 --scaling weak --mode replicated --streamed --no-latency 1 2 4 8 &&
+  timeout -k 10 300 python tools/emulate_world.py --config C4 --mode replicated --streamed --no-latency 1 2 4 8; } > $O/${TAG}_emulated_world.txt 2>&1 \
   || { tail -5 $O/${TAG}_emulated_world.txt; exit 1; }   # a failed GPU step ends the call: no further GPU step after it
 grep -v amdgpu.ids $O/${TAG}_emulated_world.txt | cut -c1-170
 bash tools/prof_emulate.sh ${TAG}_emuC3w8 C3 8 > $O/${TAG}_emulated_C3_world8_kernels.txt 2>&1 || { tail -5 $O/${TAG}_emulated_C3_world8_kernels.txt; exit 1; }
