@@ -1,9 +1,11 @@
 #!/usr/bin/env python3
-"""Soak: one context, thousands of calls over alternating problem sizes and four forms of the call — the two phase-1 forms of
+"""Soak: one context (two for the bursts), thousands of calls over alternating problem sizes and six forms of the call — the two phase-1 forms of
 the phase API (certified pruning bound, host waits in the middle) and sc_register_device (r04: estimated bound, fused edge
 kernel, host-free enqueue of a repeated shape); every result must be byte-identical to the first one of its configuration
 (tickets, polled read-backs, speculative launches and the validate-and-repeat paths are exercised on buffers left over from
-other sizes).   python tools/soak.py [seconds] [--big]"""
+other sizes); r04c: BURSTS of 2 - 6 frames of one configuration as a stream — frame k + 1 enqueued before frame k is waited for, two
+contexts on the stream — through sc_register_device_async / sc_wait and through host-free sc_hypothesize_device +
+sc_finalize_gathered_device_async / sc_wait.   python tools/soak.py [seconds] [--big]"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -15,6 +17,7 @@ budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
 big = "--big" in sys.argv   # also C3 and C4 (the Gram filter's cut at its largest shapes; ~1 ms per call)
 dev = torch.device("cuda", 0)
 reg = pkg.Registrar(0)
+regB = pkg.Registrar(0)
 stream = torch.cuda.Stream(device=dev)
 cases = []
 for name, T in (("C0", 200), ("C1", 10000), ("C2", 50000), ("C1", 3000), ("C2", 200000)) + ((("C3", 200000), ("C4", 500000)) if big else ()):
@@ -28,12 +31,53 @@ t0 = time.time()
 rng = np.random.default_rng(0)
 with torch.cuda.stream(stream):
     reg.set_stream(stream.cuda_stream)
+    regB.set_stream(stream.cuda_stream)
+    pair = [reg, regB]
+    bursts = [0, 0]
+    d_keys2 = [torch.zeros(2, dtype=torch.int64, device=dev) for _ in range(2)]
+    d_Rt2 = [torch.zeros(12, dtype=torch.float32, device=dev) for _ in range(2)]
     d_key = torch.zeros(2, dtype=torch.int64, device=dev)
     d_hist = torch.zeros(pkg.SC_HIST_WORDS, dtype=torch.int32, device=dev)
     d_Rt = torch.zeros(12, dtype=torch.float32, device=dev)
     while time.time() - t0 < budget:
         name, n, kw, s, t = cases[int(rng.integers(len(cases)))]
-        form = int(rng.integers(4))   # 0 hypothesize + finalize, 1 its split-sample form, 2 sc_register_device, 3 form 0 with SC_FLAG_EST_BOUND (r04b)
+        form = int(rng.integers(6))   # 0 hypothesize + finalize, 1 its split-sample form, 2 sc_register_device, 3 form 0 with SC_FLAG_EST_BOUND (r04b), 4 / 5 bursts (r04c)
+        if form >= 4:
+            # a burst of frames as a stream: 4 = sc_register_device_async, 5 = hypothesize (estimated bound: host-free from its
+            # context's second frame on) + finalize in two halves; every frame must equal the configuration's first result
+            nb = int(rng.integers(2, 7))
+            pb = pkg.make_params(flags=pkg.SC_FLAG_EST_BOUND if form == 5 else 0, **kw)
+            masks = [torch.zeros(n, dtype=torch.uint8, device=dev) for _ in range(2)]
+
+            def enq(k):
+                i = k & 1
+                if form == 4:
+                    pair[i].register_device_async(s.data_ptr(), t.data_ptr(), n, pb, d_Rt2[i].data_ptr(), masks[i].data_ptr())
+                else:
+                    pair[i].hypothesize_device(s.data_ptr(), t.data_ptr(), n, pb, d_keys2[i].data_ptr())
+                    pair[i].finalize_gathered_device_async(d_keys2[i].data_ptr(), 1, d_Rt2[i].data_ptr(), masks[i].data_ptr())
+            enq(0)
+            for k in range(1, nb + 1):
+                if k < nb:
+                    enq(k)
+                i = (k - 1) & 1
+                rc, st = pair[i].wait()
+                if rc == pkg.SC_EBOUND:   # (form 5 only: the caller's repeat, the certifying way)
+                    p0 = pkg.make_params(**kw)
+                    pair[i].hypothesize_device(s.data_ptr(), t.data_ptr(), n, p0, d_keys2[i].data_ptr())
+                    rc, st = pair[i].finalize_gathered_device(d_keys2[i].data_ptr(), 1, d_Rt2[i].data_ptr(), masks[i].data_ptr())
+                    bursts[1] += 1
+                # (the copies below run on this stream, behind frame k: frame k - 1's outputs are complete, frame k + 1 reuses them)
+                sig = (rc, st["edges"], st["tri_kept"], st["best_rank"], st["best_count"],
+                       d_Rt2[i].cpu().numpy().tobytes(), masks[i].cpu().numpy().tobytes())
+                if name not in first:
+                    first[name] = sig
+                elif first[name] != sig:
+                    mism += 1
+                    print("MISMATCH", name, ("burst register", "burst hypothesize")[form - 4], k - 1, sig[:5], "vs", first[name][:5], flush=True)
+                calls += 1
+            bursts[0] += 1
+            continue
         split = form == 1
         p = pkg.make_params(flags=pkg.SC_FLAG_EST_BOUND if form == 3 else 0, **kw)
         d_mask = torch.zeros(n, dtype=torch.uint8, device=dev)
@@ -60,5 +104,6 @@ with torch.cuda.stream(stream):
         if calls % 2000 == 0:
             print(f"{calls} calls, {mism} mismatches, {time.time() - t0:.0f} s", flush=True)
 print(f"soak: {calls} calls over {len(first)} configurations in {time.time() - t0:.0f} s, {mism} mismatches; "
-      f"sc_register_device calls: {forms[0]} waited, {forms[1]} host-free, {forms[2]} host-free and repeated")
+      f"sc_register_device calls: {forms[0]} waited, {forms[1]} host-free, {forms[2]} host-free and repeated; {bursts[0]} bursts of streamed frames "
+      f"({bursts[1]} frames came back SC_EBOUND and were repeated)")
 sys.exit(1 if mism else 0)
