@@ -687,33 +687,35 @@ def main() -> int:
             except Exception as ex:  # RCCL not loadable on this box: report, do not fail the headline
                 out["native_multi"] = {"error": str(ex)}
             reg.set_stream(None)
-            # ---- throughput with TWO independent registrations in flight (two contexts, two streams, two host threads):
-            # the path is a chain of ~19 dependent launches, many of them small, so a second call fills the gaps.  NOT the
-            # headline (`value` is one call at a time); what a service that registers a stream of frames would see.
-            import threading
-            out["calls_in_flight"] = {"note": "independent registrations in flight at once: one context, stream and host thread "
-                                              "each, 25 calls per thread; hypotheses/s of all of them together; not `value`"}
-            for nfl in (2, 4):
+            # ---- throughput with several independent registrations in flight ON THE GPU: one context and one stream per frame in
+            # flight, ONE host thread (sc_register_device_async ring; r04c — rounds 2 - 4b used a host thread per context and waited
+            # calls).  The path is a chain of ~16 dependent launches, most of them far from filling the chip, so frames that overlap
+            # fill each other's gaps.  NOT the headline (`value` is frames back to back on ONE stream: nothing overlaps there); what a
+            # service that registers a stream of frames can get out of the card.
+            out["calls_in_flight"] = {"note": "independent registrations OVERLAPPING on the GPU: one context and one stream each, one host thread "
+                                              "(sc_register_device_async / sc_wait ring), 60 calls per line; hypotheses/s of all of them together; not `value`"}
+            p2 = pkg.make_params(flags=base_flags, **kw)
+            for nfl in (2, 3, 4):
                 regs2 = [pkg.Registrar(local_rank) for _ in range(nfl)]
                 streams2 = [torch.cuda.Stream(device=dev) for _ in range(nfl)]
                 outs2 = [(torch.zeros(12, dtype=torch.float32, device=dev), torch.zeros(n, dtype=torch.uint8, device=dev)) for _ in range(nfl)]
-                p2 = pkg.make_params(flags=base_flags, **kw)
-                res2 = [None] * nfl
-
-                def worker(i, steps):
-                    regs2[i].set_stream(streams2[i].cuda_stream)
-                    for _ in range(steps):
-                        res2[i] = regs2[i].register_device(d_src.data_ptr(), d_tgt.data_ptr(), n, p2, outs2[i][0].data_ptr(), outs2[i][1].data_ptr())
-                    streams2[i].synchronize()
-                for phase_steps in (3, 25):
-                    torch.cuda.synchronize(); tp0 = time.perf_counter()
-                    th = [threading.Thread(target=worker, args=(i, phase_steps)) for i in range(nfl)]
-                    for t_ in th: t_.start()
-                    for t_ in th: t_.join()
-                    tp = time.perf_counter() - tp0
-                same = all(r is not None and r[1]["best_rank"] == st["best_rank"] and r[1]["best_count"] == st["best_count"] for r in res2)
-                out["calls_in_flight"][str(nfl)] = {"ms_per_call": tp / (25 * nfl) * 1e3, "hypotheses_per_s": T_total * 25 * nfl / tp,
-                                                    "same_winner": bool(same)}
+                for g, s2 in zip(regs2, streams2):
+                    g.set_stream(s2.cuda_stream)
+                for g, o2 in zip(regs2, outs2):
+                    for _ in range(3):
+                        g.register_device(d_src.data_ptr(), d_tgt.data_ptr(), n, p2, o2[0].data_ptr(), o2[1].data_ptr())
+                KF = 60
+                same = True
+                torch.cuda.synchronize(); tp0 = time.perf_counter()
+                for k in range(KF + nfl - 1):
+                    if k < KF:
+                        i = k % nfl
+                        regs2[i].register_device_async(d_src.data_ptr(), d_tgt.data_ptr(), n, p2, outs2[i][0].data_ptr(), outs2[i][1].data_ptr())
+                    if k >= nfl - 1:
+                        _, s2_ = regs2[(k - nfl + 1) % nfl].wait()
+                        same = same and s2_["best_rank"] == st["best_rank"] and s2_["best_count"] == st["best_count"]
+                torch.cuda.synchronize(); tp = time.perf_counter() - tp0
+                out["calls_in_flight"][str(nfl)] = {"ms_per_call": tp / KF * 1e3, "hypotheses_per_s": T_total * KF / tp, "same_winner": bool(same)}
                 for g in regs2:
                     g.close()
         else:
