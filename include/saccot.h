@@ -244,7 +244,9 @@ int sc_finalize_gathered_device(sc_ctx* ctx, const uint64_t* d_keys, int n_pairs
  * run sc_hypothesize_device, the exchange and this call for the job's NEXT frame on a second context bound to the same stream, so
  * that the GPU never waits for a winner's way to the host.  With SC_FLAG_EST_BOUND a sc_hypothesize_device call that repeats the
  * last call's shape on its context is itself enqueued without a host wait (as sc_register_device_async's calls are); its
- * validation happens in the finalize call / sc_wait, and a failed one is one more reason for SC_EBOUND — on every rank alike. */
+ * validation happens in the finalize call / sc_wait, and a failed one is one more reason for SC_EBOUND — on every rank alike.
+ * (The statistics sc_hypothesize_device itself returns are provisional for such a call — its counts are what the launches COVER;
+ * the finalize call / sc_wait deliver the real ones.) */
 int sc_finalize_gathered_device_async(sc_ctx* ctx, const uint64_t* d_keys, int n_pairs, float* d_Rt, uint8_t* d_mask);
 
 /* Phase 1 in two halves, for large T_total over several GPUs: stage B's certificate (sc_tri.hip 3b) samples ~5T/8
