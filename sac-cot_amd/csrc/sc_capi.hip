@@ -1052,6 +1052,10 @@ int hyp_begin(sc_ctx* c, const float* d_src, const float* d_tgt, int64_t n, cons
               uint32_t part, uint32_t parts) {
   int rc = check_params(p);
   if (rc) return rc;
+  if (c->pending) {  // (every entry that starts a call on the context comes through here or through sc_shard_compat_device)
+    c->last_error = "a call is outstanding on this context (sc_wait first)";
+    return SC_EINVAL;
+  }
   HIPCHK(c, hipSetDevice(c->device));
   c->have_hyp = false;
   c->begun = false;
@@ -1319,6 +1323,7 @@ int sc_shard_compat_device(sc_ctx* c, const float* d_src, const float* d_tgt, in
   int rc = check_params(p);
   if (rc) return rc;
   if (p->shard_world > 64) return SC_EINVAL;
+  if (c->pending) { c->last_error = "a call is outstanding on this context (sc_wait first)"; return SC_EINVAL; }
   HIPCHK(c, hipSetDevice(c->device));
   c->have_hyp = false; c->begun = false; c->timed_trikeys = false;
   if ((rc = set_timing(c, p))) return rc;

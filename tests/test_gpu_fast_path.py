@@ -265,6 +265,10 @@ def test_replicated_ranks_enqueue_host_free_and_finalize_in_two_halves(pkg):
         with pytest.raises(pkg.SacCotError):                       # one call outstanding per context
             ctx[0][0].finalize_gathered_device_async(keys[0].data_ptr(), world, outs[0][0][0].data_ptr(), outs[0][0][1].data_ptr())
             ctx[0][0].finalize_gathered_device_async(keys[0].data_ptr(), world, outs[0][0][0].data_ptr(), outs[0][0][1].data_ptr())
+        with pytest.raises(pkg.SacCotError):                       # ... whatever the entry
+            ctx[0][0].hypothesize_device(dsc["regular"][0].data_ptr(), dsc["regular"][1].data_ptr(), n, prm[0], keys[0].data_ptr())
+        with pytest.raises(pkg.SacCotError):
+            ctx[0][0].register(scenes["regular"].src, scenes["regular"].tgt, **kw)
         ctx[0][0].wait()
         # ~9 x the edges under the same shape: the host-free launches do not cover it -> SC_EBOUND on every rank, then the repeat
         enqueue(0, "dense", prm)
