@@ -584,6 +584,14 @@ def main() -> int:
                        "dense_S": dense},
             "score_stage_hyp_per_s": n_local * world / ((avg["kabsch"] + avg["score"] + avg["argmax"]) * 1e-6),
             "stage_us": {k: round(v, 2) for k, v in avg.items()} | {"trikeys": round(tk, 2)},
+            # the stage as a whole — triangles enumerated per second and the bytes the row asks for (bit matrix once,
+            # 12 per enumerated triangle, 16 per selected one) over the stage's bracket; data-dependent gathers, no fraction target
+            "stage_b": {"triangles_enumerated": st["tri_total"], "us": round(avg["triangles"], 2),
+                        "triangles_enumerated_per_s": round(st["tri_total"] / (max(avg["triangles"], 1e-3) * 1e-6), 1),
+                        "algorithmic_bytes": int(n * n / 8 + 12 * st["tri_total"] + 16 * st["tri_scored"] * (world if not sharded_ab else 1)),
+                        "achieved_GBs": round((n * n / 8 + 12 * st["tri_total"] + 16 * st["tri_scored"]) / (max(avg["triangles"], 1e-3) * 1e-6) / 1e9, 1),
+                        "note": "the graph is pruned by a bound on the T-th key before it is enumerated (DESIGN 5.0): `triangles_enumerated` is what "
+                                "the pruned graph holds, a fraction of the graph's triangles; the stage is ten dependent launches of gathers, latency-bound"},
             "stage_us_note": "one HIP-event bracket per pass on the hot path (SC_FLAG_TIMING_ONE); `triangles` includes its "
                              "read-backs" + (" and the collectives between the phases" if sharded_ab else ""),
             "winner": {"rank": st["best_rank"], "inliers": st["best_count"], "status": rc},
