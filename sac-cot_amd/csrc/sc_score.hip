@@ -1541,7 +1541,7 @@ __global__ __launch_bounds__(64 * GX_WAVES, 2) void score_gram_kernel(GramCoef c
                                                                      uint32_t splits, uint32_t n_waves8,
                                                                      uint32_t* __restrict__ cnt_out, uint2* __restrict__ gq,
                                                                      uint32_t cap_sq, uint32_t* __restrict__ qcount,
-                                                                     uint32_t* __restrict__ redo_bits, uint32_t ql) {
+                                                                     uint32_t* __restrict__ redo_bits, uint32_t ql, uint32_t group_major) {
   __shared__ uint4 Bt[3][GX_UNIT * GX_TILE_Q];   // ring of three 16 KiB units: one being read, one landing, one being issued
   __shared__ uint2 queue[GX_WAVES][GX_QL];
   constexpr int PIECES = GX_UNIT * GX_TILE_Q / (64 * GX_WAVES);  // LDS-DMA instructions per wave and unit
@@ -1554,15 +1554,29 @@ __global__ __launch_bounds__(64 * GX_WAVES, 2) void score_gram_kernel(GramCoef c
 #else
 #define SC_GRAM_TICK(i)
 #endif
-  // The grid is one-dimensional, groups x splits workgroups, and within a split the LONG ones go first: the row blocks that hold
+  // The grid is one-dimensional, groups x splits workgroups, and the LONG ones go first: the row blocks that hold
   // a hypothesis not near the reference are the LAST ones of their segment (sc_gramref.hpp: segment = row block % S) — the highest
   // row blocks — and walk every correspondence, the others a few near units (dispatched in row order, the last workgroups to
   // start were the longest: a tail as long as the kernel's useful part).
   const GramFrame* __restrict__ fr = coef.frame;
   const uint32_t groups = gridDim.x / splits, S = gram_segments(groups);
-  // (split-major: consecutive workgroups go to different XCDs — blockIdx % 8 — and with by = blockIdx % splits every WORKING
-  // workgroup of the near rows, by = 0, landed on the same XCD when splits was 8: C3 508 us instead of 150)
-  const uint32_t bx = groups - 1u - blockIdx.x % groups, by = blockIdx.x / groups;
+  // GROUP-major, highest row blocks first (r04c): EVERY split of a far row block is dispatched before the first near one.  Split-
+  // major (r04b) started split k's far workgroups — the longest of the launch — only after the splits before it had been
+  // dispatched, near workgroups, empty ones and all (C4: the second split's 267 far workgroups of 10 units began ~45 us into the
+  // launch).  Within a row block the splits are rotated by r(block): workgroup b runs on XCD b % 8, and with by = b % splits the
+  // WORKING workgroups of the near rows (by < ns) would sit on 8 / gcd(splits, 8) of the eight XCDs (by = b % 8 at 8 splits put
+  // them all on one: C3 508 us instead of 150); r advances once per 8 / gcd blocks, which deals them to all eight evenly.
+  // Only for launches of about two resident generations (launch_score_filter: C2's 980 workgroups, 22.6 -> 20.2 us): at C4's 3908
+  // the same order measured 147 us against 109 — two far workgroups sharing a CU run at half speed each, and far-first pairs them
+  // all; split-major pairs most of them with short near ones.  There: split-major, the highest row blocks first within a split.
+  uint32_t bx, by;
+  if (group_major) {
+    const uint32_t gidx = blockIdx.x / splits, sidx = blockIdx.x - gidx * splits;
+    const uint32_t dg = min(splits & (0u - splits), 8u);            // gcd(splits, 8): splits <= 8
+    bx = groups - 1u - gidx; by = (sidx + ((gidx * dg) >> 3) % dg) % splits;
+  } else {
+    bx = groups - 1u - blockIdx.x % groups; by = blockIdx.x / groups;
+  }
   const uint32_t wid = bx * GX_WAVES + wave;  // wave of 32 hypotheses
   // The cut: a workgroup whose 256 rows are all hypotheses NEAR the reference walks the NEAR correspondences only — the tile's
   // first rows; every other correspondence is an outlier of every one of them by the triangle inequality (see the header).
@@ -1875,10 +1889,11 @@ void launch_score_filter(const Points& pts, const float* RtSoA, const float* RtA
     if (ql > (uint32_t)GX_QL) ql = GX_QL;
     if (ql < 64) ql = 64;
     const GramCoef gc = gram_coef_view(coef, sh.ld_local, frame);
+    const uint32_t group_major = (uint64_t)((sh.ld_local + 32 * GX_WAVES - 1) / (32 * GX_WAVES)) * fp.splits <= 1024u ? 1u : 0u;  // (see the kernel)
 #define SC_GRAM_LAUNCH(V)                                                                                                         \
     hipExtLaunchKernelGGL(score_gram_kernel<V>, dim3((sh.ld_local + 32 * GX_WAVES - 1) / (32 * GX_WAVES) * fp.splits), dim3(64 * GX_WAVES), \
                           0, st, ev0, ev_mid, 0, gc, sh.ld_local, static_cast<const uint4*>(tile), fp.windows, fp.splits, fp.n_waves, partial, \
-                          f.queue, f.cap_sq, f.qcount, f.redo, ql)
+                          f.queue, f.cap_sq, f.qcount, f.redo, ql, group_major)
     // The shipped library holds variant 0 only.  -DSC_ABLATIONS (sac-cot_amd/build.py --ablations; tools/pmc_gram_variants.sh)
     // also instantiates the bit-identical scheduling variant 1 and the TIMING-ONLY bodies (no shell test / no barrier / no
     // epilogue: wrong counts by design), which sc_set_debug refuses without it.
