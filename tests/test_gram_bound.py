@@ -137,3 +137,27 @@ def test_far_correspondences_of_a_near_hypothesis_are_outliers_by_the_triangle_i
         far = np.linalg.norm(V, axis=1) > reach + 1.05 * st + 1e-3
         resid = s * np.linalg.norm(sc["p"] @ R.T + t - sc["q"], axis=1)
         assert far.any() and np.all(resid[far] > 1.04 * st), (it, resid[far].min() / st)
+
+
+def test_group_major_grid_order_is_a_bijection_and_spreads_the_working_workgroups_over_the_xcds():
+    """score_gram_kernel's group-major decode of its one-dimensional grid (sc_score.hip; restated here on purpose):
+    workgroup b -> row block groups - 1 - b / splits, split (b % splits + r) % splits with r = (b / splits * g / 8) % g,
+    g = gcd(splits, 8).  Every (row block, split) is taken once, and for every ns the workgroups with split < ns — the
+    ones of the near rows that work — fall on all eight XCDs (workgroup b runs on XCD b % 8) evenly."""
+    from collections import Counter
+    for splits in range(1, 9):
+        g = min(splits & -splits, 8)
+        for groups in (1, 7, 64, 196, 200):
+            seen, per_xcd = set(), {ns: Counter() for ns in range(1, splits + 1)}
+            for b in range(groups * splits):
+                gi, si = divmod(b, splits)
+                bx, by = groups - 1 - gi, (si + ((gi * g) >> 3) % g) % splits
+                assert 0 <= bx < groups and 0 <= by < splits
+                seen.add((bx, by))
+                for ns in range(by + 1, splits + 1):
+                    per_xcd[ns][b % 8] += 1
+            assert len(seen) == groups * splits
+            if groups >= 64:
+                for ns, cnt in per_xcd.items():
+                    v = [cnt[x] for x in range(8)]
+                    assert max(v) - min(v) <= max(2, max(v) // 10), (splits, groups, ns, v)
