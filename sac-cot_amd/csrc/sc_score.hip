@@ -691,9 +691,12 @@ FilterPlan filter_plan(int n, uint32_t ld_local, const Tuning& tn, uint32_t mode
     // set-up (C4: 112 / 127 / 138 / 150 us at 1 / 3 / 5 / 8 splits).  So: the fewest splits that keep a far workgroup's walk —
     // ~4.2 us per unit — under half of what the whole launch should take if 15 % of the rows are far and a fifth of the
     // correspondences near (0.32 units' worth per group and unit, over 512 resident workgroups), and never below 4 units.
-    // C2 5 splits (4 units), C3 5 (16), C4 2 (10).  (Empty workgroups cost nothing: tools/ubench/dispatch_rate.hip, 0.25 ns apiece.)
+    // C2 5 splits (4 units), C3 4 (20), C4 1 (20).  (Empty workgroups cost nothing: tools/ubench/dispatch_rate.hip, 0.25 ns apiece.)
     const uint32_t units = fp.windows * (uint32_t)(FX_WIN / GX_UNIT);
-    const double launch_units = 0.5 * (double)groups * 0.32 * (double)units / 512.0;  // half the launch, in units of one workgroup's walk
+    // r04c: + 2.5 units' worth of set-up per workgroup in the launch's length, and 0.6 of it instead of half — C4 (1954 row blocks of
+    // 20 units) is a launch of ~34 units, most of it the near workgroups' fixed cost; its far workgroups' 20 units fit in it whole:
+    // 1 split 98 us, 2 splits 108, 3 108, 4 112, 8 131 (C3: 1 167, 3 149, 4 133, 5 131, 8 130 — it takes 4 now; C2 unchanged: 5)
+    const double launch_units = 0.6 * (double)groups * (2.5 + 0.32 * (double)units) / 512.0;  // 0.6 of the launch, in units of one workgroup's walk
     const uint32_t walk = launch_units < 4.0 ? 4u : (uint32_t)launch_units;
     uint32_t sp = tn.filter_splits ? tn.filter_splits : (units + walk - 1) / walk;
     sp = sp < 1u ? 1u : (sp > 8u ? 8u : sp);
