@@ -732,7 +732,10 @@ void launch_tri_count_events(const Graph& g, const uint64_t* mbits, const Strong
   if (E == 0) return;
   // lanes per edge: a lane walks (W - j / 64) / TG words one dependent round after the other, so wide rows want wide
   // groups (Tuning::tg_events forces one; measured r02: see DESIGN.md)
-  int tg = tn.tg_events ? tn.tg_events : (g.W <= 128 ? 8 : (g.W <= 512 ? 16 : 32));
+  // r04c, on the pruned graph (a third of the triangles of r03's: shorter walks, more edges per wave pay): 4 lanes between 65 and 128
+  // words — C2 (79): stage B's bracket 101.5 -> 99.4 us in eight alternating pairs of runs, C4 (79): 138.6 vs 138.5 — but not
+  // below: C1 (32 words) 68.3 -> 69.7 us with 4
+  int tg = tn.tg_events ? tn.tg_events : (g.W <= 64 ? 8 : (g.W <= 128 ? 4 : (g.W <= 512 ? 16 : 32)));
   const uint64_t per = 256 / tg;
   // the strong edges are a fraction of E that only the device knows (20 - 45 % on C1 .. C4): size the grid for ~E/3
   uint64_t nb = (E / 3 + per - 1) / per;
