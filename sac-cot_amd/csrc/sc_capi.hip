@@ -121,7 +121,11 @@ struct sc_ctx {
   bool est_allowed = false;  // the running call came in through an entry point that can repeat it
   bool est_active = false;   // ... and prunes by an estimate
   bool est_void = false;     // ... which could not be verified on the path taken (event overflow): repeat
-  bool est_failed = false;   // sticky: an estimate failed on this context — it certifies from now on (sc_set_debug resets)
+  bool est_failed = false;   // an estimate failed on this context: it certifies for the next est_holdoff completed calls (sc_set_debug resets)
+  // r04c: not for ever.  One frame whose estimate fails — a change of scene — used to cost the context its estimating sample (25 us per
+  // C2 call) for the rest of its life; now the k-th failure costs 64 << min(k - 1, 6) certifying calls, then the context estimates
+  // again: a stream whose estimates always fail wastes one repeated call in 4096.
+  uint32_t est_holdoff = 0, est_failures = 0;
   int est_state = 0;         // last pass: 0 certified bound (or no pruning), 1 estimated and verified
   bool est_failed_call = false;  // the running / last call saw its estimate fail and was repeated (sc_debug_last: prune_bound 2)
   SamplePlan plan{false, 1u, 0};
@@ -963,7 +967,7 @@ const char* sc_last_error(const sc_ctx* c) { return c ? c->last_error.c_str() : 
 
 int sc_set_debug(sc_ctx* c, const sc_debug* d) {
   if (!c) return SC_EINVAL;
-  if (!d) { c->tn = Tuning(); c->fast_ok = false; c->est_failed = false; return SC_OK; }
+  if (!d) { c->tn = Tuning(); c->fast_ok = false; c->est_failed = false; c->est_holdoff = 0; c->est_failures = 0; return SC_OK; }
   if (d->size != sizeof(sc_debug)) return SC_EINVAL;
   auto tg_ok = [](uint32_t t) { return t == 0 || t == 4 || t == 8 || t == 16 || t == 32 || t == 64; };
   if (!tg_ok(d->tg_count) || !tg_ok(d->tg_keys) || !tg_ok(d->tg_sample) || !tg_ok(d->tg_events)) return SC_EINVAL;
@@ -1017,7 +1021,7 @@ int sc_set_debug(sc_ctx* c, const sc_debug* d) {
   t.est_margin_pct = d->est_margin_pct;
   c->tn = t;
   c->fast_ok = false;  // (the next call waits: its launch geometry may differ from the last call's)
-  c->est_failed = false;
+  c->est_failed = false; c->est_holdoff = 0; c->est_failures = 0;
   return SC_OK;
 }
 
@@ -1469,6 +1473,7 @@ void note_completed(sc_ctx* c, bool regular) {
   c->fast_ok = regular && !c->sharded_ab && c->E >= 4096 && c->T_eff == c->params.max_triangles;  // (stages A and B whole on this GPU: one rank, or replicated ranks)
   c->E_last = c->E; c->M_last = c->M; c->last_n = c->n;
   c->last_p = c->params;
+  if (c->est_failed && !c->est_failed_call && c->est_holdoff != 0 && --c->est_holdoff == 0) c->est_failed = false;  // (the repeat itself does not count)
   c->mx_last = __atomic_load_n(&c->pinned[13], __ATOMIC_ACQUIRE);  // (the call is complete: its staging kernel's words have arrived)
   for (int k = 0; k < 6; k++) c->box_last[k] = *const_cast<volatile uint64_t*>(&c->pinned[16 + k]);
   // room for the event list of a call like this one: an event holds >= 1 triangle, so 2 M records can only overflow a region
@@ -1529,7 +1534,9 @@ int finalize_wait(sc_ctx* c, sc_stats* stats) {
       return SC_EBOUND;
     }
     c->last_error = "estimated pruning bound too high: call repeated with a certifying sample";
-    c->est_failed = true;  // this context certifies from now on
+    c->est_failed = true;  // this context certifies for a while (note_completed counts the hold-off down)
+    c->est_failures++;
+    c->est_holdoff = 64u << (c->est_failures - 1 < 6 ? c->est_failures - 1 : 6);
     c->est_failed_call = true;
     c->fast_ok = false;
     return SC_ESPEC;

@@ -48,7 +48,7 @@ def test_estimated_bound_is_verified_and_changes_nothing_but_the_work(pkg, O, na
 def test_estimate_that_is_too_high_is_caught_and_the_call_repeated(pkg, name):
     """est_margin_pct = 1 aims the bound at the key of rank T / 100: the pruned graph then holds far fewer than T triangles
     above it, the select reports the shortfall, the call is repeated with a certifying sample — same outputs — and the
-    context certifies from then on."""
+    context certifies for a while (64 calls after the first failure, twice as many after each further one)."""
     import torch
     dev = torch.device("cuda:0")
     cfg, scene = pkg.synth.make_config_scene(name)
@@ -61,8 +61,16 @@ def test_estimate_that_is_too_high_is_caught_and_the_call_repeated(pkg, name):
         got = r.register(scene.src, scene.tgt, **cfg.params())
         assert r.debug_last()["prune_bound"] == 2, r.debug_last()
         assert _same(got, ref) and got["stats"]["tri_total"] == ref["stats"]["tri_total"]
-        nxt = r.register(scene.src, scene.tgt, **cfg.params())          # sticky: no second failure on this context
+        nxt = r.register(scene.src, scene.tgt, **cfg.params())          # held off: no second failure right away
         assert r.debug_last()["prune_bound"] == 0 and _same(nxt, ref)
+        if name == "C1":
+            # r04c: ... but not for ever.  The first failure costs 64 certifying calls; then the context estimates again (here the
+            # knob makes that fail again: 128 certifying calls follow, and so on up to 4096)
+            seen = [0]
+            for _ in range(63 + 1 + 128 + 1):
+                r.register(scene.src, scene.tgt, **cfg.params())
+                seen.append(r.debug_last()["prune_bound"])
+            assert seen[:64] == [0] * 64 and seen[64] == 2 and seen[65:193] == [0] * 128 and seen[193] == 2, seen
         # the same through the host-free form: a good call, then the knob makes the REPEATED shape's estimate fail
         r.set_debug()                                                   # (also forgets the failure)
         ds = torch.from_numpy(scene.src).to(dev); dt = torch.from_numpy(scene.tgt).to(dev)
