@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Soak: one context (two for the bursts), thousands of calls over alternating problem sizes and six forms of the call — the two phase-1 forms of
+"""Soak: one context (two for the bursts), thousands of calls over alternating problem sizes and six forms of the call (seven with the rings of overlapping frames, r04c) — the two phase-1 forms of
 the phase API (certified pruning bound, host waits in the middle) and sc_register_device (r04: estimated bound, fused edge
 kernel, host-free enqueue of a repeated shape); every result must be byte-identical to the first one of its configuration
 (tickets, polled read-backs, speculative launches and the validate-and-repeat paths are exercised on buffers left over from
@@ -39,9 +39,39 @@ with torch.cuda.stream(stream):
     d_key = torch.zeros(2, dtype=torch.int64, device=dev)
     d_hist = torch.zeros(pkg.SC_HIST_WORDS, dtype=torch.int32, device=dev)
     d_Rt = torch.zeros(12, dtype=torch.float32, device=dev)
+    # form 6 (r04c): frames OVERLAPPING on the GPU — a ring of three contexts, each on a stream of its own
+    ring = [pkg.Registrar(0) for _ in range(3)]
+    ring_streams = [torch.cuda.Stream(device=dev) for _ in range(3)]
+    for g_, s_ in zip(ring, ring_streams):
+        g_.set_stream(s_.cuda_stream)
+    ring_Rt = [torch.zeros(12, dtype=torch.float32, device=dev) for _ in range(3)]
+    overlapped = 0
     while time.time() - t0 < budget:
         name, n, kw, s, t = cases[int(rng.integers(len(cases)))]
-        form = int(rng.integers(6))   # 0 hypothesize + finalize, 1 its split-sample form, 2 sc_register_device, 3 form 0 with SC_FLAG_EST_BOUND (r04b), 4 / 5 bursts (r04c)
+        form = int(rng.integers(7))
+        if form == 6:
+            stream.synchronize()   # (the inputs were uploaded on `stream`; the ring's streams do not wait for it)
+            nb = int(rng.integers(3, 10))
+            pb = pkg.make_params(**kw)
+            rmask = [torch.zeros(n, dtype=torch.uint8, device=dev) for _ in range(3)]
+            for k in range(nb + 2):
+                if k < nb:
+                    i = k % 3
+                    ring[i].register_device_async(s.data_ptr(), t.data_ptr(), n, pb, ring_Rt[i].data_ptr(), rmask[i].data_ptr())
+                if k >= 2:
+                    i = (k - 2) % 3
+                    rc, st = ring[i].wait()
+                    ring_streams[i].synchronize()
+                    sig = (rc, st["edges"], st["tri_kept"], st["best_rank"], st["best_count"],
+                           ring_Rt[i].cpu().numpy().tobytes(), rmask[i].cpu().numpy().tobytes())
+                    if name not in first:
+                        first[name] = sig
+                    elif first[name] != sig:
+                        mism += 1
+                        print("MISMATCH", name, "overlapped frames", k - 2, sig[:5], "vs", first[name][:5], flush=True)
+                    calls += 1
+            overlapped += 1
+            continue   # 0 hypothesize + finalize, 1 its split-sample form, 2 sc_register_device, 3 form 0 with SC_FLAG_EST_BOUND (r04b), 4 / 5 bursts (r04c)
         if form >= 4:
             # a burst of frames as a stream: 4 = sc_register_device_async, 5 = hypothesize (estimated bound: host-free from its
             # context's second frame on) + finalize in two halves; every frame must equal the configuration's first result
@@ -105,5 +135,5 @@ with torch.cuda.stream(stream):
             print(f"{calls} calls, {mism} mismatches, {time.time() - t0:.0f} s", flush=True)
 print(f"soak: {calls} calls over {len(first)} configurations in {time.time() - t0:.0f} s, {mism} mismatches; "
       f"sc_register_device calls: {forms[0]} waited, {forms[1]} host-free, {forms[2]} host-free and repeated; {bursts[0]} bursts of streamed frames "
-      f"({bursts[1]} frames came back SC_EBOUND and were repeated)")
+      f"({bursts[1]} frames came back SC_EBOUND and were repeated); {overlapped} rings of frames overlapping on three streams")
 sys.exit(1 if mism else 0)
