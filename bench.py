@@ -21,10 +21,15 @@ strong` is BASELINE configs[3] as specified (200k triangles over 8 GPUs) and C4 
 
 `value` = hypotheses scored per second by the whole job = T_total * K / wall time of the K timed steps (barrier +
 synchronize on both sides, MAX over ranks): the end-to-end rate, stages A, B and the mask included.
-The K steps are a STREAM of frames (--frames-in-flight 2, r04c; one rank, or ranks that replicate stages A and B): step k + 1 is
-enqueued before the host waits for step k's winner, the way a registration pipeline feeds the library; every step runs every kernel
-on the inputs and delivers its winner, statistics, (R, t) and mask like any other call.  The form of rounds 1 - 3 (a step begins when the previous winner has reached the
-host: ~19 us of idle GPU per step) is timed right after it over the same number of steps and reported as `waited`.
+The K steps are a STREAM of DISTINCT frames (r05: --scenes 32 device-resident scenes of the config's shape whose inlier ratio —
+hence edge and triangle counts — differs from frame to frame; frame f registers scene f mod 32) and --frames-in-flight 2 (r04c; one
+rank, or ranks that replicate stages A and B): step k + 1 is enqueued before the host waits for step k's winner, the way a
+registration pipeline feeds the library; every step runs every kernel on its inputs and delivers its winner, statistics, (R, t) and
+mask like any other call, and every frame's outputs are compared with the waited form's and (checker leg) with the CPU restatement
+of its scene.  `how_the_timed_frames_ran` counts the frames the library had to repeat inside the timed region.  The form of rounds
+1 - 3 (a step begins when the previous winner has reached the host: ~19 us of idle GPU per step) is timed right after it over the
+same frames and reported as `waited`; round 4's headline form (one scene repeated) as `stream_identical_frames`; `stream_long`
+runs the distinct stream over 256 frames for the rates of the fallbacks.
 """
 from __future__ import annotations
 
@@ -210,6 +215,10 @@ def main() -> int:
                          "sc_hypothesize_device + all-gather + sc_finalize_gathered_device_async; a second context on the same stream) before "
                          "step k's winner is waited for (sc_wait), so the GPU runs the steps back to back; 1 = every step ends with its winner "
                          "on the host before the next begins (rounds 1 - 3; still reported as `waited`).  --shard ab waits every step")
+    ap.add_argument("--scenes", type=int, default=32,
+                    help="distinct synthetic scenes of the config's shape the frames cycle through (seeds cfg.seed + k, inlier ratio drawn "
+                         "in [2/3, 4/3] of the config's: C2 0.10 .. 0.20, so edge counts move by ~1.6 x and triangle counts by ~4 x from "
+                         "frame to frame); frame f registers scene f mod SCENES.  1 = every frame the config's own scene (rounds 1 - 4)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--headline-only", action="store_true",
                     help="only the timed loop and the per-stage passes (no cold call, host-I/O, varying-N, no-dense-S or CPU "
@@ -254,7 +263,8 @@ def main() -> int:
         else:
             dist.init_process_group("nccl", device_id=dev)  # "nccl" is RCCL on ROCm
 
-    cfg, scene = pkg.synth.make_config_scene(args.config)
+    cfg, scenes = pkg.synth.make_stream_scenes(args.config, max(1, args.scenes))
+    scene, K = scenes[0], len(scenes)   # scenes[0] is the config's own scene (what the stage passes, the CPU baseline and the other legs use)
     T_total = cfg.T * world if args.scaling == "weak" else cfg.T
     kw = cfg.params()
     kw["max_triangles"] = T_total
@@ -278,8 +288,9 @@ def main() -> int:
     if knobs:
         reg.set_debug(**{k: int(v) for k, v in knobs.items()})
     reg.set_stream(torch.cuda.current_stream().cuda_stream)  # same stream as torch, so the collectives are ordered
-    d_src = torch.from_numpy(scene.src).to(dev)
-    d_tgt = torch.from_numpy(scene.tgt).to(dev)
+    d_srcs = [torch.from_numpy(sc_.src).to(dev) for sc_ in scenes]
+    d_tgts = [torch.from_numpy(sc_.tgt).to(dev) for sc_ in scenes]
+    d_src, d_tgt = d_srcs[0], d_tgts[0]
     torch.cuda.synchronize()
 
     # auto: A and B sharded too (phase API, three or four collectives per step) on graphs of 8192 correspondences and more; below,
@@ -294,8 +305,8 @@ def main() -> int:
         ss = pkg.shard.ShardedStep(pkg, reg, cfg.n, mk(pkg.SC_FLAG_TIMING_HOT), rank, world, dev)
         d_Rt, d_mask = ss.Rt, ss.mask
 
-        def step(prm):
-            return ss.step(d_src.data_ptr(), d_tgt.data_ptr(), prm)
+        def step(prm, k=0):
+            return ss.step(d_srcs[k % K].data_ptr(), d_tgts[k % K].data_ptr(), prm)
     else:
         d_key = torch.zeros(2, dtype=torch.int64, device=dev)  # winner key pair (include/saccot.h)
         d_Rt = torch.zeros(12, dtype=torch.float32, device=dev)
@@ -303,31 +314,49 @@ def main() -> int:
         d_hist = torch.zeros(pkg.SC_HIST_WORDS, dtype=torch.int32, device=dev)
         d_all = torch.zeros(2 * world, dtype=torch.int64, device=dev)  # every rank's key pair (one all-gather)
 
-        def step(prm):
+        def step(prm, k=0, g=None, Rt=None, mask=None):
+            """one frame (scene k mod K), complete on return: its winner is on the host"""
+            g = g or reg
+            Rt = d_Rt if Rt is None else Rt
+            mask = d_mask if mask is None else mask
+            ps, pt = d_srcs[k % K].data_ptr(), d_tgts[k % K].data_ptr()
             if world == 1:
                 # the drop-in entry with everything resident in HBM: sc_register_device (a repeated shape is enqueued without a
                 # host wait in the middle of the call — include/saccot.h; `fast_path` below says how the timed calls ran)
-                return reg.register_device(d_src.data_ptr(), d_tgt.data_ptr(), cfg.n, prm, d_Rt.data_ptr(), d_mask.data_ptr())
+                return g.register_device(ps, pt, cfg.n, prm, Rt.data_ptr(), mask.data_ptr())
             if split:
-                reg.hypothesize_begin_device(d_src.data_ptr(), d_tgt.data_ptr(), cfg.n, prm, d_hist.data_ptr())
+                g.hypothesize_begin_device(ps, pt, cfg.n, prm, d_hist.data_ptr())
                 pkg.shard.allreduce_hist(d_hist)
-                reg.hypothesize_end_device(d_hist.data_ptr(), d_key.data_ptr())
+                g.hypothesize_end_device(d_hist.data_ptr(), d_key.data_ptr())
                 pkg.shard.allgather_best(d_key, d_all)
-                return reg.finalize_gathered_device(d_all.data_ptr(), world, d_Rt.data_ptr(), d_mask.data_ptr())
+                return g.finalize_gathered_device(d_all.data_ptr(), world, Rt.data_ptr(), mask.data_ptr())
             # stages A and B replicated, stage B pruned by the ESTIMATED bound (SC_FLAG_EST_BOUND, r04b: what sc_register_device does
-            # on one GPU): every rank runs the same deterministic stages, so every rank gets SC_EBOUND together if the select finds the
-            # bound too high — then, and from then on, without the flag
-            for _ in range(2):
-                q = type(prm).from_buffer_copy(prm)
-                if rep_est[0]:
-                    q.flags |= pkg.SC_FLAG_EST_BOUND
-                reg.hypothesize_device(d_src.data_ptr(), d_tgt.data_ptr(), cfg.n, q, d_key.data_ptr())
+            # on one GPU): every rank runs the same deterministic stages on the same scenes in the same order, so every rank gets
+            # SC_EBOUND together — the select found the bound too high, or (a host-free call) a count outgrew what the launches
+            # covered: this frame again without the flag; estimates that FAIL twice switch the flag off for good
+            def run(q):
+                g.hypothesize_device(ps, pt, cfg.n, q, d_key.data_ptr())
                 pkg.shard.allgather_best(d_key, d_all)  # ONE collective (16 bytes per rank); the reduction runs in the kernel
-                rc, st_ = reg.finalize_gathered_device(d_all.data_ptr(), world, d_Rt.data_ptr(), d_mask.data_ptr())
-                if rc != pkg.SC_EBOUND:
-                    return rc, st_
-                rep_est[0] = False
+                return g.finalize_gathered_device(d_all.data_ptr(), world, Rt.data_ptr(), mask.data_ptr())
+
+            q = type(prm).from_buffer_copy(prm)
+            if rep_est[0]:
+                q.flags |= pkg.SC_FLAG_EST_BOUND
+            rc, st_ = run(q)
+            if rc == pkg.SC_EBOUND:     # (only with the flag)
+                note_ebound(g)
+                rc, st_ = run(prm)
             return rc, st_
+
+    est_fails = [0]
+
+    def note_ebound(g):
+        """SC_EBOUND came back: was it the ESTIMATE (sc_debug_last.prune_bound == 2) or a host-free call's cover?  (Off the fast path:
+        sc_debug_last synchronises.  Deterministic and the same on every rank: stages A and B are replicated.)"""
+        if g.debug_last()["prune_bound"] == 2:
+            est_fails[0] += 1
+            if est_fails[0] >= 2:
+                rep_est[0] = False
 
     def fence():
         torch.cuda.synchronize()
@@ -336,12 +365,13 @@ def main() -> int:
         torch.cuda.synchronize()
 
     p_hot = mk(pkg.SC_FLAG_TIMING_HOT)
-    # Warm-up.  No fallback of any kind: a failure here is the result (every rank runs the same sequence of
-    # collectives, so an exception on one rank must end the job, not change that rank's path).
-    for _ in range(args.warmup):
-        step(p_hot)
+    W = args.warmup
+    # Warm-up: the W frames BEFORE frame 0 of the cycle (scenes K - W .. K - 1), so that no timed frame repeats the frame its context
+    # saw last.  No fallback of any kind: a failure here is the result (every rank runs the same sequence of collectives, so an
+    # exception on one rank must end the job, not change that rank's path).
+    for i in range(W):
+        step(p_hot, K - W + i)
     hot_score = 0.0
-    step_s = []
     # The interpreter's cyclic garbage collector stays out of every timed region of this process: a generation-2 pass costs ~40 ms
     # here — 170 steps' worth — and landed in the varying-n leg in round 4 (20 calls: 2.4 ms per call on average, median 0.24).  Nothing the
     # timed code allocates is cyclic; what exists so far is frozen, reference counting keeps freeing the rest.
@@ -351,6 +381,25 @@ def main() -> int:
     # all-gather, sc_finalize_gathered_device_async).  The sharded form (--shard ab) and the split sample wait every step.
     pipelined = args.frames_in_flight == 2 and not sharded_ab and not split
     waited = None
+    stream_identical = None
+    stream_long = None
+    counters = None
+    # every frame's outputs in a slot of its scene's: checked against the waited form below and, in the checker leg, against the CPU
+    # restatement of every scene
+    Rt_all = torch.zeros(K, 12, dtype=torch.float32, device=dev)
+    mask_all = torch.zeros(K, cfg.n, dtype=torch.uint8, device=dev)
+    CTRS = ("n_frames", "n_fast_ok", "n_fast_repeat", "n_est_ok", "n_est_fail", "n_hostfree_grow")
+
+    def ctr_now(gs):   # (sc_debug_last synchronises: only between the timed regions)
+        return [sum(g_.debug_last()[c_] for g_ in gs) for c_ in CTRS]
+
+    def ctr_diff(a, b, extra_repeats=0):
+        d = dict(zip(CTRS, [y - x for x, y in zip(a, b)]))
+        return {"frames": d["n_frames"] - extra_repeats, "host_free": d["n_fast_ok"], "host_free_then_repeated": d["n_fast_repeat"],
+                "waited": d["n_frames"] - d["n_fast_ok"] - d["n_fast_repeat"] - extra_repeats,
+                "bound_estimated_and_verified": d["n_est_ok"], "estimate_failed_call_repeated": d["n_est_fail"],
+                "buffers_grown_inside_host_free_enqueues": d["n_hostfree_grow"]}
+
     if pipelined:
         # two contexts on ONE stream: strictly serial on the GPU, nothing overlaps on the device; the host is off the critical path
         regB = pkg.Registrar(local_rank)
@@ -358,15 +407,13 @@ def main() -> int:
             regB.set_debug(**{k: int(v) for k, v in knobs.items()})
         regB.set_stream(torch.cuda.current_stream().cuda_stream)
         pair = [reg, regB]
-        outs = [(d_Rt, d_mask), (torch.zeros(12, dtype=torch.float32, device=dev), torch.zeros(cfg.n, dtype=torch.uint8, device=dev))]
+        for i in range(max(W, 2)):   # the second context's own history: other scenes than the first one's (every rank alike)
+            rcb, _ = step(p_hot, K // 2 + i, regB)
         if world == 1:
-            for _ in range(max(args.warmup, 2)):
-                regB.register_device(d_src.data_ptr(), d_tgt.data_ptr(), cfg.n, p_hot, outs[1][0].data_ptr(), outs[1][1].data_ptr())
+            def enqueue(f, k):
+                pair[f & 1].register_device_async(d_srcs[k].data_ptr(), d_tgts[k].data_ptr(), cfg.n, p_hot, Rt_all[k].data_ptr(), mask_all[k].data_ptr())
 
-            def enqueue(k):
-                pair[k & 1].register_device_async(d_src.data_ptr(), d_tgt.data_ptr(), cfg.n, p_hot, outs[k & 1][0].data_ptr(), outs[k & 1][1].data_ptr())
-
-            def redo(k):
+            def redo(f, k):
                 raise RuntimeError("unreachable: sc_wait repeats a single-GPU call inside the library")
         else:
             keys = [d_key, torch.zeros(2, dtype=torch.int64, device=dev)]
@@ -374,84 +421,123 @@ def main() -> int:
             p_est = type(p_hot).from_buffer_copy(p_hot)
             p_est.flags |= pkg.SC_FLAG_EST_BOUND
 
-            def waited_on(g_, k_, a_, o_, prm):
-                g_.hypothesize_device(d_src.data_ptr(), d_tgt.data_ptr(), cfg.n, prm, k_.data_ptr())
-                pkg.shard.allgather_best(k_, a_)
-                return g_.finalize_gathered_device(a_.data_ptr(), world, o_[0].data_ptr(), o_[1].data_ptr())
-
-            for _ in range(max(args.warmup, 2)):   # (every rank runs the same sequence of collectives)
-                rcb, _ = waited_on(regB, keys[1], alls[1], outs[1], p_est if rep_est[0] else p_hot)
-                if rcb == pkg.SC_EBOUND:
-                    rep_est[0] = False
-
-            def enqueue(k):
-                i = k & 1
-                pair[i].hypothesize_device(d_src.data_ptr(), d_tgt.data_ptr(), cfg.n, p_est if rep_est[0] else p_hot, keys[i].data_ptr())
+            def enqueue(f, k):
+                i = f & 1
+                pair[i].hypothesize_device(d_srcs[k].data_ptr(), d_tgts[k].data_ptr(), cfg.n, p_est if rep_est[0] else p_hot, keys[i].data_ptr())
                 pkg.shard.allgather_best(keys[i], alls[i])   # ONE collective (16 bytes per rank), in stream order
-                pair[i].finalize_gathered_device_async(alls[i].data_ptr(), world, outs[i][0].data_ptr(), outs[i][1].data_ptr())
+                pair[i].finalize_gathered_device_async(alls[i].data_ptr(), world, Rt_all[k].data_ptr(), mask_all[k].data_ptr())
 
-            def redo(k):   # SC_EBOUND (every rank alike: stages A and B are replicated): this frame again, the certifying way
-                i = k & 1
-                return waited_on(pair[i], keys[i], alls[i], outs[i], p_hot)
+            def redo(f, k):   # SC_EBOUND (every rank alike: stages A and B are replicated): this frame again, the certifying way
+                i = f & 1
+                note_ebound(pair[i])
+                pair[i].hypothesize_device(d_srcs[k].data_ptr(), d_tgts[k].data_ptr(), cfg.n, p_hot, keys[i].data_ptr())
+                pkg.shard.allgather_best(keys[i], alls[i])
+                return pair[i].finalize_gathered_device(alls[i].data_ptr(), world, Rt_all[k].data_ptr(), mask_all[k].data_ptr())
 
-        winners = set()
-        n_redo = 0
-        fence()
-        t0 = time.perf_counter()
-        enqueue(0)
-        tl = t0
-        for k in range(1, args.steps + 1):
-            if k < args.steps:
-                enqueue(k)
-            rc, st = pair[(k - 1) & 1].wait()     # step k - 1: status, statistics; (R, t) and mask complete
-            if rc == pkg.SC_EBOUND:
-                rc, st = redo(k - 1)
-                n_redo += 1
-                if n_redo >= 2:
-                    rep_est[0] = False            # (this input's estimates fail: the frames enqueued from here on certify)
-            tn_ = time.perf_counter()
-            step_s.append(tn_ - tl); tl = tn_     # (winner to winner)
-            hot_score += st["us_score"]
-            winners.add((rc, st["best_rank"], st["best_count"]))
-        fence()
-        dt = time.perf_counter() - t0
-        fast_path_pair = [g_.debug_last().get("fast_path") for g_ in pair]
-        if len(winners) != 1:
-            print(f"bench.py: the frames of the stream disagree: {sorted(winners)}", file=sys.stderr)
-            return 1
-        # the waited form, same number of steps, same context and parameters
+        def run_stream(frames, scene_of, timed_hot=False):
+            """`frames` frames, frame f + 1 enqueued before frame f's winner is waited for -> (wall s, per-frame (scene, rc, rank,
+            count, edges, triangles), winner-to-winner times, frames the CALLER had to repeat, sum of us_score)"""
+            res, ts, n_redo, hot = [], [], 0, 0.0
+            fence()
+            t0 = time.perf_counter()
+            enqueue(0, scene_of(0))
+            tl = t0
+            for f in range(1, frames + 1):
+                if f < frames:
+                    enqueue(f, scene_of(f))
+                rc, st = pair[(f - 1) & 1].wait()     # frame f - 1: status, statistics; (R, t) and mask complete
+                if rc == pkg.SC_EBOUND:
+                    rc, st = redo(f - 1, scene_of(f - 1))
+                    n_redo += 1
+                tn_ = time.perf_counter()
+                ts.append(tn_ - tl); tl = tn_         # (winner to winner)
+                hot += st["us_score"]
+                res.append((scene_of(f - 1), rc, st["best_rank"], st["best_count"], st["edges"], st["tri_total"]))
+            fence()
+            return time.perf_counter() - t0, res, ts, n_redo, hot, st
+
+        c0 = ctr_now(pair)
+        dt, res, step_s, n_redo, hot_score, st = run_stream(args.steps, lambda f: f % K)
+        rc = res[-1][1]
+        c1 = ctr_now(pair)
+        counters = ctr_diff(c0, c1, n_redo)
+        counters["frames_repeated"] = counters["host_free_then_repeated"] + counters["estimate_failed_call_repeated"] if world == 1 else n_redo
+        per_scene = {}
+        for k_, rc_, rk_, cn_, _, _ in res:
+            if per_scene.setdefault(k_, (rc_, rk_, cn_)) != (rc_, rk_, cn_):
+                print(f"bench.py: two frames of scene {k_} disagree: {per_scene[k_]} vs {(rc_, rk_, cn_)}", file=sys.stderr)
+                return 1
+        got_stream = (Rt_all.cpu().numpy().copy(), mask_all.cpu().numpy().copy())
+        # ---- the waited form: the same frames, each begun only when the previous winner has reached the host
         w_s = []
         fence()
         tw0 = time.perf_counter()
-        for _ in range(args.steps):
+        for f in range(args.steps):
             ts0 = time.perf_counter()
-            rcw, stw = step(p_hot)
+            rcw, stw = step(p_hot, f % K, reg, Rt_all[f % K], mask_all[f % K])
             w_s.append(time.perf_counter() - ts0)
+            if per_scene[f % K] != (rcw, stw["best_rank"], stw["best_count"]):
+                print(f"bench.py: waited and streamed frames of scene {f % K} disagree: {(rcw, stw['best_rank'], stw['best_count'])} vs {per_scene[f % K]}", file=sys.stderr)
+                return 1
         fence()
         dtw = time.perf_counter() - tw0
-        if (rcw, stw["best_rank"], stw["best_count"]) not in winners:
-            print(f"bench.py: waited and streamed steps disagree: {(rcw, stw['best_rank'], stw['best_count'])} vs {sorted(winners)}", file=sys.stderr)
+        got_waited = (Rt_all.cpu().numpy(), mask_all.cpu().numpy())
+        seen = sorted(per_scene)
+        if not (np.array_equal(got_stream[0][seen].view(np.uint32), got_waited[0][seen].view(np.uint32)) and np.array_equal(got_stream[1][seen], got_waited[1][seen])):
+            print("bench.py: (R, t) or mask of a streamed frame differs from the waited call's", file=sys.stderr)
             return 1
         if world > 1:
             twm = torch.tensor([dtw], dtype=torch.float64, device=dev)
             dist.all_reduce(twm, op=dist.ReduceOp.MAX)
             dtw = float(twm.item())
         waited = {"ms_per_step": dtw / args.steps * 1e3, "ms_per_step_median": float(np.median(w_s)) * 1e3,
-                  "hypotheses_per_s": T_total * args.steps / dtw, "frames_repeated_in_the_stream": n_redo,
-                  "note": "the same steps, each begun only when the previous winner has reached the host (--frames-in-flight 1: "
-                          "the headline form of rounds 1 - 3)"}
+                  "hypotheses_per_s": T_total * args.steps / dtw,
+                  "note": "the same frames, each begun only when the previous winner has reached the host (--frames-in-flight 1: "
+                          "the headline form of rounds 1 - 3, there on one repeated scene)"}
+        if not args.headline_only:
+            # ---- r04's headline form beside it: every frame the SAME scene (the config's own), streamed
+            dti, resi, si, _, _, _ = run_stream(args.steps, lambda f: 0)
+            if world > 1:
+                tim = torch.tensor([dti], dtype=torch.float64, device=dev)
+                dist.all_reduce(tim, op=dist.ReduceOp.MAX)
+                dti = float(tim.item())
+            stream_identical = {"ms_per_step": dti / args.steps * 1e3, "ms_per_step_median": float(np.median(si)) * 1e3,
+                                "hypotheses_per_s": T_total * args.steps / dti,
+                                "note": "the same stream with every frame the config's own scene (round 4's headline form): the covers of "
+                                        "the host-free enqueue, the estimate and the choice of stage C2's kernel only ever see their best case there"}
+            # ---- the distinct-frame stream over many cycles of the scenes: rates of the fallbacks (repeated frames, failed estimates)
+            n_long = max(256, 8 * K) if K > 1 else 64
+            c2_ = ctr_now(pair)
+            dtl, resl, sl_, n_redo_l, _, _ = run_stream(n_long, lambda f: f % K)
+            c3_ = ctr_now(pair)
+            for k_, rc_, rk_, cn_, _, _ in resl:
+                if per_scene.setdefault(k_, (rc_, rk_, cn_)) != (rc_, rk_, cn_):
+                    print(f"bench.py: two frames of scene {k_} disagree (long stream): {per_scene[k_]} vs {(rc_, rk_, cn_)}", file=sys.stderr)
+                    return 1
+            if world > 1:
+                tlm = torch.tensor([dtl], dtype=torch.float64, device=dev)
+                dist.all_reduce(tlm, op=dist.ReduceOp.MAX)
+                dtl = float(tlm.item())
+            stream_long = {"frames": n_long, "ms_per_step": dtl / n_long * 1e3, "ms_per_step_median": float(np.median(sl_)) * 1e3,
+                           "ms_per_step_max": float(np.max(sl_)) * 1e3, "hypotheses_per_s": T_total * n_long / dtl,
+                           "how_the_frames_ran": ctr_diff(c2_, c3_, n_redo_l),
+                           "edges_min_max": [int(min(r_[4] for r_ in resl)), int(max(r_[4] for r_ in resl))],
+                           "triangles_enumerated_min_max": [int(min(r_[5] for r_ in resl)), int(max(r_[5] for r_ in resl))],
+                           "inliers_of_the_winner_min_max": [int(min(r_[3] for r_ in resl)), int(max(r_[3] for r_ in resl))]}
         regB.close()
     else:
+        step_s, per_scene = [], {}
         fence()
         t0 = time.perf_counter()
-        for _ in range(args.steps):
+        for f in range(args.steps):
             ts0 = time.perf_counter()
-            rc, st = step(p_hot)
+            rc, st = step(p_hot, f % K)
             step_s.append(time.perf_counter() - ts0)   # (every step ends with the winner on the host: its own wall time is meaningful)
             hot_score += st["us_score"]
         fence()
         dt = time.perf_counter() - t0
-    fast_path_timed = reg.debug_last().get("fast_path") if world == 1 else None
+    # (the stage passes, the CPU baseline and the legs below run the config's own scene, scenes[0]: make it the context's last call)
+    rc, st = step(p_hot, 0)
     # ---- per-stage times of THE SAME code path: one bracket per pass (SC_FLAG_TIMING_ONE: two event records per call,
     # speculative launches on), a few passes per stage; then one fully bracketed pass for the key kernel alone
     n_diag = max(3, min(8, args.steps))
@@ -574,14 +660,17 @@ def main() -> int:
             "value": value, "unit": "hypotheses/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "ms_per_step_median": float(np.median(step_s)) * 1e3,
             "ms_per_step_min_max": [round(float(np.min(step_s)) * 1e3, 4), round(float(np.max(step_s)) * 1e3, 4)],
+            "ms_of_each_timed_step": [round(float(x) * 1e3, 4) for x in step_s[:64]],
             "higher_is_better": True, "scaling": args.scaling,
             "vs_baseline": None, "dtype": "f32", "data": "synthetic" + (" (REHEARSAL: all ranks on one GPU over gloo)" if rehearsal else ""),
-            "config": {"workload": f"{cfg.name}: N={n} synthetic correspondences ({cfg.rho:.0%} inliers, L={cfg.L}, "
-                                   f"tau={cfg.tau}), T_total={T_total} ranked triangles scored per step "
-                                   f"({n_local} on this GPU)",
-                       "n_corr": n, "triangles_total": T_total, "triangles_this_gpu": n_local,
-                       "edges": st["edges"], "triangles_enumerated": st["tri_total"], "parallelism": f"{mode}{world}",
-                       "dense_S": dense},
+            "config": {"workload": f"{cfg.name}: N={n} synthetic correspondences (L={cfg.L}, tau={cfg.tau}; "
+                                   + (f"a stream of {K} DISTINCT scenes, seeds {cfg.seed} + k, inlier ratio {cfg.rho * 2 / 3:.0%} .. {cfg.rho * 4 / 3:.0%}: frame f registers scene f mod {K}"
+                                      if K > 1 else f"{cfg.rho:.0%} inliers, one scene repeated")
+                                   + f"), T_total={T_total} ranked triangles scored per step ({n_local} on this GPU)",
+                       "n_corr": n, "triangles_total": T_total, "triangles_this_gpu": n_local, "scenes": K,
+                       "edges": st["edges"], "triangles_enumerated": st["tri_total"],
+                       "edges_note": "`edges`, `triangles_enumerated`, `winner`, `stage_us`, the rooflines' counts: the config's own scene (scene 0 of the stream)",
+                       "parallelism": f"{mode}{world}", "dense_S": dense},
             "score_stage_hyp_per_s": n_local * world / ((avg["kabsch"] + avg["score"] + avg["argmax"]) * 1e-6),
             "stage_us": {k: round(v, 2) for k, v in avg.items()} | {"trikeys": round(tk, 2)},
             # the stage as a whole — triangles enumerated per second and the bytes the row asks for (bit matrix once,
@@ -598,8 +687,13 @@ def main() -> int:
             "host_gap_us": round(ms_per_step * 1e3 - sum(avg.values()), 1),
             "host_gap_note": "step minus the sum of the stage brackets (taken on waited calls): the ramps between the stages; in the waited "
                              "form also the launch of the first kernel into an idle queue, the winner's way back to the host, Python between the calls",
-            "fast_path": fast_path_pair if pipelined else fast_path_timed,
-            "step_form": ("stream of frames: step k + 1 enqueued before step k's winner is waited for ("
+            "how_the_timed_frames_ran": counters,
+            "how_the_timed_frames_ran_note": "cumulative counters of the two contexts over the timed frames (sc_debug_last): host_free = enqueued without a "
+                                             "host wait and valid at its end; host_free_then_repeated = a count outgrew what the launches covered (or "
+                                             "another assumption failed): the frame ran again the waiting way INSIDE the timed region; estimate_failed = "
+                                             "stage B's estimated pruning bound was too high: repeated with a certifying sample",
+            "stream_long": stream_long, "stream_identical_frames": stream_identical,
+            "step_form": ("stream of DISTINCT frames: step k + 1 enqueued before step k's winner is waited for ("
                           + ("sc_register_device_async" if world == 1 else "host-free sc_hypothesize_device, all-gather, sc_finalize_gathered_device_async")
                           + " / sc_wait, two contexts on one stream; serial on the GPU)") if pipelined else "waited: a step begins when the previous winner is on the host",
             "waited": waited,
@@ -683,10 +777,16 @@ def main() -> int:
                 for _ in range(20):
                     ss1.step(d_src.data_ptr(), d_tgt.data_ptr())
                 torch.cuda.synchronize(); phase_ms = (time.perf_counter() - tq0) / 20 * 1e3
-                host_io_ms = out["ms_to_best_Rt"] - (waited["ms_per_step"] if waited else ms_per_step)   # what host arrays in / out add to the device-resident (waited) step
+                for _ in range(3):
+                    step(p_hot, 0)
+                torch.cuda.synchronize(); td0 = time.perf_counter()
+                for _ in range(20):
+                    step(p_hot, 0)
+                torch.cuda.synchronize(); dev0_ms = (time.perf_counter() - td0) / 20 * 1e3   # the device-resident waited step on the same scene
+                host_io_ms = out["ms_to_best_Rt"] - dev0_ms   # what host arrays in / out add to the device-resident (waited) step
                 out["native_multi"] = {
                     "sc_register_multi_loopback1_ms": multi_ms, "sc_register_ms": out["ms_to_best_Rt"],
-                    "phase_api_world1_device_resident_ms": phase_ms, "single_device_resident_ms": (waited["ms_per_step"] if waited else ms_per_step),
+                    "phase_api_world1_device_resident_ms": phase_ms, "single_device_resident_ms": dev0_ms,
                     "orchestration_us": round((multi_ms - phase_ms - host_io_ms) * 1e3, 1),
                     "same_result": bool(gm["stats"]["best_rank"] == st["best_rank"] and np.array_equal(gm["mask"], d_mask.cpu().numpy())),
                     "note": "orchestration_us = sc_register_multi (one rank, real single-rank RCCL communicator: worker thread, "
@@ -749,6 +849,22 @@ def main() -> int:
             out["parity_vs_cpu_restatement"] = bool(
                 np.array_equal(got_mask, ref["mask"]) and st["best_rank"] == ref["best_rank"]
                 and got_Rt.tobytes() == np.concatenate([ref["R"].ravel(), ref["t"]]).astype(np.float32).tobytes())
+            if pipelined and per_scene:
+                # every scene of the stream against the CPU restatement: winner, its rank and count, (R, t) bit for bit, the mask — of the
+                # outputs the STREAMED frames left in their scenes' slots (the timed frames, the waited ones and the long stream all
+                # wrote them, and were compared with one another above)
+                sR, sM = Rt_all.cpu().numpy(), mask_all.cpu().numpy()
+                bad = []
+                for k_ in sorted(per_scene):
+                    r_ = O.register(scenes[k_].src, scenes[k_].tgt, threads=threads, **kw)
+                    same = (per_scene[k_] == (r_["rc"], r_["best_rank"], r_["best_count"]) and np.array_equal(sM[k_], r_["mask"])
+                            and sR[k_].tobytes() == np.concatenate([r_["R"].ravel(), r_["t"]]).astype(np.float32).tobytes())
+                    if not same:
+                        bad.append(k_)
+                out["stream_parity_vs_cpu_restatement"] = {"scenes_checked": len(per_scene), "scenes_that_differ": bad, "all_equal": not bad,
+                                                           "frames_behind_them": args.steps * 2 + (stream_long["frames"] if stream_long else 0)}
+                if bad:
+                    print(f"bench.py: scenes {bad} of the stream differ from the CPU restatement", file=sys.stderr)
             t1 = time.perf_counter()
             n1 = 0
             while True:                                                     # one core: a bounded sample (~5 s)

@@ -34,7 +34,7 @@ extern "C" {
 #endif
 
 #define SC_VERSION_MAJOR 0
-#define SC_VERSION_MINOR 7   /* 0.7: sc_finalize_gathered_device_async (+ sc_wait), sc_hypothesize_device with SC_FLAG_EST_BOUND host-free on a repeated shape.  0.6: SC_FLAG_EST_BOUND also on sc_hypothesize_device (SC_EBOUND from the finalize call); SC_FLAG_SHARD_AB (sc_register_multi replicates stages A and B on small graphs unless told otherwise); sc_debug / sc_debug_info grew (the Gram filter's frame and cut: saccot_debug.h).  0.5: sc_register_device_async / sc_wait (host-free enqueue), SC_FLAG_EST_BOUND / SC_EBOUND (sharded stage B pruned by an estimated bound), sc_stats.bytes_moved, the debug hooks moved to
+#define SC_VERSION_MINOR 8   /* 0.8: sc_debug_info grew cumulative counters of how a context's frames ran (saccot_debug.h); every entry refuses a context with an outstanding call; a host-free enqueue that does not fit the workspace cap runs the waited way.  0.7: sc_finalize_gathered_device_async (+ sc_wait), sc_hypothesize_device with SC_FLAG_EST_BOUND host-free on a repeated shape.  0.6: SC_FLAG_EST_BOUND also on sc_hypothesize_device (SC_EBOUND from the finalize call); SC_FLAG_SHARD_AB (sc_register_multi replicates stages A and B on small graphs unless told otherwise); sc_debug / sc_debug_info grew (the Gram filter's frame and cut: saccot_debug.h).  0.5: sc_register_device_async / sc_wait (host-free enqueue), SC_FLAG_EST_BOUND / SC_EBOUND (sharded stage B pruned by an estimated bound), sc_stats.bytes_moved, the debug hooks moved to
                                 saccot_debug.h; 0.4: sc_debug_last / sc_debug_info, sc_debug.filter_blind; 0.3: sc_set_debug (no environment variables), SC_FLAG_NO_DENSE_S, sc_shard_* (stages A and B sharded); 0.2: SC_FLAG_TIMING_HOT,
                                 SC_STREAM_DEFAULT, sc_hypothesize_begin/end_device, sc_finalize_gathered_device */
 
@@ -99,7 +99,12 @@ extern "C" {
                                 /* rank (nothing returned): repeat the call without this flag.  Results are identical either way.         */
                                 /* Also taken by sc_hypothesize_device (stages A and B replicated on every rank; NOT by the _begin / _end   */
                                 /* pair, whose shared histogram is a certifying sample's): sc_finalize_device / _gathered_device then      */
-                                /* returns SC_EBOUND when the select found the bound too high — on every rank alike.                     */
+                                /* returns SC_EBOUND when the select found the bound too high — on every rank alike (the estimate is a      */
+                                /* function of the input).  A HOST-FREE enqueue that outgrew its covers comes back as SC_EBOUND too, and     */
+                                /* whether a rank enqueues host-free, and what its launches cover, follows from the history of ITS context:  */
+                                /* ranks whose contexts have seen the same calls in the same order (bench.py's, sc_register_multi's) fail    */
+                                /* together; a caller whose ranks may differ (a context recreated or warmed up differently) must AGREE on   */
+                                /* the status before it repeats — any rank's SC_EBOUND means every rank repeats (sc_register_multi does).    */
 #define SC_FLAG_SHARD_AB 4096u /* sc_register_multi only: shard stages A and B over the devices at EVERY size.  By default it does so from   */
                                 /* 8192 correspondences on; below, every device runs stages A and B for the whole job (pruned by the      */
                                 /* estimated bound) and scores its share — one 16-byte exchange per call instead of three collectives.    */

@@ -78,6 +78,15 @@ typedef struct sc_debug_info {
   uint32_t gram_ref;          /* position (in this rank's share of the ranked list) of the hypothesis voted reference frame; 0xFFFFFFFF: none (box-centre frame) */
   uint32_t gram_ref_votes_q8; /* its soft vote count x 256 (of 64 voters) */
   float    us_c2_filter;      /* SC_FLAG_TIMING_HOT, a filtered stage C2: the FILTER kernel's own duration, from its dispatch packet's timestamps (sc_stats.us_score spans filter + exact pass); 0 otherwise */
+  /* CUMULATIVE over the context's life (r05: what a stream of frames reports — the fields above only describe the last call).
+   * A frame = one sc_register / sc_register_device(_async) call, or one sc_hypothesize_device + finalize pair: */
+  uint64_t n_frames;          /* frames that have come to their end                                                        */
+  uint64_t n_fast_ok;         /* ... enqueued host-free and valid (fast_path 1)                                              */
+  uint64_t n_fast_repeat;     /* ... enqueued host-free, void at the end (a count outgrew the cover, fewer triangles than T, event overflow, a failed estimate): repeated the waiting way (fast_path 2; SC_EBOUND on the sc_hypothesize_device path) */
+  uint64_t n_est_ok;          /* ... whose estimated pruning bound the select verified (prune_bound 1)                       */
+  uint64_t n_est_fail;        /* ... whose estimate was too high: repeated with a certifying sample (prune_bound 2)          */
+  uint64_t cover_edges, cover_triangles;  /* what the LAST call's launches covered if it was enqueued host-free (0: it waited)  */
+  uint64_t n_hostfree_grow;   /* buffers re-allocated inside host-free enqueues (each synchronises the stream: a stall in a stream of frames)  */
 } sc_debug_info;
 int         sc_debug_last(sc_ctx* ctx, sc_debug_info* out);
 

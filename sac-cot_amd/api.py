@@ -98,7 +98,9 @@ class ScDebugInfo(C.Structure):
                 ("gram_guard", C.c_uint32), ("prune_bound", C.c_uint32), ("gram_guard_worst", C.c_float),
                 ("reserved2", C.c_uint32), ("gram_near_corr", C.c_uint32), ("gram_near_hyp", C.c_uint32),
                 ("gram_rows", C.c_uint32), ("gram_ref", C.c_uint32), ("gram_ref_votes_q8", C.c_uint32),
-                ("us_c2_filter", C.c_float)]
+                ("us_c2_filter", C.c_float),
+                ("n_frames", C.c_uint64), ("n_fast_ok", C.c_uint64), ("n_fast_repeat", C.c_uint64),
+                ("n_est_ok", C.c_uint64), ("n_est_fail", C.c_uint64), ("cover_edges", C.c_uint64), ("cover_triangles", C.c_uint64), ("n_hostfree_grow", C.c_uint64)]
 
 
 class SacCotError(RuntimeError):

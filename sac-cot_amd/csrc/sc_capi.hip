@@ -105,6 +105,17 @@ struct sc_ctx {
   uint64_t E_cov = 0, M_cov = 0, E_last = 0, M_last = 0;
   int last_n = 0;
   sc_params last_p{};
+  // r05: what the covers are sized by.  A stream of DIFFERENT frames of one shape (bench.py's: 32 scenes whose inlier ratio moves the
+  // edge count by 1.6 x and the triangle count by 4 x) outgrew "the last call's counts plus half" in a frame out of six; the covers now
+  // follow the largest counts of the last HI_WINDOW .. 2 HI_WINDOW completed calls of the shape (two buckets: the current one and the one
+  // before it), so a stream pays for the spread of its frames once.  A change of shape empties the window (note_completed).
+  static constexpr uint32_t HI_WINDOW = 64, HI_YOUNG = 8;
+  uint64_t E_hi[2] = {0, 0}, M_hi[2] = {0, 0};
+  uint32_t hi_n = 0, hi_seen = 0;  // calls in the current bucket; regular calls of this shape seen so far (saturating)
+  // cumulative over the context's life (sc_debug_last): how its sc_register_device(_async) / host-free sc_hypothesize_device calls
+  // were enqueued and how stage B's pruning bound fared — what a stream of frames reports (a per-call field would only say the last)
+  uint64_t n_frames = 0, n_fast_ok = 0, n_fast_repeat = 0, n_est_ok = 0, n_est_fail = 0;
+  uint64_t n_spec_grow = 0;  // buffers re-allocated (a stream synchronisation each) inside host-free enqueues
   // the coordinate maxima and boxes the staging kernel of the last completed call published (use_filter): what a host-free call
   // picks stage C2's kernel by when it is enqueued before its own staging kernel has run — a second frame in flight on the stream
   uint64_t mx_last = ~0ull, box_last[6] = {0, 0, 0, 0, 0, 0};
@@ -169,11 +180,16 @@ int fail_hip(sc_ctx* c, hipError_t e, const char* what) {
 int ensure(sc_ctx* c, Buf& b, size_t bytes) {
   if (bytes <= b.cap) return SC_OK;
   size_t want = bytes + bytes / 8 + 256;
+  // a host-free call that has to grow a buffer stalls (the re-allocation below synchronises the stream): grow in big steps there,
+  // so that a stream whose covers are still rising pays a few of these, not one per frame; and never allocate crumbs
+  if (c->spec_on) want = 2 * bytes + 256;
+  if (want < 65536) want = 65536;
   if (c->held - b.cap + want > c->cap_bytes) {
     want = bytes;
     if (c->held - b.cap + want > c->cap_bytes) { c->last_error = "workspace cap exceeded"; return SC_ENOMEM; }
   }
   if (b.p) {
+    if (c->spec_on) c->n_spec_grow++;
     HIPCHK(c, hipStreamSynchronize(c->stream));
     HIPCHK(c, hipFree(b.p));
     c->held -= b.cap;
@@ -191,6 +207,48 @@ int ensure(sc_ctx* c, Buf& b, size_t bytes) {
     int _rc = ensure((c), (buf), (bytes));         \
     if (_rc != SC_OK) return _rc;                  \
   } while (0)
+
+// `need` bytes now, `room` bytes wanted (room for the counts of the NEXT calls of this shape: a host-free call's launches are
+// sized by a cover of the recent counts and must fit the arrays it finds — fast_plan); under a tight workspace cap: just `need`
+int ensure_room(sc_ctx* c, Buf& b, size_t need, size_t room) {
+  if (room > need && room > b.cap) {
+    const size_t want = room + room / 8 + 256;
+    if (c->held - b.cap + want <= c->cap_bytes && ensure(c, b, room) == SC_OK) return SC_OK;
+  }
+  return ensure(c, b, need);
+}
+#define ENSURE_ROOM(c, buf, need, room)                        \
+  do {                                                         \
+    int _rc = ensure_room((c), (buf), (need), (room));         \
+    if (_rc != SC_OK) return _rc;                              \
+  } while (0)
+
+// what a host-free repetition of a call's shape is sized to cover (fast_plan): the last count plus half, and the largest count of
+// the shape's recent calls plus a quarter (sc_ctx::E_hi / M_hi)
+// While the shape is young on this context (fewer than HI_YOUNG of its calls seen) the last count is doubled instead: the first
+// frames of a stream say little about the spread of the frames to come, and a miss costs a whole repeated call (bench.py's
+// stream, frames of 386 k .. 697 k edges: with "plus half" from the first frame on, one of the first twenty was repeated).
+uint64_t cover_of(uint64_t last, const uint64_t hi[2], bool young) {
+  const uint64_t h = hi[0] > hi[1] ? hi[0] : hi[1];
+  const uint64_t a = young ? 2 * last : last + last / 2, b = h + h / 4;
+  return (a > b ? a : b) + 4096;
+}
+
+// entries the edge arrays hold (what fast_plan caps a host-free call's edge cover by)
+uint64_t edge_capacity(const sc_ctx* c, bool build) {
+  uint64_t cap = c->es.cap / 4 >= 2 ? c->es.cap / 4 - 2 : 0;
+  for (const Buf* b : {&c->ei, &c->ej}) cap = b->cap / 4 < cap ? b->cap / 4 : cap;
+  if (!build) for (const Buf* b : {&c->ebi, &c->ebj}) cap = b->cap / 4 < cap ? b->cap / 4 : cap;
+  return cap;
+}
+bool same_shape(const sc_params* p, const sc_params* q);
+// entries a waited call leaves in an array indexed by one of stage B's two counts: what the host-free repetitions of its shape
+// will want to cover (the window's maxima only while the shape continues: note_completed empties it after a change)
+uint64_t room_of(const sc_ctx* c, uint64_t count, const uint64_t hi[2]) {
+  static const uint64_t none[2] = {0, 0};
+  const bool continues = c->n == c->last_n && same_shape(&c->params, &c->last_p);
+  return cover_of(count, continues ? hi : none, !continues || c->hi_seen < sc_ctx::HI_YOUNG);
+}
 
 int check_params(const sc_params* p) {
   if (!p || p->size != sizeof(sc_params)) return SC_EINVAL;
@@ -537,14 +595,30 @@ int run_edges(sc_ctx* c, const sc_params* p, uint32_t* hist, uint32_t part, uint
   if (E == 0) return SC_OK;
   // edge ids, CSR bases and the strong list are u32 (include/saccot.h, limits): a graph beyond that is refused, not wrapped
   if (E >= (1ull << 32)) { c->last_error = "the compatibility graph has 2^32 or more edges"; return SC_ETOOMANY; }
-  ENSURE(c, c->ei, E * 4);
-  ENSURE(c, c->ej, E * 4);
-  ENSURE(c, c->es, (E + 2) * 4);  // +1: the 4-way unrolled gathers of idle slots may touch index E
-  ENSURE(c, c->tcnt, E * 4);
-  if (!build) { ENSURE(c, c->ebi, E * 4); ENSURE(c, c->ebj, E * 4); }
-  ENSURE(c, c->toff, (E + 1) * 8);
-  ENSURE(c, c->scan_tmp, scan_temp_bytes(E));
-  if (E > spec_cap) {  // first call, or the graph outgrew the arrays (just re-allocated above)
+  // (a waited call leaves room for what a host-free repetition of its shape will want to cover: fast_plan caps by these arrays)
+  const uint64_t E_room = spec ? E : room_of(c, E, c->E_hi);
+  const size_t edge_arrays_before[5] = {c->ei.cap, c->ej.cap, c->es.cap, c->ebi.cap, c->ebj.cap};
+  ENSURE_ROOM(c, c->ei, E * 4, E_room * 4);
+  ENSURE_ROOM(c, c->ej, E * 4, E_room * 4);
+  ENSURE_ROOM(c, c->es, (E + 2) * 4, (E_room + 2) * 4);  // +1: the 4-way unrolled gathers of idle slots may touch index E
+  if (!build) { ENSURE_ROOM(c, c->ebi, E * 4, E_room * 4); ENSURE_ROOM(c, c->ebj, E * 4, E_room * 4); }
+  // every other array indexed by the edge count gets room for whatever the edge arrays can hold — that is what fast_plan caps a
+  // host-free call's cover by, so no such call ever has to grow one of them (a re-allocation synchronises the stream: 0.35 ms in
+  // the middle of bench.py's stream, once per array and rise of the cover)
+  const uint64_t E_hold = spec ? E : edge_capacity(c, build);
+  ENSURE_ROOM(c, c->tcnt, E * 4, E_hold * 4);
+  ENSURE_ROOM(c, c->toff, (E + 1) * 8, (E_hold + 1) * 8);
+  ENSURE_ROOM(c, c->scan_tmp, scan_temp_bytes(E), scan_temp_bytes(E_hold));
+  if (!spec) {
+    ENSURE_ROOM(c, c->strong, strong_list_bytes(E), strong_list_bytes(E_hold));
+    ENSURE_ROOM(c, c->lb_state, scan_temp_bytes(E), 2 * scan_temp_bytes(E_hold));
+  }
+  // (an array that was re-allocated above — for this call's count, or only for the ROOM the next calls want — has lost what the
+  // speculative launch wrote into it.  By CAPACITY, not by address: hipFree + hipMalloc hand the same address back often enough)
+  const size_t edge_arrays_after[5] = {c->ei.cap, c->ej.cap, c->es.cap, c->ebi.cap, c->ebj.cap};
+  bool edge_arrays_moved = false;
+  for (int k = 0; k < (build ? 3 : 5); k++) edge_arrays_moved = edge_arrays_moved || edge_arrays_before[k] != edge_arrays_after[k];
+  if (E > spec_cap || edge_arrays_moved) {  // first call, or the graph outgrew the arrays (just re-allocated above)
     if (es_hist && spec_cap && !build) HIPCHK(c, hipMemsetAsync(es_hist, 0, sizeof(uint32_t) * PR_HCOPIES * 256, st));  // the partial run's counts
     if (build && c->tn.build_sample) HIPCHK(c, hipMemsetAsync(c->ctl.as<ControlBlock>()->prune_hist, 0, sizeof(uint32_t) * PR_HCOPIES * 256, st));  // (the first run's sample)
     fill_edges(E);
@@ -592,10 +666,16 @@ int run_edges(sc_ctx* c, const sc_params* p, uint32_t* hist, uint32_t part, uint
       launch_sample_estimate(g, build ? nullptr : c->ebi.as<uint32_t>(), build ? nullptr : c->ebj.as<uint32_t>(), c->ei.as<uint32_t>(),
                              c->ej.as<uint32_t>(), c->es.as<float>(), E, 3.0f * p->t_cmp * 0.999f, c->plan.rate, ctl->prune_hist, c->tn,
                              st, E_dev, c->ebase.as<uint32_t>(), cand, cand ? ctl->ref_slot : nullptr);
-    } else
+    } else {
+      // SC_FLAG_EST_BOUND on the phase API where the plan is NOT an estimate (select window unknown: t_cmp below ~0.668; sc_debug's
+      // no_events / no_estimate / sample_mode): the caller still skips the histogram all-reduce, so every rank must end up with the
+      // SAME histogram — each takes the WHOLE certifying sample, not its share (with shares the ranks derived different
+      // bounds, cut the strong list differently, and the merged top-T could miss triangles)
+      const bool whole = est_shard;
       launch_sample_hist(g, c->ebi.as<uint32_t>(), c->ebj.as<uint32_t>(), c->ei.as<uint32_t>(), c->ej.as<uint32_t>(),
-                         c->es.as<float>(), E, p->max_triangles, 3.0f * p->t_cmp * 0.999f, part, parts,
+                         c->es.as<float>(), E, p->max_triangles, 3.0f * p->t_cmp * 0.999f, whole ? 0u : part, whole ? 1u : parts,
                          ctl->prune_hist, ctl->es_hist, es_hist != nullptr, c->tn, st, E_dev, spec ? c->E_last : 0);
+    }
     if (hist) launch_hist_reduce(ctl->prune_hist, hist, st);  // the exchanged form: one 256-bin histogram
   }
   return SC_OK;
@@ -651,7 +731,7 @@ int run_select(sc_ctx* c, const sc_params* p, const uint32_t* hist, bool want_li
   if (c->pruned) {
     ControlBlock* ctl = c->ctl.as<ControlBlock>();
     if (use_events) {  // the pruning kernel also compacts the strong edges for the counting pass
-      ENSURE(c, c->strong, strong_list_bytes(E));
+      ENSURE(c, c->strong, strong_list_bytes(E));  // (a waited call: run_edges left room)
       sl = StrongList{c->strong.as<uint32_t>(), ctl->st_fill, strong_list_cap(E), 0u};
     }
     const bool recut = c->sharded_ab && p->shard_world > 1 && use_events;
@@ -731,18 +811,27 @@ int run_select(sc_ctx* c, const sc_params* p, const uint32_t* hist, bool want_li
   if (!spec) { const int wrc = wait_word(c, 2); if (wrc) return wrc; }
   c->M_total = spec ? c->M_cov : (have_total ? c->pinned[4] : c->pinned[2]);
   const uint64_t M = c->M = spec ? c->M_cov : c->pinned[2];
-  if (M == 0) return SC_OK;
+  if (M == 0) {
+    // no triangle in the pruned graph: under a CERTIFIED bound (or none) the graph has none; an ESTIMATED bound has verified nothing
+    // (the select that checks it never runs): the call is repeated with a certifying sample (finalize_wait)
+    if (c->est_active) c->est_void = true;
+    return SC_OK;
+  }
   const uint32_t want_sel = select_want(c, p);
   const uint32_t T_eff = c->T_eff = (uint32_t)(M < want_sel ? M : want_sel);
   if (M * 12 > c->cap_bytes) { c->last_error = "triangle keys exceed the workspace cap"; return SC_ETOOMANY; }
   const size_t nb = compact_blocks(M);
-  ENSURE(c, c->wkey, M * 4);
-  ENSURE(c, c->kcol, M * 8);
+  const uint64_t M_room = spec ? M : room_of(c, M, c->M_hi);
+  const size_t key_arrays_before[2] = {c->wkey.cap, c->kcol.cap};
+  ENSURE_ROOM(c, c->wkey, M * 4, M_room * 4);
+  ENSURE_ROOM(c, c->kcol, M * 8, M_room * 8);
+  const bool key_arrays_moved = key_arrays_before[0] != c->wkey.cap || key_arrays_before[1] != c->kcol.cap;  // (re-allocated: what the speculative key pass wrote is gone)
   ENSURE(c, c->blk_minmax, 2 * 8192 * 4);
-  ENSURE(c, c->blk_gt, nb * 4);
-  ENSURE(c, c->blk_eq, nb * 4);
-  ENSURE(c, c->off_gt, (nb + 1) * 8);
-  ENSURE(c, c->off_eq, (nb + 1) * 8);
+  const size_t nb_room = compact_blocks(spec ? M : (uint64_t)(c->wkey.cap / 4 < c->kcol.cap / 8 ? c->wkey.cap / 4 : c->kcol.cap / 8));  // (whatever the key arrays can hold: fast_plan's cap)
+  ENSURE_ROOM(c, c->blk_gt, nb * 4, nb_room * 4);
+  ENSURE_ROOM(c, c->blk_eq, nb * 4, nb_room * 4);
+  ENSURE_ROOM(c, c->off_gt, (nb + 1) * 8, (nb_room + 1) * 8);
+  ENSURE_ROOM(c, c->off_eq, (nb + 1) * 8, (nb_room + 1) * 8);
   ENSURE(c, c->scan_tmp, scan_temp_bytes(nb));
   ENSURE(c, c->sel_ord, (size_t)T_eff * 8);
   ENSURE(c, c->sel_key, (size_t)T_eff * 4);
@@ -758,7 +847,7 @@ int run_select(sc_ctx* c, const sc_params* p, const uint32_t* hist, bool want_li
   }
   // weight keys of a graph whose edges all weigh >= 2/3 (0.1 % slack) lie in [2.0, 3.0]: window known a priori
   const bool fast_window = events_ok && window_known;
-  const bool keys_done = spec_cap != 0 && events_ok && M <= spec_cap;  // the speculative pass wrote every key
+  const bool keys_done = spec_cap != 0 && events_ok && M <= spec_cap && !key_arrays_moved;  // the speculative pass wrote every key
   const bool sel2 = sel2_ok && fast_window && nb <= c->tn.compact_self_max && M < (1ull << 32);
   if (hist_dirty && !keys_done && sel2) {  // the key kernel runs again, histogram included: the speculative pass's counts go
     HIPCHK(c, hipMemsetAsync(c->ctl.as<ControlBlock>()->sel_r1, 0, sizeof(uint32_t) * SEL2_COPIES * 4096, st));
@@ -860,7 +949,15 @@ float ev_us(sc_ctx* c, int a, int b) {
   return us > 0.f ? us : 0.f;
 }
 
+int busy(sc_ctx* c) {  // an sc_register_device_async / sc_finalize_gathered_device_async call is outstanding on this context
+  if (!c->pending) return SC_OK;
+  c->last_error = "a call is outstanding on this context (sc_wait first)";
+  return SC_EINVAL;
+}
+
 int host_to_planes(sc_ctx* c, const float* src, const float* tgt, int64_t n, const sc_params* p) {
+  { const int brc = busy(c); if (brc) return brc; }
+  c->spec_on = false; c->tail_done = false;  // (a host-free call that was never finalized must not leave its covers to a stage hook)
   c->build = false;  // (stage hooks: the separate kernels)
   if (!src || !tgt || n < 3 || n > (1 << 24)) return SC_EINVAL;
   ENSURE(c, c->in_src, (size_t)n * 12);
@@ -955,6 +1052,7 @@ void sc_destroy(sc_ctx* c) {
 
 int sc_set_stream(sc_ctx* c, void* hip_stream) {
   if (!c) return SC_EINVAL;
+  { const int brc = busy(c); if (brc) return brc; }
   (void)hipSetDevice(c->device);
   HIPCHK(c, hipStreamSynchronize(c->stream));
   c->ev_overhead_us = -1.f;  // event cost differs between streams: calibrate again on the next timed call
@@ -967,6 +1065,7 @@ const char* sc_last_error(const sc_ctx* c) { return c ? c->last_error.c_str() : 
 
 int sc_set_debug(sc_ctx* c, const sc_debug* d) {
   if (!c) return SC_EINVAL;
+  { const int brc = busy(c); if (brc) return brc; }
   if (!d) { c->tn = Tuning(); c->fast_ok = false; c->est_failed = false; c->est_holdoff = 0; c->est_failures = 0; return SC_OK; }
   if (d->size != sizeof(sc_debug)) return SC_EINVAL;
   auto tg_ok = [](uint32_t t) { return t == 0 || t == 4 || t == 8 || t == 16 || t == 32 || t == 64; };
@@ -1037,6 +1136,9 @@ int sc_debug_last(sc_ctx* c, sc_debug_info* out) {
   out->prune_bound = c->est_failed_call ? 2u : (uint32_t)c->est_state; out->reserved2 = 0;
   out->gram_near_corr = out->gram_near_hyp = out->gram_rows = out->gram_ref_votes_q8 = 0u; out->gram_ref = 0xFFFFFFFFu;
   out->us_c2_filter = (c->hot_ext && c->filter_on) ? ev_us_raw(c, 4, 11) : 0.f;
+  out->n_frames = c->n_frames; out->n_fast_ok = c->n_fast_ok; out->n_fast_repeat = c->n_fast_repeat;
+  out->n_est_ok = c->n_est_ok; out->n_est_fail = c->n_est_fail;
+  out->cover_edges = c->E_cov; out->cover_triangles = c->M_cov; out->n_hostfree_grow = c->n_spec_grow;
   if (c->filter_on && c->fx_state.p)
     HIPCHK(c, filter_read_counters(c->fx_state.p, c->fx_plan, c->stream, &out->filter_undecided, &out->filter_recounts));
   if (c->filter_on && c->filter_mode == 2 && c->fx_frame.p) {
@@ -1066,6 +1168,7 @@ int hyp_begin(sc_ctx* c, const float* d_src, const float* d_tgt, int64_t n, cons
   c->timed_trikeys = false;
   c->regular = false;
   c->tail_done = false;
+  if (!c->spec_on) c->E_cov = c->M_cov = 0;  // (only the entry that has just planned a host-free call leaves spec_on set)
   if (!c->est_allowed) c->est_failed_call = false;  // (an entry point that never estimates)
   if ((rc = set_timing(c, p))) return rc;
   c->refine = (p->flags & SC_FLAG_REFINE) != 0;
@@ -1299,6 +1402,7 @@ int sc_hypothesize_begin_device(sc_ctx* c, const float* d_src, const float* d_tg
 
 int sc_hypothesize_end_device(sc_ctx* c, const uint32_t* d_hist, uint64_t* d_key, sc_stats* stats) {
   if (!c || !d_hist || !d_key) return SC_EINVAL;
+  { const int brc = busy(c); if (brc) return brc; }
   if (!c->begun) { c->last_error = "sc_hypothesize_end_device without a preceding sc_hypothesize_begin_device"; return SC_EINVAL; }
   HIPCHK(c, hipSetDevice(c->device));
   return hyp_end(c, d_hist, d_key, stats);
@@ -1330,6 +1434,7 @@ int sc_shard_compat_device(sc_ctx* c, const float* d_src, const float* d_tgt, in
   if (c->pending) { c->last_error = "a call is outstanding on this context (sc_wait first)"; return SC_EINVAL; }
   HIPCHK(c, hipSetDevice(c->device));
   c->have_hyp = false; c->begun = false; c->timed_trikeys = false;
+  c->spec_on = false; c->tail_done = false;
   if ((rc = set_timing(c, p))) return rc;
   c->refine = (p->flags & SC_FLAG_REFINE) != 0;
   c->cap_bytes = p->max_workspace ? p->max_workspace : (64ull << 30);
@@ -1362,6 +1467,7 @@ int sc_shard_compat_device(sc_ctx* c, const float* d_src, const float* d_tgt, in
 
 int sc_shard_edges_device(sc_ctx* c, uint32_t* d_hist) {
   if (!c || !d_hist) return SC_EINVAL;
+  { const int brc = busy(c); if (brc) return brc; }
   if (!c->sharded_ab || c->shard_phase != 1) { c->last_error = "sc_shard_edges_device: call sc_shard_compat_device first"; return SC_EINVAL; }
   HIPCHK(c, hipSetDevice(c->device));
   const sc_params* p = &c->params;
@@ -1375,6 +1481,7 @@ int sc_shard_edges_device(sc_ctx* c, uint32_t* d_hist) {
 
 int sc_shard_select_device(sc_ctx* c, const uint32_t* d_hist, void* d_cand_mine) {
   if (!c || !d_hist || !d_cand_mine) return SC_EINVAL;
+  { const int brc = busy(c); if (brc) return brc; }
   if (!c->sharded_ab || c->shard_phase != 2) { c->last_error = "sc_shard_select_device: call sc_shard_edges_device first"; return SC_EINVAL; }
   HIPCHK(c, hipSetDevice(c->device));
   const sc_params* p = &c->params;
@@ -1397,6 +1504,7 @@ int sc_shard_select_device(sc_ctx* c, const uint32_t* d_hist, void* d_cand_mine)
 
 int sc_shard_score_device(sc_ctx* c, const void* d_cand_all, uint64_t* d_key, sc_stats* stats) {
   if (!c || !d_cand_all || !d_key) return SC_EINVAL;
+  { const int brc = busy(c); if (brc) return brc; }
   if (!c->sharded_ab || c->shard_phase != 3) { c->last_error = "sc_shard_score_device: call sc_shard_select_device first"; return SC_EINVAL; }
   HIPCHK(c, hipSetDevice(c->device));
   const sc_params* p = &c->params;
@@ -1468,9 +1576,25 @@ int finalize_enqueue(sc_ctx* c, const uint64_t* d_keys, int n_pairs, float* d_Rt
   return rec(c, 8);
 }
 
+// the parameters that make two calls "the same shape" (a host-free call repeats the last call's; timing flags aside)
+bool same_shape(const sc_params* p, const sc_params* q) {
+  constexpr uint32_t TIMING_BITS = SC_FLAG_TIMING | SC_FLAG_TIMING_HOT | SC_FLAG_TIMING_ONE | (15u << 8);
+  return p->sigma == q->sigma && p->t_cmp == q->t_cmp && p->tau == q->tau && p->min_len == q->min_len &&
+         p->max_triangles == q->max_triangles && p->rank_mode == q->rank_mode && p->layout == q->layout &&
+         p->shard_world == q->shard_world && p->shard_rank == q->shard_rank && p->shard_block == q->shard_block &&
+         p->score_mode == q->score_mode && (p->flags & ~TIMING_BITS) == (q->flags & ~TIMING_BITS);
+}
+
 // what the next call on this context may assume (fast_plan): the call that just completed was a "regular" one
 void note_completed(sc_ctx* c, bool regular) {
   c->fast_ok = regular && !c->sharded_ab && c->E >= 4096 && c->T_eff == c->params.max_triangles;  // (stages A and B whole on this GPU: one rank, or replicated ranks)
+  if (c->n != c->last_n || !same_shape(&c->params, &c->last_p)) { c->E_hi[0] = c->E_hi[1] = c->M_hi[0] = c->M_hi[1] = 0; c->hi_n = 0; c->hi_seen = 0; }
+  if (c->fast_ok) {  // (the counts of a regular call of this shape: what a host-free repetition has to cover)
+    if (c->hi_seen < 0xFFFFFFFFu) c->hi_seen++;
+    if (c->E > c->E_hi[0]) c->E_hi[0] = c->E;
+    if (c->M > c->M_hi[0]) c->M_hi[0] = c->M;
+    if (++c->hi_n >= sc_ctx::HI_WINDOW) { c->E_hi[1] = c->E_hi[0]; c->M_hi[1] = c->M_hi[0]; c->E_hi[0] = c->M_hi[0] = 0; c->hi_n = 0; }
+  }
   c->E_last = c->E; c->M_last = c->M; c->last_n = c->n;
   c->last_p = c->params;
   if (c->est_failed && !c->est_failed_call && c->est_holdoff != 0 && --c->est_holdoff == 0) c->est_failed = false;  // (the repeat itself does not count)
@@ -1487,16 +1611,17 @@ int finalize_wait(sc_ctx* c, sc_stats* stats) {
   // The finalize kernel publishes key / position / rank.  On a caller-provided stream (sc_set_stream) d_Rt and d_mask
   // are complete in stream order, like any other work the caller enqueues there; on the context's private stream —
   // which the caller cannot order against — and when the per-stage events are read below, wait for everything.
+  const bool was_spec = c->spec_on;
+  c->spec_on = false;  // (on EVERY way out of here: a timed-out wait below must not leave the covers to the next entry — ADVICE r04)
   if (c->timing || c->stream == c->own_stream) HIPCHK(c, hipStreamSynchronize(c->stream));
   else if (c->timing_one == 6) HIPCHK(c, hipEventSynchronize(c->ev[8]));  // the mask bracket ends after the kernel polled below
-  if ((rc = wait_word(c, 8))) return rc;
+  if ((rc = wait_word(c, 8))) { c->fast_ok = false; return rc; }
   HIPCHK(c, hipGetLastError());
-  if (c->spec_on) {
+  if (was_spec) {
     // Host-free call: every kernel of it has finished (the winner word is the last thing the stream writes), so the two
     // counts and the flags are final.  The launches covered E_cov edges and M_cov keys and assumed T triangles exist, an
     // event list that did not overflow and a graph big enough to prune: anything else and the outputs are void — the
     // caller (sc_wait) repeats the call the waiting way, which handles every one of these cases.
-    c->spec_on = false;
     if ((uint32_t)c->pinned[1] != 0) { c->fast_ok = false; c->last_error = "non-finite input coordinate"; return SC_EINVAL; }
     const uint64_t E = c->pinned[0], M = c->pinned[2];
     const bool ok = E != PIN_PENDING && M != PIN_PENDING && E >= 4096 && E <= c->E_cov && M <= c->M_cov &&
@@ -1584,13 +1709,7 @@ int finalize_wait(sc_ctx* c, sc_stats* stats) {
 bool fast_plan(sc_ctx* c, int64_t n, const sc_params* p) {
   if (!c->fast_ok || c->tn.no_fast || c->tn.no_events || n != c->last_n) return false;
   if (p->flags & (SC_FLAG_TIMING | SC_FLAG_EXACT_TOTAL | SC_FLAG_NO_PRUNE)) return false;
-  constexpr uint32_t TIMING_BITS = SC_FLAG_TIMING | SC_FLAG_TIMING_HOT | SC_FLAG_TIMING_ONE | (15u << 8);
-  const sc_params& q = c->last_p;
-  if (p->sigma != q.sigma || p->t_cmp != q.t_cmp || p->tau != q.tau || p->min_len != q.min_len ||
-      p->max_triangles != q.max_triangles || p->rank_mode != q.rank_mode || p->layout != q.layout ||
-      p->shard_world != q.shard_world || p->shard_rank != q.shard_rank || p->shard_block != q.shard_block || p->score_mode != q.score_mode ||
-      (p->flags & ~TIMING_BITS) != (q.flags & ~TIMING_BITS))
-    return false;
+  if (!same_shape(p, &c->last_p)) return false;
   if (!(p->rank_mode == SC_RANK_WEIGHT && 3.0f * p->t_cmp * 0.999f >= 2.0f)) return false;  // the a-priori select window
   uint64_t ecap = c->es.cap / 4 >= 2 ? c->es.cap / 4 - 2 : 0;
   for (const Buf* b : {&c->ei, &c->ej}) ecap = b->cap / 4 < ecap ? b->cap / 4 : ecap;
@@ -1599,7 +1718,9 @@ bool fast_plan(sc_ctx* c, int64_t n, const sc_params* p) {
   c->est_allowed = false;
   if (!will_build) for (const Buf* b : {&c->ebi, &c->ebj}) ecap = b->cap / 4 < ecap ? b->cap / 4 : ecap;  // (the fused edge kernel writes no per-edge bases)
   const uint64_t kcap = c->wkey.cap / 4 < c->kcol.cap / 8 ? c->wkey.cap / 4 : c->kcol.cap / 8;
-  uint64_t ecov = c->E_last + c->E_last / 2 + 4096, mcov = c->M_last + c->M_last / 2 + 4096;
+  // the last call's counts plus half, and the largest counts of the shape's recent calls plus a quarter (sc_ctx::E_hi)
+  const bool young = c->hi_seen < sc_ctx::HI_YOUNG;
+  uint64_t ecov = cover_of(c->E_last, c->E_hi, young), mcov = cover_of(c->M_last, c->M_hi, young);
   if (ecov > ecap) ecov = ecap;
   if (mcov > kcap) mcov = kcap;
   if (ecov < c->E_last || ecov < 4096 || ecov >= (1ull << 32) || mcov < c->M_last || mcov < p->max_triangles) return false;
@@ -1635,6 +1756,16 @@ int register_waited(sc_ctx* c, const float* d_src, const float* d_tgt, int64_t n
 
 extern "C" {
 
+// one more frame (a call of sc_register_device(_async) / sc_register, or sc_hypothesize_device + its finalize call) has come to its
+// end with status rc: the context's cumulative counters (sc_debug_last)
+static void count_frame(sc_ctx* c, int rc) {
+  c->n_frames++;
+  if (c->est_failed_call) c->n_est_fail++;
+  else if (c->est_state == 1 && (rc == SC_OK || rc == SC_ENOHYP)) c->n_est_ok++;
+  if (c->fast_state == 2 || (rc == SC_EBOUND && !c->est_failed_call)) c->n_fast_repeat++;  // host-free, void: repeated (here, or by the caller)
+  else if (c->fast_state == 1) c->n_fast_ok++;
+}
+
 // the finalize call of a HOST-FREE sc_hypothesize_device: a failed validation is the caller's to repeat (every rank alike)
 static int finalize_status(sc_ctx* c, int rc) {
   if (rc != SC_ESPEC) return rc;
@@ -1648,8 +1779,11 @@ int sc_finalize_gathered_device(sc_ctx* c, const uint64_t* d_keys, int n_pairs, 
   if (c->pending) { c->last_error = "a call is outstanding on this context (sc_wait first)"; return SC_EINVAL; }
   if (!c->have_hyp) { c->last_error = "sc_finalize_device without a preceding sc_hypothesize_device"; return SC_EINVAL; }
   HIPCHK(c, hipSetDevice(c->device));
-  const int rc = finalize_enqueue(c, d_keys, n_pairs, d_Rt, d_mask);
-  return rc ? rc : finalize_status(c, finalize_wait(c, stats));
+  int rc = finalize_enqueue(c, d_keys, n_pairs, d_Rt, d_mask);
+  if (rc) return rc;
+  rc = finalize_status(c, finalize_wait(c, stats));
+  count_frame(c, rc);
+  return rc;
 }
 
 int sc_finalize_gathered_device_async(sc_ctx* c, const uint64_t* d_keys, int n_pairs, float* d_Rt, uint8_t* d_mask) {
@@ -1692,9 +1826,16 @@ int sc_register_device_async(sc_ctx* c, const float* d_src, const float* d_tgt, 
     c->tail_Rt = nullptr; c->tail_mask = nullptr;
     if (!rc) rc = finalize_enqueue(c, c->key.as<uint64_t>(), 1, d_Rt, d_mask);
     SC_TICK(c, 6);
-    if (rc) { c->spec_on = false; c->fast_ok = false; return rc; }  // (a launch or allocation failed: nothing is outstanding)
-    c->pending = true; c->pend_done = false; c->pend_finalize = false;
-    return SC_OK;
+    if (!rc) {
+      c->pending = true; c->pend_done = false; c->pend_finalize = false;
+      return SC_OK;
+    }
+    // The host-free enqueue failed (an allocation sized by the COVERS hit the workspace cap, a launch failed): the waited form of
+    // the same call may well fit — "results are identical either way" (include/saccot.h) includes the status.  What was enqueued
+    // so far runs out first: its kernels publish into the pinned words the waited call is about to arm.  
+    c->spec_on = false; c->fast_ok = false;
+    (void)hipStreamSynchronize(c->stream);
+    (void)hipGetLastError();
   }
   rc = register_waited(c, d_src, d_tgt, n, p, d_Rt, d_mask, &c->pend_stats);
   if (rc != SC_OK && rc != SC_ENOHYP) return rc;
@@ -1710,6 +1851,7 @@ int sc_wait(sc_ctx* c, sc_stats* stats) {
   if (c->pend_finalize) {  // sc_finalize_gathered_device's second half
     c->pend_finalize = false;
     const int frc = finalize_status(c, finalize_wait(c, &c->pend_stats));
+    count_frame(c, frc);
     if (stats && stats->size == sizeof(sc_stats)) *stats = c->pend_stats;
     return frc;
   }
@@ -1730,6 +1872,7 @@ int sc_wait(sc_ctx* c, sc_stats* stats) {
       c->fast_state = 2;
     }
   }
+  count_frame(c, rc);
   if (stats && stats->size == sizeof(sc_stats)) *stats = c->pend_stats;
   return rc;
 }

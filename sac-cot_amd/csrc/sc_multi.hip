@@ -44,6 +44,7 @@
 #include <vector>
 
 #include "../../include/saccot.h"
+#include "../../include/saccot_debug.h"
 
 namespace {
 
@@ -141,7 +142,9 @@ struct sc_multi {
   int64_t npts = 0;
   sc_params params{};
   int cand_level = 0;  // sticky: raised whenever a call came back with SC_ERETRY (candidate blobs too small)
-  bool estimate = true;  // SC_FLAG_EST_BOUND (stage B pruned by an estimated bound, no histogram all-reduce); sticky off after SC_EBOUND
+  bool estimate = true;  // SC_FLAG_EST_BOUND (stage B pruned by an estimated bound, no histogram all-reduce); sticky off once estimates have FAILED twice
+  bool certify_once = false;  // the running call is a repeat after SC_EBOUND: without the flag, this once
+  int est_fails = 0;
   float* R = nullptr; float* t = nullptr; uint8_t* mask = nullptr;
   // pinned, device-mapped staging (portable: every device reads h_in, rank 0's finalize kernel writes h_out)
   void* h_in = nullptr; size_t h_in_cap = 0;
@@ -241,7 +244,7 @@ int run_rank(sc_multi* M, int r) {
   p.shard_cand_level = M->cand_level;
   // (only on graphs below 8192 correspondences: beyond that a replicated sample costs more than the shared certifying one — measured
   // by tools/emulate_world.py at C3, see sac-cot_amd/shard.py)
-  const bool est = M->estimate && G > 1 && n < 8192;
+  const bool est = M->estimate && !M->certify_once && G > 1 && n < 8192;
   // r04b: on those small graphs stages A and B are REPLICATED — every device runs them for the whole job, pruned by the estimated bound
   // (sc_hypothesize_device with SC_FLAG_EST_BOUND), and scores its share: ONE exchange of the 16-byte key pairs per call instead of
   // three collectives (one rank's emulated step, C2 weak / C4 strong at 8 ranks: 0.26 / 0.27 ms against 0.31 / 0.32 sharded).
@@ -510,9 +513,23 @@ int sc_register_multi(sc_multi* M, const float* src, const float* tgt, int64_t n
     run_job(M);
     // SC_ERETRY: a candidate blob was too small for this input.  Every rank sees the same blobs and reports it together;
     // bigger blobs from now on (sticky), and the call runs again.
-    bool retry = true, bound = true;
-    for (int r = 0; r < M->n; r++) { retry = retry && M->ranks[r].status == SC_ERETRY; bound = bound && M->ranks[r].status == SC_EBOUND; }
-    if (bound && M->estimate && attempt < 16) { M->estimate = false; continue; }  // the estimated bound failed: certify from now on
+    bool retry = true, bound = false;
+    for (int r = 0; r < M->n; r++) { retry = retry && M->ranks[r].status == SC_ERETRY; bound = bound || M->ranks[r].status == SC_EBOUND; }
+    // SC_EBOUND from ANY rank (a rank whose context has another history — recreated, warmed up differently — can fail
+    // the validation of a host-free enqueue alone): every rank runs the call again, without the flag this once.  Two reasons hide
+    // behind the status: the ESTIMATE was too high (the same on every rank; sc_debug_last.prune_bound == 2) — after two of those
+    // the handle certifies for good — or a host-free call's covers were outgrown, which says nothing about the next frame.
+    if (bound && !M->certify_once && attempt < 16) {
+      bool est_failed = false;
+      for (int r = 0; r < M->n; r++) {
+        sc_debug_info di; memset(&di, 0, sizeof di); di.size = sizeof di;
+        if (M->ranks[r].status == SC_EBOUND && sc_debug_last(M->ranks[r].ctx, &di) == SC_OK && di.prune_bound == 2) est_failed = true;
+      }
+      if (est_failed && ++M->est_fails >= 2) M->estimate = false;
+      M->certify_once = true;
+      continue;
+    }
+    M->certify_once = false;
     if (!retry || attempt >= 16) break;
     M->cand_level++;
   }

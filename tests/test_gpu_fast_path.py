@@ -282,3 +282,78 @@ def test_replicated_ranks_enqueue_host_free_and_finalize_in_two_halves(pkg):
         for pr in ctx:
             for g in pr:
                 g.close()
+
+
+def test_entries_refuse_a_context_with_an_outstanding_call(pkg):
+    """while a call of sc_register_device_async is outstanding EVERY entry that would start work on (or reconfigure)
+    the context answers SC_EINVAL — the stage hooks, the later halves of the phase APIs, sc_set_debug, sc_set_stream — and the
+    outstanding call is none the worse for it."""
+    import torch
+    dev = torch.device("cuda:0")
+    cfg, scene = pkg.synth.make_config_scene("C1")
+    ds, dt = _dev(torch, scene, dev)
+    p = pkg.make_params(**cfg.params())
+    r = pkg.Registrar(0)
+    try:
+        r.set_stream(torch.cuda.current_stream().cuda_stream)
+        first = _run(torch, r, ds, dt, cfg.n, p, dev)
+        d_Rt = torch.zeros(12, dtype=torch.float32, device=dev)
+        d_mask = torch.full((cfg.n,), 7, dtype=torch.uint8, device=dev)
+        d_hist = torch.zeros(pkg.SC_HIST_WORDS, dtype=torch.int32, device=dev)
+        d_key = torch.zeros(2, dtype=torch.int64, device=dev)
+        r.register_device_async(ds.data_ptr(), dt.data_ptr(), cfg.n, p, d_Rt.data_ptr(), d_mask.data_ptr())   # host-free: outstanding
+        tries = {
+            "sc_compat_host": lambda: r.compat(scene.src, scene.tgt, p, want_S=False),
+            "sc_triangles_host": lambda: r.triangles(scene.src, scene.tgt, p),
+            "sc_mask_host": lambda: r.mask(scene.src, scene.tgt, p, np.zeros(12, np.float32)),
+            "sc_hypothesize_end_device": lambda: r.hypothesize_end_device(d_hist.data_ptr(), d_key.data_ptr()),
+            "sc_hypothesize_device": lambda: r.hypothesize_device(ds.data_ptr(), dt.data_ptr(), cfg.n, p, d_key.data_ptr()),
+            "sc_shard_edges_device": lambda: r.shard_edges_device(d_hist.data_ptr()),
+            "sc_shard_select_device": lambda: r.shard_select_device(d_hist.data_ptr(), d_hist.data_ptr()),
+            "sc_shard_score_device": lambda: r.shard_score_device(d_hist.data_ptr(), d_key.data_ptr()),
+            "sc_set_debug": lambda: r.set_debug(no_fast=1),
+            "sc_set_stream": lambda: r.set_stream(None),
+            "sc_register_device_async": lambda: r.register_device_async(ds.data_ptr(), dt.data_ptr(), cfg.n, p, d_Rt.data_ptr(), d_mask.data_ptr()),
+        }
+        for name, call in tries.items():
+            with pytest.raises(pkg.SacCotError) as ei:
+                call()
+            assert ei.value.status == pkg.SC_EINVAL, (name, ei.value.status)
+        rc, st = r.wait()
+        torch.cuda.synchronize()
+        got = dict(rc=rc, st=st, Rt=d_Rt.cpu().numpy(), mask=d_mask.cpu().numpy())
+        assert r.debug_last()["fast_path"] == 1 and _same(got, first)
+        again = _run(torch, r, ds, dt, cfg.n, p, dev)   # and the context is as usable as before
+        assert _same(again, first)
+    finally:
+        r.close()
+
+
+def test_a_host_free_enqueue_that_does_not_fit_the_workspace_cap_runs_the_waited_way(pkg):
+    """the allocations of a host-free call are sized by its COVERS; under a workspace cap that only just holds the waited
+    call they fail — the call then runs the waited way and returns what that returns (SC_OK), not SC_ENOMEM."""
+    import torch
+    dev = torch.device("cuda:0")
+    cfg, scenes = pkg.synth.make_stream_scenes("C1", 3)
+    p = pkg.make_params(**cfg.params())
+    r = pkg.Registrar(0)
+    try:
+        r.set_stream(torch.cuda.current_stream().cuda_stream)
+        outs = []
+        for s in scenes:   # waited / host-free under the default cap: what the context holds afterwards is what these calls need
+            ds, dt = _dev(torch, s, dev)
+            outs.append(_run(torch, r, ds, dt, cfg.n, p, dev))
+        held = outs[-1]["st"]["workspace_bytes"]
+        big = pkg.synth.make_scene(cfg.n, cfg.rho * 1.6, cfg.L, cfg.tau, cfg.seed + 77)   # more edges than anything seen so far
+        ds, dt = _dev(torch, big, dev)
+        tight = pkg.make_params(max_workspace=held + (1 << 20), **cfg.params())
+        got = _run(torch, r, ds, dt, cfg.n, tight, dev)
+        loose = pkg.Registrar(0)
+        try:
+            loose.set_stream(torch.cuda.current_stream().cuda_stream)
+            ref = _run(torch, loose, ds, dt, cfg.n, p, dev)
+        finally:
+            loose.close()
+        assert got["rc"] == 0 and _same(got, ref), (got["rc"], got["st"], ref["st"])
+    finally:
+        r.close()

@@ -808,6 +808,33 @@ def test_sharded_with_an_estimated_bound_equals_unsharded(pkg, O, name, worlds):
             g.close()
 
 
+@pytest.mark.parametrize("knobs", [dict(), dict(sample_mode=1), dict(no_estimate=1), dict(no_events=1)])
+def test_sharded_with_the_flag_where_the_plan_is_no_estimate_still_gives_every_rank_the_same_histogram(pkg, O, knobs):
+    """SC_FLAG_EST_BOUND makes the callers skip the histogram all-reduce.  Where the plan is NOT an estimate —
+    the select window unknown (t_cmp = 0.6 < 0.668), or sc_debug asks for a certifying form — every rank used to take only ITS
+    share of the sample, derived its own bound and cut the strong list its own way.  Every rank now takes the whole certifying
+    sample: identical histograms (asserted inside the helper), results bit-identical to the single-GPU call and the oracle."""
+    import torch
+    cfg, scene = pkg.synth.make_config_scene("C1")
+    kw = dict(cfg.params(), t_cmp=0.9 if knobs else 0.6)
+    ref = O.register(scene.src, scene.tgt, threads=8, **kw)
+    dev = torch.device("cuda:0")
+    d_src = torch.from_numpy(scene.src).to(dev); d_tgt = torch.from_numpy(scene.tgt).to(dev)
+    for world in (2, 4):
+        regs = [pkg.Registrar(0) for _ in range(world)]
+        try:
+            for g in regs:
+                if knobs:
+                    g.set_debug(**knobs)
+            rc, st, Rt, mask, _ = _run_sharded_ab_once(pkg, cfg.n, dict(kw, shard_cand_level=0), d_src, d_tgt, world, flags=pkg.SC_FLAG_EST_BOUND, regs=regs)
+        finally:
+            for g in regs:
+                g.close()
+        assert rc == ref["rc"] == 0, (world, rc)
+        assert (st["best_rank"], st["best_count"], st["tri_kept"]) == (ref["best_rank"], ref["best_count"], ref["t_eff"]), world
+        assert np.array_equal(mask, ref["mask"]) and Rt.tobytes() == np.concatenate([ref["R"].ravel(), ref["t"]]).astype(np.float32).tobytes()
+
+
 @pytest.mark.parametrize("extra", [dict(rank_mode=1), dict(flags=4), dict(flags=32), dict(t_cmp=0.5), dict(max_triangles=10_000_000)])
 def test_sharded_A_and_B_other_modes(pkg, O, extra):
     """The sharded phases where the certificate does not run (degree ranking, SC_FLAG_NO_PRUNE), without the dense

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Soak: one context (two for the bursts), thousands of calls over alternating problem sizes and six forms of the call (seven with the rings of overlapping frames, r04c) — the two phase-1 forms of
+"""Soak: one context (two for the bursts), thousands of calls over alternating problem sizes and eight forms of the call (r04c: rings of overlapping frames; r05: streams of DISTINCT frames of one shape) — the two phase-1 forms of
 the phase API (certified pruning bound, host waits in the middle) and sc_register_device (r04: estimated bound, fused edge
 kernel, host-free enqueue of a repeated shape); every result must be byte-identical to the first one of its configuration
 (tickets, polled read-backs, speculative launches and the validate-and-repeat paths are exercised on buffers left over from
@@ -13,6 +13,8 @@ import torch
 import __graft_entry__ as ge
 
 pkg = ge.load_package()
+if os.environ.get("SC_SOAK_LIB"):   # (A/B of library builds: tools/r5)
+    pkg.api.LIB_PATH = os.environ["SC_SOAK_LIB"]
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
 big = "--big" in sys.argv   # also C3 and C4 (the Gram filter's cut at its largest shapes; ~1 ms per call)
 dev = torch.device("cuda", 0)
@@ -24,6 +26,13 @@ for name, T in (("C0", 200), ("C1", 10000), ("C2", 50000), ("C1", 3000), ("C2", 
     cfg, sc = pkg.synth.make_config_scene(name)
     kw = cfg.params(); kw["max_triangles"] = T
     cases.append((f"{name}/T={T}", cfg.n, kw, torch.from_numpy(sc.src).to(dev), torch.from_numpy(sc.tgt).to(dev)))
+# form 7 (r05): streams of DISTINCT frames — families of 16 scenes of one shape whose counts differ from frame to frame (synth.make_stream_scenes)
+families = []
+for name, T in (("C1", 10000), ("C2", 50000)):
+    cfg, scs = pkg.synth.make_stream_scenes(name, 16)
+    kw = cfg.params(); kw["max_triangles"] = T
+    families.append((f"{name}/T={T}", cfg.n, kw, [(torch.from_numpy(x.src).to(dev), torch.from_numpy(x.tgt).to(dev)) for x in scs]))
+distinct = [0, 0]   # streams of distinct frames, frames in them
 first = {}
 forms = [0, 0, 0]   # sc_register_device calls by sc_debug_last.fast_path: waited / host-free / host-free then repeated
 calls = mism = 0
@@ -48,7 +57,39 @@ with torch.cuda.stream(stream):
     overlapped = 0
     while time.time() - t0 < budget:
         name, n, kw, s, t = cases[int(rng.integers(len(cases)))]
-        form = int(rng.integers(7))
+        form = int(rng.integers(8))
+        if form == 7:
+            # a stream of 4 - 24 DISTINCT frames of one shape through the two contexts of the stream (what bench.py times): every frame
+            # must equal the first result of ITS scene — whatever the frames before it left in the contexts' covers and buffers
+            fam, n, kw, devs = families[int(rng.integers(len(families)))]
+            nb, k0 = int(rng.integers(4, 25)), int(rng.integers(16))
+            pb = pkg.make_params(**kw)
+            fRt = torch.zeros(nb, 12, dtype=torch.float32, device=dev)
+            fmask = torch.zeros(nb, n, dtype=torch.uint8, device=dev)
+            sts = []
+            for k in range(nb + 1):
+                if k < nb:
+                    a, b = devs[(k0 + k) % 16]
+                    pair[k & 1].register_device_async(a.data_ptr(), b.data_ptr(), n, pb, fRt[k].data_ptr(), fmask[k].data_ptr())
+                if k >= 1:
+                    sts.append(pair[(k - 1) & 1].wait())
+                    if sts[-1][0] != 0:   # (none of these scenes lacks a hypothesis: say what the context knows, while it knows it)
+                        g_ = pair[(k - 1) & 1]
+                        print("UNEXPECTED STATUS", sts[-1][0], fam, "scene", (k0 + k - 1) % 16, "frame", k - 1, sts[-1][1], g_.debug_last(),
+                              g_._lib.sc_last_error(g_._h).decode(), flush=True)
+            stream.synchronize()
+            hRt, hmask = fRt.cpu().numpy(), fmask.cpu().numpy()
+            for k, (rc, st) in enumerate(sts):
+                key = f"{fam}/scene{(k0 + k) % 16}"
+                sig = (rc, st["edges"], st["tri_kept"], st["best_rank"], st["best_count"], hRt[k].tobytes(), hmask[k].tobytes())
+                if key not in first:
+                    first[key] = sig
+                elif first[key] != sig:
+                    mism += 1
+                    print("MISMATCH", key, "stream of distinct frames", k, sig[:5], "vs", first[key][:5], flush=True)
+                calls += 1
+            distinct[0] += 1; distinct[1] += nb
+            continue
         if form == 6:
             stream.synchronize()   # (the inputs were uploaded on `stream`; the ring's streams do not wait for it)
             nb = int(rng.integers(3, 10))
@@ -135,5 +176,7 @@ with torch.cuda.stream(stream):
             print(f"{calls} calls, {mism} mismatches, {time.time() - t0:.0f} s", flush=True)
 print(f"soak: {calls} calls over {len(first)} configurations in {time.time() - t0:.0f} s, {mism} mismatches; "
       f"sc_register_device calls: {forms[0]} waited, {forms[1]} host-free, {forms[2]} host-free and repeated; {bursts[0]} bursts of streamed frames "
-      f"({bursts[1]} frames came back SC_EBOUND and were repeated); {overlapped} rings of frames overlapping on three streams")
+      f"({bursts[1]} frames came back SC_EBOUND and were repeated); {overlapped} rings of frames overlapping on three streams; "
+      f"{distinct[0]} streams of DISTINCT frames ({distinct[1]} frames; the two contexts of the stream: "
+      + ", ".join(f"{k_} {sum(g_.debug_last()[k_] for g_ in pair)}" for k_ in ("n_frames", "n_fast_ok", "n_fast_repeat", "n_est_ok", "n_est_fail")) + ")")
 sys.exit(1 if mism else 0)
