@@ -5,7 +5,7 @@
  * The library reads no environment variable (SURVEY.md §5 "config / flags"): the scheduling knobs and forced fallbacks
  * live in the per-context struct below.  None of them can change a result — only launch geometry, or which of two
  * bit-identical code paths runs.  (Timing-only ablation bodies of the C2 filters, which DO return wrong counts, exist only
- * in a library built with -DSC_ABLATIONS: the default build rejects their filter_variant values with SC_EINVAL.)
+ * in a library built with -DSC_ABLATIONS, whose sc_debug has a field more: the product's struct has no slot for them.)
  */
 #ifndef SACCOT_DEBUG_H
 #define SACCOT_DEBUG_H
@@ -16,46 +16,44 @@
 extern "C" {
 #endif
 
-/* 0 = default everywhere (-1 for the two *_self_max fields).  sc_set_debug(ctx, NULL) restores the defaults. */
+/* 0 = default everywhere (-1 for the two *_self_max fields).  sc_set_debug(ctx, NULL) restores the defaults.
+ * Every knob selects between code paths that return IDENTICAL results (a launch geometry, a fallback the library would take by
+ * itself on other inputs, a forced failure of a speculation that is then repeated); each has a parity test that sets it.  The knobs
+ * of round 4's measured-and-slower variants (one-launch select, one-launch compaction, winner step inside the arg-max launch, the
+ * sample inside the edge kernel, the lane = correspondence scoring kernel, the weight histogram's own launch) left with their code
+ * in round 5. */
 typedef struct sc_debug {
   uint32_t size;              /* = sizeof(sc_debug)                                                          */
   uint32_t no_events;         /* 1: stage B walks the bit rows twice instead of recording an event list       */
   uint64_t event_cap;         /* event records per call (>= 256): forces the overflow fallback when too small  */
   int64_t  compact_self_max;  /* key tiles up to which the compaction sums the tile counts itself (-1: 4096)  */
   int64_t  scan_self_max;     /* scan tiles up to which the down-sweep sums the block sums itself (-1: 4096)  */
-  uint32_t cnt_blocks, keys_blocks, sel_blocks;   /* grid sizes of the counting / key / select kernels        */
-  uint32_t tg_count, tg_keys, tg_sample;          /* lanes per edge: 4, 8 (default), 16, 32 (64: keys, sample)*/
-  uint64_t sample_edges;      /* edges in stage B's pruning sample (default ~5T/8, at least 32768)            */
+  uint32_t grid_blocks[4];    /* grid sizes (0 = automatic): [0] counting pass, [1] key kernel, [2] select rounds, [3] heaviest-edge sample */
+  uint32_t lanes_per_edge[4]; /* 4, 8, 16, 32, 64 (0 = default): [0] row-walking count (no 64), [1] row-walking keys, [2] certifying sample, [3] event-recording count */
+  uint64_t sample_edges;      /* edges in stage B's certifying pruning sample (default ~5T/8, at least 32768)   */
   uint32_t score_split;       /* share (of 256) of the hypotheses scored by the f32-MFMA body of C2 */
   uint32_t compat_one_phase;  /* 1: stage A runs the exact chain on every pair of an interior tile            */
   uint32_t compat_rows;       /* stage A tile height: 0 = by size (16 rows below 10 000 correspondences, 32 from there), 16, 32, 64 */
   uint32_t compat_store_mode; /* stage A stores of S: 0 = by size; bit 0 = 4 bytes per lane, bit 2 = 16 bytes, bit 1 = non-temporal */
-  uint32_t tg_events;         /* lanes per edge of the event-recording counting pass: 4 .. 64 (default: by row width) */
+  uint32_t compat_linear_order; /* 1: stage A's 64 x 64 blocks in index order instead of the XCD-aware order   */
   uint32_t sample_mode;       /* stage B's pruning sample: 0 = chosen by entry point and size (an estimating sample where the call can be repeated, else one of the two certifying ones), 1 = every stride-th edge, 2 = the heaviest edges (1, 2: certifying) */
-  uint32_t sample_blocks;     /* grid size of the heaviest-edge sample (0 = one block per 256 edges)              */
-  uint32_t compact_fused;     /* 1: compaction in one launch (look-back over the tiles) instead of count + write    */
   uint32_t rows_unfused;      /* 1: row statistics and the scans of the row counts as separate launches             */
-  uint32_t score_scalar;      /* 1: stage C2 counts inliers with the lane = correspondence kernel (measured slower)  */
+  uint32_t no_edge_build;     /* 1: row statistics and edge list as two launches instead of the hot path's one (launch_edge_build) */
+  uint32_t no_estimate;       /* 1: stage B never prunes by an ESTIMATED bound (verified by the select, call repeated when it was too high) — always by a certifying sample, as every entry point other than sc_register / sc_register_device(_async) does anyway */
+  uint32_t est_margin_pct;    /* the estimated bound aims at the key of rank (pct / 100) x T (0 = by T and rate, 115 .. 200); a small value forces the failure-and-repeat path (tests) */
+  uint32_t no_fast;           /* 1: sc_register_device always waits for stage B's two counts in the middle of the call (the form every other entry point uses) instead of enqueueing the whole chain of a repeated shape host-free */
   uint32_t score_filter;      /* stage C2, inlier count: 0 = by size and scale (plain fp32 kernel for small calls; for large ones a matrix-pipe filter + exact fix-up: the Gram filter — in the frame of a voted reference hypothesis, with its triangle-inequality cut — wherever its shells fit inside tau^2, else the linear one); 1 = always plain; 2 = always the linear filter; 3 = always the Gram filter */
   uint32_t filter_splits;     /* grid.y of the filter kernel (0 = by size)                                            */
   uint32_t filter_queue_cap;  /* entries of the filter's queue of undecided tests (0 = by size): a small one forces the recount path */
   uint32_t filter_lds_queue;  /* entries of a wave's own queue, 64 .. 256 (0 = 256)                                   */
-  uint32_t es_hist_unfused;   /* 1: stage B's edge-weight histogram by a launch of its own instead of inside edge_fill  */
-  uint32_t filter_variant;    /* body of the filter kernel: 0 = default, 1 .. 3 = bit-identical scheduling variants; the timing-only ablations (>= 16, wrong counts) only in a -DSC_ABLATIONS build (SC_EINVAL otherwise) */
-  uint32_t gram_kappa_q4;     /* the Gram filter's cut: a hypothesis counts as NEAR the call's reference frame while its reach stays under (value / 16) x tau; 0 = 8 tau (default), 1 = practically no cut (every workgroup walks every correspondence).  (Slot of the persistent-form knob of round 4, whose code is gone.) */
   uint32_t filter_blind;      /* 1: the host picks stage C2's kernel as if the coordinate maxima had not arrived yet (it then assumes the filter applies; the filter's own range test sends what it cannot bound to the exact recount) */
-  uint32_t no_fast;           /* 1: sc_register_device always waits for stage B's two counts in the middle of the call (the form every other entry point uses) instead of enqueueing the whole chain of a repeated shape host-free */
-  uint32_t gram_guard_fail;   /* 1: the run-time probe of the matrix pipe's accumulation model reports a violation (tests: the Gram filter must then never be chosen) */
-  uint32_t tail_fused;        /* 1: sc_register / sc_register_device let the arg-max launch's last workgroup do the winner / mask step (C3, rank index, (R, t)) instead of a launch of its own.  Built, bit-exact, SLOWER (one workgroup's dependent load rounds: the arg-max launch 8.6 -> 33 us at C2 against 6.4 us for finalize_kernel): off by default */
-  uint32_t no_estimate;       /* 1: stage B never prunes by an ESTIMATED bound (verified by the select, call repeated when it was too high) — always by a certifying sample, as every entry point other than sc_register / sc_register_device(_async) does anyway */
-  uint32_t est_margin_pct;    /* the estimated bound aims at the key of rank (pct / 100) x T (0 = 200); a small value forces the failure-and-repeat path (tests) */
-  uint32_t no_edge_build;     /* 1: row statistics, edge list and the estimating sample as three launches instead of the hot path's one (launch_edge_build) */
-  uint32_t build_sample;      /* 1: the fused edge kernel also takes the estimating sample (instead of a launch of its own) */
-  uint32_t reserved[1];       /* development hook (a kernel under study stops early: WRONG results); leave 0 */
-  uint32_t select_final;      /* 1: the select as ONE launch after a key kernel that also takes round 1's histogram, instead of round 1 + round 2 + per-tile count (built, bit-exact, measured no faster: off by default) */
-  uint32_t pad_;              /* compat_linear_order: 1 = stage A's 64 x 64 blocks in index order instead of the XCD-aware order */
+  uint32_t gram_kappa_q4;     /* the Gram filter's cut: a hypothesis counts as NEAR the call's reference frame while its reach stays under (value / 16) x tau; 0 = 8 tau (default), 1 = practically no cut (every workgroup walks every correspondence) */
   uint32_t gram_ref_late;     /* 1: the Gram filter's reference frame is voted after the selection, in a launch of its own (what every path but sc_register / sc_register_device does anyway), instead of by an extra workgroup of stage B's counting pass among the estimating sample's best triangles */
-  uint32_t pad2_;
+  uint32_t gram_guard_fail;   /* 1: the run-time probe of the matrix pipe's accumulation model reports a violation (tests: the Gram filter must then never be chosen) */
+#ifdef SC_ABLATIONS           /* lab builds only (sac-cot_amd/build.py --ablations): NOT in the product's struct */
+  uint32_t filter_variant;    /* body of the filter kernel: 1 .. 3 = bit-identical scheduling variants; >= 16 = timing-only ablations that return WRONG counts */
+  uint32_t lab_pad_;
+#endif
 } sc_debug;
 int         sc_set_debug(sc_ctx* ctx, const sc_debug* dbg);
 

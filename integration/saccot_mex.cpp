@@ -1,8 +1,11 @@
 // saccot_mex.cpp — MATLAB mex gateway for libsaccot.so.
 //
-// UNTESTED: MATLAB / Octave / mex are not installed in the build image, and the upstream repository ships no MATLAB
-// code to plug it into (/root/reference/README.md:1-2 is the whole tree).  It is the binding BASELINE.json's north star
-// describes ("MATLAB/C++ mex calling HIP through a thin C-ABI layer").
+// NEVER RUN UNDER MATLAB: MATLAB / Octave / mex are not installed in the build image, and the upstream repository ships no
+// MATLAB code to plug it into (/root/reference/README.md:1-2 is the whole tree).  What IS tested: it compiles with
+// -Wall -Wextra -Werror against a declarations-only mex.h in the CPU suite (tests/test_abi.py), and its mexFunction is run
+// on the GPU under a stand-in runtime — column-major arrays, parameter struct, logical mask — and compared with the CPU
+// restatement (tests/test_gpu_cabi_example.py, tests/mex_stub/).  It is the binding BASELINE.json's north star describes
+// ("MATLAB/C++ mex calling HIP through a thin C-ABI layer").
 //   build:  mex saccot_mex.cpp -I../include -L../sac-cot_amd -lsaccot
 //   use:    [R, t, inl] = saccot_mex(single(src), single(tgt), struct('sigma',0.1,'t_cmp',0.9,'tau',0.1,'min_len',0.1,'T',50000));
 //           src, tgt: N x 3 single (column-major = SC_SOA); R 3x3, t 3x1, inl N x 1 logical;  q ~ R p + t

@@ -73,21 +73,27 @@ class ScShardPlan(C.Structure):
 
 
 class ScDebug(C.Structure):
-    """Mirror of `sc_debug` (include/saccot_debug.h): test / tuning hook, 0 = default (-1 for the *_self_max fields)."""
+    """Mirror of `sc_debug` (include/saccot_debug.h): test / tuning hook, 0 = default (-1 for the *_self_max fields).  The two
+    arrays are set through the names of their slots (`_ALIASES`): set_debug(tg_count=4, cnt_blocks=37)."""
     _fields_ = [("size", C.c_uint32), ("no_events", C.c_uint32), ("event_cap", C.c_uint64),
                 ("compact_self_max", C.c_int64), ("scan_self_max", C.c_int64),
-                ("cnt_blocks", C.c_uint32), ("keys_blocks", C.c_uint32), ("sel_blocks", C.c_uint32),
-                ("tg_count", C.c_uint32), ("tg_keys", C.c_uint32), ("tg_sample", C.c_uint32),
+                ("grid_blocks", C.c_uint32 * 4), ("lanes_per_edge", C.c_uint32 * 4),
                 ("sample_edges", C.c_uint64), ("score_split", C.c_uint32), ("compat_one_phase", C.c_uint32),
-                ("compat_rows", C.c_uint32), ("compat_store_mode", C.c_uint32), ("tg_events", C.c_uint32), ("sample_mode", C.c_uint32),
-                ("sample_blocks", C.c_uint32), ("compact_fused", C.c_uint32), ("rows_unfused", C.c_uint32),
-                ("score_scalar", C.c_uint32), ("score_filter", C.c_uint32), ("filter_splits", C.c_uint32),
-                ("filter_queue_cap", C.c_uint32), ("filter_lds_queue", C.c_uint32), ("es_hist_unfused", C.c_uint32),
-                ("filter_variant", C.c_uint32), ("gram_kappa_q4", C.c_uint32), ("filter_blind", C.c_uint32),
-                ("no_fast", C.c_uint32), ("gram_guard_fail", C.c_uint32), ("tail_fused", C.c_uint32),
-                ("no_estimate", C.c_uint32), ("est_margin_pct", C.c_uint32), ("no_edge_build", C.c_uint32),
-                ("build_sample", C.c_uint32), ("reserved", C.c_uint32 * 1), ("select_final", C.c_uint32),
-                ("pad_", C.c_uint32), ("gram_ref_late", C.c_uint32), ("pad2_", C.c_uint32)]
+                ("compat_rows", C.c_uint32), ("compat_store_mode", C.c_uint32), ("compat_linear_order", C.c_uint32),
+                ("sample_mode", C.c_uint32), ("rows_unfused", C.c_uint32), ("no_edge_build", C.c_uint32),
+                ("no_estimate", C.c_uint32), ("est_margin_pct", C.c_uint32), ("no_fast", C.c_uint32),
+                ("score_filter", C.c_uint32), ("filter_splits", C.c_uint32), ("filter_queue_cap", C.c_uint32),
+                ("filter_lds_queue", C.c_uint32), ("filter_blind", C.c_uint32), ("gram_kappa_q4", C.c_uint32),
+                ("gram_ref_late", C.c_uint32), ("gram_guard_fail", C.c_uint32)]
+    _ALIASES = {"cnt_blocks": ("grid_blocks", 0), "keys_blocks": ("grid_blocks", 1), "sel_blocks": ("grid_blocks", 2),
+                "sample_blocks": ("grid_blocks", 3), "tg_count": ("lanes_per_edge", 0), "tg_keys": ("lanes_per_edge", 1),
+                "tg_sample": ("lanes_per_edge", 2), "tg_events": ("lanes_per_edge", 3)}
+
+
+class ScDebugLab(C.Structure):
+    """`sc_debug` of a library built with -DSC_ABLATIONS (sac-cot_amd/build.py --ablations): one knob more."""
+    _fields_ = ScDebug._fields_ + [("filter_variant", C.c_uint32), ("lab_pad_", C.c_uint32)]
+    _ALIASES = ScDebug._ALIASES
 
 
 class ScDebugInfo(C.Structure):
@@ -239,12 +245,18 @@ class Registrar:
         if not knobs:
             self._check(self._lib.sc_set_debug(self._h, None))
             return
-        d = ScDebug(size=C.sizeof(ScDebug), compact_self_max=-1, scan_self_max=-1)
+        cls = ScDebugLab if "filter_variant" in knobs else ScDebug   # (lab builds have a field more; the product rejects the lab struct's size)
+        d = cls(size=C.sizeof(cls), compact_self_max=-1, scan_self_max=-1)
+        names = dict(cls._fields_)
         for k, v in knobs.items():
-            if k not in dict(ScDebug._fields_) or k in ("size", "reserved"):
+            if k in cls._ALIASES:
+                arr, slot = cls._ALIASES[k]
+                getattr(d, arr)[slot] = int(v)
+            elif k in names and k not in ("size", "grid_blocks", "lanes_per_edge", "lab_pad_"):
+                setattr(d, k, int(v))
+            else:
                 raise KeyError(f"sc_debug has no field {k!r}")
-            setattr(d, k, int(v))
-        self._check(self._lib.sc_set_debug(self._h, C.byref(d)))
+        self._check(self._lib.sc_set_debug(self._h, C.cast(C.byref(d), C.POINTER(ScDebug))))
 
     def debug_last(self) -> dict:
         """sc_debug_last: which stage C2 kernel the last call ran (0 plain fp32, 1 linear filter + exact pass, 2 Gram

@@ -20,12 +20,6 @@
 #include "sc_kernels.hpp"
 #include "sc_gramref.hpp"
 
-#ifdef SC_ABLATIONS
-#define SC_TICK(c, k) ((c)->tick[k] = std::chrono::steady_clock::now())
-#else
-#define SC_TICK(c, k) ((void)0)
-#endif
-
 using namespace sc;
 
 namespace {
@@ -54,7 +48,7 @@ struct sc_ctx {
   // workspace
   Buf in_src, in_tgt, planes, S, bits, deg, degp, wpre, ebase, edge_off, scan_tmp, ei, ej, es, ebi, ebj, tcnt, toff, wkey, kcol, ctl, events, blk_gt,
       blk_eq, blk_minmax, bits2, off_gt, off_eq, sel_ord, sel_key, sortkey, sorted, sort_tmp, tri, tri_rk, key_rk, rt, rt_aos, partial, cnt, key, rt12,
-      mask, refine_tmp, amx_pairs, strong, rowcost, cost_pre, lb_state, lb_ticket, fx_tile, fx_state, fx_mx, fx_part, fx_coef, guard_tmp, sel_list, fx_frame, ref_cand;
+      mask, refine_tmp, amx_pairs, strong, rowcost, cost_pre, lb_state, lb_ticket, fx_tile, fx_state, fx_mx, fx_part, fx_coef, guard_tmp, fx_frame, ref_cand;
   // the XCD-aware block orders of stage A (compat_wg_map), one per row width met so far: a context that alternates between a few
   // sizes must not rebuild and upload the map on every call (that cost 2 ms per call in bench.py's varying-n leg)
   static constexpr int N_WG_MAPS = 8;
@@ -140,18 +134,11 @@ struct sc_ctx {
   int est_state = 0;         // last pass: 0 certified bound (or no pruning), 1 estimated and verified
   bool est_failed_call = false;  // the running / last call saw its estimate fail and was repeated (sc_debug_last: prune_bound 2)
   SamplePlan plan{false, 1u, 0};
-  // the winner / mask step inside the arg-max launch (sc_score.hip argmax_tail): the entry points that own the whole call
-  // (register_waited, sc_register_device_async) say where the outputs go before stage C is enqueued
-  float* tail_Rt = nullptr; uint8_t* tail_mask = nullptr;
-  bool tail_done = false;    // the running call's arg-max launch did the finalize step too
   // stage C2's reference frame (sc_gramref.hpp): on the hot path the estimating sample leaves candidate triangles behind
   // (ref_cand_n of them) and the counting pass carries the vote as an extra workgroup (ref_done); everywhere else stage C
   // votes in a launch of its own
   uint32_t ref_cand_n = 0;
   bool ref_done = false;
-#ifdef SC_ABLATIONS
-  std::chrono::steady_clock::time_point tick[16];  // lab build: host-side time stamps along the enqueue (sc_debug.reserved[0] == 99 prints them)
-#endif
   bool build = false;        // the running call takes launch_edge_build (row statistics + edge list + estimating sample in one launch)
   // run-time probe of the matrix pipe's accumulation model (sc_score.hip gram_guard): 0 not run, 1 holds, 2 violated
   int gram_guard = 0;
@@ -374,7 +361,7 @@ int stage_inputs(sc_ctx* c, const float* d_src, const float* d_tgt, int64_t n, c
   ENSURE(c, c->planes, (size_t)(6 + 8) * c->ld * sizeof(float));  // 6 SoA planes + the AoS copy (8 floats each)
   // per-call control block (flags, histograms, counters, select state): cleared by the staging kernel itself
   ENSURE(c, c->ctl, sizeof(ControlBlock));
-  static_assert(sizeof(ControlBlock) % 4 == 0 && offsetof(ControlBlock, sel2_hist) % 4 == 0, "cleared word-wise");
+  static_assert(sizeof(ControlBlock) % 4 == 0, "cleared word-wise");
   c->pinned[1] = 0;  // "non-finite input" flag lives in host-pinned memory: the kernel only touches it on bad data
   if (!c->fx_mx.p) {  // coordinate statistics for C2's filters (written whole by every call's staging kernel) + its ticket
     ENSURE(c, c->fx_mx, (FX_MX_WORDS + 1) * 4);
@@ -385,7 +372,7 @@ int stage_inputs(sc_ctx* c, const float* d_src, const float* d_tgt, int64_t n, c
   if (c->build) ENSURE(c, c->degp, (size_t)c->ld * sizeof(uint32_t));  // stage A accumulates deg+ there: cleared on the way
   launch_stage_points(d_src, d_tgt, c->n, c->ld, p->layout, c->planes.as<float>(),
                       reinterpret_cast<uint32_t*>(&c->pinned[1]), c->ctl.as<uint32_t>(),
-                      (uint32_t)((c->tn.select_final ? sizeof(ControlBlock) : offsetof(ControlBlock, sel2_hist)) / 4), c->fx_mx.as<uint32_t>(), c->fx_part.as<uint32_t>(),
+                      (uint32_t)(sizeof(ControlBlock) / 4), c->fx_mx.as<uint32_t>(), c->fx_part.as<uint32_t>(),
                       c->fx_mx.as<uint32_t>() + FX_MX_WORDS, &c->pinned[13], &c->pinned[16], c->stream,
                       c->build ? c->degp.as<uint32_t>() : nullptr, c->build ? (uint32_t)c->ld : 0u);
   return SC_OK;
@@ -564,13 +551,11 @@ int run_edges(sc_ctx* c, const sc_params* p, uint32_t* hist, uint32_t part, uint
   if (!build) for (const Buf* b : {&c->ebi, &c->ebj}) spec_cap = b->cap / 4 < spec_cap ? b->cap / 4 : spec_cap;
   // the weight histogram of the heaviest-edge pruning sample is collected by the same kernel (sc_debug.sample_mode = ...
   // any: it costs edge_fill ~1 us and saves a launch whenever that sample is chosen)
-  uint32_t* es_hist = c->tn.es_hist_unfused ? nullptr : c->ctl.as<ControlBlock>()->es_hist;
-  const SamplePlan plan0 = sample_plan(p->max_triangles, build, c->tn);  // (build: the sample rides the edge kernel)
+  uint32_t* es_hist = c->ctl.as<ControlBlock>()->es_hist;
   auto fill_edges = [&](uint64_t cap) {
     if (build) {
       launch_edge_build(g, points_of(c), c->dv, c->bits2.as<uint64_t>(), c->edge_off.as<uint64_t>(), c->ebase.as<uint32_t>(),
-                        c->ei.as<uint32_t>(), c->ej.as<uint32_t>(), c->es.as<float>(), cap, &c->pinned[0], plan0.rate,
-                        c->tn.build_sample ? c->ctl.as<ControlBlock>()->prune_hist : nullptr, st);
+                        c->ei.as<uint32_t>(), c->ej.as<uint32_t>(), c->es.as<float>(), cap, &c->pinned[0], st);
       return;
     }
     launch_edge_fill(g, points_of(c), c->dv, c->edge_off.as<uint64_t>(), c->ei.as<uint32_t>(), c->ej.as<uint32_t>(),
@@ -619,8 +604,7 @@ int run_edges(sc_ctx* c, const sc_params* p, uint32_t* hist, uint32_t part, uint
   bool edge_arrays_moved = false;
   for (int k = 0; k < (build ? 3 : 5); k++) edge_arrays_moved = edge_arrays_moved || edge_arrays_before[k] != edge_arrays_after[k];
   if (E > spec_cap || edge_arrays_moved) {  // first call, or the graph outgrew the arrays (just re-allocated above)
-    if (es_hist && spec_cap && !build) HIPCHK(c, hipMemsetAsync(es_hist, 0, sizeof(uint32_t) * PR_HCOPIES * 256, st));  // the partial run's counts
-    if (build && c->tn.build_sample) HIPCHK(c, hipMemsetAsync(c->ctl.as<ControlBlock>()->prune_hist, 0, sizeof(uint32_t) * PR_HCOPIES * 256, st));  // (the first run's sample)
+    if (spec_cap && !build) HIPCHK(c, hipMemsetAsync(es_hist, 0, sizeof(uint32_t) * PR_HCOPIES * 256, st));  // the partial run's counts
     fill_edges(E);
   }
   // certified pruning (sc_tri.hip 3b): weight ranking only; pointless on tiny graphs
@@ -644,12 +628,10 @@ int run_edges(sc_ctx* c, const sc_params* p, uint32_t* hist, uint32_t part, uint
     const bool est_local = c->est_allowed && !c->est_failed && hist == nullptr && parts == 1 && !c->sharded_ab;
     const bool est_shard = c->sharded_ab && hist != nullptr && (p->flags & SC_FLAG_EST_BOUND) != 0;
     c->plan = sample_plan(p->max_triangles, (est_local || est_shard) && c->use_events && window_known, c->tn,
-                          (build && c->tn.build_sample) ? 0 : (spec ? c->E_last : E), g.W);  // (a sample taken by the edge kernel was taken before E was known)
+                          spec ? c->E_last : E, g.W);
     c->est_active = c->plan.estimate;
     if (build && !c->plan.estimate) { c->last_error = "internal: the fused edge kernel ran but the bound is not an estimate"; return SC_EHIP; }
-    if (build && c->tn.build_sample) {
-      // (the sample's histogram came out of launch_edge_build)
-    } else if (c->plan.estimate) {
+    if (c->plan.estimate) {
       // an estimating sample (the single-GPU hot path; sharded, SC_FLAG_EST_BOUND: every rank takes the whole of it), inlier count, a call
       // big enough for stage C2's Gram filter to be in question: the sample also
       // leaves its workgroups' best triangles behind — the voters of that filter's reference frame (run_select passes them on)
@@ -674,7 +656,7 @@ int run_edges(sc_ctx* c, const sc_params* p, uint32_t* hist, uint32_t part, uint
       const bool whole = est_shard;
       launch_sample_hist(g, c->ebi.as<uint32_t>(), c->ebj.as<uint32_t>(), c->ei.as<uint32_t>(), c->ej.as<uint32_t>(),
                          c->es.as<float>(), E, p->max_triangles, 3.0f * p->t_cmp * 0.999f, whole ? 0u : part, whole ? 1u : parts,
-                         ctl->prune_hist, ctl->es_hist, es_hist != nullptr, c->tn, st, E_dev, spec ? c->E_last : 0);
+                         ctl->prune_hist, ctl->es_hist, c->tn, st, E_dev, spec ? c->E_last : 0);
     }
     if (hist) launch_hist_reduce(ctl->prune_hist, hist, st);  // the exchanged form: one 256-bin histogram
   }
@@ -682,25 +664,12 @@ int run_edges(sc_ctx* c, const sc_params* p, uint32_t* hist, uint32_t part, uint
 }
 
 // Ordinal-order compaction of the keys at or above the threshold the select found -> sel_ord / sel_key.
-// Default: two launches (count per tile; write, every tile summing the counts before it by itself).  The ONE-launch form
-// (counts of the earlier tiles by decoupled look-back, Tuning::compact_fused) was built as VERDICT r01 asked and is
-// bit-exact, but slower: 16.4 us against 4.7 + 4.7 on C2 (525 tiles of 1024 keys publish their counts at the same moment,
-// so the prefixes trickle through ~8 dependent 64-tile windows); the same look-back does pay in the scan, whose tiles
-// are 4096 elements and few.  Tuning::compact_self_max == 0 (a test) takes the scanned three-launch form.
-int run_compaction(sc_ctx* c, const KeyView& view, size_t nb, bool counted = false) {
+// Two launches (count per tile; write, every tile summing the counts before it by itself).  (The ONE-launch form — counts of the
+// earlier tiles by decoupled look-back — was built as VERDICT r01 asked, bit-exact and slower: 16.4 us against 4.7 + 4.7 on C2;
+// removed in r05.)  Tuning::compact_self_max == 0 (a test) takes the scanned three-launch form.
+int run_compaction(sc_ctx* c, const KeyView& view, size_t nb) {
   hipStream_t st = c->stream;
   SelectState* sel = &c->ctl.as<ControlBlock>()->sel;
-  if (counted) {  // launch_select_final left the per-tile counts: the writing launch alone (it sums the counts before its tile itself)
-    launch_compact_write(view, sel, c->blk_gt.as<uint32_t>(), c->blk_eq.as<uint32_t>(), nullptr, nullptr, c->sel_ord.as<uint64_t>(),
-                         c->sel_key.as<uint32_t>(), c->sel_ord.cap / 8 < c->sel_key.cap / 4 ? c->sel_ord.cap / 8 : c->sel_key.cap / 4, st);
-    return SC_OK;
-  }
-  if (c->tn.compact_fused) {
-    LbArgs lb;
-    { const int lrc = lb_next(c, compact_state_bytes(view.M), 0, 0, &lb); if (lrc) return lrc; }
-    launch_compact_fused(view, sel, lb, c->sel_ord.as<uint64_t>(), c->sel_key.as<uint32_t>(), st);
-    return SC_OK;
-  }
   launch_compact_count(view, sel, c->blk_gt.as<uint32_t>(), c->blk_eq.as<uint32_t>(), st);
   // few tiles (and M < 2^32): compact_write adds up the tile counts itself, no scan launch in between
   const bool self_off = nb <= c->tn.compact_self_max && view.M < (1ull << 32);
@@ -791,9 +760,6 @@ int run_select(sc_ctx* c, const sc_params* p, const uint32_t* hist, bool want_li
   // and not when every stage is bracketed by events; re-run below if the count outgrew the arrays or a region overflowed.
   SelectState* sel = &c->ctl.as<ControlBlock>()->sel;
   const bool window_known = p->rank_mode == SC_RANK_WEIGHT && 3.0f * p->t_cmp * 0.999f >= 2.0f;
-  // the hot path's select: round 1's histogram rides the key kernel, launch_select_final does the rest (sc_tri.hip 4')
-  const bool sel2_ok = use_events && window_known && !c->sharded_ab && c->tn.select_final && !c->tn.compact_fused;
-  bool hist_dirty = false;  // a key pass has added to sel->hist
   uint64_t spec_cap = 0;
   if (use_events && window_known && !c->timing) {
     spec_cap = c->wkey.cap / 4 < c->kcol.cap / 8 ? c->wkey.cap / 4 : c->kcol.cap / 8;
@@ -802,8 +768,7 @@ int run_select(sc_ctx* c, const sc_params* p, const uint32_t* hist, bool want_li
       ENSURE(c, c->blk_minmax, 2 * 8192 * 4);
       launch_tri_keys_events(g, c->es.as<float>(), c->toff.as<uint64_t>(), p->rank_mode, ev, c->wkey.as<uint32_t>(),
                              c->kcol.as<uint2>(), c->blk_minmax.as<uint32_t>(), sel, select_want(c, p),
-                             &c->ctl.as<ControlBlock>()->klb, E, spec_cap, c->tn, st, !c->sharded_ab, sel2_ok, c->ctl.as<ControlBlock>()->sel_r1);
-      hist_dirty = sel2_ok;
+                             &c->ctl.as<ControlBlock>()->klb, E, spec_cap, c->tn, st, !c->sharded_ab);
     }
   }
   // host-free call: no wait — M is what the key arrays and the launches below cover, T_eff the requested T; the kernels
@@ -848,17 +813,12 @@ int run_select(sc_ctx* c, const sc_params* p, const uint32_t* hist, bool want_li
   // weight keys of a graph whose edges all weigh >= 2/3 (0.1 % slack) lie in [2.0, 3.0]: window known a priori
   const bool fast_window = events_ok && window_known;
   const bool keys_done = spec_cap != 0 && events_ok && M <= spec_cap && !key_arrays_moved;  // the speculative pass wrote every key
-  const bool sel2 = sel2_ok && fast_window && nb <= c->tn.compact_self_max && M < (1ull << 32);
-  if (hist_dirty && !keys_done && sel2) {  // the key kernel runs again, histogram included: the speculative pass's counts go
-    HIPCHK(c, hipMemsetAsync(c->ctl.as<ControlBlock>()->sel_r1, 0, sizeof(uint32_t) * SEL2_COPIES * 4096, st));
-    hist_dirty = false;
-  }
   if (keys_done) {
     // nothing to do
   } else if (events_ok) {
     launch_tri_keys_events(g, c->es.as<float>(), c->toff.as<uint64_t>(), p->rank_mode, ev, c->wkey.as<uint32_t>(),
                            c->kcol.as<uint2>(), c->blk_minmax.as<uint32_t>(), sel, fast_window ? (uint64_t)select_want(c, p) : (uint64_t)T_eff,
-                           fast_window ? &c->ctl.as<ControlBlock>()->klb : nullptr, E, M, c->tn, st, !c->sharded_ab, sel2, c->ctl.as<ControlBlock>()->sel_r1);
+                           fast_window ? &c->ctl.as<ControlBlock>()->klb : nullptr, E, M, c->tn, st, !c->sharded_ab);
   } else {
     launch_tri_keys(g, mbits, smin, c->ebase.as<uint32_t>(), c->ei.as<uint32_t>(), c->ej.as<uint32_t>(),
                     c->es.as<float>(), c->toff.as<uint64_t>(), E, p->rank_mode, c->wkey.as<uint32_t>(),
@@ -870,15 +830,8 @@ int run_select(sc_ctx* c, const sc_params* p, const uint32_t* hist, bool want_li
   if (spec) view.M_dev = c->toff.as<uint64_t>() + E;
   // an estimated bound is verified by the first round over the a-priori window; any other path leaves it unverified
   if (c->est_active && !fast_window) c->est_void = true;
-  if (sel2) {
-    ENSURE(c, c->sel_list, select_final_list_words(M) * 4);
-    uint32_t* lists = c->sel_list.as<uint32_t>();  // the tiles' key lists (128 bytes each), then their lengths
-    launch_select_final(view, sel, c->ctl.as<ControlBlock>()->sel_r1, c->ctl.as<ControlBlock>()->sel2_hist, c->blk_gt.as<uint32_t>(),
-                        c->blk_eq.as<uint32_t>(), lists, lists + compact_blocks(M) * 32, &c->pinned[14], st);
-  } else {
-    launch_select_rounds(view, sel, fast_window ? 2 : 3, c->tn, st, c->sharded_ab ? nullptr : &c->pinned[14]);
-  }
-  { const int crc = run_compaction(c, view, nb, sel2); if (crc) return crc; }
+  launch_select_rounds(view, sel, fast_window ? 2 : 3, c->tn, st, c->sharded_ab ? nullptr : &c->pinned[14]);
+  { const int crc = run_compaction(c, view, nb); if (crc) return crc; }
   // the list stays in ordinal order: no sort on the hot path (the winner is found by (count, key, position))
   if (want_list)
     launch_tri_decode(c->ei.as<uint32_t>(), c->ej.as<uint32_t>(), c->kcol.as<uint2>(), c->sel_ord.as<uint64_t>(), T_eff,
@@ -957,7 +910,7 @@ int busy(sc_ctx* c) {  // an sc_register_device_async / sc_finalize_gathered_dev
 
 int host_to_planes(sc_ctx* c, const float* src, const float* tgt, int64_t n, const sc_params* p) {
   { const int brc = busy(c); if (brc) return brc; }
-  c->spec_on = false; c->tail_done = false;  // (a host-free call that was never finalized must not leave its covers to a stage hook)
+  c->spec_on = false;  // (a host-free call that was never finalized must not leave its covers to a stage hook)
   c->build = false;  // (stage hooks: the separate kernels)
   if (!src || !tgt || n < 3 || n > (1 << 24)) return SC_EINVAL;
   ENSURE(c, c->in_src, (size_t)n * 12);
@@ -1039,7 +992,7 @@ void sc_destroy(sc_ctx* c) {
   Buf* bufs[] = {&c->in_src, &c->in_tgt, &c->planes, &c->S, &c->bits, &c->deg, &c->degp, &c->wpre, &c->ebase, &c->edge_off, &c->scan_tmp,
                  &c->ei, &c->ej, &c->es, &c->ebi, &c->ebj, &c->tcnt, &c->toff, &c->wkey, &c->kcol, &c->ctl, &c->events, &c->blk_gt, &c->blk_eq, &c->blk_minmax, &c->bits2, &c->off_gt,
                  &c->off_eq, &c->sel_ord, &c->sel_key, &c->sortkey, &c->sorted, &c->sort_tmp, &c->tri, &c->tri_rk, &c->key_rk, &c->rt,
-                 &c->rt_aos, &c->partial, &c->cnt, &c->key, &c->rt12, &c->mask, &c->refine_tmp, &c->amx_pairs, &c->strong, &c->rowcost, &c->cost_pre, &c->lb_state, &c->lb_ticket, &c->fx_tile, &c->fx_state, &c->fx_mx, &c->fx_part, &c->fx_coef, &c->guard_tmp, &c->sel_list, &c->fx_frame, &c->ref_cand};
+                 &c->rt_aos, &c->partial, &c->cnt, &c->key, &c->rt12, &c->mask, &c->refine_tmp, &c->amx_pairs, &c->strong, &c->rowcost, &c->cost_pre, &c->lb_state, &c->lb_ticket, &c->fx_tile, &c->fx_state, &c->fx_mx, &c->fx_part, &c->fx_coef, &c->guard_tmp, &c->fx_frame, &c->ref_cand};
   for (sc_ctx::WgMap& m : c->wg_maps) if (m.buf.p) (void)hipFree(m.buf.p);
   for (Buf* b : bufs) if (b->p) (void)hipFree(b->p);
   for (int i = 0; i < N_EVENTS; i++) if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
@@ -1069,54 +1022,42 @@ int sc_set_debug(sc_ctx* c, const sc_debug* d) {
   if (!d) { c->tn = Tuning(); c->fast_ok = false; c->est_failed = false; c->est_holdoff = 0; c->est_failures = 0; return SC_OK; }
   if (d->size != sizeof(sc_debug)) return SC_EINVAL;
   auto tg_ok = [](uint32_t t) { return t == 0 || t == 4 || t == 8 || t == 16 || t == 32 || t == 64; };
-  if (!tg_ok(d->tg_count) || !tg_ok(d->tg_keys) || !tg_ok(d->tg_sample) || !tg_ok(d->tg_events)) return SC_EINVAL;
-  if (d->tg_count == 64) return SC_EINVAL;  // the plain counting kernel has no 64-lane form
+  for (int k = 0; k < 4; k++) if (!tg_ok(d->lanes_per_edge[k])) return SC_EINVAL;
+  if (d->lanes_per_edge[0] == 64) return SC_EINVAL;  // the plain counting kernel has no 64-lane form
   if (d->score_split > 256 || (d->compat_rows != 0 && d->compat_rows != 16 && d->compat_rows != 32 && d->compat_rows != 64)) return SC_EINVAL;
   if (d->event_cap != 0 && d->event_cap < 256) return SC_EINVAL;
-  if (d->filter_variant != 0 && !filter_ablations_built()) {  // (most of them are timing-only bodies that return wrong counts)
-    c->last_error = "sc_debug.filter_variant needs a library built with -DSC_ABLATIONS";
-    return SC_EINVAL;
-  }
   Tuning t;
   t.no_events = d->no_events != 0;
   t.event_cap = d->event_cap;
   if (d->compact_self_max >= 0) t.compact_self_max = (size_t)d->compact_self_max;
   if (d->scan_self_max >= 0) t.scan_self_max = (size_t)d->scan_self_max;
-  t.cnt_blocks = d->cnt_blocks; t.keys_blocks = d->keys_blocks; t.sel_blocks = d->sel_blocks;
-  if (d->tg_count) t.tg_count = (int)d->tg_count;
-  if (d->tg_keys) t.tg_keys = (int)d->tg_keys;
-  if (d->tg_sample) t.tg_sample = (int)d->tg_sample;
-  if (d->tg_events) t.tg_events = (int)d->tg_events;
+  t.cnt_blocks = d->grid_blocks[0]; t.keys_blocks = d->grid_blocks[1]; t.sel_blocks = d->grid_blocks[2]; t.sample_blocks = d->grid_blocks[3];
+  if (d->lanes_per_edge[0]) t.tg_count = (int)d->lanes_per_edge[0];
+  if (d->lanes_per_edge[1]) t.tg_keys = (int)d->lanes_per_edge[1];
+  if (d->lanes_per_edge[2]) t.tg_sample = (int)d->lanes_per_edge[2];
+  if (d->lanes_per_edge[3]) t.tg_events = (int)d->lanes_per_edge[3];
   t.sample_edges = d->sample_edges;
   t.score_split = d->score_split;
   t.compat_one_phase = d->compat_one_phase != 0;
   t.compat_rows = (int)d->compat_rows;  // 0 (by size), 16, 32, 64: checked above
   t.compat_store_mode = d->compat_store_mode & 7u;
+  t.compat_linear_order = d->compat_linear_order != 0;
   t.sample_mode = d->sample_mode <= 2 ? d->sample_mode : 0u;  // (!= 0 also keeps the estimate off: a certifying form was asked for)
-  t.sample_blocks = d->sample_blocks;
-  t.compact_fused = d->compact_fused != 0;
   t.rows_unfused = d->rows_unfused != 0;
-  t.score_scalar = d->score_scalar != 0;
-  t.es_hist_unfused = d->es_hist_unfused != 0;
   t.score_filter = d->score_filter <= 3 ? d->score_filter : 0u;
   t.filter_splits = d->filter_splits;
   t.filter_queue_cap = d->filter_queue_cap;
   t.filter_lds_queue = d->filter_lds_queue;
   t.filter_blind = d->filter_blind != 0;
-  t.filter_variant = d->filter_variant;
   t.gram_kappa_q4 = d->gram_kappa_q4;
   t.gram_ref_late = d->gram_ref_late != 0;
   t.no_fast = d->no_fast != 0;
   t.gram_guard_fail = d->gram_guard_fail != 0;
-  t.tail_fused = d->tail_fused != 0;
   t.no_estimate = d->no_estimate != 0;
   t.no_edge_build = d->no_edge_build != 0;
-  t.build_sample = d->build_sample != 0;
-  t.select_final = d->select_final != 0;
-  t.compat_linear_order = d->pad_ != 0;
-  // development hook (a kernel under study returns after a phase: WRONG results) — lab builds only, like the filter ablations
-  if (d->reserved[0] != 0 && !filter_ablations_built()) { c->last_error = "sc_debug.reserved[0] (phase stop) needs a library built with -DSC_ABLATIONS"; return SC_EINVAL; }
-  t.dbg_stop = d->reserved[0];
+#ifdef SC_ABLATIONS
+  t.filter_variant = d->filter_variant;  // (lab builds only: most values are timing-only bodies that return WRONG counts)
+#endif
   t.est_margin_pct = d->est_margin_pct;
   c->tn = t;
   c->fast_ok = false;  // (the next call waits: its launch geometry may differ from the last call's)
@@ -1167,7 +1108,6 @@ int hyp_begin(sc_ctx* c, const float* d_src, const float* d_tgt, int64_t n, cons
   c->begun = false;
   c->timed_trikeys = false;
   c->regular = false;
-  c->tail_done = false;
   if (!c->spec_on) c->E_cov = c->M_cov = 0;  // (only the entry that has just planned a host-free call leaves spec_on set)
   if (!c->est_allowed) c->est_failed_call = false;  // (an entry point that never estimates)
   if ((rc = set_timing(c, p))) return rc;
@@ -1183,16 +1123,12 @@ int hyp_begin(sc_ctx* c, const float* d_src, const float* d_tgt, int64_t n, cons
   }
   c->build = d_hist == nullptr && parts == 1 && edge_build_ok(c, p, n);
   if ((rc = rec(c, 0))) return rc;
-  SC_TICK(c, 1);
   if ((rc = stage_inputs(c, d_src, d_tgt, n, p))) return rc;
-  SC_TICK(c, 2);
   if ((rc = rec(c, 1))) return rc;
   if ((rc = run_compat(c, !(p->flags & SC_FLAG_NO_DENSE_S)))) return rc;
-  SC_TICK(c, 3);
   if ((rc = rec(c, 2))) return rc;
   if ((rc = run_row_stats(c, may_prune(p), true))) return rc;
   if ((rc = run_edges(c, p, d_hist, part, parts))) return rc;
-  SC_TICK(c, 4);
   c->begun = true;
   return SC_OK;
 }
@@ -1289,8 +1225,7 @@ int run_score(sc_ctx* c, const sc_params* p, const Shard& sh, uint32_t* rows, bo
                         c->fx_coef.p, c->fx_frame.p, c->partial.as<uint32_t>(), c->tn, c->stream, ev0, ev1, ev_mid);
     return SC_OK;
   }
-  const bool scalar = score_is_scalar(p->score_mode, c->tn);
-  *rows = score_chunks(c->n, sh.ld_local, scalar);
+  *rows = score_chunks(c->n, sh.ld_local);
   if (sh.ld_local) ENSURE(c, c->partial, (size_t)*rows * sh.ld_local * 4);
   launch_score(points_of(c), c->rt.as<float>(), c->rt_aos.as<float>(), sh, c->dv, p->score_mode, c->partial.as<uint32_t>(),
                c->tn, c->stream, ev0, ev1);
@@ -1324,7 +1259,7 @@ int run_stage_c(sc_ctx* c, uint64_t* d_key, sc_stats* stats) {
     ENSURE(c, c->cnt, (size_t)sh.ld_local * 4);
     if ((rc = decide_filter(c, p, sh))) return rc;
     const bool filter = c->filter_on;
-    const bool aos = filter || score_is_scalar(p->score_mode, c->tn);  // both read 12 consecutive floats per hypothesis
+    const bool aos = filter;  // (the exact pass reads 12 consecutive floats per hypothesis)
     if (aos) ENSURE(c, c->rt_aos, (size_t)12 * sh.ld_local * 4);
     FilterTileJob job;
     if (filter && (rc = filter_job(c, sh, &job))) return rc;
@@ -1348,13 +1283,8 @@ int run_stage_c(sc_ctx* c, uint64_t* d_key, sc_stats* stats) {
   if ((rc = run_score(c, p, sh, &score_rows, true, hot_ext ? c->ev[4] : nullptr, hot_ext ? c->ev[5] : nullptr, hot_ext ? c->ev[11] : nullptr))) return rc;
   if (!hot_ext && (rc = rec(c, 5))) return rc;
   ENSURE(c, c->amx_pairs, argmax_scratch_bytes(sh.ld_local));
-  c->tail_done = c->tail_mask != nullptr && c->tn.tail_fused && c->T_eff != 0 && argmax_tail_fits(c->n, c->T_eff, sh);
-  if (c->tail_done) arm_word(c, 8);
-  launch_argmax(points_of(c), sh, c->partial.as<uint32_t>(), score_rows,
-                c->T_eff ? c->sel_key.as<uint32_t>() : nullptr,
-                c->cnt.as<uint32_t>(), c->amx_pairs.as<uint64_t>(), &c->ctl.as<ControlBlock>()->amx_ticket, d_key,
-                c->stream, c->tail_done ? c->rt.as<float>() : nullptr, c->dv.tau2, c->tail_done ? c->tail_Rt : nullptr,
-                c->tail_done ? c->tail_mask : nullptr, c->ctl.as<ControlBlock>()->key2, &c->pinned[8]);
+  launch_argmax(sh, c->partial.as<uint32_t>(), score_rows, c->T_eff ? c->sel_key.as<uint32_t>() : nullptr,
+                c->cnt.as<uint32_t>(), c->amx_pairs.as<uint64_t>(), &c->ctl.as<ControlBlock>()->amx_ticket, d_key, c->stream);
   if ((rc = rec(c, 6))) return rc;
   HIPCHK(c, hipGetLastError());
   c->have_hyp = true;
@@ -1434,7 +1364,7 @@ int sc_shard_compat_device(sc_ctx* c, const float* d_src, const float* d_tgt, in
   if (c->pending) { c->last_error = "a call is outstanding on this context (sc_wait first)"; return SC_EINVAL; }
   HIPCHK(c, hipSetDevice(c->device));
   c->have_hyp = false; c->begun = false; c->timed_trikeys = false;
-  c->spec_on = false; c->tail_done = false;
+  c->spec_on = false;
   if ((rc = set_timing(c, p))) return rc;
   c->refine = (p->flags & SC_FLAG_REFINE) != 0;
   c->cap_bytes = p->max_workspace ? p->max_workspace : (64ull << 30);
@@ -1557,14 +1487,6 @@ int finalize_enqueue(sc_ctx* c, const uint64_t* d_keys, int n_pairs, float* d_Rt
   int rc;
   if ((rc = rec(c, 7))) return rc;
   ControlBlock* ctl = c->ctl.as<ControlBlock>();
-  if (c->tail_done) {  // the arg-max launch already did this step (run_stage_c); only the optional refit is left
-    c->pinned[11] = 0;
-    if (c->refine) {
-      ENSURE(c, c->refine_tmp, refine_scratch_bytes(c->n));
-      launch_refine(points_of(c), d_mask, ctl->key2, c->refine_tmp.as<double>(), d_Rt, c->stream);
-    }
-    return rec(c, 8);
-  }
   arm_word(c, 8);
   launch_finalize(points_of(c), tri_source_of(c), c->sh, c->sh.n_local ? c->rt.as<float>() : nullptr,
                   c->T_eff ? c->sel_key.as<uint32_t>() : nullptr, c->T_eff, d_keys, n_pairs,
@@ -1737,11 +1659,9 @@ int register_waited(sc_ctx* c, const float* d_src, const float* d_tgt, int64_t n
   int rc = SC_OK;
   for (int pass = 0; pass < 2; pass++) {
     c->est_allowed = true;
-    c->tail_Rt = d_Rt; c->tail_mask = d_mask;
     rc = hyp_begin(c, d_src, d_tgt, n, p, nullptr, 0, 1);
     if (!rc) rc = hyp_end(c, nullptr, c->key.as<uint64_t>(), stats);
     c->est_allowed = false;
-    c->tail_Rt = nullptr; c->tail_mask = nullptr;
     if (rc) return rc;
     HIPCHK(c, hipSetDevice(c->device));
     rc = finalize_enqueue(c, c->key.as<uint64_t>(), 1, d_Rt, d_mask);
@@ -1813,19 +1733,14 @@ int sc_register_device_async(sc_ctx* c, const float* d_src, const float* d_tgt, 
   c->pend_stats.size = sizeof(sc_stats);
   c->fast_state = 0;
   c->est_failed_call = false;
-  SC_TICK(c, 0);
   if (fast_plan(c, n, p)) {
     // host-free: the whole chain is enqueued without looking at anything the GPU produces; sc_wait validates
     c->spec_on = true;
     c->est_allowed = true;  // (sc_wait repeats a call whose estimated pruning bound fails, like any other failed assumption)
-    c->tail_Rt = d_Rt; c->tail_mask = d_mask;
     rc = hyp_begin(c, d_src, d_tgt, n, p, nullptr, 0, 1);
     if (!rc) rc = hyp_end(c, nullptr, c->key.as<uint64_t>(), &c->pend_stats);
-    SC_TICK(c, 5);
     c->est_allowed = false;
-    c->tail_Rt = nullptr; c->tail_mask = nullptr;
     if (!rc) rc = finalize_enqueue(c, c->key.as<uint64_t>(), 1, d_Rt, d_mask);
-    SC_TICK(c, 6);
     if (!rc) {
       c->pending = true; c->pend_done = false; c->pend_finalize = false;
       return SC_OK;
@@ -1856,17 +1771,8 @@ int sc_wait(sc_ctx* c, sc_stats* stats) {
     return frc;
   }
   int rc = c->pending_rc;
-  SC_TICK(c, 7);
   if (!c->pend_done) {
     rc = finalize_wait(c, &c->pend_stats);
-    SC_TICK(c, 8);
-#ifdef SC_ABLATIONS
-    if (c->tn.dbg_stop == 99) {
-      auto us = [&](int a, int b) { return std::chrono::duration<double, std::micro>(c->tick[b] - c->tick[a]).count(); };
-      fprintf(stderr, "host us: entry->stage_launch %.1f | stage launch %.1f | ->compat launched %.1f | ->edges+sample launched %.1f | ->rest of hyp_end %.1f | finalize enq %.1f | to sc_wait %.1f | wait %.1f | total %.1f\n",
-              us(0, 1), us(1, 2), us(2, 3), us(3, 4), us(4, 5), us(5, 6), us(6, 7), us(7, 8), us(0, 8));
-    }
-#endif
     if (rc == SC_ESPEC) {  // a count outgrew what the launches covered (or another fallback was needed): the waiting way
       rc = register_waited(c, c->pend_src, c->pend_tgt, c->pend_n, &c->pend_p, c->pend_Rt, c->pend_mask, &c->pend_stats);
       c->fast_state = 2;
@@ -2063,10 +1969,8 @@ int sc_score_host(sc_ctx* c, const float* src, const float* tgt, int64_t n, cons
   if ((rc = run_score(c, p, sh, &score_rows, false))) return rc;
   ENSURE(c, c->cnt, (size_t)(sh.ld_local ? sh.ld_local : 256) * 4);
   ENSURE(c, c->amx_pairs, argmax_scratch_bytes(sh.ld_local));
-  launch_argmax(points_of(c), sh, c->partial.as<uint32_t>(), score_rows,
-                nullptr, c->cnt.as<uint32_t>(), c->amx_pairs.as<uint64_t>(),
-                &c->ctl.as<ControlBlock>()->amx_ticket, c->key.as<uint64_t>(),
-                c->stream);  // positions in Rt ARE the rank indices here: single-stage key
+  launch_argmax(sh, c->partial.as<uint32_t>(), score_rows, nullptr, c->cnt.as<uint32_t>(), c->amx_pairs.as<uint64_t>(),
+                &c->ctl.as<ControlBlock>()->amx_ticket, c->key.as<uint64_t>(), c->stream);  // positions in Rt ARE the rank indices here: single-stage key
   if ((rc = check_flag(c))) return rc;
   if (cnt && n_hyp) HIPCHK(c, hipMemcpyAsync(cnt, c->cnt.p, (size_t)n_hyp * 4, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipMemcpyAsync(key, c->key.p, 8, hipMemcpyDeviceToHost, c->stream));

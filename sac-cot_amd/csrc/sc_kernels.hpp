@@ -34,16 +34,10 @@ struct Tuning {
   uint32_t sample_mode = 0;        // pruning sample: 0 by size (launch_sample_hist), 1 every stride-th edge, 2 the heaviest edges (both CERTIFY their bound)
   bool no_edge_build = false;      // row statistics and edge list as separate launches (not launch_edge_build)
   bool compat_linear_order = false;  // stage A's 64 x 64 blocks in index order (r03) instead of the XCD-aware order
-  bool select_final = false;       // the select as ONE launch after a key kernel that takes round 1's histogram (launch_select_final): built, bit-exact, NOT faster (sc_tri.hip 4'), off by default
-  bool build_sample = false;       // launch_edge_build also takes the estimating sample (measured slower: see edge_build_kernel)
-  uint32_t dbg_stop = 0;           // development only: a kernel under study returns after phase dbg_stop (WRONG results)
   bool no_estimate = false;        // never prune by an ESTIMATED bound (sc_tri.hip 3c): always one of the certifying samples
   uint32_t est_margin_pct = 0;     // the estimate aims at the (pct / 100 x T)-th key (0: 200; tests force failures with a small one)
   uint32_t sample_blocks = 0;      // grid of the heaviest-edge sample (0: one block per 256 edges)
-  bool compact_fused = false;      // compaction in one launch (decoupled look-back) instead of count + write
   bool rows_unfused = false;       // row_stats and the scan(s) of the row counts as separate launches (round 1's form)
-  bool es_hist_unfused = false;    // the weight histogram of the heaviest-edge sample by a launch of its own (not inside edge_fill)
-  bool score_scalar = false;       // C2: count inliers with the lane = correspondence kernel (coefficients as scalar operands)
   uint64_t sample_edges = 0;       // edges of the pruning sample (0: automatic, ~5T/8)
   uint32_t score_split = 0;        // share (of 256) of the hypotheses scored on the matrix pipe
   uint32_t score_filter = 0;       // C2, inlier count: 0 = by size and scale (plain kernel / linear filter / Gram filter), 1 = plain kernel, 2 = linear filter, 3 = Gram filter
@@ -55,7 +49,6 @@ struct Tuning {
   bool gram_ref_late = false;      // the Gram filter's reference frame is voted after the selection, in a launch of its own (what every path but the hot one does anyway), instead of under the counting pass
   bool no_fast = false;            // sc_register_device never enqueues host-free (always waits for stage B's two counts)
   bool gram_guard_fail = false;    // the matrix-pipe probe reports a violation (tests of the guard)
-  bool tail_fused = false;         // the register path's winner / mask step inside the arg-max launch (measured slower: off)
   bool filter_blind = false;       // the host decides C2's kernel WITHOUT the coordinate maxima (as if they had not arrived yet)
   bool compat_one_phase = false;   // exact chain on every pair of an interior tile
   int compat_rows = 0;             // tile height of stage A: 0 = by size (16 below 10 000 correspondences, 32 from there), 16, 32, 64
@@ -183,13 +176,12 @@ void launch_edge_fill(const Graph& g, const Points& pts, const Derived& dv, cons
                       uint32_t* ej, float* es, uint32_t* ebase, bool ebase_ready, uint32_t* ebi, uint32_t* ebj,
                       uint64_t cap, uint32_t* es_hist, hipStream_t st);  // es_hist: see launch_sample_hist (optional)
 // The hot path's form (r04; n <= 20 480, weight ranking, estimated pruning bound): row statistics (wpre), CSR offsets and
-// bases from g.degp — which launch_compat accumulated —, the strong-bit rows cleared, the edge list (ei / ej / es; NO ebi /
-// ebj: launch_tri_count_events looks the bases up) and the estimating sample's histogram (PR_HCOPIES x 256 words, zeroed),
-// in one launch.  host_total (pinned) receives the edge count, which also lands in edge_off[n].
+// bases from g.degp — which launch_compat accumulated —, the strong-bit rows cleared and the edge list (ei / ej / es; NO ebi /
+// ebj: launch_tri_count_events looks the bases up), in one launch.  host_total (pinned) receives the edge count, which also
+// lands in edge_off[n].
 bool edge_build_fits(int n);
 void launch_edge_build(const Graph& g, const Points& pts, const Derived& dv, uint64_t* zero_rows, uint64_t* edge_off, uint32_t* ebase,
-                       uint32_t* ei, uint32_t* ej, float* es, uint64_t cap, uint64_t* host_total, uint32_t rate, uint32_t* hist,
-                       hipStream_t st);
+                       uint32_t* ei, uint32_t* ej, float* es, uint64_t cap, uint64_t* host_total, hipStream_t st);
 // tcnt[e] = #k > j adjacent (in `mbits`) to both ends of edge e = (i,j); edges with es[e] < *smin count 0
 // (smin == nullptr: no pruning, mbits = g.bits).
 void launch_tri_count(const Graph& g, const uint64_t* mbits, const float* es, const float* smin, const uint32_t* ei,
@@ -223,7 +215,7 @@ size_t strong_list_bytes(uint64_t E);
 // host-side choices (sample form, stride) are made with.
 void launch_sample_hist(const Graph& g, const uint32_t* ebi, const uint32_t* ebj, const uint32_t* ei,
                         const uint32_t* ej, const float* es, uint64_t E, uint64_t want, float key_floor, uint32_t part,
-                        uint32_t parts, uint32_t* hist, uint32_t* es_hist, bool es_hist_ready, const Tuning& tn, hipStream_t st,
+                        uint32_t parts, uint32_t* hist, uint32_t* es_hist, const Tuning& tn, hipStream_t st,
                         const uint64_t* E_dev = nullptr, uint64_t E_hint = 0);
 // The ESTIMATING sample (r04, sc_tri.hip 3c): one sampled 64-column word in `rate` of every edge's row pair, its triangles'
 // keys into `hist` — a uniform 1-in-rate sample of ALL the graph's triangles.  launch_prune_bits then takes the bin where
@@ -241,8 +233,7 @@ void launch_sample_estimate(const Graph& g, const uint32_t* ebi, const uint32_t*
                             uint4* cand = nullptr, unsigned long long* cand_slot = nullptr);  // cand (optional, sample_estimate_blocks() entries): the best-keyed triangle each workgroup sampled {key bits, i, j, k} — the voters of stage C2's reference frame (sc_gramref.hpp)
 uint32_t sample_estimate_blocks(uint64_t E, const Tuning& tn);  // workgroups launch_sample_estimate uses
 uint32_t sample_candidate_blocks(uint64_t E, const Tuning& tn);  // ... of which the first so many leave a candidate behind
-// es_hist: PR_HCOPIES x 256 words (control block) for the weight histogram of the heaviest-edge sample: zeroed, or —
-// es_hist_ready — already filled by launch_edge_fill
+// es_hist: PR_HCOPIES x 256 words (control block): the weight histogram of the heaviest-edge sample, filled by launch_edge_fill
 // launch_sample_hist ALWAYS accumulates into PR_HCOPIES x 256 words (`hist` = the control block's copies);
 // launch_hist_reduce sums them into one 256-bin histogram (the exchanged form); launch_prune_bits reads either
 // (hist_is_copies).
@@ -300,7 +291,6 @@ struct SelectState {
 };
 static_assert(offsetof(SelectState, hist) % 16 == 0, "SelectState::hist must be 16-byte aligned");
 
-constexpr int SEL2_COPIES = 4;  // global copies of the select's round-1 histogram when the key kernel takes it (sc_tri.hip 4')
 constexpr int PR_HCOPIES = 4;  // global copies of the pruning-sample histogram (block b adds into copy b % 4): with one
                                // copy a thousand blocks' adds into the same 256 words serialise (C2 sample 34 -> 27 us);
                                // with 16 the readers' 16 loads per bin cost prune_bits what the sample gained
@@ -323,9 +313,6 @@ struct ControlBlock {
   // stage C2's reference frame (sc_gramref.hpp): slot v = the best (key bits << 32 | workgroup) among the workgroups = v (mod 64) of the
   // estimating sample — its voter v is that workgroup's candidate triangle
   alignas(8) unsigned long long ref_slot[64];
-  // --- everything below is used (and cleared per call) only with sc_debug.select_final: 72 KiB the staging kernel need not touch otherwise
-  uint32_t sel2_hist[2048];  // round 2 of launch_select_final
-  uint32_t sel_r1[SEL2_COPIES * 4096];  // round 1, taken by the key kernel: SEL2_COPIES copies by workgroup index
 };
 static_assert(offsetof(ControlBlock, sel) % 16 == 0, "ControlBlock::sel must be 16-byte aligned");
 
@@ -339,8 +326,7 @@ void launch_tri_keys(const Graph& g, const uint64_t* mbits, const float* smin, c
 void launch_tri_keys_events(const Graph& g, const float* es, const uint64_t* toff, int rank_mode,
                             const EventList& ev, uint32_t* wkey, uint2* kcol, uint32_t* blk_minmax,
                             SelectState* s, uint64_t want, const uint32_t* klb, uint64_t E, uint64_t cap,
-                            const Tuning& tn, hipStream_t st, bool check_bound = false,  // cap: entries of wkey / kcol (writes beyond are dropped); want is clipped to toff[E]
-                            bool round1 = false, uint32_t* r1hist = nullptr);  // with klb: also the histogram of the select's first round into r1hist (ControlBlock::sel_r1, zeroed): launch_select_final follows
+                            const Tuning& tn, hipStream_t st, bool check_bound = false);  // cap: entries of wkey / kcol (writes beyond are dropped); want is clipped to toff[E]
 // check_bound: with a pruning bound in *klb the select must find `want` keys at or above it (SelectState::want_req)
 // klb != nullptr (weight ranking, every edge weight >= 2/3): the kernel presets the select window to
 // [*klb or 2.0, 3.0] and no key-range pass runs; two select rounds then always suffice.
@@ -364,12 +350,6 @@ KeyView plain_view(const uint32_t* wkey, uint64_t M);
 // fewer are there
 void launch_select_rounds(const KeyView& view, SelectState* s, int rounds, const Tuning& tn, hipStream_t st,
                           uint64_t* host_short = nullptr);
-// The hot path's select (plain view, a-priori window, round 1's histogram taken by launch_tri_keys_events(round1 = true)): ONE
-// launch finds the threshold key and leaves the per-tile counts launch_compact_write takes (blk_gt / blk_eq: compact_blocks(M)
-// entries each) — select round 1, round 2 and launch_compact_count in one.  lists: select_final_list_words(M) u32 of scratch.
-size_t select_final_list_words(uint64_t M);
-void launch_select_final(const KeyView& view, SelectState* s, const uint32_t* r1hist, uint32_t* hist2, uint32_t* blk_gt, uint32_t* blk_eq,
-                         uint32_t* mlist, uint32_t* mcnt, uint64_t* host_short, hipStream_t st);  // r1hist / hist2: ControlBlock::sel_r1 / sel2_hist
 // compaction of the selected keys in ordinal order
 size_t compact_blocks(uint64_t M);
 void launch_compact_count(const KeyView& view, const SelectState* s, uint32_t* blk_gt, uint32_t* blk_eq,
@@ -377,12 +357,6 @@ void launch_compact_count(const KeyView& view, const SelectState* s, uint32_t* b
 void launch_compact_write(const KeyView& view, const SelectState* s, const uint32_t* blk_gt,
                           const uint32_t* blk_eq, const uint64_t* off_gt, const uint64_t* off_eq,
                           uint64_t* sel_ord, uint32_t* sel_key, uint64_t n_sel, hipStream_t st);  // n_sel: entries sel_ord / sel_key hold
-
-// both in ONE launch (decoupled look-back over the tiles); state: compact_state_bytes(M) of the caller's look-back
-// state area, epoch: this launch's (ScanExtra)
-size_t compact_state_bytes(uint64_t M);
-void launch_compact_fused(const KeyView& view, const SelectState* s, const LbArgs& lb, uint64_t* sel_ord,
-                          uint32_t* sel_key, hipStream_t st);
 
 // ---- sharded stage B: the candidate blob a rank sends, and the merge of the gathered blobs ----
 constexpr int CAND_HDR_WORDS = 32;  // u64 words: [0] triangles enumerated, [1] entries sent, [2] local threshold key,
@@ -464,11 +438,9 @@ void launch_kabsch_aos(const Points& pts, const uint32_t* tri, uint32_t T, float
 // AoS T x 12 -> SoA planes (stage hook for sc_score_host)
 void launch_rt_to_soa(const float* Rt, uint32_t T, uint32_t ld_local, float* RtSoA, hipStream_t st);
 // C2: inlier counts.  partial: n_chunks * ld_local u32 scratch.
-// Two C2 kernels: lane = hypothesis with the points in LDS (the default; every score mode, the matrix-pipe share), and
-// lane = correspondence with the hypothesis in scalar registers (inlier count only; measured slower, Tuning::score_scalar).
-// score_is_scalar says which one a call runs; score_chunks: point chunks that launch will use (rows of `partial`).
-bool score_is_scalar(int score_mode, const Tuning& tn);
-uint32_t score_chunks(int n, uint32_t ld_local, bool scalar);
+// The plain C2 kernel: lane = hypothesis with the points in LDS (every score mode, the matrix-pipe share).
+// score_chunks: point chunks that launch will use (rows of `partial`).
+uint32_t score_chunks(int n, uint32_t ld_local);
 // score_mode: 0 inlier count, 1 truncated squared residual, 2 truncated absolute residual (include/saccot.h)
 // ev0 / ev1 (both or neither): start and stop timestamps taken from the dispatch packets of the stage's first and last kernel
 // (hipExtLaunchKernelGGL) — no extra packet on the stream, unlike a bracket of hipEventRecord calls (~4.5 us each on this part)
@@ -553,14 +525,8 @@ hipError_t filter_read_frame(const void* frame, hipStream_t st, uint32_t out[5])
 // cnt (n_local u32): the per-hypothesis counts (the stage hook returns them).  pairs: argmax_scratch_bytes() of
 // per-block (key, position) pairs; ticket: a zeroed u32 in the control block (left zero).
 size_t argmax_scratch_bytes(uint32_t ld_local);
-// tail_* (all or none; argmax_tail_fits: unsharded, T <= 65536, n <= 32768, sel_key given): the workgroup that takes the last
-// ticket also does launch_finalize's work — winner (R, t) into tail_Rt12, mask, rank index, the pair into tail_key_out, and
-// tail_host_out (pinned, 4 x u64, [0] polled) — so no finalize launch follows.
-bool argmax_tail_fits(int n, uint32_t T, const Shard& sh);
-void launch_argmax(const Points& pts, const Shard& sh, const uint32_t* partial, uint32_t n_chunks, const uint32_t* sel_key,
-                   uint32_t* cnt, uint64_t* pairs, uint32_t* ticket, uint64_t* key2, hipStream_t st,
-                   const float* tail_RtSoA = nullptr, float tau2 = 0.f, float* tail_Rt12 = nullptr, uint8_t* tail_mask = nullptr,
-                   uint64_t* tail_key_out = nullptr, uint64_t* tail_host_out = nullptr);
+void launch_argmax(const Shard& sh, const uint32_t* partial, uint32_t n_chunks, const uint32_t* sel_key,
+                   uint32_t* cnt, uint64_t* pairs, uint32_t* ticket, uint64_t* key2, hipStream_t st);
 // C3: winner decode + re-solve + mask.  Rt12 receives R (row-major) and t; identity / zero mask when key2[0] == 0.
 // sel_key / T: the ordinal-ordered ranking keys (for the winner's rank index); host_out (pinned, 3 x u64) receives
 // key2[0], the winner's position and its rank index.

@@ -150,10 +150,6 @@ void launch_rt_to_soa(const float* Rt, uint32_t T, uint32_t ld_local, float* RtS
 // C2
 // ------------------------------------------------------------------------------------------------
 constexpr int SCORE_THREADS = 256;
-// the lane = correspondence kernel (score_scalar_kernel, below)
-constexpr int SC_P = 8;                    // correspondences per lane
-constexpr int SC_CHUNK = 64 * SC_P;        // correspondences per wave and point chunk
-constexpr int SC_HYPS = 64;                // hypotheses per wave
 constexpr int SCORE_PC = 512;  // correspondences per chunk (LDS: 12 KiB per workgroup, 8 workgroups per CU)
 
 // Point chunking of C2: workgroups = (hypothesis groups of 256) x chunks.  Chunks are as long as LDS allows (512) for
@@ -172,12 +168,10 @@ void score_plan(int n, uint32_t ld_local, uint32_t* chunks, int* chunk_pts) {
   *chunk_pts = per;
   *chunks = (uint32_t)((n + per - 1) / per);
 }
-// Which C2 kernel a call runs: the lane = correspondence mapping counts inliers only and has no matrix-pipe share.
-// (Measured r02 and NOT the default: 114.8 us against 93.9 on C2, 1534 against 1245 on C3 — see score_scalar_kernel.)
-bool score_is_scalar(int score_mode, const Tuning& tn) { return score_mode == 0 && tn.score_split == 0 && tn.score_scalar; }
-
-uint32_t score_chunks(int n, uint32_t ld_local, bool scalar) {
-  if (scalar) return (uint32_t)((n + SC_CHUNK - 1) / SC_CHUNK);
+// (r02 also had a lane = correspondence mapping with the hypothesis in scalar registers: bit-exact, 114.8 us against 93.9 at C2
+// — VALU instructions with a scalar-register operand issue at 4.4 cycles on this part against 3.04 — removed in r05;
+// profiles/r02_* keep its numbers.)
+uint32_t score_chunks(int n, uint32_t ld_local) {
   uint32_t c; int p;
   score_plan(n, ld_local, &c, &p);
   return c;
@@ -343,66 +337,6 @@ __global__ __launch_bounds__(SCORE_THREADS, 8) void score_kernel(const float* __
                     partial);
 }
 
-// ------------------------------------------------------------------------------------------------
-// C2, inlier count, second mapping (r02; built, bit-exact, SLOWER, kept behind sc_debug.score_scalar):
-// lane = CORRESPONDENCE, hypothesis = wave-uniform.
-// A lane keeps SC_P correspondences in registers (6 floats each: no LDS at all); the wave walks its 64 hypotheses, whose 12
-// coefficients arrive by scalar loads and are SGPR operands of the same fma chain (one scalar source per instruction);
-// the inlier test is a v_cmp whose lane mask is counted on the SCALAR unit (s_bcnt1 + s_add) — so a test costs 16 VALU
-// instructions (12 for the residual, 3 for its square norm, 1 compare) instead of 17.5 + 1.5 LDS reads, and the counting
-// runs beside the vector pipe.  A hypothesis with a non-finite coefficient yields a non-finite d2 for every point
-// (finite x inf = inf or NaN, inf - inf = NaN, and squares keep them), i.e. no inlier: the same 0 the other mapping forces.
-// Counts of 64 hypotheses are collected in one VGPR (lane k keeps hypothesis k's) and stored coalesced per (point chunk,
-// hypothesis).
-// Result on MI355X: 16.4 VALU instructions per 64 tests as planned (ISA checked), but they issue at 4.4 cycles each
-// against 3.04 in the lane = hypothesis kernel — VALU instructions that take a scalar-register operand (all of them here)
-// are the slower kind on this part, whatever the scalar unit does beside them (first form: 59 SALU per hypothesis, 122 us;
-// with 21: 114.8 us; the LDS kernel: 93.9 us).
-// ------------------------------------------------------------------------------------------------
-
-__global__ __launch_bounds__(256, 8) void score_scalar_kernel(const float* __restrict__ planes, int n, int ld,
-                                                              const float4* __restrict__ RtAoS, uint32_t ld_local,
-                                                              float tau2, uint32_t* __restrict__ partial) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int m0 = blockIdx.y * SC_CHUNK;
-  float px[SC_P], py[SC_P], pz[SC_P], qx[SC_P], qy[SC_P], qz[SC_P];
-#pragma unroll
-  for (int p = 0; p < SC_P; p++) {
-    const int m = m0 + p * 64 + lane;
-    const bool in = m < n;  // beyond n: p = 0, q = 1e30 -> d2 = +inf, never an inlier (planes are padded to ld >= m only up to ld)
-    px[p] = in ? planes[m] : 0.0f;
-    py[p] = in ? planes[(size_t)ld + m] : 0.0f;
-    pz[p] = in ? planes[2 * (size_t)ld + m] : 0.0f;
-    qx[p] = in ? planes[3 * (size_t)ld + m] : 1e30f;
-    qy[p] = in ? planes[4 * (size_t)ld + m] : 1e30f;
-    qz[p] = in ? planes[5 * (size_t)ld + m] : 1e30f;
-  }
-  const uint32_t h0 = __builtin_amdgcn_readfirstlane((blockIdx.x * 4 + wave) * SC_HYPS);  // first hypothesis of this wave
-  uint32_t acc = 0;  // lane k: count of hypothesis h0 + k over this wave's correspondences
-  // The first form read the twelve coefficients from the SoA planes — twelve scalar loads with their own 64-bit address
-  // arithmetic, 59 SALU instructions per hypothesis — and the ONE scalar unit of the CU, shared by the four SIMDs, became
-  // the limiter (C2 122 us against 93 for the LDS kernel).  From the AoS copy they are three s_load_dwordx4 off one
-  // address; two hypotheses per trip so that one wait covers both loads.
-  const float4* __restrict__ myRt = RtAoS + 3 * (size_t)h0;
-#pragma clang loop unroll_count(2)
-  for (uint32_t k = 0; k < (uint32_t)SC_HYPS; k++) {
-    const float4 c0 = myRt[3 * k], c1 = myRt[3 * k + 1], c2 = myRt[3 * k + 2];  // wave-uniform: scalar loads
-    const float r00 = c0.x, r01 = c0.y, r02 = c0.z, r10 = c0.w, r11 = c1.x, r12 = c1.y, r20 = c1.z, r21 = c1.w, r22 = c2.x;
-    const float t0 = c2.y, t1 = c2.z, t2 = c2.w;
-    uint32_t cnt = 0;  // scalar
-#pragma unroll
-    for (int p = 0; p < SC_P; p++) {
-      const float ex = t0 + fma_(r02, pz[p], fma_(r01, py[p], fma_(r00, px[p], -qx[p])));
-      const float ey = t1 + fma_(r12, pz[p], fma_(r11, py[p], fma_(r10, px[p], -qy[p])));
-      const float ez = t2 + fma_(r22, pz[p], fma_(r21, py[p], fma_(r20, px[p], -qz[p])));
-      const float d2 = fma_(ez, ez, fma_(ey, ey, ex * ex));
-      cnt += (uint32_t)__popcll(__ballot(d2 < tau2));
-    }
-    acc = ((uint32_t)lane == k) ? cnt : acc;  // lane k keeps hypothesis h0 + k's count (2 VALU per 128)
-  }
-  partial[(size_t)blockIdx.y * ld_local + h0 + lane] = acc;
-}
-
 __device__ __forceinline__ unsigned long long block_max_u64(unsigned long long k, unsigned long long* lds) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) {
@@ -420,71 +354,15 @@ __device__ __forceinline__ unsigned long long block_max_u64(unsigned long long k
 // the keys: every block reduces its hypotheses to (best key, lowest position attaining it) and stores the pair; the
 // block that takes the last ticket reduces the pairs and writes key2[0..1] (so key2 needs no zeroing).
 //   key = (count << 32) | second, second = sel_key[g] or, without sel_key, 0xFFFFFFFF - g;  position = 0xFFFFFFFF - g.
-// The winner's own work — C3 (mask), its rank index, (R, t) and the words the host polls for — by ONE workgroup: what
-// finalize_kernel does with a grid, for the unsharded path and selections short enough for a single workgroup's pass over
-// the keys (launch_argmax: the workgroup that takes the arg-max's last ticket goes straight on, no launch in between).
-// BUILT, BIT-EXACT, SLOWER, off by default (sc_debug.tail_fused): one workgroup walks 5000 correspondences and 50 000 keys in
-// ~70 dependent load rounds — the arg-max launch went from 8.6 to 33 us at C2, against 6.4 us for finalize_kernel's grid.
-struct ArgmaxTail {
-  const float* planes; int n, ld;
-  const float* RtSoA;       // the (R, t) planes of this launch's hypotheses (world 1: position g = local index g)
-  uint32_t T;               // entries of sel_key
-  float tau2;
-  float* Rt12; uint8_t* mask;
-  unsigned long long* key_out;   // ControlBlock::key2 (launch_refine reads it)
-  unsigned long long* host_out;  // pinned: [0] key (published last), [1] position, [2] rank index, [3] 0
-};
-__device__ void argmax_tail(const ArgmaxTail& t, const Shard& sh, const uint32_t* __restrict__ sel_key, unsigned long long K,
-                            unsigned long long P) {
-  __shared__ uint64_t lds[8];
-  __shared__ float sRt[12];
-  const uint32_t g = K ? 0xFFFFFFFFu - (uint32_t)(P & 0xFFFFFFFFull) : 0u;  // (a position this very launch produced: < T)
-  if (threadIdx.x < 12) {
-    const float v = K ? t.RtSoA[(size_t)threadIdx.x * sh.ld_local + g] : ((threadIdx.x % 4 == 0 && threadIdx.x < 9) ? 1.f : 0.f);
-    sRt[threadIdx.x] = v;
-    t.Rt12[threadIdx.x] = v;
-  }
-  uint32_t r = 0;
-  if (K) {
-    const uint32_t wk = sel_key[g];
-    const uint32_t T4 = t.T >> 2;
-    const uint4* __restrict__ k4 = reinterpret_cast<const uint4*>(sel_key);
-    for (uint32_t q = threadIdx.x; q < T4; q += 256) {
-      const uint4 v = k4[q];
-      const uint32_t p = q << 2;
-      r += (v.x > wk) || (v.x == wk && p < g);
-      r += (v.y > wk) || (v.y == wk && p + 1 < g);
-      r += (v.z > wk) || (v.z == wk && p + 2 < g);
-      r += (v.w > wk) || (v.w == wk && p + 3 < g);
-    }
-    const uint32_t p = (T4 << 2) + threadIdx.x;
-    if (p < t.T) { const uint32_t kt = sel_key[p]; r += (kt > wk) || (kt == wk && p < g); }
-  }
-  const uint64_t rank = block_reduce_u64(r, lds);  // (also the barrier that publishes sRt)
-  float M[12];
-#pragma unroll
-  for (int c = 0; c < 12; c++) M[c] = sRt[c];
-  const bool live = K != 0ull && finite12(M);
-  for (int m = threadIdx.x; m < t.n; m += 256) {
-    const float d2 = resid2(M, t.planes[m], t.planes[(size_t)t.ld + m], t.planes[2 * (size_t)t.ld + m], t.planes[3 * (size_t)t.ld + m],
-                            t.planes[4 * (size_t)t.ld + m], t.planes[5 * (size_t)t.ld + m]);
-    t.mask[m] = (live && d2 < t.tau2) ? 1 : 0;
-  }
-  if (threadIdx.x == 0) {
-    t.key_out[0] = K; t.key_out[1] = K ? P : 0ull;
-    t.host_out[3] = 0ull;
-    t.host_out[1] = g;
-    t.host_out[2] = K ? rank : 0ull;
-    publish_host(reinterpret_cast<uint64_t*>(t.host_out), K);  // [0] last: the host polls it
-  }
-}
-
+// (r04 let the workgroup that takes the last ticket go on with the winner's own work — mask, rank index, (R, t) — instead of
+// finalize_kernel's launch: bit-exact, and the arg-max launch went from 8.6 to 33 us at C2 against 6.4 us for that kernel's grid
+// (one workgroup walks 5000 correspondences and 50 000 keys in ~70 dependent load rounds); removed in r05.)
 __global__ __launch_bounds__(256) void score_argmax_kernel(const uint32_t* __restrict__ partial, uint32_t n_chunks,
                                                            Shard sh, const uint32_t* __restrict__ sel_key,
                                                            uint32_t* __restrict__ cnt_out,
                                                            unsigned long long* __restrict__ pairs,
                                                            uint32_t* __restrict__ ticket,
-                                                           unsigned long long* __restrict__ key2, ArgmaxTail tail) {
+                                                           unsigned long long* __restrict__ key2) {
   __shared__ unsigned long long lds[4];
   __shared__ uint32_t s_last;
   // grid-stride over the hypotheses: at most 256 workgroups take a ticket (2000 same-address atomics cost ~20 us: C4)
@@ -527,10 +405,6 @@ __global__ __launch_bounds__(256) void score_argmax_kernel(const uint32_t* __res
     key2[0] = K;
     key2[1] = (K != 0 && sel_key) ? P : 0ull;
     __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // ready for the next launch
-  }
-  if (tail.mask) {  // (kernel-uniform) the winner's mask, rank index and (R, t) right here: no finalize launch follows
-    __syncthreads();
-    argmax_tail(tail, sh, sel_key, K, P);
   }
 }
 
@@ -605,7 +479,7 @@ static FilterState filter_state(void* state, const FilterPlan& fp) {
 // r04b; until then tau had to be > ~2 % of the clouds' extent, which left C3 to the linear filter), else the linear one.
 int score_filter_mode(int score_mode, const Tuning& tn, int n, uint32_t ld_local, uint64_t host_max, const uint64_t* host_box,
                       float tau2) {
-  if (score_mode != 0 || tn.score_filter == 1 || tn.score_split != 0 || tn.score_scalar) return 0;
+  if (score_mode != 0 || tn.score_filter == 1 || tn.score_split != 0) return 0;
   if (ld_local == 0 || ld_local / 8 >= (1u << 27)) return 0;
   // beyond 2^36 tests the queue of undecided tests (sized T n / 512 entries: ~20x what the BASELINE scenes need) would
   // pass 1 GB: such calls keep the plain kernel rather than a queue that may overflow into wholesale recounts
@@ -1988,13 +1862,7 @@ hipError_t filter_read_frame(const void* frame, hipStream_t st, uint32_t out[5])
 void launch_score(const Points& pts, const float* RtSoA, const float* RtAoS, const Shard& sh, const Derived& dv,
                   int score_mode, uint32_t* partial, const Tuning& tn, hipStream_t st, hipEvent_t ev0, hipEvent_t ev1) {
   if (sh.n_local == 0) return;
-  if (score_is_scalar(score_mode, tn)) {  // 256 hypotheses per workgroup (4 waves x 64), one point chunk of 512 per wave
-    static_assert(4 * SC_HYPS == 256, "ld_local is a multiple of 256");
-    hipExtLaunchKernelGGL(score_scalar_kernel, dim3(sh.ld_local / 256, score_chunks(pts.n, sh.ld_local, true)), dim3(256), 0, st,
-                          ev0, ev1, 0, pts.planes, pts.n, pts.ld, reinterpret_cast<const float4*>(RtAoS), sh.ld_local, dv.tau2,
-                          partial);
-    return;
-  }
+  (void)RtAoS;
   uint32_t chunks;
   int chunk_pts;
   score_plan(pts.n, sh.ld_local, &chunks, &chunk_pts);
@@ -2016,25 +1884,15 @@ void launch_score(const Points& pts, const float* RtSoA, const float* RtAoS, con
 
 size_t argmax_scratch_bytes(uint32_t ld_local) { return (size_t)(ld_local / 256 + 1) * 2 * sizeof(uint64_t); }
 
-bool argmax_tail_fits(int n, uint32_t T, const Shard& sh) {
-  return sh.world == 1 && sh.n_local != 0 && sh.n_local == T && T <= 65536u && n <= 32768;
-}
-
-void launch_argmax(const Points& pts, const Shard& sh, const uint32_t* partial, uint32_t n_chunks, const uint32_t* sel_key,
-                   uint32_t* cnt, uint64_t* pairs, uint32_t* ticket, uint64_t* key2, hipStream_t st, const float* tail_RtSoA,
-                   float tau2, float* tail_Rt12, uint8_t* tail_mask, uint64_t* tail_key_out, uint64_t* tail_host_out) {
+void launch_argmax(const Shard& sh, const uint32_t* partial, uint32_t n_chunks, const uint32_t* sel_key,
+                   uint32_t* cnt, uint64_t* pairs, uint32_t* ticket, uint64_t* key2, hipStream_t st) {
   if (sh.n_local == 0) {  // nothing scored: the pair is (0, 0)
     (void)hipMemsetAsync(key2, 0, 2 * sizeof(uint64_t), st);
     return;
   }
-  ArgmaxTail tail{};
-  if (tail_mask) {
-    tail = ArgmaxTail{pts.planes, pts.n, pts.ld, tail_RtSoA, sh.T_eff, tau2, tail_Rt12, tail_mask,
-                      reinterpret_cast<unsigned long long*>(tail_key_out), reinterpret_cast<unsigned long long*>(tail_host_out)};
-  }
   const uint32_t blocks = sh.ld_local / 256 < 256 ? sh.ld_local / 256 : 256;
   hipLaunchKernelGGL(score_argmax_kernel, dim3(blocks), dim3(256), 0, st, partial, n_chunks, sh, sel_key, cnt,
-                     reinterpret_cast<unsigned long long*>(pairs), ticket, reinterpret_cast<unsigned long long*>(key2), tail);
+                     reinterpret_cast<unsigned long long*>(pairs), ticket, reinterpret_cast<unsigned long long*>(key2));
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -427,8 +427,7 @@ __global__ __launch_bounds__(256) void tri_count_events_kernel(const uint64_t* _
                                                                StrongList sl, int rank_mode,
                                                                uint32_t* __restrict__ tcnt, EventList ev,
                                                                const uint64_t* __restrict__ own,
-                                                               const uint32_t* __restrict__ ebase, int dbg_stop,
-                                                               GramRefJob ref) {
+                                                               const uint32_t* __restrict__ ebase, GramRefJob ref) {
   // ref (ref.out != null): workgroup 0 is a RIDER — it does none of this kernel's work but votes for the reference frame of
   // stage C2's Gram filter among the candidate triangles the estimating sample left behind (sc_gramref.hpp): ~10 us of one
   // workgroup's latency that would otherwise stand between the selection and the Kabsch launch, hidden under this launch
@@ -454,7 +453,6 @@ __global__ __launch_bounds__(256) void tri_count_events_kernel(const uint64_t* _
     if (threadIdx.x == 0) l_pre[ST_SHARDS] = (uint32_t)tot;
   }
   __syncthreads();
-  if (dbg_stop == 1) return;
   const uint64_t S = l_pre[ST_SHARDS];  // strong edges (only they can carry a triangle of the pruned graph)
   // the part of the flat list this rank walks: everything, or — regions being contiguous edge ranges — the regions its own
   // edge range touches (the others' tcnt entries were zeroed by the pruning kernel)
@@ -521,7 +519,6 @@ __global__ __launch_bounds__(256) void tri_count_events_kernel(const uint64_t* _
         rounds = (W - w0 + TG - 1) / TG;
       }
     }
-    if (dbg_stop == 2) { if (gl == 0 && on) tcnt[e] = rowi + rowj + fa + fb; continue; }
     int wave_rounds = rounds;  // max over the wave: the loop below is wave-uniform
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) wave_rounds = max(wave_rounds, __shfl_xor(wave_rounds, o));
@@ -548,27 +545,7 @@ __global__ __launch_bounds__(256) void tri_count_events_kernel(const uint64_t* _
     }
     if (gl == 0 && on) tcnt[e] = c;  // weak edges were zeroed by prune_bits_kernel
   }
-  if (dbg_stop == 3) return;
   if (scnt) flush();
-}
-
-// The select over the a-priori window [lo, 3.0] in two rounds that split its bits evenly (at most 11 + 11: the window is at
-// most the binade [2, 4)); shared by the key kernel (which takes round 1's histogram) and select_final_kernel.
-constexpr int SEL2_BINS = 4096;   // bins of round 1 (12 bits at most)
-constexpr int SEL2_BINS2 = 2048;  // bins of round 2 (11 bits at most: exact key values)
-static_assert(SEL2_COPIES == 4 && SEL2_BINS == 4096, "ControlBlock::sel_r1");
-struct Sel2Split { uint32_t wbits, shift1, nbins1; };
-__device__ __forceinline__ Sel2Split sel2_split(uint32_t lo) {
-  const uint32_t range_m1 = 0x40400000u - lo;  // 3.0f
-  Sel2Split s;
-  s.wbits = range_m1 == 0 ? 0u : (uint32_t)(32 - __builtin_clz(range_m1));
-  // round 1 takes as many bits as it may (12): its bins are filled by global atomics from every workgroup of the key kernel, and
-  // what those cost is the number of adds that meet on ONE address (~12 ns each, serialised) — with the bits split evenly (512
-  // bins at C2) the key kernel went from 9 to 20 us; round 2's bins are exact key values either way
-  const uint32_t b1 = s.wbits < 12u ? s.wbits : 12u;
-  s.shift1 = s.wbits - b1;
-  s.nbins1 = 1u << b1;
-  return s;
 }
 
 // one lane per event
@@ -583,27 +560,12 @@ __global__ __launch_bounds__(256) void tri_keys_events_kernel(const uint64_t* __
                                                               uint32_t* __restrict__ blk_max,
                                                               SelectState* __restrict__ preset,
                                                               const uint32_t* __restrict__ klb, uint64_t want,
-                                                              uint64_t E, uint64_t cap, int check_bound,
-                                                              uint32_t* __restrict__ r1hist) {
-  // r1hist (optional, with preset; SEL2_BINS zeroed words): the histogram of the select's FIRST round over the a-priori window,
-  // taken here, where the keys are made (select_final_kernel reads it: one launch instead of select round 1)
+                                                              uint64_t E, uint64_t cap, int check_bound) {
   // cap: entries wkey / kcol hold.  The host may launch this kernel BEFORE it knows the triangle count (into the
   // arrays of the previous call, while it polls for the count): writes beyond cap are dropped and the host re-runs.
   // For the same reason `want` is clipped here to the count the scan left in toff[E].
   __shared__ uint32_t lmin[4], lmax[4];
   __shared__ uint64_t pre[EV_SHARDS + 1];
-  // What the histogram costs is the number of adds that meet on ONE global address (~12 ns each, serialised at the memory side):
-  // with a key per add, or 2048 workgroups each adding its own LDS copy, the hottest bin held the launch back by 9 - 11 us.  So:
-  // few workgroups (launch_tri_keys_events: 512 when the histogram rides along — about an event per thread at C2), an LDS copy
-  // each, and SEL2_COPIES global copies by workgroup index: at most 128 adds per address.
-  __shared__ uint32_t lh1[SEL2_BINS];
-  uint32_t h_lo = 0, h_shift = 0, h_bins = 0;
-  if (r1hist) {  // (kernel-uniform) the window every block bins by: the one block 0 presets below
-    h_lo = *klb ? *klb : 0x40000000u;
-    const Sel2Split sp = sel2_split(h_lo);
-    h_shift = sp.shift1; h_bins = sp.nbins1;
-    for (uint32_t b = threadIdx.x; b < h_bins; b += 256) lh1[b] = 0u;
-  }
   // Weight keys of a graph whose edges all weigh >= 2/3 live in one binade, [2.0, 3.0]: the select window is known
   // before a single key exists — [certified bound (or 2.0), 3.0] — so no key-range pass, and two 12-bit rounds
   // always resolve it.  (Keys below a certified bound cannot be among the `want` largest: sc_tri.hip 3b.)
@@ -665,7 +627,6 @@ __global__ __launch_bounds__(256) void tri_keys_events_kernel(const uint64_t* __
             if (q < nbits) {
               const uint32_t key = __float_as_uint((s_ij + s_ik[q]) + s_jk[q]);
               if (out < cap) { kcol[out] = make_uint2(kbase + (uint32_t)b[q], e); wkey[out] = key; }
-              if (r1hist && key >= h_lo) atomicAdd(&lh1[(key - h_lo) >> h_shift], 1u);  // (keys never pass 3.0: inside the window)
               out++;
               kmin = min(kmin, key);
               kmax = max(kmax, key);
@@ -695,13 +656,6 @@ __global__ __launch_bounds__(256) void tri_keys_events_kernel(const uint64_t* __
   if (threadIdx.x == 0) {
     blk_min[blockIdx.x] = min(min(lmin[0], lmin[1]), min(lmin[2], lmin[3]));
     blk_max[blockIdx.x] = max(max(lmax[0], lmax[1]), max(lmax[2], lmax[3]));
-  }
-  if (r1hist) {  // (the barrier above also orders the LDS adds)
-    uint32_t* __restrict__ mine = r1hist + (size_t)(blockIdx.x & (SEL2_COPIES - 1)) * SEL2_BINS;
-    for (uint32_t b = threadIdx.x; b < h_bins; b += 256) {
-      const uint32_t v = lh1[b];
-      if (v) atomicAdd(&mine[b], v);
-    }
   }
 }
 
@@ -744,7 +698,7 @@ void launch_tri_count_events(const Graph& g, const uint64_t* mbits, const Strong
   if (tn.cnt_blocks >= 1 && tn.cnt_blocks <= 65535) nb = tn.cnt_blocks;
   const GramRefJob rj = ref ? *ref : GramRefJob{};
   if (rj.out) nb++;  // (workgroup 0 is the rider)
-#define SC_LAUNCH_CE(TGV) hipLaunchKernelGGL(tri_count_events_kernel<TGV>, dim3((unsigned)nb), dim3(256), 0, st, mbits, g.W, g.deg, ebi, ebj, ei, ej, sl, rank_mode, tcnt, ev, own, ebase, (int)tn.dbg_stop, rj)
+#define SC_LAUNCH_CE(TGV) hipLaunchKernelGGL(tri_count_events_kernel<TGV>, dim3((unsigned)nb), dim3(256), 0, st, mbits, g.W, g.deg, ebi, ebj, ei, ej, sl, rank_mode, tcnt, ev, own, ebase, rj)
   if (tg == 4) SC_LAUNCH_CE(4); else if (tg == 16) SC_LAUNCH_CE(16); else if (tg == 32) SC_LAUNCH_CE(32); else if (tg == 64) SC_LAUNCH_CE(64); else SC_LAUNCH_CE(8);
 #undef SC_LAUNCH_CE
 }
@@ -752,12 +706,12 @@ void launch_tri_count_events(const Graph& g, const uint64_t* mbits, const Strong
 void launch_tri_keys_events(const Graph& g, const float* es, const uint64_t* toff, int rank_mode,
                             const EventList& ev, uint32_t* wkey, uint2* kcol, uint32_t* blk_minmax,
                             SelectState* s, uint64_t want, const uint32_t* klb, uint64_t E, uint64_t cap,
-                            const Tuning& tn, hipStream_t st, bool check_bound, bool round1, uint32_t* r1hist) {
-  int nb = (klb && round1) ? 512 : 2048;  // (with the histogram: few workgroups — see the kernel)
+                            const Tuning& tn, hipStream_t st, bool check_bound) {
+  int nb = 2048;
   if (tn.keys_blocks >= 1 && tn.keys_blocks <= (uint32_t)TK_MAX_BLOCKS) nb = (int)tn.keys_blocks;
   hipLaunchKernelGGL(tri_keys_events_kernel, dim3(nb), dim3(256), 0, st, g.bits, g.wpre, g.deg, es, toff, rank_mode,
                      ev, wkey, kcol, blk_minmax, blk_minmax + TK_MAX_BLOCKS, klb ? s : (SelectState*)nullptr, klb, want, E, cap,
-                     check_bound ? 1 : 0, (klb && round1) ? r1hist : (uint32_t*)nullptr);
+                     check_bound ? 1 : 0);
   if (!klb)  // no a-priori window: the key range comes from the per-block extremes
     hipLaunchKernelGGL(key_range_kernel, dim3(1), dim3(1024), 0, st, blk_minmax, blk_minmax + TK_MAX_BLOCKS, nb, s, want);
 }
@@ -819,23 +773,6 @@ __device__ __forceinline__ uint32_t weight_bin(uint32_t wbits, uint32_t wlo, uin
   const uint32_t lb = __float_as_uint(1.0f - __uint_as_float(wbits)) >> 20;  // sign 0, exponent, 3 mantissa bits
   const int b = (int)(103u << 3) + 255 - (int)lb;                              // 2^-24 has exponent field 103
   return (uint32_t)(b < 0 ? 0 : (b > 255 ? 255 : b));
-}
-
-// 256-bin histogram of the edge weights over [wlo, 1.0], ES_HCOPIES global copies (block b adds into copy b % copies)
-__global__ __launch_bounds__(256) void es_hist_kernel(const float* __restrict__ es, uint64_t E, uint32_t wlo,
-                                                      uint32_t wshift, uint32_t* __restrict__ hist) {
-  __shared__ uint32_t lh[PR_BINS * PR_COPIES];
-  for (int b = threadIdx.x; b < PR_BINS * PR_COPIES; b += 256) lh[b] = 0;
-  __syncthreads();
-  const uint64_t stride = (uint64_t)gridDim.x * 256;
-  for (uint64_t e = (uint64_t)blockIdx.x * 256 + threadIdx.x; e < E; e += stride)
-    atomicAdd(&lh[weight_bin(__float_as_uint(es[e]), wlo, wshift) * PR_COPIES + (threadIdx.x & (PR_COPIES - 1))], 1u);
-  __syncthreads();
-  uint32_t* __restrict__ myh = hist + (size_t)(blockIdx.x & (PR_HCOPIES - 1)) * PR_BINS;
-  uint32_t v = 0;
-#pragma unroll
-  for (int c = 0; c < PR_COPIES; c++) v += lh[threadIdx.x * PR_COPIES + ((c + threadIdx.x) & (PR_COPIES - 1))];
-  if (v) atomicAdd(&myh[threadIdx.x], v);
 }
 
 template <int TG, bool TOP>
@@ -1013,8 +950,7 @@ __global__ __launch_bounds__(256) void tri_sample_words_kernel(const uint64_t* _
                                                                const float* __restrict__ es, uint64_t E, uint32_t rmask,
                                                                uint32_t* __restrict__ hist,
                                                                const uint64_t* __restrict__ E_dev,
-                                                               const uint32_t* __restrict__ ebase, int dbg_stop,
-                                                               uint4* __restrict__ cand,
+                                                               const uint32_t* __restrict__ ebase, uint4* __restrict__ cand,
                                                                unsigned long long* __restrict__ cand_slot) {
   // ebase (with ebi == ebj == nullptr): the per-row CSR bases are looked up (after launch_edge_build)
   // cand (optional): the best-keyed triangle this workgroup sampled, {key bits, i, j, k} (key 0: none) — the voters of stage
@@ -1032,17 +968,15 @@ __global__ __launch_bounds__(256) void tri_sample_words_kernel(const uint64_t* _
   for (uint64_t e = (uint64_t)blockIdx.x * 256 + threadIdx.x; e < E; e += stride) {
     const uint32_t j = ej[e], i = ei[e];
     const int w0 = (int)(j >> 6);
-    // the first word >= w0 in this edge's residue class (hashed by its END POINTS, as edge_build_kernel does: same sample)
+    // the first word >= w0 in this edge's residue class (hashed by its END POINTS: the sample does not depend on the edge numbering)
     int w = w0 + (int)((edge_hash(i * 0x9E3779B1u + j) - (uint32_t)w0) & rmask);
     if (w >= W) continue;
-    if (dbg_stop == 1) { if (i == 0xFFFFFFFFu) lh[0] = j; continue; }
     const uint32_t rowi = i * (uint32_t)W, rowj = j * (uint32_t)W;
     for (; w < W; w += (int)rmask + 1) {
       const uint64_t ai = bits[rowi + w], aj = bits[rowj + w];
       uint64_t m = ai & aj;
       if (w == w0) m &= mask_above((int)(j & 63));
       if (m == 0) continue;
-      if (dbg_stop == 2) { atomicAdd(&lh[(uint32_t)__popcll(m) * PR_COPIES], 1u); continue; }
       // only the lanes that found a triangle pay for the edge's weight and CSR bases (one memory level, beside the prefix words)
       const float s_ij = es[e];
       const uint32_t bi = ebi ? ebi[e] : ebase[i], bj = ebj ? ebj[e] : ebase[j];
@@ -1097,27 +1031,24 @@ __global__ __launch_bounds__(256) void tri_sample_words_kernel(const uint64_t* _
 }
 
 // ------------------------------------------------------------------------------------------------
-// 1'. edge_build (r04): everything between stage A and the pruning in ONE launch — the hot path's form of
-//     row_stats_scan + edge_fill + the estimating sample (three launches, 43 us at C2).
+// 1'. edge_build (r04): everything between stage A and the estimating sample in ONE launch — the hot path's form of
+//     row_stats_scan + edge_fill (two launches, 29.5 us at C2).
 //
 // What made the row kernel a launch of its own was the prefix over the rows: a wave cannot place row i's edges before it
 // knows how many edges the rows before it hold, and counting them meant reading their bit rows.  Stage A now leaves
 // deg+[i] behind (atomics where the adjacency words are made, sc_compat.hip), so a workgroup of EBK_ROWS waves sums
 // deg+[0 .. its first row) itself — a few 16-byte loads per thread, no look-back, no cross-workgroup dependency — and then
 // each wave, for its row: word-prefix popcounts (wpre), the CSR offset and base, the strong-bit row cleared, the row's
-// edges with their recomputed weights (as edge_fill_kernel), and the row's share of the ESTIMATING sample (3c).
-// The sample cannot look up s_ik / s_jk in the edge arrays — they are being written by this very launch — so it recomputes
-// them from the three correspondences with the same chain (bit-identical, though an estimate would not need that): sampled
-// triangles are collected in a per-wave LDS queue and evaluated 64 at a time, all lanes busy (evaluating them where they
-// are found would cost a divergent ~170-instruction body per set bit).
+// edges with their recomputed weights (as edge_fill_kernel).
+// (r04 also took the ESTIMATING sample here — sampled triangles recomputed from the correspondences through a per-wave LDS
+// queue: 50.3 us against 16.4 + 13.7 for the two launches, a dense row being one wave's serial chain; removed in r05,
+// profiles/r04_ab_edge_build.txt keeps the numbers.)
 // The CSR bases of an edge's OTHER end (ebj) are not known here (row j's wave may not have run): the counting pass looks
 // them up in ebase instead (one more gather, beside its row loads).  n <= 64 * EBK_WMAX only.
 // ------------------------------------------------------------------------------------------------
 constexpr int EBK_ROWS = 8;     // rows (waves) per workgroup
 constexpr int EBK_CH = 256;     // column indices staged per wave and chunk
 constexpr int EBK_WMAX = 320;   // words per bit row it can handle (n <= 20 480): NCH = 2 chunks of 64 words up to 8192, 5 beyond
-constexpr int EBK_Q = 128;      // sampled triangles queued per wave (drained at 64)
-constexpr int EBK_HC = 4;       // LDS copies of the key histogram
 
 template <int NCH>  // 64-word chunks of a bit row: W <= 64 NCH
 __global__ __launch_bounds__(64 * EBK_ROWS) void edge_build_kernel(const uint64_t* __restrict__ bits,
@@ -1129,17 +1060,11 @@ __global__ __launch_bounds__(64 * EBK_ROWS) void edge_build_kernel(const uint64_
                                                                    uint32_t* __restrict__ ebase,
                                                                    uint32_t* __restrict__ ei, uint32_t* __restrict__ ej,
                                                                    float* __restrict__ es, uint64_t cap,
-                                                                   uint64_t* __restrict__ host_total, uint32_t rmask,
-                                                                   uint32_t* __restrict__ hist) {
+                                                                   uint64_t* __restrict__ host_total) {
   __shared__ uint64_t s_red[EBK_ROWS];
   __shared__ uint32_t l_j[EBK_ROWS][EBK_CH];
-  __shared__ uint64_t l_row[EBK_ROWS][64 * NCH];
-  __shared__ uint32_t q_j[EBK_ROWS][EBK_Q], q_k[EBK_ROWS][EBK_Q];
-  __shared__ float q_s[EBK_ROWS][EBK_Q];
-  __shared__ uint32_t lh[PR_BINS * EBK_HC];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r0 = blockIdx.x * EBK_ROWS, i = r0 + wave;
-  for (int b = tid; b < PR_BINS * EBK_HC; b += 64 * EBK_ROWS) lh[b] = 0u;
   // edges of the rows before this workgroup's (r0 is a multiple of 4: whole 16-byte pieces)
   uint64_t acc = 0;
   for (int q = tid * 4; q < r0; q += 64 * EBK_ROWS * 4) {
@@ -1150,149 +1075,88 @@ __global__ __launch_bounds__(64 * EBK_ROWS) void edge_build_kernel(const uint64_
   for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
   if (lane == 0) s_red[wave] = acc;
   __syncthreads();
-  if (i < n) {
-    uint64_t my_off = 0;
+  if (i >= n) return;
+  uint64_t my_off = 0;
 #pragma unroll
-    for (int w8 = 0; w8 < EBK_ROWS; w8++) my_off += s_red[w8];
-    for (int r = r0; r < i; r++) my_off += degp[r];  // wave-uniform: scalar loads
-    const int wi = i >> 6, bi = i & 63;
-    const float4* __restrict__ aos4 = reinterpret_cast<const float4*>(planes + 6 * (size_t)ld);
-    const float pix = planes[i], piy = planes[ld + i], piz = planes[2 * ld + i];
-    const float qix = planes[3 * ld + i], qiy = planes[4 * ld + i], qiz = planes[5 * ld + i];
-    uint64_t* const myrow = l_row[wave];
-    // ---- the row's words: prefix popcounts, the strong row cleared, the words kept for the sample
-    uint32_t d_all = 0, d_low = 0;
-    uint64_t up[NCH];
+  for (int w8 = 0; w8 < EBK_ROWS; w8++) my_off += s_red[w8];
+  for (int r = r0; r < i; r++) my_off += degp[r];  // wave-uniform: scalar loads
+  const int wi = i >> 6, bi = i & 63;
+  const float4* __restrict__ aos4 = reinterpret_cast<const float4*>(planes + 6 * (size_t)ld);
+  const float pix = planes[i], piy = planes[ld + i], piz = planes[2 * ld + i];
+  const float qix = planes[3 * ld + i], qiy = planes[4 * ld + i], qiz = planes[5 * ld + i];
+  // ---- the row's words: prefix popcounts, the strong row cleared
+  uint32_t d_all = 0, d_low = 0;
+  uint64_t up[NCH];
 #pragma unroll
-    for (int c = 0; c < NCH; c++) {
-      const int w = 64 * c + lane;
-      const uint64_t v = w < W ? bits[(size_t)i * W + w] : 0ull;
-      myrow[w] = v;
-      const uint32_t pc = (uint32_t)__popcll(v);
-      uint32_t tot;
-      const uint32_t ex = group_exscan<64>(pc, &tot);
-      if (w < W) {
-        wpre[(size_t)i * W + w] = d_all + ex;
-        zero_rows[(size_t)i * W + w] = 0ull;
-      }
-      d_all += tot;
-      const uint64_t below = (1ull << bi) - 1ull;
-      d_low += w < wi ? pc : (w == wi ? (uint32_t)__popcll(v & below) : 0u);
-      up[c] = w < wi ? 0ull : (w == wi ? (v & mask_above(bi)) : v);
+  for (int c = 0; c < NCH; c++) {
+    const int w = 64 * c + lane;
+    const uint64_t v = w < W ? bits[(size_t)i * W + w] : 0ull;
+    const uint32_t pc = (uint32_t)__popcll(v);
+    uint32_t tot;
+    const uint32_t ex = group_exscan<64>(pc, &tot);
+    if (w < W) {
+      wpre[(size_t)i * W + w] = d_all + ex;
+      zero_rows[(size_t)i * W + w] = 0ull;
     }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) d_low += __shfl_xor(d_low, o);
-    const uint32_t my_base = (uint32_t)my_off - d_low;
-    if (lane == 0) { edge_off[i] = my_off; ebase[i] = my_base; }
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // myrow is read by index below (LDS is in-order within a wave)
-    // ---- edges, chunk by chunk, and the sampled triangles they own
-    uint32_t qn = 0;  // sampled triangles queued (wave-uniform)
-    auto evaluate = [&](uint32_t idx) {  // the key of queued triangle idx -> histogram
-      const uint32_t j = q_j[wave][idx], k = q_k[wave][idx];
-      const float s_ij = q_s[wave][idx];
-      const float4 ja = aos4[2 * (size_t)j], jb = aos4[2 * (size_t)j + 1];
-      const float4 ka = aos4[2 * (size_t)k], kb = aos4[2 * (size_t)k + 1];
-      bool edge;
-      const float s_ik = pair_weight(dist3(pix, piy, piz, ka.x, ka.y, ka.z), dist3(qix, qiy, qiz, ka.w, kb.x, kb.y), dv.d_thr,
-                                     dv.min_len, dv.neg_inv2sig2, edge);
-      const float s_jk = pair_weight(dist3(ja.x, ja.y, ja.z, ka.x, ka.y, ka.z), dist3(ja.w, jb.x, jb.y, ka.w, kb.x, kb.y), dv.d_thr,
-                                     dv.min_len, dv.neg_inv2sig2, edge);
-      atomicAdd(&lh[est_bin(__float_as_uint((s_ij + s_ik) + s_jk)) * EBK_HC + (lane & (EBK_HC - 1))], 1u);
-    };
-    uint64_t ebase_row = my_off;
-#pragma unroll
-    for (int c = 0; c < NCH; c++) {
-      const int w = 64 * c + lane;
-      const uint64_t v = up[c];
-      uint32_t tot;
-      const uint32_t r = group_exscan<64>((uint32_t)__popcll(v), &tot);
-      for (uint32_t c0 = 0; c0 < tot; c0 += EBK_CH) {  // wave-uniform
-        uint64_t vv = v;
-        uint32_t rr = r - c0;  // modular: positions outside [0, EBK_CH) are skipped
-        while (vv) {
-          const int b = __builtin_ctzll(vv);
-          vv &= vv - 1;
-          if (rr < (uint32_t)EBK_CH) l_j[wave][rr] = (uint32_t)(w * 64 + b);
-          rr++;
-        }
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        const uint32_t cnt = min((uint32_t)EBK_CH, tot - c0);
-        for (uint32_t t0 = 0; t0 < cnt; t0 += 64) {  // wave-uniform
-          const uint32_t t = t0 + lane;
-          const bool on = t < cnt;
-          const uint32_t j = on ? l_j[wave][t] : 0u;
-          float sw = 0.f;
-          int ws = W;  // the next sampled word of this lane's edge (W: none)
-          if (on) {
-            const uint64_t e = ebase_row + c0 + t;
-            const float4 a4 = aos4[2 * (size_t)j], b4 = aos4[2 * (size_t)j + 1];
-            bool edge;
-            sw = pair_weight(dist3(pix, piy, piz, a4.x, a4.y, a4.z), dist3(qix, qiy, qiz, a4.w, b4.x, b4.y), dv.d_thr, dv.min_len,
-                             dv.neg_inv2sig2, edge);
-            if (e < cap) { ei[e] = (uint32_t)i; ej[e] = j; es[e] = sw; }
-            const int w0 = (int)(j >> 6);
-            if (hist) ws = w0 + (int)((edge_hash((uint32_t)i * 0x9E3779B1u + j) - (uint32_t)w0) & rmask);  // (hist == nullptr: no sample here)
-          }
-          // sampled words of the 64 edges: found triangles go to the queue, one per lane and trip
-          while (__ballot(ws < W) != 0) {  // wave-uniform
-            uint64_t m = 0;
-            const int wcur = ws;
-            if (ws < W) {
-              m = myrow[ws] & bits[(size_t)j * W + ws];
-              if (ws == (int)(j >> 6)) m &= mask_above((int)(j & 63));
-              ws += (int)rmask + 1;
-            }
-            uint64_t bal;
-            while ((bal = __ballot(m != 0)) != 0) {  // wave-uniform
-              if (m != 0) {
-                const uint32_t slot = qn + __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
-                q_j[wave][slot] = j; q_k[wave][slot] = (uint32_t)(wcur * 64 + __builtin_ctzll(m)); q_s[wave][slot] = sw;
-                m &= m - 1;
-              }
-              qn += (uint32_t)__popcll(bal);
-              if (qn >= 64u) {  // (qn < 64 before the push, <= 127 after: EBK_Q = 128 holds it)
-                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-                qn -= 64u;
-                evaluate(qn + (uint32_t)lane);
-                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-              }
-            }
-          }
-        }
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // l_j is rewritten by the next chunk
-      }
-      ebase_row += tot;
-    }
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    if ((uint32_t)lane < qn) evaluate((uint32_t)lane);
-    if (i == n - 1 && lane == 0) {  // the last row's wave knows the edge count: the host polls for it
-      edge_off[n] = ebase_row;
-      publish_host(host_total, ebase_row);
-    }
+    d_all += tot;
+    const uint64_t below = (1ull << bi) - 1ull;
+    d_low += w < wi ? pc : (w == wi ? (uint32_t)__popcll(v & below) : 0u);
+    up[c] = w < wi ? 0ull : (w == wi ? (v & mask_above(bi)) : v);
   }
-  if (!hist) return;  // (kernel-uniform)
-  __syncthreads();
-  uint32_t* __restrict__ myh = hist + (size_t)(blockIdx.x & (PR_HCOPIES - 1)) * PR_BINS;
-  for (int b = tid; b < PR_BINS; b += 64 * EBK_ROWS) {
-    uint32_t v = 0;
 #pragma unroll
-    for (int c = 0; c < EBK_HC; c++) v += lh[b * EBK_HC + c];
-    if (v) atomicAdd(&myh[b], v);
+  for (int o = 32; o > 0; o >>= 1) d_low += __shfl_xor(d_low, o);
+  const uint32_t my_base = (uint32_t)my_off - d_low;
+  if (lane == 0) { edge_off[i] = my_off; ebase[i] = my_base; }
+  // ---- edges, chunk by chunk
+  uint64_t ebase_row = my_off;
+#pragma unroll
+  for (int c = 0; c < NCH; c++) {
+    const int w = 64 * c + lane;
+    const uint64_t v = up[c];
+    uint32_t tot;
+    const uint32_t r = group_exscan<64>((uint32_t)__popcll(v), &tot);
+    for (uint32_t c0 = 0; c0 < tot; c0 += EBK_CH) {  // wave-uniform
+      uint64_t vv = v;
+      uint32_t rr = r - c0;  // modular: positions outside [0, EBK_CH) are skipped
+      while (vv) {
+        const int b = __builtin_ctzll(vv);
+        vv &= vv - 1;
+        if (rr < (uint32_t)EBK_CH) l_j[wave][rr] = (uint32_t)(w * 64 + b);
+        rr++;
+      }
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // LDS is in-order within a wave
+      const uint32_t cnt = min((uint32_t)EBK_CH, tot - c0);
+      for (uint32_t t = lane; t < cnt; t += 64) {
+        const uint32_t j = l_j[wave][t];
+        const uint64_t e = ebase_row + c0 + t;
+        if (e >= cap) continue;
+        const float4 a4 = aos4[2 * (size_t)j], b4 = aos4[2 * (size_t)j + 1];
+        bool edge;
+        const float sw = pair_weight(dist3(pix, piy, piz, a4.x, a4.y, a4.z), dist3(qix, qiy, qiz, a4.w, b4.x, b4.y), dv.d_thr, dv.min_len,
+                                     dv.neg_inv2sig2, edge);
+        ei[e] = (uint32_t)i; ej[e] = j; es[e] = sw;
+      }
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // l_j is rewritten by the next chunk
+    }
+    ebase_row += tot;
+  }
+  if (i == n - 1 && lane == 0) {  // the last row's wave knows the edge count: the host polls for it
+    edge_off[n] = ebase_row;
+    publish_host(host_total, ebase_row);
   }
 }
 
 bool edge_build_fits(int n) { return n <= 64 * EBK_WMAX; }
 
 void launch_edge_build(const Graph& g, const Points& pts, const Derived& dv, uint64_t* zero_rows, uint64_t* edge_off, uint32_t* ebase,
-                       uint32_t* ei, uint32_t* ej, float* es, uint64_t cap, uint64_t* host_total, uint32_t rate, uint32_t* hist,
-                       hipStream_t st) {
+                       uint32_t* ei, uint32_t* ej, float* es, uint64_t cap, uint64_t* host_total, hipStream_t st) {
   const dim3 grid((g.n + EBK_ROWS - 1) / EBK_ROWS), block(64 * EBK_ROWS);
   if (g.W <= 128)
     hipLaunchKernelGGL(edge_build_kernel<2>, grid, block, 0, st, g.bits, pts.planes, dv, g.n, g.ld, g.W, g.degp,
-                       const_cast<uint32_t*>(g.wpre), zero_rows, edge_off, ebase, ei, ej, es, cap, host_total, rate - 1u, hist);
+                       const_cast<uint32_t*>(g.wpre), zero_rows, edge_off, ebase, ei, ej, es, cap, host_total);
   else
     hipLaunchKernelGGL(edge_build_kernel<5>, grid, block, 0, st, g.bits, pts.planes, dv, g.n, g.ld, g.W, g.degp,
-                       const_cast<uint32_t*>(g.wpre), zero_rows, edge_off, ebase, ei, ej, es, cap, host_total, rate - 1u, hist);
+                       const_cast<uint32_t*>(g.wpre), zero_rows, edge_off, ebase, ei, ej, es, cap, host_total);
 }
 
 // sum of the copies -> one 256-bin histogram (the form the ranks exchange)
@@ -1399,7 +1263,7 @@ static void prune_window(float key_floor, uint32_t* klo_out, uint32_t* shift_out
 
 void launch_sample_hist(const Graph& g, const uint32_t* ebi, const uint32_t* ebj, const uint32_t* ei,
                         const uint32_t* ej, const float* es, uint64_t E, uint64_t want, float key_floor, uint32_t part,
-                        uint32_t parts, uint32_t* hist, uint32_t* es_hist, bool es_hist_ready, const Tuning& tn, hipStream_t st,
+                        uint32_t parts, uint32_t* hist, uint32_t* es_hist, const Tuning& tn, hipStream_t st,
                         const uint64_t* E_dev, uint64_t E_hint) {
   uint32_t klo, shift;
   prune_window(key_floor, &klo, &shift);
@@ -1428,10 +1292,6 @@ void launch_sample_hist(const Graph& g, const uint32_t* ebi, const uint32_t* ebj
       wlo = lo; wshift = bitsn > 8 ? (uint32_t)(bitsn - 8) : 0u;
     }
     uint64_t target = tn.sample_edges ? tn.sample_edges : (want / 3 < 16384 ? 16384 : want / 3);
-    uint64_t hb = (E + 4095) / 4096;
-    if (hb > 1024) hb = 1024;
-    if (hb < 1) hb = 1;
-    if (!es_hist_ready) hipLaunchKernelGGL(es_hist_kernel, dim3((unsigned)hb), dim3(256), 0, st, es, E, wlo, wshift, es_hist);
     const int tg = tn.tg_sample ? tn.tg_sample : (g.W > 256 ? 32 : 16);  // C3 (W = 313): 134 (16) vs 107 us (32); C2: 24.4 vs 25.9
     uint64_t nb = (E + (uint64_t)SM_CHUNK * parts - 1) / ((uint64_t)SM_CHUNK * parts);
     if (nb > 8192) nb = 8192;
@@ -1509,7 +1369,7 @@ void launch_sample_estimate(const Graph& g, const uint32_t* ebi, const uint32_t*
   (void)key_floor;  // (the logarithmic bins need no window)
   const uint32_t nb = sample_estimate_blocks(E, tn);
   hipLaunchKernelGGL(tri_sample_words_kernel, dim3(nb), dim3(256), 0, st, g.bits, g.W, g.wpre, ebi, ebj, ei, ej, es, E,
-                     rate - 1u, hist, E_dev, ebase, (int)tn.dbg_stop, cand_slot ? cand : nullptr, cand_slot);
+                     rate - 1u, hist, E_dev, ebase, cand_slot ? cand : nullptr, cand_slot);
 }
 
 void launch_prune_bits(const Graph& g, const uint32_t* hist, bool hist_is_copies, const uint32_t* ei, const uint32_t* ej, const float* es,
@@ -1828,198 +1688,6 @@ __global__ __launch_bounds__(SEL_THREADS) void select_round_kernel(KeyView view,
   }
 }
 
-// ------------------------------------------------------------------------------------------------
-// 4'. the select in ONE launch after the key kernel (r04; VERDICT r03 #2 (i) asked for round 1's histogram inside
-//     tri_keys_events).  BUILT, BIT-EXACT, NOT FASTER — off by default (sc_debug.select_final):
-//       C2, 186 k keys:  key kernel 8.9 us + round 1 7.7 + round 2 7.7 + compact_count 4.7 = 29.0 us   (the default)
-//                        key kernel with the histogram 13.7 + select_final 17.7               = 31.4 us   (this)
-//     Why: a histogram filled by global atomics costs the adds that meet on its hottest address (~12 ns each): one add per key
-//     20 us for the key kernel, an LDS copy per workgroup of 2048 18 - 20 us, 512 workgroups and four global copies 13.7 — and
-//     then every workgroup of the select walks 4 x 4096 bins before it can start.  The two rounds it replaces are ~5 us of
-//     launch floor + ticket each; there is little left to win.
-//   What it does:
-//   round 1's histogram arrives with the keys (tri_keys_events_kernel); every workgroup here walks it (2048 bins at most:
-//   a block scan) and knows the window of round 2 — one bin of round 1, at most 2^11 keys wide, so its bins are EXACT keys;
-//   a workgroup takes whole 1024-key tiles: keys above the window are selected for sure and counted per tile; keys inside it
-//   (a few hundred in the whole array) go into round 2's histogram and into the tile's short list;
-//   the workgroup that takes the last ticket finds k* and the number of keys == k* to keep, and settles the listed keys:
-//   per tile #(> k*) joins the sure count, #(== k*) is the tile's "equal" count — exactly what compact_write_kernel wants.
-// A tile with more in-window keys than its list holds (massive ties) is recounted by the last workgroup from the keys.
-// ------------------------------------------------------------------------------------------------
-constexpr int SEL2_SEG = 32;  // in-window keys a tile can list (sc_capi.hip lays the lists out by this)
-
-__global__ __launch_bounds__(256) void select_final_kernel(const uint32_t* __restrict__ wkey, uint64_t M,
-                                                           const uint64_t* __restrict__ M_dev,
-                                                           SelectState* __restrict__ sel, uint32_t* __restrict__ blk_gt,
-                                                           uint32_t* __restrict__ blk_eq, uint32_t* __restrict__ mlist,
-                                                           uint32_t* __restrict__ mcnt, uint64_t* __restrict__ host_short,
-                                                           uint32_t* __restrict__ hist2, const uint32_t* __restrict__ r1hist) {
-  // r1hist: round 1's histogram as the key kernel left it (SEL2_COPIES copies of SEL2_BINS words)
-  // hist2: SEL2_BINS2 words of round 2's histogram, zeroed (control block)
-  __shared__ uint64_t lds[8];
-  __shared__ uint32_t lh2[SEL2_BINS2];
-  __shared__ uint32_t s_bin, s_last, s_wsum[4], s_lcnt;
-  __shared__ uint64_t s_above;
-  __shared__ uint32_t s_list[SEL2_SEG];
-  const uint64_t ntiles = (M + 1023) / 1024;  // of what the launch COVERS: compact_write_kernel runs as many workgroups
-  if (M_dev) M = min(M, *M_dev);
-  const uint32_t lo = sel->lo;
-  const Sel2Split sp = sel2_split(lo);
-  const uint64_t want = sel->want;
-  const int nbins1 = (int)sp.nbins1;
-  // ---- round 1's pick, by every workgroup: thread t owns `per` bins counted from the top
-  const int per = nbins1 >= 256 ? nbins1 / 256 : 1;
-  const bool owner = (int)threadIdx.x * per < nbins1;
-  uint32_t h[SEL2_BINS / 256];
-  uint64_t mine = 0;
-#pragma unroll
-  for (int k = 0; k < SEL2_BINS / 256; k++) {
-    h[k] = 0u;
-    if (owner && k < per) {
-      const int bin = nbins1 - 1 - ((int)threadIdx.x * per + k);
-#pragma unroll
-      for (int c = 0; c < SEL2_COPIES; c++) h[k] += r1hist[c * SEL2_BINS + bin];
-    }
-    mine += h[k];
-  }
-  if (threadIdx.x == 0) { s_bin = 0; s_above = 0; }
-  uint64_t tot;
-  const uint64_t before = block_exscan_u64(mine, lds, &tot);  // (its barriers also order the defaults above)
-  const uint64_t want_eff = want < tot ? want : tot;
-  if (before < want_eff && want_eff <= before + mine) {
-    uint64_t run = before;
-#pragma unroll
-    for (int k = 0; k < SEL2_BINS / 256; k++) {
-      if (k < per && run < want_eff && want_eff <= run + h[k]) { s_bin = (uint32_t)(nbins1 - 1 - ((int)threadIdx.x * per + k)); s_above = run; }
-      run += h[k];
-    }
-  }
-  // (see select_round_kernel: an estimated pruning bound that promised more keys above it than there are)
-  if (blockIdx.x == 0 && threadIdx.x == 0 && host_short && sel->want_req != 0 && tot < sel->want_req) publish_host(host_short, 1ull);
-  for (int b = threadIdx.x; b < SEL2_BINS2; b += 256) lh2[b] = 0u;
-  __syncthreads();
-  const uint32_t lo2 = lo + (s_bin << sp.shift1);
-  const uint64_t width2 = 1ull << sp.shift1;  // <= 2^11: one bin per key value
-  const uint64_t above1 = s_above;
-  // ---- the tiles
-  for (uint64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-    const uint64_t base = tile * 1024 + (uint64_t)threadIdx.x * 4;
-    uint32_t keys[4];
-    int valid;
-    if (base + 4 <= M) {
-      const uint4 k4 = *reinterpret_cast<const uint4*>(wkey + base);
-      keys[0] = k4.x; keys[1] = k4.y; keys[2] = k4.z; keys[3] = k4.w;
-      valid = 4;
-    } else {
-      valid = base < M ? (int)(M - base) : 0;
-#pragma unroll
-      for (int k = 0; k < 4; k++) keys[k] = k < valid ? wkey[base + k] : 0u;
-    }
-    if (threadIdx.x == 0) s_lcnt = 0u;
-    __syncthreads();
-    uint32_t g = 0;
-#pragma unroll
-    for (int k = 0; k < 4; k++) {
-      if (k >= valid || keys[k] < lo2) continue;
-      const uint64_t rel = (uint64_t)keys[k] - lo2;
-      if (rel >= width2) { g++; continue; }
-      atomicAdd(&lh2[(uint32_t)rel], 1u);
-      const uint32_t slot = atomicAdd(&s_lcnt, 1u);  // (LDS: a handful per tile)
-      if (slot < (uint32_t)SEL2_SEG) s_list[slot] = keys[k];
-    }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) g += __shfl_xor(g, o);
-    if ((threadIdx.x & 63) == 0) s_wsum[threadIdx.x >> 6] = g;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-      blk_gt[tile] = s_wsum[0] + s_wsum[1] + s_wsum[2] + s_wsum[3];
-      blk_eq[tile] = 0u;
-      mcnt[tile] = s_lcnt;
-    }
-    if (threadIdx.x < (uint32_t)SEL2_SEG && threadIdx.x < s_lcnt) mlist[tile * SEL2_SEG + threadIdx.x] = s_list[threadIdx.x];
-    __syncthreads();
-  }
-  // round 2's histogram (zeroed with the control block)
-  for (int b = threadIdx.x; b < SEL2_BINS2; b += 256) {
-    const uint32_t v = lh2[b];
-    if (v) atomicAdd(&hist2[b], v);
-  }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    const uint32_t t = __hip_atomic_fetch_add(&sel->ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    s_last = (t == gridDim.x - 1) ? 1u : 0u;
-  }
-  __syncthreads();
-  if (!s_last) return;
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-  // ---- the last workgroup: k* = the largest key v of the window with above1 + #(keys >= v) >= want_eff
-  {
-    const int nb2 = (int)width2;  // bins = key values lo2 .. lo2 + nb2 - 1
-    const int per2 = nb2 >= 256 ? nb2 / 256 : 1;
-    const bool own2 = (int)threadIdx.x * per2 < nb2;
-    uint32_t h2[SEL2_BINS2 / 256];
-    uint64_t mine2 = 0;
-#pragma unroll
-    for (int k = 0; k < SEL2_BINS2 / 256; k++) {
-      h2[k] = (own2 && k < per2) ? hist2[nb2 - 1 - ((int)threadIdx.x * per2 + k)] : 0u;  // (plain loads: every wave acquired above)
-      mine2 += h2[k];
-    }
-    if (threadIdx.x == 0) { s_bin = 0; s_above = above1; }
-    uint64_t tot2;
-    const uint64_t before2 = above1 + block_exscan_u64(mine2, lds, &tot2);
-    if (before2 < want_eff && want_eff <= before2 + mine2) {
-      uint64_t run = before2;
-#pragma unroll
-      for (int k = 0; k < SEL2_BINS2 / 256; k++) {
-        if (k < per2 && run < want_eff && want_eff <= run + h2[k]) { s_bin = (uint32_t)(nb2 - 1 - ((int)threadIdx.x * per2 + k)); s_above = run; }
-        run += h2[k];
-      }
-    }
-    __syncthreads();
-  }
-  const uint32_t kstar = lo2 + s_bin;
-  const uint64_t need_eq = want_eff - s_above;
-  // ---- settle the listed keys, a tile per thread
-  for (uint64_t tile = threadIdx.x; tile < ntiles; tile += 256) {
-    const uint32_t cnt = mcnt[tile];
-    uint32_t gt = 0, eq = 0;
-    if (cnt <= (uint32_t)SEL2_SEG) {
-      const uint4* __restrict__ l4 = reinterpret_cast<const uint4*>(mlist + tile * SEL2_SEG);
-      for (uint32_t k = 0; k < cnt; k += 4) {  // (entries beyond cnt hold stale keys: masked)
-        const uint4 v = l4[k >> 2];
-        gt += (v.x > kstar) + (k + 1 < cnt && v.y > kstar) + (k + 2 < cnt && v.z > kstar) + (k + 3 < cnt && v.w > kstar);
-        eq += (v.x == kstar) + (k + 1 < cnt && v.y == kstar) + (k + 2 < cnt && v.z == kstar) + (k + 3 < cnt && v.w == kstar);
-      }
-    } else {  // the list overflowed (heavy ties inside the window): the tile's keys themselves
-      const uint64_t k0 = tile * 1024, k1 = min(M, k0 + 1024);
-      const uint64_t top = (uint64_t)lo2 + width2;
-      for (uint64_t q = k0; q < k1; q++) {
-        const uint32_t key = wkey[q];
-        gt += (key > kstar && (uint64_t)key < top); eq += key == kstar;
-      }
-    }
-    if (gt) blk_gt[tile] = blk_gt[tile] + gt;
-    blk_eq[tile] = eq;
-  }
-  if (threadIdx.x == 0) {
-    sel->above = s_above; sel->lo = kstar; sel->wbits = 0; sel->started = 1; sel->ticket = 0; sel->want = want_eff;
-    sel->done = 1; sel->kstar = kstar; sel->need_eq = need_eq;
-  }
-}
-
-void launch_select_final(const KeyView& view, SelectState* s, const uint32_t* r1hist, uint32_t* hist2, uint32_t* blk_gt, uint32_t* blk_eq,
-                         uint32_t* mlist, uint32_t* mcnt, uint64_t* host_short, hipStream_t st) {
-  if (view.M == 0) return;
-  uint64_t nb = (view.M + 1023) / 1024;
-  if (nb > 1024) nb = 1024;
-  hipLaunchKernelGGL(select_final_kernel, dim3((unsigned)nb), dim3(256), 0, st, view.base, view.M, view.M_dev, s, blk_gt, blk_eq, mlist,
-                     mcnt, host_short, hist2, r1hist);
-}
-size_t select_final_list_words(uint64_t M) { return (size_t)((M + 1023) / 1024) * (SEL2_SEG + 1); }
-
 KeyView plain_view(const uint32_t* wkey, uint64_t M) { return KeyView{wkey, M, 0, 0, nullptr, 0, nullptr}; }
 
 void launch_select_rounds(const KeyView& view, SelectState* s, int rounds, const Tuning& tn, hipStream_t st,
@@ -2155,76 +1823,6 @@ __global__ __launch_bounds__(CP_THREADS) void compact_write_kernel(KeyView view,
       eq_before += isq;
     }
   }
-}
-
-// Count and write in ONE launch: the counts of the tiles before this one come by decoupled look-back (sc_block.hpp:
-// ticket-ordered tiles, one epoch-tagged 8-byte descriptor per tile and count) instead of from a counting launch.
-// lb.desc: nb descriptors of the "greater" counts, then nb of the "equal" counts.
-template <bool SEG>
-__global__ __launch_bounds__(CP_THREADS) void compact_fused_kernel(KeyView view, const SelectState* __restrict__ sel,
-                                                                   LbArgs lb, uint64_t* __restrict__ sel_ord,
-                                                                   uint32_t* __restrict__ sel_key) {
-  __shared__ uint64_t lds[8];
-  __shared__ uint32_t s_tile;
-  __shared__ uint64_t s_pre[2];
-  uint32_t* ticket = lb.ticket;
-  const uint32_t epoch = lb.epoch;
-  if (threadIdx.x == 0) s_tile = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  __syncthreads();
-  const uint32_t tile = s_tile, nb = gridDim.x;
-  if (tile >= nb) return;  // (a ticket that was not zero at launch: never index memory with it)
-  const uint32_t kstar = sel->kstar;
-  const uint64_t need_eq = sel->need_eq;
-  const uint64_t base = (uint64_t)tile * CP_TILE + (uint64_t)threadIdx.x * CP_ITEMS;
-  uint32_t keys[CP_ITEMS];
-  int valid;
-  load_tile_keys<SEG>(view, base, keys, valid);
-  uint32_t g = 0, q = 0;
-#pragma unroll
-  for (int k = 0; k < CP_ITEMS; k++)
-    if (k < valid) { g += keys[k] > kstar; q += keys[k] == kstar; }
-  uint64_t tot;
-  const uint64_t ex = block_exscan_u64(((uint64_t)g << 32) | q, lds, &tot);  // gt high, eq low: <= 1024 each per tile
-  if (threadIdx.x < 64) {
-    uint64_t* const desc[2] = {lb.desc, lb.desc + nb};
-    const uint64_t own[2] = {tot >> 32, tot & 0xFFFFFFFFull};
-    uint64_t pre[2];
-    lb_lookback<2>(desc, tile, epoch, own, pre, lb.err);
-    if (threadIdx.x == 0) { s_pre[0] = pre[0]; s_pre[1] = pre[1]; }
-  }
-  __syncthreads();
-  if (tile == nb - 1 && threadIdx.x == 0)
-    __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // every tile has taken its ticket
-  if (tot == 0) return;  // nothing of this tile is above or at the threshold (block-uniform)
-  const uint64_t n_sel = sel->want;  // entries the selection holds: a position beyond it can only come from a failed
-                                     // look-back (spin limit) and is dropped rather than written out of bounds
-  uint64_t gt_before = s_pre[0] + (ex >> 32);
-  uint64_t eq_before = s_pre[1] + (ex & 0xFFFFFFFFull);
-#pragma unroll
-  for (int k = 0; k < CP_ITEMS; k++) {
-    if (k < valid) {
-      const uint32_t key = keys[k];
-      const bool isg = key > kstar, isq = key == kstar;
-      if (isg || (isq && eq_before < need_eq)) {
-        const uint64_t pos = gt_before + (eq_before < need_eq ? eq_before : need_eq);
-        if (pos < n_sel) { sel_ord[pos] = base + k; sel_key[pos] = key; }
-      }
-      gt_before += isg;
-      eq_before += isq;
-    }
-  }
-}
-
-size_t compact_state_bytes(uint64_t M) { return 2 * compact_blocks(M) * sizeof(uint64_t); }
-
-void launch_compact_fused(const KeyView& view, const SelectState* s, const LbArgs& lb, uint64_t* sel_ord,
-                          uint32_t* sel_key, hipStream_t st) {
-  if (view.M == 0) return;
-  const dim3 grid((unsigned)compact_blocks(view.M));
-  if (view.seg_len)
-    hipLaunchKernelGGL(compact_fused_kernel<true>, grid, dim3(CP_THREADS), 0, st, view, s, lb, sel_ord, sel_key);
-  else
-    hipLaunchKernelGGL(compact_fused_kernel<false>, grid, dim3(CP_THREADS), 0, st, view, s, lb, sel_ord, sel_key);
 }
 
 void launch_compact_write(const KeyView& view, const SelectState* s, const uint32_t* blk_gt,

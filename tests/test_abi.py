@@ -60,15 +60,17 @@ def test_product_reads_no_environment(pkg):
     und = subprocess.check_output(["nm", "-D", "--undefined-only", pkg.api.LIB_PATH]).decode()
     assert "getenv" not in und
     exe = os.path.join(ROOT, "tests", ".abi_probe_dbg")
-    src = '#include <stdio.h>\n#include <stddef.h>\n#include "saccot_debug.h"\nint main(void){printf("%zu %zu %zu %zu %zu", sizeof(sc_debug), offsetof(sc_debug, sample_edges), offsetof(sc_debug, compat_rows), sizeof(sc_debug_info), offsetof(sc_debug_info, filter_recounts));return 0;}\n'
+    src = '#include <stdio.h>\n#include <stddef.h>\n#include "saccot_debug.h"\nint main(void){printf("%zu %zu %zu %zu %zu %zu %zu %zu", sizeof(sc_debug), offsetof(sc_debug, sample_edges), offsetof(sc_debug, compat_rows), sizeof(sc_debug_info), offsetof(sc_debug_info, filter_recounts), offsetof(sc_debug, lanes_per_edge), offsetof(sc_debug, gram_guard_fail), offsetof(sc_debug_info, n_frames));return 0;}\n'
     subprocess.run(["gcc", "-I", os.path.join(ROOT, "include"), "-x", "c", "-", "-o", exe], input=src.encode(), check=True)
     try:
-        a, b, c, d, e = (int(x) for x in subprocess.check_output([exe]).decode().split())
+        a, b, c, d, e, f, g, h = (int(x) for x in subprocess.check_output([exe]).decode().split())
     finally:
         os.remove(exe)
     D, I = pkg.api.ScDebug, pkg.api.ScDebugInfo
     assert (a, b, c) == (C.sizeof(D), D.sample_edges.offset, D.compat_rows.offset)
     assert (d, e) == (C.sizeof(I), I.filter_recounts.offset)
+    assert (f, g, h) == (D.lanes_per_edge.offset, D.gram_guard_fail.offset, I.n_frames.offset)
+    assert len(D._fields_) <= 30   # (the lab's knobs left the product's struct)
 
 
 def test_version_and_strerror(pkg):

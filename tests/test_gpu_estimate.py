@@ -148,67 +148,22 @@ def _ties_scene():
     return src, src + np.float32(0.25), dict(sigma=1e4, t_cmp=0.9, tau=0.01, min_len=0.1, rank_mode=0)
 
 
-@pytest.mark.parametrize("name", ["C0", "C1", "C2", "C4", "ties", "ties_small_T", "few"])
-def test_one_launch_select_equals_the_three_it_replaces(pkg, O, name):
-    """launch_select_final (sc_debug.select_final: round 1's histogram taken by the key kernel; pick, round 2, per-tile counts and
-    the settling of the in-window keys in one launch — built as VERDICT r03 #2 (i) asked, measured no faster, off by default)
-    against select round 1 + round 2 + compact_count: same
-    selection, hence the same everything — on the BASELINE shapes, with every key tied (the window's per-tile lists
-    overflow: the last workgroup recounts those tiles), with T above the number of triangles."""
-    if name.startswith("ties"):
-        src, tgt, kw = _ties_scene()
-        kw = dict(kw, max_triangles=5000 if name == "ties" else 37)
-    elif name == "few":
-        sc = pkg.synth.make_scene(2000, 0.20, 1.0, 0.02, 77)
-        src, tgt = sc.src, sc.tgt
-        kw = dict(sigma=0.02, t_cmp=0.9, tau=0.02, min_len=0.02, max_triangles=3_000_000, rank_mode=0)
-    else:
-        cfg, scene = pkg.synth.make_config_scene(name)
-        src, tgt, kw = scene.src, scene.tgt, cfg.params()
-    a = pkg.Registrar(0); a.set_debug(select_final=1)
-    b = pkg.Registrar(0)
+@pytest.mark.parametrize("T", [5000, 37, 3_000_000])
+def test_the_select_with_every_key_tied_equals_the_oracle(pkg, O, T):
+    """the two select rounds + count + write on a lattice moved rigidly under a huge sigma — every edge weight rounds to the same
+    value, every key ties, the threshold's `need_eq` decides the whole selection by ordinal — with T below, far below and above
+    the number of triangles; the waited call and its host-free repetition"""
+    src, tgt, kw = _ties_scene()
+    kw = dict(kw, max_triangles=T)
+    r = pkg.Registrar(0)
     try:
-        for k in range(2):   # (the waited call, then the host-free repetition)
-            ra = a.register(src, tgt, **kw)
-            rb = b.register(src, tgt, **kw)
-            assert _same(ra, rb) and ra["stats"]["tri_total"] == rb["stats"]["tri_total"], (name, k)
+        outs = [r.register(src, tgt, **kw) for _ in range(2)]
     finally:
-        a.close(); b.close()
+        r.close()
     ref = O.register(src, tgt, threads=8, **kw)
-    assert ra["status"] == ref["rc"] and np.array_equal(ra["mask"], ref["mask"])
-    assert ra["stats"]["best_rank"] == ref["best_rank"] and ra["stats"]["tri_kept"] == ref["t_eff"]
-
-
-@pytest.mark.parametrize("name", ["C0", "C1", "C2", "nohyp"])
-def test_winner_step_inside_the_argmax_launch_equals_its_own_launch(pkg, O, name):
-    """sc_debug.tail_fused: the arg-max launch's last workgroup does the finalize step (C3 mask, rank index, (R, t), the host's
-    words) instead of finalize_kernel — built, measured slower (one workgroup's dependent load rounds), off by default.  Same outputs — also with the
-    fp64 refit behind it, with a truncated score, and when no hypothesis has an inlier (identity, zero mask, SC_ENOHYP)."""
-    if name == "nohyp":
-        rng = np.random.default_rng(3)
-        src = rng.uniform(-1, 1, (700, 3)).astype(np.float32); tgt = rng.uniform(-1, 1, (700, 3)).astype(np.float32)
-        kws = [dict(sigma=0.05, t_cmp=0.9, tau=1e-6, min_len=0.05, max_triangles=500, rank_mode=0)]
-    else:
-        cfg, scene = pkg.synth.make_config_scene(name)
-        src, tgt = scene.src, scene.tgt
-        kws = [cfg.params(), dict(cfg.params(), flags=pkg.SC_FLAG_REFINE), dict(cfg.params(), score_mode=1)]
-    a = pkg.Registrar(0); a.set_debug(tail_fused=1)
-    b = pkg.Registrar(0)
-    try:
-        for kw in kws:
-            for k in range(2):
-                ra = a.register(src, tgt, **kw); rb = b.register(src, tgt, **kw)
-                assert _same(ra, rb), (name, kw.get("flags"), kw.get("score_mode"), k)
-            if name == "nohyp":
-                assert ra["status"] == pkg.SC_ENOHYP and not ra["mask"].any() and np.array_equal(ra["R"], np.eye(3, dtype=np.float32))
-    finally:
-        a.close(); b.close()
-    if name != "nohyp":
-        ref = O.register(src, tgt, threads=8, **cfg.params())
-        got = pkg.Registrar(0)
-        r0 = got.register(src, tgt, **cfg.params()); got.close()
-        assert np.array_equal(r0["mask"], ref["mask"]) and r0["stats"]["best_rank"] == ref["best_rank"]
-        assert nan_equal_bits(np.concatenate([r0["R"].ravel(), r0["t"]]), np.concatenate([ref["R"].ravel(), ref["t"]]))
+    for o in outs:
+        assert o["status"] == ref["rc"] and np.array_equal(o["mask"], ref["mask"])
+        assert o["stats"]["best_rank"] == ref["best_rank"] and o["stats"]["tri_kept"] == ref["t_eff"]
 
 
 @pytest.mark.parametrize("n,rho,L,tau,T", [(8200, 0.12, 3.0, 0.1, 30000), (10007, 0.10, 8.0, 0.2, 60000), (12345, 0.08, 20.0, 0.5, 5000)])

@@ -203,13 +203,10 @@ def test_kabsch_bit_exact_random_and_degenerate(pkg, O, reg):
 # ---------------------------------------------------------------------------------------------------------
 # stage C2 / C3
 # ---------------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("scalar", [0, 1])
 @pytest.mark.parametrize("n,T", [(500, 200), (1000, 257), (2000, 10000), (1025, 3000), (513, 70)])
-def test_score_counts_bit_exact(pkg, O, n, T, scalar):
-    """both C2 kernels: lane = hypothesis with the points in LDS (the default) and lane = correspondence with the
-    hypothesis in scalar registers (sc_debug.score_scalar); ragged point chunks and hypothesis counts"""
+def test_score_counts_bit_exact(pkg, O, n, T):
+    """the plain C2 kernel (lane = hypothesis, the points in LDS); ragged point chunks and hypothesis counts"""
     reg = pkg.Registrar(0)
-    reg.set_debug(score_scalar=scalar)
     sc = _scene(pkg, n, seed=n)
     rng = np.random.default_rng(n)
     tri = np.sort(np.stack([rng.choice(n, 3, replace=False) for _ in range(T)]), axis=1).astype(np.uint32)
@@ -281,9 +278,7 @@ def test_certified_pruning_changes_nothing_but_the_work(pkg, reg, name):
 @pytest.mark.parametrize("knobs", [dict(cnt_blocks=37, keys_blocks=53, sel_blocks=7, sample_edges=5000),
                                    dict(cnt_blocks=4096, keys_blocks=1, sel_blocks=1, sample_edges=1000000, tg_sample=32, sample_blocks=3, sample_mode=2),
                                    dict(sample_mode=2, sample_edges=700, tg_sample=8, compact_self_max=100000, scan_self_max=0),
-                                   dict(compact_fused=1),          # one-launch compaction (decoupled look-back over 500+ tiles)
                                    dict(rows_unfused=1, scan_self_max=0),   # round 1's separate row_stats + three-kernel scans
-                                   dict(score_scalar=1),           # C2 by the lane = correspondence kernel (coefficients as scalar operands)
                                    dict(no_events=1, tg_count=4, tg_keys=64, sel_blocks=3, sample_mode=1),
                                    dict(sample_mode=1, sample_edges=5000, tg_sample=4, tg_events=32)])
 def test_results_do_not_depend_on_grid_or_sample_size(pkg, O, knobs):

@@ -1,5 +1,5 @@
-"""Lab: where does a stream of frames lose time?  python tools/r4/b2b.py <sync|b2b> [C2] [nodense]"""
-import os, sys, time; sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
+"""Lab: where does a stream of frames lose time?  python tools/frames_b2b.py <sync|b2b> [C2] [nodense]"""
+import os, sys, time; sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 import torch
 import __graft_entry__ as ge
 pkg = ge.load_package()

@@ -3,9 +3,10 @@ For every ranked hypothesis h: dM = R0^T R_h - I, tau_h = R0^T (t_h - t0); reach
 a correspondence with |V_i| = |R0^T (q_i - t0) - p_i| > reach_h + tau cannot be an inlier of h."""
 import sys, json
 import numpy as np
-sys.path.insert(0, ".")
-import importlib
-pkg = importlib.import_module("sac-cot_amd")
+import os
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+import __graft_entry__ as ge
+pkg = ge.load_package()
 
 def run(name):
     cfg, sc = pkg.synth.make_config_scene(name)
