@@ -412,27 +412,13 @@ def main() -> int:
         if world == 1:
             def enqueue(f, k):
                 pair[f & 1].register_device_async(d_srcs[k].data_ptr(), d_tgts[k].data_ptr(), cfg.n, p_hot, Rt_all[k].data_ptr(), mask_all[k].data_ptr())
-
-            def redo(f, k):
-                raise RuntimeError("unreachable: sc_wait repeats a single-GPU call inside the library")
+            # (a frame whose host-free enqueue turns out void is repeated inside sc_wait)
         else:
-            keys = [d_key, torch.zeros(2, dtype=torch.int64, device=dev)]
-            alls = [d_all, torch.zeros(2 * world, dtype=torch.int64, device=dev)]
-            p_est = type(p_hot).from_buffer_copy(p_hot)
-            p_est.flags |= pkg.SC_FLAG_EST_BOUND
+            rs = pkg.shard.ReplicatedStream(pkg, pair, cfg.n, p_hot, world, lambda k_: torch.zeros(k_, dtype=torch.int64, device=dev))
+            rs.estimate = rep_est[0]
 
             def enqueue(f, k):
-                i = f & 1
-                pair[i].hypothesize_device(d_srcs[k].data_ptr(), d_tgts[k].data_ptr(), cfg.n, p_est if rep_est[0] else p_hot, keys[i].data_ptr())
-                pkg.shard.allgather_best(keys[i], alls[i])   # ONE collective (16 bytes per rank), in stream order
-                pair[i].finalize_gathered_device_async(alls[i].data_ptr(), world, Rt_all[k].data_ptr(), mask_all[k].data_ptr())
-
-            def redo(f, k):   # SC_EBOUND (every rank alike: stages A and B are replicated): this frame again, the certifying way
-                i = f & 1
-                note_ebound(pair[i])
-                pair[i].hypothesize_device(d_srcs[k].data_ptr(), d_tgts[k].data_ptr(), cfg.n, p_hot, keys[i].data_ptr())
-                pkg.shard.allgather_best(keys[i], alls[i])
-                return pair[i].finalize_gathered_device(alls[i].data_ptr(), world, Rt_all[k].data_ptr(), mask_all[k].data_ptr())
+                rs.enqueue(f, d_srcs[k], d_tgts[k], Rt_all[k], mask_all[k])
 
         def run_stream(frames, scene_of, timed_hot=False):
             """`frames` frames, frame f + 1 enqueued before frame f's winner is waited for -> (wall s, per-frame (scene, rc, rank,
@@ -445,10 +431,12 @@ def main() -> int:
             for f in range(1, frames + 1):
                 if f < frames:
                     enqueue(f, scene_of(f))
-                rc, st = pair[(f - 1) & 1].wait()     # frame f - 1: status, statistics; (R, t) and mask complete
-                if rc == pkg.SC_EBOUND:
-                    rc, st = redo(f - 1, scene_of(f - 1))
-                    n_redo += 1
+                if world == 1:
+                    rc, st = pair[(f - 1) & 1].wait()     # frame f - 1: status, statistics; (R, t) and mask complete
+                else:
+                    r0_ = rs.redone
+                    rc, st = rs.collect(f - 1)            # (SC_EBOUND: the frame again, certifying — every rank alike)
+                    n_redo += rs.redone - r0_
                 tn_ = time.perf_counter()
                 ts.append(tn_ - tl); tl = tn_         # (winner to winner)
                 hot += st["us_score"]

@@ -198,3 +198,64 @@ class ShardedStep:
         reg.shard_score_device(self.cand.data_ptr(), self.keys.data_ptr() + 16 * r)
         allgather_inplace(self.keys, r, w)
         return reg.finalize_gathered_device(self.keys.data_ptr(), w, self.Rt.data_ptr(), self.mask.data_ptr())
+
+
+class ReplicatedStream:
+    """One rank of a job whose ranks REPLICATE stages A and B (graphs below 8192 correspondences: what `bench.py --gpus N` runs by
+    default), registering a STREAM of frames: frame f + 1 is enqueued — host-free sc_hypothesize_device (SC_FLAG_EST_BOUND) on the
+    second of two contexts bound to one stream, ONE all-gather of the 16-byte key pairs, sc_finalize_gathered_device_async —
+    before frame f's sc_wait delivers its status.  SC_EBOUND (every rank alike: the stages are replicated and deterministic, and the
+    ranks' contexts have seen the same calls in the same order) means this frame again without the flag; two FAILED ESTIMATES
+    (sc_debug_last.prune_bound == 2, as opposed to a host-free call whose covers were outgrown) switch the flag off for good.
+    `pair`: two Registrar-like objects; `ptr`: how a buffer becomes what they take (tensor.data_ptr() for the library; the CPU test of
+    this class passes the tensors themselves to stand-ins built on the CPU restatement: tests/test_shard_gloo.py)."""
+
+    def __init__(self, pkg, pair, n: int, params, world: int, make_i64, ptr=lambda t: t.data_ptr()):
+        self.pkg, self.pair, self.n, self.world, self.ptr = pkg, pair, n, world, ptr
+        self.p_plain = type(params).from_buffer_copy(params)
+        self.p_plain.flags &= ~pkg.SC_FLAG_EST_BOUND
+        self.p_est = type(params).from_buffer_copy(params)
+        self.p_est.flags |= pkg.SC_FLAG_EST_BOUND
+        self.keys = [make_i64(2), make_i64(2)]
+        self.alls = [make_i64(2 * world), make_i64(2 * world)]
+        self.estimate, self.est_fails, self.redone = True, 0, 0
+        self._frame = {}
+
+    def _run(self, i, params, src, tgt):
+        g = self.pair[i]
+        g.hypothesize_device(self.ptr(src), self.ptr(tgt), self.n, params, self.ptr(self.keys[i]))
+        allgather_best(self.keys[i], self.alls[i])   # ONE collective (16 bytes per rank), in stream order
+
+    def enqueue(self, f: int, src, tgt, Rt, mask) -> None:
+        i = f & 1
+        self._frame[i] = (src, tgt, Rt, mask)
+        self._run(i, self.p_est if self.estimate else self.p_plain, src, tgt)
+        self.pair[i].finalize_gathered_device_async(self.ptr(self.alls[i]), self.world, self.ptr(Rt), self.ptr(mask))
+
+    def collect(self, f: int):
+        """frame f's status and statistics; its (R, t) and mask are complete"""
+        i = f & 1
+        rc, st = self.pair[i].wait()
+        if rc == self.pkg.SC_EBOUND:
+            rc, st = self._again(i)
+        return rc, st
+
+    def waited(self, i: int, src, tgt, Rt, mask):
+        """one frame on context i, complete on return (warm-up; the `waited` leg of bench.py)"""
+        self._frame[i] = (src, tgt, Rt, mask)
+        self._run(i, self.p_est if self.estimate else self.p_plain, src, tgt)
+        rc, st = self.pair[i].finalize_gathered_device(self.ptr(self.alls[i]), self.world, self.ptr(Rt), self.ptr(mask))
+        if rc == self.pkg.SC_EBOUND:
+            rc, st = self._again(i)
+        return rc, st
+
+    def _again(self, i: int):
+        """SC_EBOUND came back: the frame once more, the certifying (and waiting) way — on every rank alike"""
+        self.redone += 1
+        if self.pair[i].debug_last()["prune_bound"] == 2:   # (off the fast path: sc_debug_last synchronises)
+            self.est_fails += 1
+            if self.est_fails >= 2:
+                self.estimate = False
+        src, tgt, Rt, mask = self._frame[i]
+        self._run(i, self.p_plain, src, tgt)
+        return self.pair[i].finalize_gathered_device(self.ptr(self.alls[i]), self.world, self.ptr(Rt), self.ptr(mask))

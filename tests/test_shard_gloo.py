@@ -233,6 +233,117 @@ def test_sharded_A_and_B_host_logic_gloo(pkg, O, tmp_path, world, level):
         assert total > 6000 and int(outs[0]["retries"]) >= 1
 
 
+# ---------------------------------------------------------------------------------------------------------
+# the STREAMED replicated form (what `bench.py --gpus N` runs below 8192 correspondences): shard.ReplicatedStream — two frames in
+# flight per rank, one all-gather of the key pairs per frame, SC_EBOUND answered by every rank with the same repeat — over gloo,
+# with stand-ins for the two contexts that restate a rank's share of a frame with the CPU restatement
+# ---------------------------------------------------------------------------------------------------------
+class _StandInContext:
+    """What ReplicatedStream needs of a Registrar, on CPU tensors: hypothesize_device (this rank's key pair of the frame),
+    finalize_gathered_device(_async) + wait (reduce the gathered pairs, re-solve the winner, mask), debug_last.  `fail`: frames (by
+    the number of hypothesize calls with SC_FLAG_EST_BOUND seen so far) whose estimate 'fails': SC_EBOUND from the finalize step."""
+
+    def __init__(self, pkg, O, rank, world, block, kw, fail=()):
+        self.pkg, self.O, self.rank, self.world, self.block, self.kw, self.fail = pkg, O, rank, world, block, kw, set(fail)
+        self.est_calls, self.pending, self.last_bound = 0, None, 0
+
+    def hypothesize_device(self, src, tgt, n, p, key):
+        O, pkg = self.O, self.pkg
+        src, tgt = src.numpy(), tgt.numpy()
+        est = bool(p.flags & pkg.SC_FLAG_EST_BOUND)
+        self.bad = est and self.est_calls in self.fail
+        self.est_calls += est
+        S, bits, deg = O.compat(src, tgt, self.kw["sigma"], self.kw["t_cmp"], self.kw["min_len"], self.kw["tau"])
+        tri, wkey, _ = O.triangles(S, bits, deg, self.kw["max_triangles"], 0)
+        mine = pkg.shard.local_indices(len(tri), self.block, self.rank, self.world)
+        cnt = O.score(src, tgt, O.kabsch3(src, tgt, tri[mine]), self.kw["tau"])
+        best = (0, 0)
+        for c, g in zip(cnt, mine):
+            best = max(best, pkg.shard.encode_pair(int(c), int(wkey[g]), int(g)))
+        key[0], key[1] = best
+        self.frame = (src, tgt, tri)
+        return {}
+
+    def _finish(self, alls, Rt, mask):
+        if self.bad:
+            self.last_bound = 2
+            return self.pkg.SC_EBOUND, {}
+        self.last_bound = 1
+        src, tgt, tri = self.frame
+        k0, k1 = self.pkg.shard.reduce_pairs([tuple(int(x) for x in alls[2 * r:2 * r + 2]) for r in range(self.world)])
+        count, _, widx = self.pkg.shard.decode_pair(k0, k1)
+        Rt_w = self.O.kabsch3(src, tgt, tri[widx:widx + 1])[0]
+        Rt.copy_(__import__("torch").from_numpy(Rt_w))
+        mask.copy_(__import__("torch").from_numpy(self.O.mask(src, tgt, Rt_w, self.kw["tau"])))
+        return 0, dict(best_rank=widx, best_count=count)
+
+    def finalize_gathered_device(self, alls, world, Rt, mask):
+        return self._finish(alls.clone(), Rt, mask)
+
+    def finalize_gathered_device_async(self, alls, world, Rt, mask):
+        self.pending = (alls.clone(), Rt, mask)   # (the gathered pairs as they are NOW: the other context's frame overwrites nothing of this one)
+
+    def wait(self):
+        a, self.pending = self.pending, None
+        return self._finish(*a)
+
+    def debug_last(self):
+        return dict(prune_bound=self.last_bound)
+
+
+def _worker_stream(rank, world, port, out_dir):
+    import sys
+    import torch
+    import torch.distributed as dist
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import __graft_entry__ as ge
+    pkg = ge.load_package(); O = ge.load_oracle()
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    cfg, scenes = pkg.synth.make_stream_scenes("C0", 5)
+    kw = cfg.params()
+    p = pkg.make_params(shard_rank=rank, shard_world=world, shard_block=32, **kw)
+    # context 0's second and context 1's first estimating call 'fail' (frames 2 and 1): one repeat each, then — two failed estimates —
+    # the stream certifies from there on; the same on every rank, as on the GPU (replicated, deterministic stages)
+    pair = [_StandInContext(pkg, O, rank, world, 32, kw, fail=(1,)), _StandInContext(pkg, O, rank, world, 32, kw, fail=(0,))]
+    rs = pkg.shard.ReplicatedStream(pkg, pair, cfg.n, p, world, lambda k: torch.zeros(k, dtype=torch.int64), ptr=lambda t: t)
+    src = [torch.from_numpy(s.src.copy()) for s in scenes]; tgt = [torch.from_numpy(s.tgt.copy()) for s in scenes]
+    frames = 9
+    Rt = torch.zeros(frames, 12); mask = torch.zeros(frames, cfg.n, dtype=torch.uint8)
+    out = []
+    rs.enqueue(0, src[0], tgt[0], Rt[0], mask[0])
+    for f in range(1, frames + 1):
+        if f < frames:
+            k = f % len(scenes)
+            rs.enqueue(f, src[k], tgt[k], Rt[f], mask[f])
+        rc, st = rs.collect(f - 1)
+        out.append((rc, st["best_rank"], st["best_count"]))
+    np.savez(os.path.join(out_dir, f"stream{rank}.npz"), out=np.array(out), Rt=Rt.numpy(), mask=mask.numpy(),
+             redone=rs.redone, estimate=int(rs.estimate), est_fails=rs.est_fails)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_replicated_ranks_stream_distinct_frames_over_gloo(pkg, O, tmp_path):
+    """bench.py's N > 1 default on CPU: two ranks, nine frames over five distinct scenes, two frames in flight per rank, the key
+    pairs all-gathered over gloo; two frames come back SC_EBOUND on every rank (a 'failed estimate' each) and are repeated without
+    the flag, after which the stream stops estimating.  Every frame equals the single-rank restatement of ITS scene."""
+    import torch.multiprocessing as mp
+    world = 2
+    mp.spawn(_worker_stream, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    cfg, scenes = pkg.synth.make_stream_scenes("C0", 5)
+    refs = [O.register(s.src, s.tgt, threads=1, **cfg.params()) for s in scenes]
+    outs = [np.load(tmp_path / f"stream{r}.npz") for r in range(world)]
+    for o in outs:
+        assert int(o["redone"]) == 2 and int(o["est_fails"]) == 2 and int(o["estimate"]) == 0
+        for f in range(9):
+            ref = refs[f % 5]
+            assert tuple(o["out"][f]) == (0, ref["best_rank"], ref["best_count"]), (f, o["out"][f])
+            assert o["Rt"][f].astype(np.float32).tobytes() == np.concatenate([ref["R"].ravel(), ref["t"]]).astype(np.float32).tobytes()
+            assert np.array_equal(o["mask"][f], ref["mask"])
+
+
 def test_bench_parent_ends_the_ranks_when_one_dies():
     """bench.py --gpus N without a launcher supervises the ranks it starts: rank 1 exits with a code at once,
     the others sleep as if stuck in a rendezvous — the parent must return that code promptly instead of waiting on them."""
