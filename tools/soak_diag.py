@@ -3,7 +3,7 @@
 mismatch / exception with the last calls of each context printed."""
 import collections, os, sys, traceback
 HERE = os.path.dirname(os.path.abspath(__file__))
-ROOT = os.path.dirname(os.path.dirname(HERE))
+ROOT = os.path.dirname(HERE)
 sys.path.insert(0, ROOT)
 import __graft_entry__ as ge
 pkg = ge.load_package()

@@ -2,9 +2,9 @@
 """r05 development: two contexts on one stream, random streams of frames over several SHAPES and scenes through
 sc_register_device_async / sc_wait only; every result against the first result of its (shape, scene); at the first wrong one the
 recent history of both contexts is printed (what ran before it, how it was enqueued, what the launches covered).
-python tools/r5/stress_shapes.py [seconds]"""
+python tools/stress_shapes.py [seconds]"""
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import torch
 import __graft_entry__ as ge
