@@ -373,7 +373,7 @@ int stage_inputs(sc_ctx* c, const float* d_src, const float* d_tgt, int64_t n, c
   launch_stage_points(d_src, d_tgt, c->n, c->ld, p->layout, c->planes.as<float>(),
                       reinterpret_cast<uint32_t*>(&c->pinned[1]), c->ctl.as<uint32_t>(),
                       (uint32_t)(sizeof(ControlBlock) / 4), c->fx_mx.as<uint32_t>(), c->fx_part.as<uint32_t>(),
-                      c->fx_mx.as<uint32_t>() + FX_MX_WORDS, &c->pinned[13], &c->pinned[16], c->stream,
+                      c->fx_mx.as<uint32_t>() + FX_MX_WORDS, c->spec_on ? nullptr : &c->pinned[13], c->spec_on ? nullptr : &c->pinned[16], c->stream,  // (host-free: finalize hands them over, DeferredPub)
                       c->build ? c->degp.as<uint32_t>() : nullptr, c->build ? (uint32_t)c->ld : 0u);
   return SC_OK;
 }
@@ -555,7 +555,7 @@ int run_edges(sc_ctx* c, const sc_params* p, uint32_t* hist, uint32_t part, uint
   auto fill_edges = [&](uint64_t cap) {
     if (build) {
       launch_edge_build(g, points_of(c), c->dv, c->bits2.as<uint64_t>(), c->edge_off.as<uint64_t>(), c->ebase.as<uint32_t>(),
-                        c->ei.as<uint32_t>(), c->ej.as<uint32_t>(), c->es.as<float>(), cap, &c->pinned[0], st);
+                        c->ei.as<uint32_t>(), c->ej.as<uint32_t>(), c->es.as<float>(), cap, c->spec_on ? nullptr : &c->pinned[0], st);
       return;
     }
     launch_edge_fill(g, points_of(c), c->dv, c->edge_off.as<uint64_t>(), c->ei.as<uint32_t>(), c->ej.as<uint32_t>(),
@@ -754,7 +754,7 @@ int run_select(sc_ctx* c, const sc_params* p, const uint32_t* hist, bool want_li
   ScanExtra xr;  // sharded: the counts outside this rank's edge range are zero — their tiles are skipped
   xr.range = own_range_of(c);
   { const int lrc = lb_next(c, scan_temp_bytes(E), 0, 0, &xr.lb); if (lrc) return lrc; }
-  launch_scan_u32(c->tcnt.as<uint32_t>(), E, c->toff.as<uint64_t>(), c->scan_tmp.p, c->tn, st, &c->pinned[2], &xr);
+  launch_scan_u32(c->tcnt.as<uint32_t>(), E, c->toff.as<uint64_t>(), c->scan_tmp.p, c->tn, st, spec ? nullptr : &c->pinned[2], &xr);
   // While the host polls for the count, the key kernel already runs into the key arrays this context holds from earlier
   // calls (it takes everything else from device memory).  Only in the common form — events, a-priori select window —
   // and not when every stage is bracketed by events; re-run below if the count outgrew the arrays or a region overflowed.
@@ -1488,9 +1488,13 @@ int finalize_enqueue(sc_ctx* c, const uint64_t* d_keys, int n_pairs, float* d_Rt
   if ((rc = rec(c, 7))) return rc;
   ControlBlock* ctl = c->ctl.as<ControlBlock>();
   arm_word(c, 8);
+  // a host-free call's kernels have published nothing yet: this one hands the counts and the coordinate statistics over with the winner
+  DeferredPub dp{c->edge_off.as<uint64_t>() + c->n, c->toff.as<uint64_t>() + c->E, c->fx_mx.as<uint32_t>(),
+                 reinterpret_cast<unsigned long long*>(c->pinned), (c->n_fast_ok & 63u) == 63u ? 1 : 0};
   launch_finalize(points_of(c), tri_source_of(c), c->sh, c->sh.n_local ? c->rt.as<float>() : nullptr,
                   c->T_eff ? c->sel_key.as<uint32_t>() : nullptr, c->T_eff, d_keys, n_pairs,
-                  ctl->key2, c->dv.tau2, d_Rt, d_mask, &ctl->fin_rank, &ctl->fin_ticket, &c->pinned[8], c->stream);
+                  ctl->key2, c->dv.tau2, d_Rt, d_mask, &ctl->fin_rank, &ctl->fin_ticket, &c->pinned[8], c->stream,
+                  c->spec_on ? &dp : nullptr);
   if (c->refine) {  // fp64 least-squares refit over the winner's inliers (mask unchanged)
     ENSURE(c, c->refine_tmp, refine_scratch_bytes(c->n));
     launch_refine(points_of(c), d_mask, ctl->key2, c->refine_tmp.as<double>(), d_Rt, c->stream);
@@ -1520,8 +1524,13 @@ void note_completed(sc_ctx* c, bool regular) {
   c->E_last = c->E; c->M_last = c->M; c->last_n = c->n;
   c->last_p = c->params;
   if (c->est_failed && !c->est_failed_call && c->est_holdoff != 0 && --c->est_holdoff == 0) c->est_failed = false;  // (the repeat itself does not count)
-  c->mx_last = __atomic_load_n(&c->pinned[13], __ATOMIC_ACQUIRE);  // (the call is complete: its staging kernel's words have arrived)
-  for (int k = 0; k < 6; k++) c->box_last[k] = *const_cast<volatile uint64_t*>(&c->pinned[16 + k]);
+  // (the call is complete: its staging kernel's words have arrived — unless it was a host-free call, whose statistics travel with
+  // the winner only now and then: DeferredPub; the last ones known stay)
+  const uint64_t mx_now = __atomic_load_n(&c->pinned[13], __ATOMIC_ACQUIRE);
+  if (mx_now != ~0ull) {
+    c->mx_last = mx_now;
+    for (int k = 0; k < 6; k++) c->box_last[k] = *const_cast<volatile uint64_t*>(&c->pinned[16 + k]);
+  }
   // room for the event list of a call like this one: an event holds >= 1 triangle, so 2 M records can only overflow a region
   // on a fill 2 x off the mean (the regions fill evenly: a wave moves to the next one with every flush)
   if (c->use_events && c->ev_capacity < 2 * c->M) c->ev_capacity = 2 * c->M < (1ull << 28) ? 2 * c->M : (1ull << 28);
@@ -1545,7 +1554,9 @@ int finalize_wait(sc_ctx* c, sc_stats* stats) {
     // event list that did not overflow and a graph big enough to prune: anything else and the outputs are void — the
     // caller (sc_wait) repeats the call the waiting way, which handles every one of these cases.
     if ((uint32_t)c->pinned[1] != 0) { c->fast_ok = false; c->last_error = "non-finite input coordinate"; return SC_EINVAL; }
-    const uint64_t E = c->pinned[0], M = c->pinned[2];
+    // (the finalize kernel handed both counts over in one word: DeferredPub)
+    const uint64_t em = c->pinned[0];
+    const uint64_t E = em == PIN_PENDING ? PIN_PENDING : (em & 0xFFFFFFFFull), M = em == PIN_PENDING ? PIN_PENDING : (em >> 32);
     const bool ok = E != PIN_PENDING && M != PIN_PENDING && E >= 4096 && E <= c->E_cov && M <= c->M_cov &&
                     M >= (uint64_t)c->params.max_triangles && (uint32_t)c->pinned[5] == 0;
     if (!ok) {
@@ -1594,7 +1605,7 @@ int finalize_wait(sc_ctx* c, sc_stats* stats) {
     c->last_error = "a candidate blob was too small for this input: repeat the call with sc_params.shard_cand_level raised by one";
     return SC_ERETRY;
   }
-  if (c->pinned[11] != 0) {  // finalize_kernel: a pair decodes to a position outside the selection (outputs: identity, zero mask)
+  if (c->pinned[9] == ~0ull) {  // finalize_kernel: a pair decodes to a position outside the selection (outputs: identity, zero mask)
     c->last_error = "a winner key pair points outside the selected list (stale / uninitialised pair, or ranks that disagree on T or the parameters)";
     return SC_EINVAL;
   }
@@ -1603,7 +1614,7 @@ int finalize_wait(sc_ctx* c, sc_stats* stats) {
   if (stats && stats->size == sizeof(sc_stats)) {
     fill_stats(c, stats);
     stats->best_count = (uint32_t)(key >> 32);
-    stats->best_rank = key ? (uint32_t)c->pinned[10] : 0u;
+    stats->best_rank = key ? (uint32_t)(c->pinned[9] >> 32) : 0u;  // (rank index << 32 | position: one word beside the key)
     if (c->timing) {
       stats->us_stage = ev_us(c, 0, 1);
       stats->us_compat = ev_us(c, 1, 2);

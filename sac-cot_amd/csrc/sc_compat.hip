@@ -93,11 +93,14 @@ __global__ __launch_bounds__(256) void stage_points_kernel(const float* __restri
       if (threadIdx.x == 0) {
         // the host gets the two maxima (max |q| << 32 | max |p|, bit patterns) and the boxes: it decides from them which C2
         // kernel can work at this tau (sc_capi.hip decide_filter); nothing waits for it
-        if (host_box)
+        if (host_box && host_max)
           for (int k = 0; k < 6; k++)  // (relaxed system-scope stores: the release of host_max below orders them)
             __hip_atomic_store(&host_box[k], ((uint64_t)fin[0][8 + k] << 32) | fin[0][2 + k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         __hip_atomic_store(mx_ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // ready for the next call
-        publish_host(host_max, ((uint64_t)fin[0][1] << 32) | fin[0][0]);  // last: the host takes this word as "the boxes are there too"
+        // (host_max == nullptr: a host-free call — nothing on the host looks at these words before the call's last kernel, which
+        // hands them over with the winner: launch_finalize's DeferredPub.  A system-scope release here costs the staging kernel ~1 us
+        // and the launch behind it another: measured, profiles/r05_ab_deferred_publish.txt)
+        if (host_max) publish_host(host_max, ((uint64_t)fin[0][1] << 32) | fin[0][0]);  // last: the host takes this word as "the boxes are there too"
       }
     }
   }

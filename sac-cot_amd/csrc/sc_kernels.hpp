@@ -528,14 +528,25 @@ size_t argmax_scratch_bytes(uint32_t ld_local);
 void launch_argmax(const Shard& sh, const uint32_t* partial, uint32_t n_chunks, const uint32_t* sel_key,
                    uint32_t* cnt, uint64_t* pairs, uint32_t* ticket, uint64_t* key2, hipStream_t st);
 // C3: winner decode + re-solve + mask.  Rt12 receives R (row-major) and t; identity / zero mask when key2[0] == 0.
-// sel_key / T: the ordinal-ordered ranking keys (for the winner's rank index); host_out (pinned, 3 x u64) receives
-// key2[0], the winner's position and its rank index.
+// sel_key / T: the ordinal-ordered ranking keys (for the winner's rank index); host_out (pinned, 2 x u64) receives
+// [1] = rank index << 32 | position (all ones: the key pair decodes to nothing of the selection) and then, released, [0] = key2[0].
 // key2: npairs key pairs (all-gathered, one per rank; 1 = already reduced); key_out (2 x u64, optional) receives the
 // reduced pair.
 // sh / RtSoA: this rank's shard and the (R,t) planes phase 1 produced — a locally scored winner is looked up there.
+// dp (optional; host-free calls): what the call's earlier kernels would have published to the host one by one — stage B's two counts
+// (device words; they go to dp->host[0] as ONE word: edges | triangles << 32, ~0 if either needs more than 32 bits) and, with_stats,
+// the staging kernel's coordinate statistics (FX_MX_WORDS words -> [13] maxima, [16 .. 21] boxes) — written by THIS kernel, before
+// the winner.  Those kernels then publish nothing: a system-scope store costs the kernel that makes it ~0.5 us.
+struct DeferredPub {
+  const uint64_t* dev_edges;
+  const uint64_t* dev_triangles;
+  const uint32_t* coord_max;
+  unsigned long long* host;
+  int with_stats;
+};
 void launch_finalize(const Points& pts, const TriSource& ts, const Shard& sh, const float* RtSoA,
                      const uint32_t* sel_key, uint32_t T, const uint64_t* key2, int npairs, uint64_t* key_out, float tau2, float* Rt12, uint8_t* mask,
-                     uint32_t* rank_acc, uint32_t* ticket, uint64_t* host_out, hipStream_t st);
+                     uint32_t* rank_acc, uint32_t* ticket, uint64_t* host_out, hipStream_t st, const DeferredPub* dp = nullptr);
 // SURVEY §8f-2 (SC_FLAG_REFINE): fp64 least-squares refit of Rt12 over the inlier mask; no-op when key2[0] == 0 or
 // fewer than 3 inliers.  scratch: refine_scratch_bytes(n).
 size_t refine_scratch_bytes(int n);

@@ -1910,7 +1910,7 @@ __global__ __launch_bounds__(256) void finalize_kernel(const float* __restrict__
                                                        unsigned long long* __restrict__ key_out, float tau2,
                                                        float* __restrict__ Rt12, uint8_t* __restrict__ mask,
                                                        uint32_t* __restrict__ rank_acc, uint32_t* __restrict__ ticket,
-                                                       unsigned long long* __restrict__ host_out) {
+                                                       unsigned long long* __restrict__ host_out, DeferredPub dp) {
   __shared__ uint64_t lds[8];
   __shared__ float sRt[12];
   __shared__ uint32_t s_last;
@@ -1926,7 +1926,7 @@ __global__ __launch_bounds__(256) void finalize_kernel(const float* __restrict__
   if (k0 != 0) g = 0xFFFFFFFFu - (uint32_t)((two_stage ? k1 : k0) & 0xFFFFFFFFull);
   // The pairs come from the caller (an all-gather): a position outside the selection — a stale or uninitialised pair,
   // ranks that disagree on T or the parameters — must not index sel_key / the triangle lookup.  It is treated as "no
-  // hypothesis" (identity, zero mask) and reported: host_out[3] = 1 makes the host return SC_EINVAL.
+  // hypothesis" (identity, zero mask) and reported: host_out[1] = all ones makes the host return SC_EINVAL.
   const bool bad_pair = k0 != 0 && g >= T;
   if (bad_pair) { k0 = 0; k1 = 0; g = 0; }
   if (key_out && blockIdx.x == 0 && threadIdx.x == 0) { key_out[0] = k0; key_out[1] = k0 ? k1 : 0ull; }
@@ -1995,10 +1995,27 @@ __global__ __launch_bounds__(256) void finalize_kernel(const float* __restrict__
       const uint32_t rank = __hip_atomic_load(rank_acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       __hip_atomic_store(rank_acc, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // ready for the next call
       __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (host_out && dp.host) {
+        // a host-free call: the words its earlier kernels would have published one by one go to the host HERE, with the winner
+        // (relaxed system-scope stores: the release store of the key below orders them before it).  Every such store costs the
+        // kernel that makes it ~0.5 us (seven of them cost the staging kernel 1.7 us; nine here cost this kernel 5:
+        // profiles/r05_ab_deferred_publish.txt), so stage B's two counts travel in ONE word — edges in the low half, triangles in
+        // the high half, all ones where one of them does not fit (the host then repeats the call) — and the staging kernel's
+        // coordinate statistics only every 64th host-free call of a context (dp.with_stats): a host-free call picks stage C2's
+        // kernel by the statistics of an earlier frame anyway, and any pick gives the same counts.
+        auto put = [&](int idx, unsigned long long v) { __hip_atomic_store(&dp.host[idx], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); };
+        const unsigned long long e = *dp.dev_edges, m = *dp.dev_triangles;
+        put(0, (e < (1ull << 32) && m < (1ull << 32)) ? (e | (m << 32)) : ~0ull);
+        if (dp.with_stats) {
+          for (int k = 0; k < 6; k++) put(16 + k, ((unsigned long long)dp.coord_max[8 + k] << 32) | dp.coord_max[2 + k]);
+          put(13, ((unsigned long long)dp.coord_max[1] << 32) | dp.coord_max[0]);
+        }
+      }
       if (host_out) {  // [0] last: the host polls it (release orders the others before it)
-        host_out[3] = bad_pair ? 1ull : 0ull;
-        host_out[1] = g;
-        host_out[2] = k0 ? (two_stage ? (unsigned long long)rank : (unsigned long long)g) : 0ull;
+        // ONE word beside the key (a system-scope store costs ~0.5 us: see DeferredPub): the winner's rank index in the high half,
+        // its position in the low half — or all ones: a key pair that decodes to nothing of the selection (the host: SC_EINVAL)
+        const unsigned long long rk = k0 ? (two_stage ? (unsigned long long)rank : (unsigned long long)g) : 0ull;
+        __hip_atomic_store(&host_out[1], bad_pair ? ~0ull : ((rk << 32) | (unsigned long long)g), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         publish_host(reinterpret_cast<uint64_t*>(host_out), k0);
       }
     }
@@ -2022,14 +2039,14 @@ __global__ __launch_bounds__(256) void mask_kernel(const float* __restrict__ pla
 
 void launch_finalize(const Points& pts, const TriSource& ts, const Shard& sh, const float* RtSoA,
                      const uint32_t* sel_key, uint32_t T, const uint64_t* key2, int npairs, uint64_t* key_out, float tau2, float* Rt12, uint8_t* mask,
-                     uint32_t* rank_acc, uint32_t* ticket, uint64_t* host_out, hipStream_t st) {
+                     uint32_t* rank_acc, uint32_t* ticket, uint64_t* host_out, hipStream_t st, const DeferredPub* dp) {
   uint32_t blocks = (uint32_t)((pts.n + 255) / 256);  // the mask needs these; more only if the key list is long
   const uint32_t for_keys = (T / 4 + 1023) / 1024;    // >= 4 uint4 per thread before another block pays off
   if (for_keys > blocks) blocks = for_keys < 1024u ? for_keys : 1024u;
   hipLaunchKernelGGL(finalize_kernel, dim3(blocks), dim3(256), 0, st, pts.planes, pts.n, pts.ld, ts, sh, RtSoA, sel_key, T,
                      reinterpret_cast<const unsigned long long*>(key2), npairs,
                      reinterpret_cast<unsigned long long*>(key_out), tau2, Rt12, mask, rank_acc, ticket,
-                     reinterpret_cast<unsigned long long*>(host_out));
+                     reinterpret_cast<unsigned long long*>(host_out), dp ? *dp : DeferredPub{nullptr, nullptr, nullptr, nullptr, 0});
 }
 
 // ------------------------------------------------------------------------------------------------

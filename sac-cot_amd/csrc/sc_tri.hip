@@ -1142,7 +1142,7 @@ __global__ __launch_bounds__(64 * EBK_ROWS) void edge_build_kernel(const uint64_
   }
   if (i == n - 1 && lane == 0) {  // the last row's wave knows the edge count: the host polls for it
     edge_off[n] = ebase_row;
-    publish_host(host_total, ebase_row);
+    if (host_total) publish_host(host_total, ebase_row);  // (nullptr: a host-free call reads the count from edge_off[n] — DeferredPub)
   }
 }
 
