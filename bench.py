@@ -409,16 +409,21 @@ def main() -> int:
         pair = [reg, regB]
         for i in range(max(W, 2)):   # the second context's own history: other scenes than the first one's (every rank alike)
             rcb, _ = step(p_hot, K // 2 + i, regB)
+        # (the device addresses of every scene and of its output slot, taken once: indexing a tensor inside the timed loop costs
+        # microseconds per frame, and its first use ~0.1 ms — that was the first timed step's 0.33 ms)
+        ptrs = [(d_srcs[k].data_ptr(), d_tgts[k].data_ptr(), Rt_all[k].data_ptr(), mask_all[k].data_ptr()) for k in range(K)]
         if world == 1:
             def enqueue(f, k):
-                pair[f & 1].register_device_async(d_srcs[k].data_ptr(), d_tgts[k].data_ptr(), cfg.n, p_hot, Rt_all[k].data_ptr(), mask_all[k].data_ptr())
+                a_ = ptrs[k]
+                pair[f & 1].register_device_async(a_[0], a_[1], cfg.n, p_hot, a_[2], a_[3])
             # (a frame whose host-free enqueue turns out void is repeated inside sc_wait)
         else:
-            rs = pkg.shard.ReplicatedStream(pkg, pair, cfg.n, p_hot, world, lambda k_: torch.zeros(k_, dtype=torch.int64, device=dev))
+            rs = pkg.shard.ReplicatedStream(pkg, pair, cfg.n, p_hot, world, lambda k_: torch.zeros(k_, dtype=torch.int64, device=dev),
+                                            ptr=lambda t_: t_ if isinstance(t_, int) else t_.data_ptr())
             rs.estimate = rep_est[0]
 
             def enqueue(f, k):
-                rs.enqueue(f, d_srcs[k], d_tgts[k], Rt_all[k], mask_all[k])
+                rs.enqueue(f, *ptrs[k])
 
         def run_stream(frames, scene_of, timed_hot=False):
             """`frames` frames, frame f + 1 enqueued before frame f's winner is waited for -> (wall s, per-frame (scene, rc, rank,

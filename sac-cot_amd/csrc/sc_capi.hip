@@ -217,7 +217,11 @@ int ensure_room(sc_ctx* c, Buf& b, size_t need, size_t room) {
 // stream, frames of 386 k .. 697 k edges: with "plus half" from the first frame on, one of the first twenty was repeated).
 uint64_t cover_of(uint64_t last, const uint64_t hi[2], bool young) {
   const uint64_t h = hi[0] > hi[1] ? hi[0] : hi[1];
-  const uint64_t a = young ? 2 * last : last + last / 2, b = h + h / 4;
+  const uint64_t b = h + h / 4;
+  // young: twice the last count (or the window's maximum plus a quarter, if larger); later the window alone decides — the last
+  // count is in it — so that a stream's covers stay put from frame to frame instead of following every large frame by half
+  // (a cover beyond 2^20 edges takes the scan's two-launch form, and every launch sized by it grows with it)
+  const uint64_t a = young ? 2 * last : (h ? 0 : last + last / 2);
   return (a > b ? a : b) + 4096;
 }
 
@@ -555,7 +559,8 @@ int run_edges(sc_ctx* c, const sc_params* p, uint32_t* hist, uint32_t part, uint
   auto fill_edges = [&](uint64_t cap) {
     if (build) {
       launch_edge_build(g, points_of(c), c->dv, c->bits2.as<uint64_t>(), c->edge_off.as<uint64_t>(), c->ebase.as<uint32_t>(),
-                        c->ei.as<uint32_t>(), c->ej.as<uint32_t>(), c->es.as<float>(), cap, c->spec_on ? nullptr : &c->pinned[0], st);
+                        c->ei.as<uint32_t>(), c->ej.as<uint32_t>(), c->es.as<float>(), cap, c->spec_on ? nullptr : &c->pinned[0], st,
+                        c->spec_on ? c->ctl.as<ControlBlock>()->live_edges : nullptr);
       return;
     }
     launch_edge_fill(g, points_of(c), c->dv, c->edge_off.as<uint64_t>(), c->ei.as<uint32_t>(), c->ej.as<uint32_t>(),
@@ -713,7 +718,8 @@ int run_select(sc_ctx* c, const sc_params* p, const uint32_t* hist, bool want_li
     // launches make the cut, and the counting pass skips the edges of the other ranks.
     launch_prune_bits(g, hist ? hist : ctl->prune_hist, hist == nullptr, c->ei.as<uint32_t>(), c->ej.as<uint32_t>(), c->es.as<float>(), E,
                       c->est_active ? c->plan.hist_want : (uint64_t)p->max_triangles, 3.0f * p->t_cmp * 0.999f, c->bits2.as<uint64_t>(), &ctl->smin, &ctl->klb, sl,
-                      c->tcnt.as<uint32_t>(), recut ? nullptr : own_range_of(c), st, E_dev, c->est_active);
+                      c->tcnt.as<uint32_t>(), recut ? nullptr : own_range_of(c), st, E_dev, c->est_active,
+                      spec && c->build && !c->sharded_ab);  // (the scan of such a call is trimmed to the real edges: below)
     if (recut) {
       ENSURE(c, c->rowcost, ((size_t)c->n + 4 + 1024) * 4);  // (cost_split_kernel reads whole 16-byte pieces)
       launch_strong_rowcost(g, c->bits2.as<uint64_t>(), c->rowcost.as<uint32_t>(), st);
@@ -753,6 +759,9 @@ int run_select(sc_ctx* c, const sc_params* p, const uint32_t* hist, bool want_li
   arm_word(c, 2);
   ScanExtra xr;  // sharded: the counts outside this rank's edge range are zero — their tiles are skipped
   xr.range = own_range_of(c);
+  // a host-free call on the fused edge kernel: the launches cover E edges, the graph has fewer — the scan skips the tiles beyond
+  // them (the pruning kernel's workgroups there have left without writing their counts)
+  if (spec && c->build && !c->sharded_ab) xr.range = c->ctl.as<ControlBlock>()->live_edges;
   { const int lrc = lb_next(c, scan_temp_bytes(E), 0, 0, &xr.lb); if (lrc) return lrc; }
   launch_scan_u32(c->tcnt.as<uint32_t>(), E, c->toff.as<uint64_t>(), c->scan_tmp.p, c->tn, st, spec ? nullptr : &c->pinned[2], &xr);
   // While the host polls for the count, the key kernel already runs into the key arrays this context holds from earlier

@@ -729,6 +729,11 @@ constexpr int SCAN_TILE = SCAN_THREADS * SCAN_ITEMS;
 
 // range (optional, device): [lo, hi) outside which every input is known to be zero (sharded stage B: the per-edge
 // triangle counts of the edges other ranks enumerate) — tiles wholly outside are neither read nor written.
+// ... and inside a tile that straddles an end of the range the elements outside it read as zero WITHOUT being read (r05: a host-free
+// call's per-edge counts beyond its real edge count are never written — sc_capi.hip, ControlBlock::live_edges)
+__device__ __forceinline__ bool scan_live(const uint64_t* __restrict__ range, size_t idx) {
+  return !range || ((uint64_t)idx >= range[0] && (uint64_t)idx < range[1]);
+}
 __device__ __forceinline__ bool scan_tile_dead(const uint64_t* __restrict__ range, size_t tile) {
   if (!range) return false;
   const uint64_t t0 = (uint64_t)tile * SCAN_TILE;
@@ -743,7 +748,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_block_sums_kernel(const uin
   const size_t base = (size_t)blockIdx.x * SCAN_TILE + (size_t)threadIdx.x * SCAN_ITEMS;
   uint64_t s = 0;
 #pragma unroll
-  for (int k = 0; k < SCAN_ITEMS; k++) if (base + k < n) s += in[base + k];
+  for (int k = 0; k < SCAN_ITEMS; k++) if (base + k < n && scan_live(range, base + k)) s += in[base + k];
   s = block_reduce_u64(s, lds);
   if (threadIdx.x == 0) bsum[blockIdx.x] = s;
 }
@@ -786,7 +791,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_downsweep_kernel(const uint
   uint32_t v[SCAN_ITEMS];
   uint64_t s = 0;
 #pragma unroll
-  for (int k = 0; k < SCAN_ITEMS; k++) { v[k] = (base + k < n) ? in[base + k] : 0u; s += v[k]; }
+  for (int k = 0; k < SCAN_ITEMS; k++) { v[k] = (base + k < n && scan_live(range, base + k)) ? in[base + k] : 0u; s += v[k]; }
   uint64_t pre;
   if (SELF) {
     uint64_t a = 0;
@@ -831,7 +836,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_lookback_kernel(const uint3
   uint32_t v[SCAN_ITEMS];
   uint64_t s = 0;
 #pragma unroll
-  for (int k = 0; k < SCAN_ITEMS; k++) { v[k] = (!dead && base + k < n) ? in[base + k] : 0u; s += v[k]; }
+  for (int k = 0; k < SCAN_ITEMS; k++) { v[k] = (!dead && base + k < n && scan_live(range, base + k)) ? in[base + k] : 0u; s += v[k]; }
   uint64_t tot;
   const uint64_t ex = block_exscan_u64(s, lds, &tot);
   if (threadIdx.x < 64) {
@@ -926,7 +931,7 @@ void launch_scan_u32(const uint32_t* in, size_t n, uint64_t* out, void* temp, co
   if (nb == 0) return;  // n == 0 is handled by the small path above
   // single-pass form while the look-back stays shallow (r02: 116 tiles 10.6 us against 4.9 + 7.9; 781 tiles 16.4 against
   // 5.0 + 9.4 — every 64 tiles are one more dependent round of descriptor loads)
-  if (x && x->lb.epoch && x->lb.desc && x->lb.ticket && tn.scan_self_max != 0 && nb <= 256) {
+  if (x && x->lb.epoch && x->lb.desc && x->lb.ticket && tn.scan_self_max != 0 && nb <= (size_t)(range ? 512 : 256)) {  // (tiles outside a range publish a zero at once: a trimmed launch may be longer)
     hipLaunchKernelGGL(scan_lookback_kernel, dim3((unsigned)nb), dim3(SCAN_THREADS), 0, st, in, n, out, x->lb, host_total,
                        range, eb);
     return;

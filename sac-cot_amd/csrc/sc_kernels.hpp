@@ -181,7 +181,8 @@ void launch_edge_fill(const Graph& g, const Points& pts, const Derived& dv, cons
 // lands in edge_off[n].
 bool edge_build_fits(int n);
 void launch_edge_build(const Graph& g, const Points& pts, const Derived& dv, uint64_t* zero_rows, uint64_t* edge_off, uint32_t* ebase,
-                       uint32_t* ei, uint32_t* ej, float* es, uint64_t cap, uint64_t* host_total, hipStream_t st);
+                       uint32_t* ei, uint32_t* ej, float* es, uint64_t cap, uint64_t* host_total, hipStream_t st,
+                       uint64_t* live_range = nullptr);  // live_range (optional, device, 2 x u64): receives [0, edge count)
 // tcnt[e] = #k > j adjacent (in `mbits`) to both ends of edge e = (i,j); edges with es[e] < *smin count 0
 // (smin == nullptr: no pruning, mbits = g.bits).
 void launch_tri_count(const Graph& g, const uint64_t* mbits, const float* es, const float* smin, const uint32_t* ei,
@@ -242,7 +243,8 @@ void launch_prune_bits(const Graph& g, const uint32_t* hist, bool hist_is_copies
                        uint64_t E, uint64_t want, float key_floor, uint64_t* mbits, float* smin, uint32_t* klb,
                        const StrongList& sl, uint32_t* tcnt, const uint64_t* own, hipStream_t st,
                        const uint64_t* E_dev = nullptr,   // E_dev: as above; with sl.list the tcnt entries of [*E_dev, E) are zeroed too
-                       bool logbins = false);             // hist comes from launch_sample_estimate (logarithmic bins of 3.0 - key)
+                       bool logbins = false,              // hist comes from launch_sample_estimate (logarithmic bins of 3.0 - key)
+                       bool trimmed = false);             // (with E_dev) the scan that follows skips the counts beyond *E_dev: the workgroups there leave at once
 // sharded stage B, after the certificate: work estimate per row of the PRUNED graph (strong_rowcost_kernel), and — in one
 // single-block launch — its prefix and this rank's row / edge range (the rule of launch_shard_split)
 void launch_strong_rowcost(const Graph& g, const uint64_t* mbits, uint32_t* rowcost, hipStream_t st);
@@ -308,7 +310,8 @@ struct ControlBlock {
   uint32_t pad0[9];
   uint64_t key2[2];          // internal winner key pair (sc_register_device)
   uint64_t own_edge[2];      // ... and its CSR edge range (launch_shard_split)
-  uint64_t pad1[4];
+  uint64_t live_edges[2];    // host-free calls: [0, edges of the graph) — written by launch_edge_build; the scan of the per-edge counts skips the tiles beyond it
+  uint64_t pad1[2];
   SelectState sel;
   // stage C2's reference frame (sc_gramref.hpp): slot v = the best (key bits << 32 | workgroup) among the workgroups = v (mod 64) of the
   // estimating sample — its voter v is that workgroup's candidate triangle

@@ -957,6 +957,12 @@ __global__ __launch_bounds__(256) void tri_sample_words_kernel(const uint64_t* _
   // C2's reference frame (sc_gramref.hpp)
   if (E_dev && *E_dev > E) return;  // (launched before the host knew the count: see tri_sample_hist_kernel)
   if (E_dev) E = *E_dev;
+  // a host-free call's grid covers more edges than there are: the workgroups beyond them leave before they clear 16 KiB of LDS
+  // (one that would have left a candidate says "none": cand is not cleared between calls)
+  if ((uint64_t)blockIdx.x * 256 >= E) {
+    if (cand != nullptr && blockIdx.x < SAMPLE_CAND_BLOCKS && threadIdx.x == 0) cand[blockIdx.x] = make_uint4(0u, 0u, 0u, 0u);
+    return;
+  }
   uint32_t best_key = 0u, best_e = 0u, best_k = 0u;  // (E < 2^32)
   // only the first SAMPLE_CAND_BLOCKS workgroups keep their best triangle (tracking it in every one cost the launch 3.6 us at C2;
   // 64 voters want 64 good triangles, and the best of these workgroups' ~50 000 sampled keys per voter is that)
@@ -1060,7 +1066,8 @@ __global__ __launch_bounds__(64 * EBK_ROWS) void edge_build_kernel(const uint64_
                                                                    uint32_t* __restrict__ ebase,
                                                                    uint32_t* __restrict__ ei, uint32_t* __restrict__ ej,
                                                                    float* __restrict__ es, uint64_t cap,
-                                                                   uint64_t* __restrict__ host_total) {
+                                                                   uint64_t* __restrict__ host_total,
+                                                                   uint64_t* __restrict__ live_range) {
   __shared__ uint64_t s_red[EBK_ROWS];
   __shared__ uint32_t l_j[EBK_ROWS][EBK_CH];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -1142,6 +1149,7 @@ __global__ __launch_bounds__(64 * EBK_ROWS) void edge_build_kernel(const uint64_
   }
   if (i == n - 1 && lane == 0) {  // the last row's wave knows the edge count: the host polls for it
     edge_off[n] = ebase_row;
+    if (live_range) { live_range[0] = 0ull; live_range[1] = ebase_row; }
     if (host_total) publish_host(host_total, ebase_row);  // (nullptr: a host-free call reads the count from edge_off[n] — DeferredPub)
   }
 }
@@ -1149,14 +1157,14 @@ __global__ __launch_bounds__(64 * EBK_ROWS) void edge_build_kernel(const uint64_
 bool edge_build_fits(int n) { return n <= 64 * EBK_WMAX; }
 
 void launch_edge_build(const Graph& g, const Points& pts, const Derived& dv, uint64_t* zero_rows, uint64_t* edge_off, uint32_t* ebase,
-                       uint32_t* ei, uint32_t* ej, float* es, uint64_t cap, uint64_t* host_total, hipStream_t st) {
+                       uint32_t* ei, uint32_t* ej, float* es, uint64_t cap, uint64_t* host_total, hipStream_t st, uint64_t* live_range) {
   const dim3 grid((g.n + EBK_ROWS - 1) / EBK_ROWS), block(64 * EBK_ROWS);
   if (g.W <= 128)
     hipLaunchKernelGGL(edge_build_kernel<2>, grid, block, 0, st, g.bits, pts.planes, dv, g.n, g.ld, g.W, g.degp,
-                       const_cast<uint32_t*>(g.wpre), zero_rows, edge_off, ebase, ei, ej, es, cap, host_total);
+                       const_cast<uint32_t*>(g.wpre), zero_rows, edge_off, ebase, ei, ej, es, cap, host_total, live_range);
   else
     hipLaunchKernelGGL(edge_build_kernel<5>, grid, block, 0, st, g.bits, pts.planes, dv, g.n, g.ld, g.W, g.degp,
-                       const_cast<uint32_t*>(g.wpre), zero_rows, edge_off, ebase, ei, ej, es, cap, host_total);
+                       const_cast<uint32_t*>(g.wpre), zero_rows, edge_off, ebase, ei, ej, es, cap, host_total, live_range);
 }
 
 // sum of the copies -> one 256-bin histogram (the form the ranks exchange)
@@ -1182,12 +1190,16 @@ __global__ __launch_bounds__(256) void prune_bits_kernel(const uint32_t* __restr
                                                          uint32_t* __restrict__ klb_out, StrongList sl,
                                                          uint32_t* __restrict__ tcnt,
                                                          const uint64_t* __restrict__ own,
-                                                         const uint64_t* __restrict__ E_dev) {
+                                                         const uint64_t* __restrict__ E_dev, int trimmed) {
   // E: what the grid and the arrays cover; Ea: the edges there really are (E_dev: launched before the host knew).  More than
   // the arrays hold: nothing may run — no strong edge is listed, so the counting and key kernels that follow find no work
   // (the host repeats the call)
   if (E_dev && *E_dev > E) return;
   const uint64_t Ea = E_dev ? *E_dev : E;
+  // a host-free call's grid covers more edges than there are: the workgroups beyond them have nothing to list, and their tcnt
+  // entries are never read (the scan of a host-free call skips the tiles beyond ControlBlock::live_edges and treats what lies
+  // beyond the count as zero) — they leave before the histogram walk
+  if (trimmed && E_dev && sl.region_blocks == 0 && (uint64_t)blockIdx.x * 256 >= Ea) return;
   __shared__ uint64_t lds[8];
   __shared__ float s_smin;
   __shared__ uint32_t s_klb, s_base, s_wcnt[4];
@@ -1374,14 +1386,15 @@ void launch_sample_estimate(const Graph& g, const uint32_t* ebi, const uint32_t*
 
 void launch_prune_bits(const Graph& g, const uint32_t* hist, bool hist_is_copies, const uint32_t* ei, const uint32_t* ej, const float* es,
                        uint64_t E, uint64_t want, float key_floor, uint64_t* mbits, float* smin, uint32_t* klb,
-                       const StrongList& sl, uint32_t* tcnt, const uint64_t* own, hipStream_t st, const uint64_t* E_dev, bool logbins) {
+                       const StrongList& sl, uint32_t* tcnt, const uint64_t* own, hipStream_t st, const uint64_t* E_dev, bool logbins,
+                       bool trimmed) {
   uint32_t klo, shift;
   prune_window(key_floor, &klo, &shift);
   if (logbins) shift = PR_LOGBINS;  // the histogram of launch_sample_estimate
   const uint64_t blocks = sl.region_blocks ? (uint64_t)sl.region_blocks * ST_SHARDS : (E + 255) / 256;
   hipLaunchKernelGGL(prune_bits_kernel, dim3((unsigned)blocks), dim3(256), 0, st, hist,
                      hist_is_copies ? PR_HCOPIES : 1, want, klo, shift, ei,
-                     ej, es, E, g.W, reinterpret_cast<unsigned long long*>(mbits), smin, klb, sl, tcnt, own, E_dev);
+                     ej, es, E, g.W, reinterpret_cast<unsigned long long*>(mbits), smin, klb, sl, tcnt, own, E_dev, trimmed ? 1 : 0);
 }
 
 // Sharded stage B, after the certificate: what enumerating row i of the PRUNED graph costs — 32 x the triangles of a
