@@ -219,6 +219,8 @@ def main() -> int:
                     help="distinct synthetic scenes of the config's shape the frames cycle through (seeds cfg.seed + k, inlier ratio drawn "
                          "in [2/3, 4/3] of the config's: C2 0.10 .. 0.20, so edge counts move by ~1.6 x and triangle counts by ~4 x from "
                          "frame to frame); frame f registers scene f mod SCENES.  1 = every frame the config's own scene (rounds 1 - 4)")
+    ap.add_argument("--hot-timing-every", type=int, default=1,
+                    help="SC_FLAG_TIMING_HOT (the dominant kernel's duration from its dispatch packets' timestamps) on every N-th timed frame (0: none)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--headline-only", action="store_true",
                     help="only the timed loop and the per-stage passes (no cold call, host-I/O, varying-N, no-dense-S or CPU "
@@ -365,6 +367,11 @@ def main() -> int:
         torch.cuda.synchronize()
 
     p_hot = mk(pkg.SC_FLAG_TIMING_HOT)
+    p_plain = mk(0)
+    HE = max(0, args.hot_timing_every)
+
+    def p_of(f):   # SC_FLAG_TIMING_HOT on every HE-th timed frame: the flag's two dispatch-packet timestamps are not free
+        return p_hot if HE and f % HE == 0 else p_plain
     W = args.warmup
     # Warm-up: the W frames BEFORE frame 0 of the cycle (scenes K - W .. K - 1), so that no timed frame repeats the frame its context
     # saw last.  No fallback of any kind: a failure here is the result (every rank runs the same sequence of collectives, so an
@@ -372,6 +379,8 @@ def main() -> int:
     for i in range(W):
         step(p_hot, K - W + i)
     hot_score = 0.0
+    n_hot = [0]
+    n_hot_timed = 0
     # The interpreter's cyclic garbage collector stays out of every timed region of this process: a generation-2 pass costs ~40 ms
     # here — 170 steps' worth — and landed in the varying-n leg in round 4 (20 calls: 2.4 ms per call on average, median 0.24).  Nothing the
     # timed code allocates is cyclic; what exists so far is frozen, reference counting keeps freeing the rest.
@@ -415,7 +424,7 @@ def main() -> int:
         if world == 1:
             def enqueue(f, k):
                 a_ = ptrs[k]
-                pair[f & 1].register_device_async(a_[0], a_[1], cfg.n, p_hot, a_[2], a_[3])
+                pair[f & 1].register_device_async(a_[0], a_[1], cfg.n, p_of(f), a_[2], a_[3])
             # (a frame whose host-free enqueue turns out void is repeated inside sc_wait)
         else:
             rs = pkg.shard.ReplicatedStream(pkg, pair, cfg.n, p_hot, world, lambda k_: torch.zeros(k_, dtype=torch.int64, device=dev),
@@ -429,6 +438,7 @@ def main() -> int:
             """`frames` frames, frame f + 1 enqueued before frame f's winner is waited for -> (wall s, per-frame (scene, rc, rank,
             count, edges, triangles), winner-to-winner times, frames the CALLER had to repeat, sum of us_score)"""
             res, ts, n_redo, hot = [], [], 0, 0.0
+            n_hot[0] = 0
             fence()
             t0 = time.perf_counter()
             enqueue(0, scene_of(0))
@@ -444,13 +454,15 @@ def main() -> int:
                     n_redo += rs.redone - r0_
                 tn_ = time.perf_counter()
                 ts.append(tn_ - tl); tl = tn_         # (winner to winner)
-                hot += st["us_score"]
+                if HE and (f - 1) % HE == 0:
+                    hot += st["us_score"]; n_hot[0] += 1
                 res.append((scene_of(f - 1), rc, st["best_rank"], st["best_count"], st["edges"], st["tri_total"]))
             fence()
             return time.perf_counter() - t0, res, ts, n_redo, hot, st
 
         c0 = ctr_now(pair)
         dt, res, step_s, n_redo, hot_score, st = run_stream(args.steps, lambda f: f % K)
+        n_hot_timed = n_hot[0]
         rc = res[-1][1]
         c1 = ctr_now(pair)
         counters = ctr_diff(c0, c1, n_redo)
@@ -467,7 +479,11 @@ def main() -> int:
         tw0 = time.perf_counter()
         for f in range(args.steps):
             ts0 = time.perf_counter()
-            rcw, stw = step(p_hot, f % K, reg, Rt_all[f % K], mask_all[f % K])
+            a_ = ptrs[f % K]
+            if world == 1:
+                rcw, stw = reg.register_device(a_[0], a_[1], cfg.n, p_hot, a_[2], a_[3])
+            else:
+                rcw, stw = rs.waited(0, *a_)
             w_s.append(time.perf_counter() - ts0)
             if per_scene[f % K] != (rcw, stw["best_rank"], stw["best_count"]):
                 print(f"bench.py: waited and streamed frames of scene {f % K} disagree: {(rcw, stw['best_rank'], stw['best_count'])} vs {per_scene[f % K]}", file=sys.stderr)
@@ -524,9 +540,10 @@ def main() -> int:
         t0 = time.perf_counter()
         for f in range(args.steps):
             ts0 = time.perf_counter()
-            rc, st = step(p_hot, f % K)
+            rc, st = step(p_of(f), f % K)
             step_s.append(time.perf_counter() - ts0)   # (every step ends with the winner on the host: its own wall time is meaningful)
-            hot_score += st["us_score"]
+            if HE and f % HE == 0:
+                hot_score += st["us_score"]; n_hot_timed += 1
         fence()
         dt = time.perf_counter() - t0
     # (the stage passes, the CPU baseline and the legs below run the config's own scene, scenes[0]: make it the context's last call)
@@ -552,7 +569,11 @@ def main() -> int:
         tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
-    us_score = hot_score / args.steps  # the roofline duration of the dominant kernel: measured inside the timed steps
+    if n_hot_timed:
+        us_score = hot_score / n_hot_timed  # the roofline duration of the dominant kernel: measured inside the timed steps
+    else:                                   # (--hot-timing-every 0: from eight calls after them)
+        us_score = sum(step(p_hot, f % K)[1]["us_score"] for f in range(8)) / 8
+        step(p_hot, 0)
     c2_info = reg.debug_last()         # which C2 kernel the last call ran, the filter's hand-overs
     # the filter kernel alone (its own dispatch timestamps; us_score spans filter + exact pass): eight more calls, outside the timed region
     us_filter = []
