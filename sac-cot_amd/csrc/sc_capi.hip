@@ -73,6 +73,7 @@ struct sc_ctx {
   bool have_hyp = false, begun = false;
   sc_params params{};  // the parameters of the running call (begin -> end)
   bool timing = false, timing_hot = false;
+  uint32_t amx_blocks = 0;  // workgroups of the last arg-max launch whose pairs this context's finalize step reduces itself (0: one reduced pair in `key`)
   bool hot_ext = false;  // SC_FLAG_TIMING_HOT took its timestamps from the kernels' dispatch packets (run_stage_c)
   int timing_one = -1;  // SC_FLAG_TIMING_ONE: the one stage bracket recorded this call (0 .. 6), -1: none
   float ev_overhead_us = -1.f;  // cost of one event record inside a bracket (calibrate_events); < 0: not measured yet
@@ -672,10 +673,10 @@ int run_edges(sc_ctx* c, const sc_params* p, uint32_t* hist, uint32_t part, uint
 // Two launches (count per tile; write, every tile summing the counts before it by itself).  (The ONE-launch form — counts of the
 // earlier tiles by decoupled look-back — was built as VERDICT r01 asked, bit-exact and slower: 16.4 us against 4.7 + 4.7 on C2;
 // removed in r05.)  Tuning::compact_self_max == 0 (a test) takes the scanned three-launch form.
-int run_compaction(sc_ctx* c, const KeyView& view, size_t nb) {
+int run_compaction(sc_ctx* c, const KeyView& view, size_t nb, int rounds, uint64_t* host_short) {
   hipStream_t st = c->stream;
   SelectState* sel = &c->ctl.as<ControlBlock>()->sel;
-  launch_compact_count(view, sel, c->blk_gt.as<uint32_t>(), c->blk_eq.as<uint32_t>(), st);
+  launch_compact_count(view, sel, rounds, c->blk_gt.as<uint32_t>(), c->blk_eq.as<uint32_t>(), st, host_short);
   // few tiles (and M < 2^32): compact_write adds up the tile counts itself, no scan launch in between
   const bool self_off = nb <= c->tn.compact_self_max && view.M < (1ull << 32);
   if (!self_off)
@@ -840,7 +841,7 @@ int run_select(sc_ctx* c, const sc_params* p, const uint32_t* hist, bool want_li
   // an estimated bound is verified by the first round over the a-priori window; any other path leaves it unverified
   if (c->est_active && !fast_window) c->est_void = true;
   launch_select_rounds(view, sel, fast_window ? 2 : 3, c->tn, st, c->sharded_ab ? nullptr : &c->pinned[14]);
-  { const int crc = run_compaction(c, view, nb); if (crc) return crc; }
+  { const int crc = run_compaction(c, view, nb, fast_window ? 2 : 3, c->sharded_ab ? nullptr : &c->pinned[14]); if (crc) return crc; }
   // the list stays in ordinal order: no sort on the hot path (the winner is found by (count, key, position))
   if (want_list)
     launch_tri_decode(c->ei.as<uint32_t>(), c->ej.as<uint32_t>(), c->kcol.as<uint2>(), c->sel_ord.as<uint64_t>(), T_eff,
@@ -1292,8 +1293,12 @@ int run_stage_c(sc_ctx* c, uint64_t* d_key, sc_stats* stats) {
   if ((rc = run_score(c, p, sh, &score_rows, true, hot_ext ? c->ev[4] : nullptr, hot_ext ? c->ev[5] : nullptr, hot_ext ? c->ev[11] : nullptr))) return rc;
   if (!hot_ext && (rc = rec(c, 5))) return rc;
   ENSURE(c, c->amx_pairs, argmax_scratch_bytes(sh.ld_local));
+  // the winner pair: reduced by the launch for a caller that gathers it; left as one pair per workgroup for this context's own
+  // finalize step (sc_register*: d_key is the context's own word), whose workgroups reduce them themselves
+  const bool own_pairs = d_key == c->key.as<uint64_t>() && sh.n_local != 0;
+  c->amx_blocks = own_pairs ? argmax_blocks(sh.ld_local) : 0u;
   launch_argmax(sh, c->partial.as<uint32_t>(), score_rows, c->T_eff ? c->sel_key.as<uint32_t>() : nullptr,
-                c->cnt.as<uint32_t>(), c->amx_pairs.as<uint64_t>(), &c->ctl.as<ControlBlock>()->amx_ticket, d_key, c->stream);
+                c->cnt.as<uint32_t>(), c->amx_pairs.as<uint64_t>(), &c->ctl.as<ControlBlock>()->amx_ticket, own_pairs ? nullptr : d_key, c->stream);
   if ((rc = rec(c, 6))) return rc;
   HIPCHK(c, hipGetLastError());
   c->have_hyp = true;
@@ -1472,8 +1477,8 @@ int sc_shard_score_device(sc_ctx* c, const void* d_cand_all, uint64_t* d_key, sc
                        c->est_active ? &c->pinned[15] : nullptr);
   launch_select_rounds(view, sel, window_known ? 2 : 3, c->tn, st);
   c->pinned[12] = 0;  // "a cut candidate list could have mattered": read by the finalize call (SC_ERETRY)
-  launch_merge_check(d_cand_all, blob_bytes, G, sel, &c->pinned[12], st);
-  { const int crc = run_compaction(c, view, nb); if (crc) return crc; }
+  { const int crc = run_compaction(c, view, nb, window_known ? 2 : 3, nullptr); if (crc) return crc; }
+  launch_merge_check(d_cand_all, blob_bytes, G, sel, &c->pinned[12], st);  // (behind the compaction: its counting kernel is what resolves the last round into k*)
   // the merged length, published by merge_prepare long before the compaction ends: the poll costs no GPU time
   { const int wrc = wait_word(c, 6); if (wrc) return wrc; }
   c->T_eff = (uint32_t)c->pinned[6];
@@ -1500,6 +1505,7 @@ int finalize_enqueue(sc_ctx* c, const uint64_t* d_keys, int n_pairs, float* d_Rt
   // a host-free call's kernels have published nothing yet: this one hands the counts and the coordinate statistics over with the winner
   DeferredPub dp{c->edge_off.as<uint64_t>() + c->n, c->toff.as<uint64_t>() + c->E, c->fx_mx.as<uint32_t>(),
                  reinterpret_cast<unsigned long long*>(c->pinned), (c->n_fast_ok & 63u) == 63u ? 1 : 0};
+  if (d_keys == c->key.as<uint64_t>() && n_pairs == 1 && c->amx_blocks) { d_keys = c->amx_pairs.as<uint64_t>(); n_pairs = (int)c->amx_blocks; }
   launch_finalize(points_of(c), tri_source_of(c), c->sh, c->sh.n_local ? c->rt.as<float>() : nullptr,
                   c->T_eff ? c->sel_key.as<uint32_t>() : nullptr, c->T_eff, d_keys, n_pairs,
                   ctl->key2, c->dv.tau2, d_Rt, d_mask, &ctl->fin_rank, &ctl->fin_ticket, &c->pinned[8], c->stream,

@@ -277,19 +277,29 @@ void launch_tri_count_events(const Graph& g, const uint64_t* mbits, const Strong
                              const uint32_t* ebase = nullptr,  // with ebi == ebj == nullptr: the per-row CSR bases (launch_edge_build)
                              const GramRefJob* ref = nullptr); // one extra workgroup votes for stage C2's reference frame (sc_gramref.hpp)
 
-// Radix-select state.  Lives in the context's control block, which ONE memset zeroes per call; key_range_kernel
-// (end of launch_tri_keys) fills kmin / kmax / want.
+// Radix-select state.  Lives in the context's control block, which the staging kernel zeroes per call.
+// r05: no workgroup of a select round stays behind to "pick": a round only adds its keys into hist[r], and the NEXT launch —
+// round r + 1, or the compaction's counting kernel after the last round — resolves that histogram in every workgroup's prologue
+// (select_resolve: 16 loads per thread + one block scan, ~1 us, overlapped with its first key loads); its workgroup 0 stores the
+// resolved state for the launches after it.  The release + ticket + last workgroup's pass this replaces were ~4 us of a round's 8.
+struct SelSnap {           // the select after some rounds: keys in [lo, lo + 2^wbits) still undecided, `above` keys above it
+  uint32_t lo, wbits;      // valid once started != 0 (before: the window is the key range [kmin, kmax])
+  uint32_t started, done;  // done: the window is one key value, lo = k*
+  uint64_t want;           // number of keys to keep (clamped to what the window holds)
+  uint64_t above;          // keys strictly above the window
+  uint64_t need_eq;        // done: how many keys == k* to keep (lowest ordinals first)
+  uint64_t pad;
+};
 struct SelectState {
   uint32_t kmin, kmax;     // key range
-  uint32_t lo, wbits;      // current window [lo, lo + 2^wbits), valid once started != 0
-  uint32_t started, done;  // kstar / need_eq valid when done
-  uint32_t kstar, ticket;  // ticket: blocks-finished counter of the running round
-  uint64_t want;           // number of keys to keep
-  uint64_t above;          // keys strictly above the current window
-  uint64_t need_eq;        // how many keys == kstar to keep (lowest ordinals first)
-  uint64_t want_req;       // != 0: the window's floor is a bound that must have this many keys at or above it (the last block of
-                           // a select round reports a shortfall: an ESTIMATED pruning bound that was too high, sc_tri.hip 3c)
-  uint32_t hist[4096];
+  uint32_t kstar, done;    // the result (compact_count_kernel's workgroup 0 writes it; every later kernel reads these)
+  uint64_t want;           //   keys kept
+  uint64_t need_eq;        //   how many keys == kstar among them
+  uint64_t want_req;       // != 0: the window's floor is a bound that must have this many keys at or above it (whoever resolves a
+                           // round reports a shortfall: an ESTIMATED pruning bound that was too high, sc_tri.hip 3c)
+  uint64_t pad;
+  SelSnap st[4];           // st[r]: the state BEFORE round r (st[0]: key_range_kernel / the key kernel's preset / merge_prepare_kernel)
+  uint32_t hist[3][4096];  // hist[r]: round r's bins; all zero between selects (compact_write_kernel clears them behind the select)
 };
 static_assert(offsetof(SelectState, hist) % 16 == 0, "SelectState::hist must be 16-byte aligned");
 
@@ -355,9 +365,10 @@ void launch_select_rounds(const KeyView& view, SelectState* s, int rounds, const
                           uint64_t* host_short = nullptr);
 // compaction of the selected keys in ordinal order
 size_t compact_blocks(uint64_t M);
-void launch_compact_count(const KeyView& view, const SelectState* s, uint32_t* blk_gt, uint32_t* blk_eq,
-                          hipStream_t st);
-void launch_compact_write(const KeyView& view, const SelectState* s, const uint32_t* blk_gt,
+// rounds: what launch_select_rounds was given (the counting kernel resolves the last round's histogram; host_short as there)
+void launch_compact_count(const KeyView& view, SelectState* s, int rounds, uint32_t* blk_gt, uint32_t* blk_eq,
+                          hipStream_t st, uint64_t* host_short = nullptr);
+void launch_compact_write(const KeyView& view, SelectState* s, const uint32_t* blk_gt,
                           const uint32_t* blk_eq, const uint64_t* off_gt, const uint64_t* off_eq,
                           uint64_t* sel_ord, uint32_t* sel_key, uint64_t n_sel, hipStream_t st);  // n_sel: entries sel_ord / sel_key hold
 
@@ -528,6 +539,7 @@ hipError_t filter_read_frame(const void* frame, hipStream_t st, uint32_t out[5])
 // cnt (n_local u32): the per-hypothesis counts (the stage hook returns them).  pairs: argmax_scratch_bytes() of
 // per-block (key, position) pairs; ticket: a zeroed u32 in the control block (left zero).
 size_t argmax_scratch_bytes(uint32_t ld_local);
+uint32_t argmax_blocks(uint32_t ld_local);  // workgroups of launch_argmax = pairs it leaves when key2 == nullptr
 void launch_argmax(const Shard& sh, const uint32_t* partial, uint32_t n_chunks, const uint32_t* sel_key,
                    uint32_t* cnt, uint64_t* pairs, uint32_t* ticket, uint64_t* key2, hipStream_t st);
 // C3: winner decode + re-solve + mask.  Rt12 receives R (row-major) and t; identity / zero mask when key2[0] == 0.

@@ -385,6 +385,11 @@ __global__ __launch_bounds__(256) void score_argmax_kernel(const uint32_t* __res
   if (threadIdx.x == 0) {
     __hip_atomic_store(&pairs[2 * blockIdx.x], bk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __hip_atomic_store(&pairs[2 * blockIdx.x + 1], bp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  // key2 == nullptr: the pairs go to this context's own finalize_kernel, whose workgroups each reduce them themselves (r05: the
+  // release, the ticket and the last workgroup's pass over the pairs were ~2.5 us of this launch's 8.6 at C2)
+  if (!key2) return;
+  if (threadIdx.x == 0) {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
     const uint32_t t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     s_last = (t == gridDim.x - 1) ? 1u : 0u;
@@ -1882,6 +1887,7 @@ void launch_score(const Points& pts, const float* RtSoA, const float* RtAoS, con
                           sh.ld_local, dv.tau2, chunk_pts, partial, nv, nm);
 }
 
+uint32_t argmax_blocks(uint32_t ld_local) { return ld_local / 256 < 256 ? ld_local / 256 : 256; }
 size_t argmax_scratch_bytes(uint32_t ld_local) { return (size_t)(ld_local / 256 + 1) * 2 * sizeof(uint64_t); }
 
 void launch_argmax(const Shard& sh, const uint32_t* partial, uint32_t n_chunks, const uint32_t* sel_key,
@@ -1890,7 +1896,7 @@ void launch_argmax(const Shard& sh, const uint32_t* partial, uint32_t n_chunks, 
     (void)hipMemsetAsync(key2, 0, 2 * sizeof(uint64_t), st);
     return;
   }
-  const uint32_t blocks = sh.ld_local / 256 < 256 ? sh.ld_local / 256 : 256;
+  const uint32_t blocks = argmax_blocks(sh.ld_local);
   hipLaunchKernelGGL(score_argmax_kernel, dim3(blocks), dim3(256), 0, st, partial, n_chunks, sh, sel_key, cnt,
                      reinterpret_cast<unsigned long long*>(pairs), ticket, reinterpret_cast<unsigned long long*>(key2));
 }
@@ -1917,9 +1923,22 @@ __global__ __launch_bounds__(256) void finalize_kernel(const float* __restrict__
   // key2: npairs winner key pairs (one per rank, all-gathered; npairs = 1: an already reduced pair).  The reduction of
   // include/saccot.h — K0 = max pair[0], K1 = max pair[1] among the pairs attaining K0 — is a lexicographic max.
   unsigned long long k0 = 0, k1 = 0;
-  for (int w = 0; w < npairs; w++) {  // wave-uniform addresses: scalar loads
-    const unsigned long long a = key2[2 * w], b = key2[2 * w + 1];
-    if (a > k0 || (a == k0 && b > k1)) { k0 = a; k1 = b; }
+  if (npairs <= 8) {
+    for (int w = 0; w < npairs; w++) {  // wave-uniform addresses: scalar loads
+      const unsigned long long a = key2[2 * w], b = key2[2 * w + 1];
+      if (a > k0 || (a == k0 && b > k1)) { k0 = a; k1 = b; }
+    }
+  } else {  // many pairs (the arg-max launch's own workgroups', or a large world's): a thread takes every 256th, the block reduces
+    for (int w = threadIdx.x; w < npairs; w += 256) {
+      const unsigned long long a = key2[2 * w], b = key2[2 * w + 1];
+      if (a > k0 || (a == k0 && b > k1)) { k0 = a; k1 = b; }
+    }
+    unsigned long long* l4 = reinterpret_cast<unsigned long long*>(lds);
+    const unsigned long long K = block_max_u64(k0, l4);
+    __syncthreads();
+    const unsigned long long P = block_max_u64(k0 == K ? k1 : 0ull, l4);
+    __syncthreads();
+    k0 = K; k1 = P;
   }
   const bool two_stage = sel_key != nullptr;
   uint32_t g = 0;

@@ -369,8 +369,8 @@ __global__ __launch_bounds__(1024) void key_range_kernel(const uint32_t* __restr
   __syncthreads();
   if (threadIdx.x == 0) {
     for (int w = 1; w < 16; w++) { kmin = min(kmin, lmin[w]); kmax = max(kmax, lmax[w]); }
-    sel->kmin = kmin; sel->kmax = kmax; sel->want = want;
-    sel->started = 0; sel->done = 0; sel->above = 0;  // (a speculative key pass may have preset a window)
+    sel->kmin = kmin; sel->kmax = kmax;
+    sel->st[0] = SelSnap{0u, 0u, 0u, 0u, want, 0ull, 0ull, 0ull};  // (a speculative key pass may have preset a window)
     sel->want_req = 0;
   }
 }
@@ -572,10 +572,8 @@ __global__ __launch_bounds__(256) void tri_keys_events_kernel(const uint64_t* __
   if (preset && blockIdx.x == 0 && threadIdx.x == 0) {
     const uint32_t lo = *klb ? *klb : 0x40000000u, hi = 0x40400000u;  // 2.0f, 3.0f
     const uint32_t range_m1 = hi - lo;
-    preset->lo = lo;
-    preset->wbits = range_m1 == 0 ? 0u : (uint32_t)(32 - __builtin_clz(range_m1));
     preset->kmin = lo; preset->kmax = hi;
-    preset->started = 1; preset->done = 0; preset->above = 0; preset->want = min(want, (uint64_t)toff[E]);
+    preset->st[0] = SelSnap{lo, range_m1 == 0 ? 0u : (uint32_t)(32 - __builtin_clz(range_m1)), 1u, 0u, min(want, (uint64_t)toff[E]), 0ull, 0ull, 0ull};
     // a pruning bound promises `want` keys at or above it — a certified one by construction, an ESTIMATED one (3c) unless
     // it was set too high: the select's last block compares (the UNclipped want: a pruned graph with fewer triangles than
     // that proves nothing about the full one)
@@ -1539,15 +1537,15 @@ constexpr int SEL_ITEMS = 16;
 // SEL_BITS per round): a 16-bit window resolved in two rounds uses 256 bins per round, not 4096 — every block flushes its
 // non-zero bins with global atomics, and all per-bin loops scale with the bin count.
 struct SelWindow { uint32_t lo, wbits, shift, nbins; };
-__device__ __forceinline__ SelWindow select_window(const SelectState* sel, int rounds_left) {
+__device__ __forceinline__ SelWindow select_window(const SelectState* sel, const SelSnap& cur, int rounds_left) {
   SelWindow w;
-  if (!sel->started) {  // first round: the window is the key range [kmin, kmax]
+  if (!cur.started) {  // first round: the window is the key range [kmin, kmax]
     w.lo = sel->kmin;
     const uint32_t range_m1 = sel->kmax - sel->kmin;
     w.wbits = range_m1 == 0 ? 0u : (uint32_t)(32 - __builtin_clz(range_m1));
   } else {
-    w.lo = sel->lo;
-    w.wbits = sel->wbits;
+    w.lo = cur.lo;
+    w.wbits = cur.wbits;
   }
   const uint32_t rl = rounds_left > 0 ? (uint32_t)rounds_left : 1u;
   uint32_t br = (w.wbits + rl - 1u) / rl;                    // this round's share of the bits
@@ -1600,21 +1598,86 @@ __device__ __forceinline__ uint4 view_load4(const KeyView& v, uint64_t q) {
   return k;
 }
 
+// The state after round r from the state before it and the round's histogram.  Whole workgroup (SEL_THREADS threads, all
+// arrive); lds: 10 words of 8 bytes.  Thread t owns `per` bins counted from the TOP: bins nbins - 1 - (per t + k).  The bins were
+// filled by the previous launch's L2-side atomics: plain loads see them.  *shortfall: a pruning bound promised want_req keys at
+// or above the window's floor and did not keep it (an estimate set too high — sc_tri.hip 3c): the selection of this call proves
+// nothing; the host repeats it with a certifying sample.
+__device__ SelSnap select_resolve(const SelectState* __restrict__ sel, int r, int rounds, uint64_t* lds, bool* shortfall) {
+  static_assert(SEL_THREADS == 256 && SEL_PER == 16, "256 threads, at most 16 bins each");
+  const SelSnap prev = sel->st[r];
+  *shortfall = false;
+  if (prev.done) return prev;  // (an earlier round already came down to one key value: round r added nothing)
+  const SelWindow win = select_window(sel, prev, rounds - r);
+  const int nbins = (int)win.nbins;
+  const int per = nbins >= SEL_THREADS ? nbins / SEL_THREADS : 1;
+  const bool owner = (int)threadIdx.x * per < nbins;
+  const uint32_t* __restrict__ hist = sel->hist[r];
+  uint32_t h[SEL_PER];
+  uint64_t mine = 0;
+#pragma unroll
+  for (int k = 0; k < SEL_PER; k++) {
+    h[k] = (owner && k < per) ? hist[nbins - 1 - ((int)threadIdx.x * per + k)] : 0u;
+    mine += h[k];
+  }
+  const uint64_t want = prev.want, above0 = prev.above;
+  if (threadIdx.x == 0) { lds[8] = 0; lds[9] = above0; }
+  uint64_t tot;
+  const uint64_t before = above0 + block_exscan_u64(mine, lds, &tot);
+  // A window may hold fewer than want - above0 keys only where a rank selects among ITS triangles alone (sharded
+  // stage B: the certified bound promises T keys above it in the whole graph, not in one rank's share): then every key
+  // of the window is taken.  (Unsharded, the window always holds enough and this changes nothing.)
+  const uint64_t want_eff = want < above0 + tot ? want : above0 + tot;
+  *shortfall = sel->want_req != 0 && above0 + tot < sel->want_req;
+  // the crossing thread: before < want <= before + mine (exactly one: the window holds >= want - above0 keys)
+  if (before < want_eff && want_eff <= before + mine) {
+    uint64_t run = before;
+#pragma unroll
+    for (int k = 0; k < SEL_PER; k++) {
+      if (k < per && run < want_eff && want_eff <= run + h[k]) { lds[8] = (uint64_t)(nbins - 1 - ((int)threadIdx.x * per + k)); lds[9] = run; }
+      run += h[k];
+    }
+  }
+  __syncthreads();
+  const uint32_t bin = (uint32_t)lds[8];
+  const uint64_t above = lds[9];
+  __syncthreads();  // (lds is the caller's again)
+  SelSnap nx;
+  nx.lo = win.lo + (bin << win.shift);
+  nx.wbits = win.shift;  // the chosen bin is the next window
+  nx.started = 1u;
+  nx.done = win.shift == 0 ? 1u : 0u;
+  nx.want = want_eff;
+  nx.above = above;
+  nx.need_eq = nx.done ? want_eff - above : 0ull;
+  nx.pad = 0;
+  return nx;
+}
+
+// round r of `rounds` (see SelectState): resolve round r - 1, then add this launch's share of the keys into hist[r]
 template <bool SEG>
 __global__ __launch_bounds__(SEL_THREADS) void select_round_kernel(KeyView view, SelectState* __restrict__ sel,
-                                                                   int rounds_left, uint64_t* __restrict__ host_short) {
+                                                                   int r, int rounds, uint64_t* __restrict__ host_short) {
   const uint64_t M = view_count(view);
   const uint32_t* __restrict__ wkey = view.base;
   __shared__ uint32_t lh[SEL_BINS];
-  __shared__ uint64_t lds[8];
-  __shared__ uint32_t s_bin, s_last;
-  __shared__ uint64_t s_above;
-  if (sel->done) return;  // set by an earlier launch: uniform over the grid
-  const SelWindow win = select_window(sel, rounds_left);
+  __shared__ uint64_t lds[10];
+  for (int b = threadIdx.x; b < SEL_BINS; b += SEL_THREADS) lh[b] = 0;
+  SelSnap cur;
+  if (r == 0) {
+    cur = sel->st[0];
+  } else {
+    bool shortfall;
+    cur = select_resolve(sel, r - 1, rounds, lds, &shortfall);
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+      sel->st[r] = cur;
+      if (shortfall && host_short) publish_host(host_short, 1ull);
+    }
+  }
+  if (cur.done) return;  // uniform over the grid
+  const SelWindow win = select_window(sel, cur, rounds - r);
   const int nbins = (int)win.nbins;
-  for (int b = threadIdx.x; b < nbins; b += SEL_THREADS) lh[b] = 0;
   __syncthreads();
-  const uint64_t want = sel->want, above0 = sel->above;
   const uint64_t width = 1ull << win.wbits;
   const uint64_t M4 = M >> 2;  // whole uint4 groups (wkey comes from hipMalloc: 16-byte aligned)
   const uint64_t stride = (uint64_t)gridDim.x * SEL_THREADS;
@@ -1633,71 +1696,10 @@ __global__ __launch_bounds__(SEL_THREADS) void select_round_kernel(KeyView view,
     if ((key >= win.lo) && (rel < width)) atomicAdd(&lh[(uint32_t)(rel >> win.shift)], 1u);
   }
   __syncthreads();
+  uint32_t* __restrict__ hist = sel->hist[r];
   for (int b = threadIdx.x; b < nbins; b += SEL_THREADS) {
     const uint32_t v = lh[b];
-    if (v) atomicAdd(&sel->hist[b], v);
-  }
-  // ---- arrive; the last block picks.  The bin adds are device-scope atomics (performed at L2 / memory side); every
-  // wave drains them, the block meets, then ONE lane releases at agent scope and takes a ticket (a __threadfence()
-  // by all 256 threads costs ~10 us per block here; this form ~2 us, and only the last block acquires).
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    const uint32_t t = __hip_atomic_fetch_add(&sel->ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    s_last = (t == gridDim.x - 1) ? 1u : 0u;
-    if (s_last) {
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
-  }
-  __syncthreads();
-  if (!s_last) return;
-  // thread t owns `per` bins counted from the TOP: bins nbins - 1 - (per t + k), k = 0 .. per - 1 (threads beyond the
-  // last bin own nothing).  The bins were only ever touched by L2-side atomics; after an acquire by every wave of this
-  // block plain loads see them (agent-scope atomic loads serialise: ~0.8 us each, measured).
-  static_assert(SEL_THREADS == 256 && SEL_PER == 16, "the picking block: 256 threads, at most 16 bins each");
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-  const int per = nbins >= SEL_THREADS ? nbins / SEL_THREADS : 1;
-  const bool owner = (int)threadIdx.x * per < nbins;
-  uint32_t h[SEL_PER];
-  uint64_t mine = 0;
-#pragma unroll
-  for (int k = 0; k < SEL_PER; k++) {
-    h[k] = (owner && k < per) ? sel->hist[nbins - 1 - ((int)threadIdx.x * per + k)] : 0u;
-    mine += h[k];
-  }
-  if (threadIdx.x == 0) { s_bin = 0; s_above = above0; }
-  uint64_t tot;
-  const uint64_t before = above0 + block_exscan_u64(mine, lds, &tot);
-  // A window may hold fewer than want - above0 keys only where a rank selects among ITS triangles alone (sharded
-  // stage B: the certified bound promises T keys above it in the whole graph, not in one rank's share): then every key
-  // of the window is taken.  (Unsharded, the window always holds enough and this changes nothing.)
-  const uint64_t want_eff = want < above0 + tot ? want : above0 + tot;
-  // a pruning bound that promised want_req keys at or above the window's floor and did not keep it (an estimate set too
-  // high — sc_tri.hip 3c): the selection of this call proves nothing; the host repeats it with a certifying sample
-  if (threadIdx.x == 0 && host_short && sel->want_req != 0 && above0 + tot < sel->want_req) publish_host(host_short, 1ull);
-  // the crossing thread: before < want <= before + mine (exactly one: the window holds >= want - above0 keys)
-  if (before < want_eff && want_eff <= before + mine) {
-    uint64_t run = before;
-#pragma unroll
-    for (int k = 0; k < SEL_PER; k++) {
-      if (k < per && run < want_eff && want_eff <= run + h[k]) { s_bin = (uint32_t)(nbins - 1 - ((int)threadIdx.x * per + k)); s_above = run; }
-      run += h[k];
-    }
-  }
-  __syncthreads();
-  for (int b2 = threadIdx.x; b2 < nbins; b2 += SEL_THREADS) sel->hist[b2] = 0u;  // ready for the next round (next launch)
-  if (threadIdx.x == 0) {
-    const uint32_t nlo = win.lo + (s_bin << win.shift);
-    sel->above = s_above;
-    sel->lo = nlo;
-    sel->wbits = win.shift;  // the chosen bin is the next window
-    sel->started = 1;
-    sel->ticket = 0;
-    sel->want = want_eff;
-    if (win.shift == 0) { sel->done = 1; sel->kstar = nlo; sel->need_eq = want_eff - s_above; }
+    if (v) atomicAdd(&hist[b], v);
   }
 }
 
@@ -1713,9 +1715,10 @@ void launch_select_rounds(const KeyView& view, SelectState* s, int rounds, const
   if (tn.sel_blocks >= 1) cap = tn.sel_blocks;
   if (blocks > cap) blocks = cap;
   if (blocks == 0) blocks = 1;
+  if (rounds > 3) rounds = 3;  // (SelectState::hist; 3 x SEL_BITS covers a 32-bit key)
   for (int round = 0; round < rounds; round++) {
-    if (view.seg_len) hipLaunchKernelGGL(select_round_kernel<true>, dim3((unsigned)blocks), dim3(SEL_THREADS), 0, st, view, s, rounds - round, host_short);
-    else hipLaunchKernelGGL(select_round_kernel<false>, dim3((unsigned)blocks), dim3(SEL_THREADS), 0, st, view, s, rounds - round, host_short);
+    if (view.seg_len) hipLaunchKernelGGL(select_round_kernel<true>, dim3((unsigned)blocks), dim3(SEL_THREADS), 0, st, view, s, round, rounds, host_short);
+    else hipLaunchKernelGGL(select_round_kernel<false>, dim3((unsigned)blocks), dim3(SEL_THREADS), 0, st, view, s, round, rounds, host_short);
   }
 }
 
@@ -1751,16 +1754,25 @@ __device__ __forceinline__ void load_tile_keys(const KeyView& view, uint64_t bas
 
 static_assert(CP_ITEMS == 4, "load_tile_keys reads one uint4 group of a segmented view");
 template <bool SEG>
-__global__ __launch_bounds__(CP_THREADS) void compact_count_kernel(KeyView view,
-                                                                   const SelectState* __restrict__ sel,
+__global__ __launch_bounds__(CP_THREADS) void compact_count_kernel(KeyView view, SelectState* __restrict__ sel, int rounds,
                                                                    uint32_t* __restrict__ blk_gt,
-                                                                   uint32_t* __restrict__ blk_eq) {
+                                                                   uint32_t* __restrict__ blk_eq,
+                                                                   uint64_t* __restrict__ host_short) {
+  static_assert(CP_THREADS == SEL_THREADS, "select_resolve: one workgroup of SEL_THREADS");
   __shared__ uint32_t lds[2][4];
-  const uint32_t kstar = sel->kstar;
+  __shared__ uint64_t rl[10];
   const uint64_t base = (uint64_t)blockIdx.x * CP_TILE + (uint64_t)threadIdx.x * CP_ITEMS;
   uint32_t keys[CP_ITEMS];
   int valid;
   load_tile_keys<SEG>(view, base, keys, valid);
+  // the last select round's histogram -> k* (every workgroup by itself; workgroup 0 leaves the result for the launches after this one)
+  bool shortfall;
+  const SelSnap fin = select_resolve(sel, rounds - 1, rounds, rl, &shortfall);
+  const uint32_t kstar = fin.done ? fin.lo : 0u;
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    sel->kstar = kstar; sel->done = fin.done; sel->want = fin.want; sel->need_eq = fin.need_eq;
+    if (shortfall && host_short) publish_host(host_short, 1ull);
+  }
   uint32_t g = 0, q = 0;
 #pragma unroll
   for (int k = 0; k < CP_ITEMS; k++)
@@ -1775,17 +1787,18 @@ __global__ __launch_bounds__(CP_THREADS) void compact_count_kernel(KeyView view,
   }
 }
 
-void launch_compact_count(const KeyView& view, const SelectState* s, uint32_t* blk_gt, uint32_t* blk_eq,
-                          hipStream_t st) {
+void launch_compact_count(const KeyView& view, SelectState* s, int rounds, uint32_t* blk_gt, uint32_t* blk_eq,
+                          hipStream_t st, uint64_t* host_short) {
   if (view.M == 0) return;
+  if (rounds > 3) rounds = 3;
   const dim3 grid((unsigned)compact_blocks(view.M));
-  if (view.seg_len) hipLaunchKernelGGL(compact_count_kernel<true>, grid, dim3(CP_THREADS), 0, st, view, s, blk_gt, blk_eq);
-  else hipLaunchKernelGGL(compact_count_kernel<false>, grid, dim3(CP_THREADS), 0, st, view, s, blk_gt, blk_eq);
+  if (view.seg_len) hipLaunchKernelGGL(compact_count_kernel<true>, grid, dim3(CP_THREADS), 0, st, view, s, rounds, blk_gt, blk_eq, host_short);
+  else hipLaunchKernelGGL(compact_count_kernel<false>, grid, dim3(CP_THREADS), 0, st, view, s, rounds, blk_gt, blk_eq, host_short);
 }
 
 template <bool SEG>
 __global__ __launch_bounds__(CP_THREADS) void compact_write_kernel(KeyView view,
-                                                                   const SelectState* __restrict__ sel,
+                                                                   SelectState* __restrict__ sel,
                                                                    const uint32_t* __restrict__ blk_gt,
                                                                    const uint32_t* __restrict__ blk_eq,
                                                                    const uint64_t* __restrict__ off_gt,
@@ -1797,6 +1810,8 @@ __global__ __launch_bounds__(CP_THREADS) void compact_write_kernel(KeyView view,
   __shared__ uint64_t lds[8];
   const uint32_t kstar = sel->kstar;
   const uint64_t need_eq = sel->need_eq;
+  // the select's histograms are all zero again behind it (no launch reads them any more; a call may select twice: sharded stage B)
+  for (uint32_t z = blockIdx.x * CP_THREADS + threadIdx.x; z < 3u * 4096u; z += gridDim.x * CP_THREADS) (&sel->hist[0][0])[z] = 0u;
   // off_gt == nullptr: this block adds up the tile counts before it by itself (a few thousand u32 from L2) — saves
   // the scan launch in between; both sums ride one u64 (gt high, eq low: each below 2^32 since M < 2^32 here)
   uint64_t gt0, eq0;
@@ -1838,7 +1853,7 @@ __global__ __launch_bounds__(CP_THREADS) void compact_write_kernel(KeyView view,
   }
 }
 
-void launch_compact_write(const KeyView& view, const SelectState* s, const uint32_t* blk_gt,
+void launch_compact_write(const KeyView& view, SelectState* s, const uint32_t* blk_gt,
                           const uint32_t* blk_eq, const uint64_t* off_gt, const uint64_t* off_eq,
                           uint64_t* sel_ord, uint32_t* sel_key, uint64_t n_sel, hipStream_t st) {
   if (view.M == 0) return;
@@ -1965,15 +1980,17 @@ __global__ __launch_bounds__(64) void merge_prepare_kernel(const uint64_t* __res
   }
   if (r != 0) return;
   const uint64_t want = ns < (uint64_t)T ? ns : (uint64_t)T;
-  sel->want = want; sel->above = 0; sel->done = 0; sel->ticket = 0; sel->want_req = 0;
+  sel->want_req = 0;
   if (fast) {
     const uint32_t lo = *klb ? *klb : 0x40000000u, hi = 0x40400000u;  // 2.0f, 3.0f
     const uint32_t range_m1 = hi - lo;
-    sel->lo = lo; sel->wbits = range_m1 == 0 ? 0u : (uint32_t)(32 - __builtin_clz(range_m1));
-    sel->kmin = lo; sel->kmax = hi; sel->started = 1;
+    sel->kmin = lo; sel->kmax = hi;
+    sel->st[0] = SelSnap{lo, range_m1 == 0 ? 0u : (uint32_t)(32 - __builtin_clz(range_m1)), 1u, 0u, want, 0ull, 0ull, 0ull};
   } else {
-    sel->kmin = kmin <= kmax ? kmin : 0u; sel->kmax = kmin <= kmax ? kmax : 0u; sel->started = 0;
+    sel->kmin = kmin <= kmax ? kmin : 0u; sel->kmax = kmin <= kmax ? kmax : 0u;
+    sel->st[0] = SelSnap{0u, 0u, 0u, 0u, want, 0ull, 0ull, 0ull};
   }
+  sel->want = want;  // (what the candidate kernels read if no select runs: an empty view)
   // SC_FLAG_EST_BOUND: the bound in *klb was an estimate.  A rank only ever sends keys at or above it (its select window's
   // floor), so fewer than T entries in all means fewer than T triangles of the whole graph lie above it — unless it certified
   // nothing (0: no pruning) — and the top-T of the pruned graph proves nothing about the full one (sc_tri.hip 3c)
