@@ -378,7 +378,7 @@ int stage_inputs(sc_ctx* c, const float* d_src, const float* d_tgt, int64_t n, c
   launch_stage_points(d_src, d_tgt, c->n, c->ld, p->layout, c->planes.as<float>(),
                       reinterpret_cast<uint32_t*>(&c->pinned[1]), c->ctl.as<uint32_t>(),
                       (uint32_t)(sizeof(ControlBlock) / 4), c->fx_mx.as<uint32_t>(), c->fx_part.as<uint32_t>(),
-                      c->fx_mx.as<uint32_t>() + FX_MX_WORDS, c->spec_on ? nullptr : &c->pinned[13], c->spec_on ? nullptr : &c->pinned[16], c->stream,  // (host-free: finalize hands them over, DeferredPub)
+                      c->spec_on ? nullptr : c->fx_mx.as<uint32_t>() + FX_MX_WORDS, c->spec_on ? nullptr : &c->pinned[13], c->spec_on ? nullptr : &c->pinned[16], c->stream,  // (host-free: no ticket — stage A's launch reduces the rows, run_compat; finalize hands the words over, DeferredPub)
                       c->build ? c->degp.as<uint32_t>() : nullptr, c->build ? (uint32_t)c->ld : 0u);
   return SC_OK;
 }
@@ -417,7 +417,8 @@ int run_compat(sc_ctx* c, bool dense) {
     map = slot->buf.as<uint32_t>(); map_len = slot->len;
   }
   launch_compat(points_of(c), c->dv, dense ? c->S.as<float>() : nullptr, c->bits_cur, 0, c->n, c->tn, c->stream,
-                c->build ? c->degp.as<uint32_t>() : nullptr, map, map_len);
+                c->build ? c->degp.as<uint32_t>() : nullptr, map, map_len, c->spec_on ? c->fx_part.as<uint32_t>() : nullptr,
+                c->fx_mx.as<uint32_t>());
   return SC_OK;
 }
 

@@ -64,14 +64,19 @@ __global__ __launch_bounds__(256) void stage_points_kernel(const float* __restri
     __syncthreads();
     if (threadIdx.x < 14)
       coord_part[(size_t)blockIdx.x * 16 + threadIdx.x] = max(max(red[0][threadIdx.x], red[1][threadIdx.x]), max(red[2][threadIdx.x], red[3][threadIdx.x]));
+    // mx_ticket == nullptr (a host-free call): no workgroup stays behind — stage A's first workgroup reduces the rows (stats_reduce_wave)
+    __shared__ uint32_t s_last;
+    if (mx_ticket == nullptr) {
+      if (threadIdx.x == 0) s_last = 0u;
+    } else {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    __shared__ uint32_t s_last;
     if (threadIdx.x == 0) {
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
       const uint32_t t = __hip_atomic_fetch_add(mx_ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       s_last = (t == gridDim.x - 1) ? 1u : 0u;
       if (s_last) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    }
     }
     __syncthreads();
     if (s_last) {  // (block-uniform) the last block: reduce the rows, publish
@@ -160,6 +165,19 @@ __device__ __forceinline__ void store_s1(float* p, float a, bool nt) {
   else *p = a;
 }
 
+// The staging kernel's per-workgroup coordinate statistics -> the FX_MX_WORDS words of the call (one wave; the rows were written by
+// the launch before this one: plain loads).  Lane = (row group lane / 16, word lane % 16).
+struct StatsJob { const uint32_t* part; uint32_t rows; uint32_t* out; };
+__device__ __forceinline__ void stats_reduce_wave(const StatsJob& sj, int lane) {
+  const uint32_t c = (uint32_t)lane & 15u;
+  uint32_t best = 0;
+  if (c < 14)
+    for (uint32_t r = (uint32_t)lane >> 4; r < sj.rows; r += 4) best = max(best, sj.part[(size_t)r * 16 + c]);
+  best = max(best, (uint32_t)__shfl_xor((int)best, 16));
+  best = max(best, (uint32_t)__shfl_xor((int)best, 32));
+  if (lane < 14) sj.out[lane] = best;
+}
+
 // TILE_R rows per tile (16 or 64): 64 / TILE_R tiles stack into one 64-row block.
 // DENSE: write the weight matrix S (false: SC_FLAG_NO_DENSE_S — adjacency bits only, no LDS tile image, no S traffic).
 // RECT:  one-sided form for a ROW BLOCK [row0, row1) x all columns (stage A sharded by row blocks):
@@ -172,11 +190,14 @@ __global__ __launch_bounds__(64 * COMPAT_WAVES) void compat_tiles_kernel(const f
                                                                          uint64_t* __restrict__ bits, int n_tiles,
                                                                          int two_phase, int row0, int row1,
                                                                          int mode, uint32_t* __restrict__ degp,
-                                                                         const uint32_t* __restrict__ wg_map) {
+                                                                         const uint32_t* __restrict__ wg_map, StatsJob sj) {
   constexpr int TILE_PAD = TILE_R + 1;  // LDS row stride of the transposed tile: conflict-free both ways
   constexpr int SUB = 64 / TILE_R;      // tiles per 64-row block
   __shared__ float tileT[DENSE ? COMPAT_WAVES : 1][DENSE ? 64 * TILE_PAD : 1];  // [column][row] per wave
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  // a host-free call's coordinate statistics: reduced HERE, by one wave of this launch, instead of by a workgroup of the staging
+  // launch that stays behind for it (release + ticket + acquire: ~2.5 us of that launch); nothing before stage B's vote reads them
+  if (sj.part && blockIdx.x == 0 && wave == COMPAT_WAVES - 1) stats_reduce_wave(sj, lane);
   // wg_map (whole-matrix form, COMPAT_WAVES == SUB: a workgroup = one 64 x 64 block of the matrix): which block this
   // workgroup takes — the XCD-aware order of compat_wg_map() below; ~0: a padding workgroup
   const uint32_t wg = wg_map ? wg_map[blockIdx.x] : blockIdx.x;
@@ -656,7 +677,9 @@ std::vector<uint32_t> compat_wg_map(int W) {
 }
 
 void launch_compat(const Points& pts, const Derived& dv, float* S, uint64_t* bits, int row0, int row1, const Tuning& tn,
-                   hipStream_t st, uint32_t* degp, const uint32_t* wg_map, uint32_t wg_map_len) {
+                   hipStream_t st, uint32_t* degp, const uint32_t* wg_map, uint32_t wg_map_len, const uint32_t* stat_part,
+                   uint32_t* stat_out) {
+  const StatsJob sj{stat_part, stat_part ? (uint32_t)((pts.ld + 255) / 256) : 0u, stat_out};
   const int W = pts.ld >> 6;
   const int two_phase = tn.compat_one_phase ? 0 : 1;  // the one-phase interior form stays for A/B and parity
   const bool rect = !(row0 == 0 && row1 >= pts.n);
@@ -670,7 +693,7 @@ void launch_compat(const Points& pts, const Derived& dv, float* S, uint64_t* bit
   if (tn.compat_store_mode & 1u) mode = 1;
   if (tn.compat_store_mode & 4u) mode = 0;
   mode |= (int)(tn.compat_store_mode & 2u);
-#define SC_COMPAT_ARGS pts.planes, pts.n, pts.ld, dv.d_thr, dv.min_len, dv.neg_inv2sig2, S, bits, n_tiles, two_phase, row0, row1, mode, degp, map_arg
+#define SC_COMPAT_ARGS pts.planes, pts.n, pts.ld, dv.d_thr, dv.min_len, dv.neg_inv2sig2, S, bits, n_tiles, two_phase, row0, row1, mode, degp, map_arg, sj
   const uint32_t* map_arg = nullptr;  // (only the symmetric 16- and 32-row forms take the map: there a workgroup is a 64 x 64 block)
   if (rect) {
     if (row1 <= row0) return;

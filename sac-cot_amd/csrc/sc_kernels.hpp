@@ -81,7 +81,8 @@ struct Points {
 // bad_flag may be host-pinned memory: it is only touched (atomicOr) when a non-finite value is found.
 // zero / zero_words: a buffer (the per-call control block) the kernel clears on the way — saves a memset launch.
 // coord_max (optional, 2 x u32): atomicMax of the bit patterns of max |src coordinate| and max |tgt coordinate|; with it:
-// coord_max_next (the pair the NEXT call uses: cleared by the last block), mx_ticket (a zeroed u32, left zero) and
+// coord_max_next (the pair the NEXT call uses: cleared by the last block), mx_ticket (a zeroed u32, left zero; nullptr: the rows
+// of coord_part stay unreduced — launch_compat's stat_part) and
 // host_max (pinned u64: receives max|tgt| << 32 | max|src| once every block is done).
 // The coordinate statistics are FX_MX_WORDS u32 (coord_max, WRITTEN — not accumulated — by the last block of the launch):
 // [0] max |src coordinate|, [1] max |tgt coordinate| (bit patterns), [2 + c] / [8 + c]: float_key of the largest / of minus
@@ -114,8 +115,11 @@ bool filter_in_range(uint64_t host_max, float tau2);
 // degp (optional, whole-matrix form only; n u32, ZEROED): also accumulates deg+[i] = edges (i, j) with j > i (atomics).
 // wg_map / wg_map_len (optional, whole-matrix form): the XCD-aware order of the 64 x 64 blocks, compat_wg_map(ld / 64) on the
 // device — the launch then has wg_map_len workgroups.
+// stat_part / stat_out (optional): the staging launch was given no ticket (mx_ticket == nullptr) and left its per-workgroup rows
+// of coordinate statistics unreduced: one wave of this launch reduces them into the FX_MX_WORDS words.
 void launch_compat(const Points& pts, const Derived& dv, float* S, uint64_t* bits, int row0, int row1, const Tuning& tn,
-                   hipStream_t st, uint32_t* degp = nullptr, const uint32_t* wg_map = nullptr, uint32_t wg_map_len = 0);
+                   hipStream_t st, uint32_t* degp = nullptr, const uint32_t* wg_map = nullptr, uint32_t wg_map_len = 0,
+                   const uint32_t* stat_part = nullptr, uint32_t* stat_out = nullptr);
 // deg[i] = edges of i; degp[i] = edges (i,j) with j > i; wpre: n x (ld/64) u32, set bits of row i in words [0,w).
 // zero_rows (optional): an n x W u64 matrix cleared on the way (the pruned bit matrix of stage B).
 // rowcost (optional, n u32): per-row estimate of stage B's work (see row_stats_kernel), for launch_shard_split.

@@ -1920,6 +1920,17 @@ __global__ __launch_bounds__(256) void finalize_kernel(const float* __restrict__
   __shared__ uint64_t lds[8];
   __shared__ float sRt[12];
   __shared__ uint32_t s_last;
+  // (what does not depend on the winner is on its way before the pairs are looked at: this thread's correspondence, its first
+  // keys of the rank count — the kernel is a chain of dependent loads, ~1 us each)
+  const int m = blockIdx.x * 256 + threadIdx.x;
+  float cp[6];
+#pragma unroll
+  for (int c = 0; c < 6; c++) cp[c] = m < n ? planes[(size_t)c * ld + m] : 0.f;
+  const uint32_t T4 = T >> 2;  // 16-byte loads, grid-strided
+  const uint4* __restrict__ k4 = reinterpret_cast<const uint4*>(sel_key);
+  const uint32_t q_first = blockIdx.x * 256 + threadIdx.x;
+  uint4 v_first = make_uint4(0u, 0u, 0u, 0u);
+  if (sel_key != nullptr && q_first < T4) v_first = k4[q_first];
   // key2: npairs winner key pairs (one per rank, all-gathered; npairs = 1: an already reduced pair).  The reduction of
   // include/saccot.h — K0 = max pair[0], K1 = max pair[1] among the pairs attaining K0 — is a lexicographic max.
   unsigned long long k0 = 0, k1 = 0;
@@ -1977,11 +1988,9 @@ __global__ __launch_bounds__(256) void finalize_kernel(const float* __restrict__
   }
   uint32_t r = 0;
   if (two_stage && k0 != 0) {
-    const uint32_t wk = sel_key[g];
-    const uint32_t T4 = T >> 2;  // 16-byte loads, grid-strided
-    const uint4* __restrict__ k4 = reinterpret_cast<const uint4*>(sel_key);
-    for (uint32_t q = blockIdx.x * 256 + threadIdx.x; q < T4; q += gridDim.x * 256) {
-      const uint4 v = k4[q];
+    const uint32_t wk = (uint32_t)(k0 & 0xFFFFFFFFull);  // = sel_key[g]: the key's low half (score_argmax_kernel)
+    for (uint32_t q = q_first; q < T4; q += gridDim.x * 256) {
+      const uint4 v = q == q_first ? v_first : k4[q];
       const uint32_t t = q << 2;
       r += (v.x > wk) || (v.x == wk && t < g);
       r += (v.y > wk) || (v.y == wk && t + 1 < g);
@@ -1994,14 +2003,12 @@ __global__ __launch_bounds__(256) void finalize_kernel(const float* __restrict__
     }
   }
   const uint64_t rb = block_reduce_u64(r, lds);  // also the barrier that publishes sRt to the block
-  const int m = blockIdx.x * 256 + threadIdx.x;
   if (m < n) {
     float M[12];
 #pragma unroll
     for (int c = 0; c < 12; c++) M[c] = sRt[c];
     const bool live = k0 != 0ull && finite12(M);
-    const float d2 = resid2(M, planes[m], planes[(size_t)ld + m], planes[2 * (size_t)ld + m],
-                            planes[3 * (size_t)ld + m], planes[4 * (size_t)ld + m], planes[5 * (size_t)ld + m]);
+    const float d2 = resid2(M, cp[0], cp[1], cp[2], cp[3], cp[4], cp[5]);
     mask[m] = (live && d2 < tau2) ? 1 : 0;
   }
   if (threadIdx.x == 0) {
