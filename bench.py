@@ -828,7 +828,7 @@ def main() -> int:
             # fill each other's gaps.  NOT the headline (`value` is frames back to back on ONE stream: nothing overlaps there); what a
             # service that registers a stream of frames can get out of the card.
             out["calls_in_flight"] = {"note": "independent registrations OVERLAPPING on the GPU: one context and one stream each, one host thread "
-                                              "(sc_register_device_async / sc_wait ring), 60 calls per line; hypotheses/s of all of them together; not `value`"}
+                                              "(sc_register_device_async / sc_wait ring), 64 frames per line — the stream's DISTINCT scenes, every winner compared with the timed stream's; hypotheses/s of all of them together; not `value`"}
             p2 = pkg.make_params(flags=base_flags, **kw)
             for nfl in (2, 3, 4):
                 regs2 = [pkg.Registrar(local_rank) for _ in range(nfl)]
@@ -836,19 +836,24 @@ def main() -> int:
                 outs2 = [(torch.zeros(12, dtype=torch.float32, device=dev), torch.zeros(n, dtype=torch.uint8, device=dev)) for _ in range(nfl)]
                 for g, s2 in zip(regs2, streams2):
                     g.set_stream(s2.cuda_stream)
-                for g, o2 in zip(regs2, outs2):
-                    for _ in range(3):
-                        g.register_device(d_src.data_ptr(), d_tgt.data_ptr(), n, p2, o2[0].data_ptr(), o2[1].data_ptr())
-                KF = 60
+                # (r05: the stream's DISTINCT frames — frame k registers scene k mod K; every winner against the timed stream's)
+                sp2 = [(d_srcs[k_].data_ptr(), d_tgts[k_].data_ptr()) for k_ in range(K)]
+                for j_, (g, o2) in enumerate(zip(regs2, outs2)):
+                    for w_ in range(3):
+                        a2 = sp2[(K - 3 * nfl + 3 * j_ + w_) % K]
+                        g.register_device(a2[0], a2[1], n, p2, o2[0].data_ptr(), o2[1].data_ptr())
+                KF = 64
                 same = True
                 torch.cuda.synchronize(); tp0 = time.perf_counter()
                 for k in range(KF + nfl - 1):
                     if k < KF:
                         i = k % nfl
-                        regs2[i].register_device_async(d_src.data_ptr(), d_tgt.data_ptr(), n, p2, outs2[i][0].data_ptr(), outs2[i][1].data_ptr())
+                        regs2[i].register_device_async(sp2[k % K][0], sp2[k % K][1], n, p2, outs2[i][0].data_ptr(), outs2[i][1].data_ptr())
                     if k >= nfl - 1:
-                        _, s2_ = regs2[(k - nfl + 1) % nfl].wait()
-                        same = same and s2_["best_rank"] == st["best_rank"] and s2_["best_count"] == st["best_count"]
+                        kd = k - nfl + 1
+                        rc2_, s2_ = regs2[kd % nfl].wait()
+                        want2 = per_scene.get(kd % K)
+                        same = same and (want2 is None or want2 == (rc2_, s2_["best_rank"], s2_["best_count"]))
                 torch.cuda.synchronize(); tp = time.perf_counter() - tp0
                 out["calls_in_flight"][str(nfl)] = {"ms_per_call": tp / KF * 1e3, "hypotheses_per_s": T_total * KF / tp, "same_winner": bool(same)}
                 for g in regs2:
