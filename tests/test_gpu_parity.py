@@ -487,6 +487,46 @@ def test_split_phase1_without_pruning_and_gathered_finalize(pkg, reg, name, extr
     assert np.array_equal(d_Rt.cpu().numpy(), np.array([1, 0, 0, 0, 1, 0, 0, 0, 1, 0, 0, 0], np.float32))
 
 
+@pytest.mark.parametrize("n_pairs", [9, 40, 300, 4096])
+def test_finalize_reduces_many_gathered_pairs_like_few(pkg, reg, n_pairs):
+    """r05: more than eight key pairs are reduced by the whole workgroup (a thread takes every 256th pair) instead of one scalar loop —
+    the form this context's own arg-max launch now feeds (one pair per workgroup).  The lexicographic maximum must come out wherever
+    the winning pair sits, with ties on the first word decided by the second, and an out-of-range pair must still be refused."""
+    import torch
+    cfg, scene = pkg.synth.make_config_scene("C0")
+    kw = cfg.params()
+    base = reg.register(scene.src, scene.tgt, **kw)
+    dev = torch.device("cuda:0")
+    d_src = torch.from_numpy(scene.src).to(dev); d_tgt = torch.from_numpy(scene.tgt).to(dev)
+    d_key = torch.zeros(2, dtype=torch.int64, device=dev)
+    d_Rt = torch.zeros(12, dtype=torch.float32, device=dev); d_mask = torch.zeros(cfg.n, dtype=torch.uint8, device=dev)
+    torch.cuda.synchronize()
+    reg.hypothesize_device(d_src.data_ptr(), d_tgt.data_ptr(), cfg.n, pkg.make_params(**kw), d_key.data_ptr())
+    torch.cuda.synchronize()
+    good = [int(x) for x in d_key.cpu()]
+    rng = np.random.default_rng(n_pairs)
+    for where in (0, n_pairs // 2, n_pairs - 1):
+        pairs = np.zeros((n_pairs, 2), dtype=np.int64)
+        for k in range(n_pairs):                     # losers: the same first word with a smaller second, smaller first words, empty pairs
+            kind = rng.integers(0, 3)
+            if kind == 0:
+                pairs[k] = (good[0], max(good[1] - int(rng.integers(1, 1000)), 0))
+            elif kind == 1:
+                pairs[k] = (max(good[0] - (int(rng.integers(1, 50)) << 32), 1), good[1] + int(rng.integers(0, 1000)))
+        pairs[where] = good
+        d_all = torch.from_numpy(pairs.reshape(-1)).to(dev); torch.cuda.synchronize()
+        rc, st = reg.finalize_gathered_device(d_all.data_ptr(), n_pairs, d_Rt.data_ptr(), d_mask.data_ptr())
+        torch.cuda.synchronize()
+        assert rc == 0 and (st["best_rank"], st["best_count"]) == (base["stats"]["best_rank"], base["stats"]["best_count"]), (n_pairs, where)
+        assert np.array_equal(d_mask.cpu().numpy(), base["mask"])
+        assert d_Rt.cpu().numpy().tobytes() == np.concatenate([base["R"].ravel(), base["t"]]).tobytes()
+    pairs[n_pairs // 3] = (good[0] + (1 << 40), 0xFFFFFFFF - (base["stats"]["tri_kept"] + 7))   # wins the reduction, points outside
+    d_all = torch.from_numpy(pairs.reshape(-1)).to(dev); torch.cuda.synchronize()
+    with pytest.raises(pkg.SacCotError) as e:
+        reg.finalize_gathered_device(d_all.data_ptr(), n_pairs, d_Rt.data_ptr(), d_mask.data_ptr())
+    assert e.value.status == pkg.SC_EINVAL
+
+
 def test_finalize_rejects_a_pair_outside_the_selection(pkg, reg):
     """The key pairs of phase 2 come from the caller (an all-gather).  A pair whose position lies outside the selected
     list — a stale or uninitialised buffer, ranks that disagree on T — must not be used as an index on the device: the
