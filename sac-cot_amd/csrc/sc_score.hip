@@ -1175,17 +1175,19 @@ __device__ void gram_coef_block(const GramCoef& coef, const float v[12], uint32_
   for (int i = 0; i < 3; i++)
 #pragma unroll
     for (int j = 0; j < 3; j++) {
-      const double Mij = s_fr.R0[i] * R[j] + s_fr.R0[3 + i] * R[3 + j] + s_fr.R0[6 + i] * R[6 + j];  // (R0^T R)_ij
+      // (fp64 products of this block are fused by hand: the build runs -ffp-contract=off for the canonical fp32 chains, and an
+      // unfused a b + c is two half-rate instructions here — C4's 500 000 hypotheses make this launch 12 % of its step)
+      const double Mij = __builtin_fma(s_fr.R0[i], R[j], __builtin_fma(s_fr.R0[3 + i], R[3 + j], s_fr.R0[6 + i] * R[6 + j]));  // (R0^T R)_ij
       const double d = Mij - (i == j ? 1.0 : 0.0);
       dM[3 * i + j] = d;
-      F2 += d * d;
+      F2 = __builtin_fma(d, d, F2);
       mm = fmax(mm, fabs(d));
     }
 #pragma unroll
   for (int i = 0; i < 3; i++)
 #pragma unroll
     for (int j = i; j < 3; j++) {  // (R^T R - I)_ij, symmetric
-      const double g = R[i] * R[j] + R[3 + i] * R[3 + j] + R[6 + i] * R[6 + j] - (i == j ? 1.0 : 0.0);
+      const double g = __builtin_fma(R[i], R[j], __builtin_fma(R[3 + i], R[3 + j], __builtin_fma(R[6 + i], R[6 + j], i == j ? -1.0 : 0.0)));
       G[3 * i + j] = g; G[3 * j + i] = g;
       gdef = fmax(gdef, fabs(g));
     }
@@ -1193,14 +1195,14 @@ __device__ void gram_coef_block(const GramCoef& coef, const float v[12], uint32_
     const double d0 = (double)v[9] - s_fr.t0[0], d1 = (double)v[10] - s_fr.t0[1], d2 = (double)v[11] - s_fr.t0[2];
 #pragma unroll
     for (int i = 0; i < 3; i++)
-      Tp[i] = s * ((s_fr.R0[i] * d0 + s_fr.R0[3 + i] * d1 + s_fr.R0[6 + i] * d2) +
-                   (dM[3 * i] * s_fr.c[0] + dM[3 * i + 1] * s_fr.c[1] + dM[3 * i + 2] * s_fr.c[2]));
+      Tp[i] = s * __builtin_fma(s_fr.R0[i], d0, __builtin_fma(s_fr.R0[3 + i], d1, __builtin_fma(s_fr.R0[6 + i], d2,
+                   __builtin_fma(dM[3 * i], s_fr.c[0], __builtin_fma(dM[3 * i + 1], s_fr.c[1], dM[3 * i + 2] * s_fr.c[2])))));
   }
   float nanp = 0.f;
 #pragma unroll
   for (int c = 0; c < 12; c++) nanp += v[c] * 0.f;
   // |dM|_F and |tau'|: fp32 square roots, pushed up / down by more than their rounding — every bound below is monotone in them
-  const double T2 = Tp[0] * Tp[0] + Tp[1] * Tp[1] + Tp[2] * Tp[2];
+  const double T2 = __builtin_fma(Tp[0], Tp[0], __builtin_fma(Tp[1], Tp[1], Tp[2] * Tp[2]));
   const double Fn = (double)sqrt_rn((float)F2) * (1.0 + 4e-7) + 1e-30, Tr = (double)sqrt_rn((float)T2);
   const double Tn = Tr * (1.0 + 4e-7) + 1e-30, Tn_lo = Tr * (1.0 - 4e-7);
   const double tmax_o = fmax(fabs((double)v[9]), fmax(fabs((double)v[10]), fabs((double)v[11])));
@@ -1224,10 +1226,10 @@ __device__ void gram_coef_block(const GramCoef& coef, const float v[12], uint32_
   // coefficients (A operand), scaled by GX_RS; the P' / V' features are stored x 256
   double a16[16], cmax = 0.0;
 #pragma unroll
-  for (int k = 0; k < 9; k++) a16[k] = (double)GX_RS * (-2.0 * dM[k] + G[k]);
+  for (int k = 0; k < 9; k++) a16[k] = (double)GX_RS * __builtin_fma(-2.0, dM[k], G[k]);
   a16[9] = 2.0 * (double)GX_RS;
 #pragma unroll
-  for (int j = 0; j < 3; j++) a16[10 + j] = 2.0 * (double)GX_RS / 256.0 * (dM[j] * Tp[0] + dM[3 + j] * Tp[1] + dM[6 + j] * Tp[2]);
+  for (int j = 0; j < 3; j++) a16[10 + j] = 2.0 * (double)GX_RS / 256.0 * __builtin_fma(dM[j], Tp[0], __builtin_fma(dM[3 + j], Tp[1], dM[6 + j] * Tp[2]));
 #pragma unroll
   for (int i = 0; i < 3; i++) a16[13 + i] = -2.0 * (double)GX_RS / 256.0 * Tp[i];
 #pragma unroll
