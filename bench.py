@@ -554,16 +554,17 @@ def main() -> int:
     avg = {}
     for k, name in enumerate(STAGES):
         prm = mk(pkg.SC_FLAG_TIMING_ONE | pkg.SC_TIMING_STAGE(k))
-        acc = 0.0
+        acc = []
         for _ in range(n_diag):
             _, sd = step(prm)
-            acc += sd["us_" + name]
-        avg[name] = acc / n_diag
+            acc.append(sd["us_" + name])
+        avg[name] = float(np.median(acc))
     p_all = mk(pkg.SC_FLAG_TIMING)
-    tk = 0.0
-    for _ in range(3):
+    tk = []
+    for _ in range(5):
         _, sd = step(p_all)
-        tk += sd["us_trikeys"] / 3
+        tk.append(sd["us_trikeys"])
+    tk = float(np.median(tk))   # (a mean of three once carried a 40 us outlier into roofline_other)
     fence()
     if world > 1:
         tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
@@ -708,7 +709,7 @@ def main() -> int:
                         "achieved_GBs": round((n * n / 8 + 12 * st["tri_total"] + 16 * st["tri_scored"]) / (max(avg["triangles"], 1e-3) * 1e-6) / 1e9, 1),
                         "note": "the graph is pruned by a bound on the T-th key before it is enumerated (DESIGN 5.0): `triangles_enumerated` is what "
                                 "the pruned graph holds, a fraction of the graph's triangles; the stage is ten dependent launches of gathers, latency-bound"},
-            "stage_us_note": "one HIP-event bracket per pass on the hot path (SC_FLAG_TIMING_ONE); `triangles` includes its "
+            "stage_us_note": "one HIP-event bracket per pass on the hot path (SC_FLAG_TIMING_ONE), median of the passes; `triangles` includes its "
                              "read-backs" + (" and the collectives between the phases" if sharded_ab else ""),
             "winner": {"rank": st["best_rank"], "inliers": st["best_count"], "status": rc},
             "host_gap_us": round(ms_per_step * 1e3 - sum(avg.values()), 1),
@@ -791,28 +792,31 @@ def main() -> int:
                     mm = pkg.MultiRegistrar((local_rank,), loopback_ranks=1)
                     for _ in range(3):
                         gm = mm.register(scene.src, scene.tgt, params=p1)
-                tm0 = time.perf_counter()
-                for _ in range(20):
-                    gm = mm.register(scene.src, scene.tgt, params=p1)
-                multi_ms = (time.perf_counter() - tm0) / 20 * 1e3
+                # (every call below returns with its result on the host, so each is timed by itself; MEDIANS of 24, and the host-array
+                # form measured again right here — round 5's means of separate legs once gave a negative difference of differences)
+                def med_ms(fn, reps=24):
+                    ts_ = []
+                    for _ in range(reps):
+                        t0_ = time.perf_counter(); r_ = fn(); ts_.append(time.perf_counter() - t0_)
+                    return float(np.median(ts_)) * 1e3, r_
+                multi_ms, gm = med_ms(lambda: mm.register(scene.src, scene.tgt, params=p1))
                 mm.close()
+                for _ in range(3):
+                    reg.register(scene.src, scene.tgt, params=p1)
+                host_ms, _ = med_ms(lambda: reg.register(scene.src, scene.tgt, params=p1))
                 reg.set_stream(torch.cuda.current_stream().cuda_stream)
                 ss1 = pkg.shard.ShardedStep(pkg, reg, n, pkg.make_params(shard_block=block, flags=base_flags, **kw), 0, 1, dev)
                 for _ in range(3):
                     ss1.step(d_src.data_ptr(), d_tgt.data_ptr())
-                torch.cuda.synchronize(); tq0 = time.perf_counter()
-                for _ in range(20):
-                    ss1.step(d_src.data_ptr(), d_tgt.data_ptr())
-                torch.cuda.synchronize(); phase_ms = (time.perf_counter() - tq0) / 20 * 1e3
+                torch.cuda.synchronize()
+                phase_ms, _ = med_ms(lambda: ss1.step(d_src.data_ptr(), d_tgt.data_ptr()))
                 for _ in range(3):
                     step(p_hot, 0)
-                torch.cuda.synchronize(); td0 = time.perf_counter()
-                for _ in range(20):
-                    step(p_hot, 0)
-                torch.cuda.synchronize(); dev0_ms = (time.perf_counter() - td0) / 20 * 1e3   # the device-resident waited step on the same scene
-                host_io_ms = out["ms_to_best_Rt"] - dev0_ms   # what host arrays in / out add to the device-resident (waited) step
+                torch.cuda.synchronize()
+                dev0_ms, _ = med_ms(lambda: step(p_hot, 0))   # the device-resident waited step on the same scene
+                host_io_ms = host_ms - dev0_ms   # what host arrays in / out add to the device-resident (waited) step
                 out["native_multi"] = {
-                    "sc_register_multi_loopback1_ms": multi_ms, "sc_register_ms": out["ms_to_best_Rt"],
+                    "sc_register_multi_loopback1_ms": multi_ms, "sc_register_ms": host_ms,
                     "phase_api_world1_device_resident_ms": phase_ms, "single_device_resident_ms": dev0_ms,
                     "orchestration_us": round((multi_ms - phase_ms - host_io_ms) * 1e3, 1),
                     "same_result": bool(gm["stats"]["best_rank"] == st["best_rank"] and np.array_equal(gm["mask"], d_mask.cpu().numpy())),
