@@ -1509,7 +1509,7 @@ int finalize_enqueue(sc_ctx* c, const uint64_t* d_keys, int n_pairs, float* d_Rt
   if (d_keys == c->key.as<uint64_t>() && n_pairs == 1 && c->amx_blocks) { d_keys = c->amx_pairs.as<uint64_t>(); n_pairs = (int)c->amx_blocks; }
   launch_finalize(points_of(c), tri_source_of(c), c->sh, c->sh.n_local ? c->rt.as<float>() : nullptr,
                   c->T_eff ? c->sel_key.as<uint32_t>() : nullptr, c->T_eff, d_keys, n_pairs,
-                  ctl->key2, c->dv.tau2, d_Rt, d_mask, &ctl->fin_rank, &ctl->fin_ticket, &c->pinned[8], c->stream,
+                  ctl->key2, c->dv.tau2, d_Rt, d_mask, &ctl->fin_word, &c->pinned[8], c->stream,
                   c->spec_on ? &dp : nullptr);
   if (c->refine) {  // fp64 least-squares refit over the winner's inliers (mask unchanged)
     ENSURE(c, c->refine_tmp, refine_scratch_bytes(c->n));

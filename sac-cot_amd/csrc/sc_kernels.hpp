@@ -319,13 +319,14 @@ struct ControlBlock {
   float smin;                // strong-edge threshold (written by prune_bits_kernel)
   uint32_t amx_ticket;       // blocks-finished counter of score_argmax_kernel
   uint32_t klb;              // key of the certified lower bound of the pruning (0: none)
-  uint32_t fin_rank, fin_ticket;  // finalize_kernel: rank-count accumulator, blocks-finished counter (left zero)
+  uint32_t pad_fin[2];
   uint32_t own_row[2];       // sharded stage B: this rank's row range [lo, hi) ...
   uint32_t pad0[9];
   uint64_t key2[2];          // internal winner key pair (sc_register_device)
+  unsigned long long fin_word;  // finalize_kernel: workgroups finished << 32 | rank count so far — ONE returning atomic per workgroup (left zero)
   uint64_t own_edge[2];      // ... and its CSR edge range (launch_shard_split)
   uint64_t live_edges[2];    // host-free calls: [0, edges of the graph) — written by launch_edge_build; the scan of the per-edge counts skips the tiles beyond it
-  uint64_t pad1[2];
+  uint64_t pad1[1];
   SelectState sel;
   // stage C2's reference frame (sc_gramref.hpp): slot v = the best (key bits << 32 | workgroup) among the workgroups = v (mod 64) of the
   // estimating sample — its voter v is that workgroup's candidate triangle
@@ -565,7 +566,7 @@ struct DeferredPub {
 };
 void launch_finalize(const Points& pts, const TriSource& ts, const Shard& sh, const float* RtSoA,
                      const uint32_t* sel_key, uint32_t T, const uint64_t* key2, int npairs, uint64_t* key_out, float tau2, float* Rt12, uint8_t* mask,
-                     uint32_t* rank_acc, uint32_t* ticket, uint64_t* host_out, hipStream_t st, const DeferredPub* dp = nullptr);
+                     unsigned long long* fin_word, uint64_t* host_out, hipStream_t st, const DeferredPub* dp = nullptr);
 // SURVEY §8f-2 (SC_FLAG_REFINE): fp64 least-squares refit of Rt12 over the inlier mask; no-op when key2[0] == 0 or
 // fewer than 3 inliers.  scratch: refine_scratch_bytes(n).
 size_t refine_scratch_bytes(int n);

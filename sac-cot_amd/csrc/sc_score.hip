@@ -1917,7 +1917,7 @@ __global__ __launch_bounds__(256) void finalize_kernel(const float* __restrict__
                                                        const unsigned long long* __restrict__ key2, int npairs,
                                                        unsigned long long* __restrict__ key_out, float tau2,
                                                        float* __restrict__ Rt12, uint8_t* __restrict__ mask,
-                                                       uint32_t* __restrict__ rank_acc, uint32_t* __restrict__ ticket,
+                                                       unsigned long long* __restrict__ fin_word,
                                                        unsigned long long* __restrict__ host_out, DeferredPub dp) {
   __shared__ uint64_t lds[8];
   __shared__ float sRt[12];
@@ -2014,15 +2014,14 @@ __global__ __launch_bounds__(256) void finalize_kernel(const float* __restrict__
     mask[m] = (live && d2 < tau2) ? 1 : 0;
   }
   if (threadIdx.x == 0) {
-    if (rb) __hip_atomic_fetch_add(rank_acc, (uint32_t)rb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // ONE returning atomic per workgroup: workgroups finished in the high half, the rank count so far in the low half — the workgroup
+    // that finds every other one finished holds the whole count in the value it got back (no second accumulator, no acquire, no load)
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-    const uint32_t t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    s_last = (t == gridDim.x - 1) ? 1u : 0u;
+    const unsigned long long was = __hip_atomic_fetch_add(fin_word, (1ull << 32) | (unsigned long long)(uint32_t)rb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    s_last = ((uint32_t)(was >> 32) == gridDim.x - 1) ? 1u : 0u;
     if (s_last) {
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-      const uint32_t rank = __hip_atomic_load(rank_acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __hip_atomic_store(rank_acc, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // ready for the next call
-      __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const uint32_t rank = (uint32_t)was + (uint32_t)rb;
+      __hip_atomic_store(fin_word, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // ready for the next call
       if (host_out && dp.host) {
         // a host-free call: the words its earlier kernels would have published one by one go to the host HERE, with the winner
         // (relaxed system-scope stores: the release store of the key below orders them before it).  Every such store costs the
@@ -2067,13 +2066,13 @@ __global__ __launch_bounds__(256) void mask_kernel(const float* __restrict__ pla
 
 void launch_finalize(const Points& pts, const TriSource& ts, const Shard& sh, const float* RtSoA,
                      const uint32_t* sel_key, uint32_t T, const uint64_t* key2, int npairs, uint64_t* key_out, float tau2, float* Rt12, uint8_t* mask,
-                     uint32_t* rank_acc, uint32_t* ticket, uint64_t* host_out, hipStream_t st, const DeferredPub* dp) {
+                     unsigned long long* fin_word, uint64_t* host_out, hipStream_t st, const DeferredPub* dp) {
   uint32_t blocks = (uint32_t)((pts.n + 255) / 256);  // the mask needs these; more only if the key list is long
   const uint32_t for_keys = (T / 4 + 1023) / 1024;    // >= 4 uint4 per thread before another block pays off
   if (for_keys > blocks) blocks = for_keys < 1024u ? for_keys : 1024u;
   hipLaunchKernelGGL(finalize_kernel, dim3(blocks), dim3(256), 0, st, pts.planes, pts.n, pts.ld, ts, sh, RtSoA, sel_key, T,
                      reinterpret_cast<const unsigned long long*>(key2), npairs,
-                     reinterpret_cast<unsigned long long*>(key_out), tau2, Rt12, mask, rank_acc, ticket,
+                     reinterpret_cast<unsigned long long*>(key_out), tau2, Rt12, mask, fin_word,
                      reinterpret_cast<unsigned long long*>(host_out), dp ? *dp : DeferredPub{nullptr, nullptr, nullptr, nullptr, 0});
 }
 
