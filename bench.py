@@ -219,7 +219,7 @@ def main() -> int:
                     help="distinct synthetic scenes of the config's shape the frames cycle through (seeds cfg.seed + k, inlier ratio drawn "
                          "in [2/3, 4/3] of the config's: C2 0.10 .. 0.20, so edge counts move by ~1.6 x and triangle counts by ~4 x from "
                          "frame to frame); frame f registers scene f mod SCENES.  1 = every frame the config's own scene (rounds 1 - 4)")
-    ap.add_argument("--hot-timing-every", type=int, default=1,
+    ap.add_argument("--hot-timing-every", type=int, default=8,
                     help="SC_FLAG_TIMING_HOT (the dominant kernel's duration from its dispatch packets' timestamps) on every N-th timed frame (0: none)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--headline-only", action="store_true",
@@ -654,7 +654,8 @@ def main() -> int:
                                    "the frame skip every correspondence the triangle inequality rules out: `tests`) + exact fp32 pass over the "
                                    "undecided tests; counts identical to the fp32 kernel. ", 0: "fp32 vector kernel. "}[c2_info["c2_kernel"]]) +
                               "not HBM-bound (~8 MB moved); duration from HIP events inside the timed steps (SC_FLAG_TIMING_HOT: the "
-                              "dispatch packets' own timestamps)"}
+                              "dispatch packets' own timestamps), taken on every %d-th timed frame (a launch that carries events costs "
+                              "the frame ~1 us: --hot-timing-every)" % max(1, HE)}
         # HBM bytes per launch from the committed rocprofv3 --pmc passes of this same command (tools/pmc_collect.sh,
         # FETCH_SIZE doubled per the gfx950 correction, WRITE_SIZE as is); PMC counters cannot be read from inside the
         # process, so `traffic` is the committed measurement of this code state, valid for the headline workload only

@@ -445,6 +445,13 @@ __global__ __launch_bounds__(256) void score_argmax_kernel(const uint32_t* __res
 //   Tmax) >= 2^-16 S / 1.73 leaves a factor 1.7; LO and HI carry another 4e-6 for the roundings of the squares, of
 //   sqrt(tau^2) and of d2 itself.  The parity suite compares every count with the canonical kernel's.
 // ------------------------------------------------------------------------------------------------
+// a launch that takes its dispatch packet's own start / stop timestamps only when asked to (SC_FLAG_TIMING_HOT): without events it is
+// a plain launch
+#define SC_LAUNCH_EV(kernel, grid, block, st, e0, e1, ...)                                              \
+  do {                                                                                                  \
+    if ((e0) != nullptr || (e1) != nullptr) hipExtLaunchKernelGGL(kernel, grid, block, 0, st, e0, e1, 0, __VA_ARGS__); \
+    else hipLaunchKernelGGL(kernel, grid, block, 0, st, __VA_ARGS__);                                   \
+  } while (0)
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 constexpr float FX_RS = 1024.0f;
@@ -1775,8 +1782,8 @@ void launch_score_filter(const Points& pts, const float* RtSoA, const float* RtA
     const GramCoef gc = gram_coef_view(coef, sh.ld_local, frame);
     const uint32_t group_major = (uint64_t)((sh.ld_local + 32 * GX_WAVES - 1) / (32 * GX_WAVES)) * fp.splits <= 1024u ? 1u : 0u;  // (see the kernel)
 #define SC_GRAM_LAUNCH(V)                                                                                                         \
-    hipExtLaunchKernelGGL(score_gram_kernel<V>, dim3((sh.ld_local + 32 * GX_WAVES - 1) / (32 * GX_WAVES) * fp.splits), dim3(64 * GX_WAVES), \
-                          0, st, ev0, ev_mid, 0, gc, sh.ld_local, static_cast<const uint4*>(tile), fp.windows, fp.splits, fp.n_waves, partial, \
+    SC_LAUNCH_EV(score_gram_kernel<V>, dim3((sh.ld_local + 32 * GX_WAVES - 1) / (32 * GX_WAVES) * fp.splits), dim3(64 * GX_WAVES), \
+                          st, ev0, ev_mid, gc, sh.ld_local, static_cast<const uint4*>(tile), fp.windows, fp.splits, fp.n_waves, partial, \
                           f.queue, f.cap_sq, f.qcount, f.redo, ql, group_major)
     // The shipped library holds variant 0 only.  -DSC_ABLATIONS (sac-cot_amd/build.py --ablations; tools/pmc_gram_variants.sh)
     // also instantiates the bit-identical scheduling variant 1 and the TIMING-ONLY bodies (no shell test / no barrier / no
@@ -1795,7 +1802,7 @@ void launch_score_filter(const Points& pts, const float* RtSoA, const float* RtA
       default: SC_GRAM_LAUNCH(0); break;
     }
 #undef SC_GRAM_LAUNCH
-    hipExtLaunchKernelGGL(score_exact_kernel, dim3(FX_NQ * exact_mult), dim3(256), 0, st, nullptr, ev1, 0, pts.planes, pts.n, pts.ld,
+    SC_LAUNCH_EV(score_exact_kernel, dim3(FX_NQ * exact_mult), dim3(256), st, (hipEvent_t) nullptr, ev1, pts.planes, pts.n, pts.ld,
                           reinterpret_cast<const float4*>(RtAoS), sh.ld_local, dv.tau2, fp.windows, fp.splits, fp.n_waves,
                           static_cast<const uint2*>(f.queue), f.cap_sq, static_cast<const uint32_t*>(f.qcount),
                           static_cast<const uint32_t*>(f.redo), partial, static_cast<const uint32_t*>(gc.hperm),
@@ -1807,7 +1814,7 @@ void launch_score_filter(const Points& pts, const float* RtSoA, const float* RtA
   if (ql < 64) ql = 64;  // one step can add 64 entries
   const dim3 grid(sh.ld_local / (8 * FX_WAVES), fp.splits), block(64 * FX_WAVES);
 #define SC_FILTER_LAUNCH(V)                                                                                                  \
-  hipExtLaunchKernelGGL((score_filter_kernel<FX_WAVES, V>), grid, block, 0, st, ev0, ev_mid, 0, RtSoA, sh.ld_local, dv.tau2, \
+  SC_LAUNCH_EV((score_filter_kernel<FX_WAVES, V>), grid, block, st, ev0, ev_mid, RtSoA, sh.ld_local, dv.tau2, \
                      static_cast<const uint4*>(tile), f.info, fp.windows, fp.splits, fp.n_waves, partial, f.queue, f.cap_sq, \
                      f.qcount, f.redo, ql)
   switch (tn.filter_variant) {
@@ -1832,7 +1839,7 @@ void launch_score_filter(const Points& pts, const float* RtSoA, const float* RtA
     default: SC_FILTER_LAUNCH(0); break;
   }
 #undef SC_FILTER_LAUNCH
-  hipExtLaunchKernelGGL(score_exact_kernel, dim3(FX_NQ * exact_mult), dim3(256), 0, st, nullptr, ev1, 0, pts.planes, pts.n, pts.ld,
+  SC_LAUNCH_EV(score_exact_kernel, dim3(FX_NQ * exact_mult), dim3(256), st, (hipEvent_t) nullptr, ev1, pts.planes, pts.n, pts.ld,
                         reinterpret_cast<const float4*>(RtAoS), sh.ld_local, dv.tau2, fp.windows, fp.splits, fp.n_waves,
                         static_cast<const uint2*>(f.queue), f.cap_sq, static_cast<const uint32_t*>(f.qcount),
                         static_cast<const uint32_t*>(f.redo), partial, static_cast<const uint32_t*>(nullptr),
@@ -1879,13 +1886,13 @@ void launch_score(const Points& pts, const float* RtSoA, const float* RtAoS, con
   const uint32_t nv = groups - gm, nm = gm * (SCORE_THREADS / MF_HYPS_PER_BLOCK);
   const dim3 grid(nv + nm, chunks);
   if (score_mode == 1)
-    hipExtLaunchKernelGGL(score_kernel<1>, grid, dim3(SCORE_THREADS), 0, st, ev0, ev1, 0, pts.planes, pts.n, pts.ld, RtSoA,
+    SC_LAUNCH_EV(score_kernel<1>, grid, dim3(SCORE_THREADS), st, ev0, ev1, pts.planes, pts.n, pts.ld, RtSoA,
                           sh.ld_local, dv.inv_tau2, chunk_pts, partial, nv, nm);
   else if (score_mode == 2)
-    hipExtLaunchKernelGGL(score_kernel<2>, grid, dim3(SCORE_THREADS), 0, st, ev0, ev1, 0, pts.planes, pts.n, pts.ld, RtSoA,
+    SC_LAUNCH_EV(score_kernel<2>, grid, dim3(SCORE_THREADS), st, ev0, ev1, pts.planes, pts.n, pts.ld, RtSoA,
                           sh.ld_local, dv.inv_tau, chunk_pts, partial, nv, nm);
   else
-    hipExtLaunchKernelGGL(score_kernel<0>, grid, dim3(SCORE_THREADS), 0, st, ev0, ev1, 0, pts.planes, pts.n, pts.ld, RtSoA,
+    SC_LAUNCH_EV(score_kernel<0>, grid, dim3(SCORE_THREADS), st, ev0, ev1, pts.planes, pts.n, pts.ld, RtSoA,
                           sh.ld_local, dv.tau2, chunk_pts, partial, nv, nm);
 }
 
