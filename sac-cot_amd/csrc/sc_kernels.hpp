@@ -363,7 +363,8 @@ struct KeyView {
   const uint64_t* M_dev;
 };
 KeyView plain_view(const uint32_t* wkey, uint64_t M);
-// `rounds` launches (histogram + pick by the last block to finish; 12 key bits each) find the exact threshold key
+// `rounds` launches (one histogram of <= 12 key bits each; round r + 1 — and launch_compact_count after the last — resolves round r:
+// see SelectState) find the exact threshold key
 // host_short (optional, pinned u64): set to 1 when SelectState::want_req keys were promised above the window's floor and
 // fewer are there
 void launch_select_rounds(const KeyView& view, SelectState* s, int rounds, const Tuning& tn, hipStream_t st,

@@ -575,7 +575,7 @@ __global__ __launch_bounds__(256) void tri_keys_events_kernel(const uint64_t* __
     preset->kmin = lo; preset->kmax = hi;
     preset->st[0] = SelSnap{lo, range_m1 == 0 ? 0u : (uint32_t)(32 - __builtin_clz(range_m1)), 1u, 0u, min(want, (uint64_t)toff[E]), 0ull, 0ull, 0ull};
     // a pruning bound promises `want` keys at or above it — a certified one by construction, an ESTIMATED one (3c) unless
-    // it was set too high: the select's last block compares (the UNclipped want: a pruned graph with fewer triangles than
+    // it was set too high: whoever resolves the select's first round compares (the UNclipped want: a pruned graph with fewer triangles than
     // that proves nothing about the full one)
     preset->want_req = (check_bound && *klb) ? want : 0ull;
   }  // exclusive prefix of the region fills: one flat index space over all events
@@ -920,7 +920,7 @@ __global__ __launch_bounds__(256) void tri_sample_hist_kernel(const uint64_t* __
 // subgraph turns out to hold >= T triangles with key >= LB, the proof of 3b applies word for word (it only needs "at least
 // T triangles have key >= LB") and the selection is the full graph's top-T, ties included; if not, nothing is known and the
 // call is repeated with a certifying sample.  The select's first round already counts the keys in [LB, 3.0] — the check
-// is one comparison in its last block (SelectState::want_req).
+// is one comparison where that round is resolved (select_resolve, SelectState::want_req).
 // So LB only has to be a good GUESS of a key of rank ~2 T: the lower edge of the histogram bin where
 // rate x (sampled count from the top) reaches margin x T, from a uniform 1-in-rate sample of ALL the graph's triangles.
 // The sample: a triangle (i, j, k), i < j < k, is found from its edge (i, j) in the 64-column word k / 64 of the row pair;
@@ -1573,11 +1573,9 @@ __device__ __forceinline__ void hist_add(uint32_t* lh, bool in, uint32_t bin) {
 // (Tried and dropped, r01: an EXACT histogram of the keys in [certified bound, 3.0] — ~50 k distinct fp32 values on C2 —
 // filled by the key kernel with one device-scope atomic per key and read by a single pick kernel, replacing both rounds:
 // bit-exact, but the atomics cost the key kernel +20 us and the pick 10-50 us, against 26 us for the two rounds.)
-// One select round: every block histograms its share of the keys into the window's bins; the LAST block to finish
-// (device-scope ticket) walks the bins from the top, picks the bin holding the want-th key and narrows the window —
-// one launch per round instead of a histogram launch plus a pick launch.  Hand-off per cdna guide §6 G16, counter
-// form: hist adds are device-scope atomics; each block fences (release) before its ticket; the last block fences
-// (acquire) and reads the bins with device-scope atomic loads.
+// One select round: every block histograms its share of the keys into the window's bins (LDS, then one global add per non-zero
+// bin).  Until r05 the LAST block to finish (device-scope ticket, release / acquire) walked the bins from the top, picked the bin
+// holding the want-th key and narrowed the window; now the NEXT launch does that in every workgroup's prologue (select_resolve).
 // four keys of the view at logical positions 4q .. 4q + 3 (entries beyond a segment's valid count read as 0, which
 // no window and no threshold ever admits: real keys are positive)
 // keys the view really holds (M_dev: the launch was sized before the host knew the count)
