@@ -522,15 +522,9 @@ __global__ __launch_bounds__(256) void tri_count_events_kernel(const uint64_t* _
     int wave_rounds = rounds;  // max over the wave: the loop below is wave-uniform
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) wave_rounds = max(wave_rounds, __shfl_xor(wave_rounds, o));
-    for (int it = 0; it < wave_rounds; it++) {
-      const int w = w0 + it * TG + gl;
-      uint64_t m = 0;
-      if (it < rounds && w < W) {
-        m = mbits[rowi + w] & mbits[rowj + w];
-        if (w == w0) m &= mask_above(jbit);
-      }
+    auto take = [&](uint64_t m, int w) {  // one round's words: count, stage the non-zero ones (wave-uniform control flow)
       const uint64_t bal = __ballot(m != 0);
-      if (bal != 0) {  // wave-uniform
+      if (bal != 0) {
         uint32_t tm;
         const uint32_t rb = c + group_exscan<TG>((uint32_t)__popcll(m), &tm);
         c += tm;
@@ -541,6 +535,27 @@ __global__ __launch_bounds__(256) void tri_count_events_kernel(const uint64_t* _
         }
         scnt += (uint32_t)__popcll(bal);
         if (scnt > (uint32_t)(EVW - 64)) flush();
+      }
+    };
+    // SEVERAL rounds' row words are loaded before the first is looked at (r05, by time stamps inside the workgroups: a round is one
+    // L2 round trip, ~0.45 us, and an edge's 6 - 19 rounds were most of a workgroup's 9 - 14 us)
+    constexpr int RU = 2;  // rounds whose words are in flight together (4: no better at C2 and C4, + 6 us at C3)
+    for (int it = 0; it < wave_rounds; it += RU) {
+      uint64_t mi[RU], mj[RU];
+#pragma unroll
+      for (int u = 0; u < RU; u++) {
+        const int w = w0 + (it + u) * TG + gl;
+        const bool in = it + u < rounds && w < W;
+        mi[u] = in ? mbits[rowi + w] : 0ull;
+        mj[u] = in ? mbits[rowj + w] : 0ull;
+      }
+#pragma unroll
+      for (int u = 0; u < RU; u++) {
+        if (it + u >= wave_rounds) break;  // (wave-uniform)
+        const int w = w0 + (it + u) * TG + gl;
+        uint64_t m = mi[u] & mj[u];
+        if (w == w0) m &= mask_above(jbit);
+        take(m, w);
       }
     }
     if (gl == 0 && on) tcnt[e] = c;  // weak edges were zeroed by prune_bits_kernel
