@@ -763,17 +763,99 @@ __device__ __forceinline__ bool scan_tile_dead(const uint64_t* __restrict__ rang
   return t0 + SCAN_TILE <= range[0] || t0 >= range[1];
 }
 
+// ---- a tile of the scans, coalesced (r05).  By time stamps inside the look-back kernel's tiles a tile's life was 3 us of loads + local scan
+// and 3 us of stores around 1 us of look-back: every thread owned SCAN_ITEMS CONSECUTIVE elements, so a wave's load touched 64 pieces 64
+// bytes apart and its 8-byte stores 64 lines each, sixteen times over.  Now a tile is SCAN_SUB sub-tiles of 1024 elements and a thread takes
+// four consecutive elements of each: a wave reads 1 KiB and writes 2 KiB at a stretch (C2: scan_lookback_kernel 11.7 -> 9.3 us).  A piece
+// inside the array is loaded BEFORE `range` is looked at (its two words were a dependent round trip at the head of the chain) and masked
+// afterwards: what lies beyond a host-free call's real edge count was never written, but it is the array's own memory.
+constexpr int SCAN_SUB = SCAN_ITEMS / 4;
+static_assert(SCAN_ITEMS % 4 == 0 && SCAN_THREADS == 256, "sub-tiles of 4 x 256 elements, four waves");
+struct ScanTile { uint32_t v[SCAN_SUB][4]; uint64_t ex[SCAN_SUB]; uint64_t tot; bool dead; };
+// loads + masks the tile's elements; returns with ex[r] = sum of the tile's elements before this thread's piece of sub-tile r and tot =
+// the tile's sum.  wsum: 4 x SCAN_SUB words of LDS; one barrier; every thread of the workgroup calls it.
+// (mask_dead: a tile wholly outside `range` reads as zeros — t.dead says so; `range` is looked at only AFTER the loads are on their way)
+__device__ __forceinline__ void scan_tile_load(const uint32_t* __restrict__ in, size_t n, size_t tile, const uint64_t* __restrict__ range,
+                                               bool mask_dead, uint64_t (*wsum)[SCAN_SUB], ScanTile& t) {
+  const size_t tbase = tile * SCAN_TILE + (size_t)threadIdx.x * 4;
+  if ((tile + 1) * SCAN_TILE <= n) {  // (block-uniform: ONE branch around all the loads — a branch per piece made the compiler wait for each)
+    uint4 q[SCAN_SUB];
+#pragma unroll
+    for (int r = 0; r < SCAN_SUB; r++) q[r] = *reinterpret_cast<const uint4*>(in + tbase + (size_t)r * 1024);
+#pragma unroll
+    for (int r = 0; r < SCAN_SUB; r++) { t.v[r][0] = q[r].x; t.v[r][1] = q[r].y; t.v[r][2] = q[r].z; t.v[r][3] = q[r].w; }
+  } else {
+#pragma unroll
+    for (int r = 0; r < SCAN_SUB; r++)
+#pragma unroll
+      for (int k = 0; k < 4; k++) { const size_t idx = tbase + (size_t)r * 1024 + k; t.v[r][k] = idx < n ? in[idx] : 0u; }
+  }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const bool dead = mask_dead && scan_tile_dead(range, tile);  // block-uniform
+  t.dead = dead;
+  uint64_t inc[SCAN_SUB], mine[SCAN_SUB];
+#pragma unroll
+  for (int r = 0; r < SCAN_SUB; r++) {
+    const size_t idx = tbase + (size_t)r * 1024;
+    uint64_t a = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) { t.v[r][k] = (!dead && scan_live(range, idx + k)) ? t.v[r][k] : 0u; a += t.v[r][k]; }
+    mine[r] = a; inc[r] = a;
+  }
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1)
+#pragma unroll
+    for (int r = 0; r < SCAN_SUB; r++) {
+      const uint64_t x = __shfl_up(inc[r], o);
+      if (lane >= o) inc[r] += x;
+    }
+  if (lane == 63)
+#pragma unroll
+    for (int r = 0; r < SCAN_SUB; r++) wsum[wave][r] = inc[r];
+  __syncthreads();
+  uint64_t tot = 0;
+#pragma unroll
+  for (int r = 0; r < SCAN_SUB; r++) {
+    uint64_t before = tot;
+#pragma unroll
+    for (int w = 0; w < 4; w++) { const uint64_t x = wsum[w][r]; before += w < wave ? x : 0ull; tot += x; }
+    t.ex[r] = before + inc[r] - mine[r];
+  }
+  t.tot = tot;
+}
+struct ScanEbase { const uint32_t* deg; const uint32_t* degp; uint32_t* ebase; };
+// out[i] = pre + (exclusive prefix inside the tile) for the tile's elements below n; eb: see scan_downsweep_kernel
+__device__ __forceinline__ void scan_tile_store(uint64_t* __restrict__ out, size_t n, size_t tile, uint64_t pre, const ScanTile& t, const ScanEbase& eb) {
+  const size_t tbase = tile * SCAN_TILE + (size_t)threadIdx.x * 4;
+  const bool whole = (tile + 1) * SCAN_TILE <= n;  // block-uniform
+#pragma unroll
+  for (int r = 0; r < SCAN_SUB; r++) {
+    const size_t idx = tbase + (size_t)r * 1024;
+    uint64_t o4[4], run = pre + t.ex[r];
+#pragma unroll
+    for (int k = 0; k < 4; k++) { o4[k] = run; run += t.v[r][k]; }
+    if (whole) {
+      typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
+      u64x2* dst = reinterpret_cast<u64x2*>(out + idx);  // (idx is a multiple of 4: 32-byte aligned)
+      dst[0] = u64x2{o4[0], o4[1]}; dst[1] = u64x2{o4[2], o4[3]};
+    } else {
+#pragma unroll
+      for (int k = 0; k < 4; k++) if (idx + k < n) out[idx + k] = o4[k];
+    }
+    if (eb.ebase)
+#pragma unroll
+      for (int k = 0; k < 4; k++) if (idx + k < n) eb.ebase[idx + k] = (uint32_t)o4[k] - (eb.deg[idx + k] - eb.degp[idx + k]);
+  }
+}
+
 __global__ __launch_bounds__(SCAN_THREADS) void scan_block_sums_kernel(const uint32_t* __restrict__ in, size_t n,
                                                                        uint64_t* __restrict__ bsum,
                                                                        const uint64_t* __restrict__ range) {
-  __shared__ uint64_t lds[8];
+  __shared__ uint64_t wsum[4][SCAN_SUB];
   if (scan_tile_dead(range, blockIdx.x)) { if (threadIdx.x == 0) bsum[blockIdx.x] = 0; return; }
-  const size_t base = (size_t)blockIdx.x * SCAN_TILE + (size_t)threadIdx.x * SCAN_ITEMS;
-  uint64_t s = 0;
-#pragma unroll
-  for (int k = 0; k < SCAN_ITEMS; k++) if (base + k < n && scan_live(range, base + k)) s += in[base + k];
-  s = block_reduce_u64(s, lds);
-  if (threadIdx.x == 0) bsum[blockIdx.x] = s;
+  ScanTile t;
+  scan_tile_load(in, n, blockIdx.x, range, false, wsum, t);
+  if (threadIdx.x == 0) bsum[blockIdx.x] = t.tot;
 }
 
 __global__ __launch_bounds__(1024) void scan_of_sums_kernel(uint64_t* __restrict__ bsum, size_t nb,
@@ -798,8 +880,6 @@ __global__ __launch_bounds__(1024) void scan_of_sums_kernel(uint64_t* __restrict
 // SELF: every block sums the raw block sums before it by itself (<= SCAN_SELF_MAX of them, from L2) and the last one
 // writes the total — the single-block scan-of-sums launch (a ~4.6 us floor) disappears.
 // eb (optional): also ebase[i] = (u32) out[i] - (deg[i] - degp[i]), the CSR base of row i (see launch_edge_fill)
-struct ScanEbase { const uint32_t* deg; const uint32_t* degp; uint32_t* ebase; };
-
 template <bool SELF>
 __global__ __launch_bounds__(SCAN_THREADS) void scan_downsweep_kernel(const uint32_t* __restrict__ in, size_t n,
                                                                       const uint64_t* __restrict__ bsum,
@@ -808,13 +888,11 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_downsweep_kernel(const uint
                                                                       const uint64_t* __restrict__ range,
                                                                       ScanEbase eb) {
   __shared__ uint64_t lds[8];
-  const size_t base = (size_t)blockIdx.x * SCAN_TILE + (size_t)threadIdx.x * SCAN_ITEMS;
+  __shared__ uint64_t wsum[4][SCAN_SUB];
   const bool dead = scan_tile_dead(range, blockIdx.x) && !(SELF && blockIdx.x == gridDim.x - 1);  // block-uniform
   if (dead) return;
-  uint32_t v[SCAN_ITEMS];
-  uint64_t s = 0;
-#pragma unroll
-  for (int k = 0; k < SCAN_ITEMS; k++) { v[k] = (base + k < n && scan_live(range, base + k)) ? in[base + k] : 0u; s += v[k]; }
+  ScanTile t;
+  scan_tile_load(in, n, blockIdx.x, range, false, wsum, t);
   uint64_t pre;
   if (SELF) {
     uint64_t a = 0;
@@ -823,19 +901,10 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_downsweep_kernel(const uint
   } else {
     pre = bsum[blockIdx.x];
   }
-  uint64_t tot;
-  uint64_t run = pre + block_exscan_u64(s, lds, &tot);
-#pragma unroll
-  for (int k = 0; k < SCAN_ITEMS; k++) {
-    if (base + k < n) {
-      out[base + k] = run;
-      if (eb.ebase) eb.ebase[base + k] = (uint32_t)run - (eb.deg[base + k] - eb.degp[base + k]);
-    }
-    run += v[k];
-  }
+  scan_tile_store(out, n, blockIdx.x, pre, t, eb);
   if (SELF && blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) {
-    out[n] = pre + tot;
-    if (host_total) publish_host(host_total, pre + tot);
+    out[n] = pre + t.tot;
+    if (host_total) publish_host(host_total, pre + t.tot);
   }
 }
 
@@ -845,7 +914,6 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_lookback_kernel(const uint3
                                                                      uint64_t* __restrict__ out, LbArgs lb,
                                                                      uint64_t* __restrict__ host_total,
                                                                      const uint64_t* __restrict__ range, ScanEbase eb) {
-  __shared__ uint64_t lds[8];
   __shared__ uint32_t s_tile;
   __shared__ uint64_t s_prefix;
   uint32_t* ticket = lb.ticket;
@@ -854,14 +922,11 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_lookback_kernel(const uint3
   __syncthreads();
   const uint32_t tile = s_tile;
   if (tile >= gridDim.x) return;  // (a ticket that was not zero at launch: never index memory with it)
-  const size_t base = (size_t)tile * SCAN_TILE + (size_t)threadIdx.x * SCAN_ITEMS;
-  const bool dead = scan_tile_dead(range, tile);  // block-uniform: known zeros, neither read nor written
-  uint32_t v[SCAN_ITEMS];
-  uint64_t s = 0;
-#pragma unroll
-  for (int k = 0; k < SCAN_ITEMS; k++) { v[k] = (!dead && base + k < n && scan_live(range, base + k)) ? in[base + k] : 0u; s += v[k]; }
-  uint64_t tot;
-  const uint64_t ex = block_exscan_u64(s, lds, &tot);
+  __shared__ uint64_t wsum[4][SCAN_SUB];
+  ScanTile t;
+  scan_tile_load(in, n, tile, range, true, wsum, t);  // (a tile wholly outside the range: known zeros, never written)
+  const bool dead = t.dead;
+  const uint64_t tot = t.tot;
   if (threadIdx.x < 64) {
     uint64_t* const desc[1] = {lb.desc};
     const uint64_t own[1] = {tot};
@@ -871,17 +936,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_lookback_kernel(const uint3
   }
   __syncthreads();
   const uint64_t pre = s_prefix;
-  if (!dead) {
-    uint64_t run = pre + ex;
-#pragma unroll
-    for (int k = 0; k < SCAN_ITEMS; k++) {
-      if (base + k < n) {
-        out[base + k] = run;
-        if (eb.ebase) eb.ebase[base + k] = (uint32_t)run - (eb.deg[base + k] - eb.degp[base + k]);
-      }
-      run += v[k];
-    }
-  }
+  if (!dead) scan_tile_store(out, n, tile, pre, t, eb);
   if (tile == gridDim.x - 1 && threadIdx.x == 0) {
     out[n] = pre + tot;
     if (host_total) publish_host(host_total, pre + tot);
