@@ -369,7 +369,18 @@ __global__ __launch_bounds__(256) void score_argmax_kernel(const uint32_t* __res
   unsigned long long k = 0, pos = 0;
   for (uint32_t l = blockIdx.x * 256 + threadIdx.x; l < sh.n_local; l += gridDim.x * 256) {
     uint32_t c = 0;
-    for (uint32_t ch = 0; ch < n_chunks; ch++) c += partial[(size_t)ch * sh.ld_local + l];
+    {  // (four rows in flight: a loop of n_chunks trips is n_chunks dependent round trips to hipcc — five at C2)
+      uint32_t ch = 0;
+      for (; ch + 4 <= n_chunks; ch += 4) {
+        const uint32_t p0 = partial[(size_t)ch * sh.ld_local + l], p1 = partial[(size_t)(ch + 1) * sh.ld_local + l],
+                       p2 = partial[(size_t)(ch + 2) * sh.ld_local + l], p3 = partial[(size_t)(ch + 3) * sh.ld_local + l];
+        c += (p0 + p1) + (p2 + p3);
+      }
+      uint32_t pr[3];
+#pragma unroll
+      for (uint32_t u = 0; u < 3; u++) pr[u] = ch + u < n_chunks ? partial[(size_t)(ch + u) * sh.ld_local + l] : 0u;
+      c += pr[0] + pr[1] + pr[2];
+    }
     cnt_out[l] = c;
     const uint32_t g = shard_global_index(l, sh.block, sh.rank, sh.world);
     const uint32_t second = sel_key ? sel_key[g] : 0xFFFFFFFFu - g;
@@ -1998,13 +2009,26 @@ __global__ __launch_bounds__(256) void finalize_kernel(const float* __restrict__
   uint32_t r = 0;
   if (two_stage && k0 != 0) {
     const uint32_t wk = (uint32_t)(k0 & 0xFFFFFFFFull);  // = sel_key[g]: the key's low half (score_argmax_kernel)
-    for (uint32_t q = q_first; q < T4; q += gridDim.x * 256) {
-      const uint4 v = q == q_first ? v_first : k4[q];
+    auto rank4 = [&](const uint4& v, uint32_t q) {
       const uint32_t t = q << 2;
       r += (v.x > wk) || (v.x == wk && t < g);
       r += (v.y > wk) || (v.y == wk && t + 1 < g);
       r += (v.z > wk) || (v.z == wk && t + 2 < g);
       r += (v.w > wk) || (v.w == wk && t + 3 < g);
+    };
+    const uint32_t qs = gridDim.x * 256;
+    if (q_first < T4) rank4(v_first, q_first);
+    uint32_t q = q_first + qs;
+    for (; q + 3 * qs < T4; q += 4 * qs) {  // (four loads in flight: see score_argmax_kernel)
+      const uint4 a0 = k4[q], a1 = k4[q + qs], a2 = k4[q + 2 * qs], a3 = k4[q + 3 * qs];
+      rank4(a0, q); rank4(a1, q + qs); rank4(a2, q + 2 * qs); rank4(a3, q + 3 * qs);
+    }
+    {
+      uint4 w[3];
+#pragma unroll
+      for (uint32_t u = 0; u < 3; u++) w[u] = q + u * qs < T4 ? k4[q + u * qs] : make_uint4(0u, 0u, 0u, 0u);
+#pragma unroll
+      for (uint32_t u = 0; u < 3; u++) if (q + u * qs < T4) rank4(w[u], q + u * qs);
     }
     if (blockIdx.x == 0) {
       const uint32_t t = (T4 << 2) + threadIdx.x;  // the last T % 4 keys

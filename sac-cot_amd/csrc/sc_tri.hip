@@ -1087,9 +1087,22 @@ __global__ __launch_bounds__(64 * EBK_ROWS) void edge_build_kernel(const uint64_
   const int r0 = blockIdx.x * EBK_ROWS, i = r0 + wave;
   // edges of the rows before this workgroup's (r0 is a multiple of 4: whole 16-byte pieces)
   uint64_t acc = 0;
-  for (int q = tid * 4; q < r0; q += 64 * EBK_ROWS * 4) {
-    const uint4 v = *reinterpret_cast<const uint4*>(degp + q);
-    acc += (uint64_t)v.x + v.y + v.z + v.w;
+  {  // (four 16-byte loads in flight: the loop's trips were dependent round trips — up to three for the last rows at C2, ten at C3)
+    constexpr int QS = 64 * EBK_ROWS * 4;
+    int q = tid * 4;
+    for (; q + 3 * QS < r0; q += 4 * QS) {
+      const uint4 v0 = *reinterpret_cast<const uint4*>(degp + q), v1 = *reinterpret_cast<const uint4*>(degp + q + QS),
+                  v2 = *reinterpret_cast<const uint4*>(degp + q + 2 * QS), v3 = *reinterpret_cast<const uint4*>(degp + q + 3 * QS);
+      acc += ((uint64_t)v0.x + v0.y + v0.z + v0.w) + ((uint64_t)v1.x + v1.y + v1.z + v1.w) + ((uint64_t)v2.x + v2.y + v2.z + v2.w) +
+             ((uint64_t)v3.x + v3.y + v3.z + v3.w);
+    }
+    uint4 w[3];
+    int nw = 0;
+#pragma unroll
+    for (int u = 0; u < 3; u++) { const bool in = q + u * QS < r0; w[u] = in ? *reinterpret_cast<const uint4*>(degp + q + u * QS) : make_uint4(0u, 0u, 0u, 0u); nw += in; }
+#pragma unroll
+    for (int u = 0; u < 3; u++) acc += (uint64_t)w[u].x + w[u].y + w[u].z + w[u].w;
+    (void)nw;
   }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
@@ -1219,7 +1232,13 @@ __global__ __launch_bounds__(256) void prune_bits_kernel(const uint32_t* __restr
   static_assert(PR_BINS == 256, "one bin per thread, walked from the top");
   const uint32_t bin = PR_BINS - 1 - threadIdx.x;
   uint64_t mine = 0;
-  for (int c = 0; c < copies; c++) mine += hist[c * PR_BINS + bin];  // copies: PR_HCOPIES (the sample's own) or 1 (summed)
+  if (copies == PR_HCOPIES) {  // (the sample's own copies: four loads in flight — a loop of `copies` trips is four round trips to hipcc)
+    static_assert(PR_HCOPIES == 4, "four copies");
+    const uint32_t h0 = hist[bin], h1 = hist[PR_BINS + bin], h2 = hist[2 * PR_BINS + bin], h3 = hist[3 * PR_BINS + bin];
+    mine = (uint64_t)h0 + h1 + h2 + h3;
+  } else {
+    for (int c = 0; c < copies; c++) mine += hist[c * PR_BINS + bin];  // (1: summed by the caller)
+  }
   if (threadIdx.x == 0) { s_smin = -1.0f; s_klb = 0u; }  // default: no certified bound -> every edge is strong
   uint64_t tot;
   const uint64_t before = block_exscan_u64(mine, lds, &tot);
@@ -1698,15 +1717,23 @@ __global__ __launch_bounds__(SEL_THREADS) void select_round_kernel(KeyView view,
   const uint64_t width = 1ull << win.wbits;
   const uint64_t M4 = M >> 2;  // whole uint4 groups (wkey comes from hipMalloc: 16-byte aligned)
   const uint64_t stride = (uint64_t)gridDim.x * SEL_THREADS;
-  for (uint64_t q = (uint64_t)blockIdx.x * SEL_THREADS + threadIdx.x; q < M4; q += stride) {
-    const uint4 k4 = view_load4<SEG>(view, q);
+  auto bin4 = [&](const uint4& k4) {
     const uint32_t ks[4] = {k4.x, k4.y, k4.z, k4.w};
 #pragma unroll
     for (int c = 0; c < 4; c++) {
       const uint64_t rel = (uint64_t)ks[c] - (uint64_t)win.lo;  // wraps huge when key < lo
       hist_add(lh, (ks[c] >= win.lo) && (rel < width), (uint32_t)(rel >> win.shift));
     }
+  };
+  // (hipcc does not carry loads across the trips of a loop: four grid-strided loads are issued together — a thread's SEL_ITEMS keys
+  // used to be four dependent round trips, ~2 us of the launch's 6)
+  uint64_t q = (uint64_t)blockIdx.x * SEL_THREADS + threadIdx.x;
+  for (; q + 3 * stride < M4; q += 4 * stride) {
+    const uint4 a0 = view_load4<SEG>(view, q), a1 = view_load4<SEG>(view, q + stride), a2 = view_load4<SEG>(view, q + 2 * stride),
+                a3 = view_load4<SEG>(view, q + 3 * stride);
+    bin4(a0); bin4(a1); bin4(a2); bin4(a3);
   }
+  for (; q < M4; q += stride) bin4(view_load4<SEG>(view, q));
   if (!SEG && blockIdx.x == 0 && threadIdx.x < (M & 3)) {  // tail (a segmented view is a whole number of groups)
     const uint32_t key = wkey[(M4 << 2) + threadIdx.x];
     const uint64_t rel = (uint64_t)key - (uint64_t)win.lo;
