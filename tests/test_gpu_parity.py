@@ -164,6 +164,26 @@ def test_triangles_massive_ties(pkg, O, reg):
     assert np.array_equal(key, key0) and np.array_equal(tri, tri0)
 
 
+@pytest.mark.parametrize("n,T", [(40, 500), (40, 1_000_000), (64, 3000), (96, 20_000)])
+def test_select_whose_window_is_one_key_before_its_last_round(pkg, O, reg, n, T):
+    """r05: a select round only fills its histogram; the NEXT launch resolves it.  Degree ranking on a complete graph — every vertex
+    has the same degree, so every key is the same value: the key range is ONE value (a window of zero bits), round 0 already comes
+    down to k*, rounds 1 and 2 find the select done and add nothing, the compaction's counting kernel resolves a round that never
+    ran.  The top-T is then the first T triangles in (i, j, k) order; T beyond the triangle count takes them all."""
+    sc = pkg.synth.make_scene(n, 1.0, 1.0, 1e-7, 7)
+    kw = _params(pkg, 0.05, T, rank_mode=1)
+    tri, key, total, _ = reg.triangles(sc.src, sc.tgt, pkg.make_params(**kw))
+    S0, bits0, deg0 = O.compat(sc.src, sc.tgt, kw["sigma"], kw["t_cmp"], kw["min_len"], kw["tau"])
+    tri0, key0, total0 = O.triangles(S0, bits0, deg0, T, 1)
+    assert total == total0 and len(np.unique(key0)) == 1   # (n = 40: the graph is complete — total = n (n - 1) (n - 2) / 6 — and the key RANGE is one value)
+    if n == 40:
+        assert total0 == n * (n - 1) * (n - 2) // 6
+    assert np.array_equal(key, key0) and np.array_equal(tri, tri0)
+    out = reg.register(sc.src, sc.tgt, **kw)
+    ref = O.register(sc.src, sc.tgt, threads=4, **kw)
+    assert out["status"] == ref["rc"] == 0 and out["stats"]["best_rank"] == ref["best_rank"] and np.array_equal(out["mask"], ref["mask"])
+
+
 def test_triangles_none(pkg, reg):
     """A scene with no compatible pair at all: zero edges, zero triangles, and the path reports SC_ENOHYP."""
     rng = np.random.default_rng(5)
