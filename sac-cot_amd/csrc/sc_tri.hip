@@ -745,6 +745,7 @@ void launch_tri_keys_events(const Graph& g, const float* es, const uint64_t* tof
 // ------------------------------------------------------------------------------------------------
 constexpr int PR_BINS = 256;   // coarse is enough: LB only needs to be a valid, reasonably tight lower bound
 constexpr int PR_COPIES = 16;  // one private copy per lane-in-group: same-bin hits land on different LDS words
+constexpr int EST_COPIES = 4;  // the estimating sample (one lane per edge, ~200 hits per workgroup): fewer copies to clear and to add up
 
 __device__ __forceinline__ uint32_t prune_bin(uint32_t key, uint32_t klo, uint32_t shift) {
   if (key <= klo) return 0u;
@@ -980,8 +981,8 @@ __global__ __launch_bounds__(256) void tri_sample_words_kernel(const uint64_t* _
   // only the first SAMPLE_CAND_BLOCKS workgroups keep their best triangle (tracking it in every one cost the launch 3.6 us at C2;
   // 64 voters want 64 good triangles, and the best of these workgroups' ~50 000 sampled keys per voter is that)
   const bool track = cand != nullptr && blockIdx.x < SAMPLE_CAND_BLOCKS;
-  __shared__ uint32_t lh[PR_BINS * PR_COPIES];
-  for (int b = threadIdx.x; b < PR_BINS * PR_COPIES; b += 256) lh[b] = 0;
+  __shared__ uint32_t lh[PR_BINS * EST_COPIES];
+  for (int b = threadIdx.x; b < PR_BINS * EST_COPIES; b += 256) lh[b] = 0;
   __syncthreads();
   const uint64_t stride = (uint64_t)gridDim.x * 256;
   for (uint64_t e = (uint64_t)blockIdx.x * 256 + threadIdx.x; e < E; e += stride) {
@@ -1015,7 +1016,7 @@ __global__ __launch_bounds__(256) void tri_sample_words_kernel(const uint64_t* _
         for (int q = 0; q < 4; q++)
           if (q < nbits) {
             const uint32_t kb = __float_as_uint((s_ij + s_ik[q]) + s_jk[q]);  // (keys are positive floats: their bits order like they do)
-            atomicAdd(&lh[est_bin(kb) * PR_COPIES + (threadIdx.x & (PR_COPIES - 1))], 1u);
+            atomicAdd(&lh[est_bin(kb) * EST_COPIES + (threadIdx.x & (EST_COPIES - 1))], 1u);
             if (track && kb > best_key) { best_key = kb; best_e = (uint32_t)e; best_k = (uint32_t)(64 * w + b[q]); }
           }
       }
@@ -1026,7 +1027,7 @@ __global__ __launch_bounds__(256) void tri_sample_words_kernel(const uint64_t* _
   for (int b = threadIdx.x; b < PR_BINS; b += 256) {
     uint32_t v = 0;
 #pragma unroll
-    for (int c = 0; c < PR_COPIES; c++) v += lh[b * PR_COPIES + ((c + threadIdx.x) & (PR_COPIES - 1))];
+    for (int c = 0; c < EST_COPIES; c++) v += lh[b * EST_COPIES + ((c + threadIdx.x) & (EST_COPIES - 1))];
     if (v) atomicAdd(&myh[b], v);
   }
   if (track) {  // (workgroup-uniform) the workgroup's best: by key, then by lowest thread — the sample is deterministic, so is this
